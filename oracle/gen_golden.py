@@ -1,0 +1,344 @@
+"""Golden-fixture generator -- runs ONLY in the build container (needs /root/reference).
+
+Imports the real reference (Spiking-Diffusion ``snn_model`` + its vendored
+spikingjelly zip) on PyTorch-CPU following SURVEY.md Appendix B, loads the
+synthetic checkpoints of ``spkdiff/synth.py``, runs reference and oracle
+(``oracle/snn_ref.py``) on identical inputs/seeds, asserts they agree BIT-EXACTLY,
+and writes the reference's outputs as small ``.npz`` fixtures to ``tests/golden/``.
+Only data (inputs, expected outputs) is written; no reference source travels.
+
+    python oracle/gen_golden.py            # regenerates tests/golden/*.npz
+
+Fixtures: F1 LIF, F2 per-layer VQ-VAE (teacher forced), F3 encode,
+F4 decode glue, F5 denoiser, F6 p_sample + RNG-order trajectory, F7 BN eval.
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import tempfile
+import types
+import zipfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/Spiking-Diffusion-release"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _import_reference():
+    import matplotlib
+    matplotlib.use("Agg")
+    tmp = tempfile.mkdtemp(prefix="sj_")
+    with zipfile.ZipFile(os.path.join(REF, "spikingjelly.zip")) as z:
+        z.extractall(os.path.join(tmp, "spikingjelly"))
+    for n in ("torchvision", "torchvision.datasets", "torchvision.transforms"):
+        sys.modules[n] = types.ModuleType(n)
+    sys.modules["torchvision"].datasets = sys.modules["torchvision.datasets"]
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = object
+    sys.modules["torch.utils.tensorboard"] = tb
+    sys.path[:0] = [tmp, REF]
+    import snn_model.vae_model as vm
+    import snn_model.vq_diffusion as vd
+    return vm, vd
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class _CpuTorch:
+    """Forwarding proxy for the module-global ``torch`` of R/snn_model/vq_diffusion.py that
+    rewrites the hard-coded device='cuda' (:105-107,113) to 'cpu' (SURVEY.md App. B step 5)."""
+
+    def __init__(self, torch):
+        self._t = torch
+
+    def __getattr__(self, k):
+        a = getattr(self._t, k)
+        if k in ("ones", "zeros", "zeros_like", "full"):
+            def f(*args, **kw):
+                if kw.get("device") == "cuda":
+                    kw["device"] = "cpu"
+                return a(*args, **kw)
+            return f
+        return a
+
+
+def pack(x):
+    """bool/0-1 tensor -> packed bits + shape."""
+    a = np.asarray(x.detach().cpu().numpy() if hasattr(x, "detach") else x)
+    return np.packbits(a.astype(np.uint8).reshape(-1)), np.array(a.shape, dtype=np.int64)
+
+
+def lif_trace(y_seq):
+    """Membrane potential h[t] before thresholding, for margins / fragile sets."""
+    import torch
+    v = torch.zeros_like(y_seq[0])
+    hs = []
+    for t in range(y_seq.shape[0]):
+        h = v + (y_seq[t] - v) / 2.0
+        hs.append(h)
+        s = (h >= 1.0).to(h)
+        v = (1.0 - s) * h
+    return torch.stack(hs)
+
+
+def main():
+    import torch
+    torch.set_num_threads(8)
+    vm, vd = _import_reference()
+    synth = _load(os.path.join(ROOT, "spiking-diffusion_amd", "spkdiff", "synth.py"), "spk_synth")
+    ref = _load(os.path.join(ROOT, "oracle", "snn_ref.py"), "spk_oracle")
+    functional = vm.functional
+    os.makedirs(OUT, exist_ok=True)
+    FRAG = 1e-4
+
+    def eq(a, b, what):
+        assert a.shape == b.shape and torch.equal(a, b), f"oracle != reference: {what}"
+
+    # ------------------------------------------------------------------ F1 LIF
+    g = torch.Generator().manual_seed(101)
+    x_seq = torch.randn(16, 1000, generator=g) * 1.5
+    node = vm.neuron.LIFNode(surrogate_function=vm.surrogate.ATan(), step_mode="m").eval()
+    with torch.inference_mode():
+        s1 = node(x_seq)
+        v1 = node.v.clone()
+        s2 = node(x_seq.flip(0))              # second call WITHOUT reset: v carries over
+        v2 = node.v.clone()
+        node.reset()
+        assert node.v == 0.0 and isinstance(node.v, float)
+        o1, ov1 = ref.lif_multi_step(x_seq)
+        o2, ov2 = ref.lif_multi_step(x_seq.flip(0), ov1)
+    eq(s1, o1, "F1 spikes"); eq(v1, ov1, "F1 v"); eq(s2, o2, "F1 spikes (carry)"); eq(v2, ov2, "F1 v (carry)")
+    b1, shp = pack(s1)
+    b2, _ = pack(s2)
+    np.savez_compressed(os.path.join(OUT, "f1_lif.npz"), x_seq=x_seq.numpy(), spikes=b1, spikes_shape=shp,
+                        v=v1.numpy(), spikes_carry=b2, v_carry=v2.numpy())
+    print("F1 ok: firing rate", float(s1.mean()))
+
+    # ------------------------------------------------------------------ models
+    for tag, cfg, B in (("mnist", synth.MNIST, 16), ("cifar", synth.CIFAR, 4)):
+        sd = synth.synth_vqvae_state(cfg)
+        model = vm.SNN_VQVAE(cfg.in_dim, cfg.latent_dim, cfg.num_embeddings, torch.tensor(1.0))
+        functional.set_step_mode(net=model, step_mode="m")
+        model.load_state_dict(sd)
+        model.eval()
+
+        # -------------------------------------------------------------- F3 encode / recon
+        g = torch.Generator().manual_seed(42)
+        images = torch.rand(B, cfg.in_dim, cfg.img, cfg.img, generator=g) - 0.5
+        x = images.unsqueeze(0).repeat(16, 1, 1, 1, 1)
+        with torch.inference_mode():
+            e, xr, idx = model(x, images)
+            functional.reset_net(model)
+            oe, oxr, oidx = ref.snn_vqvae_forward(x, sd)
+            eq(e, oe, f"F3 {tag} e"); eq(xr, oxr, f"F3 {tag} recon"); eq(idx, oidx, f"F3 {tag} idx")
+            # margins
+            z, enc_layers = ref.encoder_forward(x, sd, return_layers=True)
+            flat, _ = ref.vq_readout(z, sd)
+            d = ref.vq_distances(flat, sd["vq_layer.embeddings.weight"])
+            top2 = torch.topk(d, 2, dim=1, largest=False).values
+            gap = (top2[:, 1] - top2[:, 0])
+            q = torch.nn.functional.embedding(idx, sd["vq_layer.embeddings.weight"]).view(
+                B, cfg.latent, cfg.latent, -1).permute(0, 3, 1, 2).contiguous()
+            pe, py = ref.poisson_forward(q, sd, 16)
+            _, dec_layers = ref.decoder_forward(pe, sd, return_layers=True)
+            margins = {}
+            for name, (s, y) in zip(("enc1", "enc2", "enc3"), enc_layers):
+                margins[name] = float((lif_trace(y) - 1.0).abs().min())
+            margins["poisson"] = float((lif_trace(py) - 1.0).abs().min())
+            for name, (s, y) in zip(("dec1", "dec2"), dec_layers):
+                margins[name] = float((lif_trace(y) - 1.0).abs().min())
+        eb, eshape = pack(e)
+        np.savez_compressed(
+            os.path.join(OUT, f"f3_encode_{tag}.npz"), images=images.numpy(), indices=idx.numpy(),
+            x_recon=xr.numpy(), e_bits=eb, e_shape=eshape, top2_gap_min=float(gap.min()),
+            top2_gap=gap.numpy(), margin_names=np.array(list(margins)), margins=np.array(list(margins.values())),
+            firing=np.array([float(s.mean()) for s, _ in enc_layers] + [float(pe.mean())] +
+                            [float(s.mean()) for s, _ in dec_layers]),
+            weights_crc=synth.state_checksum(sd))
+        print(f"F3 {tag} ok: unique codes {idx.unique().numel()}, min top2 gap {float(gap.min()):.3e}, margins {margins}")
+
+        # -------------------------------------------------------------- F2 per-layer, teacher forced (B=2)
+        if tag == "mnist":
+            Bs = 2
+            xs = x[:, :Bs].contiguous()
+            with torch.inference_mode():
+                seqs = [
+                    ("enc1", model.encoder.snn_convs[0:3], xs),
+                ]
+                out = {}
+                cur = xs
+                blocks = [("enc1", model.encoder.snn_convs[0:3]), ("enc2", model.encoder.snn_convs[3:6]),
+                          ("enc3", model.encoder.snn_convs[6:9])]
+                for name, blk in blocks:
+                    conv, bn, lif = blk[0], blk[1], blk[2]
+                    y = bn(conv(cur)); s = lif(y); functional.reset_net(model)
+                    out[name] = (cur, y, s); cur = s
+                z2 = cur
+                e2, idx2 = model.vq_layer(z2); functional.reset_net(model)
+                q2 = model.vq_layer.quantize(idx2).view(Bs, cfg.latent, cfg.latent, -1).permute(0, 3, 1, 2).contiguous()
+                qin = q2.unsqueeze(0).repeat(16, 1, 1, 1, 1)
+                conv, bn, lif = model.vq_layer.poisson
+                y = bn(conv(qin)); s = lif(y); functional.reset_net(model)
+                out["poisson"] = (qin, y, s); cur = s
+                for name, blk in (("dec1", model.decoder.snn_convs[0:3]), ("dec2", model.decoder.snn_convs[3:6])):
+                    conv, bn, lif = blk[0], blk[1], blk[2]
+                    y = bn(conv(cur)); s = lif(y); functional.reset_net(model)
+                    out[name] = (cur, y, s); cur = s
+                y3 = model.decoder.snn_convs[6](cur)
+                out["dec3"] = (cur, y3, None)
+                mo = model.memout(y3)
+            save = {"weights_crc": synth.state_checksum(sd), "frag_eps": FRAG, "images": images[:Bs].numpy(),
+                    "quantized": q2.numpy(), "memout": mo.numpy()}
+            for name, (inp, y, s) in out.items():
+                if name in ("enc1", "poisson"):
+                    save[name + "_in"] = inp[0].numpy()                    # T-invariant fp32 input: keep t=0
+                else:
+                    save[name + "_in_bits"], save[name + "_in_shape"] = pack(inp)
+                save[name + "_y_b0"] = y[:, 0].numpy() if name != "dec2" else y[:4, 0].numpy()
+                if s is not None:
+                    h = lif_trace(y)
+                    save[name + "_out_bits"], save[name + "_out_shape"] = pack(s)
+                    save[name + "_frag_bits"], _ = pack((h - 1.0).abs() < FRAG)
+                    save[name + "_margin"] = float((h - 1.0).abs().min())
+            np.savez_compressed(os.path.join(OUT, "f2_layers_mnist.npz"), **save)
+            print("F2 ok:", {k: float(v) for k, v in save.items() if k.endswith("_margin")})
+
+        # -------------------------------------------------------------- F4 decode glue
+        g = torch.Generator().manual_seed(7)
+        tokens = torch.randint(0, cfg.num_embeddings, (8, cfg.latent, cfg.latent), generator=g)
+        with torch.inference_mode():
+            zq = model.vq_layer.quantize(tokens)
+            zq = zq.permute(0, 3, 1, 2).contiguous()
+            quant = torch.unsqueeze(zq, dim=0).repeat(16, 1, 1, 1, 1)
+            quant = model.vq_layer.poisson(quant)
+            pred = model.decoder(quant)
+            pred = torch.tanh(model.memout(pred))
+            functional.reset_net(model)
+            opred = ref.decode_tokens(tokens, sd, 16)
+        eq(pred, opred, f"F4 {tag} pred")
+        u8 = np.array(np.clip((pred + 0.5).cpu().numpy(), 0.0, 1.0) * 255, dtype=np.uint8)
+        assert np.array_equal(u8, ref.to_uint8(opred))
+        # distance of pred*255 from an integer boundary (uint8 truncation is discontinuous there)
+        f = np.clip((pred + 0.5).numpy(), 0, 1) * 255
+        edge = np.abs(f - np.round(f))
+        np.savez_compressed(os.path.join(OUT, f"f4_decode_{tag}.npz"), tokens=tokens.numpy(), pred=pred.numpy(),
+                            u8=u8, u8_edge_dist=edge.astype(np.float32), weights_crc=synth.state_checksum(sd))
+        print(f"F4 {tag} ok: pred range [{float(pred.min()):.3f},{float(pred.max()):.3f}]")
+
+    # ------------------------------------------------------------------ F5 denoiser (MNIST 7x7 and CIFAR-shaped 8x8)
+    for tag, cfg, B in (("mnist", synth.MNIST, 4), ("cifar", synth.CIFAR, 2)):
+        sdd = synth.synth_denoiser_state(cfg)
+        K, L = cfg.num_embeddings, cfg.latent
+        den = vd.DummyModel(1, K)
+        functional.set_step_mode(net=den, step_mode="m")
+        den.load_state_dict(sdd)
+        den.eval()
+        g = torch.Generator().manual_seed(55)
+        x_t = torch.randint(0, K, (B, 1, L, L), generator=g)
+        msk = torch.rand(B, 1, L, L, generator=g) < torch.tensor([0.9, 0.5, 0.2, 1.0][:B]).view(-1, 1, 1, 1)
+        x_t[msk] = K
+        t = torch.tensor([90, 40, 7, 100][:B], dtype=torch.long)
+        with torch.inference_mode():
+            logits = den(x_t.float(), t=t)
+            functional.reset_net(den)
+            ologits, layers = ref.denoiser_forward(x_t.float(), t, sdd, 16, return_layers=True)
+        eq(logits, ologits, f"F5 {tag} logits")
+        save = {"x_t": x_t.numpy(), "t": t.numpy(), "logits": logits.numpy(), "frag_eps": 1e-5,
+                "weights_crc": synth.state_checksum(sdd)}
+        for i, (s, y) in enumerate(layers, 1):
+            h = lif_trace(y)
+            save[f"s{i}_bits"], save[f"s{i}_shape"] = pack(s)
+            save[f"frag{i}_bits"], _ = pack((h - 1.0).abs() < 1e-5)
+            save[f"count{i}"] = int(s.sum())
+            save[f"margin{i}"] = float((h - 1.0).abs().min())
+        np.savez_compressed(os.path.join(OUT, f"f5_denoiser_{tag}.npz"), **save)
+        print(f"F5 {tag} ok: firing", [round(float(s.mean()), 4) for s, _ in layers],
+              "margins", [save[f"margin{i}"] for i in range(1, 6)])
+
+    # ------------------------------------------------------------------ F6 p_sample step + RNG-order trajectory
+    cfg = synth.MNIST
+    sdd = synth.synth_denoiser_state(cfg)
+    den = vd.DummyModel(1, 128)
+    functional.set_step_mode(net=den, step_mode="m")
+    den.load_state_dict(sdd)
+    den.eval()
+    B, steps = 4, 4
+    ab = vd.AbsorbingDiffusion(den, mask_id=128)
+    ab.n_samples = B
+    vd.torch = _CpuTorch(torch)
+    try:
+        torch.manual_seed(42)
+        with torch.inference_mode():
+            ref_tokens = ab.sample(temp=1.0, sample_steps=steps)
+    finally:
+        vd.torch = torch
+    rec = []
+    torch.manual_seed(42)
+    with torch.inference_mode():
+        or_tokens = ref.absorbing_sample(sdd, B, 128, 1.0, steps, 7, 16, record=rec)
+    eq(ref_tokens, or_tokens, "F6 trajectory tokens (global-RNG order)")
+    # replay the same noise explicitly (u then q per step) to pin the consumption order
+    torch.manual_seed(42)
+    us, qs = [], []
+    x_chk = torch.ones(B, 1, 7, 7).long() * 128
+    un_chk = torch.zeros_like(x_chk).bool()
+    for (t, x_after, un_after, logits) in rec:
+        u = torch.rand(B, 1, 7, 7)
+        q = torch.empty(B * 49, 128).exponential_(1)
+        us.append(u); qs.append(q)
+        x_chk, un_chk = ref.p_sample_step(x_chk, un_chk, logits, t, 1.0, u, q)
+        eq(x_chk, x_after, f"F6 step t={t} x_t"); eq(un_chk, un_after, f"F6 step t={t} unmasked")
+    # argmax robustness: relative gap between best and second best of probs/q at every position
+    gaps = []
+    for (t, _, _, logits), q in zip(rec, qs):
+        ln = logits - logits.logsumexp(-1, keepdim=True)
+        r = (torch.softmax(ln, -1).reshape(-1, 128) / q)
+        top = torch.topk(r, 2, dim=1).values
+        gaps.append(((top[:, 0] - top[:, 1]) / top[:, 0]).numpy())
+    np.savez_compressed(
+        os.path.join(OUT, "f6_psample.npz"), steps=steps, B=B, seed=42,
+        ts=np.array([r[0] for r in rec]), logits=np.stack([r[3].numpy() for r in rec]),
+        x_after=np.stack([r[1].numpy() for r in rec]), unmasked_after=np.stack([r[2].numpy() for r in rec]),
+        u=np.stack([u.numpy() for u in us]), q=np.stack([q.numpy() for q in qs]),
+        rel_gap=np.stack(gaps), final_tokens=ref_tokens.numpy(), weights_crc=synth.state_checksum(sdd))
+    print("F6 ok: tokens", ref_tokens.flatten()[:12].tolist(), "min rel gap", float(np.min(gaps)))
+
+    # ------------------------------------------------------------------ F7 BN eval (pins the fma form)
+    g = torch.Generator().manual_seed(77)
+    C = 48
+    xb = torch.randn(16, 3, C, 5, 5, generator=g) * 3
+    bn = vm.layer.BatchNorm2d(C, step_mode="m").eval()
+    bsd = {"weight": 1 + 0.3 * torch.randn(C, generator=g), "bias": torch.randn(C, generator=g),
+           "running_mean": torch.randn(C, generator=g), "running_var": torch.rand(C, generator=g) + 0.2,
+           "num_batches_tracked": torch.tensor(1)}
+    bn.load_state_dict(bsd)
+    with torch.inference_mode():
+        yb = bn(xb)
+    oy = ref.seq_bn_eval(xb, {"p." + k: v for k, v in bsd.items()}, "p")
+    eq(yb, oy, "F7 bn")
+    a, b = ref.bn_affine_terms({"p." + k: v for k, v in bsd.items()}, "p")
+    y_mul_add = xb * a.view(1, 1, C, 1, 1) + b.view(1, 1, C, 1, 1)
+    y_fma = torch.from_numpy(np.asarray(
+        (xb.double().numpy() * a.double().view(1, 1, C, 1, 1).numpy() + b.double().view(1, 1, C, 1, 1).numpy())
+    ).astype(np.float32))
+    form = "fma" if torch.equal(y_fma, yb) else ("mul_add" if torch.equal(y_mul_add, yb) else "other")
+    n_fma = int((y_fma != yb).sum()); n_ma = int((y_mul_add != yb).sum())
+    np.savez_compressed(os.path.join(OUT, "f7_bn.npz"), x=xb.numpy(), y=yb.numpy(), form=form,
+                        **{k: v.numpy() for k, v in bsd.items()})
+    print(f"F7 ok: BN form = {form} (mismatches: fma {n_fma}, mul+add {n_ma} of {yb.numel()})")
+    print("all fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,193 @@
+"""Deterministic synthetic checkpoints for the Spiking-Diffusion inference path.
+
+The reference ships no checkpoints, and there is no network, so
+tests, ``bench.py`` and ``smoke()`` use weights produced here: every tensor is
+drawn from a CPU ``torch.Generator`` seeded by (seed, crc32(key)), and the
+BatchNorm running statistics are then calibrated layer by layer on a small
+synthetic batch so that the LIF layers fire at a few percent (un-calibrated
+random weights are degenerate: every latent position maps to one code).
+
+The result is a plain ``state_dict`` with exactly the key names and shapes of
+the reference modules:
+  * ``SNN_VQVAE``  -- R/snn_model/vae_model.py:22-196 (keys listed SURVEY.md §8b)
+  * ``DummyModel`` -- R/snn_model/vq_diffusion.py:150-187
+
+This is set-up code (it runs once, on the host, before anything is timed); it
+is NOT part of the HIP hot path and NOT the oracle.  It only uses torch CPU ops.
+"""
+from __future__ import annotations
+
+import zlib
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass(frozen=True)
+class PathConfig:
+    """Shape parameters the reference hard-codes (SURVEY.md §5 'Config')."""
+    in_dim: int = 1          # image channels (1 MNIST-like, 3 CIFAR-shaped)
+    img: int = 28            # image side
+    latent_dim: int = 16     # embedding_dim, R/main.py:69
+    num_embeddings: int = 128  # --codebook_size, R/main.py:58
+    T: int = 16              # time steps
+
+    @property
+    def latent(self) -> int:
+        return self.img // 4
+
+    @property
+    def tokens(self) -> int:
+        return self.latent * self.latent
+
+
+MNIST = PathConfig()
+CIFAR = PathConfig(in_dim=3, img=32)
+
+
+def _gen(seed: int, key: str) -> torch.Generator:
+    g = torch.Generator(device="cpu")
+    g.manual_seed((int(seed) * 1000003 + zlib.crc32(key.encode())) & 0x7FFFFFFFFFFFFFFF)
+    return g
+
+
+def _uniform(shape, bound, seed, key):
+    return (torch.rand(shape, generator=_gen(seed, key), dtype=torch.float32) * 2.0 - 1.0) * bound
+
+
+def _conv_params(sd, prefix, cout, cin, k, seed, transposed=False):
+    fan_in = (cout if transposed else cin) * k * k
+    bound = 1.0 / (fan_in ** 0.5)
+    shape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+    sd[prefix + ".weight"] = _uniform(shape, bound, seed, prefix + ".weight")
+    sd[prefix + ".bias"] = _uniform((cout,), bound, seed, prefix + ".bias")
+
+
+def _bn_params(sd, prefix, c, seed):
+    # gamma in [0.8, 1.2], beta in [-0.1, 0.1]: not the identity, so the affine is exercised
+    sd[prefix + ".weight"] = 1.0 + _uniform((c,), 0.2, seed, prefix + ".weight")
+    sd[prefix + ".bias"] = _uniform((c,), 0.1, seed, prefix + ".bias")
+    sd[prefix + ".running_mean"] = torch.zeros(c)
+    sd[prefix + ".running_var"] = torch.ones(c)
+    sd[prefix + ".num_batches_tracked"] = torch.tensor(1, dtype=torch.long)
+
+
+def memout_coef(T: int) -> torch.Tensor:
+    """``MembraneOutputLayer.coef`` buffer, R/snn_model/snn_layers.py:31-34 with T a parameter."""
+    return torch.pow(0.8, torch.arange(T - 1, -1, -1))[:, None, None, None, None]
+
+
+def _lif(x_seq):
+    v = torch.zeros_like(x_seq[0])
+    out = torch.empty_like(x_seq)
+    for t in range(x_seq.shape[0]):
+        v = v + (x_seq[t] - v) * 0.5
+        s = (v >= 1.0).to(x_seq.dtype)
+        v = (1.0 - s) * v
+        out[t] = s
+    return out
+
+
+def _calibrate(sd, bn_prefix, y_seq):
+    """Set running stats of ``bn_prefix`` to the batch statistics of y_seq [T,B,C,H,W]; return BN(y)."""
+    c = y_seq.shape[2]
+    flat = y_seq.transpose(0, 2).reshape(c, -1)
+    mean = flat.mean(1)
+    var = flat.var(1, unbiased=True).clamp_min(1e-6)
+    sd[bn_prefix + ".running_mean"] = mean
+    sd[bn_prefix + ".running_var"] = var
+    g, b = sd[bn_prefix + ".weight"], sd[bn_prefix + ".bias"]
+    a = g / torch.sqrt(var + 1e-5)
+    return y_seq * a.view(1, 1, c, 1, 1) + (b - mean * a).view(1, 1, c, 1, 1)
+
+
+def _seq(fn, x_seq):
+    T, B = x_seq.shape[:2]
+    y = fn(x_seq.flatten(0, 1))
+    return y.view(T, B, *y.shape[1:])
+
+
+def synth_vqvae_state(cfg: PathConfig = MNIST, seed: int = 1234, calib_batch: int = 16) -> dict:
+    """Synthetic, BN-calibrated ``SNN_VQVAE`` state_dict (keys: SURVEY.md §8b)."""
+    sd: dict = {}
+    D, K = cfg.latent_dim, cfg.num_embeddings
+    _conv_params(sd, "encoder.snn_convs.0", 32, cfg.in_dim, 3, seed)
+    _bn_params(sd, "encoder.snn_convs.1", 32, seed)
+    _conv_params(sd, "encoder.snn_convs.3", 64, 32, 3, seed)
+    _bn_params(sd, "encoder.snn_convs.4", 64, seed)
+    _conv_params(sd, "encoder.snn_convs.6", D, 64, 1, seed)
+    _bn_params(sd, "encoder.snn_convs.7", D, seed)
+    sd["vq_layer.alpha"] = torch.tensor(0.5)
+    sd["vq_layer.memout.coef"] = memout_coef(cfg.T)
+    sd["vq_layer.embeddings.weight"] = torch.zeros(K, D)
+    _conv_params(sd, "vq_layer.poisson.0", D, D, 1, seed)
+    _bn_params(sd, "vq_layer.poisson.1", D, seed)
+    _conv_params(sd, "decoder.snn_convs.0", 64, D, 3, seed, transposed=True)
+    _bn_params(sd, "decoder.snn_convs.1", 64, seed)
+    _conv_params(sd, "decoder.snn_convs.3", 32, 64, 3, seed, transposed=True)
+    _bn_params(sd, "decoder.snn_convs.4", 32, seed)
+    _conv_params(sd, "decoder.snn_convs.6", cfg.in_dim, 32, 3, seed, transposed=True)
+    sd["memout.coef"] = memout_coef(cfg.T)
+
+    # ---- calibration pass (host, once) ----
+    T = cfg.T
+    img = torch.rand(calib_batch, cfg.in_dim, cfg.img, cfg.img, generator=_gen(seed, "calib.images")) - 0.5
+    x = img.unsqueeze(0).repeat(T, 1, 1, 1, 1)
+    p = "encoder.snn_convs."
+    x = _lif(_calibrate(sd, p + "1", _seq(lambda y: F.conv2d(y, sd[p + "0.weight"], sd[p + "0.bias"], 2, 1), x)))
+    x = _lif(_calibrate(sd, p + "4", _seq(lambda y: F.conv2d(y, sd[p + "3.weight"], sd[p + "3.bias"], 2, 1), x)))
+    z = _lif(_calibrate(sd, p + "7", _seq(lambda y: F.conv2d(y, sd[p + "6.weight"], sd[p + "6.bias"]), x)))
+    coef = sd["vq_layer.memout.coef"]
+    xm = 0.5 * (z * coef).sum(0) + 0.5 * z.sum(0) / T                      # [B,D,h,w]
+    flat = xm.permute(0, 2, 3, 1).reshape(-1, D)
+    # codebook: K rows drawn around real latent vectors so that the argmin is non-degenerate
+    pick = torch.randint(0, flat.shape[0], (K,), generator=_gen(seed, "codebook.pick"))
+    noise = torch.randn(K, D, generator=_gen(seed, "codebook.noise")) * flat.std(0, keepdim=True) * 0.5
+    sd["vq_layer.embeddings.weight"] = (flat[pick] + noise).contiguous()
+    d = (flat ** 2).sum(1, keepdim=True) + (sd["vq_layer.embeddings.weight"] ** 2).sum(1) \
+        - 2.0 * flat @ sd["vq_layer.embeddings.weight"].t()
+    q = sd["vq_layer.embeddings.weight"][d.argmin(1)].view(calib_batch, cfg.latent, cfg.latent, D).permute(0, 3, 1, 2)
+    x = q.unsqueeze(0).repeat(T, 1, 1, 1, 1).contiguous()
+    p = "vq_layer.poisson."
+    x = _lif(_calibrate(sd, p + "1", _seq(lambda y: F.conv2d(y, sd[p + "0.weight"], sd[p + "0.bias"]), x)))
+    p = "decoder.snn_convs."
+    x = _lif(_calibrate(sd, p + "1", _seq(
+        lambda y: F.conv_transpose2d(y, sd[p + "0.weight"], sd[p + "0.bias"], 2, 1, 1), x)))
+    x = _lif(_calibrate(sd, p + "4", _seq(
+        lambda y: F.conv_transpose2d(y, sd[p + "3.weight"], sd[p + "3.bias"], 2, 1, 1), x)))
+    return {k: v.contiguous() for k, v in sd.items()}
+
+
+def synth_denoiser_state(cfg: PathConfig = MNIST, seed: int = 4321, calib_batch: int = 8,
+                         sample_steps: int = 100) -> dict:
+    """Synthetic, BN-calibrated ``DummyModel`` state_dict (R/snn_model/vq_diffusion.py:158-187)."""
+    sd: dict = {}
+    K = cfg.num_embeddings
+    chans = [2, 64, 128, 256, 512, 256]
+    for i in range(5):
+        _conv_params(sd, f"conv{i + 1}.0", chans[i + 1], chans[i], 3, seed)
+        _bn_params(sd, f"conv{i + 1}.1", chans[i + 1], seed)
+    _conv_params(sd, "conv6.0", K, 256 + 64, 3, seed)
+
+    T, L = cfg.T, cfg.latent
+    tok = torch.randint(0, K + 1, (calib_batch, 1, L, L), generator=_gen(seed, "calib.tokens")).float()
+    # half of the calibration batch is heavily masked, as during sampling
+    mask = torch.rand(calib_batch, 1, L, L, generator=_gen(seed, "calib.mask")) < \
+        torch.linspace(0.1, 1.0, calib_batch).view(-1, 1, 1, 1)
+    tok[mask] = float(K)
+    t = torch.randint(1, sample_steps + 1, (calib_batch,), generator=_gen(seed, "calib.t")).float()
+    x = torch.cat((tok, torch.ones_like(tok) * t.view(-1, 1, 1, 1)), 1).unsqueeze(0).repeat(T, 1, 1, 1, 1)
+    for i in range(5):
+        p = f"conv{i + 1}."
+        x = _lif(_calibrate(sd, p + "1", _seq(
+            lambda y: F.conv2d(y, sd[p + "0.weight"], sd[p + "0.bias"], 1, 1), x)))
+    return {k: v.contiguous() for k, v in sd.items()}
+
+
+def state_checksum(sd: dict) -> str:
+    """crc32 over all tensors' bytes in key order (pins fixtures to the generator version)."""
+    c = 0
+    for k in sorted(sd):
+        c = zlib.crc32(sd[k].detach().cpu().contiguous().numpy().tobytes(), c)
+    return f"{c:08x}"

@@ -1,0 +1,27 @@
+"""pytest configuration: registers the ``gpu`` marker and puts the drop-in tree on sys.path.
+
+``spiking-diffusion_amd/`` is a *directory of top-level packages* (``snn_model``,
+``spikingjelly``, ``spkdiff``) laid out like the reference's release directory, so the
+reference's ``main.py`` placed beside them imports them unchanged.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "spiking-diffusion_amd")
+for p in (PKG, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
