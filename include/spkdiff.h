@@ -1,0 +1,127 @@
+/* libspkdiff -- C-ABI of the MI355X-native (gfx950) Spiking-Diffusion inference kernels.
+ *
+ * This is the drop-in boundary for the reference's time-stepped SNN inference path.  The reference has no
+ * FFI of its own for this path: its operator-plugin point is spikingjelly's ``backend`` switch
+ * (SJ/activation_based/base.py:199-208, functional.py:109-149), whose only native plugin is the CuPy one with the
+ * call contract  LIFNodeATGF.apply(x_seq[T,N], v[N], v_th, v_reset, 1/tau, ...)  (SJ/activation_based/neuron.py:954-966,
+ * auto_cuda/neuron_kernel.py:496-522).  Every entry point below names the reference interface it replaces
+ * (R/ = Spiking-Diffusion-release/, SJ/ = member of R/spikingjelly.zip).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Contract (all functions):
+ *   - plain C types only; every pointer is a DEVICE pointer owned by the caller (PyTorch); the library never
+ *     allocates or frees device memory and keeps no mutable global state;
+ *   - work is enqueued asynchronously on ``stream`` (a hipStream_t; pass torch.cuda.current_stream().cuda_stream);
+ *   - returns 0 on success, SPK_ERR_* (< 0) for argument errors, a positive hipError_t for launch failures;
+ *   - reentrant across streams and host threads.
+ *
+ * Layouts: "TBCHW" = fp32 [T,B,C,H,W] contiguous (the reference's tensors); "PTC" = u8 {0,1} [B,H,W,T,C]
+ * (the library's compact inter-layer spike format); packed conv weights = fp32 [k*k][Cin][Cout].
+ */
+#ifndef SPKDIFF_H
+#define SPKDIFF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* spk_stream_t; /* == hipStream_t */
+
+#define SPK_VERSION 100 /* 0.1.0 */
+
+/* fused-kernel epilogue modes (spk_conv_fused_fwd) */
+#define SPK_MODE_LIF 0    /* BN + LIF -> spikes                                    */
+#define SPK_MODE_RAW 1    /* conv output per time step, fp32 TBCHW                 */
+#define SPK_MODE_MEMOUT 2 /* sum_t x[t]*coef[t] (+tanh, +uint8)  -> [B,C,H,W]      */
+#define SPK_MODE_MEAN 3   /* sum_t x[t] / T                      -> [B,C,H,W]      */
+
+/* input kinds of spk_conv_fused_fwd */
+#define SPK_IN_PTC 0  /* u8 spikes [B,H,W,T,C]                                               */
+#define SPK_IN_TINV 1 /* fp32 [B,C,H,W], the same frame at every time step                  */
+#define SPK_IN_SEQ 2  /* fp32 [T,B,C,H,W], arbitrary values (the reference's tensor format) */
+
+int spk_version(void);
+/* Returns a static string for an SPK_ERR_* / hipError_t code. */
+const char* spk_error_string(int code);
+
+/* ---- neuron surface -------------------------------------------------------------------------------------- */
+
+/* Multi-step eval LIF (hard reset, decay_input): replaces LIFNode.multi_step_forward eval branch
+ * SJ/activation_based/neuron.py:971-1011 -> jit_eval_multi_step_forward_hard_reset_decay_input :799-811, and mirrors the
+ * cupy plugin contract :954-966.  x_seq [T,N] fp32; v_inout [N] fp32 (state before / after); spike_out [T,N] as
+ * spike_dtype 0 = fp32, 1 = u8, 2 = bit-packed u64 words [T, ceil(N/64)] (bit l of word w = neuron 64w+l). */
+int spk_lif_fwd(const float* x_seq, float* v_inout, void* spike_out, int T, long long N, float tau, float v_threshold,
+                float v_reset, int spike_dtype, spk_stream_t stream);
+
+/* ---- stateless step-mode layers ---------------------------------------------------------------------------- */
+
+/* Eval BatchNorm as PyTorch evaluates it (pinned by fixture F7): a = (1/sqrt(var+eps))*gamma, b = fma(-mean,a,beta). */
+int spk_bn_prepare(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                   float eps, float* a_out, float* b_out, int C, spk_stream_t stream);
+/* y = fma(x, a[c], b[c]) over x [M,C,HW]: layer.BatchNorm2d 'm' mode, SJ/activation_based/layer.py:458-465. */
+int spk_bn_eval_fwd(const float* x, const float* a, const float* b, float* y, long long M, int C, int HW,
+                    spk_stream_t stream);
+/* layer.Conv2d 'm' mode body (T folded into M), SJ/activation_based/layer.py:164-173. w [Cout,Cin,k,k]. */
+int spk_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, long long M, int Cin, int H, int W,
+                   int Cout, int k, int stride, int pad, spk_stream_t stream);
+/* layer.ConvTranspose2d 'm' mode body, SJ/activation_based/layer.py:316-325. w [Cin,Cout,k,k]. */
+int spk_conv_transpose2d_fwd(const float* x, const float* w, const float* bias, float* y, long long M, int Cin, int H,
+                             int W, int Cout, int k, int stride, int pad, int out_pad, spk_stream_t stream);
+/* MembraneOutputLayer.forward, R/snn_model/snn_layers.py:36-41: out[N] = sum_t x_seq[t][N]*coef[t]. */
+int spk_memout_fwd(const float* x_seq, const float* coef, float* out, int T, long long N, spk_stream_t stream);
+
+/* ---- layout converters --------------------------------------------------------------------------------------- */
+int spk_spikes_to_ptc(const float* spikes_tbchw, uint8_t* out_bhwtc, int T, int B, int C, int HW, spk_stream_t stream);
+int spk_ptc_to_spikes(const uint8_t* in_bhwtc, float* spikes_tbchw, int T, int B, int C, int HW, spk_stream_t stream);
+
+/* ---- fused (Conv|ConvT) [+BN+LIF] --------------------------------------------------------------------------- */
+int spk_conv_out_size(int in, int k, int stride, int pad, int transposed, int out_pad);
+/* [Cout,Cin,k,k] (Conv2d) or [Cin,Cout,k,k] (ConvTranspose2d) -> packed [k*k][Cin][Cout]. */
+int spk_pack_conv_weight(const float* w, float* packed, int Cout, int Cin, int k, int transposed, spk_stream_t stream);
+/* One Conv|ConvT block of Encoder / poisson / Decoder / DummyModel with its BN + LIF (or read-out) fused:
+ * R/snn_model/vae_model.py:34-38,109-124,139-155; R/snn_model/vq_diffusion.py:161-187,200-206.
+ *   in0: per in_kind -- SPK_IN_TINV fp32 [B,C0,H,W] (same frame every step: R/main.py:309, vae_model.py:54-56,
+ *        vq_diffusion.py:198), SPK_IN_PTC u8 [B,H,W,T,C0], SPK_IN_SEQ fp32 [T,B,C0,H,W];
+ *   in1: optional second PTC source [B,H,W,T,C1] (channel concat of conv6, vq_diffusion.py:205).
+ *   mode LIF:    bn_a/bn_b required; v_inout [B,Cout,Ho,Wo] or NULL (fresh state, not written back);
+ *                out_ptc u8 PTC and/or out_f32 fp32 TBCHW spikes; out_pre optional BN output.
+ *   mode RAW:    out_f32 TBCHW conv output.    mode MEMOUT: coef [T]; out_f32 [B,Cout,Ho,Wo] (tanh if apply_tanh),
+ *                out_u8 = uint8(clip(p+0.5,0,1)*255) (R/main.py:401).   mode MEAN: out_f32 = sum_t x[t] / T. */
+int spk_conv_fused_fwd(const void* in0, const uint8_t* in1, int C0, int C1, int in_kind, const float* w_packed,
+                       const float* bias, const float* bn_a, const float* bn_b, float* v_inout, uint8_t* out_ptc,
+                       float* out_f32, float* out_pre, uint8_t* out_u8, const float* coef, int apply_tanh, int mode,
+                       int T, int B, int H, int W, int Cout, int k, int stride, int pad, int transposed, int out_pad,
+                       spk_stream_t stream);
+
+/* ---- vector quantizer ----------------------------------------------------------------------------------------- */
+/* VectorQuantizer.forward eval up to the codebook gather, R/snn_model/vae_model.py:40-52,87-99.
+ * z_ptc u8 [B,h,w,T,D]; coef [T]; alpha [1] (device); codebook [K,D]; idx_out int64 [B*HW];
+ * zq_out_bdhw fp32 [B,D,h,w] or NULL; xm_out fp32 [B*HW,D] or NULL (the read-out, for tests). */
+int spk_vq_readout_argmin(const uint8_t* z_ptc, const float* coef, const float* alpha, const float* codebook,
+                          long long* idx_out, float* zq_out_bdhw, float* xm_out, int T, int B, int D, int HW, int K,
+                          spk_stream_t stream);
+/* VectorQuantizer.get_code_indices on explicit rows flat_x [N,D], R/snn_model/vae_model.py:87-95. */
+int spk_vq_argmin(const float* flat_x, const float* codebook, long long* idx_out, long long N, int D, int K,
+                  spk_stream_t stream);
+/* VectorQuantizer.quantize (nn.Embedding), R/snn_model/vae_model.py:97-99; nchw=1 also applies the
+ * permute(0,3,1,2) of R/main.py:391 and writes [B,D,h,w].  Out-of-range tokens give NaN rows. */
+int spk_embedding_fwd(const long long* tokens, const float* codebook, float* out, long long N, int D, int K, int HW,
+                      int nchw, spk_stream_t stream);
+
+/* ---- sampler ---------------------------------------------------------------------------------------------------- */
+/* cat(x, ones_like(x)*t) of DummyModel.forward, R/snn_model/vq_diffusion.py:195-197 -> fp32 [B,2,h,w]. */
+int spk_den_build_input(const float* x_float_or_null, const long long* x_tokens_or_null, const long long* t_vec_or_null,
+                        long long t_scalar, float* out_b2hw, int B, int HW, spk_stream_t stream);
+/* Loop body of AbsorbingDiffusion.sample after the denoiser call, R/snn_model/vq_diffusion.py:113-124,134-140.
+ * logits [B,K,h,w] fp32; x_t int64 [B*HW]; unmasked u8/bool [B*HW]; u [B*HW] / q [B*HW*K] injected noise or NULL
+ * (then Philox4x32-10(seed, offset + index)); x0_hat_out optional int64 [B*HW]. */
+int spk_psample_step(const float* logits_bkhw, long long* x_t_inout, uint8_t* unmasked_inout, int t, float temp,
+                     const float* u_or_null, const float* q_or_null, unsigned long long philox_seed,
+                     unsigned long long philox_offset, long long* x0_hat_out_or_null, int B, int HW, int K,
+                     spk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPKDIFF_H */

@@ -1,0 +1,332 @@
+// Direct (non-MFMA) convolution kernels of the SNN path.
+//
+//   spk_pack_conv_weight      [Cout,Cin,k,k] / [Cin,Cout,k,k] (ConvT)  ->  packed [k*k][Cin][Cout]
+//   spk_conv2d_fwd            layer.Conv2d 'm'-mode body     SJ/activation_based/layer.py:164-173
+//   spk_conv_transpose2d_fwd  layer.ConvTranspose2d body     SJ/activation_based/layer.py:316-325
+//   spk_conv_fused_fwd        (Conv|ConvT) [+ BN + LIF | raw | membrane read-out | time mean] fused:
+//                             R/snn_model/vae_model.py:109-124 (Encoder), :34-38 (poisson), :139-155 (Decoder),
+//                             R/snn_model/vq_diffusion.py:161-187,200-206 (denoiser; MFMA kernel replaces conv2-5)
+//
+// Numerics contract of every convolution in this library: the pre-activation is the CORRECTLY ROUNDED fp32
+// value of the exact dot product (+ bias), obtained by accumulating in fp64 (products of two fp32 are exact in
+// fp64).  It is therefore independent of accumulation order, bit-reproducible, and at most half an ulp away
+// from the real number that oneDNN's fp32 result approximates.  BN is y = fma(x, a, b) (fixture F7), LIF is the
+// reference's arithmetic (spk_common.h).
+//
+// Spike tensors between fused layers are u8 {0,1} in "PTC" layout [B][H][W][T][C] (position, time, channel):
+// the T steps of one neuron's inputs are adjacent, and channels are the unit-stride dimension that both the
+// direct kernels (lanes = output channels) and the MFMA kernel (K = taps x channels) read as 4..16 B vectors.
+#include "spk_common.h"
+#include "../../include/spkdiff.h"
+#include <math.h>
+
+namespace {
+
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int kk,
+                                   int transposed) {
+  int total = Cout * Cin * kk;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int co = i % Cout;
+    int ci = (i / Cout) % Cin;
+    int tap = i / (Cout * Cin);
+    // Conv2d weight [Cout][Cin][kk]; ConvTranspose2d weight [Cin][Cout][kk]
+    out[i] = transposed ? w[((long long)ci * Cout + co) * kk + tap] : w[((long long)co * Cin + ci) * kk + tap];
+  }
+}
+
+// ---------------------------------------------------------------- generic fp32 NCHW conv (API surface)
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(256) void conv_nchw_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        long long M, int Cin, int H, int W, int Cout, int Ho, int Wo,
+                                                        int k, int stride, int pad) {
+  const long long total = M * Cout * Ho * Wo;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    int ox = (int)(i % Wo);
+    long long r = i / Wo;
+    int oy = (int)(r % Ho); r /= Ho;
+    int co = (int)(r % Cout);
+    long long m = r / Cout;
+    double acc = bias ? (double)bias[co] : 0.0;
+    const float* xm = x + m * Cin * H * W;
+    for (int ky = 0; ky < k; ++ky) {
+      int iy;
+      if (TRANSPOSED) {
+        int ty = oy + pad - ky;
+        if (ty < 0 || ty % stride) continue;
+        iy = ty / stride;
+      } else {
+        iy = oy * stride - pad + ky;
+      }
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        int ix;
+        if (TRANSPOSED) {
+          int tx = ox + pad - kx;
+          if (tx < 0 || tx % stride) continue;
+          ix = tx / stride;
+        } else {
+          ix = ox * stride - pad + kx;
+        }
+        if (ix < 0 || ix >= W) continue;
+        const float* xp = xm + (long long)iy * W + ix;
+        const int tap = ky * k + kx;
+        for (int ci = 0; ci < Cin; ++ci) {
+          float wv = TRANSPOSED ? w[((long long)ci * Cout + co) * k * k + tap] : w[((long long)co * Cin + ci) * k * k + tap];
+          acc += (double)xp[(long long)ci * H * W] * (double)wv;
+        }
+      }
+    }
+    y[i] = (float)acc;
+  }
+}
+
+// ---------------------------------------------------------------- fused direct kernel
+struct FusedArgs {
+  const void* in0;      // PTC: u8 [B,H,W,T,C0]; TINV: fp32 [B,Cin,H,W]; SEQ: fp32 [T,B,Cin,H,W]
+  const uint8_t* in1;   // optional second PTC source concatenated after in0 along channels (C1 channels)
+  int C0, C1;
+  const float* wt;      // packed [k*k][Cin][Cout], Cin = C0 + C1
+  const float* bias;    // [Cout] or null
+  const float* bn_a;    // [Cout]  (MODE_LIF)
+  const float* bn_b;
+  float* v_io;          // [B,Cout,Ho,Wo] membrane potential in/out, or null (= fresh state, not written back)
+  uint8_t* out_ptc;     // MODE_LIF: spikes u8 [B,Ho,Wo,T,Cout] or null
+  float* out_f32;       // MODE_LIF: spikes fp32 [T,B,Cout,Ho,Wo] or null; MODE_RAW: x [T,B,Cout,Ho,Wo];
+                        // MODE_MEMOUT / MODE_MEAN: [B,Cout,Ho,Wo]
+  float* out_pre;       // optional BN output: TINV [B,Cout,Ho,Wo]; else [T,B,Cout,Ho,Wo]
+  uint8_t* out_u8;      // MODE_MEMOUT: uint8 image [B,Cout,Ho,Wo] or null
+  const float* coef;    // MODE_MEMOUT: [T]
+  int apply_tanh;
+  int T, B, H, W, Cout, Ho, Wo, k, stride, pad;
+};
+
+template <int INKIND, bool TRANSPOSED, int MODE>
+__global__ __launch_bounds__(256) void conv_fused_kernel(FusedArgs a) {
+  constexpr bool TINV = INKIND == SPK_IN_TINV;
+  const int Cin = a.C0 + a.C1;
+  const long long total = (long long)a.B * a.Ho * a.Wo * a.Cout;
+  const int T = a.T;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % a.Cout);
+    long long r = i / a.Cout;
+    const int ox = (int)(r % a.Wo); r /= a.Wo;
+    const int oy = (int)(r % a.Ho);
+    const int b = (int)(r / a.Ho);
+
+    double acc[TINV ? 1 : SPK_MAX_T];
+    const double b0 = a.bias ? (double)a.bias[co] : 0.0;
+#pragma unroll
+    for (int t = 0; t < (TINV ? 1 : SPK_MAX_T); ++t) acc[t] = b0;
+
+    for (int ky = 0; ky < a.k; ++ky) {
+      int iy;
+      if (TRANSPOSED) {
+        int ty = oy + a.pad - ky;
+        if (ty < 0 || ty % a.stride) continue;
+        iy = ty / a.stride;
+      } else {
+        iy = oy * a.stride - a.pad + ky;
+      }
+      if (iy < 0 || iy >= a.H) continue;
+      for (int kx = 0; kx < a.k; ++kx) {
+        int ix;
+        if (TRANSPOSED) {
+          int tx = ox + a.pad - kx;
+          if (tx < 0 || tx % a.stride) continue;
+          ix = tx / a.stride;
+        } else {
+          ix = ox * a.stride - a.pad + kx;
+        }
+        if (ix < 0 || ix >= a.W) continue;
+        const float* wp = a.wt + ((long long)(ky * a.k + kx) * Cin) * a.Cout + co;
+        if constexpr (TINV) {
+          const float* xp = reinterpret_cast<const float*>(a.in0) + ((long long)b * Cin * a.H + iy) * a.W + ix;
+          for (int ci = 0; ci < Cin; ++ci)
+            acc[0] += (double)xp[(long long)ci * a.H * a.W] * (double)wp[(long long)ci * a.Cout];
+        } else if constexpr (INKIND == SPK_IN_SEQ) {
+          const long long chw = (long long)a.H * a.W;
+          const float* xp = reinterpret_cast<const float*>(a.in0) + ((long long)b * Cin * a.H + iy) * a.W + ix;
+          const long long ts = (long long)a.B * Cin * chw;
+          for (int ci = 0; ci < Cin; ++ci) {
+            const double wv = (double)wp[(long long)ci * a.Cout];
+#pragma unroll
+            for (int t = 0; t < SPK_MAX_T; ++t)
+              if (t < T) acc[t] += (double)xp[t * ts + ci * chw] * wv;
+          }
+        } else {
+          const long long pos = ((long long)b * a.H + iy) * a.W + ix;
+          for (int src = 0; src < 2; ++src) {
+            const int Cs = src ? a.C1 : a.C0;
+            if (Cs == 0) continue;
+            const uint8_t* sp = (src ? a.in1 : reinterpret_cast<const uint8_t*>(a.in0)) + pos * T * Cs;
+            const float* wsrc = wp + (src ? (long long)a.C0 * a.Cout : 0);
+            for (int ci = 0; ci < Cs; ci += 4) {
+              const float w0 = wsrc[(long long)(ci + 0) * a.Cout], w1 = wsrc[(long long)(ci + 1) * a.Cout];
+              const float w2 = wsrc[(long long)(ci + 2) * a.Cout], w3 = wsrc[(long long)(ci + 3) * a.Cout];
+#pragma unroll
+              for (int t = 0; t < SPK_MAX_T; ++t) {
+                if (t < T) {
+                  const uint32_t s4 = *reinterpret_cast<const uint32_t*>(sp + t * Cs + ci);
+                  if (s4) {
+                    // exact: the selected weights are added in fp64
+                    acc[t] += (s4 & 0x000000ffu) ? (double)w0 : 0.0;
+                    acc[t] += (s4 & 0x0000ff00u) ? (double)w1 : 0.0;
+                    acc[t] += (s4 & 0x00ff0000u) ? (double)w2 : 0.0;
+                    acc[t] += (s4 & 0xff000000u) ? (double)w3 : 0.0;
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+
+    const long long plane = (long long)a.Ho * a.Wo;
+    const long long o_bchw = (((long long)b * a.Cout + co) * a.Ho + oy) * a.Wo + ox;     // [B,Cout,Ho,Wo]
+    const long long tstride = (long long)a.B * a.Cout * plane;                            // [T,B,Cout,Ho,Wo]
+
+    if constexpr (MODE == SPK_MODE_LIF) {
+      const float al = a.bn_a[co], be = a.bn_b[co];
+      float v = a.v_io ? a.v_io[o_bchw] : 0.0f;
+      float y0 = 0.f;
+      if constexpr (TINV) {
+        y0 = fmaf((float)acc[0], al, be);
+        if (a.out_pre) a.out_pre[o_bchw] = y0;
+      }
+      const long long o_ptc = ((((long long)b * a.Ho + oy) * a.Wo + ox) * T) * a.Cout + co;
+#pragma unroll
+      for (int t = 0; t < SPK_MAX_T; ++t) {
+        if (t < T) {
+          float y;
+          if constexpr (TINV) {
+            y = y0;
+          } else {
+            y = fmaf((float)acc[t], al, be);
+            if (a.out_pre) a.out_pre[o_bchw + t * tstride] = y;
+          }
+          const bool s = spk_lif_step_default(v, y);
+          if (a.out_ptc) a.out_ptc[o_ptc + (long long)t * a.Cout] = (uint8_t)s;
+          if (a.out_f32) a.out_f32[o_bchw + t * tstride] = s ? 1.0f : 0.0f;
+        }
+      }
+      if (a.v_io) a.v_io[o_bchw] = v;
+    } else if constexpr (MODE == SPK_MODE_RAW) {
+#pragma unroll
+      for (int t = 0; t < SPK_MAX_T; ++t)
+        if (t < T) a.out_f32[o_bchw + t * tstride] = (float)acc[TINV ? 0 : t];
+    } else if constexpr (MODE == SPK_MODE_MEMOUT) {
+      float m = 0.f;
+#pragma unroll
+      for (int t = 0; t < SPK_MAX_T; ++t)
+        if (t < T) m = m + (float)acc[TINV ? 0 : t] * a.coef[t];          // torch.sum(x * coef, dim=0)
+      const float p = a.apply_tanh ? tanhf(m) : m;
+      if (a.out_f32) a.out_f32[o_bchw] = p;
+      if (a.out_u8) {
+        // R/main.py:401: np.array(np.clip(pred + 0.5, 0, 1) * 255, dtype=np.uint8)  (truncating cast)
+        float q = fminf(fmaxf(p + 0.5f, 0.0f), 1.0f) * 255.0f;
+        a.out_u8[o_bchw] = (uint8_t)q;
+      }
+    } else {  // SPK_MODE_MEAN: torch.sum(x6, dim=0) / T     R/snn_model/vq_diffusion.py:206
+      float m = 0.f;
+#pragma unroll
+      for (int t = 0; t < SPK_MAX_T; ++t)
+        if (t < T) m = m + (float)acc[TINV ? 0 : t];
+      a.out_f32[o_bchw] = m / (float)T;
+    }
+  }
+}
+
+inline int grid_for(long long work_items) {
+  long long g = (work_items + 255) / 256;
+  const long long cap = 256 * 8 * 8;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+template <int INKIND, bool TR>
+int launch_mode(const FusedArgs& a, int mode, hipStream_t stream) {
+  const long long total = (long long)a.B * a.Ho * a.Wo * a.Cout;
+  dim3 g(grid_for(total)), blk(256);
+  switch (mode) {
+    case SPK_MODE_LIF: hipLaunchKernelGGL((conv_fused_kernel<INKIND, TR, SPK_MODE_LIF>), g, blk, 0, stream, a); break;
+    case SPK_MODE_RAW: hipLaunchKernelGGL((conv_fused_kernel<INKIND, TR, SPK_MODE_RAW>), g, blk, 0, stream, a); break;
+    case SPK_MODE_MEMOUT: hipLaunchKernelGGL((conv_fused_kernel<INKIND, TR, SPK_MODE_MEMOUT>), g, blk, 0, stream, a); break;
+    case SPK_MODE_MEAN: hipLaunchKernelGGL((conv_fused_kernel<INKIND, TR, SPK_MODE_MEAN>), g, blk, 0, stream, a); break;
+    default: return SPK_ERR_UNSUPPORTED;
+  }
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+}  // namespace
+
+extern "C" int spk_conv_out_size(int in, int k, int stride, int pad, int transposed, int out_pad) {
+  return transposed ? (in - 1) * stride - 2 * pad + k + out_pad : (in + 2 * pad - k) / stride + 1;
+}
+
+extern "C" int spk_pack_conv_weight(const float* w, float* packed, int Cout, int Cin, int k, int transposed,
+                                    hipStream_t stream) {
+  if (!w || !packed || Cout <= 0 || Cin <= 0 || k <= 0) return SPK_ERR_ARG;
+  int total = Cout * Cin * k * k;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w, packed, Cout, Cin, k * k,
+                     transposed);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, long long M, int Cin, int H,
+                              int W, int Cout, int k, int stride, int pad, hipStream_t stream) {
+  if (!x || !w || !y || M <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || stride <= 0 || pad < 0) return SPK_ERR_ARG;
+  int Ho = spk_conv_out_size(H, k, stride, pad, 0, 0), Wo = spk_conv_out_size(W, k, stride, pad, 0, 0);
+  if (Ho <= 0 || Wo <= 0) return SPK_ERR_ARG;
+  hipLaunchKernelGGL(conv_nchw_kernel<false>, dim3(grid_for(M * Cout * Ho * Wo)), dim3(256), 0, stream, x, w, bias, y,
+                     M, Cin, H, W, Cout, Ho, Wo, k, stride, pad);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_conv_transpose2d_fwd(const float* x, const float* w, const float* bias, float* y, long long M,
+                                        int Cin, int H, int W, int Cout, int k, int stride, int pad, int out_pad,
+                                        hipStream_t stream) {
+  if (!x || !w || !y || M <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || stride <= 0 || pad < 0 || out_pad < 0)
+    return SPK_ERR_ARG;
+  int Ho = spk_conv_out_size(H, k, stride, pad, 1, out_pad), Wo = spk_conv_out_size(W, k, stride, pad, 1, out_pad);
+  if (Ho <= 0 || Wo <= 0) return SPK_ERR_ARG;
+  hipLaunchKernelGGL(conv_nchw_kernel<true>, dim3(grid_for(M * Cout * Ho * Wo)), dim3(256), 0, stream, x, w, bias, y,
+                     M, Cin, H, W, Cout, Ho, Wo, k, stride, pad);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_conv_fused_fwd(const void* in0, const uint8_t* in1, int C0, int C1, int in_kind,
+                                  const float* w_packed, const float* bias, const float* bn_a, const float* bn_b,
+                                  float* v_inout, uint8_t* out_ptc, float* out_f32, float* out_pre, uint8_t* out_u8,
+                                  const float* coef, int apply_tanh, int mode, int T, int B, int H, int W, int Cout,
+                                  int k, int stride, int pad, int transposed, int out_pad, hipStream_t stream) {
+  if (!in0 || !w_packed || T <= 0 || T > SPK_MAX_T || B <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0 || k <= 0 ||
+      stride <= 0 || pad < 0)
+    return SPK_ERR_ARG;
+  if (in_kind < 0 || in_kind > 2) return SPK_ERR_ARG;
+  if (in_kind == SPK_IN_PTC && ((C0 % 4) || (C1 % 4))) return SPK_ERR_UNSUPPORTED;   // u32 spike loads
+  if (in_kind != SPK_IN_PTC && C1 != 0) return SPK_ERR_UNSUPPORTED;
+  if (in_kind == SPK_IN_TINV && transposed) return SPK_ERR_UNSUPPORTED;
+  if (C1 > 0 && !in1) return SPK_ERR_ARG;
+  if (mode == SPK_MODE_LIF && (!bn_a || !bn_b || (!out_ptc && !out_f32))) return SPK_ERR_ARG;
+  if ((mode == SPK_MODE_RAW || mode == SPK_MODE_MEAN) && !out_f32) return SPK_ERR_ARG;
+  if (mode == SPK_MODE_MEMOUT && (!coef || (!out_f32 && !out_u8))) return SPK_ERR_ARG;
+  FusedArgs a;
+  a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.wt = w_packed; a.bias = bias; a.bn_a = bn_a; a.bn_b = bn_b;
+  a.v_io = v_inout; a.out_ptc = out_ptc; a.out_f32 = out_f32; a.out_pre = out_pre; a.out_u8 = out_u8; a.coef = coef;
+  a.apply_tanh = apply_tanh; a.T = T; a.B = B; a.H = H; a.W = W; a.Cout = Cout;
+  a.Ho = spk_conv_out_size(H, k, stride, pad, transposed, out_pad);
+  a.Wo = spk_conv_out_size(W, k, stride, pad, transposed, out_pad);
+  a.k = k; a.stride = stride; a.pad = pad;
+  if (a.Ho <= 0 || a.Wo <= 0) return SPK_ERR_ARG;
+  if (in_kind == SPK_IN_TINV) return launch_mode<SPK_IN_TINV, false>(a, mode, stream);
+  if (in_kind == SPK_IN_SEQ)
+    return transposed ? launch_mode<SPK_IN_SEQ, true>(a, mode, stream) : launch_mode<SPK_IN_SEQ, false>(a, mode, stream);
+  return transposed ? launch_mode<SPK_IN_PTC, true>(a, mode, stream) : launch_mode<SPK_IN_PTC, false>(a, mode, stream);
+}

@@ -1,0 +1,175 @@
+// One reverse step of the absorbing-state discrete diffusion sampler, after the denoiser produced the logits:
+//   R/snn_model/vq_diffusion.py:113-124 (where to unmask), :134-140 (temperature, Categorical sample, scatter).
+//
+//   changes  = (u < 1/t) & ~unmasked ;  unmasked |= changes
+//   x0_hat   = Categorical(logits = logits/temp).sample()
+//            = argmax_k softmax(l - logsumexp l)_k / q_k ,  q ~ Exp(1)      (torch.multinomial one-draw fast path)
+//   x_t[changes] = x0_hat[changes]
+//
+// Noise sources: (a) injected u [B*HW] and q [B*HW*K] (parity mode: the host draws them with the reference's CPU
+// generator in the reference's order), or (b) on-device Philox4x32-10 keyed by (seed, offset)
+// (throughput mode).  One wave per latent position; lanes stride over the K classes; wave reductions by DPP shuffles.
+#include "spk_common.h"
+#include "../../include/spkdiff.h"
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+  uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+  uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+// Philox4x32-10: counter (index, stream) , key = seed
+__device__ __forceinline__ void philox4x32(unsigned long long seed, unsigned long long index, uint32_t stream,
+                                            uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)index, (uint32_t)(index >> 32), stream, 0u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+__device__ __forceinline__ float u01_open_left(uint32_t r) {   // (0, 1]
+  return ((float)(r >> 8) + 1.0f) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ float u01_open_right(uint32_t r) {  // [0, 1)
+  return (float)(r >> 8) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+constexpr int KPL = 4;  // classes per lane: K <= 256
+
+__global__ __launch_bounds__(256) void psample_kernel(const float* __restrict__ logits, long long* __restrict__ x_t,
+                                                      uint8_t* __restrict__ unmasked, int t, float temp,
+                                                      const float* __restrict__ u_in, const float* __restrict__ q_in,
+                                                      unsigned long long seed, unsigned long long offset,
+                                                      long long* __restrict__ x0_hat_out, int B, int HW, int K) {
+  const int lane = threadIdx.x & 63;
+  const long long npos = (long long)B * HW;
+  const float inv_t = 1.0f / (float)t;
+  for (long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); p < npos; p += (long long)gridDim.x * 4) {
+    const int b = (int)(p / HW), hw = (int)(p % HW);
+    float l[KPL];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+      const int k = lane + 64 * j;
+      l[j] = k < K ? logits[((long long)b * K + k) * HW + hw] / temp : -INFINITY;
+      mx = fmaxf(mx, l[j]);
+    }
+    mx = wave_max(mx);
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) se += (lane + 64 * j < K) ? expf(l[j] - mx) : 0.f;
+    se = wave_sum(se);
+    const float lse = mx + logf(se);
+    // Categorical normalises logits, then .probs = softmax(normalised logits)
+    float e[KPL];
+    float mx2 = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) { l[j] = l[j] - lse; mx2 = fmaxf(mx2, l[j]); }
+    mx2 = wave_max(mx2);
+    float se2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) { e[j] = (lane + 64 * j < K) ? expf(l[j] - mx2) : 0.f; se2 += e[j]; }
+    se2 = wave_sum(se2);
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+      const int k = lane + 64 * j;
+      if (k < K) {
+        float q;
+        if (q_in) {
+          q = q_in[p * K + k];
+        } else {
+          uint32_t r[4];
+          philox4x32(seed, offset + (unsigned long long)(p * K + k), 1u, r);
+          q = -logf(u01_open_left(r[0]));
+        }
+        const float ratio = (e[j] / se2) / q;
+        if (ratio > best) { best = ratio; besti = k; }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      float ob = __shfl_xor(best, off);
+      int oi = __shfl_xor(besti, off);
+      if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    if (lane == 0) {
+      float u;
+      if (u_in) {
+        u = u_in[p];
+      } else {
+        uint32_t r[4];
+        philox4x32(seed, offset + (unsigned long long)p, 0u, r);
+        u = u01_open_right(r[0]);
+      }
+      bool ch = (u < inv_t) && !unmasked[p];
+      if (ch) { unmasked[p] = 1; x_t[p] = (long long)besti; }
+      if (x0_hat_out) x0_hat_out[p] = (long long)besti;
+    }
+  }
+}
+
+// Denoiser input map, R/snn_model/vq_diffusion.py:195-197:  cat(x, ones_like(x) * t[:,None,None,None]) -> [B,2,h,w]
+// x comes either as float [B,1,h,w] (the module API) or as the int64 token state x_t of the sampler.
+__global__ void den_input_kernel(const float* __restrict__ xf, const long long* __restrict__ xi,
+                                 const long long* __restrict__ t_vec, long long t_scalar, float* __restrict__ out,
+                                 int B, int HW) {
+  const int total = B * HW;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int b = i / HW, hw = i % HW;
+    const float x = xf ? xf[i] : (float)xi[i];
+    const float tv = (float)(t_vec ? t_vec[b] : t_scalar);
+    out[((long long)b * 2 + 0) * HW + hw] = x;
+    out[((long long)b * 2 + 1) * HW + hw] = 1.0f * tv;
+  }
+}
+
+}  // namespace
+
+extern "C" int spk_den_build_input(const float* x_float_or_null, const long long* x_tokens_or_null,
+                                   const long long* t_vec_or_null, long long t_scalar, float* out_b2hw, int B, int HW,
+                                   hipStream_t stream) {
+  if ((!x_float_or_null && !x_tokens_or_null) || !out_b2hw || B <= 0 || HW <= 0) return SPK_ERR_ARG;
+  int total = B * HW;
+  hipLaunchKernelGGL(den_input_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, x_float_or_null,
+                     x_tokens_or_null, t_vec_or_null, t_scalar, out_b2hw, B, HW);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_psample_step(const float* logits_bkhw, long long* x_t_inout, uint8_t* unmasked_inout, int t,
+                                float temp, const float* u_or_null, const float* q_or_null,
+                                unsigned long long philox_seed, unsigned long long philox_offset,
+                                long long* x0_hat_out_or_null, int B, int HW, int K, hipStream_t stream) {
+  if (!logits_bkhw || !x_t_inout || !unmasked_inout || t <= 0 || !(temp > 0.f) || B <= 0 || HW <= 0 || K <= 0)
+    return SPK_ERR_ARG;
+  if (K > 64 * KPL) return SPK_ERR_UNSUPPORTED;
+  long long npos = (long long)B * HW;
+  int grid = (int)((npos + 3) / 4);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(psample_kernel, dim3(grid), dim3(256), 0, stream, logits_bkhw, x_t_inout, unmasked_inout, t, temp,
+                     u_or_null, q_or_null, philox_seed, philox_offset, x0_hat_out_or_null, B, HW, K);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}

@@ -1,0 +1,201 @@
+"""``snn_model.vae_model`` of the MI355X build: the spiking VQ-VAE inference path.
+
+Counterpart of R/snn_model/vae_model.py:22-196 -- same class names, constructor signatures, attribute paths
+(``model.encoder``, ``model.vq_layer.quantize/poisson``, ``model.decoder``, ``model.memout``) and ``state_dict``
+keys, so R/main.py's test/sampling section runs against it unchanged.  The eval branches run on
+``libspkdiff.so`` (fused Conv+BN+LIF kernels, VQ argmin kernel); the training branches (losses, STE:
+vae_model.py:61-85,189-196) are outside the hot path and raise NotImplementedError.
+
+Re-exported names match what ``from snn_model.vae_model import *`` gives R/main.py (``functional`` in particular,
+R/main.py:101-107,317).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from spikingjelly.activation_based import neuron, functional, layer, surrogate, monitor  # noqa: F401
+from spikingjelly import visualizing  # noqa: F401
+
+from spkdiff import ops
+from spkdiff.fused import FusedSequential
+from spkdiff.ops import IN_PTC, IN_SEQ, IN_TINV
+
+from .snn_layers import *  # noqa: F401,F403
+from .snn_layers import MembraneOutputLayer, PSP
+
+
+def _training_oos(what):
+    raise NotImplementedError(f'spkdiff: {what} is a training branch of the reference, outside the inference hot '
+                              'path (SURVEY.md §8f); call .eval()')
+
+
+class VectorQuantizer(nn.Module):
+    def __init__(self, embedding_dim, num_embeddings, commitment_cost, n_steps: int = 16):
+        super().__init__()
+        self.embedding_dim = embedding_dim
+        self.num_embeddings = num_embeddings
+        self.commitment_cost = commitment_cost
+        self.memout = MembraneOutputLayer(n_steps)
+        self.num_step = n_steps
+        self.psp = PSP()
+        self.alpha = nn.Parameter(torch.tensor(0.5))
+        self.embeddings = nn.Embedding(self.num_embeddings, self.embedding_dim)
+        self.poisson = FusedSequential(
+            layer.Conv2d(in_channels=embedding_dim, out_channels=embedding_dim, kernel_size=1),
+            layer.BatchNorm2d(embedding_dim),
+            neuron.LIFNode(surrogate_function=surrogate.ATan()),
+        )
+
+    # -- fused pieces, shared with SNN_VQVAE's end-to-end path ------------------------------------------------
+    def _quantize_ptc(self, z_ptc, want_xm=False):
+        """z_ptc u8 [B,h,w,T,D] -> (indices int64 [B*h*w], quantized fp32 [B,D,h,w])."""
+        idx, zq, xm = ops.vq_readout_argmin(z_ptc, self.memout.coef.flatten(), self.alpha, self.embeddings.weight,
+                                            want_zq=True, want_xm=want_xm)
+        return (idx, zq, xm) if want_xm else (idx, zq)
+
+    def _spike_generator(self, zq, T, final='f32'):
+        """'adaptive spike generator': repeat(T) + poisson, the repeat folded into the kernel (same frame each step)."""
+        return self.poisson.run(zq, IN_TINV, final=final, T=T)
+
+    def forward(self, x):
+        # x: (T,N,C,H,W) spikes of the encoder
+        if self.training:
+            _training_oos('VectorQuantizer.forward (VQ / commitment / PSP losses)')
+        T = x.shape[0]
+        idx, zq = self._quantize_ptc(ops.spikes_to_ptc(x))
+        quantized = self._spike_generator(zq, T)['f32']
+        return quantized, idx
+
+    def get_code_indices(self, flat_x):
+        """argmin_k ||x - e_k||^2 for rows of flat_x [N, D] (R/snn_model/vae_model.py:87-95)."""
+        return ops.vq_argmin(flat_x, self.embeddings.weight)
+
+    def quantize(self, encoding_indices):
+        """Returns embedding tensor for a batch of indices."""
+        return ops.embedding(encoding_indices, self.embeddings.weight)
+
+
+class Encoder(nn.Module):
+    """Encoder of VQ-VAE"""
+
+    def __init__(self, in_dim=1, latent_dim=16):
+        super().__init__()
+        self.in_dim = in_dim
+        self.latent_dim = latent_dim
+        self.snn_convs = FusedSequential(
+            layer.Conv2d(in_channels=in_dim, out_channels=32, kernel_size=3, stride=2, padding=1),
+            layer.BatchNorm2d(32),
+            neuron.LIFNode(surrogate_function=surrogate.ATan()),
+
+            layer.Conv2d(in_channels=32, out_channels=64, kernel_size=3, stride=2, padding=1),
+            layer.BatchNorm2d(64),
+            neuron.LIFNode(surrogate_function=surrogate.ATan()),
+
+            layer.Conv2d(in_channels=64, out_channels=latent_dim, kernel_size=1, stride=1, padding=0),
+            layer.BatchNorm2d(latent_dim),
+            neuron.LIFNode(surrogate_function=surrogate.ATan()),
+        )
+
+    def forward(self, x):
+        # [t, b, c, h, w]
+        return self.snn_convs(x)
+
+
+class Decoder(nn.Module):
+    """Decoder of VQ-VAE"""
+
+    def __init__(self, out_dim=1, latent_dim=16):
+        super().__init__()
+        self.out_dim = out_dim
+        self.latent_dim = latent_dim
+        self.snn_convs = FusedSequential(
+            layer.ConvTranspose2d(in_channels=latent_dim, out_channels=64, kernel_size=3, stride=2, padding=1,
+                                  output_padding=1),
+            layer.BatchNorm2d(64),
+            neuron.LIFNode(surrogate_function=surrogate.ATan()),
+
+            layer.ConvTranspose2d(in_channels=64, out_channels=32, kernel_size=3, stride=2, padding=1,
+                                  output_padding=1),
+            layer.BatchNorm2d(32),
+            neuron.LIFNode(surrogate_function=surrogate.ATan()),
+
+            layer.ConvTranspose2d(in_channels=32, out_channels=out_dim, kernel_size=3, stride=1, padding=1,
+                                  output_padding=0),
+        )
+
+    def forward(self, x):
+        # [t, b, c, h, w]
+        return self.snn_convs(x)
+
+
+class SNN_VQVAE(nn.Module):
+    """VQ-VAE"""
+
+    def __init__(self, in_dim, embedding_dim, num_embeddings, data_variance, commitment_cost=0.25,
+                 n_steps: int = 16):
+        super().__init__()
+        self.in_dim = in_dim
+        self.embedding_dim = embedding_dim
+        self.num_embeddings = num_embeddings
+        self.data_variance = data_variance
+
+        self.encoder = Encoder(in_dim, embedding_dim)
+        self.vq_layer = VectorQuantizer(embedding_dim, num_embeddings, commitment_cost, n_steps)
+        self.decoder = Decoder(in_dim, embedding_dim)
+        self.memout = MembraneOutputLayer(n_steps)
+
+    def forward(self, x, image):
+        # x: [t, B, C, H, W]
+        if self.training:
+            _training_oos('SNN_VQVAE.forward (reconstruction / VQ losses)')
+        T = x.shape[0]
+        enc = self.encoder.snn_convs
+        dec = self.decoder.snn_convs
+        if enc._fusable(enc._blocks()) and dec._fusable(dec._blocks()) and T <= ops.MAX_T:
+            # end-to-end fused: spikes stay u8 PTC between encoder, VQ, spike generator and decoder
+            z_ptc = enc.run(x, IN_SEQ, final='ptc')['ptc']
+            idx, zq = self.vq_layer._quantize_ptc(z_ptc)
+            e = self.vq_layer._spike_generator(zq, T, final='both')
+            x_recon = dec.run(e['ptc'], IN_PTC, final='memout', coef=self.memout.coef.flatten(),
+                              apply_tanh=True)['f32']
+            return e['f32'], x_recon, idx
+        z = self.encoder(x)
+        e, enco = self.vq_layer(z)
+        x_recon = self.decoder(e)
+        x_recon = torch.tanh(self.memout(x_recon))
+        return e, x_recon, enco
+
+    # ---- convenience entry points of the MI355X build (not in the reference) -----------------------------------
+    @torch.no_grad()
+    def encode_images(self, images, T=16):
+        """images [B,C,H,W] already normalised (images - 0.5) -> code indices [B,h,w]; the T-fold repeat of
+        R/main.py:309 / vq_diffusion.py:30 is folded into the first kernel (time-invariant input)."""
+        z_ptc = self.encoder.snn_convs.run(images, IN_TINV, final='ptc', T=T, stateful=False)['ptc']
+        idx, _ = self.vq_layer._quantize_ptc(z_ptc)
+        L = images.shape[-1] // 4
+        return idx.reshape(images.shape[0], L, L)
+
+    @torch.no_grad()
+    def decode_tokens(self, tokens, T=16, want_u8=True):
+        """tokens int64 [B,h,w] -> (pred fp32 [B,C,H,W] in (-1,1), uint8 image): the glue of R/main.py:388-401 as
+        three launches (embedding gather, spike generator, fused decoder + read-out + tanh + uint8)."""
+        B, h, w = tokens.shape
+        zq = ops.embedding(tokens, self.vq_layer.embeddings.weight, nchw_hw=(h, w))
+        e_ptc = self.vq_layer.poisson.run(zq, IN_TINV, final='ptc', T=T, stateful=False)['ptc']
+        r = self.decoder.snn_convs.run(e_ptc, IN_PTC, final='memout', coef=self.memout.coef.flatten(), apply_tanh=True,
+                                       want_u8=want_u8, stateful=False)
+        return r['f32'], r['u8']
+
+
+def _not_in_scope(name):
+    class _Stub(nn.Module):
+        def __init__(self, *a, **k):
+            raise NotImplementedError(f'spkdiff: {name} is a baseline model outside the named hot path '
+                                      '(SURVEY.md §2.1 #3); only SNN_VQVAE is implemented')
+    _Stub.__name__ = name
+    return _Stub
+
+
+SNN_VAE = _not_in_scope('SNN_VAE')
+VQVAE = _not_in_scope('VQVAE')
+SNN_VQVAE_uni = _not_in_scope('SNN_VQVAE_uni')

@@ -1,0 +1,157 @@
+"""``snn_model.vq_diffusion`` of the MI355X build: spiking denoiser + absorbing-state reverse diffusion sampler.
+
+Counterpart of R/snn_model/vq_diffusion.py -- ``DummyModel`` (:150-208), ``AbsorbingDiffusion`` (:43-147, only
+``sample`` is on the hot path) and ``get_data_for_diff`` (:23-36) -- with the same names, constructor arguments,
+attributes (``num_embeddings``, ``n_samples``, ``mask_id``, ``shape``...) and ``state_dict`` keys.
+
+The denoiser runs as fused Conv+BN+LIF kernels (conv1 sees a time-invariant input, conv6 + the time mean are one
+kernel), the per-step token update is one ``spk_psample_step`` launch, and ``sample()`` enqueues the whole
+reverse process without any host synchronisation.  Latent size and T are parameters (the reference hard-codes
+7x7 and 16: vq_diffusion.py:47-48,106,198,206).
+"""
+import torch
+import torch.nn as nn
+
+from spikingjelly.activation_based import neuron, functional, layer, surrogate, monitor  # noqa: F401
+from spikingjelly import visualizing  # noqa: F401
+
+from spkdiff import ops
+from spkdiff.fused import FusedSequential
+from spkdiff.ops import IN_PTC, IN_TINV
+
+from .vae_model import *  # noqa: F401,F403  (R/snn_model/vq_diffusion.py:21)
+
+
+def get_data_for_diff(train_loader, model, T: int = 16):
+    """Encode a data set to code indices (R/snn_model/vq_diffusion.py:23-36): one fused encode per batch."""
+    print('prepare data for train diffusion...')
+    model.eval()
+    train_indices = []
+    dev = next(model.parameters()).device
+    for images, labels in train_loader:
+        images = (images - 0.5).to(dev)  # normalize to [-0.5, 0.5]
+        with torch.inference_mode():
+            idx = model.encode_images(images.float().contiguous(), T)
+            train_indices.append(idx.cpu())
+    return train_indices
+
+
+class Sampler(nn.Module):
+    def __init__(self):
+        super().__init__()
+
+
+class AbsorbingDiffusion(Sampler):
+    def __init__(self, denoise_fn, mask_id, latent_shape=(7, 7)):
+        super().__init__()
+        self.num_classes = denoise_fn.num_embeddings
+        self.shape = list(latent_shape)
+        self.num_timesteps = latent_shape[0] * latent_shape[1]
+        self.mask_id = mask_id
+        self._denoise_fn = denoise_fn
+        self.n_samples = 16
+        self.mask_schedule = 'random'
+        self.loss_type = 'reweighted_elbo'
+        # 'philox': on-device counter-based noise (throughput); 'host': u and q drawn per step from torch's global
+        # CPU generator in the reference's order (rand_like, then multinomial's exponential_), which reproduces the
+        # reference CPU path token for token under the same torch.manual_seed.
+        self.noise_source = 'philox'
+        self._philox_calls = 0
+
+    def sample_time(self, *args, **kwargs):
+        raise NotImplementedError('spkdiff: AbsorbingDiffusion training (sample_time/q_sample/_train_loss) is outside '
+                                  'the inference hot path (SURVEY.md §8f)')
+
+    q_sample = _train_loss = train_iter = sample_time
+
+    @torch.no_grad()
+    def sample(self, temp=1.0, sample_steps=None, noise=None, record=None):
+        """Reverse absorbing diffusion (R/snn_model/vq_diffusion.py:103-142).  Returns x_t int64 [B,1,h,w].
+
+        ``noise``: optional callable t -> (u [B,1,h,w], q [B*h*w, K]) of device tensors (tests inject fixtures).
+        ``record``: optional list receiving (t, x_t.clone(), unmasked.clone(), logits.clone()) per step."""
+        dn = self._denoise_fn
+        dev = next(dn.parameters()).device
+        if dev.type != 'cuda':
+            raise RuntimeError('spkdiff: the sampler runs on a ROCm device; move the denoiser with .cuda()')
+        b = int(self.n_samples)
+        h, w = self.shape
+        K = self.num_classes
+        x_t = torch.full((b, 1, h, w), int(self.mask_id), dtype=torch.int64, device=dev)
+        unmasked = torch.zeros((b, 1, h, w), dtype=torch.bool, device=dev)
+        if sample_steps is None:
+            sample_steps = self.num_timesteps
+        seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        base = self._philox_calls * (1 << 40)
+        self._philox_calls += 1
+        for t in reversed(range(1, sample_steps + 1)):
+            u = q = None
+            if noise is not None:
+                u, q = noise(t)
+            elif self.noise_source == 'host':
+                u = torch.rand(b, 1, h, w).to(dev)                       # rand_like(x_t.float()), drawn first (:116)
+            logits = dn.logits_from_tokens(x_t, t)                       # denoiser + reset_net (:128-129)
+            if noise is None and self.noise_source == 'host':
+                q = torch.empty(b * h * w, K).exponential_(1).to(dev)    # multinomial's one-draw fast path (:138)
+            ops.psample_step(logits, x_t, unmasked, t, temp, u, q, seed, base + (sample_steps - t) * (b * h * w * K))
+            if record is not None:
+                record.append((t, x_t.clone(), unmasked.clone(), logits.clone()))
+        return x_t
+
+
+class DummyModel(nn.Module):
+    """Spiking convolutional denoiser ("SDID"); R/snn_model/vq_diffusion.py:150-208."""
+
+    def __init__(self, n_channel: int, num_embeddings, n_steps: int = 16) -> None:
+        super(DummyModel, self).__init__()
+        self.num_embeddings = num_embeddings
+        self.n_steps = n_steps
+
+        def block(cin, cout):
+            return FusedSequential(
+                layer.Conv2d(in_channels=cin, out_channels=cout, kernel_size=3, stride=1, padding=1),
+                layer.BatchNorm2d(cout),
+                neuron.LIFNode(surrogate_function=surrogate.ATan()))
+
+        self.conv1 = block(n_channel * 2, 64)
+        self.conv2 = block(64, 128)
+        self.conv3 = block(128, 256)
+        self.conv4 = block(256, 512)
+        self.conv5 = block(512, 256)
+        self.conv6 = FusedSequential(
+            layer.Conv2d(256 + 64, num_embeddings, 3, 1, 1),
+        )
+
+    def _fused_ok(self):
+        return all(c._fusable(c._blocks()) for c in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5,
+                                                     self.conv6)) and self.n_steps <= ops.MAX_T
+
+    def _run(self, inp_b2hw, stateful, record=None):
+        T = self.n_steps
+        x1 = self.conv1.run(inp_b2hw, IN_TINV, final='ptc', T=T, stateful=stateful)['ptc']
+        x = x1
+        outs = [x1]
+        for blk in (self.conv2, self.conv3, self.conv4, self.conv5):
+            x = blk.run(x, IN_PTC, final='ptc', stateful=stateful)['ptc']
+            outs.append(x)
+        if record is not None:
+            record.extend(outs)
+        return self.conv6.run(x, IN_PTC, final='mean', in1=x1)['f32']
+
+    def forward(self, x, t) -> torch.Tensor:
+        # x: b,c,h,w (token ids as floats); t: b
+        if self.training:
+            raise NotImplementedError('spkdiff: DummyModel training is outside the inference hot path; call .eval()')
+        if not self._fused_ok():
+            raise RuntimeError('spkdiff: DummyModel needs functional.set_step_mode(net, "m") and .eval()')
+        return self._run(ops.den_build_input(x, t), stateful=True)
+
+    @torch.no_grad()
+    def logits_from_tokens(self, x_t, t: int, record=None):
+        """Sampler fast path: ``self(x_t.float(), full((b,), t))`` followed by ``functional.reset_net(self)``
+        (R/snn_model/vq_diffusion.py:128-129) -- every LIF starts from and returns to the reset state, so no
+        membrane tensors are read or written."""
+        if not self._fused_ok() or self.training:
+            raise RuntimeError('spkdiff: DummyModel needs functional.set_step_mode(net, "m") and .eval()')
+        functional.reset_net(self)
+        return self._run(ops.den_build_input(x_t, int(t)), stateful=False, record=record)

@@ -1,0 +1,89 @@
+"""Spiking neurons of the inference path: ``BaseNode`` state handling and ``LIFNode``.
+
+Surface of SJ/activation_based/neuron.py:23-263 (BaseNode) and :603-1011 (LIFNode); the eval multi-step kernel
+``jit_eval_multi_step_forward_hard_reset_decay_input`` (:799-811) is replaced by ``spk_lif_fwd`` (HIP, one pass,
+membrane potential in registers across T).  ``v`` keeps the reference's lifetime: python float after
+``reset()``, tensor after the first forward, carried across forwards until the next ``reset()``.
+"""
+from typing import Callable
+
+import torch
+
+from spkdiff import ops
+
+from . import base, surrogate
+
+
+class BaseNode(base.MemoryModule):
+    def __init__(self, v_threshold: float = 1., v_reset: float = 0.,
+                 surrogate_function: Callable = surrogate.Sigmoid(), detach_reset: bool = False,
+                 step_mode='s', backend='torch', store_v_seq: bool = False):
+        assert isinstance(v_reset, float) or v_reset is None
+        assert isinstance(v_threshold, float)
+        assert isinstance(detach_reset, bool)
+        super().__init__()
+        self.register_memory('v', 0. if v_reset is None else v_reset)
+        self.v_threshold = v_threshold
+        self.v_reset = v_reset
+        self.detach_reset = detach_reset
+        self.surrogate_function = surrogate_function
+        self.step_mode = step_mode
+        self.backend = backend
+        self.store_v_seq = store_v_seq
+
+    @property
+    def store_v_seq(self):
+        return self._store_v_seq
+
+    @store_v_seq.setter
+    def store_v_seq(self, value: bool):
+        if value:
+            raise NotImplementedError('spkdiff: store_v_seq is a training/debug feature outside the inference path')
+        self._store_v_seq = False
+
+    def extra_repr(self):
+        return (f'v_threshold={self.v_threshold}, v_reset={self.v_reset}, detach_reset={self.detach_reset}, '
+                f'step_mode={self.step_mode}, backend={self.backend}')
+
+    def v_float_to_tensor(self, x: torch.Tensor):
+        """SJ/activation_based/neuron.py:260-263: expand the float state to x's shape on first use."""
+        if isinstance(self.v, float):
+            self.v = torch.full_like(x.data, self.v)
+
+
+class LIFNode(BaseNode):
+    def __init__(self, tau: float = 2., decay_input: bool = True, v_threshold: float = 1.,
+                 v_reset: float = 0., surrogate_function: Callable = surrogate.Sigmoid(),
+                 detach_reset: bool = False, step_mode='s', backend='torch', store_v_seq: bool = False):
+        assert isinstance(tau, float) and tau > 1.
+        super().__init__(v_threshold, v_reset, surrogate_function, detach_reset, step_mode, backend, store_v_seq)
+        self.tau = tau
+        self.decay_input = decay_input
+
+    @property
+    def supported_backends(self):
+        # both names run the same HIP kernel; 'torch' is kept because it is the reference's default string
+        return ('torch', 'hip')
+
+    def extra_repr(self):
+        return super().extra_repr() + f', tau={self.tau}'
+
+    def _check_supported(self, x):
+        if self.training:
+            raise NotImplementedError('spkdiff: LIFNode training (surrogate-gradient BPTT) is outside the inference '
+                                      'hot path; call .eval()')
+        if self.v_reset is None or not self.decay_input:
+            raise NotImplementedError('spkdiff: only hard reset with decay_input=True (the configuration used by '
+                                      'snn_model) is implemented')
+        if x.dtype != torch.float32:
+            raise NotImplementedError(x.dtype)
+
+    def multi_step_forward(self, x_seq: torch.Tensor):
+        self._check_supported(x_seq)
+        self.v_float_to_tensor(x_seq[0])
+        if not self.v.is_contiguous():
+            self.v = self.v.contiguous()
+        return ops.lif_fwd(x_seq, self.v, self.tau, self.v_threshold, self.v_reset)
+
+    def single_step_forward(self, x: torch.Tensor):
+        return self.multi_step_forward(x.unsqueeze(0))[0]

@@ -1,0 +1,80 @@
+"""ctypes binding of ``libspkdiff.so`` (the C-ABI declared in ``include/spkdiff.h``).
+
+The library is the ONLY engine of this package: if it is missing (not built) the import fails loudly --
+there is no PyTorch/CPU fallback anywhere in the product path.  ``torch`` is imported first so that the
+HIP runtime the library binds to is the one PyTorch-ROCm already loaded (same ``libamdhip64.so`` soname),
+which is what makes torch's device pointers and streams valid arguments.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_ulonglong, c_void_p
+
+import torch  # noqa: F401  (must precede the dlopen below: shares torch's HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspkdiff.so")
+
+
+class SpkdiffError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"spkdiff: native library not found at {LIB_PATH}. Build it with "
+            f"`make -C {os.path.join(os.path.dirname(_HERE), 'csrc')}` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no fallback path: the HIP kernels are the implementation.")
+    return ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+
+
+lib = _load()
+
+P = c_void_p
+_SIGS = {
+    "spk_version": (c_int, []),
+    "spk_error_string": (c_char_p, [c_int]),
+    "spk_lif_fwd": (c_int, [P, P, P, c_int, c_longlong, c_float, c_float, c_float, c_int, P]),
+    "spk_bn_prepare": (c_int, [P, P, P, P, c_float, P, P, c_int, P]),
+    "spk_bn_eval_fwd": (c_int, [P, P, P, P, c_longlong, c_int, c_int, P]),
+    "spk_conv2d_fwd": (c_int, [P, P, P, P, c_longlong, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "spk_conv_transpose2d_fwd": (c_int, [P, P, P, P, c_longlong, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                         c_int, P]),
+    "spk_memout_fwd": (c_int, [P, P, P, c_int, c_longlong, P]),
+    "spk_spikes_to_ptc": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "spk_ptc_to_spikes": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "spk_conv_out_size": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "spk_pack_conv_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "spk_conv_fused_fwd": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int,
+                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "spk_vq_readout_argmin": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "spk_vq_argmin": (c_int, [P, P, P, c_longlong, c_int, c_int, P]),
+    "spk_embedding_fwd": (c_int, [P, P, P, c_longlong, c_int, c_int, c_int, c_int, P]),
+    "spk_den_build_input": (c_int, [P, P, P, c_longlong, P, c_int, c_int, P]),
+    "spk_psample_step": (c_int, [P, P, P, c_int, c_float, P, P, c_ulonglong, c_ulonglong, P, c_int, c_int, c_int, P]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)      # AttributeError here = header/library mismatch: fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def check(rc: int, what: str = ""):
+    """Translate a C-ABI return code into the exception the reference surface would raise."""
+    if rc == 0:
+        return
+    msg = lib.spk_error_string(rc).decode()
+    if rc == -1:
+        raise ValueError(f"{what}: {msg}")
+    if rc == -2:
+        raise NotImplementedError(f"{what}: {msg}")
+    raise SpkdiffError(f"{what}: HIP error {rc}: {msg}")
+
+
+def version() -> int:
+    return lib.spk_version()

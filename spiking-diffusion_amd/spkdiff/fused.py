@@ -1,0 +1,152 @@
+"""Layer fusion for the drop-in modules: a ``(Conv2d|ConvTranspose2d) -> BatchNorm2d -> LIFNode`` triple of an
+``nn.Sequential`` becomes ONE kernel launch (``spk_conv_fused_fwd``), spikes travel between blocks as u8 "PTC"
+tensors, and fp32 [T,B,C,H,W] tensors (the reference's format) are only materialised at the module boundary.
+
+``FusedSequential`` is an ``nn.Sequential`` (same children, same ``state_dict`` keys as the reference's
+``snn_convs`` / ``poisson`` / ``convN`` containers: R/snn_model/vae_model.py:34-38,109-124,139-155,
+R/snn_model/vq_diffusion.py:161-187).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from spikingjelly.activation_based import layer, neuron
+
+from . import ops
+from .ops import IN_PTC, IN_SEQ, IN_TINV, MODE_LIF, MODE_MEAN, MODE_MEMOUT, MODE_RAW
+
+
+def _ver(t):
+    return None if t is None else (t.data_ptr(), t._version, str(t.device))
+
+
+class ConvParams:
+    """Packed weight [k*k][Cin][Cout] + bias of one conv layer, rebuilt when the parameters change."""
+
+    def __init__(self):
+        self.key = None
+        self.w_packed = None
+
+    def get(self, conv):
+        key = (_ver(conv.weight), _ver(conv.bias))
+        if key != self.key:
+            transposed = isinstance(conv, nn.ConvTranspose2d)
+            self.w_packed = ops.pack_conv_weight(conv.weight, transposed)
+            self.key = key
+        return self.w_packed
+
+
+def conv_geometry(conv):
+    layer._check_plain(conv)
+    transposed = isinstance(conv, nn.ConvTranspose2d)
+    return dict(k=layer._one(conv.kernel_size, 'kernel_size'), stride=layer._one(conv.stride, 'stride'),
+                pad=layer._one(conv.padding, 'padding'), transposed=transposed,
+                out_pad=layer._one(conv.output_padding, 'output_padding') if transposed else 0)
+
+
+def _is_conv(m):
+    return isinstance(m, (layer.Conv2d, layer.ConvTranspose2d))
+
+
+class FusedSequential(nn.Sequential):
+    """nn.Sequential whose (conv, bn, lif) triples run as fused HIP kernels in eval / multi-step mode."""
+
+    def _blocks(self):
+        mods = list(self)
+        blocks, i = [], 0
+        while i < len(mods):
+            if (i + 2 < len(mods) and _is_conv(mods[i]) and isinstance(mods[i + 1], layer.BatchNorm2d)
+                    and isinstance(mods[i + 2], neuron.LIFNode)):
+                blocks.append((mods[i], mods[i + 1], mods[i + 2]))
+                i += 3
+            elif _is_conv(mods[i]) and i == len(mods) - 1:
+                blocks.append((mods[i], None, None))
+                i += 1
+            else:
+                return None
+        return blocks
+
+    def _fusable(self, blocks):
+        if blocks is None:
+            return False
+        for conv, bn, lif in blocks:
+            if conv.step_mode != 'm':
+                return False
+            if lif is not None:
+                if lif.step_mode != 'm' or bn.step_mode != 'm' or lif.training or bn.training:
+                    return False
+                if (lif.tau != 2.0 or lif.v_threshold != 1.0 or lif.v_reset != 0.0 or not lif.decay_input):
+                    return False
+        return True
+
+    def forward(self, x):
+        blocks = self._blocks()
+        if not self._fusable(blocks) or x.dim() != 5 or x.shape[0] > ops.MAX_T:
+            for m in self:                      # layer by layer: still HIP kernels, just not fused
+                x = m(x)
+            return x
+        return self.run(x, IN_SEQ, final='f32')['f32']
+
+    def run(self, x, in_kind, final='f32', T=None, in1=None, coef=None, apply_tanh=False, want_u8=False,
+            stateful=True, want_pre=False):
+        """Run all blocks fused.
+
+        x: per in_kind (IN_SEQ fp32 [T,B,C,H,W]; IN_TINV fp32 [B,C,H,W] with ``T`` given; IN_PTC u8 [B,H,W,T,C]).
+        final: output of the LAST block -- 'f32' (spikes TBCHW, or the raw conv output when the last block has no
+        BN/LIF), 'ptc', 'both', 'memout' (read-out of a conv-only last block) or 'mean'.
+        stateful: honour and update each LIFNode's ``v`` (module semantics); False = fresh state, nothing written.
+        Returns dict(ptc=, f32=, pre=[...], u8=)."""
+        blocks = self._blocks()
+        if not self._fusable(blocks):
+            raise RuntimeError('spkdiff: this container is not in fused-eval configuration (eval(), step_mode "m")')
+        if in_kind == IN_SEQ:
+            T = x.shape[0]
+        elif in_kind == IN_PTC:
+            T = x.shape[3]
+        elif T is None:
+            raise ValueError('T is required for a time-invariant input')
+        cur, kind = x, in_kind
+        out = {'ptc': None, 'f32': None, 'u8': None, 'pre': []}
+        for bi, (conv, bn, lif) in enumerate(blocks):
+            last = bi == len(blocks) - 1
+            if not hasattr(conv, '_spk_params'):
+                object.__setattr__(conv, '_spk_params', ConvParams())
+            w_packed = conv._spk_params.get(conv)
+            geo = conv_geometry(conv)
+            bias = None if conv.bias is None else conv.bias.detach()
+            src1 = in1 if (last and in1 is not None) else None
+            if lif is not None:
+                a, b = bn.affine_terms()
+                v = None
+                if stateful:
+                    B = cur.shape[0] if kind != IN_SEQ else cur.shape[1]
+                    H, W = (cur.shape[1], cur.shape[2]) if kind == IN_PTC else (cur.shape[-2], cur.shape[-1])
+                    Ho = ops.conv_out_size(H, geo['k'], geo['stride'], geo['pad'], geo['transposed'], geo['out_pad'])
+                    Wo = ops.conv_out_size(W, geo['k'], geo['stride'], geo['pad'], geo['transposed'], geo['out_pad'])
+                    if isinstance(lif.v, float):
+                        lif.v = torch.full((B, conv.out_channels, Ho, Wo), lif.v, dtype=torch.float32,
+                                           device=cur.device)
+                    elif tuple(lif.v.shape) != (B, conv.out_channels, Ho, Wo):
+                        raise RuntimeError(f'LIFNode state has shape {tuple(lif.v.shape)} but the input implies '
+                                           f'{(B, conv.out_channels, Ho, Wo)}; call functional.reset_net first')
+                    v = lif.v
+                r = ops.conv_fused(cur, w_packed, bias, in_kind=kind, T=T, mode=MODE_LIF, in1=src1, bn_a=a, bn_b=b,
+                                   v=v, want_ptc=(not last) or final in ('ptc', 'both'),
+                                   want_f32=last and final in ('f32', 'both'), want_pre=want_pre, **geo)
+                if want_pre:
+                    out['pre'].append(r['pre'])
+                if last:
+                    out['ptc'], out['f32'] = r['ptc'], r['f32']
+                else:
+                    cur, kind = r['ptc'], IN_PTC
+            else:
+                if final == 'memout':
+                    r = ops.conv_fused(cur, w_packed, bias, in_kind=kind, T=T, mode=MODE_MEMOUT, in1=src1, coef=coef,
+                                       apply_tanh=apply_tanh, want_u8=want_u8, **geo)
+                elif final == 'mean':
+                    r = ops.conv_fused(cur, w_packed, bias, in_kind=kind, T=T, mode=MODE_MEAN, in1=src1, **geo)
+                else:
+                    r = ops.conv_fused(cur, w_packed, bias, in_kind=kind, T=T, mode=MODE_RAW, in1=src1, **geo)
+                out['f32'], out['u8'] = r['f32'], r['u8']
+        return out

@@ -1,0 +1,313 @@
+"""Tensor-level wrappers over the C-ABI: validate, allocate outputs with torch, launch on torch's current stream.
+
+PyTorch is plumbing here (device memory, streams); every operation is executed by ``libspkdiff.so``.
+All tensors must live on a ROCm device ("cuda"); CPU tensors are rejected -- there is no fallback.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+MODE_LIF, MODE_RAW, MODE_MEMOUT, MODE_MEAN = 0, 1, 2, 3
+SPIKE_F32, SPIKE_U8, SPIKE_BITS = 0, 1, 2
+MAX_T = 16
+
+
+def _stream(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str, dtype=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"spkdiff: {name} is on '{t.device}'. The HIP kernels are the implementation; "
+                           "there is no CPU path (move the module / tensors to a ROCm device).")
+    if dtype is not None and t.dtype != dtype:
+        raise NotImplementedError(f"spkdiff: {name} must be {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def conv_out_size(n, k, stride, pad, transposed=False, out_pad=0):
+    return lib.spk_conv_out_size(n, k, stride, pad, int(transposed), out_pad)
+
+
+# ---------------------------------------------------------------------------------------------- neuron
+def lif_fwd(x_seq: torch.Tensor, v: torch.Tensor, tau=2.0, v_threshold=1.0, v_reset=0.0, spike_dtype=SPIKE_F32):
+    """x_seq [T, ...] fp32, v [...] fp32 (updated in place) -> spikes. Mirrors the cupy-plugin contract
+    SJ/activation_based/neuron.py:954-966 (x_seq.flatten(1), v.flatten(0))."""
+    x_seq = _dev(x_seq, "x_seq", torch.float32)
+    v = _dev(v, "v", torch.float32)
+    T = x_seq.shape[0]
+    N = x_seq[0].numel()
+    if v.numel() != N:
+        raise ValueError(f"v has {v.numel()} elements, x_seq[0] has {N}")
+    if spike_dtype == SPIKE_F32:
+        out = torch.empty_like(x_seq)
+    elif spike_dtype == SPIKE_U8:
+        out = torch.empty(x_seq.shape, dtype=torch.uint8, device=x_seq.device)
+    elif spike_dtype == SPIKE_BITS:
+        out = torch.empty((T, (N + 63) // 64), dtype=torch.int64, device=x_seq.device)
+    else:
+        raise NotImplementedError(spike_dtype)
+    check(lib.spk_lif_fwd(_p(x_seq), _p(v), _p(out), T, N, float(tau), float(v_threshold), float(v_reset),
+                          spike_dtype, _stream(x_seq)), "spk_lif_fwd")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- stateless layers
+def bn_prepare(gamma, beta, mean, var, eps):
+    mean = _dev(mean, "running_mean", torch.float32)
+    var = _dev(var, "running_var", torch.float32)
+    C = mean.numel()
+    a = torch.empty(C, dtype=torch.float32, device=mean.device)
+    b = torch.empty_like(a)
+    g = None if gamma is None else _dev(gamma.detach(), "bn.weight", torch.float32)
+    be = None if beta is None else _dev(beta.detach(), "bn.bias", torch.float32)
+    check(lib.spk_bn_prepare(_p(g), _p(be), _p(mean), _p(var), float(eps), _p(a), _p(b), C, _stream(mean)),
+          "spk_bn_prepare")
+    return a, b
+
+
+def bn_eval(x, a, b):
+    """x [M, C, H, W] (or [M, C, HW]) fp32."""
+    x = _dev(x, "x", torch.float32)
+    M, C = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    y = torch.empty_like(x)
+    check(lib.spk_bn_eval_fwd(_p(x), _p(a), _p(b), _p(y), M, C, HW, _stream(x)), "spk_bn_eval_fwd")
+    return y
+
+
+def conv2d(x, w, bias, stride, pad):
+    x = _dev(x, "x", torch.float32)
+    w = _dev(w.detach(), "weight", torch.float32)
+    b = None if bias is None else _dev(bias.detach(), "bias", torch.float32)
+    M, Cin, H, W = x.shape
+    Cout, Cin_w, k, k2 = w.shape
+    if Cin_w != Cin or k != k2:
+        raise ValueError(f"weight {tuple(w.shape)} does not match input channels {Cin} / square kernels only")
+    Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+    y = torch.empty((M, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    check(lib.spk_conv2d_fwd(_p(x), _p(w), _p(b), _p(y), M, Cin, H, W, Cout, k, stride, pad, _stream(x)),
+          "spk_conv2d_fwd")
+    return y
+
+
+def conv_transpose2d(x, w, bias, stride, pad, out_pad):
+    x = _dev(x, "x", torch.float32)
+    w = _dev(w.detach(), "weight", torch.float32)
+    b = None if bias is None else _dev(bias.detach(), "bias", torch.float32)
+    M, Cin, H, W = x.shape
+    Cin_w, Cout, k, k2 = w.shape
+    if Cin_w != Cin or k != k2:
+        raise ValueError(f"weight {tuple(w.shape)} does not match input channels {Cin} / square kernels only")
+    Ho, Wo = conv_out_size(H, k, stride, pad, True, out_pad), conv_out_size(W, k, stride, pad, True, out_pad)
+    y = torch.empty((M, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    check(lib.spk_conv_transpose2d_fwd(_p(x), _p(w), _p(b), _p(y), M, Cin, H, W, Cout, k, stride, pad, out_pad,
+                                       _stream(x)), "spk_conv_transpose2d_fwd")
+    return y
+
+
+def memout(x_seq, coef):
+    x_seq = _dev(x_seq, "x_seq", torch.float32)
+    coef = _dev(coef, "coef", torch.float32)
+    T = x_seq.shape[0]
+    if coef.numel() != T:
+        raise RuntimeError(f"The size of tensor a ({T}) must match the size of tensor b ({coef.numel()}) at "
+                           "non-singleton dimension 0")      # what torch raises for x*coef in the reference
+    out = torch.empty(x_seq.shape[1:], dtype=torch.float32, device=x_seq.device)
+    check(lib.spk_memout_fwd(_p(x_seq), _p(coef), _p(out), T, out.numel(), _stream(x_seq)), "spk_memout_fwd")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- layouts
+def spikes_to_ptc(s):
+    """fp32 [T,B,C,H,W] -> u8 [B,H,W,T,C]."""
+    s = _dev(s, "spikes", torch.float32)
+    T, B, C, H, W = s.shape
+    o = torch.empty((B, H, W, T, C), dtype=torch.uint8, device=s.device)
+    check(lib.spk_spikes_to_ptc(_p(s), _p(o), T, B, C, H * W, _stream(s)), "spk_spikes_to_ptc")
+    return o
+
+
+def ptc_to_spikes(p):
+    """u8 [B,H,W,T,C] -> fp32 [T,B,C,H,W]."""
+    p = _dev(p, "ptc", torch.uint8)
+    B, H, W, T, C = p.shape
+    o = torch.empty((T, B, C, H, W), dtype=torch.float32, device=p.device)
+    check(lib.spk_ptc_to_spikes(_p(p), _p(o), T, B, C, H * W, _stream(p)), "spk_ptc_to_spikes")
+    return o
+
+
+# ---------------------------------------------------------------------------------------------- fused conv
+def pack_conv_weight(w, transposed):
+    w = _dev(w.detach(), "weight", torch.float32)
+    if transposed:
+        Cin, Cout, k, k2 = w.shape
+    else:
+        Cout, Cin, k, k2 = w.shape
+    if k != k2:
+        raise NotImplementedError("square kernels only")
+    out = torch.empty((k * k, Cin, Cout), dtype=torch.float32, device=w.device)
+    check(lib.spk_pack_conv_weight(_p(w), _p(out), Cout, Cin, k, int(transposed), _stream(w)), "spk_pack_conv_weight")
+    return out
+
+
+IN_PTC, IN_TINV, IN_SEQ = 0, 1, 2
+
+
+def conv_fused(in0, w_packed, bias, *, in_kind, T, mode, k, stride, pad, transposed=False, out_pad=0, in1=None,
+               bn_a=None, bn_b=None, v=None, want_ptc=False, want_f32=False, want_pre=False, want_u8=False,
+               coef=None, apply_tanh=False, out_ptc=None, out_f32=None):
+    """Launch spk_conv_fused_fwd. Returns dict(ptc=, f32=, pre=, u8=).
+
+    in_kind IN_PTC: in0 u8 [B,H,W,T,C0] (+ in1 [B,H,W,T,C1]);  IN_TINV: in0 fp32 [B,C0,H,W];
+    IN_SEQ: in0 fp32 [T,B,C0,H,W] (any values)."""
+    dev = in0.device
+    if in_kind == IN_PTC:
+        in0 = _dev(in0, "in0", torch.uint8)
+        B, H, W, T_in, C0 = in0.shape
+        if T_in != T:
+            raise ValueError("T mismatch")
+    elif in_kind == IN_TINV:
+        in0 = _dev(in0, "in0", torch.float32)
+        B, C0, H, W = in0.shape
+    else:
+        in0 = _dev(in0, "in0", torch.float32)
+        T_in, B, C0, H, W = in0.shape
+        if T_in != T:
+            raise ValueError("T mismatch")
+    if T > MAX_T:
+        raise NotImplementedError(f"fused kernels keep T <= {MAX_T} steps in registers, got T={T}")
+    C1 = 0
+    if in1 is not None:
+        in1 = _dev(in1, "in1", torch.uint8)
+        C1 = in1.shape[-1]
+    kk, Cin, Cout = w_packed.shape
+    if Cin != C0 + C1 or kk != k * k:
+        raise ValueError(f"packed weight {tuple(w_packed.shape)} does not match Cin={C0 + C1}, k={k}")
+    Ho, Wo = conv_out_size(H, k, stride, pad, transposed, out_pad), conv_out_size(W, k, stride, pad, transposed, out_pad)
+    res = {"ptc": None, "f32": None, "pre": None, "u8": None}
+    if mode == MODE_LIF:
+        if want_ptc:
+            res["ptc"] = out_ptc if out_ptc is not None else torch.empty((B, Ho, Wo, T, Cout), dtype=torch.uint8, device=dev)
+        if want_f32:
+            res["f32"] = out_f32 if out_f32 is not None else torch.empty((T, B, Cout, Ho, Wo), dtype=torch.float32, device=dev)
+        if want_pre:
+            shape = (B, Cout, Ho, Wo) if in_kind == IN_TINV else (T, B, Cout, Ho, Wo)
+            res["pre"] = torch.empty(shape, dtype=torch.float32, device=dev)
+    elif mode == MODE_RAW:
+        res["f32"] = out_f32 if out_f32 is not None else torch.empty((T, B, Cout, Ho, Wo), dtype=torch.float32, device=dev)
+    else:
+        res["f32"] = out_f32 if out_f32 is not None else torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=dev)
+        if want_u8:
+            res["u8"] = torch.empty((B, Cout, Ho, Wo), dtype=torch.uint8, device=dev)
+    if v is not None:
+        v = _dev(v, "v", torch.float32)
+        if v.numel() != B * Cout * Ho * Wo:
+            raise ValueError("membrane potential tensor has the wrong size")
+    check(lib.spk_conv_fused_fwd(
+        _p(in0), _p(in1), C0, C1, in_kind, _p(w_packed), _p(bias), _p(bn_a), _p(bn_b), _p(v), _p(res["ptc"]),
+        _p(res["f32"]), _p(res["pre"]), _p(res["u8"]), _p(coef), int(apply_tanh), mode, T, B, H, W, Cout, k, stride,
+        pad, int(transposed), out_pad, _stream(in0)), "spk_conv_fused_fwd")
+    return res
+
+
+# ---------------------------------------------------------------------------------------------- VQ
+def vq_readout_argmin(z_ptc, coef, alpha, codebook, want_zq=True, want_xm=False):
+    z_ptc = _dev(z_ptc, "z_ptc", torch.uint8)
+    B, H, W, T, D = z_ptc.shape
+    codebook = _dev(codebook.detach(), "codebook", torch.float32)
+    K = codebook.shape[0]
+    coef = _dev(coef, "coef", torch.float32)
+    if coef.numel() != T:
+        raise RuntimeError(f"The size of tensor a ({T}) must match the size of tensor b ({coef.numel()}) at "
+                           "non-singleton dimension 0")
+    alpha = _dev(alpha.detach().reshape(1), "alpha", torch.float32)
+    idx = torch.empty(B * H * W, dtype=torch.int64, device=z_ptc.device)
+    zq = torch.empty((B, D, H, W), dtype=torch.float32, device=z_ptc.device) if want_zq else None
+    xm = torch.empty((B * H * W, D), dtype=torch.float32, device=z_ptc.device) if want_xm else None
+    check(lib.spk_vq_readout_argmin(_p(z_ptc), _p(coef), _p(alpha), _p(codebook), _p(idx), _p(zq), _p(xm), T, B, D,
+                                    H * W, K, _stream(z_ptc)), "spk_vq_readout_argmin")
+    return idx, zq, xm
+
+
+def vq_argmin(flat_x, codebook):
+    flat_x = _dev(flat_x, "flat_x", torch.float32)
+    codebook = _dev(codebook.detach(), "codebook", torch.float32)
+    N, D = flat_x.shape
+    idx = torch.empty(N, dtype=torch.int64, device=flat_x.device)
+    check(lib.spk_vq_argmin(_p(flat_x), _p(codebook), _p(idx), N, D, codebook.shape[0], _stream(flat_x)),
+          "spk_vq_argmin")
+    return idx
+
+
+def embedding(tokens, codebook, nchw_hw=None):
+    """nn.Embedding lookup; nchw_hw=(h,w) writes [B,D,h,w] for tokens [B,h,w]."""
+    tokens = _dev(tokens, "tokens", torch.int64)
+    codebook = _dev(codebook.detach(), "codebook", torch.float32)
+    K, D = codebook.shape
+    N = tokens.numel()
+    if nchw_hw is None:
+        out = torch.empty(tuple(tokens.shape) + (D,), dtype=torch.float32, device=tokens.device)
+        HW, nchw = 1, 0
+    else:
+        h, w = nchw_hw
+        HW, nchw = h * w, 1
+        out = torch.empty((N // HW, D, h, w), dtype=torch.float32, device=tokens.device)
+    check(lib.spk_embedding_fwd(_p(tokens), _p(codebook), _p(out), N, D, K, HW, nchw, _stream(tokens)),
+          "spk_embedding_fwd")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- sampler
+def den_build_input(x, t, out=None):
+    """x: float [B,1,h,w] or int64 tokens; t: int64 [B] tensor or python int -> fp32 [B,2,h,w]."""
+    xf = xi = None
+    if x.dtype == torch.int64:
+        xi = _dev(x, "x_t", torch.int64)
+    else:
+        xf = _dev(x, "x", torch.float32)
+    B = x.shape[0]
+    HW = x[0].numel()
+    h, w = x.shape[-2], x.shape[-1]
+    if out is None:
+        out = torch.empty((B, 2, h, w), dtype=torch.float32, device=x.device)
+    tv, ts = None, 0
+    if torch.is_tensor(t):
+        tv = _dev(t, "t", torch.int64)
+        if tv.numel() != B:
+            raise ValueError("t must have one entry per sample")
+    else:
+        ts = int(t)
+    check(lib.spk_den_build_input(_p(xf), _p(xi), _p(tv), ts, _p(out), B, HW, _stream(x)), "spk_den_build_input")
+    return out
+
+
+def psample_step(logits, x_t, unmasked, t, temp=1.0, u=None, q=None, seed=0, offset=0, x0_hat=None):
+    """In-place update of x_t (int64) and unmasked (bool/u8) from logits [B,K,h,w]."""
+    logits = _dev(logits, "logits", torch.float32)
+    B, K = logits.shape[0], logits.shape[1]
+    HW = logits[0, 0].numel()
+    if x_t.dtype != torch.int64 or not x_t.is_cuda or not x_t.is_contiguous():
+        raise ValueError("x_t must be a contiguous int64 device tensor (updated in place)")
+    if unmasked.dtype not in (torch.bool, torch.uint8) or not unmasked.is_contiguous():
+        raise ValueError("unmasked must be a contiguous bool/uint8 device tensor (updated in place)")
+    if x_t.numel() != B * HW or unmasked.numel() != B * HW:
+        raise ValueError("x_t / unmasked size mismatch")
+    if u is not None:
+        u = _dev(u, "u", torch.float32)
+    if q is not None:
+        q = _dev(q, "q", torch.float32)
+        if q.numel() != B * HW * K:
+            raise ValueError("q must have B*HW*K entries")
+    check(lib.spk_psample_step(_p(logits), _p(x_t), _p(unmasked), int(t), float(temp), _p(u), _p(q), int(seed),
+                               int(offset), _p(x0_hat), B, HW, K, _stream(logits)), "spk_psample_step")
+    return x_t, unmasked
