@@ -279,13 +279,14 @@ def test_f3_encode_decode_end_to_end(golden_dir, dev, tag, cfg):
             margin = torch.minimum(margin, (h - 1).abs().flatten(1).min(1).values)
             s = (h >= 1).float()
             v = (1 - s) * h
-    clean = margin > 2e-5
+    clean = margin > 3e-6
     same_idx = (got_idx == want_idx).all(1)
     err = (xr.cpu() - want_xr).abs().flatten(1).max(1).values
-    print(f"F3 {tag}: {int(clean.sum())}/{B} clean images; index-exact {int(same_idx.sum())}/{B}; "
-          f"max recon err over index-exact images {float(err[same_idx].max()):.2e}; min margin {float(margin.min()):.2e}")
+    print(f"F3 {tag}: {int(clean.sum())}/{B} clean images (margin > 3e-6); index-exact {int(same_idx.sum())}/{B}; "
+          f"pixels within 1e-4 on {int((err <= 1e-4).sum())}/{B}; max recon err {float(err.max()):.2e}; "
+          f"per-image margins {[f'{m:.1e}' for m in margin.tolist()]}")
     assert bool(same_idx[clean].all()), "code indices must be bit-exact on every clean image"
-    assert float(err[clean].max()) <= 1e-4, "decoded pixels must be within 1e-4 on every clean image"
+    assert bool((err[clean] <= 1e-4).all()), "decoded pixels must be within 1e-4 on every clean image"
     assert int(same_idx.sum()) >= B - 2 and int((err <= 1e-4).sum()) >= B - 2
     # the time-invariant fast path (repeat folded into the kernel) gives the same indices as the module call
     with torch.inference_mode():
