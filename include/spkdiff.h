@@ -72,8 +72,12 @@ int spk_conv_transpose2d_fwd(const float* x, const float* w, const float* bias, 
 int spk_memout_fwd(const float* x_seq, const float* coef, float* out, int T, long long N, spk_stream_t stream);
 
 /* ---- layout converters --------------------------------------------------------------------------------------- */
-int spk_spikes_to_ptc(const float* spikes_tbchw, uint8_t* out_bhwtc, int T, int B, int C, int HW, spk_stream_t stream);
-int spk_ptc_to_spikes(const uint8_t* in_bhwtc, float* spikes_tbchw, int T, int B, int C, int HW, spk_stream_t stream);
+/* chunk = C gives plain PTC [B,HW,T,C]; chunk = 32 gives the channel-chunked "CPTC" [B,C/32,HW,T,32] the MFMA
+ * kernel reads (one contiguous slab per image and 32-channel K chunk). */
+int spk_spikes_to_ptc(const float* spikes_tbchw, uint8_t* out_bhwtc, int T, int B, int C, int HW, int chunk,
+                      spk_stream_t stream);
+int spk_ptc_to_spikes(const uint8_t* in_bhwtc, float* spikes_tbchw, int T, int B, int C, int HW, int chunk,
+                      spk_stream_t stream);
 
 /* ---- fused (Conv|ConvT) [+BN+LIF] --------------------------------------------------------------------------- */
 int spk_conv_out_size(int in, int k, int stride, int pad, int transposed, int out_pad);
@@ -87,12 +91,29 @@ int spk_pack_conv_weight(const float* w, float* packed, int Cout, int Cin, int k
  *   mode LIF:    bn_a/bn_b required; v_inout [B,Cout,Ho,Wo] or NULL (fresh state, not written back);
  *                out_ptc u8 PTC and/or out_f32 fp32 TBCHW spikes; out_pre optional BN output.
  *   mode RAW:    out_f32 TBCHW conv output.    mode MEMOUT: coef [T]; out_f32 [B,Cout,Ho,Wo] (tanh if apply_tanh),
- *                out_u8 = uint8(clip(p+0.5,0,1)*255) (R/main.py:401).   mode MEAN: out_f32 = sum_t x[t] / T. */
+ *                out_u8 = uint8(clip(p+0.5,0,1)*255) (R/main.py:401).   mode MEAN: out_f32 = sum_t x[t] / T.
+ *   chunk0 / chunk1 / chunk_out: channel chunking of in0 / in1 / out_ptc (<= 0: plain PTC). */
 int spk_conv_fused_fwd(const void* in0, const uint8_t* in1, int C0, int C1, int in_kind, const float* w_packed,
                        const float* bias, const float* bn_a, const float* bn_b, float* v_inout, uint8_t* out_ptc,
                        float* out_f32, float* out_pre, uint8_t* out_u8, const float* coef, int apply_tanh, int mode,
                        int T, int B, int H, int W, int Cout, int k, int stride, int pad, int transposed, int out_pad,
-                       spk_stream_t stream);
+                       int chunk0, int chunk1, int chunk_out, spk_stream_t stream);
+
+/* ---- denoiser convolutions on the matrix cores ------------------------------------------------------------------ */
+/* Bytes of the packed int8 digit-plane weights of one 3x3 layer ([Cout/16][Cin/32][9][2][32][32]); -1 if unsupported. */
+long long spk_den_packed_weight_bytes(int Cout, int Cin);
+/* fp32 conv weight [Cout,Cin,3,3] (+bias) -> four balanced base-256 int8 digit planes + per-channel 2^-s scale and
+ * fp64 bias.  One-time weight preparation for spk_den_conv3x3_mfma. */
+int spk_den_pack_weight_i8(const float* w, const float* bias, int8_t* wq, double* scale, double* bias_d, int Cout,
+                           int Cin, spk_stream_t stream);
+/* 3x3 / stride 1 / pad 1 convolution over binary spikes (CPTC u8, T = 16) + BN + LIF (mode SPK_MODE_LIF -> out_cptc)
+ * or + time mean (mode SPK_MODE_MEAN -> out_f32 [B,Cout,h,w]): DummyModel conv2..conv6,
+ * R/snn_model/vq_diffusion.py:166-187,201-206.  in1 (nch1 chunks) is concatenated after in0 along channels.
+ * v_inout [B,Cout,h,w] or NULL (fresh LIF state, nothing written back). */
+int spk_den_conv3x3_mfma(const uint8_t* in0_cptc, int nch0, const uint8_t* in1_cptc, int nch1, const int8_t* wq,
+                         const double* scale, const double* bias_d, const float* bn_a, const float* bn_b,
+                         float* v_inout, uint8_t* out_cptc, float* out_f32, int mode, int T, int B, int H, int W,
+                         int Cout, spk_stream_t stream);
 
 /* ---- vector quantizer ----------------------------------------------------------------------------------------- */
 /* VectorQuantizer.forward eval up to the codebook gather, R/snn_model/vae_model.py:40-52,87-99.

@@ -100,6 +100,7 @@ struct FusedArgs {
   const float* coef;    // MODE_MEMOUT: [T]
   int apply_tanh;
   int T, B, H, W, Cout, Ho, Wo, k, stride, pad;
+  int chunk0, chunk1, chunk_out;   // channel chunking of the PTC tensors ([B][C/chunk][HW][T][chunk]); chunk == C: plain
 };
 
 template <int INKIND, bool TRANSPOSED, int MODE>
@@ -157,19 +158,22 @@ __global__ __launch_bounds__(256) void conv_fused_kernel(FusedArgs a) {
               if (t < T) acc[t] += (double)xp[t * ts + ci * chw] * wv;
           }
         } else {
-          const long long pos = ((long long)b * a.H + iy) * a.W + ix;
+          const int ipos = iy * a.W + ix, HWi = a.H * a.W;
           for (int src = 0; src < 2; ++src) {
             const int Cs = src ? a.C1 : a.C0;
             if (Cs == 0) continue;
-            const uint8_t* sp = (src ? a.in1 : reinterpret_cast<const uint8_t*>(a.in0)) + pos * T * Cs;
+            const int chk = src ? a.chunk1 : a.chunk0;
+            const uint8_t* sbase = (src ? a.in1 : reinterpret_cast<const uint8_t*>(a.in0)) + (long long)b * HWi * T * Cs;
             const float* wsrc = wp + (src ? (long long)a.C0 * a.Cout : 0);
             for (int ci = 0; ci < Cs; ci += 4) {
+              // [C/chunk][HW][T][chunk]: 4 consecutive channels never straddle a chunk (chunk % 4 == 0)
+              const uint8_t* sp = sbase + ((long long)(ci / chk) * HWi + ipos) * T * chk + (ci % chk);
               const float w0 = wsrc[(long long)(ci + 0) * a.Cout], w1 = wsrc[(long long)(ci + 1) * a.Cout];
               const float w2 = wsrc[(long long)(ci + 2) * a.Cout], w3 = wsrc[(long long)(ci + 3) * a.Cout];
 #pragma unroll
               for (int t = 0; t < SPK_MAX_T; ++t) {
                 if (t < T) {
-                  const uint32_t s4 = *reinterpret_cast<const uint32_t*>(sp + t * Cs + ci);
+                  const uint32_t s4 = *reinterpret_cast<const uint32_t*>(sp + t * chk);
                   if (s4) {
                     // exact: the selected weights are added in fp64
                     acc[t] += (s4 & 0x000000ffu) ? (double)w0 : 0.0;
@@ -197,7 +201,8 @@ __global__ __launch_bounds__(256) void conv_fused_kernel(FusedArgs a) {
         y0 = fmaf((float)acc[0], al, be);
         if (a.out_pre) a.out_pre[o_bchw] = y0;
       }
-      const long long o_ptc = ((((long long)b * a.Ho + oy) * a.Wo + ox) * T) * a.Cout + co;
+      const long long o_ptc = ((((long long)b * (a.Cout / a.chunk_out) + co / a.chunk_out) * plane + oy * a.Wo + ox) * T) *
+                                  a.chunk_out + co % a.chunk_out;
 #pragma unroll
       for (int t = 0; t < SPK_MAX_T; ++t) {
         if (t < T) {
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(256) void conv_fused_kernel(FusedArgs a) {
             if (a.out_pre) a.out_pre[o_bchw + t * tstride] = y;
           }
           const bool s = spk_lif_step_default(v, y);
-          if (a.out_ptc) a.out_ptc[o_ptc + (long long)t * a.Cout] = (uint8_t)s;
+          if (a.out_ptc) a.out_ptc[o_ptc + (long long)t * a.chunk_out] = (uint8_t)s;
           if (a.out_f32) a.out_f32[o_bchw + t * tstride] = s ? 1.0f : 0.0f;
         }
       }
@@ -305,12 +310,19 @@ extern "C" int spk_conv_fused_fwd(const void* in0, const uint8_t* in1, int C0, i
                                   const float* w_packed, const float* bias, const float* bn_a, const float* bn_b,
                                   float* v_inout, uint8_t* out_ptc, float* out_f32, float* out_pre, uint8_t* out_u8,
                                   const float* coef, int apply_tanh, int mode, int T, int B, int H, int W, int Cout,
-                                  int k, int stride, int pad, int transposed, int out_pad, hipStream_t stream) {
+                                  int k, int stride, int pad, int transposed, int out_pad, int chunk0, int chunk1,
+                                  int chunk_out, hipStream_t stream) {
   if (!in0 || !w_packed || T <= 0 || T > SPK_MAX_T || B <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0 || k <= 0 ||
       stride <= 0 || pad < 0)
     return SPK_ERR_ARG;
   if (in_kind < 0 || in_kind > 2) return SPK_ERR_ARG;
   if (in_kind == SPK_IN_PTC && ((C0 % 4) || (C1 % 4))) return SPK_ERR_UNSUPPORTED;   // u32 spike loads
+  if (chunk0 <= 0) chunk0 = C0;
+  if (chunk1 <= 0) chunk1 = C1 > 0 ? C1 : 4;
+  if (chunk_out <= 0) chunk_out = Cout;
+  if (in_kind == SPK_IN_PTC && ((chunk0 % 4) || (C0 % chunk0) || (C1 > 0 && ((chunk1 % 4) || (C1 % chunk1)))))
+    return SPK_ERR_ARG;
+  if (Cout % chunk_out) return SPK_ERR_ARG;
   if (in_kind != SPK_IN_PTC && C1 != 0) return SPK_ERR_UNSUPPORTED;
   if (in_kind == SPK_IN_TINV && transposed) return SPK_ERR_UNSUPPORTED;
   if (C1 > 0 && !in1) return SPK_ERR_ARG;
@@ -320,6 +332,7 @@ extern "C" int spk_conv_fused_fwd(const void* in0, const uint8_t* in1, int C0, i
   FusedArgs a;
   a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.wt = w_packed; a.bias = bias; a.bn_a = bn_a; a.bn_b = bn_b;
   a.v_io = v_inout; a.out_ptc = out_ptc; a.out_f32 = out_f32; a.out_pre = out_pre; a.out_u8 = out_u8; a.coef = coef;
+  a.chunk0 = chunk0; a.chunk1 = chunk1; a.chunk_out = chunk_out;
   a.apply_tanh = apply_tanh; a.T = T; a.B = B; a.H = H; a.W = W; a.Cout = Cout;
   a.Ho = spk_conv_out_size(H, k, stride, pad, transposed, out_pad);
   a.Wo = spk_conv_out_size(W, k, stride, pad, transposed, out_pad);

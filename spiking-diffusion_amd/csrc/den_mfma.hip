@@ -1,0 +1,336 @@
+// 3x3 convolution over binary spike tensors on the MI355X matrix cores, with the BN + LIF scan (or the time-mean
+// read-out) fused into the accumulator epilogue.  This is the denoiser's conv2..conv6
+// (R/snn_model/vq_diffusion.py:166-187,201-206): >99.9 % of the sampling FLOPs.
+//
+// EXACT INTEGER FORMULATION.  The A operand is spikes (0/1, exact in int8).  Each fp32 weight is re-encoded once
+// (spk_den_pack_weight_i8) as a 30-bit fixed-point number relative to its output channel's largest magnitude and
+// split into four balanced base-256 digits D0..D3 in [-128,127]:  w_q = 2^-s * sum_d D_d * 256^(3-d).  Weights within
+// 2^7 of the channel maximum are represented exactly (w_q == w); smaller ones are rounded at 2^-30 of that maximum
+// (orders of magnitude below one fp32 ulp of any sum they take part in).  The four digit planes are four int8 GEMMs
+// sharing the A operand, accumulated EXACTLY in int32 by v_mfma_i32_32x32x32_i8 (2x the bf16 MFMA rate), recombined
+// exactly in fp64 and rounded ONCE to fp32: the pre-activation is the correctly rounded value of sum(w_q) + bias --
+// independent of accumulation order and bit-reproducible.
+//
+// MAPPING.  GEMM rows = (position, time step), columns = output channels x digit planes, K = 9 taps x Cin.
+//   * A work item = one image x 16 output channels.  The kernel is PERSISTENT: one workgroup (4 waves, one per
+//     SIMD, 512 registers each) per CU walks items image-major, so consecutive items reuse the image from L2.
+//     All accumulators of an item stay in registers over the whole K loop (7 row tiles x 2 column tiles x 16).
+//   * A 32x32 row tile = 2 latent positions x 16 time steps, ordered so that lane-half h of the accumulator holds
+//     position h with t = register index: the LIF scan over T is a 16-step in-register loop, no cross-lane traffic.
+//   * A 32-wide column tile = 16 channels x 2 digit planes (digit parity = lane bit 4); v_permlane16_swap hands each
+//     partner lane both digits of 8 of the 16 time steps, they recombine in fp64 and swap the fp32 results.
+//   * Spikes are stored channel-chunked ("CPTC": [B][C/32][HW][T][32] u8) so that the 32-channel slab of one image
+//     needed per K chunk is ONE contiguous 25 KB block.  It is copied by LDS-DMA (global_load_lds_dwordx4, no
+//     staging registers) into a zero-bordered LDS image [(H+2)(W+2)][T][32]; all 9 taps read it with a constant
+//     address offset (no im2col, no 9x re-fetch).  Packed weights are laid out exactly in LDS order (18 KB linear).
+//   * LDS is double buffered: the DMA of chunk i+1 (also across item boundaries) is in flight while the 126 MFMAs
+//     per wave of chunk i run, and the epilogue of an item overlaps the first DMA of the next one.  One barrier per
+//     chunk.  LDS fragment reads are software pipelined two fragments ahead of the MFMA that consumes them.
+//   * LDS images are XOR-swizzled at 16-B granularity (A: by t >= 8 through the DMA source lane; W: by column >= 16,
+//     baked into the packed weights) so that every ds_read_b128 of a fragment is bank-conflict free.
+//   * Spike emission: one wave ballot per time step gathers the 16 channels of both positions; lane t expands its
+//     16 bits to 16 bytes and writes ONE 16-byte store per (position, time step).
+#include "spk_common.h"
+#include "../../include/spkdiff.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+constexpr int T16 = 16;
+constexpr int CK = 32;                           // channels per K chunk
+constexpr int POS_BYTES = T16 * CK;              // 512 B per latent position per chunk
+constexpr int W_CHUNK_BYTES = 9 * 2 * 32 * CK;   // 18432 B per (channel group, chunk)
+constexpr int W_PIECES = W_CHUNK_BYTES / 1024;   // 18 one-KiB DMA pieces
+
+struct MfmaArgs {
+  const uint8_t* in0; const uint8_t* in1; int nch0, nch1;
+  const int8_t* wq; const double* scale; const double* bias; const float* bn_a; const float* bn_b;
+  uint8_t* out; float* out_f32; float* v_io;
+  int B, H, W, Cout, mode;
+};
+
+#define SPK_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+#define SPK_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// NT = row tiles per wave (7 for 7x7 latents, 8 for 8x8).
+template <int NT, int MODE>
+__global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int HW = a.H * a.W, PW = a.W + 2;
+  const int npp = (a.H + 2) * PW;
+  const int A_BYTES = npp * POS_BYTES;
+  // LDS: [A buf0][A buf1][W buf0][W buf1]
+  uint8_t* const sA = lds;
+  uint8_t* const sW = lds + 2 * A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nchunks = a.nch0 + a.nch1;
+  const int G = a.Cout >> 4;
+  const int total = a.B * G;
+
+  // zero both A images once: the borders stay zero for the whole kernel, interiors are overwritten by DMA
+  for (int i = tid; i < 2 * A_BYTES / 16; i += 256) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
+
+  // per-lane LDS byte offsets of this wave's A fragments (tile ti = wave + 4*i); absent tiles read the zero border
+  const int row = lane & 31, half = lane >> 5;
+  const int hsel = (row >> 2) & 1, tt = (row & 3) + 4 * (row >> 3);
+  int a_off[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int p = 2 * (wave + 4 * i) + hsel;
+    const int pp = p < HW ? (p / a.W + 1) * PW + (p % a.W) + 1 : 0;
+    a_off[i] = pp * POS_BYTES + tt * CK + 16 * (half ^ (tt >> 3));   // 16-B halves swapped for t >= 8: bank-conflict-free
+  }
+  const int b_off = (lane & 31) * CK + 16 * (half ^ ((lane >> 4) & 1));   // same swizzle, baked into the packed weights
+
+  // DMA piece table: A slab = H image rows x ceil(W/2) pieces of 2 positions (1 KiB); W slab = 18 pieces
+  const int pprow = (a.W + 1) >> 1;
+  const int nA = a.H * pprow;
+  const int npieces = nA + W_PIECES;
+
+  auto issue_dma = [&](int item, int c, int buf) {
+    const int b = item / G, g = item - b * G;
+    const uint8_t* aslab = c < a.nch0 ? a.in0 + ((long long)b * a.nch0 + c) * HW * POS_BYTES
+                                      : a.in1 + ((long long)b * a.nch1 + (c - a.nch0)) * HW * POS_BYTES;
+    const int8_t* wslab = a.wq + ((long long)g * nchunks + c) * W_CHUNK_BYTES;
+    uint8_t* dA = sA + buf * A_BYTES;
+    uint8_t* dW = sW + buf * W_CHUNK_BYTES;
+    for (int id = wave; id < npieces; id += 4) {               // wave-uniform
+      if (id < nA) {
+        const int y = id / pprow, px = id - y * pprow;
+        const int p0 = y * a.W + 2 * px;
+        const bool second_ok = 2 * px + 1 < a.W;
+        if (lane < 32 || second_ok)
+          __builtin_amdgcn_global_load_lds(SPK_GLB(aslab + (long long)p0 * POS_BYTES + (lane ^ ((lane >> 4) & 1)) * 16),
+                                           SPK_LDS(dA + ((y + 1) * PW + 1 + 2 * px) * POS_BYTES), 16, 0, 0);
+      } else {
+        const int k = id - nA;
+        __builtin_amdgcn_global_load_lds(SPK_GLB(wslab + k * 1024 + lane * 16), SPK_LDS(dW + k * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  const int col = lane & 31, ch = col & 15, odd = col >> 4;
+
+  int it = 0;                                      // running chunk counter: LDS buffer = it & 1
+  if ((int)blockIdx.x < total) issue_dma(blockIdx.x, 0, 0);
+  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    v16i acc[NT][2];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0; acc[i][1][r] = 0; }
+    }
+    // epilogue constants of this item's channel: loaded now, their latency hides under the K loop
+    const int b = item / G, g = item - b * G;
+    const int co = g * 16 + ch;
+    const double sc = a.scale[co], bi = a.bias[co];
+    float bn_a = 1.f, bn_b = 0.f;
+    if (MODE == SPK_MODE_LIF) { bn_a = a.bn_a[co]; bn_b = a.bn_b[co]; }
+    for (int c = 0; c < nchunks; ++c, ++it) {
+    const int buf = it & 1;
+    __syncthreads();     // vmcnt(0) + barrier: this chunk's DMA has landed; everyone is done with the other buffer
+    {
+      int nitem = item, nc = c + 1;
+      if (nc == nchunks) { nc = 0; nitem = item + gridDim.x; }
+      if (nitem < total) issue_dma(nitem, nc, buf ^ 1);
+    }
+
+    // ---------------- 9 taps x NT row tiles x 2 column tiles, fragments read two steps ahead -------------------
+    {
+      const uint8_t* A = sA + buf * A_BYTES;
+      const uint8_t* Wb = sW + buf * W_CHUNK_BYTES + b_off;
+      auto lda = [&](int s) -> v4i {
+        const int tap = s / NT, i = s % NT;
+        const int toff = ((tap / 3 - 1) * PW + (tap % 3 - 1)) * POS_BYTES;
+        return *reinterpret_cast<const v4i*>(A + a_off[i] + toff);
+      };
+      v4i bc0 = *reinterpret_cast<const v4i*>(Wb), bc1 = *reinterpret_cast<const v4i*>(Wb + 32 * CK);
+      v4i bn0 = bc0, bn1 = bc1;
+      constexpr int PF = 4;                      // A fragments in flight ahead of the MFMA that consumes them
+      v4i af[PF];
+#pragma unroll
+      for (int s = 0; s < PF; ++s) af[s] = lda(s);
+#pragma unroll
+      for (int s = 0; s < 9 * NT; ++s) {
+        const int tap = s / NT, i = s % NT;
+        const v4i av = af[s % PF];
+        if (s + PF < 9 * NT) af[s % PF] = lda(s + PF);
+        if (i == 0 && tap + 1 < 9) {
+          bn0 = *reinterpret_cast<const v4i*>(Wb + ((tap + 1) * 2 + 0) * 32 * CK);
+          bn1 = *reinterpret_cast<const v4i*>(Wb + ((tap + 1) * 2 + 1) * 32 * CK);
+        }
+        acc[i][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bc0, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bc1, acc[i][1], 0, 0, 0);
+        if (i == NT - 1) { bc0 = bn0; bc1 = bn1; }
+        __builtin_amdgcn_sched_barrier(0);     // keep the read-ahead distance: hipcc otherwise sinks every ds_read
+      }                                         // to just before its MFMA (one exposed LDS latency per tile)
+    }
+
+    }   // chunks
+    {
+      // ---------------- epilogue: exact recombination, BN, LIF scan over the 16 accumulator registers ----------
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int ti = wave + 4 * i;
+        const int p = 2 * ti + half;                  // accumulator lane-half == position within the tile
+        const bool pos_ok = p < HW;
+        // partner lanes (col, col^16) hold digit planes {0,2} and {1,3} of the same channel: each recombines 8 of
+        // the 16 time steps in fp64 (even lane t = 0..7, odd lane t = 8..15), then they swap the fp32 results
+        float x[16];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          // v_permlane16_swap(A, B): A' = {even row: A.even, odd row: B.even}, B' = {even row: A.odd, odd row: B.odd}
+          // with A = acc[.][r] (t = r) and B = acc[.][r + 8]: every lane ends up with both digits of ITS time step
+          const v2u p01 = __builtin_amdgcn_permlane16_swap((unsigned)acc[i][0][r], (unsigned)acc[i][0][r + 8], false, false);
+          const v2u p23 = __builtin_amdgcn_permlane16_swap((unsigned)acc[i][1][r], (unsigned)acc[i][1][r + 8], false, false);
+          const int hi = (int)p01[0] * 256 + (int)p01[1], lo = (int)p23[0] * 256 + (int)p23[1];
+          const double s = fma((double)hi, 65536.0, (double)lo);        // exact
+          const float xm = (float)fma(s, sc, bi);                        // the one rounding to fp32 (s*sc is exact)
+          const v2u xx = __builtin_amdgcn_permlane16_swap(__float_as_uint(xm), __float_as_uint(xm), false, false);
+          x[r] = __uint_as_float(xx[0]);                                 // t = r     (computed by the even lane)
+          x[r + 8] = __uint_as_float(xx[1]);                             // t = r + 8 (computed by the odd lane)
+        }
+        if (MODE == SPK_MODE_LIF) {
+          const long long vidx = ((long long)b * a.Cout + co) * HW + (pos_ok ? p : 0);
+          float v = a.v_io ? a.v_io[vidx] : 0.f;
+          unsigned long long mine = 0;                 // lane t keeps the ballot of time step t
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool s = spk_lif_step_default(v, fmaf(x[r], bn_a, bn_b)) && !odd && pos_ok;
+            const unsigned long long m = __ballot(s);  // bits 0..15: channels of position 0, bits 32..47: position 1
+            if ((lane & 15) == r) mine = m;
+          }
+          if (a.v_io && !odd && pos_ok) a.v_io[vidx] = v;
+          // lanes 0..15 write position 0 (t = lane), lanes 16..31 position 1 (t = lane - 16): 16 channels = 16 bytes
+          const int wp = 2 * ti + (lane >> 4);
+          if (lane < 32 && wp < HW) {
+            const uint32_t bits = (uint32_t)((lane & 16) ? (mine >> 32) : mine) & 0xffffu;
+            uint4 o;
+            o.x = ((bits & 0xfu) * 0x00204081u) & 0x01010101u;
+            o.y = (((bits >> 4) & 0xfu) * 0x00204081u) & 0x01010101u;
+            o.z = (((bits >> 8) & 0xfu) * 0x00204081u) & 0x01010101u;
+            o.w = (((bits >> 12) & 0xfu) * 0x00204081u) & 0x01010101u;
+            const int co0 = g * 16;
+            uint8_t* dst = a.out + ((((long long)b * (a.Cout >> 5) + (co0 >> 5)) * HW + wp) * T16 + (lane & 15)) * CK +
+                           (co0 & 31);
+            *reinterpret_cast<uint4*>(dst) = o;
+          }
+        } else {
+          float msum = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) msum = msum + x[r];                // torch.sum(x6, dim=0), t order
+          if (!odd && pos_ok) a.out_f32[((long long)b * a.Cout + co) * HW + p] = msum / 16.0f;
+        }
+        __builtin_amdgcn_sched_barrier(0);          // keep the tiles' epilogues from being interleaved (VGPR pressure)
+      }
+    }
+  }   // items
+}
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// one block per output channel: channel maximum -> shift s, then every weight -> 4 balanced base-256 digits
+__global__ __launch_bounds__(256) void pack_i8_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                      int8_t* __restrict__ wq, double* __restrict__ scale,
+                                                      double* __restrict__ bias_d, int Cout, int Cin) {
+  __shared__ float smax[256];
+  const int co = blockIdx.x, n = Cin * 9;
+  const float* wc = w + (long long)co * n;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(wc[i]));
+  smax[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s]);
+    __syncthreads();
+  }
+  m = smax[0];
+  int e = 0;
+  if (m > 0.f) frexpf(m, &e);                 // m = f * 2^e, f in [0.5, 1)  ->  m < 2^e
+  const int sh = 30 - e;                      // |w| * 2^sh < 2^30
+  if (threadIdx.x == 0) { scale[co] = ldexp(1.0, -sh); bias_d[co] = bias ? (double)bias[co] : 0.0; }
+  const int nchunks = Cin / CK, g = co >> 4, ch = co & 15;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int ci = i / 9, tap = i % 9;
+    long long q = (long long)rint(ldexp((double)wc[i], sh));
+    int dg[4];
+#pragma unroll
+    for (int d = 3; d >= 0; --d) {
+      int r = (int)(((q + 128) & 255) - 128);
+      dg[d] = r;
+      q = (q - r) >> 8;
+    }
+    const int c = ci / CK, k = ci % CK;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int ct = d >> 1, colw = (d & 1) * 16 + ch;
+      wq[((((long long)(g * nchunks + c) * 9 + tap) * 2 + ct) * 32 + colw) * CK + (k ^ (colw & 16))] = (int8_t)dg[d];
+    }
+  }
+}
+
+template <int MODE>
+int launch(const MfmaArgs& a, hipStream_t stream) {
+  const int HW = a.H * a.W;
+  const int ntiles = (HW + 1) / 2;
+  const int nt = (ntiles + 3) / 4;
+  const size_t lds = 2 * ((size_t)(a.H + 2) * (a.W + 2) * POS_BYTES + W_CHUNK_BYTES);
+  if (lds > 160 * 1024) return SPK_ERR_UNSUPPORTED;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  const int total = a.B * (a.Cout / 16);
+  dim3 grid(total < cus ? total : cus), blk(256);          // persistent: one workgroup per CU
+  if (nt <= 7) {
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<7, MODE>), grid, blk, lds, stream, a);
+  } else if (nt <= 8) {
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<8, MODE>), grid, blk, lds, stream, a);
+  } else {
+    return SPK_ERR_UNSUPPORTED;
+  }
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+}  // namespace
+
+extern "C" long long spk_den_packed_weight_bytes(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0 || (Cout % 16) || (Cin % CK)) return -1;
+  return (long long)(Cout / 16) * (Cin / CK) * W_CHUNK_BYTES;
+}
+
+extern "C" int spk_den_pack_weight_i8(const float* w, const float* bias, int8_t* wq, double* scale, double* bias_d,
+                                      int Cout, int Cin, hipStream_t stream) {
+  if (!w || !wq || !scale || !bias_d || Cout <= 0 || Cin <= 0) return SPK_ERR_ARG;
+  if ((Cout % 16) || (Cin % CK)) return SPK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(pack_i8_kernel, dim3(Cout), dim3(256), 0, stream, w, bias, wq, scale, bias_d, Cout, Cin);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_den_conv3x3_mfma(const uint8_t* in0_cptc, int nch0, const uint8_t* in1_cptc, int nch1,
+                                    const int8_t* wq, const double* scale, const double* bias_d, const float* bn_a,
+                                    const float* bn_b, float* v_inout, uint8_t* out_cptc, float* out_f32, int mode,
+                                    int T, int B, int H, int W, int Cout, hipStream_t stream) {
+  if (!in0_cptc || nch0 <= 0 || nch1 < 0 || (nch1 > 0 && !in1_cptc) || !wq || !scale || !bias_d || B <= 0 || H <= 0 ||
+      W <= 0 || Cout <= 0)
+    return SPK_ERR_ARG;
+  if (T != T16 || (Cout % 32)) return SPK_ERR_UNSUPPORTED;
+  MfmaArgs a;
+  a.in0 = in0_cptc; a.in1 = in1_cptc; a.nch0 = nch0; a.nch1 = nch1; a.wq = wq; a.scale = scale; a.bias = bias_d;
+  a.bn_a = bn_a; a.bn_b = bn_b; a.out = out_cptc; a.out_f32 = out_f32; a.v_io = v_inout; a.B = B; a.H = H; a.W = W;
+  a.Cout = Cout; a.mode = mode;
+  if (mode == SPK_MODE_LIF) {
+    if (!bn_a || !bn_b || !out_cptc) return SPK_ERR_ARG;
+    return launch<SPK_MODE_LIF>(a, stream);
+  }
+  if (mode == SPK_MODE_MEAN) {
+    if (!out_f32) return SPK_ERR_ARG;
+    return launch<SPK_MODE_MEAN>(a, stream);
+  }
+  return SPK_ERR_UNSUPPORTED;
+}

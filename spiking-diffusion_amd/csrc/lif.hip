@@ -171,15 +171,18 @@ __global__ __launch_bounds__(256) void memout_kernel(const float* __restrict__ x
 // ------------------------------------------------------------------------------------------ layout
 // fp32 spikes [T,B,C,H,W]  ->  u8 [B,H,W,T,C]   (one thread per (b, hw, t, c); reads strided, writes coalesced)
 __global__ __launch_bounds__(256) void spikes_to_ptc_kernel(const float* __restrict__ s, uint8_t* __restrict__ o,
-                                                            int T, int B, int C, int HW) {
+                                                            int T, int B, int C, int HW, int chunk) {
+  // output memory order: [B][C/chunk][HW][T][chunk]  (chunk == C: plain PTC [B][HW][T][C])
   long long total = (long long)T * B * C * HW;
+  const int nch = C / chunk;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    int c = (int)(i % C);
-    long long r = i / C;
+    int cc = (int)(i % chunk);
+    long long r = i / chunk;
     int t = (int)(r % T); r /= T;
-    int hw = (int)(r % HW);
-    int b = (int)(r / HW);
+    int hw = (int)(r % HW); r /= HW;
+    int c = (int)(r % nch) * chunk + cc;
+    int b = (int)(r / nch);
     float f = s[(((long long)t * B + b) * C + c) * HW + hw];
     o[i] = f != 0.0f ? 1 : 0;
   }
@@ -187,8 +190,9 @@ __global__ __launch_bounds__(256) void spikes_to_ptc_kernel(const float* __restr
 
 // u8 [B,H,W,T,C] -> fp32 [T,B,C,H,W]   (one thread per output element)
 __global__ __launch_bounds__(256) void ptc_to_spikes_kernel(const uint8_t* __restrict__ s, float* __restrict__ o,
-                                                            int T, int B, int C, int HW) {
+                                                            int T, int B, int C, int HW, int chunk) {
   long long total = (long long)T * B * C * HW;
+  const int nch = C / chunk;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     int hw = (int)(i % HW);
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void ptc_to_spikes_kernel(const uint8_t* __res
     int c = (int)(r % C); r /= C;
     int b = (int)(r % B);
     int t = (int)(r / B);
-    o[i] = (float)s[(((long long)b * HW + hw) * T + t) * C + c];
+    o[i] = (float)s[((((long long)b * nch + c / chunk) * HW + hw) * T + t) * chunk + c % chunk];
   }
 }
 
@@ -282,19 +286,21 @@ extern "C" int spk_memout_fwd(const float* x_seq, const float* coef, float* out,
 }
 
 extern "C" int spk_spikes_to_ptc(const float* spikes_tbchw, uint8_t* out_bhwtc, int T, int B, int C, int HW,
-                                 hipStream_t stream) {
-  if (!spikes_tbchw || !out_bhwtc || T <= 0 || B <= 0 || C <= 0 || HW <= 0) return SPK_ERR_ARG;
+                                 int chunk, hipStream_t stream) {
+  if (!spikes_tbchw || !out_bhwtc || T <= 0 || B <= 0 || C <= 0 || HW <= 0 || chunk <= 0 || C % chunk)
+    return SPK_ERR_ARG;
   hipLaunchKernelGGL(spikes_to_ptc_kernel, dim3(grid_for((long long)T * B * C * HW)), dim3(256), 0, stream,
-                     spikes_tbchw, out_bhwtc, T, B, C, HW);
+                     spikes_tbchw, out_bhwtc, T, B, C, HW, chunk);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }
 
 extern "C" int spk_ptc_to_spikes(const uint8_t* in_bhwtc, float* spikes_tbchw, int T, int B, int C, int HW,
-                                 hipStream_t stream) {
-  if (!in_bhwtc || !spikes_tbchw || T <= 0 || B <= 0 || C <= 0 || HW <= 0) return SPK_ERR_ARG;
+                                 int chunk, hipStream_t stream) {
+  if (!in_bhwtc || !spikes_tbchw || T <= 0 || B <= 0 || C <= 0 || HW <= 0 || chunk <= 0 || C % chunk)
+    return SPK_ERR_ARG;
   hipLaunchKernelGGL(ptc_to_spikes_kernel, dim3(grid_for((long long)T * B * C * HW)), dim3(256), 0, stream,
-                     in_bhwtc, spikes_tbchw, T, B, C, HW);
+                     in_bhwtc, spikes_tbchw, T, B, C, HW, chunk);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

@@ -37,7 +37,13 @@ __device__ __forceinline__ bool spk_lif_step(float& v, float x, float tau, float
   return s;
 }
 
-// default neuron of the models (tau 2, v_th 1, v_reset 0): R/snn_model/vae_model.py:37,112,...
+// Default neuron of the models (tau 2, v_th 1, v_reset 0: R/snn_model/vae_model.py:37,112,...), lean form for the
+// fused epilogues:  h = v + (x - v)/2 ; s = h >= 1 ; v = s ? 0 : h.  Same spikes and the same v as the reference's
+// arithmetic except that a zero membrane potential may keep its sign (-0.0 instead of +0.0), which no later
+// operation can observe (x - (-0) == x - (+0), and torch.equal(-0., +0.) is True).
 __device__ __forceinline__ bool spk_lif_step_default(float& v, float x) {
-  return spk_lif_step<false>(v, x, 2.0f, 0.5f, 1.0f, 0.0f);
+  const float h = v + (x - v) * 0.5f;
+  const bool s = h >= 1.0f;
+  v = s ? 0.0f : h;
+  return s;
 }

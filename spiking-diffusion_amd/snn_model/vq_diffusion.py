@@ -126,17 +126,33 @@ class DummyModel(nn.Module):
         return all(c._fusable(c._blocks()) for c in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5,
                                                      self.conv6)) and self.n_steps <= ops.MAX_T
 
+    # 'mfma-i8x4': conv2..conv6 on the matrix cores (4 exact int8 digit planes); 'direct-f64': fp64-accumulating
+    # direct kernels.  Both return the same correctly rounded pre-activations; 'auto' picks MFMA when T == 16.
+    conv_impl_request = 'auto'
+
+    @property
+    def conv_impl(self):
+        h = w = 7
+        ok = self.conv_impl_request != 'direct' and ops.den_mfma_supported(128, 64, 3, 1, 1, self.n_steps, h, w)
+        return 'mfma-i8x4' if ok else 'direct-f64'
+
     def _run(self, inp_b2hw, stateful, record=None):
         T = self.n_steps
-        x1 = self.conv1.run(inp_b2hw, IN_TINV, final='ptc', T=T, stateful=stateful)['ptc']
+        impl = 'direct' if self.conv_impl_request == 'direct' else 'auto'
+        # spikes travel channel-chunked (CPTC, 32 channels per chunk): the layout the MFMA kernel stages per K chunk
+        with ops.timed('den.conv1'):
+            x1 = self.conv1.run(inp_b2hw, IN_TINV, final='ptc', T=T, stateful=stateful, chunk_out=32)['ptc']
         x = x1
         outs = [x1]
-        for blk in (self.conv2, self.conv3, self.conv4, self.conv5):
-            x = blk.run(x, IN_PTC, final='ptc', stateful=stateful)['ptc']
+        for name, blk in (('den.conv2', self.conv2), ('den.conv3', self.conv3), ('den.conv4', self.conv4),
+                          ('den.conv5', self.conv5)):
+            with ops.timed(name):
+                x = blk.run(x, IN_PTC, final='ptc', stateful=stateful, chunk_out=32, impl=impl)['ptc']
             outs.append(x)
         if record is not None:
             record.extend(outs)
-        return self.conv6.run(x, IN_PTC, final='mean', in1=x1)['f32']
+        with ops.timed('den.conv6'):
+            return self.conv6.run(x, IN_PTC, final='mean', in1=x1, impl=impl)['f32']
 
     def forward(self, x, t) -> torch.Tensor:
         # x: b,c,h,w (token ids as floats); t: b

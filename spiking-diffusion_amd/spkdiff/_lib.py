@@ -43,12 +43,17 @@ _SIGS = {
     "spk_conv_transpose2d_fwd": (c_int, [P, P, P, P, c_longlong, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                          c_int, P]),
     "spk_memout_fwd": (c_int, [P, P, P, c_int, c_longlong, P]),
-    "spk_spikes_to_ptc": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
-    "spk_ptc_to_spikes": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "spk_spikes_to_ptc": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "spk_ptc_to_spikes": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_conv_out_size": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "spk_pack_conv_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spk_conv_fused_fwd": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int,
-                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_int, c_int, c_int, P]),
+    "spk_den_packed_weight_bytes": (c_longlong, [c_int, c_int]),
+    "spk_den_pack_weight_i8": (c_int, [P, P, P, P, P, c_int, c_int, P]),
+    "spk_den_conv3x3_mfma": (c_int, [P, c_int, P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int,
+                                     c_int, P]),
     "spk_vq_readout_argmin": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_vq_argmin": (c_int, [P, P, P, c_longlong, c_int, c_int, P]),
     "spk_embedding_fwd": (c_int, [P, P, P, c_longlong, c_int, c_int, c_int, c_int, P]),

@@ -22,11 +22,15 @@ def _ver(t):
 
 
 class ConvParams:
-    """Packed weight [k*k][Cin][Cout] + bias of one conv layer, rebuilt when the parameters change."""
+    """Prepared weights of one conv layer, rebuilt when the parameters change:
+    ``get``  -> fp32 packed [k*k][Cin][Cout] for the direct kernels;
+    ``get_i8`` -> int8 digit planes + fp64 scale / bias for the MFMA kernel (built on first use)."""
 
     def __init__(self):
         self.key = None
         self.w_packed = None
+        self.key_i8 = None
+        self.i8 = None
 
     def get(self, conv):
         key = (_ver(conv.weight), _ver(conv.bias))
@@ -35,6 +39,13 @@ class ConvParams:
             self.w_packed = ops.pack_conv_weight(conv.weight, transposed)
             self.key = key
         return self.w_packed
+
+    def get_i8(self, conv):
+        key = (_ver(conv.weight), _ver(conv.bias))
+        if key != self.key_i8:
+            self.i8 = ops.den_pack_weight_i8(conv.weight, conv.bias)
+            self.key_i8 = key
+        return self.i8
 
 
 def conv_geometry(conv):
@@ -89,13 +100,15 @@ class FusedSequential(nn.Sequential):
         return self.run(x, IN_SEQ, final='f32')['f32']
 
     def run(self, x, in_kind, final='f32', T=None, in1=None, coef=None, apply_tanh=False, want_u8=False,
-            stateful=True, want_pre=False):
+            stateful=True, want_pre=False, chunk_out=None, impl='auto'):
         """Run all blocks fused.
 
         x: per in_kind (IN_SEQ fp32 [T,B,C,H,W]; IN_TINV fp32 [B,C,H,W] with ``T`` given; IN_PTC u8 [B,H,W,T,C]).
         final: output of the LAST block -- 'f32' (spikes TBCHW, or the raw conv output when the last block has no
         BN/LIF), 'ptc', 'both', 'memout' (read-out of a conv-only last block) or 'mean'.
         stateful: honour and update each LIFNode's ``v`` (module semantics); False = fresh state, nothing written.
+        chunk_out: channel chunking of the PTC output of the last block (32 = the CPTC layout the MFMA kernel reads).
+        impl: 'auto' uses the int8 MFMA kernel where it applies (3x3/s1/p1, CPTC input, T=16), 'direct' never.
         Returns dict(ptc=, f32=, pre=[...], u8=)."""
         blocks = self._blocks()
         if not self._fusable(blocks):
@@ -103,7 +116,7 @@ class FusedSequential(nn.Sequential):
         if in_kind == IN_SEQ:
             T = x.shape[0]
         elif in_kind == IN_PTC:
-            T = x.shape[3]
+            T = x.shape[-2]
         elif T is None:
             raise ValueError('T is required for a time-invariant input')
         cur, kind = x, in_kind
@@ -112,16 +125,46 @@ class FusedSequential(nn.Sequential):
             last = bi == len(blocks) - 1
             if not hasattr(conv, '_spk_params'):
                 object.__setattr__(conv, '_spk_params', ConvParams())
-            w_packed = conv._spk_params.get(conv)
             geo = conv_geometry(conv)
             bias = None if conv.bias is None else conv.bias.detach()
             src1 = in1 if (last and in1 is not None) else None
+            cptc = kind == IN_PTC and cur.dim() == 6 and cur.shape[-1] == 32 and (src1 is None or src1.dim() == 6)
+            use_mfma = (impl != 'direct' and cptc and not geo['transposed'] and not want_pre and
+                        (lif is not None or final == 'mean') and
+                        ops.den_mfma_supported(conv.out_channels, conv.in_channels, geo['k'], geo['stride'], geo['pad'],
+                                               T, cur.shape[2], cur.shape[3]) and
+                        (lif is None or not last or (final == 'ptc' and chunk_out == 32)))
+            if use_mfma:
+                packed = conv._spk_params.get_i8(conv)
+                if lif is not None:
+                    a, b = bn.affine_terms()
+                    v = None
+                    if stateful:
+                        shape = (cur.shape[0], conv.out_channels, cur.shape[2], cur.shape[3])
+                        if isinstance(lif.v, float):
+                            lif.v = torch.full(shape, lif.v, dtype=torch.float32, device=cur.device)
+                        elif tuple(lif.v.shape) != shape:
+                            raise RuntimeError(f'LIFNode state has shape {tuple(lif.v.shape)} but the input implies '
+                                               f'{shape}; call functional.reset_net first')
+                        v = lif.v
+                    o = ops.den_conv3x3_mfma(cur, packed, conv.out_channels, mode=MODE_LIF, in1=src1, bn_a=a, bn_b=b, v=v)
+                    if last:
+                        out['ptc'] = o
+                    else:
+                        cur, kind = o, IN_PTC
+                else:
+                    out['f32'] = ops.den_conv3x3_mfma(cur, packed, conv.out_channels, mode=MODE_MEAN, in1=src1)
+                continue
+            w_packed = conv._spk_params.get(conv)
             if lif is not None:
                 a, b = bn.affine_terms()
                 v = None
                 if stateful:
                     B = cur.shape[0] if kind != IN_SEQ else cur.shape[1]
-                    H, W = (cur.shape[1], cur.shape[2]) if kind == IN_PTC else (cur.shape[-2], cur.shape[-1])
+                    if kind == IN_PTC:
+                        H, W = (cur.shape[2], cur.shape[3]) if cur.dim() == 6 else (cur.shape[1], cur.shape[2])
+                    else:
+                        H, W = cur.shape[-2], cur.shape[-1]
                     Ho = ops.conv_out_size(H, geo['k'], geo['stride'], geo['pad'], geo['transposed'], geo['out_pad'])
                     Wo = ops.conv_out_size(W, geo['k'], geo['stride'], geo['pad'], geo['transposed'], geo['out_pad'])
                     if isinstance(lif.v, float):
@@ -133,7 +176,8 @@ class FusedSequential(nn.Sequential):
                     v = lif.v
                 r = ops.conv_fused(cur, w_packed, bias, in_kind=kind, T=T, mode=MODE_LIF, in1=src1, bn_a=a, bn_b=b,
                                    v=v, want_ptc=(not last) or final in ('ptc', 'both'),
-                                   want_f32=last and final in ('f32', 'both'), want_pre=want_pre, **geo)
+                                   want_f32=last and final in ('f32', 'both'), want_pre=want_pre,
+                                   chunk_out=(chunk_out if last else None), **geo)
                 if want_pre:
                     out['pre'].append(r['pre'])
                 if last:

@@ -15,6 +15,32 @@ SPIKE_F32, SPIKE_U8, SPIKE_BITS = 0, 1, 2
 MAX_T = 16
 
 
+# ---------------------------------------------------------------------------------------------- in-situ kernel timing
+# bench.py switches this on to bracket named launches with HIP events recorded on the SAME stream the kernels
+# are enqueued on (torch's current stream): TIMERS[tag] = [(start_event, end_event), ...].
+TIMERS = None
+
+
+class timed:
+    __slots__ = ("tag", "e1")
+
+    def __init__(self, tag):
+        self.tag = tag
+
+    def __enter__(self):
+        if TIMERS is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            TIMERS.setdefault(self.tag, []).append((e0, self.e1))
+        return self
+
+    def __exit__(self, *exc):
+        if TIMERS is not None:
+            self.e1.record()
+        return False
+
+
 def _stream(t: torch.Tensor):
     return torch.cuda.current_stream(t.device).cuda_stream
 
@@ -128,21 +154,29 @@ def memout(x_seq, coef):
 
 
 # ---------------------------------------------------------------------------------------------- layouts
-def spikes_to_ptc(s):
-    """fp32 [T,B,C,H,W] -> u8 [B,H,W,T,C]."""
+def spikes_to_ptc(s, chunk=None):
+    """fp32 [T,B,C,H,W] -> u8 [B,H,W,T,C] (plain PTC) or, with ``chunk``, CPTC [B,C/chunk,H,W,T,chunk]."""
     s = _dev(s, "spikes", torch.float32)
     T, B, C, H, W = s.shape
-    o = torch.empty((B, H, W, T, C), dtype=torch.uint8, device=s.device)
-    check(lib.spk_spikes_to_ptc(_p(s), _p(o), T, B, C, H * W, _stream(s)), "spk_spikes_to_ptc")
+    if chunk is None:
+        o = torch.empty((B, H, W, T, C), dtype=torch.uint8, device=s.device)
+    else:
+        o = torch.empty((B, C // chunk, H, W, T, chunk), dtype=torch.uint8, device=s.device)
+    check(lib.spk_spikes_to_ptc(_p(s), _p(o), T, B, C, H * W, chunk or C, _stream(s)), "spk_spikes_to_ptc")
     return o
 
 
 def ptc_to_spikes(p):
-    """u8 [B,H,W,T,C] -> fp32 [T,B,C,H,W]."""
+    """u8 [B,H,W,T,C] or CPTC [B,C/chunk,H,W,T,chunk] -> fp32 [T,B,C,H,W]."""
     p = _dev(p, "ptc", torch.uint8)
-    B, H, W, T, C = p.shape
+    if p.dim() == 6:
+        B, nch, H, W, T, chunk = p.shape
+        C = nch * chunk
+    else:
+        B, H, W, T, C = p.shape
+        chunk = C
     o = torch.empty((T, B, C, H, W), dtype=torch.float32, device=p.device)
-    check(lib.spk_ptc_to_spikes(_p(p), _p(o), T, B, C, H * W, _stream(p)), "spk_ptc_to_spikes")
+    check(lib.spk_ptc_to_spikes(_p(p), _p(o), T, B, C, H * W, chunk, _stream(p)), "spk_ptc_to_spikes")
     return o
 
 
@@ -165,15 +199,20 @@ IN_PTC, IN_TINV, IN_SEQ = 0, 1, 2
 
 def conv_fused(in0, w_packed, bias, *, in_kind, T, mode, k, stride, pad, transposed=False, out_pad=0, in1=None,
                bn_a=None, bn_b=None, v=None, want_ptc=False, want_f32=False, want_pre=False, want_u8=False,
-               coef=None, apply_tanh=False, out_ptc=None, out_f32=None):
+               coef=None, apply_tanh=False, out_ptc=None, out_f32=None, chunk_out=None):
     """Launch spk_conv_fused_fwd. Returns dict(ptc=, f32=, pre=, u8=).
 
     in_kind IN_PTC: in0 u8 [B,H,W,T,C0] (+ in1 [B,H,W,T,C1]);  IN_TINV: in0 fp32 [B,C0,H,W];
     IN_SEQ: in0 fp32 [T,B,C0,H,W] (any values)."""
     dev = in0.device
+    chunk0 = chunk1 = 0
     if in_kind == IN_PTC:
         in0 = _dev(in0, "in0", torch.uint8)
-        B, H, W, T_in, C0 = in0.shape
+        if in0.dim() == 6:                                   # CPTC [B, C/chunk, H, W, T, chunk]
+            B, nch, H, W, T_in, chunk0 = in0.shape
+            C0 = nch * chunk0
+        else:
+            B, H, W, T_in, C0 = in0.shape
         if T_in != T:
             raise ValueError("T mismatch")
     elif in_kind == IN_TINV:
@@ -189,7 +228,11 @@ def conv_fused(in0, w_packed, bias, *, in_kind, T, mode, k, stride, pad, transpo
     C1 = 0
     if in1 is not None:
         in1 = _dev(in1, "in1", torch.uint8)
-        C1 = in1.shape[-1]
+        if in1.dim() == 6:
+            chunk1 = in1.shape[-1]
+            C1 = in1.shape[1] * chunk1
+        else:
+            C1 = in1.shape[-1]
     kk, Cin, Cout = w_packed.shape
     if Cin != C0 + C1 or kk != k * k:
         raise ValueError(f"packed weight {tuple(w_packed.shape)} does not match Cin={C0 + C1}, k={k}")
@@ -197,7 +240,8 @@ def conv_fused(in0, w_packed, bias, *, in_kind, T, mode, k, stride, pad, transpo
     res = {"ptc": None, "f32": None, "pre": None, "u8": None}
     if mode == MODE_LIF:
         if want_ptc:
-            res["ptc"] = out_ptc if out_ptc is not None else torch.empty((B, Ho, Wo, T, Cout), dtype=torch.uint8, device=dev)
+            shape = (B, Ho, Wo, T, Cout) if not chunk_out else (B, Cout // chunk_out, Ho, Wo, T, chunk_out)
+            res["ptc"] = out_ptc if out_ptc is not None else torch.empty(shape, dtype=torch.uint8, device=dev)
         if want_f32:
             res["f32"] = out_f32 if out_f32 is not None else torch.empty((T, B, Cout, Ho, Wo), dtype=torch.float32, device=dev)
         if want_pre:
@@ -216,8 +260,56 @@ def conv_fused(in0, w_packed, bias, *, in_kind, T, mode, k, stride, pad, transpo
     check(lib.spk_conv_fused_fwd(
         _p(in0), _p(in1), C0, C1, in_kind, _p(w_packed), _p(bias), _p(bn_a), _p(bn_b), _p(v), _p(res["ptc"]),
         _p(res["f32"]), _p(res["pre"]), _p(res["u8"]), _p(coef), int(apply_tanh), mode, T, B, H, W, Cout, k, stride,
-        pad, int(transposed), out_pad, _stream(in0)), "spk_conv_fused_fwd")
+        pad, int(transposed), out_pad, chunk0, chunk1, chunk_out or 0, _stream(in0)), "spk_conv_fused_fwd")
     return res
+
+
+# ---------------------------------------------------------------------------------------------- MFMA denoiser convs
+def den_mfma_supported(Cout, Cin, k, stride, pad, T, H, W):
+    ntiles = (H * W + 1) // 2
+    nt = (ntiles + 3) // 4
+    lds = 2 * ((H + 2) * (W + 2) * 512 + 18432)
+    return (k == 3 and stride == 1 and pad == 1 and T == 16 and Cout % 32 == 0 and Cin % 32 == 0
+            and nt <= 8 and lds <= 160 * 1024)
+
+
+def den_pack_weight_i8(w, bias):
+    """[Cout,Cin,3,3] fp32 -> (int8 digit planes, fp64 scale [Cout], fp64 bias [Cout])."""
+    w = _dev(w.detach(), "weight", torch.float32)
+    Cout, Cin = w.shape[0], w.shape[1]
+    nbytes = lib.spk_den_packed_weight_bytes(Cout, Cin)
+    if nbytes < 0:
+        raise NotImplementedError("spkdiff: MFMA conv needs Cout % 16 == 0 and Cin % 32 == 0")
+    wq = torch.empty(nbytes, dtype=torch.int8, device=w.device)
+    scale = torch.empty(Cout, dtype=torch.float64, device=w.device)
+    bias_d = torch.empty(Cout, dtype=torch.float64, device=w.device)
+    b = None if bias is None else _dev(bias.detach(), "bias", torch.float32)
+    check(lib.spk_den_pack_weight_i8(_p(w), _p(b), _p(wq), _p(scale), _p(bias_d), Cout, Cin, _stream(w)),
+          "spk_den_pack_weight_i8")
+    return wq, scale, bias_d
+
+
+def den_conv3x3_mfma(in0, packed, Cout, *, mode, in1=None, bn_a=None, bn_b=None, v=None, out=None):
+    """in0/in1: CPTC u8 [B, C/32, H, W, 16, 32]. mode LIF -> CPTC spikes [B, Cout/32, H, W, 16, 32];
+    mode MEAN -> fp32 [B, Cout, H, W]."""
+    in0 = _dev(in0, "in0", torch.uint8)
+    B, nch0, H, W, T, chunk = in0.shape
+    if chunk != 32:
+        raise ValueError("MFMA conv reads 32-channel chunked spikes")
+    nch1 = 0
+    if in1 is not None:
+        in1 = _dev(in1, "in1", torch.uint8)
+        nch1 = in1.shape[1]
+    wq, scale, bias_d = packed
+    out_c = out_f = None
+    if mode == MODE_LIF:
+        out_c = out if out is not None else torch.empty((B, Cout // 32, H, W, T, 32), dtype=torch.uint8, device=in0.device)
+    else:
+        out_f = out if out is not None else torch.empty((B, Cout, H, W), dtype=torch.float32, device=in0.device)
+    check(lib.spk_den_conv3x3_mfma(_p(in0), nch0, _p(in1), nch1, _p(wq), _p(scale), _p(bias_d), _p(bn_a), _p(bn_b),
+                                   _p(v), _p(out_c), _p(out_f), mode, T, B, H, W, Cout, _stream(in0)),
+          "spk_den_conv3x3_mfma")
+    return out_c if mode == MODE_LIF else out_f
 
 
 # ---------------------------------------------------------------------------------------------- VQ

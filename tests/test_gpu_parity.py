@@ -393,6 +393,50 @@ def test_f5_denoiser(golden_dir, dev, ops, tag, cfg):
     assert frac_close >= 0.98 and float(diff.max()) <= 0.1
 
 
+@pytest.mark.parametrize("tag,cfg", [("mnist", synth.MNIST), ("cifar", synth.CIFAR)])
+def test_f5_denoiser_mfma_int8_kernel(golden_dir, dev, ops, tag, cfg):
+    """conv2..conv6 on the matrix cores (four exact int8 digit planes) against the golden spikes (teacher forced),
+    and bit-for-bit against the fp64-accumulating direct kernel: both are the correctly rounded exact dot product."""
+    from spkdiff.ops import IN_PTC
+    from snn_model.vq_diffusion import functional
+    d = load(golden_dir, f"f5_denoiser_{tag}.npz")
+    den, sd = build_den(cfg, dev)
+    assert den.conv_impl == 'mfma-i8x4'
+    spikes = {i: unpack(d[f"s{i}_bits"], d[f"s{i}_shape"]) for i in range(1, 6)}
+    report = {}
+    for i, blk in enumerate((den.conv2, den.conv3, den.conv4, den.conv5), 2):
+        frag = unpack(d[f"frag{i}_bits"], d[f"s{i}_shape"]).bool()
+        x_c = ops.spikes_to_ptc(spikes[i - 1].to(dev), chunk=32)
+        assert torch.equal(ops.ptc_to_spikes(x_c).cpu(), spikes[i - 1])                       # CPTC round trip
+        got_c = blk.run(x_c, IN_PTC, final='ptc', stateful=False, chunk_out=32)['ptc']
+        assert got_c.dim() == 6 and got_c.shape[-1] == 32
+        got = ops.ptc_to_spikes(got_c).cpu()
+        direct = blk.run(x_c, IN_PTC, final='f32', stateful=False, impl='direct')['f32'].cpu()
+        bad = got != spikes[i]
+        report[f"conv{i}"] = (int(bad.sum()), int(frag.sum()), int((got != direct).sum()))
+        assert not bool((bad & ~frag).any()), f"conv{i} (MFMA): spike differs outside the fragile set"
+        assert torch.equal(got, direct), f"conv{i}: MFMA int8 path != fp64 direct path"
+    print(f"F5 {tag} MFMA teacher-forced (mismatch vs golden, fragile, mismatch vs direct):", report)
+    x5 = ops.spikes_to_ptc(spikes[5].to(dev), chunk=32); x1 = ops.spikes_to_ptc(spikes[1].to(dev), chunk=32)
+    lg = den.conv6.run(x5, IN_PTC, final='mean', in1=x1)['f32'].cpu()
+    lg_d = den.conv6.run(x5, IN_PTC, final='mean', in1=x1, impl='direct')['f32'].cpu()
+    assert float((lg - torch.from_numpy(d["logits"])).abs().max()) <= 1e-5
+    # weights below 2^-7 of their channel's maximum are fixed-point rounded at 2^-30 of that maximum (den_mfma.hip):
+    # a pre-activation may then round to the neighbouring fp32 value; bound: a few percent of logits, by <= 1 ulp
+    assert float((lg != lg_d).float().mean()) <= 0.03 and float((lg - lg_d).abs().max()) <= 6e-8
+    # module semantics on the MFMA path: state carried across forwards without reset == direct path, then reset
+    x_t = torch.from_numpy(d["x_t"]).float().to(dev); t = torch.from_numpy(d["t"]).to(dev)
+    with torch.inference_mode():
+        a1 = den(x_t, t=t); a2 = den(x_t, t=t)
+        functional.reset_net(den)
+        den.conv_impl_request = 'direct'
+        b1 = den(x_t, t=t); b2 = den(x_t, t=t)
+        functional.reset_net(den)
+        den.conv_impl_request = 'auto'
+    assert float((a1 - b1).abs().max()) <= 1e-6 and float((a2 - b2).abs().max()) <= 1e-6
+    assert not torch.equal(a1, a2), "second call starts from the carried membrane potentials"
+
+
 # ------------------------------------------------------------------------------------------------- F6 p_sample
 def test_f6_psample_steps_exact(golden_dir, dev, ops):
     d = load(golden_dir, "f6_psample.npz")
