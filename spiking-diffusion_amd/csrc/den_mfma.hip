@@ -32,6 +32,7 @@
 //     16 bits to 16 bytes and writes ONE 16-byte store per (position, time step).
 #include "spk_common.h"
 #include "../../include/spkdiff.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -50,13 +51,21 @@ struct MfmaArgs {
   const int8_t* wq; const double* scale; const double* bias; const float* bn_a; const float* bn_b;
   uint8_t* out; float* out_f32; float* v_io;
   int B, H, W, Cout, mode;
+  int dbg;   // -DSPK_MFMA_ABLATION builds only (env SPK_MFMA_DEBUG): 1 = skip steady-state DMA, 2 = skip MFMAs, 4 = skip epilogue
 };
+
+// v_writelane_b32 with an immediate lane: drop a wave-uniform value into one lane of a VGPR
+template <int L>
+__device__ __forceinline__ unsigned writelane_imm(unsigned old, unsigned uniform_val) {
+  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(uniform_val), "n"(L));
+  return old;
+}
 
 #define SPK_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 #define SPK_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
 
-// NT = row tiles per wave (7 for 7x7 latents, 8 for 8x8).
-template <int NT, int MODE>
+// NT = row tiles per wave (7 for 7x7 latents, 8 for 8x8); NPA = A-slab DMA pieces per wave (H*ceil(W/2)/4, rounded up).
+template <int NT, int NPA, int MODE, int DBG>
 __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int HW = a.H * a.W, PW = a.W + 2;
@@ -85,10 +94,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
   }
   const int b_off = (lane & 31) * CK + 16 * (half ^ ((lane >> 4) & 1));   // same swizzle, baked into the packed weights
 
-  // DMA piece table: A slab = H image rows x ceil(W/2) pieces of 2 positions (1 KiB); W slab = 18 pieces
+  // DMA piece table, built ONCE per wave with wave-uniform (scalar) values: the A slab of a chunk is H image rows x
+  // ceil(W/2) pieces of two positions (1 KiB, the last piece of an odd-width row is half a KiB), wave w copies
+  // pieces [w*NPA, (w+1)*NPA); the W slab is 18 one-KiB pieces, wave w copies pieces w, w+4, ...
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const int pprow = (a.W + 1) >> 1;
   const int nA = a.H * pprow;
-  const int npieces = nA + W_PIECES;
+  int pa_src[NPA], pa_dst[NPA];      // byte offsets; pa_src < 0: absent piece
+  bool pa_full[NPA];
+#pragma unroll
+  for (int j = 0; j < NPA; ++j) {
+    const int id = wave_s * NPA + j;
+    const int y = id / pprow, px = id - y * pprow;
+    pa_src[j] = id < nA ? (y * a.W + 2 * px) * POS_BYTES : -1;
+    pa_dst[j] = ((y + 1) * PW + 1 + 2 * px) * POS_BYTES;
+    pa_full[j] = 2 * px + 1 < a.W;
+  }
+  const unsigned lane_a = (unsigned)(lane ^ ((lane >> 4) & 1)) * 16u;     // swizzled source lane (see a_off)
+  const unsigned lane_w = (unsigned)lane * 16u;
 
   auto issue_dma = [&](int item, int c, int buf) {
     const int b = item / G, g = item - b * G;
@@ -97,18 +120,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
     const int8_t* wslab = a.wq + ((long long)g * nchunks + c) * W_CHUNK_BYTES;
     uint8_t* dA = sA + buf * A_BYTES;
     uint8_t* dW = sW + buf * W_CHUNK_BYTES;
-    for (int id = wave; id < npieces; id += 4) {               // wave-uniform
-      if (id < nA) {
-        const int y = id / pprow, px = id - y * pprow;
-        const int p0 = y * a.W + 2 * px;
-        const bool second_ok = 2 * px + 1 < a.W;
-        if (lane < 32 || second_ok)
-          __builtin_amdgcn_global_load_lds(SPK_GLB(aslab + (long long)p0 * POS_BYTES + (lane ^ ((lane >> 4) & 1)) * 16),
-                                           SPK_LDS(dA + ((y + 1) * PW + 1 + 2 * px) * POS_BYTES), 16, 0, 0);
-      } else {
-        const int k = id - nA;
-        __builtin_amdgcn_global_load_lds(SPK_GLB(wslab + k * 1024 + lane * 16), SPK_LDS(dW + k * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+      if (pa_src[j] >= 0) {                                       // wave-uniform
+        if (pa_full[j] || lane < 32)
+          __builtin_amdgcn_global_load_lds(SPK_GLB(aslab + pa_src[j] + lane_a), SPK_LDS(dA + pa_dst[j]), 16, 0, 0);
       }
+    }
+#pragma unroll
+    for (int j = 0; j < (W_PIECES + 3) / 4; ++j) {
+      const int k = wave_s + 4 * j;
+      if (k < W_PIECES)
+        __builtin_amdgcn_global_load_lds(SPK_GLB(wslab + k * 1024 + lane_w), SPK_LDS(dW + k * 1024), 16, 0, 0);
     }
   };
 
@@ -135,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
     {
       int nitem = item, nc = c + 1;
       if (nc == nchunks) { nc = 0; nitem = item + gridDim.x; }
-      if (nitem < total) issue_dma(nitem, nc, buf ^ 1);
+      if (nitem < total && !(DBG & 1)) issue_dma(nitem, nc, buf ^ 1);
     }
 
     // ---------------- 9 taps x NT row tiles x 2 column tiles, fragments read two steps ahead -------------------
@@ -162,28 +185,27 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
           bn0 = *reinterpret_cast<const v4i*>(Wb + ((tap + 1) * 2 + 0) * 32 * CK);
           bn1 = *reinterpret_cast<const v4i*>(Wb + ((tap + 1) * 2 + 1) * 32 * CK);
         }
-        acc[i][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bc0, acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bc1, acc[i][1], 0, 0, 0);
+        if (!(DBG & 2)) {
+          acc[i][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bc0, acc[i][0], 0, 0, 0);
+          acc[i][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bc1, acc[i][1], 0, 0, 0);
+        } else {
+          acc[i][0][0] += av[0] + bc0[1]; acc[i][1][0] += av[1] + bc1[0];
+        }
         if (i == NT - 1) { bc0 = bn0; bc1 = bn1; }
         __builtin_amdgcn_sched_barrier(0);     // keep the read-ahead distance: hipcc otherwise sinks every ds_read
       }                                         // to just before its MFMA (one exposed LDS latency per tile)
     }
 
     }   // chunks
-    {
+    if (!(DBG & 4)) {
       // ---------------- epilogue: exact recombination, BN, LIF scan over the 16 accumulator registers ----------
-#pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        const int ti = wave + 4 * i;
-        const int p = 2 * ti + half;                  // accumulator lane-half == position within the tile
-        const bool pos_ok = p < HW;
-        // partner lanes (col, col^16) hold digit planes {0,2} and {1,3} of the same channel: each recombines 8 of
-        // the 16 time steps in fp64 (even lane t = 0..7, odd lane t = 8..15), then they swap the fp32 results
-        float x[16];
+      // Partner lanes (col, col ^ 16) hold digit planes {0,2} and {1,3} of the same channel.  recombine(i, x):
+      // v_permlane16_swap(A, B) gives A' = {even row: A.even, odd row: B.even}, B' = {even row: A.odd, odd row: B.odd};
+      // with A = acc[.][r] (t = r) and B = acc[.][r + 8] every lane ends up with both digits of ITS time step (even
+      // lane t = r, odd lane t = r + 8), recombines it in fp64, and a third swap hands both lanes all 16 fp32 values.
+      auto recombine = [&](int i, float (&x)[16]) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-          // v_permlane16_swap(A, B): A' = {even row: A.even, odd row: B.even}, B' = {even row: A.odd, odd row: B.odd}
-          // with A = acc[.][r] (t = r) and B = acc[.][r + 8]: every lane ends up with both digits of ITS time step
           const v2u p01 = __builtin_amdgcn_permlane16_swap((unsigned)acc[i][0][r], (unsigned)acc[i][0][r + 8], false, false);
           const v2u p23 = __builtin_amdgcn_permlane16_swap((unsigned)acc[i][1][r], (unsigned)acc[i][1][r + 8], false, false);
           const int hi = (int)p01[0] * 256 + (int)p01[1], lo = (int)p23[0] * 256 + (int)p23[1];
@@ -193,38 +215,64 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
           x[r] = __uint_as_float(xx[0]);                                 // t = r     (computed by the even lane)
           x[r + 8] = __uint_as_float(xx[1]);                             // t = r + 8 (computed by the odd lane)
         }
-        if (MODE == SPK_MODE_LIF) {
+      };
+      if (MODE == SPK_MODE_LIF) {
+        // Both partner lanes now hold the same 16 pre-activations, so the LIF scan runs on TWO row tiles at once: even
+        // lanes scan tile ip, odd lanes tile ip + 1.  The ballot of time step r then carries 4 positions x 16 channels;
+        // v_writelane drops each 16-bit group into the lane that will store it: lane (pos_half*32 + parity*16 + r).
+#pragma unroll
+        for (int ip = 0; ip < NT; ip += 2) {
+          float xa[16], xb[16];
+          recombine(ip, xa);
+          if (ip + 1 < NT) recombine(ip + 1, xb);
+          const int ti = wave + 4 * (ip + odd);
+          const int p = 2 * ti + half;                  // accumulator lane-half == position within the tile
+          const bool pos_ok = p < HW && (ip + 1 < NT || !odd);
           const long long vidx = ((long long)b * a.Cout + co) * HW + (pos_ok ? p : 0);
           float v = a.v_io ? a.v_io[vidx] : 0.f;
-          unsigned long long mine = 0;                 // lane t keeps the ballot of time step t
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const bool s = spk_lif_step_default(v, fmaf(x[r], bn_a, bn_b)) && !odd && pos_ok;
-            const unsigned long long m = __ballot(s);  // bits 0..15: channels of position 0, bits 32..47: position 1
-            if ((lane & 15) == r) mine = m;
-          }
-          if (a.v_io && !odd && pos_ok) a.v_io[vidx] = v;
-          // lanes 0..15 write position 0 (t = lane), lanes 16..31 position 1 (t = lane - 16): 16 channels = 16 bytes
-          const int wp = 2 * ti + (lane >> 4);
-          if (lane < 32 && wp < HW) {
-            const uint32_t bits = (uint32_t)((lane & 16) ? (mine >> 32) : mine) & 0xffffu;
+          unsigned bitsv = 0;
+#define SPK_LIF_STEP(r)                                                                                     \
+  {                                                                                                         \
+    const float xv = (ip + 1 < NT && odd) ? xb[r] : xa[r];                                                  \
+    const bool s = spk_lif_step_default(v, fmaf(xv, bn_a, bn_b)) && pos_ok;                                 \
+    const unsigned long long m = __ballot(s);                                                               \
+    const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);                                            \
+    bitsv = writelane_imm<r>(bitsv, mlo & 0xffffu);      /* tile ip,   position 0, t = r */                 \
+    bitsv = writelane_imm<16 + r>(bitsv, mlo >> 16);     /* tile ip+1, position 0 */                        \
+    bitsv = writelane_imm<32 + r>(bitsv, mhi & 0xffffu); /* tile ip,   position 1 */                        \
+    bitsv = writelane_imm<48 + r>(bitsv, mhi >> 16);     /* tile ip+1, position 1 */                        \
+  }
+          SPK_LIF_STEP(0) SPK_LIF_STEP(1) SPK_LIF_STEP(2) SPK_LIF_STEP(3) SPK_LIF_STEP(4) SPK_LIF_STEP(5)
+          SPK_LIF_STEP(6) SPK_LIF_STEP(7) SPK_LIF_STEP(8) SPK_LIF_STEP(9) SPK_LIF_STEP(10) SPK_LIF_STEP(11)
+          SPK_LIF_STEP(12) SPK_LIF_STEP(13) SPK_LIF_STEP(14) SPK_LIF_STEP(15)
+#undef SPK_LIF_STEP
+          if (a.v_io && pos_ok) a.v_io[vidx] = v;
+          // every lane stores one (position, time step): 16 channels = 16 bytes
+          if (pos_ok) {
             uint4 o;
-            o.x = ((bits & 0xfu) * 0x00204081u) & 0x01010101u;
-            o.y = (((bits >> 4) & 0xfu) * 0x00204081u) & 0x01010101u;
-            o.z = (((bits >> 8) & 0xfu) * 0x00204081u) & 0x01010101u;
-            o.w = (((bits >> 12) & 0xfu) * 0x00204081u) & 0x01010101u;
+            o.x = ((bitsv & 0xfu) * 0x00204081u) & 0x01010101u;
+            o.y = (((bitsv >> 4) & 0xfu) * 0x00204081u) & 0x01010101u;
+            o.z = (((bitsv >> 8) & 0xfu) * 0x00204081u) & 0x01010101u;
+            o.w = (((bitsv >> 12) & 0xfu) * 0x00204081u) & 0x01010101u;
             const int co0 = g * 16;
-            uint8_t* dst = a.out + ((((long long)b * (a.Cout >> 5) + (co0 >> 5)) * HW + wp) * T16 + (lane & 15)) * CK +
+            uint8_t* dst = a.out + ((((long long)b * (a.Cout >> 5) + (co0 >> 5)) * HW + p) * T16 + (lane & 15)) * CK +
                            (co0 & 31);
             *reinterpret_cast<uint4*>(dst) = o;
           }
-        } else {
+          __builtin_amdgcn_sched_barrier(0);        // keep the tile pairs from being interleaved (VGPR pressure)
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          float x[16];
+          recombine(i, x);
+          const int p = 2 * (wave + 4 * i) + half;
           float msum = 0.f;
 #pragma unroll
           for (int r = 0; r < 16; ++r) msum = msum + x[r];                // torch.sum(x6, dim=0), t order
-          if (!odd && pos_ok) a.out_f32[((long long)b * a.Cout + co) * HW + p] = msum / 16.0f;
+          if (!odd && p < HW) a.out_f32[((long long)b * a.Cout + co) * HW + p] = msum / 16.0f;
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);          // keep the tiles' epilogues from being interleaved (VGPR pressure)
       }
     }
   }   // items
@@ -285,10 +333,21 @@ int launch(const MfmaArgs& a, hipStream_t stream) {
   }
   const int total = a.B * (a.Cout / 16);
   dim3 grid(total < cus ? total : cus), blk(256);          // persistent: one workgroup per CU
-  if (nt <= 7) {
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<7, MODE>), grid, blk, lds, stream, a);
-  } else if (nt <= 8) {
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<8, MODE>), grid, blk, lds, stream, a);
+  const int npa = (a.H * ((a.W + 1) / 2) + 3) / 4;
+  if (nt <= 7 && npa <= 7) {
+#ifdef SPK_MFMA_ABLATION
+    switch (a.dbg) {
+      case 1: hipLaunchKernelGGL((conv3x3_mfma_kernel<7, 7, MODE, 1>), grid, blk, lds, stream, a); break;
+      case 2: hipLaunchKernelGGL((conv3x3_mfma_kernel<7, 7, MODE, 2>), grid, blk, lds, stream, a); break;
+      case 3: hipLaunchKernelGGL((conv3x3_mfma_kernel<7, 7, MODE, 3>), grid, blk, lds, stream, a); break;
+      case 4: hipLaunchKernelGGL((conv3x3_mfma_kernel<7, 7, MODE, 4>), grid, blk, lds, stream, a); break;
+      default: hipLaunchKernelGGL((conv3x3_mfma_kernel<7, 7, MODE, 0>), grid, blk, lds, stream, a); break;
+    }
+#else
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<7, 7, MODE, 0>), grid, blk, lds, stream, a);
+#endif
+  } else if (nt <= 8 && npa <= 8) {
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<8, 8, MODE, 0>), grid, blk, lds, stream, a);
   } else {
     return SPK_ERR_UNSUPPORTED;
   }
@@ -324,6 +383,7 @@ extern "C" int spk_den_conv3x3_mfma(const uint8_t* in0_cptc, int nch0, const uin
   a.in0 = in0_cptc; a.in1 = in1_cptc; a.nch0 = nch0; a.nch1 = nch1; a.wq = wq; a.scale = scale; a.bias = bias_d;
   a.bn_a = bn_a; a.bn_b = bn_b; a.out = out_cptc; a.out_f32 = out_f32; a.v_io = v_inout; a.B = B; a.H = H; a.W = W;
   a.Cout = Cout; a.mode = mode;
+  { const char* e = getenv("SPK_MFMA_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   if (mode == SPK_MODE_LIF) {
     if (!bn_a || !bn_b || !out_cptc) return SPK_ERR_ARG;
     return launch<SPK_MODE_LIF>(a, stream);

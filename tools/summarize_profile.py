@@ -1,0 +1,35 @@
+"""Summarise a rocprofv3 --kernel-trace CSV into a per-kernel / per-denoiser-layer table (markdown on stdout).
+
+usage: python tools/summarize_profile.py <kernel_trace.csv> [<pmc_fetch counter csv> <pmc_write counter csv>]
+The MFMA kernel is one symbol for conv2..conv5; the layers are told apart by dispatch order (4 consecutive
+dispatches per denoiser call)."""
+import csv
+import sys
+from collections import defaultdict
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+dur = defaultdict(list)
+k = 0
+for r in rows:
+    name = r["Kernel_Name"]
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    if "conv3x3_mfma_kernel<7, 0>" in name or "conv3x3_mfma_kernel<8, 0>" in name:
+        name = f"conv3x3_mfma_kernel<LIF> den.conv{2 + k % 4}"
+        k += 1
+    elif "conv3x3_mfma_kernel" in name:
+        name = "conv3x3_mfma_kernel<MEAN> den.conv6"
+    dur[name.replace("(anonymous namespace)::", "")[:90]].append(d)
+tot = sum(sum(v) for v in dur.values())
+print("| kernel | calls | avg us | min us | max us | total ms | % |")
+print("|---|---|---|---|---|---|---|")
+for n, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+    print(f"| `{n}` | {len(v)} | {sum(v)/len(v):.1f} | {min(v):.1f} | {max(v):.1f} | {sum(v)/1e3:.2f} | {100*sum(v)/tot:.1f} |")
+for path in sys.argv[2:]:
+    cr = list(csv.DictReader(open(path)))
+    acc = defaultdict(list)
+    for r in cr:
+        acc[(r["Kernel_Name"].replace("(anonymous namespace)::", "")[:60], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    print()
+    for (n, c), v in acc.items():
+        print(f"- `{n}` {c}: mean {sum(v)/len(v):.4g} over {len(v)} dispatches")
