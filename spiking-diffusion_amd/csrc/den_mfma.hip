@@ -135,6 +135,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
     }
   };
 
+  // the same copy, one piece at a time (piece q of this wave: q < NPA -> A piece q, else W piece q - NPA), so that the
+  // K loop can interleave the DMA issues with its MFMAs instead of paying ~12 x 20 issue slots up front
+  constexpr int NPW = (W_PIECES + 3) / 4;
+  auto issue_piece = [&](int q, const uint8_t* aslab, const int8_t* wslab, uint8_t* dA, uint8_t* dW) {
+    if (q < NPA) {
+      if (pa_src[q] >= 0) {
+        if (pa_full[q] || lane < 32)
+          __builtin_amdgcn_global_load_lds(SPK_GLB(aslab + pa_src[q] + lane_a), SPK_LDS(dA + pa_dst[q]), 16, 0, 0);
+      }
+    } else {
+      const int k = wave_s + 4 * (q - NPA);
+      if (k < W_PIECES)
+        __builtin_amdgcn_global_load_lds(SPK_GLB(wslab + k * 1024 + lane_w), SPK_LDS(dW + k * 1024), 16, 0, 0);
+    }
+  };
+
   const int col = lane & 31, ch = col & 15, odd = col >> 4;
 
   int it = 0;                                      // running chunk counter: LDS buffer = it & 1
@@ -155,11 +171,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
     for (int c = 0; c < nchunks; ++c, ++it) {
     const int buf = it & 1;
     __syncthreads();     // vmcnt(0) + barrier: this chunk's DMA has landed; everyone is done with the other buffer
-    {
-      int nitem = item, nc = c + 1;
-      if (nc == nchunks) { nc = 0; nitem = item + gridDim.x; }
-      if (nitem < total && !(DBG & 1)) issue_dma(nitem, nc, buf ^ 1);
-    }
+    // next chunk (possibly of the next item): its DMA pieces are issued between the MFMA groups below
+    int nitem = item, nc = c + 1;
+    if (nc == nchunks) { nc = 0; nitem = item + gridDim.x; }
+    const bool have_next = nitem < total && !(DBG & 1);
+    const int nb = nitem / G, ng = nitem - nb * G;
+    const uint8_t* n_aslab = nc < a.nch0 ? a.in0 + ((long long)nb * a.nch0 + nc) * HW * POS_BYTES
+                                         : a.in1 + ((long long)nb * a.nch1 + (nc - a.nch0)) * HW * POS_BYTES;
+    const int8_t* n_wslab = a.wq + ((long long)ng * nchunks + nc) * W_CHUNK_BYTES;
+    uint8_t* const n_dA = sA + (buf ^ 1) * A_BYTES;
+    uint8_t* const n_dW = sW + (buf ^ 1) * W_CHUNK_BYTES;
 
     // ---------------- 9 taps x NT row tiles x 2 column tiles, fragments read two steps ahead -------------------
     {
@@ -192,6 +213,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
           acc[i][0][0] += av[0] + bc0[1]; acc[i][1][0] += av[1] + bc1[0];
         }
         if (i == NT - 1) { bc0 = bn0; bc1 = bn1; }
+        // DMA schedule: NPA + NPW pieces spread over the 9*NT steps (every DMA_EVERY-th step issues one piece)
+        {
+          constexpr int NPIECES = NPA + NPW;
+          constexpr int DMA_EVERY = (9 * NT) / NPIECES;
+          if (s % DMA_EVERY == 0 && s / DMA_EVERY < NPIECES) {
+            if (have_next) issue_piece(s / DMA_EVERY, n_aslab, n_wslab, n_dA, n_dW);
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);     // keep the read-ahead distance: hipcc otherwise sinks every ds_read
       }                                         // to just before its MFMA (one exposed LDS latency per tile)
     }
