@@ -587,3 +587,70 @@ def test_main_py_call_sequence_conformance(dev):
     model.train()
     with pytest.raises(NotImplementedError):
         model(images_spike, norm_images)
+
+
+# ------------------------------------------------------------------------------------------------- BASELINE configs 3, 4, 5
+def test_config3_fmnist_b1024_encode_decode_properties(dev):
+    """BASELINE config 3 (FMNIST-shaped == MNIST shapes, B=1024, T=16 encode->decode): size-independent properties.
+    Samples are independent, so any slice of the big batch must equal the same images run alone -- and the small run
+    is oracle-checked in test_f3 -- plus determinism and range checks."""
+    from snn_model.vae_model import functional
+    model, sd = build_vae(synth.MNIST, dev)
+    g = torch.Generator().manual_seed(42)
+    images = torch.rand(1024, 1, 28, 28, generator=g) - 0.5
+    with torch.inference_mode():
+        x = images.to(dev).unsqueeze(0).repeat(16, 1, 1, 1, 1)
+        e, xr, idx = model(x, images.to(dev))
+        functional.reset_net(model)
+        e2, xr2, idx2 = model(x[:, 500:508].contiguous(), images[500:508].to(dev))
+        functional.reset_net(model)
+        idx_fast = model.encode_images(images.to(dev), 16)
+    assert e.shape == (16, 1024, 16, 7, 7) and xr.shape == (1024, 1, 28, 28) and idx.shape == (1024 * 49,)
+    assert int(idx.min()) >= 0 and int(idx.max()) < 128 and float(xr.abs().max()) <= 1.0
+    assert torch.equal(idx.view(1024, 49)[500:508], idx2.view(8, 49))
+    assert torch.equal(xr[500:508], xr2) and torch.equal(e[:, 500:508], e2)
+    assert torch.equal(idx_fast.reshape(-1), idx)
+    assert bool(((e == 0) | (e == 1)).all())
+    # the first 16 images are the F3 fixture images (same generator, same seed): indices must match the reference
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "f3_encode_mnist.npz"))
+    assert torch.equal(images[:16], torch.from_numpy(d["images"]))
+    assert torch.equal(idx.view(1024, 49)[:16].cpu(), torch.from_numpy(d["indices"]).view(16, 49))
+
+
+def test_config4_cifar_shaped_b512_sample_properties(dev):
+    """BASELINE config 4 (CIFAR-shaped 3x32x32, latent 8x8, B=512, T=16): the denoiser runs the 8-tile MFMA variant;
+    a few reverse steps + decode; properties as above + agreement of a slice with a small direct-kernel run."""
+    from snn_model.vq_diffusion import AbsorbingDiffusion
+    den, _ = build_den(synth.CIFAR, dev)
+    model, _ = build_vae(synth.CIFAR, dev)
+    ab = AbsorbingDiffusion(den, mask_id=128, latent_shape=(8, 8))
+    ab.n_samples = 512
+    torch.manual_seed(3)
+    ab._philox_calls = 0
+    tok = ab.sample(temp=1.0, sample_steps=4)
+    assert tok.shape == (512, 1, 8, 8) and int(tok.min()) >= 0 and int(tok.max()) < 128
+    pred, u8 = model.decode_tokens(tok.reshape(512, 8, 8))
+    assert pred.shape == (512, 3, 32, 32) and u8.dtype == torch.uint8 and float(pred.abs().max()) <= 1.0
+    # one denoiser call at B=512 on the MFMA path == the fp64 direct path on a slice of the batch
+    x_t = tok.clone(); x_t[::3] = 128
+    lg = den.logits_from_tokens(x_t, 3)
+    den.conv_impl_request = 'direct'
+    lg_d = den.logits_from_tokens(x_t[100:104].contiguous(), 3)
+    den.conv_impl_request = 'auto'
+    assert float((lg[100:104] - lg_d).abs().max()) <= 1e-6
+
+
+def test_config5_per_rank_shape_b1024(dev):
+    """BASELINE config 5 shards B=8192 over 8 GPUs: 1024 samples per rank. Two reverse steps at that shape + decode;
+    the sharding itself (one uint8 all-gather) is covered on CPU by tests/test_dist_gloo.py."""
+    from snn_model.vq_diffusion import AbsorbingDiffusion
+    from spkdiff import dist as sdist
+    den, _ = build_den(synth.MNIST, dev)
+    model, _ = build_vae(synth.MNIST, dev)
+    ab = AbsorbingDiffusion(den, mask_id=128)
+    ab.n_samples = 1024
+    tok = ab.sample(temp=1.0, sample_steps=2)
+    _, u8 = model.decode_tokens(tok.reshape(1024, 7, 7))
+    out = sdist.gather_images(u8, 1024)
+    assert out.shape == (1024, 1, 28, 28) and out.dtype == torch.uint8 and int(tok.max()) < 128
+    assert sdist.shard_range(8192, 3, 8) == (3072, 4096)
