@@ -136,11 +136,13 @@ int spk_den_build_input(const float* x_float_or_null, const long long* x_tokens_
                         long long t_scalar, float* out_b2hw, int B, int HW, spk_stream_t stream);
 /* Loop body of AbsorbingDiffusion.sample after the denoiser call, R/snn_model/vq_diffusion.py:113-124,134-140.
  * logits [B,K,h,w] fp32; x_t int64 [B*HW]; unmasked u8/bool [B*HW]; u [B*HW] / q [B*HW*K] injected noise or NULL
- * (then Philox4x32-10(seed, offset + index)); x0_hat_out optional int64 [B*HW]. */
+ * (then Philox4x32-10(seed, offset + index)); philox_state optional device {seed, base offset} pair that overrides
+ * the seed and is added to the offset (lets a captured hipGraph draw fresh noise on every replay);
+ * x0_hat_out optional int64 [B*HW]. */
 int spk_psample_step(const float* logits_bkhw, long long* x_t_inout, uint8_t* unmasked_inout, int t, float temp,
                      const float* u_or_null, const float* q_or_null, unsigned long long philox_seed,
-                     unsigned long long philox_offset, long long* x0_hat_out_or_null, int B, int HW, int K,
-                     spk_stream_t stream);
+                     unsigned long long philox_offset, const unsigned long long* philox_state_or_null,
+                     long long* x0_hat_out_or_null, int B, int HW, int K, spk_stream_t stream);
 
 #ifdef __cplusplus
 }

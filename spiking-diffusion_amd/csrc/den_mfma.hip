@@ -355,11 +355,14 @@ int launch(const MfmaArgs& a, hipStream_t stream) {
   const int nt = (ntiles + 3) / 4;
   const size_t lds = 2 * ((size_t)(a.H + 2) * (a.W + 2) * POS_BYTES + W_CHUNK_BYTES);
   if (lds > 160 * 1024) return SPK_ERR_UNSUPPORTED;
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-  }
+  // CU count of the current device, queried once (a constant of the machine; keeps device queries out of hipGraph capture)
+  static const int cus = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      return v;
+    return 256;
+  }();
   const int total = a.B * (a.Cout / 16);
   dim3 grid(total < cus ? total : cus), blk(256);          // persistent: one workgroup per CU
   const int npa = (a.H * ((a.W + 1) / 2) + 3) / 4;

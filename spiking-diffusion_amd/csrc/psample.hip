@@ -60,7 +60,11 @@ __global__ __launch_bounds__(256) void psample_kernel(const float* __restrict__ 
                                                       uint8_t* __restrict__ unmasked, int t, float temp,
                                                       const float* __restrict__ u_in, const float* __restrict__ q_in,
                                                       unsigned long long seed, unsigned long long offset,
+                                                      const unsigned long long* __restrict__ philox_state,
                                                       long long* __restrict__ x0_hat_out, int B, int HW, int K) {
+  // a captured (hipGraph) launch bakes its arguments: the per-call part of the Philox counter then comes from a
+  // 2-word device buffer {seed, base offset} the host updates before each replay
+  if (philox_state) { seed = philox_state[0]; offset += philox_state[1]; }
   const int lane = threadIdx.x & 63;
   const long long npos = (long long)B * HW;
   const float inv_t = 1.0f / (float)t;
@@ -161,7 +165,8 @@ extern "C" int spk_den_build_input(const float* x_float_or_null, const long long
 extern "C" int spk_psample_step(const float* logits_bkhw, long long* x_t_inout, uint8_t* unmasked_inout, int t,
                                 float temp, const float* u_or_null, const float* q_or_null,
                                 unsigned long long philox_seed, unsigned long long philox_offset,
-                                long long* x0_hat_out_or_null, int B, int HW, int K, hipStream_t stream) {
+                                const unsigned long long* philox_state_or_null, long long* x0_hat_out_or_null, int B,
+                                int HW, int K, hipStream_t stream) {
   if (!logits_bkhw || !x_t_inout || !unmasked_inout || t <= 0 || !(temp > 0.f) || B <= 0 || HW <= 0 || K <= 0)
     return SPK_ERR_ARG;
   if (K > 64 * KPL) return SPK_ERR_UNSUPPORTED;
@@ -169,7 +174,7 @@ extern "C" int spk_psample_step(const float* logits_bkhw, long long* x_t_inout, 
   int grid = (int)((npos + 3) / 4);
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(psample_kernel, dim3(grid), dim3(256), 0, stream, logits_bkhw, x_t_inout, unmasked_inout, t, temp,
-                     u_or_null, q_or_null, philox_seed, philox_offset, x0_hat_out_or_null, B, HW, K);
+                     u_or_null, q_or_null, philox_seed, philox_offset, philox_state_or_null, x0_hat_out_or_null, B, HW, K);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

@@ -57,6 +57,11 @@ class AbsorbingDiffusion(Sampler):
         # reference CPU path token for token under the same torch.manual_seed.
         self.noise_source = 'philox'
         self._philox_calls = 0
+        # Replay the whole reverse process as ONE hipGraph (philox mode, no hooks): the ~800 kernel launches of a
+        # 100-step sample are captured once per (batch, steps, temp) and replayed; fresh noise per replay comes from a
+        # 2-word device buffer {seed, counter base} the kernels read (spk_psample_step philox_state).
+        self.use_graph = True
+        self._graphs = {}
 
     def sample_time(self, *args, **kwargs):
         raise NotImplementedError('spkdiff: AbsorbingDiffusion training (sample_time/q_sample/_train_loss) is outside '
@@ -77,13 +82,15 @@ class AbsorbingDiffusion(Sampler):
         b = int(self.n_samples)
         h, w = self.shape
         K = self.num_classes
-        x_t = torch.full((b, 1, h, w), int(self.mask_id), dtype=torch.int64, device=dev)
-        unmasked = torch.zeros((b, 1, h, w), dtype=torch.bool, device=dev)
         if sample_steps is None:
             sample_steps = self.num_timesteps
-        seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
         base = self._philox_calls * (1 << 40)
         self._philox_calls += 1
+        if self.use_graph and noise is None and record is None and self.noise_source == 'philox':
+            return self._sample_graphed(dev, b, h, w, K, float(temp), int(sample_steps), seed, base)
+        x_t = torch.full((b, 1, h, w), int(self.mask_id), dtype=torch.int64, device=dev)
+        unmasked = torch.zeros((b, 1, h, w), dtype=torch.bool, device=dev)
         for t in reversed(range(1, sample_steps + 1)):
             u = q = None
             if noise is not None:
@@ -97,6 +104,50 @@ class AbsorbingDiffusion(Sampler):
             if record is not None:
                 record.append((t, x_t.clone(), unmasked.clone(), logits.clone()))
         return x_t
+
+
+def _weights_key(module):
+    return tuple((p.data_ptr(), p._version) for p in list(module.parameters()) + list(module.buffers()))
+
+
+def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
+    """Capture-once / replay-many form of the loop in ``sample``; same kernels, same results as the eager loop for the
+    same (seed, counter base)."""
+    dn = self._denoise_fn
+    key = (str(dev), b, h, w, K, temp, sample_steps, int(self.mask_id), _weights_key(dn))
+    entry = self._graphs.get(key)
+    if entry is None:
+        self._graphs.clear()                                    # one live graph per sampler (buffers are not small)
+        state = torch.zeros(2, dtype=torch.int64, device=dev)
+        x_t = torch.empty((b, 1, h, w), dtype=torch.int64, device=dev)
+        unmasked = torch.empty((b, 1, h, w), dtype=torch.bool, device=dev)
+
+        def body():
+            x_t.fill_(int(self.mask_id))
+            unmasked.zero_()
+            for t in reversed(range(1, sample_steps + 1)):
+                logits = dn.logits_from_tokens(x_t, t)
+                ops.psample_step(logits, x_t, unmasked, t, temp, None, None, 0, (sample_steps - t) * (b * h * w * K),
+                                 philox_state=state)
+
+        # warm-up on a side stream (weight packing, BN terms, allocator pools), then capture
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            dn.logits_from_tokens(torch.full((b, 1, h, w), int(self.mask_id), dtype=torch.int64, device=dev), 1)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            body()
+        entry = (graph, state, x_t)
+        self._graphs[key] = entry
+    graph, state, x_t = entry
+    state.copy_(torch.tensor([seed, base], dtype=torch.int64), non_blocking=False)
+    graph.replay()
+    return x_t.clone()
+
+
+AbsorbingDiffusion._sample_graphed = _sample_graphed
 
 
 class DummyModel(nn.Module):

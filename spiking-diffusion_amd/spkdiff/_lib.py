@@ -58,7 +58,8 @@ _SIGS = {
     "spk_vq_argmin": (c_int, [P, P, P, c_longlong, c_int, c_int, P]),
     "spk_embedding_fwd": (c_int, [P, P, P, c_longlong, c_int, c_int, c_int, c_int, P]),
     "spk_den_build_input": (c_int, [P, P, P, c_longlong, P, c_int, c_int, P]),
-    "spk_psample_step": (c_int, [P, P, P, c_int, c_float, P, P, c_ulonglong, c_ulonglong, P, c_int, c_int, c_int, P]),
+    "spk_psample_step": (c_int, [P, P, P, c_int, c_float, P, P, c_ulonglong, c_ulonglong, P, P, c_int, c_int, c_int,
+                                 P]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -383,7 +383,7 @@ def den_build_input(x, t, out=None):
     return out
 
 
-def psample_step(logits, x_t, unmasked, t, temp=1.0, u=None, q=None, seed=0, offset=0, x0_hat=None):
+def psample_step(logits, x_t, unmasked, t, temp=1.0, u=None, q=None, seed=0, offset=0, x0_hat=None, philox_state=None):
     """In-place update of x_t (int64) and unmasked (bool/u8) from logits [B,K,h,w]."""
     logits = _dev(logits, "logits", torch.float32)
     B, K = logits.shape[0], logits.shape[1]
@@ -400,6 +400,9 @@ def psample_step(logits, x_t, unmasked, t, temp=1.0, u=None, q=None, seed=0, off
         q = _dev(q, "q", torch.float32)
         if q.numel() != B * HW * K:
             raise ValueError("q must have B*HW*K entries")
+    if philox_state is not None and (philox_state.dtype != torch.int64 or philox_state.numel() != 2):
+        raise ValueError("philox_state must be an int64 device tensor {seed, base offset}")
     check(lib.spk_psample_step(_p(logits), _p(x_t), _p(unmasked), int(t), float(temp), _p(u), _p(q), int(seed),
-                               int(offset), _p(x0_hat), B, HW, K, _stream(logits)), "spk_psample_step")
+                               int(offset), _p(philox_state), _p(x0_hat), B, HW, K, _stream(logits)),
+          "spk_psample_step")
     return x_t, unmasked

@@ -517,6 +517,14 @@ def test_full_sample_properties_b256(dev):
     ab._philox_calls = 0
     tok2 = ab.sample(temp=1.0, sample_steps=6)
     assert torch.equal(tok, tok2), "same seed and counter -> same tokens"
+    assert len(ab._graphs) == 1, "the reverse process was replayed from one captured hipGraph"
+    ab.use_graph = False
+    ab._philox_calls = 0
+    tok3 = ab.sample(temp=1.0, sample_steps=6)
+    ab.use_graph = True
+    assert torch.equal(tok, tok3), "graph replay == eager launches (same kernels, same Philox counters)"
+    tok4 = ab.sample(temp=1.0, sample_steps=6)
+    assert not torch.equal(tok, tok4), "the next call advances the Philox counter base"
     pred, u8 = model.decode_tokens(tok.reshape(256, 7, 7))
     assert pred.shape == (256, 1, 28, 28) and u8.dtype == torch.uint8
     assert float(pred.abs().max()) <= 1.0
