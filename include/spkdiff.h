@@ -92,12 +92,13 @@ int spk_pack_conv_weight(const float* w, float* packed, int Cout, int Cin, int k
  *                out_ptc u8 PTC and/or out_f32 fp32 TBCHW spikes; out_pre optional BN output.
  *   mode RAW:    out_f32 TBCHW conv output.    mode MEMOUT: coef [T]; out_f32 [B,Cout,Ho,Wo] (tanh if apply_tanh),
  *                out_u8 = uint8(clip(p+0.5,0,1)*255) (R/main.py:401).   mode MEAN: out_f32 = sum_t x[t] / T.
- *   chunk0 / chunk1 / chunk_out: channel chunking of in0 / in1 / out_ptc (<= 0: plain PTC). */
+ *   chunk0 / chunk1 / chunk_out: channel chunking of in0 / in1 / out_ptc (<= 0: plain PTC).
+ *   out_counts (mode LIF, optional): per-neuron spike counts over T, u8 [B,Cout/32,Ho*Wo,32]. */
 int spk_conv_fused_fwd(const void* in0, const uint8_t* in1, int C0, int C1, int in_kind, const float* w_packed,
                        const float* bias, const float* bn_a, const float* bn_b, float* v_inout, uint8_t* out_ptc,
                        float* out_f32, float* out_pre, uint8_t* out_u8, const float* coef, int apply_tanh, int mode,
                        int T, int B, int H, int W, int Cout, int k, int stride, int pad, int transposed, int out_pad,
-                       int chunk0, int chunk1, int chunk_out, spk_stream_t stream);
+                       int chunk0, int chunk1, int chunk_out, uint8_t* out_counts, spk_stream_t stream);
 
 /* ---- denoiser convolutions on the matrix cores ------------------------------------------------------------------ */
 /* Bytes of the packed int8 digit-plane weights of one 3x3 layer ([Cout/16][Cin/32][9][2][32][32]); -1 if unsupported. */
@@ -109,11 +110,18 @@ int spk_den_pack_weight_i8(const float* w, const float* bias, int8_t* wq, double
 /* 3x3 / stride 1 / pad 1 convolution over binary spikes (CPTC u8, T = 16) + BN + LIF (mode SPK_MODE_LIF -> out_cptc)
  * or + time mean (mode SPK_MODE_MEAN -> out_f32 [B,Cout,h,w]): DummyModel conv2..conv6,
  * R/snn_model/vq_diffusion.py:166-187,201-206.  in1 (nch1 chunks) is concatenated after in0 along channels.
- * v_inout [B,Cout,h,w] or NULL (fresh LIF state, nothing written back). */
+ * v_inout [B,Cout,h,w] or NULL (fresh LIF state, nothing written back).  out_counts (LIF mode, optional): per-neuron
+ * spike counts over T as u8 [B,Cout/32,h*w,32], the input format of spk_den_conv3x3_counts_mfma. */
 int spk_den_conv3x3_mfma(const uint8_t* in0_cptc, int nch0, const uint8_t* in1_cptc, int nch1, const int8_t* wq,
                          const double* scale, const double* bias_d, const float* bn_a, const float* bn_b,
-                         float* v_inout, uint8_t* out_cptc, float* out_f32, int mode, int T, int B, int H, int W,
-                         int Cout, spk_stream_t stream);
+                         float* v_inout, uint8_t* out_cptc, uint8_t* out_counts, float* out_f32, int mode, int T, int B,
+                         int H, int W, int Cout, spk_stream_t stream);
+/* conv6 + time mean of DummyModel (R/snn_model/vq_diffusion.py:185-187,205-206) in its time-collapsed form:
+ * (sum_t conv(s_t)) / T = (conv_linear(sum_t s_t) + T*bias) / T.  cnt0 / cnt1: spike counts u8 [B,nch,h*w,32]
+ * (channel concat: cnt1 after cnt0); same packed weights as spk_den_conv3x3_mfma; out_f32 [B,Cout,h,w]. */
+int spk_den_conv3x3_counts_mfma(const uint8_t* cnt0, int nch0, const uint8_t* cnt1, int nch1, const int8_t* wq,
+                                const double* scale, const double* bias_d, float* out_f32, int T, int B, int H, int W,
+                                int Cout, spk_stream_t stream);
 
 /* ---- vector quantizer ----------------------------------------------------------------------------------------- */
 /* VectorQuantizer.forward eval up to the codebook gather, R/snn_model/vae_model.py:40-52,87-99.

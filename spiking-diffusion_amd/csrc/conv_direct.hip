@@ -100,6 +100,7 @@ struct FusedArgs {
   const float* coef;    // MODE_MEMOUT: [T]
   int apply_tanh;
   int T, B, H, W, Cout, Ho, Wo, k, stride, pad;
+  uint8_t* out_cnt;     // MODE_LIF, optional: spike counts over T, u8 [B][Cout/32][Ho*Wo][32]
   int chunk0, chunk1, chunk_out;   // channel chunking of the PTC tensors ([B][C/chunk][HW][T][chunk]); chunk == C: plain
 };
 
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(256) void conv_fused_kernel(FusedArgs a) {
       const float al = a.bn_a[co], be = a.bn_b[co];
       float v = a.v_io ? a.v_io[o_bchw] : 0.0f;
       float y0 = 0.f;
+      int nspk = 0;
       if constexpr (TINV) {
         y0 = fmaf((float)acc[0], al, be);
         if (a.out_pre) a.out_pre[o_bchw] = y0;
@@ -214,11 +216,13 @@ __global__ __launch_bounds__(256) void conv_fused_kernel(FusedArgs a) {
             if (a.out_pre) a.out_pre[o_bchw + t * tstride] = y;
           }
           const bool s = spk_lif_step_default(v, y);
+          nspk += s ? 1 : 0;
           if (a.out_ptc) a.out_ptc[o_ptc + (long long)t * a.chunk_out] = (uint8_t)s;
           if (a.out_f32) a.out_f32[o_bchw + t * tstride] = s ? 1.0f : 0.0f;
         }
       }
       if (a.v_io) a.v_io[o_bchw] = v;
+      if (a.out_cnt) a.out_cnt[(((long long)b * (a.Cout >> 5) + (co >> 5)) * plane + oy * a.Wo + ox) * 32 + (co & 31)] = (uint8_t)nspk;
     } else if constexpr (MODE == SPK_MODE_RAW) {
 #pragma unroll
       for (int t = 0; t < SPK_MAX_T; ++t)
@@ -311,7 +315,7 @@ extern "C" int spk_conv_fused_fwd(const void* in0, const uint8_t* in1, int C0, i
                                   float* v_inout, uint8_t* out_ptc, float* out_f32, float* out_pre, uint8_t* out_u8,
                                   const float* coef, int apply_tanh, int mode, int T, int B, int H, int W, int Cout,
                                   int k, int stride, int pad, int transposed, int out_pad, int chunk0, int chunk1,
-                                  int chunk_out, hipStream_t stream) {
+                                  int chunk_out, uint8_t* out_counts, hipStream_t stream) {
   if (!in0 || !w_packed || T <= 0 || T > SPK_MAX_T || B <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0 || k <= 0 ||
       stride <= 0 || pad < 0)
     return SPK_ERR_ARG;
@@ -332,7 +336,8 @@ extern "C" int spk_conv_fused_fwd(const void* in0, const uint8_t* in1, int C0, i
   FusedArgs a;
   a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.wt = w_packed; a.bias = bias; a.bn_a = bn_a; a.bn_b = bn_b;
   a.v_io = v_inout; a.out_ptc = out_ptc; a.out_f32 = out_f32; a.out_pre = out_pre; a.out_u8 = out_u8; a.coef = coef;
-  a.chunk0 = chunk0; a.chunk1 = chunk1; a.chunk_out = chunk_out;
+  a.chunk0 = chunk0; a.chunk1 = chunk1; a.chunk_out = chunk_out; a.out_cnt = out_counts;
+  if (out_counts && (mode != SPK_MODE_LIF || (Cout % 32))) return SPK_ERR_ARG;
   a.apply_tanh = apply_tanh; a.T = T; a.B = B; a.H = H; a.W = W; a.Cout = Cout;
   a.Ho = spk_conv_out_size(H, k, stride, pad, transposed, out_pad);
   a.Wo = spk_conv_out_size(W, k, stride, pad, transposed, out_pad);

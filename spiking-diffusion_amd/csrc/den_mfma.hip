@@ -50,6 +50,7 @@ struct MfmaArgs {
   const uint8_t* in0; const uint8_t* in1; int nch0, nch1;
   const int8_t* wq; const double* scale; const double* bias; const float* bn_a; const float* bn_b;
   uint8_t* out; float* out_f32; float* v_io;
+  uint8_t* out_cnt;   // optional per-neuron spike counts over T, [B][Cout/32][HW][32] (input of the time-collapsed conv6)
   int B, H, W, Cout, mode;
   int dbg;   // -DSPK_MFMA_ABLATION builds only (env SPK_MFMA_DEBUG): 1 = skip steady-state DMA, 2 = skip MFMAs, 4 = skip epilogue
 };
@@ -259,11 +260,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
           const bool pos_ok = p < HW && (ip + 1 < NT || !odd);
           const long long vidx = ((long long)b * a.Cout + co) * HW + (pos_ok ? p : 0);
           float v = a.v_io ? a.v_io[vidx] : 0.f;
-          unsigned bitsv = 0;
+          unsigned bitsv = 0, cnt = 0;
 #define SPK_LIF_STEP(r)                                                                                     \
   {                                                                                                         \
     const float xv = (ip + 1 < NT && odd) ? xb[r] : xa[r];                                                  \
     const bool s = spk_lif_step_default(v, fmaf(xv, bn_a, bn_b)) && pos_ok;                                 \
+    cnt += s ? 1u : 0u;                                                                                     \
     const unsigned long long m = __ballot(s);                                                               \
     const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);                                            \
     bitsv = writelane_imm<r>(bitsv, mlo & 0xffffu);      /* tile ip,   position 0, t = r */                 \
@@ -276,6 +278,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
           SPK_LIF_STEP(12) SPK_LIF_STEP(13) SPK_LIF_STEP(14) SPK_LIF_STEP(15)
 #undef SPK_LIF_STEP
           if (a.v_io && pos_ok) a.v_io[vidx] = v;
+          if (a.out_cnt && pos_ok)
+            a.out_cnt[(((long long)b * (a.Cout >> 5) + (co >> 5)) * HW + p) * CK + (co & 31)] = (uint8_t)cnt;
           // every lane stores one (position, time step): 16 channels = 16 bytes
           if (pos_ok) {
             uint4 o;
@@ -305,6 +309,71 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
       }
     }
   }   // items
+}
+
+// ------------------------------------------------------------------------------------------------ time-collapsed conv6
+// conv6 has no BN / LIF: logits = (sum_t conv6(s_t)) / T = (conv6_linear(sum_t s_t) + T*bias) / T.  The A operand
+// becomes the per-neuron spike COUNT over T (0..16, exact in int8) and the GEMM loses its factor T in M: rows are
+// (image, position) pairs only.  The work is tiny (~0.6 M MFMAs for B = 256), so the kernel is deliberately simple:
+// one wave per 32-row tile x 16 output channels, operands straight from L2 (counts 4 MB, weights 3.7 MB), no LDS.
+// Numerics: sum first, round once -- at least as accurate as the reference's per-step rounding (|diff| <~ 1 ulp).
+struct CntArgs {
+  const uint8_t* c0; const uint8_t* c1; int nch0, nch1;
+  const int8_t* wq; const double* scale; const double* bias; float* out;
+  int B, H, W, Cout, T;
+};
+
+__global__ __launch_bounds__(256) void conv3x3_counts_mfma_kernel(CntArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int HW = a.H * a.W;
+  const long long nrows = (long long)a.B * HW;
+  const long long tile = (long long)blockIdx.x * 4 + wave;
+  if (tile * 32 >= nrows) return;
+  const int g = blockIdx.y;
+  const int nchunks = a.nch0 + a.nch1;
+  const int row = lane & 31, half = lane >> 5;
+  const long long R = tile * 32 + row;
+  const bool rvalid = R < nrows;
+  const int b = rvalid ? (int)(R / HW) : 0, p = rvalid ? (int)(R % HW) : 0;
+  const int y = p / a.W, x = p % a.W;
+  const int boff = (lane & 31) * CK + 16 * (half ^ ((lane >> 4) & 1));
+  v16i acc0 = {0}, acc1 = {0};
+  for (int c = 0; c < nchunks; ++c) {
+    const uint8_t* src = c < a.nch0 ? a.c0 + ((long long)b * a.nch0 + c) * HW * CK
+                                    : a.c1 + ((long long)b * a.nch1 + (c - a.nch0)) * HW * CK;
+    const int8_t* wsrc = a.wq + ((long long)g * nchunks + c) * W_CHUNK_BYTES + boff;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+      const bool ok = rvalid && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+      v4i av = {0, 0, 0, 0};
+      if (ok) av = *reinterpret_cast<const v4i*>(src + (long long)(yy * a.W + xx) * CK + 16 * half);
+      const v4i b0 = *reinterpret_cast<const v4i*>(wsrc + (tap * 2 + 0) * 32 * CK);
+      const v4i b1 = *reinterpret_cast<const v4i*>(wsrc + (tap * 2 + 1) * 32 * CK);
+      acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b1, acc1, 0, 0, 0);
+    }
+  }
+  const int col = lane & 31, ch = col & 15, odd = col >> 4;
+  const int co = g * 16 + ch;
+  const double sc = a.scale[co], bT = a.bias[co] * (double)a.T;
+  const float invT = 1.0f / (float)a.T;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    // after the swaps the even lane holds all four digits of accumulator row r, the odd lane those of row r + 8
+    const v2u p01 = __builtin_amdgcn_permlane16_swap((unsigned)acc0[r], (unsigned)acc0[r + 8], false, false);
+    const v2u p23 = __builtin_amdgcn_permlane16_swap((unsigned)acc1[r], (unsigned)acc1[r + 8], false, false);
+    const long long hi = (long long)(int)p01[0] * 256 + (int)p01[1], lo = (long long)(int)p23[0] * 256 + (int)p23[1];
+    const double s = fma((double)hi, 65536.0, (double)lo);
+    const float xsum = (float)fma(s, sc, bT);                       // sum over T of the pre-activations, rounded once
+    const int rr = r + 8 * odd;
+    const int orow = (rr & 3) + 8 * (rr >> 2) + 4 * half;           // accumulator row of register rr
+    const long long Ro = tile * 32 + orow;
+    if (Ro < nrows) {
+      const int ob = (int)(Ro / HW), op = (int)(Ro % HW);
+      a.out[((long long)ob * a.Cout + co) * HW + op] = xsum * invT;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ weight packing
@@ -403,17 +472,35 @@ extern "C" int spk_den_pack_weight_i8(const float* w, const float* bias, int8_t*
   return SPK_OK;
 }
 
+extern "C" int spk_den_conv3x3_counts_mfma(const uint8_t* cnt0, int nch0, const uint8_t* cnt1, int nch1,
+                                           const int8_t* wq, const double* scale, const double* bias_d, float* out_f32,
+                                           int T, int B, int H, int W, int Cout, hipStream_t stream) {
+  if (!cnt0 || nch0 <= 0 || nch1 < 0 || (nch1 > 0 && !cnt1) || !wq || !scale || !bias_d || !out_f32 || B <= 0 ||
+      H <= 0 || W <= 0 || Cout <= 0 || T <= 0)
+    return SPK_ERR_ARG;
+  if (T > 127 || (Cout % 16)) return SPK_ERR_UNSUPPORTED;      // counts must fit the signed int8 A operand
+  CntArgs a;
+  a.c0 = cnt0; a.c1 = cnt1; a.nch0 = nch0; a.nch1 = nch1; a.wq = wq; a.scale = scale; a.bias = bias_d; a.out = out_f32;
+  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.T = T;
+  const long long tiles = ((long long)B * H * W + 31) / 32;
+  dim3 grid((unsigned)((tiles + 3) / 4), Cout / 16), blk(256);
+  hipLaunchKernelGGL(conv3x3_counts_mfma_kernel, grid, blk, 0, stream, a);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
 extern "C" int spk_den_conv3x3_mfma(const uint8_t* in0_cptc, int nch0, const uint8_t* in1_cptc, int nch1,
                                     const int8_t* wq, const double* scale, const double* bias_d, const float* bn_a,
-                                    const float* bn_b, float* v_inout, uint8_t* out_cptc, float* out_f32, int mode,
-                                    int T, int B, int H, int W, int Cout, hipStream_t stream) {
+                                    const float* bn_b, float* v_inout, uint8_t* out_cptc, uint8_t* out_counts,
+                                    float* out_f32, int mode, int T, int B, int H, int W, int Cout,
+                                    hipStream_t stream) {
   if (!in0_cptc || nch0 <= 0 || nch1 < 0 || (nch1 > 0 && !in1_cptc) || !wq || !scale || !bias_d || B <= 0 || H <= 0 ||
       W <= 0 || Cout <= 0)
     return SPK_ERR_ARG;
   if (T != T16 || (Cout % 32)) return SPK_ERR_UNSUPPORTED;
   MfmaArgs a;
   a.in0 = in0_cptc; a.in1 = in1_cptc; a.nch0 = nch0; a.nch1 = nch1; a.wq = wq; a.scale = scale; a.bias = bias_d;
-  a.bn_a = bn_a; a.bn_b = bn_b; a.out = out_cptc; a.out_f32 = out_f32; a.v_io = v_inout; a.B = B; a.H = H; a.W = W;
+  a.bn_a = bn_a; a.bn_b = bn_b; a.out = out_cptc; a.out_f32 = out_f32; a.v_io = v_inout; a.out_cnt = out_counts; a.B = B; a.H = H; a.W = W;
   a.Cout = Cout; a.mode = mode;
   { const char* e = getenv("SPK_MFMA_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   if (mode == SPK_MODE_LIF) {

@@ -180,6 +180,9 @@ class DummyModel(nn.Module):
     # 'mfma-i8x4': conv2..conv6 on the matrix cores (4 exact int8 digit planes); 'direct-f64': fp64-accumulating
     # direct kernels.  Both return the same correctly rounded pre-activations; 'auto' picks MFMA when T == 16.
     conv_impl_request = 'auto'
+    # conv6 + mean over T evaluated as ONE convolution of the per-neuron spike counts (exact linearity; the sum over T
+    # is rounded once instead of T times: logits agree with the per-step form to ~1 ulp).  False = per-step form.
+    collapse_conv6 = True
 
     @property
     def conv_impl(self):
@@ -191,18 +194,31 @@ class DummyModel(nn.Module):
         T = self.n_steps
         impl = 'direct' if self.conv_impl_request == 'direct' else 'auto'
         # spikes travel channel-chunked (CPTC, 32 channels per chunk): the layout the MFMA kernel stages per K chunk
+        collapse = self.conv_impl == 'mfma-i8x4' and self.collapse_conv6
         with ops.timed('den.conv1'):
-            x1 = self.conv1.run(inp_b2hw, IN_TINV, final='ptc', T=T, stateful=stateful, chunk_out=32)['ptc']
+            r1 = self.conv1.run(inp_b2hw, IN_TINV, final='ptc', T=T, stateful=stateful, chunk_out=32,
+                                want_counts=collapse)
+        x1 = r1['ptc']
         x = x1
         outs = [x1]
+        cnt5 = None
         for name, blk in (('den.conv2', self.conv2), ('den.conv3', self.conv3), ('den.conv4', self.conv4),
                           ('den.conv5', self.conv5)):
             with ops.timed(name):
-                x = blk.run(x, IN_PTC, final='ptc', stateful=stateful, chunk_out=32, impl=impl)['ptc']
+                r = blk.run(x, IN_PTC, final='ptc', stateful=stateful, chunk_out=32, impl=impl,
+                            want_counts=collapse and blk is self.conv5)
+            x, cnt5 = r['ptc'], r['cnt']
             outs.append(x)
         if record is not None:
             record.extend(outs)
         with ops.timed('den.conv6'):
+            if collapse and cnt5 is not None and r1['cnt'] is not None:
+                # conv6 is linear and followed by the mean over T: convolve the spike COUNTS once instead of T frames
+                conv = self.conv6[0]
+                if not hasattr(conv, '_spk_params'):
+                    from spkdiff.fused import ConvParams
+                    object.__setattr__(conv, '_spk_params', ConvParams())
+                return ops.den_conv3x3_counts(cnt5, conv._spk_params.get_i8(conv), conv.out_channels, T, cnt1=r1['cnt'])
             return self.conv6.run(x, IN_PTC, final='mean', in1=x1, impl=impl)['f32']
 
     def forward(self, x, t) -> torch.Tensor:

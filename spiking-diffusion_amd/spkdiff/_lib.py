@@ -49,11 +49,12 @@ _SIGS = {
     "spk_pack_conv_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spk_conv_fused_fwd": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int,
                                    c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                   c_int, c_int, c_int, P]),
+                                   c_int, c_int, c_int, P, P]),
     "spk_den_packed_weight_bytes": (c_longlong, [c_int, c_int]),
     "spk_den_pack_weight_i8": (c_int, [P, P, P, P, P, c_int, c_int, P]),
-    "spk_den_conv3x3_mfma": (c_int, [P, c_int, P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int,
+    "spk_den_conv3x3_mfma": (c_int, [P, c_int, P, c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int,
                                      c_int, P]),
+    "spk_den_conv3x3_counts_mfma": (c_int, [P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_vq_readout_argmin": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_vq_argmin": (c_int, [P, P, P, c_longlong, c_int, c_int, P]),
     "spk_embedding_fwd": (c_int, [P, P, P, c_longlong, c_int, c_int, c_int, c_int, P]),

@@ -100,7 +100,7 @@ class FusedSequential(nn.Sequential):
         return self.run(x, IN_SEQ, final='f32')['f32']
 
     def run(self, x, in_kind, final='f32', T=None, in1=None, coef=None, apply_tanh=False, want_u8=False,
-            stateful=True, want_pre=False, chunk_out=None, impl='auto'):
+            stateful=True, want_pre=False, chunk_out=None, impl='auto', want_counts=False):
         """Run all blocks fused.
 
         x: per in_kind (IN_SEQ fp32 [T,B,C,H,W]; IN_TINV fp32 [B,C,H,W] with ``T`` given; IN_PTC u8 [B,H,W,T,C]).
@@ -120,7 +120,7 @@ class FusedSequential(nn.Sequential):
         elif T is None:
             raise ValueError('T is required for a time-invariant input')
         cur, kind = x, in_kind
-        out = {'ptc': None, 'f32': None, 'u8': None, 'pre': []}
+        out = {'ptc': None, 'f32': None, 'u8': None, 'pre': [], 'cnt': None}
         for bi, (conv, bn, lif) in enumerate(blocks):
             last = bi == len(blocks) - 1
             if not hasattr(conv, '_spk_params'):
@@ -147,8 +147,11 @@ class FusedSequential(nn.Sequential):
                             raise RuntimeError(f'LIFNode state has shape {tuple(lif.v.shape)} but the input implies '
                                                f'{shape}; call functional.reset_net first')
                         v = lif.v
-                    o = ops.den_conv3x3_mfma(cur, packed, conv.out_channels, mode=MODE_LIF, in1=src1, bn_a=a, bn_b=b, v=v)
-                    if last:
+                    o = ops.den_conv3x3_mfma(cur, packed, conv.out_channels, mode=MODE_LIF, in1=src1, bn_a=a, bn_b=b, v=v,
+                                             want_counts=last and want_counts)
+                    if last and want_counts:
+                        out['ptc'], out['cnt'] = o
+                    elif last:
                         out['ptc'] = o
                     else:
                         cur, kind = o, IN_PTC
@@ -177,11 +180,11 @@ class FusedSequential(nn.Sequential):
                 r = ops.conv_fused(cur, w_packed, bias, in_kind=kind, T=T, mode=MODE_LIF, in1=src1, bn_a=a, bn_b=b,
                                    v=v, want_ptc=(not last) or final in ('ptc', 'both'),
                                    want_f32=last and final in ('f32', 'both'), want_pre=want_pre,
-                                   chunk_out=(chunk_out if last else None), **geo)
+                                   chunk_out=(chunk_out if last else None), want_counts=last and want_counts, **geo)
                 if want_pre:
                     out['pre'].append(r['pre'])
                 if last:
-                    out['ptc'], out['f32'] = r['ptc'], r['f32']
+                    out['ptc'], out['f32'], out['cnt'] = r['ptc'], r['f32'], r['cnt']
                 else:
                     cur, kind = r['ptc'], IN_PTC
             else:

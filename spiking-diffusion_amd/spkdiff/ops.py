@@ -199,7 +199,7 @@ IN_PTC, IN_TINV, IN_SEQ = 0, 1, 2
 
 def conv_fused(in0, w_packed, bias, *, in_kind, T, mode, k, stride, pad, transposed=False, out_pad=0, in1=None,
                bn_a=None, bn_b=None, v=None, want_ptc=False, want_f32=False, want_pre=False, want_u8=False,
-               coef=None, apply_tanh=False, out_ptc=None, out_f32=None, chunk_out=None):
+               coef=None, apply_tanh=False, out_ptc=None, out_f32=None, chunk_out=None, want_counts=False):
     """Launch spk_conv_fused_fwd. Returns dict(ptc=, f32=, pre=, u8=).
 
     in_kind IN_PTC: in0 u8 [B,H,W,T,C0] (+ in1 [B,H,W,T,C1]);  IN_TINV: in0 fp32 [B,C0,H,W];
@@ -237,8 +237,10 @@ def conv_fused(in0, w_packed, bias, *, in_kind, T, mode, k, stride, pad, transpo
     if Cin != C0 + C1 or kk != k * k:
         raise ValueError(f"packed weight {tuple(w_packed.shape)} does not match Cin={C0 + C1}, k={k}")
     Ho, Wo = conv_out_size(H, k, stride, pad, transposed, out_pad), conv_out_size(W, k, stride, pad, transposed, out_pad)
-    res = {"ptc": None, "f32": None, "pre": None, "u8": None}
+    res = {"ptc": None, "f32": None, "pre": None, "u8": None, "cnt": None}
     if mode == MODE_LIF:
+        if want_counts:
+            res["cnt"] = torch.empty((B, Cout // 32, Ho, Wo, 32), dtype=torch.uint8, device=dev)
         if want_ptc:
             shape = (B, Ho, Wo, T, Cout) if not chunk_out else (B, Cout // chunk_out, Ho, Wo, T, chunk_out)
             res["ptc"] = out_ptc if out_ptc is not None else torch.empty(shape, dtype=torch.uint8, device=dev)
@@ -260,7 +262,8 @@ def conv_fused(in0, w_packed, bias, *, in_kind, T, mode, k, stride, pad, transpo
     check(lib.spk_conv_fused_fwd(
         _p(in0), _p(in1), C0, C1, in_kind, _p(w_packed), _p(bias), _p(bn_a), _p(bn_b), _p(v), _p(res["ptc"]),
         _p(res["f32"]), _p(res["pre"]), _p(res["u8"]), _p(coef), int(apply_tanh), mode, T, B, H, W, Cout, k, stride,
-        pad, int(transposed), out_pad, chunk0, chunk1, chunk_out or 0, _stream(in0)), "spk_conv_fused_fwd")
+        pad, int(transposed), out_pad, chunk0, chunk1, chunk_out or 0, _p(res["cnt"]), _stream(in0)),
+        "spk_conv_fused_fwd")
     return res
 
 
@@ -289,9 +292,9 @@ def den_pack_weight_i8(w, bias):
     return wq, scale, bias_d
 
 
-def den_conv3x3_mfma(in0, packed, Cout, *, mode, in1=None, bn_a=None, bn_b=None, v=None, out=None):
-    """in0/in1: CPTC u8 [B, C/32, H, W, 16, 32]. mode LIF -> CPTC spikes [B, Cout/32, H, W, 16, 32];
-    mode MEAN -> fp32 [B, Cout, H, W]."""
+def den_conv3x3_mfma(in0, packed, Cout, *, mode, in1=None, bn_a=None, bn_b=None, v=None, out=None, want_counts=False):
+    """in0/in1: CPTC u8 [B, C/32, H, W, 16, 32]. mode LIF -> CPTC spikes [B, Cout/32, H, W, 16, 32]
+    (or (spikes, counts u8 [B, Cout/32, H, W, 32]) with want_counts); mode MEAN -> fp32 [B, Cout, H, W]."""
     in0 = _dev(in0, "in0", torch.uint8)
     B, nch0, H, W, T, chunk = in0.shape
     if chunk != 32:
@@ -306,10 +309,32 @@ def den_conv3x3_mfma(in0, packed, Cout, *, mode, in1=None, bn_a=None, bn_b=None,
         out_c = out if out is not None else torch.empty((B, Cout // 32, H, W, T, 32), dtype=torch.uint8, device=in0.device)
     else:
         out_f = out if out is not None else torch.empty((B, Cout, H, W), dtype=torch.float32, device=in0.device)
+    cnt = None
+    if want_counts and mode == MODE_LIF:
+        cnt = torch.empty((B, Cout // 32, H, W, 32), dtype=torch.uint8, device=in0.device)
     check(lib.spk_den_conv3x3_mfma(_p(in0), nch0, _p(in1), nch1, _p(wq), _p(scale), _p(bias_d), _p(bn_a), _p(bn_b),
-                                   _p(v), _p(out_c), _p(out_f), mode, T, B, H, W, Cout, _stream(in0)),
+                                   _p(v), _p(out_c), _p(cnt), _p(out_f), mode, T, B, H, W, Cout, _stream(in0)),
           "spk_den_conv3x3_mfma")
-    return out_c if mode == MODE_LIF else out_f
+    if mode == MODE_LIF:
+        return (out_c, cnt) if want_counts else out_c
+    return out_f
+
+
+def den_conv3x3_counts(cnt0, packed, Cout, T, cnt1=None):
+    """Time-collapsed conv6: cnt0/cnt1 u8 spike counts [B, C/32, H, W, 32] -> logits fp32 [B, Cout, H, W]."""
+    cnt0 = _dev(cnt0, "cnt0", torch.uint8)
+    B, nch0, H, W, ck = cnt0.shape
+    if ck != 32:
+        raise ValueError("counts are 32-channel chunked")
+    nch1 = 0
+    if cnt1 is not None:
+        cnt1 = _dev(cnt1, "cnt1", torch.uint8)
+        nch1 = cnt1.shape[1]
+    wq, scale, bias_d = packed
+    out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=cnt0.device)
+    check(lib.spk_den_conv3x3_counts_mfma(_p(cnt0), nch0, _p(cnt1), nch1, _p(wq), _p(scale), _p(bias_d), _p(out), T, B,
+                                          H, W, Cout, _stream(cnt0)), "spk_den_conv3x3_counts_mfma")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------- VQ

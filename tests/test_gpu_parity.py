@@ -662,3 +662,33 @@ def test_config5_per_rank_shape_b1024(dev):
     out = sdist.gather_images(u8, 1024)
     assert out.shape == (1024, 1, 28, 28) and out.dtype == torch.uint8 and int(tok.max()) < 128
     assert sdist.shard_range(8192, 3, 8) == (3072, 4096)
+
+
+@pytest.mark.parametrize("tag,cfg", [("mnist", synth.MNIST), ("cifar", synth.CIFAR)])
+def test_conv6_time_collapsed_form(golden_dir, dev, ops, tag, cfg):
+    """conv6 + mean over T as one convolution of the spike counts (spk_den_conv3x3_counts_mfma) against the per-step
+    form and the reference logits; the count tensors against the spikes they summarise."""
+    from spkdiff.ops import IN_PTC
+    d = load(golden_dir, f"f5_denoiser_{tag}.npz")
+    den, sd = build_den(cfg, dev)
+    s5 = unpack(d["s5_bits"], d["s5_shape"]); s1 = unpack(d["s1_bits"], d["s1_shape"]); s4 = unpack(d["s4_bits"], d["s4_shape"])
+    x4 = ops.spikes_to_ptc(s4.to(dev), chunk=32)
+    r = den.conv5.run(x4, IN_PTC, final='ptc', stateful=False, chunk_out=32, want_counts=True)
+    got5 = ops.ptc_to_spikes(r['ptc']).cpu()                                  # [T,B,C,H,W]
+    cnt = r['cnt'].cpu()                                                       # [B,C/32,H,W,32]
+    B, C = got5.shape[1], got5.shape[2]
+    want_cnt = got5.sum(0).view(B, C // 32, 32, *got5.shape[3:]).permute(0, 1, 3, 4, 2)
+    assert torch.equal(cnt.float(), want_cnt)
+    x_t = torch.from_numpy(d["x_t"]).to(dev)
+    with torch.inference_mode():
+        den.collapse_conv6 = True
+        a = den.logits_from_tokens(x_t, 7)
+        den.collapse_conv6 = False
+        b = den.logits_from_tokens(x_t, 7)
+        den.collapse_conv6 = True
+        full = den(x_t.float(), t=torch.from_numpy(d["t"]).to(dev))
+        from snn_model.vq_diffusion import functional
+        functional.reset_net(den)
+    print(f"conv6 collapsed vs per-step: max abs diff {float((a - b).abs().max()):.3e}")
+    assert float((a - b).abs().max()) <= 2e-7
+    assert float((full.cpu() - torch.from_numpy(d["logits"])).abs().max()) <= 1e-5
