@@ -88,7 +88,14 @@ class AbsorbingDiffusion(Sampler):
         base = self._philox_calls * (1 << 40)
         self._philox_calls += 1
         if self.use_graph and noise is None and record is None and self.noise_source == 'philox':
-            return self._sample_graphed(dev, b, h, w, K, float(temp), int(sample_steps), seed, base)
+            try:
+                return self._sample_graphed(dev, b, h, w, K, float(temp), int(sample_steps), seed, base)
+            except RuntimeError as e:          # capture refused (e.g. another thread touched the device): same kernels,
+                import warnings                # issued one by one
+                warnings.warn(f'spkdiff: hipGraph capture of the sampler failed ({e}); launching eagerly')
+                self.use_graph = False
+                self._graphs.clear()
+                torch.cuda.synchronize(dev)
         x_t = torch.full((b, 1, h, w), int(self.mask_id), dtype=torch.int64, device=dev)
         unmasked = torch.zeros((b, 1, h, w), dtype=torch.bool, device=dev)
         for t in reversed(range(1, sample_steps + 1)):
@@ -137,7 +144,7 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
             dn.logits_from_tokens(torch.full((b, 1, h, w), int(self.mask_id), dtype=torch.int64, device=dev), 1)
         torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             body()
         entry = (graph, state, x_t)
         self._graphs[key] = entry
