@@ -28,11 +28,13 @@
 //     chunk.  LDS fragment reads are software pipelined two fragments ahead of the MFMA that consumes them.
 //   * LDS images are XOR-swizzled at 16-B granularity (A: by t >= 8 through the DMA source lane; W: by column >= 16,
 //     baked into the packed weights) so that every ds_read_b128 of a fragment is bank-conflict free.
-//   * Spike emission: one wave ballot per time step gathers the 16 channels of both positions; lane t expands its
-//     16 bits to 16 bytes and writes ONE 16-byte store per (position, time step).
+//   * Spike emission: every lane collects the 16 spike bits of its neuron; a 16x16 bit-matrix transpose inside each
+//     16-lane row (4 DPP exchange rounds) hands lane t the 16 channel bits of step t, which it expands to 16 bytes and
+//     writes as ONE 16-byte store per (position, time step).
 #include "spk_common.h"
 #include "../../include/spkdiff.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -60,6 +62,21 @@ template <int L>
 __device__ __forceinline__ unsigned writelane_imm(unsigned old, unsigned uniform_val) {
   asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(uniform_val), "n"(L));
   return old;
+}
+
+// 16x16 bit-matrix transpose inside every 16-lane row (lane = row, bit = column) with DPP lane exchanges:
+// lane^8 = row_mirror o row_half_mirror, lane^4 = row_half_mirror o quad-reverse, lane^2 / lane^1 = quad_perm.
+__device__ __forceinline__ unsigned transpose16_rows(unsigned x, int lane) {
+  unsigned y;
+  y = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(x, 0x140, 0xF, 0xF, true), 0x141, 0xF, 0xF, true);
+  x = (lane & 8) ? (((y >> 8) & 0x00FFu) | (x & 0xFF00u)) : ((x & 0x00FFu) | ((y & 0x00FFu) << 8));
+  y = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
+  x = (lane & 4) ? (((y >> 4) & 0x0F0Fu) | (x & 0xF0F0u)) : ((x & 0x0F0Fu) | ((y & 0x0F0Fu) << 4));
+  y = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);
+  x = (lane & 2) ? (((y >> 2) & 0x3333u) | (x & 0xCCCCu)) : ((x & 0x3333u) | ((y & 0x3333u) << 2));
+  y = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);
+  x = (lane & 1) ? (((y >> 1) & 0x5555u) | (x & 0xAAAAu)) : ((x & 0x5555u) | ((y & 0x5555u) << 1));
+  return x;
 }
 
 #define SPK_LDS(p) ((__attribute__((address_space(3))) void*)(p))
@@ -157,12 +174,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
   int it = 0;                                      // running chunk counter: LDS buffer = it & 1
   if ((int)blockIdx.x < total) issue_dma(blockIdx.x, 0, 0);
   for (int item = blockIdx.x; item < total; item += gridDim.x) {
-    v16i acc[NT][2];
+    v16i acc[NT][2];      // written (not accumulated) by tap 0 of the first chunk: no explicit zeroing
+#ifdef SPK_NO_PEEL
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0; acc[i][1][r] = 0; }
     }
+#endif
     // epilogue constants of this item's channel: loaded now, their latency hides under the K loop
     const int b = item / G, g = item - b * G;
     const int co = g * 16 + ch;
@@ -183,8 +202,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
     uint8_t* const n_dA = sA + (buf ^ 1) * A_BYTES;
     uint8_t* const n_dW = sW + (buf ^ 1) * W_CHUNK_BYTES;
 
-    // ---------------- 9 taps x NT row tiles x 2 column tiles, fragments read two steps ahead -------------------
-    {
+    // ---------------- 9 taps x NT row tiles x 2 column tiles, fragments read four steps ahead ------------------
+    // FIRST (the first K chunk of an item): tap 0 starts every accumulator from a zero C operand instead of zeroing
+    // 224 accumulator registers by hand before the loop.
+    auto compute = [&](auto first_tag) {
+      constexpr bool FIRST = decltype(first_tag)::value;
       const uint8_t* A = sA + buf * A_BYTES;
       const uint8_t* Wb = sW + buf * W_CHUNK_BYTES + b_off;
       auto lda = [&](int s) -> v4i {
@@ -208,8 +230,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
           bn1 = *reinterpret_cast<const v4i*>(Wb + ((tap + 1) * 2 + 1) * 32 * CK);
         }
         if (!(DBG & 2)) {
-          acc[i][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bc0, acc[i][0], 0, 0, 0);
-          acc[i][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bc1, acc[i][1], 0, 0, 0);
+          if (FIRST && tap == 0) {
+            const v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            acc[i][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bc0, z, 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bc1, z, 0, 0, 0);
+          } else {
+            acc[i][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bc0, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bc1, acc[i][1], 0, 0, 0);
+          }
         } else {
           acc[i][0][0] += av[0] + bc0[1]; acc[i][1][0] += av[1] + bc1[0];
         }
@@ -224,7 +252,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);     // keep the read-ahead distance: hipcc otherwise sinks every ds_read
       }                                         // to just before its MFMA (one exposed LDS latency per tile)
-    }
+    };
+#ifdef SPK_NO_PEEL
+    compute(std::false_type{});
+#else
+    if (c == 0) compute(std::true_type{}); else compute(std::false_type{});
+#endif
 
     }   // chunks
     if (!(DBG & 4)) {
@@ -248,8 +281,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
       };
       if (MODE == SPK_MODE_LIF) {
         // Both partner lanes now hold the same 16 pre-activations, so the LIF scan runs on TWO row tiles at once: even
-        // lanes scan tile ip, odd lanes tile ip + 1.  The ballot of time step r then carries 4 positions x 16 channels;
-        // v_writelane drops each 16-bit group into the lane that will store it: lane (pos_half*32 + parity*16 + r).
+        // lanes scan tile ip, odd lanes tile ip + 1.  Each lane collects its neuron's 16 spike bits; a DPP bit-matrix
+        // transpose inside every 16-lane row (= 16 channels of one position) turns them into per-time-step channel masks.
 #pragma unroll
         for (int ip = 0; ip < NT; ip += 2) {
           float xa[16], xb[16];
@@ -260,23 +293,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
           const bool pos_ok = p < HW && (ip + 1 < NT || !odd);
           const long long vidx = ((long long)b * a.Cout + co) * HW + (pos_ok ? p : 0);
           float v = a.v_io ? a.v_io[vidx] : 0.f;
-          unsigned bitsv = 0, cnt = 0;
-#define SPK_LIF_STEP(r)                                                                                     \
-  {                                                                                                         \
-    const float xv = (ip + 1 < NT && odd) ? xb[r] : xa[r];                                                  \
-    const bool s = spk_lif_step_default(v, fmaf(xv, bn_a, bn_b)) && pos_ok;                                 \
-    cnt += s ? 1u : 0u;                                                                                     \
-    const unsigned long long m = __ballot(s);                                                               \
-    const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);                                            \
-    bitsv = writelane_imm<r>(bitsv, mlo & 0xffffu);      /* tile ip,   position 0, t = r */                 \
-    bitsv = writelane_imm<16 + r>(bitsv, mlo >> 16);     /* tile ip+1, position 0 */                        \
-    bitsv = writelane_imm<32 + r>(bitsv, mhi & 0xffffu); /* tile ip,   position 1 */                        \
-    bitsv = writelane_imm<48 + r>(bitsv, mhi >> 16);     /* tile ip+1, position 1 */                        \
-  }
-          SPK_LIF_STEP(0) SPK_LIF_STEP(1) SPK_LIF_STEP(2) SPK_LIF_STEP(3) SPK_LIF_STEP(4) SPK_LIF_STEP(5)
-          SPK_LIF_STEP(6) SPK_LIF_STEP(7) SPK_LIF_STEP(8) SPK_LIF_STEP(9) SPK_LIF_STEP(10) SPK_LIF_STEP(11)
-          SPK_LIF_STEP(12) SPK_LIF_STEP(13) SPK_LIF_STEP(14) SPK_LIF_STEP(15)
-#undef SPK_LIF_STEP
+          unsigned mybits = 0;                    // bit r = this lane's neuron fired at t = r
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float xv = (ip + 1 < NT && odd) ? xb[r] : xa[r];
+            const bool s = spk_lif_step_default(v, fmaf(xv, bn_a, bn_b)) && pos_ok;
+            mybits |= s ? (1u << r) : 0u;
+          }
+          const unsigned cnt = __popc(mybits);
+          // lanes of a 16-lane row are the 16 channels of one (tile, position): transposing the 16x16 bit matrix gives
+          // lane t the 16 channel bits of time step t -- the 16 bytes it stores
+          const unsigned bitsv = transpose16_rows(mybits, lane);
           if (a.v_io && pos_ok) a.v_io[vidx] = v;
           if (a.out_cnt && pos_ok)
             a.out_cnt[(((long long)b * (a.Cout >> 5) + (co >> 5)) * HW + p) * CK + (co & 31)] = (uint8_t)cnt;

@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_longlong, c_ulonglong, c_void_p
 import torch  # noqa: F401  (must precede the dlopen below: shares torch's HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspkdiff.so")
+LIB_PATH = os.environ.get("SPKDIFF_LIB") or os.path.join(_HERE, "libspkdiff.so")   # SPKDIFF_LIB: A/B builds
 
 
 class SpkdiffError(RuntimeError):
