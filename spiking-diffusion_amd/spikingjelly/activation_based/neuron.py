@@ -15,21 +15,17 @@ from . import base, surrogate
 
 
 class BaseNode(base.MemoryModule):
-    def __init__(self, v_threshold: float = 1., v_reset: float = 0.,
-                 surrogate_function: Callable = surrogate.Sigmoid(), detach_reset: bool = False,
-                 step_mode='s', backend='torch', store_v_seq: bool = False):
-        assert isinstance(v_reset, float) or v_reset is None
-        assert isinstance(v_threshold, float)
-        assert isinstance(detach_reset, bool)
+    def __init__(self, v_threshold: float = 1., v_reset: float = 0., surrogate_function: Callable = surrogate.Sigmoid(),
+                 detach_reset: bool = False, step_mode='s', backend='torch', store_v_seq: bool = False):
+        for name, val, ok in (('v_reset', v_reset, v_reset is None or isinstance(v_reset, float)),
+                              ('v_threshold', v_threshold, isinstance(v_threshold, float)),
+                              ('detach_reset', detach_reset, isinstance(detach_reset, bool))):
+            assert ok, f'{name}={val!r} has the wrong type'
         super().__init__()
-        self.register_memory('v', 0. if v_reset is None else v_reset)
-        self.v_threshold = v_threshold
-        self.v_reset = v_reset
-        self.detach_reset = detach_reset
+        self.register_memory('v', v_reset if v_reset is not None else 0.)      # membrane potential, float until first use
+        self.v_threshold, self.v_reset, self.detach_reset = v_threshold, v_reset, detach_reset
         self.surrogate_function = surrogate_function
-        self.step_mode = step_mode
-        self.backend = backend
-        self.store_v_seq = store_v_seq
+        self.step_mode, self.backend, self.store_v_seq = step_mode, backend, store_v_seq
 
     @property
     def store_v_seq(self):
@@ -42,8 +38,8 @@ class BaseNode(base.MemoryModule):
         self._store_v_seq = False
 
     def extra_repr(self):
-        return (f'v_threshold={self.v_threshold}, v_reset={self.v_reset}, detach_reset={self.detach_reset}, '
-                f'step_mode={self.step_mode}, backend={self.backend}')
+        fields = ('v_threshold', 'v_reset', 'detach_reset', 'step_mode', 'backend')
+        return ', '.join(f'{k}={getattr(self, k)}' for k in fields)
 
     def v_float_to_tensor(self, x: torch.Tensor):
         """SJ/activation_based/neuron.py:260-263: expand the float state to x's shape on first use."""
@@ -55,10 +51,9 @@ class LIFNode(BaseNode):
     def __init__(self, tau: float = 2., decay_input: bool = True, v_threshold: float = 1.,
                  v_reset: float = 0., surrogate_function: Callable = surrogate.Sigmoid(),
                  detach_reset: bool = False, step_mode='s', backend='torch', store_v_seq: bool = False):
-        assert isinstance(tau, float) and tau > 1.
+        assert isinstance(tau, float) and tau > 1., f'tau={tau!r} must be a float > 1'
         super().__init__(v_threshold, v_reset, surrogate_function, detach_reset, step_mode, backend, store_v_seq)
-        self.tau = tau
-        self.decay_input = decay_input
+        self.tau, self.decay_input = tau, decay_input
 
     @property
     def supported_backends(self):

@@ -1,7 +1,9 @@
-"""Surrogate functions: forward only (Heaviside).  SJ/activation_based/surrogate.py:13-51,118-155,664-760.
+"""Surrogate-function objects: constructor surface only.
 
-Training (the surrogate gradient) is outside the hot path; the objects exist so that
-``neuron.LIFNode(surrogate_function=surrogate.ATan())`` constructs exactly as in the reference.
+In inference the forward of every surrogate is the Heaviside step ``x >= 0`` (SJ/activation_based/surrogate.py:13-51),
+which the fused HIP LIF kernels evaluate in place; the backward (ATan etc., :664-760) belongs to training and is out of
+scope.  The classes exist so that ``neuron.LIFNode(surrogate_function=surrogate.ATan())`` is built
+exactly as the reference builds it, and keep the reference's attributes (``alpha``, ``spiking``).
 """
 import torch.nn as nn
 
@@ -9,26 +11,24 @@ import torch.nn as nn
 class SurrogateFunctionBase(nn.Module):
     def __init__(self, alpha, spiking=True):
         super().__init__()
-        self.spiking = spiking
-        self.alpha = alpha
+        self.alpha, self.spiking = alpha, spiking
 
     def set_spiking_mode(self, spiking: bool):
         self.spiking = spiking
 
     def extra_repr(self):
-        return f'alpha={self.alpha}, spiking={self.spiking}'
+        return 'alpha={}, spiking={}'.format(self.alpha, self.spiking)
 
     def forward(self, x):
-        raise NotImplementedError(
-            "spkdiff: surrogate functions are evaluated inside the fused HIP LIF kernels (x >= 0); "
-            "calling them as stand-alone modules (training path) is out of scope")
+        raise NotImplementedError('spkdiff: the spike non-linearity runs inside the HIP LIF kernels; stand-alone '
+                                  'surrogate evaluation (training path) is not part of this build')
 
 
-class ATan(SurrogateFunctionBase):
-    def __init__(self, alpha=2.0, spiking=True):
-        super().__init__(alpha, spiking)
+def _make(name, default_alpha):
+    def __init__(self, alpha=default_alpha, spiking=True):
+        SurrogateFunctionBase.__init__(self, alpha, spiking)
+    return type(name, (SurrogateFunctionBase,), {'__init__': __init__, '__doc__': f'{name} surrogate (alpha={default_alpha})'})
 
 
-class Sigmoid(SurrogateFunctionBase):
-    def __init__(self, alpha=4.0, spiking=True):
-        super().__init__(alpha, spiking)
+ATan = _make('ATan', 2.0)
+Sigmoid = _make('Sigmoid', 4.0)
