@@ -7,11 +7,16 @@ import torch
 from spkdiff import ops
 
 dev = torch.device("cuda")
+ONLY = None
+if len(sys.argv) > 1:      # "--only Cout,Cin": a few launches of one shape (for rocprofv3 counter passes)
+    ONLY = tuple(int(v) for v in sys.argv[-1].split(","))
 B, H, W = 256, 7, 7
 torch.manual_seed(0)
 res = {}
 for Cout in (128, 512):
     for Cin in (32, 64, 128, 256, 512):
+        if ONLY and (Cout, Cin) != ONLY:
+            continue
         w = (torch.rand(Cout, Cin, 3, 3, device=dev) - 0.5) * 0.05
         bias = torch.zeros(Cout, device=dev)
         packed = ops.den_pack_weight_i8(w, bias)
@@ -31,7 +36,7 @@ for Cout in (128, 512):
             per_item_us = ms * 1e3 / items_per_cu
             res[(Cout, Cin, mode)] = per_item_us
             print(f"Cout={Cout} Cin={Cin} nchunks={Cin//32} mode={'LIF' if mode==0 else 'MEAN'}: {ms:.3f} ms, per item {per_item_us:.2f} us", flush=True)
-for Cout in (128, 512):
+for Cout in (() if ONLY else (128, 512)):
     for mode in (0, 3):
         xs = [c // 32 for c in (32, 64, 128, 256, 512)]
         ys = [res[(Cout, c, mode)] for c in (32, 64, 128, 256, 512)]

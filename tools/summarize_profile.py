@@ -14,11 +14,15 @@ k = 0
 for r in rows:
     name = r["Kernel_Name"]
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    if "conv3x3_mfma_kernel<7, 0>" in name or "conv3x3_mfma_kernel<8, 0>" in name:
-        name = f"conv3x3_mfma_kernel<LIF> den.conv{2 + k % 4}"
-        k += 1
-    elif "conv3x3_mfma_kernel" in name:
-        name = "conv3x3_mfma_kernel<MEAN> den.conv6"
+    if "conv3x3_mfma_kernel<" in name:
+        targs = name.split("conv3x3_mfma_kernel<")[1].split(">")[0].split(",")
+        if int(targs[2]) == 0:          # template <NT, NPA, MODE, DBG>: MODE 0 = LIF (conv2..conv5, in launch order)
+            name = f"conv3x3_mfma_kernel<LIF> den.conv{2 + k % 4}"
+            k += 1
+        else:
+            name = "conv3x3_mfma_kernel<MEAN>"
+    elif "conv3x3_counts_mfma_kernel" in name:
+        name = "conv3x3_counts_mfma_kernel den.conv6 (time-collapsed)"
     dur[name.replace("(anonymous namespace)::", "")[:90]].append(d)
 tot = sum(sum(v) for v in dur.values())
 print("| kernel | calls | avg us | min us | max us | total ms | % |")
