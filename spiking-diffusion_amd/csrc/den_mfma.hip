@@ -57,13 +57,6 @@ struct MfmaArgs {
   int dbg;   // -DSPK_MFMA_ABLATION builds only (env SPK_MFMA_DEBUG): 1 = skip steady-state DMA, 2 = skip MFMAs, 4 = skip epilogue
 };
 
-// v_writelane_b32 with an immediate lane: drop a wave-uniform value into one lane of a VGPR
-template <int L>
-__device__ __forceinline__ unsigned writelane_imm(unsigned old, unsigned uniform_val) {
-  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(uniform_val), "n"(L));
-  return old;
-}
-
 // 16x16 bit-matrix transpose inside every 16-lane row (lane = row, bit = column) with DPP lane exchanges:
 // lane^8 = row_mirror o row_half_mirror, lane^4 = row_half_mirror o quad-reverse, lane^2 / lane^1 = quad_perm.
 __device__ __forceinline__ unsigned transpose16_rows(unsigned x, int lane) {
