@@ -123,6 +123,22 @@ int spk_den_conv3x3_counts_mfma(const uint8_t* cnt0, int nch0, const uint8_t* cn
                                 const double* scale, const double* bias_d, float* out_f32, int T, int B, int H, int W,
                                 int Cout, spk_stream_t stream);
 
+/* ---- spiking VQ-VAE layers on the matrix cores ------------------------------------------------------------------- */
+/* Bytes of the packed int8 digit planes of a k x k (transposed) conv: [ceil(Cout/16)][ceil(Cin/32)][k*k][2][32][32]. */
+long long spk_conv_packed_weight_i8_bytes(int Cout, int Cin, int k);
+/* Conv2d [Cout,Cin,k,k] or ConvTranspose2d [Cin,Cout,k,k] weight (+bias) -> int8 digit planes; scale / bias_d have
+ * ceil(Cout/16)*16 entries (padding channels are zero). */
+int spk_pack_conv_weight_i8(const float* w, const float* bias, int8_t* wq, double* scale, double* bias_d, int Cout,
+                            int Cin, int k, int transposed, spk_stream_t stream);
+/* (Conv2d | ConvTranspose2d) over binary spikes (plain PTC u8 [B,H*W,16,Cin], T = 16, Cin % 16 == 0) with exact int8
+ * MFMA accumulation, fused with BN + LIF (mode SPK_MODE_LIF -> out_ptc [B,Ho*Wo,16,Cout]) or with the membrane
+ * read-out (mode SPK_MODE_MEMOUT: coef[16] -> out_f32 [B,Cout,Ho,Wo] (+tanh), out_u8): Encoder conv2/conv3, Decoder
+ * convT1/convT2/convT3 of R/snn_model/vae_model.py:115-124,139-155,186. */
+int spk_conv_mfma_fused_fwd(const uint8_t* in_ptc, const int8_t* wq, const double* scale, const double* bias_d,
+                            const float* bn_a, const float* bn_b, float* v_inout, uint8_t* out_ptc, const float* coef,
+                            float* out_f32, uint8_t* out_u8, int apply_tanh, int mode, int T, int B, int H, int W, int Cin,
+                            int Cout, int k, int stride, int pad, int transposed, int out_pad, spk_stream_t stream);
+
 /* ---- vector quantizer ----------------------------------------------------------------------------------------- */
 /* VectorQuantizer.forward eval up to the codebook gather, R/snn_model/vae_model.py:40-52,87-99.
  * z_ptc u8 [B,h,w,T,D]; coef [T]; alpha [1] (device); codebook [K,D]; idx_out int64 [B*HW];

@@ -1,0 +1,317 @@
+// Generic (Conv2d | ConvTranspose2d) + BN + LIF over binary spike tensors on the matrix cores, for the spiking
+// VQ-VAE layers whose input is spikes: Encoder conv2/conv3, Decoder convT1/convT2 and the final convT + membrane
+// read-out (R/snn_model/vae_model.py:115-124,139-155,186).  Same exact int8 digit-plane arithmetic and the same
+// accumulator epilogue (permlane recombination, paired LIF scan, bit-matrix transpose, 16-byte spike stores) as the
+// denoiser kernel (den_mfma.hip); what differs is the data movement: these layers have small K (64..576) and large
+// spatial extents (up to 28x28), so there is nothing to keep resident -- every wave owns one task
+//     4 output positions of one sub-pixel class  x  16 time steps  x  16 output channels (x 4 digit planes)
+// gathers its A fragments (16 B per lane: 16 channels of one input position and time step) and its weight fragments
+// straight from L2/HBM, issues 2 x 2 MFMAs per K step, and runs the epilogue.  No LDS, no barriers; latency is hidden
+// by occupancy (~100 registers per wave).  Transposed stride-2 convolutions are handled as their 4 sub-pixel classes:
+// all 4 positions of a task share (oy % stride, ox % stride), so the set of contributing taps is wave-uniform.
+//
+// Layouts: input / output spikes plain PTC u8 [B][H*W][T=16][C]; packed weights [ceil(Cout/16)][ceil(Cin/32)][k*k]
+// [2 column tiles][32 cols][32 k] int8 (spk_pack_conv_weight_i8; Cin / Cout are zero-padded to 32 / 16).
+#include "spk_common.h"
+#include "../../include/spkdiff.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+constexpr int T16 = 16;
+
+__device__ __forceinline__ unsigned transpose16_rows_g(unsigned x, int lane) {
+  unsigned y;
+  y = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(x, 0x140, 0xF, 0xF, true), 0x141, 0xF, 0xF, true);
+  x = (lane & 8) ? (((y >> 8) & 0x00FFu) | (x & 0xFF00u)) : ((x & 0x00FFu) | ((y & 0x00FFu) << 8));
+  y = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
+  x = (lane & 4) ? (((y >> 4) & 0x0F0Fu) | (x & 0xF0F0u)) : ((x & 0x0F0Fu) | ((y & 0x0F0Fu) << 4));
+  y = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);
+  x = (lane & 2) ? (((y >> 2) & 0x3333u) | (x & 0xCCCCu)) : ((x & 0x3333u) | ((y & 0x3333u) << 2));
+  y = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);
+  x = (lane & 1) ? (((y >> 1) & 0x5555u) | (x & 0xAAAAu)) : ((x & 0x5555u) | ((y & 0x5555u) << 1));
+  return x;
+}
+
+struct GArgs {
+  const uint8_t* in;      // PTC [B][H*W][16][Cin]
+  const int8_t* wq; const double* scale; const double* bias; const float* bn_a; const float* bn_b;
+  float* v_io;            // [B][Cout][Ho*Wo] or null
+  uint8_t* out_ptc;       // MODE_LIF: PTC [B][Ho*Wo][16][Cout]
+  const float* coef;      // MODE_MEMOUT: [16]
+  float* out_f32;         // MODE_MEMOUT: [B][Cout][Ho*Wo]
+  uint8_t* out_u8;        // MODE_MEMOUT, optional
+  int apply_tanh;
+  int B, H, W, Cin, Cout, Ho, Wo, k, stride, pad, transposed;
+};
+
+// sub-pixel classes: transposed -> stride*stride classes over the INPUT grid (class-local grid Hc x Wc);
+// plain conv -> one class over the output grid.
+template <int MODE>
+__global__ __launch_bounds__(256) void conv_mfma_gather_kernel(GArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ncls = a.transposed ? a.stride * a.stride : 1;
+  // class-local output grid
+  const int G = (a.Cout + 15) >> 4;
+  const int nchunks = (a.Cin + 31) >> 5;
+  const int KK = a.k * a.k;
+  const long long task = (long long)blockIdx.x * 4 + wave_s;
+  // task -> (b, class, position group of 4, channel group): channel group fastest (waves of a block share A rows)
+  const int g = (int)(task % G);
+  long long r1 = task / G;
+  // positions per class
+  int cls, Hc, Wc, py = 0, px = 0;
+  long long pg;
+  {
+    // all classes have ceil-divided grids; enumerate (b, cls, pg) with per-class group counts computed on the fly
+    const int Hc0 = a.transposed ? (a.Ho + a.stride - 1) / a.stride : a.Ho;
+    const int Wc0 = a.transposed ? (a.Wo + a.stride - 1) / a.stride : a.Wo;
+    const long long groups_per_cls = ((long long)Hc0 * Wc0 + 3) / 4;      // upper bound shared by all classes
+    pg = r1 % groups_per_cls; r1 /= groups_per_cls;
+    cls = (int)(r1 % ncls); r1 /= ncls;
+    if (a.transposed) { py = cls / a.stride; px = cls % a.stride; }
+    Hc = a.transposed ? (a.Ho - py + a.stride - 1) / a.stride : a.Ho;
+    Wc = a.transposed ? (a.Wo - px + a.stride - 1) / a.stride : a.Wo;
+  }
+  const int b = (int)r1;
+  if (b >= a.B) return;
+  const int npos_c = Hc * Wc;
+  if (pg * 4 >= npos_c) return;                                        // wave-uniform
+
+  // this lane's A rows: tile i (0,1), position h, time t
+  const int row = lane & 31, half = lane >> 5;
+  const int hsel = (row >> 2) & 1, tt = (row & 3) + 4 * (row >> 3);
+  int oy[2], ox[2];
+  bool pvalid[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = (int)pg * 4 + 2 * i + hsel;
+    pvalid[i] = q < npos_c;
+    const int qy = pvalid[i] ? q / Wc : 0, qx = pvalid[i] ? q % Wc : 0;
+    oy[i] = a.transposed ? qy * a.stride + py : qy;
+    ox[i] = a.transposed ? qx * a.stride + px : qx;
+  }
+  const int boff = (lane & 31) * 32 + 16 * (half ^ ((lane >> 4) & 1));
+  const int HWi = a.H * a.W;
+  const uint8_t* inb = a.in + (long long)b * HWi * T16 * a.Cin;
+
+  v16i acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0; acc[i][1][r] = 0; }
+
+  for (int ky = 0; ky < a.k; ++ky) {
+    // wave-uniform class test (all 4 positions share oy % stride): does this kernel row contribute at all?
+    if (a.transposed && ((py + a.pad - ky) % a.stride + a.stride) % a.stride != 0) continue;
+    for (int kx = 0; kx < a.k; ++kx) {
+      if (a.transposed && ((px + a.pad - kx) % a.stride + a.stride) % a.stride != 0) continue;
+      const int tap = ky * a.k + kx;
+      // input position of each tile's row for this tap
+      long long ioff[2];
+      bool ok[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int iy, ix;
+        if (a.transposed) {
+          const int ty = oy[i] + a.pad - ky, tx = ox[i] + a.pad - kx;
+          iy = ty / a.stride; ix = tx / a.stride;
+          ok[i] = pvalid[i] && ty >= 0 && tx >= 0 && iy < a.H && ix < a.W;
+        } else {
+          iy = oy[i] * a.stride - a.pad + ky; ix = ox[i] * a.stride - a.pad + kx;
+          ok[i] = pvalid[i] && iy >= 0 && ix >= 0 && iy < a.H && ix < a.W;
+        }
+        ioff[i] = ((long long)(iy * a.W + ix) * T16 + tt) * a.Cin + 16 * half;
+      }
+      for (int c = 0; c < nchunks; ++c) {
+        const bool chan_ok = c * 32 + 16 * half < a.Cin;              // Cin = 16: the upper k-half is zero padding
+        v4i av[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          av[i] = (v4i){0, 0, 0, 0};
+          if (ok[i] && chan_ok) av[i] = *reinterpret_cast<const v4i*>(inb + ioff[i] + c * 32);
+        }
+        const int8_t* wp = a.wq + ((((long long)g * nchunks + c) * KK + tap) * 2) * 1024 + boff;
+        const v4i b0 = *reinterpret_cast<const v4i*>(wp);
+        const v4i b1 = *reinterpret_cast<const v4i*>(wp + 1024);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          acc[i][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i], b0, acc[i][0], 0, 0, 0);
+          acc[i][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i], b1, acc[i][1], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---------------- epilogue (see den_mfma.hip for the scheme) -------------------------------------------------
+  const int col = lane & 31, ch = col & 15, odd = col >> 4;
+  const int co = g * 16 + ch;
+  const bool co_ok = co < a.Cout;
+  const double sc = a.scale[g * 16 + ch], bi = a.bias[g * 16 + ch];     // padded to 16 per group by the packer
+  auto recombine = [&](int i, float (&x)[16]) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const v2u p01 = __builtin_amdgcn_permlane16_swap((unsigned)acc[i][0][r], (unsigned)acc[i][0][r + 8], false, false);
+      const v2u p23 = __builtin_amdgcn_permlane16_swap((unsigned)acc[i][1][r], (unsigned)acc[i][1][r + 8], false, false);
+      const int hi = (int)p01[0] * 256 + (int)p01[1], lo = (int)p23[0] * 256 + (int)p23[1];
+      const double s = fma((double)hi, 65536.0, (double)lo);
+      const float xm = (float)fma(s, sc, bi);
+      const v2u xx = __builtin_amdgcn_permlane16_swap(__float_as_uint(xm), __float_as_uint(xm), false, false);
+      x[r] = __uint_as_float(xx[0]);
+      x[r + 8] = __uint_as_float(xx[1]);
+    }
+  };
+  float xa[16], xb[16];
+  recombine(0, xa);
+  recombine(1, xb);
+  // even lanes own tile 0, odd lanes tile 1; accumulator lane-half = position within the tile
+  const int q = (int)pg * 4 + 2 * odd + half;
+  const bool pos_ok = q < npos_c;
+  const int qy = pos_ok ? q / Wc : 0, qx = pos_ok ? q % Wc : 0;
+  const int opos = (a.transposed ? qy * a.stride + py : qy) * a.Wo + (a.transposed ? qx * a.stride + px : qx);
+  const long long HWo = (long long)a.Ho * a.Wo;
+  if (MODE == SPK_MODE_LIF) {
+    const float bn_a = co_ok ? a.bn_a[co] : 0.f, bn_b = co_ok ? a.bn_b[co] : 0.f;
+    const long long vidx = ((long long)b * a.Cout + (co_ok ? co : 0)) * HWo + opos;
+    float v = (a.v_io && pos_ok && co_ok) ? a.v_io[vidx] : 0.f;
+    unsigned mybits = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float xv = odd ? xb[r] : xa[r];
+      const bool s = spk_lif_step_default(v, fmaf(xv, bn_a, bn_b)) && pos_ok && co_ok;
+      mybits |= s ? (1u << r) : 0u;
+    }
+    if (a.v_io && pos_ok && co_ok) a.v_io[vidx] = v;
+    const unsigned bitsv = transpose16_rows_g(mybits, lane);      // lane t of each 16-lane row: 16 channel bits of step t
+    if (pos_ok) {
+      uint4 o;
+      o.x = ((bitsv & 0xfu) * 0x00204081u) & 0x01010101u;
+      o.y = (((bitsv >> 4) & 0xfu) * 0x00204081u) & 0x01010101u;
+      o.z = (((bitsv >> 8) & 0xfu) * 0x00204081u) & 0x01010101u;
+      o.w = (((bitsv >> 12) & 0xfu) * 0x00204081u) & 0x01010101u;
+      uint8_t* dst = a.out_ptc + (((long long)b * HWo + opos) * T16 + (lane & 15)) * a.Cout + g * 16;
+      if (g * 16 + 16 <= a.Cout) {
+        *reinterpret_cast<uint4*>(dst) = o;
+      } else {                                                     // ragged last channel group
+        const uint8_t* ob = reinterpret_cast<const uint8_t*>(&o);
+        for (int c2 = 0; g * 16 + c2 < a.Cout; ++c2) dst[c2] = ob[c2];
+      }
+    }
+  } else {  // SPK_MODE_MEMOUT: sum_t x[t] * coef[t]  (+ tanh, + uint8), R/snn_model/snn_layers.py:36-41, R/main.py:399-401
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = m + (odd ? xb[r] : xa[r]) * a.coef[r];
+    if (pos_ok && co_ok) {
+      const float pv = a.apply_tanh ? tanhf(m) : m;
+      const long long oidx = ((long long)b * a.Cout + co) * HWo + opos;
+      if (a.out_f32) a.out_f32[oidx] = pv;
+      if (a.out_u8) a.out_u8[oidx] = (uint8_t)(fminf(fmaxf(pv + 0.5f, 0.0f), 1.0f) * 255.0f);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// one block per PADDED output channel (ceil(Cout/16)*16): zero digits / zero bias for the padding channels
+__global__ __launch_bounds__(256) void pack_i8_generic_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                              int8_t* __restrict__ wq, double* __restrict__ scale,
+                                                              double* __restrict__ bias_d, int Cout, int Cin, int k,
+                                                              int transposed) {
+  __shared__ float smax[256];
+  const int co = blockIdx.x, KK = k * k, n = Cin * KK;
+  const int nchunks = (Cin + 31) >> 5, g = co >> 4, ch = co & 15;
+  const bool real = co < Cout;
+  auto wat = [&](int ci, int tap) -> float {
+    return transposed ? w[((long long)ci * Cout + co) * KK + tap] : w[((long long)co * Cin + ci) * KK + tap];
+  };
+  float m = 0.f;
+  if (real)
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(wat(i / KK, i % KK)));
+  smax[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s]);
+    __syncthreads();
+  }
+  m = smax[0];
+  int e = 0;
+  if (m > 0.f) frexpf(m, &e);
+  const int sh = 30 - e;
+  if (threadIdx.x == 0) { scale[co] = ldexp(1.0, -sh); bias_d[co] = (real && bias) ? (double)bias[co] : 0.0; }
+  const int npad = nchunks * 32 * KK;
+  for (int i = threadIdx.x; i < npad; i += 256) {
+    const int ci = i / KK, tap = i % KK;
+    long long q = (real && ci < Cin) ? (long long)rint(ldexp((double)wat(ci, tap), sh)) : 0;
+    int dg[4];
+#pragma unroll
+    for (int d = 3; d >= 0; --d) {
+      int r = (int)(((q + 128) & 255) - 128);
+      dg[d] = r;
+      q = (q - r) >> 8;
+    }
+    const int c = ci >> 5, kk = ci & 31;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int ct = d >> 1, colw = (d & 1) * 16 + ch;
+      wq[((((long long)(g * nchunks + c) * KK + tap) * 2 + ct) * 32 + colw) * 32 + (kk ^ (colw & 16))] = (int8_t)dg[d];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" long long spk_conv_packed_weight_i8_bytes(int Cout, int Cin, int k) {
+  if (Cout <= 0 || Cin <= 0 || k <= 0) return -1;
+  return (long long)((Cout + 15) / 16) * ((Cin + 31) / 32) * k * k * 2048;
+}
+
+extern "C" int spk_pack_conv_weight_i8(const float* w, const float* bias, int8_t* wq, double* scale, double* bias_d,
+                                       int Cout, int Cin, int k, int transposed, hipStream_t stream) {
+  if (!w || !wq || !scale || !bias_d || Cout <= 0 || Cin <= 0 || k <= 0) return SPK_ERR_ARG;
+  const int cpad = ((Cout + 15) / 16) * 16;
+  hipLaunchKernelGGL(pack_i8_generic_kernel, dim3(cpad), dim3(256), 0, stream, w, bias, wq, scale, bias_d, Cout, Cin, k,
+                     transposed);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_conv_mfma_fused_fwd(const uint8_t* in_ptc, const int8_t* wq, const double* scale,
+                                       const double* bias_d, const float* bn_a, const float* bn_b, float* v_inout,
+                                       uint8_t* out_ptc, const float* coef, float* out_f32, uint8_t* out_u8,
+                                       int apply_tanh, int mode, int T, int B, int H, int W, int Cin, int Cout, int k,
+                                       int stride, int pad, int transposed, int out_pad, hipStream_t stream) {
+  if (!in_ptc || !wq || !scale || !bias_d || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 ||
+      stride <= 0 || pad < 0)
+    return SPK_ERR_ARG;
+  if (T != T16 || (Cin % 16) != 0) return SPK_ERR_UNSUPPORTED;
+  GArgs a;
+  a.in = in_ptc; a.wq = wq; a.scale = scale; a.bias = bias_d; a.bn_a = bn_a; a.bn_b = bn_b; a.v_io = v_inout;
+  a.out_ptc = out_ptc; a.coef = coef; a.out_f32 = out_f32; a.out_u8 = out_u8; a.apply_tanh = apply_tanh;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.k = k; a.stride = stride; a.pad = pad;
+  a.transposed = transposed;
+  a.Ho = spk_conv_out_size(H, k, stride, pad, transposed, out_pad);
+  a.Wo = spk_conv_out_size(W, k, stride, pad, transposed, out_pad);
+  if (a.Ho <= 0 || a.Wo <= 0) return SPK_ERR_ARG;
+  const int ncls = transposed ? stride * stride : 1;
+  const int Hc0 = transposed ? (a.Ho + stride - 1) / stride : a.Ho;
+  const int Wc0 = transposed ? (a.Wo + stride - 1) / stride : a.Wo;
+  const long long groups = ((long long)Hc0 * Wc0 + 3) / 4;
+  const long long tasks = (long long)B * ncls * groups * ((Cout + 15) / 16);
+  const long long blocks = (tasks + 3) / 4;
+  if (blocks > 0x7fffffffLL) return SPK_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)blocks), blk(256);
+  if (mode == SPK_MODE_LIF) {
+    if (!bn_a || !bn_b || !out_ptc) return SPK_ERR_ARG;
+    hipLaunchKernelGGL(conv_mfma_gather_kernel<SPK_MODE_LIF>, grid, blk, 0, stream, a);
+  } else if (mode == SPK_MODE_MEMOUT) {
+    if (!coef || (!out_f32 && !out_u8)) return SPK_ERR_ARG;
+    hipLaunchKernelGGL(conv_mfma_gather_kernel<SPK_MODE_MEMOUT>, grid, blk, 0, stream, a);
+  } else {
+    return SPK_ERR_UNSUPPORTED;
+  }
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}

@@ -55,6 +55,10 @@ _SIGS = {
     "spk_den_conv3x3_mfma": (c_int, [P, c_int, P, c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int,
                                      c_int, P]),
     "spk_den_conv3x3_counts_mfma": (c_int, [P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "spk_conv_packed_weight_i8_bytes": (c_longlong, [c_int, c_int, c_int]),
+    "spk_pack_conv_weight_i8": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "spk_conv_mfma_fused_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_vq_readout_argmin": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_vq_argmin": (c_int, [P, P, P, c_longlong, c_int, c_int, P]),
     "spk_embedding_fwd": (c_int, [P, P, P, c_longlong, c_int, c_int, c_int, c_int, P]),

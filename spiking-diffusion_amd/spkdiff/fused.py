@@ -47,6 +47,14 @@ class ConvParams:
             self.key_i8 = key
         return self.i8
 
+    def get_i8_generic(self, conv):
+        """int8 digit planes in the layout of the gather-MFMA kernel (any k, Conv2d or ConvTranspose2d)."""
+        key = (_ver(conv.weight), _ver(conv.bias))
+        if key != getattr(self, 'key_i8g', None):
+            self.i8g = ops.pack_conv_weight_i8(conv.weight, conv.bias, isinstance(conv, nn.ConvTranspose2d))
+            self.key_i8g = key
+        return self.i8g
+
 
 def conv_geometry(conv):
     layer._check_plain(conv)
@@ -157,6 +165,39 @@ class FusedSequential(nn.Sequential):
                         cur, kind = o, IN_PTC
                 else:
                     out['f32'] = ops.den_conv3x3_mfma(cur, packed, conv.out_channels, mode=MODE_MEAN, in1=src1)
+                continue
+            # spiking VQ-VAE layers: gather-MFMA kernel (plain PTC input, T = 16)
+            plain_ptc = kind == IN_PTC and cur.dim() == 5 and src1 is None
+            g_mode = MODE_LIF if lif is not None else (MODE_MEMOUT if final == 'memout' else None)
+            use_gather = (impl != 'direct' and plain_ptc and g_mode is not None and not want_pre and not want_counts and
+                          not (last and chunk_out) and
+                          ops.conv_mfma_supported(conv.in_channels, conv.out_channels, T, g_mode))
+            if use_gather:
+                packed = conv._spk_params.get_i8_generic(conv)
+                if lif is not None:
+                    a, b = bn.affine_terms()
+                    v = None
+                    if stateful:
+                        Ho = ops.conv_out_size(cur.shape[1], geo['k'], geo['stride'], geo['pad'], geo['transposed'], geo['out_pad'])
+                        Wo = ops.conv_out_size(cur.shape[2], geo['k'], geo['stride'], geo['pad'], geo['transposed'], geo['out_pad'])
+                        shape = (cur.shape[0], conv.out_channels, Ho, Wo)
+                        if isinstance(lif.v, float):
+                            lif.v = torch.full(shape, lif.v, dtype=torch.float32, device=cur.device)
+                        elif tuple(lif.v.shape) != shape:
+                            raise RuntimeError(f'LIFNode state has shape {tuple(lif.v.shape)} but the input implies '
+                                               f'{shape}; call functional.reset_net first')
+                        v = lif.v
+                    o = ops.conv_mfma_fused(cur, packed, conv.out_channels, mode=MODE_LIF, bn_a=a, bn_b=b, v=v, **geo)
+                    if last:
+                        out['ptc'] = o
+                        if final in ('f32', 'both'):
+                            out['f32'] = ops.ptc_to_spikes(o)
+                    else:
+                        cur, kind = o, IN_PTC
+                else:
+                    r = ops.conv_mfma_fused(cur, packed, conv.out_channels, mode=MODE_MEMOUT, coef=coef,
+                                            apply_tanh=apply_tanh, want_u8=want_u8, **geo)
+                    out['f32'], out['u8'] = r['f32'], r['u8']
                 continue
             w_packed = conv._spk_params.get(conv)
             if lif is not None:

@@ -337,6 +337,51 @@ def den_conv3x3_counts(cnt0, packed, Cout, T, cnt1=None):
     return out
 
 
+# ---------------------------------------------------------------------------------------------- MFMA VQ-VAE layers
+def conv_mfma_supported(Cin, Cout, T, mode):
+    return T == 16 and Cin % 16 == 0 and (mode == MODE_MEMOUT or Cout % 16 == 0)
+
+
+def pack_conv_weight_i8(w, bias, transposed):
+    """Conv2d [Cout,Cin,k,k] / ConvTranspose2d [Cin,Cout,k,k] fp32 -> (int8 digit planes, scale, bias) (padded to 16)."""
+    w = _dev(w.detach(), "weight", torch.float32)
+    if transposed:
+        Cin, Cout, k, k2 = w.shape
+    else:
+        Cout, Cin, k, k2 = w.shape
+    if k != k2:
+        raise NotImplementedError("square kernels only")
+    nbytes = lib.spk_conv_packed_weight_i8_bytes(Cout, Cin, k)
+    cpad = (Cout + 15) // 16 * 16
+    wq = torch.empty(nbytes, dtype=torch.int8, device=w.device)
+    scale = torch.empty(cpad, dtype=torch.float64, device=w.device)
+    bias_d = torch.empty(cpad, dtype=torch.float64, device=w.device)
+    b = None if bias is None else _dev(bias.detach(), "bias", torch.float32)
+    check(lib.spk_pack_conv_weight_i8(_p(w), _p(b), _p(wq), _p(scale), _p(bias_d), Cout, Cin, k, int(transposed),
+                                      _stream(w)), "spk_pack_conv_weight_i8")
+    return wq, scale, bias_d
+
+
+def conv_mfma_fused(in_ptc, packed, Cout, *, mode, k, stride, pad, transposed=False, out_pad=0, bn_a=None, bn_b=None,
+                    v=None, coef=None, apply_tanh=False, want_u8=False):
+    """in_ptc u8 [B,H,W,16,Cin] -> LIF: spikes u8 [B,Ho,Wo,16,Cout]; MEMOUT: dict(f32=[B,Cout,Ho,Wo], u8=...)."""
+    in_ptc = _dev(in_ptc, "in_ptc", torch.uint8)
+    B, H, W, T, Cin = in_ptc.shape
+    Ho, Wo = conv_out_size(H, k, stride, pad, transposed, out_pad), conv_out_size(W, k, stride, pad, transposed, out_pad)
+    wq, scale, bias_d = packed
+    out_p = out_f = out_u = None
+    if mode == MODE_LIF:
+        out_p = torch.empty((B, Ho, Wo, T, Cout), dtype=torch.uint8, device=in_ptc.device)
+    else:
+        out_f = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=in_ptc.device)
+        if want_u8:
+            out_u = torch.empty((B, Cout, Ho, Wo), dtype=torch.uint8, device=in_ptc.device)
+    check(lib.spk_conv_mfma_fused_fwd(_p(in_ptc), _p(wq), _p(scale), _p(bias_d), _p(bn_a), _p(bn_b), _p(v), _p(out_p),
+                                      _p(coef), _p(out_f), _p(out_u), int(apply_tanh), mode, T, B, H, W, Cin, Cout, k,
+                                      stride, pad, int(transposed), out_pad, _stream(in_ptc)), "spk_conv_mfma_fused_fwd")
+    return out_p if mode == MODE_LIF else {"f32": out_f, "u8": out_u}
+
+
 # ---------------------------------------------------------------------------------------------- VQ
 def vq_readout_argmin(z_ptc, coef, alpha, codebook, want_zq=True, want_xm=False):
     z_ptc = _dev(z_ptc, "z_ptc", torch.uint8)
