@@ -28,7 +28,7 @@ class timed:
         self.tag = tag
 
     def __enter__(self):
-        if TIMERS is not None:
+        if TIMERS is not None and self.tag is not None:
             e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -36,7 +36,7 @@ class timed:
         return self
 
     def __exit__(self, *exc):
-        if TIMERS is not None:
+        if TIMERS is not None and self.tag is not None:
             self.e1.record()
         return False
 
