@@ -522,7 +522,10 @@ extern "C" int spk_den_conv3x3_mfma(const uint8_t* in0_cptc, int nch0, const uin
   a.in0 = in0_cptc; a.in1 = in1_cptc; a.nch0 = nch0; a.nch1 = nch1; a.wq = wq; a.scale = scale; a.bias = bias_d;
   a.bn_a = bn_a; a.bn_b = bn_b; a.out = out_cptc; a.out_f32 = out_f32; a.v_io = v_inout; a.out_cnt = out_counts; a.B = B; a.H = H; a.W = W;
   a.Cout = Cout; a.mode = mode;
-  { const char* e = getenv("SPK_MFMA_DEBUG"); a.dbg = e ? atoi(e) : 0; }
+  a.dbg = 0;
+#ifdef SPK_MFMA_ABLATION
+  { const char* e = getenv("SPK_MFMA_DEBUG"); a.dbg = e ? atoi(e) : 0; }     // timing experiments only
+#endif
   if (mode == SPK_MODE_LIF) {
     if (!bn_a || !bn_b || !out_cptc) return SPK_ERR_ARG;
     return launch<SPK_MODE_LIF>(a, stream);

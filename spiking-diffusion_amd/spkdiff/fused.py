@@ -130,112 +130,112 @@ class FusedSequential(nn.Sequential):
         cur, kind = x, in_kind
         out = {'ptc': None, 'f32': None, 'u8': None, 'pre': [], 'cnt': None}
         for bi, (conv, bn, lif) in enumerate(blocks):
-          with ops.timed(getattr(conv, '_spk_tag', None)):          # bench.py tags layers it wants timed in situ
-              last = bi == len(blocks) - 1
-              if not hasattr(conv, '_spk_params'):
-                  object.__setattr__(conv, '_spk_params', ConvParams())
-              geo = conv_geometry(conv)
-              bias = None if conv.bias is None else conv.bias.detach()
-              src1 = in1 if (last and in1 is not None) else None
-              cptc = kind == IN_PTC and cur.dim() == 6 and cur.shape[-1] == 32 and (src1 is None or src1.dim() == 6)
-              use_mfma = (impl != 'direct' and cptc and not geo['transposed'] and not want_pre and
-                          (lif is not None or final == 'mean') and
-                          ops.den_mfma_supported(conv.out_channels, conv.in_channels, geo['k'], geo['stride'], geo['pad'],
-                                                 T, cur.shape[2], cur.shape[3]) and
-                          (lif is None or not last or (final == 'ptc' and chunk_out == 32)))
-              if use_mfma:
-                  packed = conv._spk_params.get_i8(conv)
-                  if lif is not None:
-                      a, b = bn.affine_terms()
-                      v = None
-                      if stateful:
-                          shape = (cur.shape[0], conv.out_channels, cur.shape[2], cur.shape[3])
-                          if isinstance(lif.v, float):
-                              lif.v = torch.full(shape, lif.v, dtype=torch.float32, device=cur.device)
-                          elif tuple(lif.v.shape) != shape:
-                              raise RuntimeError(f'LIFNode state has shape {tuple(lif.v.shape)} but the input implies '
-                                                 f'{shape}; call functional.reset_net first')
-                          v = lif.v
-                      o = ops.den_conv3x3_mfma(cur, packed, conv.out_channels, mode=MODE_LIF, in1=src1, bn_a=a, bn_b=b, v=v,
-                                               want_counts=last and want_counts)
-                      if last and want_counts:
-                          out['ptc'], out['cnt'] = o
-                      elif last:
-                          out['ptc'] = o
-                      else:
-                          cur, kind = o, IN_PTC
-                  else:
-                      out['f32'] = ops.den_conv3x3_mfma(cur, packed, conv.out_channels, mode=MODE_MEAN, in1=src1)
-                  continue
-              # spiking VQ-VAE layers: gather-MFMA kernel (plain PTC input, T = 16)
-              plain_ptc = kind == IN_PTC and cur.dim() == 5 and src1 is None
-              g_mode = MODE_LIF if lif is not None else (MODE_MEMOUT if final == 'memout' else None)
-              use_gather = (impl != 'direct' and plain_ptc and g_mode is not None and not want_pre and not want_counts and
-                            not (last and chunk_out) and
-                            ops.conv_mfma_supported(conv.in_channels, conv.out_channels, T, g_mode))
-              if use_gather:
-                  packed = conv._spk_params.get_i8_generic(conv)
-                  if lif is not None:
-                      a, b = bn.affine_terms()
-                      v = None
-                      if stateful:
-                          Ho = ops.conv_out_size(cur.shape[1], geo['k'], geo['stride'], geo['pad'], geo['transposed'], geo['out_pad'])
-                          Wo = ops.conv_out_size(cur.shape[2], geo['k'], geo['stride'], geo['pad'], geo['transposed'], geo['out_pad'])
-                          shape = (cur.shape[0], conv.out_channels, Ho, Wo)
-                          if isinstance(lif.v, float):
-                              lif.v = torch.full(shape, lif.v, dtype=torch.float32, device=cur.device)
-                          elif tuple(lif.v.shape) != shape:
-                              raise RuntimeError(f'LIFNode state has shape {tuple(lif.v.shape)} but the input implies '
-                                                 f'{shape}; call functional.reset_net first')
-                          v = lif.v
-                      o = ops.conv_mfma_fused(cur, packed, conv.out_channels, mode=MODE_LIF, bn_a=a, bn_b=b, v=v, **geo)
-                      if last:
-                          out['ptc'] = o
-                          if final in ('f32', 'both'):
-                              out['f32'] = ops.ptc_to_spikes(o)
-                      else:
-                          cur, kind = o, IN_PTC
-                  else:
-                      r = ops.conv_mfma_fused(cur, packed, conv.out_channels, mode=MODE_MEMOUT, coef=coef,
-                                              apply_tanh=apply_tanh, want_u8=want_u8, **geo)
-                      out['f32'], out['u8'] = r['f32'], r['u8']
-                  continue
-              w_packed = conv._spk_params.get(conv)
-              if lif is not None:
-                  a, b = bn.affine_terms()
-                  v = None
-                  if stateful:
-                      B = cur.shape[0] if kind != IN_SEQ else cur.shape[1]
-                      if kind == IN_PTC:
-                          H, W = (cur.shape[2], cur.shape[3]) if cur.dim() == 6 else (cur.shape[1], cur.shape[2])
-                      else:
-                          H, W = cur.shape[-2], cur.shape[-1]
-                      Ho = ops.conv_out_size(H, geo['k'], geo['stride'], geo['pad'], geo['transposed'], geo['out_pad'])
-                      Wo = ops.conv_out_size(W, geo['k'], geo['stride'], geo['pad'], geo['transposed'], geo['out_pad'])
-                      if isinstance(lif.v, float):
-                          lif.v = torch.full((B, conv.out_channels, Ho, Wo), lif.v, dtype=torch.float32,
-                                             device=cur.device)
-                      elif tuple(lif.v.shape) != (B, conv.out_channels, Ho, Wo):
-                          raise RuntimeError(f'LIFNode state has shape {tuple(lif.v.shape)} but the input implies '
-                                             f'{(B, conv.out_channels, Ho, Wo)}; call functional.reset_net first')
-                      v = lif.v
-                  r = ops.conv_fused(cur, w_packed, bias, in_kind=kind, T=T, mode=MODE_LIF, in1=src1, bn_a=a, bn_b=b,
-                                     v=v, want_ptc=(not last) or final in ('ptc', 'both'),
-                                     want_f32=last and final in ('f32', 'both'), want_pre=want_pre,
-                                     chunk_out=(chunk_out if last else None), want_counts=last and want_counts, **geo)
-                  if want_pre:
-                      out['pre'].append(r['pre'])
-                  if last:
-                      out['ptc'], out['f32'], out['cnt'] = r['ptc'], r['f32'], r['cnt']
-                  else:
-                      cur, kind = r['ptc'], IN_PTC
-              else:
-                  if final == 'memout':
-                      r = ops.conv_fused(cur, w_packed, bias, in_kind=kind, T=T, mode=MODE_MEMOUT, in1=src1, coef=coef,
-                                         apply_tanh=apply_tanh, want_u8=want_u8, **geo)
-                  elif final == 'mean':
-                      r = ops.conv_fused(cur, w_packed, bias, in_kind=kind, T=T, mode=MODE_MEAN, in1=src1, **geo)
-                  else:
-                      r = ops.conv_fused(cur, w_packed, bias, in_kind=kind, T=T, mode=MODE_RAW, in1=src1, **geo)
-                  out['f32'], out['u8'] = r['f32'], r['u8']
+            with ops.timed(getattr(conv, '_spk_tag', None)):          # bench.py tags layers it wants timed in situ
+                last = bi == len(blocks) - 1
+                if not hasattr(conv, '_spk_params'):
+                    object.__setattr__(conv, '_spk_params', ConvParams())
+                geo = conv_geometry(conv)
+                bias = None if conv.bias is None else conv.bias.detach()
+                src1 = in1 if (last and in1 is not None) else None
+                cptc = kind == IN_PTC and cur.dim() == 6 and cur.shape[-1] == 32 and (src1 is None or src1.dim() == 6)
+                use_mfma = (impl != 'direct' and cptc and not geo['transposed'] and not want_pre and
+                            (lif is not None or final == 'mean') and
+                            ops.den_mfma_supported(conv.out_channels, conv.in_channels, geo['k'], geo['stride'], geo['pad'],
+                                                   T, cur.shape[2], cur.shape[3]) and
+                            (lif is None or not last or (final == 'ptc' and chunk_out == 32)))
+                if use_mfma:
+                    packed = conv._spk_params.get_i8(conv)
+                    if lif is not None:
+                        a, b = bn.affine_terms()
+                        v = None
+                        if stateful:
+                            shape = (cur.shape[0], conv.out_channels, cur.shape[2], cur.shape[3])
+                            if isinstance(lif.v, float):
+                                lif.v = torch.full(shape, lif.v, dtype=torch.float32, device=cur.device)
+                            elif tuple(lif.v.shape) != shape:
+                                raise RuntimeError(f'LIFNode state has shape {tuple(lif.v.shape)} but the input implies '
+                                                   f'{shape}; call functional.reset_net first')
+                            v = lif.v
+                        o = ops.den_conv3x3_mfma(cur, packed, conv.out_channels, mode=MODE_LIF, in1=src1, bn_a=a, bn_b=b, v=v,
+                                                 want_counts=last and want_counts)
+                        if last and want_counts:
+                            out['ptc'], out['cnt'] = o
+                        elif last:
+                            out['ptc'] = o
+                        else:
+                            cur, kind = o, IN_PTC
+                    else:
+                        out['f32'] = ops.den_conv3x3_mfma(cur, packed, conv.out_channels, mode=MODE_MEAN, in1=src1)
+                    continue
+                # spiking VQ-VAE layers: gather-MFMA kernel (plain PTC input, T = 16)
+                plain_ptc = kind == IN_PTC and cur.dim() == 5 and src1 is None
+                g_mode = MODE_LIF if lif is not None else (MODE_MEMOUT if final == 'memout' else None)
+                use_gather = (impl != 'direct' and plain_ptc and g_mode is not None and not want_pre and not want_counts and
+                              not (last and chunk_out) and
+                              ops.conv_mfma_supported(conv.in_channels, conv.out_channels, T, g_mode))
+                if use_gather:
+                    packed = conv._spk_params.get_i8_generic(conv)
+                    if lif is not None:
+                        a, b = bn.affine_terms()
+                        v = None
+                        if stateful:
+                            Ho = ops.conv_out_size(cur.shape[1], geo['k'], geo['stride'], geo['pad'], geo['transposed'], geo['out_pad'])
+                            Wo = ops.conv_out_size(cur.shape[2], geo['k'], geo['stride'], geo['pad'], geo['transposed'], geo['out_pad'])
+                            shape = (cur.shape[0], conv.out_channels, Ho, Wo)
+                            if isinstance(lif.v, float):
+                                lif.v = torch.full(shape, lif.v, dtype=torch.float32, device=cur.device)
+                            elif tuple(lif.v.shape) != shape:
+                                raise RuntimeError(f'LIFNode state has shape {tuple(lif.v.shape)} but the input implies '
+                                                   f'{shape}; call functional.reset_net first')
+                            v = lif.v
+                        o = ops.conv_mfma_fused(cur, packed, conv.out_channels, mode=MODE_LIF, bn_a=a, bn_b=b, v=v, **geo)
+                        if last:
+                            out['ptc'] = o
+                            if final in ('f32', 'both'):
+                                out['f32'] = ops.ptc_to_spikes(o)
+                        else:
+                            cur, kind = o, IN_PTC
+                    else:
+                        r = ops.conv_mfma_fused(cur, packed, conv.out_channels, mode=MODE_MEMOUT, coef=coef,
+                                                apply_tanh=apply_tanh, want_u8=want_u8, **geo)
+                        out['f32'], out['u8'] = r['f32'], r['u8']
+                    continue
+                w_packed = conv._spk_params.get(conv)
+                if lif is not None:
+                    a, b = bn.affine_terms()
+                    v = None
+                    if stateful:
+                        B = cur.shape[0] if kind != IN_SEQ else cur.shape[1]
+                        if kind == IN_PTC:
+                            H, W = (cur.shape[2], cur.shape[3]) if cur.dim() == 6 else (cur.shape[1], cur.shape[2])
+                        else:
+                            H, W = cur.shape[-2], cur.shape[-1]
+                        Ho = ops.conv_out_size(H, geo['k'], geo['stride'], geo['pad'], geo['transposed'], geo['out_pad'])
+                        Wo = ops.conv_out_size(W, geo['k'], geo['stride'], geo['pad'], geo['transposed'], geo['out_pad'])
+                        if isinstance(lif.v, float):
+                            lif.v = torch.full((B, conv.out_channels, Ho, Wo), lif.v, dtype=torch.float32,
+                                               device=cur.device)
+                        elif tuple(lif.v.shape) != (B, conv.out_channels, Ho, Wo):
+                            raise RuntimeError(f'LIFNode state has shape {tuple(lif.v.shape)} but the input implies '
+                                               f'{(B, conv.out_channels, Ho, Wo)}; call functional.reset_net first')
+                        v = lif.v
+                    r = ops.conv_fused(cur, w_packed, bias, in_kind=kind, T=T, mode=MODE_LIF, in1=src1, bn_a=a, bn_b=b,
+                                       v=v, want_ptc=(not last) or final in ('ptc', 'both'),
+                                       want_f32=last and final in ('f32', 'both'), want_pre=want_pre,
+                                       chunk_out=(chunk_out if last else None), want_counts=last and want_counts, **geo)
+                    if want_pre:
+                        out['pre'].append(r['pre'])
+                    if last:
+                        out['ptc'], out['f32'], out['cnt'] = r['ptc'], r['f32'], r['cnt']
+                    else:
+                        cur, kind = r['ptc'], IN_PTC
+                else:
+                    if final == 'memout':
+                        r = ops.conv_fused(cur, w_packed, bias, in_kind=kind, T=T, mode=MODE_MEMOUT, in1=src1, coef=coef,
+                                           apply_tanh=apply_tanh, want_u8=want_u8, **geo)
+                    elif final == 'mean':
+                        r = ops.conv_fused(cur, w_packed, bias, in_kind=kind, T=T, mode=MODE_MEAN, in1=src1, **geo)
+                    else:
+                        r = ops.conv_fused(cur, w_packed, bias, in_kind=kind, T=T, mode=MODE_RAW, in1=src1, **geo)
+                    out['f32'], out['u8'] = r['f32'], r['u8']
         return out
