@@ -40,7 +40,7 @@ def gather_images(local_u8: torch.Tensor, total: int | None = None) -> torch.Ten
 
     Equal shards use a single ``all_gather_into_tensor``; ragged shards are padded to the largest shard so that
     it is still one collective.  With world_size == 1 (or no process group) it returns the input."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local_u8
     world = dist.get_world_size()
     if total is None:
