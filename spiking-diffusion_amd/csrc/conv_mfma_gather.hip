@@ -132,8 +132,9 @@ __global__ __launch_bounds__(256) void conv_mfma_gather_kernel(GArgs a) {
         v4i av[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          av[i] = (v4i){0, 0, 0, 0};
-          if (ok[i] && chan_ok) av[i] = *reinterpret_cast<const v4i*>(inb + ioff[i] + c * 32);
+          const bool use = ok[i] && chan_ok;
+          const v4i ld = *reinterpret_cast<const v4i*>(inb + (use ? ioff[i] + c * 32 : 0));    // see gather2_body
+          av[i] = use ? ld : (v4i){0, 0, 0, 0};
         }
         const int8_t* wp = a.wq + ((((long long)g * nchunks + c) * KK + tap) * 2) * 1024 + boff;
         const v4i b0 = *reinterpret_cast<const v4i*>(wp);
@@ -212,6 +213,217 @@ __global__ __launch_bounds__(256) void conv_mfma_gather_kernel(GArgs a) {
       if (a.out_u8) a.out_u8[oidx] = (uint8_t)(fminf(fmaxf(pv + 0.5f, 0.0f), 1.0f) * 255.0f);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------ specialised form
+// Same task, geometry known at compile time (KS x KS taps, stride S, transposed or not, NCH 32-channel K chunks,
+// pad = KS/2, sub-pixel class PY,PX): the valid (tap, chunk) steps are a compile-time list, every A and B fragment
+// of a task is requested before the first MFMA waits (up to 18 + 18 loads of 16 B per lane in flight per wave
+// instead of one dependent L2 round trip per K step), and the task decode has no integer division by runtime values
+// other than one per wave.  grid.y = image x class, grid.x*4 + wave = (position group, channel group).
+template <int MODE, int KS, int S, bool TR, int NCH, int PY, int PX>
+__device__ __forceinline__ void gather2_body(const GArgs& a, int b, int g, int pg, int lane) {
+  constexpr int PAD = KS / 2;
+  constexpr int KK = KS * KS;
+  const int Hc = TR ? (a.Ho - PY + S - 1) / S : a.Ho;
+  const int Wc = TR ? (a.Wo - PX + S - 1) / S : a.Wo;
+  const int npos_c = Hc * Wc;
+  if (pg * 4 >= npos_c) return;
+  const float inv_wc = 1.0f / (float)Wc;
+  const int row = lane & 31, half = lane >> 5;
+  const int hsel = (row >> 2) & 1, tt = (row & 3) + 4 * (row >> 3);
+  int oy[2], ox[2];
+  bool pvalid[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = pg * 4 + 2 * i + hsel;
+    pvalid[i] = q < npos_c;
+    const int qy = (int)(((float)q + 0.5f) * inv_wc), qx = q - qy * Wc;      // q < 2^20: exact
+    oy[i] = TR ? qy * S + PY : qy;
+    ox[i] = TR ? qx * S + PX : qx;
+  }
+  const int boff = (lane & 31) * 32 + 16 * (half ^ ((lane >> 4) & 1));
+  const uint8_t* inb = a.in + (long long)b * a.H * a.W * T16 * a.Cin;
+  const int8_t* wg = a.wq + (long long)g * NCH * KK * 2048 + boff;
+  const bool chan_hi_ok = 16 * half < a.Cin;                                  // Cin = 16: upper k-half is zero padding
+
+  v4i av[KK * NCH][2], bv[KK * NCH][2];
+  // ---- request everything
+#pragma unroll
+  for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+      constexpr int dummy = 0; (void)dummy;
+      const bool tap_ok = !TR || ((((PY + PAD - ky) % S + S) % S == 0) && (((PX + PAD - kx) % S + S) % S == 0));
+      if (tap_ok) {
+        long long ioff[2];
+        bool ok[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          int iy, ix;
+          if (TR) {
+            const int ty = oy[i] + PAD - ky, tx = ox[i] + PAD - kx;
+            iy = ty / S; ix = tx / S;
+            ok[i] = pvalid[i] && ty >= 0 && tx >= 0 && iy < a.H && ix < a.W;
+          } else {
+            iy = oy[i] * S - PAD + ky; ix = ox[i] * S - PAD + kx;
+            ok[i] = pvalid[i] && iy >= 0 && ix >= 0 && iy < a.H && ix < a.W;
+          }
+          ioff[i] = ((long long)(iy * a.W + ix) * T16 + tt) * a.Cin + 16 * half;
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int st = (ky * KS + kx) * NCH + c;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            // UNCONDITIONAL load from a clamped address + select afterwards: a load under a per-lane condition makes
+            // hipcc branch around it and drain vmcnt(0) per element, which serialises the whole gather
+            const bool use = ok[i] && (c * 32 + 16 * half < a.Cin) && chan_hi_ok;
+            const v4i ld = *reinterpret_cast<const v4i*>(inb + (use ? ioff[i] + c * 32 : 0));
+            av[st][i] = use ? ld : (v4i){0, 0, 0, 0};
+          }
+          const int8_t* wp = wg + ((long long)c * KK + (ky * KS + kx)) * 2048;
+          bv[st][0] = *reinterpret_cast<const v4i*>(wp);
+          bv[st][1] = *reinterpret_cast<const v4i*>(wp + 1024);
+        }
+      }
+    }
+  }
+  // ---- consume
+  v16i acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0; acc[i][1][r] = 0; }
+#pragma unroll
+  for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+      const bool tap_ok = !TR || ((((PY + PAD - ky) % S + S) % S == 0) && (((PX + PAD - kx) % S + S) % S == 0));
+      if (tap_ok) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int st = (ky * KS + kx) * NCH + c;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            acc[i][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[st][i], bv[st][0], acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[st][i], bv[st][1], acc[i][1], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // ---- epilogue (identical to the generic kernel)
+  const int col = lane & 31, ch = col & 15, odd = col >> 4;
+  const int co = g * 16 + ch;
+  const bool co_ok = co < a.Cout;
+  const double sc = a.scale[g * 16 + ch], bi = a.bias[g * 16 + ch];
+  auto recombine = [&](int i, float (&x)[16]) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const v2u p01 = __builtin_amdgcn_permlane16_swap((unsigned)acc[i][0][r], (unsigned)acc[i][0][r + 8], false, false);
+      const v2u p23 = __builtin_amdgcn_permlane16_swap((unsigned)acc[i][1][r], (unsigned)acc[i][1][r + 8], false, false);
+      const int hi = (int)p01[0] * 256 + (int)p01[1], lo = (int)p23[0] * 256 + (int)p23[1];
+      const double s = fma((double)hi, 65536.0, (double)lo);
+      const float xm = (float)fma(s, sc, bi);
+      const v2u xx = __builtin_amdgcn_permlane16_swap(__float_as_uint(xm), __float_as_uint(xm), false, false);
+      x[r] = __uint_as_float(xx[0]);
+      x[r + 8] = __uint_as_float(xx[1]);
+    }
+  };
+  float xa[16], xb[16];
+  recombine(0, xa);
+  recombine(1, xb);
+  const int q = pg * 4 + 2 * odd + half;
+  const bool pos_ok = q < npos_c;
+  const int qy = (int)(((float)q + 0.5f) * inv_wc), qx = q - qy * Wc;
+  const int opos = (TR ? qy * S + PY : qy) * a.Wo + (TR ? qx * S + PX : qx);
+  const long long HWo = (long long)a.Ho * a.Wo;
+  if (MODE == SPK_MODE_LIF) {
+    const float bn_a = co_ok ? a.bn_a[co] : 0.f, bn_b = co_ok ? a.bn_b[co] : 0.f;
+    const long long vidx = ((long long)b * a.Cout + (co_ok ? co : 0)) * HWo + (pos_ok ? opos : 0);
+    float v = (a.v_io && pos_ok && co_ok) ? a.v_io[vidx] : 0.f;
+    unsigned mybits = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float xv = odd ? xb[r] : xa[r];
+      const bool s = spk_lif_step_default(v, fmaf(xv, bn_a, bn_b)) && pos_ok && co_ok;
+      mybits |= s ? (1u << r) : 0u;
+    }
+    if (a.v_io && pos_ok && co_ok) a.v_io[vidx] = v;
+    const unsigned bitsv = transpose16_rows_g(mybits, lane);
+    if (pos_ok) {
+      uint4 o;
+      o.x = ((bitsv & 0xfu) * 0x00204081u) & 0x01010101u;
+      o.y = (((bitsv >> 4) & 0xfu) * 0x00204081u) & 0x01010101u;
+      o.z = (((bitsv >> 8) & 0xfu) * 0x00204081u) & 0x01010101u;
+      o.w = (((bitsv >> 12) & 0xfu) * 0x00204081u) & 0x01010101u;
+      uint8_t* dst = a.out_ptc + (((long long)b * HWo + opos) * T16 + (lane & 15)) * a.Cout + g * 16;
+      if (g * 16 + 16 <= a.Cout) {
+        *reinterpret_cast<uint4*>(dst) = o;
+      } else {
+        const uint8_t* ob = reinterpret_cast<const uint8_t*>(&o);
+        for (int c2 = 0; g * 16 + c2 < a.Cout; ++c2) dst[c2] = ob[c2];
+      }
+    }
+  } else {
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = m + (odd ? xb[r] : xa[r]) * a.coef[r];
+    if (pos_ok && co_ok) {
+      const float pv = a.apply_tanh ? tanhf(m) : m;
+      const long long oidx = ((long long)b * a.Cout + co) * HWo + opos;
+      if (a.out_f32) a.out_f32[oidx] = pv;
+      if (a.out_u8) a.out_u8[oidx] = (uint8_t)(fminf(fmaxf(pv + 0.5f, 0.0f), 1.0f) * 255.0f);
+    }
+  }
+}
+
+template <int MODE, int KS, int S, bool TR, int NCH>
+__global__ __launch_bounds__(256) void conv_mfma_gather2_kernel(GArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int NCLS = TR ? S * S : 1;
+  const int G = (a.Cout + 15) >> 4;
+  const int b = blockIdx.y / NCLS, cls = blockIdx.y - b * NCLS;
+  const int wt = blockIdx.x * 4 + wave_s;
+  const int pg = wt / G, g = wt - pg * G;
+  if (TR && S == 2) {
+    switch (cls) {
+      case 0: gather2_body<MODE, KS, S, TR, NCH, 0, 0>(a, b, g, pg, lane); break;
+      case 1: gather2_body<MODE, KS, S, TR, NCH, 0, 1>(a, b, g, pg, lane); break;
+      case 2: gather2_body<MODE, KS, S, TR, NCH, 1, 0>(a, b, g, pg, lane); break;
+      default: gather2_body<MODE, KS, S, TR, NCH, 1, 1>(a, b, g, pg, lane); break;
+    }
+  } else {
+    gather2_body<MODE, KS, S, TR, NCH, 0, 0>(a, b, g, pg, lane);
+  }
+}
+
+template <int MODE, int KS, int S, bool TR, int NCH>
+int launch_gather2(const GArgs& a, hipStream_t stream) {
+  constexpr int NCLS = TR ? S * S : 1;
+  const int Hc0 = TR ? (a.Ho + S - 1) / S : a.Ho, Wc0 = TR ? (a.Wo + S - 1) / S : a.Wo;
+  const int groups = (Hc0 * Wc0 + 3) / 4, G = (a.Cout + 15) / 16;
+  const long long by = (long long)a.B * NCLS;
+  if (by > 65535) return SPK_ERR_UNSUPPORTED;
+  dim3 grid((groups * G + 3) / 4, (unsigned)by), blk(256);
+  hipLaunchKernelGGL((conv_mfma_gather2_kernel<MODE, KS, S, TR, NCH>), grid, blk, 0, stream, a);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+// returns SPK_ERR_UNSUPPORTED when no specialisation matches (the caller then uses the generic kernel)
+template <int MODE>
+int dispatch_gather2(const GArgs& a, hipStream_t stream) {
+  const int nch = (a.Cin + 31) / 32;
+  if (a.pad != a.k / 2 || a.B > 16000) return SPK_ERR_UNSUPPORTED;
+  if (!a.transposed && a.k == 3 && a.stride == 2 && nch == 1) return launch_gather2<MODE, 3, 2, false, 1>(a, stream);   // enc conv2
+  if (!a.transposed && a.k == 1 && a.stride == 1 && nch == 2) return launch_gather2<MODE, 1, 1, false, 2>(a, stream);   // enc conv3
+  if (a.transposed && a.k == 3 && a.stride == 2 && nch == 1) return launch_gather2<MODE, 3, 2, true, 1>(a, stream);     // dec convT1
+  if (a.transposed && a.k == 3 && a.stride == 2 && nch == 2) return launch_gather2<MODE, 3, 2, true, 2>(a, stream);     // dec convT2
+  if (a.transposed && a.k == 3 && a.stride == 1 && nch == 1) return launch_gather2<MODE, 3, 1, true, 1>(a, stream);     // dec convT3
+  return SPK_ERR_UNSUPPORTED;
 }
 
 // ------------------------------------------------------------------------------------------------ weight packing
@@ -305,9 +517,11 @@ extern "C" int spk_conv_mfma_fused_fwd(const uint8_t* in_ptc, const int8_t* wq, 
   dim3 grid((unsigned)blocks), blk(256);
   if (mode == SPK_MODE_LIF) {
     if (!bn_a || !bn_b || !out_ptc) return SPK_ERR_ARG;
+    if (dispatch_gather2<SPK_MODE_LIF>(a, stream) == SPK_OK) return SPK_OK;          // compile-time geometry
     hipLaunchKernelGGL(conv_mfma_gather_kernel<SPK_MODE_LIF>, grid, blk, 0, stream, a);
   } else if (mode == SPK_MODE_MEMOUT) {
     if (!coef || (!out_f32 && !out_u8)) return SPK_ERR_ARG;
+    if (dispatch_gather2<SPK_MODE_MEMOUT>(a, stream) == SPK_OK) return SPK_OK;
     hipLaunchKernelGGL(conv_mfma_gather_kernel<SPK_MODE_MEMOUT>, grid, blk, 0, stream, a);
   } else {
     return SPK_ERR_UNSUPPORTED;
