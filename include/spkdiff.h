@@ -31,6 +31,7 @@ typedef struct ihipStream_t* spk_stream_t; /* == hipStream_t */
 #define SPK_VERSION 100 /* 0.1.0 */
 
 /* fused-kernel epilogue modes (spk_conv_fused_fwd) */
+#define SPK_CHUNK_C4 (-64) /* chunk_out value: fp4 nibble-packed output, 64 channels per chunk */
 #define SPK_MODE_LIF 0    /* BN + LIF -> spikes                                    */
 #define SPK_MODE_RAW 1    /* conv output per time step, fp32 TBCHW                 */
 #define SPK_MODE_MEMOUT 2 /* sum_t x[t]*coef[t] (+tanh, +uint8)  -> [B,C,H,W]      */
@@ -92,7 +93,8 @@ int spk_pack_conv_weight(const float* w, float* packed, int Cout, int Cin, int k
  *                out_ptc u8 PTC and/or out_f32 fp32 TBCHW spikes; out_pre optional BN output.
  *   mode RAW:    out_f32 TBCHW conv output.    mode MEMOUT: coef [T]; out_f32 [B,Cout,Ho,Wo] (tanh if apply_tanh),
  *                out_u8 = uint8(clip(p+0.5,0,1)*255) (R/main.py:401).   mode MEAN: out_f32 = sum_t x[t] / T.
- *   chunk0 / chunk1 / chunk_out: channel chunking of in0 / in1 / out_ptc (<= 0: plain PTC).
+ *   chunk0 / chunk1 / chunk_out: channel chunking of in0 / in1 / out_ptc (0: plain PTC); chunk_out = SPK_CHUNK_C4:
+ *                out_ptc is written as nibble-packed fp4 "C4" (see spk_den_conv3x3_mfma_fp6; Cout % 64 == 0).
  *   out_counts (mode LIF, optional): per-neuron spike counts over T, u8 [B,Cout/32,Ho*Wo,32]. */
 int spk_conv_fused_fwd(const void* in0, const uint8_t* in1, int C0, int C1, int in_kind, const float* w_packed,
                        const float* bias, const float* bn_a, const float* bn_b, float* v_inout, uint8_t* out_ptc,
@@ -122,6 +124,27 @@ int spk_den_conv3x3_mfma(const uint8_t* in0_cptc, int nch0, const uint8_t* in1_c
 int spk_den_conv3x3_counts_mfma(const uint8_t* cnt0, int nch0, const uint8_t* cnt1, int nch1, const int8_t* wq,
                                 const double* scale, const double* bias_d, float* out_f32, int T, int B, int H, int W,
                                 int Cout, spk_stream_t stream);
+
+/* ---- denoiser convolutions on the block-scaled fp6/fp4 MFMA (CDNA4 v_mfma_scale_f32_32x32x64_f8f6f4) -------------- */
+/* Same operator and numerics contract as spk_den_conv3x3_mfma (LIF mode: DummyModel conv2..conv5,
+ * R/snn_model/vq_diffusion.py:166-184,201-204) at 3/4 of its matrix-core time: weights as six radix-32 fp6 (e2m3)
+ * digit planes, spikes as fp4 (e2m1) nibbles.  Spike tensors are "C4": [B][C/64][h*w][16][32 B], channel c of a
+ * 64-channel chunk in byte c/2 (low nibble first), nibble = 0x2 for a spike.
+ * Bytes of the packed weights of one layer ([Cout/16][Cin/64] slabs of [9][3][64 lanes x 24 B], each padded to 41 KiB);
+ * -1 if unsupported. */
+long long spk_den_packed_weight_fp6_bytes(int Cout, int Cin);
+/* fp32 conv weight [Cout,Cin,3,3] (+bias) -> six balanced radix-32 digit planes as e2m3 codes + per-channel 2^-s
+ * scale and fp64 bias. */
+int spk_den_pack_weight_fp6(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d, int Cout,
+                            int Cin, spk_stream_t stream);
+/* in_c4: nch chunks of 64 channels; out_c4 [B][Cout/64][h*w][16][32]; v_inout / out_counts as in spk_den_conv3x3_mfma.
+ * SPK_ERR_UNSUPPORTED unless T == 16, Cout % 64 == 0 and the latent fits the kernel's LDS plan (7x7). */
+int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* scale, const double* bias_d,
+                             const float* bn_a, const float* bn_b, float* v_inout, uint8_t* out_c4, uint8_t* out_counts,
+                             int T, int B, int H, int W, int Cout, spk_stream_t stream);
+/* fp32 spikes [T,B,C,HW] <-> C4 (C % 64 == 0): module boundaries and tests. */
+int spk_spikes_to_fp4(const float* spikes, uint8_t* out_c4, int T, int B, int C, int HW, spk_stream_t stream);
+int spk_fp4_to_spikes(const uint8_t* in_c4, float* spikes, int T, int B, int C, int HW, spk_stream_t stream);
 
 /* ---- spiking VQ-VAE layers on the matrix cores ------------------------------------------------------------------- */
 /* Bytes of the packed int8 digit planes of a k x k (transposed) conv: [ceil(Cout/16)][ceil(Cin/32)][k*k][2][32][32]. */

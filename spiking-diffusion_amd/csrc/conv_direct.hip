@@ -102,6 +102,7 @@ struct FusedArgs {
   int T, B, H, W, Cout, Ho, Wo, k, stride, pad;
   uint8_t* out_cnt;     // MODE_LIF, optional: spike counts over T, u8 [B][Cout/32][Ho*Wo][32]
   int chunk0, chunk1, chunk_out;   // channel chunking of the PTC tensors ([B][C/chunk][HW][T][chunk]); chunk == C: plain
+  int out_c4;           // out_ptc is nibble-packed fp4 "C4" ([B][Cout/64][HW][T][32 B]) for the fp6 MFMA kernel
 };
 
 template <int INKIND, bool TRANSPOSED, int MODE>
@@ -217,7 +218,15 @@ __global__ __launch_bounds__(256) void conv_fused_kernel(FusedArgs a) {
           }
           const bool s = spk_lif_step_default(v, y);
           nspk += s ? 1 : 0;
-          if (a.out_ptc) a.out_ptc[o_ptc + (long long)t * a.chunk_out] = (uint8_t)s;
+          if (a.out_c4) {
+            // channels (co, co ^ 1) are neighbouring lanes: the even one stores both e2m1 nibbles (0x2 = 1.0)
+            const int so = __shfl_xor((int)s, 1);
+            if (!(co & 1))
+              a.out_ptc[((((long long)b * (a.Cout >> 6) + (co >> 6)) * plane + oy * a.Wo + ox) * T + t) * 32 + ((co & 63) >> 1)] =
+                  (uint8_t)((s ? 0x02 : 0) | (so ? 0x20 : 0));
+          } else if (a.out_ptc) {
+            a.out_ptc[o_ptc + (long long)t * a.chunk_out] = (uint8_t)s;
+          }
           if (a.out_f32) a.out_f32[o_bchw + t * tstride] = s ? 1.0f : 0.0f;
         }
       }
@@ -323,6 +332,8 @@ extern "C" int spk_conv_fused_fwd(const void* in0, const uint8_t* in1, int C0, i
   if (in_kind == SPK_IN_PTC && ((C0 % 4) || (C1 % 4))) return SPK_ERR_UNSUPPORTED;   // u32 spike loads
   if (chunk0 <= 0) chunk0 = C0;
   if (chunk1 <= 0) chunk1 = C1 > 0 ? C1 : 4;
+  const int out_c4 = chunk_out == SPK_CHUNK_C4;
+  if (out_c4 && (mode != SPK_MODE_LIF || !out_ptc || (Cout % 64))) return SPK_ERR_ARG;
   if (chunk_out <= 0) chunk_out = Cout;
   if (in_kind == SPK_IN_PTC && ((chunk0 % 4) || (C0 % chunk0) || (C1 > 0 && ((chunk1 % 4) || (C1 % chunk1)))))
     return SPK_ERR_ARG;
@@ -336,7 +347,7 @@ extern "C" int spk_conv_fused_fwd(const void* in0, const uint8_t* in1, int C0, i
   FusedArgs a;
   a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.wt = w_packed; a.bias = bias; a.bn_a = bn_a; a.bn_b = bn_b;
   a.v_io = v_inout; a.out_ptc = out_ptc; a.out_f32 = out_f32; a.out_pre = out_pre; a.out_u8 = out_u8; a.coef = coef;
-  a.chunk0 = chunk0; a.chunk1 = chunk1; a.chunk_out = chunk_out; a.out_cnt = out_counts;
+  a.chunk0 = chunk0; a.chunk1 = chunk1; a.chunk_out = chunk_out; a.out_cnt = out_counts; a.out_c4 = out_c4;
   if (out_counts && (mode != SPK_MODE_LIF || (Cout % 32))) return SPK_ERR_ARG;
   a.apply_tanh = apply_tanh; a.T = T; a.B = B; a.H = H; a.W = W; a.Cout = Cout;
   a.Ho = spk_conv_out_size(H, k, stride, pad, transposed, out_pad);

@@ -1,0 +1,60 @@
+// Helpers shared by the two matrix-core denoiser kernels (den_mfma.hip: int8 digit planes, den_mfma_fp6.hip: fp6).
+#pragma once
+#include "spk_common.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+#define SPK_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+#define SPK_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// 16x16 bit-matrix transpose inside every 16-lane row (lane = row, bit = column) with DPP lane exchanges:
+// lane^8 = row_mirror o row_half_mirror, lane^4 = row_half_mirror o quad-reverse, lane^2 / lane^1 = quad_perm.
+__device__ __forceinline__ unsigned spk_transpose16_rows(unsigned x, int lane) {
+  unsigned y;
+  y = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(x, 0x140, 0xF, 0xF, true), 0x141, 0xF, 0xF, true);
+  x = (lane & 8) ? (((y >> 8) & 0x00FFu) | (x & 0xFF00u)) : ((x & 0x00FFu) | ((y & 0x00FFu) << 8));
+  y = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
+  x = (lane & 4) ? (((y >> 4) & 0x0F0Fu) | (x & 0xF0F0u)) : ((x & 0x0F0Fu) | ((y & 0x0F0Fu) << 4));
+  y = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);
+  x = (lane & 2) ? (((y >> 2) & 0x3333u) | (x & 0xCCCCu)) : ((x & 0x3333u) | ((y & 0x3333u) << 2));
+  y = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);
+  x = (lane & 1) ? (((y >> 1) & 0x5555u) | (x & 0xAAAAu)) : ((x & 0x5555u) | ((y & 0x5555u) << 1));
+  return x;
+}
+
+// CU count of the current device, queried once (a constant of the machine; keeps device queries out of hipGraph capture)
+static inline int spk_cu_count() {
+  static const int cus = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      return v;
+    return 256;
+  }();
+  return cus;
+}
+
+// LDS-DMA of 16 bytes per lane: LDS[lds_base + lane * 16] = *(gsrc of this lane); lds_base is wave-uniform.
+// Issued as inline assembly on purpose: hipcc treats the builtin (__builtin_amdgcn_global_load_lds) as a FLAT access
+// that may touch LDS, and while one is in flight every LDS wait it inserts degrades to s_waitcnt lgkmcnt(0) -- which
+// exposes the latency of the most recent fragment prefetch at every fourth MFMA group.  Hidden from the compiler the
+// copy only moves the VM counter, so the caller MUST drain it itself (spk_dma_wait_all) before the barrier that
+// publishes the data.
+__device__ __forceinline__ void spk_dma16(const void* gsrc, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               : : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_base)) : "memory", "m0");
+}
+// The same copy with the source given as a wave-uniform base (SGPR pair) + a 32-bit per-lane byte offset: no vector
+// address arithmetic per piece.
+__device__ __forceinline__ void spk_dma16s(const void* sbase, unsigned voff, unsigned lds_base) {
+  const unsigned long long b = (unsigned long long)sbase;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  const unsigned long long bs = ((unsigned long long)hi << 32) | lo;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               : : "v"(voff), "s"(bs), "s"(__builtin_amdgcn_readfirstlane(lds_base)) : "memory", "m0");
+}
+__device__ __forceinline__ void spk_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned spk_lds_addr(const void* p) { return (unsigned)(size_t)SPK_LDS(p); }

@@ -31,16 +31,13 @@
 //   * Spike emission: every lane collects the 16 spike bits of its neuron; a 16x16 bit-matrix transpose inside each
 //     16-lane row (4 DPP exchange rounds) hands lane t the 16 channel bits of step t, which it expands to 16 bytes and
 //     writes as ONE 16-byte store per (position, time step).
-#include "spk_common.h"
+#include "den_common.h"
 #include "../../include/spkdiff.h"
 #include <stdlib.h>
 #include <type_traits>
 
 namespace {
 
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
-typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
 constexpr int T16 = 16;
 constexpr int CK = 32;                           // channels per K chunk
@@ -56,24 +53,6 @@ struct MfmaArgs {
   int B, H, W, Cout, mode;
   int dbg;   // -DSPK_MFMA_ABLATION builds only (env SPK_MFMA_DEBUG): 1 = skip steady-state DMA, 2 = skip MFMAs, 4 = skip epilogue
 };
-
-// 16x16 bit-matrix transpose inside every 16-lane row (lane = row, bit = column) with DPP lane exchanges:
-// lane^8 = row_mirror o row_half_mirror, lane^4 = row_half_mirror o quad-reverse, lane^2 / lane^1 = quad_perm.
-__device__ __forceinline__ unsigned transpose16_rows(unsigned x, int lane) {
-  unsigned y;
-  y = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(x, 0x140, 0xF, 0xF, true), 0x141, 0xF, 0xF, true);
-  x = (lane & 8) ? (((y >> 8) & 0x00FFu) | (x & 0xFF00u)) : ((x & 0x00FFu) | ((y & 0x00FFu) << 8));
-  y = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
-  x = (lane & 4) ? (((y >> 4) & 0x0F0Fu) | (x & 0xF0F0u)) : ((x & 0x0F0Fu) | ((y & 0x0F0Fu) << 4));
-  y = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);
-  x = (lane & 2) ? (((y >> 2) & 0x3333u) | (x & 0xCCCCu)) : ((x & 0x3333u) | ((y & 0x3333u) << 2));
-  y = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);
-  x = (lane & 1) ? (((y >> 1) & 0x5555u) | (x & 0xAAAAu)) : ((x & 0x5555u) | ((y & 0x5555u) << 1));
-  return x;
-}
-
-#define SPK_LDS(p) ((__attribute__((address_space(3))) void*)(p))
-#define SPK_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
 
 // NT = row tiles per wave (7 for 7x7 latents, 8 for 8x8); NPA = A-slab DMA pieces per wave (H*ceil(W/2)/4, rounded up).
 template <int NT, int NPA, int MODE, int DBG>
@@ -296,7 +275,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
           const unsigned cnt = __popc(mybits);
           // lanes of a 16-lane row are the 16 channels of one (tile, position): transposing the 16x16 bit matrix gives
           // lane t the 16 channel bits of time step t -- the 16 bytes it stores
-          const unsigned bitsv = transpose16_rows(mybits, lane);
+          const unsigned bitsv = spk_transpose16_rows(mybits, lane);
           if (a.v_io && pos_ok) a.v_io[vidx] = v;
           if (a.out_cnt && pos_ok)
             a.out_cnt[(((long long)b * (a.Cout >> 5) + (co >> 5)) * HW + p) * CK + (co & 31)] = (uint8_t)cnt;
@@ -444,14 +423,7 @@ int launch(const MfmaArgs& a, hipStream_t stream) {
   const int nt = (ntiles + 3) / 4;
   const size_t lds = 2 * ((size_t)(a.H + 2) * (a.W + 2) * POS_BYTES + W_CHUNK_BYTES);
   if (lds > 160 * 1024) return SPK_ERR_UNSUPPORTED;
-  // CU count of the current device, queried once (a constant of the machine; keeps device queries out of hipGraph capture)
-  static const int cus = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-      return v;
-    return 256;
-  }();
+  const int cus = spk_cu_count();
   const int total = a.B * (a.Cout / 16);
   dim3 grid(total < cus ? total : cus), blk(256);          // persistent: one workgroup per CU
   const int npa = (a.H * ((a.W + 1) / 2) + 3) / 4;

@@ -1,0 +1,486 @@
+// 3x3 convolution over binary spike tensors on the MI355X matrix cores with the CDNA4 block-scaled MFMA
+// (v_mfma_scale_f32_32x32x64_f8f6f4): spikes as fp4 (e2m1), weights as six radix-32 fp6 (e2m3) digit planes.
+// BN + LIF scan fused into the accumulator epilogue.  Denoiser conv2..conv5, R/snn_model/vq_diffusion.py:166-184,
+// 201-204.  Same mapping as den_mfma.hip (read that header first); what differs:
+//
+// EXACT FORMULATION.  Each fp32 weight is re-encoded once (spk_den_pack_weight_fp6) as a 29-bit fixed-point number
+// relative to its output channel's largest magnitude and split into six balanced radix-32 digits D0..D5 in [-16,16]:
+// w_q = 2^-s * sum_p D_p * 32^(5-p).  A digit d is the e2m3 value d/8 (e2m3 holds every multiple of 1/8 up to 2.0
+// exactly: code = sign<<5 | |d|), the B-side block scale 2^3 makes the products integers again.  Spikes are the e2m1
+// codes 0x0 / 0x2 (0.0 / 1.0).  Products are exact, and the fp32 accumulators hold integers below 4608*16 < 2^24, so
+// the accumulation is exact (probe: tools/f8f6f4_probe.hip).  The six digit sums are recombined exactly in fp64 and
+// rounded ONCE to fp32 -- the same contract as the int8 kernel.  Weights within 2^6 of the channel maximum are
+// represented exactly, smaller ones are rounded at 2^-29 of that maximum.
+//
+// WHY.  The fp6/fp4 MFMA retires K = 64 in the 33 cycles the int8 MFMA needs for K = 32 (measured), i.e. 5 digit bits
+// x 2 per unit time against 8: six fp6 planes cost 3/4 of the matrix-core time of four int8 planes.
+//
+// MAPPING.  A work item = one image x 16 output channels = 7 row tiles x 3 column tiles (16 channels x 2 planes
+// each) per wave = 336 accumulator registers: 15 tiles live in AGPRs, 6 in VGPRs.  hipcc cannot split an MFMA
+// accumulator set over both files, so the MFMAs are inline assembly with explicit register classes; the wait states
+// between the last MFMA and the first read of an accumulator are inserted by hand.
+// K chunk = 64 input channels: spikes travel nibble-packed ("C4": [B][C/64][HW][T][32 B], channel c of a chunk in
+// byte c/2, low nibble first), so one position is still 512 B and the LDS image / DMA geometry equals the int8
+// kernel's.  The zero-bordered LDS image uses a pitch of W+1 cells (the zero column is shared by x = -1 of a row and
+// x = W of the previous one) so that two images and two 40.5 KB weight slabs fit the 160 KB LDS.
+#include "den_common.h"
+#include "../../include/spkdiff.h"
+#include <type_traits>
+
+namespace {
+
+typedef int v6i __attribute__((ext_vector_type(6)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int T16 = 16;
+constexpr int CK = 64;                              // channels per K chunk
+constexpr int POS_BYTES = T16 * CK / 2;             // 512 B per latent position per chunk
+constexpr int W_TILE_BYTES = 64 * 24;               // one (tap, column tile): 64 lanes x 32 six-bit codes
+constexpr int W_PIECES = (9 * 3 * W_TILE_BYTES + 1023) / 1024;   // 41 one-KiB DMA pieces
+constexpr int W_CHUNK_BYTES = W_PIECES * 1024;      // 41984 B per (channel group, chunk): 27 tiles + 512 B of padding
+constexpr int NPW = (W_PIECES + 3) / 4;             // W pieces per wave (wave w copies pieces w, w + 4, ...)
+
+struct Fp6Args {
+  const uint8_t* in0; int nch0;
+  const uint8_t* wq; const double* scale; const double* bias; const float* bn_a; const float* bn_b;
+  uint8_t* out; float* v_io; uint8_t* out_cnt;
+  int B, H, W, Cout;
+};
+
+// D = A(32 x 64 fp4) * B(64 x 32 fp6) + C, accumulator in AGPRs ("a") or VGPRs ("v"); *_Z: C = 0 (first MFMA of an item).
+// s_nop 1: the two wait states between a VALU write of an operand register (the B fragment hand-over is v_mov) and
+// the MFMA that reads it, which hipcc's hazard recognizer cannot insert around inline assembly.
+#define SPK_MFMA_FP6(CLS, acc, av, bv, sa, sb)                                                                       \
+  asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:2"  \
+               : "+" CLS(acc) : "v"(av), "v"(bv), "v"(sa), "v"(sb))
+#define SPK_MFMA_FP6_Z(CLS, acc, av, bv, sa, sb)                                                                     \
+  asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:2"   \
+               : "=&" CLS(acc) : "v"(av), "v"(bv), "v"(sa), "v"(sb))
+
+#ifndef SPK_FP6_DBG
+#define SPK_FP6_DBG 0           // timing experiments only: 1 = no steady-state DMA, 4 = no epilogue (results are wrong)
+#endif
+#ifndef SPK_FP6_PF
+#define SPK_FP6_PF 4
+#endif
+#ifndef SPK_FP6_DMA_EVERY
+#define SPK_FP6_DMA_EVERY 3     // (9 * NT) / (NPA + NPW) spreads the pieces over the whole chunk
+#endif
+constexpr int NT = 7;          // row tiles per wave (7x7 latents: 25 tiles of 2 positions, padded to 28)
+constexpr int NPA = 7;         // A-slab DMA pieces per wave
+constexpr int N_AGPR = 16;     // accumulators (row tile i, column tile j: index 3*i + j) that live in AGPRs (256 registers)
+
+__global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int HW = a.H * a.W, PW = a.W + 1;
+  const int npp = (a.H + 2) * PW + 1;
+  const int A_BYTES = npp * POS_BYTES;
+  // LDS: [A buf0][A buf1][W buf0][W buf1]
+  uint8_t* const sA = lds;
+  uint8_t* const sW = lds + 2 * A_BYTES;
+  const unsigned sA_addr = spk_lds_addr(sA), sW_addr = sA_addr + 2 * A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nchunks = a.nch0;
+  const int G = a.Cout >> 4;
+  const int total = a.B * G;
+
+  // zero both A images once: the borders stay zero for the whole kernel, interiors are overwritten by DMA
+  for (int i = tid; i < 2 * A_BYTES / 16; i += 256) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
+
+  // per-lane LDS byte offsets of this wave's A fragments (tile ti = wave + 4*i); absent tiles read garbage that the
+  // epilogue discards
+  const int row = lane & 31, half = lane >> 5;
+  const int hsel = (row >> 2) & 1, tt = (row & 3) + 4 * (row >> 3);
+  int a_off[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int p = 2 * (wave + 4 * i) + hsel;
+    const int pp = p < HW ? (p / a.W + 1) * PW + (p % a.W) + 1 : PW + 1;
+    a_off[i] = pp * POS_BYTES + tt * 32 + 16 * (half ^ (tt >> 3));   // 16-B halves swapped for t >= 8: bank-conflict-free
+  }
+
+  // DMA piece table, wave-uniform (scalar) values: see den_mfma.hip
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int pprow = (a.W + 1) >> 1;
+  const int nA = a.H * pprow;
+  int pa_src[NPA], pa_dst[NPA];      // byte offsets; pa_src < 0: absent piece
+  bool pa_full[NPA];
+#pragma unroll
+  for (int j = 0; j < NPA; ++j) {
+    const int id = wave_s * NPA + j;
+    const int y = id / pprow, px = id - y * pprow;
+    pa_src[j] = id < nA ? (y * a.W + 2 * px) * POS_BYTES : -1;
+    pa_dst[j] = ((y + 1) * PW + 1 + 2 * px) * POS_BYTES;
+    pa_full[j] = 2 * px + 1 < a.W;
+  }
+  const unsigned lane_a = (unsigned)(lane ^ ((lane >> 4) & 1)) * 16u;     // swizzled source lane (see a_off)
+  const unsigned lane_w = (unsigned)lane * 16u;
+
+  // piece q of this wave: q < NPA -> A piece q, else W piece wave + 4 * (q - NPA)
+  auto issue_piece = [&](int q, const uint8_t* aslab, const uint8_t* wslab, unsigned dA, unsigned dW) {
+    if (q < NPA) {
+      if (pa_src[q] >= 0) {
+        if (pa_full[q] || lane < 32)
+          spk_dma16s(aslab + pa_src[q], lane_a, dA + pa_dst[q]);
+      }
+    } else {
+      const int k = wave_s + 4 * (q - NPA);
+      if (k < W_PIECES) spk_dma16s(wslab + k * 1024, lane_w, dW + k * 1024);
+    }
+  };
+  auto slabs = [&](int item, int c, const uint8_t*& aslab, const uint8_t*& wslab) {
+    const int b = item / G, g = item - b * G;
+    aslab = a.in0 + ((long long)b * nchunks + c) * HW * POS_BYTES;
+    wslab = a.wq + ((long long)g * nchunks + c) * W_CHUNK_BYTES;
+  };
+
+  const int col = lane & 31, ch = col & 15, odd = col >> 4;
+  const int sc_a = 0x7f7f7f7f;             // e8m0 block scales: spikes x 1
+  const int sc_b = (int)0x82828282u;       //                    digits x 8 (e2m3 value d/8 -> d)
+
+  int it = 0;                                      // running chunk counter: LDS buffer = it & 1
+  if ((int)blockIdx.x < total) {
+    const uint8_t *as0, *ws0;
+    slabs(blockIdx.x, 0, as0, ws0);
+#pragma unroll
+    for (int q = 0; q < NPA + NPW; ++q) issue_piece(q, as0, ws0, sA_addr, sW_addr);
+  }
+  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    v16f acc[NT][3];      // written (not accumulated) by tap 0 of the first chunk: no explicit zeroing
+    // epilogue constants of this item's channel: loaded now, their latency hides under the K loop
+    const int b = item / G, g = item - b * G;
+    const int co = g * 16 + ch;
+    const double sc = a.scale[co], bi = a.bias[co];
+    const float bn_a = a.bn_a[co], bn_b = a.bn_b[co];
+    for (int c = 0; c < nchunks; ++c, ++it) {
+      const int buf = it & 1;
+      spk_dma_wait_all();  // this wave's share of the chunk's DMA has landed ...
+      __syncthreads();     // ... and so has everyone else's; everyone is done with the other buffer
+      // next chunk (possibly of the next item): its DMA pieces are issued between the MFMA groups below
+      int nitem = item, nc = c + 1;
+      if (nc == nchunks) { nc = 0; nitem = item + gridDim.x; }
+      const bool have_next = nitem < total && !(SPK_FP6_DBG & 1);
+      const uint8_t *n_aslab, *n_wslab;
+      slabs(have_next ? nitem : item, nc, n_aslab, n_wslab);
+      const unsigned n_dA = sA_addr + (buf ^ 1) * A_BYTES;            // LDS byte addresses of the DMA destinations
+      const unsigned n_dW = sW_addr + (buf ^ 1) * W_CHUNK_BYTES;
+
+      // ---------------- 9 taps x NT row tiles x 3 column tiles, A fragments read four steps ahead ------------------
+      auto compute = [&](auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const uint8_t* A = sA + buf * A_BYTES;
+        const uint8_t* Wb = sW + buf * W_CHUNK_BYTES;
+        auto lda = [&](int s) -> v4i {
+          const int tap = s / NT, i = s % NT;
+          const int toff = ((tap / 3 - 1) * PW + (tap % 3 - 1)) * POS_BYTES;
+          return *reinterpret_cast<const v4i*>(A + a_off[i] + toff);
+        };
+        auto ldb = [&](int tap, int j) -> v6i {
+          // 16 + 8 bytes per lane.  The 8-byte read is volatile so that hipcc does not pair the tails of two tiles in
+          // one ds_read2st64_b64 -- which lands them in the wrong registers and costs a wait + v_mov per tap.
+          const uint8_t* p = Wb + (tap * 3 + j) * W_TILE_BYTES;
+          const v4i x = *reinterpret_cast<const v4i*>(p + lane * 16);
+          typedef const volatile __attribute__((address_space(3))) v2i* lds_v2i_ptr;
+          const v2i y = *(lds_v2i_ptr)SPK_LDS(p + 1024 + lane * 8);
+          const v6i r = {x[0], x[1], x[2], x[3], y[0], y[1]};
+          return r;
+        };
+        v6i bc[3], bn[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { bc[j] = ldb(0, j); bn[j] = bc[j]; }
+        constexpr int PF = SPK_FP6_PF;             // A fragments in flight ahead of the MFMA that consumes them
+        v4i af[PF];
+#pragma unroll
+        for (int s = 0; s < PF; ++s) af[s] = lda(s);
+#pragma unroll
+        for (int s = 0; s < 9 * NT; ++s) {
+          const int tap = s / NT, i = s % NT;
+          const v4i av = af[s % PF];
+          if (s + PF < 9 * NT) af[s % PF] = lda(s + PF);
+          auto mfma = [&](int j) {
+            if (FIRST && tap == 0) {
+              if (3 * i + j < N_AGPR) SPK_MFMA_FP6_Z("a", acc[i][j], av, bc[j], sc_a, sc_b);
+              else SPK_MFMA_FP6_Z("v", acc[i][j], av, bc[j], sc_a, sc_b);
+            } else {
+              if (3 * i + j < N_AGPR) SPK_MFMA_FP6("a", acc[i][j], av, bc[j], sc_a, sc_b);
+              else SPK_MFMA_FP6("v", acc[i][j], av, bc[j], sc_a, sc_b);
+            }
+          };
+          // One MFMA keeps the matrix pipe busy for ~33 cycles, i.e. ~6 issue slots: the other work of a step is dealt
+          // out over its three MFMA shadows (fragment prefetch | DMA piece | weight prefetch) instead of piling up in one.
+          mfma(0);
+          __builtin_amdgcn_sched_barrier(0);
+          {
+            // DMA schedule: NPA + NPW pieces spread over the 9*NT steps (every DMA_EVERY-th step issues one piece)
+            constexpr int NPIECES = NPA + NPW;
+            constexpr int DMA_EVERY = SPK_FP6_DMA_EVERY;
+            if (s % DMA_EVERY == 0 && s / DMA_EVERY < NPIECES) {
+              const int q = s / DMA_EVERY;
+              const bool skip = ((SPK_FP6_DBG & 8) && q >= NPA) || ((SPK_FP6_DBG & 16) && q < NPA);
+              if (have_next && !skip) issue_piece(q, n_aslab, n_wslab, n_dA, n_dW);
+            }
+          }
+          mfma(1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (i == 0 && tap + 1 < 9) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) bn[j] = ldb(tap + 1, j);
+          }
+          mfma(2);
+          if (i == NT - 1) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) bc[j] = bn[j];
+          }
+          __builtin_amdgcn_sched_barrier(0);     // keep the read-ahead distance (see den_mfma.hip)
+        }
+      };
+      if (c == 0) compute(std::true_type{}); else compute(std::false_type{});
+    }   // chunks
+
+    // The MFMAs are opaque to hipcc's hazard recognizer: an accumulator may be read 18 wait states after the (16-pass)
+    // MFMA that wrote it was issued.
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (SPK_FP6_DBG & 4) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if (3 * i + j < N_AGPR) asm volatile("" : "+a"(acc[i][j]));
+          sacc += acc[i][j][0];
+        }
+      if (sacc == 12345.f) a.out[0] = 1;
+      continue;
+    }
+
+    // ---------------- epilogue: exact recombination, BN, LIF scan over the 16 accumulator registers ----------------
+    // Partner lanes (col, col ^ 16) hold digit planes {0,2,4} and {1,3,5} of the same channel.  As in den_mfma.hip,
+    // v_permlane16_swap(acc[r], acc[r + 8]) leaves every lane with both digits of a column tile for ITS time step (even
+    // lane t = r, odd lane t = r + 8); a digit pair 32*D_even + D_odd is exact in fp32, the three pairs are combined
+    // in fp64, and one more swap hands both lanes all 16 fp32 pre-activations.
+    // Element r of an accumulator.  The empty asm in recombine() pins an AGPR-resident accumulator to its AGPRs up to
+    // that point: without it hipcc copies all the 16-register tuples to VGPRs at the top of the epilogue (and spills).
+    auto acc_get = [&](int i, int j, int r) -> unsigned { return __float_as_uint(acc[i][j][r]); };
+    auto recombine = [&](int i, float (&x)[16]) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (3 * i + j < N_AGPR) asm volatile("" : "+a"(acc[i][j]));
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float pr[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const v2u p = __builtin_amdgcn_permlane16_swap(acc_get(i, j, r), acc_get(i, j, r + 8), false, false);
+          pr[j] = fmaf(__uint_as_float(p[0]), 32.0f, __uint_as_float(p[1]));       // exact: |.| < 2^22
+        }
+        const double s1 = fma((double)pr[0], 1024.0, (double)pr[1]);               // exact
+        const double s = fma(s1, 1024.0, (double)pr[2]);                           // exact: |s| < 2^43
+        const float xm = (float)fma(s, sc, bi);                                    // the one rounding to fp32
+        const v2u xx = __builtin_amdgcn_permlane16_swap(__float_as_uint(xm), __float_as_uint(xm), false, false);
+        x[r] = __uint_as_float(xx[0]);                                 // t = r     (computed by the even lane)
+        x[r + 8] = __uint_as_float(xx[1]);                             // t = r + 8 (computed by the odd lane)
+      }
+    };
+    // Both partner lanes hold the same 16 pre-activations, so the LIF scan runs on TWO row tiles at once: even lanes
+    // scan tile ip, odd lanes tile ip + 1; spike bits -> per-time-step channel masks by the DPP bit transpose.
+    // The pair holding the VGPR-resident accumulators goes first (frees their registers for the scan temporaries).
+#pragma unroll
+    for (int k = 0; k < (NT + 1) / 2; ++k) {
+      // 7 tiles: (5,6) (0,1) (2,3) (4,-)
+      const int ip = (NT & 1) ? (k == 0 ? NT - 2 : (k == (NT + 1) / 2 - 1 ? NT - 3 : 2 * (k - 1))) : 2 * k;
+      const bool paired = !((NT & 1) && k == (NT + 1) / 2 - 1);
+      float xa[16], xb[16];
+      recombine(ip, xa);
+      if (paired) recombine(ip + 1, xb);
+      const int ti = wave + 4 * (ip + (paired ? odd : 0));
+      const int p = 2 * ti + half;                  // accumulator lane-half == position within the tile
+      const bool pos_ok = p < HW && (paired || !odd);
+      const long long vidx = ((long long)b * a.Cout + co) * HW + (pos_ok ? p : 0);
+      float v = a.v_io ? a.v_io[vidx] : 0.f;
+      unsigned mybits = 0;                    // bit r = this lane's neuron fired at t = r
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float xv = (paired && odd) ? xb[r] : xa[r];
+        const bool s = spk_lif_step_default(v, fmaf(xv, bn_a, bn_b)) && pos_ok;
+        mybits |= s ? (1u << r) : 0u;
+      }
+      const unsigned cnt = __popc(mybits);
+      const unsigned bitsv = spk_transpose16_rows(mybits, lane);     // lane t of a 16-lane row: channel bits of step t
+      if (a.v_io && pos_ok) a.v_io[vidx] = v;
+      if (a.out_cnt && pos_ok)
+        a.out_cnt[(((long long)b * (a.Cout >> 5) + (co >> 5)) * HW + p) * 32 + (co & 31)] = (uint8_t)cnt;
+      // every lane stores one (position, time step): 16 channels = 16 e2m1 nibbles = 8 bytes
+      if (pos_ok) {
+        auto spread8 = [](unsigned x) -> unsigned {          // bit k -> nibble k, as the e2m1 code of 1.0 (0x2)
+          x = (x | (x << 12)) & 0x000f000fu;
+          x = (x | (x << 6)) & 0x03030303u;
+          x = (x | (x << 3)) & 0x11111111u;
+          return x << 1;
+        };
+        uint2 o;
+        o.x = spread8(bitsv & 0xffu);
+        o.y = spread8((bitsv >> 8) & 0xffu);
+        const int co0 = g * 16;
+        uint8_t* dst = a.out + ((((long long)b * (a.Cout >> 6) + (co0 >> 6)) * HW + p) * T16 + (lane & 15)) * 32 +
+                       ((co0 & 63) >> 1);
+        *reinterpret_cast<uint2*>(dst) = o;
+      }
+      __builtin_amdgcn_sched_barrier(0);        // keep the tile pairs from being interleaved (VGPR pressure)
+    }
+  }   // items
+}
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// one block per output channel: channel maximum -> shift s, then every weight -> 6 balanced radix-32 digits, written
+// as the per-lane 24-byte B fragments of the MFMA (lane = k-half * 32 + plane parity * 16 + channel, 32 six-bit codes,
+// little-endian; bytes 0..15 in the ds_read_b128 part of the tile, bytes 16..23 in its ds_read_b64 part; a chunk slab
+// is padded to whole KiB DMA pieces)
+__global__ __launch_bounds__(256) void pack_fp6_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                       uint8_t* __restrict__ wq, double* __restrict__ scale,
+                                                       double* __restrict__ bias_d, int Cout, int Cin) {
+  __shared__ float smax[256];
+  const int co = blockIdx.x, n = Cin * 9;
+  const float* wc = w + (long long)co * n;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(wc[i]));
+  smax[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s]);
+    __syncthreads();
+  }
+  m = smax[0];
+  int e = 0;
+  if (m > 0.f) frexpf(m, &e);                 // m = f * 2^e, f in [0.5, 1)  ->  m < 2^e
+  const int sh = 29 - e;                      // |w| * 2^sh < 2^29 <= 16.5 * 32^5
+  if (threadIdx.x == 0) { scale[co] = ldexp(1.0, -sh); bias_d[co] = bias ? (double)bias[co] : 0.0; }
+  const int nchunks = Cin / CK, g = co >> 4, ch = co & 15;
+  // one record = the 32 k values of (chunk, tap, k-half)
+  for (int rec = threadIdx.x; rec < nchunks * 18; rec += 256) {
+    const int kh = rec & 1, tap = (rec >> 1) % 9, c = rec / 18;
+    unsigned bits[6][6];
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+      for (int q = 0; q < 6; ++q) bits[p][q] = 0;
+    for (int j = 0; j < 32; ++j) {
+      const int ci = c * CK + kh * 32 + j;
+      long long q = (long long)rint(ldexp((double)wc[ci * 9 + tap], sh));
+      int dg[6];
+#pragma unroll
+      for (int p = 5; p >= 1; --p) {
+        const int r = (int)(((q + 16) & 31) - 16);
+        dg[p] = r;
+        q = (q - r) >> 5;
+      }
+      dg[0] = (int)q;                          // in [-16, 16]
+      const int bit = 6 * j, wd = bit >> 5, sft = bit & 31;
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        const unsigned code = (dg[p] < 0 ? 0x20u : 0u) | (unsigned)(dg[p] < 0 ? -dg[p] : dg[p]);
+#pragma unroll
+        for (int q2 = 0; q2 < 6; ++q2) {       // static register indexing
+          if (q2 == wd) bits[p][q2] |= code << sft;
+          if (q2 == wd + 1 && sft > 26) bits[p][q2] |= code >> (32 - sft);
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      const int ct = p >> 1, ln = kh * 32 + (p & 1) * 16 + ch;
+      uint8_t* tile = wq + (long long)(g * nchunks + c) * W_CHUNK_BYTES + (tap * 3 + ct) * W_TILE_BYTES;
+      unsigned* d16 = reinterpret_cast<unsigned*>(tile + ln * 16);
+      unsigned* d8 = reinterpret_cast<unsigned*>(tile + 1024 + ln * 8);
+      d16[0] = bits[p][0]; d16[1] = bits[p][1]; d16[2] = bits[p][2]; d16[3] = bits[p][3];
+      d8[0] = bits[p][4]; d8[1] = bits[p][5];
+    }
+  }
+}
+
+// fp32 spikes [T,B,C,HW] <-> nibble-packed C4 [B][C/64][HW][T][32] (tests, module boundaries)
+__global__ void spikes_to_fp4_kernel(const float* __restrict__ s, uint8_t* __restrict__ o, int T, int B, int C, int HW) {
+  const long long total = (long long)B * (C / 64) * HW * T * 32;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int byte = (int)(i & 31);
+    long long r = i >> 5;
+    const int t = (int)(r % T); r /= T;
+    const int p = (int)(r % HW); r /= HW;
+    const int cc = (int)(r % (C / 64));
+    const int b = (int)(r / (C / 64));
+    const int c0 = cc * 64 + 2 * byte;
+    const float s0 = s[(((long long)t * B + b) * C + c0) * HW + p], s1 = s[(((long long)t * B + b) * C + c0 + 1) * HW + p];
+    o[i] = (uint8_t)((s0 != 0.f ? 0x02 : 0) | (s1 != 0.f ? 0x20 : 0));
+  }
+}
+__global__ void fp4_to_spikes_kernel(const uint8_t* __restrict__ q, float* __restrict__ s, int T, int B, int C, int HW) {
+  const long long total = (long long)T * B * C * HW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW);
+    long long r = i / HW;
+    const int c = (int)(r % C); r /= C;
+    const int b = (int)(r % B);
+    const int t = (int)(r / B);
+    const uint8_t by = q[((((long long)b * (C / 64) + c / 64) * HW + p) * T + t) * 32 + (c % 64) / 2];
+    s[i] = ((by >> (4 * (c & 1))) & 0xf) ? 1.0f : 0.0f;
+  }
+}
+
+}  // namespace
+
+extern "C" long long spk_den_packed_weight_fp6_bytes(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0 || (Cout % 16) || (Cin % CK)) return -1;
+  return (long long)(Cout / 16) * (Cin / CK) * W_CHUNK_BYTES;
+}
+
+extern "C" int spk_den_pack_weight_fp6(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d,
+                                       int Cout, int Cin, hipStream_t stream) {
+  if (!w || !wq || !scale || !bias_d || Cout <= 0 || Cin <= 0) return SPK_ERR_ARG;
+  if ((Cout % 16) || (Cin % CK)) return SPK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(pack_fp6_kernel, dim3(Cout), dim3(256), 0, stream, w, bias, wq, scale, bias_d, Cout, Cin);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* scale,
+                                        const double* bias_d, const float* bn_a, const float* bn_b, float* v_inout,
+                                        uint8_t* out_c4, uint8_t* out_counts, int T, int B, int H, int W, int Cout,
+                                        hipStream_t stream) {
+  if (!in_c4 || nch <= 0 || !wq || !scale || !bias_d || !bn_a || !bn_b || !out_c4 || B <= 0 || H <= 0 || W <= 0 ||
+      Cout <= 0)
+    return SPK_ERR_ARG;
+  if (T != T16 || (Cout % 64)) return SPK_ERR_UNSUPPORTED;
+  const int ntiles = (H * W + 1) / 2;
+  const int npa = (H * ((W + 1) / 2) + 3) / 4;
+  const size_t lds = 2 * ((size_t)((H + 2) * (W + 1) + 1) * POS_BYTES + W_CHUNK_BYTES);
+  if ((ntiles + 3) / 4 > NT || npa > NPA || lds > 160 * 1024) return SPK_ERR_UNSUPPORTED;
+  Fp6Args a;
+  a.in0 = in_c4; a.nch0 = nch; a.wq = wq; a.scale = scale; a.bias = bias_d; a.bn_a = bn_a; a.bn_b = bn_b;
+  a.out = out_c4; a.v_io = v_inout; a.out_cnt = out_counts; a.B = B; a.H = H; a.W = W; a.Cout = Cout;
+  const int cus = spk_cu_count();
+  const int total = B * (Cout / 16);
+  dim3 grid(total < cus ? total : cus), blk(256);          // persistent: one workgroup per CU
+  hipLaunchKernelGGL(conv3x3_fp6_kernel, grid, blk, lds, stream, a);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_spikes_to_fp4(const float* spikes, uint8_t* out_c4, int T, int B, int C, int HW, hipStream_t stream) {
+  if (!spikes || !out_c4 || T <= 0 || B <= 0 || C <= 0 || HW <= 0) return SPK_ERR_ARG;
+  if (C % 64) return SPK_ERR_UNSUPPORTED;
+  const long long total = (long long)B * (C / 64) * HW * T * 32;
+  hipLaunchKernelGGL(spikes_to_fp4_kernel, dim3(spk_blocks(total, 256) > 65536 ? 65536 : spk_blocks(total, 256)), dim3(256),
+                     0, stream, spikes, out_c4, T, B, C, HW);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_fp4_to_spikes(const uint8_t* in_c4, float* spikes, int T, int B, int C, int HW, hipStream_t stream) {
+  if (!spikes || !in_c4 || T <= 0 || B <= 0 || C <= 0 || HW <= 0) return SPK_ERR_ARG;
+  if (C % 64) return SPK_ERR_UNSUPPORTED;
+  const long long total = (long long)T * B * C * HW;
+  hipLaunchKernelGGL(fp4_to_spikes_kernel, dim3(spk_blocks(total, 256) > 65536 ? 65536 : spk_blocks(total, 256)), dim3(256),
+                     0, stream, in_c4, spikes, T, B, C, HW);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}

@@ -184,26 +184,42 @@ class DummyModel(nn.Module):
         return all(c._fusable(c._blocks()) for c in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5,
                                                      self.conv6)) and self.n_steps <= ops.MAX_T
 
-    # 'mfma-i8x4': conv2..conv6 on the matrix cores (4 exact int8 digit planes); 'direct-f64': fp64-accumulating
-    # direct kernels.  Both return the same correctly rounded pre-activations; 'auto' picks MFMA when T == 16.
+    # 'mfma-fp6x6': conv2..conv5 on the block-scaled fp6/fp4 MFMA (six exact radix-32 digit planes), conv6 time-collapsed
+    # on int8 spike counts; 'mfma-i8x4': conv2..conv6 on the int8 MFMA (four exact base-256 digit planes); 'direct-f64':
+    # fp64-accumulating direct kernels.  All return correctly rounded pre-activations of (fixed-point) exact dot products.
+    # Request: 'auto' (fastest supported), 'fp6', 'i8', 'direct'.
     conv_impl_request = 'auto'
     # conv6 + mean over T evaluated as ONE convolution of the per-neuron spike counts (exact linearity; the sum over T
     # is rounded once instead of T times: logits agree with the per-step form to ~1 ulp).  False = per-step form.
     collapse_conv6 = True
 
+    _latent_hw = (7, 7)        # latent size of the last call (7x7 MNIST-shaped, 8x8 CIFAR-shaped)
+
+    def impl_for(self, h, w):
+        """Kernel family used for conv2..conv6 on an h x w latent."""
+        req = self.conv_impl_request
+        if req == 'direct':
+            return 'direct-f64'
+        if (req in ('auto', 'fp6') and self.collapse_conv6 and
+                ops.den_fp6_supported(128, 64, 3, 1, 1, self.n_steps, h, w)):
+            return 'mfma-fp6x6'
+        return 'mfma-i8x4' if ops.den_mfma_supported(128, 64, 3, 1, 1, self.n_steps, h, w) else 'direct-f64'
+
     @property
     def conv_impl(self):
-        h = w = 7
-        ok = self.conv_impl_request != 'direct' and ops.den_mfma_supported(128, 64, 3, 1, 1, self.n_steps, h, w)
-        return 'mfma-i8x4' if ok else 'direct-f64'
+        return self.impl_for(*self._latent_hw)
 
     def _run(self, inp_b2hw, stateful, record=None):
         T = self.n_steps
         impl = 'direct' if self.conv_impl_request == 'direct' else 'auto'
-        # spikes travel channel-chunked (CPTC, 32 channels per chunk): the layout the MFMA kernel stages per K chunk
-        collapse = self.conv_impl == 'mfma-i8x4' and self.collapse_conv6
+        # spikes travel channel-chunked: CPTC (32 u8 channels per chunk) for the int8 kernel, C4 (64 fp4 nibbles per
+        # chunk) for the fp6 kernel -- the layout each stages per K chunk
+        self._latent_hw = (int(inp_b2hw.shape[-2]), int(inp_b2hw.shape[-1]))
+        which = self.conv_impl
+        collapse = which != 'direct-f64' and self.collapse_conv6
+        chunk = ops.CHUNK_C4 if which == 'mfma-fp6x6' else 32
         with ops.timed('den.conv1'):
-            r1 = self.conv1.run(inp_b2hw, IN_TINV, final='ptc', T=T, stateful=stateful, chunk_out=32,
+            r1 = self.conv1.run(inp_b2hw, IN_TINV, final='ptc', T=T, stateful=stateful, chunk_out=chunk,
                                 want_counts=collapse)
         x1 = r1['ptc']
         x = x1
@@ -212,7 +228,7 @@ class DummyModel(nn.Module):
         for name, blk in (('den.conv2', self.conv2), ('den.conv3', self.conv3), ('den.conv4', self.conv4),
                           ('den.conv5', self.conv5)):
             with ops.timed(name):
-                r = blk.run(x, IN_PTC, final='ptc', stateful=stateful, chunk_out=32, impl=impl,
+                r = blk.run(x, IN_PTC, final='ptc', stateful=stateful, chunk_out=chunk, impl=impl,
                             want_counts=collapse and blk is self.conv5)
             x, cnt5 = r['ptc'], r['cnt']
             outs.append(x)

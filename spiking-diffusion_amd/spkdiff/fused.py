@@ -47,6 +47,14 @@ class ConvParams:
             self.key_i8 = key
         return self.i8
 
+    def get_fp6(self, conv):
+        """six fp6 digit planes + fp64 scale / bias for the block-scaled MFMA kernel (built on first use)."""
+        key = (_ver(conv.weight), _ver(conv.bias))
+        if key != getattr(self, 'key_fp6', None):
+            self.fp6 = ops.den_pack_weight_fp6(conv.weight, conv.bias)
+            self.key_fp6 = key
+        return self.fp6
+
     def get_i8_generic(self, conv):
         """int8 digit planes in the layout of the gather-MFMA kernel (any k, Conv2d or ConvTranspose2d)."""
         key = (_ver(conv.weight), _ver(conv.bias))
@@ -115,8 +123,10 @@ class FusedSequential(nn.Sequential):
         final: output of the LAST block -- 'f32' (spikes TBCHW, or the raw conv output when the last block has no
         BN/LIF), 'ptc', 'both', 'memout' (read-out of a conv-only last block) or 'mean'.
         stateful: honour and update each LIFNode's ``v`` (module semantics); False = fresh state, nothing written.
-        chunk_out: channel chunking of the PTC output of the last block (32 = the CPTC layout the MFMA kernel reads).
-        impl: 'auto' uses the int8 MFMA kernel where it applies (3x3/s1/p1, CPTC input, T=16), 'direct' never.
+        chunk_out: channel chunking of the PTC output of the last block (32 = the CPTC layout the int8 MFMA kernel reads,
+        ops.CHUNK_C4 = the nibble-packed fp4 layout of the fp6 MFMA kernel).
+        impl: 'auto' uses the MFMA kernel that matches the input layout (CPTC u8 -> int8 planes, C4 -> fp6 planes;
+        3x3/s1/p1, T=16), 'direct' never.
         Returns dict(ptc=, f32=, pre=[...], u8=)."""
         blocks = self._blocks()
         if not self._fusable(blocks):
@@ -137,6 +147,34 @@ class FusedSequential(nn.Sequential):
                 geo = conv_geometry(conv)
                 bias = None if conv.bias is None else conv.bias.detach()
                 src1 = in1 if (last and in1 is not None) else None
+                c4 = kind == IN_PTC and cur.dim() == 6 and cur.dtype == ops.C4_DTYPE
+                if c4:
+                    ok = (impl != 'direct' and lif is not None and not want_pre and src1 is None and not geo['transposed'] and
+                          ops.den_fp6_supported(conv.out_channels, conv.in_channels, geo['k'], geo['stride'], geo['pad'], T,
+                                                cur.shape[2], cur.shape[3]) and
+                          (not last or (final == 'ptc' and chunk_out == ops.CHUNK_C4)))
+                    if not ok:
+                        raise NotImplementedError('spkdiff: fp4-packed (C4) spikes are only consumed by the fp6 MFMA conv '
+                                                  '(3x3/s1/p1 + BN + LIF, T=16, C4 output)')
+                    a, b = bn.affine_terms()
+                    v = None
+                    if stateful:
+                        shape = (cur.shape[0], conv.out_channels, cur.shape[2], cur.shape[3])
+                        if isinstance(lif.v, float):
+                            lif.v = torch.full(shape, lif.v, dtype=torch.float32, device=cur.device)
+                        elif tuple(lif.v.shape) != shape:
+                            raise RuntimeError(f'LIFNode state has shape {tuple(lif.v.shape)} but the input implies '
+                                               f'{shape}; call functional.reset_net first')
+                        v = lif.v
+                    o = ops.den_conv3x3_mfma_fp6(cur, conv._spk_params.get_fp6(conv), conv.out_channels, bn_a=a, bn_b=b, v=v,
+                                                 want_counts=last and want_counts)
+                    if last and want_counts:
+                        out['ptc'], out['cnt'] = o
+                    elif last:
+                        out['ptc'] = o
+                    else:
+                        cur, kind = o, IN_PTC
+                    continue
                 cptc = kind == IN_PTC and cur.dim() == 6 and cur.shape[-1] == 32 and (src1 is None or src1.dim() == 6)
                 use_mfma = (impl != 'direct' and cptc and not geo['transposed'] and not want_pre and
                             (lif is not None or final == 'mean') and

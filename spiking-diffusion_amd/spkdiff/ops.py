@@ -167,7 +167,9 @@ def spikes_to_ptc(s, chunk=None):
 
 
 def ptc_to_spikes(p):
-    """u8 [B,H,W,T,C] or CPTC [B,C/chunk,H,W,T,chunk] -> fp32 [T,B,C,H,W]."""
+    """u8 [B,H,W,T,C] or CPTC [B,C/chunk,H,W,T,chunk] (or int8-tagged C4) -> fp32 [T,B,C,H,W]."""
+    if p.dtype == C4_DTYPE:
+        return c4_to_spikes(p)
     p = _dev(p, "ptc", torch.uint8)
     if p.dim() == 6:
         B, nch, H, W, T, chunk = p.shape
@@ -195,6 +197,10 @@ def pack_conv_weight(w, transposed):
 
 
 IN_PTC, IN_TINV, IN_SEQ = 0, 1, 2
+# "C4" spike tensors (fp4 e2m1 nibbles, 64 channels per 32-byte record: [B, C/64, H, W, 16, 32]) carry dtype int8 so that
+# they cannot be mistaken for the u8 CPTC layout of the same shape
+CHUNK_C4 = -64
+C4_DTYPE = torch.int8
 
 
 def conv_fused(in0, w_packed, bias, *, in_kind, T, mode, k, stride, pad, transposed=False, out_pad=0, in1=None,
@@ -242,8 +248,11 @@ def conv_fused(in0, w_packed, bias, *, in_kind, T, mode, k, stride, pad, transpo
         if want_counts:
             res["cnt"] = torch.empty((B, Cout // 32, Ho, Wo, 32), dtype=torch.uint8, device=dev)
         if want_ptc:
-            shape = (B, Ho, Wo, T, Cout) if not chunk_out else (B, Cout // chunk_out, Ho, Wo, T, chunk_out)
-            res["ptc"] = out_ptc if out_ptc is not None else torch.empty(shape, dtype=torch.uint8, device=dev)
+            if chunk_out == CHUNK_C4:                        # nibble-packed fp4 spikes, tagged by dtype int8
+                res["ptc"] = torch.empty((B, Cout // 64, Ho, Wo, T, 32), dtype=C4_DTYPE, device=dev)
+            else:
+                shape = (B, Ho, Wo, T, Cout) if not chunk_out else (B, Cout // chunk_out, Ho, Wo, T, chunk_out)
+                res["ptc"] = out_ptc if out_ptc is not None else torch.empty(shape, dtype=torch.uint8, device=dev)
         if want_f32:
             res["f32"] = out_f32 if out_f32 is not None else torch.empty((T, B, Cout, Ho, Wo), dtype=torch.float32, device=dev)
         if want_pre:
@@ -335,6 +344,64 @@ def den_conv3x3_counts(cnt0, packed, Cout, T, cnt1=None):
     check(lib.spk_den_conv3x3_counts_mfma(_p(cnt0), nch0, _p(cnt1), nch1, _p(wq), _p(scale), _p(bias_d), _p(out), T, B,
                                           H, W, Cout, _stream(cnt0)), "spk_den_conv3x3_counts_mfma")
     return out
+
+
+# ------------------------------------------------------------------------------- fp6/fp4 block-scaled MFMA denoiser convs
+def den_fp6_supported(Cout, Cin, k, stride, pad, T, H, W):
+    ntiles = (H * W + 1) // 2
+    npa = (H * ((W + 1) // 2) + 3) // 4
+    lds = 2 * (((H + 2) * (W + 1) + 1) * 512 + 41984)
+    return (k == 3 and stride == 1 and pad == 1 and T == 16 and Cout % 64 == 0 and Cin % 64 == 0
+            and (ntiles + 3) // 4 <= 7 and npa <= 7 and lds <= 160 * 1024)
+
+
+def den_pack_weight_fp6(w, bias):
+    """[Cout,Cin,3,3] fp32 -> (e2m3 digit planes u8, fp64 scale [Cout], fp64 bias [Cout])."""
+    w = _dev(w.detach(), "weight", torch.float32)
+    Cout, Cin = w.shape[0], w.shape[1]
+    nbytes = lib.spk_den_packed_weight_fp6_bytes(Cout, Cin)
+    if nbytes < 0:
+        raise NotImplementedError("spkdiff: fp6 MFMA conv needs Cout % 16 == 0 and Cin % 64 == 0")
+    wq = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    scale = torch.empty(Cout, dtype=torch.float64, device=w.device)
+    bias_d = torch.empty(Cout, dtype=torch.float64, device=w.device)
+    b = None if bias is None else _dev(bias.detach(), "bias", torch.float32)
+    check(lib.spk_den_pack_weight_fp6(_p(w), _p(b), _p(wq), _p(scale), _p(bias_d), Cout, Cin, _stream(w)),
+          "spk_den_pack_weight_fp6")
+    return wq, scale, bias_d
+
+
+def den_conv3x3_mfma_fp6(in0, packed, Cout, *, bn_a, bn_b, v=None, want_counts=False):
+    """in0: C4 spikes [B, C/64, H, W, 16, 32] (int8-tagged). Returns C4 spikes [B, Cout/64, H, W, 16, 32]
+    (or (spikes, counts u8 [B, Cout/32, H, W, 32]) with want_counts)."""
+    in0 = _dev(in0, "in0", C4_DTYPE)
+    B, nch, H, W, T, rec = in0.shape
+    if rec != 32:
+        raise ValueError("C4 spike records are 32 bytes (64 channels)")
+    wq, scale, bias_d = packed
+    out = torch.empty((B, Cout // 64, H, W, T, 32), dtype=C4_DTYPE, device=in0.device)
+    cnt = torch.empty((B, Cout // 32, H, W, 32), dtype=torch.uint8, device=in0.device) if want_counts else None
+    check(lib.spk_den_conv3x3_mfma_fp6(_p(in0), nch, _p(wq), _p(scale), _p(bias_d), _p(bn_a), _p(bn_b), _p(v), _p(out),
+                                       _p(cnt), T, B, H, W, Cout, _stream(in0)), "spk_den_conv3x3_mfma_fp6")
+    return (out, cnt) if want_counts else out
+
+
+def spikes_to_c4(s):
+    """fp32 [T,B,C,H,W] -> C4 [B, C/64, H, W, T, 32]."""
+    s = _dev(s, "spikes", torch.float32)
+    T, B, C, H, W = s.shape
+    o = torch.empty((B, C // 64, H, W, T, 32), dtype=C4_DTYPE, device=s.device)
+    check(lib.spk_spikes_to_fp4(_p(s), _p(o), T, B, C, H * W, _stream(s)), "spk_spikes_to_fp4")
+    return o
+
+
+def c4_to_spikes(q):
+    """C4 [B, C/64, H, W, T, 32] -> fp32 [T,B,C,H,W]."""
+    q = _dev(q, "c4", C4_DTYPE)
+    B, nch, H, W, T, _ = q.shape
+    o = torch.empty((T, B, nch * 64, H, W), dtype=torch.float32, device=q.device)
+    check(lib.spk_fp4_to_spikes(_p(q), _p(o), T, B, nch * 64, H * W, _stream(q)), "spk_fp4_to_spikes")
+    return o
 
 
 # ---------------------------------------------------------------------------------------------- MFMA VQ-VAE layers

@@ -401,6 +401,7 @@ def test_f5_denoiser_mfma_int8_kernel(golden_dir, dev, ops, tag, cfg):
     from snn_model.vq_diffusion import functional
     d = load(golden_dir, f"f5_denoiser_{tag}.npz")
     den, sd = build_den(cfg, dev)
+    den.conv_impl_request = 'i8'
     assert den.conv_impl == 'mfma-i8x4'
     spikes = {i: unpack(d[f"s{i}_bits"], d[f"s{i}_shape"]) for i in range(1, 6)}
     report = {}
@@ -433,6 +434,48 @@ def test_f5_denoiser_mfma_int8_kernel(golden_dir, dev, ops, tag, cfg):
         b1 = den(x_t, t=t); b2 = den(x_t, t=t)
         functional.reset_net(den)
         den.conv_impl_request = 'auto'
+    assert float((a1 - b1).abs().max()) <= 1e-6 and float((a2 - b2).abs().max()) <= 1e-6
+    assert not torch.equal(a1, a2), "second call starts from the carried membrane potentials"
+
+
+def test_f5_denoiser_mfma_fp6_kernel(golden_dir, dev, ops):
+    """conv2..conv5 on the block-scaled fp6 x fp4 MFMA (six exact radix-32 digit planes, C4 nibble-packed spikes)
+    against the golden spikes (teacher forced) and bit-for-bit against the fp64-accumulating direct kernel; spike
+    counts, carried membrane state and the whole-call logits against the direct path."""
+    from spkdiff.ops import IN_PTC
+    from snn_model.vq_diffusion import functional
+    d = load(golden_dir, "f5_denoiser_mnist.npz")
+    den, sd = build_den(synth.MNIST, dev)
+    assert den.conv_impl == 'mfma-fp6x6'
+    spikes = {i: unpack(d[f"s{i}_bits"], d[f"s{i}_shape"]) for i in range(1, 6)}
+    report = {}
+    for i, blk in enumerate((den.conv2, den.conv3, den.conv4, den.conv5), 2):
+        frag = unpack(d[f"frag{i}_bits"], d[f"s{i}_shape"]).bool()
+        x_4 = ops.spikes_to_c4(spikes[i - 1].to(dev))
+        assert x_4.dtype == ops.C4_DTYPE and x_4.shape[-1] == 32
+        assert torch.equal(ops.c4_to_spikes(x_4).cpu(), spikes[i - 1])                        # C4 round trip
+        r = blk.run(x_4, IN_PTC, final='ptc', stateful=False, chunk_out=ops.CHUNK_C4, want_counts=True)
+        got = ops.c4_to_spikes(r['ptc']).cpu()
+        x_c = ops.spikes_to_ptc(spikes[i - 1].to(dev), chunk=32)
+        direct = blk.run(x_c, IN_PTC, final='f32', stateful=False, impl='direct')['f32'].cpu()
+        bad = got != spikes[i]
+        report[f"conv{i}"] = (int(bad.sum()), int(frag.sum()), int((got != direct).sum()))
+        assert not bool((bad & ~frag).any()), f"conv{i} (fp6 MFMA): spike differs outside the fragile set"
+        assert torch.equal(got, direct), f"conv{i}: fp6 MFMA path != fp64 direct path"
+        cnt = r['cnt'].cpu()                                   # [B, C/32, H, W, 32] == sum over T of the spikes
+        B, C, H, W = got.shape[1:]
+        want_cnt = got.sum(0).reshape(B, C // 32, 32, H, W).permute(0, 1, 3, 4, 2)
+        assert torch.equal(cnt.float(), want_cnt)
+    print("F5 mnist fp6-MFMA teacher-forced (mismatch vs golden, fragile, mismatch vs direct):", report)
+    x_t = torch.from_numpy(d["x_t"]).float().to(dev); t = torch.from_numpy(d["t"]).to(dev)
+    with torch.inference_mode():
+        a1 = den(x_t, t=t); a2 = den(x_t, t=t)
+        functional.reset_net(den)
+        den.conv_impl_request = 'direct'
+        b1 = den(x_t, t=t); b2 = den(x_t, t=t)
+        functional.reset_net(den)
+        den.conv_impl_request = 'auto'
+    assert float((a1 - torch.from_numpy(d["logits"]).to(dev)).abs().max()) <= 1e-5
     assert float((a1 - b1).abs().max()) <= 1e-6 and float((a2 - b2).abs().max()) <= 1e-6
     assert not torch.equal(a1, a2), "second call starts from the carried membrane potentials"
 
@@ -737,10 +780,13 @@ def test_f2_gather_mfma_layers_teacher_forced(golden_dir, dev, ops):
     assert torch.equal(a1, b1) and torch.equal(a2, b2) and not torch.equal(a1, a2)
 
 
-def test_denoiser_mfma_vs_direct_b64_random_tokens(dev):
-    """A whole denoiser call at B=64 on random, partly masked tokens: the int8-MFMA path (conv2..5 + time-collapsed
+@pytest.mark.parametrize("req,name", [("fp6", "mfma-fp6x6"), ("i8", "mfma-i8x4")])
+def test_denoiser_mfma_vs_direct_b64_random_tokens(dev, req, name):
+    """A whole denoiser call at B=64 on random, partly masked tokens: both MFMA paths (conv2..5 + time-collapsed
     conv6) against the fp64 direct path -- every layer's spikes bit-equal, logits within 2e-7."""
     den, _ = build_den(synth.MNIST, dev)
+    den.conv_impl_request = req
+    assert den.conv_impl == name
     g = torch.Generator().manual_seed(123)
     x_t = torch.randint(0, 128, (64, 1, 7, 7), generator=g)
     x_t[torch.rand(64, 1, 7, 7, generator=g) < 0.6] = 128
@@ -750,7 +796,6 @@ def test_denoiser_mfma_vs_direct_b64_random_tokens(dev):
         lm = den.logits_from_tokens(x_t, 37, record=rec_m)
         den.conv_impl_request = 'direct'
         ld = den.logits_from_tokens(x_t, 37, record=rec_d)
-        den.conv_impl_request = 'auto'
     from spkdiff import ops
     for i, (a, b) in enumerate(zip(rec_m, rec_d), 1):
         sa, sb = ops.ptc_to_spikes(a), ops.ptc_to_spikes(b)

@@ -43,3 +43,33 @@ for Cout in (() if ONLY else (128, 512)):
         n = len(xs); sx = sum(xs); sy = sum(ys); sxx = sum(v * v for v in xs); sxy = sum(p * q for p, q in zip(xs, ys))
         slope = (n * sxy - sx * sy) / (n * sxx - sx * sx); icpt = (sy - slope * sx) / n
         print(f"fit Cout={Cout} mode={'LIF' if mode==0 else 'MEAN'}: t_chunk = {slope:.3f} us, t_epilogue+fixed = {icpt:.3f} us")
+
+# ---- the fp6 x fp4 block-scaled kernel (64-channel K chunks, LIF mode only) at the same shapes
+if not ONLY:
+    res6 = {}
+    for Cout in (128, 512):
+        for Cin in (64, 128, 256, 512):
+            w = (torch.rand(Cout, Cin, 3, 3, device=dev) - 0.5) * 0.05
+            packed = ops.den_pack_weight_fp6(w, torch.zeros(Cout, device=dev))
+            s = (torch.rand(16, B, Cin, H, W, device=dev) < 0.06).float()
+            x = ops.spikes_to_c4(s)
+            del s
+            a = torch.ones(Cout, device=dev); b = torch.zeros(Cout, device=dev)
+            for _ in range(3):
+                ops.den_conv3x3_mfma_fp6(x, packed, Cout, bn_a=a, bn_b=b)
+            evs = []
+            for _ in range(10):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); ops.den_conv3x3_mfma_fp6(x, packed, Cout, bn_a=a, bn_b=b); e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            ms = sorted(p.elapsed_time(q) for p, q in evs)[5]
+            per_item_us = ms * 1e3 / (B * (Cout // 16) / 256)
+            res6[(Cout, Cin)] = per_item_us
+            print(f"fp6 Cout={Cout} Cin={Cin} nchunks={Cin//64}: {ms:.3f} ms, per item {per_item_us:.2f} us", flush=True)
+    for Cout in (128, 512):
+        xs = [c // 64 for c in (64, 128, 256, 512)]
+        ys = [res6[(Cout, c)] for c in (64, 128, 256, 512)]
+        n = len(xs); sx = sum(xs); sy = sum(ys); sxx = sum(v * v for v in xs); sxy = sum(p * q for p, q in zip(xs, ys))
+        slope = (n * sxy - sx * sy) / (n * sxx - sx * sx); icpt = (sy - slope * sx) / n
+        print(f"fit fp6 Cout={Cout}: t_chunk(64 ch) = {slope:.3f} us, t_epilogue+fixed = {icpt:.3f} us")
