@@ -56,5 +56,16 @@ __device__ __forceinline__ void spk_dma16s(const void* sbase, unsigned voff, uns
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                : : "v"(voff), "s"(bs), "s"(__builtin_amdgcn_readfirstlane(lds_base)) : "memory", "m0");
 }
+// ... and with an explicit EXEC mask for the copy (all lanes must be active around the call: EXEC is restored to -1).
+// A piece that covers only lanes 0..31 costs two scalar moves instead of a saveexec / branch / restore sequence.
+__device__ __forceinline__ void spk_dma16s_masked(const void* sbase, unsigned voff, unsigned lds_base, unsigned long long mask) {
+  const unsigned long long b = (unsigned long long)sbase;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  const unsigned long long bs = ((unsigned long long)hi << 32) | lo;
+  const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)mask), mhi = __builtin_amdgcn_readfirstlane((unsigned)(mask >> 32));
+  const unsigned long long ms = ((unsigned long long)mhi << 32) | mlo;
+  asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, %3\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1"
+               : : "v"(voff), "s"(bs), "s"(__builtin_amdgcn_readfirstlane(lds_base)), "s"(ms) : "memory", "m0");
+}
 __device__ __forceinline__ void spk_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned spk_lds_addr(const void* p) { return (unsigned)(size_t)SPK_LDS(p); }

@@ -100,33 +100,36 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
     a_off[i] = pp * POS_BYTES + tt * 32 + 16 * (half ^ (tt >> 3));   // 16-B halves swapped for t >= 8: bank-conflict-free
   }
 
-  // DMA piece table, wave-uniform (scalar) values: see den_mfma.hip
+  // DMA piece table, wave-uniform (scalar) values, one packed word per A piece to keep the SGPR budget (a spilled SGPR
+  // costs a v_readlane in the K loop): bits 0..14 source byte offset in the slab, 15..30 LDS byte offset in the image,
+  // bit 31 = full piece (two positions; the last piece of an odd-width row covers one position = lanes 0..31).
+  // Pieces beyond the slab repeat the last one (a harmless duplicate copy) so that the K loop issues unconditionally.
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const int pprow = (a.W + 1) >> 1;
   const int nA = a.H * pprow;
-  int pa_src[NPA], pa_dst[NPA];      // byte offsets; pa_src < 0: absent piece
-  bool pa_full[NPA];
+  unsigned pa_pk[NPA];
 #pragma unroll
   for (int j = 0; j < NPA; ++j) {
-    const int id = wave_s * NPA + j;
+    int id = wave_s * NPA + j;
+    id = id < nA ? id : nA - 1;
     const int y = id / pprow, px = id - y * pprow;
-    pa_src[j] = id < nA ? (y * a.W + 2 * px) * POS_BYTES : -1;
-    pa_dst[j] = ((y + 1) * PW + 1 + 2 * px) * POS_BYTES;
-    pa_full[j] = 2 * px + 1 < a.W;
+    const unsigned src = (unsigned)((y * a.W + 2 * px) * POS_BYTES), dst = (unsigned)(((y + 1) * PW + 1 + 2 * px) * POS_BYTES);
+    pa_pk[j] = src | (dst << 15) | ((2 * px + 1 < a.W) ? 0x80000000u : 0u);
   }
   const unsigned lane_a = (unsigned)(lane ^ ((lane >> 4) & 1)) * 16u;     // swizzled source lane (see a_off)
   const unsigned lane_w = (unsigned)lane * 16u;
+  const unsigned wave_k = (unsigned)wave_s * 1024u;
 
-  // piece q of this wave: q < NPA -> A piece q, else W piece wave + 4 * (q - NPA)
+  // piece q of this wave: q < NPA -> A piece q, else W piece wave + 4 * (q - NPA) (the 42nd..44th repeat an earlier one)
   auto issue_piece = [&](int q, const uint8_t* aslab, const uint8_t* wslab, unsigned dA, unsigned dW) {
     if (q < NPA) {
-      if (pa_src[q] >= 0) {
-        if (pa_full[q] || lane < 32)
-          spk_dma16s(aslab + pa_src[q], lane_a, dA + pa_dst[q]);
-      }
+      const unsigned pk = pa_pk[q];
+      const unsigned long long mask = (pk >> 31) ? ~0ull : 0xffffffffull;
+      spk_dma16s_masked(aslab + (pk & 0x7fffu), lane_a, dA + ((pk >> 15) & 0xffffu), mask);
     } else {
-      const int k = wave_s + 4 * (q - NPA);
-      if (k < W_PIECES) spk_dma16s(wslab + k * 1024, lane_w, dW + k * 1024);
+      unsigned ko = wave_k + 4096u * (unsigned)(q - NPA);
+      if (4 * (q - NPA) + 3 >= W_PIECES) ko = ko < (unsigned)W_PIECES * 1024u ? ko : ko - 4096u;
+      spk_dma16s(wslab + ko, lane_w, dW + ko);
     }
   };
   auto slabs = [&](int item, int c, const uint8_t*& aslab, const uint8_t*& wslab) {
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
   const int sc_a = 0x7f7f7f7f;             // e8m0 block scales: spikes x 1
   const int sc_b = (int)0x82828282u;       //                    digits x 8 (e2m3 value d/8 -> d)
 
+  long long dbg_t[4] = {0, 0, 0, 0};               // SPK_FP6_DBG & 64: cycles in DMA wait / barrier / K loop, chunk count
   int it = 0;                                      // running chunk counter: LDS buffer = it & 1
   if ((int)blockIdx.x < total) {
     const uint8_t *as0, *ws0;
@@ -155,14 +159,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
     const float bn_a = a.bn_a[co], bn_b = a.bn_b[co];
     for (int c = 0; c < nchunks; ++c, ++it) {
       const int buf = it & 1;
+      long long tq0 = 0, tq1 = 0, tq2 = 0;
+      if (SPK_FP6_DBG & 64) tq0 = __builtin_amdgcn_s_memtime();
       spk_dma_wait_all();  // this wave's share of the chunk's DMA has landed ...
+      if (SPK_FP6_DBG & 64) tq1 = __builtin_amdgcn_s_memtime();
       __syncthreads();     // ... and so has everyone else's; everyone is done with the other buffer
+      if (SPK_FP6_DBG & 64) tq2 = __builtin_amdgcn_s_memtime();
       // next chunk (possibly of the next item): its DMA pieces are issued between the MFMA groups below
       int nitem = item, nc = c + 1;
       if (nc == nchunks) { nc = 0; nitem = item + gridDim.x; }
-      const bool have_next = nitem < total && !(SPK_FP6_DBG & 1);
+      const bool have_next = nitem < total;      // otherwise the last chunk is copied once more (never read)
       const uint8_t *n_aslab, *n_wslab;
       slabs(have_next ? nitem : item, nc, n_aslab, n_wslab);
+      if (SPK_FP6_DBG & 128) { n_aslab = a.in0; n_wslab = a.wq; }      // timing experiment: L2-hot, tiny DMA footprint
       const unsigned n_dA = sA_addr + (buf ^ 1) * A_BYTES;            // LDS byte addresses of the DMA destinations
       const unsigned n_dW = sW_addr + (buf ^ 1) * W_CHUNK_BYTES;
 
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
             if (s % DMA_EVERY == 0 && s / DMA_EVERY < NPIECES) {
               const int q = s / DMA_EVERY;
               const bool skip = ((SPK_FP6_DBG & 8) && q >= NPA) || ((SPK_FP6_DBG & 16) && q < NPA);
-              if (have_next && !skip) issue_piece(q, n_aslab, n_wslab, n_dA, n_dW);
+              if (!(SPK_FP6_DBG & 1) && !skip) issue_piece(q, n_aslab, n_wslab, n_dA, n_dW);
             }
           }
           mfma(1);
@@ -236,6 +245,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
         }
       };
       if (c == 0) compute(std::true_type{}); else compute(std::false_type{});
+      if (SPK_FP6_DBG & 64) {
+        const long long tq3 = __builtin_amdgcn_s_memtime();
+        dbg_t[0] += tq1 - tq0; dbg_t[1] += tq2 - tq1; dbg_t[2] += tq3 - tq2; dbg_t[3] += 1;
+      }
     }   // chunks
 
     // The MFMAs are opaque to hipcc's hazard recognizer: an accumulator may be read 18 wait states after the (16-pass)
@@ -329,6 +342,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
       __builtin_amdgcn_sched_barrier(0);        // keep the tile pairs from being interleaved (VGPR pressure)
     }
   }   // items
+  spk_dma_wait_all();     // the copy issued during the very last chunk must not outlive the workgroup's LDS allocation
+  if ((SPK_FP6_DBG & 64) && lane == 0 && blockIdx.x < 4) {
+    long long* o = reinterpret_cast<long long*>(a.out) + (blockIdx.x * 4 + wave) * 4;
+    o[0] = dbg_t[0]; o[1] = dbg_t[1]; o[2] = dbg_t[2]; o[3] = dbg_t[3];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ weight packing

@@ -35,6 +35,10 @@ __global__ __launch_bounds__(256, 1) void loopk(const uint8_t* in, float* out, i
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int sa = 0x7f7f7f7f, sb = 0x7f7f7f7f;
+  int dummy = 0;
+  typedef int v4ii __attribute__((ext_vector_type(4)));
+  v4ii rsrc; { const unsigned long long b = (unsigned long long)in; rsrc[0] = (int)(unsigned)b; rsrc[1] = (int)(unsigned)(b >> 32); rsrc[2] = 0x7fffffff; rsrc[3] = 0x00020000; }
+  asm volatile("s_mov_b32 m0, %0" :: "s"(__builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) void*)(lds + 120000 + wave * 1024)))) : "m0");
   __syncthreads();
   long long t0 = __builtin_amdgcn_s_memtime();
   for (int c = 0; c < nchunks; ++c) {
@@ -87,8 +91,30 @@ __global__ __launch_bounds__(256, 1) void loopk(const uint8_t* in, float* out, i
 #pragma unroll
         for (int j = 0; j < 3; ++j) bc[j] = bn[j];
       }
+#ifdef DMAV
+      if (s % 3 == 0 && s / 3 < 18) {
+        const unsigned ldsb = (unsigned)(size_t)((__attribute__((address_space(3))) void*)(lds + 120000 + wave * 1024));
+        const unsigned voff = lane * 16 + (s / 3) * 1024 + wave * 20480;
+#if DMAV == 1
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(in), "s"(__builtin_amdgcn_readfirstlane(ldsb + (s & 1) * 4096)) : "memory", "m0");
+#elif DMAV == 2
+        asm volatile("global_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(in) : "memory");
+#elif DMAV == 3
+        v4i tmp;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(tmp) : "v"(voff), "s"(in) : "memory");
+        dummy += tmp[0];
+#elif DMAV == 4
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(in), "s"(__builtin_amdgcn_readfirstlane(ldsb + (s & 1) * 4096)) : "memory", "m0");
+#elif DMAV == 5
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(ldsb + (s & 1) * 4096)) : "memory", "m0");
+#endif
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef DMAV
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   }
   long long t1 = __builtin_amdgcn_s_memtime();
   asm volatile("s_nop 15\n\ts_nop 15");
@@ -101,13 +127,13 @@ __global__ __launch_bounds__(256, 1) void loopk(const uint8_t* in, float* out, i
 #pragma unroll
       for (int r = 0; r < 16; ++r) s += acc[i][j][r] * (float)(r + j);
     }
-    out[(blockIdx.x * NT + i) * 256 + threadIdx.x] = s;
+    out[(blockIdx.x * NT + i) * 256 + threadIdx.x] = s + dummy;
   }
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 int main() {
   uint8_t* in; float* out; long long* cyc; long long h[256];
-  hipMalloc(&in, 160000); hipMemset(in, 0x22, 160000); hipMalloc(&out, 256 * NT * 256 * 4); hipMalloc(&cyc, 256 * 8);
+  hipMalloc(&in, 1 << 20); hipMemset(in, 0x22, 1 << 20); hipMalloc(&out, 256 * NT * 256 * 4); hipMalloc(&cyc, 256 * 8);
   const int nchunks = 2000;
   hipFuncSetAttribute((const void*)loopk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   for (int rep = 0; rep < 2; ++rep) {
