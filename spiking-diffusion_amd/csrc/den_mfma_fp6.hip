@@ -51,11 +51,14 @@ struct Fp6Args {
 // D = A(32 x 64 fp4) * B(64 x 32 fp6) + C, accumulator in AGPRs ("a") or VGPRs ("v"); *_Z: C = 0 (first MFMA of an item).
 // s_nop 1: the two wait states between a VALU write of an operand register (the B fragment hand-over is v_mov) and
 // the MFMA that reads it, which hipcc's hazard recognizer cannot insert around inline assembly.
+#ifndef SPK_FP6_PRE
+#define SPK_FP6_PRE "s_nop 1\n\t"
+#endif
 #define SPK_MFMA_FP6(CLS, acc, av, bv, sa, sb)                                                                       \
-  asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:2"  \
+  asm volatile(SPK_FP6_PRE "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:2"  \
                : "+" CLS(acc) : "v"(av), "v"(bv), "v"(sa), "v"(sb))
 #define SPK_MFMA_FP6_Z(CLS, acc, av, bv, sa, sb)                                                                     \
-  asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:2"   \
+  asm volatile(SPK_FP6_PRE "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:2"   \
                : "=&" CLS(acc) : "v"(av), "v"(bv), "v"(sa), "v"(sb))
 
 #ifndef SPK_FP6_DBG
@@ -65,7 +68,7 @@ struct Fp6Args {
 #define SPK_FP6_PF 4
 #endif
 #ifndef SPK_FP6_DMA_EVERY
-#define SPK_FP6_DMA_EVERY 3     // (9 * NT) / (NPA + NPW) spreads the pieces over the whole chunk
+#define SPK_FP6_DMA_EVERY 2     // one piece every second step: all 18 are issued in the first 60 % of a chunk and land before its end
 #endif
 constexpr int NT = 7;          // row tiles per wave (7x7 latents: 25 tiles of 2 positions, padded to 28)
 constexpr int NPA = 7;         // A-slab DMA pieces per wave
@@ -268,45 +271,42 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
     }
 
     // ---------------- epilogue: exact recombination, BN, LIF scan over the 16 accumulator registers ----------------
-    // Partner lanes (col, col ^ 16) hold digit planes {0,2,4} and {1,3,5} of the same channel.  As in den_mfma.hip,
-    // v_permlane16_swap(acc[r], acc[r + 8]) leaves every lane with both digits of a column tile for ITS time step (even
-    // lane t = r, odd lane t = r + 8); a digit pair 32*D_even + D_odd is exact in fp32, the three pairs are combined
-    // in fp64, and one more swap hands both lanes all 16 fp32 pre-activations.
-    // Element r of an accumulator.  The empty asm in recombine() pins an AGPR-resident accumulator to its AGPRs up to
-    // that point: without it hipcc copies all the 16-register tuples to VGPRs at the top of the epilogue (and spills).
-    auto acc_get = [&](int i, int j, int r) -> unsigned { return __float_as_uint(acc[i][j][r]); };
-    auto recombine = [&](int i, float (&x)[16]) {
+    // Partner lanes (col, col ^ 16) hold digit planes {0,2,4} and {1,3,5} of the same channel, for every row tile.
+    // Tiles are finished in PAIRS (ia, ib):  v_permlane16_swap(acc[ia][j][r], acc[ib][j][r])  (A' = {A.row0, B.row0},
+    // B' = {A.row1, B.row1} per 16-lane row pair) leaves the even lane with both digits of column tile j of tile ia and
+    // the odd lane with both digits of tile ib -- 48 swaps hand every lane all six digits of ONE neuron for all 16 time
+    // steps, and both lane parities then do useful, different work: recombine + BN + LIF scan of their own tile.
+    // A digit pair 32*D_even + D_odd is exact in fp32, the three pairs are combined exactly in fp64, one rounding.
+    // (ia == ib for the odd tile out: both parities compute the same neuron, the odd lanes' copy is discarded.)
+    // The empty asm pins an AGPR-resident accumulator to its AGPRs up to that point: without it hipcc copies all the
+    // 16-register tuples to VGPRs at the top of the epilogue (and spills).  The pair holding the VGPR-resident
+    // accumulators goes first (frees their registers for the scan temporaries).
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
-        if (3 * i + j < N_AGPR) asm volatile("" : "+a"(acc[i][j]));
+    for (int k = 0; k < (NT + 1) / 2; ++k) {
+      // 7 tiles: (5,6) (0,1) (2,3) (4,4)
+      const int ia = (NT & 1) ? (k == 0 ? NT - 2 : (k == (NT + 1) / 2 - 1 ? NT - 3 : 2 * (k - 1))) : 2 * k;
+      const bool paired = !((NT & 1) && k == (NT + 1) / 2 - 1);
+      const int ib = paired ? ia + 1 : ia;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
+      for (int j = 0; j < 3; ++j) {
+        if (3 * ia + j < N_AGPR) asm volatile("" : "+a"(acc[ia][j]));
+        if (paired && 3 * ib + j < N_AGPR) asm volatile("" : "+a"(acc[ib][j]));
+      }
+      float x[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
         float pr[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          const v2u p = __builtin_amdgcn_permlane16_swap(acc_get(i, j, r), acc_get(i, j, r + 8), false, false);
+          const v2u p = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ia][j][r]), __float_as_uint(acc[ib][j][r]),
+                                                         false, false);
           pr[j] = fmaf(__uint_as_float(p[0]), 32.0f, __uint_as_float(p[1]));       // exact: |.| < 2^22
         }
         const double s1 = fma((double)pr[0], 1024.0, (double)pr[1]);               // exact
         const double s = fma(s1, 1024.0, (double)pr[2]);                           // exact: |s| < 2^43
-        const float xm = (float)fma(s, sc, bi);                                    // the one rounding to fp32
-        const v2u xx = __builtin_amdgcn_permlane16_swap(__float_as_uint(xm), __float_as_uint(xm), false, false);
-        x[r] = __uint_as_float(xx[0]);                                 // t = r     (computed by the even lane)
-        x[r + 8] = __uint_as_float(xx[1]);                             // t = r + 8 (computed by the odd lane)
+        x[r] = (float)fma(s, sc, bi);                                              // the one rounding to fp32
       }
-    };
-    // Both partner lanes hold the same 16 pre-activations, so the LIF scan runs on TWO row tiles at once: even lanes
-    // scan tile ip, odd lanes tile ip + 1; spike bits -> per-time-step channel masks by the DPP bit transpose.
-    // The pair holding the VGPR-resident accumulators goes first (frees their registers for the scan temporaries).
-#pragma unroll
-    for (int k = 0; k < (NT + 1) / 2; ++k) {
-      // 7 tiles: (5,6) (0,1) (2,3) (4,-)
-      const int ip = (NT & 1) ? (k == 0 ? NT - 2 : (k == (NT + 1) / 2 - 1 ? NT - 3 : 2 * (k - 1))) : 2 * k;
-      const bool paired = !((NT & 1) && k == (NT + 1) / 2 - 1);
-      float xa[16], xb[16];
-      recombine(ip, xa);
-      if (paired) recombine(ip + 1, xb);
-      const int ti = wave + 4 * (ip + (paired ? odd : 0));
+      const int ti = wave + 4 * (odd ? ib : ia);
       const int p = 2 * ti + half;                  // accumulator lane-half == position within the tile
       const bool pos_ok = p < HW && (paired || !odd);
       const long long vidx = ((long long)b * a.Cout + co) * HW + (pos_ok ? p : 0);
@@ -314,8 +314,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
       unsigned mybits = 0;                    // bit r = this lane's neuron fired at t = r
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float xv = (paired && odd) ? xb[r] : xa[r];
-        const bool s = spk_lif_step_default(v, fmaf(xv, bn_a, bn_b)) && pos_ok;
+        const bool s = spk_lif_step_default(v, fmaf(x[r], bn_a, bn_b)) && pos_ok;
         mybits |= s ? (1u << r) : 0u;
       }
       const unsigned cnt = __popc(mybits);
