@@ -25,6 +25,7 @@
 // x = W of the previous one) so that two images and two 40.5 KB weight slabs fit the 160 KB LDS.
 #include "den_common.h"
 #include "../../include/spkdiff.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -46,6 +47,7 @@ struct Fp6Args {
   const uint8_t* wq; const double* scale; const double* bias; const float* bn_a; const float* bn_b;
   uint8_t* out; float* v_io; uint8_t* out_cnt;
   int B, H, W, Cout;
+  int gx;      // > 0: XCD-aware item walk with gx channel groups per XCD (see the kernel); 0: image-major
 };
 
 // D = A(32 x 64 fp4) * B(64 x 32 fp6) + C, accumulator in AGPRs ("a") or VGPRs ("v"); *_Z: C = 0 (first MFMA of an item).
@@ -135,8 +137,31 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
       spk_dma16s(wslab + ko, lane_w, dW + ko);
     }
   };
+  // Item -> (image b, channel group g).  Workgroups are dealt round-robin over the 8 XCDs (k and k + 8 share one, each
+  // XCD has its own 4 MB L2).  An XCD-aware walk (a.gx > 0, chosen by the host so that the packed weights of gx channel
+  // groups stay L2-resident): XCD x owns group set x % nsets (gx consecutive groups) and image partition x / nsets,
+  // and its gridDim.x / 8 workgroups take those gx groups of S / gx images at a time.  Against the image-major walk
+  // this (1) fetches an image's spike slabs into 8 / npart L2s instead of all eight and (2) brings the four 8-byte
+  // partial records that make up one 32-byte output record together in ONE L2, which merges them (measured on the
+  // conv4 shape: HBM-side writes 218 -> 56 MB per launch).  a.gx == 0: image-major.
+  const int S = gridDim.x >> 3;                       // workgroups per XCD
+  const int gx = a.gx;
+  const int nsets = gx > 0 ? G / gx : 1, npart = 8 / nsets, ipx = gx > 0 ? S / gx : 1;
+  auto decode = [&](int item, int& b, int& g) {
+    if (gx > 0) {
+      const int j = item / (int)gridDim.x, k = item - j * (int)gridDim.x;
+      const int x = k & 7, slot = k >> 3;
+      const int set = x % nsets, xi = x / nsets;
+      g = set * gx + slot % gx;
+      b = (j * npart + xi) * ipx + slot / gx;
+    } else {
+      b = item / G;
+      g = item - b * G;
+    }
+  };
   auto slabs = [&](int item, int c, const uint8_t*& aslab, const uint8_t*& wslab) {
-    const int b = item / G, g = item - b * G;
+    int b, g;
+    decode(item, b, g);
     aslab = a.in0 + ((long long)b * nchunks + c) * HW * POS_BYTES;
     wslab = a.wq + ((long long)g * nchunks + c) * W_CHUNK_BYTES;
   };
@@ -156,7 +181,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
   for (int item = blockIdx.x; item < total; item += gridDim.x) {
     v16f acc[NT][3];      // written (not accumulated) by tap 0 of the first chunk: no explicit zeroing
     // epilogue constants of this item's channel: loaded now, their latency hides under the K loop
-    const int b = item / G, g = item - b * G;
+    int b, g;
+    decode(item, b, g);
     const int co = g * 16 + ch;
     const double sc = a.scale[co], bi = a.bias[co];
     const float bn_a = a.bn_a[co], bn_b = a.bn_b[co];
@@ -475,8 +501,22 @@ extern "C" int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uin
   a.in0 = in_c4; a.nch0 = nch; a.wq = wq; a.scale = scale; a.bias = bias_d; a.bn_a = bn_a; a.bn_b = bn_b;
   a.out = out_c4; a.v_io = v_inout; a.out_cnt = out_counts; a.B = B; a.H = H; a.W = W; a.Cout = Cout;
   const int cus = spk_cu_count();
-  const int total = B * (Cout / 16);
+  const int G = Cout / 16, total = B * G;
   dim3 grid(total < cus ? total : cus), blk(256);          // persistent: one workgroup per CU
+  // XCD-aware walk: the largest power-of-two group count whose packed weights (gx * nch slabs) fit ~1.5 MB of an XCD's
+  // 4 MB L2, if the shape tiles exactly (see decode() in the kernel)
+  // Measured on the conv4 shape (B = 256): L2-miss reads 206 -> 111 MB and HBM-side writes 218 -> 56 MB per launch, but
+  // the launch takes ~2 % LONGER (32 workgroups of one XCD pull the same slab lines at the same moment), so the walk is
+  // opt-in: SPKDIFF_FP6_XCD_WALK=1.
+  static const bool xcd_walk = [] { const char* e = getenv("SPKDIFF_FP6_XCD_WALK"); return e && e[0] == '1'; }();
+  a.gx = 0;
+  if (xcd_walk && (grid.x & 7) == 0) {
+    const int S = grid.x / 8;
+    int gx = 1;
+    while (gx * 2 <= G && (long long)gx * 2 * nch * W_CHUNK_BYTES <= 1536 * 1024) gx *= 2;
+    const int nsets = G / gx;
+    if (gx >= 4 && G % gx == 0 && nsets <= 8 && 8 % nsets == 0 && S % gx == 0 && B % ((8 / nsets) * (S / gx)) == 0) a.gx = gx;
+  }
   hipLaunchKernelGGL(conv3x3_fp6_kernel, grid, blk, lds, stream, a);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
