@@ -1,8 +1,8 @@
 """Summarise a rocprofv3 --kernel-trace CSV into a per-kernel / per-denoiser-layer table (markdown on stdout).
 
 usage: python tools/summarize_profile.py <kernel_trace.csv> [<pmc_fetch counter csv> <pmc_write counter csv>]
-The MFMA kernel is one symbol for conv2..conv5; the layers are told apart by dispatch order (4 consecutive
-dispatches per denoiser call)."""
+The MFMA kernel (fp6: conv3x3_fp6_kernel, int8: conv3x3_mfma_kernel<.., LIF, ..>) is one symbol for conv2..conv5; the
+layers are told apart by dispatch order (4 consecutive dispatches per denoiser call)."""
 import csv
 import sys
 from collections import defaultdict
@@ -21,6 +21,9 @@ for r in rows:
             k += 1
         else:
             name = "conv3x3_mfma_kernel<MEAN>"
+    elif "conv3x3_fp6_kernel" in name:      # one symbol for conv2..conv5, in launch order
+        name = f"conv3x3_fp6_kernel den.conv{2 + k % 4}"
+        k += 1
     elif "conv3x3_counts_mfma_kernel" in name:
         name = "conv3x3_counts_mfma_kernel den.conv6 (time-collapsed)"
     dur[name.replace("(anonymous namespace)::", "")[:90]].append(d)
