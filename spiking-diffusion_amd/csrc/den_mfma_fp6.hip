@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
     // the odd lane with both digits of tile ib -- 48 swaps hand every lane all six digits of ONE neuron for all 16 time
     // steps, and both lane parities then do useful, different work: recombine + BN + LIF scan of their own tile.
     // A digit pair 32*D_even + D_odd is exact in fp32, the three pairs are combined exactly in fp64, one rounding.
-    // (ia == ib for the odd tile out: both parities compute the same neuron, the odd lanes' copy is discarded.)
+    // (The odd tile out is split over the lane parities by time steps instead, as in den_mfma.hip.)
     // The empty asm pins an AGPR-resident accumulator to its AGPRs up to that point: without it hipcc copies all the
     // 16-register tuples to VGPRs at the top of the epilogue (and spills).  The pair holding the VGPR-resident
     // accumulators goes first (frees their registers for the scan temporaries).
@@ -319,18 +319,40 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
         if (paired && 3 * ib + j < N_AGPR) asm volatile("" : "+a"(acc[ib][j]));
       }
       float x[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float pr[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const v2u p = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ia][j][r]), __float_as_uint(acc[ib][j][r]),
-                                                         false, false);
-          pr[j] = fmaf(__uint_as_float(p[0]), 32.0f, __uint_as_float(p[1]));       // exact: |.| < 2^22
-        }
+      auto recombine3 = [&](const float (&pr)[3]) -> float {
         const double s1 = fma((double)pr[0], 1024.0, (double)pr[1]);               // exact
         const double s = fma(s1, 1024.0, (double)pr[2]);                           // exact: |s| < 2^43
-        x[r] = (float)fma(s, sc, bi);                                              // the one rounding to fp32
+        return (float)fma(s, sc, bi);                                              // the one rounding to fp32
+      };
+      if (paired) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float pr[3];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const v2u p = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ia][j][r]), __float_as_uint(acc[ib][j][r]),
+                                                           false, false);
+            pr[j] = fmaf(__uint_as_float(p[0]), 32.0f, __uint_as_float(p[1]));     // exact: |.| < 2^22
+          }
+          x[r] = recombine3(pr);
+        }
+      } else {
+        // the odd tile out: swapping acc[r] with acc[r + 8] of the SAME tile gives the even lane both digits of step r and
+        // the odd lane those of step r + 8; each recombines 8 steps and one more swap hands both all 16 values
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          float pr[3];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const v2u p = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ia][j][r]), __float_as_uint(acc[ia][j][r + 8]),
+                                                           false, false);
+            pr[j] = fmaf(__uint_as_float(p[0]), 32.0f, __uint_as_float(p[1]));
+          }
+          const float xm = recombine3(pr);
+          const v2u xx = __builtin_amdgcn_permlane16_swap(__float_as_uint(xm), __float_as_uint(xm), false, false);
+          x[r] = __uint_as_float(xx[0]);                                 // t = r     (computed by the even lane)
+          x[r + 8] = __uint_as_float(xx[1]);                             // t = r + 8 (computed by the odd lane)
+        }
       }
       const int ti = wave + 4 * (odd ? ib : ia);
       const int p = 2 * ti + half;                  // accumulator lane-half == position within the tile
