@@ -804,6 +804,25 @@ def test_denoiser_mfma_vs_direct_b64_random_tokens(dev, req, name):
     assert float((lm - ld).abs().max()) <= 2e-7
 
 
+def test_syops_report_matches_golden_spike_rates(golden_dir, dev):
+    """the syops-style energy report (R/syops/ops.py:14-24,121-158) from the fused kernels' own spike
+    maps: layer firing rates equal the reference fixture's, ACs = overall * input rate, conv1 counts as MACs."""
+    from spkdiff import syops
+    d = load(golden_dir, "f5_denoiser_mnist.npz")
+    den, _ = build_den(synth.MNIST, dev)
+    x_t = torch.from_numpy(d["x_t"]).to(dev); t = torch.from_numpy(d["t"]).to(dev)
+    logits, rep = syops.denoiser_syops(den, x_t, t)
+    assert float((logits.cpu() - torch.from_numpy(d["logits"])).abs().max()) <= 1e-5
+    B = x_t.shape[0]
+    for i in range(1, 6):
+        want = float(unpack(d[f"s{i}_bits"], d[f"s{i}_shape"]).mean())
+        assert abs(rep[i - 1]["out_rate"] - want) <= 1e-6, (i, rep[i - 1]["out_rate"], want)
+    assert rep[0]["macs"] == (9 * 2 * 64 + 64) * 16 * B * 49 and rep[0]["acs"] == 0.0
+    assert rep[3]["overall"] == (9 * 256 * 512 + 512) * 16 * B * 49
+    assert abs(rep[3]["acs"] - rep[3]["overall"] * rep[2]["out_rate"]) <= 1e-6 * rep[3]["overall"]
+    assert rep[-1]["layer"] == "total" and rep[-1]["acs"] < 0.2 * rep[-1]["overall"]
+
+
 def test_sampler_trajectory_vs_live_oracle_12_steps(dev):
     """12 reverse steps, B=8, noise drawn on the host in the reference's order under the same torch.manual_seed:
     the HIP sampler must reproduce the CPU oracle's tokens (the oracle is bit-identical to the reference, F6)."""
