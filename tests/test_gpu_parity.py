@@ -804,6 +804,41 @@ def test_denoiser_mfma_vs_direct_b64_random_tokens(dev, req, name):
     assert float((lm - ld).abs().max()) <= 2e-7
 
 
+@pytest.mark.parametrize("B", [1, 3, 9, 17])
+def test_fp6_conv_ragged_item_counts_vs_direct(dev, ops, B):
+    """The persistent fp6 kernel with fewer work items than CUs (B=1,3), a ragged second round (B=9: 288 items on 256
+    workgroups) and an odd batch (B=17), carried membrane state included: spikes and counts bit-equal to the fp64
+    direct kernel, membrane potentials within 1e-6."""
+    from spkdiff.ops import IN_PTC
+    from snn_model.vq_diffusion import DummyModel, functional
+    torch.manual_seed(100 + B)
+    den = DummyModel(1, 128).cuda(0)
+    functional.set_step_mode(net=den, step_mode='m')
+    den.load_state_dict(synth.synth_denoiser_state(synth.MNIST))
+    den.eval()
+    for blk, cin in ((den.conv2, 64), (den.conv4, 256)):
+        s_in = (torch.rand(16, B, cin, 7, 7, device=dev) < 0.05).float()
+        x4 = ops.spikes_to_c4(s_in); xc = ops.spikes_to_ptc(s_in, chunk=32)
+        functional.reset_net(blk)
+        a1 = blk.run(x4, IN_PTC, final='ptc', chunk_out=ops.CHUNK_C4, want_counts=True)
+        a2 = blk.run(x4, IN_PTC, final='ptc', chunk_out=ops.CHUNK_C4)          # second call: carried v
+        va = blk[2].v.clone()
+        functional.reset_net(blk)
+        b1 = blk.run(xc, IN_PTC, final='f32', impl='direct')['f32']
+        b2 = blk.run(xc, IN_PTC, final='f32', impl='direct')['f32']
+        vb = blk[2].v.clone()
+        functional.reset_net(blk)
+        g1, g2 = ops.c4_to_spikes(a1['ptc']), ops.c4_to_spikes(a2['ptc'])
+        assert torch.equal(g1, b1) and torch.equal(g2, b2)
+        # weights below 2^-6 of their channel's maximum are fixed-point rounded at 2^-29 of that maximum
+        # (den_mfma_fp6.hip): a pre-activation may round to the neighbouring fp32 value -> v within an ulp or two
+        assert float((va - vb).abs().max()) <= 1e-6 and float((va != vb).float().mean()) <= 0.1
+        assert 0.001 < float(g1.mean()) < 0.5 and not torch.equal(g1, g2)
+        C = g1.shape[2]
+        want_cnt = g1.sum(0).reshape(B, C // 32, 32, 7, 7).permute(0, 1, 3, 4, 2)
+        assert torch.equal(a1['cnt'].float(), want_cnt)
+
+
 def test_syops_report_matches_golden_spike_rates(golden_dir, dev):
     """the syops-style energy report (R/syops/ops.py:14-24,121-158) from the fused kernels' own spike
     maps: layer firing rates equal the reference fixture's, ACs = overall * input rate, conv1 counts as MACs."""
