@@ -72,6 +72,18 @@ int spk_conv_transpose2d_fwd(const float* x, const float* w, const float* bias, 
 /* MembraneOutputLayer.forward, R/snn_model/snn_layers.py:36-41: out[N] = sum_t x_seq[t][N]*coef[t]. */
 int spk_memout_fwd(const float* x_seq, const float* coef, float* out, int T, long long N, spk_stream_t stream);
 
+/* ---- surrogate-gradient LIF (training path) ---------------------------------------------- */
+/* LIFNode training forward (hard reset, decay_input): SJ/activation_based/neuron.py:739-749,133-135; the native pair it
+ * mirrors: LIFNodeFPTTKernel / LIFNodeBPTTKernel, SJ/activation_based/auto_cuda/neuron_kernel.py:102-225,479-540.
+ * h_seq [T,N] (membrane potential before reset, kept for the backward), spike_seq [T,N] fp32, v_out [N] final state. */
+int spk_lif_train_fwd(const float* x_seq, const float* v_init, float* h_seq, float* spike_seq, float* v_out, int T,
+                      long long N, float tau, float v_threshold, float v_reset, spk_stream_t stream);
+/* BPTT with the ATan surrogate g'(x) = alpha/2 / (1 + (pi/2 alpha x)^2) (SJ/activation_based/surrogate.py:664-678).
+ * grad_v_last [N] (gradient of the final state) and grad_v_init [N] may be NULL.  detach_reset as in the reference. */
+int spk_lif_train_bwd(const float* grad_spike_seq, const float* grad_v_last, const float* h_seq, float* grad_x_seq,
+                      float* grad_v_init, int T, long long N, float tau, float v_threshold, float v_reset, float alpha,
+                      int detach_reset, spk_stream_t stream);
+
 /* ---- layout converters --------------------------------------------------------------------------------------- */
 /* chunk = C gives plain PTC [B,HW,T,C]; chunk = 32 gives the channel-chunked "CPTC" [B,C/32,HW,T,32] the MFMA
  * kernel reads (one contiguous slab per image and 32-channel K chunk). */

@@ -10,7 +10,8 @@ Only data (inputs, expected outputs) is written; no reference source travels.
     python oracle/gen_golden.py            # regenerates tests/golden/*.npz
 
 Fixtures: F1 LIF, F2 per-layer VQ-VAE (teacher forced), F3 encode,
-F4 decode glue, F5 denoiser, F6 p_sample + RNG-order trajectory, F7 BN eval.
+F4 decode glue, F5 denoiser, F6 p_sample + RNG-order trajectory, F7 BN eval,
+F8 LIF training forward + surrogate-gradient BPTT (next-row scope).
 """
 from __future__ import annotations
 
@@ -337,6 +338,30 @@ def main():
     np.savez_compressed(os.path.join(OUT, "f7_bn.npz"), x=xb.numpy(), y=yb.numpy(), form=form,
                         **{k: v.numpy() for k, v in bsd.items()})
     print(f"F7 ok: BN form = {form} (mismatches: fma {n_fma}, mul+add {n_ma} of {yb.numel()})")
+
+    # ------------------------------------------------------------------ F8 LIF training (surrogate-gradient BPTT)
+    # SURVEY.md §8f item 2.  The reference's torch-backend LIFNode in train mode, two calls without reset (the state
+    # stays in the graph), ATan surrogate; gradients of a fixed linear functional of both spike trains and the final v.
+    for det in (False, True):
+        g = torch.Generator().manual_seed(808)
+        xs = (torch.randn(16, 512, generator=g) * 1.5)
+        w1 = torch.randn(16, 512, generator=g); w2 = torch.randn(16, 512, generator=g); w3 = torch.randn(512, generator=g)
+        xr = xs.clone().requires_grad_(True)
+        node = vm.neuron.LIFNode(surrogate_function=vm.surrogate.ATan(), detach_reset=det, step_mode="m").train()
+        sa = node(xr); sb = node(xr.flip(0))
+        loss = (sa * w1).sum() + (sb * w2).sum() + (node.v * w3).sum()
+        loss.backward()
+        xo = xs.clone().requires_grad_(True)
+        oa, ov = ref.lif_multi_step_train(xo, detach_reset=det)
+        ob, ov = ref.lif_multi_step_train(xo.flip(0), ov, detach_reset=det)
+        ((oa * w1).sum() + (ob * w2).sum() + (ov * w3).sum()).backward()
+        eq(sa.detach(), oa.detach(), "F8 spikes"); eq(sb.detach(), ob.detach(), "F8 spikes (carry)")
+        eq(node.v.detach(), ov.detach(), "F8 v"); eq(xr.grad, xo.grad, "F8 grad_x")
+        np.savez_compressed(os.path.join(OUT, f"f8_lif_train_{'detach' if det else 'nodetach'}.npz"), x_seq=xs.numpy(),
+                            w1=w1.numpy(), w2=w2.numpy(), w3=w3.numpy(), spikes_a=pack(sa.detach())[0],
+                            spikes_b=pack(sb.detach())[0], spikes_shape=np.array(sa.shape), v=node.v.detach().numpy(),
+                            grad_x=xr.grad.numpy(), detach_reset=det)
+        print(f"F8 ok (detach_reset={det}): |grad_x| mean", float(xr.grad.abs().mean()))
     print("all fixtures written to", OUT)
 
 

@@ -32,6 +32,8 @@ number of time steps T (taken from the tensors) and the latent side.
 from __future__ import annotations
 
 import numpy as np
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -57,6 +59,44 @@ def lif_multi_step(x_seq: torch.Tensor, v=0.0, v_threshold: float = 1.0, v_reset
         v = v_reset * spike + (1.0 - spike) * v
         spike_seq[t] = spike
     return spike_seq, v
+
+
+class _ATanSpike(torch.autograd.Function):
+    """Heaviside forward, arc-tangent surrogate backward: SJ/activation_based/surrogate.py:664-678
+    (``atan_backward``: alpha / 2 / (1 + (pi / 2 * alpha * x)^2) * grad_output)."""
+
+    @staticmethod
+    def forward(ctx, x, alpha):
+        ctx.save_for_backward(x)
+        ctx.alpha = alpha
+        return (x >= 0).to(x)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (x,) = ctx.saved_tensors
+        return ctx.alpha / 2 / (1 + (math.pi / 2 * ctx.alpha * x).pow_(2)) * grad_output, None
+
+
+def lif_multi_step_train(x_seq: torch.Tensor, v=0.0, v_threshold: float = 1.0, v_reset: float = 0.0,
+                         tau: float = 2.0, alpha: float = 2.0, detach_reset: bool = False):
+    """Training-mode multi-step LIF (torch backend of the reference): per step ``neuronal_charge`` (decay_input;
+    SJ/activation_based/neuron.py:739-749: ``v + (x - v) / tau`` when v_reset == 0, else ``v + (x - (v - v_reset)) / tau``),
+    ``neuronal_fire`` = surrogate(v - v_threshold), hard ``neuronal_reset`` (:133-135: ``(1 - spike_d) * v + spike_d *
+    v_reset``, spike_d detached iff detach_reset).  Differentiable through torch autograd.  Returns (spike_seq, v_final).
+    SURVEY.md §8f item 2."""
+    if not torch.is_tensor(v):
+        v = torch.full_like(x_seq[0], float(v))
+    spikes = []
+    for t in range(x_seq.shape[0]):
+        if v_reset == 0.0:
+            v = v + (x_seq[t] - v) / tau
+        else:
+            v = v + (x_seq[t] - (v - v_reset)) / tau
+        spike = _ATanSpike.apply(v - v_threshold, alpha)
+        spike_d = spike.detach() if detach_reset else spike
+        v = (1.0 - spike_d) * v + spike_d * v_reset
+        spikes.append(spike)
+    return torch.stack(spikes), v
 
 
 # --------------------------------------------------------------------------- a2

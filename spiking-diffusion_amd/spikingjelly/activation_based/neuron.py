@@ -2,7 +2,8 @@
 
 Surface of SJ/activation_based/neuron.py:23-263 (BaseNode) and :603-1011 (LIFNode); the eval multi-step kernel
 ``jit_eval_multi_step_forward_hard_reset_decay_input`` (:799-811) is replaced by ``spk_lif_fwd`` (HIP, one pass,
-membrane potential in registers across T).  ``v`` keeps the reference's lifetime: python float after
+membrane potential in registers across T); in training mode the surrogate-gradient pair ``spk_lif_train_fwd`` /
+``spk_lif_train_bwd`` runs behind a ``torch.autograd.Function`` (the reference's CuPy ATGF contract, :954-966).  ``v`` keeps the reference's lifetime: python float after
 ``reset()``, tensor after the first forward, carried across forwards until the next ``reset()``.
 """
 from typing import Callable
@@ -64,9 +65,6 @@ class LIFNode(BaseNode):
         return super().extra_repr() + f', tau={self.tau}'
 
     def _check_supported(self, x):
-        if self.training:
-            raise NotImplementedError('spkdiff: LIFNode training (surrogate-gradient BPTT) is outside the inference '
-                                      'hot path; call .eval()')
         if self.v_reset is None or not self.decay_input:
             raise NotImplementedError('spkdiff: only hard reset with decay_input=True (the configuration used by '
                                       'snn_model) is implemented')
@@ -78,6 +76,16 @@ class LIFNode(BaseNode):
         self.v_float_to_tensor(x_seq[0])
         if not self.v.is_contiguous():
             self.v = self.v.contiguous()
+        if self.training:
+            # surrogate-gradient BPTT: HIP forward that keeps h, HIP backward; the state stays
+            # in the autograd graph across calls like the reference's ``self.v = v_seq[-1]``
+            # (SJ/activation_based/neuron.py:954-966)
+            if not isinstance(self.surrogate_function, surrogate.ATan):
+                raise NotImplementedError('spkdiff: the BPTT kernel implements the ATan surrogate (the one snn_model uses)')
+            spike_seq, self.v = ops.LIFTrainFunction.apply(x_seq.contiguous(), self.v, self.tau, self.v_threshold,
+                                                           self.v_reset, float(self.surrogate_function.alpha),
+                                                           self.detach_reset)
+            return spike_seq
         return ops.lif_fwd(x_seq, self.v, self.tau, self.v_threshold, self.v_reset)
 
     def single_step_forward(self, x: torch.Tensor):

@@ -1,8 +1,8 @@
 """Surrogate-function objects: constructor surface only.
 
 In inference the forward of every surrogate is the Heaviside step ``x >= 0`` (SJ/activation_based/surrogate.py:13-51),
-which the fused HIP LIF kernels evaluate in place; the backward (ATan etc., :664-760) belongs to training and is out of
-scope.  The classes exist so that ``neuron.LIFNode(surrogate_function=surrogate.ATan())`` is built
+which the fused HIP LIF kernels evaluate in place; the ATan backward (:664-678) is evaluated inside the BPTT kernel
+``spk_lif_train_bwd`` when a ``LIFNode`` runs in training mode.  The classes exist so that ``neuron.LIFNode(surrogate_function=surrogate.ATan())`` is built
 exactly as the reference builds it, and keep the reference's attributes (``alpha``, ``spiking``).
 """
 import torch.nn as nn

@@ -88,6 +88,58 @@ def lif_fwd(x_seq: torch.Tensor, v: torch.Tensor, tau=2.0, v_threshold=1.0, v_re
 
 
 # ---------------------------------------------------------------------------------------------- stateless layers
+def lif_train_fwd(x_seq: torch.Tensor, v_init: torch.Tensor, tau=2.0, v_threshold=1.0, v_reset=0.0):
+    """Training-mode multi-step LIF (hard reset, decay_input). Returns (spike_seq, h_seq, v_last), all fp32."""
+    x = _dev(x_seq, "x_seq", torch.float32)
+    v0 = _dev(v_init, "v", torch.float32)
+    T = x.shape[0]
+    N = x[0].numel()
+    if v0.numel() != N:
+        raise ValueError(f"v has {v0.numel()} elements, x_seq[0] has {N}")
+    h = torch.empty_like(x)
+    s = torch.empty_like(x)
+    v_last = torch.empty_like(v0)
+    check(lib.spk_lif_train_fwd(_p(x), _p(v0), _p(h), _p(s), _p(v_last), T, N, float(tau), float(v_threshold),
+                                float(v_reset), _stream(x)), "spk_lif_train_fwd")
+    return s, h, v_last
+
+
+def lif_train_bwd(grad_spike_seq, grad_v_last, h_seq, tau=2.0, v_threshold=1.0, v_reset=0.0, alpha=2.0,
+                  detach_reset=False, need_grad_v=True):
+    """BPTT of lif_train_fwd with the ATan surrogate. Returns (grad_x_seq, grad_v_init or None)."""
+    gs = _dev(grad_spike_seq, "grad_spike_seq", torch.float32)
+    h = _dev(h_seq, "h_seq", torch.float32)
+    gv = None if grad_v_last is None else _dev(grad_v_last, "grad_v_last", torch.float32)
+    T = h.shape[0]
+    N = h[0].numel()
+    gx = torch.empty_like(h)
+    gv0 = torch.empty(h.shape[1:], dtype=torch.float32, device=h.device) if need_grad_v else None
+    check(lib.spk_lif_train_bwd(_p(gs), _p(gv), _p(h), _p(gx), _p(gv0), T, N, float(tau), float(v_threshold),
+                                float(v_reset), float(alpha), int(bool(detach_reset)), _stream(h)), "spk_lif_train_bwd")
+    return gx, gv0
+
+
+class LIFTrainFunction(torch.autograd.Function):
+    """spike_seq, v_last = f(x_seq, v_init): the HIP counterpart of the reference's LIFNodeATGF
+    (SJ/activation_based/auto_cuda/neuron_kernel.py:496-540), ATan surrogate."""
+
+    @staticmethod
+    def forward(ctx, x_seq, v_init, tau, v_threshold, v_reset, alpha, detach_reset):
+        s, h, v_last = lif_train_fwd(x_seq, v_init, tau, v_threshold, v_reset)
+        ctx.save_for_backward(h)
+        ctx.cfg = (tau, v_threshold, v_reset, alpha, detach_reset)
+        return s, v_last
+
+    @staticmethod
+    def backward(ctx, grad_s, grad_v_last):
+        (h,) = ctx.saved_tensors
+        tau, v_threshold, v_reset, alpha, detach_reset = ctx.cfg
+        gs = grad_s if grad_s is not None else torch.zeros_like(h)
+        gx, gv0 = lif_train_bwd(gs.contiguous(), None if grad_v_last is None else grad_v_last.contiguous(), h, tau,
+                                v_threshold, v_reset, alpha, detach_reset, need_grad_v=ctx.needs_input_grad[1])
+        return gx, gv0, None, None, None, None, None
+
+
 def bn_prepare(gamma, beta, mean, var, eps):
     mean = _dev(mean, "running_mean", torch.float32)
     var = _dev(var, "running_var", torch.float32)

@@ -480,6 +480,53 @@ def test_f5_denoiser_mfma_fp6_kernel(golden_dir, dev, ops):
     assert not torch.equal(a1, a2), "second call starts from the carried membrane potentials"
 
 
+# ------------------------------------------------------------------------------------------------- F8 LIF training
+@pytest.mark.parametrize("det", [False, True])
+def test_f8_lif_training_bptt_vs_reference_fixture(golden_dir, dev, det):
+    """LIFNode in train mode -- HIP forward that keeps h + HIP surrogate-gradient backward behind a
+    torch.autograd.Function -- against the reference's torch-backend autograd (fixture F8): two calls without reset
+    (state in the graph), spikes exact, final v and dL/dx to fp32 round-off (the reference sums the same terms in
+    autograd's order)."""
+    from spikingjelly.activation_based import neuron, surrogate
+    d = load(golden_dir, f"f8_lif_train_{'detach' if det else 'nodetach'}.npz")
+    x = torch.from_numpy(d["x_seq"]).to(dev).requires_grad_(True)
+    w1, w2, w3 = (torch.from_numpy(d[k]).to(dev) for k in ("w1", "w2", "w3"))
+    node = neuron.LIFNode(surrogate_function=surrogate.ATan(), detach_reset=det, step_mode='m').train()
+    sa = node(x); sb = node(x.flip(0))
+    ((sa * w1).sum() + (sb * w2).sum() + (node.v * w3).sum()).backward()
+    assert torch.equal(sa.detach().cpu(), unpack(d["spikes_a"], d["spikes_shape"]))
+    assert torch.equal(sb.detach().cpu(), unpack(d["spikes_b"], d["spikes_shape"]))
+    want_v, want_g = torch.from_numpy(d["v"]), torch.from_numpy(d["grad_x"])
+    assert float((node.v.detach().cpu() - want_v).abs().max()) <= 1e-6
+    err = (x.grad.cpu() - want_g).abs()
+    assert float((err / (1e-6 + 1e-5 * want_g.abs())).max()) <= 1.0, float(err.max())
+    node.reset()
+    assert node.v == 0.0 and isinstance(node.v, float)
+    node.eval()                                  # and the inference kernel is untouched by the training path
+    with torch.no_grad():
+        assert torch.equal(node(x.detach()).cpu(), unpack(d["spikes_a"], d["spikes_shape"]))
+
+
+@pytest.mark.parametrize("N,tau,vr", [(1000, 2.0, 0.0), (1001, 3.0, -0.25)])
+def test_lif_train_kernels_vs_live_oracle(dev, ops, N, tau, vr):
+    """spk_lif_train_fwd / spk_lif_train_bwd through the C-ABI on vector (N % 4 == 0) and scalar paths, tau not a power
+    of two, v_reset != 0, non-zero initial state and an incoming gradient on the final state, against the oracle's
+    autograd."""
+    g = torch.Generator().manual_seed(7 + N)
+    xs = torch.randn(9, N, generator=g) * 1.5; v0 = torch.rand(N, generator=g) - 0.5
+    gs = torch.randn(9, N, generator=g); gv = torch.randn(N, generator=g)
+    xo = xs.clone().requires_grad_(True); vo = v0.clone().requires_grad_(True)
+    so, vlast = ref.lif_multi_step_train(xo, vo, v_reset=vr, tau=tau, alpha=2.0)
+    ((so * gs).sum() + (vlast * gv).sum()).backward()
+    s, h, vl = ops.lif_train_fwd(xs.to(dev), v0.to(dev), tau, 1.0, vr)
+    gx, gv0 = ops.lif_train_bwd(gs.to(dev), gv.to(dev), h, tau, 1.0, vr, 2.0, False)
+    assert torch.equal(s.cpu(), so.detach())
+    assert float((vl.cpu() - vlast.detach()).abs().max()) <= 1e-6
+    for got, want in ((gx.cpu(), xo.grad), (gv0.cpu(), vo.grad)):
+        err = (got - want).abs()
+        assert float((err / (1e-6 + 1e-5 * want.abs())).max()) <= 1.0, float(err.max())
+
+
 # ------------------------------------------------------------------------------------------------- F6 p_sample
 def test_f6_psample_steps_exact(golden_dir, dev, ops):
     d = load(golden_dir, "f6_psample.npz")

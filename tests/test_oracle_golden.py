@@ -45,6 +45,22 @@ def test_f1_lif_exact(golden_dir):
     assert torch.equal(v2, torch.from_numpy(d["v_carry"]))
 
 
+@pytest.mark.parametrize("det", [False, True])
+def test_f8_lif_training_forward_and_bptt(golden_dir, det):
+    """the oracle's training-mode LIF (surrogate-gradient autograd) against the reference's
+    torch-backend LIFNode in train mode: spikes, carried state and dL/dx of a fixed linear functional."""
+    d = load(golden_dir, f"f8_lif_train_{'detach' if det else 'nodetach'}.npz")
+    x = torch.from_numpy(d["x_seq"]).requires_grad_(True)
+    w1, w2, w3 = (torch.from_numpy(d[k]) for k in ("w1", "w2", "w3"))
+    sa, v = ref.lif_multi_step_train(x, detach_reset=det)
+    sb, v = ref.lif_multi_step_train(x.flip(0), v, detach_reset=det)
+    ((sa * w1).sum() + (sb * w2).sum() + (v * w3).sum()).backward()
+    assert torch.equal(sa.detach(), unpack(d["spikes_a"], d["spikes_shape"]))
+    assert torch.equal(sb.detach(), unpack(d["spikes_b"], d["spikes_shape"]))
+    assert torch.equal(v.detach(), torch.from_numpy(d["v"]))
+    assert torch.equal(x.grad, torch.from_numpy(d["grad_x"]))
+
+
 def test_memout_coef():
     # SURVEY §8 a4: coef = 0.8 ** arange(15..0) fp32, shape (16,1,1,1,1)
     c = ref.memout_coef(16)
