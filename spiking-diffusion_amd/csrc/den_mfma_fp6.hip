@@ -402,43 +402,55 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
 // With an odd number of positions (7x7 = 49) the 25th row tile of an image would hold ONE position: carried along in the
 // main kernel it costs a seventh tile per wave -- 1/7 of the MFMAs and a fourth epilogue pass for three padding tiles
 // and one real half tile.  Instead the main kernel runs 24 full tiles (NT = 6) and this kernel finishes position
-// H*W - 1 of every image: one wave = two images x 16 output channels, a 32-row tile whose lane halves are the two
-// images (the same accumulator layout, so the same epilogue); only the taps that fall inside the image exist (4 of 9
-// for a corner); operands come straight from L2 (16 B of spikes and 24 B of weights per lane and MFMA), no LDS.
+// H*W - 1 of every image: one wave = four images x 16 output channels, two 32-row tiles whose lane halves are two
+// images each (the same accumulator layout, so the same pairwise epilogue); only the taps that fall inside the image exist (4 of 9
+// for the corner); operands come straight from L2 (16 B of spikes and 24 B of weights per lane and MFMA), no LDS.
 // ~3 % of the main kernel's MFMA count.
+constexpr int LP_TILES = 2;      // 32-row tiles (= image pairs) per wave: a weight fragment serves 2 x 3 MFMAs
 __global__ __launch_bounds__(256) void conv3x3_fp6_lastpos_kernel(Fp6Args a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int HW = a.H * a.W, nchunks = a.nch0;
   const int g = blockIdx.y * 4 + wave;                      // Cout % 64 == 0: groups come in fours
-  const int b0 = blockIdx.x * 2;
+  const int b0 = blockIdx.x * 2 * LP_TILES;
   const int row = lane & 31, half = lane >> 5;
   const int hsel = (row >> 2) & 1, tt = (row & 3) + 4 * (row >> 3);       // A row -> (image parity, time step)
-  const int bA = b0 + hsel;
-  const bool a_ok = bA < a.B;
   const int py = a.H - 1, px = a.W - 1, p = HW - 1;
   typedef int v8i __attribute__((ext_vector_type(8)));
-  v16f acc[3];
+  v16f acc[LP_TILES][3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
+  for (int i = 0; i < LP_TILES; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // the taps that reach the last position (H-1, W-1) from inside the image are (dy, dx) in {-1, 0}^2 = taps 0, 1, 3, 4
+  // (H, W >= 2): a fixed list, so a (chunk, tap) step is straight-line code
   for (int c = 0; c < nchunks; ++c) {
-    const uint8_t* aslab = a.in0 + ((long long)(a_ok ? bA : b0) * nchunks + c) * HW * POS_BYTES;
     const uint8_t* wslab = a.wq + ((long long)g * nchunks + c) * W_CHUNK_BYTES;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int q = 0; q < 4; ++q) {
+      const int tap = (q >> 1) * 3 + (q & 1);
       const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
-      if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;          // workgroup-uniform
-      v4i av = {0, 0, 0, 0};
-      if (a_ok) av = *reinterpret_cast<const v4i*>(aslab + ((yy * a.W + xx) * T16 + tt) * 32 + 16 * half);
-      const v8i a8 = {av[0], av[1], av[2], av[3], 0, 0, 0, 0};
+      v8i b8[3];
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const uint8_t* wt = wslab + (tap * 3 + j) * W_TILE_BYTES;
-        const v4i x = *reinterpret_cast<const v4i*>(wt + lane * 16);
-        const v2i y = *reinterpret_cast<const v2i*>(wt + 1024 + lane * 8);
-        const v8i b8 = {x[0], x[1], x[2], x[3], y[0], y[1], 0, 0};
-        acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[j], 4, 2, 0, 0x7f7f7f7f, 0, (int)0x82828282u);
+        const v4i bx = *reinterpret_cast<const v4i*>(wt + lane * 16);
+        const v2i by = *reinterpret_cast<const v2i*>(wt + 1024 + lane * 8);
+        b8[j] = v8i{bx[0], bx[1], bx[2], bx[3], by[0], by[1], 0, 0};
+      }
+#pragma unroll
+      for (int i = 0; i < LP_TILES; ++i) {
+        const int bA = b0 + 2 * i + hsel;
+        v4i av = {0, 0, 0, 0};
+        if (bA < a.B)
+          av = *reinterpret_cast<const v4i*>(a.in0 + ((long long)bA * nchunks + c) * HW * POS_BYTES +
+                                             ((yy * a.W + xx) * T16 + tt) * 32 + 16 * half);
+        const v8i a8 = {av[0], av[1], av[2], av[3], 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[j], acc[i][j], 4, 2, 0, 0x7f7f7f7f, 0,
+                                                                      (int)0x82828282u);
       }
     }
   }
@@ -446,49 +458,51 @@ __global__ __launch_bounds__(256) void conv3x3_fp6_lastpos_kernel(Fp6Args a) {
   const int co = g * 16 + ch;
   const double sc = a.scale[co], bi = a.bias[co];
   const float bn_a = a.bn_a[co], bn_b = a.bn_b[co];
-  float x[16];
+  // tiles are finished in pairs exactly like the main kernel's: even lanes tile ia, odd lanes tile ia + 1
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {        // digits of step r to the even lane, of step r + 8 to the odd lane (see the main kernel)
-    float pr[3];
+  for (int ia = 0; ia < LP_TILES; ia += 2) {
+    float x[16];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const v2u q = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[j][r]), __float_as_uint(acc[j][r + 8]), false, false);
-      pr[j] = fmaf(__uint_as_float(q[0]), 32.0f, __uint_as_float(q[1]));
+    for (int r = 0; r < 16; ++r) {
+      float pr[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const v2u q = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ia][j][r]), __float_as_uint(acc[ia + 1][j][r]),
+                                                       false, false);
+        pr[j] = fmaf(__uint_as_float(q[0]), 32.0f, __uint_as_float(q[1]));
+      }
+      const double s1 = fma((double)pr[0], 1024.0, (double)pr[1]);
+      const double s = fma(s1, 1024.0, (double)pr[2]);
+      x[r] = (float)fma(s, sc, bi);
     }
-    const double s1 = fma((double)pr[0], 1024.0, (double)pr[1]);
-    const double s = fma(s1, 1024.0, (double)pr[2]);
-    const float xm = (float)fma(s, sc, bi);
-    const v2u xx = __builtin_amdgcn_permlane16_swap(__float_as_uint(xm), __float_as_uint(xm), false, false);
-    x[r] = __uint_as_float(xx[0]);
-    x[r + 8] = __uint_as_float(xx[1]);
-  }
-  const int b = b0 + half;                         // accumulator lane-half == image within the pair
-  const bool ok = b < a.B && !odd;                 // both lane parities hold the same neuron: the even one writes
-  const long long vidx = ((long long)(ok ? b : b0) * a.Cout + co) * HW + p;
-  float v = (a.v_io && ok) ? a.v_io[vidx] : 0.f;
-  unsigned mybits = 0;
+    const int b = b0 + 2 * (ia + odd) + half;          // accumulator lane-half == image within the tile's pair
+    const bool ok = b < a.B;
+    const long long vidx = ((long long)(ok ? b : 0) * a.Cout + co) * HW + p;
+    float v = (a.v_io && ok) ? a.v_io[vidx] : 0.f;
+    unsigned mybits = 0;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const bool s = spk_lif_step_default(v, fmaf(x[r], bn_a, bn_b)) && ok;
-    mybits |= s ? (1u << r) : 0u;
-  }
-  const unsigned cnt = __popc(mybits);
-  const unsigned bitsv = spk_transpose16_rows(mybits, lane);
-  if (a.v_io && ok) a.v_io[vidx] = v;
-  if (a.out_cnt && ok) a.out_cnt[(((long long)b * (a.Cout >> 5) + (co >> 5)) * HW + p) * 32 + (co & 31)] = (uint8_t)cnt;
-  if (ok) {
-    auto spread8 = [](unsigned q) -> unsigned {
-      q = (q | (q << 12)) & 0x000f000fu;
-      q = (q | (q << 6)) & 0x03030303u;
-      q = (q | (q << 3)) & 0x11111111u;
-      return q << 1;
-    };
-    uint2 o;
-    o.x = spread8(bitsv & 0xffu);
-    o.y = spread8((bitsv >> 8) & 0xffu);
-    const int co0 = g * 16;
-    uint8_t* dst = a.out + ((((long long)b * (a.Cout >> 6) + (co0 >> 6)) * HW + p) * T16 + (lane & 15)) * 32 + ((co0 & 63) >> 1);
-    *reinterpret_cast<uint2*>(dst) = o;
+    for (int r = 0; r < 16; ++r) {
+      const bool s = spk_lif_step_default(v, fmaf(x[r], bn_a, bn_b)) && ok;
+      mybits |= s ? (1u << r) : 0u;
+    }
+    const unsigned cnt = __popc(mybits);
+    const unsigned bitsv = spk_transpose16_rows(mybits, lane);
+    if (a.v_io && ok) a.v_io[vidx] = v;
+    if (a.out_cnt && ok) a.out_cnt[(((long long)b * (a.Cout >> 5) + (co >> 5)) * HW + p) * 32 + (co & 31)] = (uint8_t)cnt;
+    if (ok) {
+      auto spread8 = [](unsigned q) -> unsigned {
+        q = (q | (q << 12)) & 0x000f000fu;
+        q = (q | (q << 6)) & 0x03030303u;
+        q = (q | (q << 3)) & 0x11111111u;
+        return q << 1;
+      };
+      uint2 o;
+      o.x = spread8(bitsv & 0xffu);
+      o.y = spread8((bitsv >> 8) & 0xffu);
+      const int co0 = g * 16;
+      uint8_t* dst = a.out + ((((long long)b * (a.Cout >> 6) + (co0 >> 6)) * HW + p) * T16 + (lane & 15)) * 32 + ((co0 & 63) >> 1);
+      *reinterpret_cast<uint2*>(dst) = o;
+    }
   }
 }
 
@@ -616,7 +630,7 @@ extern "C" int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uin
   const size_t lds = 2 * ((size_t)((H + 2) * (W + 1) + 1) * POS_BYTES + W_CHUNK_BYTES);
   if ((ntiles + 3) / 4 > 7 || npa > NPA || lds > 160 * 1024) return SPK_ERR_UNSUPPORTED;
   // odd position count with at most 24 full tiles: 6 tiles per wave + the last-position kernel (see there)
-  const bool split_last = ((H * W) & 1) && (H * W) / 2 <= 24;
+  const bool split_last = ((H * W) & 1) && (H * W) / 2 <= 24 && H >= 2 && W >= 2;
   Fp6Args a;
   a.in0 = in_c4; a.nch0 = nch; a.wq = wq; a.scale = scale; a.bias = bias_d; a.bn_a = bn_a; a.bn_b = bn_b;
   a.out = out_c4; a.v_io = v_inout; a.out_cnt = out_counts; a.B = B; a.H = H; a.W = W; a.Cout = Cout;
@@ -640,7 +654,7 @@ extern "C" int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uin
   if (split_last) {
     hipLaunchKernelGGL(conv3x3_fp6_kernel<6>, grid, blk, lds, stream, a);
     SPK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv3x3_fp6_lastpos_kernel, dim3((B + 1) / 2, G / 4), blk, 0, stream, a);
+    hipLaunchKernelGGL(conv3x3_fp6_lastpos_kernel, dim3((B + 2 * LP_TILES - 1) / (2 * LP_TILES), G / 4), blk, 0, stream, a);
   } else {
     hipLaunchKernelGGL(conv3x3_fp6_kernel<7>, grid, blk, lds, stream, a);
   }
