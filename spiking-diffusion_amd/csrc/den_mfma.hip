@@ -84,67 +84,59 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
   }
   const int b_off = (lane & 31) * CK + 16 * (half ^ ((lane >> 4) & 1));   // same swizzle, baked into the packed weights
 
-  // DMA piece table, built ONCE per wave with wave-uniform (scalar) values: the A slab of a chunk is H image rows x
-  // ceil(W/2) pieces of two positions (1 KiB, the last piece of an odd-width row is half a KiB), wave w copies
-  // pieces [w*NPA, (w+1)*NPA); the W slab is 18 one-KiB pieces, wave w copies pieces w, w+4, ...
+  // DMA piece table, built ONCE per wave with wave-uniform (scalar) values, one packed word per A piece (bits 0..14
+  // source byte offset in the slab, 15..30 LDS byte offset in the image, bit 31 = full piece): the A slab of a chunk is
+  // H image rows x ceil(W/2) pieces of two positions (1 KiB, the last piece of an odd-width row covers one position =
+  // lanes 0..31), wave w copies pieces [w*NPA, (w+1)*NPA); the W slab is 18 one-KiB pieces, wave w copies pieces w,
+  // w+4, ...  Pieces beyond the slab repeat an earlier one (a harmless duplicate) so that the K loop issues
+  // unconditionally.  The copies are issued from inline assembly with a scalar base (den_common.h: hipcc then keeps
+  // counted lgkmcnt waits for the fragment prefetch instead of lgkmcnt(0) while a copy is in flight).
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const int pprow = (a.W + 1) >> 1;
   const int nA = a.H * pprow;
-  int pa_src[NPA], pa_dst[NPA];      // byte offsets; pa_src < 0: absent piece
-  bool pa_full[NPA];
+  unsigned pa_pk[NPA];
 #pragma unroll
   for (int j = 0; j < NPA; ++j) {
-    const int id = wave_s * NPA + j;
+    int id = wave_s * NPA + j;
+    id = id < nA ? id : nA - 1;
     const int y = id / pprow, px = id - y * pprow;
-    pa_src[j] = id < nA ? (y * a.W + 2 * px) * POS_BYTES : -1;
-    pa_dst[j] = ((y + 1) * PW + 1 + 2 * px) * POS_BYTES;
-    pa_full[j] = 2 * px + 1 < a.W;
+    const unsigned src = (unsigned)((y * a.W + 2 * px) * POS_BYTES), dst = (unsigned)(((y + 1) * PW + 1 + 2 * px) * POS_BYTES);
+    pa_pk[j] = src | (dst << 15) | ((2 * px + 1 < a.W) ? 0x80000000u : 0u);
   }
   const unsigned lane_a = (unsigned)(lane ^ ((lane >> 4) & 1)) * 16u;     // swizzled source lane (see a_off)
   const unsigned lane_w = (unsigned)lane * 16u;
+  const unsigned wave_k = (unsigned)wave_s * 1024u;
+  const unsigned sA_addr = spk_lds_addr(sA), sW_addr = sA_addr + 2 * A_BYTES;
 
-  auto issue_dma = [&](int item, int c, int buf) {
-    const int b = item / G, g = item - b * G;
-    const uint8_t* aslab = c < a.nch0 ? a.in0 + ((long long)b * a.nch0 + c) * HW * POS_BYTES
-                                      : a.in1 + ((long long)b * a.nch1 + (c - a.nch0)) * HW * POS_BYTES;
-    const int8_t* wslab = a.wq + ((long long)g * nchunks + c) * W_CHUNK_BYTES;
-    uint8_t* dA = sA + buf * A_BYTES;
-    uint8_t* dW = sW + buf * W_CHUNK_BYTES;
-#pragma unroll
-    for (int j = 0; j < NPA; ++j) {
-      if (pa_src[j] >= 0) {                                       // wave-uniform
-        if (pa_full[j] || lane < 32)
-          __builtin_amdgcn_global_load_lds(SPK_GLB(aslab + pa_src[j] + lane_a), SPK_LDS(dA + pa_dst[j]), 16, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < (W_PIECES + 3) / 4; ++j) {
-      const int k = wave_s + 4 * j;
-      if (k < W_PIECES)
-        __builtin_amdgcn_global_load_lds(SPK_GLB(wslab + k * 1024 + lane_w), SPK_LDS(dW + k * 1024), 16, 0, 0);
+  // piece q of this wave: q < NPA -> A piece q, else W piece wave + 4 * (q - NPA)
+  constexpr int NPW = (W_PIECES + 3) / 4;
+  auto issue_piece = [&](int q, const uint8_t* aslab, const int8_t* wslab, unsigned dA, unsigned dW) {
+    if (q < NPA) {
+      const unsigned pk = pa_pk[q];
+      const unsigned long long mask = (pk >> 31) ? ~0ull : 0xffffffffull;
+      spk_dma16s_masked(aslab + (pk & 0x7fffu), lane_a, dA + ((pk >> 15) & 0xffffu), mask);
+    } else {
+      unsigned ko = wave_k + 4096u * (unsigned)(q - NPA);
+      if (4 * (q - NPA) + 3 >= W_PIECES) ko = ko < (unsigned)W_PIECES * 1024u ? ko : ko - 4096u;
+      spk_dma16s(wslab + ko, lane_w, dW + ko);
     }
   };
-
-  // the same copy, one piece at a time (piece q of this wave: q < NPA -> A piece q, else W piece q - NPA), so that the
-  // K loop can interleave the DMA issues with its MFMAs instead of paying ~12 x 20 issue slots up front
-  constexpr int NPW = (W_PIECES + 3) / 4;
-  auto issue_piece = [&](int q, const uint8_t* aslab, const int8_t* wslab, uint8_t* dA, uint8_t* dW) {
-    if (q < NPA) {
-      if (pa_src[q] >= 0) {
-        if (pa_full[q] || lane < 32)
-          __builtin_amdgcn_global_load_lds(SPK_GLB(aslab + pa_src[q] + lane_a), SPK_LDS(dA + pa_dst[q]), 16, 0, 0);
-      }
-    } else {
-      const int k = wave_s + 4 * (q - NPA);
-      if (k < W_PIECES)
-        __builtin_amdgcn_global_load_lds(SPK_GLB(wslab + k * 1024 + lane_w), SPK_LDS(dW + k * 1024), 16, 0, 0);
-    }
+  auto slabs = [&](int item, int c, const uint8_t*& aslab, const int8_t*& wslab) {
+    const int b = item / G, g = item - b * G;
+    aslab = c < a.nch0 ? a.in0 + ((long long)b * a.nch0 + c) * HW * POS_BYTES
+                       : a.in1 + ((long long)b * a.nch1 + (c - a.nch0)) * HW * POS_BYTES;
+    wslab = a.wq + ((long long)g * nchunks + c) * W_CHUNK_BYTES;
   };
 
   const int col = lane & 31, ch = col & 15, odd = col >> 4;
 
   int it = 0;                                      // running chunk counter: LDS buffer = it & 1
-  if ((int)blockIdx.x < total) issue_dma(blockIdx.x, 0, 0);
+  if ((int)blockIdx.x < total) {
+    const uint8_t* as0; const int8_t* ws0;
+    slabs(blockIdx.x, 0, as0, ws0);
+#pragma unroll
+    for (int q = 0; q < NPA + NPW; ++q) issue_piece(q, as0, ws0, sA_addr, sW_addr);
+  }
   for (int item = blockIdx.x; item < total; item += gridDim.x) {
     v16i acc[NT][2];      // written (not accumulated) by tap 0 of the first chunk: no explicit zeroing
 #ifdef SPK_NO_PEEL
@@ -162,17 +154,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
     if (MODE == SPK_MODE_LIF) { bn_a = a.bn_a[co]; bn_b = a.bn_b[co]; }
     for (int c = 0; c < nchunks; ++c, ++it) {
     const int buf = it & 1;
-    __syncthreads();     // vmcnt(0) + barrier: this chunk's DMA has landed; everyone is done with the other buffer
+    spk_dma_wait_all();  // this wave's share of the chunk's DMA has landed ...
+    __syncthreads();     // ... and so has everyone else's; everyone is done with the other buffer
     // next chunk (possibly of the next item): its DMA pieces are issued between the MFMA groups below
     int nitem = item, nc = c + 1;
     if (nc == nchunks) { nc = 0; nitem = item + gridDim.x; }
-    const bool have_next = nitem < total && !(DBG & 1);
-    const int nb = nitem / G, ng = nitem - nb * G;
-    const uint8_t* n_aslab = nc < a.nch0 ? a.in0 + ((long long)nb * a.nch0 + nc) * HW * POS_BYTES
-                                         : a.in1 + ((long long)nb * a.nch1 + (nc - a.nch0)) * HW * POS_BYTES;
-    const int8_t* n_wslab = a.wq + ((long long)ng * nchunks + nc) * W_CHUNK_BYTES;
-    uint8_t* const n_dA = sA + (buf ^ 1) * A_BYTES;
-    uint8_t* const n_dW = sW + (buf ^ 1) * W_CHUNK_BYTES;
+    const bool have_next = nitem < total;      // otherwise the same chunk is copied once more (never read)
+    const uint8_t* n_aslab; const int8_t* n_wslab;
+    slabs(have_next ? nitem : item, have_next ? nc : c, n_aslab, n_wslab);
+    const unsigned n_dA = sA_addr + (buf ^ 1) * A_BYTES;            // LDS byte addresses of the DMA destinations
+    const unsigned n_dW = sW_addr + (buf ^ 1) * W_CHUNK_BYTES;
 
     // ---------------- 9 taps x NT row tiles x 2 column tiles, fragments read four steps ahead ------------------
     // FIRST (the first K chunk of an item): tap 0 starts every accumulator from a zero C operand instead of zeroing
@@ -219,7 +210,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
           constexpr int NPIECES = NPA + NPW;
           constexpr int DMA_EVERY = (9 * NT) / NPIECES;
           if (s % DMA_EVERY == 0 && s / DMA_EVERY < NPIECES) {
-            if (have_next) issue_piece(s / DMA_EVERY, n_aslab, n_wslab, n_dA, n_dW);
+            if (!(DBG & 1)) issue_piece(s / DMA_EVERY, n_aslab, n_wslab, n_dA, n_dW);
           }
         }
         __builtin_amdgcn_sched_barrier(0);     // keep the read-ahead distance: hipcc otherwise sinks every ds_read
@@ -252,24 +243,45 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
         }
       };
       if (MODE == SPK_MODE_LIF) {
-        // Both partner lanes now hold the same 16 pre-activations, so the LIF scan runs on TWO row tiles at once: even
-        // lanes scan tile ip, odd lanes tile ip + 1.  Each lane collects its neuron's 16 spike bits; a DPP bit-matrix
+        // The LIF scan runs on TWO row tiles at once: even lanes scan tile ip, odd lanes tile ip + 1.  Each lane collects
+        // its neuron's 16 spike bits; a DPP bit-matrix
         // transpose inside every 16-lane row (= 16 channels of one position) turns them into per-time-step channel masks.
 #pragma unroll
         for (int ip = 0; ip < NT; ip += 2) {
-          float xa[16], xb[16];
-          recombine(ip, xa);
-          if (ip + 1 < NT) recombine(ip + 1, xb);
-          const int ti = wave + 4 * (ip + odd);
+          // Pairwise exchange (as in den_mfma_fp6.hip): v_permlane16_swap(acc[ip][ct][r], acc[ip + 1][ct][r]) leaves the
+          // even lane with both digits of column tile ct of tile ip and the odd lane with those of tile ip + 1, so 32
+          // swaps give every lane all four digits of ONE neuron for all 16 steps; the odd tile out of an odd NT is
+          // split over the lane parities by time steps (recombine()).
+          float xa[16];
+          const bool paired = ip + 1 < NT;
+          // keep this pair's accumulators in their AGPR tuples up to here: hipcc otherwise copies 16-register tuples
+          // to VGPRs at the top of the epilogue and spills (den_mfma_fp6.hip)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            asm volatile("" : "+a"(acc[ip][ct]));
+            if (paired) asm volatile("" : "+a"(acc[ip + 1][ct]));
+          }
+          if (paired) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const v2u p01 = __builtin_amdgcn_permlane16_swap((unsigned)acc[ip][0][r], (unsigned)acc[paired ? ip + 1 : ip][0][r], false, false);
+              const v2u p23 = __builtin_amdgcn_permlane16_swap((unsigned)acc[ip][1][r], (unsigned)acc[paired ? ip + 1 : ip][1][r], false, false);
+              const int hi = (int)p01[0] * 256 + (int)p01[1], lo = (int)p23[0] * 256 + (int)p23[1];
+              const double s = fma((double)hi, 65536.0, (double)lo);        // exact
+              xa[r] = (float)fma(s, sc, bi);                                 // the one rounding to fp32
+            }
+          } else {
+            recombine(ip, xa);
+          }
+          const int ti = wave + 4 * (ip + (paired ? odd : 0));
           const int p = 2 * ti + half;                  // accumulator lane-half == position within the tile
-          const bool pos_ok = p < HW && (ip + 1 < NT || !odd);
+          const bool pos_ok = p < HW && (paired || !odd);
           const long long vidx = ((long long)b * a.Cout + co) * HW + (pos_ok ? p : 0);
           float v = a.v_io ? a.v_io[vidx] : 0.f;
           unsigned mybits = 0;                    // bit r = this lane's neuron fired at t = r
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float xv = (ip + 1 < NT && odd) ? xb[r] : xa[r];
-            const bool s = spk_lif_step_default(v, fmaf(xv, bn_a, bn_b)) && pos_ok;
+            const bool s = spk_lif_step_default(v, fmaf(xa[r], bn_a, bn_b)) && pos_ok;
             mybits |= s ? (1u << r) : 0u;
           }
           const unsigned cnt = __popc(mybits);
@@ -297,6 +309,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
           float x[16];
+          asm volatile("" : "+a"(acc[i][0]));
+          asm volatile("" : "+a"(acc[i][1]));
           recombine(i, x);
           const int p = 2 * (wave + 4 * i) + half;
           float msum = 0.f;
@@ -308,6 +322,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
       }
     }
   }   // items
+  spk_dma_wait_all();     // the copy issued during the very last chunk must not outlive the workgroup's LDS allocation
 }
 
 // ------------------------------------------------------------------------------------------------ time-collapsed conv6
