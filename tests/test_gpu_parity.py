@@ -886,6 +886,31 @@ def test_fp6_conv_ragged_item_counts_vs_direct(dev, ops, B):
         assert torch.equal(a1['cnt'].float(), want_cnt)
 
 
+@pytest.mark.parametrize("H,W", [(5, 5), (6, 6), (7, 5), (4, 7), (3, 3), (2, 2), (8, 6)])
+def test_fp6_conv_other_latent_sizes_vs_direct(dev, ops, H, W):
+    """The fp6 kernel away from 7x7: odd position counts (24-full-tile form + last-position kernel with fewer tiles),
+    even ones and non-square latents (7-tile form), B=5: spikes and counts bit-equal to the fp64 direct kernel."""
+    from spkdiff.ops import IN_PTC
+    from snn_model.vq_diffusion import DummyModel, functional
+    assert ops.den_fp6_supported(128, 64, 3, 1, 1, 16, H, W)
+    torch.manual_seed(10 * H + W)
+    den = DummyModel(1, 128).cuda(0)
+    functional.set_step_mode(net=den, step_mode='m')
+    den.load_state_dict(synth.synth_denoiser_state(synth.MNIST))
+    den.eval()
+    B = 5
+    for blk, cin in ((den.conv2, 64), (den.conv3, 128)):
+        s_in = (torch.rand(16, B, cin, H, W, device=dev) < 0.06).float()
+        x4 = ops.spikes_to_c4(s_in); xc = ops.spikes_to_ptc(s_in, chunk=32)
+        a = blk.run(x4, IN_PTC, final='ptc', stateful=False, chunk_out=ops.CHUNK_C4, want_counts=True)
+        d = blk.run(xc, IN_PTC, final='f32', stateful=False, impl='direct')['f32']
+        got = ops.c4_to_spikes(a['ptc'])
+        assert torch.equal(got, d), f"{H}x{W}: fp6 path != direct"
+        C = got.shape[2]
+        assert torch.equal(a['cnt'].float(), got.sum(0).reshape(B, C // 32, 32, H, W).permute(0, 1, 3, 4, 2))
+        assert float(got.mean()) > 0.0005
+
+
 def test_syops_report_matches_golden_spike_rates(golden_dir, dev):
     """the syops-style energy report (R/syops/ops.py:14-24,121-158) from the fused kernels' own spike
     maps: layer firing rates equal the reference fixture's, ACs = overall * input rate, conv1 counts as MACs."""
