@@ -639,10 +639,10 @@ extern "C" int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uin
   dim3 grid(total < cus ? total : cus), blk(256);          // persistent: one workgroup per CU
   // XCD-aware walk: the largest power-of-two group count whose packed weights (gx * nch slabs) fit ~1.5 MB of an XCD's
   // 4 MB L2, if the shape tiles exactly (see decode() in the kernel)
-  // Measured on the conv4 shape (B = 256): L2-miss reads 206 -> 111 MB and HBM-side writes 218 -> 56 MB per launch, but
-  // the launch takes ~2 % LONGER (32 workgroups of one XCD pull the same slab lines at the same moment), so the walk is
-  // opt-in: SPKDIFF_FP6_XCD_WALK=1.
-  static const bool xcd_walk = [] { const char* e = getenv("SPKDIFF_FP6_XCD_WALK"); return e && e[0] == '1'; }();
+  // Measured on the conv4 shape (B = 256): L2-miss reads 206 -> 111 MB and HBM-side writes 218 -> 56 MB per launch at
+  // the same launch time (with 7 tiles per wave it was ~2 % slower; rotating the chunk order per workgroup to spread the
+  // slab requests of an XCD made it slower still).  SPKDIFF_FP6_XCD_WALK=0 selects the image-major walk.
+  static const bool xcd_walk = [] { const char* e = getenv("SPKDIFF_FP6_XCD_WALK"); return !(e && e[0] == '0'); }();
   a.gx = 0;
   if (xcd_walk && (grid.x & 7) == 0) {
     const int S = grid.x / 8;
