@@ -153,22 +153,18 @@ __global__ __launch_bounds__(256) void conv_mfma_gather_kernel(GArgs a) {
   const int co = g * 16 + ch;
   const bool co_ok = co < a.Cout;
   const double sc = a.scale[g * 16 + ch], bi = a.bias[g * 16 + ch];     // padded to 16 per group by the packer
-  auto recombine = [&](int i, float (&x)[16]) {
+  // Pairwise exchange (den_mfma_fp6.hip): v_permlane16_swap(acc[0][ct][r], acc[1][ct][r]) leaves the even lane with both
+  // digits of column tile ct of row tile 0 and the odd lane with those of row tile 1 -- 32 swaps give every lane all four
+  // digits of ONE neuron for all 16 steps; both lane parities recombine and scan their own tile.
+  float xs[16];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const v2u p01 = __builtin_amdgcn_permlane16_swap((unsigned)acc[i][0][r], (unsigned)acc[i][0][r + 8], false, false);
-      const v2u p23 = __builtin_amdgcn_permlane16_swap((unsigned)acc[i][1][r], (unsigned)acc[i][1][r + 8], false, false);
-      const int hi = (int)p01[0] * 256 + (int)p01[1], lo = (int)p23[0] * 256 + (int)p23[1];
-      const double s = fma((double)hi, 65536.0, (double)lo);
-      const float xm = (float)fma(s, sc, bi);
-      const v2u xx = __builtin_amdgcn_permlane16_swap(__float_as_uint(xm), __float_as_uint(xm), false, false);
-      x[r] = __uint_as_float(xx[0]);
-      x[r + 8] = __uint_as_float(xx[1]);
-    }
-  };
-  float xa[16], xb[16];
-  recombine(0, xa);
-  recombine(1, xb);
+  for (int r = 0; r < 16; ++r) {
+    const v2u p01 = __builtin_amdgcn_permlane16_swap((unsigned)acc[0][0][r], (unsigned)acc[1][0][r], false, false);
+    const v2u p23 = __builtin_amdgcn_permlane16_swap((unsigned)acc[0][1][r], (unsigned)acc[1][1][r], false, false);
+    const int hi = (int)p01[0] * 256 + (int)p01[1], lo = (int)p23[0] * 256 + (int)p23[1];
+    const double s = fma((double)hi, 65536.0, (double)lo);
+    xs[r] = (float)fma(s, sc, bi);
+  }
   // even lanes own tile 0, odd lanes tile 1; accumulator lane-half = position within the tile
   const int q = (int)pg * 4 + 2 * odd + half;
   const bool pos_ok = q < npos_c;
@@ -182,7 +178,7 @@ __global__ __launch_bounds__(256) void conv_mfma_gather_kernel(GArgs a) {
     unsigned mybits = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float xv = odd ? xb[r] : xa[r];
+      const float xv = xs[r];
       const bool s = spk_lif_step_default(v, fmaf(xv, bn_a, bn_b)) && pos_ok && co_ok;
       mybits |= s ? (1u << r) : 0u;
     }
@@ -205,7 +201,7 @@ __global__ __launch_bounds__(256) void conv_mfma_gather_kernel(GArgs a) {
   } else {  // SPK_MODE_MEMOUT: sum_t x[t] * coef[t]  (+ tanh, + uint8), R/snn_model/snn_layers.py:36-41, R/main.py:399-401
     float m = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) m = m + (odd ? xb[r] : xa[r]) * a.coef[r];
+    for (int r = 0; r < 16; ++r) m = m + xs[r] * a.coef[r];
     if (pos_ok && co_ok) {
       const float pv = a.apply_tanh ? tanhf(m) : m;
       const long long oidx = ((long long)b * a.Cout + co) * HWo + opos;
@@ -318,22 +314,18 @@ __device__ __forceinline__ void gather2_body(const GArgs& a, int b, int g, int p
   const int co = g * 16 + ch;
   const bool co_ok = co < a.Cout;
   const double sc = a.scale[g * 16 + ch], bi = a.bias[g * 16 + ch];
-  auto recombine = [&](int i, float (&x)[16]) {
+  // Pairwise exchange (den_mfma_fp6.hip): v_permlane16_swap(acc[0][ct][r], acc[1][ct][r]) leaves the even lane with both
+  // digits of column tile ct of row tile 0 and the odd lane with those of row tile 1 -- 32 swaps give every lane all four
+  // digits of ONE neuron for all 16 steps; both lane parities recombine and scan their own tile.
+  float xs[16];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const v2u p01 = __builtin_amdgcn_permlane16_swap((unsigned)acc[i][0][r], (unsigned)acc[i][0][r + 8], false, false);
-      const v2u p23 = __builtin_amdgcn_permlane16_swap((unsigned)acc[i][1][r], (unsigned)acc[i][1][r + 8], false, false);
-      const int hi = (int)p01[0] * 256 + (int)p01[1], lo = (int)p23[0] * 256 + (int)p23[1];
-      const double s = fma((double)hi, 65536.0, (double)lo);
-      const float xm = (float)fma(s, sc, bi);
-      const v2u xx = __builtin_amdgcn_permlane16_swap(__float_as_uint(xm), __float_as_uint(xm), false, false);
-      x[r] = __uint_as_float(xx[0]);
-      x[r + 8] = __uint_as_float(xx[1]);
-    }
-  };
-  float xa[16], xb[16];
-  recombine(0, xa);
-  recombine(1, xb);
+  for (int r = 0; r < 16; ++r) {
+    const v2u p01 = __builtin_amdgcn_permlane16_swap((unsigned)acc[0][0][r], (unsigned)acc[1][0][r], false, false);
+    const v2u p23 = __builtin_amdgcn_permlane16_swap((unsigned)acc[0][1][r], (unsigned)acc[1][1][r], false, false);
+    const int hi = (int)p01[0] * 256 + (int)p01[1], lo = (int)p23[0] * 256 + (int)p23[1];
+    const double s = fma((double)hi, 65536.0, (double)lo);
+    xs[r] = (float)fma(s, sc, bi);
+  }
   const int q = pg * 4 + 2 * odd + half;
   const bool pos_ok = q < npos_c;
   const int qy = (int)(((float)q + 0.5f) * inv_wc), qx = q - qy * Wc;
@@ -346,7 +338,7 @@ __device__ __forceinline__ void gather2_body(const GArgs& a, int b, int g, int p
     unsigned mybits = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float xv = odd ? xb[r] : xa[r];
+      const float xv = xs[r];
       const bool s = spk_lif_step_default(v, fmaf(xv, bn_a, bn_b)) && pos_ok && co_ok;
       mybits |= s ? (1u << r) : 0u;
     }
@@ -369,7 +361,7 @@ __device__ __forceinline__ void gather2_body(const GArgs& a, int b, int g, int p
   } else {
     float m = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) m = m + (odd ? xb[r] : xa[r]) * a.coef[r];
+    for (int r = 0; r < 16; ++r) m = m + xs[r] * a.coef[r];
     if (pos_ok && co_ok) {
       const float pv = a.apply_tanh ? tanhf(m) : m;
       const long long oidx = ((long long)b * a.Cout + co) * HWo + opos;
