@@ -33,7 +33,6 @@ namespace {
 typedef int v6i __attribute__((ext_vector_type(6)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
-template <int V> using ic = std::integral_constant<int, V>;
 
 constexpr int T16 = 16;
 constexpr int CK = 64;                              // channels per K chunk
@@ -66,9 +65,6 @@ struct Fp6Args {
 
 #ifndef SPK_FP6_DBG
 #define SPK_FP6_DBG 0           // timing experiments only: 1 = no steady-state DMA, 4 = no epilogue (results are wrong)
-#endif
-#ifndef SPK_FP6_SPLIT_LAST
-#define SPK_FP6_SPLIT_LAST 1    // an item's last K chunk runs tile-group-major with the read-out of tiles 0, 1 under its MFMAs
 #endif
 #ifndef SPK_FP6_PF
 #define SPK_FP6_PF 4
@@ -132,7 +128,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
   const unsigned wave_k = (unsigned)wave_s * 1024u;
 
   // piece q of this wave: q < NPA -> A piece q, else W piece wave + 4 * (q - NPA) (the 42nd..44th repeat an earlier one)
-  auto issue_piece = [&](int q, const uint8_t* aslab, const uint8_t* wslab, unsigned dA, unsigned dW) __attribute__((always_inline)) {
+  auto issue_piece = [&](int q, const uint8_t* aslab, const uint8_t* wslab, unsigned dA, unsigned dW) {
     if (q < NPA) {
       const unsigned pk = pa_pk[q];
       const unsigned long long mask = (pk >> 31) ? ~0ull : 0xffffffffull;
@@ -153,7 +149,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
   const int S = gridDim.x >> 3;                       // workgroups per XCD
   const int gx = a.gx;
   const int nsets = gx > 0 ? G / gx : 1, npart = 8 / nsets, ipx = gx > 0 ? S / gx : 1;
-  auto decode = [&](int item, int& b, int& g) __attribute__((always_inline)) {
+  auto decode = [&](int item, int& b, int& g) {
     if (gx > 0) {
       const int j = item / (int)gridDim.x, k = item - j * (int)gridDim.x;
       const int x = k & 7, slot = k >> 3;
@@ -165,7 +161,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
       g = item - b * G;
     }
   };
-  auto slabs = [&](int item, int c, const uint8_t*& aslab, const uint8_t*& wslab) __attribute__((always_inline)) {
+  auto slabs = [&](int item, int c, const uint8_t*& aslab, const uint8_t*& wslab) {
     int b, g;
     decode(item, b, g);
     aslab = a.in0 + ((long long)b * nchunks + c) * HW * POS_BYTES;
@@ -192,33 +188,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
     const int co = g * 16 + ch;
     const double sc = a.scale[co], bi = a.bias[co];
     const float bn_a = a.bn_a[co], bn_b = a.bn_b[co];
-    // pre-activations of the tile pair (0, 1), recombined under the MFMAs of the other tiles in the item's last chunk
-    float x01[16];
-    auto recombine3 = [&](const float (&pr)[3]) __attribute__((always_inline)) -> float {
-      const double s1 = fma((double)pr[0], 1024.0, (double)pr[1]);               // exact
-      const double s = fma(s1, 1024.0, (double)pr[2]);                           // exact: |s| < 2^43
-      return (float)fma(s, sc, bi);                                              // the one rounding to fp32
-    };
-    // step r of a pair's read-out: see the epilogue comment below
-    auto pair_step = [&](int ia, int ib, int r) __attribute__((always_inline)) -> float {
-      float pr[3];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const v2u p = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ia][j][r]), __float_as_uint(acc[ib][j][r]),
-                                                       false, false);
-        pr[j] = fmaf(__uint_as_float(p[0]), 32.0f, __uint_as_float(p[1]));       // exact: |.| < 2^22
-      }
-      return recombine3(pr);
-    };
-    auto pin_pair = [&](int ia, int ib) __attribute__((always_inline)) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        if (3 * ia + j < N_AGPR) asm volatile("" : "+a"(acc[ia][j]));
-        if (ib != ia && 3 * ib + j < N_AGPR) asm volatile("" : "+a"(acc[ib][j]));
-      }
-    };
-    // one K chunk of the item; FIRST / LAST are compile-time so that every call site is straight-line code
-    auto do_chunk = [&](int c, auto first_tag, auto last_tag) __attribute__((always_inline)) {
+    for (int c = 0; c < nchunks; ++c, ++it) {
       const int buf = it & 1;
       long long tq0 = 0, tq1 = 0, tq2 = 0;
       if (SPK_FP6_DBG & 64) tq0 = __builtin_amdgcn_s_memtime();
@@ -237,26 +207,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
       const unsigned n_dW = sW_addr + (buf ^ 1) * W_CHUNK_BYTES;
 
       // ---------------- 9 taps x NT row tiles x 3 column tiles, A fragments read four steps ahead ------------------
-      // LAST (the item's last chunk, SPK_FP6_SPLIT_LAST, NT = 6): the chunk is taken in two tile groups -- first all taps
-      // of tiles 0 and 1, then all taps of tiles 2..5.  The accumulators of the pair (0, 1) are final after the first
-      // group, and the 16 recombination steps of their read-out (~22 vector instructions each) are dealt out over the
-      // 108 MFMAs of the second group: a third of the epilogue runs while the matrix pipe is busy.  (Reads only -- no
-      // accumulator is redefined in this region, which is what hipcc cannot cope with)
-      // `run`: 9 taps x the NTL row tiles [T0, T0 + NTL) x 3 column tiles, tap-major, A fragments read PF steps ahead;
-      // DMA pieces [Q0, ...) of the following chunk and (EPI) the read-out steps of the tile pair (0, 1) are dealt out
-      // over the steps.  Plain div / mod step indices: they must fold to constants after unrolling, or hipcc demotes
-      // the accumulator array to scratch memory.
-      auto run = [&](auto first_tag, auto t0_tag, auto ntl_tag, auto q0_tag, auto epi_tag) __attribute__((always_inline)) {
-        constexpr bool FIRST = decltype(first_tag)::value, EPI = decltype(epi_tag)::value;
-        constexpr int T0 = decltype(t0_tag)::value, NTL = decltype(ntl_tag)::value, Q0 = decltype(q0_tag)::value;
+      auto compute = [&](auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         const uint8_t* A = sA + buf * A_BYTES;
         const uint8_t* Wb = sW + buf * W_CHUNK_BYTES;
-        auto lda = [&](int s) __attribute__((always_inline)) -> v4i {
-          const int tap = s / NTL, i = T0 + s % NTL;
+        auto lda = [&](int s) -> v4i {
+          const int tap = s / NT, i = s % NT;
           const int toff = ((tap / 3 - 1) * PW + (tap % 3 - 1)) * POS_BYTES;
           return *reinterpret_cast<const v4i*>(A + a_off[i] + toff);
         };
-        auto ldb = [&](int tap, int j) __attribute__((always_inline)) -> v6i {
+        auto ldb = [&](int tap, int j) -> v6i {
           // 16 + 8 bytes per lane.  The 8-byte read is volatile so that hipcc does not pair the tails of two tiles in
           // one ds_read2st64_b64 -- which lands them in the wrong registers and costs a wait + v_mov per tap.
           const uint8_t* p = Wb + (tap * 3 + j) * W_TILE_BYTES;
@@ -274,11 +234,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
 #pragma unroll
         for (int s = 0; s < PF; ++s) af[s] = lda(s);
 #pragma unroll
-        for (int s = 0; s < 9 * NTL; ++s) {
-          const int tap = s / NTL, i = T0 + s % NTL;
+        for (int s = 0; s < 9 * NT; ++s) {
+          const int tap = s / NT, i = s % NT;
           const v4i av = af[s % PF];
-          if (s + PF < 9 * NTL) af[s % PF] = lda(s + PF);
-          auto mfma = [&](int j) __attribute__((always_inline)) {
+          if (s + PF < 9 * NT) af[s % PF] = lda(s + PF);
+          auto mfma = [&](int j) {
             if (FIRST && tap == 0) {
               if (3 * i + j < N_AGPR) SPK_MFMA_FP6_Z("a", acc[i][j], av, bc[j], sc_a, sc_b);
               else SPK_MFMA_FP6_Z("v", acc[i][j], av, bc[j], sc_a, sc_b);
@@ -292,65 +252,35 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
           mfma(0);
           __builtin_amdgcn_sched_barrier(0);
           {
-            // DMA schedule: NPA + NPW pieces, one every DMA_EVERY-th step
+            // DMA schedule: NPA + NPW pieces spread over the 9*NT steps (every DMA_EVERY-th step issues one piece)
             constexpr int NPIECES = NPA + NPW;
             constexpr int DMA_EVERY = SPK_FP6_DMA_EVERY;
-            if (s % DMA_EVERY == 0 && Q0 + s / DMA_EVERY < NPIECES) {
-              const int q = Q0 + s / DMA_EVERY;
+            if (s % DMA_EVERY == 0 && s / DMA_EVERY < NPIECES) {
+              const int q = s / DMA_EVERY;
               const bool skip = ((SPK_FP6_DBG & 8) && q >= NPA) || ((SPK_FP6_DBG & 16) && q < NPA);
               if (!(SPK_FP6_DBG & 1) && !skip) issue_piece(q, n_aslab, n_wslab, n_dA, n_dW);
             }
           }
           mfma(1);
           __builtin_amdgcn_sched_barrier(0);
-          if (s % NTL == 0 && tap + 1 < 9) {
+          if (i == 0 && tap + 1 < 9) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) bn[j] = ldb(tap + 1, j);
           }
           mfma(2);
-          if (s % NTL == NTL - 1) {
+          if (i == NT - 1) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) bc[j] = bn[j];
-          }
-          if (EPI) {
-            // one read-out step of the pair (0, 1) every second MFMA step, from the third step on (its last MFMAs were
-            // issued >= 6 MFMAs ago: beyond the 18 wait states an accumulator read needs)
-            if (s == 2) pin_pair(0, 1);
-            if (s >= 2 && (s - 2) % 2 == 0 && (s - 2) / 2 < 16) x01[(s - 2) / 2] = pair_step(0, 1, (s - 2) / 2);
           }
           __builtin_amdgcn_sched_barrier(0);     // keep the read-ahead distance (see den_mfma.hip)
         }
       };
-      // LAST (the item's last chunk, SPK_FP6_SPLIT_LAST, NT = 6): the chunk is taken in two tile groups -- first all taps
-      // of tiles 0 and 1, then all taps of tiles 2..5.  The accumulators of the pair (0, 1) are final after the first
-      // group, and the 16 recombination steps of their read-out (~22 vector instructions each) are dealt out over the
-      // 108 MFMAs of the second group: a third of the epilogue runs while the matrix pipe is busy.  (Reads only -- no
-      // accumulator is redefined in this region, which is what hipcc cannot cope with)
-      auto compute = [&](auto first_tag, auto last_tag) __attribute__((always_inline)) {
-        constexpr bool LAST = decltype(last_tag)::value;
-        if constexpr (LAST) {
-          run(first_tag, ic<0>{}, ic<2>{}, ic<0>{}, std::false_type{});
-          run(first_tag, ic<2>{}, ic<NT - 2>{}, ic<(18 + SPK_FP6_DMA_EVERY - 1) / SPK_FP6_DMA_EVERY>{}, std::true_type{});
-        } else {
-          run(first_tag, ic<0>{}, ic<NT>{}, ic<0>{}, std::false_type{});
-        }
-      };
-      compute(first_tag, last_tag);
+      if (c == 0) compute(std::true_type{}); else compute(std::false_type{});
       if (SPK_FP6_DBG & 64) {
         const long long tq3 = __builtin_amdgcn_s_memtime();
         dbg_t[0] += tq1 - tq0; dbg_t[1] += tq2 - tq1; dbg_t[2] += tq3 - tq2; dbg_t[3] += 1;
       }
-      ++it;
-    };
-    // first chunk | middle chunks | last chunk, peeled: no join of differently-defined accumulator values inside a loop
-    typedef std::bool_constant<(SPK_FP6_SPLIT_LAST && NT == 6)> split_tag;
-    if (nchunks == 1) {
-      do_chunk(0, std::true_type{}, split_tag{});
-    } else {
-      do_chunk(0, std::true_type{}, std::false_type{});
-      for (int c = 1; c < nchunks - 1; ++c) do_chunk(c, std::false_type{}, std::false_type{});
-      do_chunk(nchunks - 1, std::false_type{}, split_tag{});
-    }
+    }   // chunks
 
     // The MFMAs are opaque to hipcc's hazard recognizer: an accumulator may be read 18 wait states after the (16-pass)
     // MFMA that wrote it was issued.
@@ -385,16 +315,29 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
       const int ia = k == 0 ? NT - 2 : (((NT & 1) && k == (NT + 1) / 2 - 1) ? NT - 3 : 2 * (k - 1));
       const bool paired = !((NT & 1) && k == (NT + 1) / 2 - 1);
       const int ib = paired ? ia + 1 : ia;
-      // with the split last chunk the pair (0, 1) was already read out under the MFMAs of tiles 2..5 (x01)
-      const bool pre = SPK_FP6_SPLIT_LAST && NT == 6 && ia == 0;
-      if (!pre) pin_pair(ia, ib);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        if (3 * ia + j < N_AGPR) asm volatile("" : "+a"(acc[ia][j]));
+        if (paired && 3 * ib + j < N_AGPR) asm volatile("" : "+a"(acc[ib][j]));
+      }
       float x[16];
-      if (pre) {
+      auto recombine3 = [&](const float (&pr)[3]) -> float {
+        const double s1 = fma((double)pr[0], 1024.0, (double)pr[1]);               // exact
+        const double s = fma(s1, 1024.0, (double)pr[2]);                           // exact: |s| < 2^43
+        return (float)fma(s, sc, bi);                                              // the one rounding to fp32
+      };
+      if (paired) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = x01[r];
-      } else if (paired) {
+        for (int r = 0; r < 16; ++r) {
+          float pr[3];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = pair_step(ia, ib, r);
+          for (int j = 0; j < 3; ++j) {
+            const v2u p = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ia][j][r]), __float_as_uint(acc[ib][j][r]),
+                                                           false, false);
+            pr[j] = fmaf(__uint_as_float(p[0]), 32.0f, __uint_as_float(p[1]));     // exact: |.| < 2^22
+          }
+          x[r] = recombine3(pr);
+        }
       } else {
         // the odd tile out: swapping acc[r] with acc[r + 8] of the SAME tile gives the even lane both digits of step r and
         // the odd lane those of step r + 8; each recombines 8 steps and one more swap hands both all 16 values
