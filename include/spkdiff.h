@@ -84,6 +84,30 @@ int spk_lif_train_bwd(const float* grad_spike_seq, const float* grad_v_last, con
                       float* grad_v_init, int T, long long N, float tau, float v_threshold, float v_reset, float alpha,
                       int detach_reset, spk_stream_t stream);
 
+/* Training-mode BatchNorm2d ('m' mode, batch statistics: SJ/activation_based/layer.py:458-465 -> F.batch_norm(training=True))
+ * fused with the surrogate-gradient LIF above -- one denoiser block tail of DummyModel.forward in train() mode
+ * (R/snn_model/vq_diffusion.py:163-183,199-203).  y, spike_seq, grad_* are [T,B,C,HW] fp32; gamma/beta/running_* /save_*
+ * [C]; v_init / v_out / grad_v_* [B,C,HW] (v_init NULL = reset state, v_out / running_* / grad_v_* may be NULL).
+ * running_mean / running_var are updated in place with `momentum` (unbiased variance), save_mean / save_invstd receive
+ * the batch statistics the backward needs.  ws: caller-allocated scratch of spk_bn_lif_train_ws_bytes(B, C, HW) bytes.
+ * The backward recomputes the membrane potentials from y (only y and the two statistics vectors are kept). */
+long long spk_bn_lif_train_ws_bytes(int B, int C, int HW);
+int spk_bn_lif_train_fwd(const float* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                         float momentum, float eps, const float* v_init, float* spike_seq, float* v_out, float* save_mean,
+                         float* save_invstd, void* ws, long long ws_bytes, int T, int B, int C, int HW, float tau,
+                         float v_threshold, float v_reset, spk_stream_t stream);
+int spk_bn_lif_train_bwd(const float* grad_spike_seq, const float* grad_v_last, const float* y, const float* gamma,
+                         const float* beta, const float* save_mean, const float* save_invstd, const float* v_init,
+                         float* grad_y, float* grad_gamma, float* grad_beta, float* grad_v_init, void* ws,
+                         long long ws_bytes, int T, int B, int C, int HW, float tau, float v_threshold, float v_reset,
+                         float alpha, int detach_reset, spk_stream_t stream);
+/* Masked cross-entropy of AbsorbingDiffusion._train_loss (R/snn_model/vq_diffusion.py:85-88: F.cross_entropy with
+ * ignore_index=-1, reduction='none') and its gradient in one pass.  logits / dlogits [B,K,HW] fp32; target [B,HW] fp32
+ * token ids (-1 = ignored, as x_0_ignore); coef [B] per-sample gradient factor; ce_out [B,HW] (0 where ignored).
+ * dlogits (and coef) may be NULL for the forward alone. */
+int spk_masked_ce(const float* logits, const float* target, const float* coef, float* ce_out, float* dlogits, int B, int K,
+                  int HW, spk_stream_t stream);
+
 /* ---- layout converters --------------------------------------------------------------------------------------- */
 /* chunk = C gives plain PTC [B,HW,T,C]; chunk = 32 gives the channel-chunked "CPTC" [B,C/32,HW,T,32] the MFMA
  * kernel reads (one contiguous slab per image and 32-channel K chunk). */

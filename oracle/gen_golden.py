@@ -11,7 +11,10 @@ Only data (inputs, expected outputs) is written; no reference source travels.
 
 Fixtures: F1 LIF, F2 per-layer VQ-VAE (teacher forced), F3 encode,
 F4 decode glue, F5 denoiser, F6 p_sample + RNG-order trajectory, F7 BN eval,
-F8 LIF training forward + surrogate-gradient BPTT (next-row scope).
+F8 LIF training forward + surrogate-gradient BPTT (next-row scope),
+F9 one diffusion training step (q_sample + denoiser in train() mode + reweighted-ELBO loss + backward).
+
+    python oracle/gen_golden.py f9         # only rewrite the fixtures whose file name starts with "f9"
 """
 from __future__ import annotations
 
@@ -96,6 +99,14 @@ def lif_trace(y_seq):
 def main():
     import torch
     torch.set_num_threads(8)
+    only = tuple(a.lower() for a in sys.argv[1:])
+    if only:        # everything still runs (and is checked); only the selected fixtures are rewritten
+        real_save = np.savez_compressed
+
+        def save(path, **kw):
+            if os.path.basename(path).startswith(only):
+                real_save(path, **kw)
+        np.savez_compressed = save
     vm, vd = _import_reference()
     synth = _load(os.path.join(ROOT, "spiking-diffusion_amd", "spkdiff", "synth.py"), "spk_synth")
     ref = _load(os.path.join(ROOT, "oracle", "snn_ref.py"), "spk_oracle")
@@ -362,6 +373,50 @@ def main():
                             spikes_b=pack(sb.detach())[0], spikes_shape=np.array(sa.shape), v=node.v.detach().numpy(),
                             grad_x=xr.grad.numpy(), detach_reset=det)
         print(f"F8 ok (detach_reset={det}): |grad_x| mean", float(xr.grad.abs().mean()))
+
+    # ------------------------------------------------------------------ F9 one diffusion training step
+    # AbsorbingDiffusion._train_loss (R/snn_model/vq_diffusion.py:56-101) on the reference's
+    # DummyModel in train() mode (batch-statistics BN, surrogate-gradient LIF), loss.backward().  The global CPU
+    # generator is seeded so that sample_time's randint and q_sample's rand_like are reproducible.
+    B9 = 4
+    g = torch.Generator().manual_seed(909)
+    x0 = torch.randint(0, 128, (B9, 1, 7, 7), generator=g).float()
+    den9 = vd.DummyModel(1, 128)
+    vd.functional.set_step_mode(net=den9, step_mode="m")
+    den9.load_state_dict(sdd)
+    den9.train()
+    ab9 = vd.AbsorbingDiffusion(den9, mask_id=128)
+    torch.manual_seed(909)
+    loss_ref = ab9._train_loss(x0)
+    loss_ref.backward()
+    grads_ref = {k: p.grad.clone() for k, p in den9.named_parameters()}
+    stats_ref = {k: v.clone() for k, v in den9.state_dict().items() if "running_" in k}
+    vd.functional.reset_net(den9)
+    # oracle on the same draws
+    sdo = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
+           for k, v in sdd.items()}
+    torch.manual_seed(909)
+    stats_o = {}
+    loss_o, (t9, xt9, x0i9, mask9, logits9) = ref.train_loss(x0, sdo, 128, stats_out=stats_o)
+    loss_o.backward()
+    eq(loss_ref.detach(), loss_o.detach(), "F9 loss")
+    for k, gr in grads_ref.items():
+        eq(gr, sdo[k].grad, "F9 grad " + k)
+    for k, v in stats_ref.items():
+        eq(v, stats_o[k], "F9 " + k)
+    with torch.no_grad():
+        _, spikes9 = ref.denoiser_forward_train(xt9, t9, sdd, return_layers=True)
+    keep = ("conv1.0.weight", "conv1.1.weight", "conv1.1.bias", "conv3.1.weight", "conv5.0.bias", "conv6.0.bias")
+    np.savez_compressed(
+        os.path.join(OUT, "f9_train_step.npz"), x0=x0.numpy(), t=t9.numpy(), x_t=xt9.numpy(), mask=mask9.numpy(),
+        x0_ignore=x0i9.numpy(), loss=loss_ref.detach().numpy(), logits=logits9.detach().numpy(), seed=909,
+        grad_names=np.array(list(grads_ref)), grad_norms=np.array([float(v.norm()) for v in grads_ref.values()]),
+        rates=np.array([float(s.mean()) for s in spikes9]),
+        **{"grad." + k: grads_ref[k].numpy() for k in keep},
+        **{"stat." + k: v.numpy() for k, v in stats_ref.items() if k.startswith(("conv1.", "conv5."))},
+        weights_crc=synth.state_checksum(sdd))
+    print("F9 ok: loss", float(loss_ref), "t", t9.tolist(), "masked", int(mask9.sum()), "rates",
+          [round(float(s.mean()), 4) for s in spikes9])
     print("all fixtures written to", OUT)
 
 

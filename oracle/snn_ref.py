@@ -286,6 +286,88 @@ def denoiser_forward(x, t, sd, T=16, return_layers=False):
     return logits
 
 
+# --------------------------------------------------------------------------- §8f item 2: diffusion training step
+def seq_bn_train(x_seq, sd, prefix, momentum=0.1, stats_out=None):
+    """layer.BatchNorm2d in 'm' mode, TRAINING: T folded into the batch, ``F.batch_norm(..., training=True)``
+    (SJ/activation_based/layer.py:458-465 -> torch.nn.BatchNorm2d.forward).  Batch statistics over (T*B, H, W);
+    the running statistics are updated on copies returned through ``stats_out`` (a dict), never in ``sd``."""
+    rm = sd[prefix + ".running_mean"].detach().clone()
+    rv = sd[prefix + ".running_var"].detach().clone()
+    y = seq_to_ann(x_seq, lambda z: F.batch_norm(z, rm, rv, sd[prefix + ".weight"], sd[prefix + ".bias"], True,
+                                                 momentum, BN_EPS))
+    if stats_out is not None:
+        stats_out[prefix + ".running_mean"] = rm
+        stats_out[prefix + ".running_var"] = rv
+    return y
+
+
+def denoiser_forward_train(x, t, sd, T=16, alpha=2.0, stats_out=None, return_layers=False):
+    """DummyModel.forward in train() mode, R/snn_model/vq_diffusion.py:189-208: same graph as ``denoiser_forward``
+    with batch-statistics BN and the surrogate-gradient LIF; differentiable w.r.t. the tensors of ``sd``."""
+    tt = torch.ones_like(x) * (t.unsqueeze(1).unsqueeze(2).unsqueeze(3))
+    h = torch.cat((x, tt), dim=1).unsqueeze(dim=0).repeat(T, 1, 1, 1, 1)
+    outs = []
+    for i in range(1, 6):
+        y = seq_conv2d(h, sd[f"conv{i}.0.weight"], sd[f"conv{i}.0.bias"], 1, 1)
+        y = seq_bn_train(y, sd, f"conv{i}.1", stats_out=stats_out)
+        h, _ = lif_multi_step_train(y, alpha=alpha)
+        outs.append(h)
+    x6 = seq_conv2d(torch.cat((outs[4], outs[0]), dim=2), sd["conv6.0.weight"], sd["conv6.0.bias"], 1, 1)
+    logits = torch.sum(x6, dim=0) / T
+    if return_layers:
+        return logits, outs
+    return logits
+
+
+def sample_time(b, num_timesteps):
+    """AbsorbingDiffusion.sample_time, R/snn_model/vq_diffusion.py:56-59 (global generator: one randint)."""
+    t = torch.randint(1, num_timesteps + 1, (b,)).long()
+    pt = torch.ones_like(t).float() / num_timesteps
+    return t, pt
+
+
+def q_sample(x_0, t, num_timesteps, mask_id, u=None):
+    """AbsorbingDiffusion.q_sample, R/snn_model/vq_diffusion.py:61-74: mask each token with probability t/T.
+    ``u`` (uniforms shaped like x_0) may be injected, otherwise one ``rand_like`` draw from the global generator."""
+    x_t, x_0_ignore = x_0.clone(), x_0.clone()
+    t_mask = t.reshape(x_0.shape[0], 1, 1, 1).expand(x_0.shape[0], 1, x_0.shape[2], x_0.shape[3])
+    if u is None:
+        u = torch.rand_like(x_t.float())
+    mask = u < (t_mask.float() / num_timesteps)
+    x_t[mask] = mask_id
+    x_0_ignore[torch.bitwise_not(mask)] = -1
+    return x_t, x_0_ignore, mask
+
+
+def masked_ce_loss(logits, x_0_ignore, t, num_timesteps, loss_type="reweighted_elbo"):
+    """Loss tail of AbsorbingDiffusion._train_loss, R/snn_model/vq_diffusion.py:85-101.  logits [B,K,h,w]."""
+    b, K = logits.shape[0], logits.shape[1]
+    hw = logits.shape[2] * logits.shape[3]
+    ce = F.cross_entropy(logits.reshape(b, K, hw), x_0_ignore.reshape(b, hw).long(), ignore_index=-1,
+                         reduction='none').sum(1)
+    denom = math.log(2) * x_0_ignore.shape[1:].numel()
+    if loss_type == 'elbo':
+        pt = torch.ones_like(t).float() / num_timesteps
+        loss = ce / t / pt / denom
+    elif loss_type == 'reweighted_elbo':
+        loss = (1 - (t / num_timesteps)) * ce / denom
+    else:
+        raise ValueError
+    return loss.mean()
+
+
+def train_loss(x_0, sd, mask_id, num_timesteps=None, T=16, t=None, u=None, stats_out=None):
+    """AbsorbingDiffusion._train_loss, R/snn_model/vq_diffusion.py:77-101.  RNG order: sample_time's randint,
+    then q_sample's rand_like (global generator) unless ``t`` / ``u`` are injected."""
+    if num_timesteps is None:
+        num_timesteps = x_0.shape[2] * x_0.shape[3]
+    if t is None:
+        t, _ = sample_time(x_0.size(0), num_timesteps)
+    x_t, x_0_ignore, mask = q_sample(x_0, t, num_timesteps, mask_id, u)
+    logits = denoiser_forward_train(x_t, t, sd, T, stats_out=stats_out)
+    return masked_ce_loss(logits, x_0_ignore, t, num_timesteps), (t, x_t, x_0_ignore, mask, logits)
+
+
 # --------------------------------------------------------------------------- a9
 def categorical_sample(logits, q=None):
     """``dists.Categorical(logits=l).sample()`` as torch evaluates it on CPU:

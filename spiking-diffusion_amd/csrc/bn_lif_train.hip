@@ -1,0 +1,249 @@
+// Training-mode BatchNorm2d + surrogate-gradient LIF as ONE native operator (the diffusion training
+// step).  The reference runs, per denoiser block in train() mode, layer.BatchNorm2d 'm' mode with batch statistics
+// (SJ/activation_based/layer.py:458-465 -> F.batch_norm(training=True)) followed by the LIFNode training forward
+// (SJ/activation_based/neuron.py:739-749 charge, :133-135 hard reset, surrogate.atan SJ/activation_based/surrogate.py:664-678);
+// its native contract for the neuron half is the CuPy pair LIFNodeFPTTKernel / LIFNodeBPTTKernel
+// (SJ/activation_based/auto_cuda/neuron_kernel.py:102-225,479-540).  Here both halves are fused:
+//
+//   forward   stats:    per channel sum / sum of squares over (T, B, HW) in fp64, deterministic two-stage reduction
+//             finalize: mean, biased var, invstd = 1/sqrt(var + eps); running statistics (momentum, unbiased var)
+//             apply:    z_t = fma(y_t, a, b), a = gamma invstd, b = beta - mean a;  LIF scan over T in registers -> spikes
+//   backward  B1:       recompute z_t and the membrane potentials h_t from y (nothing but y is kept from the forward),
+//                       BPTT with the ATan surrogate -> g_t = dL/dz_t (stored in grad_y), per-channel sum g, sum g zhat
+//             finalize: grad_beta = sum g, grad_gamma = sum g zhat
+//             B2:       grad_y = a (g - grad_beta / M - zhat grad_gamma / M),  zhat = (y - mean) invstd,  M = T B HW
+//
+// HBM bytes per neuron-step: forward 4 (stats) + 4 (apply read) + 4 (spikes) = 12; backward 8 + 4 (B1) + 8 + 4 (B2) = 24;
+// the unfused module sequence moves ~3x that (BN output, h_seq, their gradients).  Layout: y, spikes, gradients
+// [T][B][C][HW] fp32 (what the library convolution produces / consumes); one thread owns one neuron (b, c, hw).
+#include "spk_common.h"
+#include "../../include/spkdiff.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// block-wide sum of two doubles, result valid in thread 0
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* sh) {
+  a = wave_sum(a); b = wave_sum(b);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) { sh[w * 2] = a; sh[w * 2 + 1] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = 0.0; b = 0.0;
+    for (int i = 0; i < TPB / 64; ++i) { a += sh[i * 2]; b += sh[i * 2 + 1]; }
+  }
+}
+
+struct Geo {
+  int T, B, C, HW;
+  __device__ __forceinline__ bool locate(long long& base, long long& tstride, long long& nidx) const {
+    const int i = blockIdx.x * TPB + threadIdx.x;           // neuron of channel blockIdx.y
+    if (i >= B * HW) return false;
+    const int b = i / HW, hw = i - b * HW;
+    nidx = ((long long)b * C + blockIdx.y) * HW + hw;        // index into [B][C][HW]
+    base = nidx;
+    tstride = (long long)B * C * HW;
+    return true;
+  }
+};
+
+__global__ __launch_bounds__(TPB) void bn_stats_kernel(const float* __restrict__ y, double* __restrict__ ws, Geo g) {
+  __shared__ double sh[2 * TPB / 64];
+  long long base, ts, n;
+  double s = 0.0, q = 0.0;
+  if (g.locate(base, ts, n)) {
+    for (int t = 0; t < g.T; ++t) {
+      const double v = (double)y[base + t * ts];
+      s += v; q += v * v;
+    }
+  }
+  block_sum2(s, q, sh);
+  if (threadIdx.x == 0) {
+    double* o = ws + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+    o[0] = s; o[1] = q;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void bn_finalize_kernel(const double* __restrict__ ws, int S, int C, double M, float eps,
+                                                          float momentum, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float* __restrict__ save_mean,
+                                                          float* __restrict__ save_invstd) {
+  const int c = blockIdx.x * TPB + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int i = 0; i < S; ++i) { s += ws[((long long)c * S + i) * 2]; q += ws[((long long)c * S + i) * 2 + 1]; }
+  const double mean = s / M;
+  double var = q / M - mean * mean;
+  if (var < 0.0) var = 0.0;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) running_mean[c] = (float)((double)momentum * mean + (1.0 - (double)momentum) * (double)running_mean[c]);
+  if (running_var) {
+    const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
+    running_var[c] = (float)((double)momentum * unbiased + (1.0 - (double)momentum) * (double)running_var[c]);
+  }
+}
+
+__global__ __launch_bounds__(TPB) void bn_lif_apply_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ save_mean,
+                                                           const float* __restrict__ save_invstd, const float* __restrict__ v_init,
+                                                           float* __restrict__ spikes, float* __restrict__ v_out, Geo g,
+                                                           float tau, float v_th, float v_reset) {
+  long long base, ts, n;
+  if (!g.locate(base, ts, n)) return;
+  const int c = blockIdx.y;
+  const float a = (gamma ? gamma[c] : 1.0f) * save_invstd[c];
+  const float b = (beta ? beta[c] : 0.0f) - save_mean[c] * a;
+  float v = v_init ? v_init[n] : v_reset;
+  for (int t = 0; t < g.T; ++t) {
+    const float z = fmaf(y[base + t * ts], a, b);
+    const float h = v + (z - (v - v_reset)) / tau;
+    const float s = (h - v_th >= 0.0f) ? 1.0f : 0.0f;
+    v = (1.0f - s) * h + s * v_reset;
+    spikes[base + t * ts] = s;
+  }
+  if (v_out) v_out[n] = v;
+}
+
+template <bool DETACH>
+__global__ __launch_bounds__(TPB) void bn_lif_bwd1_kernel(const float* __restrict__ grad_s, const float* __restrict__ grad_v_last,
+                                                          const float* __restrict__ y, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ save_mean,
+                                                          const float* __restrict__ save_invstd, const float* __restrict__ v_init,
+                                                          float* __restrict__ grad_y, float* __restrict__ grad_v_init,
+                                                          double* __restrict__ ws, Geo g, float tau, float v_th, float v_reset,
+                                                          float alpha) {
+  __shared__ double sh[2 * TPB / 64];
+  long long base, ts, n;
+  double s1 = 0.0, s2 = 0.0;
+  if (g.locate(base, ts, n)) {
+    const int c = blockIdx.y;
+    const float mean = save_mean[c], invstd = save_invstd[c];
+    const float a = (gamma ? gamma[c] : 1.0f) * invstd;
+    const float b = (beta ? beta[c] : 0.0f) - mean * a;
+    const float inv_tau = 1.0f / tau, carry = 1.0f - inv_tau;
+    float yv[SPK_MAX_T], hv[SPK_MAX_T];
+    float v = v_init ? v_init[n] : v_reset;
+#pragma unroll
+    for (int t = 0; t < SPK_MAX_T; ++t) {
+      if (t < g.T) {
+        yv[t] = y[base + t * ts];
+        const float z = fmaf(yv[t], a, b);
+        const float h = v + (z - (v - v_reset)) / tau;
+        const float s = (h - v_th >= 0.0f) ? 1.0f : 0.0f;
+        v = (1.0f - s) * h + s * v_reset;
+        hv[t] = h;
+      }
+    }
+    float G = grad_v_last ? grad_v_last[n] : 0.0f;
+#pragma unroll
+    for (int t = SPK_MAX_T - 1; t >= 0; --t) {
+      if (t < g.T) {
+        const float over = hv[t] - v_th;
+        const float s = over >= 0.0f ? 1.0f : 0.0f;
+        const float ax = 1.57079632679489661923f * alpha * over;
+        const float g_s = alpha / 2.0f / (1.0f + ax * ax);
+        float dv_dh = 1.0f - s;
+        if (!DETACH) dv_dh = (v_reset - hv[t]) * g_s + dv_dh;
+        const float gh = G * dv_dh + grad_s[base + t * ts] * g_s;
+        const float gz = gh * inv_tau;
+        G = gh * carry;
+        grad_y[base + t * ts] = gz;
+        s1 += (double)gz;
+        s2 += (double)gz * (double)((yv[t] - mean) * invstd);
+      }
+    }
+    if (grad_v_init) grad_v_init[n] = G;
+  }
+  block_sum2(s1, s2, sh);
+  if (threadIdx.x == 0) {
+    double* o = ws + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+    o[0] = s1; o[1] = s2;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void bn_bwd_finalize_kernel(const double* __restrict__ ws, int S, int C,
+                                                              float* __restrict__ grad_gamma, float* __restrict__ grad_beta) {
+  const int c = blockIdx.x * TPB + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < S; ++i) { s1 += ws[((long long)c * S + i) * 2]; s2 += ws[((long long)c * S + i) * 2 + 1]; }
+  grad_beta[c] = (float)s1;
+  grad_gamma[c] = (float)s2;
+}
+
+__global__ __launch_bounds__(TPB) void bn_bwd2_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
+                                                      const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                                      const float* __restrict__ grad_gamma, const float* __restrict__ grad_beta,
+                                                      float* __restrict__ grad_y, Geo g, float inv_M) {
+  long long base, ts, n;
+  if (!g.locate(base, ts, n)) return;
+  const int c = blockIdx.y;
+  const float mean = save_mean[c], invstd = save_invstd[c];
+  const float a = (gamma ? gamma[c] : 1.0f) * invstd;
+  const float c1 = grad_beta[c] * inv_M, c2 = grad_gamma[c] * inv_M;
+  for (int t = 0; t < g.T; ++t) {
+    const float zh = (y[base + t * ts] - mean) * invstd;
+    grad_y[base + t * ts] = a * (grad_y[base + t * ts] - c1 - zh * c2);
+  }
+}
+
+inline int slices(int B, int HW) { return (B * HW + TPB - 1) / TPB; }
+
+}  // namespace
+
+extern "C" long long spk_bn_lif_train_ws_bytes(int B, int C, int HW) {
+  if (B <= 0 || C <= 0 || HW <= 0) return SPK_ERR_ARG;
+  return (long long)C * slices(B, HW) * 2 * (long long)sizeof(double);
+}
+
+extern "C" int spk_bn_lif_train_fwd(const float* y, const float* gamma, const float* beta, float* running_mean,
+                                    float* running_var, float momentum, float eps, const float* v_init, float* spike_seq,
+                                    float* v_out, float* save_mean, float* save_invstd, void* ws, long long ws_bytes, int T,
+                                    int B, int C, int HW, float tau, float v_threshold, float v_reset, hipStream_t stream) {
+  if (!y || !spike_seq || !save_mean || !save_invstd || !ws || T <= 0 || T > SPK_MAX_T || B <= 0 || C <= 0 || HW <= 0 ||
+      !(tau > 0.f) || (long long)B * HW > (1LL << 30))
+    return SPK_ERR_ARG;
+  if (ws_bytes < spk_bn_lif_train_ws_bytes(B, C, HW)) return SPK_ERR_ARG;
+  const int S = slices(B, HW);
+  const Geo g{T, B, C, HW};
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(S, C), dim3(TPB), 0, stream, y, (double*)ws, g);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + TPB - 1) / TPB), dim3(TPB), 0, stream, (const double*)ws, S, C,
+                     (double)T * B * HW, eps, momentum, running_mean, running_var, save_mean, save_invstd);
+  hipLaunchKernelGGL(bn_lif_apply_kernel, dim3(S, C), dim3(TPB), 0, stream, y, gamma, beta, save_mean, save_invstd, v_init,
+                     spike_seq, v_out, g, tau, v_threshold, v_reset);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_bn_lif_train_bwd(const float* grad_spike_seq, const float* grad_v_last, const float* y, const float* gamma,
+                                    const float* beta, const float* save_mean, const float* save_invstd, const float* v_init,
+                                    float* grad_y, float* grad_gamma, float* grad_beta, float* grad_v_init, void* ws,
+                                    long long ws_bytes, int T, int B, int C, int HW, float tau, float v_threshold,
+                                    float v_reset, float alpha, int detach_reset, hipStream_t stream) {
+  if (!grad_spike_seq || !y || !save_mean || !save_invstd || !grad_y || !grad_gamma || !grad_beta || !ws || T <= 0 ||
+      T > SPK_MAX_T || B <= 0 || C <= 0 || HW <= 0 || !(tau > 0.f) || !(alpha > 0.f) || (long long)B * HW > (1LL << 30))
+    return SPK_ERR_ARG;
+  if (ws_bytes < spk_bn_lif_train_ws_bytes(B, C, HW)) return SPK_ERR_ARG;
+  const int S = slices(B, HW);
+  const Geo g{T, B, C, HW};
+  if (detach_reset)
+    hipLaunchKernelGGL(bn_lif_bwd1_kernel<true>, dim3(S, C), dim3(TPB), 0, stream, grad_spike_seq, grad_v_last, y, gamma, beta,
+                       save_mean, save_invstd, v_init, grad_y, grad_v_init, (double*)ws, g, tau, v_threshold, v_reset, alpha);
+  else
+    hipLaunchKernelGGL(bn_lif_bwd1_kernel<false>, dim3(S, C), dim3(TPB), 0, stream, grad_spike_seq, grad_v_last, y, gamma, beta,
+                       save_mean, save_invstd, v_init, grad_y, grad_v_init, (double*)ws, g, tau, v_threshold, v_reset, alpha);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + TPB - 1) / TPB), dim3(TPB), 0, stream, (const double*)ws, S, C, grad_gamma,
+                     grad_beta);
+  hipLaunchKernelGGL(bn_bwd2_kernel, dim3(S, C), dim3(TPB), 0, stream, y, gamma, save_mean, save_invstd, grad_gamma, grad_beta,
+                     grad_y, g, (float)(1.0 / ((double)T * B * HW)));
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}

@@ -9,6 +9,8 @@ kernel), the per-step token update is one ``spk_psample_step`` launch, and ``sam
 reverse process without any host synchronisation.  Latent size and T are parameters (the reference hard-codes
 7x7 and 16: vq_diffusion.py:47-48,106,198,206).
 """
+import math
+
 import torch
 import torch.nn as nn
 
@@ -63,11 +65,47 @@ class AbsorbingDiffusion(Sampler):
         self.use_graph = True
         self._graphs = {}
 
-    def sample_time(self, *args, **kwargs):
-        raise NotImplementedError('spkdiff: AbsorbingDiffusion training (sample_time/q_sample/_train_loss) is outside '
-                                  'the inference hot path (SURVEY.md §8f)')
+    # ---- training step (R/snn_model/vq_diffusion.py:56-101,144-147) -------------------------
+    def sample_time(self, b, device):
+        t = torch.randint(1, self.num_timesteps + 1, (b,), device=device).long()
+        pt = torch.ones_like(t).float() / self.num_timesteps
+        return t, pt
 
-    q_sample = _train_loss = train_iter = sample_time
+    def q_sample(self, x_0, t):
+        """Mask each token of x_0 [B,1,h,w] with probability t/T.  Returns (x_t, x_0_ignore, mask): masked positions
+        hold ``mask_id`` in x_t, unmasked positions hold -1 (the loss's ignore index) in x_0_ignore."""
+        b = x_0.shape[0]
+        t_mask = t.reshape(b, 1, 1, 1).expand(b, 1, x_0.shape[2], x_0.shape[3])
+        mask = torch.rand_like(x_0.float()) < (t_mask.float() / self.num_timesteps)
+        x_t = torch.where(mask, torch.full_like(x_0, self.mask_id), x_0)
+        x_0_ignore = torch.where(mask, x_0, torch.full_like(x_0, -1))
+        return x_t, x_0_ignore, mask
+
+    def _loss_from_logits(self, x_0_hat_logits, x_0_ignore, t):
+        """Loss tail of _train_loss (:85-101): masked cross-entropy summed over positions, weighted per sample, in bits
+        per latent dimension, mean over the batch.  Cross-entropy and its gradient: one spk_masked_ce launch."""
+        b = x_0_hat_logits.shape[0]
+        denom = math.log(2) * x_0_ignore.shape[1:].numel()
+        if self.loss_type == 'elbo':
+            pt = torch.ones_like(t).float() / self.num_timesteps
+            coef = 1.0 / t.float() / pt / denom
+        elif self.loss_type == 'reweighted_elbo':
+            coef = (1 - (t / self.num_timesteps)).float() / denom
+        else:
+            raise ValueError
+        return ops.MaskedCEFunction.apply(x_0_hat_logits, x_0_ignore.float(), coef / b)
+
+    def _train_loss(self, x_0):
+        b, device = x_0.size(0), x_0.device
+        t, pt = self.sample_time(b, device)
+        x_t, x_0_ignore, mask = self.q_sample(x_0=x_0, t=t)
+        x_0_hat_logits = self._denoise_fn(x_t, t=t)
+        return self._loss_from_logits(x_0_hat_logits, x_0_ignore, t)
+
+    def train_iter(self, x):
+        loss = self._train_loss(x)
+        stats = {'loss': loss}
+        return stats
 
     @torch.no_grad()
     def sample(self, temp=1.0, sample_steps=None, noise=None, record=None):
@@ -244,10 +282,25 @@ class DummyModel(nn.Module):
                 return ops.den_conv3x3_counts(cnt5, conv._spk_params.get_i8(conv), conv.out_channels, T, cnt1=r1['cnt'])
             return self.conv6.run(x, IN_PTC, final='mean', in1=x1, impl=impl)['f32']
 
+    def _run_train(self, x, t):
+        """train() mode (R/snn_model/vq_diffusion.py:189-208 with batch-statistics BN and surrogate-gradient LIF): the
+        convolutions are the ROCm library operator through torch, each block tail is the native fused BN+LIF operator
+        (``FusedSequential.train_forward``).  Membrane state follows the module semantics (kept until reset_net)."""
+        T = self.n_steps
+        inp = ops.den_build_input(x.detach(), t)                      # [B,2,h,w]: token ids and step as floats
+        h = inp.unsqueeze(0).repeat(T, 1, 1, 1, 1)
+        x1 = self.conv1(h)
+        x5 = self.conv5(self.conv4(self.conv3(self.conv2(x1))))
+        x6 = self.conv6(torch.cat((x5, x1), dim=2))
+        return torch.sum(x6, dim=0) / T
+
     def forward(self, x, t) -> torch.Tensor:
         # x: b,c,h,w (token ids as floats); t: b
+        if self.training and torch.is_grad_enabled():
+            return self._run_train(x, t)
         if self.training:
-            raise NotImplementedError('spkdiff: DummyModel training is outside the inference hot path; call .eval()')
+            raise NotImplementedError('spkdiff: DummyModel in train() mode runs the differentiable training graph and '
+                                      'needs autograd enabled; call .eval() for inference')
         if not self._fused_ok():
             raise RuntimeError('spkdiff: DummyModel needs functional.set_step_mode(net, "m") and .eval()')
         return self._run(ops.den_build_input(x, t), stateful=True)

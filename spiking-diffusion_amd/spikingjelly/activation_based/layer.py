@@ -3,9 +3,16 @@
 Surface of SJ/activation_based/layer.py:125-173, :276-325, :423-465, :900-922.  They subclass the ``torch.nn``
 layers (parameters, ``state_dict`` keys and constructors are torch's), but ``forward`` runs the HIP kernels of
 ``libspkdiff.so``; in 'm' mode T is folded into the batch exactly like ``functional.seq_to_ann_forward``.
+
+Training: when a module is in train() mode with autograd enabled, the convolution and the
+stand-alone batch-norm run as the ROCm library operators through torch (MIOpen; autograd supplies their backward) --
+the same split as the reference, whose training uses cuDNN for these and a native kernel pair for the neuron.  The
+native training operators of this build are the surrogate-gradient LIF and the fused BatchNorm+LIF block tail
+(``spkdiff.ops.LIFTrainFunction`` / ``BNLIFTrainFunction``), which ``snn_model`` uses for its Conv-BN-LIF blocks.
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from spkdiff import ops
 
@@ -25,6 +32,17 @@ def _one(v, what):
 def _check_plain(m):
     if m.groups != 1 or _one(m.dilation, 'dilation') != 1 or m.padding_mode != 'zeros':
         raise NotImplementedError('spkdiff: groups/dilation/padding_mode other than the defaults are not implemented')
+
+
+def _library_path(m, x):
+    """Training with autograd: the differentiable library operator (see the module docstring).  Device tensors only --
+    there is no CPU path in either mode."""
+    if not (m.training and torch.is_grad_enabled()):
+        return False
+    if not x.is_cuda:
+        raise RuntimeError(f"spkdiff: input is on '{x.device}'; there is no CPU path (move module and tensors to a ROCm "
+                           "device)")
+    return True
 
 
 def _fold(x, step_mode, nd):
@@ -52,7 +70,10 @@ class Conv2d(nn.Conv2d, base.StepModule):
     def forward(self, x: torch.Tensor):
         _check_plain(self)
         y, prefix = _fold(x, self.step_mode, 4)
-        y = ops.conv2d(y, self.weight, self.bias, _one(self.stride, 'stride'), _one(self.padding, 'padding'))
+        if _library_path(self, y):
+            y = F.conv2d(y, self.weight, self.bias, self.stride, self.padding)
+        else:
+            y = ops.conv2d(y, self.weight, self.bias, _one(self.stride, 'stride'), _one(self.padding, 'padding'))
         return _unfold(y, prefix)
 
 
@@ -69,6 +90,9 @@ class ConvTranspose2d(nn.ConvTranspose2d, base.StepModule):
     def forward(self, x: torch.Tensor):
         _check_plain(self)
         y, prefix = _fold(x, self.step_mode, 4)
+        if _library_path(self, y):
+            return _unfold(F.conv_transpose2d(y, self.weight, self.bias, self.stride, self.padding,
+                                              self.output_padding), prefix)
         y = ops.conv_transpose2d(y, self.weight, self.bias, _one(self.stride, 'stride'), _one(self.padding, 'padding'),
                                  _one(self.output_padding, 'output_padding'))
         return _unfold(y, prefix)
@@ -97,6 +121,9 @@ class BatchNorm2d(nn.BatchNorm2d, base.StepModule):
 
     def forward(self, x: torch.Tensor):
         y, prefix = _fold(x, self.step_mode, 4)
+        if self.training and torch.is_grad_enabled() and _library_path(self, y):
+            # nn.BatchNorm2d.forward in training mode: batch statistics, running statistics and the counter updated
+            return _unfold(nn.BatchNorm2d.forward(self, y), prefix)
         a, b = self.affine_terms()
         return _unfold(ops.bn_eval(y, a, b), prefix)
 

@@ -45,6 +45,12 @@ _SIGS = {
     "spk_memout_fwd": (c_int, [P, P, P, c_int, c_longlong, P]),
     "spk_lif_train_fwd": (c_int, [P, P, P, P, P, c_int, c_longlong, c_float, c_float, c_float, P]),
     "spk_lif_train_bwd": (c_int, [P, P, P, P, P, c_int, c_longlong, c_float, c_float, c_float, c_float, c_int, P]),
+    "spk_bn_lif_train_ws_bytes": (c_longlong, [c_int, c_int, c_int]),
+    "spk_bn_lif_train_fwd": (c_int, [P, P, P, P, P, c_float, c_float, P, P, P, P, P, P, c_longlong, c_int, c_int, c_int,
+                                     c_int, c_float, c_float, c_float, P]),
+    "spk_bn_lif_train_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_longlong, c_int, c_int, c_int, c_int,
+                                     c_float, c_float, c_float, c_float, c_int, P]),
+    "spk_masked_ce": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     "spk_spikes_to_ptc": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_ptc_to_spikes": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_conv_out_size": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),

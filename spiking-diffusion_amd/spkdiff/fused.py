@@ -11,7 +11,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from spikingjelly.activation_based import layer, neuron
+from spikingjelly.activation_based import layer, neuron, surrogate
 
 from . import ops
 from .ops import IN_PTC, IN_SEQ, IN_TINV, MODE_LIF, MODE_MEAN, MODE_MEMOUT, MODE_RAW
@@ -107,8 +107,42 @@ class FusedSequential(nn.Sequential):
                     return False
         return True
 
+    def _trainable_fused(self, blocks, x):
+        """train() mode with autograd: every (conv, bn, lif) triple can run as library conv + the native fused
+        BatchNorm(batch statistics)+LIF(surrogate gradient) operator."""
+        if blocks is None or not torch.is_grad_enabled() or x.dim() != 5 or x.shape[0] > ops.MAX_T or not x.is_cuda:
+            return False
+        for conv, bn, lif in blocks:
+            if not conv.training or conv.step_mode != 'm':
+                return False
+            if lif is not None:
+                if not (lif.training and bn.training) or lif.step_mode != 'm' or bn.step_mode != 'm':
+                    return False
+                if (not isinstance(lif.surrogate_function, surrogate.ATan) or lif.v_reset is None or not lif.decay_input
+                        or lif.store_v_seq or bn.momentum is None or not bn.track_running_stats):
+                    return False
+        return True
+
+    def train_forward(self, x):
+        """[T,B,C,H,W] -> spikes [T,B,C',H',W'] (or the raw conv output of a conv-only last block), differentiable.
+        Convolution: ROCm library operator through torch; BN + LIF: ops.BNLIFTrainFunction (one native operator)."""
+        for conv, bn, lif in self._blocks():
+            x = conv(x)
+            if lif is None:
+                continue
+            v0 = lif.v if torch.is_tensor(lif.v) else None
+            if v0 is None and float(lif.v) != float(lif.v_reset):
+                v0 = torch.full_like(x[0], float(lif.v))
+            x, lif.v = ops.BNLIFTrainFunction.apply(x, bn.weight, bn.bias, v0, bn.running_mean, bn.running_var,
+                                                    bn.momentum, bn.eps, lif.tau, lif.v_threshold, lif.v_reset,
+                                                    float(lif.surrogate_function.alpha), lif.detach_reset)
+            bn.num_batches_tracked.add_(1)
+        return x
+
     def forward(self, x):
         blocks = self._blocks()
+        if self._trainable_fused(blocks, x):
+            return self.train_forward(x)
         if not self._fusable(blocks) or x.dim() != 5 or x.shape[0] > ops.MAX_T:
             for m in self:                      # layer by layer: still HIP kernels, just not fused
                 x = m(x)

@@ -140,6 +140,97 @@ class LIFTrainFunction(torch.autograd.Function):
         return gx, gv0, None, None, None, None, None
 
 
+class BNLIFTrainFunction(torch.autograd.Function):
+    """spike_seq, v_last = f(y_seq, gamma, beta, v_init): training-mode BatchNorm2d (batch statistics over T*B*H*W,
+    running statistics updated in place) fused with the surrogate-gradient LIF -- the tail of one denoiser block in
+    train() mode (SJ/activation_based/layer.py:458-465 + neuron.py:739-749,133-135).  y_seq [T,B,C,H,W] fp32.
+    Only y and the two per-channel statistics are kept for the backward, which recomputes the membrane potentials."""
+
+    @staticmethod
+    def forward(ctx, y_seq, gamma, beta, v_init, running_mean, running_var, momentum, eps, tau, v_threshold, v_reset,
+                alpha, detach_reset):
+        y = _dev(y_seq, "y_seq", torch.float32)
+        if y.dim() != 5:
+            raise ValueError(f'expected y_seq with shape [T, N, C, H, W], but got {tuple(y.shape)}')
+        T, B, C = int(y.shape[0]), int(y.shape[1]), int(y.shape[2])
+        HW = int(y.shape[3] * y.shape[4])
+        g = None if gamma is None else _dev(gamma, "gamma", torch.float32)
+        b = None if beta is None else _dev(beta, "beta", torch.float32)
+        v0 = None if v_init is None else _dev(v_init, "v", torch.float32)
+        for name, r in (("running_mean", running_mean), ("running_var", running_var)):
+            if r is not None and (not r.is_cuda or r.dtype != torch.float32 or not r.is_contiguous()):
+                raise ValueError(f"{name} must be a contiguous fp32 device tensor (updated in place)")
+        ws = torch.empty(int(lib.spk_bn_lif_train_ws_bytes(B, C, HW)), dtype=torch.uint8, device=y.device)
+        s = torch.empty_like(y)
+        v_last = torch.empty(y.shape[1:], dtype=torch.float32, device=y.device)
+        mean = torch.empty(C, dtype=torch.float32, device=y.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=y.device)
+        check(lib.spk_bn_lif_train_fwd(_p(y), _p(g), _p(b), _p(running_mean), _p(running_var), float(momentum),
+                                       float(eps), _p(v0), _p(s), _p(v_last), _p(mean), _p(invstd), _p(ws), ws.numel(),
+                                       T, B, C, HW, float(tau), float(v_threshold), float(v_reset), _stream(y)),
+              "spk_bn_lif_train_fwd")
+        ctx.save_for_backward(y, g, b, mean, invstd, v0)
+        ctx.cfg = (tau, v_threshold, v_reset, alpha, detach_reset)
+        return s, v_last
+
+    @staticmethod
+    def backward(ctx, grad_s, grad_v_last):
+        y, g, b, mean, invstd, v0 = ctx.saved_tensors
+        tau, v_threshold, v_reset, alpha, detach_reset = ctx.cfg
+        T, B, C = int(y.shape[0]), int(y.shape[1]), int(y.shape[2])
+        HW = int(y.shape[3] * y.shape[4])
+        gs = torch.zeros_like(y) if grad_s is None else _dev(grad_s, "grad_spike_seq", torch.float32)
+        gv = None if grad_v_last is None else _dev(grad_v_last, "grad_v_last", torch.float32)
+        ws = torch.empty(int(lib.spk_bn_lif_train_ws_bytes(B, C, HW)), dtype=torch.uint8, device=y.device)
+        gy = torch.empty_like(y)
+        gg = torch.empty(C, dtype=torch.float32, device=y.device)
+        gb = torch.empty(C, dtype=torch.float32, device=y.device)
+        gv0 = torch.empty(y.shape[1:], dtype=torch.float32, device=y.device) if (v0 is not None and
+                                                                                 ctx.needs_input_grad[3]) else None
+        check(lib.spk_bn_lif_train_bwd(_p(gs), _p(gv), _p(y), _p(g), _p(b), _p(mean), _p(invstd), _p(v0), _p(gy), _p(gg),
+                                       _p(gb), _p(gv0), _p(ws), ws.numel(), T, B, C, HW, float(tau), float(v_threshold),
+                                       float(v_reset), float(alpha), int(bool(detach_reset)), _stream(y)),
+              "spk_bn_lif_train_bwd")
+        return (gy, gg if g is not None else None, gb if b is not None else None, gv0) + (None,) * 9
+
+
+class MaskedCEFunction(torch.autograd.Function):
+    """loss = sum_b coef_b * sum_p ce[b, p] with ce the masked cross-entropy of R/snn_model/vq_diffusion.py:85-88
+    (ignore_index = -1).  logits [B,K,h,w] fp32, target [B,1,h,w] (or [B,h,w]) fp32 token ids, coef [B] fp32.
+    Forward and gradient come from one spk_masked_ce launch; the weighted sum over [B, hw] is a tiny torch reduction."""
+
+    @staticmethod
+    def forward(ctx, logits, target, coef):
+        lg = _dev(logits, "logits", torch.float32)
+        B, K = int(lg.shape[0]), int(lg.shape[1])
+        HW = lg[0, 0].numel()
+        tg = _dev(target, "target", torch.float32)
+        cf = _dev(coef, "coef", torch.float32)
+        if tg.numel() != B * HW or cf.numel() != B:
+            raise ValueError("target must have B*h*w entries and coef B entries")
+        ce = torch.empty((B, HW), dtype=torch.float32, device=lg.device)
+        dl = torch.empty_like(lg) if ctx.needs_input_grad[0] else None
+        check(lib.spk_masked_ce(_p(lg), _p(tg), _p(cf), _p(ce), _p(dl), B, K, HW, _stream(lg)), "spk_masked_ce")
+        ctx.dl = dl
+        return (ce.sum(1) * cf).sum()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        dl, ctx.dl = ctx.dl, None
+        return (None if dl is None else dl * grad_out), None, None
+
+
+def masked_ce(logits, target):
+    """Per-position masked cross-entropy [B, hw] (no gradient): the forward half of spk_masked_ce."""
+    lg = _dev(logits, "logits", torch.float32)
+    B, K = int(lg.shape[0]), int(lg.shape[1])
+    HW = lg[0, 0].numel()
+    tg = _dev(target, "target", torch.float32)
+    ce = torch.empty((B, HW), dtype=torch.float32, device=lg.device)
+    check(lib.spk_masked_ce(_p(lg), _p(tg), None, _p(ce), None, B, K, HW, _stream(lg)), "spk_masked_ce")
+    return ce
+
+
 def bn_prepare(gamma, beta, mean, var, eps):
     mean = _dev(mean, "running_mean", torch.float32)
     var = _dev(var, "running_var", torch.float32)

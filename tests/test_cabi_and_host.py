@@ -112,8 +112,25 @@ def test_no_cpu_fallback_and_training_branches_raise():
     d.eval()
     with pytest.raises(RuntimeError):
         AbsorbingDiffusion(d, 128).sample(sample_steps=2)
-    with pytest.raises(NotImplementedError):
+    d.train()                                     # the training graph has no CPU path either
+    with pytest.raises(RuntimeError, match="CPU"):
         AbsorbingDiffusion(d, 128).train_iter(torch.zeros(2, 1, 7, 7))
+
+
+def test_training_noise_follows_the_reference_draw_order():
+    """sample_time / q_sample (R/snn_model/vq_diffusion.py:56-74) are host logic over torch's generator: under the
+    fixture's torch.manual_seed they reproduce the reference's t, x_t, x_0_ignore and mask exactly (fixture F9)."""
+    import numpy as np
+    from snn_model.vq_diffusion import DummyModel, AbsorbingDiffusion
+    d = np.load(os.path.join(ROOT, "tests", "golden", "f9_train_step.npz"))
+    ab = AbsorbingDiffusion(DummyModel(1, 128), mask_id=128)
+    x0 = torch.from_numpy(d["x0"])
+    torch.manual_seed(int(d["seed"]))
+    t, pt = ab.sample_time(x0.shape[0], x0.device)
+    x_t, x0_ignore, mask = ab.q_sample(x_0=x0, t=t)
+    assert torch.equal(t, torch.from_numpy(d["t"])) and abs(float(pt[0]) - 1 / 49) < 1e-8
+    assert torch.equal(x_t, torch.from_numpy(d["x_t"])) and torch.equal(mask, torch.from_numpy(d["mask"]))
+    assert torch.equal(x0_ignore, torch.from_numpy(d["x0_ignore"]))
 
 
 def test_oracle_is_not_imported_by_the_product():

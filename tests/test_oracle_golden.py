@@ -61,6 +61,35 @@ def test_f8_lif_training_forward_and_bptt(golden_dir, det):
     assert torch.equal(x.grad, torch.from_numpy(d["grad_x"]))
 
 
+def test_f9_diffusion_train_step(golden_dir):
+    """one AbsorbingDiffusion._train_loss + backward of the reference (DummyModel in train() mode,
+    batch-statistics BN, surrogate-gradient LIF) against the oracle's restatement under the same torch.manual_seed:
+    the RNG order (randint, then rand_like), x_t / mask, the loss, every recorded gradient and the updated running
+    statistics are bit-identical."""
+    d = load(golden_dir, "f9_train_step.npz")
+    sdd = synth.synth_denoiser_state(synth.MNIST)
+    assert str(d["weights_crc"]) == synth.state_checksum(sdd)
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
+          for k, v in sdd.items()}
+    x0 = torch.from_numpy(d["x0"])
+    torch.manual_seed(int(d["seed"]))
+    stats = {}
+    loss, (t, x_t, x0_ignore, mask, logits) = ref.train_loss(x0, sd, 128, stats_out=stats)
+    loss.backward()
+    assert torch.equal(t, torch.from_numpy(d["t"])) and torch.equal(x_t, torch.from_numpy(d["x_t"]))
+    assert torch.equal(mask, torch.from_numpy(d["mask"])) and torch.equal(x0_ignore, torch.from_numpy(d["x0_ignore"]))
+    assert torch.equal(loss.detach(), torch.from_numpy(d["loss"]))
+    assert torch.equal(logits.detach(), torch.from_numpy(d["logits"]))
+    for k in d.files:
+        if k.startswith("grad."):
+            assert torch.equal(sd[k[5:]].grad, torch.from_numpy(d[k])), k
+        if k.startswith("stat."):
+            assert torch.equal(stats[k[5:]], torch.from_numpy(d[k])), k
+    norms = dict(zip(d["grad_names"].tolist(), d["grad_norms"].tolist()))
+    for k, n in norms.items():
+        assert abs(float(sd[k].grad.norm()) - n) <= 1e-6 * max(1.0, n), k
+
+
 def test_memout_coef():
     # SURVEY §8 a4: coef = 0.8 ** arange(15..0) fp32, shape (16,1,1,1,1)
     c = ref.memout_coef(16)
