@@ -86,8 +86,9 @@ int spk_lif_train_bwd(const float* grad_spike_seq, const float* grad_v_last, con
 
 /* Training-mode BatchNorm2d ('m' mode, batch statistics: SJ/activation_based/layer.py:458-465 -> F.batch_norm(training=True))
  * fused with the surrogate-gradient LIF above -- one denoiser block tail of DummyModel.forward in train() mode
- * (R/snn_model/vq_diffusion.py:163-183,199-203).  y, spike_seq, grad_* are [T,B,C,HW] fp32; gamma/beta/running_* /save_*
- * [C]; v_init / v_out / grad_v_* [B,C,HW] (v_init NULL = reset state, v_out / running_* / grad_v_* may be NULL).
+ * (R/snn_model/vq_diffusion.py:163-183,199-203).  CHANNELS-LAST memory: y, spike_seq, grad_* are [T][B][HW][C] fp32
+ * (what the library's NHWC convolutions read and write), v_init / v_out / grad_v_* [B][HW][C]; gamma/beta/running_* /
+ * save_* [C]  (v_init NULL = reset state, v_out / running_* / grad_v_* may be NULL).
  * running_mean / running_var are updated in place with `momentum` (unbiased variance), save_mean / save_invstd receive
  * the batch statistics the backward needs.  ws: caller-allocated scratch of spk_bn_lif_train_ws_bytes(B, C, HW) bytes.
  * The backward recomputes the membrane potentials from y (only y and the two statistics vectors are kept). */

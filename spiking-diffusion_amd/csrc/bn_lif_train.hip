@@ -14,14 +14,59 @@
 //             B2:       grad_y = a (g - grad_beta / M - zhat grad_gamma / M),  zhat = (y - mean) invstd,  M = T B HW
 //
 // HBM bytes per neuron-step: forward 4 (stats) + 4 (apply read) + 4 (spikes) = 12; backward 8 + 4 (B1) + 8 + 4 (B2) = 24;
-// the unfused module sequence moves ~3x that (BN output, h_seq, their gradients).  Layout: y, spikes, gradients
-// [T][B][C][HW] fp32 (what the library convolution produces / consumes); one thread owns one neuron (b, c, hw).
+// the unfused module sequence moves ~3x that (BN output, h_seq, their gradients).
+//
+// Layout: channels-last, [T][B][HW][C] fp32 for y, spikes and gradients, [B][HW][C] for the membrane state -- the
+// layout the library's NHWC convolution kernels read and write without transposes, and the one in which a per-channel
+// reduction is coalesced: a lane owns one channel, a wave reads 64 consecutive channels (256 B) of one (b, hw) row, walks
+// its rows, and keeps T steps of one neuron in registers.
 #include "spk_common.h"
 #include "../../include/spkdiff.h"
 
 namespace {
 
-constexpr int TPB = 256;
+constexpr int TPB = 256;          // 4 waves: 64 channels x 4 row phases
+constexpr int NW = TPB / 64;
+
+struct Geo {
+  int T, R, C;                    // time steps, rows (B * HW) per step, channels
+  int S;                          // row slices (gridDim.y); a wave walks rows  (blockIdx.y * NW + wave) + k * NW * S
+};
+
+// per-(slice, channel) partial of two doubles: waves of a block are reduced in LDS in a fixed order
+__device__ __forceinline__ void store_partials(double a, double b, double* __restrict__ ws, const Geo& g, int c) {
+  __shared__ double sh[NW][64][2];
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  sh[w][l][0] = a; sh[w][l][1] = b;
+  __syncthreads();
+  if (w == 0 && c < g.C) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { s0 += sh[i][l][0]; s1 += sh[i][l][1]; }
+    double* o = ws + ((long long)blockIdx.y * g.C + c) * 2;
+    o[0] = s0; o[1] = s1;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void bn_stats_kernel(const float* __restrict__ y, double* __restrict__ ws, Geo g) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const long long ts = (long long)g.R * g.C;
+  double s = 0.0, q = 0.0;
+  if (c < g.C) {
+    for (int r = blockIdx.y * NW + (threadIdx.x >> 6); r < g.R; r += NW * g.S) {
+      const float* p = y + (long long)r * g.C + c;
+      float yv[SPK_MAX_T];
+#pragma unroll
+      for (int t = 0; t < SPK_MAX_T; ++t) yv[t] = t < g.T ? p[t * ts] : 0.0f;
+#pragma unroll
+      for (int t = 0; t < SPK_MAX_T; ++t) {
+        const double v = (double)yv[t];
+        s += v; q += v * v;
+      }
+    }
+  }
+  store_partials(s, q, ws, g, c);
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -29,56 +74,22 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// block-wide sum of two doubles, result valid in thread 0
-__device__ __forceinline__ void block_sum2(double& a, double& b, double* sh) {
+// one wave per channel: lanes stride over the S slice partials (fixed order -> deterministic), shuffle tree, lane 0 writes
+__device__ __forceinline__ void reduce_slices(const double* __restrict__ ws, int S, int C, int c, double& a, double& b) {
+  a = 0.0; b = 0.0;
+  for (int i = threadIdx.x & 63; i < S; i += 64) { a += ws[((long long)i * C + c) * 2]; b += ws[((long long)i * C + c) * 2 + 1]; }
   a = wave_sum(a); b = wave_sum(b);
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  if (l == 0) { sh[w * 2] = a; sh[w * 2 + 1] = b; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    a = 0.0; b = 0.0;
-    for (int i = 0; i < TPB / 64; ++i) { a += sh[i * 2]; b += sh[i * 2 + 1]; }
-  }
-}
-
-struct Geo {
-  int T, B, C, HW;
-  __device__ __forceinline__ bool locate(long long& base, long long& tstride, long long& nidx) const {
-    const int i = blockIdx.x * TPB + threadIdx.x;           // neuron of channel blockIdx.y
-    if (i >= B * HW) return false;
-    const int b = i / HW, hw = i - b * HW;
-    nidx = ((long long)b * C + blockIdx.y) * HW + hw;        // index into [B][C][HW]
-    base = nidx;
-    tstride = (long long)B * C * HW;
-    return true;
-  }
-};
-
-__global__ __launch_bounds__(TPB) void bn_stats_kernel(const float* __restrict__ y, double* __restrict__ ws, Geo g) {
-  __shared__ double sh[2 * TPB / 64];
-  long long base, ts, n;
-  double s = 0.0, q = 0.0;
-  if (g.locate(base, ts, n)) {
-    for (int t = 0; t < g.T; ++t) {
-      const double v = (double)y[base + t * ts];
-      s += v; q += v * v;
-    }
-  }
-  block_sum2(s, q, sh);
-  if (threadIdx.x == 0) {
-    double* o = ws + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 2;
-    o[0] = s; o[1] = q;
-  }
 }
 
 __global__ __launch_bounds__(TPB) void bn_finalize_kernel(const double* __restrict__ ws, int S, int C, double M, float eps,
                                                           float momentum, float* __restrict__ running_mean,
                                                           float* __restrict__ running_var, float* __restrict__ save_mean,
                                                           float* __restrict__ save_invstd) {
-  const int c = blockIdx.x * TPB + threadIdx.x;
+  const int c = blockIdx.x * NW + (threadIdx.x >> 6);
   if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int i = 0; i < S; ++i) { s += ws[((long long)c * S + i) * 2]; q += ws[((long long)c * S + i) * 2 + 1]; }
+  double s, q;
+  reduce_slices(ws, S, C, c, s, q);
+  if ((threadIdx.x & 63) != 0) return;
   const double mean = s / M;
   double var = q / M - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -96,20 +107,29 @@ __global__ __launch_bounds__(TPB) void bn_lif_apply_kernel(const float* __restri
                                                            const float* __restrict__ save_invstd, const float* __restrict__ v_init,
                                                            float* __restrict__ spikes, float* __restrict__ v_out, Geo g,
                                                            float tau, float v_th, float v_reset) {
-  long long base, ts, n;
-  if (!g.locate(base, ts, n)) return;
-  const int c = blockIdx.y;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  if (c >= g.C) return;
+  const long long ts = (long long)g.R * g.C;
   const float a = (gamma ? gamma[c] : 1.0f) * save_invstd[c];
   const float b = (beta ? beta[c] : 0.0f) - save_mean[c] * a;
-  float v = v_init ? v_init[n] : v_reset;
-  for (int t = 0; t < g.T; ++t) {
-    const float z = fmaf(y[base + t * ts], a, b);
-    const float h = v + (z - (v - v_reset)) / tau;
-    const float s = (h - v_th >= 0.0f) ? 1.0f : 0.0f;
-    v = (1.0f - s) * h + s * v_reset;
-    spikes[base + t * ts] = s;
+  for (int r = blockIdx.y * NW + (threadIdx.x >> 6); r < g.R; r += NW * g.S) {
+    const long long n = (long long)r * g.C + c;
+    float v = v_init ? v_init[n] : v_reset;
+    float yv[SPK_MAX_T];
+#pragma unroll
+    for (int t = 0; t < SPK_MAX_T; ++t) yv[t] = t < g.T ? y[n + t * ts] : 0.0f;
+#pragma unroll
+    for (int t = 0; t < SPK_MAX_T; ++t) {
+      if (t < g.T) {
+        const float z = fmaf(yv[t], a, b);
+        const float h = v + (z - (v - v_reset)) / tau;
+        const float s = (h - v_th >= 0.0f) ? 1.0f : 0.0f;
+        v = (1.0f - s) * h + s * v_reset;
+        spikes[n + t * ts] = s;
+      }
+    }
+    if (v_out) v_out[n] = v;
   }
-  if (v_out) v_out[n] = v;
 }
 
 template <bool DETACH>
@@ -120,61 +140,66 @@ __global__ __launch_bounds__(TPB) void bn_lif_bwd1_kernel(const float* __restric
                                                           float* __restrict__ grad_y, float* __restrict__ grad_v_init,
                                                           double* __restrict__ ws, Geo g, float tau, float v_th, float v_reset,
                                                           float alpha) {
-  __shared__ double sh[2 * TPB / 64];
-  long long base, ts, n;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const long long ts = (long long)g.R * g.C;
   double s1 = 0.0, s2 = 0.0;
-  if (g.locate(base, ts, n)) {
-    const int c = blockIdx.y;
+  if (c < g.C) {
     const float mean = save_mean[c], invstd = save_invstd[c];
     const float a = (gamma ? gamma[c] : 1.0f) * invstd;
     const float b = (beta ? beta[c] : 0.0f) - mean * a;
     const float inv_tau = 1.0f / tau, carry = 1.0f - inv_tau;
-    float yv[SPK_MAX_T], hv[SPK_MAX_T];
-    float v = v_init ? v_init[n] : v_reset;
+    for (int r = blockIdx.y * NW + (threadIdx.x >> 6); r < g.R; r += NW * g.S) {
+      const long long n = (long long)r * g.C + c;
+      float yv[SPK_MAX_T], hv[SPK_MAX_T], gsv[SPK_MAX_T];
+      float v = v_init ? v_init[n] : v_reset;
 #pragma unroll
-    for (int t = 0; t < SPK_MAX_T; ++t) {
-      if (t < g.T) {
-        yv[t] = y[base + t * ts];
-        const float z = fmaf(yv[t], a, b);
-        const float h = v + (z - (v - v_reset)) / tau;
-        const float s = (h - v_th >= 0.0f) ? 1.0f : 0.0f;
-        v = (1.0f - s) * h + s * v_reset;
-        hv[t] = h;
+      for (int t = 0; t < SPK_MAX_T; ++t) {
+        if (t < g.T) {
+          yv[t] = y[n + t * ts];
+          gsv[t] = grad_s[n + t * ts];
+        }
       }
-    }
-    float G = grad_v_last ? grad_v_last[n] : 0.0f;
 #pragma unroll
-    for (int t = SPK_MAX_T - 1; t >= 0; --t) {
-      if (t < g.T) {
-        const float over = hv[t] - v_th;
-        const float s = over >= 0.0f ? 1.0f : 0.0f;
-        const float ax = 1.57079632679489661923f * alpha * over;
-        const float g_s = alpha / 2.0f / (1.0f + ax * ax);
-        float dv_dh = 1.0f - s;
-        if (!DETACH) dv_dh = (v_reset - hv[t]) * g_s + dv_dh;
-        const float gh = G * dv_dh + grad_s[base + t * ts] * g_s;
-        const float gz = gh * inv_tau;
-        G = gh * carry;
-        grad_y[base + t * ts] = gz;
-        s1 += (double)gz;
-        s2 += (double)gz * (double)((yv[t] - mean) * invstd);
+      for (int t = 0; t < SPK_MAX_T; ++t) {
+        if (t < g.T) {
+          const float z = fmaf(yv[t], a, b);
+          const float h = v + (z - (v - v_reset)) / tau;
+          const float s = (h - v_th >= 0.0f) ? 1.0f : 0.0f;
+          v = (1.0f - s) * h + s * v_reset;
+          hv[t] = h;
+        }
       }
+      float G = grad_v_last ? grad_v_last[n] : 0.0f;
+#pragma unroll
+      for (int t = SPK_MAX_T - 1; t >= 0; --t) {
+        if (t < g.T) {
+          const float over = hv[t] - v_th;
+          const float s = over >= 0.0f ? 1.0f : 0.0f;
+          const float ax = 1.57079632679489661923f * alpha * over;
+          const float g_s = alpha / 2.0f / (1.0f + ax * ax);
+          float dv_dh = 1.0f - s;
+          if (!DETACH) dv_dh = (v_reset - hv[t]) * g_s + dv_dh;
+          const float gh = G * dv_dh + gsv[t] * g_s;
+          const float gz = gh * inv_tau;
+          G = gh * carry;
+          grad_y[n + t * ts] = gz;
+          s1 += (double)gz;
+          s2 += (double)gz * (double)((yv[t] - mean) * invstd);
+        }
+      }
+      if (grad_v_init) grad_v_init[n] = G;
     }
-    if (grad_v_init) grad_v_init[n] = G;
   }
-  block_sum2(s1, s2, sh);
-  if (threadIdx.x == 0) {
-    double* o = ws + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 2;
-    o[0] = s1; o[1] = s2;
-  }
+  store_partials(s1, s2, ws, g, c);
 }
 
 __global__ __launch_bounds__(TPB) void bn_bwd_finalize_kernel(const double* __restrict__ ws, int S, int C,
                                                               float* __restrict__ grad_gamma, float* __restrict__ grad_beta) {
-  const int c = blockIdx.x * TPB + threadIdx.x;
+  const int c = blockIdx.x * NW + (threadIdx.x >> 6);
   if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int i = 0; i < S; ++i) { s1 += ws[((long long)c * S + i) * 2]; s2 += ws[((long long)c * S + i) * 2 + 1]; }
+  double s1, s2;
+  reduce_slices(ws, S, C, c, s1, s2);
+  if ((threadIdx.x & 63) != 0) return;
   grad_beta[c] = (float)s1;
   grad_gamma[c] = (float)s2;
 }
@@ -183,25 +208,44 @@ __global__ __launch_bounds__(TPB) void bn_bwd2_kernel(const float* __restrict__ 
                                                       const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                                       const float* __restrict__ grad_gamma, const float* __restrict__ grad_beta,
                                                       float* __restrict__ grad_y, Geo g, float inv_M) {
-  long long base, ts, n;
-  if (!g.locate(base, ts, n)) return;
-  const int c = blockIdx.y;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  if (c >= g.C) return;
+  const long long ts = (long long)g.R * g.C;
   const float mean = save_mean[c], invstd = save_invstd[c];
   const float a = (gamma ? gamma[c] : 1.0f) * invstd;
   const float c1 = grad_beta[c] * inv_M, c2 = grad_gamma[c] * inv_M;
-  for (int t = 0; t < g.T; ++t) {
-    const float zh = (y[base + t * ts] - mean) * invstd;
-    grad_y[base + t * ts] = a * (grad_y[base + t * ts] - c1 - zh * c2);
+  for (int r = blockIdx.y * NW + (threadIdx.x >> 6); r < g.R; r += NW * g.S) {
+    const long long n = (long long)r * g.C + c;
+    float yv[SPK_MAX_T], gv[SPK_MAX_T];
+#pragma unroll
+    for (int t = 0; t < SPK_MAX_T; ++t) {
+      yv[t] = t < g.T ? y[n + t * ts] : 0.0f;
+      gv[t] = t < g.T ? grad_y[n + t * ts] : 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < SPK_MAX_T; ++t) {
+      if (t < g.T) {
+        const float zh = (yv[t] - mean) * invstd;
+        grad_y[n + t * ts] = a * (gv[t] - c1 - zh * c2);
+      }
+    }
   }
 }
 
-inline int slices(int B, int HW) { return (B * HW + TPB - 1) / TPB; }
+// row slices: enough waves to fill 256 CUs several times over, never more than one row per wave
+inline int slices(int R, int C) {
+  const int groups = (C + 63) / 64;
+  int s = 8192 / (groups * NW);
+  const int cap = (R + NW - 1) / NW;
+  if (s > cap) s = cap;
+  return s < 1 ? 1 : s;
+}
 
 }  // namespace
 
 extern "C" long long spk_bn_lif_train_ws_bytes(int B, int C, int HW) {
-  if (B <= 0 || C <= 0 || HW <= 0) return SPK_ERR_ARG;
-  return (long long)C * slices(B, HW) * 2 * (long long)sizeof(double);
+  if (B <= 0 || C <= 0 || HW <= 0 || (long long)B * HW > (1LL << 30)) return SPK_ERR_ARG;
+  return (long long)C * slices(B * HW, C) * 2 * (long long)sizeof(double);
 }
 
 extern "C" int spk_bn_lif_train_fwd(const float* y, const float* gamma, const float* beta, float* running_mean,
@@ -212,12 +256,13 @@ extern "C" int spk_bn_lif_train_fwd(const float* y, const float* gamma, const fl
       !(tau > 0.f) || (long long)B * HW > (1LL << 30))
     return SPK_ERR_ARG;
   if (ws_bytes < spk_bn_lif_train_ws_bytes(B, C, HW)) return SPK_ERR_ARG;
-  const int S = slices(B, HW);
-  const Geo g{T, B, C, HW};
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(S, C), dim3(TPB), 0, stream, y, (double*)ws, g);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + TPB - 1) / TPB), dim3(TPB), 0, stream, (const double*)ws, S, C,
+  const int S = slices(B * HW, C);
+  const Geo g{T, B * HW, C, S};
+  const dim3 grid((C + 63) / 64, S);
+  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(TPB), 0, stream, y, (double*)ws, g);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + NW - 1) / NW), dim3(TPB), 0, stream, (const double*)ws, S, C,
                      (double)T * B * HW, eps, momentum, running_mean, running_var, save_mean, save_invstd);
-  hipLaunchKernelGGL(bn_lif_apply_kernel, dim3(S, C), dim3(TPB), 0, stream, y, gamma, beta, save_mean, save_invstd, v_init,
+  hipLaunchKernelGGL(bn_lif_apply_kernel, grid, dim3(TPB), 0, stream, y, gamma, beta, save_mean, save_invstd, v_init,
                      spike_seq, v_out, g, tau, v_threshold, v_reset);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
@@ -232,17 +277,18 @@ extern "C" int spk_bn_lif_train_bwd(const float* grad_spike_seq, const float* gr
       T > SPK_MAX_T || B <= 0 || C <= 0 || HW <= 0 || !(tau > 0.f) || !(alpha > 0.f) || (long long)B * HW > (1LL << 30))
     return SPK_ERR_ARG;
   if (ws_bytes < spk_bn_lif_train_ws_bytes(B, C, HW)) return SPK_ERR_ARG;
-  const int S = slices(B, HW);
-  const Geo g{T, B, C, HW};
+  const int S = slices(B * HW, C);
+  const Geo g{T, B * HW, C, S};
+  const dim3 grid((C + 63) / 64, S);
   if (detach_reset)
-    hipLaunchKernelGGL(bn_lif_bwd1_kernel<true>, dim3(S, C), dim3(TPB), 0, stream, grad_spike_seq, grad_v_last, y, gamma, beta,
+    hipLaunchKernelGGL(bn_lif_bwd1_kernel<true>, grid, dim3(TPB), 0, stream, grad_spike_seq, grad_v_last, y, gamma, beta,
                        save_mean, save_invstd, v_init, grad_y, grad_v_init, (double*)ws, g, tau, v_threshold, v_reset, alpha);
   else
-    hipLaunchKernelGGL(bn_lif_bwd1_kernel<false>, dim3(S, C), dim3(TPB), 0, stream, grad_spike_seq, grad_v_last, y, gamma, beta,
+    hipLaunchKernelGGL(bn_lif_bwd1_kernel<false>, grid, dim3(TPB), 0, stream, grad_spike_seq, grad_v_last, y, gamma, beta,
                        save_mean, save_invstd, v_init, grad_y, grad_v_init, (double*)ws, g, tau, v_threshold, v_reset, alpha);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + TPB - 1) / TPB), dim3(TPB), 0, stream, (const double*)ws, S, C, grad_gamma,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + NW - 1) / NW), dim3(TPB), 0, stream, (const double*)ws, S, C, grad_gamma,
                      grad_beta);
-  hipLaunchKernelGGL(bn_bwd2_kernel, dim3(S, C), dim3(TPB), 0, stream, y, gamma, save_mean, save_invstd, grad_gamma, grad_beta,
+  hipLaunchKernelGGL(bn_bwd2_kernel, grid, dim3(TPB), 0, stream, y, gamma, save_mean, save_invstd, grad_gamma, grad_beta,
                      grad_y, g, (float)(1.0 / ((double)T * B * HW)));
   SPK_LAUNCH_CHECK();
   return SPK_OK;

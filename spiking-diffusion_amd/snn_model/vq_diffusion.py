@@ -291,7 +291,13 @@ class DummyModel(nn.Module):
         h = inp.unsqueeze(0).repeat(T, 1, 1, 1, 1)
         x1 = self.conv1(h)
         x5 = self.conv5(self.conv4(self.conv3(self.conv2(x1))))
-        x6 = self.conv6(torch.cat((x5, x1), dim=2))
+        if x1.permute(0, 1, 3, 4, 2).is_contiguous() and x5.permute(0, 1, 3, 4, 2).is_contiguous():
+            # the fused block tails hand over channels-last spikes: concatenate as 4-D so that the layout survives
+            cat = torch.cat((x5.flatten(0, 1), x1.flatten(0, 1)), dim=1)
+            cat = cat.view((T, x1.shape[1]) + tuple(cat.shape[1:]))
+        else:
+            cat = torch.cat((x5, x1), dim=2)
+        x6 = self.conv6(cat)
         return torch.sum(x6, dim=0) / T
 
     def forward(self, x, t) -> torch.Tensor:

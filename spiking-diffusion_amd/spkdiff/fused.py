@@ -127,6 +127,11 @@ class FusedSequential(nn.Sequential):
         """[T,B,C,H,W] -> spikes [T,B,C',H',W'] (or the raw conv output of a conv-only last block), differentiable.
         Convolution: ROCm library operator through torch; BN + LIF: ops.BNLIFTrainFunction (one native operator)."""
         for conv, bn, lif in self._blocks():
+            w = conv.weight
+            if w.dim() == 4 and not w.is_contiguous(memory_format=torch.channels_last):
+                # keep the parameter itself channels-last while training: the library's NHWC kernels then read it (and
+                # write its gradient) without a per-call layout copy; values, shape and state_dict keys are unchanged
+                w.data = w.data.contiguous(memory_format=torch.channels_last)
             x = conv(x)
             if lif is None:
                 continue

@@ -140,35 +140,65 @@ class LIFTrainFunction(torch.autograd.Function):
         return gx, gv0, None, None, None, None, None
 
 
+def _cl5(x, name):
+    """[T,B,C,H,W] fp32 device tensor -> the same values with channels-last memory ([T][B][H][W][C]); no copy if it
+    already is (the output of a channels-last library convolution viewed as [T,B,...])."""
+    if not x.is_cuda:
+        raise RuntimeError(f"spkdiff: {name} is on '{x.device}'; there is no CPU path")
+    if x.dtype != torch.float32:
+        raise NotImplementedError(f"spkdiff: {name} must be float32, got {x.dtype}")
+    if x.permute(0, 1, 3, 4, 2).is_contiguous():
+        return x
+    return x.flatten(0, 1).contiguous(memory_format=torch.channels_last).view(x.shape)
+
+
+def _cl4(x, name):
+    if x is None:
+        return None
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise RuntimeError(f"spkdiff: {name} must be a float32 device tensor")
+    return x if x.permute(0, 2, 3, 1).is_contiguous() else x.contiguous(memory_format=torch.channels_last)
+
+
+def _empty_cl(shape, device):
+    """Uninitialised fp32 [..., C, H, W] tensor whose memory is [...][H][W][C]."""
+    perm = tuple(range(len(shape) - 3)) + (len(shape) - 2, len(shape) - 1, len(shape) - 3)
+    inv = tuple(range(len(shape) - 3)) + (len(shape) - 1, len(shape) - 3, len(shape) - 2)
+    return torch.empty(tuple(shape[i] for i in perm), dtype=torch.float32, device=device).permute(inv)
+
+
 class BNLIFTrainFunction(torch.autograd.Function):
     """spike_seq, v_last = f(y_seq, gamma, beta, v_init): training-mode BatchNorm2d (batch statistics over T*B*H*W,
     running statistics updated in place) fused with the surrogate-gradient LIF -- the tail of one denoiser block in
     train() mode (SJ/activation_based/layer.py:458-465 + neuron.py:739-749,133-135).  y_seq [T,B,C,H,W] fp32.
-    Only y and the two per-channel statistics are kept for the backward, which recomputes the membrane potentials."""
+    Only y and the two per-channel statistics are kept for the backward, which recomputes the membrane potentials.
+    The kernels work on channels-last memory ([T][B][H][W][C]): inputs in another layout are converted, outputs and
+    gradients are returned channels-last (what the library's NHWC convolutions consume without a transpose)."""
 
     @staticmethod
     def forward(ctx, y_seq, gamma, beta, v_init, running_mean, running_var, momentum, eps, tau, v_threshold, v_reset,
                 alpha, detach_reset):
-        y = _dev(y_seq, "y_seq", torch.float32)
-        if y.dim() != 5:
-            raise ValueError(f'expected y_seq with shape [T, N, C, H, W], but got {tuple(y.shape)}')
+        if y_seq.dim() != 5:
+            raise ValueError(f'expected y_seq with shape [T, N, C, H, W], but got {tuple(y_seq.shape)}')
+        y = _cl5(y_seq, "y_seq")
         T, B, C = int(y.shape[0]), int(y.shape[1]), int(y.shape[2])
         HW = int(y.shape[3] * y.shape[4])
         g = None if gamma is None else _dev(gamma, "gamma", torch.float32)
         b = None if beta is None else _dev(beta, "beta", torch.float32)
-        v0 = None if v_init is None else _dev(v_init, "v", torch.float32)
+        v0 = _cl4(v_init, "v")
         for name, r in (("running_mean", running_mean), ("running_var", running_var)):
             if r is not None and (not r.is_cuda or r.dtype != torch.float32 or not r.is_contiguous()):
                 raise ValueError(f"{name} must be a contiguous fp32 device tensor (updated in place)")
         ws = torch.empty(int(lib.spk_bn_lif_train_ws_bytes(B, C, HW)), dtype=torch.uint8, device=y.device)
-        s = torch.empty_like(y)
-        v_last = torch.empty(y.shape[1:], dtype=torch.float32, device=y.device)
+        s = _empty_cl(y.shape, y.device)
+        v_last = _empty_cl(y.shape[1:], y.device)
         mean = torch.empty(C, dtype=torch.float32, device=y.device)
         invstd = torch.empty(C, dtype=torch.float32, device=y.device)
-        check(lib.spk_bn_lif_train_fwd(_p(y), _p(g), _p(b), _p(running_mean), _p(running_var), float(momentum),
-                                       float(eps), _p(v0), _p(s), _p(v_last), _p(mean), _p(invstd), _p(ws), ws.numel(),
-                                       T, B, C, HW, float(tau), float(v_threshold), float(v_reset), _stream(y)),
-              "spk_bn_lif_train_fwd")
+        with timed("train.bn_lif_fwd"):
+            check(lib.spk_bn_lif_train_fwd(_p(y), _p(g), _p(b), _p(running_mean), _p(running_var), float(momentum),
+                                           float(eps), _p(v0), _p(s), _p(v_last), _p(mean), _p(invstd), _p(ws),
+                                           ws.numel(), T, B, C, HW, float(tau), float(v_threshold), float(v_reset),
+                                           _stream(y)), "spk_bn_lif_train_fwd")
         ctx.save_for_backward(y, g, b, mean, invstd, v0)
         ctx.cfg = (tau, v_threshold, v_reset, alpha, detach_reset)
         return s, v_last
@@ -179,18 +209,18 @@ class BNLIFTrainFunction(torch.autograd.Function):
         tau, v_threshold, v_reset, alpha, detach_reset = ctx.cfg
         T, B, C = int(y.shape[0]), int(y.shape[1]), int(y.shape[2])
         HW = int(y.shape[3] * y.shape[4])
-        gs = torch.zeros_like(y) if grad_s is None else _dev(grad_s, "grad_spike_seq", torch.float32)
-        gv = None if grad_v_last is None else _dev(grad_v_last, "grad_v_last", torch.float32)
+        gs = _empty_cl(y.shape, y.device).zero_() if grad_s is None else _cl5(grad_s, "grad_spike_seq")
+        gv = _cl4(grad_v_last, "grad_v_last")
         ws = torch.empty(int(lib.spk_bn_lif_train_ws_bytes(B, C, HW)), dtype=torch.uint8, device=y.device)
-        gy = torch.empty_like(y)
+        gy = _empty_cl(y.shape, y.device)
         gg = torch.empty(C, dtype=torch.float32, device=y.device)
         gb = torch.empty(C, dtype=torch.float32, device=y.device)
-        gv0 = torch.empty(y.shape[1:], dtype=torch.float32, device=y.device) if (v0 is not None and
-                                                                                 ctx.needs_input_grad[3]) else None
-        check(lib.spk_bn_lif_train_bwd(_p(gs), _p(gv), _p(y), _p(g), _p(b), _p(mean), _p(invstd), _p(v0), _p(gy), _p(gg),
-                                       _p(gb), _p(gv0), _p(ws), ws.numel(), T, B, C, HW, float(tau), float(v_threshold),
-                                       float(v_reset), float(alpha), int(bool(detach_reset)), _stream(y)),
-              "spk_bn_lif_train_bwd")
+        gv0 = _empty_cl(y.shape[1:], y.device) if (v0 is not None and ctx.needs_input_grad[3]) else None
+        with timed("train.bn_lif_bwd"):
+            check(lib.spk_bn_lif_train_bwd(_p(gs), _p(gv), _p(y), _p(g), _p(b), _p(mean), _p(invstd), _p(v0), _p(gy),
+                                           _p(gg), _p(gb), _p(gv0), _p(ws), ws.numel(), T, B, C, HW, float(tau),
+                                           float(v_threshold), float(v_reset), float(alpha), int(bool(detach_reset)),
+                                           _stream(y)), "spk_bn_lif_train_bwd")
         return (gy, gg if g is not None else None, gb if b is not None else None, gv0) + (None,) * 9
 
 
