@@ -109,6 +109,11 @@ int spk_bn_lif_train_bwd(const float* grad_spike_seq, const float* grad_v_last, 
 int spk_masked_ce(const float* logits, const float* target, const float* coef, float* ce_out, float* dlogits, int B, int K,
                   int HW, spk_stream_t stream);
 
+/* PSP filter of the VQ-VAE training losses (R/snn_model/snn_layers.py:6-26; used at R/snn_model/vae_model.py:81-82):
+ * out[t] = syn_t, syn_t = syn_{t-1} + (in[t] - syn_{t-1}) / tau_s, syn_{-1} = 0, over a dense [T][N] fp32 tensor.
+ * backward != 0 runs the adjoint instead (in = dL/dsyn, out = dL/dx). */
+int spk_psp(const float* in, float* out, int T, long long N, float tau_s, int backward, spk_stream_t stream);
+
 /* ---- layout converters --------------------------------------------------------------------------------------- */
 /* chunk = C gives plain PTC [B,HW,T,C]; chunk = 32 gives the channel-chunked "CPTC" [B,C/32,HW,T,32] the MFMA
  * kernel reads (one contiguous slab per image and 32-channel K chunk). */

@@ -12,7 +12,8 @@ Only data (inputs, expected outputs) is written; no reference source travels.
 Fixtures: F1 LIF, F2 per-layer VQ-VAE (teacher forced), F3 encode,
 F4 decode glue, F5 denoiser, F6 p_sample + RNG-order trajectory, F7 BN eval,
 F8 LIF training forward + surrogate-gradient BPTT (next-row scope),
-F9 one diffusion training step (q_sample + denoiser in train() mode + reweighted-ELBO loss + backward).
+F9 one diffusion training step (q_sample + denoiser in train() mode + reweighted-ELBO loss + backward),
+F10 one VQ-VAE training step (SNN_VQVAE in train() mode: VQ / commitment / PSP / reconstruction losses + backward).
 
     python oracle/gen_golden.py f9         # only rewrite the fixtures whose file name starts with "f9"
 """
@@ -417,6 +418,54 @@ def main():
         weights_crc=synth.state_checksum(sdd))
     print("F9 ok: loss", float(loss_ref), "t", t9.tolist(), "masked", int(mask9.sum()), "rates",
           [round(float(s.mean()), 4) for s in spikes9])
+
+    # ------------------------------------------------------------------ F10 one VQ-VAE training step
+    # SURVEY.md §8f item 2, second half: SNN_VQVAE.forward in train() mode (R/snn_model/vae_model.py:40-85,179-196) and
+    # (loss_eq + loss_rec).backward() as R/main.py:136-142 runs it.
+    cfg = synth.MNIST
+    sdv = synth.synth_vqvae_state(cfg)
+    g = torch.Generator().manual_seed(1010)
+    img10 = torch.rand(4, 1, 28, 28, generator=g) - 0.5
+    xs10 = img10.unsqueeze(0).repeat(16, 1, 1, 1, 1)
+    dvar = torch.tensor(0.09)
+    m10 = vm.SNN_VQVAE(1, 16, 128, dvar)
+    vm.functional.set_step_mode(net=m10, step_mode="m")
+    m10.load_state_dict(sdv)
+    m10.train()
+    leq, lrec, lreal = m10(xs10, img10)
+    (leq + lrec).backward()
+    grads10 = {k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for k, p in m10.named_parameters()}
+    stats10 = {k: v.clone() for k, v in m10.state_dict().items() if "running_" in k}
+    vm.functional.reset_net(m10)
+    sdo = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k and "coef" not in k
+               else v.clone()) for k, v in sdv.items()}
+    so10 = {}
+    (oeq, orec, oreal), idx10 = ref.snn_vqvae_train_forward(xs10, img10, sdo, dvar, stats_out=so10)
+    (oeq + orec).backward()
+    eq(leq.detach(), oeq.detach(), "F10 loss_eq"); eq(lrec.detach(), orec.detach(), "F10 loss_rec")
+    eq(lreal.detach(), oreal.detach(), "F10 real_loss_rec")
+    n_exact10 = 0
+    for k, gr in grads10.items():
+        go = sdo[k].grad if sdo[k].grad is not None else torch.zeros_like(sdo[k])
+        # decoder, codebook, alpha and BN gradients are bit-identical; the encoder-side ones (two gradient paths meet at
+        # the encoder output: read-out/STE and PSP) agree to fp32 round-off (autograd accumulation order)
+        assert float((gr - go).abs().max()) <= 1e-7 + 1e-6 * float(gr.abs().max()), "F10 grad " + k
+        n_exact10 = n_exact10 + int(torch.equal(gr, go))
+    for k, v in stats10.items():
+        eq(v, so10[k], "F10 " + k)
+    keep10 = ("encoder.snn_convs.0.weight", "encoder.snn_convs.7.weight", "vq_layer.alpha", "vq_layer.embeddings.weight",
+              "vq_layer.poisson.1.bias", "decoder.snn_convs.3.weight", "decoder.snn_convs.6.weight",
+              "decoder.snn_convs.6.bias")
+    np.savez_compressed(
+        os.path.join(OUT, "f10_vqvae_train_step.npz"), images=img10.numpy(), data_variance=dvar.numpy(),
+        loss_eq=leq.detach().numpy(), loss_rec=lrec.detach().numpy(), real_loss_rec=lreal.detach().numpy(),
+        indices=idx10.numpy(), grad_names=np.array(list(grads10)),
+        grad_norms=np.array([float(v.norm()) for v in grads10.values()]),
+        **{"grad." + k: grads10[k].numpy() for k in keep10},
+        **{"stat." + k: v.numpy() for k, v in stats10.items() if k.startswith(("encoder.snn_convs.1.", "decoder.snn_convs.4."))},
+        weights_crc=synth.state_checksum(sdv))
+    print("F10 ok: loss_eq", float(leq), "loss_rec", float(lrec), "real", float(lreal), "codes used", int(idx10.unique().numel()),
+          f"gradients bit-identical: {n_exact10} of {len(grads10)}")
     print("all fixtures written to", OUT)
 
 

@@ -368,6 +368,59 @@ def train_loss(x_0, sd, mask_id, num_timesteps=None, T=16, t=None, u=None, stats
     return masked_ce_loss(logits, x_0_ignore, t, num_timesteps), (t, x_t, x_0_ignore, mask, logits)
 
 
+def psp_filter(inputs, tau_s=2):
+    """PSP.forward, R/snn_model/snn_layers.py:12-26: syn_t = syn_{t-1} + (inputs[t] - syn_{t-1}) / tau_s, stacked over t."""
+    syn = 0
+    syns = []
+    for t in range(inputs.shape[0]):
+        syn = syn + (inputs[t, ...] - syn) / tau_s
+        syns.append(syn)
+    return torch.stack(syns)
+
+
+def conv_bn_lif_train(x_seq, sd, conv_prefix, bn_prefix, stride, padding, transposed=False, output_padding=0,
+                      stats_out=None):
+    """One (Conv|ConvT)+BN+LIF block in train() mode: library convolution, batch-statistics BN, surrogate-gradient LIF."""
+    w, b = sd[conv_prefix + ".weight"], sd[conv_prefix + ".bias"]
+    if transposed:
+        y = seq_conv_transpose2d(x_seq, w, b, stride, padding, output_padding)
+    else:
+        y = seq_conv2d(x_seq, w, b, stride, padding)
+    s, _ = lif_multi_step_train(seq_bn_train(y, sd, bn_prefix, stats_out=stats_out))
+    return s
+
+
+def snn_vqvae_train_forward(x_seq, image, sd, data_variance, commitment_cost=0.25, stats_out=None):
+    """SNN_VQVAE.forward in train() mode, R/snn_model/vae_model.py:179-196 with VectorQuantizer.forward's training branch
+    (:40-47,61-85), Encoder (:101-129) and Decoder (:131-159).  Returns (e_q_loss, recon_loss, real_recon_loss) and
+    the code indices; differentiable w.r.t. the floating-point tensors of ``sd``."""
+    T = x_seq.shape[0]
+    p = "encoder.snn_convs."
+    z = conv_bn_lif_train(x_seq, sd, p + "0", p + "1", 2, 1, stats_out=stats_out)
+    z = conv_bn_lif_train(z, sd, p + "3", p + "4", 2, 1, stats_out=stats_out)
+    z = conv_bn_lif_train(z, sd, p + "6", p + "7", 1, 0, stats_out=stats_out)
+    alpha = sd["vq_layer.alpha"]
+    x_memout = (1 - alpha) * membrane_output(z, sd["vq_layer.memout.coef"]) + alpha * torch.sum(z, dim=0) / T
+    x_memout = x_memout.permute(0, 2, 3, 1).contiguous()
+    flat_x = x_memout.reshape(-1, x_memout.shape[-1])
+    idx = vq_code_indices(flat_x, sd["vq_layer.embeddings.weight"])
+    quantized = F.embedding(idx, sd["vq_layer.embeddings.weight"]).view_as(x_memout)
+    loss_1 = F.mse_loss(quantized, x_memout.detach()) + commitment_cost * F.mse_loss(x_memout, quantized.detach())
+    quantized = x_memout + (quantized - x_memout).detach()
+    quantized = quantized.permute(0, 3, 1, 2).contiguous().unsqueeze(0).repeat(T, 1, 1, 1, 1)
+    e = conv_bn_lif_train(quantized, sd, "vq_layer.poisson.0", "vq_layer.poisson.1", 1, 0, stats_out=stats_out)
+    q2 = torch.mean((psp_filter(e) - psp_filter(z.detach())) ** 2)
+    e2 = torch.mean((psp_filter(e.detach()) - psp_filter(z)) ** 2)
+    e_q_loss = loss_1 + (q2 + commitment_cost * e2)
+    p = "decoder.snn_convs."
+    d = conv_bn_lif_train(e, sd, p + "0", p + "1", 2, 1, True, 1, stats_out=stats_out)
+    d = conv_bn_lif_train(d, sd, p + "3", p + "4", 2, 1, True, 1, stats_out=stats_out)
+    y3 = seq_conv_transpose2d(d, sd[p + "6.weight"], sd[p + "6.bias"], 1, 1, 0)
+    x_recon = torch.tanh(membrane_output(y3, sd["memout.coef"]))
+    real_recon_loss = F.mse_loss(x_recon, image)
+    return (e_q_loss, real_recon_loss / data_variance, real_recon_loss), idx
+
+
 # --------------------------------------------------------------------------- a9
 def categorical_sample(logits, q=None):
     """``dists.Categorical(logits=l).sample()`` as torch evaluates it on CPU:

@@ -147,3 +147,60 @@ extern "C" int spk_lif_train_bwd(const float* grad_spike_seq, const float* grad_
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }
+
+// ---- PSP: the post-synaptic-potential filter of the VQ-VAE training losses (R/snn_model/snn_layers.py:6-26) ---------
+//   forward   syn_t = syn_{t-1} + (x_t - syn_{t-1}) / tau_s,  syn_{-1} = 0            (one output per step)
+//   backward  (adjoint, t = T-1..0)   G <- G + dL/dsyn_t;  dL/dx_t = G / tau_s;  G <- G (1 - 1/tau_s)
+// Element-wise over the N neurons of a dense [T][N] tensor (any memory order inside N), T steps in a register.
+namespace {
+
+template <int VEC, bool BWD>
+__global__ __launch_bounds__(256) void psp_kernel(const float* __restrict__ in, float* __restrict__ out, int T, long long N,
+                                                  float tau) {
+  const long long ngroups = (N + VEC - 1) / VEC;
+  const float inv_tau = 1.0f / tau, carry = 1.0f - inv_tau;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (long long)gridDim.x * blockDim.x) {
+    const long long n0 = g * VEC;
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+    for (int i = 0; i < T; ++i) {
+      const int t = BWD ? T - 1 - i : i;
+      float xv[VEC], ov[VEC];
+      const float* p = in + (long long)t * N + n0;
+      if constexpr (VEC == 4) {
+        const f32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+        xv[0] = t4.x; xv[1] = t4.y; xv[2] = t4.z; xv[3] = t4.w;
+      } else {
+        xv[0] = *p;
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        if (BWD) {
+          const float G = acc[k] + xv[k];
+          ov[k] = G * inv_tau;
+          acc[k] = G * carry;
+        } else {
+          acc[k] = acc[k] + (xv[k] - acc[k]) / tau;
+          ov[k] = acc[k];
+        }
+      }
+      float* q = out + (long long)t * N + n0;
+      if constexpr (VEC == 4) *reinterpret_cast<float4*>(q) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+      else *q = ov[0];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int spk_psp(const float* in, float* out, int T, long long N, float tau_s, int backward, hipStream_t stream) {
+  if (!in || !out || T <= 0 || N <= 0 || !(tau_s > 0.f)) return SPK_ERR_ARG;
+  const bool vec = (N % 4 == 0) && ((((uintptr_t)in | (uintptr_t)out) % 16) == 0);
+  if (vec && backward) hipLaunchKernelGGL((psp_kernel<4, true>), dim3(grid_for(N / 4)), dim3(256), 0, stream, in, out, T, N, tau_s);
+  else if (vec) hipLaunchKernelGGL((psp_kernel<4, false>), dim3(grid_for(N / 4)), dim3(256), 0, stream, in, out, T, N, tau_s);
+  else if (backward) hipLaunchKernelGGL((psp_kernel<1, true>), dim3(grid_for(N)), dim3(256), 0, stream, in, out, T, N, tau_s);
+  else hipLaunchKernelGGL((psp_kernel<1, false>), dim3(grid_for(N)), dim3(256), 0, stream, in, out, T, N, tau_s);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}

@@ -3,7 +3,8 @@
 * ``MembraneOutputLayer``: sum_t x[t] * 0.8**(T-1-t); the ``coef`` buffer (shape (T,1,1,1,1), in ``state_dict``)
   is built exactly like R/snn_model/snn_layers.py:31-34, with ``n_steps`` a constructor argument (default 16,
   the reference's literal) so that BASELINE config 1 (T=4) is expressible.  Forward = ``spk_memout_fwd`` (HIP).
-* ``PSP``: training-loss filter (R/snn_model/snn_layers.py:6-26), outside the inference hot path.
+* ``PSP``: the post-synaptic-potential filter of the VQ-VAE training losses (R/snn_model/snn_layers.py:6-26):
+  ``spk_psp`` forward, its adjoint as the backward.
 """
 import torch
 import torch.nn as nn
@@ -19,8 +20,8 @@ class PSP(torch.nn.Module):
         self.tau_s = 2
 
     def forward(self, inputs):
-        raise NotImplementedError('spkdiff: PSP is only used by the VQ-VAE training losses '
-                                  '(R/snn_model/vae_model.py:81-82), outside the inference hot path')
+        """inputs: (T, N, ...) -> syns (T, N, ...): syn_t = syn_{t-1} + (inputs[t] - syn_{t-1}) / tau_s."""
+        return ops.PSPFunction.apply(inputs, float(self.tau_s))
 
 
 class MembraneOutputLayer(nn.Module):
@@ -31,4 +32,6 @@ class MembraneOutputLayer(nn.Module):
 
     def forward(self, x):
         """x : (T,N,C,H,W) -> (N,C,H,W)"""
+        if torch.is_grad_enabled() and x.requires_grad:
+            return ops.MemoutFunction.apply(x, self.coef)
         return ops.memout(x, self.coef)

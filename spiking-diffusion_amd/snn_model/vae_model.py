@@ -3,8 +3,10 @@
 Counterpart of R/snn_model/vae_model.py:22-196 -- same class names, constructor signatures, attribute paths
 (``model.encoder``, ``model.vq_layer.quantize/poisson``, ``model.decoder``, ``model.memout``) and ``state_dict``
 keys, so R/main.py's test/sampling section runs against it unchanged.  The eval branches run on
-``libspkdiff.so`` (fused Conv+BN+LIF kernels, VQ argmin kernel); the training branches (losses, STE:
-vae_model.py:61-85,189-196) are outside the hot path and raise NotImplementedError.
+``libspkdiff.so`` (fused Conv+BN+LIF kernels, VQ argmin kernel).  The training branches (VQ / commitment / PSP /
+reconstruction losses, straight-through estimator: vae_model.py:61-85,189-196) run in train()
+mode with autograd: library (transposed) convolutions through torch, native BatchNorm+LIF block tails
+(``spk_bn_lif_train_*``), membrane read-out, code search and PSP filter (``spk_psp``).
 
 Re-exported names match what ``from snn_model.vae_model import *`` gives R/main.py (``functional`` in particular,
 R/main.py:101-107,317).
@@ -60,11 +62,38 @@ class VectorQuantizer(nn.Module):
     def forward(self, x):
         # x: (T,N,C,H,W) spikes of the encoder
         if self.training:
-            _training_oos('VectorQuantizer.forward (VQ / commitment / PSP losses)')
+            return self._train_forward(x)
         T = x.shape[0]
         idx, zq = self._quantize_ptc(ops.spikes_to_ptc(x))
         quantized = self._spike_generator(zq, T)['f32']
         return quantized, idx
+
+    def _train_forward(self, x):
+        """Training branch, R/snn_model/vae_model.py:40-47,61-85: read-out, nearest code, VQ and
+        commitment losses, straight-through estimator, spike generator, PSP losses.  Native pieces: the membrane read-out
+        (spk_memout_fwd), the code search (spk_vq_argmin), the spike generator's BatchNorm+LIF (spk_bn_lif_train_*) and
+        the PSP filter (spk_psp); the remaining element-wise algebra and the embedding gradient are torch plumbing."""
+        if not torch.is_grad_enabled():
+            _training_oos('VectorQuantizer.forward in train() mode without autograd')
+        T = x.shape[0]
+        x_memout = (1 - self.alpha) * self.memout(x) + self.alpha * torch.sum(x, dim=0) / self.num_step
+        x_memout = x_memout.permute(0, 2, 3, 1).contiguous()
+        flat_x = x_memout.reshape(-1, self.embedding_dim)
+        encoding_indices = self.get_code_indices(flat_x.detach())
+        quantized = F.embedding(encoding_indices, self.embeddings.weight).view_as(x_memout)
+        q_latent_loss = F.mse_loss(quantized, x_memout.detach())
+        e_latent_loss = F.mse_loss(x_memout, quantized.detach())
+        loss_1 = q_latent_loss + self.commitment_cost * e_latent_loss
+        quantized = x_memout + (quantized - x_memout).detach()           # straight-through estimator
+        quantized = quantized.permute(0, 3, 1, 2).contiguous()
+        quantized = torch.unsqueeze(quantized, dim=0).repeat(T, 1, 1, 1, 1)
+        quantized = self.poisson(quantized)
+        # psp(x.detach()) and psp(x).detach() are the same numbers: each filter runs once
+        pq, px = self.psp(quantized), self.psp(x)
+        q_latent_loss_2 = torch.mean((pq - px.detach()) ** 2)
+        e_latent_loss_2 = torch.mean((pq.detach() - px) ** 2)
+        loss_2 = q_latent_loss_2 + self.commitment_cost * e_latent_loss_2
+        return quantized, loss_1 + loss_2
 
     def get_code_indices(self, flat_x):
         """argmin_k ||x - e_k||^2 for rows of flat_x [N, D] (R/snn_model/vae_model.py:87-95)."""
@@ -147,7 +176,14 @@ class SNN_VQVAE(nn.Module):
     def forward(self, x, image):
         # x: [t, B, C, H, W]
         if self.training:
-            _training_oos('SNN_VQVAE.forward (reconstruction / VQ losses)')
+            # training branch, R/snn_model/vae_model.py:189-196
+            if not torch.is_grad_enabled():
+                _training_oos('SNN_VQVAE.forward in train() mode without autograd')
+            z = self.encoder(x)
+            e, e_q_loss = self.vq_layer(z)
+            x_recon = torch.tanh(self.memout(self.decoder(e)))
+            real_recon_loss = F.mse_loss(x_recon, image)
+            return e_q_loss, real_recon_loss / self.data_variance, real_recon_loss
         T = x.shape[0]
         enc = self.encoder.snn_convs
         dec = self.decoder.snn_convs

@@ -326,6 +326,55 @@ def memout(x_seq, coef):
     return out
 
 
+class MemoutFunction(torch.autograd.Function):
+    """Differentiable MembraneOutputLayer (training path): forward = spk_memout_fwd, backward dL/dx[t] = dL/dout * coef[t]
+    (one broadcast multiply)."""
+
+    @staticmethod
+    def forward(ctx, x_seq, coef):
+        ctx.save_for_backward(coef)
+        return memout(x_seq, coef)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (coef,) = ctx.saved_tensors
+        return grad_out.unsqueeze(0) * coef.view((-1,) + (1,) * grad_out.dim()), None
+
+
+def _dense_tn(x, name):
+    """[T, ...] fp32 device tensor whose memory is T dense planes (any element order inside a plane)."""
+    if not x.is_cuda:
+        raise RuntimeError(f"spkdiff: {name} is on '{x.device}'; there is no CPU path")
+    if x.dtype != torch.float32:
+        raise NotImplementedError(f"spkdiff: {name} must be float32, got {x.dtype}")
+    n = x[0].numel()
+    if x.shape[0] > 1 and x.stride(0) != n:
+        return x.contiguous()
+    if not torch.empty_like(x).stride() == x.stride():       # not a dense permutation: copy
+        return x.contiguous()
+    return x
+
+
+def psp(x_seq, tau_s=2.0, backward=False):
+    x = _dense_tn(x_seq, "inputs")
+    out = torch.empty_like(x)
+    check(lib.spk_psp(_p(x), _p(out), int(x.shape[0]), x[0].numel(), float(tau_s), int(backward), _stream(x)), "spk_psp")
+    return out
+
+
+class PSPFunction(torch.autograd.Function):
+    """syns = PSP(inputs) (R/snn_model/snn_layers.py:12-26) with its adjoint as the backward, both spk_psp."""
+
+    @staticmethod
+    def forward(ctx, x_seq, tau_s):
+        ctx.tau_s = tau_s
+        return psp(x_seq, tau_s, False)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return psp(grad_out, ctx.tau_s, True), None
+
+
 # ---------------------------------------------------------------------------------------------- layouts
 def spikes_to_ptc(s, chunk=None):
     """fp32 [T,B,C,H,W] -> u8 [B,H,W,T,C] (plain PTC) or, with ``chunk``, CPTC [B,C/chunk,H,W,T,chunk]."""

@@ -105,7 +105,9 @@ def test_no_cpu_fallback_and_training_branches_raise():
     with pytest.raises(RuntimeError, match="no CPU path"):
         m(x, x[0])
     m.train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="CPU"):
+        m(x, x[0])
+    with torch.no_grad(), pytest.raises(NotImplementedError):
         m(x, x[0])
     d = DummyModel(1, 128)
     functional.set_step_mode(net=d, step_mode='m')

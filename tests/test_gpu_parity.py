@@ -152,7 +152,7 @@ def test_bn_f7_exact(golden_dir, dev):
 def test_conv2d_layer_vs_fp64_oracle(dev, cin, cout, k, s, p, hw):
     from spikingjelly.activation_based import layer
     torch.manual_seed(cin * 100 + cout)
-    conv = layer.Conv2d(cin, cout, k, s, p, step_mode='m')
+    conv = layer.Conv2d(cin, cout, k, s, p, step_mode='m').eval()      # (train() + autograd = the library operator)
     x = torch.randn(3, 2, cin, hw, hw)
     want64 = ref.seq_conv2d(x.double(), conv.weight.detach().double(), conv.bias.detach().double(), s, p)
     want32 = ref.seq_conv2d(x, conv.weight.detach(), conv.bias.detach(), s, p)
@@ -170,7 +170,7 @@ def test_conv2d_layer_vs_fp64_oracle(dev, cin, cout, k, s, p, hw):
 def test_conv_transpose2d_layer_vs_fp64_oracle(dev, cin, cout, k, s, p, op, hw):
     from spikingjelly.activation_based import layer
     torch.manual_seed(cin * 100 + cout)
-    conv = layer.ConvTranspose2d(cin, cout, k, s, p, op, step_mode='m')
+    conv = layer.ConvTranspose2d(cin, cout, k, s, p, op, step_mode='m').eval()
     x = torch.randn(2, 2, cin, hw, hw)
     want64 = ref.seq_conv_transpose2d(x.double(), conv.weight.detach().double(), conv.bias.detach().double(), s, p, op)
     want32 = ref.seq_conv_transpose2d(x, conv.weight.detach(), conv.bias.detach(), s, p, op)
@@ -689,6 +689,70 @@ def test_train_iter_fused_vs_module_by_module_and_optimizer_step(dev):
     assert tok.shape == (4, 1, 7, 7) and int(tok.max()) < 128
 
 
+@pytest.mark.parametrize("shape", [(16, 3, 5, 7, 7), (7, 1001)])
+def test_psp_filter_and_adjoint_vs_oracle(dev, ops, shape):
+    """spk_psp forward and adjoint (PSP of the VQ-VAE training losses, R/snn_model/snn_layers.py:12-26) against the
+    oracle's loop under autograd; vector and scalar paths."""
+    g = torch.Generator().manual_seed(len(shape))
+    x = torch.randn(shape, generator=g); w = torch.randn(shape, generator=g)
+    xo = x.clone().requires_grad_(True)
+    so = ref.psp_filter(xo)
+    (so * w).sum().backward()
+    xd = x.clone().to(dev).requires_grad_(True)
+    sdv = ops.PSPFunction.apply(xd, 2.0)
+    (sdv * w.to(dev)).sum().backward()
+    assert float((sdv.detach().cpu() - so.detach()).abs().max()) <= 1e-6
+    assert float((xd.grad.cpu() - xo.grad).abs().max()) <= 1e-5 * float(xo.grad.abs().max())
+
+
+def test_f10_vqvae_train_step_vs_reference_fixture(golden_dir, dev):
+    """SURVEY §8f item 2 (second half): SNN_VQVAE.forward in train() mode and (loss_eq + loss_rec).backward() as
+    R/main.py:136-142 runs it -- library (transposed) convolutions, native BatchNorm+LIF block tails, membrane read-out,
+    code search, PSP filter -- against the reference's run (fixture F10).  Same floating-point caveat as F9 (a neuron-step
+    may flip, which here can also move a code index): losses 2 % relative, gradients 5 % relative L2 / norms 5 %,
+    running statistics 1e-4 relative.  The measured values are printed."""
+    from snn_model.vae_model import functional
+    d = load(golden_dir, "f10_vqvae_train_step.npz")
+    model, sd = build_vae(synth.MNIST, dev)
+    assert str(d["weights_crc"]) == synth.state_checksum(sd)
+    model.data_variance = torch.from_numpy(d["data_variance"]).to(dev)
+    model.train()
+    img = torch.from_numpy(d["images"]).to(dev)
+    leq, lrec, lreal = model(img.unsqueeze(0).repeat(16, 1, 1, 1, 1), img)
+    (leq + lrec).backward()
+    rel = {k: abs(float(v.detach()) - float(d[k])) / float(d[k]) for k, v in
+           (("loss_eq", leq), ("loss_rec", lrec), ("real_loss_rec", lreal))}
+    grads = {k: (p.grad.cpu() if p.grad is not None else torch.zeros_like(p).cpu()) for k, p in model.named_parameters()}
+    gerr = {k[5:]: round(_rel_l2(grads[k[5:]], torch.from_numpy(d[k])), 6) for k in d.files if k.startswith("grad.")}
+    print("F10 measured: loss rel err", rel, "grad rel L2", gerr)
+    assert max(rel.values()) <= 2e-2, rel
+    for k in d.files:
+        if k.startswith("grad.") and float(np.linalg.norm(d[k])) > 1e-6:
+            assert gerr[k[5:]] <= 5e-2, (k, gerr[k[5:]])
+    for k, n in zip(d["grad_names"].tolist(), d["grad_norms"].tolist()):
+        # (a convolution bias in front of a batch-statistics BN has a zero gradient: both sides hold only round-off,
+        # here ~1e-5 because the reconstruction loss is divided by the data variance)
+        assert abs(float(grads[k].norm()) - n) <= 5e-2 * n + 5e-5, (k, float(grads[k].norm()), n)
+    st = model.state_dict()
+    for k in d.files:
+        if k.startswith("stat."):
+            want = torch.from_numpy(d[k])
+            assert float(((st[k[5:]].cpu() - want).abs() / (1 + want.abs())).max()) <= 1e-4, k
+    functional.reset_net(model)
+    # the reference's loop body (R/main.py:136-146) runs and moves the weights; inference still works afterwards
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.001)
+    for _ in range(2):
+        a, b, c = model(img.unsqueeze(0).repeat(16, 1, 1, 1, 1), img)
+        opt.zero_grad(); (a + b).backward(); opt.step(); functional.reset_net(model)
+    assert np.isfinite(float(a.detach())) and np.isfinite(float(b.detach()))
+    assert not torch.equal(model.decoder.snn_convs[3].weight.detach().cpu(), sd["decoder.snn_convs.3.weight"])
+    model.eval()
+    with torch.inference_mode():
+        e, xr, idx = model(img.unsqueeze(0).repeat(16, 1, 1, 1, 1), img)
+    functional.reset_net(model)
+    assert xr.shape == (4, 1, 28, 28) and idx.shape == (4 * 49,)
+
+
 # ------------------------------------------------------------------------------------------------- F6 p_sample
 def test_f6_psample_steps_exact(golden_dir, dev, ops):
     d = load(golden_dir, "f6_psample.npz")
@@ -844,9 +908,10 @@ def test_main_py_call_sequence_conformance(dev):
     loader = [(torch.rand(8, 1, 28, 28), torch.zeros(8)) for _ in range(2)]
     idxs = ns["get_data_for_diff"](loader, model)
     assert len(idxs) == 2 and idxs[0].shape == (8, 7, 7) and idxs[0].dtype == torch.int64
-    model.train()
-    with pytest.raises(NotImplementedError):
-        model(images_spike, norm_images)
+    model.train()                                 # the training branch returns the reference's three losses
+    out = model(norm_images.unsqueeze(0).repeat(16, 1, 1, 1, 1), norm_images)
+    assert len(out) == 3 and all(o.dim() == 0 for o in out)
+    ns["functional"].reset_net(model)
 
 
 # ------------------------------------------------------------------------------------------------- BASELINE configs 3, 4, 5

@@ -90,6 +90,38 @@ def test_f9_diffusion_train_step(golden_dir):
         assert abs(float(sd[k].grad.norm()) - n) <= 1e-6 * max(1.0, n), k
 
 
+def test_f10_vqvae_train_step(golden_dir):
+    """SURVEY §8f item 2 (second half): SNN_VQVAE.forward in train() mode + (loss_eq + loss_rec).backward() of the
+    reference against the oracle's restatement: the three losses, the code indices and the running statistics are
+    bit-identical; gradients agree to fp32 round-off (decoder / codebook / alpha ones bit-identically; where the
+    read-out and PSP gradient paths meet at the encoder output autograd's accumulation order differs in the last bit)."""
+    d = load(golden_dir, "f10_vqvae_train_step.npz")
+    sdv = synth.synth_vqvae_state(synth.MNIST)
+    assert str(d["weights_crc"]) == synth.state_checksum(sdv)
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k and "coef" not in k
+              else v.clone()) for k, v in sdv.items()}
+    img = torch.from_numpy(d["images"])
+    stats = {}
+    (leq, lrec, lreal), idx = ref.snn_vqvae_train_forward(img.unsqueeze(0).repeat(16, 1, 1, 1, 1), img, sd,
+                                                          torch.from_numpy(d["data_variance"]), stats_out=stats)
+    (leq + lrec).backward()
+    assert torch.equal(leq.detach(), torch.from_numpy(d["loss_eq"]))
+    assert torch.equal(lrec.detach(), torch.from_numpy(d["loss_rec"]))
+    assert torch.equal(lreal.detach(), torch.from_numpy(d["real_loss_rec"]))
+    assert torch.equal(idx, torch.from_numpy(d["indices"]))
+    for k in d.files:
+        if k.startswith("grad."):
+            want = torch.from_numpy(d[k])
+            assert float((sd[k[5:]].grad - want).abs().max()) <= 1e-7 + 1e-6 * float(want.abs().max()), k
+        if k.startswith("stat."):
+            assert torch.equal(stats[k[5:]], torch.from_numpy(d[k])), k
+    for k in ("decoder.snn_convs.3.weight", "decoder.snn_convs.6.bias", "vq_layer.embeddings.weight", "vq_layer.alpha"):
+        assert torch.equal(sd[k].grad, torch.from_numpy(d["grad." + k])), k
+    for k, n in zip(d["grad_names"].tolist(), d["grad_norms"].tolist()):
+        got = 0.0 if sd[k].grad is None else float(sd[k].grad.norm())
+        assert abs(got - n) <= 1e-6 * max(1.0, n) + 1e-7, k
+
+
 def test_memout_coef():
     # SURVEY §8 a4: coef = 0.8 ** arange(15..0) fp32, shape (16,1,1,1,1)
     c = ref.memout_coef(16)
