@@ -232,7 +232,242 @@ __global__ __launch_bounds__(TPB) void bn_bwd2_kernel(const float* __restrict__ 
   }
 }
 
-// row slices: enough waves to fill 256 CUs several times over, never more than one row per wave
+// ---- vector forms: a thread owns VEC consecutive channels (q = tid % Q, Q = C / VEC, 256 % Q == 0) and walks rows
+// j = tid / Q, j + 256 / Q, ...: consecutive threads read consecutive 4*VEC-byte words, a workgroup reads 256 * VEC
+// contiguous floats per step and keeps T of them in flight per thread.  Partials land in the same ws layout [slice][C][2].
+template <int VEC> struct Vec;
+template <> struct Vec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct Vec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+struct GeoV {
+  int T, R, C, S, Q, RPB;         // Q = C / VEC threads per row, RPB = 256 / Q rows per workgroup step
+};
+
+template <int VEC>
+__device__ __forceinline__ void store_partials_v(const double (&a)[VEC], const double (&b)[VEC], double* __restrict__ ws,
+                                                 const GeoV& g) {
+  __shared__ double sh[TPB][2 * VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { sh[threadIdx.x][2 * i] = a[i]; sh[threadIdx.x][2 * i + 1] = b[i]; }
+  __syncthreads();
+  if ((int)threadIdx.x < g.Q) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      double s0 = 0.0, s1 = 0.0;
+      for (int j = 0; j < g.RPB; ++j) { s0 += sh[threadIdx.x + j * g.Q][2 * i]; s1 += sh[threadIdx.x + j * g.Q][2 * i + 1]; }
+      double* o = ws + ((long long)blockIdx.x * g.C + threadIdx.x * VEC + i) * 2;
+      o[0] = s0; o[1] = s1;
+    }
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(TPB) void bn_stats_v_kernel(const float* __restrict__ y, double* __restrict__ ws, GeoV g) {
+  typedef typename Vec<VEC>::type vf;
+  const int q = threadIdx.x % g.Q, j = threadIdx.x / g.Q;
+  const long long ts = (long long)g.R * g.Q;
+  const vf* yv = reinterpret_cast<const vf*>(y);
+  double s[VEC], sq[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { s[i] = 0.0; sq[i] = 0.0; }
+  for (int r = blockIdx.x * g.RPB + j; r < g.R; r += g.RPB * g.S) {
+    const long long n = (long long)r * g.Q + q;
+    vf v[SPK_MAX_T];
+#pragma unroll
+    for (int t = 0; t < SPK_MAX_T; ++t) if (t < g.T) v[t] = yv[n + t * ts];
+#pragma unroll
+    for (int t = 0; t < SPK_MAX_T; ++t) {
+      if (t < g.T) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { const double d = (double)v[t][i]; s[i] += d; sq[i] += d * d; }
+      }
+    }
+  }
+  store_partials_v<VEC>(s, sq, ws, g);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(TPB) void bn_lif_apply_v_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ save_mean,
+                                                             const float* __restrict__ save_invstd, const float* __restrict__ v_init,
+                                                             float* __restrict__ spikes, float* __restrict__ v_out, GeoV g,
+                                                             float tau, float v_th, float v_reset) {
+  typedef typename Vec<VEC>::type vf;
+  const int q = threadIdx.x % g.Q, j = threadIdx.x / g.Q;
+  const long long ts = (long long)g.R * g.Q;
+  const vf* yv = reinterpret_cast<const vf*>(y);
+  vf* sv = reinterpret_cast<vf*>(spikes);
+  float a[VEC], b[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int c = q * VEC + i;
+    a[i] = (gamma ? gamma[c] : 1.0f) * save_invstd[c];
+    b[i] = (beta ? beta[c] : 0.0f) - save_mean[c] * a[i];
+  }
+  for (int r = blockIdx.x * g.RPB + j; r < g.R; r += g.RPB * g.S) {
+    const long long n = (long long)r * g.Q + q;
+    vf in[SPK_MAX_T];
+#pragma unroll
+    for (int t = 0; t < SPK_MAX_T; ++t) if (t < g.T) in[t] = yv[n + t * ts];
+    vf v;
+    if (v_init) v = reinterpret_cast<const vf*>(v_init)[n];
+    else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) v[i] = v_reset;
+    }
+#pragma unroll
+    for (int t = 0; t < SPK_MAX_T; ++t) {
+      if (t < g.T) {
+        vf o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float z = fmaf(in[t][i], a[i], b[i]);
+          const float h = v[i] + (z - (v[i] - v_reset)) / tau;
+          const float sp = (h - v_th >= 0.0f) ? 1.0f : 0.0f;
+          v[i] = (1.0f - sp) * h + sp * v_reset;
+          o[i] = sp;
+        }
+        sv[n + t * ts] = o;
+      }
+    }
+    if (v_out) reinterpret_cast<vf*>(v_out)[n] = v;
+  }
+}
+
+template <int VEC, bool DETACH>
+__global__ __launch_bounds__(TPB) void bn_lif_bwd1_v_kernel(const float* __restrict__ grad_s, const float* __restrict__ grad_v_last,
+                                                            const float* __restrict__ y, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ save_mean,
+                                                            const float* __restrict__ save_invstd, const float* __restrict__ v_init,
+                                                            float* __restrict__ grad_y, float* __restrict__ grad_v_init,
+                                                            double* __restrict__ ws, GeoV g, float tau, float v_th, float v_reset,
+                                                            float alpha) {
+  typedef typename Vec<VEC>::type vf;
+  const int q = threadIdx.x % g.Q, j = threadIdx.x / g.Q;
+  const long long ts = (long long)g.R * g.Q;
+  const vf* yv = reinterpret_cast<const vf*>(y);
+  const vf* gsv = reinterpret_cast<const vf*>(grad_s);
+  vf* gyv = reinterpret_cast<vf*>(grad_y);
+  const float inv_tau = 1.0f / tau, carry = 1.0f - inv_tau;
+  float mean[VEC], invstd[VEC], a[VEC], b[VEC];
+  double s1[VEC], s2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int c = q * VEC + i;
+    mean[i] = save_mean[c]; invstd[i] = save_invstd[c];
+    a[i] = (gamma ? gamma[c] : 1.0f) * invstd[i];
+    b[i] = (beta ? beta[c] : 0.0f) - mean[i] * a[i];
+    s1[i] = 0.0; s2[i] = 0.0;
+  }
+  for (int r = blockIdx.x * g.RPB + j; r < g.R; r += g.RPB * g.S) {
+    const long long n = (long long)r * g.Q + q;
+    vf yy[SPK_MAX_T], hh[SPK_MAX_T], gs[SPK_MAX_T];
+#pragma unroll
+    for (int t = 0; t < SPK_MAX_T; ++t) {
+      if (t < g.T) { yy[t] = yv[n + t * ts]; gs[t] = gsv[n + t * ts]; }
+    }
+    vf v;
+    if (v_init) v = reinterpret_cast<const vf*>(v_init)[n];
+    else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) v[i] = v_reset;
+    }
+#pragma unroll
+    for (int t = 0; t < SPK_MAX_T; ++t) {
+      if (t < g.T) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float z = fmaf(yy[t][i], a[i], b[i]);
+          const float h = v[i] + (z - (v[i] - v_reset)) / tau;
+          const float sp = (h - v_th >= 0.0f) ? 1.0f : 0.0f;
+          v[i] = (1.0f - sp) * h + sp * v_reset;
+          hh[t][i] = h;
+        }
+      }
+    }
+    vf G;
+    if (grad_v_last) G = reinterpret_cast<const vf*>(grad_v_last)[n];
+    else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) G[i] = 0.0f;
+    }
+#pragma unroll
+    for (int t = SPK_MAX_T - 1; t >= 0; --t) {
+      if (t < g.T) {
+        vf o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float over = hh[t][i] - v_th;
+          const float sp = over >= 0.0f ? 1.0f : 0.0f;
+          const float ax = 1.57079632679489661923f * alpha * over;
+          const float g_s = alpha / 2.0f / (1.0f + ax * ax);
+          float dv_dh = 1.0f - sp;
+          if (!DETACH) dv_dh = (v_reset - hh[t][i]) * g_s + dv_dh;
+          const float gh = G[i] * dv_dh + gs[t][i] * g_s;
+          const float gz = gh * inv_tau;
+          G[i] = gh * carry;
+          o[i] = gz;
+          s1[i] += (double)gz;
+          s2[i] += (double)gz * (double)((yy[t][i] - mean[i]) * invstd[i]);
+        }
+        gyv[n + t * ts] = o;
+      }
+    }
+    if (grad_v_init) reinterpret_cast<vf*>(grad_v_init)[n] = G;
+  }
+  store_partials_v<VEC>(s1, s2, ws, g);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(TPB) void bn_bwd2_v_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
+                                                        const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                                        const float* __restrict__ grad_gamma, const float* __restrict__ grad_beta,
+                                                        float* __restrict__ grad_y, GeoV g, float inv_M) {
+  typedef typename Vec<VEC>::type vf;
+  const int q = threadIdx.x % g.Q, j = threadIdx.x / g.Q;
+  const long long ts = (long long)g.R * g.Q;
+  const vf* yv = reinterpret_cast<const vf*>(y);
+  vf* gyv = reinterpret_cast<vf*>(grad_y);
+  float mean[VEC], invstd[VEC], a[VEC], c1[VEC], c2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int c = q * VEC + i;
+    mean[i] = save_mean[c]; invstd[i] = save_invstd[c];
+    a[i] = (gamma ? gamma[c] : 1.0f) * invstd[i];
+    c1[i] = grad_beta[c] * inv_M; c2[i] = grad_gamma[c] * inv_M;
+  }
+  for (int r = blockIdx.x * g.RPB + j; r < g.R; r += g.RPB * g.S) {
+    const long long n = (long long)r * g.Q + q;
+    vf yy[SPK_MAX_T], gg[SPK_MAX_T];
+#pragma unroll
+    for (int t = 0; t < SPK_MAX_T; ++t) {
+      if (t < g.T) { yy[t] = yv[n + t * ts]; gg[t] = gyv[n + t * ts]; }
+    }
+#pragma unroll
+    for (int t = 0; t < SPK_MAX_T; ++t) {
+      if (t < g.T) {
+        vf o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o[i] = a[i] * (gg[t][i] - c1[i] - ((yy[t][i] - mean[i]) * invstd[i]) * c2[i]);
+        gyv[n + t * ts] = o;
+      }
+    }
+  }
+}
+
+// vector width usable for C channels: Q = C / VEC threads per row must divide the workgroup
+inline int vec_for(int C, int want) {
+  for (int v = want; v >= 2; v >>= 1)
+    if (C % v == 0 && C / v <= TPB && TPB % (C / v) == 0) return v;
+  return 1;
+}
+
+inline GeoV geo_v(int T, int R, int C, int vec, int S) {
+  const int Q = C / vec, RPB = TPB / Q;
+  return GeoV{T, R, C, S, Q, RPB};
+}
+
+// row slices of the scalar form: enough waves to fill 256 CUs several times over, never more than one row per wave
 inline int slices(int R, int C) {
   const int groups = (C + 63) / 64;
   int s = 8192 / (groups * NW);
@@ -241,11 +476,30 @@ inline int slices(int R, int C) {
   return s < 1 ? 1 : s;
 }
 
+// workgroups of the vector forms: 4 per CU (8-16 KB in flight per wave), never more than one row step per workgroup
+inline int slices_v(int R, int C, int vec) {
+  const int rpb = TPB / (C / vec);
+  int s = 1024;
+  const int cap = (R + rpb - 1) / rpb;
+  if (s > cap) s = cap;
+  return s < 1 ? 1 : s;
+}
+
+inline int max_slices(int R, int C) {
+  int m = slices(R, C);
+  for (int v = 2; v <= 4; v <<= 1) {
+    if (vec_for(C, v) == v) { const int s = slices_v(R, C, v); if (s > m) m = s; }
+  }
+  return m;
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
 }  // namespace
 
 extern "C" long long spk_bn_lif_train_ws_bytes(int B, int C, int HW) {
   if (B <= 0 || C <= 0 || HW <= 0 || (long long)B * HW > (1LL << 30)) return SPK_ERR_ARG;
-  return (long long)C * slices(B * HW, C) * 2 * (long long)sizeof(double);
+  return (long long)C * max_slices(B * HW, C) * 2 * (long long)sizeof(double);
 }
 
 extern "C" int spk_bn_lif_train_fwd(const float* y, const float* gamma, const float* beta, float* running_mean,
@@ -256,14 +510,33 @@ extern "C" int spk_bn_lif_train_fwd(const float* y, const float* gamma, const fl
       !(tau > 0.f) || (long long)B * HW > (1LL << 30))
     return SPK_ERR_ARG;
   if (ws_bytes < spk_bn_lif_train_ws_bytes(B, C, HW)) return SPK_ERR_ARG;
-  const int S = slices(B * HW, C);
-  const Geo g{T, B * HW, C, S};
-  const dim3 grid((C + 63) / 64, S);
-  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(TPB), 0, stream, y, (double*)ws, g);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + NW - 1) / NW), dim3(TPB), 0, stream, (const double*)ws, S, C,
-                     (double)T * B * HW, eps, momentum, running_mean, running_var, save_mean, save_invstd);
-  hipLaunchKernelGGL(bn_lif_apply_kernel, grid, dim3(TPB), 0, stream, y, gamma, beta, save_mean, save_invstd, v_init,
-                     spike_seq, v_out, g, tau, v_threshold, v_reset);
+  const int R = B * HW;
+  const double M = (double)T * R;
+  const bool al = aligned16(y) && aligned16(spike_seq) && (!v_init || aligned16(v_init)) && (!v_out || aligned16(v_out));
+  const int vec = al ? vec_for(C, 4) : 1;
+  if (vec >= 2) {
+    const int S = slices_v(R, C, vec);
+    const GeoV g = geo_v(T, R, C, vec, S);
+    if (vec == 4) hipLaunchKernelGGL(bn_stats_v_kernel<4>, dim3(S), dim3(TPB), 0, stream, y, (double*)ws, g);
+    else hipLaunchKernelGGL(bn_stats_v_kernel<2>, dim3(S), dim3(TPB), 0, stream, y, (double*)ws, g);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + NW - 1) / NW), dim3(TPB), 0, stream, (const double*)ws, S, C, M, eps,
+                       momentum, running_mean, running_var, save_mean, save_invstd);
+    if (vec == 4)
+      hipLaunchKernelGGL(bn_lif_apply_v_kernel<4>, dim3(S), dim3(TPB), 0, stream, y, gamma, beta, save_mean, save_invstd,
+                         v_init, spike_seq, v_out, g, tau, v_threshold, v_reset);
+    else
+      hipLaunchKernelGGL(bn_lif_apply_v_kernel<2>, dim3(S), dim3(TPB), 0, stream, y, gamma, beta, save_mean, save_invstd,
+                         v_init, spike_seq, v_out, g, tau, v_threshold, v_reset);
+  } else {
+    const int S = slices(R, C);
+    const Geo g{T, R, C, S};
+    const dim3 grid((C + 63) / 64, S);
+    hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(TPB), 0, stream, y, (double*)ws, g);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + NW - 1) / NW), dim3(TPB), 0, stream, (const double*)ws, S, C, M, eps,
+                       momentum, running_mean, running_var, save_mean, save_invstd);
+    hipLaunchKernelGGL(bn_lif_apply_kernel, grid, dim3(TPB), 0, stream, y, gamma, beta, save_mean, save_invstd, v_init,
+                       spike_seq, v_out, g, tau, v_threshold, v_reset);
+  }
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }
@@ -277,19 +550,50 @@ extern "C" int spk_bn_lif_train_bwd(const float* grad_spike_seq, const float* gr
       T > SPK_MAX_T || B <= 0 || C <= 0 || HW <= 0 || !(tau > 0.f) || !(alpha > 0.f) || (long long)B * HW > (1LL << 30))
     return SPK_ERR_ARG;
   if (ws_bytes < spk_bn_lif_train_ws_bytes(B, C, HW)) return SPK_ERR_ARG;
-  const int S = slices(B * HW, C);
-  const Geo g{T, B * HW, C, S};
-  const dim3 grid((C + 63) / 64, S);
-  if (detach_reset)
-    hipLaunchKernelGGL(bn_lif_bwd1_kernel<true>, grid, dim3(TPB), 0, stream, grad_spike_seq, grad_v_last, y, gamma, beta,
-                       save_mean, save_invstd, v_init, grad_y, grad_v_init, (double*)ws, g, tau, v_threshold, v_reset, alpha);
-  else
-    hipLaunchKernelGGL(bn_lif_bwd1_kernel<false>, grid, dim3(TPB), 0, stream, grad_spike_seq, grad_v_last, y, gamma, beta,
-                       save_mean, save_invstd, v_init, grad_y, grad_v_init, (double*)ws, g, tau, v_threshold, v_reset, alpha);
+  const int R = B * HW;
+  const float inv_M = (float)(1.0 / ((double)T * R));
+  const bool al = aligned16(y) && aligned16(grad_spike_seq) && aligned16(grad_y) && (!v_init || aligned16(v_init)) &&
+                  (!grad_v_last || aligned16(grad_v_last)) && (!grad_v_init || aligned16(grad_v_init));
+  // the BPTT pass keeps y, h and grad_s of T steps per channel in registers: 2 channels per thread; the rest 4
+  const int vec1 = al ? vec_for(C, 2) : 1, vec2 = al ? vec_for(C, 4) : 1;
+#define SPK_BWD1_ARGS grad_spike_seq, grad_v_last, y, gamma, beta, save_mean, save_invstd, v_init, grad_y, grad_v_init, (double*)ws
+  int S;
+  if (vec1 == 2) {
+    S = slices_v(R, C, 2);
+    const GeoV g = geo_v(T, R, C, 2, S);
+    if (detach_reset)
+      hipLaunchKernelGGL((bn_lif_bwd1_v_kernel<2, true>), dim3(S), dim3(TPB), 0, stream, SPK_BWD1_ARGS, g, tau, v_threshold,
+                         v_reset, alpha);
+    else
+      hipLaunchKernelGGL((bn_lif_bwd1_v_kernel<2, false>), dim3(S), dim3(TPB), 0, stream, SPK_BWD1_ARGS, g, tau, v_threshold,
+                         v_reset, alpha);
+  } else {
+    S = slices(R, C);
+    const Geo g{T, R, C, S};
+    const dim3 grid((C + 63) / 64, S);
+    if (detach_reset)
+      hipLaunchKernelGGL(bn_lif_bwd1_kernel<true>, grid, dim3(TPB), 0, stream, SPK_BWD1_ARGS, g, tau, v_threshold, v_reset, alpha);
+    else
+      hipLaunchKernelGGL(bn_lif_bwd1_kernel<false>, grid, dim3(TPB), 0, stream, SPK_BWD1_ARGS, g, tau, v_threshold, v_reset, alpha);
+  }
+#undef SPK_BWD1_ARGS
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + NW - 1) / NW), dim3(TPB), 0, stream, (const double*)ws, S, C, grad_gamma,
                      grad_beta);
-  hipLaunchKernelGGL(bn_bwd2_kernel, grid, dim3(TPB), 0, stream, y, gamma, save_mean, save_invstd, grad_gamma, grad_beta,
-                     grad_y, g, (float)(1.0 / ((double)T * B * HW)));
+  if (vec2 >= 2) {
+    const int S2 = slices_v(R, C, vec2);
+    const GeoV g = geo_v(T, R, C, vec2, S2);
+    if (vec2 == 4)
+      hipLaunchKernelGGL(bn_bwd2_v_kernel<4>, dim3(S2), dim3(TPB), 0, stream, y, gamma, save_mean, save_invstd, grad_gamma,
+                         grad_beta, grad_y, g, inv_M);
+    else
+      hipLaunchKernelGGL(bn_bwd2_v_kernel<2>, dim3(S2), dim3(TPB), 0, stream, y, gamma, save_mean, save_invstd, grad_gamma,
+                         grad_beta, grad_y, g, inv_M);
+  } else {
+    const int S2 = slices(R, C);
+    const Geo g{T, R, C, S2};
+    hipLaunchKernelGGL(bn_bwd2_kernel, dim3((C + 63) / 64, S2), dim3(TPB), 0, stream, y, gamma, save_mean, save_invstd,
+                       grad_gamma, grad_beta, grad_y, g, inv_M);
+  }
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

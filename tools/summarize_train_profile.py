@@ -2,7 +2,7 @@
 
 usage: python tools/summarize_train_profile.py <kernel_trace.csv> <timed steps>
 The first calls contain the library's convolution algorithm search; only the last <timed steps> iterations are kept
-(an iteration starts at its first bn_stats_kernel launch: 5 per iteration)."""
+(an iteration starts at its first bn_stats launch: 5 per iteration)."""
 import csv
 import sys
 from collections import defaultdict
@@ -10,7 +10,7 @@ from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2])
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "bn_stats_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "bn_stats" in r["Kernel_Name"]]
 sel = rows[idx[-5 * steps]:]
 d = defaultdict(list)
 for r in sel:
