@@ -102,6 +102,16 @@ int spk_bn_lif_train_bwd(const float* grad_spike_seq, const float* grad_v_last, 
                          float* grad_y, float* grad_gamma, float* grad_beta, float* grad_v_init, void* ws,
                          long long ws_bytes, int T, int B, int C, int HW, float tau, float v_threshold, float v_reset,
                          float alpha, int detach_reset, spk_stream_t stream);
+/* Training forward of a denoiser convolution on spike input (layer.Conv2d 'm' mode in train(), SJ/activation_based/layer.py:164-173,
+ * for conv2..conv5 of DummyModel, R/snn_model/vq_diffusion.py:166-184): the exact fp6 x fp4 MFMA convolution of
+ * spk_den_conv3x3_mfma_fp6 with the pre-activations (conv + bias, correctly rounded fp32 of the exact dot product) written
+ * out instead of the fused BN + LIF -- batch-statistics BN needs all of them first.  in_c4 as for the inference kernel;
+ * pre_nhwc fp32 channels-last [T][B][H*W][Cout].  spk_spikes_nhwc_to_fp4 packs channels-last fp32 spikes [T][B][HW][C]
+ * (the output of spk_bn_lif_train_fwd) into the C4 input layout. */
+int spk_den_conv3x3_fp6_raw(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* scale, const double* bias_d,
+                            float* pre_nhwc, int T, int B, int H, int W, int Cout, spk_stream_t stream);
+int spk_spikes_nhwc_to_fp4(const float* spikes_nhwc, uint8_t* out_c4, int T, int B, int C, int HW, spk_stream_t stream);
+
 /* Masked cross-entropy of AbsorbingDiffusion._train_loss (R/snn_model/vq_diffusion.py:85-88: F.cross_entropy with
  * ignore_index=-1, reduction='none') and its gradient in one pass.  logits / dlogits [B,K,HW] fp32; target [B,HW] fp32
  * token ids (-1 = ignored, as x_0_ignore); coef [B] per-sample gradient factor; ce_out [B,HW] (0 where ignored).

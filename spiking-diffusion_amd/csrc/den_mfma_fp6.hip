@@ -46,6 +46,7 @@ struct Fp6Args {
   const uint8_t* in0; int nch0;
   const uint8_t* wq; const double* scale; const double* bias; const float* bn_a; const float* bn_b;
   uint8_t* out; float* v_io; uint8_t* out_cnt;
+  float* pre;  // RAW form only: pre-activations (conv + bias) fp32, channels-last [T][B][HW][Cout]
   int B, H, W, Cout;
   int gx;      // > 0: XCD-aware item walk with gx channel groups per XCD (see the kernel); 0: image-major
 };
@@ -77,7 +78,9 @@ struct Fp6Args {
 constexpr int NPA = 7;         // A-slab DMA pieces per wave
 constexpr int N_AGPR = 16;     // accumulators (row tile i, column tile j: index 3*i + j) that live in AGPRs (256 registers)
 
-template <int NT>
+// RAW = true: the training forward -- the same exact pre-activations written as fp32 instead of
+// the BN + LIF scan (batch-statistics BN needs them all before any neuron can be stepped).
+template <int NT, bool RAW = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int HW = a.H * a.W, PW = a.W + 1;
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
     decode(item, b, g);
     const int co = g * 16 + ch;
     const double sc = a.scale[co], bi = a.bias[co];
-    const float bn_a = a.bn_a[co], bn_b = a.bn_b[co];
+    const float bn_a = RAW ? 1.0f : a.bn_a[co], bn_b = RAW ? 0.0f : a.bn_b[co];
     for (int c = 0; c < nchunks; ++c, ++it) {
       const int buf = it & 1;
       long long tq0 = 0, tq1 = 0, tq2 = 0;
@@ -359,6 +362,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
       const int ti = wave + 4 * (odd ? ib : ia);
       const int p = 2 * ti + half;                  // accumulator lane-half == position within the tile
       const bool pos_ok = p < HW && (paired || !odd);
+      if constexpr (RAW) {
+        // x[r] = pre-activation of neuron (b, p, co) at t = r; 16 consecutive channels (64 B) per 16-lane row and step
+        if (pos_ok) {
+          float* dst = a.pre + ((long long)b * HW + p) * a.Cout + co;
+          const long long tstride = (long long)a.B * HW * a.Cout;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[r * tstride] = x[r];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
       const long long vidx = ((long long)b * a.Cout + co) * HW + (pos_ok ? p : 0);
       float v = a.v_io ? a.v_io[vidx] : 0.f;
       unsigned mybits = 0;                    // bit r = this lane's neuron fired at t = r
@@ -407,6 +421,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
 // for the corner); operands come straight from L2 (16 B of spikes and 24 B of weights per lane and MFMA), no LDS.
 // ~3 % of the main kernel's MFMA count.
 constexpr int LP_TILES = 2;      // 32-row tiles (= image pairs) per wave: a weight fragment serves 2 x 3 MFMAs
+template <bool RAW = false>
 __global__ __launch_bounds__(256) void conv3x3_fp6_lastpos_kernel(Fp6Args a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int HW = a.H * a.W, nchunks = a.nch0;
@@ -457,7 +472,7 @@ __global__ __launch_bounds__(256) void conv3x3_fp6_lastpos_kernel(Fp6Args a) {
   const int col = lane & 31, ch = col & 15, odd = col >> 4;
   const int co = g * 16 + ch;
   const double sc = a.scale[co], bi = a.bias[co];
-  const float bn_a = a.bn_a[co], bn_b = a.bn_b[co];
+  const float bn_a = RAW ? 1.0f : a.bn_a[co], bn_b = RAW ? 0.0f : a.bn_b[co];
   // tiles are finished in pairs exactly like the main kernel's: even lanes tile ia, odd lanes tile ia + 1
 #pragma unroll
   for (int ia = 0; ia < LP_TILES; ia += 2) {
@@ -477,6 +492,15 @@ __global__ __launch_bounds__(256) void conv3x3_fp6_lastpos_kernel(Fp6Args a) {
     }
     const int b = b0 + 2 * (ia + odd) + half;          // accumulator lane-half == image within the tile's pair
     const bool ok = b < a.B;
+    if constexpr (RAW) {
+      if (ok) {
+        float* dst = a.pre + ((long long)b * HW + p) * a.Cout + co;
+        const long long tstride = (long long)a.B * HW * a.Cout;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[r * tstride] = x[r];
+      }
+      continue;
+    }
     const long long vidx = ((long long)(ok ? b : 0) * a.Cout + co) * HW + p;
     float v = (a.v_io && ok) ? a.v_io[vidx] : 0.f;
     unsigned mybits = 0;
@@ -617,13 +641,11 @@ extern "C" int spk_den_pack_weight_fp6(const float* w, const float* bias, uint8_
   return SPK_OK;
 }
 
-extern "C" int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* scale,
-                                        const double* bias_d, const float* bn_a, const float* bn_b, float* v_inout,
-                                        uint8_t* out_c4, uint8_t* out_counts, int T, int B, int H, int W, int Cout,
-                                        hipStream_t stream) {
-  if (!in_c4 || nch <= 0 || !wq || !scale || !bias_d || !bn_a || !bn_b || !out_c4 || B <= 0 || H <= 0 || W <= 0 ||
-      Cout <= 0)
-    return SPK_ERR_ARG;
+namespace {
+template <bool RAW>
+int launch_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* scale, const double* bias_d, const float* bn_a,
+               const float* bn_b, float* v_inout, uint8_t* out_c4, uint8_t* out_counts, float* pre, int T, int B, int H,
+               int W, int Cout, hipStream_t stream) {
   if (T != T16 || (Cout % 64)) return SPK_ERR_UNSUPPORTED;
   const int ntiles = (H * W + 1) / 2;
   const int npa = (H * ((W + 1) / 2) + 3) / 4;
@@ -633,7 +655,7 @@ extern "C" int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uin
   const bool split_last = ((H * W) & 1) && (H * W) / 2 <= 24 && H >= 2 && W >= 2;
   Fp6Args a;
   a.in0 = in_c4; a.nch0 = nch; a.wq = wq; a.scale = scale; a.bias = bias_d; a.bn_a = bn_a; a.bn_b = bn_b;
-  a.out = out_c4; a.v_io = v_inout; a.out_cnt = out_counts; a.B = B; a.H = H; a.W = W; a.Cout = Cout;
+  a.out = out_c4; a.v_io = v_inout; a.out_cnt = out_counts; a.pre = pre; a.B = B; a.H = H; a.W = W; a.Cout = Cout;
   const int cus = spk_cu_count();
   const int G = Cout / 16, total = B * G;
   dim3 grid(total < cus ? total : cus), blk(256);          // persistent: one workgroup per CU
@@ -652,12 +674,65 @@ extern "C" int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uin
     if (gx >= 4 && G % gx == 0 && nsets <= 8 && 8 % nsets == 0 && S % gx == 0 && B % ((8 / nsets) * (S / gx)) == 0) a.gx = gx;
   }
   if (split_last) {
-    hipLaunchKernelGGL(conv3x3_fp6_kernel<6>, grid, blk, lds, stream, a);
+    hipLaunchKernelGGL((conv3x3_fp6_kernel<6, RAW>), grid, blk, lds, stream, a);
     SPK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv3x3_fp6_lastpos_kernel, dim3((B + 2 * LP_TILES - 1) / (2 * LP_TILES), G / 4), blk, 0, stream, a);
+    hipLaunchKernelGGL(conv3x3_fp6_lastpos_kernel<RAW>, dim3((B + 2 * LP_TILES - 1) / (2 * LP_TILES), G / 4), blk, 0, stream, a);
   } else {
-    hipLaunchKernelGGL(conv3x3_fp6_kernel<7>, grid, blk, lds, stream, a);
+    hipLaunchKernelGGL((conv3x3_fp6_kernel<7, RAW>), grid, blk, lds, stream, a);
   }
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+}  // namespace
+
+extern "C" int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* scale,
+                                        const double* bias_d, const float* bn_a, const float* bn_b, float* v_inout,
+                                        uint8_t* out_c4, uint8_t* out_counts, int T, int B, int H, int W, int Cout,
+                                        hipStream_t stream) {
+  if (!in_c4 || nch <= 0 || !wq || !scale || !bias_d || !bn_a || !bn_b || !out_c4 || B <= 0 || H <= 0 || W <= 0 ||
+      Cout <= 0)
+    return SPK_ERR_ARG;
+  return launch_fp6<false>(in_c4, nch, wq, scale, bias_d, bn_a, bn_b, v_inout, out_c4, out_counts, nullptr, T, B, H, W, Cout,
+                           stream);
+}
+
+extern "C" int spk_den_conv3x3_fp6_raw(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* scale,
+                                       const double* bias_d, float* pre_nhwc, int T, int B, int H, int W, int Cout,
+                                       hipStream_t stream) {
+  if (!in_c4 || nch <= 0 || !wq || !scale || !bias_d || !pre_nhwc || B <= 0 || H <= 0 || W <= 0 || Cout <= 0)
+    return SPK_ERR_ARG;
+  return launch_fp6<true>(in_c4, nch, wq, scale, bias_d, nullptr, nullptr, nullptr, nullptr, nullptr, pre_nhwc, T, B, H, W,
+                          Cout, stream);
+}
+
+namespace {
+// channels-last fp32 spikes [T][B][HW][C] -> C4: one thread = 4 consecutive channels of one (t, b, hw) = one 16-bit word
+__global__ void spikes_nhwc_to_fp4_kernel(const float* __restrict__ s, uint8_t* __restrict__ o, int T, int B, int C, int HW) {
+  const long long total = (long long)T * B * HW * (C / 4);
+  const int Q = C / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % Q);
+    const long long row = i / Q;                       // (t * B + b) * HW + hw
+    const int hw = (int)(row % HW);
+    const long long tb = row / HW;
+    const int b = (int)(tb % B), t = (int)(tb / B);
+    const float4 v = reinterpret_cast<const float4*>(s)[i];
+    const unsigned w = (v.x != 0.f ? 0x2u : 0u) | (v.y != 0.f ? 0x20u : 0u) | (v.z != 0.f ? 0x200u : 0u) |
+                       (v.w != 0.f ? 0x2000u : 0u);
+    const int c = q * 4;
+    uint8_t* dst = o + ((((long long)b * (C >> 6) + (c >> 6)) * HW + hw) * T + t) * 32 + ((c & 63) >> 1);
+    *reinterpret_cast<uint16_t*>(dst) = (uint16_t)w;
+  }
+}
+}  // namespace
+
+extern "C" int spk_spikes_nhwc_to_fp4(const float* spikes_nhwc, uint8_t* out_c4, int T, int B, int C, int HW,
+                                      hipStream_t stream) {
+  if (!spikes_nhwc || !out_c4 || T <= 0 || B <= 0 || C <= 0 || HW <= 0) return SPK_ERR_ARG;
+  if (C % 64) return SPK_ERR_UNSUPPORTED;
+  const long long total = (long long)T * B * HW * (C / 4);
+  hipLaunchKernelGGL(spikes_nhwc_to_fp4_kernel, dim3(spk_blocks(total, 256) > 65536 ? 65536 : spk_blocks(total, 256)),
+                     dim3(256), 0, stream, spikes_nhwc, out_c4, T, B, C, HW);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

@@ -123,18 +123,31 @@ class FusedSequential(nn.Sequential):
                     return False
         return True
 
-    def train_forward(self, x):
+    # exact MFMA forward for spike-input 3x3 convolutions in training (ops.SpikeConvTrainFunction); False = library forward
+    exact_train_forward = True
+
+    def train_forward(self, x, binary_input=False):
         """[T,B,C,H,W] -> spikes [T,B,C',H',W'] (or the raw conv output of a conv-only last block), differentiable.
-        Convolution: ROCm library operator through torch; BN + LIF: ops.BNLIFTrainFunction (one native operator)."""
+        Convolution: ROCm library operator through torch -- or, when the caller states that x holds spikes
+        (``binary_input``) and the shape fits, the exact fp6 MFMA forward with the library backward; BN + LIF:
+        ops.BNLIFTrainFunction (one native operator)."""
         for conv, bn, lif in self._blocks():
             w = conv.weight
             if w.dim() == 4 and not w.is_contiguous(memory_format=torch.channels_last):
                 # keep the parameter itself channels-last while training: the library's NHWC kernels then read it (and
                 # write its gradient) without a per-call layout copy; values, shape and state_dict keys are unchanged
                 w.data = w.data.contiguous(memory_format=torch.channels_last)
-            x = conv(x)
+            if (binary_input and self.exact_train_forward and isinstance(conv, layer.Conv2d) and conv.groups == 1
+                    and tuple(conv.dilation) == (1, 1) and conv.padding_mode == 'zeros'
+                    and ops.den_fp6_supported(conv.out_channels, conv.in_channels, conv.kernel_size[0], conv.stride[0],
+                                              conv.padding[0] if not isinstance(conv.padding, str) else -1, x.shape[0],
+                                              x.shape[3], x.shape[4]) and conv.kernel_size[0] == conv.kernel_size[1]):
+                x = ops.SpikeConvTrainFunction.apply(x, conv.weight, conv.bias)
+            else:
+                x = conv(x)
             if lif is None:
                 continue
+            binary_input = True                      # what follows a LIF is a spike train
             v0 = lif.v if torch.is_tensor(lif.v) else None
             if v0 is None and float(lif.v) != float(lif.v_reset):
                 v0 = torch.full_like(x[0], float(lif.v))

@@ -608,6 +608,54 @@ def den_conv3x3_mfma_fp6(in0, packed, Cout, *, bn_a, bn_b, v=None, want_counts=F
     return (out, cnt) if want_counts else out
 
 
+def spikes_cl_to_c4(s):
+    """fp32 spikes [T,B,C,H,W] with channels-last memory -> C4 [B, C/64, H, W, T, 32]."""
+    s = _cl5(s, "spikes")
+    T, B, C, H, W = s.shape
+    o = torch.empty((B, C // 64, H, W, T, 32), dtype=C4_DTYPE, device=s.device)
+    check(lib.spk_spikes_nhwc_to_fp4(_p(s), _p(o), T, B, C, H * W, _stream(s)), "spk_spikes_nhwc_to_fp4")
+    return o
+
+
+def den_conv3x3_fp6_raw(in0, packed, Cout):
+    """in0: C4 spikes [B, C/64, H, W, 16, 32] -> exact pre-activations fp32 [T,B,Cout,H,W], channels-last memory."""
+    in0 = _dev(in0, "in0", C4_DTYPE)
+    B, nch, H, W, T, rec = in0.shape
+    wq, scale, bias_d = packed
+    y = _empty_cl((T, B, Cout, H, W), in0.device)
+    check(lib.spk_den_conv3x3_fp6_raw(_p(in0), nch, _p(wq), _p(scale), _p(bias_d), _p(y), T, B, H, W, Cout, _stream(in0)),
+          "spk_den_conv3x3_fp6_raw")
+    return y
+
+
+class SpikeConvTrainFunction(torch.autograd.Function):
+    """y = conv3x3(spikes, weight) + bias for BINARY input spikes in training: the forward is the exact
+    fp6 x fp4 MFMA convolution (weights re-packed into six radix-32 digit planes each call -- they change every optimizer
+    step -- spikes packed to C4), the backward is the library's (aten convolution_backward: dense fp32 GEMMs with no
+    spike structure to exploit).  spikes [T,B,Cin,H,W] in {0,1}; returns channels-last [T,B,Cout,H,W]."""
+
+    @staticmethod
+    def forward(ctx, spikes, weight, bias):
+        s = _cl5(spikes, "spikes")
+        Cout = int(weight.shape[0])
+        with timed("train.conv_fwd_fp6"):
+            y = den_conv3x3_fp6_raw(spikes_cl_to_c4(s), den_pack_weight_fp6(weight, bias), Cout)
+        ctx.save_for_backward(s, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        s, weight = ctx.saved_tensors
+        gy = _cl5(grad_y, "grad_y").flatten(0, 1)
+        gi, gw, gb = torch.ops.aten.convolution_backward(
+            gy, s.flatten(0, 1), weight, [int(weight.shape[0])], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+            [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), bool(ctx.has_bias and ctx.needs_input_grad[2])])
+        if gi is not None:
+            gi = gi.view(s.shape)
+        return gi, gw, gb
+
+
 def spikes_to_c4(s):
     """fp32 [T,B,C,H,W] -> C4 [B, C/64, H, W, T, 32]."""
     s = _dev(s, "spikes", torch.float32)

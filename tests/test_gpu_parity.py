@@ -576,6 +576,33 @@ def test_bn_lif_train_operator_vs_oracle(dev, ops, shape, det, with_v):
             assert _rel_l2(got.cpu(), want) <= 2e-5, _rel_l2(got.cpu(), want)
 
 
+@pytest.mark.parametrize("B,cin,cout,hw", [(3, 64, 128, (7, 7)), (5, 128, 64, (6, 6)), (2, 256, 64, (7, 5))])
+def test_spike_conv_train_forward_exact_and_library_backward(dev, ops, B, cin, cout, hw):
+    """ops.SpikeConvTrainFunction (spk_spikes_nhwc_to_fp4 + spk_den_pack_weight_fp6 + spk_den_conv3x3_fp6_raw): the
+    training forward of a spike-input 3x3 convolution is the correctly rounded fixed-point-exact dot product (fp64 oracle
+    to one fp32 rounding), written channels-last; weight / bias / input gradients come from the library and match the oracle's autograd."""
+    g = torch.Generator().manual_seed(B * cin + cout)
+    s = (torch.rand(16, B, cin, *hw, generator=g) < 0.07).float()
+    w = (torch.rand(cout, cin, 3, 3, generator=g) - 0.5) * 0.1
+    bias = torch.randn(cout, generator=g) * 0.1
+    gy = torch.randn(16, B, cout, *hw, generator=g)
+    so, wo, bo = s.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yo = ref.seq_conv2d(so, wo, bo, 1, 1)
+    (yo * gy).sum().backward()
+    exact = ref.seq_conv2d(s.double(), w.double(), bias.double(), 1, 1).float()
+    sd_, wd, bd = (a.clone().to(dev).requires_grad_(True) for a in (s, w, bias))
+    y = ops.SpikeConvTrainFunction.apply(sd_, wd, bd)
+    assert y.permute(0, 1, 3, 4, 2).is_contiguous()
+    (y * gy.to(dev)).sum().backward()
+    # six radix-32 digits = 29-bit fixed point per output channel: weights below 2^-6 of their channel's maximum (1.5 % of
+    # these uniform ones) are rounded at 2^-29 of it, so a result may sit one fp32 rounding away from the fp64 value
+    yc = y.detach().cpu()
+    assert float((yc - exact).abs().max()) <= 2.5e-7 * (1 + float(exact.abs().max()))
+    assert float((yc != exact).float().mean()) <= 0.05, "not (almost everywhere) the correctly rounded exact dot product"
+    for got, want in ((sd_.grad, so.grad), (wd.grad, wo.grad), (bd.grad, bo.grad)):
+        assert _rel_l2(got.cpu(), want) <= 1e-5, _rel_l2(got.cpu(), want)
+
+
 @pytest.mark.parametrize("B,K,hw", [(4, 128, (7, 7)), (3, 128, (8, 8)), (2, 10, (3, 5))])
 def test_masked_ce_vs_torch(dev, ops, B, K, hw):
     """spk_masked_ce: cross-entropy with ignore_index=-1 and its gradient, against torch's F.cross_entropy on CPU
