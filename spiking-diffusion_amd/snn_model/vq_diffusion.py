@@ -300,7 +300,8 @@ class DummyModel(nn.Module):
             cat = cat.view((T, x1.shape[1]) + tuple(cat.shape[1:]))
         else:
             cat = torch.cat((x5, x1), dim=2)
-        x6 = self.conv6(cat)
+        c6 = self.conv6
+        x6 = c6.train_forward(cat, binary_input=True) if c6._trainable_fused(c6._blocks(), cat) else c6(cat)
         return torch.sum(x6, dim=0) / T
 
     def forward(self, x, t) -> torch.Tensor:
