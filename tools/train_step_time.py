@@ -1,7 +1,8 @@
 """Time the diffusion training step (train_iter + backward + AdamW step + reset_net, R/main.py:243-252) on one GPU.
 
 usage: python tools/train_step_time.py [B] [steps] [--modular]
---modular runs the blocks module by module (library BatchNorm + LIF-only HIP pair) instead of the fused BN+LIF operator."""
+--modular runs the blocks module by module (library convolution and BatchNorm + the LIF-only HIP pair) instead of the fused
+graph; --library-forward keeps the fused block tails but uses the library's forward convolutions."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "spiking-diffusion_amd"), ROOT]
@@ -13,7 +14,13 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 B = int(args[0]) if args else 32
 steps = int(args[1]) if len(args) > 1 else 10
 if "--modular" in sys.argv:
-    fused.FusedSequential._trainable_fused = lambda self, blocks, x: False
+    def _module_by_module(self, x, binary_input=False):
+        for m in self:
+            x = m(x)
+        return x
+    fused.FusedSequential.train_forward = _module_by_module
+if "--library-forward" in sys.argv:
+    fused.FusedSequential.exact_train_forward = False
 dev = torch.device("cuda")
 den = DummyModel(1, 128).cuda(0)
 functional.set_step_mode(net=den, step_mode='m')
