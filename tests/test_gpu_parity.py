@@ -671,6 +671,33 @@ def test_f9_diffusion_train_step_vs_reference_fixture(golden_dir, dev):
     assert den.conv1[2].v == 0.0
 
 
+def test_diffusion_train_step_8x8_latent_vs_live_oracle(dev):
+    """BASELINE config 4 shapes in training (8x8 latent, 64 diffusion steps; parity unpinned by the reference, whose
+    AbsorbingDiffusion hard-codes 7x7): the HIP training graph -- library forward here, the fp6 forward does not hold an
+    8x8 image -- against the oracle's restatement on the same (t, u): loss 1e-3 relative, gradient norms 2 %."""
+    from snn_model.vq_diffusion import AbsorbingDiffusion, functional
+    den, sd = build_den(synth.CIFAR, dev)
+    den.train()
+    ab = AbsorbingDiffusion(den, mask_id=128, latent_shape=(8, 8))
+    g = torch.Generator().manual_seed(88)
+    x0 = torch.randint(0, 128, (2, 1, 8, 8), generator=g).float()
+    t = torch.tensor([9, 40])
+    u = torch.rand(2, 1, 8, 8, generator=g)
+    sdo = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
+           for k, v in sd.items()}
+    want, (_, x_t, x0i, mask, want_logits) = ref.train_loss(x0, sdo, 128, num_timesteps=64, t=t, u=u)
+    want.backward()
+    logits = den(x_t.to(dev), t.to(dev))
+    loss = ab._loss_from_logits(logits, x0i.to(dev), t.to(dev))
+    loss.backward()
+    functional.reset_net(den)
+    assert logits.shape == (2, 128, 8, 8) and ab.num_timesteps == 64
+    assert abs(float(loss.detach()) - float(want.detach())) <= 1e-3 * float(want.detach())
+    for k, p in den.named_parameters():
+        n = float(sdo[k].grad.norm())
+        assert abs(float(p.grad.norm()) - n) <= 2e-2 * n + 1e-7, (k, float(p.grad.norm()), n)
+
+
 def test_train_iter_fused_vs_module_by_module_and_optimizer_step(dev):
     """The fused training graph (FusedSequential.train_forward) against the same model run module by module (library
     BatchNorm + the LIF-only HIP pair): same loss and gradients; then the reference's training loop body
