@@ -147,12 +147,15 @@ int spk_pack_conv_weight(const float* w, float* packed, int Cout, int Cin, int k
  *                out_u8 = uint8(clip(p+0.5,0,1)*255) (R/main.py:401).   mode MEAN: out_f32 = sum_t x[t] / T.
  *   chunk0 / chunk1 / chunk_out: channel chunking of in0 / in1 / out_ptc (0: plain PTC); chunk_out = SPK_CHUNK_C4:
  *                out_ptc is written as nibble-packed fp4 "C4" (see spk_den_conv3x3_mfma_fp6; Cout % 64 == 0).
- *   out_counts (mode LIF, optional): per-neuron spike counts over T, u8 [B,Cout/32,Ho*Wo,32]. */
+ *   out_counts (mode LIF, optional): per-neuron spike counts over T, u8 [B,Cout/32,Ho*Wo,32].
+ *   n_dyn_or_null: optional device-side image count (<= B, see spk_select_active): only images [0, *n_dyn) are computed;
+ *                buffers stay sized by B. */
 int spk_conv_fused_fwd(const void* in0, const uint8_t* in1, int C0, int C1, int in_kind, const float* w_packed,
                        const float* bias, const float* bn_a, const float* bn_b, float* v_inout, uint8_t* out_ptc,
                        float* out_f32, float* out_pre, uint8_t* out_u8, const float* coef, int apply_tanh, int mode,
                        int T, int B, int H, int W, int Cout, int k, int stride, int pad, int transposed, int out_pad,
-                       int chunk0, int chunk1, int chunk_out, uint8_t* out_counts, spk_stream_t stream);
+                       int chunk0, int chunk1, int chunk_out, uint8_t* out_counts, const int* n_dyn_or_null,
+                       spk_stream_t stream);
 
 /* ---- denoiser convolutions on the matrix cores ------------------------------------------------------------------ */
 /* Bytes of the packed int8 digit-plane weights of one 3x3 layer ([Cout/16][Cin/32][9][2][32][32]); -1 if unsupported. */
@@ -172,10 +175,11 @@ int spk_den_conv3x3_mfma(const uint8_t* in0_cptc, int nch0, const uint8_t* in1_c
                          int H, int W, int Cout, spk_stream_t stream);
 /* conv6 + time mean of DummyModel (R/snn_model/vq_diffusion.py:185-187,205-206) in its time-collapsed form:
  * (sum_t conv(s_t)) / T = (conv_linear(sum_t s_t) + T*bias) / T.  cnt0 / cnt1: spike counts u8 [B,nch,h*w,32]
- * (channel concat: cnt1 after cnt0); same packed weights as spk_den_conv3x3_mfma; out_f32 [B,Cout,h,w]. */
+ * (channel concat: cnt1 after cnt0); same packed weights as spk_den_conv3x3_mfma; out_f32 [B,Cout,h,w].
+ * n_dyn_or_null as in spk_conv_fused_fwd. */
 int spk_den_conv3x3_counts_mfma(const uint8_t* cnt0, int nch0, const uint8_t* cnt1, int nch1, const int8_t* wq,
                                 const double* scale, const double* bias_d, float* out_f32, int T, int B, int H, int W,
-                                int Cout, spk_stream_t stream);
+                                int Cout, const int* n_dyn_or_null, spk_stream_t stream);
 
 /* ---- denoiser convolutions on the block-scaled fp6/fp4 MFMA (CDNA4 v_mfma_scale_f32_32x32x64_f8f6f4) -------------- */
 /* Same operator and numerics contract as spk_den_conv3x3_mfma (LIF mode: DummyModel conv2..conv5,
@@ -190,10 +194,11 @@ long long spk_den_packed_weight_fp6_bytes(int Cout, int Cin);
 int spk_den_pack_weight_fp6(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d, int Cout,
                             int Cin, spk_stream_t stream);
 /* in_c4: nch chunks of 64 channels; out_c4 [B][Cout/64][h*w][16][32]; v_inout / out_counts as in spk_den_conv3x3_mfma.
- * SPK_ERR_UNSUPPORTED unless T == 16, Cout % 64 == 0 and the latent fits the kernel's LDS plan (7x7). */
+ * SPK_ERR_UNSUPPORTED unless T == 16, Cout % 64 == 0 and the latent fits the kernel's LDS plan (7x7).
+ * n_dyn_or_null as in spk_conv_fused_fwd (the work items are then walked image-major). */
 int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* scale, const double* bias_d,
                              const float* bn_a, const float* bn_b, float* v_inout, uint8_t* out_c4, uint8_t* out_counts,
-                             int T, int B, int H, int W, int Cout, spk_stream_t stream);
+                             int T, int B, int H, int W, int Cout, const int* n_dyn_or_null, spk_stream_t stream);
 /* fp32 spikes [T,B,C,HW] <-> C4 (C % 64 == 0): module boundaries and tests. */
 int spk_spikes_to_fp4(const float* spikes, uint8_t* out_c4, int T, int B, int C, int HW, spk_stream_t stream);
 int spk_fp4_to_spikes(const uint8_t* in_c4, float* spikes, int T, int B, int C, int HW, spk_stream_t stream);
@@ -230,18 +235,31 @@ int spk_embedding_fwd(const long long* tokens, const float* codebook, float* out
                       int nchw, spk_stream_t stream);
 
 /* ---- sampler ---------------------------------------------------------------------------------------------------- */
-/* cat(x, ones_like(x)*t) of DummyModel.forward, R/snn_model/vq_diffusion.py:195-197 -> fp32 [B,2,h,w]. */
+/* Images touched by reverse step t.  R/snn_model/vq_diffusion.py:113-124 computes `changes = (u < 1/t) & ~unmasked`
+ * BEFORE the denoiser call and only scatters the sample there (:140): for an image without a change at step t the
+ * denoiser output is never read.  Writes the ascending list of images with >= 1 change (active_out [B] int32) and its
+ * length (n_active_out [1]); u / Philox arguments exactly as spk_psample_step (same draws).  With sample_steps = 100
+ * and 49 positions an image is touched by 39 % of the steps on average: the per-step kernels take the list / count as
+ * `active` / `n_dyn` arguments and skip the rest -- the same tokens as the dense loop, fewer evaluations. */
+int spk_select_active(const uint8_t* unmasked, int t, const float* u_or_null, unsigned long long philox_seed,
+                      unsigned long long philox_offset, const unsigned long long* philox_state_or_null, int* active_out,
+                      int* n_active_out, int B, int HW, spk_stream_t stream);
+/* cat(x, ones_like(x)*t) of DummyModel.forward, R/snn_model/vq_diffusion.py:195-197 -> fp32 [B,2,h,w].
+ * active / n_active (both or neither): slot s of the output is image active[s], s < *n_active. */
 int spk_den_build_input(const float* x_float_or_null, const long long* x_tokens_or_null, const long long* t_vec_or_null,
-                        long long t_scalar, float* out_b2hw, int B, int HW, spk_stream_t stream);
+                        long long t_scalar, float* out_b2hw, int B, int HW, const int* active_or_null,
+                        const int* n_active_or_null, spk_stream_t stream);
 /* Loop body of AbsorbingDiffusion.sample after the denoiser call, R/snn_model/vq_diffusion.py:113-124,134-140.
  * logits [B,K,h,w] fp32; x_t int64 [B*HW]; unmasked u8/bool [B*HW]; u [B*HW] / q [B*HW*K] injected noise or NULL
  * (then Philox4x32-10(seed, offset + index)); philox_state optional device {seed, base offset} pair that overrides
  * the seed and is added to the offset (lets a captured hipGraph draw fresh noise on every replay);
- * x0_hat_out optional int64 [B*HW]. */
+ * x0_hat_out optional int64 [B*HW].  active / n_active (both or neither; not with x0_hat_out): logits hold one slot
+ * per active image (slot s = image active[s]); noise, x_t and unmasked stay indexed by image. */
 int spk_psample_step(const float* logits_bkhw, long long* x_t_inout, uint8_t* unmasked_inout, int t, float temp,
                      const float* u_or_null, const float* q_or_null, unsigned long long philox_seed,
                      unsigned long long philox_offset, const unsigned long long* philox_state_or_null,
-                     long long* x0_hat_out_or_null, int B, int HW, int K, spk_stream_t stream);
+                     long long* x0_hat_out_or_null, int B, int HW, int K, const int* active_or_null,
+                     const int* n_active_or_null, spk_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -103,13 +103,15 @@ struct FusedArgs {
   uint8_t* out_cnt;     // MODE_LIF, optional: spike counts over T, u8 [B][Cout/32][Ho*Wo][32]
   int chunk0, chunk1, chunk_out;   // channel chunking of the PTC tensors ([B][C/chunk][HW][T][chunk]); chunk == C: plain
   int out_c4;           // out_ptc is nibble-packed fp4 "C4" ([B][Cout/64][HW][T][32 B]) for the fp6 MFMA kernel
+  const int* n_dyn;     // optional device-side batch count (<= B): only the first *n_dyn images are processed
 };
 
 template <int INKIND, bool TRANSPOSED, int MODE>
 __global__ __launch_bounds__(256) void conv_fused_kernel(FusedArgs a) {
   constexpr bool TINV = INKIND == SPK_IN_TINV;
   const int Cin = a.C0 + a.C1;
-  const long long total = (long long)a.B * a.Ho * a.Wo * a.Cout;
+  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;     // buffers and strides stay sized by a.B
+  const long long total = (long long)Bn * a.Ho * a.Wo * a.Cout;
   const int T = a.T;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -324,7 +326,7 @@ extern "C" int spk_conv_fused_fwd(const void* in0, const uint8_t* in1, int C0, i
                                   float* v_inout, uint8_t* out_ptc, float* out_f32, float* out_pre, uint8_t* out_u8,
                                   const float* coef, int apply_tanh, int mode, int T, int B, int H, int W, int Cout,
                                   int k, int stride, int pad, int transposed, int out_pad, int chunk0, int chunk1,
-                                  int chunk_out, uint8_t* out_counts, hipStream_t stream) {
+                                  int chunk_out, uint8_t* out_counts, const int* n_dyn_or_null, hipStream_t stream) {
   if (!in0 || !w_packed || T <= 0 || T > SPK_MAX_T || B <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0 || k <= 0 ||
       stride <= 0 || pad < 0)
     return SPK_ERR_ARG;
@@ -348,6 +350,7 @@ extern "C" int spk_conv_fused_fwd(const void* in0, const uint8_t* in1, int C0, i
   a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.wt = w_packed; a.bias = bias; a.bn_a = bn_a; a.bn_b = bn_b;
   a.v_io = v_inout; a.out_ptc = out_ptc; a.out_f32 = out_f32; a.out_pre = out_pre; a.out_u8 = out_u8; a.coef = coef;
   a.chunk0 = chunk0; a.chunk1 = chunk1; a.chunk_out = chunk_out; a.out_cnt = out_counts; a.out_c4 = out_c4;
+  a.n_dyn = n_dyn_or_null;
   if (out_counts && (mode != SPK_MODE_LIF || (Cout % 32))) return SPK_ERR_ARG;
   a.apply_tanh = apply_tanh; a.T = T; a.B = B; a.H = H; a.W = W; a.Cout = Cout;
   a.Ho = spk_conv_out_size(H, k, stride, pad, transposed, out_pad);

@@ -335,12 +335,14 @@ struct CntArgs {
   const uint8_t* c0; const uint8_t* c1; int nch0, nch1;
   const int8_t* wq; const double* scale; const double* bias; float* out;
   int B, H, W, Cout, T;
+  const int* n_dyn;     // optional device-side batch count (<= B)
 };
 
 __global__ __launch_bounds__(256) void conv3x3_counts_mfma_kernel(CntArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int HW = a.H * a.W;
-  const long long nrows = (long long)a.B * HW;
+  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
+  const long long nrows = (long long)Bn * HW;
   const long long tile = (long long)blockIdx.x * 4 + wave;
   if (tile * 32 >= nrows) return;
   const int g = blockIdx.y;
@@ -481,14 +483,15 @@ extern "C" int spk_den_pack_weight_i8(const float* w, const float* bias, int8_t*
 
 extern "C" int spk_den_conv3x3_counts_mfma(const uint8_t* cnt0, int nch0, const uint8_t* cnt1, int nch1,
                                            const int8_t* wq, const double* scale, const double* bias_d, float* out_f32,
-                                           int T, int B, int H, int W, int Cout, hipStream_t stream) {
+                                           int T, int B, int H, int W, int Cout, const int* n_dyn_or_null,
+                                           hipStream_t stream) {
   if (!cnt0 || nch0 <= 0 || nch1 < 0 || (nch1 > 0 && !cnt1) || !wq || !scale || !bias_d || !out_f32 || B <= 0 ||
       H <= 0 || W <= 0 || Cout <= 0 || T <= 0)
     return SPK_ERR_ARG;
   if (T > 127 || (Cout % 16)) return SPK_ERR_UNSUPPORTED;      // counts must fit the signed int8 A operand
   CntArgs a;
   a.c0 = cnt0; a.c1 = cnt1; a.nch0 = nch0; a.nch1 = nch1; a.wq = wq; a.scale = scale; a.bias = bias_d; a.out = out_f32;
-  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.T = T;
+  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.T = T; a.n_dyn = n_dyn_or_null;
   const long long tiles = ((long long)B * H * W + 31) / 32;
   dim3 grid((unsigned)((tiles + 3) / 4), Cout / 16), blk(256);
   hipLaunchKernelGGL(conv3x3_counts_mfma_kernel, grid, blk, 0, stream, a);

@@ -46,6 +46,7 @@ struct Fp6Args {
   const uint8_t* in0; int nch0;
   const uint8_t* wq; const double* scale; const double* bias; const float* bn_a; const float* bn_b;
   uint8_t* out; float* v_io; uint8_t* out_cnt;
+  const int* n_dyn;   // optional device-side batch count (<= B): only images [0, *n_dyn) are processed
   float* pre;  // RAW form only: pre-activations (conv + bias) fp32, channels-last [T][B][HW][Cout]
   int B, H, W, Cout;
   int gx;      // > 0: XCD-aware item walk with gx channel groups per XCD (see the kernel); 0: image-major
@@ -93,7 +94,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nchunks = a.nch0;
   const int G = a.Cout >> 4;
-  const int total = a.B * G;
+  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
+  const int total = Bn * G;
 
   // zero both A images once: the borders stay zero for the whole kernel, interiors are overwritten by DMA
   for (int i = tid; i < 2 * A_BYTES / 16; i += 256) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
@@ -427,6 +429,8 @@ __global__ __launch_bounds__(256) void conv3x3_fp6_lastpos_kernel(Fp6Args a) {
   const int HW = a.H * a.W, nchunks = a.nch0;
   const int g = blockIdx.y * 4 + wave;                      // Cout % 64 == 0: groups come in fours
   const int b0 = blockIdx.x * 2 * LP_TILES;
+  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
+  if (b0 >= Bn) return;
   const int row = lane & 31, half = lane >> 5;
   const int hsel = (row >> 2) & 1, tt = (row & 3) + 4 * (row >> 3);       // A row -> (image parity, time step)
   const int py = a.H - 1, px = a.W - 1, p = HW - 1;
@@ -458,7 +462,7 @@ __global__ __launch_bounds__(256) void conv3x3_fp6_lastpos_kernel(Fp6Args a) {
       for (int i = 0; i < LP_TILES; ++i) {
         const int bA = b0 + 2 * i + hsel;
         v4i av = {0, 0, 0, 0};
-        if (bA < a.B)
+        if (bA < Bn)
           av = *reinterpret_cast<const v4i*>(a.in0 + ((long long)bA * nchunks + c) * HW * POS_BYTES +
                                              ((yy * a.W + xx) * T16 + tt) * 32 + 16 * half);
         const v8i a8 = {av[0], av[1], av[2], av[3], 0, 0, 0, 0};
@@ -491,7 +495,7 @@ __global__ __launch_bounds__(256) void conv3x3_fp6_lastpos_kernel(Fp6Args a) {
       x[r] = (float)fma(s, sc, bi);
     }
     const int b = b0 + 2 * (ia + odd) + half;          // accumulator lane-half == image within the tile's pair
-    const bool ok = b < a.B;
+    const bool ok = b < Bn;
     if constexpr (RAW) {
       if (ok) {
         float* dst = a.pre + ((long long)b * HW + p) * a.Cout + co;
@@ -644,8 +648,8 @@ extern "C" int spk_den_pack_weight_fp6(const float* w, const float* bias, uint8_
 namespace {
 template <bool RAW>
 int launch_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* scale, const double* bias_d, const float* bn_a,
-               const float* bn_b, float* v_inout, uint8_t* out_c4, uint8_t* out_counts, float* pre, int T, int B, int H,
-               int W, int Cout, hipStream_t stream) {
+               const float* bn_b, float* v_inout, uint8_t* out_c4, uint8_t* out_counts, float* pre, const int* n_dyn, int T,
+               int B, int H, int W, int Cout, hipStream_t stream) {
   if (T != T16 || (Cout % 64)) return SPK_ERR_UNSUPPORTED;
   const int ntiles = (H * W + 1) / 2;
   const int npa = (H * ((W + 1) / 2) + 3) / 4;
@@ -655,7 +659,7 @@ int launch_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* s
   const bool split_last = ((H * W) & 1) && (H * W) / 2 <= 24 && H >= 2 && W >= 2;
   Fp6Args a;
   a.in0 = in_c4; a.nch0 = nch; a.wq = wq; a.scale = scale; a.bias = bias_d; a.bn_a = bn_a; a.bn_b = bn_b;
-  a.out = out_c4; a.v_io = v_inout; a.out_cnt = out_counts; a.pre = pre; a.B = B; a.H = H; a.W = W; a.Cout = Cout;
+  a.out = out_c4; a.v_io = v_inout; a.out_cnt = out_counts; a.pre = pre; a.n_dyn = n_dyn; a.B = B; a.H = H; a.W = W; a.Cout = Cout;
   const int cus = spk_cu_count();
   const int G = Cout / 16, total = B * G;
   dim3 grid(total < cus ? total : cus), blk(256);          // persistent: one workgroup per CU
@@ -666,7 +670,7 @@ int launch_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* s
   // slab requests of an XCD made it slower still).  SPKDIFF_FP6_XCD_WALK=0 selects the image-major walk.
   static const bool xcd_walk = [] { const char* e = getenv("SPKDIFF_FP6_XCD_WALK"); return !(e && e[0] == '0'); }();
   a.gx = 0;
-  if (xcd_walk && (grid.x & 7) == 0) {
+  if (xcd_walk && !n_dyn && (grid.x & 7) == 0) {      // (a device-side batch count walks image-major)
     const int S = grid.x / 8;
     int gx = 1;
     while (gx * 2 <= G && (long long)gx * 2 * nch * W_CHUNK_BYTES <= 1536 * 1024) gx *= 2;
@@ -688,12 +692,12 @@ int launch_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* s
 extern "C" int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* scale,
                                         const double* bias_d, const float* bn_a, const float* bn_b, float* v_inout,
                                         uint8_t* out_c4, uint8_t* out_counts, int T, int B, int H, int W, int Cout,
-                                        hipStream_t stream) {
+                                        const int* n_dyn_or_null, hipStream_t stream) {
   if (!in_c4 || nch <= 0 || !wq || !scale || !bias_d || !bn_a || !bn_b || !out_c4 || B <= 0 || H <= 0 || W <= 0 ||
       Cout <= 0)
     return SPK_ERR_ARG;
-  return launch_fp6<false>(in_c4, nch, wq, scale, bias_d, bn_a, bn_b, v_inout, out_c4, out_counts, nullptr, T, B, H, W, Cout,
-                           stream);
+  return launch_fp6<false>(in_c4, nch, wq, scale, bias_d, bn_a, bn_b, v_inout, out_c4, out_counts, nullptr, n_dyn_or_null, T,
+                           B, H, W, Cout, stream);
 }
 
 extern "C" int spk_den_conv3x3_fp6_raw(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* scale,
@@ -701,8 +705,8 @@ extern "C" int spk_den_conv3x3_fp6_raw(const uint8_t* in_c4, int nch, const uint
                                        hipStream_t stream) {
   if (!in_c4 || nch <= 0 || !wq || !scale || !bias_d || !pre_nhwc || B <= 0 || H <= 0 || W <= 0 || Cout <= 0)
     return SPK_ERR_ARG;
-  return launch_fp6<true>(in_c4, nch, wq, scale, bias_d, nullptr, nullptr, nullptr, nullptr, nullptr, pre_nhwc, T, B, H, W,
-                          Cout, stream);
+  return launch_fp6<true>(in_c4, nch, wq, scale, bias_d, nullptr, nullptr, nullptr, nullptr, nullptr, pre_nhwc, nullptr, T, B,
+                          H, W, Cout, stream);
 }
 
 namespace {

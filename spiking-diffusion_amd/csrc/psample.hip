@@ -61,15 +61,28 @@ __global__ __launch_bounds__(256) void psample_kernel(const float* __restrict__ 
                                                       const float* __restrict__ u_in, const float* __restrict__ q_in,
                                                       unsigned long long seed, unsigned long long offset,
                                                       const unsigned long long* __restrict__ philox_state,
-                                                      long long* __restrict__ x0_hat_out, int B, int HW, int K) {
+                                                      long long* __restrict__ x0_hat_out,
+                                                      const int* __restrict__ active, const int* __restrict__ n_active,
+                                                      int B, int HW, int K) {
   // a captured (hipGraph) launch bakes its arguments: the per-call part of the Philox counter then comes from a
   // 2-word device buffer {seed, base offset} the host updates before each replay
   if (philox_state) { seed = philox_state[0]; offset += philox_state[1]; }
   const int lane = threadIdx.x & 63;
-  const long long npos = (long long)B * HW;
+  // active-set form (spk_select_active): logits hold one slot per ACTIVE image (slot s = image active[s]); noise, x_t
+  // and unmasked stay indexed by image, so the draws are those of the dense form
+  const int Bn = active ? (*n_active < B ? *n_active : B) : B;
+  const long long npos = (long long)Bn * HW;
   const float inv_t = 1.0f / (float)t;
-  for (long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); p < npos; p += (long long)gridDim.x * 4) {
-    const int b = (int)(p / HW), hw = (int)(p % HW);
+  for (long long ps = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); ps < npos; ps += (long long)gridDim.x * 4) {
+    const int b = (int)(ps / HW), hw = (int)(ps % HW);            // b = logits slot
+    const long long p = active ? (long long)active[b] * HW + hw : ps;   // image position: noise / state index
+    if (active) {
+      // only positions that change consume the sample: skip the rest before the softmax (wave-uniform test)
+      float u;
+      if (u_in) u = u_in[p];
+      else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)p, 0u, r); u = u01_open_right(r[0]); }
+      if (!((u < inv_t) && !unmasked[p])) continue;
+    }
     float l[KPL];
     float mx = -INFINITY;
 #pragma unroll
@@ -138,26 +151,82 @@ __global__ __launch_bounds__(256) void psample_kernel(const float* __restrict__ 
 // x comes either as float [B,1,h,w] (the module API) or as the int64 token state x_t of the sampler.
 __global__ void den_input_kernel(const float* __restrict__ xf, const long long* __restrict__ xi,
                                  const long long* __restrict__ t_vec, long long t_scalar, float* __restrict__ out,
-                                 int B, int HW) {
-  const int total = B * HW;
+                                 const int* __restrict__ active, const int* __restrict__ n_active, int B, int HW) {
+  const int Bn = active ? (*n_active < B ? *n_active : B) : B;
+  const int total = Bn * HW;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int b = i / HW, hw = i % HW;
-    const float x = xf ? xf[i] : (float)xi[i];
-    const float tv = (float)(t_vec ? t_vec[b] : t_scalar);
+    const int b = i / HW, hw = i % HW;                            // output slot
+    const int src = active ? active[b] * HW + hw : i;             // active-set form: slot b holds image active[b]
+    const float x = xf ? xf[src] : (float)xi[src];
+    const float tv = (float)(t_vec ? t_vec[active ? active[b] : b] : t_scalar);
     out[((long long)b * 2 + 0) * HW + hw] = x;
     out[((long long)b * 2 + 1) * HW + hw] = 1.0f * tv;
   }
 }
 
+// Which images does reverse step t touch?  R/snn_model/vq_diffusion.py:113-124 computes `changes` BEFORE the denoiser
+// call and scatters x_0_hat only there (:140): for an image without a change at this step the denoiser output is never
+// read and x_t / unmasked stay as they are.  This kernel evaluates the same test (same u: injected or the same Philox
+// counters as spk_psample_step) per image and writes the ascending list of images with at least one change plus its
+// length; the per-step kernels then run on that list only.  One workgroup: the list must be ordered (deterministic slots).
+__global__ __launch_bounds__(256) void select_active_kernel(const uint8_t* __restrict__ unmasked, int t,
+                                                            const float* __restrict__ u_in, unsigned long long seed,
+                                                            unsigned long long offset,
+                                                            const unsigned long long* __restrict__ philox_state,
+                                                            int* __restrict__ active, int* __restrict__ n_active, int B, int HW) {
+  __shared__ int wave_cnt[4];
+  __shared__ int base_s;
+  if (philox_state) { seed = philox_state[0]; offset += philox_state[1]; }
+  const float inv_t = 1.0f / (float)t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < B; b0 += 256) {
+    const int b = b0 + threadIdx.x;
+    bool any = false;
+    if (b < B) {
+      for (int hw = 0; hw < HW && !any; ++hw) {
+        const long long p = (long long)b * HW + hw;
+        if (unmasked[p]) continue;
+        float u;
+        if (u_in) u = u_in[p];
+        else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)p, 0u, r); u = u01_open_right(r[0]); }
+        any = u < inv_t;
+      }
+    }
+    const unsigned long long m = __ballot(any);
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int pre = base_s;
+    for (int w = 0; w < wave; ++w) pre += wave_cnt[w];
+    if (any) active[pre + __popcll(m & ((1ull << lane) - 1ull))] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) base_s += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_active = base_s;
+}
+
 }  // namespace
+
+extern "C" int spk_select_active(const uint8_t* unmasked, int t, const float* u_or_null, unsigned long long philox_seed,
+                                 unsigned long long philox_offset, const unsigned long long* philox_state_or_null,
+                                 int* active_out, int* n_active_out, int B, int HW, hipStream_t stream) {
+  if (!unmasked || !active_out || !n_active_out || t <= 0 || B <= 0 || HW <= 0) return SPK_ERR_ARG;
+  hipLaunchKernelGGL(select_active_kernel, dim3(1), dim3(256), 0, stream, unmasked, t, u_or_null, philox_seed, philox_offset,
+                     philox_state_or_null, active_out, n_active_out, B, HW);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
 
 extern "C" int spk_den_build_input(const float* x_float_or_null, const long long* x_tokens_or_null,
                                    const long long* t_vec_or_null, long long t_scalar, float* out_b2hw, int B, int HW,
-                                   hipStream_t stream) {
+                                   const int* active_or_null, const int* n_active_or_null, hipStream_t stream) {
   if ((!x_float_or_null && !x_tokens_or_null) || !out_b2hw || B <= 0 || HW <= 0) return SPK_ERR_ARG;
+  if ((active_or_null == nullptr) != (n_active_or_null == nullptr)) return SPK_ERR_ARG;
   int total = B * HW;
   hipLaunchKernelGGL(den_input_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, x_float_or_null,
-                     x_tokens_or_null, t_vec_or_null, t_scalar, out_b2hw, B, HW);
+                     x_tokens_or_null, t_vec_or_null, t_scalar, out_b2hw, active_or_null, n_active_or_null, B, HW);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }
@@ -166,15 +235,18 @@ extern "C" int spk_psample_step(const float* logits_bkhw, long long* x_t_inout, 
                                 float temp, const float* u_or_null, const float* q_or_null,
                                 unsigned long long philox_seed, unsigned long long philox_offset,
                                 const unsigned long long* philox_state_or_null, long long* x0_hat_out_or_null, int B,
-                                int HW, int K, hipStream_t stream) {
+                                int HW, int K, const int* active_or_null, const int* n_active_or_null, hipStream_t stream) {
   if (!logits_bkhw || !x_t_inout || !unmasked_inout || t <= 0 || !(temp > 0.f) || B <= 0 || HW <= 0 || K <= 0)
+    return SPK_ERR_ARG;
+  if ((active_or_null == nullptr) != (n_active_or_null == nullptr) || (active_or_null && x0_hat_out_or_null))
     return SPK_ERR_ARG;
   if (K > 64 * KPL) return SPK_ERR_UNSUPPORTED;
   long long npos = (long long)B * HW;
   int grid = (int)((npos + 3) / 4);
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(psample_kernel, dim3(grid), dim3(256), 0, stream, logits_bkhw, x_t_inout, unmasked_inout, t, temp,
-                     u_or_null, q_or_null, philox_seed, philox_offset, philox_state_or_null, x0_hat_out_or_null, B, HW, K);
+                     u_or_null, q_or_null, philox_seed, philox_offset, philox_state_or_null, x0_hat_out_or_null, active_or_null,
+                     n_active_or_null, B, HW, K);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

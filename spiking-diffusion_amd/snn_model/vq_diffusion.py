@@ -64,6 +64,11 @@ class AbsorbingDiffusion(Sampler):
         # 2-word device buffer {seed, counter base} the kernels read (spk_psample_step philox_state).
         self.use_graph = True
         self._graphs = {}
+        # Reverse step t only writes the positions in `changes` (computed before the denoiser call, :113-124,140): an
+        # image without a change at step t never has its denoiser output read.  True = evaluate the denoiser only for the
+        # images spk_select_active lists for the step (61 % of (image, step) pairs drop out at 100 steps x 49 positions);
+        # the sampled tokens are those of the dense loop, draw for draw.  Needs the fp6 kernel family (7x7 latents).
+        self.skip_untouched = True
 
     # ---- training step (R/snn_model/vq_diffusion.py:56-101,144-147) -------------------------
     def sample_time(self, b, device):
@@ -136,19 +141,28 @@ class AbsorbingDiffusion(Sampler):
                 torch.cuda.synchronize(dev)
         x_t = torch.full((b, 1, h, w), int(self.mask_id), dtype=torch.int64, device=dev)
         unmasked = torch.zeros((b, 1, h, w), dtype=torch.bool, device=dev)
+        skip = self._skip_ok(h, w) and record is None
+        act = None
         for t in reversed(range(1, sample_steps + 1)):
             u = q = None
             if noise is not None:
                 u, q = noise(t)
             elif self.noise_source == 'host':
                 u = torch.rand(b, 1, h, w).to(dev)                       # rand_like(x_t.float()), drawn first (:116)
-            logits = dn.logits_from_tokens(x_t, t)                       # denoiser + reset_net (:128-129)
-            if noise is None and self.noise_source == 'host':
-                q = torch.empty(b * h * w, K).exponential_(1).to(dev)    # multinomial's one-draw fast path (:138)
-            ops.psample_step(logits, x_t, unmasked, t, temp, u, q, seed, base + (sample_steps - t) * (b * h * w * K))
+            off = base + (sample_steps - t) * (b * h * w * K)
+            if skip:
+                act = ops.select_active(unmasked, t, u, seed, off, out=act)
+            with ops.active_set(*(act if skip else (None, None))):
+                logits = dn.logits_from_tokens(x_t, t)                   # denoiser + reset_net (:128-129)
+                if noise is None and self.noise_source == 'host':
+                    q = torch.empty(b * h * w, K).exponential_(1).to(dev)    # multinomial's one-draw fast path (:138)
+                ops.psample_step(logits, x_t, unmasked, t, temp, u, q, seed, off)
             if record is not None:
                 record.append((t, x_t.clone(), unmasked.clone(), logits.clone()))
         return x_t
+
+    def _skip_ok(self, h, w):
+        return bool(self.skip_untouched) and self._denoise_fn.impl_for(h, w) == 'mfma-fp6x6' 
 
 
 def _weights_key(module):
@@ -159,7 +173,8 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
     """Capture-once / replay-many form of the loop in ``sample``; same kernels, same results as the eager loop for the
     same (seed, counter base)."""
     dn = self._denoise_fn
-    key = (str(dev), b, h, w, K, temp, sample_steps, int(self.mask_id), _weights_key(dn))
+    skip = self._skip_ok(h, w)
+    key = (str(dev), b, h, w, K, temp, sample_steps, int(self.mask_id), skip, _weights_key(dn))
     entry = self._graphs.get(key)
     if entry is None:
         self._graphs.clear()                                    # one live graph per sampler (buffers are not small)
@@ -167,13 +182,18 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
         x_t = torch.empty((b, 1, h, w), dtype=torch.int64, device=dev)
         unmasked = torch.empty((b, 1, h, w), dtype=torch.bool, device=dev)
 
+        act = (torch.zeros(b, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)) if skip else None
+
         def body():
             x_t.fill_(int(self.mask_id))
             unmasked.zero_()
             for t in reversed(range(1, sample_steps + 1)):
-                logits = dn.logits_from_tokens(x_t, t)
-                ops.psample_step(logits, x_t, unmasked, t, temp, None, None, 0, (sample_steps - t) * (b * h * w * K),
-                                 philox_state=state)
+                off = (sample_steps - t) * (b * h * w * K)
+                if skip:
+                    ops.select_active(unmasked, t, None, 0, off, philox_state=state, out=act)
+                with ops.active_set(*(act if skip else (None, None))):
+                    logits = dn.logits_from_tokens(x_t, t)
+                    ops.psample_step(logits, x_t, unmasked, t, temp, None, None, 0, off, philox_state=state)
 
         # warm-up on a side stream (weight packing, BN terms, allocator pools), then capture
         side = torch.cuda.Stream(device=dev)

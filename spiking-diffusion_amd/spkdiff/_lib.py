@@ -60,17 +60,17 @@ _SIGS = {
     "spk_pack_conv_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spk_conv_fused_fwd": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int,
                                    c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                   c_int, c_int, c_int, P, P]),
+                                   c_int, c_int, c_int, P, P, P]),
     "spk_den_packed_weight_bytes": (c_longlong, [c_int, c_int]),
     "spk_den_pack_weight_i8": (c_int, [P, P, P, P, P, c_int, c_int, P]),
     "spk_den_conv3x3_mfma": (c_int, [P, c_int, P, c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int,
                                      c_int, P]),
     "spk_den_packed_weight_fp6_bytes": (c_longlong, [c_int, c_int]),
     "spk_den_pack_weight_fp6": (c_int, [P, P, P, P, P, c_int, c_int, P]),
-    "spk_den_conv3x3_mfma_fp6": (c_int, [P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "spk_den_conv3x3_mfma_fp6": (c_int, [P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "spk_spikes_to_fp4": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spk_fp4_to_spikes": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
-    "spk_den_conv3x3_counts_mfma": (c_int, [P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "spk_den_conv3x3_counts_mfma": (c_int, [P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "spk_conv_packed_weight_i8_bytes": (c_longlong, [c_int, c_int, c_int]),
     "spk_pack_conv_weight_i8": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "spk_conv_mfma_fused_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -78,9 +78,10 @@ _SIGS = {
     "spk_vq_readout_argmin": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_vq_argmin": (c_int, [P, P, P, c_longlong, c_int, c_int, P]),
     "spk_embedding_fwd": (c_int, [P, P, P, c_longlong, c_int, c_int, c_int, c_int, P]),
-    "spk_den_build_input": (c_int, [P, P, P, c_longlong, P, c_int, c_int, P]),
+    "spk_select_active": (c_int, [P, c_int, P, c_ulonglong, c_ulonglong, P, P, P, c_int, c_int, P]),
+    "spk_den_build_input": (c_int, [P, P, P, c_longlong, P, c_int, c_int, P, P, P]),
     "spk_psample_step": (c_int, [P, P, P, c_int, c_float, P, P, c_ulonglong, c_ulonglong, P, P, c_int, c_int, c_int,
-                                 P]),
+                                 P, P, P]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -15,6 +15,32 @@ SPIKE_F32, SPIKE_U8, SPIKE_BITS = 0, 1, 2
 MAX_T = 16
 
 
+# ---------------------------------------------------------------------------------------------- active-set batch
+# Set by the sampler around one denoiser call (``with ops.active_set(active, n_active)``): the per-step kernels then
+# process only the images listed by spk_select_active -- ``active`` int32 [B] (slot -> image), ``n_active`` int32 [1],
+# both on the device, so that a captured hipGraph replays with fresh lists.  None = every image (dense).
+ACTIVE = None
+
+
+class active_set:
+    def __init__(self, active, n_active):
+        self.pair = None if active is None else (active, n_active)
+
+    def __enter__(self):
+        global ACTIVE
+        self.prev, ACTIVE = ACTIVE, self.pair
+        return self
+
+    def __exit__(self, *exc):
+        global ACTIVE
+        ACTIVE = self.prev
+        return False
+
+
+def _n_dyn():
+    return None if ACTIVE is None else ACTIVE[1].data_ptr()
+
+
 # ---------------------------------------------------------------------------------------------- in-situ kernel timing
 # bench.py switches this on to bracket named launches with HIP events recorded on the SAME stream the kernels
 # are enqueued on (torch's current stream): TIMERS[tag] = [(start_event, end_event), ...].
@@ -493,7 +519,7 @@ def conv_fused(in0, w_packed, bias, *, in_kind, T, mode, k, stride, pad, transpo
     check(lib.spk_conv_fused_fwd(
         _p(in0), _p(in1), C0, C1, in_kind, _p(w_packed), _p(bias), _p(bn_a), _p(bn_b), _p(v), _p(res["ptc"]),
         _p(res["f32"]), _p(res["pre"]), _p(res["u8"]), _p(coef), int(apply_tanh), mode, T, B, H, W, Cout, k, stride,
-        pad, int(transposed), out_pad, chunk0, chunk1, chunk_out or 0, _p(res["cnt"]), _stream(in0)),
+        pad, int(transposed), out_pad, chunk0, chunk1, chunk_out or 0, _p(res["cnt"]), _n_dyn(), _stream(in0)),
         "spk_conv_fused_fwd")
     return res
 
@@ -564,7 +590,7 @@ def den_conv3x3_counts(cnt0, packed, Cout, T, cnt1=None):
     wq, scale, bias_d = packed
     out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=cnt0.device)
     check(lib.spk_den_conv3x3_counts_mfma(_p(cnt0), nch0, _p(cnt1), nch1, _p(wq), _p(scale), _p(bias_d), _p(out), T, B,
-                                          H, W, Cout, _stream(cnt0)), "spk_den_conv3x3_counts_mfma")
+                                          H, W, Cout, _n_dyn(), _stream(cnt0)), "spk_den_conv3x3_counts_mfma")
     return out
 
 
@@ -604,7 +630,7 @@ def den_conv3x3_mfma_fp6(in0, packed, Cout, *, bn_a, bn_b, v=None, want_counts=F
     out = torch.empty((B, Cout // 64, H, W, T, 32), dtype=C4_DTYPE, device=in0.device)
     cnt = torch.empty((B, Cout // 32, H, W, 32), dtype=torch.uint8, device=in0.device) if want_counts else None
     check(lib.spk_den_conv3x3_mfma_fp6(_p(in0), nch, _p(wq), _p(scale), _p(bias_d), _p(bn_a), _p(bn_b), _p(v), _p(out),
-                                       _p(cnt), T, B, H, W, Cout, _stream(in0)), "spk_den_conv3x3_mfma_fp6")
+                                       _p(cnt), T, B, H, W, Cout, _n_dyn(), _stream(in0)), "spk_den_conv3x3_mfma_fp6")
     return (out, cnt) if want_counts else out
 
 
@@ -786,7 +812,9 @@ def den_build_input(x, t, out=None):
             raise ValueError("t must have one entry per sample")
     else:
         ts = int(t)
-    check(lib.spk_den_build_input(_p(xf), _p(xi), _p(tv), ts, _p(out), B, HW, _stream(x)), "spk_den_build_input")
+    act, nact = (None, None) if ACTIVE is None else ACTIVE
+    check(lib.spk_den_build_input(_p(xf), _p(xi), _p(tv), ts, _p(out), B, HW, _p(act), _p(nact), _stream(x)),
+          "spk_den_build_input")
     return out
 
 
@@ -809,7 +837,25 @@ def psample_step(logits, x_t, unmasked, t, temp=1.0, u=None, q=None, seed=0, off
             raise ValueError("q must have B*HW*K entries")
     if philox_state is not None and (philox_state.dtype != torch.int64 or philox_state.numel() != 2):
         raise ValueError("philox_state must be an int64 device tensor {seed, base offset}")
+    act, nact = (None, None) if ACTIVE is None else ACTIVE
     check(lib.spk_psample_step(_p(logits), _p(x_t), _p(unmasked), int(t), float(temp), _p(u), _p(q), int(seed),
-                               int(offset), _p(philox_state), _p(x0_hat), B, HW, K, _stream(logits)),
+                               int(offset), _p(philox_state), _p(x0_hat), B, HW, K, _p(act), _p(nact), _stream(logits)),
           "spk_psample_step")
     return x_t, unmasked
+
+
+def select_active(unmasked, t, u=None, seed=0, offset=0, philox_state=None, out=None):
+    """Images that reverse step t touches (at least one position with u < 1/t still masked): returns (active int32 [B]
+    ascending image list, n_active int32 [1]) on the device; same u / Philox arguments as psample_step."""
+    if unmasked.dtype not in (torch.bool, torch.uint8) or not unmasked.is_cuda or not unmasked.is_contiguous():
+        raise ValueError("unmasked must be a contiguous bool/uint8 device tensor")
+    B = unmasked.shape[0]
+    HW = unmasked[0].numel()
+    if u is not None:
+        u = _dev(u, "u", torch.float32)
+    if out is None:
+        out = (torch.empty(B, dtype=torch.int32, device=unmasked.device),
+               torch.empty(1, dtype=torch.int32, device=unmasked.device))
+    check(lib.spk_select_active(_p(unmasked), int(t), _p(u), int(seed), int(offset), _p(philox_state), _p(out[0]),
+                                _p(out[1]), B, HW, _stream(unmasked)), "spk_select_active")
+    return out

@@ -527,6 +527,49 @@ def test_lif_train_kernels_vs_live_oracle(dev, ops, N, tau, vr):
         assert float((err / (1e-6 + 1e-5 * want.abs())).max()) <= 1.0, float(err.max())
 
 
+# ------------------------------------------------------------------------------------------------- untouched-image elimination
+def test_select_active_matches_the_change_test(dev, ops):
+    """spk_select_active against the `changes` expression of R/snn_model/vq_diffusion.py:113-124 evaluated with torch on
+    injected uniforms: ascending list of the images with at least one change, and its length; B > 256 walks in chunks."""
+    g = torch.Generator().manual_seed(3)
+    for B, t in ((300, 7), (16, 100), (5, 1)):
+        u = torch.rand(B, 1, 7, 7, generator=g)
+        unmasked = torch.rand(B, 1, 7, 7, generator=g) < 0.6
+        changes = (u < 1.0 / t) & ~unmasked
+        want = torch.nonzero(changes.flatten(1).any(1)).flatten().int()
+        act, n = ops.select_active(unmasked.to(dev), t, u.to(dev))
+        assert int(n) == want.numel()
+        assert torch.equal(act[:int(n)].cpu(), want)
+
+
+@pytest.mark.parametrize("steps", [100, 49])
+def test_sampler_skipping_untouched_images_gives_the_same_tokens(dev, steps):
+    """AbsorbingDiffusion.skip_untouched: the denoiser is evaluated only for the images a step touches; tokens are
+    identical to the dense loop -- graph-replayed Philox mode (two consecutive calls), eager Philox mode and host-noise
+    mode (the reference's CPU RNG order) -- because only `changes` positions ever read the logits (:140)."""
+    from snn_model.vq_diffusion import AbsorbingDiffusion
+    den, _ = build_den(synth.MNIST, dev)
+    out = {}
+    for skip in (False, True):
+        ab = AbsorbingDiffusion(den, mask_id=128)
+        ab.n_samples = 24
+        ab.skip_untouched = skip
+        torch.manual_seed(1234)
+        a = ab.sample(temp=0.9, sample_steps=steps).cpu()
+        b = ab.sample(temp=0.9, sample_steps=steps).cpu()          # second replay: next Philox base
+        ab.use_graph = False
+        ab._philox_calls = 0
+        c = ab.sample(temp=0.9, sample_steps=steps).cpu()          # eager, same counters as `a`
+        ab.noise_source = 'host'
+        torch.manual_seed(99)
+        d = ab.sample(temp=0.9, sample_steps=min(steps, 12)).cpu()
+        out[skip] = (a, b, c, d)
+        assert torch.equal(a, c) and not torch.equal(a, b)
+        assert int(a.max()) < 128 and int(b.max()) < 128
+    for x, y in zip(out[False], out[True]):
+        assert torch.equal(x, y)
+
+
 # ------------------------------------------------------------------------------------------------- F9 training step
 def _rel_l2(got, want):
     return float((got - want).norm() / (want.norm() + 1e-30))
