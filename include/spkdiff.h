@@ -168,11 +168,12 @@ int spk_den_pack_weight_i8(const float* w, const float* bias, int8_t* wq, double
  * or + time mean (mode SPK_MODE_MEAN -> out_f32 [B,Cout,h,w]): DummyModel conv2..conv6,
  * R/snn_model/vq_diffusion.py:166-187,201-206.  in1 (nch1 chunks) is concatenated after in0 along channels.
  * v_inout [B,Cout,h,w] or NULL (fresh LIF state, nothing written back).  out_counts (LIF mode, optional): per-neuron
- * spike counts over T as u8 [B,Cout/32,h*w,32], the input format of spk_den_conv3x3_counts_mfma. */
+ * spike counts over T as u8 [B,Cout/32,h*w,32], the input format of spk_den_conv3x3_counts_mfma.
+ * n_dyn_or_null as in spk_conv_fused_fwd. */
 int spk_den_conv3x3_mfma(const uint8_t* in0_cptc, int nch0, const uint8_t* in1_cptc, int nch1, const int8_t* wq,
                          const double* scale, const double* bias_d, const float* bn_a, const float* bn_b,
                          float* v_inout, uint8_t* out_cptc, uint8_t* out_counts, float* out_f32, int mode, int T, int B,
-                         int H, int W, int Cout, spk_stream_t stream);
+                         int H, int W, int Cout, const int* n_dyn_or_null, spk_stream_t stream);
 /* conv6 + time mean of DummyModel (R/snn_model/vq_diffusion.py:185-187,205-206) in its time-collapsed form:
  * (sum_t conv(s_t)) / T = (conv_linear(sum_t s_t) + T*bias) / T.  cnt0 / cnt1: spike counts u8 [B,nch,h*w,32]
  * (channel concat: cnt1 after cnt0); same packed weights as spk_den_conv3x3_mfma; out_f32 [B,Cout,h,w].

@@ -51,6 +51,7 @@ struct MfmaArgs {
   uint8_t* out; float* out_f32; float* v_io;
   uint8_t* out_cnt;   // optional per-neuron spike counts over T, [B][Cout/32][HW][32] (input of the time-collapsed conv6)
   int B, H, W, Cout, mode;
+  const int* n_dyn;   // optional device-side batch count (<= B): only images [0, *n_dyn) are processed
   int dbg;   // -DSPK_MFMA_ABLATION builds only (env SPK_MFMA_DEBUG): 1 = skip steady-state DMA, 2 = skip MFMAs, 4 = skip epilogue
 };
 
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nchunks = a.nch0 + a.nch1;
   const int G = a.Cout >> 4;
-  const int total = a.B * G;
+  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
+  const int total = Bn * G;
 
   // zero both A images once: the borders stay zero for the whole kernel, interiors are overwritten by DMA
   for (int i = tid; i < 2 * A_BYTES / 16; i += 256) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
@@ -503,7 +505,7 @@ extern "C" int spk_den_conv3x3_mfma(const uint8_t* in0_cptc, int nch0, const uin
                                     const int8_t* wq, const double* scale, const double* bias_d, const float* bn_a,
                                     const float* bn_b, float* v_inout, uint8_t* out_cptc, uint8_t* out_counts,
                                     float* out_f32, int mode, int T, int B, int H, int W, int Cout,
-                                    hipStream_t stream) {
+                                    const int* n_dyn_or_null, hipStream_t stream) {
   if (!in0_cptc || nch0 <= 0 || nch1 < 0 || (nch1 > 0 && !in1_cptc) || !wq || !scale || !bias_d || B <= 0 || H <= 0 ||
       W <= 0 || Cout <= 0)
     return SPK_ERR_ARG;
@@ -511,7 +513,7 @@ extern "C" int spk_den_conv3x3_mfma(const uint8_t* in0_cptc, int nch0, const uin
   MfmaArgs a;
   a.in0 = in0_cptc; a.in1 = in1_cptc; a.nch0 = nch0; a.nch1 = nch1; a.wq = wq; a.scale = scale; a.bias = bias_d;
   a.bn_a = bn_a; a.bn_b = bn_b; a.out = out_cptc; a.out_f32 = out_f32; a.v_io = v_inout; a.out_cnt = out_counts; a.B = B; a.H = H; a.W = W;
-  a.Cout = Cout; a.mode = mode;
+  a.Cout = Cout; a.mode = mode; a.n_dyn = n_dyn_or_null;
   a.dbg = 0;
 #ifdef SPK_MFMA_ABLATION
   { const char* e = getenv("SPK_MFMA_DEBUG"); a.dbg = e ? atoi(e) : 0; }     // timing experiments only

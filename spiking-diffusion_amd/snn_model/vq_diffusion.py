@@ -67,7 +67,7 @@ class AbsorbingDiffusion(Sampler):
         # Reverse step t only writes the positions in `changes` (computed before the denoiser call, :113-124,140): an
         # image without a change at step t never has its denoiser output read.  True = evaluate the denoiser only for the
         # images spk_select_active lists for the step (61 % of (image, step) pairs drop out at 100 steps x 49 positions);
-        # the sampled tokens are those of the dense loop, draw for draw.  Needs the fp6 kernel family (7x7 latents).
+        # the sampled tokens are those of the dense loop, draw for draw.
         self.skip_untouched = True
 
     # ---- training step (R/snn_model/vq_diffusion.py:56-101,144-147) -------------------------
@@ -162,7 +162,7 @@ class AbsorbingDiffusion(Sampler):
         return x_t
 
     def _skip_ok(self, h, w):
-        return bool(self.skip_untouched) and self._denoise_fn.impl_for(h, w) == 'mfma-fp6x6' 
+        return bool(self.skip_untouched)            # every kernel family takes the device-side image count
 
 
 def _weights_key(module):

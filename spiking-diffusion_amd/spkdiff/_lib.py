@@ -64,7 +64,7 @@ _SIGS = {
     "spk_den_packed_weight_bytes": (c_longlong, [c_int, c_int]),
     "spk_den_pack_weight_i8": (c_int, [P, P, P, P, P, c_int, c_int, P]),
     "spk_den_conv3x3_mfma": (c_int, [P, c_int, P, c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int,
-                                     c_int, P]),
+                                     c_int, P, P]),
     "spk_den_packed_weight_fp6_bytes": (c_longlong, [c_int, c_int]),
     "spk_den_pack_weight_fp6": (c_int, [P, P, P, P, P, c_int, c_int, P]),
     "spk_den_conv3x3_mfma_fp6": (c_int, [P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),

@@ -570,8 +570,8 @@ def den_conv3x3_mfma(in0, packed, Cout, *, mode, in1=None, bn_a=None, bn_b=None,
     if want_counts and mode == MODE_LIF:
         cnt = torch.empty((B, Cout // 32, H, W, 32), dtype=torch.uint8, device=in0.device)
     check(lib.spk_den_conv3x3_mfma(_p(in0), nch0, _p(in1), nch1, _p(wq), _p(scale), _p(bias_d), _p(bn_a), _p(bn_b),
-                                   _p(v), _p(out_c), _p(cnt), _p(out_f), mode, T, B, H, W, Cout, _stream(in0)),
-          "spk_den_conv3x3_mfma")
+                                   _p(v), _p(out_c), _p(cnt), _p(out_f), mode, T, B, H, W, Cout, _n_dyn(),
+                                   _stream(in0)), "spk_den_conv3x3_mfma")
     if mode == MODE_LIF:
         return (out_c, cnt) if want_counts else out_c
     return out_f

@@ -542,6 +542,23 @@ def test_select_active_matches_the_change_test(dev, ops):
         assert torch.equal(act[:int(n)].cpu(), want)
 
 
+@pytest.mark.parametrize("cfgname,impl", [("cifar", "auto"), ("mnist", "i8"), ("mnist", "direct")])
+def test_skipping_untouched_images_other_kernel_families(dev, cfgname, impl):
+    """The same elimination on the int8 MFMA family (8x8 latents, and 7x7 on request) and on the fp64 direct kernels."""
+    from snn_model.vq_diffusion import AbsorbingDiffusion
+    cfg = synth.CIFAR if cfgname == "cifar" else synth.MNIST
+    den, _ = build_den(cfg, dev)
+    den.conv_impl_request = impl
+    out = []
+    for skip in (False, True):
+        ab = AbsorbingDiffusion(den, mask_id=128, latent_shape=(cfg.latent, cfg.latent))
+        ab.n_samples = 8 if impl == "direct" else 20
+        ab.skip_untouched = skip
+        torch.manual_seed(77)
+        out.append(ab.sample(temp=1.0, sample_steps=20 if impl == "direct" else 64).cpu())
+    assert torch.equal(out[0], out[1]) and int(out[0].max()) < 128
+
+
 @pytest.mark.parametrize("steps", [100, 49])
 def test_sampler_skipping_untouched_images_gives_the_same_tokens(dev, steps):
     """AbsorbingDiffusion.skip_untouched: the denoiser is evaluated only for the images a step touches; tokens are
