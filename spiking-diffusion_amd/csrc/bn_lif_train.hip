@@ -18,8 +18,11 @@
 //
 // Layout: channels-last, [T][B][HW][C] fp32 for y, spikes and gradients, [B][HW][C] for the membrane state -- the
 // layout the library's NHWC convolution kernels read and write without transposes, and the one in which a per-channel
-// reduction is coalesced: a lane owns one channel, a wave reads 64 consecutive channels (256 B) of one (b, hw) row, walks
-// its rows, and keeps T steps of one neuron in registers.
+// reduction is coalesced.  Two kernel families with the same partial-sum workspace [slice][C][2]:
+//   vector forms (*_v_kernel<VEC>, C % VEC == 0 and 256 % (C / VEC) == 0 -- every layer of the models): a thread owns
+//     VEC = 2 or 4 consecutive channels of a row and keeps all T steps in flight (8-16 B loads, 256 consecutive words per
+//     workgroup step);
+//   scalar forms (any C): a lane owns one channel, a wave reads 64 consecutive channels of one (b, hw) row.
 #include "spk_common.h"
 #include "../../include/spkdiff.h"
 
