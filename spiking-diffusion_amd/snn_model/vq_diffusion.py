@@ -177,7 +177,8 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
     key = (str(dev), b, h, w, K, temp, sample_steps, int(self.mask_id), skip, _weights_key(dn))
     entry = self._graphs.get(key)
     if entry is None:
-        self._graphs.clear()                                    # one live graph per sampler (buffers are not small)
+        if len(self._graphs) >= 2:                              # at most two live graphs per sampler (e.g. dense and
+            self._graphs.clear()                                #  elimination forms): their buffers are not small
         state = torch.zeros(2, dtype=torch.int64, device=dev)
         x_t = torch.empty((b, 1, h, w), dtype=torch.int64, device=dev)
         unmasked = torch.empty((b, 1, h, w), dtype=torch.bool, device=dev)
