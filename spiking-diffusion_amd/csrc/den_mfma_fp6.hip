@@ -244,6 +244,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
           const v4i av = af[s % PF];
           if (s + PF < 9 * NT) af[s % PF] = lda(s + PF);
           auto mfma = [&](int j) {
+#ifdef SPK_FP6_KEEP
+            if (i >= SPK_FP6_KEEP) return;        // bound experiment: only the first KEEP row tiles of a wave are computed
+#endif
             if (FIRST && tap == 0) {
               if (3 * i + j < N_AGPR) SPK_MFMA_FP6_Z("a", acc[i][j], av, bc[j], sc_a, sc_b);
               else SPK_MFMA_FP6_Z("v", acc[i][j], av, bc[j], sc_a, sc_b);
@@ -320,6 +323,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
       const int ia = k == 0 ? NT - 2 : (((NT & 1) && k == (NT + 1) / 2 - 1) ? NT - 3 : 2 * (k - 1));
       const bool paired = !((NT & 1) && k == (NT + 1) / 2 - 1);
       const int ib = paired ? ia + 1 : ia;
+#ifdef SPK_FP6_KEEP
+      if (ia >= SPK_FP6_KEEP) continue;
+#endif
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         if (3 * ia + j < N_AGPR) asm volatile("" : "+a"(acc[ia][j]));
