@@ -76,8 +76,9 @@ __global__ __launch_bounds__(256) void psample_kernel(const float* __restrict__ 
   for (long long ps = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); ps < npos; ps += (long long)gridDim.x * 4) {
     const int b = (int)(ps / HW), hw = (int)(ps % HW);            // b = logits slot
     const long long p = active ? (long long)active[b] * HW + hw : ps;   // image position: noise / state index
-    if (active) {
-      // only positions that change consume the sample: skip the rest before the softmax (wave-uniform test)
+    if (!x0_hat_out) {
+      // only positions that change consume the sample (:140): skip the rest before the softmax (wave-uniform test;
+      // the noise is counter-based / injected per position, so skipping a draw does not move any other)
       float u;
       if (u_in) u = u_in[p];
       else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)p, 0u, r); u = u01_open_right(r[0]); }
