@@ -54,6 +54,13 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+__device__ __forceinline__ bool __any_sync_quad(bool v) {      // OR over the 4 lanes of a quad
+  int x = v ? 1 : 0;
+  x |= __shfl_xor(x, 1);
+  x |= __shfl_xor(x, 2);
+  return x != 0;
+}
+
 constexpr int KPL = 4;  // classes per lane: K <= 256
 
 __global__ __launch_bounds__(256) void psample_kernel(const float* __restrict__ logits, long long* __restrict__ x_t,
@@ -170,23 +177,26 @@ __global__ void den_input_kernel(const float* __restrict__ xf, const long long* 
 // read and x_t / unmasked stay as they are.  This kernel evaluates the same test (same u: injected or the same Philox
 // counters as spk_psample_step) per image and writes the ascending list of images with at least one change plus its
 // length; the per-step kernels then run on that list only.  One workgroup: the list must be ordered (deterministic slots).
-__global__ __launch_bounds__(256) void select_active_kernel(const uint8_t* __restrict__ unmasked, int t,
-                                                            const float* __restrict__ u_in, unsigned long long seed,
-                                                            unsigned long long offset,
-                                                            const unsigned long long* __restrict__ philox_state,
-                                                            int* __restrict__ active, int* __restrict__ n_active, int B, int HW) {
-  __shared__ int wave_cnt[4];
+// 1024 threads: 4 threads per image (positions q, q + 4, ...) over chunks of 256 images, so that the serial Philox depth is
+// HW / 4; lane q == 0 of each quad carries the image's flag into the ordered compaction.
+__global__ __launch_bounds__(1024) void select_active_kernel(const uint8_t* __restrict__ unmasked, int t,
+                                                             const float* __restrict__ u_in, unsigned long long seed,
+                                                             unsigned long long offset,
+                                                             const unsigned long long* __restrict__ philox_state,
+                                                             int* __restrict__ active, int* __restrict__ n_active, int B, int HW) {
+  __shared__ int wave_cnt[16];
   __shared__ int base_s;
   if (philox_state) { seed = philox_state[0]; offset += philox_state[1]; }
   const float inv_t = 1.0f / (float)t;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = threadIdx.x & 3;
   if (threadIdx.x == 0) base_s = 0;
   __syncthreads();
   for (int b0 = 0; b0 < B; b0 += 256) {
-    const int b = b0 + threadIdx.x;
+    const int b = b0 + (threadIdx.x >> 2);
     bool any = false;
     if (b < B) {
-      for (int hw = 0; hw < HW && !any; ++hw) {
+      for (int hw = q; hw < HW && !any; hw += 4) {
         const long long p = (long long)b * HW + hw;
         if (unmasked[p]) continue;
         float u;
@@ -195,14 +205,20 @@ __global__ __launch_bounds__(256) void select_active_kernel(const uint8_t* __res
         any = u < inv_t;
       }
     }
-    const unsigned long long m = __ballot(any);
+    any = __any_sync_quad(any);
+    const bool flag = any && q == 0;
+    const unsigned long long m = __ballot(flag);
     if (lane == 0) wave_cnt[wave] = __popcll(m);
     __syncthreads();
     int pre = base_s;
     for (int w = 0; w < wave; ++w) pre += wave_cnt[w];
-    if (any) active[pre + __popcll(m & ((1ull << lane) - 1ull))] = b;
+    if (flag) active[pre + __popcll(m & ((1ull << lane) - 1ull))] = b;
     __syncthreads();
-    if (threadIdx.x == 0) base_s += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    if (threadIdx.x == 0) {
+      int tot = 0;
+      for (int w = 0; w < 16; ++w) tot += wave_cnt[w];
+      base_s += tot;
+    }
     __syncthreads();
   }
   if (threadIdx.x == 0) *n_active = base_s;
@@ -214,7 +230,7 @@ extern "C" int spk_select_active(const uint8_t* unmasked, int t, const float* u_
                                  unsigned long long philox_offset, const unsigned long long* philox_state_or_null,
                                  int* active_out, int* n_active_out, int B, int HW, hipStream_t stream) {
   if (!unmasked || !active_out || !n_active_out || t <= 0 || B <= 0 || HW <= 0) return SPK_ERR_ARG;
-  hipLaunchKernelGGL(select_active_kernel, dim3(1), dim3(256), 0, stream, unmasked, t, u_or_null, philox_seed, philox_offset,
+  hipLaunchKernelGGL(select_active_kernel, dim3(1), dim3(1024), 0, stream, unmasked, t, u_or_null, philox_seed, philox_offset,
                      philox_state_or_null, active_out, n_active_out, B, HW);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
