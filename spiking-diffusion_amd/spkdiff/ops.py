@@ -340,6 +340,39 @@ def conv_transpose2d(x, w, bias, stride, pad, out_pad):
     return y
 
 
+class ExactConvTrainFunction(torch.autograd.Function):
+    """y = conv2d / conv_transpose2d(x, weight) + bias in training: the forward is this library's direct kernel (fp64
+    accumulation: the correctly rounded exact result, the same numbers as the inference path and -- up to the reference's
+    own fp32 round-off -- the reference's), the backward is the framework's convolution backward.  Used for the small
+    layers (VQ-VAE, the denoiser's first convolution); the denoiser's spike-input layers use SpikeConvTrainFunction."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, transposed, out_pad):
+        if transposed:
+            y = conv_transpose2d(x, weight, bias, stride, pad, out_pad)
+        else:
+            y = conv2d(x, weight, bias, stride, pad)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (int(stride), int(pad), bool(transposed), int(out_pad), bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, weight = ctx.saved_tensors
+        stride, pad, transposed, out_pad, has_bias = ctx.cfg
+        cout = int(weight.shape[1] if transposed else weight.shape[0])
+        gi, gw, gb = torch.ops.aten.convolution_backward(
+            grad_y.contiguous(), x.contiguous(), weight, [cout], [stride, stride], [pad, pad], [1, 1], transposed,
+            [out_pad, out_pad], 1,
+            [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), bool(has_bias and ctx.needs_input_grad[2])])
+        return gi, gw, gb, None, None, None, None
+
+
+# Training forward of a stand-alone convolution: exact direct kernel up to this many multiply-accumulates per call (its fp64
+# accumulation is not a matrix-core kernel), the library operator beyond
+EXACT_TRAIN_FORWARD_MACS = 4_000_000_000
+
+
 def memout(x_seq, coef):
     x_seq = _dev(x_seq, "x_seq", torch.float32)
     coef = _dev(coef, "coef", torch.float32)
