@@ -195,7 +195,8 @@ long long spk_den_packed_weight_fp6_bytes(int Cout, int Cin);
 int spk_den_pack_weight_fp6(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d, int Cout,
                             int Cin, spk_stream_t stream);
 /* in_c4: nch chunks of 64 channels; out_c4 [B][Cout/64][h*w][16][32]; v_inout / out_counts as in spk_den_conv3x3_mfma.
- * SPK_ERR_UNSUPPORTED unless T == 16, Cout % 64 == 0 and the latent fits the kernel's LDS plan (7x7).
+ * SPK_ERR_UNSUPPORTED unless T == 16, Cout % 64 == 0 and the latent fits one of the kernel's LDS plans (up to 7x8 as
+ * one item per image and channel group, 8x8 as two row bands).
  * n_dyn_or_null as in spk_conv_fused_fwd (the work items are then walked image-major). */
 int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* scale, const double* bias_d,
                              const float* bn_a, const float* bn_b, float* v_inout, uint8_t* out_c4, uint8_t* out_counts,

@@ -81,11 +81,18 @@ constexpr int N_AGPR = 16;     // accumulators (row tile i, column tile j: index
 
 // RAW = true: the training forward -- the same exact pre-activations written as fp32 instead of
 // the BN + LIF scan (batch-statistics BN needs them all before any neuron can be stepped).
-template <int NT, bool RAW = false>
+// SPLIT = true (latents too large for one item, 8x8): an item is one of the two row BANDS of an image (H / 2 output rows,
+// H / 2 + 1 input rows: one halo row from the other band).  Both bands sit in LDS rows 1..H/2+1 of a (H/2 + 3)-row padded
+// image whose rows 0 and H/2 + 2 stay zero; the top band's outputs are centred on LDS rows 1.., the bottom band's on
+// rows 2.. -- one row offset added to the fragment addresses per item.
+template <int NT, bool RAW = false, bool SPLIT = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int HW = a.H * a.W, PW = a.W + 1;
-  const int npp = (a.H + 2) * PW + 1;
+  const int Hb = SPLIT ? a.H / 2 : a.H;               // output rows of an item
+  const int Hin = SPLIT ? Hb + 1 : a.H;               // input rows staged per item
+  const int HWb = Hb * a.W;                           // output positions of an item
+  const int npp = (Hin + 2) * PW + 1;
   const int A_BYTES = npp * POS_BYTES;
   // LDS: [A buf0][A buf1][W buf0][W buf1]
   uint8_t* const sA = lds;
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
   const int nchunks = a.nch0;
   const int G = a.Cout >> 4;
   const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
-  const int total = Bn * G;
+  const int total = Bn * G * (SPLIT ? 2 : 1);
 
   // zero both A images once: the borders stay zero for the whole kernel, interiors are overwritten by DMA
   for (int i = tid; i < 2 * A_BYTES / 16; i += 256) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     const int p = 2 * (wave + 4 * i) + hsel;
-    const int pp = p < HW ? (p / a.W + 1) * PW + (p % a.W) + 1 : PW + 1;
+    const int pp = p < HWb ? (p / a.W + 1) * PW + (p % a.W) + 1 : PW + 1;
     a_off[i] = pp * POS_BYTES + tt * 32 + 16 * (half ^ (tt >> 3));   // 16-B halves swapped for t >= 8: bank-conflict-free
   }
 
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
   // Pieces beyond the slab repeat the last one (a harmless duplicate copy) so that the K loop issues unconditionally.
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const int pprow = (a.W + 1) >> 1;
-  const int nA = a.H * pprow;
+  const int nA = Hin * pprow;
   unsigned pa_pk[NPA];
 #pragma unroll
   for (int j = 0; j < NPA; ++j) {
@@ -162,14 +169,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
       g = set * gx + slot % gx;
       b = (j * npart + xi) * ipx + slot / gx;
     } else {
-      b = item / G;
+      b = item / G;            // SPLIT: b = 2 * image + band
       g = item - b * G;
     }
   };
   auto slabs = [&](int item, int c, const uint8_t*& aslab, const uint8_t*& wslab) {
     int b, g;
     decode(item, b, g);
-    aslab = a.in0 + ((long long)b * nchunks + c) * HW * POS_BYTES;
+    if constexpr (SPLIT) aslab = a.in0 + ((long long)(b >> 1) * nchunks + c) * HW * POS_BYTES + (b & 1) * (Hb - 1) * a.W * POS_BYTES;
+    else aslab = a.in0 + ((long long)b * nchunks + c) * HW * POS_BYTES;
     wslab = a.wq + ((long long)g * nchunks + c) * W_CHUNK_BYTES;
   };
 
@@ -190,6 +198,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
     // epilogue constants of this item's channel: loaded now, their latency hides under the K loop
     int b, g;
     decode(item, b, g);
+    const int band = SPLIT ? (b & 1) : 0;
+    if constexpr (SPLIT) b >>= 1;
+    const int band_off = band * PW * POS_BYTES;          // bottom band: fragment addresses one LDS row further down
     const int co = g * 16 + ch;
     const double sc = a.scale[co], bi = a.bias[co];
     const float bn_a = RAW ? 1.0f : a.bn_a[co], bn_b = RAW ? 0.0f : a.bn_b[co];
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
       // ---------------- 9 taps x NT row tiles x 3 column tiles, A fragments read four steps ahead ------------------
       auto compute = [&](auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
-        const uint8_t* A = sA + buf * A_BYTES;
+        const uint8_t* A = sA + buf * A_BYTES + band_off;
         const uint8_t* Wb = sW + buf * W_CHUNK_BYTES;
         auto lda = [&](int s) -> v4i {
           const int tap = s / NT, i = s % NT;
@@ -368,8 +379,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
         }
       }
       const int ti = wave + 4 * (odd ? ib : ia);
-      const int p = 2 * ti + half;                  // accumulator lane-half == position within the tile
-      const bool pos_ok = p < HW && (paired || !odd);
+      const int pl = 2 * ti + half;                 // accumulator lane-half == position within the tile
+      const int p = pl + band * HWb;                // position in the image
+      const bool pos_ok = pl < HWb && (paired || !odd);
       if constexpr (RAW) {
         // x[r] = pre-activation of neuron (b, p, co) at t = r; 16 consecutive channels (64 B) per 16-lane row and step
         if (pos_ok) {
@@ -658,16 +670,20 @@ int launch_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* s
                int B, int H, int W, int Cout, hipStream_t stream) {
   if (T != T16 || (Cout % 64)) return SPK_ERR_UNSUPPORTED;
   const int ntiles = (H * W + 1) / 2;
-  const int npa = (H * ((W + 1) / 2) + 3) / 4;
-  const size_t lds = 2 * ((size_t)((H + 2) * (W + 1) + 1) * POS_BYTES + W_CHUNK_BYTES);
-  if ((ntiles + 3) / 4 > 7 || npa > NPA || lds > 160 * 1024) return SPK_ERR_UNSUPPORTED;
+  // latents that do not fit one item (8x8): two row bands per image, 4 tiles per wave each (see the kernel)
+  const bool bands = (ntiles + 3) / 4 > 7 && (H % 2) == 0 && (H / 2) * W <= 32 && H >= 4;
+  const int Hin = bands ? H / 2 + 1 : H;
+  const int npa = (Hin * ((W + 1) / 2) + 3) / 4;
+  const size_t lds = 2 * ((size_t)((Hin + 2) * (W + 1) + 1) * POS_BYTES + W_CHUNK_BYTES);
+  if ((!bands && (ntiles + 3) / 4 > 7) || npa > NPA || lds > 160 * 1024) return SPK_ERR_UNSUPPORTED;
+  if (bands && ((Hin * W + 2 * (W + 1)) * POS_BYTES >= 32768)) return SPK_ERR_UNSUPPORTED;     // piece-table field widths
   // odd position count with at most 24 full tiles: 6 tiles per wave + the last-position kernel (see there)
-  const bool split_last = ((H * W) & 1) && (H * W) / 2 <= 24 && H >= 2 && W >= 2;
+  const bool split_last = !bands && ((H * W) & 1) && (H * W) / 2 <= 24 && H >= 2 && W >= 2;
   Fp6Args a;
   a.in0 = in_c4; a.nch0 = nch; a.wq = wq; a.scale = scale; a.bias = bias_d; a.bn_a = bn_a; a.bn_b = bn_b;
   a.out = out_c4; a.v_io = v_inout; a.out_cnt = out_counts; a.pre = pre; a.n_dyn = n_dyn; a.B = B; a.H = H; a.W = W; a.Cout = Cout;
   const int cus = spk_cu_count();
-  const int G = Cout / 16, total = B * G;
+  const int G = Cout / 16, total = B * G * (bands ? 2 : 1);
   dim3 grid(total < cus ? total : cus), blk(256);          // persistent: one workgroup per CU
   // XCD-aware walk: the largest power-of-two group count whose packed weights (gx * nch slabs) fit ~1.5 MB of an XCD's
   // 4 MB L2, if the shape tiles exactly (see decode() in the kernel)
@@ -676,14 +692,16 @@ int launch_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* s
   // slab requests of an XCD made it slower still).  SPKDIFF_FP6_XCD_WALK=0 selects the image-major walk.
   static const bool xcd_walk = [] { const char* e = getenv("SPKDIFF_FP6_XCD_WALK"); return !(e && e[0] == '0'); }();
   a.gx = 0;
-  if (xcd_walk && !n_dyn && (grid.x & 7) == 0) {      // (a device-side batch count walks image-major)
+  if (xcd_walk && !n_dyn && !bands && (grid.x & 7) == 0) {      // (a device-side batch count / row bands walk image-major)
     const int S = grid.x / 8;
     int gx = 1;
     while (gx * 2 <= G && (long long)gx * 2 * nch * W_CHUNK_BYTES <= 1536 * 1024) gx *= 2;
     const int nsets = G / gx;
     if (gx >= 4 && G % gx == 0 && nsets <= 8 && 8 % nsets == 0 && S % gx == 0 && B % ((8 / nsets) * (S / gx)) == 0) a.gx = gx;
   }
-  if (split_last) {
+  if (bands) {
+    hipLaunchKernelGGL((conv3x3_fp6_kernel<4, RAW, true>), grid, blk, lds, stream, a);
+  } else if (split_last) {
     hipLaunchKernelGGL((conv3x3_fp6_kernel<6, RAW>), grid, blk, lds, stream, a);
     SPK_LAUNCH_CHECK();
     hipLaunchKernelGGL(conv3x3_fp6_lastpos_kernel<RAW>, dim3((B + 2 * LP_TILES - 1) / (2 * LP_TILES), G / 4), blk, 0, stream, a);

@@ -630,10 +630,12 @@ def den_conv3x3_counts(cnt0, packed, Cout, T, cnt1=None):
 # ------------------------------------------------------------------------------- fp6/fp4 block-scaled MFMA denoiser convs
 def den_fp6_supported(Cout, Cin, k, stride, pad, T, H, W):
     ntiles = (H * W + 1) // 2
-    npa = (H * ((W + 1) // 2) + 3) // 4
-    lds = 2 * (((H + 2) * (W + 1) + 1) * 512 + 41984)
+    bands = (ntiles + 3) // 4 > 7 and H % 2 == 0 and (H // 2) * W <= 32 and H >= 4     # 8x8: two row bands per image
+    Hin = H // 2 + 1 if bands else H
+    npa = (Hin * ((W + 1) // 2) + 3) // 4
+    lds = 2 * (((Hin + 2) * (W + 1) + 1) * 512 + 41984)
     return (k == 3 and stride == 1 and pad == 1 and T == 16 and Cout % 64 == 0 and Cin % 64 == 0
-            and (ntiles + 3) // 4 <= 7 and npa <= 7 and lds <= 160 * 1024)
+            and (bands or (ntiles + 3) // 4 <= 7) and npa <= 7 and lds <= 160 * 1024)
 
 
 def den_pack_weight_fp6(w, bias):

@@ -542,9 +542,10 @@ def test_select_active_matches_the_change_test(dev, ops):
         assert torch.equal(act[:int(n)].cpu(), want)
 
 
-@pytest.mark.parametrize("cfgname,impl", [("cifar", "auto"), ("mnist", "i8"), ("mnist", "direct")])
+@pytest.mark.parametrize("cfgname,impl", [("cifar", "auto"), ("cifar", "i8"), ("mnist", "i8"), ("mnist", "direct")])
 def test_skipping_untouched_images_other_kernel_families(dev, cfgname, impl):
-    """The same elimination on the int8 MFMA family (8x8 latents, and 7x7 on request) and on the fp64 direct kernels."""
+    """The same elimination on the fp6 row-band form (8x8 latents), the int8 MFMA family (8x8 and 7x7 on request) and the
+    fp64 direct kernels."""
     from snn_model.vq_diffusion import AbsorbingDiffusion
     cfg = synth.CIFAR if cfgname == "cifar" else synth.MNIST
     den, _ = build_den(cfg, dev)
@@ -1189,6 +1190,30 @@ def test_denoiser_mfma_vs_direct_b64_random_tokens(dev, req, name):
         sa, sb = ops.ptc_to_spikes(a), ops.ptc_to_spikes(b)
         assert torch.equal(sa, sb), f"conv{i} spikes differ between the MFMA and the direct path"
         assert 0.005 < float(sa.mean()) < 0.5
+    assert float((lm - ld).abs().max()) <= 2e-7
+
+
+@pytest.mark.parametrize("req,name,B", [("fp6", "mfma-fp6x6", 37), ("fp6", "mfma-fp6x6", 3), ("i8", "mfma-i8x4", 20)])
+def test_denoiser_8x8_latent_mfma_vs_direct(dev, req, name, B):
+    """8x8 latents (BASELINE config 4): the fp6 kernel in its row-band form (two items per image: H/2 output rows each,
+    one halo row) and the int8 kernel, against the fp64 direct path -- every layer's spikes bit-equal, logits within 2e-7;
+    B = 37 / 3: ragged and fewer-than-CUs band items."""
+    den, _ = build_den(synth.CIFAR, dev)
+    den.conv_impl_request = req
+    assert den.impl_for(8, 8) == name
+    g = torch.Generator().manual_seed(321 + B)
+    x_t = torch.randint(0, 128, (B, 1, 8, 8), generator=g)
+    x_t[torch.rand(B, 1, 8, 8, generator=g) < 0.5] = 128
+    x_t = x_t.to(dev)
+    rec_m, rec_d = [], []
+    with torch.inference_mode():
+        lm = den.logits_from_tokens(x_t, 21, record=rec_m)
+        den.conv_impl_request = 'direct'
+        ld = den.logits_from_tokens(x_t, 21, record=rec_d)
+    from spkdiff import ops
+    for i, (a, b) in enumerate(zip(rec_m, rec_d), 1):
+        sa, sb = ops.ptc_to_spikes(a), ops.ptc_to_spikes(b)
+        assert torch.equal(sa, sb), f"conv{i} spikes differ between the MFMA and the direct path"
     assert float((lm - ld).abs().max()) <= 2e-7
 
 
