@@ -85,8 +85,16 @@ constexpr int N_AGPR = 16;     // accumulators (row tile i, column tile j: index
 // H / 2 + 1 input rows: one halo row from the other band).  Both bands sit in LDS rows 1..H/2+1 of a (H/2 + 3)-row padded
 // image whose rows 0 and H/2 + 2 stay zero; the top band's outputs are centred on LDS rows 1.., the bottom band's on
 // rows 2.. -- one row offset added to the fragment addresses per item.
-template <int NT, bool RAW = false, bool SPLIT = false>
-__global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
+// NWV = waves per workgroup: 4 (one per SIMD, NT = 6 / 7 / 4 tiles each) or 8 (two per SIMD with NT = 3 tiles each: the same
+// item, LDS plan and DMA volume; meant to let the second wave of a SIMD fill the matrix pipe while the first reads
+// fragments, issues copies or runs its epilogue).  Measured (SPKDIFF_FP6_WAVES=8, correct, same results): 7 % SLOWER on
+// conv4 / conv5 (620 vs 580 us, 531 vs 501 us), with or without de-phasing the two waves -- the kernel is not starved
+// for issue slots but limited by the power the matrix pipe may draw; kept as an experiment, not the default.
+template <int NT, bool RAW = false, bool SPLIT = false, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6_kernel(Fp6Args a) {
+  constexpr int NPA_ = NWV == 8 ? 4 : NPA;                    // A pieces per wave
+  constexpr int NAG = NWV == 8 ? 8 : N_AGPR;                  // accumulators kept in AGPRs (two waves per SIMD: 256 registers each)
+  constexpr int NPW_ = (W_PIECES + NWV - 1) / NWV;            // W pieces per wave (wave w copies pieces w, w + NWV, ...)
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int HW = a.H * a.W, PW = a.W + 1;
   const int Hb = SPLIT ? a.H / 2 : a.H;               // output rows of an item
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
   const int total = Bn * G * (SPLIT ? 2 : 1);
 
   // zero both A images once: the borders stay zero for the whole kernel, interiors are overwritten by DMA
-  for (int i = tid; i < 2 * A_BYTES / 16; i += 256) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < 2 * A_BYTES / 16; i += NWV * 64) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
 
   // per-lane LDS byte offsets of this wave's A fragments (tile ti = wave + 4*i); absent tiles read garbage that the
   // epilogue discards
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
   int a_off[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
-    const int p = 2 * (wave + 4 * i) + hsel;
+    const int p = 2 * (wave + NWV * i) + hsel;
     const int pp = p < HWb ? (p / a.W + 1) * PW + (p % a.W) + 1 : PW + 1;
     a_off[i] = pp * POS_BYTES + tt * 32 + 16 * (half ^ (tt >> 3));   // 16-B halves swapped for t >= 8: bank-conflict-free
   }
@@ -126,10 +134,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const int pprow = (a.W + 1) >> 1;
   const int nA = Hin * pprow;
-  unsigned pa_pk[NPA];
+  unsigned pa_pk[NPA_];
 #pragma unroll
-  for (int j = 0; j < NPA; ++j) {
-    int id = wave_s * NPA + j;
+  for (int j = 0; j < NPA_; ++j) {
+    int id = wave_s * NPA_ + j;
     id = id < nA ? id : nA - 1;
     const int y = id / pprow, px = id - y * pprow;
     const unsigned src = (unsigned)((y * a.W + 2 * px) * POS_BYTES), dst = (unsigned)(((y + 1) * PW + 1 + 2 * px) * POS_BYTES);
@@ -141,13 +149,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
 
   // piece q of this wave: q < NPA -> A piece q, else W piece wave + 4 * (q - NPA) (the 42nd..44th repeat an earlier one)
   auto issue_piece = [&](int q, const uint8_t* aslab, const uint8_t* wslab, unsigned dA, unsigned dW) {
-    if (q < NPA) {
+    if (q < NPA_) {
       const unsigned pk = pa_pk[q];
       const unsigned long long mask = (pk >> 31) ? ~0ull : 0xffffffffull;
       spk_dma16s_masked(aslab + (pk & 0x7fffu), lane_a, dA + ((pk >> 15) & 0xffffu), mask);
     } else {
-      unsigned ko = wave_k + 4096u * (unsigned)(q - NPA);
-      if (4 * (q - NPA) + 3 >= W_PIECES) ko = ko < (unsigned)W_PIECES * 1024u ? ko : ko - 4096u;
+      unsigned ko = wave_k + (unsigned)NWV * 1024u * (unsigned)(q - NPA_);
+      if (NWV * (q - NPA_) + NWV - 1 >= W_PIECES) ko = ko < (unsigned)W_PIECES * 1024u ? ko : ko - (unsigned)NWV * 1024u;
       spk_dma16s(wslab + ko, lane_w, dW + ko);
     }
   };
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
     const uint8_t *as0, *ws0;
     slabs(blockIdx.x, 0, as0, ws0);
 #pragma unroll
-    for (int q = 0; q < NPA + NPW; ++q) issue_piece(q, as0, ws0, sA_addr, sW_addr);
+    for (int q = 0; q < NPA_ + NPW_; ++q) issue_piece(q, as0, ws0, sA_addr, sW_addr);
   }
   for (int item = blockIdx.x; item < total; item += gridDim.x) {
     v16f acc[NT][3];      // written (not accumulated) by tap 0 of the first chunk: no explicit zeroing
@@ -245,7 +253,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
         v6i bc[3], bn[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) { bc[j] = ldb(0, j); bn[j] = bc[j]; }
-        constexpr int PF = SPK_FP6_PF;             // A fragments in flight ahead of the MFMA that consumes them
+        // A fragments in flight ahead of the MFMA that consumes them; with two waves per SIMD the other wave covers the
+        // latency instead of registers (no second set of weight fragments either)
+        constexpr int PF = NWV == 8 ? 2 : SPK_FP6_PF;
+        constexpr bool BPF = NWV != 8;
         v4i af[PF];
 #pragma unroll
         for (int s = 0; s < PF; ++s) af[s] = lda(s);
@@ -259,10 +270,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
             if (i >= SPK_FP6_KEEP) return;        // bound experiment: only the first KEEP row tiles of a wave are computed
 #endif
             if (FIRST && tap == 0) {
-              if (3 * i + j < N_AGPR) SPK_MFMA_FP6_Z("a", acc[i][j], av, bc[j], sc_a, sc_b);
+              if (3 * i + j < NAG) SPK_MFMA_FP6_Z("a", acc[i][j], av, bc[j], sc_a, sc_b);
               else SPK_MFMA_FP6_Z("v", acc[i][j], av, bc[j], sc_a, sc_b);
             } else {
-              if (3 * i + j < N_AGPR) SPK_MFMA_FP6("a", acc[i][j], av, bc[j], sc_a, sc_b);
+              if (3 * i + j < NAG) SPK_MFMA_FP6("a", acc[i][j], av, bc[j], sc_a, sc_b);
               else SPK_MFMA_FP6("v", acc[i][j], av, bc[j], sc_a, sc_b);
             }
           };
@@ -272,24 +283,29 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
           __builtin_amdgcn_sched_barrier(0);
           {
             // DMA schedule: NPA + NPW pieces spread over the 9*NT steps (every DMA_EVERY-th step issues one piece)
-            constexpr int NPIECES = NPA + NPW;
+            constexpr int NPIECES = NPA_ + NPW_;
             constexpr int DMA_EVERY = SPK_FP6_DMA_EVERY;
             if (s % DMA_EVERY == 0 && s / DMA_EVERY < NPIECES) {
               const int q = s / DMA_EVERY;
-              const bool skip = ((SPK_FP6_DBG & 8) && q >= NPA) || ((SPK_FP6_DBG & 16) && q < NPA);
+              const bool skip = ((SPK_FP6_DBG & 8) && q >= NPA_) || ((SPK_FP6_DBG & 16) && q < NPA_);
               if (!(SPK_FP6_DBG & 1) && !skip) issue_piece(q, n_aslab, n_wslab, n_dA, n_dW);
             }
           }
           mfma(1);
           __builtin_amdgcn_sched_barrier(0);
-          if (i == 0 && tap + 1 < 9) {
+          if (BPF && i == 0 && tap + 1 < 9) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) bn[j] = ldb(tap + 1, j);
           }
           mfma(2);
           if (i == NT - 1) {
+            if constexpr (BPF) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) bc[j] = bn[j];
+              for (int j = 0; j < 3; ++j) bc[j] = bn[j];
+            } else if (tap + 1 < 9) {
+#pragma unroll
+              for (int j = 0; j < 3; ++j) bc[j] = ldb(tap + 1, j);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);     // keep the read-ahead distance (see den_mfma.hip)
         }
@@ -310,7 +326,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          if (3 * i + j < N_AGPR) asm volatile("" : "+a"(acc[i][j]));
+          if (3 * i + j < NAG) asm volatile("" : "+a"(acc[i][j]));
           sacc += acc[i][j][0];
         }
       if (sacc == 12345.f) a.out[0] = 1;
@@ -339,8 +355,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
 #endif
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        if (3 * ia + j < N_AGPR) asm volatile("" : "+a"(acc[ia][j]));
-        if (paired && 3 * ib + j < N_AGPR) asm volatile("" : "+a"(acc[ib][j]));
+        if (3 * ia + j < NAG) asm volatile("" : "+a"(acc[ia][j]));
+        if (paired && 3 * ib + j < NAG) asm volatile("" : "+a"(acc[ib][j]));
       }
       float x[16];
       auto recombine3 = [&](const float (&pr)[3]) -> float {
@@ -378,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6_kernel(Fp6Args a) {
           x[r + 8] = __uint_as_float(xx[1]);                             // t = r + 8 (computed by the odd lane)
         }
       }
-      const int ti = wave + 4 * (odd ? ib : ia);
+      const int ti = wave + NWV * (odd ? ib : ia);
       const int pl = 2 * ti + half;                 // accumulator lane-half == position within the tile
       const int p = pl + band * HWb;                // position in the image
       const bool pos_ok = pl < HWb && (paired || !odd);
@@ -702,7 +718,11 @@ int launch_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* s
   if (bands) {
     hipLaunchKernelGGL((conv3x3_fp6_kernel<4, RAW, true>), grid, blk, lds, stream, a);
   } else if (split_last) {
-    hipLaunchKernelGGL((conv3x3_fp6_kernel<6, RAW>), grid, blk, lds, stream, a);
+    static const bool eight = [] { const char* e = getenv("SPKDIFF_FP6_WAVES"); return e && e[0] == '8'; }();
+    if (eight && (H * ((W + 1) / 2) + 7) / 8 <= 4)
+      hipLaunchKernelGGL((conv3x3_fp6_kernel<3, RAW, false, 8>), grid, dim3(512), lds, stream, a);
+    else
+      hipLaunchKernelGGL((conv3x3_fp6_kernel<6, RAW>), grid, blk, lds, stream, a);
     SPK_LAUNCH_CHECK();
     hipLaunchKernelGGL(conv3x3_fp6_lastpos_kernel<RAW>, dim3((B + 2 * LP_TILES - 1) / (2 * LP_TILES), G / 4), blk, 0, stream, a);
   } else {
