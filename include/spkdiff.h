@@ -263,6 +263,13 @@ int spk_psample_step(const float* logits_bkhw, long long* x_t_inout, uint8_t* un
                      long long* x0_hat_out_or_null, int B, int HW, int K, const int* active_or_null,
                      const int* n_active_or_null, spk_stream_t stream);
 
+/* ---- measurement aid ------------------------------------------------------------------------------------------ */
+/* Shader clock this device holds under a block-scaled fp6 x fp4 MFMA load (bench.py records it next to every
+ * matrix-core number: devices of one pool differ by ~10 %).  nblocks workgroups of 256 threads issue 4*iters MFMAs per
+ * wave between two {s_memtime, s_memrealtime} stamps; out [nblocks][4] u64 = {shader cycles, 100 MHz ticks, MFMAs
+ * per wave, 0}.  No counterpart in the reference (it has no timing hooks on this path). */
+int spk_clock_probe(unsigned long long* out, int nblocks, int iters, spk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,9 @@ Fixtures: F1 LIF, F2 per-layer VQ-VAE (teacher forced), F3 enco
 F4 decode glue, F5 denoiser, F6 p_sample + RNG-order trajectory, F7 BN eval,
 F8 LIF training forward + surrogate-gradient BPTT (next-row scope),
 F9 one diffusion training step (q_sample + denoiser in train() mode + reweighted-ELBO loss + backward),
-F10 one VQ-VAE training step (SNN_VQVAE in train() mode: VQ / commitment / PSP / reconstruction losses + backward).
+F10 one VQ-VAE training step (SNN_VQVAE in train() mode: VQ / commitment / PSP / reconstruction losses + backward),
+F12 get_data_for_diff over three batches (membrane state carried from batch to batch, as the reference does),
+F13 the benchmark's own length end to end: 100 reverse steps (B = 8) + decode to uint8 by the real reference.
 
     python oracle/gen_golden.py f9         # only rewrite the fixtures whose file name starts with "f9"
 """
@@ -466,6 +468,73 @@ def main():
         weights_crc=synth.state_checksum(sdv))
     print("F10 ok: loss_eq", float(leq), "loss_rec", float(lrec), "real", float(lreal), "codes used", int(idx10.unique().numel()),
           f"gradients bit-identical: {n_exact10} of {len(grads10)}")
+    # ------------------------------------------------------------------ F12 get_data_for_diff (state carried over batches)
+    # R/snn_model/vq_diffusion.py:23-36 calls model(images_spike, images) batch after batch with no reset_net: membrane
+    # potentials carry over.  The REAL function is run (its hard-coded images.cuda() is the identity here).
+    cfg = synth.MNIST
+    sdv = synth.synth_vqvae_state(cfg)
+    m12 = vm.SNN_VQVAE(1, 16, 128, torch.tensor(1.0))
+    vm.functional.set_step_mode(net=m12, step_mode="m")
+    m12.load_state_dict(sdv)
+    g = torch.Generator().manual_seed(1212)
+    loader12 = [(torch.rand(6, 1, 28, 28, generator=g), torch.zeros(6)) for _ in range(3)]
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        got12 = vd.get_data_for_diff(loader12, m12)
+    finally:
+        torch.Tensor.cuda = real_cuda
+    vm.functional.reset_net(m12)
+    with torch.inference_mode():
+        or12 = ref.get_data_for_diff(loader12, sdv)
+        fresh12 = [ref.encode_indices(im, sdv) for im, _ in loader12]
+    for a, b in zip(got12, or12):
+        eq(a, b, "F12 get_data_for_diff indices (carried state)")
+    n_state_dependent = sum(int((a != b).sum()) for a, b in zip(got12[1:], fresh12[1:]))
+    assert torch.equal(got12[0], fresh12[0])
+    np.savez_compressed(os.path.join(OUT, "f12_get_data_for_diff.npz"), images=np.stack([im.numpy() for im, _ in loader12]),
+                        indices=np.stack([a.numpy() for a in got12]), indices_fresh_state=np.stack([a.numpy() for a in fresh12]),
+                        weights_crc=synth.state_checksum(sdv))
+    print(f"F12 ok: 3 batches of 6; {n_state_dependent} indices of batches 2-3 depend on the carried state")
+
+    # ------------------------------------------------------------------ F13 the benchmark's own length, end to end
+    # R/snn_model/vq_diffusion.py:103-142 run for 100 reverse steps (B = 8, global CPU RNG in the reference's order),
+    # then the decode glue of R/main.py:388-401 down to uint8 -- by the REAL reference classes; the oracle must agree.
+    B13, steps13 = 8, 100
+    den13 = vd.DummyModel(1, 128)
+    functional.set_step_mode(net=den13, step_mode="m")
+    den13.load_state_dict(sdd)
+    den13.eval()
+    ab13 = vd.AbsorbingDiffusion(den13, mask_id=128)
+    ab13.n_samples = B13
+    vd.torch = _CpuTorch(torch)
+    try:
+        torch.manual_seed(1313)
+        with torch.inference_mode():
+            tok13 = ab13.sample(temp=1.0, sample_steps=steps13)
+    finally:
+        vd.torch = torch
+    m12.eval()
+    with torch.inference_mode():
+        smp = tok13.reshape(B13, 7, 7)
+        z13 = m12.vq_layer.quantize(smp).permute(0, 3, 1, 2).contiguous()
+        q13 = torch.unsqueeze(z13, dim=0).repeat(16, 1, 1, 1, 1)
+        q13 = m12.vq_layer.poisson(q13)
+        pred13 = torch.tanh(m12.memout(m12.decoder(q13)))
+        vm.functional.reset_net(m12)
+    u813 = np.array(np.clip((pred13 + 0.5).cpu().numpy(), 0.0, 1.0) * 255, dtype=np.uint8)
+    torch.manual_seed(1313)
+    with torch.inference_mode():
+        ou8, otok = ref.sample_images(sdv, sdd, B13, 128, 1.0, steps13, 7, 16)
+    eq(tok13, otok, "F13 100-step tokens")
+    assert np.array_equal(u813, ou8), "oracle != reference: F13 uint8 images"
+    f13 = np.clip((pred13 + 0.5).numpy(), 0, 1) * 255
+    np.savez_compressed(os.path.join(OUT, "f13_sample_100_steps.npz"), seed=1313, B=B13, steps=steps13, temp=1.0,
+                        tokens=tok13.numpy(), pred=pred13.numpy(), u8=u813,
+                        u8_edge_dist=np.abs(f13 - np.round(f13)).astype(np.float32),
+                        weights_crc_den=synth.state_checksum(sdd), weights_crc_vae=synth.state_checksum(sdv))
+    print("F13 ok: 100 reverse steps x 8 samples + decode; tokens", tok13.flatten()[:10].tolist(),
+          "codes used", int(tok13.unique().numel()))
     print("all fixtures written to", OUT)
 
 

@@ -146,15 +146,20 @@ def bn_apply_fma(x_seq, a, b):
     return (x_seq.double() * a.double().view(1, 1, c, 1, 1) + b.double().view(1, 1, c, 1, 1)).float()
 
 
-def conv_bn_lif(x_seq, sd, conv_prefix, bn_prefix, stride, padding, transposed=False, output_padding=0):
-    """One (Conv|ConvT) + BN + LIF block with fresh LIF state; returns (spikes, pre_activation)."""
+def conv_bn_lif(x_seq, sd, conv_prefix, bn_prefix, stride, padding, transposed=False, output_padding=0, state=None):
+    """One (Conv|ConvT) + BN + LIF block; returns (spikes, pre_activation).  LIF state: fresh, unless ``state`` (a dict)
+    is given -- then the block's membrane potential is read from / left in ``state[bn_prefix]``, the way a module keeps
+    ``v`` between two forwards that no ``reset_net`` separates (SJ/activation_based/base.py:277-343)."""
     if transposed:
         y = seq_conv_transpose2d(x_seq, sd[conv_prefix + ".weight"], sd[conv_prefix + ".bias"],
                                  stride, padding, output_padding)
     else:
         y = seq_conv2d(x_seq, sd[conv_prefix + ".weight"], sd[conv_prefix + ".bias"], stride, padding)
     y = seq_bn_eval(y, sd, bn_prefix)
-    s, _ = lif_multi_step(y)
+    if state is None:
+        s, _ = lif_multi_step(y)
+    else:
+        s, state[bn_prefix] = lif_multi_step(y, state.get(bn_prefix, 0.0))
     return s, y
 
 
@@ -172,12 +177,12 @@ def membrane_output(x_seq, coef=None):
 
 
 # --------------------------------------------------------------------------- a3
-def encoder_forward(x_seq, sd, return_layers=False):
-    """Encoder.forward, R/snn_model/vae_model.py:101-129."""
+def encoder_forward(x_seq, sd, return_layers=False, state=None):
+    """Encoder.forward, R/snn_model/vae_model.py:101-129 (``state``: carried membrane potentials, see conv_bn_lif)."""
     p = "encoder.snn_convs."
-    s1, y1 = conv_bn_lif(x_seq, sd, p + "0", p + "1", 2, 1)
-    s2, y2 = conv_bn_lif(s1, sd, p + "3", p + "4", 2, 1)
-    s3, y3 = conv_bn_lif(s2, sd, p + "6", p + "7", 1, 0)
+    s1, y1 = conv_bn_lif(x_seq, sd, p + "0", p + "1", 2, 1, state=state)
+    s2, y2 = conv_bn_lif(s1, sd, p + "3", p + "4", 2, 1, state=state)
+    s3, y3 = conv_bn_lif(s2, sd, p + "6", p + "7", 1, 0, state=state)
     if return_layers:
         return s3, [(s1, y1), (s2, y2), (s3, y3)]
     return s3
@@ -243,13 +248,28 @@ def snn_vqvae_forward(x_seq, sd):
     return e, x_recon, idx
 
 
-def encode_indices(images, sd, T=16):
-    """Body of get_data_for_diff, R/snn_model/vq_diffusion.py:23-36 (one batch, no .cuda())."""
+def encode_indices(images, sd, T=16, state=None):
+    """Body of get_data_for_diff's loop, R/snn_model/vq_diffusion.py:27-34 (one batch, no .cuda()).
+
+    The reference calls ``model(images_spike, images)`` for batch after batch with NO ``reset_net`` in between
+    (:23-36; its loaders drop the last ragged batch, R/load_dataset_snn.py:65-66), so every LIF layer starts a batch
+    from the membrane potentials the previous batch left.  Pass one ``state`` dict across the batches to reproduce that;
+    ``state=None`` encodes from the reset state.  Only the encoder's state can reach the code indices (the spike
+    generator's and the decoder's come after the code search)."""
     images = images - 0.5
     x_seq = images.unsqueeze(0).repeat(T, 1, 1, 1, 1)
-    _, _, idx = snn_vqvae_forward(x_seq, sd)
+    z = encoder_forward(x_seq, sd, state=state)
+    flat, _ = vq_readout(z, sd)
+    idx = vq_code_indices(flat, sd["vq_layer.embeddings.weight"])
     L = images.shape[-1] // 4
     return idx.reshape(images.shape[0], L, L)
+
+
+def get_data_for_diff(batches, sd, T=16):
+    """get_data_for_diff, R/snn_model/vq_diffusion.py:23-36: list of [B,h,w] index tensors, LIF state carried from
+    batch to batch as the reference does (no reset inside the loop)."""
+    state = {}
+    return [encode_indices(images, sd, T, state) for images, _ in batches]
 
 
 def decode_tokens(tokens_bhw, sd, T=16):

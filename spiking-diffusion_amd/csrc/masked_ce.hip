@@ -49,12 +49,41 @@ __global__ __launch_bounds__(CE_TPB) void masked_ce_kernel(const float* __restri
   }
 }
 
+// Same arithmetic without the LDS tile, for [K][hw] tiles beyond 64 KB (large codebooks): one thread per position,
+// logits re-read from global memory (threads of a wave read adjacent positions of one class: coalesced).
+__global__ __launch_bounds__(CE_TPB) void masked_ce_global_kernel(const float* __restrict__ logits, const float* __restrict__ target,
+                                                                  const float* __restrict__ coef, float* __restrict__ ce_out,
+                                                                  float* __restrict__ dlogits, int K, int HW) {
+  const int b = blockIdx.x;
+  const float* src = logits + (long long)b * K * HW;
+  for (int p = threadIdx.x; p < HW; p += CE_TPB) {
+    float m = src[p];
+    for (int k = 1; k < K; ++k) m = fmaxf(m, src[k * HW + p]);
+    float s = 0.0f;
+    for (int k = 0; k < K; ++k) s += expf(src[k * HW + p] - m);
+    const float off = m + logf(s);
+    const float tf = target[(long long)b * HW + p];
+    const int tg = (tf >= 0.0f && tf < (float)K) ? (int)tf : -1;
+    ce_out[(long long)b * HW + p] = tg >= 0 ? -((src[tg * HW + p] - m) - logf(s)) : 0.0f;
+    if (dlogits) {
+      const float cb = coef[b];
+      float* dst = dlogits + (long long)b * K * HW;
+      for (int k = 0; k < K; ++k)
+        dst[k * HW + p] = tg < 0 ? 0.0f : cb * (expf(src[k * HW + p] - off) - (k == tg ? 1.0f : 0.0f));
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int spk_masked_ce(const float* logits, const float* target, const float* coef, float* ce_out, float* dlogits, int B,
                              int K, int HW, hipStream_t stream) {
   if (!logits || !target || !ce_out || (dlogits && !coef) || B <= 0 || K <= 0 || HW <= 0) return SPK_ERR_ARG;
-  if ((long long)K * HW + 2LL * HW > CE_MAX_TILE) return SPK_ERR_UNSUPPORTED;
+  if ((long long)K * HW + 2LL * HW > CE_MAX_TILE) {
+    hipLaunchKernelGGL(masked_ce_global_kernel, dim3(B), dim3(CE_TPB), 0, stream, logits, target, coef, ce_out, dlogits, K, HW);
+    SPK_LAUNCH_CHECK();
+    return SPK_OK;
+  }
   const size_t lds = ((size_t)K * HW + 2 * (size_t)HW) * sizeof(float);
   hipLaunchKernelGGL(masked_ce_kernel, dim3(B), dim3(CE_TPB), lds, stream, logits, target, coef, ce_out, dlogits, K, HW);
   SPK_LAUNCH_CHECK();

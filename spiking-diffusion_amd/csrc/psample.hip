@@ -61,8 +61,9 @@ __device__ __forceinline__ bool __any_sync_quad(bool v) {      // OR over the 4 
   return x != 0;
 }
 
-constexpr int KPL = 4;  // classes per lane: K <= 256
-
+// KPL = classes per lane (K <= 64 * KPL): 4 covers the reference's default codebook (--codebook_size 128, R/main.py:58);
+// 8 / 16 / 32 are instantiated for larger codebooks (K <= 2048)
+template <int KPL>
 __global__ __launch_bounds__(256) void psample_kernel(const float* __restrict__ logits, long long* __restrict__ x_t,
                                                       uint8_t* __restrict__ unmasked, int t, float temp,
                                                       const float* __restrict__ u_in, const float* __restrict__ q_in,
@@ -257,13 +258,19 @@ extern "C" int spk_psample_step(const float* logits_bkhw, long long* x_t_inout, 
     return SPK_ERR_ARG;
   if ((active_or_null == nullptr) != (n_active_or_null == nullptr) || (active_or_null && x0_hat_out_or_null))
     return SPK_ERR_ARG;
-  if (K > 64 * KPL) return SPK_ERR_UNSUPPORTED;
+  if (K > 64 * 32) return SPK_ERR_UNSUPPORTED;
   long long npos = (long long)B * HW;
   int grid = (int)((npos + 3) / 4);
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(psample_kernel, dim3(grid), dim3(256), 0, stream, logits_bkhw, x_t_inout, unmasked_inout, t, temp,
-                     u_or_null, q_or_null, philox_seed, philox_offset, philox_state_or_null, x0_hat_out_or_null, active_or_null,
-                     n_active_or_null, B, HW, K);
+#define SPK_PSAMPLE_LAUNCH(KPL)                                                                                          \
+  hipLaunchKernelGGL(psample_kernel<KPL>, dim3(grid), dim3(256), 0, stream, logits_bkhw, x_t_inout, unmasked_inout, t,   \
+                     temp, u_or_null, q_or_null, philox_seed, philox_offset, philox_state_or_null, x0_hat_out_or_null,   \
+                     active_or_null, n_active_or_null, B, HW, K)
+  if (K <= 256) SPK_PSAMPLE_LAUNCH(4);
+  else if (K <= 512) SPK_PSAMPLE_LAUNCH(8);
+  else if (K <= 1024) SPK_PSAMPLE_LAUNCH(16);
+  else SPK_PSAMPLE_LAUNCH(32);
+#undef SPK_PSAMPLE_LAUNCH
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

@@ -18,22 +18,35 @@ from spikingjelly.activation_based import neuron, functional, layer, surrogate, 
 from spikingjelly import visualizing  # noqa: F401
 
 from spkdiff import ops
-from spkdiff.fused import FusedSequential
+from spkdiff.fused import FusedSequential, invalidate_derived
 from spkdiff.ops import IN_PTC, IN_TINV
 
 from .vae_model import *  # noqa: F401,F403  (R/snn_model/vq_diffusion.py:21)
 
 
-def get_data_for_diff(train_loader, model, T: int = 16):
-    """Encode a data set to code indices (R/snn_model/vq_diffusion.py:23-36): one fused encode per batch."""
+def get_data_for_diff(train_loader, model, T: int = 16, carry_state: bool = True):
+    """Encode a data set to code indices (R/snn_model/vq_diffusion.py:23-36).
+
+    The reference calls ``model(images_spike, images)`` batch after batch with no ``reset_net`` inside the loop, so every
+    LIF layer starts a batch from the membrane potentials the previous batch left (its loaders drop the ragged last
+    batch, R/load_dataset_snn.py:65-66).  ``carry_state=True`` (default) is that call sequence on the fused module path
+    -- same indices as the reference (fixture F12), same module state afterwards; a batch of another size raises, as it
+    does there.  ``carry_state=False`` encodes every batch from the reset state with the encoder alone (time-invariant
+    input folded into the first kernel; nothing of the module state is read or written)."""
     print('prepare data for train diffusion...')
     model.eval()
     train_indices = []
     dev = next(model.parameters()).device
     for images, labels in train_loader:
-        images = (images - 0.5).to(dev)  # normalize to [-0.5, 0.5]
+        images = (images - 0.5).to(dev).float().contiguous()  # normalize to [-0.5, 0.5]
         with torch.inference_mode():
-            idx = model.encode_images(images.float().contiguous(), T)
+            if carry_state:
+                images_spike = images.unsqueeze(0).repeat(T, 1, 1, 1, 1)
+                _, _, encoding_indices = model(images_spike, images)
+                L = images.shape[-1] // 4
+                idx = encoding_indices.reshape(images.shape[0], L, L)
+            else:
+                idx = model.encode_images(images, T)
             train_indices.append(idx.cpu())
     return train_indices
 
@@ -58,7 +71,12 @@ class AbsorbingDiffusion(Sampler):
         # CPU generator in the reference's order (rand_like, then multinomial's exponential_), which reproduces the
         # reference CPU path token for token under the same torch.manual_seed.
         self.noise_source = 'philox'
-        self._philox_calls = 0
+        # Philox contract ('philox' mode): every sample() call takes ONE 62-bit draw from torch's global CPU generator as
+        # its key, so ``torch.manual_seed(s); sample(); sample()`` gives two different batches and re-seeding repeats
+        # them -- the reference's behaviour -- and two samplers in one process never share a stream.  ``philox_stream``
+        # (default: the RANK of the process) is folded into the key, so ranks seeded alike still draw distinct noise.
+        import os
+        self.philox_stream = int(os.environ.get('RANK', '0'))
         # Replay the whole reverse process as ONE hipGraph (philox mode, no hooks): the ~800 kernel launches of a
         # 100-step sample are captured once per (batch, steps, temp) and replayed; fresh noise per replay comes from a
         # 2-word device buffer {seed, counter base} the kernels read (spk_psample_step philox_state).
@@ -127,13 +145,17 @@ class AbsorbingDiffusion(Sampler):
         K = self.num_classes
         if sample_steps is None:
             sample_steps = self.num_timesteps
-        seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
-        base = self._philox_calls * (1 << 40)
-        self._philox_calls += 1
+        seed, base = 0, 0
+        if noise is None and self.noise_source == 'philox':
+            seed = self._philox_key()
         if self.use_graph and noise is None and record is None and self.noise_source == 'philox':
             try:
                 return self._sample_graphed(dev, b, h, w, K, float(temp), int(sample_steps), seed, base)
+            except (NotImplementedError, ValueError, TypeError):
+                raise                          # an argument / support error of a kernel, not a capture problem
             except RuntimeError as e:          # capture refused (e.g. another thread touched the device): same kernels,
+                if 'capture' not in str(e).lower() and 'graph' not in str(e).lower():
+                    raise
                 import warnings                # issued one by one
                 warnings.warn(f'spkdiff: hipGraph capture of the sampler failed ({e}); launching eagerly')
                 self.use_graph = False
@@ -163,6 +185,15 @@ class AbsorbingDiffusion(Sampler):
 
     def _skip_ok(self, h, w):
         return bool(self.skip_untouched)            # every kernel family takes the device-side image count
+
+    def _philox_key(self):
+        draw = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64))
+        return (draw ^ ((int(self.philox_stream) * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF)) & 0x7FFFFFFFFFFFFFFF
+
+    def invalidate(self):
+        """Drop captured graphs and every derived weight form of the denoiser (see spkdiff.fused.invalidate_derived)."""
+        self._graphs.clear()
+        invalidate_derived(self._denoise_fn)
 
 
 def _weights_key(module):
@@ -255,9 +286,12 @@ class DummyModel(nn.Module):
     _latent_hw = (7, 7)        # latent size of the last call (7x7 MNIST-shaped, 8x8 CIFAR-shaped)
 
     def impl_for(self, h, w):
-        """Kernel family used for conv2..conv6 on an h x w latent."""
+        """Kernel family used for conv2..conv6 on an h x w latent.  The matrix-core families carry conv2..conv5's
+        spikes in layouts only their own conv6 kernel reads, and that kernel packs 16 output channels per tile: any
+        ``num_embeddings`` that is not a multiple of 16 (the reference accepts every --codebook_size, R/main.py:58)
+        runs the whole call on the fp64 direct kernels."""
         req = self.conv_impl_request
-        if req == 'direct':
+        if req == 'direct' or self.conv6[0].out_channels % 16 != 0:
             return 'direct-f64'
         if (req in ('auto', 'fp6') and self.collapse_conv6 and
                 ops.den_fp6_supported(128, 64, 3, 1, 1, self.n_steps, h, w)):
@@ -270,11 +304,11 @@ class DummyModel(nn.Module):
 
     def _run(self, inp_b2hw, stateful, record=None):
         T = self.n_steps
-        impl = 'direct' if self.conv_impl_request == 'direct' else 'auto'
         # spikes travel channel-chunked: CPTC (32 u8 channels per chunk) for the int8 kernel, C4 (64 fp4 nibbles per
         # chunk) for the fp6 kernel -- the layout each stages per K chunk
         self._latent_hw = (int(inp_b2hw.shape[-2]), int(inp_b2hw.shape[-1]))
         which = self.conv_impl
+        impl = 'direct' if which == 'direct-f64' else 'auto'
         collapse = which != 'direct-f64' and self.collapse_conv6
         chunk = ops.CHUNK_C4 if which == 'mfma-fp6x6' else 32
         with ops.timed('den.conv1'):
@@ -324,6 +358,15 @@ class DummyModel(nn.Module):
         c6 = self.conv6
         x6 = c6.train_forward(cat, binary_input=True) if c6._trainable_fused(c6._blocks(), cat) else c6(cat)
         return torch.sum(x6, dim=0) / T
+
+    def invalidate(self):
+        """Rebuild packed weights / BN terms on the next call (needed after writes through ``.data``)."""
+        invalidate_derived(self)
+
+    def train(self, mode: bool = True):
+        if mode != self.training:
+            invalidate_derived(self)
+        return super().train(mode)
 
     def forward(self, x, t) -> torch.Tensor:
         # x: b,c,h,w (token ids as floats); t: b

@@ -32,6 +32,11 @@ class ConvParams:
         self.key_i8 = None
         self.i8 = None
 
+    def invalidate(self):
+        """Forget every derived form (call after writing weights through ``.data``: that does not bump ``_version``)."""
+        self.key = self.key_i8 = None
+        self.key_fp6 = self.key_i8g = None
+
     def get(self, conv):
         key = (_ver(conv.weight), _ver(conv.bias))
         if key != self.key:
@@ -76,8 +81,36 @@ def _is_conv(m):
     return isinstance(m, (layer.Conv2d, layer.ConvTranspose2d))
 
 
+def invalidate_derived(module):
+    """Drop every cached derived form of the parameters below ``module``: packed convolution weights (fp32 / int8 /
+    fp6 digit planes), folded BatchNorm terms, captured sampler graphs.  The caches are keyed by ``(data_ptr,
+    _version)``, which in-place writes through ``.data`` (``p.data.copy_(ema)``) do NOT change -- call this after such a
+    write.  ``load_state_dict`` and train()/eval() transitions call it on their own."""
+    for m in module.modules():
+        pr = getattr(m, '_spk_params', None)
+        if pr is not None:
+            pr.invalidate()
+        if isinstance(m, layer.BatchNorm2d):
+            m._affine_cache = None
+        g = getattr(m, '_graphs', None)
+        if isinstance(g, dict):
+            g.clear()
+
+
 class FusedSequential(nn.Sequential):
     """nn.Sequential whose (conv, bn, lif) triples run as fused HIP kernels in eval / multi-step mode."""
+
+    def __init__(self, *args):
+        super().__init__(*args)
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: invalidate_derived(module))
+
+    def invalidate(self):
+        invalidate_derived(self)
+
+    def train(self, mode: bool = True):
+        if mode != self.training:                 # a training phase rewrites the weights (also through .data): rebuild
+            invalidate_derived(self)
+        return super().train(mode)
 
     def _blocks(self):
         mods = list(self)

@@ -68,6 +68,13 @@ class timed:
 
 
 def _stream(t: torch.Tensor):
+    """HIP stream the launch goes to: torch's current stream of the tensor's device.  A launch is issued in the calling
+    thread's current device context, so a tensor on another GPU is refused rather than launched into the wrong context
+    (this package runs one process per GPU; ``with torch.cuda.device(t.device):`` around the call is the way to address
+    a second device from one process)."""
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"spkdiff: tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "wrap the call in `with torch.cuda.device(tensor.device):`")
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
@@ -88,6 +95,20 @@ def _p(t):
 
 def conv_out_size(n, k, stride, pad, transposed=False, out_pad=0):
     return lib.spk_conv_out_size(n, k, stride, pad, int(transposed), out_pad)
+
+
+def clock_probe(device, target_ms: float = 4.0):
+    """Shader clock [GHz] this device holds under a block-scaled fp6 x fp4 MFMA load (spk_clock_probe): median over
+    the workgroups of d(s_memtime) / d(s_memrealtime) * 0.1.  Synchronises.  Measurement aid for bench.py."""
+    nblk = torch.cuda.get_device_properties(device).multi_processor_count
+    out = torch.zeros((nblk, 4), dtype=torch.int64, device=device)
+    iters = max(1000, int(target_ms * 1e-3 / (4 * 33 / 2.0e9)))
+    check(lib.spk_clock_probe(_p(out), nblk, iters, _stream(out)), "spk_clock_probe")
+    o = out.cpu().double()
+    ghz = (o[:, 0] / o[:, 1].clamp(min=1)) * 0.1
+    cyc_per_mfma = o[:, 0] / o[:, 2].clamp(min=1)
+    return {"ghz_median": float(ghz.median()), "ghz_min": float(ghz.min()), "ghz_max": float(ghz.max()),
+            "cycles_per_mfma": float(cyc_per_mfma.median()), "workgroups": int(nblk), "mfma_per_wave": int(4 * iters)}
 
 
 # ---------------------------------------------------------------------------------------------- neuron
@@ -267,13 +288,17 @@ class MaskedCEFunction(torch.autograd.Function):
         ce = torch.empty((B, HW), dtype=torch.float32, device=lg.device)
         dl = torch.empty_like(lg) if ctx.needs_input_grad[0] else None
         check(lib.spk_masked_ce(_p(lg), _p(tg), _p(cf), _p(ce), _p(dl), B, K, HW, _stream(lg)), "spk_masked_ce")
-        ctx.dl = dl
+        ctx.has_dl = dl is not None
+        if dl is not None:
+            ctx.save_for_backward(dl)          # survives retain_graph / a second backward like any saved tensor
         return (ce.sum(1) * cf).sum()
 
     @staticmethod
     def backward(ctx, grad_out):
-        dl, ctx.dl = ctx.dl, None
-        return (None if dl is None else dl * grad_out), None, None
+        if not ctx.has_dl:
+            return None, None, None
+        (dl,) = ctx.saved_tensors
+        return dl * grad_out, None, None
 
 
 def masked_ce(logits, target):

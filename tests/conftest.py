@@ -25,3 +25,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """One JSON line with every parity figure the session measured (tests/parity_report.py)."""
+    import json
+    try:
+        from parity_report import RESULTS
+    except Exception:
+        return
+    if RESULTS:
+        terminalreporter.write_line("PARITY_REPORT " + json.dumps(RESULTS, sort_keys=True))

@@ -18,6 +18,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import snn_ref as ref           # noqa: E402  (checker only)
+from parity_report import record as parity  # noqa: E402  (one-line JSON parity summary at session end, tests/conftest.py)
 from spkdiff import synth                  # noqa: E402
 
 
@@ -236,6 +237,9 @@ def test_f2_fused_layers_teacher_forced(golden_dir, dev, ops):
         ygot = pre[:ny, 0] if pre.shape[0] >= ny else pre[0, 0].unsqueeze(0).expand(ny, -1, -1, -1)
         assert float((ygot - ywant).abs().max()) <= 2e-6 * (1 + float(ywant.abs().max())), name
     print("F2 spike mismatches (all inside fragile set) / fragile-set size:", report)
+    parity("f2_fused_layers_teacher_forced", spike_mismatches={k: v[0] for k, v in report.items()},
+           fragile_set={k: v[1] for k, v in report.items()})
+    assert all(v[0] == 0 for v in report.values()), "measured: 0 spike mismatches, even inside the fragile sets"
     # dec3 + membrane read-out (conv only, fused with sum_t coef[t] x[t])
     inp = unpack(d["dec3_in_bits"], d["dec3_in_shape"])
     dec3 = FusedSequential(list(dec)[6])
@@ -285,9 +289,13 @@ def test_f3_encode_decode_end_to_end(golden_dir, dev, tag, cfg):
     print(f"F3 {tag}: {int(clean.sum())}/{B} clean images (margin > 3e-6); index-exact {int(same_idx.sum())}/{B}; "
           f"pixels within 1e-4 on {int((err <= 1e-4).sum())}/{B}; max recon err {float(err.max()):.2e}; "
           f"per-image margins {[f'{m:.1e}' for m in margin.tolist()]}")
-    assert bool(same_idx[clean].all()), "code indices must be bit-exact on every clean image"
-    assert bool((err[clean] <= 1e-4).all()), "decoded pixels must be within 1e-4 on every clean image"
-    assert int(same_idx.sum()) >= B - 2 and int((err <= 1e-4).sum()) >= B - 2
+    parity("f3_encode_" + tag, images=B, index_exact_images=int(same_idx.sum()), pixels_within_1e-4=int((err <= 1e-4).sum()),
+           max_recon_err=float(err.max()), clean_images=int(clean.sum()))
+    # Measured on MI355X: every image index-exact and within 1e-4, the non-"clean" ones included (this library returns the
+    # correctly rounded exact dot product; the margins above say where the REFERENCE's own fp32 order could decide a spike).
+    # The kernels and the fixtures are deterministic, so the measured value is the bar.
+    assert bool(same_idx.all()), "code indices must be bit-exact on every image"
+    assert bool((err <= 1e-4).all()), "decoded pixels must be within 1e-4 on every image"
     # the time-invariant fast path (repeat folded into the kernel) gives the same indices as the module call
     with torch.inference_mode():
         idx2 = model.encode_images(images.to(dev), 16)
@@ -339,7 +347,9 @@ def test_f4_decode_glue(golden_dir, dev, tag, cfg):
     err2 = (pred2.cpu() - want).abs().flatten(1).max(1).values
     print(f"F4 {tag}: per-image max err (module sequence) {err.tolist()}, fused {err2.tolist()}")
     ok = (err <= 1e-4)
-    assert int(ok.sum()) >= len(err) - 1 and int((err2 <= 1e-4).sum()) >= len(err) - 1
+    parity("f4_decode_" + tag, images=len(err), within_1e-4_module_sequence=int(ok.sum()), within_1e-4_fused=int((err2 <= 1e-4).sum()),
+           max_err=float(max(err.max(), err2.max())))
+    assert bool(ok.all()) and bool((err2 <= 1e-4).all())
     assert float((pred2.cpu() - pred.cpu()).abs().max()) <= 1e-5
     safe = torch.from_numpy(d["u8_edge_dist"] > 1e-3) & ok.view(-1, 1, 1, 1)
     assert np.array_equal(generated[safe.numpy()], d["u8"][safe.numpy()])
@@ -375,6 +385,7 @@ def test_f5_denoiser(golden_dir, dev, ops, tag, cfg):
         assert not bool((bad & ~frag).any()), f"conv{i}: spike differs outside the fragile set"
         prev = want
     print(f"F5 {tag} teacher-forced (mismatches, fragile, spikes):", report)
+    report_tf = report
     s5 = unpack(d["s5_bits"], d["s5_shape"]); s1 = unpack(d["s1_bits"], d["s1_shape"])
     lg = den.conv6.run(ops.spikes_to_ptc(s5.to(dev)), IN_PTC, final='mean', in1=ops.spikes_to_ptc(s1.to(dev)))['f32']
     assert float((lg.cpu() - want_logits).abs().max()) <= 1e-5, "conv6 + time mean on the reference's spikes"
@@ -390,7 +401,9 @@ def test_f5_denoiser(golden_dir, dev, ops, tag, cfg):
     diff = (logits.cpu() - want_logits).abs()
     frac_close = float((diff <= 1e-4).float().mean())
     print(f"F5 {tag} end-to-end logits: max abs diff {float(diff.max()):.3e}, within 1e-4: {frac_close:.5f}")
-    assert frac_close >= 0.98 and float(diff.max()) <= 0.1
+    parity("f5_denoiser_" + tag, logits_max_abs_diff=float(diff.max()), frac_within_1e-4=frac_close,
+           teacher_forced_mismatches={k: v[0] for k, v in report_tf.items()})
+    assert float(diff.max()) <= 1e-6, "end-to-end logits (measured 8.9e-8 / 6.0e-8: no spike flips against the reference)"
 
 
 @pytest.mark.parametrize("tag,cfg", [("mnist", synth.MNIST), ("cifar", synth.CIFAR)])
@@ -418,6 +431,8 @@ def test_f5_denoiser_mfma_int8_kernel(golden_dir, dev, ops, tag, cfg):
         assert not bool((bad & ~frag).any()), f"conv{i} (MFMA): spike differs outside the fragile set"
         assert torch.equal(got, direct), f"conv{i}: MFMA int8 path != fp64 direct path"
     print(f"F5 {tag} MFMA teacher-forced (mismatch vs golden, fragile, mismatch vs direct):", report)
+    parity("f5_int8_mfma_" + tag, mismatch_vs_golden={k: v[0] for k, v in report.items()},
+           mismatch_vs_direct={k: v[2] for k, v in report.items()})
     x5 = ops.spikes_to_ptc(spikes[5].to(dev), chunk=32); x1 = ops.spikes_to_ptc(spikes[1].to(dev), chunk=32)
     lg = den.conv6.run(x5, IN_PTC, final='mean', in1=x1)['f32'].cpu()
     lg_d = den.conv6.run(x5, IN_PTC, final='mean', in1=x1, impl='direct')['f32'].cpu()
@@ -467,6 +482,8 @@ def test_f5_denoiser_mfma_fp6_kernel(golden_dir, dev, ops):
         want_cnt = got.sum(0).reshape(B, C // 32, 32, H, W).permute(0, 1, 3, 4, 2)
         assert torch.equal(cnt.float(), want_cnt)
     print("F5 mnist fp6-MFMA teacher-forced (mismatch vs golden, fragile, mismatch vs direct):", report)
+    parity("f5_fp6_mfma_mnist", mismatch_vs_golden={k: v[0] for k, v in report.items()},
+           mismatch_vs_direct={k: v[2] for k, v in report.items()})
     x_t = torch.from_numpy(d["x_t"]).float().to(dev); t = torch.from_numpy(d["t"]).to(dev)
     with torch.inference_mode():
         a1 = den(x_t, t=t); a2 = den(x_t, t=t)
@@ -576,8 +593,8 @@ def test_sampler_skipping_untouched_images_gives_the_same_tokens(dev, steps):
         a = ab.sample(temp=0.9, sample_steps=steps).cpu()
         b = ab.sample(temp=0.9, sample_steps=steps).cpu()          # second replay: next Philox base
         ab.use_graph = False
-        ab._philox_calls = 0
-        c = ab.sample(temp=0.9, sample_steps=steps).cpu()          # eager, same counters as `a`
+        torch.manual_seed(1234)
+        c = ab.sample(temp=0.9, sample_steps=steps).cpu()          # eager, same key as `a` (re-seeded)
         ab.noise_source = 'host'
         torch.manual_seed(99)
         d = ab.sample(temp=0.9, sample_steps=min(steps, 12)).cpu()
@@ -899,7 +916,8 @@ def test_f6_trajectory_host_noise_matches_reference_cpu_path(golden_dir, dev):
     n_bad = int((tok.cpu() != want).sum())
     print(f"F6 trajectory: token mismatches {n_bad}/{want.numel()}, per-step logits max err {lerr}")
     assert tok.shape == (4, 1, 7, 7) and tok.dtype == torch.int64
-    assert n_bad <= 2, "same seed, same RNG order as the reference CPU path -> same tokens (up to fragile flips)"
+    parity("f6_trajectory_4_steps", token_mismatches=n_bad, tokens=int(want.numel()), logits_max_err=max(lerr))
+    assert n_bad == 0, "same seed, same RNG order as the reference CPU path -> same tokens"
 
 
 def test_psample_philox_statistics(dev, ops):
@@ -942,20 +960,24 @@ def test_full_sample_properties_b256(dev):
     ab = AbsorbingDiffusion(den, mask_id=128)
     ab.n_samples = 256
     torch.manual_seed(1)
-    ab._philox_calls = 0
     tok = ab.sample(temp=1.0, sample_steps=6)
     assert tok.shape == (256, 1, 7, 7) and int(tok.min()) >= 0 and int(tok.max()) < 128
-    ab._philox_calls = 0
+    torch.manual_seed(1)
     tok2 = ab.sample(temp=1.0, sample_steps=6)
-    assert torch.equal(tok, tok2), "same seed and counter -> same tokens"
+    assert torch.equal(tok, tok2), "torch.manual_seed(s); sample() repeats after re-seeding (the reference's contract)"
     assert len(ab._graphs) == 1, "the reverse process was replayed from one captured hipGraph"
     ab.use_graph = False
-    ab._philox_calls = 0
+    torch.manual_seed(1)
     tok3 = ab.sample(temp=1.0, sample_steps=6)
     ab.use_graph = True
-    assert torch.equal(tok, tok3), "graph replay == eager launches (same kernels, same Philox counters)"
+    assert torch.equal(tok, tok3), "graph replay == eager launches (same kernels, same Philox key)"
     tok4 = ab.sample(temp=1.0, sample_steps=6)
-    assert not torch.equal(tok, tok4), "the next call advances the Philox counter base"
+    assert not torch.equal(tok, tok4), "a second call under the same seed draws a new key"
+    ab2 = AbsorbingDiffusion(den, mask_id=128)
+    ab2.n_samples, ab2.philox_stream = 256, 1
+    torch.manual_seed(1)
+    tok5 = ab2.sample(temp=1.0, sample_steps=6)
+    assert not torch.equal(tok, tok5), "another rank (philox_stream) seeded alike draws different noise"
     pred, u8 = model.decode_tokens(tok.reshape(256, 7, 7))
     assert pred.shape == (256, 1, 28, 28) and u8.dtype == torch.uint8
     assert float(pred.abs().max()) <= 1.0
@@ -979,7 +1001,8 @@ def test_config1_T4_vs_oracle(dev):
     same = (idx.cpu().view(16, -1) == oidx.view(16, -1)).all(1)
     err = (xr.cpu() - oxr).abs().flatten(1).max(1).values
     print(f"T=4: index-exact images {int(same.sum())}/16, max err on those {float(err[same].max()):.2e}")
-    assert e.shape == (4, 16, 16, 7, 7) and int(same.sum()) >= 14 and float(err[same].max()) <= 1e-4
+    parity("config1_T4", index_exact_images=int(same.sum()), images=16, max_err=float(err.max()))
+    assert e.shape == (4, 16, 16, 7, 7) and bool(same.all()) and float(err.max()) <= 1e-4
 
 
 def test_main_py_call_sequence_conformance(dev):
@@ -1066,7 +1089,6 @@ def test_config4_cifar_shaped_b512_sample_properties(dev):
     ab = AbsorbingDiffusion(den, mask_id=128, latent_shape=(8, 8))
     ab.n_samples = 512
     torch.manual_seed(3)
-    ab._philox_calls = 0
     tok = ab.sample(temp=1.0, sample_steps=4)
     assert tok.shape == (512, 1, 8, 8) and int(tok.min()) >= 0 and int(tok.max()) < 128
     pred, u8 = model.decode_tokens(tok.reshape(512, 8, 8))
@@ -1149,6 +1171,8 @@ def test_f2_gather_mfma_layers_teacher_forced(golden_dir, dev, ops):
         assert not bool((bad & ~frag).any()), f"{name}: spike differs from the reference outside the fragile set"
         assert torch.equal(got, direct), f"{name}: gather-MFMA != fp64 direct"
     print("F2 gather-MFMA (mismatch vs golden, fragile, mismatch vs direct):", report)
+    parity("f2_gather_mfma_layers", mismatch_vs_golden={k: v[0] for k, v in report.items()},
+           mismatch_vs_direct={k: v[2] for k, v in report.items()})
     x = ops.spikes_to_ptc(unpack(d["dec3_in_bits"], d["dec3_in_shape"]).to(dev))
     dec3 = FusedSequential(list(dec)[6])
     r = dec3.run(x, IN_PTC, final='memout', coef=model.memout.coef.flatten(), apply_tanh=True, want_u8=True)
@@ -1310,17 +1334,120 @@ def test_sampler_trajectory_vs_live_oracle_12_steps(dev):
     want = ref.absorbing_sample(sd, 8, 128, 0.9, 12, 7, 16)
     n_bad = int((tok != want).sum())
     print(f"12-step trajectory B=8: token mismatches {n_bad}/{want.numel()}")
-    assert n_bad <= 2
+    parity("trajectory_12_steps_vs_live_oracle", token_mismatches=n_bad, tokens=int(want.numel()))
+    assert n_bad == 0
 
 
-def test_get_data_for_diff_matches_oracle(dev):
-    """bulk encode of a loader to code indices == the oracle's encode_indices."""
-    from snn_model.vq_diffusion import get_data_for_diff
+def test_get_data_for_diff_matches_reference_fixture_f12(golden_dir, dev):
+    """bulk encode of a loader to code indices.  F12 was produced by the REAL get_data_for_diff
+    (R/snn_model/vq_diffusion.py:23-36), which carries the membrane state from batch to batch (no reset_net in its loop):
+    409 of the 588 indices of batches 2-3 depend on it.  carry_state=True reproduces it index for index;
+    carry_state=False equals the per-batch fresh-state encode."""
+    from snn_model.vq_diffusion import get_data_for_diff, functional
+    d = load(golden_dir, "f12_get_data_for_diff.npz")
     model, sd = build_vae(synth.MNIST, dev)
-    g = torch.Generator().manual_seed(5)
-    loader = [(torch.rand(6, 1, 28, 28, generator=g), torch.zeros(6)) for _ in range(2)]
+    assert synth.state_checksum(sd) == str(d["weights_crc"])
+    loader = [(torch.from_numpy(im), torch.zeros(im.shape[0])) for im in d["images"]]
     got = get_data_for_diff(loader, model)
-    for (images, _), idx in zip(loader, got):
-        want = ref.encode_indices(images, sd, 16)
-        same = (idx == want).flatten(1).all(1)
-        assert int(same.sum()) >= 5, "code indices of a batch differ from the oracle on more than one image"
+    functional.reset_net(model)
+    fresh = get_data_for_diff(loader, model, carry_state=False)
+    bad = sum(int((g != torch.from_numpy(w)).sum()) for g, w in zip(got, d["indices"]))
+    bad_fresh = sum(int((g != torch.from_numpy(w)).sum()) for g, w in zip(fresh, d["indices_fresh_state"]))
+    parity("f12_get_data_for_diff", index_mismatches_carried_state=bad, index_mismatches_fresh_state=bad_fresh,
+           indices=int(d["indices"].size))
+    assert bad == 0 and bad_fresh == 0
+    assert got[0].shape == (6, 7, 7) and got[0].dtype == torch.int64
+    live = ref.get_data_for_diff(loader, sd)
+    assert all(torch.equal(a, b) for a, b in zip(got, live))
+
+
+def test_f13_sample_100_steps_and_decode_vs_reference_fixture(golden_dir, dev):
+    """The benchmark's own length, end to end (VERDICT r1 missing #3): 100 reverse steps, B = 8, noise drawn on the host in
+    the reference's order under torch.manual_seed(1313), then the decode glue of R/main.py:388-401 down to uint8.  F13
+    holds what the REAL reference classes produced (R/snn_model/vq_diffusion.py:103-142): tokens must be equal, decoded
+    pixels within 1e-4, uint8 equal away from truncation edges."""
+    from snn_model.vq_diffusion import AbsorbingDiffusion
+    d = load(golden_dir, "f13_sample_100_steps.npz")
+    den, sdd = build_den(synth.MNIST, dev)
+    model, sdv = build_vae(synth.MNIST, dev)
+    assert synth.state_checksum(sdd) == str(d["weights_crc_den"]) and synth.state_checksum(sdv) == str(d["weights_crc_vae"])
+    B, steps = int(d["B"]), int(d["steps"])
+    out = {}
+    for skip in (False, True):
+        ab = AbsorbingDiffusion(den, mask_id=128)
+        ab.n_samples, ab.noise_source, ab.skip_untouched = B, 'host', skip
+        torch.manual_seed(int(d["seed"]))
+        out[skip] = ab.sample(temp=float(d["temp"]), sample_steps=steps)
+    tok = out[False]
+    want = torch.from_numpy(d["tokens"])
+    n_bad = int((tok.cpu() != want).sum())
+    pred, u8 = model.decode_tokens(tok.reshape(B, 7, 7))
+    err = float((pred.cpu() - torch.from_numpy(d["pred"])).abs().max()) if n_bad == 0 else float('nan')
+    safe = d["u8_edge_dist"] > 1e-3
+    u8_bad = int((u8.cpu().numpy()[safe] != d["u8"][safe]).sum())
+    u8_bad_all = int((u8.cpu().numpy() != d["u8"]).sum())
+    parity("f13_sample_100_steps_decode", token_mismatches=n_bad, tokens=int(want.numel()), pred_max_abs_err=err,
+           u8_mismatches_away_from_edges=u8_bad, u8_mismatches_all=u8_bad_all, pixels=int(d["u8"].size),
+           elimination_same_tokens=bool(torch.equal(out[True], tok)))
+    assert n_bad == 0, "100-step trajectory differs from the reference"
+    assert err <= 1e-4 and u8_bad == 0
+    assert torch.equal(out[True], tok), "untouched-image elimination changes no token over the full trajectory"
+    # and live against the oracle under another seed (the oracle is pinned to the reference by F6 and F13)
+    ab = AbsorbingDiffusion(den, mask_id=128)
+    ab.n_samples, ab.noise_source = 4, 'host'
+    torch.manual_seed(4242)
+    tok2 = ab.sample(temp=0.8, sample_steps=steps).cpu()
+    torch.manual_seed(4242)
+    ou8, otok = ref.sample_images(sdv, sdd, 4, 128, 0.8, steps, 7, 16)
+    _, u82 = model.decode_tokens(tok2.reshape(4, 7, 7).to(dev))
+    assert torch.equal(tok2, otok)
+    assert int((u82.cpu().numpy().astype(int) - ou8.astype(int)).__abs__().max()) <= 1
+
+
+@pytest.mark.parametrize("K", [100, 512])
+def test_other_codebook_sizes_sample_and_train(dev, K):
+    """The reference accepts any --codebook_size (R/main.py:58).  K = 100 (not a multiple of 16: the whole denoiser call
+    runs on the fp64 direct kernels) and K = 512 (matrix-core path; p_sample with 8 classes per lane; the cross-entropy
+    tile no longer fits 64 KB of LDS) must sample, decode indices in range, agree with the oracle, and train."""
+    from snn_model.vq_diffusion import DummyModel, AbsorbingDiffusion, functional
+    import dataclasses
+    cfg = dataclasses.replace(synth.MNIST, num_embeddings=K)
+    sd = synth.synth_denoiser_state(cfg)
+    den = DummyModel(1, K).cuda(0)
+    functional.set_step_mode(net=den, step_mode='m')
+    den.load_state_dict(sd)
+    den.eval()
+    assert den.impl_for(7, 7) == ('direct-f64' if K % 16 else 'mfma-fp6x6')
+    g = torch.Generator().manual_seed(K)
+    x_t = torch.randint(0, K + 1, (3, 1, 7, 7), generator=g)
+    t = torch.tensor([5, 50, 99])
+    with torch.inference_mode():
+        logits = den(x_t.float().to(dev), t=t.to(dev))
+        functional.reset_net(den)
+    want = ref.denoiser_forward(x_t.float(), t, sd, 16)
+    lerr = float((logits.cpu() - want).abs().max())
+    ab = AbsorbingDiffusion(den, mask_id=K)
+    ab.n_samples, ab.noise_source = 3, 'host'
+    torch.manual_seed(K)
+    tok = ab.sample(temp=1.0, sample_steps=6).cpu()
+    torch.manual_seed(K)
+    otok = ref.absorbing_sample(sd, 3, K, 1.0, 6, 7, 16)
+    n_bad = int((tok != otok).sum())
+    ab.noise_source = 'philox'
+    tokp = ab.sample(temp=1.0, sample_steps=6)
+    parity(f"codebook_size_{K}", logits_max_abs_err=lerr, token_mismatches_6_steps=n_bad, impl=den.impl_for(7, 7))
+    assert logits.shape == (3, K, 7, 7) and lerr <= 1e-5
+    assert n_bad == 0 and int(tokp.max()) < K and int(tokp.min()) >= 0
+    # one training step (masked cross-entropy with a [K][49] tile; K = 512 takes the no-LDS-tile kernel)
+    den.train()
+    x0 = torch.randint(0, K, (4, 1, 7, 7), generator=g).float().to(dev)
+    torch.manual_seed(7)
+    loss = ab.train_iter(x0)['loss']
+    loss.backward()
+    functional.reset_net(den)
+    sdo = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
+           for k, v in sd.items()}
+    torch.manual_seed(7)
+    lo, _ = ref.train_loss(x0.cpu(), sdo, K)
+    assert abs(float(loss) - float(lo)) <= 2e-5 * max(1.0, abs(float(lo)))
+    assert den.conv6[0].weight.grad is not None and bool(torch.isfinite(den.conv6[0].weight.grad).all())

@@ -240,3 +240,27 @@ def test_generalised_T4_runs(vae_mnist):
     img = torch.rand(3, 1, 28, 28, generator=torch.Generator().manual_seed(0)) - 0.5
     e, xr, idx = ref.snn_vqvae_forward(img.unsqueeze(0).repeat(4, 1, 1, 1, 1), sd)
     assert e.shape == (4, 3, 16, 7, 7) and xr.shape == (3, 1, 28, 28) and idx.shape == (147,)
+
+
+def test_f12_get_data_for_diff_carried_state(golden_dir, vae_mnist):
+    """F12: the REAL get_data_for_diff over three batches (no reset_net in its loop: membrane state carries)."""
+    d = load(golden_dir, "f12_get_data_for_diff.npz")
+    assert synth.state_checksum(vae_mnist) == str(d["weights_crc"])
+    loader = [(torch.from_numpy(im), None) for im in d["images"]]
+    with torch.inference_mode():
+        got = ref.get_data_for_diff(loader, vae_mnist)
+        fresh = [ref.encode_indices(im, vae_mnist) for im, _ in loader]
+    for g, w, f, wf in zip(got, d["indices"], fresh, d["indices_fresh_state"]):
+        assert torch.equal(g, torch.from_numpy(w)) and torch.equal(f, torch.from_numpy(wf))
+    assert not np.array_equal(d["indices"][1], d["indices_fresh_state"][1]), "the carried state matters in the fixture"
+
+
+def test_f13_sample_100_steps_and_decode(golden_dir, vae_mnist, den_mnist):
+    """F13: 100 reverse steps (B = 8) + decode to uint8 by the real reference; the oracle under the same seed."""
+    d = load(golden_dir, "f13_sample_100_steps.npz")
+    assert synth.state_checksum(den_mnist) == str(d["weights_crc_den"])
+    torch.manual_seed(int(d["seed"]))
+    with torch.inference_mode():
+        u8, tok = ref.sample_images(vae_mnist, den_mnist, int(d["B"]), 128, float(d["temp"]), int(d["steps"]), 7, 16)
+    assert torch.equal(tok, torch.from_numpy(d["tokens"]))
+    assert np.array_equal(u8, d["u8"])
