@@ -289,7 +289,7 @@ def test_f3_encode_decode_end_to_end(golden_dir, dev, tag, cfg):
     print(f"F3 {tag}: {int(clean.sum())}/{B} clean images (margin > 3e-6); index-exact {int(same_idx.sum())}/{B}; "
           f"pixels within 1e-4 on {int((err <= 1e-4).sum())}/{B}; max recon err {float(err.max()):.2e}; "
           f"per-image margins {[f'{m:.1e}' for m in margin.tolist()]}")
-    parity("f3_encode_" + tag, images=B, index_exact_images=int(same_idx.sum()), pixels_within_1e-4=int((err <= 1e-4).sum()),
+    parity("f3_encode_" + tag, images=B, index_exact_images=int(same_idx.sum()), pixels_within_1e_4=int((err <= 1e-4).sum()),
            max_recon_err=float(err.max()), clean_images=int(clean.sum()))
     # Measured on MI355X: every image index-exact and within 1e-4, the non-"clean" ones included (this library returns the
     # correctly rounded exact dot product; the margins above say where the REFERENCE's own fp32 order could decide a spike).
@@ -347,7 +347,7 @@ def test_f4_decode_glue(golden_dir, dev, tag, cfg):
     err2 = (pred2.cpu() - want).abs().flatten(1).max(1).values
     print(f"F4 {tag}: per-image max err (module sequence) {err.tolist()}, fused {err2.tolist()}")
     ok = (err <= 1e-4)
-    parity("f4_decode_" + tag, images=len(err), within_1e-4_module_sequence=int(ok.sum()), within_1e-4_fused=int((err2 <= 1e-4).sum()),
+    parity("f4_decode_" + tag, images=len(err), within_1e_4_module_sequence=int(ok.sum()), within_1e_4_fused=int((err2 <= 1e-4).sum()),
            max_err=float(max(err.max(), err2.max())))
     assert bool(ok.all()) and bool((err2 <= 1e-4).all())
     assert float((pred2.cpu() - pred.cpu()).abs().max()) <= 1e-5
@@ -401,7 +401,7 @@ def test_f5_denoiser(golden_dir, dev, ops, tag, cfg):
     diff = (logits.cpu() - want_logits).abs()
     frac_close = float((diff <= 1e-4).float().mean())
     print(f"F5 {tag} end-to-end logits: max abs diff {float(diff.max()):.3e}, within 1e-4: {frac_close:.5f}")
-    parity("f5_denoiser_" + tag, logits_max_abs_diff=float(diff.max()), frac_within_1e-4=frac_close,
+    parity("f5_denoiser_" + tag, logits_max_abs_diff=float(diff.max()), frac_within_1e_4=frac_close,
            teacher_forced_mismatches={k: v[0] for k, v in report_tf.items()})
     assert float(diff.max()) <= 1e-6, "end-to-end logits (measured 8.9e-8 / 6.0e-8: no spike flips against the reference)"
 
