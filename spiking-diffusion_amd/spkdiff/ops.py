@@ -233,6 +233,9 @@ class BNLIFTrainFunction(torch.autograd.Function):
         g = None if gamma is None else _dev(gamma, "gamma", torch.float32)
         b = None if beta is None else _dev(beta, "beta", torch.float32)
         v0 = _cl4(v_init, "v")
+        if v0 is not None and tuple(v0.shape) != tuple(y.shape[1:]):
+            raise RuntimeError(f"LIFNode state has shape {tuple(v0.shape)} but the input implies {tuple(y.shape[1:])}; "
+                               "call functional.reset_net first")
         for name, r in (("running_mean", running_mean), ("running_var", running_var)):
             if r is not None and (not r.is_cuda or r.dtype != torch.float32 or not r.is_contiguous()):
                 raise ValueError(f"{name} must be a contiguous fp32 device tensor (updated in place)")

@@ -1047,6 +1047,9 @@ def test_main_py_call_sequence_conformance(dev):
     idxs = ns["get_data_for_diff"](loader, model)
     assert len(idxs) == 2 and idxs[0].shape == (8, 7, 7) and idxs[0].dtype == torch.int64
     model.train()                                 # the training branch returns the reference's three losses
+    with pytest.raises(RuntimeError):             # get_data_for_diff left batch-8 membrane state behind, as the reference does
+        model(norm_images.unsqueeze(0).repeat(16, 1, 1, 1, 1), norm_images)
+    ns["functional"].reset_net(model)
     out = model(norm_images.unsqueeze(0).repeat(16, 1, 1, 1, 1), norm_images)
     assert len(out) == 3 and all(o.dim() == 0 for o in out)
     ns["functional"].reset_net(model)
