@@ -1441,16 +1441,19 @@ def test_other_codebook_sizes_sample_and_train(dev, K):
     parity(f"codebook_size_{K}", logits_max_abs_err=lerr, token_mismatches_6_steps=n_bad, impl=den.impl_for(7, 7))
     assert logits.shape == (3, K, 7, 7) and lerr <= 1e-5
     assert n_bad == 0 and int(tokp.max()) < K and int(tokp.min()) >= 0
-    # one training step (masked cross-entropy with a [K][49] tile; K = 512 takes the no-LDS-tile kernel)
+    # one training step on the same (t, u) as the oracle (masked cross-entropy with a [K][49] tile; K = 512 takes the
+    # no-LDS-tile kernel); library forward convolutions may flip a few spikes: the F9 tolerances
     den.train()
-    x0 = torch.randint(0, K, (4, 1, 7, 7), generator=g).float().to(dev)
-    torch.manual_seed(7)
-    loss = ab.train_iter(x0)['loss']
-    loss.backward()
-    functional.reset_net(den)
+    x0 = torch.randint(0, K, (4, 1, 7, 7), generator=g).float()
+    t4 = torch.tensor([3, 17, 30, 49])
+    u4 = torch.rand(4, 1, 7, 7, generator=g)
     sdo = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
            for k, v in sd.items()}
-    torch.manual_seed(7)
-    lo, _ = ref.train_loss(x0.cpu(), sdo, K)
-    assert abs(float(loss) - float(lo)) <= 2e-5 * max(1.0, abs(float(lo)))
+    lo, (_, x_t4, x0i4, _, _) = ref.train_loss(x0, sdo, K, t=t4, u=u4)
+    logits4 = den(x_t4.to(dev), t4.to(dev))
+    loss = ab._loss_from_logits(logits4, x0i4.to(dev), t4.to(dev))
+    loss.backward()
+    functional.reset_net(den)
+    parity(f"codebook_size_{K}_train", loss=float(loss), loss_oracle=float(lo))
+    assert abs(float(loss) - float(lo)) <= 1e-3 * max(1.0, abs(float(lo)))
     assert den.conv6[0].weight.grad is not None and bool(torch.isfinite(den.conv6[0].weight.grad).all())
