@@ -32,6 +32,7 @@ typedef struct ihipStream_t* spk_stream_t; /* == hipStream_t */
 
 /* fused-kernel epilogue modes (spk_conv_fused_fwd) */
 #define SPK_CHUNK_C4 (-64) /* chunk_out value: fp4 nibble-packed output, 64 channels per chunk */
+#define SPK_CHUNK_S32 (-32) /* chunk_out value: fp4 nibble-packed output, 32 channels per chunk ("S32", fp6v2 kernel) */
 #define SPK_MODE_LIF 0    /* BN + LIF -> spikes                                    */
 #define SPK_MODE_RAW 1    /* conv output per time step, fp32 TBCHW                 */
 #define SPK_MODE_MEMOUT 2 /* sum_t x[t]*coef[t] (+tanh, +uint8)  -> [B,C,H,W]      */
@@ -146,7 +147,8 @@ int spk_pack_conv_weight(const float* w, float* packed, int Cout, int Cin, int k
  *   mode RAW:    out_f32 TBCHW conv output.    mode MEMOUT: coef [T]; out_f32 [B,Cout,Ho,Wo] (tanh if apply_tanh),
  *                out_u8 = uint8(clip(p+0.5,0,1)*255) (R/main.py:401).   mode MEAN: out_f32 = sum_t x[t] / T.
  *   chunk0 / chunk1 / chunk_out: channel chunking of in0 / in1 / out_ptc (0: plain PTC); chunk_out = SPK_CHUNK_C4:
- *                out_ptc is written as nibble-packed fp4 "C4" (see spk_den_conv3x3_mfma_fp6; Cout % 64 == 0).
+ *                out_ptc is written as nibble-packed fp4 "C4" (see spk_den_conv3x3_mfma_fp6; Cout % 64 == 0);
+ *                SPK_CHUNK_S32: as "S32" (see spk_den_conv3x3_mfma_fp6v2; Cout % 32 == 0).
  *   out_counts (mode LIF, optional): per-neuron spike counts over T, u8 [B,Cout/32,Ho*Wo,32].
  *   n_dyn_or_null: optional device-side image count (<= B, see spk_select_active): only images [0, *n_dyn) are computed;
  *                buffers stay sized by B. */
@@ -201,6 +203,28 @@ int spk_den_pack_weight_fp6(const float* w, const float* bias, uint8_t* wq, doub
 int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* scale, const double* bias_d,
                              const float* bn_a, const float* bn_b, float* v_inout, uint8_t* out_c4, uint8_t* out_counts,
                              int T, int B, int H, int W, int Cout, const int* n_dyn_or_null, spk_stream_t stream);
+/* Second-generation form of spk_den_conv3x3_mfma_fp6 for the sampler (7x7 latents, fresh LIF state in, no state out):
+ * the SAME spikes bit for bit -- five digit planes on the matrix cores with adjacent digits sharing an accumulator through
+ * the per-block scales, fp32 recombination, every spike decision certified against a per-channel margin, and the ~1e-4 of
+ * neurons that come closer to the threshold recomputed exactly (all six digits, int64 / fp64) by a tail launch that also
+ * finishes the 49th position (csrc/den_mfma_fp6v2.hip).  DummyModel conv2..conv5, R/snn_model/vq_diffusion.py:166-184,201-204.
+ * Spikes travel as "S32": [B][C/32][H*W][16][16 B] (fp4 nibbles, channel c of a group in byte (c % 32) / 2, low nibble first).
+ * spk_den_pack_weight_fp6v2: fp32 [Cout,Cin,3,3] (+bias) -> packed digit tiles (spk_den_packed_weight_fp6v2_bytes), fp64
+ * scale / bias [Cout] as for the fp6 kernel, wl1 [Cout] = L1 norm of each channel's quantised weights (feeds the margin).
+ * w_f32: the original weights (read by the exact recomputation).  flag_words: zero-initialised u32 bitmap of
+ * spk_den_fp6v2_flag_words(B, Cout, H, W) words; it is clean again when the call's launches have run.
+ * SPK_ERR_UNSUPPORTED unless T == 16, H == W == 7, Cout % 32 == 0 (Cin = 32 * nch). */
+long long spk_den_packed_weight_fp6v2_bytes(int Cout, int Cin);
+int spk_den_pack_weight_fp6v2(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d, float* wl1,
+                              int Cout, int Cin, spk_stream_t stream);
+long long spk_den_fp6v2_flag_words(int B, int Cout, int H, int W);
+int spk_den_conv3x3_mfma_fp6v2(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale, const double* bias_d,
+                               const float* wl1, const float* w_f32, const float* bn_a, const float* bn_b, uint8_t* out_s32,
+                               uint8_t* out_counts, unsigned* flag_words, int T, int B, int H, int W, int Cout,
+                               const int* n_dyn_or_null, spk_stream_t stream);
+/* fp32 spikes [T,B,C,HW] <-> S32 (C % 32 == 0): module boundaries and tests. */
+int spk_spikes_to_s32(const float* spikes, uint8_t* out_s32, int T, int B, int C, int HW, spk_stream_t stream);
+int spk_s32_to_spikes(const uint8_t* in_s32, float* spikes, int T, int B, int C, int HW, spk_stream_t stream);
 /* fp32 spikes [T,B,C,HW] <-> C4 (C % 64 == 0): module boundaries and tests. */
 int spk_spikes_to_fp4(const float* spikes, uint8_t* out_c4, int T, int B, int C, int HW, spk_stream_t stream);
 int spk_fp4_to_spikes(const uint8_t* in_c4, float* spikes, int T, int B, int C, int HW, spk_stream_t stream);

@@ -102,7 +102,7 @@ struct FusedArgs {
   int T, B, H, W, Cout, Ho, Wo, k, stride, pad;
   uint8_t* out_cnt;     // MODE_LIF, optional: spike counts over T, u8 [B][Cout/32][Ho*Wo][32]
   int chunk0, chunk1, chunk_out;   // channel chunking of the PTC tensors ([B][C/chunk][HW][T][chunk]); chunk == C: plain
-  int out_c4;           // out_ptc is nibble-packed fp4 "C4" ([B][Cout/64][HW][T][32 B]) for the fp6 MFMA kernel
+  int out_c4;           // 64 / 32: out_ptc is nibble-packed fp4 ("C4" [B][Cout/64][HW][T][32 B] / "S32" [B][Cout/32][HW][T][16 B])
   const int* n_dyn;     // optional device-side batch count (<= B): only the first *n_dyn images are processed
 };
 
@@ -224,8 +224,8 @@ __global__ __launch_bounds__(256) void conv_fused_kernel(FusedArgs a) {
             // channels (co, co ^ 1) are neighbouring lanes: the even one stores both e2m1 nibbles (0x2 = 1.0)
             const int so = __shfl_xor((int)s, 1);
             if (!(co & 1))
-              a.out_ptc[((((long long)b * (a.Cout >> 6) + (co >> 6)) * plane + oy * a.Wo + ox) * T + t) * 32 + ((co & 63) >> 1)] =
-                  (uint8_t)((s ? 0x02 : 0) | (so ? 0x20 : 0));
+              a.out_ptc[((((long long)b * (a.Cout / a.out_c4) + (co / a.out_c4)) * plane + oy * a.Wo + ox) * T + t) * (a.out_c4 >> 1) +
+                        ((co % a.out_c4) >> 1)] = (uint8_t)((s ? 0x02 : 0) | (so ? 0x20 : 0));
           } else if (a.out_ptc) {
             a.out_ptc[o_ptc + (long long)t * a.chunk_out] = (uint8_t)s;
           }
@@ -334,8 +334,8 @@ extern "C" int spk_conv_fused_fwd(const void* in0, const uint8_t* in1, int C0, i
   if (in_kind == SPK_IN_PTC && ((C0 % 4) || (C1 % 4))) return SPK_ERR_UNSUPPORTED;   // u32 spike loads
   if (chunk0 <= 0) chunk0 = C0;
   if (chunk1 <= 0) chunk1 = C1 > 0 ? C1 : 4;
-  const int out_c4 = chunk_out == SPK_CHUNK_C4;
-  if (out_c4 && (mode != SPK_MODE_LIF || !out_ptc || (Cout % 64))) return SPK_ERR_ARG;
+  const int out_c4 = chunk_out == SPK_CHUNK_C4 ? 64 : (chunk_out == SPK_CHUNK_S32 ? 32 : 0);
+  if (out_c4 && (mode != SPK_MODE_LIF || !out_ptc || (Cout % out_c4))) return SPK_ERR_ARG;
   if (chunk_out <= 0) chunk_out = Cout;
   if (in_kind == SPK_IN_PTC && ((chunk0 % 4) || (C0 % chunk0) || (C1 > 0 && ((chunk1 % 4) || (C1 % chunk1)))))
     return SPK_ERR_ARG;

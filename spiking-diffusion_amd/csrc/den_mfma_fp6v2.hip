@@ -1,0 +1,746 @@
+// Second-generation 3x3 spike convolution for the denoiser's conv2..conv5 (R/snn_model/vq_diffusion.py:166-184,201-204;
+// SURVEY.md §8 a8) on the CDNA4 block-scaled MFMA -- the sampler's fast path (7x7 latents, fresh LIF state).  Same results,
+// bit for bit, as den_mfma_fp6.hip (the correctly rounded value of the exact 29-bit fixed-point dot product, then the
+// reference's fp32 BN and LIF arithmetic); what changes is how much matrix and vector work it takes to get there.
+//
+// 1. DIGIT PAIRS SHARE AN ACCUMULATOR.  v_mfma_scale_f32_32x32x64_f8f6f4 takes one E8M0 scale per operand row / column and
+//    32-wide K block, i.e. per lane.  The two K halves of an instruction carry the SAME 32 input channels with two
+//    adjacent radix-32 digits of the weights, the even digit scaled by 2^8 and the odd one by 2^3 (e2m3 holds d/8): the
+//    fp32 accumulator then holds 32 * D_even + D_odd directly -- an integer below 4608 * 528 < 2^24, still exact.  The
+//    column tile is 32 output channels of one digit pair, so the three values of a neuron-step (pairs 01, 23 and the
+//    fifth digit) sit in ONE lane: no cross-lane exchange in the epilogue, and all 64 lanes scan their own neuron.
+// 2. FIVE DIGITS ON THE MATRIX CORES, THE SIXTH ONLY WHERE IT MATTERS.  The sixth digit moves a pre-activation by at most
+//    E5 = 16 * 9 * Cin * 2^-s (~3e-6).  The main kernel multiplies five digits (23 instead of 27 MFMAs per row tile and
+//    32-channel chunk: the fifth digit pairs two TAPS per instruction), recombines in fp32, and CERTIFIES every spike
+//    decision: a neuron whose membrane potential ever comes within a per-channel margin of the threshold -- the margin
+//    bounds the dropped digit, the fp32 recombination and every rounding of BN / LIF, see margin_of() -- is flagged in a
+//    bitmap (about 1e-4 of the neurons).  The tail launch recomputes the flagged neurons EXACTLY (all six digits from the
+//    fp32 weights in int64, fp64 recombination, one rounding: the arithmetic of den_mfma_fp6.hip) and patches their
+//    spikes.  Unflagged neurons provably emit the spikes the exact arithmetic would; flagged ones are the exact
+//    arithmetic.  Membrane potentials are not an output here (fresh state in, nothing written back): callers that carry
+//    LIF state, and the training forward, use den_mfma_fp6.hip.
+// 3. A WORK ITEM = one image x 32 output channels, K chunk = 32 input channels: the spike slab of an image is fetched half
+//    as often, a workgroup keeps ONE channel group for the whole launch (its BN / margin constants are loaded once, its
+//    weight slabs stay L2-hot), and two images + two 35 KB weight slabs need 107 KB of LDS.
+//
+// Spike layout "S32": [B][C/32][H*W][T = 16][16 B], channel c of a group in byte (c % 32) / 2, low nibble first, e2m1 codes
+// 0x0 / 0x2.  The last position of a 7x7 latent (the 49th: 24 full 32-row tiles + 1) is computed exactly by the tail
+// launch from the same packed weights plus two sixth-digit tiles stored for its four taps.
+#include "den_common.h"
+#include "../../include/spkdiff.h"
+#include <math.h>
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+typedef int v6i __attribute__((ext_vector_type(6)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int T16 = 16;
+constexpr int CK = 32;                                   // input channels per K chunk
+constexpr int POSB = T16 * CK / 2;                       // 256 B per latent position per chunk
+constexpr int WT = 64 * 24;                              // one B tile: 64 lanes x 32 six-bit codes
+constexpr int N_PAIR = 18;                               // tiles 0..17: (tap, digit pair 01 | 23)
+constexpr int N_D4 = 5;                                  // tiles 18..22: fifth digit, taps (0,1) (2,3) (4,5) (6,7) (8,-)
+constexpr int N_MAIN = N_PAIR + N_D4;
+constexpr int N_L5 = 2;                                  // tiles 23, 24: sixth digit of taps (0,1) and (3,4), last position only
+constexpr int W_PIECES = (N_MAIN * WT + 1023) / 1024;    // 35 one-KiB DMA pieces
+constexpr int W_LDS = W_PIECES * 1024;
+constexpr int W_SLAB = ((N_MAIN + N_L5) * WT + 1023) / 1024 * 1024;   // bytes per (channel group, chunk) in memory
+
+struct V2Args {
+  const uint8_t* in0; int nch;               // S32 spikes, nch = Cin / 32
+  const uint8_t* wq; const double* scale; const double* bias; const float* wl1; const float* w_f32;
+  const float* bn_a; const float* bn_b;
+  uint8_t* out; uint8_t* out_cnt; unsigned* flags;
+  const int* n_dyn;
+  int B, Cout, Cin;
+  int gx, nsets;                             // XCD-aware walk (gx > 0) or flat walk (gx == 0)
+};
+
+#ifndef SPK_FP6_PRE
+#define SPK_FP6_PRE "s_nop 1\n\t"
+#endif
+#define SPK_MFMA2(CLS, acc, av, bv, sa, sb)                                                                          \
+  asm volatile(SPK_FP6_PRE "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:2"  \
+               : "+" CLS(acc) : "v"(av), "v"(bv), "v"(sa), "v"(sb))
+#define SPK_MFMA2_Z(CLS, acc, av, bv, sa, sb)                                                                        \
+  asm volatile(SPK_FP6_PRE "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:2"   \
+               : "=&" CLS(acc) : "v"(av), "v"(bv), "v"(sa), "v"(sb))
+
+#ifndef SPK_V2_DBG
+#define SPK_V2_DBG 0            // timing experiments only: 1 = no steady-state DMA, 4 = no epilogue (results are wrong)
+#endif
+constexpr int N_AGPR = 16;      // accumulator tiles (index 3 * i + j) that live in AGPRs (256 registers)
+
+// Certification margin of one output channel: |h_approx - h_exact| stays below it for every time step as long as the
+// spike decisions agreed so far (after a spike both paths restart from v = 0).  Y bounds |y| (L1 norm of the quantised
+// weights + |bias|), E5 the dropped sixth digit; 2^-21 / 2^-22 terms cover the fp32 recombination (two fma roundings),
+// the folded scale * bn_a constant, the rounding of y, of z = fma(y, a, b) and of the three LIF operations per step --
+// each at most 2^-24 relative to a quantity bounded by Y or Zb -- with a factor > 2 to spare; the recursion
+// d_t <= d_{t-1} / 2 + dz / 2 + rho sums to dz + 2 rho, doubled once more.
+__device__ __forceinline__ float margin_of(float wl1, float bias_f, float bna, float bnb, float scale_f, int Cin) {
+  const float Y = wl1 + fabsf(bias_f);
+  const float E5 = 16.0f * 9.0f * (float)Cin * scale_f;
+  const float dy = E5 + 4.76837158e-07f * Y;                       // 2^-21
+  const float Zb = fabsf(bna) * Y + fabsf(bnb);
+  const float dz = fabsf(bna) * dy + 2.38418579e-07f * Zb;         // 2^-22
+  const float rho = 2.38418579e-07f * 3.0f * fmaxf(Zb, 1.0f);
+  return 2.0f * (dz + 2.0f * rho);
+}
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  The K loop must be straight-line
+// code with constant accumulator indices (a runtime index would send the accumulators through scratch); this does not
+// depend on the unroller's size heuristics.
+template <typename F, int... S>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, S...>) {
+  (f(std::integral_constant<int, S>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+__device__ __forceinline__ unsigned spread8(unsigned x) {          // bit k -> nibble k, as the e2m1 code of 1.0 (0x2)
+  x = (x | (x << 12)) & 0x000f000fu;
+  x = (x | (x << 6)) & 0x03030303u;
+  x = (x | (x << 3)) & 0x11111111u;
+  return x << 1;
+}
+
+// Store the spikes of one 32-row tile: every lane holds the 16 step bits of its neuron (channel = lane & 31 of the group,
+// position = its lane half); a 16x16 bit transpose per 16-lane row gives lane t the 16 channel bits of step t = 8 bytes of
+// the (position, t) record.
+__device__ __forceinline__ void store_tile_spikes(uint8_t* out, uint8_t* out_cnt, unsigned mybits, int lane, long long rec_base,
+                                                  long long cnt_base, bool ok) {
+  const unsigned bitsv = spk_transpose16_rows(mybits, lane);
+  if (out_cnt && ok) out_cnt[cnt_base + (lane & 31)] = (uint8_t)__popc(mybits);
+  if (ok) {
+    uint2 o;
+    o.x = spread8(bitsv & 0xffu);
+    o.y = spread8((bitsv >> 8) & 0xffu);
+    *reinterpret_cast<uint2*>(out + rec_base + (lane & 15) * 16 + 8 * ((lane >> 4) & 1)) = o;
+  }
+}
+
+template <int H, int W>
+__global__ __launch_bounds__(256, 1) void conv3x3_fp6v2_kernel(V2Args a) {
+  constexpr int HW = H * W, PW = W + 1;
+  static_assert((HW & 1) == 1 && ((HW / 2) % 4) == 0, "an odd position count whose pairs fill whole tiles on four waves");
+  constexpr int NT = (HW / 2) / 4;                     // row tiles per wave (7x7: 6)
+  constexpr int NPP = (H + 2) * PW + 1;                // cells of the zero-bordered LDS image (pitch W + 1: the zero
+  constexpr int A_BYTES = NPP * POSB;                  //  column is shared by x = -1 of a row and x = W of the previous)
+  constexpr int PPR = (W + 3) / 4;                     // DMA pieces per image row (4 positions per KiB piece)
+  constexpr int NA = H * PPR;
+  constexpr int NPA = (NA + 3) / 4;                    // A pieces per wave
+  constexpr int NPW = (W_PIECES + 3) / 4;              // W pieces per wave
+  constexpr int NS_PAIR = 9 * NT, NSTEP = NS_PAIR + N_D4 * NT;
+  static_assert(NT * 3 > N_AGPR && (NT - 1) * 3 <= N_AGPR + 2, "accumulator split assumes the last tile straddles the files");
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  uint8_t* const sA = lds;
+  uint8_t* const sW = lds + 2 * A_BYTES;
+  const unsigned sA_addr = spk_lds_addr(sA), sW_addr = sA_addr + 2 * A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nch = a.nch;
+  const int G = a.Cout >> 5;
+  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
+
+  // workgroup -> (channel group g, image lane il, lanes): the group is FIXED for the whole launch.  XCD-aware form:
+  // workgroups k and k + 8 share an XCD and its L2; XCD x owns channel-group set x % nsets (gx consecutive groups, chosen
+  // by the host so that their packed weights stay L2-resident) and image partition x / nsets.
+  int g, il, lanes;
+  {
+    const int k = blockIdx.x;
+    if (a.gx > 0) {
+      const int S = gridDim.x >> 3, x = k & 7, slot = k >> 3;
+      const int npart = 8 / a.nsets, set = x % a.nsets, xi = x / a.nsets, lanes_x = S / a.gx;
+      g = set * a.gx + slot % a.gx;
+      il = xi * lanes_x + slot / a.gx;
+      lanes = npart * lanes_x;
+    } else {
+      g = k % G;
+      il = k / G;
+      lanes = gridDim.x / G;
+    }
+  }
+
+  // zero both A images once: the borders stay zero for the whole kernel, interiors are overwritten by DMA
+  for (int i = tid; i < 2 * A_BYTES / 16; i += 256) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();         // no wave's first DMA piece may land in a cell another wave has yet to zero
+
+  // per-lane LDS byte offsets of this wave's A fragments (tile ti = wave + 4 * i), relative to tap (0, 0).
+  // a_off: the same cell for both K halves (digit-pair instructions); a_off1 / a_off2: K half 1 one cell / PW - 2 cells
+  // further (fifth-digit instructions pair the taps (0,1) (4,5) (6,7) / (2,3))
+  const int row = lane & 31, half = lane >> 5;
+  const int hsel = (row >> 2) & 1, tt = (row & 3) + 4 * (row >> 3);
+  int a_off[NT], a_off1[NT], a_off2[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int p = 2 * (wave + 4 * i) + hsel;
+    a_off[i] = ((p / W) * PW + (p % W)) * POSB + tt * 16;
+    a_off1[i] = a_off[i] + half * POSB;
+    a_off2[i] = a_off[i] + half * (PW - 2) * POSB;
+  }
+
+  // DMA piece table (wave-uniform): bits 0..13 source byte offset in the slab, 14..28 LDS byte offset in the image,
+  // 29..30 positions in the piece - 1.  Pieces beyond the slab repeat the last one so that the K loop issues unconditionally.
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  unsigned pa_pk[NPA];
+#pragma unroll
+  for (int j = 0; j < NPA; ++j) {
+    int id = wave_s * NPA + j;
+    id = id < NA ? id : NA - 1;
+    const int y = id / PPR, px = id - y * PPR;
+    const int np = (W - 4 * px) < 4 ? (W - 4 * px) : 4;
+    const unsigned src = (unsigned)((y * W + 4 * px) * POSB), dst = (unsigned)(((y + 1) * PW + 1 + 4 * px) * POSB);
+    pa_pk[j] = src | (dst << 14) | ((unsigned)(np - 1) << 29);
+  }
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const unsigned wave_k = (unsigned)wave_s * 1024u;
+  auto issue_piece = [&](int q, const uint8_t* aslab, const uint8_t* wslab, unsigned dA, unsigned dW) {
+    if (q < NPA) {
+      const unsigned pk = pa_pk[q];
+      const unsigned np = ((pk >> 29) & 3u) + 1u;
+      const unsigned long long mask = np == 4 ? ~0ull : ((1ull << (16 * np)) - 1ull);
+      spk_dma16s_masked(aslab + (pk & 0x3fffu), lane16, dA + ((pk >> 14) & 0x7fffu), mask);
+    } else {
+      unsigned ko = wave_k + 4096u * (unsigned)(q - NPA);
+      if (4 * (q - NPA) + 3 >= W_PIECES) ko = ko < (unsigned)W_PIECES * 1024u ? ko : ko - 4096u;
+      spk_dma16s(wslab + ko, lane16, dW + ko);
+    }
+  };
+  const uint8_t* const wbase = a.wq + (long long)g * nch * W_SLAB;
+  auto aslab_of = [&](int b, int c) -> const uint8_t* { return a.in0 + ((long long)b * nch + c) * HW * POSB; };
+
+  // per-channel constants (the group is fixed: loaded once)
+  const int co = g * 32 + (lane & 31);
+  const float scale_f = (float)a.scale[co], bias_f = (float)a.bias[co];
+  const float bna = a.bn_a[co], bnb = a.bn_b[co];
+  const float Ac = 32.0f * scale_f * bna;                 // z = fma(Q5, Ac, Bc),  Q5 = P01 * 2^15 + P23 * 2^5 + P4
+  const float Bc = fmaf(bias_f, bna, bnb);
+  const float mrg = margin_of(a.wl1[co], bias_f, bna, bnb, scale_f, a.Cin);
+
+  const int sc_a = 0x7f7f7f7f;                            // e8m0 block scales: spikes x 1
+  const int sc_p = half ? (int)0x82828282u : (int)0x87878787u;   // digit pairs: even digit (K half 0) x 2^8, odd digit x 2^3
+  const int sc_4 = (int)0x82828282u;                      // fifth digit x 2^3 (e2m3 value d / 8 -> d)
+
+  int it = 0;                                             // running chunk counter: LDS buffer = it & 1
+  if (il < Bn) {
+    const uint8_t* as0 = aslab_of(il, 0);
+#pragma unroll
+    for (int q = 0; q < NPA + NPW; ++q) issue_piece(q, as0, wbase, sA_addr, sW_addr);
+  }
+  for (int b = il; b < Bn; b += lanes) {
+    v16f acc[NT][3];      // [i][0]: pair 01, [i][1]: pair 23, [i][2]: fifth digit; written (not accumulated) by the first MFMA
+    for (int c = 0; c < nch; ++c, ++it) {
+      const int buf = it & 1;
+      spk_dma_wait_all();  // this wave's share of the chunk's DMA has landed ...
+      __syncthreads();     // ... and so has everyone else's; everyone is done with the other buffer
+      int nb = b, nc = c + 1;
+      if (nc == nch) { nc = 0; nb = b + lanes; }
+      const bool have_next = nb < Bn;                     // otherwise the last chunk is copied once more (never read)
+      const uint8_t* n_aslab = aslab_of(have_next ? nb : b, have_next ? nc : c);
+      const uint8_t* n_wslab = wbase + (long long)(have_next ? nc : c) * W_SLAB;
+      const unsigned n_dA = sA_addr + (buf ^ 1) * A_BYTES;
+      const unsigned n_dW = sW_addr + (buf ^ 1) * W_LDS;
+
+      auto compute = [&](auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const uint8_t* A = sA + buf * A_BYTES;
+        const uint8_t* Wb = sW + buf * W_LDS;
+        auto toff = [](int tap) constexpr -> int { return ((tap / 3) * PW + (tap % 3)) * POSB; };
+        auto lda = [&](int s) -> v4i {
+          if (s < NS_PAIR) {
+            const int tap = s / NT, i = s % NT;
+            return *reinterpret_cast<const v4i*>(A + a_off[i] + toff(tap));
+          }
+          const int q = (s - NS_PAIR) / NT, i = (s - NS_PAIR) % NT;
+          const int base = q == 1 ? a_off2[i] : (q == 4 ? a_off[i] : a_off1[i]);
+          return *reinterpret_cast<const v4i*>(A + base + toff(2 * q));
+        };
+        auto ldb = [&](int tile) -> v6i {
+          // 16 + 8 bytes per lane; the 8-byte read is volatile so that hipcc does not pair the tails of two tiles
+          const uint8_t* p = Wb + tile * WT;
+          const v4i x = *reinterpret_cast<const v4i*>(p + lane * 16);
+          typedef const volatile __attribute__((address_space(3))) v2i* lds_v2i_ptr;
+          const v2i y = *(lds_v2i_ptr)SPK_LDS(p + 1024 + lane * 8);
+          const v6i r = {x[0], x[1], x[2], x[3], y[0], y[1]};
+          return r;
+        };
+        v6i bp[2][2];                                     // digit-pair tiles of tap parity [tap & 1][pair]
+        v6i b4[2];                                        // fifth-digit tiles [q & 1]
+        bp[0][0] = ldb(0); bp[0][1] = ldb(1);
+        constexpr int PF = 4;
+        v4i af[PF];
+#pragma unroll
+        for (int s = 0; s < PF; ++s) af[s] = lda(s);
+        static_for<NSTEP>([&](auto s_tag) {
+          constexpr int s = decltype(s_tag)::value;
+          const v4i av = af[s % PF];
+          if constexpr (s + PF < NSTEP) af[s % PF] = lda(s + PF);
+          constexpr int NPIECES = NPA + NPW;
+#define V2_DMA_SLOT()                                                                              \
+  do {                                                                                             \
+    if constexpr (s % NT == 0 && s / NT < NPIECES) {                                               \
+      if (!(SPK_V2_DBG & 1)) issue_piece(s / NT, n_aslab, n_wslab, n_dA, n_dW);                    \
+    }                                                                                              \
+  } while (0)
+          if constexpr (s < NS_PAIR) {
+            constexpr int tap = s / NT, i = s % NT;
+#define V2_PAIR_MFMA(J)                                                                                      \
+  do {                                                                                                        \
+    if constexpr (FIRST && tap == 0) {                                                                        \
+      if constexpr (3 * i + (J) < N_AGPR) SPK_MFMA2_Z("a", acc[i][J], av, bp[0][J], sc_a, sc_p);              \
+      else SPK_MFMA2_Z("v", acc[i][J], av, bp[0][J], sc_a, sc_p);                                             \
+    } else {                                                                                                  \
+      if constexpr (3 * i + (J) < N_AGPR) SPK_MFMA2("a", acc[i][J], av, bp[tap & 1][J], sc_a, sc_p);          \
+      else SPK_MFMA2("v", acc[i][J], av, bp[tap & 1][J], sc_a, sc_p);                                         \
+    }                                                                                                         \
+  } while (0)
+            V2_PAIR_MFMA(0);
+            __builtin_amdgcn_sched_barrier(0);
+            V2_DMA_SLOT();
+            if constexpr (i == 1) {                       // next tap's weight tiles (or the first fifth-digit tile)
+              if constexpr (tap + 1 < 9) { bp[(tap + 1) & 1][0] = ldb(2 * (tap + 1)); bp[(tap + 1) & 1][1] = ldb(2 * (tap + 1) + 1); }
+              else b4[0] = ldb(N_PAIR);
+            }
+            V2_PAIR_MFMA(1);
+            __builtin_amdgcn_sched_barrier(0);
+          } else {
+            constexpr int q = (s - NS_PAIR) / NT, i = (s - NS_PAIR) % NT;
+            if constexpr (FIRST && q == 0) {
+              if constexpr (3 * i + 2 < N_AGPR) SPK_MFMA2_Z("a", acc[i][2], av, b4[0], sc_a, sc_4);
+              else SPK_MFMA2_Z("v", acc[i][2], av, b4[0], sc_a, sc_4);
+            } else {
+              if constexpr (3 * i + 2 < N_AGPR) SPK_MFMA2("a", acc[i][2], av, b4[q & 1], sc_a, sc_4);
+              else SPK_MFMA2("v", acc[i][2], av, b4[q & 1], sc_a, sc_4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            V2_DMA_SLOT();
+            if constexpr (i == 1 && q + 1 < N_D4) b4[(q + 1) & 1] = ldb(N_PAIR + q + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
+      };
+      if (c == 0) compute(std::true_type{}); else compute(std::false_type{});
+    }   // chunks
+
+    // The MFMAs are opaque to hipcc's hazard recognizer: an accumulator may be read 18 wait states after the (16-pass)
+    // MFMA that wrote it was issued.
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (SPK_V2_DBG & 4) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if (3 * i + j < N_AGPR) asm volatile("" : "+a"(acc[i][j]));
+          sacc += acc[i][j][0];
+        }
+      if (sacc == 12345.f) a.out[0] = 1;
+      continue;
+    }
+
+    // ---------------- epilogue: fp32 recombination, BN, LIF scan, certification -------------------------------------
+    // The tile that holds the VGPR-resident accumulators goes first (frees their registers for the scan temporaries).
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      const int i = k == 0 ? NT - 1 : k - 1;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (3 * i + j < N_AGPR) asm volatile("" : "+a"(acc[i][j]));
+      float v = 0.f;
+      unsigned mybits = 0;
+      bool flg = false;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float q5 = fmaf(fmaf(acc[i][0][r], 1024.0f, acc[i][1][r]), 32.0f, acc[i][2][r]);
+        const float z = fmaf(q5, Ac, Bc);
+        const float h = v + (z - v) * 0.5f;
+        const bool s = h >= 1.0f;
+        flg = flg || (fabsf(h - 1.0f) <= mrg);
+        v = s ? 0.0f : h;
+        mybits |= s ? (1u << r) : 0u;
+      }
+      const int ti = wave + 4 * i;
+      const int p = 2 * ti + half;                        // accumulator lane half == position within the tile
+      if (flg) {
+        const long long n = ((long long)b * a.Cout + co) * HW + p;
+        atomicOr(a.flags + (n >> 5), 1u << (n & 31));
+      }
+      const long long rec = (((long long)b * G + g) * HW + p) * POSB;
+      store_tile_spikes(a.out, a.out_cnt, mybits, lane, rec, (((long long)b * G + g) * HW + p) * 32, true);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }   // images
+  spk_dma_wait_all();     // the copy issued during the very last chunk must not outlive the workgroup's LDS allocation
+}
+
+// ------------------------------------------------------------------------------------------------ tail launch
+// (1) the last position of every image, exactly: one wave = four images x one channel group, two 32-row tiles whose lane
+//     halves are images; the four taps that reach position (H-1, W-1) from inside the image; operands straight from L2;
+//     all six digits (the two sixth-digit tiles of the slab), fp64 recombination.
+// (2) the flagged neurons of the main launch, exactly: every wave scans a share of the bitmap, recomputes a flagged neuron
+//     from the fp32 weights in 64-bit integers (the quantisation of the pack kernel), patches its 16 spike nibbles and its
+//     count, and clears the bit -- the bitmap is clean again when the launch ends.
+__device__ __forceinline__ float exact_preact(double s, double sc, double bi) { return (float)fma(s, sc, bi); }
+
+template <int H, int W>
+__global__ __launch_bounds__(256) void fp6v2_tail_kernel(V2Args a, int n_lp_blocks, int n_fix_blocks, long long n_words) {
+  constexpr int HW = H * W;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = a.nch, G = a.Cout >> 5;
+  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
+  if ((int)blockIdx.x < n_lp_blocks) {
+    // ---------------------------------------------------------------- (1) last position
+    const int unit = blockIdx.x * 4 + wave;
+    const int g = unit % G, b0 = (unit / G) * 4;
+    if (b0 >= Bn) return;
+    const int row = lane & 31, half = lane >> 5;
+    const int hsel = (row >> 2) & 1, tt = (row & 3) + 4 * (row >> 3);
+    const int sc_a = 0x7f7f7f7f;
+    const int sc_p = half ? (int)0x82828282u : (int)0x87878787u;
+    const int sc_hi = (int)0x87878787u, sc_lo = (int)0x82828282u;
+    v16f acc[2][3];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[e][j][r] = 0.f;
+    const int py = H - 1, px = W - 1;
+    for (int c = 0; c < nch; ++c) {
+      const uint8_t* wslab = a.wq + ((long long)g * nch + c) * W_SLAB;
+      auto ldb = [&](int tile) -> v8i {
+        const uint8_t* wt = wslab + tile * WT;
+        const v4i bx = *reinterpret_cast<const v4i*>(wt + lane * 16);
+        const v2i by = *reinterpret_cast<const v2i*>(wt + 1024 + lane * 8);
+        return v8i{bx[0], bx[1], bx[2], bx[3], by[0], by[1], 0, 0};
+      };
+      // spikes of the four contributing taps (0, 1, 3, 4), per tile
+      v4i sp[2][4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int bA = b0 + 2 * e + hsel;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int tap = (u >> 1) * 3 + (u & 1);
+          const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+          sp[e][u] = v4i{0, 0, 0, 0};
+          if (bA < Bn)
+            sp[e][u] = *reinterpret_cast<const v4i*>(a.in0 + (((long long)bA * nch + c) * HW + yy * W + xx) * POSB + tt * 16);
+        }
+      }
+      auto mm = [&](v16f& d, const v4i& av, const v8i& bv, int sb) {
+        const v8i a8 = {av[0], av[1], av[2], av[3], 0, 0, 0, 0};
+        d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, bv, d, 4, 2, 0, sc_a, 0, sb);
+      };
+      const v4i zero = {0, 0, 0, 0};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {                        // digit pairs 01 and 23 of taps 0, 1, 3, 4
+        const int tap = (u >> 1) * 3 + (u & 1);
+        const v8i b0t = ldb(2 * tap), b1t = ldb(2 * tap + 1);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { mm(acc[e][0], sp[e][u], b0t, sc_p); mm(acc[e][1], sp[e][u], b1t, sc_p); }
+      }
+      {
+        // fifth digit (x 32) and sixth digit into acc[.][2] = 32 * D4 + D5: tiles 18 (taps 0|1), 19 (2|3), 20 (4|5) and the
+        // sixth-digit tiles 23 (taps 0|1), 24 (taps 3|4); taps 2 and 5 lie outside the image: zero spikes
+        const v8i t18 = ldb(N_PAIR), t19 = ldb(N_PAIR + 1), t20 = ldb(N_PAIR + 2), t23 = ldb(N_MAIN), t24 = ldb(N_MAIN + 1);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const v4i a01 = half ? sp[e][1] : sp[e][0];
+          const v4i az3 = half ? sp[e][2] : zero;
+          const v4i a4z = half ? zero : sp[e][3];
+          const v4i a34 = half ? sp[e][3] : sp[e][2];
+          mm(acc[e][2], a01, t18, sc_hi); mm(acc[e][2], az3, t19, sc_hi); mm(acc[e][2], a4z, t20, sc_hi);
+          mm(acc[e][2], a01, t23, sc_lo); mm(acc[e][2], a34, t24, sc_lo);
+        }
+      }
+    }
+    const int co = g * 32 + (lane & 31);
+    const double sc = a.scale[co], bi = a.bias[co];
+    const float bna = a.bn_a[co], bnb = a.bn_b[co];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int b = b0 + 2 * e + half;                      // accumulator lane half == image within the tile's pair
+      const bool ok = b < Bn;
+      float v = 0.f;
+      unsigned mybits = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const double s1 = fma((double)acc[e][0][r], 1024.0, (double)acc[e][1][r]);       // exact
+        const double s = fma(s1, 1024.0, (double)acc[e][2][r]);                           // exact: |s| < 2^43
+        const float y = exact_preact(s, sc, bi);                                          // the one rounding to fp32
+        const bool sp1 = spk_lif_step_default(v, fmaf(y, bna, bnb)) && ok;
+        mybits |= sp1 ? (1u << r) : 0u;
+      }
+      const long long cell = ((long long)(ok ? b : 0) * G + g) * HW + (HW - 1);
+      store_tile_spikes(a.out, a.out_cnt, mybits, lane, cell * POSB, cell * 32, ok);
+    }
+    return;
+  }
+  // ------------------------------------------------------------------ (2) flagged neurons
+  const int wid = ((int)blockIdx.x - n_lp_blocks) * 4 + wave, nw = n_fix_blocks * 4;
+  const long long per = (n_words + nw - 1) / nw;
+  const long long w0 = (long long)wid * per;
+  long long w1 = w0 + per;
+  if (w1 > n_words) w1 = n_words;
+  const int Cin = a.Cin, K9 = 9 * Cin;
+  for (long long base = w0; base < w1; base += 64) {
+    const long long wi = base + lane;
+    unsigned word = wi < w1 ? a.flags[wi] : 0u;
+    unsigned long long any = __ballot(word != 0u);
+    if (wi < w1 && word != 0u) a.flags[wi] = 0u;            // self-cleaning bitmap
+    while (any) {
+      const int l = __ffsll((long long)any) - 1;
+      any &= any - 1;
+      unsigned wv = (unsigned)__shfl((int)word, l);
+      while (wv) {
+        const int bit = __ffs((int)wv) - 1;
+        wv &= wv - 1;
+        const long long n = (base + l) * 32 + bit;
+        const int p = (int)(n % HW);
+        const long long r0 = n / HW;
+        const int co = (int)(r0 % a.Cout), b = (int)(r0 / a.Cout);
+        if (b >= Bn) continue;
+        const int py = p / W, px = p % W;
+        const double sc = a.scale[co], bi = a.bias[co];
+        const int sh = -ilogb(sc);                          // scale = 2^-sh exactly
+        long long S[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) S[t] = 0;
+        for (int k = lane; k < K9; k += 64) {
+          const int tap = k / Cin, ci = k - tap * Cin;
+          const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+          if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+          const long long q = (long long)rint(ldexp((double)a.w_f32[((long long)co * Cin + ci) * 9 + tap], sh));
+          const uint8_t* src = a.in0 + (((long long)b * nch + (ci >> 5)) * HW + yy * W + xx) * POSB + ((ci & 31) >> 1);
+          const int shn = 4 * (ci & 1);
+#pragma unroll
+          for (int t = 0; t < 16; ++t)
+            if ((src[t * 16] >> shn) & 0xF) S[t] += q;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) {
+            const int lo = __shfl_xor((int)(unsigned)(S[t] & 0xffffffffll), off);
+            const int hi = __shfl_xor((int)(S[t] >> 32), off);
+            S[t] += (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+          }
+        }
+        if (lane == 0) {
+          const float bna = a.bn_a[co], bnb = a.bn_b[co];
+          float v = 0.f;
+          int cnt = 0;
+          const int g = co >> 5;
+          uint8_t* rec = a.out + ((((long long)b * (a.Cout >> 5) + g) * HW + p) * POSB);
+          const int byte = (co & 31) >> 1;
+          const unsigned shw = 8u * (byte & 3) + 4u * (co & 1);
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const float y = exact_preact((double)S[t], sc, bi);
+            const bool s = spk_lif_step_default(v, fmaf(y, bna, bnb));
+            cnt += s ? 1 : 0;
+            unsigned* wp = reinterpret_cast<unsigned*>(rec + t * 16 + (byte & ~3));
+            atomicAnd(wp, ~(0xFu << shw));
+            if (s) atomicOr(wp, 0x2u << shw);
+          }
+          if (a.out_cnt) a.out_cnt[(((long long)b * (a.Cout >> 5) + g) * HW + p) * 32 + (co & 31)] = (uint8_t)cnt;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// one block per output channel: channel maximum -> shift s, every weight -> six balanced radix-32 digits, written as the
+// per-lane 24-byte B fragments (lane = K half * 32 + channel within the group of 32; 32 six-bit codes, little-endian;
+// bytes 0..15 in the ds_read_b128 part of the tile, 16..23 in its ds_read_b64 part).  Tile order per (group, 32-channel
+// chunk): (tap, pair) x 18 [K half 0: even digit, half 1: odd digit, same 32 input channels], fifth digit x 5 [K half 0:
+// tap 2q, half 1: tap 2q + 1], sixth digit x 2 [taps (0, 1) and (3, 4)].  Also the L1 norm of the quantised weights.
+__global__ __launch_bounds__(256) void pack_fp6v2_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                         uint8_t* __restrict__ wq, double* __restrict__ scale,
+                                                         double* __restrict__ bias_d, float* __restrict__ wl1, int Cout, int Cin) {
+  __shared__ float smax[256];
+  __shared__ double ssum[256];
+  const int co = blockIdx.x, n = Cin * 9;
+  const float* wc = w + (long long)co * n;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(wc[i]));
+  smax[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s]);
+    __syncthreads();
+  }
+  m = smax[0];
+  int e = 0;
+  if (m > 0.f) frexpf(m, &e);                 // m = f * 2^e, f in [0.5, 1)  ->  m < 2^e
+  const int sh = 29 - e;                      // |w| * 2^sh < 2^29 <= 16.5 * 32^5
+  double l1 = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) l1 += fabs(rint(ldexp((double)wc[i], sh)));
+  ssum[threadIdx.x] = l1;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) ssum[threadIdx.x] += ssum[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    scale[co] = ldexp(1.0, -sh);
+    bias_d[co] = bias ? (double)bias[co] : 0.0;
+    wl1[co] = (float)(ldexp(ssum[0], -sh) * 1.000001);      // rounded up: it feeds an upper bound
+  }
+  const int nchunks = Cin / CK, g = co >> 5, col = co & 31;
+  constexpr int NTILE = N_MAIN + N_L5;
+  for (int rec = threadIdx.x; rec < nchunks * NTILE * 2; rec += 256) {
+    const int kh = rec & 1, tau = (rec >> 1) % NTILE, c = rec / (2 * NTILE);
+    int tap, digit;
+    bool valid = true;
+    if (tau < N_PAIR) { tap = tau >> 1; digit = 2 * (tau & 1) + kh; }
+    else if (tau < N_MAIN) { tap = 2 * (tau - N_PAIR) + kh; digit = 4; valid = tap < 9; }
+    else { tap = (tau == N_MAIN ? 0 : 3) + kh; digit = 5; }
+    unsigned bits[6] = {0, 0, 0, 0, 0, 0};
+    if (valid) {
+      for (int j = 0; j < 32; ++j) {
+        const int ci = c * CK + j;
+        long long q = (long long)rint(ldexp((double)wc[ci * 9 + tap], sh));
+        int dg[6];
+#pragma unroll
+        for (int p = 5; p >= 1; --p) {
+          const int r = (int)(((q + 16) & 31) - 16);
+          dg[p] = r;
+          q = (q - r) >> 5;
+        }
+        dg[0] = (int)q;                          // in [-16, 16]
+        int d = 0;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) d = (p == digit) ? dg[p] : d;
+        const unsigned code = (d < 0 ? 0x20u : 0u) | (unsigned)(d < 0 ? -d : d);
+        const int bit = 6 * j, wd = bit >> 5, sft = bit & 31;
+#pragma unroll
+        for (int q2 = 0; q2 < 6; ++q2) {         // static register indexing
+          if (q2 == wd) bits[q2] |= code << sft;
+          if (q2 == wd + 1 && sft > 26) bits[q2] |= code >> (32 - sft);
+        }
+      }
+    }
+    uint8_t* tile = wq + (long long)(g * nchunks + c) * W_SLAB + tau * WT;
+    const int ln = kh * 32 + col;
+    unsigned* d16 = reinterpret_cast<unsigned*>(tile + ln * 16);
+    unsigned* d8 = reinterpret_cast<unsigned*>(tile + 1024 + ln * 8);
+    d16[0] = bits[0]; d16[1] = bits[1]; d16[2] = bits[2]; d16[3] = bits[3];
+    d8[0] = bits[4]; d8[1] = bits[5];
+  }
+}
+
+// fp32 spikes [T,B,C,HW] <-> nibble-packed S32 [B][C/32][HW][T][16] (tests, module boundaries)
+__global__ void spikes_to_s32_kernel(const float* __restrict__ s, uint8_t* __restrict__ o, int T, int B, int C, int HW) {
+  const long long total = (long long)B * (C / 32) * HW * T * 16;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int byte = (int)(i & 15);
+    long long r = i >> 4;
+    const int t = (int)(r % T); r /= T;
+    const int p = (int)(r % HW); r /= HW;
+    const int cc = (int)(r % (C / 32));
+    const int b = (int)(r / (C / 32));
+    const int c0 = cc * 32 + 2 * byte;
+    const float s0 = s[(((long long)t * B + b) * C + c0) * HW + p], s1 = s[(((long long)t * B + b) * C + c0 + 1) * HW + p];
+    o[i] = (uint8_t)((s0 != 0.f ? 0x02 : 0) | (s1 != 0.f ? 0x20 : 0));
+  }
+}
+__global__ void s32_to_spikes_kernel(const uint8_t* __restrict__ q, float* __restrict__ s, int T, int B, int C, int HW) {
+  const long long total = (long long)T * B * C * HW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW);
+    long long r = i / HW;
+    const int c = (int)(r % C); r /= C;
+    const int b = (int)(r % B);
+    const int t = (int)(r / B);
+    const uint8_t by = q[((((long long)b * (C / 32) + c / 32) * HW + p) * T + t) * 16 + (c % 32) / 2];
+    s[i] = ((by >> (4 * (c & 1))) & 0xf) ? 1.0f : 0.0f;
+  }
+}
+
+}  // namespace
+
+extern "C" long long spk_den_packed_weight_fp6v2_bytes(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0 || (Cout % 32) || (Cin % CK)) return -1;
+  return (long long)(Cout / 32) * (Cin / CK) * W_SLAB;
+}
+
+extern "C" int spk_den_pack_weight_fp6v2(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d,
+                                         float* wl1, int Cout, int Cin, hipStream_t stream) {
+  if (!w || !wq || !scale || !bias_d || !wl1 || Cout <= 0 || Cin <= 0) return SPK_ERR_ARG;
+  if ((Cout % 32) || (Cin % CK)) return SPK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(pack_fp6v2_kernel, dim3(Cout), dim3(256), 0, stream, w, bias, wq, scale, bias_d, wl1, Cout, Cin);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" long long spk_den_fp6v2_flag_words(int B, int Cout, int H, int W) {
+  if (B <= 0 || Cout <= 0 || H <= 0 || W <= 0) return -1;
+  return ((long long)B * Cout * H * W + 31) / 32;
+}
+
+extern "C" int spk_den_conv3x3_mfma_fp6v2(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale,
+                                          const double* bias_d, const float* wl1, const float* w_f32, const float* bn_a,
+                                          const float* bn_b, uint8_t* out_s32, uint8_t* out_counts, unsigned* flag_words,
+                                          int T, int B, int H, int W, int Cout, const int* n_dyn_or_null, hipStream_t stream) {
+  if (!in_s32 || nch <= 0 || !wq || !scale || !bias_d || !wl1 || !w_f32 || !bn_a || !bn_b || !out_s32 || !flag_words ||
+      B <= 0 || H <= 0 || W <= 0 || Cout <= 0)
+    return SPK_ERR_ARG;
+  if (T != T16 || (Cout % 32) || H != 7 || W != 7) return SPK_ERR_UNSUPPORTED;
+  V2Args a;
+  a.in0 = in_s32; a.nch = nch; a.wq = wq; a.scale = scale; a.bias = bias_d; a.wl1 = wl1; a.w_f32 = w_f32;
+  a.bn_a = bn_a; a.bn_b = bn_b; a.out = out_s32; a.out_cnt = out_counts; a.flags = flag_words; a.n_dyn = n_dyn_or_null;
+  a.B = B; a.Cout = Cout; a.Cin = nch * CK;
+  const int cus = spk_cu_count();
+  const int G = Cout / 32;
+  // XCD-aware walk: the largest power-of-two group count per XCD whose packed weights fit ~1.5 MB of its 4 MB L2
+  int grid = 0;
+  a.gx = 0; a.nsets = 1;
+  if ((cus & 7) == 0) {
+    const int S = cus / 8;
+    int gx = 1;
+    while (gx * 2 <= G && gx * 2 <= S && (long long)gx * 2 * nch * W_SLAB <= 1536 * 1024) gx *= 2;
+    while (G / gx > 8 && gx * 2 <= G && gx * 2 <= S) gx *= 2;
+    const int nsets = G / gx;
+    if (G % gx == 0 && nsets <= 8 && 8 % nsets == 0 && S % gx == 0) { a.gx = gx; a.nsets = nsets; grid = cus; }
+  }
+  if (a.gx == 0) grid = cus >= G ? (cus / G) * G : G;         // flat walk: workgroup k -> group k % G
+  constexpr int A_BYTES = ((7 + 2) * 8 + 1) * POSB;
+  const size_t lds = 2 * ((size_t)A_BYTES + W_LDS);
+  hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7>), dim3(grid), dim3(256), lds, stream, a);
+  SPK_LAUNCH_CHECK();
+  const int n_lp = (((B + 3) / 4) * G + 3) / 4;
+  const int n_fix = cus;
+  const long long n_words = ((long long)B * Cout * H * W + 31) / 32;
+  hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7>), dim3(n_lp + n_fix), dim3(256), 0, stream, a, n_lp, n_fix, n_words);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_spikes_to_s32(const float* spikes, uint8_t* out_s32, int T, int B, int C, int HW, hipStream_t stream) {
+  if (!spikes || !out_s32 || T <= 0 || B <= 0 || C <= 0 || HW <= 0) return SPK_ERR_ARG;
+  if (C % 32) return SPK_ERR_UNSUPPORTED;
+  const long long total = (long long)B * (C / 32) * HW * T * 16;
+  hipLaunchKernelGGL(spikes_to_s32_kernel, dim3(spk_blocks(total, 256) > 65536 ? 65536 : spk_blocks(total, 256)), dim3(256),
+                     0, stream, spikes, out_s32, T, B, C, HW);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_s32_to_spikes(const uint8_t* in_s32, float* spikes, int T, int B, int C, int HW, hipStream_t stream) {
+  if (!spikes || !in_s32 || T <= 0 || B <= 0 || C <= 0 || HW <= 0) return SPK_ERR_ARG;
+  if (C % 32) return SPK_ERR_UNSUPPORTED;
+  const long long total = (long long)T * B * C * HW;
+  hipLaunchKernelGGL(s32_to_spikes_kernel, dim3(spk_blocks(total, 256) > 65536 ? 65536 : spk_blocks(total, 256)), dim3(256),
+                     0, stream, in_s32, spikes, T, B, C, HW);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}

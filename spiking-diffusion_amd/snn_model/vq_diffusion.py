@@ -285,7 +285,7 @@ class DummyModel(nn.Module):
 
     _latent_hw = (7, 7)        # latent size of the last call (7x7 MNIST-shaped, 8x8 CIFAR-shaped)
 
-    def impl_for(self, h, w):
+    def _impl_base(self, h, w):
         """Kernel family used for conv2..conv6 on an h x w latent.  The matrix-core families carry conv2..conv5's
         spikes in layouts only their own conv6 kernel reads, and that kernel packs 16 output channels per tile: any
         ``num_embeddings`` that is not a multiple of 16 (the reference accepts every --codebook_size, R/main.py:58)
@@ -298,19 +298,35 @@ class DummyModel(nn.Module):
             return 'mfma-fp6x6'
         return 'mfma-i8x4' if ops.den_mfma_supported(128, 64, 3, 1, 1, self.n_steps, h, w) else 'direct-f64'
 
+    # the sampler's calls (fresh LIF state, nothing written back) take the second-generation fp6 kernel where it applies
+    # (7x7 latents): the same spikes from five digit planes + certified decisions + exact recomputation of the few neurons
+    # near the threshold (csrc/den_mfma_fp6v2.hip).  False = always the first-generation kernel.
+    use_fp6v2 = True
+    _last_stateful = False
+
+    def impl_for(self, h, w, stateful=False):
+        """Kernel family used for conv2..conv5 on an h x w latent (see _impl_base); stateless calls on 7x7 latents refine
+        'mfma-fp6x6' to 'mfma-fp6v2'."""
+        base = self._impl_base(h, w)
+        if (base == 'mfma-fp6x6' and self.use_fp6v2 and not stateful and
+                ops.den_fp6v2_supported(128, 64, 3, 1, 1, self.n_steps, h, w)):
+            return 'mfma-fp6v2'
+        return base
+
     @property
     def conv_impl(self):
-        return self.impl_for(*self._latent_hw)
+        return self.impl_for(*self._latent_hw, stateful=self._last_stateful)
 
     def _run(self, inp_b2hw, stateful, record=None):
         T = self.n_steps
         # spikes travel channel-chunked: CPTC (32 u8 channels per chunk) for the int8 kernel, C4 (64 fp4 nibbles per
         # chunk) for the fp6 kernel -- the layout each stages per K chunk
         self._latent_hw = (int(inp_b2hw.shape[-2]), int(inp_b2hw.shape[-1]))
+        self._last_stateful = bool(stateful)
         which = self.conv_impl
         impl = 'direct' if which == 'direct-f64' else 'auto'
         collapse = which != 'direct-f64' and self.collapse_conv6
-        chunk = ops.CHUNK_C4 if which == 'mfma-fp6x6' else 32
+        chunk = ops.CHUNK_S32 if which == 'mfma-fp6v2' else (ops.CHUNK_C4 if which == 'mfma-fp6x6' else 32)
         with ops.timed('den.conv1'):
             r1 = self.conv1.run(inp_b2hw, IN_TINV, final='ptc', T=T, stateful=stateful, chunk_out=chunk,
                                 want_counts=collapse)

@@ -35,7 +35,7 @@ class ConvParams:
     def invalidate(self):
         """Forget every derived form (call after writing weights through ``.data``: that does not bump ``_version``)."""
         self.key = self.key_i8 = None
-        self.key_fp6 = self.key_i8g = None
+        self.key_fp6 = self.key_i8g = self.key_fp6v2 = None
 
     def get(self, conv):
         key = (_ver(conv.weight), _ver(conv.bias))
@@ -59,6 +59,14 @@ class ConvParams:
             self.fp6 = ops.den_pack_weight_fp6(conv.weight, conv.bias)
             self.key_fp6 = key
         return self.fp6
+
+    def get_fp6v2(self, conv):
+        """digit tiles of the second-generation fp6 kernel (+ scale / bias / L1 norms / an fp32 copy), built on first use."""
+        key = (_ver(conv.weight), _ver(conv.bias))
+        if key != getattr(self, 'key_fp6v2', None):
+            self.fp6v2 = ops.den_pack_weight_fp6v2(conv.weight, conv.bias)
+            self.key_fp6v2 = key
+        return self.fp6v2
 
     def get_i8_generic(self, conv):
         """int8 digit planes in the layout of the gather-MFMA kernel (any k, Conv2d or ConvTranspose2d)."""
@@ -233,6 +241,25 @@ class FusedSequential(nn.Sequential):
                 bias = None if conv.bias is None else conv.bias.detach()
                 src1 = in1 if (last and in1 is not None) else None
                 c4 = kind == IN_PTC and cur.dim() == 6 and cur.dtype == ops.C4_DTYPE
+                if c4 and cur.shape[-1] == 16:               # S32 records: the sampler's second-generation fp6 kernel
+                    ok = (impl != 'direct' and lif is not None and not want_pre and src1 is None and not geo['transposed'] and
+                          not stateful and
+                          ops.den_fp6v2_supported(conv.out_channels, conv.in_channels, geo['k'], geo['stride'], geo['pad'], T,
+                                                  cur.shape[2], cur.shape[3]) and
+                          (not last or (final == 'ptc' and chunk_out == ops.CHUNK_S32)))
+                    if not ok:
+                        raise NotImplementedError('spkdiff: S32 spikes are only consumed by the fp6v2 MFMA conv (3x3/s1/p1 + BN + '
+                                                  'LIF, T=16, 7x7, fresh LIF state, S32 output)')
+                    a, b = bn.affine_terms()
+                    o = ops.den_conv3x3_mfma_fp6v2(cur, conv._spk_params.get_fp6v2(conv), conv.out_channels, bn_a=a, bn_b=b,
+                                                   want_counts=last and want_counts)
+                    if last and want_counts:
+                        out['ptc'], out['cnt'] = o
+                    elif last:
+                        out['ptc'] = o
+                    else:
+                        cur, kind = o, IN_PTC
+                    continue
                 if c4:
                     ok = (impl != 'direct' and lif is not None and not want_pre and src1 is None and not geo['transposed'] and
                           ops.den_fp6_supported(conv.out_channels, conv.in_channels, geo['k'], geo['stride'], geo['pad'], T,

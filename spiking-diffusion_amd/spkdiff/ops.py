@@ -478,7 +478,7 @@ def spikes_to_ptc(s, chunk=None):
 def ptc_to_spikes(p):
     """u8 [B,H,W,T,C] or CPTC [B,C/chunk,H,W,T,chunk] (or int8-tagged C4) -> fp32 [T,B,C,H,W]."""
     if p.dtype == C4_DTYPE:
-        return c4_to_spikes(p)
+        return s32_to_spikes(p) if p.shape[-1] == 16 else c4_to_spikes(p)
     p = _dev(p, "ptc", torch.uint8)
     if p.dim() == 6:
         B, nch, H, W, T, chunk = p.shape
@@ -509,6 +509,7 @@ IN_PTC, IN_TINV, IN_SEQ = 0, 1, 2
 # "C4" spike tensors (fp4 e2m1 nibbles, 64 channels per 32-byte record: [B, C/64, H, W, 16, 32]) carry dtype int8 so that
 # they cannot be mistaken for the u8 CPTC layout of the same shape
 CHUNK_C4 = -64
+CHUNK_S32 = -32          # "S32": the same nibbles in 32-channel records [B, C/32, H, W, 16, 16] (fp6v2 kernel)
 C4_DTYPE = torch.int8
 
 
@@ -559,6 +560,8 @@ def conv_fused(in0, w_packed, bias, *, in_kind, T, mode, k, stride, pad, transpo
         if want_ptc:
             if chunk_out == CHUNK_C4:                        # nibble-packed fp4 spikes, tagged by dtype int8
                 res["ptc"] = torch.empty((B, Cout // 64, Ho, Wo, T, 32), dtype=C4_DTYPE, device=dev)
+            elif chunk_out == CHUNK_S32:
+                res["ptc"] = torch.empty((B, Cout // 32, Ho, Wo, T, 16), dtype=C4_DTYPE, device=dev)
             else:
                 shape = (B, Ho, Wo, T, Cout) if not chunk_out else (B, Cout // chunk_out, Ho, Wo, T, chunk_out)
                 res["ptc"] = out_ptc if out_ptc is not None else torch.empty(shape, dtype=torch.uint8, device=dev)
@@ -760,6 +763,78 @@ def c4_to_spikes(q):
     B, nch, H, W, T, _ = q.shape
     o = torch.empty((T, B, nch * 64, H, W), dtype=torch.float32, device=q.device)
     check(lib.spk_fp4_to_spikes(_p(q), _p(o), T, B, nch * 64, H * W, _stream(q)), "spk_fp4_to_spikes")
+    return o
+
+
+# ------------------------------------------------------------------------------- fp6v2: the sampler's denoiser convolutions
+def den_fp6v2_supported(Cout, Cin, k, stride, pad, T, H, W):
+    return k == 3 and stride == 1 and pad == 1 and T == 16 and H == 7 and W == 7 and Cout % 32 == 0 and Cin % 32 == 0
+
+
+def den_pack_weight_fp6v2(w, bias):
+    """[Cout,Cin,3,3] fp32 -> (digit tiles u8, fp64 scale [Cout], fp64 bias [Cout], fp32 L1 norms [Cout], the fp32 weights
+    themselves, contiguous: the exact recomputation of flagged neurons reads them)."""
+    w = _dev(w.detach(), "weight", torch.float32)
+    Cout, Cin = w.shape[0], w.shape[1]
+    nbytes = lib.spk_den_packed_weight_fp6v2_bytes(Cout, Cin)
+    if nbytes < 0:
+        raise NotImplementedError("spkdiff: fp6v2 MFMA conv needs Cout % 32 == 0 and Cin % 32 == 0")
+    wq = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    scale = torch.empty(Cout, dtype=torch.float64, device=w.device)
+    bias_d = torch.empty(Cout, dtype=torch.float64, device=w.device)
+    wl1 = torch.empty(Cout, dtype=torch.float32, device=w.device)
+    b = None if bias is None else _dev(bias.detach(), "bias", torch.float32)
+    check(lib.spk_den_pack_weight_fp6v2(_p(w), _p(b), _p(wq), _p(scale), _p(bias_d), _p(wl1), Cout, Cin, _stream(w)),
+          "spk_den_pack_weight_fp6v2")
+    return wq, scale, bias_d, wl1, w.clone()       # a private copy: stays valid until the parameters' next repack
+
+
+_FLAG_WORDS = {}         # (device, words) -> zero-initialised bitmap; every call leaves it clean (the tail launch clears it)
+
+
+def _flag_bitmap(device, words):
+    key = (str(device), int(words))
+    buf = _FLAG_WORDS.get(key)
+    if buf is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("spkdiff: first use of an fp6v2 shape during hipGraph capture (run it once eagerly first)")
+        buf = torch.zeros(int(words), dtype=torch.int32, device=device)
+        _FLAG_WORDS[key] = buf
+    return buf
+
+
+def den_conv3x3_mfma_fp6v2(in0, packed, Cout, *, bn_a, bn_b, want_counts=False):
+    """in0: S32 spikes [B, C/32, 7, 7, 16, 16] (int8-tagged). Returns S32 spikes [B, Cout/32, 7, 7, 16, 16]
+    (or (spikes, counts u8 [B, Cout/32, 7, 7, 32]) with want_counts).  Fresh LIF state, none written back."""
+    in0 = _dev(in0, "in0", C4_DTYPE)
+    B, nch, H, W, T, rec = in0.shape
+    if rec != 16:
+        raise ValueError("S32 spike records are 16 bytes (32 channels)")
+    wq, scale, bias_d, wl1, w32 = packed
+    out = torch.empty((B, Cout // 32, H, W, T, 16), dtype=C4_DTYPE, device=in0.device)
+    cnt = torch.empty((B, Cout // 32, H, W, 32), dtype=torch.uint8, device=in0.device) if want_counts else None
+    flags = _flag_bitmap(in0.device, lib.spk_den_fp6v2_flag_words(B, Cout, H, W))
+    check(lib.spk_den_conv3x3_mfma_fp6v2(_p(in0), nch, _p(wq), _p(scale), _p(bias_d), _p(wl1), _p(w32), _p(bn_a), _p(bn_b),
+                                         _p(out), _p(cnt), _p(flags), T, B, H, W, Cout, _n_dyn(), _stream(in0)),
+          "spk_den_conv3x3_mfma_fp6v2")
+    return (out, cnt) if want_counts else out
+
+
+def spikes_to_s32(s):
+    """fp32 [T,B,C,H,W] -> S32 [B, C/32, H, W, T, 16]."""
+    s = _dev(s, "spikes", torch.float32)
+    T, B, C, H, W = s.shape
+    o = torch.empty((B, C // 32, H, W, T, 16), dtype=C4_DTYPE, device=s.device)
+    check(lib.spk_spikes_to_s32(_p(s), _p(o), T, B, C, H * W, _stream(s)), "spk_spikes_to_s32")
+    return o
+
+
+def s32_to_spikes(q):
+    """S32 [B, C/32, H, W, T, 16] -> fp32 [T,B,C,H,W]."""
+    q = _dev(q, "s32", C4_DTYPE)
+    B, nch, H, W, T, _ = q.shape
+    o = torch.empty((T, B, nch * 32, H, W), dtype=torch.float32, device=q.device)
+    check(lib.spk_s32_to_spikes(_p(q), _p(o), T, B, nch * 32, H * W, _stream(q)), "spk_s32_to_spikes")
     return o
 
 

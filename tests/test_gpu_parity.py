@@ -461,7 +461,7 @@ def test_f5_denoiser_mfma_fp6_kernel(golden_dir, dev, ops):
     from snn_model.vq_diffusion import functional
     d = load(golden_dir, "f5_denoiser_mnist.npz")
     den, sd = build_den(synth.MNIST, dev)
-    assert den.conv_impl == 'mfma-fp6x6'
+    assert den.impl_for(7, 7, stateful=True) == 'mfma-fp6x6' and den.impl_for(7, 7) == 'mfma-fp6v2'
     spikes = {i: unpack(d[f"s{i}_bits"], d[f"s{i}_shape"]) for i in range(1, 6)}
     report = {}
     for i, blk in enumerate((den.conv2, den.conv3, den.conv4, den.conv5), 2):
@@ -495,6 +495,41 @@ def test_f5_denoiser_mfma_fp6_kernel(golden_dir, dev, ops):
     assert float((a1 - torch.from_numpy(d["logits"]).to(dev)).abs().max()) <= 1e-5
     assert float((a1 - b1).abs().max()) <= 1e-6 and float((a2 - b2).abs().max()) <= 1e-6
     assert not torch.equal(a1, a2), "second call starts from the carried membrane potentials"
+
+
+@pytest.mark.parametrize("B", [1, 5, 64])
+def test_fp6v2_kernel_bit_equal_to_the_exact_kernels(dev, ops, B):
+    """spk_den_conv3x3_mfma_fp6v2 (five digit planes with shared accumulators + certified spike decisions + exact
+    recomputation of flagged neurons) against the first-generation fp6 kernel (six planes, fp64 recombination) on the four
+    denoiser shapes with random spikes, weights and BatchNorm terms -- including large and negative BN scales, which widen
+    the certification margins: spikes and spike counts must be bit-equal, and the flag bitmap must come back clean."""
+    g = torch.Generator().manual_seed(1000 + B)
+    H = W = 7
+    total = mism = 0
+    for li, (Cout, Cin) in enumerate(((128, 64), (256, 128), (512, 256), (256, 512))):
+        for trial, (wamp, aamp, rate) in enumerate(((0.05, 1.0, 0.06), (0.3, 25.0, 0.3))):
+            if B == 64 and li >= 2 and trial == 1:
+                continue
+            w = ((torch.rand(Cout, Cin, 3, 3, generator=g) - 0.5) * wamp)
+            w[:, :, 1, 1] *= 3.0                                      # uneven digit structure across taps
+            bias = (torch.rand(Cout, generator=g) - 0.5) * 0.2
+            a = (torch.rand(Cout, generator=g) - 0.3) * aamp          # some negative BN scales
+            b = (torch.rand(Cout, generator=g) - 0.5) * 1.0
+            spikes = (torch.rand(16, B, Cin, H, W, generator=g) < rate).float()
+            wd, biasd, ad, bd, sd = w.to(dev), bias.to(dev), a.to(dev), b.to(dev), spikes.to(dev)
+            o2, c2 = ops.den_conv3x3_mfma_fp6v2(ops.spikes_to_s32(sd), ops.den_pack_weight_fp6v2(wd, biasd), Cout, bn_a=ad,
+                                                bn_b=bd, want_counts=True)
+            o1, c1 = ops.den_conv3x3_mfma_fp6(ops.spikes_to_c4(sd), ops.den_pack_weight_fp6(wd, biasd), Cout, bn_a=ad, bn_b=bd,
+                                              want_counts=True)
+            s2, s1 = ops.s32_to_spikes(o2), ops.c4_to_spikes(o1)
+            assert torch.equal(ops.s32_to_spikes(ops.spikes_to_s32(sd)), sd)                  # S32 round trip
+            total += s1.numel(); mism += int((s1 != s2).sum())
+            assert torch.equal(s1, s2), (Cout, Cin, trial, int((s1 != s2).sum()))
+            assert torch.equal(c1, c2)
+            assert 0.001 < float(s1.mean()) < 0.9
+    torch.cuda.synchronize()
+    assert all(int(v.abs().sum()) == 0 for v in ops._FLAG_WORDS.values()), "the tail launch leaves the bitmap clean"
+    parity(f"fp6v2_vs_fp6_B{B}", neuron_steps=total, spike_mismatches=mism)
 
 
 # ------------------------------------------------------------------------------------------------- F8 LIF training
@@ -1196,12 +1231,14 @@ def test_f2_gather_mfma_layers_teacher_forced(golden_dir, dev, ops):
     assert torch.equal(a1, b1) and torch.equal(a2, b2) and not torch.equal(a1, a2)
 
 
-@pytest.mark.parametrize("req,name", [("fp6", "mfma-fp6x6"), ("i8", "mfma-i8x4")])
-def test_denoiser_mfma_vs_direct_b64_random_tokens(dev, req, name):
-    """A whole denoiser call at B=64 on random, partly masked tokens: both MFMA paths (conv2..5 + time-collapsed
-    conv6) against the fp64 direct path -- every layer's spikes bit-equal, logits within 2e-7."""
+@pytest.mark.parametrize("req,name,v2", [("fp6", "mfma-fp6v2", True), ("fp6", "mfma-fp6x6", False), ("i8", "mfma-i8x4", True)])
+def test_denoiser_mfma_vs_direct_b64_random_tokens(dev, req, name, v2):
+    """A whole denoiser call at B=64 on random, partly masked tokens: the MFMA paths (conv2..5 + time-collapsed conv6;
+    second- and first-generation fp6 kernels, int8 kernel) against the fp64 direct path -- every layer's spikes bit-equal,
+    logits within 2e-7."""
     den, _ = build_den(synth.MNIST, dev)
     den.conv_impl_request = req
+    den.use_fp6v2 = v2
     assert den.conv_impl == name
     g = torch.Generator().manual_seed(123)
     x_t = torch.randint(0, 128, (64, 1, 7, 7), generator=g)
@@ -1420,7 +1457,7 @@ def test_other_codebook_sizes_sample_and_train(dev, K):
     functional.set_step_mode(net=den, step_mode='m')
     den.load_state_dict(sd)
     den.eval()
-    assert den.impl_for(7, 7) == ('direct-f64' if K % 16 else 'mfma-fp6x6')
+    assert den.impl_for(7, 7) == ('direct-f64' if K % 16 else 'mfma-fp6v2')
     g = torch.Generator().manual_seed(K)
     x_t = torch.randint(0, K + 1, (3, 1, 7, 7), generator=g)
     t = torch.tensor([5, 50, 99])
