@@ -210,16 +210,17 @@ int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, c
  * finishes the 49th position (csrc/den_mfma_fp6v2.hip).  DummyModel conv2..conv5, R/snn_model/vq_diffusion.py:166-184,201-204.
  * Spikes travel as "S32": [B][C/32][H*W][16][16 B] (fp4 nibbles, channel c of a group in byte (c % 32) / 2, low nibble first).
  * spk_den_pack_weight_fp6v2: fp32 [Cout,Cin,3,3] (+bias) -> packed digit tiles (spk_den_packed_weight_fp6v2_bytes), fp64
- * scale / bias [Cout] as for the fp6 kernel, wl1 [Cout] = L1 norm of each channel's quantised weights (feeds the margin).
- * w_f32: the original weights (read by the exact recomputation).  flag_words: zero-initialised u32 bitmap of
- * spk_den_fp6v2_flag_words(B, Cout, H, W) words; it is clean again when the call's launches have run.
+ * scale / bias [Cout] as for the fp6 kernel, wl1 [Cout] = L1 norm of each channel's quantised weights, and qtab = the
+ * quantised weights themselves as int32 [Cout][9][Cin] (read by the exact recomputation).  flag_words: zero-initialised
+ * u32 workspace of spk_den_fp6v2_flag_words(B, Cout, H, W) words (counter, ticket, id list, overflow bitmap); it is clean
+ * again when the call's launches have run.
  * SPK_ERR_UNSUPPORTED unless T == 16, H == W == 7, Cout % 32 == 0 (Cin = 32 * nch). */
 long long spk_den_packed_weight_fp6v2_bytes(int Cout, int Cin);
 int spk_den_pack_weight_fp6v2(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d, float* wl1,
-                              int Cout, int Cin, spk_stream_t stream);
+                              int* qtab, int Cout, int Cin, spk_stream_t stream);
 long long spk_den_fp6v2_flag_words(int B, int Cout, int H, int W);
 int spk_den_conv3x3_mfma_fp6v2(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale, const double* bias_d,
-                               const float* wl1, const float* w_f32, const float* bn_a, const float* bn_b, uint8_t* out_s32,
+                               const float* wl1, const int* qtab, const float* bn_a, const float* bn_b, uint8_t* out_s32,
                                uint8_t* out_counts, unsigned* flag_words, int T, int B, int H, int W, int Cout,
                                const int* n_dyn_or_null, spk_stream_t stream);
 /* fp32 spikes [T,B,C,HW] <-> S32 (C % 32 == 0): module boundaries and tests. */

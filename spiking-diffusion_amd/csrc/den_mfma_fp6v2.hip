@@ -12,11 +12,11 @@
 // 2. FIVE DIGITS ON THE MATRIX CORES, THE SIXTH ONLY WHERE IT MATTERS.  The sixth digit moves a pre-activation by at most
 //    E5 = 16 * 9 * Cin * 2^-s (~3e-6).  The main kernel multiplies five digits (23 instead of 27 MFMAs per row tile and
 //    32-channel chunk: the fifth digit pairs two TAPS per instruction), recombines in fp32, and CERTIFIES every spike
-//    decision: a neuron whose membrane potential ever comes within a per-channel margin of the threshold -- the margin
-//    bounds the dropped digit, the fp32 recombination and every rounding of BN / LIF, see margin_of() -- is flagged in a
-//    bitmap (about 1e-4 of the neurons).  The tail launch recomputes the flagged neurons EXACTLY (all six digits from the
-//    fp32 weights in int64, fp64 recombination, one rounding: the arithmetic of den_mfma_fp6.hip) and patches their
-//    spikes.  Unflagged neurons provably emit the spikes the exact arithmetic would; flagged ones are the exact
+//    decision: every neuron carries a running bound D_t on |h_approx - h_exact| (the dropped digit, the fp32
+//    recombination and every rounding of BN / LIF on either path, see "Certification" below) and is flagged when its
+//    membrane potential ever comes within D_t of the threshold (about 1e-4 of the neurons).  The fixup launch recomputes
+//    the flagged neurons EXACTLY (all six digits as the pack kernel's int32 quantised weights, 64-bit sums, fp64
+//    recombination, one rounding: the arithmetic of den_mfma_fp6.hip) and patches their spikes.  Unflagged neurons provably emit the spikes the exact arithmetic would; flagged ones are the exact
 //    arithmetic.  Membrane potentials are not an output here (fresh state in, nothing written back): callers that carry
 //    LIF state, and the training forward, use den_mfma_fp6.hip.
 // 3. A WORK ITEM = one image x 32 output channels, K chunk = 32 input channels: the spike slab of an image is fetched half
@@ -53,9 +53,12 @@ constexpr int W_SLAB = ((N_MAIN + N_L5) * WT + 1023) / 1024 * 1024;   // bytes p
 
 struct V2Args {
   const uint8_t* in0; int nch;               // S32 spikes, nch = Cin / 32
-  const uint8_t* wq; const double* scale; const double* bias; const float* wl1; const float* w_f32;
+  const uint8_t* wq; const double* scale; const double* bias; const float* wl1;
   const float* bn_a; const float* bn_b;
-  uint8_t* out; uint8_t* out_cnt; unsigned* flags;
+  uint8_t* out; uint8_t* out_cnt;
+  unsigned* flags;                           // ws[0]: number of flagged neurons, ws[1]: ticket, ws[2..2+cap): their ids,
+  unsigned flag_cap;                         //  then the overflow bitmap (one bit per neuron; used only beyond cap)
+  const int* qtab;                           // quantised weights int32 [Cout][9][Cin] (exact recomputation)
   const int* n_dyn;
   int B, Cout, Cin;
   int gx, nsets;                             // XCD-aware walk (gx > 0) or flat walk (gx == 0)
@@ -72,25 +75,32 @@ struct V2Args {
                : "=&" CLS(acc) : "v"(av), "v"(bv), "v"(sa), "v"(sb))
 
 #ifndef SPK_V2_DBG
-#define SPK_V2_DBG 0            // timing experiments only: 1 = no steady-state DMA, 4 = no epilogue (results are wrong)
+#define SPK_V2_DBG 0            // experiments only: 1 = no steady-state DMA, 4 = no epilogue (results are wrong), 32 = zero
+                                // certification margin (nothing flagged: shows what the exact recomputation repairs),
+                                // 64 = the tail launch leaves the flag bitmap alone (flagged neurons can be counted),
+                                // 128 = every workgroup stamps {s_memtime, s_memrealtime} around its item loop into the id
+                                // list (shader clock under this kernel's own load = d memtime / d memrealtime * 100 MHz)
+#endif
+#ifndef SPK_V2_PF
+#define SPK_V2_PF 6             // A fragments requested this many steps ahead of the MFMA that consumes them
 #endif
 constexpr int N_AGPR = 16;      // accumulator tiles (index 3 * i + j) that live in AGPRs (256 registers)
 
-// Certification margin of one output channel: |h_approx - h_exact| stays below it for every time step as long as the
-// spike decisions agreed so far (after a spike both paths restart from v = 0).  Y bounds |y| (L1 norm of the quantised
-// weights + |bias|), E5 the dropped sixth digit; 2^-21 / 2^-22 terms cover the fp32 recombination (two fma roundings),
-// the folded scale * bn_a constant, the rounding of y, of z = fma(y, a, b) and of the three LIF operations per step --
-// each at most 2^-24 relative to a quantity bounded by Y or Zb -- with a factor > 2 to spare; the recursion
-// d_t <= d_{t-1} / 2 + dz / 2 + rho sums to dz + 2 rho, doubled once more.
-__device__ __forceinline__ float margin_of(float wl1, float bias_f, float bna, float bnb, float scale_f, int Cin) {
-  const float Y = wl1 + fabsf(bias_f);
+// Certification.  The approximate path (five digits, fp32 recombination, folded constants) and the exact path (six digits,
+// fp64 recombination, the reference's BN / LIF operations) run the same LIF recursion on pre-activations that differ by
+//   |z~ - z| <= cE + 2 eps |z|,      cE = |a| E5 + 2 eps (|b| + |Bc|),  E5 = 16 * 9 * Cin * 2^-s  (the dropped digit, every
+//                                                                        input active with the largest residue)
+// with eps = 2^-22 (each of the handful of fp32 roundings on either path is <= 2^-24 relative to a quantity bounded by
+// |z|, |b| or |Bc|).  One LIF step h = v + (z - v) / 2 halves the carried difference and adds its own roundings:
+//   dh_t <= dh_{t-1} / 2 + cE / 2 + 2 eps (|z_t| + |v_{t-1}|)
+// as long as the spike decisions agreed so far (after a spike both paths restart from v = 0; the bound is simply kept).
+// The epilogue carries D_t = 2 dh_t (a factor 2 to spare) per neuron and flags it when |h_t - 1| <= D_t for some t: every
+// unflagged neuron provably emits the exact path's spikes; flagged ones are recomputed exactly.
+__device__ __forceinline__ float cert_const(float bias_f, float bna, float bnb, float Bc, float scale_f, int Cin) {
   const float E5 = 16.0f * 9.0f * (float)Cin * scale_f;
-  const float dy = E5 + 4.76837158e-07f * Y;                       // 2^-21
-  const float Zb = fabsf(bna) * Y + fabsf(bnb);
-  const float dz = fabsf(bna) * dy + 2.38418579e-07f * Zb;         // 2^-22
-  const float rho = 2.38418579e-07f * 3.0f * fmaxf(Zb, 1.0f);
-  return 2.0f * (dz + 2.0f * rho);
+  return fabsf(bna) * E5 + 2.0f * 2.38418579e-07f * (fabsf(bnb) + fabsf(Bc)) + 1e-30f;
 }
+constexpr float CERT_4EPS = 4.0f * 2.38418579e-07f;
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  The K loop must be straight-line
 // code with constant accumulator indices (a runtime index would send the accumulators through scratch); this does not
@@ -221,12 +231,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6v2_kernel(V2Args a) {
   const float bna = a.bn_a[co], bnb = a.bn_b[co];
   const float Ac = 32.0f * scale_f * bna;                 // z = fma(Q5, Ac, Bc),  Q5 = P01 * 2^15 + P23 * 2^5 + P4
   const float Bc = fmaf(bias_f, bna, bnb);
-  const float mrg = margin_of(a.wl1[co], bias_f, bna, bnb, scale_f, a.Cin);
+  const float cE = cert_const(bias_f, bna, bnb, Bc, scale_f, a.Cin);
 
   const int sc_a = 0x7f7f7f7f;                            // e8m0 block scales: spikes x 1
   const int sc_p = half ? (int)0x82828282u : (int)0x87878787u;   // digit pairs: even digit (K half 0) x 2^8, odd digit x 2^3
   const int sc_4 = (int)0x82828282u;                      // fifth digit x 2^3 (e2m3 value d / 8 -> d)
 
+  unsigned long long dbg_c0 = 0, dbg_r0 = 0;
+  if (SPK_V2_DBG & 128) { dbg_c0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
   int it = 0;                                             // running chunk counter: LDS buffer = it & 1
   if (il < Bn) {
     const uint8_t* as0 = aslab_of(il, 0);
@@ -252,14 +264,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6v2_kernel(V2Args a) {
         const uint8_t* A = sA + buf * A_BYTES;
         const uint8_t* Wb = sW + buf * W_LDS;
         auto toff = [](int tap) constexpr -> int { return ((tap / 3) * PW + (tap % 3)) * POSB; };
-        auto lda = [&](int s) -> v4i {
-          if (s < NS_PAIR) {
-            const int tap = s / NT, i = s % NT;
-            return *reinterpret_cast<const v4i*>(A + a_off[i] + toff(tap));
+        // Step order: blocks of NT steps (one per row tile) -- tap 0, tap 1, D(0), tap 2, tap 3, D(1), ..., tap 8, D(4), where a
+        // tap block issues the two digit-pair MFMAs per step and D(q) the single fifth-digit MFMA of taps (2q, 2q + 1).  The
+        // one-MFMA blocks sit BETWEEN two-MFMA blocks (six in a row left the fragment prefetch only ~130 cycles ahead).
+        auto blk_is_d = [](int blk) constexpr -> bool { return blk < 12 ? (blk % 3 == 2) : (blk == 13); };
+        auto blk_tap = [](int blk) constexpr -> int { return blk < 12 ? 2 * (blk / 3) + (blk % 3) : 8; };      // tap blocks
+        auto blk_q = [](int blk) constexpr -> int { return blk < 12 ? blk / 3 : 4; };                          // D blocks
+        constexpr int NBLK = 14;
+        static_assert(NSTEP == NBLK * NT, "14 blocks of NT steps");
+        auto lda = [&](auto s_tag) -> v4i {
+          constexpr int s = decltype(s_tag)::value;
+          constexpr int blk = s / NT, i = s % NT;
+          if constexpr (!blk_is_d(blk)) {
+            return *reinterpret_cast<const v4i*>(A + a_off[i] + toff(blk_tap(blk)));
+          } else {
+            constexpr int q = blk_q(blk);
+            const int base = q == 1 ? a_off2[i] : (q == 4 ? a_off[i] : a_off1[i]);
+            return *reinterpret_cast<const v4i*>(A + base + toff(2 * q));
           }
-          const int q = (s - NS_PAIR) / NT, i = (s - NS_PAIR) % NT;
-          const int base = q == 1 ? a_off2[i] : (q == 4 ? a_off[i] : a_off1[i]);
-          return *reinterpret_cast<const v4i*>(A + base + toff(2 * q));
         };
         auto ldb = [&](int tile) -> v6i {
           // 16 + 8 bytes per lane; the 8-byte read is volatile so that hipcc does not pair the tails of two tiles
@@ -273,23 +295,34 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6v2_kernel(V2Args a) {
         v6i bp[2][2];                                     // digit-pair tiles of tap parity [tap & 1][pair]
         v6i b4[2];                                        // fifth-digit tiles [q & 1]
         bp[0][0] = ldb(0); bp[0][1] = ldb(1);
-        constexpr int PF = 4;
+        constexpr int PF = SPK_V2_PF;
         v4i af[PF];
-#pragma unroll
-        for (int s = 0; s < PF; ++s) af[s] = lda(s);
+        static_for<PF>([&](auto s_tag) { af[decltype(s_tag)::value] = lda(s_tag); });
         static_for<NSTEP>([&](auto s_tag) {
           constexpr int s = decltype(s_tag)::value;
+          constexpr int blk = s / NT, i = s % NT;
           const v4i av = af[s % PF];
-          if constexpr (s + PF < NSTEP) af[s % PF] = lda(s + PF);
+          if constexpr (s + PF < NSTEP) af[s % PF] = lda(std::integral_constant<int, s + PF>{});
           constexpr int NPIECES = NPA + NPW;
 #define V2_DMA_SLOT()                                                                              \
   do {                                                                                             \
-    if constexpr (s % NT == 0 && s / NT < NPIECES) {                                               \
-      if (!(SPK_V2_DBG & 1)) issue_piece(s / NT, n_aslab, n_wslab, n_dA, n_dW);                    \
+    if constexpr (i == 0 && blk < NPIECES) {                                                       \
+      if (!(SPK_V2_DBG & 1)) issue_piece(blk, n_aslab, n_wslab, n_dA, n_dW);                       \
     }                                                                                              \
   } while (0)
-          if constexpr (s < NS_PAIR) {
-            constexpr int tap = s / NT, i = s % NT;
+          // the next block's weight tiles are requested at the first step of this block
+#define V2_NEXT_TILES()                                                                            \
+  do {                                                                                             \
+    if constexpr (i == 0 && blk + 1 < NBLK) {                                                      \
+      if constexpr (blk_is_d(blk + 1)) b4[blk_q(blk + 1) & 1] = ldb(N_PAIR + blk_q(blk + 1));      \
+      else {                                                                                       \
+        bp[blk_tap(blk + 1) & 1][0] = ldb(2 * blk_tap(blk + 1));                                   \
+        bp[blk_tap(blk + 1) & 1][1] = ldb(2 * blk_tap(blk + 1) + 1);                               \
+      }                                                                                            \
+    }                                                                                              \
+  } while (0)
+          if constexpr (!blk_is_d(blk)) {
+            constexpr int tap = blk_tap(blk);
 #define V2_PAIR_MFMA(J)                                                                                      \
   do {                                                                                                        \
     if constexpr (FIRST && tap == 0) {                                                                        \
@@ -303,14 +336,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6v2_kernel(V2Args a) {
             V2_PAIR_MFMA(0);
             __builtin_amdgcn_sched_barrier(0);
             V2_DMA_SLOT();
-            if constexpr (i == 1) {                       // next tap's weight tiles (or the first fifth-digit tile)
-              if constexpr (tap + 1 < 9) { bp[(tap + 1) & 1][0] = ldb(2 * (tap + 1)); bp[(tap + 1) & 1][1] = ldb(2 * (tap + 1) + 1); }
-              else b4[0] = ldb(N_PAIR);
-            }
+            V2_NEXT_TILES();
             V2_PAIR_MFMA(1);
             __builtin_amdgcn_sched_barrier(0);
           } else {
-            constexpr int q = (s - NS_PAIR) / NT, i = (s - NS_PAIR) % NT;
+            constexpr int q = blk_q(blk);
             if constexpr (FIRST && q == 0) {
               if constexpr (3 * i + 2 < N_AGPR) SPK_MFMA2_Z("a", acc[i][2], av, b4[0], sc_a, sc_4);
               else SPK_MFMA2_Z("v", acc[i][2], av, b4[0], sc_a, sc_4);
@@ -320,7 +350,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6v2_kernel(V2Args a) {
             }
             __builtin_amdgcn_sched_barrier(0);
             V2_DMA_SLOT();
-            if constexpr (i == 1 && q + 1 < N_D4) b4[(q + 1) & 1] = ldb(N_PAIR + q + 1);
+            V2_NEXT_TILES();
             __builtin_amdgcn_sched_barrier(0);
           }
         });
@@ -352,24 +382,27 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6v2_kernel(V2Args a) {
 #pragma unroll
       for (int j = 0; j < 3; ++j)
         if (3 * i + j < N_AGPR) asm volatile("" : "+a"(acc[i][j]));
-      float v = 0.f;
+      float v = 0.f, D = 0.f;
       unsigned mybits = 0;
       bool flg = false;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float q5 = fmaf(fmaf(acc[i][0][r], 1024.0f, acc[i][1][r]), 32.0f, acc[i][2][r]);
         const float z = fmaf(q5, Ac, Bc);
+        D = fmaf(fabsf(z) + fabsf(v), CERT_4EPS, fmaf(D, 0.5f, cE));        // D_t = D_{t-1} / 2 + cE + 4 eps (|z| + |v|)
         const float h = v + (z - v) * 0.5f;
         const bool s = h >= 1.0f;
-        flg = flg || (fabsf(h - 1.0f) <= mrg);
+        flg = flg || (fabsf(h - 1.0f) <= D);
         v = s ? 0.0f : h;
         mybits |= s ? (1u << r) : 0u;
       }
       const int ti = wave + 4 * i;
       const int p = 2 * ti + half;                        // accumulator lane half == position within the tile
-      if (flg) {
+      if (flg && !(SPK_V2_DBG & 32)) {
         const long long n = ((long long)b * a.Cout + co) * HW + p;
-        atomicOr(a.flags + (n >> 5), 1u << (n & 31));
+        const unsigned idx = atomicAdd(a.flags, 1u);
+        if (idx < a.flag_cap) a.flags[2 + idx] = (unsigned)n;
+        else atomicOr(a.flags + 2 + a.flag_cap + (n >> 5), 1u << (n & 31));
       }
       const long long rec = (((long long)b * G + g) * HW + p) * POSB;
       store_tile_spikes(a.out, a.out_cnt, mybits, lane, rec, (((long long)b * G + g) * HW + p) * 32, true);
@@ -377,24 +410,27 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6v2_kernel(V2Args a) {
     }
   }   // images
   spk_dma_wait_all();     // the copy issued during the very last chunk must not outlive the workgroup's LDS allocation
+  if ((SPK_V2_DBG & 128) && tid == 0) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(a.flags + 2) + 2 * blockIdx.x;
+    o[0] = __builtin_amdgcn_s_memtime() - dbg_c0;
+    o[1] = __builtin_amdgcn_s_memrealtime() - dbg_r0;
+  }
 }
 
-// ------------------------------------------------------------------------------------------------ tail launch
+// ------------------------------------------------------------------------------------------------ tail launches
 // (1) the last position of every image, exactly: one wave = four images x one channel group, two 32-row tiles whose lane
 //     halves are images; the four taps that reach position (H-1, W-1) from inside the image; operands straight from L2;
 //     all six digits (the two sixth-digit tiles of the slab), fp64 recombination.
-// (2) the flagged neurons of the main launch, exactly: every wave scans a share of the bitmap, recomputes a flagged neuron
-//     from the fp32 weights in 64-bit integers (the quantisation of the pack kernel), patches its 16 spike nibbles and its
-//     count, and clears the bit -- the bitmap is clean again when the launch ends.
+// (2) the flagged neurons of the main launch, exactly (fixup_neuron / fp6v2_fixup_kernel below).
 __device__ __forceinline__ float exact_preact(double s, double sc, double bi) { return (float)fma(s, sc, bi); }
 
 template <int H, int W>
-__global__ __launch_bounds__(256) void fp6v2_tail_kernel(V2Args a, int n_lp_blocks, int n_fix_blocks, long long n_words) {
+__global__ __launch_bounds__(256) void fp6v2_lastpos_kernel(V2Args a) {
   constexpr int HW = H * W;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = a.nch, G = a.Cout >> 5;
   const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
-  if ((int)blockIdx.x < n_lp_blocks) {
+  {
     // ---------------------------------------------------------------- (1) last position
     const int unit = blockIdx.x * 4 + wave;
     const int g = unit % G, b0 = (unit / G) * 4;
@@ -481,79 +517,109 @@ __global__ __launch_bounds__(256) void fp6v2_tail_kernel(V2Args a, int n_lp_bloc
       const long long cell = ((long long)(ok ? b : 0) * G + g) * HW + (HW - 1);
       store_tile_spikes(a.out, a.out_cnt, mybits, lane, cell * POSB, cell * 32, ok);
     }
-    return;
   }
-  // ------------------------------------------------------------------ (2) flagged neurons
-  const int wid = ((int)blockIdx.x - n_lp_blocks) * 4 + wave, nw = n_fix_blocks * 4;
-  const long long per = (n_words + nw - 1) / nw;
-  const long long w0 = (long long)wid * per;
-  long long w1 = w0 + per;
-  if (w1 > n_words) w1 = n_words;
-  const int Cin = a.Cin, K9 = 9 * Cin;
-  for (long long base = w0; base < w1; base += 64) {
-    const long long wi = base + lane;
-    unsigned word = wi < w1 ? a.flags[wi] : 0u;
-    unsigned long long any = __ballot(word != 0u);
-    if (wi < w1 && word != 0u) a.flags[wi] = 0u;            // self-cleaning bitmap
-    while (any) {
-      const int l = __ffsll((long long)any) - 1;
-      any &= any - 1;
-      unsigned wv = (unsigned)__shfl((int)word, l);
+}
+
+// (2) One flagged neuron, exactly, by a whole 1024-thread workgroup: thread unit (tap, 32-channel chunk, t) reads ONE 16-byte
+// spike record and the 32 quantised weights of its (channel, tap, chunk) from the int32 table the pack kernel wrote (the
+// same rint(w * 2^s) as the digit tiles), sums the active ones in 64 bits; partial sums meet per time step through two
+// lane shuffles and 16 LDS atomics per wave; thread 0 then runs the exact epilogue (fp64 recombination of the exact sum --
+// the arithmetic of den_mfma_fp6.hip -- the reference's BN and LIF steps) and patches the neuron's 16 spike nibbles and count.
+template <int H, int W>
+__device__ __forceinline__ void fixup_neuron(const V2Args& a, long long n, unsigned long long* sS, int Bn) {
+  constexpr int HW = H * W;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nch = a.nch, Cin = a.Cin;
+  const int p = (int)(n % HW);
+  const long long r0 = n / HW;
+  const int co = (int)(r0 % a.Cout), b = (int)(r0 / a.Cout);
+  if (b >= Bn) return;                                     // (uniform over the workgroup)
+  const int py = p / W, px = p % W;
+  if (tid < 16) sS[tid] = 0ull;
+  __syncthreads();
+  long long part = 0;
+  const int units = 9 * nch * 16;
+  for (int u = tid; u < units; u += 1024) {
+    const int t = u & 15, cc = (u >> 4) % nch, tap = (u >> 4) / nch;
+    const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+    if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+    const uint4 sp = *reinterpret_cast<const uint4*>(a.in0 + (((long long)b * nch + cc) * HW + yy * W + xx) * POSB + t * 16);
+    const int4* qp = reinterpret_cast<const int4*>(a.qtab + ((long long)co * 9 + tap) * Cin + cc * 32);
+    const unsigned w4[4] = {sp.x, sp.y, sp.z, sp.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int4 q = qp[j];
+      const unsigned nib = w4[j >> 1] >> (16 * (j & 1));     // four nibbles: channels 4j .. 4j + 3
+      part += (nib & 0x000fu) ? (long long)q.x : 0ll;
+      part += (nib & 0x00f0u) ? (long long)q.y : 0ll;
+      part += (nib & 0x0f00u) ? (long long)q.z : 0ll;
+      part += (nib & 0xf000u) ? (long long)q.w : 0ll;
+    }
+  }
+  // lanes l, l + 16, l + 32, l + 48 of a wave hold the same time step (t = u & 15, 1024 and 64 are multiples of 16)
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+    const int lo = __shfl_xor((int)(unsigned)(part & 0xffffffffll), off);
+    const int hi = __shfl_xor((int)(part >> 32), off);
+    part += (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+  }
+  if (lane < 16 && part != 0) atomicAdd(&sS[lane], (unsigned long long)part);
+  __syncthreads();
+  if (tid == 0) {
+    const double sc = a.scale[co], bi = a.bias[co];
+    const float bna = a.bn_a[co], bnb = a.bn_b[co];
+    float v = 0.f;
+    int cnt = 0;
+    const int g = co >> 5;
+    uint8_t* rec = a.out + ((((long long)b * (a.Cout >> 5) + g) * HW + p) * POSB);
+    const int byte = (co & 31) >> 1;
+    const unsigned shw = 8u * (byte & 3) + 4u * (co & 1);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const float y = exact_preact((double)(long long)sS[t], sc, bi);
+      const bool s = spk_lif_step_default(v, fmaf(y, bna, bnb));
+      cnt += s ? 1 : 0;
+      unsigned* wp = reinterpret_cast<unsigned*>(rec + t * 16 + (byte & ~3));
+      atomicAnd(wp, ~(0xFu << shw));
+      if (s) atomicOr(wp, 0x2u << shw);
+    }
+    if (a.out_cnt) a.out_cnt[(((long long)b * (a.Cout >> 5) + g) * HW + p) * 32 + (co & 31)] = (uint8_t)cnt;
+  }
+  __syncthreads();
+}
+
+template <int H, int W>
+__global__ __launch_bounds__(1024) void fp6v2_fixup_kernel(V2Args a, long long n_words) {
+  __shared__ unsigned long long sS[16];
+  __shared__ unsigned s_last;
+  if (SPK_V2_DBG & 64) return;
+  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
+  const unsigned count = a.flags[0];
+  const unsigned nlist = count < a.flag_cap ? count : a.flag_cap;
+  for (unsigned e = blockIdx.x; e < nlist; e += gridDim.x) fixup_neuron<H, W>(a, (long long)a.flags[2 + e], sS, Bn);
+  if (count > a.flag_cap) {
+    // overflow path (more than flag_cap flagged neurons): the rest sit in the bitmap; scan a share of it, clear as we go
+    unsigned* bm = a.flags + 2 + a.flag_cap;
+    const long long per = (n_words + gridDim.x - 1) / gridDim.x;
+    const long long w0 = (long long)blockIdx.x * per;
+    const long long w1 = w0 + per < n_words ? w0 + per : n_words;
+    for (long long wi = w0; wi < w1; ++wi) {
+      unsigned wv = bm[wi];                                // (uniform over the workgroup)
+      __syncthreads();
+      if (threadIdx.x == 0 && wv) bm[wi] = 0u;
       while (wv) {
         const int bit = __ffs((int)wv) - 1;
         wv &= wv - 1;
-        const long long n = (base + l) * 32 + bit;
-        const int p = (int)(n % HW);
-        const long long r0 = n / HW;
-        const int co = (int)(r0 % a.Cout), b = (int)(r0 / a.Cout);
-        if (b >= Bn) continue;
-        const int py = p / W, px = p % W;
-        const double sc = a.scale[co], bi = a.bias[co];
-        const int sh = -ilogb(sc);                          // scale = 2^-sh exactly
-        long long S[16];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) S[t] = 0;
-        for (int k = lane; k < K9; k += 64) {
-          const int tap = k / Cin, ci = k - tap * Cin;
-          const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
-          if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-          const long long q = (long long)rint(ldexp((double)a.w_f32[((long long)co * Cin + ci) * 9 + tap], sh));
-          const uint8_t* src = a.in0 + (((long long)b * nch + (ci >> 5)) * HW + yy * W + xx) * POSB + ((ci & 31) >> 1);
-          const int shn = 4 * (ci & 1);
-#pragma unroll
-          for (int t = 0; t < 16; ++t)
-            if ((src[t * 16] >> shn) & 0xF) S[t] += q;
-        }
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-#pragma unroll
-          for (int off = 32; off > 0; off >>= 1) {
-            const int lo = __shfl_xor((int)(unsigned)(S[t] & 0xffffffffll), off);
-            const int hi = __shfl_xor((int)(S[t] >> 32), off);
-            S[t] += (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-          }
-        }
-        if (lane == 0) {
-          const float bna = a.bn_a[co], bnb = a.bn_b[co];
-          float v = 0.f;
-          int cnt = 0;
-          const int g = co >> 5;
-          uint8_t* rec = a.out + ((((long long)b * (a.Cout >> 5) + g) * HW + p) * POSB);
-          const int byte = (co & 31) >> 1;
-          const unsigned shw = 8u * (byte & 3) + 4u * (co & 1);
-#pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            const float y = exact_preact((double)S[t], sc, bi);
-            const bool s = spk_lif_step_default(v, fmaf(y, bna, bnb));
-            cnt += s ? 1 : 0;
-            unsigned* wp = reinterpret_cast<unsigned*>(rec + t * 16 + (byte & ~3));
-            atomicAnd(wp, ~(0xFu << shw));
-            if (s) atomicOr(wp, 0x2u << shw);
-          }
-          if (a.out_cnt) a.out_cnt[(((long long)b * (a.Cout >> 5) + g) * HW + p) * 32 + (co & 31)] = (uint8_t)cnt;
-        }
+        fixup_neuron<H, W>(a, wi * 32 + bit, sS, Bn);
       }
     }
+  }
+  // the last workgroup to finish resets the counter for the next launch
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_last = atomicAdd(a.flags + 1, 1u) == gridDim.x - 1 ? 1u : 0u;
+    if (s_last) { a.flags[0] = 0u; a.flags[1] = 0u; __threadfence(); }
   }
 }
 
@@ -565,7 +631,8 @@ __global__ __launch_bounds__(256) void fp6v2_tail_kernel(V2Args a, int n_lp_bloc
 // tap 2q, half 1: tap 2q + 1], sixth digit x 2 [taps (0, 1) and (3, 4)].  Also the L1 norm of the quantised weights.
 __global__ __launch_bounds__(256) void pack_fp6v2_kernel(const float* __restrict__ w, const float* __restrict__ bias,
                                                          uint8_t* __restrict__ wq, double* __restrict__ scale,
-                                                         double* __restrict__ bias_d, float* __restrict__ wl1, int Cout, int Cin) {
+                                                         double* __restrict__ bias_d, float* __restrict__ wl1,
+                                                         int* __restrict__ qtab, int Cout, int Cin) {
   __shared__ float smax[256];
   __shared__ double ssum[256];
   const int co = blockIdx.x, n = Cin * 9;
@@ -583,7 +650,12 @@ __global__ __launch_bounds__(256) void pack_fp6v2_kernel(const float* __restrict
   if (m > 0.f) frexpf(m, &e);                 // m = f * 2^e, f in [0.5, 1)  ->  m < 2^e
   const int sh = 29 - e;                      // |w| * 2^sh < 2^29 <= 16.5 * 32^5
   double l1 = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) l1 += fabs(rint(ldexp((double)wc[i], sh)));
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double q = rint(ldexp((double)wc[i], sh));
+    l1 += fabs(q);
+    const int ci = i / 9, tap = i - 9 * ci;
+    qtab[((long long)co * 9 + tap) * Cin + ci] = (int)q;          // |q| < 2^29
+  }
   ssum[threadIdx.x] = l1;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
@@ -674,30 +746,33 @@ extern "C" long long spk_den_packed_weight_fp6v2_bytes(int Cout, int Cin) {
 }
 
 extern "C" int spk_den_pack_weight_fp6v2(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d,
-                                         float* wl1, int Cout, int Cin, hipStream_t stream) {
-  if (!w || !wq || !scale || !bias_d || !wl1 || Cout <= 0 || Cin <= 0) return SPK_ERR_ARG;
+                                         float* wl1, int* qtab, int Cout, int Cin, hipStream_t stream) {
+  if (!w || !wq || !scale || !bias_d || !wl1 || !qtab || Cout <= 0 || Cin <= 0) return SPK_ERR_ARG;
   if ((Cout % 32) || (Cin % CK)) return SPK_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(pack_fp6v2_kernel, dim3(Cout), dim3(256), 0, stream, w, bias, wq, scale, bias_d, wl1, Cout, Cin);
+  hipLaunchKernelGGL(pack_fp6v2_kernel, dim3(Cout), dim3(256), 0, stream, w, bias, wq, scale, bias_d, wl1, qtab, Cout, Cin);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }
 
+constexpr unsigned FLAG_CAP = 1u << 20;        // list capacity; beyond it flagged neurons go to the bitmap (slow path)
+
 extern "C" long long spk_den_fp6v2_flag_words(int B, int Cout, int H, int W) {
   if (B <= 0 || Cout <= 0 || H <= 0 || W <= 0) return -1;
-  return ((long long)B * Cout * H * W + 31) / 32;
+  return 2 + (long long)FLAG_CAP + ((long long)B * Cout * H * W + 31) / 32;
 }
 
 extern "C" int spk_den_conv3x3_mfma_fp6v2(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale,
-                                          const double* bias_d, const float* wl1, const float* w_f32, const float* bn_a,
+                                          const double* bias_d, const float* wl1, const int* qtab, const float* bn_a,
                                           const float* bn_b, uint8_t* out_s32, uint8_t* out_counts, unsigned* flag_words,
                                           int T, int B, int H, int W, int Cout, const int* n_dyn_or_null, hipStream_t stream) {
-  if (!in_s32 || nch <= 0 || !wq || !scale || !bias_d || !wl1 || !w_f32 || !bn_a || !bn_b || !out_s32 || !flag_words ||
+  if (!in_s32 || nch <= 0 || !wq || !scale || !bias_d || !wl1 || !qtab || !bn_a || !bn_b || !out_s32 || !flag_words ||
       B <= 0 || H <= 0 || W <= 0 || Cout <= 0)
     return SPK_ERR_ARG;
   if (T != T16 || (Cout % 32) || H != 7 || W != 7) return SPK_ERR_UNSUPPORTED;
   V2Args a;
-  a.in0 = in_s32; a.nch = nch; a.wq = wq; a.scale = scale; a.bias = bias_d; a.wl1 = wl1; a.w_f32 = w_f32;
-  a.bn_a = bn_a; a.bn_b = bn_b; a.out = out_s32; a.out_cnt = out_counts; a.flags = flag_words; a.n_dyn = n_dyn_or_null;
+  a.in0 = in_s32; a.nch = nch; a.wq = wq; a.scale = scale; a.bias = bias_d; a.wl1 = wl1; a.qtab = qtab;
+  a.bn_a = bn_a; a.bn_b = bn_b; a.out = out_s32; a.out_cnt = out_counts; a.flags = flag_words; a.flag_cap = FLAG_CAP;
+  a.n_dyn = n_dyn_or_null;
   a.B = B; a.Cout = Cout; a.Cin = nch * CK;
   const int cus = spk_cu_count();
   const int G = Cout / 32;
@@ -718,9 +793,10 @@ extern "C" int spk_den_conv3x3_mfma_fp6v2(const uint8_t* in_s32, int nch, const 
   hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7>), dim3(grid), dim3(256), lds, stream, a);
   SPK_LAUNCH_CHECK();
   const int n_lp = (((B + 3) / 4) * G + 3) / 4;
-  const int n_fix = cus;
+  hipLaunchKernelGGL((fp6v2_lastpos_kernel<7, 7>), dim3(n_lp), dim3(256), 0, stream, a);
+  SPK_LAUNCH_CHECK();
   const long long n_words = ((long long)B * Cout * H * W + 31) / 32;
-  hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7>), dim3(n_lp + n_fix), dim3(256), 0, stream, a, n_lp, n_fix, n_words);
+  hipLaunchKernelGGL((fp6v2_fixup_kernel<7, 7>), dim3(2 * cus), dim3(1024), 0, stream, a, n_words);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

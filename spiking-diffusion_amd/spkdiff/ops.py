@@ -772,8 +772,8 @@ def den_fp6v2_supported(Cout, Cin, k, stride, pad, T, H, W):
 
 
 def den_pack_weight_fp6v2(w, bias):
-    """[Cout,Cin,3,3] fp32 -> (digit tiles u8, fp64 scale [Cout], fp64 bias [Cout], fp32 L1 norms [Cout], the fp32 weights
-    themselves, contiguous: the exact recomputation of flagged neurons reads them)."""
+    """[Cout,Cin,3,3] fp32 -> (digit tiles u8, fp64 scale [Cout], fp64 bias [Cout], fp32 L1 norms [Cout], the quantised
+    weights as int32 [Cout, 9, Cin]: the exact recomputation of flagged neurons reads them)."""
     w = _dev(w.detach(), "weight", torch.float32)
     Cout, Cin = w.shape[0], w.shape[1]
     nbytes = lib.spk_den_packed_weight_fp6v2_bytes(Cout, Cin)
@@ -783,13 +783,14 @@ def den_pack_weight_fp6v2(w, bias):
     scale = torch.empty(Cout, dtype=torch.float64, device=w.device)
     bias_d = torch.empty(Cout, dtype=torch.float64, device=w.device)
     wl1 = torch.empty(Cout, dtype=torch.float32, device=w.device)
+    qtab = torch.empty((Cout, 9, Cin), dtype=torch.int32, device=w.device)
     b = None if bias is None else _dev(bias.detach(), "bias", torch.float32)
-    check(lib.spk_den_pack_weight_fp6v2(_p(w), _p(b), _p(wq), _p(scale), _p(bias_d), _p(wl1), Cout, Cin, _stream(w)),
+    check(lib.spk_den_pack_weight_fp6v2(_p(w), _p(b), _p(wq), _p(scale), _p(bias_d), _p(wl1), _p(qtab), Cout, Cin, _stream(w)),
           "spk_den_pack_weight_fp6v2")
-    return wq, scale, bias_d, wl1, w.clone()       # a private copy: stays valid until the parameters' next repack
+    return wq, scale, bias_d, wl1, qtab
 
 
-_FLAG_WORDS = {}         # (device, words) -> zero-initialised bitmap; every call leaves it clean (the tail launch clears it)
+_FLAG_WORDS = {}         # (device, words) -> zero-initialised workspace; every call leaves it clean (the fixup launch resets it)
 
 
 def _flag_bitmap(device, words):
@@ -810,11 +811,11 @@ def den_conv3x3_mfma_fp6v2(in0, packed, Cout, *, bn_a, bn_b, want_counts=False):
     B, nch, H, W, T, rec = in0.shape
     if rec != 16:
         raise ValueError("S32 spike records are 16 bytes (32 channels)")
-    wq, scale, bias_d, wl1, w32 = packed
+    wq, scale, bias_d, wl1, qtab = packed
     out = torch.empty((B, Cout // 32, H, W, T, 16), dtype=C4_DTYPE, device=in0.device)
     cnt = torch.empty((B, Cout // 32, H, W, 32), dtype=torch.uint8, device=in0.device) if want_counts else None
     flags = _flag_bitmap(in0.device, lib.spk_den_fp6v2_flag_words(B, Cout, H, W))
-    check(lib.spk_den_conv3x3_mfma_fp6v2(_p(in0), nch, _p(wq), _p(scale), _p(bias_d), _p(wl1), _p(w32), _p(bn_a), _p(bn_b),
+    check(lib.spk_den_conv3x3_mfma_fp6v2(_p(in0), nch, _p(wq), _p(scale), _p(bias_d), _p(wl1), _p(qtab), _p(bn_a), _p(bn_b),
                                          _p(out), _p(cnt), _p(flags), T, B, H, W, Cout, _n_dyn(), _stream(in0)),
           "spk_den_conv3x3_mfma_fp6v2")
     return (out, cnt) if want_counts else out
