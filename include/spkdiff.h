@@ -288,6 +288,15 @@ int spk_psample_step(const float* logits_bkhw, long long* x_t_inout, uint8_t* un
                      long long* x0_hat_out_or_null, int B, int HW, int K, const int* active_or_null,
                      const int* n_active_or_null, spk_stream_t stream);
 
+/* ---- spike counts (syops report) -------------------------------------------------------------------------------- */
+/* Spikes in a tensor the library emitted, all time steps and time step 0 alone -- the firing rates R/syops/ops.py:14-24
+ * (`spike_rate`) and :69-75 (the LIF hook reads output[0]) feed into the ACs / MACs report.  The tensor is read as
+ * n_words u32 words; word w belongs to time step (w / inner_words) % T.  kind 0: u8 {0,1} bytes (PTC / CPTC), 1: fp4
+ * nibbles (C4 / S32), 2: fp32 ([T][N]).  out3 (device, 3 x u64): spikes, spikes at t = 0, fp32 words equal to 1.0f (kind 2:
+ * nonzero == ones  <=>  the tensor is binary). */
+int spk_count_spikes(const void* data, long long n_words, long long inner_words, int T, int kind, unsigned long long* out3,
+                     spk_stream_t stream);
+
 /* ---- measurement aid ------------------------------------------------------------------------------------------ */
 /* Shader clock this device holds under a block-scaled fp6 x fp4 MFMA load (bench.py records it next to every
  * matrix-core number: devices of one pool differ by ~10 %).  nblocks workgroups of 256 threads issue 4*iters MFMAs per

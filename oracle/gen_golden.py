@@ -14,6 +14,8 @@ F4 decode glue, F5 denoiser, F6 p_sample + RNG-order trajectory, F7 BN eval,
 F8 LIF training forward + surrogate-gradient BPTT (next-row scope),
 F9 one diffusion training step (q_sample + denoiser in train() mode + reweighted-ELBO loss + backward),
 F10 one VQ-VAE training step (SNN_VQVAE in train() mode: VQ / commitment / PSP / reconstruction losses + backward),
+F11 the reference's syops report (R/syops) on both models, as shipped and with its conv / bn hooks registered for the
+spikingjelly layer types,
 F12 get_data_for_diff over three batches (membrane state carried from batch to batch, as the reference does),
 F13 the benchmark's own length end to end: 100 reverse steps (B = 8) + decode to uint8 by the real reference.
 
@@ -535,6 +537,58 @@ def main():
                         weights_crc_den=synth.state_checksum(sdd), weights_crc_vae=synth.state_checksum(sdv))
     print("F13 ok: 100 reverse steps x 8 samples + decode; tokens", tok13.flatten()[:10].tolist(),
           "codes used", int(tok13.unique().numel()))
+    # ------------------------------------------------------------------ F11 syops report (R/syops on the reference models)
+    # SURVEY.md §8f item 4.  R/syops/engine.py hooks every module whose EXACT type is in its mapping (R/syops/engine.py:332-335):
+    # of the model's modules only neuron.LIFNode qualifies as shipped (the spikingjelly layer.* classes are subclasses of the
+    # torch.nn types in the mapping, not those types), so the default report counts the LIF layers only.  The second report
+    # registers the reference's own conv / bn hooks for the spikingjelly layer types through its custom_modules_hooks
+    # argument.  Per-module [overall, ACs, MACs, rate%] and the model totals are stored, for SNN_VQVAE and DummyModel.
+    import syops.engine as seng
+    import syops.ops as sops
+    def syops_report(model, kwargs, custom):
+        seng.CUSTOM_MODULES_MAPPING = custom
+        m = seng.add_syops_counting_methods(model)
+        m.eval()
+        m.start_syops_count(ost=open(os.devnull, "w"), verbose=False, ignore_list=[])
+        with torch.no_grad():
+            m(**kwargs)
+        functional.reset_net(m)
+        per = {name: np.array(mod.__syops__, dtype=np.float64) for name, mod in m.named_modules()
+               if seng.is_supported_instance(mod)}
+        total, params = m.compute_average_syops_cost()
+        bc, tc = m.__batch_counter__, m.__times_counter__
+        m.stop_syops_count()
+        seng.CUSTOM_MODULES_MAPPING = {}
+        return per, np.array(total, dtype=np.float64), int(params), int(bc), int(tc)
+    custom11 = {vm.layer.Conv2d: sops.conv_syops_counter_hook, vm.layer.ConvTranspose2d: sops.conv_syops_counter_hook,
+                vm.layer.BatchNorm2d: sops.bn_syops_counter_hook}
+    g = torch.Generator().manual_seed(1111)
+    img11 = torch.rand(3, 1, 28, 28, generator=g) - 0.5
+    kw_vae = {"x": img11.unsqueeze(0).repeat(16, 1, 1, 1, 1), "image": img11}
+    xt11 = torch.randint(0, 128, (3, 1, 7, 7), generator=g)
+    xt11[torch.rand(3, 1, 7, 7, generator=g) < 0.5] = 128
+    t11 = torch.tensor([70, 30, 4], dtype=torch.long)
+    kw_den = {"x": xt11.float(), "t": t11}
+    m11 = vm.SNN_VQVAE(1, 16, 128, torch.tensor(1.0))
+    vm.functional.set_step_mode(net=m11, step_mode="m")
+    m11.load_state_dict(sdv)
+    d11 = vd.DummyModel(1, 128)
+    functional.set_step_mode(net=d11, step_mode="m")
+    d11.load_state_dict(sdd)
+    save11 = {"images": img11.numpy(), "x_t": xt11.numpy(), "t": t11.numpy(),
+              "weights_crc_vae": synth.state_checksum(sdv), "weights_crc_den": synth.state_checksum(sdd)}
+    for mname, mod, kw in (("vae", m11, kw_vae), ("den", d11, kw_den)):
+        for cname, custom in (("default", {}), ("custom", custom11)):
+            per, total, params, bc, tc = syops_report(mod, kw, custom)
+            key = f"{mname}_{cname}"
+            save11[key + "_names"] = np.array(list(per))
+            save11[key + "_per"] = np.stack(list(per.values())) if per else np.zeros((0, 4))
+            save11[key + "_total"] = total
+            save11[key + "_params"] = params
+            save11[key + "_batch_counter"] = bc
+            print(f"F11 {key}: {len(per)} hooked modules, total [overall, ACs, MACs, rate%] = {total.tolist()}, params {params}, "
+                  f"batch counter {bc}")
+    np.savez_compressed(os.path.join(OUT, "f11_syops.npz"), **save11)
     print("all fixtures written to", OUT)
 
 

@@ -19,7 +19,7 @@ from spikingjelly.activation_based import neuron, functional, layer, surrogate, 
 from spikingjelly import visualizing  # noqa: F401
 
 from spkdiff import ops
-from spkdiff.fused import FusedSequential
+from spkdiff.fused import FusedSequential, has_hooks
 from spkdiff.ops import IN_PTC, IN_SEQ, IN_TINV
 
 from .snn_layers import *  # noqa: F401,F403
@@ -65,6 +65,8 @@ class VectorQuantizer(nn.Module):
             return self._train_forward(x)
         T = x.shape[0]
         idx, zq = self._quantize_ptc(ops.spikes_to_ptc(x))
+        if has_hooks(self.poisson):                   # hooks on the spike generator's layers: run it child by child
+            return self.poisson(torch.unsqueeze(zq, dim=0).repeat(T, 1, 1, 1, 1)), idx
         quantized = self._spike_generator(zq, T)['f32']
         return quantized, idx
 
@@ -187,7 +189,7 @@ class SNN_VQVAE(nn.Module):
         T = x.shape[0]
         enc = self.encoder.snn_convs
         dec = self.decoder.snn_convs
-        if enc._fusable(enc._blocks()) and dec._fusable(dec._blocks()) and T <= ops.MAX_T:
+        if enc._fusable(enc._blocks()) and dec._fusable(dec._blocks()) and T <= ops.MAX_T and not has_hooks(self):
             # end-to-end fused: spikes stay u8 PTC between encoder, VQ, spike generator and decoder
             z_ptc = enc.run(x, IN_SEQ, final='ptc')['ptc']
             idx, zq = self.vq_layer._quantize_ptc(z_ptc)

@@ -18,7 +18,7 @@ from spikingjelly.activation_based import neuron, functional, layer, surrogate, 
 from spikingjelly import visualizing  # noqa: F401
 
 from spkdiff import ops
-from spkdiff.fused import FusedSequential, invalidate_derived
+from spkdiff.fused import FusedSequential, invalidate_derived, has_hooks
 from spkdiff.ops import IN_PTC, IN_TINV
 
 from .vae_model import *  # noqa: F401,F403  (R/snn_model/vq_diffusion.py:21)
@@ -393,7 +393,19 @@ class DummyModel(nn.Module):
                                       'needs autograd enabled; call .eval() for inference')
         if not self._fused_ok():
             raise RuntimeError('spkdiff: DummyModel needs functional.set_step_mode(net, "m") and .eval()')
+        if has_hooks(self):
+            return self._run_modules(x, t)
         return self._run(ops.den_build_input(x, t), stateful=True)
+
+    def _run_modules(self, x, t):
+        """The reference's forward (R/snn_model/vq_diffusion.py:189-208) module by module -- each child a HIP kernel, fp32
+        [T,B,C,H,W] tensors in between -- so that forward hooks registered on the children fire."""
+        T = self.n_steps
+        h = ops.den_build_input(x, t).unsqueeze(0).repeat(T, 1, 1, 1, 1)
+        x1 = self.conv1(h)
+        x5 = self.conv5(self.conv4(self.conv3(self.conv2(x1))))
+        x6 = self.conv6(torch.cat((x5, x1), dim=2))
+        return torch.sum(x6, dim=0) / T
 
     @torch.no_grad()
     def logits_from_tokens(self, x_t, t: int, record=None):

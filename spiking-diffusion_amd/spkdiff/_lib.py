@@ -89,6 +89,7 @@ _SIGS = {
     "spk_psample_step": (c_int, [P, P, P, c_int, c_float, P, P, c_ulonglong, c_ulonglong, P, P, c_int, c_int, c_int,
                                  P, P, P]),
     "spk_clock_probe": (c_int, [P, c_int, c_int, P]),
+    "spk_count_spikes": (c_int, [P, c_longlong, c_longlong, c_int, c_int, P, P]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -89,6 +89,13 @@ def _is_conv(m):
     return isinstance(m, (layer.Conv2d, layer.ConvTranspose2d))
 
 
+def has_hooks(module):
+    """True if a forward (pre-)hook is registered anywhere below ``module``.  Fused launches bypass the children's
+    ``__call__``; with hooks present (the reference's syops counter, monitors) containers run child by child instead -- every
+    child is still a HIP kernel, and every hook sees the [T,B,C,H,W] tensors it would see in the reference."""
+    return any(m._forward_hooks or m._forward_pre_hooks for m in module.modules())
+
+
 def invalidate_derived(module):
     """Drop every cached derived form of the parameters below ``module``: packed convolution weights (fp32 / int8 /
     fp6 digit planes), folded BatchNorm terms, captured sampler graphs.  The caches are keyed by ``(data_ptr,
@@ -202,7 +209,7 @@ class FusedSequential(nn.Sequential):
         blocks = self._blocks()
         if self._trainable_fused(blocks, x):
             return self.train_forward(x)
-        if not self._fusable(blocks) or x.dim() != 5 or x.shape[0] > ops.MAX_T:
+        if not self._fusable(blocks) or x.dim() != 5 or x.shape[0] > ops.MAX_T or has_hooks(self):
             for m in self:                      # layer by layer: still HIP kernels, just not fused
                 x = m(x)
             return x

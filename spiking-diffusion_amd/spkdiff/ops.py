@@ -491,6 +491,33 @@ def ptc_to_spikes(p):
     return o
 
 
+def count_spikes(t: torch.Tensor):
+    """Spike statistics of a tensor in any storage format of this library, counted on the device (spk_count_spikes):
+    dict(total, t0, numel, numel_t0, binary).  fp32 [T, ...] (the reference interface; ``binary`` = every nonzero entry is
+    exactly 1.0), u8 PTC [B,H,W,T,C] / CPTC [B,C/ch,H,W,T,ch], int8-tagged C4 / S32 [B,C/rec_ch,H,W,T,rec]."""
+    if not t.is_cuda:
+        raise RuntimeError(f"spkdiff: tensor on '{t.device}'; there is no CPU path")
+    t = t if t.is_contiguous() else t.contiguous()
+    out = torch.empty(3, dtype=torch.int64, device=t.device)
+    if t.dtype == torch.float32:
+        T = int(t.shape[0])
+        n = t.numel()
+        inner, kind, numel = n // T, 2, n
+    elif t.dtype == torch.uint8:
+        T, rec = int(t.shape[-2]), int(t.shape[-1])
+        if rec % 4:
+            raise NotImplementedError("count_spikes: PTC records must be a multiple of 4 bytes")
+        n, inner, kind, numel = t.numel() // 4, rec // 4, 0, t.numel()
+    elif t.dtype == C4_DTYPE:
+        T, rec = int(t.shape[-2]), int(t.shape[-1])
+        n, inner, kind, numel = t.numel() // 4, rec // 4, 1, t.numel() * 2
+    else:
+        raise NotImplementedError(t.dtype)
+    check(lib.spk_count_spikes(_p(t), n, inner, T, kind, _p(out), _stream(t)), "spk_count_spikes")
+    tot, t0, ones = (int(v) for v in out.tolist())
+    return {"total": tot, "t0": t0, "numel": numel, "numel_t0": numel // T, "binary": kind != 2 or tot == ones}
+
+
 # ---------------------------------------------------------------------------------------------- fused conv
 def pack_conv_weight(w, transposed):
     w = _dev(w.detach(), "weight", torch.float32)

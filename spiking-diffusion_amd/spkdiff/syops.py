@@ -3,8 +3,9 @@
 convolution ``overall = (k*k*Cin*Cout + Cout) * T*B*H*W``; a layer whose input is binary spikes performs
 ``overall * input_spike_rate`` accumulates (ACs), any other layer ``overall`` multiply-accumulates (MACs).
 
-The spike rates come from the tensors the fused kernels already produce (the per-layer spike maps of a recorded call),
-so the report costs one extra read of them; SURVEY.md §8(f) item 4.
+The spike rates come from the packed spike maps the fused kernels already produce (a recorded call), counted on the
+device by ``spk_count_spikes`` without unpacking them; SURVEY.md §8(f) item 4.  This is the fused fast path for the
+denoiser; the whole-model report with the reference's entry point and per-module conventions is the ``syops`` package.
 """
 from __future__ import annotations
 
@@ -14,7 +15,8 @@ from . import ops
 
 
 def _rate(spikes_any_layout) -> float:
-    return float(ops.ptc_to_spikes(spikes_any_layout).mean())
+    st = ops.count_spikes(spikes_any_layout)
+    return st["total"] / st["numel"]
 
 
 @torch.no_grad()

@@ -1362,6 +1362,52 @@ def test_syops_report_matches_golden_spike_rates(golden_dir, dev):
     assert rep[-1]["layer"] == "total" and rep[-1]["acs"] < 0.2 * rep[-1]["overall"]
 
 
+def test_f11_syops_report_vs_reference_fixture(golden_dir, dev):
+    """SURVEY §8f item 4, whole models: ``syops.get_model_complexity_info`` (the reference's entry point, R/main.py:325-338)
+    on SNN_VQVAE and DummyModel against F11 = what the REAL R/syops produced on the reference models -- as shipped (its
+    exact-type mapping only hooks the LIF layers) and with its conv / bn hooks registered for the spikingjelly layer types
+    through custom_modules_hooks.  Per-module [overall, ACs, MACs, rate %], totals and parameter counts; the firing rates
+    are counted on the device (spk_count_spikes)."""
+    import io
+    import syops.engine as seng
+    import syops.ops as sops
+    from syops import get_model_complexity_info
+    from spikingjelly.activation_based import layer
+    d = load(golden_dir, "f11_syops.npz")
+    model, sdv = build_vae(synth.MNIST, dev)
+    den, sdd = build_den(synth.MNIST, dev)
+    assert synth.state_checksum(sdv) == str(d["weights_crc_vae"]) and synth.state_checksum(sdd) == str(d["weights_crc_den"])
+    img = torch.from_numpy(d["images"]).to(dev)
+    kw = {"vae": {"x": img.unsqueeze(0).repeat(16, 1, 1, 1, 1), "image": img},
+          "den": {"x": torch.from_numpy(d["x_t"]).float().to(dev), "t": torch.from_numpy(d["t"]).to(dev)}}
+    custom = {layer.Conv2d: sops.conv_syops_counter_hook, layer.ConvTranspose2d: sops.conv_syops_counter_hook,
+              layer.BatchNorm2d: sops.bn_syops_counter_hook}
+    worst = 0.0
+    for mname, mod in (("vae", model), ("den", den)):
+        for cname, cm in (("default", {}), ("custom", custom)):
+            key = f"{mname}_{cname}"
+            total, params = get_model_complexity_info(mod, (1, 28, 28), None, print_per_layer_stat=True, as_strings=False,
+                                                      input_constructor=lambda res, k=kw[mname]: k, ost=io.StringIO(),
+                                                      custom_modules_hooks=cm)
+            per = seng.get_syops_pytorch.last_per_module
+            assert list(per) == [str(n) for n in d[key + "_names"]], key
+            got = np.stack(list(per.values()))
+            want = d[key + "_per"]
+            assert np.array_equal(got[:, 0], want[:, 0]) and np.array_equal(got[:, 2], want[:, 2]), key   # op counts: exact
+            rel = np.abs(got - want) / (np.abs(want) + 1e-30)
+            worst = max(worst, float(rel[want != 0].max()))
+            assert float(rel[want != 0].max()) <= 1e-6, (key, float(rel.max()))                            # rates: fp32 vs count
+            assert np.allclose(total, d[key + "_total"], rtol=1e-6, atol=0) and params == int(d[key + "_params"])
+    strings, pstr = get_model_complexity_info(den, (1, 28, 28), None, print_per_layer_stat=False, as_strings=True,
+                                              input_constructor=lambda res: kw["den"], custom_modules_hooks=custom)
+    assert strings[1].endswith(" G Ops") and pstr == "3.1 M"
+    # no hook is left behind: the next call is fused again and gives the fused path's logits
+    from spkdiff.fused import has_hooks
+    assert not has_hooks(den) and not has_hooks(model)
+    parity("f11_syops_report", modules_compared=int(sum(len(d[k]) for k in d.files if k.endswith("_names"))),
+           worst_relative_difference=worst)
+
+
 def test_sampler_trajectory_vs_live_oracle_12_steps(dev):
     """12 reverse steps, B=8, noise drawn on the host in the reference's order under the same torch.manual_seed:
     the HIP sampler must reproduce the CPU oracle's tokens (the oracle is bit-identical to the reference, F6)."""
