@@ -371,8 +371,13 @@ __device__ __forceinline__ void gather2_body(const GArgs& a, int b, int g, int p
   }
 }
 
-template <int MODE, int KS, int S, bool TR, int NCH>
-__global__ __launch_bounds__(256) void conv_mfma_gather2_kernel(GArgs a) {
+// OCC = waves per SIMD the register allocation must leave room for.  The kernel hides L2 latency by occupancy alone, and the
+// "request everything first" body of the larger geometries sits at 200-220 registers (2 waves per SIMD); asking for 3 makes
+// hipcc pack accumulators and fragments into 167 without spilling where the tap list is short enough (decoder convT1 /
+// convT2, encoder conv3: 0.745 -> 0.604 ms, 0.248 -> 0.215 ms at B = 1024), and spills where it is not (encoder conv2,
+// decoder convT3: those keep 2).
+template <int MODE, int KS, int S, bool TR, int NCH, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_mfma_gather2_kernel(GArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int NCLS = TR ? S * S : 1;
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(256) void conv_mfma_gather2_kernel(GArgs a) {
   }
 }
 
-template <int MODE, int KS, int S, bool TR, int NCH>
+template <int MODE, int KS, int S, bool TR, int NCH, int OCC = 2>
 int launch_gather2(const GArgs& a, hipStream_t stream) {
   constexpr int NCLS = TR ? S * S : 1;
   const int Hc0 = TR ? (a.Ho + S - 1) / S : a.Ho, Wc0 = TR ? (a.Wo + S - 1) / S : a.Wo;
@@ -400,7 +405,7 @@ int launch_gather2(const GArgs& a, hipStream_t stream) {
   const long long by = (long long)a.B * NCLS;
   if (by > 65535) return SPK_ERR_UNSUPPORTED;
   dim3 grid((groups * G + 3) / 4, (unsigned)by), blk(256);
-  hipLaunchKernelGGL((conv_mfma_gather2_kernel<MODE, KS, S, TR, NCH>), grid, blk, 0, stream, a);
+  hipLaunchKernelGGL((conv_mfma_gather2_kernel<MODE, KS, S, TR, NCH, OCC>), grid, blk, 0, stream, a);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }
@@ -411,9 +416,9 @@ int dispatch_gather2(const GArgs& a, hipStream_t stream) {
   const int nch = (a.Cin + 31) / 32;
   if (a.pad != a.k / 2 || a.B > 16000) return SPK_ERR_UNSUPPORTED;
   if (!a.transposed && a.k == 3 && a.stride == 2 && nch == 1) return launch_gather2<MODE, 3, 2, false, 1>(a, stream);   // enc conv2
-  if (!a.transposed && a.k == 1 && a.stride == 1 && nch == 2) return launch_gather2<MODE, 1, 1, false, 2>(a, stream);   // enc conv3
-  if (a.transposed && a.k == 3 && a.stride == 2 && nch == 1) return launch_gather2<MODE, 3, 2, true, 1>(a, stream);     // dec convT1
-  if (a.transposed && a.k == 3 && a.stride == 2 && nch == 2) return launch_gather2<MODE, 3, 2, true, 2>(a, stream);     // dec convT2
+  if (!a.transposed && a.k == 1 && a.stride == 1 && nch == 2) return launch_gather2<MODE, 1, 1, false, 2, 3>(a, stream);   // enc conv3
+  if (a.transposed && a.k == 3 && a.stride == 2 && nch == 1) return launch_gather2<MODE, 3, 2, true, 1, 3>(a, stream);     // dec convT1
+  if (a.transposed && a.k == 3 && a.stride == 2 && nch == 2) return launch_gather2<MODE, 3, 2, true, 2, 3>(a, stream);     // dec convT2
   if (a.transposed && a.k == 3 && a.stride == 1 && nch == 1) return launch_gather2<MODE, 3, 1, true, 1>(a, stream);     // dec convT3
   return SPK_ERR_UNSUPPORTED;
 }
