@@ -16,7 +16,7 @@
 // Spike tensors between fused layers are u8 {0,1} in "PTC" layout [B][H][W][T][C] (position, time, channel):
 // the T steps of one neuron's inputs are adjacent, and channels are the unit-stride dimension that both the
 // direct kernels (lanes = output channels) and the MFMA kernel (K = taps x channels) read as 4..16 B vectors.
-#include "spk_common.h"
+#include "den_common.h"
 #include "../../include/spkdiff.h"
 #include <math.h>
 
@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256) void conv_fused_kernel(FusedArgs a) {
       float v = a.v_io ? a.v_io[o_bchw] : 0.0f;
       float y0 = 0.f;
       int nspk = 0;
+      unsigned mybits = 0;
       if constexpr (TINV) {
         y0 = fmaf((float)acc[0], al, be);
         if (a.out_pre) a.out_pre[o_bchw] = y0;
@@ -221,15 +222,32 @@ __global__ __launch_bounds__(256) void conv_fused_kernel(FusedArgs a) {
           const bool s = spk_lif_step_default(v, y);
           nspk += s ? 1 : 0;
           if (a.out_c4) {
-            // channels (co, co ^ 1) are neighbouring lanes: the even one stores both e2m1 nibbles (0x2 = 1.0)
-            const int so = __shfl_xor((int)s, 1);
-            if (!(co & 1))
-              a.out_ptc[((((long long)b * (a.Cout / a.out_c4) + (co / a.out_c4)) * plane + oy * a.Wo + ox) * T + t) * (a.out_c4 >> 1) +
-                        ((co % a.out_c4) >> 1)] = (uint8_t)((s ? 0x02 : 0) | (so ? 0x20 : 0));
+            mybits |= s ? (1u << t) : 0u;                  // stored after the scan (below)
           } else if (a.out_ptc) {
             a.out_ptc[o_ptc + (long long)t * a.chunk_out] = (uint8_t)s;
           }
           if (a.out_f32) a.out_f32[o_bchw + t * tstride] = s ? 1.0f : 0.0f;
+        }
+      }
+      if (a.out_c4) {
+        // nibble-packed fp4 output: lanes are consecutive output channels (Cout % 16 == 0, so the 16 lanes of a DPP row
+        // are 16 channels of ONE position); a 16x16 bit transpose per row gives lane t the 16 channel bits of step t =
+        // 8 bytes of the (position, t) record -- one 8-byte store per lane instead of a byte store per channel pair and step
+        const unsigned bitsv = spk_transpose16_rows(mybits, (int)(threadIdx.x & 63));
+        const int tl = (int)(threadIdx.x & 15), co16 = co & ~15;
+        if (tl < T) {
+          auto spread8 = [](unsigned x) -> unsigned {        // bit k -> nibble k, as the e2m1 code of 1.0 (0x2)
+            x = (x | (x << 12)) & 0x000f000fu;
+            x = (x | (x << 6)) & 0x03030303u;
+            x = (x | (x << 3)) & 0x11111111u;
+            return x << 1;
+          };
+          uint2 o;
+          o.x = spread8(bitsv & 0xffu);
+          o.y = spread8((bitsv >> 8) & 0xffu);
+          uint8_t* dst = a.out_ptc + ((((long long)b * (a.Cout / a.out_c4) + (co16 / a.out_c4)) * plane + oy * a.Wo + ox) * T + tl) *
+                                         (a.out_c4 >> 1) + ((co16 % a.out_c4) >> 1);
+          *reinterpret_cast<uint2*>(dst) = o;
         }
       }
       if (a.v_io) a.v_io[o_bchw] = v;

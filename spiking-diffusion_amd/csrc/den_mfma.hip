@@ -364,8 +364,10 @@ __global__ __launch_bounds__(256) void conv3x3_counts_mfma_kernel(CntArgs a) {
     for (int tap = 0; tap < 9; ++tap) {
       const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
       const bool ok = rvalid && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-      v4i av = {0, 0, 0, 0};
-      if (ok) av = *reinterpret_cast<const v4i*>(src + (long long)(yy * a.W + xx) * CK + 16 * half);
+      // unconditional load from a clamped address + select: a load under a per-lane condition makes hipcc branch around
+      // it and drain vmcnt(0) per tap, which serialises the nine gathers of a chunk (36 -> 2x faster launch)
+      const v4i ld = *reinterpret_cast<const v4i*>(src + (ok ? (long long)(yy * a.W + xx) * CK + 16 * half : 0));
+      const v4i av = ok ? ld : (v4i){0, 0, 0, 0};
       const v4i b0 = *reinterpret_cast<const v4i*>(wsrc + (tap * 2 + 0) * 32 * CK);
       const v4i b1 = *reinterpret_cast<const v4i*>(wsrc + (tap * 2 + 1) * 32 * CK);
       acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b0, acc0, 0, 0, 0);
