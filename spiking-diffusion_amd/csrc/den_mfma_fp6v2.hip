@@ -139,20 +139,28 @@ __device__ __forceinline__ void store_tile_spikes(uint8_t* out, uint8_t* out_cnt
 // NWV = waves per workgroup: 4 (one per SIMD, 6 row tiles each at 7x7, 512 registers) or 8 (two per SIMD, 3 row tiles
 // each, 256 registers: the partner wave's MFMAs run under this wave's copy issue, fragment waits and epilogue, and two
 // waves scanning at once get the SIMD's full vector rate).  Same item, LDS plan and DMA volume either way.
-template <int H, int W, int NWV>
+// SPLIT (latents too large for one item, 8x8): an item is one of the two ROW BANDS of an image -- H / 2 output rows, H / 2 + 1
+// input rows (one halo row from the other band).  Both bands sit in LDS rows 1 .. H/2 + 1 of a padded image whose rows 0 and
+// H/2 + 2 stay zero; the top band's outputs are centred on LDS rows 1.., the bottom band's on rows 2.. (one row offset added
+// to the fragment addresses per item).  An even position count needs no last-position launch.
+template <int H, int W, int NWV, bool SPLIT = false>
 __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6v2_kernel(V2Args a) {
   constexpr int HW = H * W, PW = W + 1;
-  static_assert((HW & 1) == 1 && ((HW / 2) % NWV) == 0, "an odd position count whose pairs fill whole tiles on every wave");
-  constexpr int NT = (HW / 2) / NWV;                   // row tiles per wave (7x7: 6 or 3)
-  constexpr int N_AGPR = NWV == 4 ? 16 : 8;            // (two waves per SIMD: hipcc splits 256 registers 128 / 128)
-  constexpr int NPP = (H + 2) * PW + 1;                // cells of the zero-bordered LDS image (pitch W + 1: the zero
+  constexpr int Hb = SPLIT ? H / 2 : H;                // output rows of an item
+  constexpr int Hin = SPLIT ? Hb + 1 : H;              // input rows staged per item
+  constexpr int HWb = Hb * W;                          // output positions of an item
+  static_assert(SPLIT ? ((H % 2) == 0 && (HWb % (2 * NWV)) == 0)
+                      : ((HW & 1) == 1 && ((HW / 2) % NWV) == 0), "whole 32-row tiles on every wave (+ one odd position)");
+  constexpr int NT = (HWb / 2) / NWV;                  // row tiles per wave (7x7: 6 or 3; 8x8 bands: 4)
+  constexpr int N_AGPR = NWV == 4 ? (3 * NT < 16 ? 3 * NT : 16) : 8;   // (two waves per SIMD: hipcc splits 256 registers 128 / 128)
+  constexpr int NPP = (Hin + 2) * PW + 1;              // cells of the zero-bordered LDS image (pitch W + 1: the zero
   constexpr int A_BYTES = NPP * POSB;                  //  column is shared by x = -1 of a row and x = W of the previous)
   constexpr int PPR = (W + 3) / 4;                     // DMA pieces per image row (4 positions per KiB piece)
-  constexpr int NA = H * PPR;
+  constexpr int NA = Hin * PPR;
   constexpr int NPA = (NA + NWV - 1) / NWV;            // A pieces per wave
   constexpr int NPW = (W_PIECES + NWV - 1) / NWV;      // W pieces per wave
   constexpr int NS_PAIR = 9 * NT, NSTEP = NS_PAIR + N_D4 * NT;
-  static_assert(NWV == 8 || (NT * 3 > N_AGPR && (NT - 1) * 3 <= N_AGPR + 2), "the last tile straddles the register files");
+  static_assert(NWV == 8 || 3 * NT <= 16 || (NT - 1) * 3 <= N_AGPR + 2, "only the last tile may straddle the register files");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   uint8_t* const sA = lds;
   uint8_t* const sW = lds + 2 * A_BYTES;
@@ -227,7 +235,12 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6v2_kernel(V2Args a) {
     }
   };
   const uint8_t* const wbase = a.wq + (long long)g * nch * W_SLAB;
-  auto aslab_of = [&](int b, int c) -> const uint8_t* { return a.in0 + ((long long)b * nch + c) * HW * POSB; };
+  // item index -> (image, band); the slab of a band starts (H/2 - 1) rows into the image for the bottom band
+  auto aslab_of = [&](int itm, int c) -> const uint8_t* {
+    const int b = SPLIT ? itm >> 1 : itm, band = SPLIT ? itm & 1 : 0;
+    return a.in0 + ((long long)b * nch + c) * HW * POSB + band * (Hb - 1) * W * POSB;
+  };
+  const int nitems = SPLIT ? 2 * Bn : Bn;
 
   // per-channel constants (the group is fixed: loaded once)
   const int co = g * 32 + (lane & 31);
@@ -244,28 +257,30 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6v2_kernel(V2Args a) {
   unsigned long long dbg_c0 = 0, dbg_r0 = 0;
   if (SPK_V2_DBG & 128) { dbg_c0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
   int it = 0;                                             // running chunk counter: LDS buffer = it & 1
-  if (il < Bn) {
+  if (il < nitems) {
     const uint8_t* as0 = aslab_of(il, 0);
 #pragma unroll
     for (int q = 0; q < NPA + NPW; ++q) issue_piece(q, as0, wbase, sA_addr, sW_addr);
   }
-  for (int b = il; b < Bn; b += lanes) {
+  for (int itm = il; itm < nitems; itm += lanes) {
+    const int b = SPLIT ? itm >> 1 : itm, band = SPLIT ? itm & 1 : 0;
+    const int band_off = band * PW * POSB;                // bottom band: fragment addresses one LDS row further down
     v16f acc[NT][3];      // [i][0]: pair 01, [i][1]: pair 23, [i][2]: fifth digit; written (not accumulated) by the first MFMA
     for (int c = 0; c < nch; ++c, ++it) {
       const int buf = it & 1;
       spk_dma_wait_all();  // this wave's share of the chunk's DMA has landed ...
       __syncthreads();     // ... and so has everyone else's; everyone is done with the other buffer
-      int nb = b, nc = c + 1;
-      if (nc == nch) { nc = 0; nb = b + lanes; }
-      const bool have_next = nb < Bn;                     // otherwise the last chunk is copied once more (never read)
-      const uint8_t* n_aslab = aslab_of(have_next ? nb : b, have_next ? nc : c);
+      int nb = itm, nc = c + 1;
+      if (nc == nch) { nc = 0; nb = itm + lanes; }
+      const bool have_next = nb < nitems;                 // otherwise the last chunk is copied once more (never read)
+      const uint8_t* n_aslab = aslab_of(have_next ? nb : itm, have_next ? nc : c);
       const uint8_t* n_wslab = wbase + (long long)(have_next ? nc : c) * W_SLAB;
       const unsigned n_dA = sA_addr + (buf ^ 1) * A_BYTES;
       const unsigned n_dW = sW_addr + (buf ^ 1) * W_LDS;
 
       auto compute = [&](auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
-        const uint8_t* A = sA + buf * A_BYTES;
+        const uint8_t* A = sA + buf * A_BYTES + band_off;
         const uint8_t* Wb = sW + buf * W_LDS;
         auto toff = [](int tap) constexpr -> int { return ((tap / 3) * PW + (tap % 3)) * POSB; };
         // Step order: blocks of NT steps (one per row tile) -- tap 0, tap 1, D(0), tap 2, tap 3, D(1), ..., tap 8, D(4), where a
@@ -401,7 +416,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6v2_kernel(V2Args a) {
         mybits |= s ? (1u << r) : 0u;
       }
       const int ti = wave + NWV * i;
-      const int p = 2 * ti + half;                        // accumulator lane half == position within the tile
+      const int p = 2 * ti + half + band * HWb;           // accumulator lane half == position within the tile
       if (flg && !(SPK_V2_DBG & 32)) {
         const long long n = ((long long)b * a.Cout + co) * HW + p;
         const unsigned idx = atomicAdd(a.flags, 1u);
@@ -608,6 +623,10 @@ __global__ __launch_bounds__(1024) void fp6v2_fixup_kernel(V2Args a, long long n
   }
 }   // (the flag counter is reset by the last-position launch that follows on the stream)
 
+__global__ void fp6v2_reset_kernel(unsigned* flags) {
+  if (threadIdx.x == 0 && !(SPK_V2_DBG & 64)) flags[0] = 0u;
+}
+
 // ------------------------------------------------------------------------------------------------ weight packing
 // one block per output channel: channel maximum -> shift s, every weight -> six balanced radix-32 digits, written as the
 // per-lane 24-byte B fragments (lane = K half * 32 + channel within the group of 32; 32 six-bit codes, little-endian;
@@ -753,7 +772,8 @@ extern "C" int spk_den_conv3x3_mfma_fp6v2(const uint8_t* in_s32, int nch, const 
   if (!in_s32 || nch <= 0 || !wq || !scale || !bias_d || !wl1 || !qtab || !bn_a || !bn_b || !out_s32 || !flag_words ||
       B <= 0 || H <= 0 || W <= 0 || Cout <= 0)
     return SPK_ERR_ARG;
-  if (T != T16 || (Cout % 32) || H != 7 || W != 7) return SPK_ERR_UNSUPPORTED;
+  const bool bands = H == 8 && W == 8;
+  if (T != T16 || (Cout % 32) || !((H == 7 && W == 7) || bands)) return SPK_ERR_UNSUPPORTED;
   V2Args a;
   a.in0 = in_s32; a.nch = nch; a.wq = wq; a.scale = scale; a.bias = bias_d; a.wl1 = wl1; a.qtab = qtab;
   a.bn_a = bn_a; a.bn_b = bn_b; a.out = out_s32; a.out_cnt = out_counts; a.flags = flag_words; a.flag_cap = FLAG_CAP;
@@ -773,8 +793,20 @@ extern "C" int spk_den_conv3x3_mfma_fp6v2(const uint8_t* in_s32, int nch, const 
     if (G % gx == 0 && nsets <= 8 && 8 % nsets == 0 && S % gx == 0) { a.gx = gx; a.nsets = nsets; grid = cus; }
   }
   if (a.gx == 0) grid = cus >= G ? (cus / G) * G : G;         // flat walk: workgroup k -> group k % G
-  constexpr int A_BYTES = ((7 + 2) * 8 + 1) * POSB;
-  const size_t lds = 2 * ((size_t)A_BYTES + W_LDS);
+  const int a_bytes = bands ? ((8 / 2 + 1 + 2) * 9 + 1) * POSB : ((7 + 2) * 8 + 1) * POSB;
+  const size_t lds = 2 * ((size_t)a_bytes + W_LDS);
+  const long long n_words = ((long long)B * Cout * H * W + 31) / 32;
+  if (bands) {
+    hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 4, true>), dim3(grid), dim3(256), lds, stream, a);
+    SPK_LAUNCH_CHECK();
+    hipLaunchKernelGGL((fp6v2_fixup_kernel<8, 8>), dim3(cus), dim3(1024), 0, stream, a, n_words);
+    SPK_LAUNCH_CHECK();
+    // (no last-position launch on an even latent: a one-wave launch resets the flag counter; a memset node in its place
+    // made a captured reverse process several times slower)
+    hipLaunchKernelGGL(fp6v2_reset_kernel, dim3(1), dim3(64), 0, stream, flag_words);
+    SPK_LAUNCH_CHECK();
+    return SPK_OK;
+  }
   // Two waves per SIMD (SPKDIFF_V2_WAVES=8) need 9 % fewer cycles per MFMA (45.6 vs 50.2 on the conv4 shape) and take the
   // same time: the device lowers its clock by the same 9 % (1.94 vs 2.13 GHz in-kernel) -- the launch is bound by the
   // power the matrix pipe may draw, not by issue slots.  One wave per SIMD (no spills, simpler) stays the default.
@@ -782,7 +814,6 @@ extern "C" int spk_den_conv3x3_mfma_fp6v2(const uint8_t* in_s32, int nch, const 
   if (eight) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 8>), dim3(grid), dim3(512), lds, stream, a);
   else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 4>), dim3(grid), dim3(256), lds, stream, a);
   SPK_LAUNCH_CHECK();
-  const long long n_words = ((long long)B * Cout * H * W + 31) / 32;
   hipLaunchKernelGGL((fp6v2_fixup_kernel<7, 7>), dim3(cus), dim3(1024), 0, stream, a, n_words);
   SPK_LAUNCH_CHECK();
   const int n_lp = (((B + 1) / 2) * G + 3) / 4;

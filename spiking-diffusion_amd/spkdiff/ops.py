@@ -795,7 +795,8 @@ def c4_to_spikes(q):
 
 # ------------------------------------------------------------------------------- fp6v2: the sampler's denoiser convolutions
 def den_fp6v2_supported(Cout, Cin, k, stride, pad, T, H, W):
-    return k == 3 and stride == 1 and pad == 1 and T == 16 and H == 7 and W == 7 and Cout % 32 == 0 and Cin % 32 == 0
+    return (k == 3 and stride == 1 and pad == 1 and T == 16 and (H, W) in ((7, 7), (8, 8)) and Cout % 32 == 0 and
+            Cin % 32 == 0)
 
 
 def den_pack_weight_fp6v2(w, bias):

@@ -497,14 +497,14 @@ def test_f5_denoiser_mfma_fp6_kernel(golden_dir, dev, ops):
     assert not torch.equal(a1, a2), "second call starts from the carried membrane potentials"
 
 
-@pytest.mark.parametrize("B", [1, 5, 64])
-def test_fp6v2_kernel_bit_equal_to_the_exact_kernels(dev, ops, B):
+@pytest.mark.parametrize("B,hw", [(1, 7), (5, 7), (64, 7), (3, 8), (33, 8)])
+def test_fp6v2_kernel_bit_equal_to_the_exact_kernels(dev, ops, B, hw):
     """spk_den_conv3x3_mfma_fp6v2 (five digit planes with shared accumulators + certified spike decisions + exact
     recomputation of flagged neurons) against the first-generation fp6 kernel (six planes, fp64 recombination) on the four
     denoiser shapes with random spikes, weights and BatchNorm terms -- including large and negative BN scales, which widen
     the certification margins: spikes and spike counts must be bit-equal, and the flag bitmap must come back clean."""
     g = torch.Generator().manual_seed(1000 + B)
-    H = W = 7
+    H = W = hw                                         # 8x8: the row-band form (two items per image, no last-position launch)
     total = mism = 0
     for li, (Cout, Cin) in enumerate(((128, 64), (256, 128), (512, 256), (256, 512))):
         for trial, (wamp, aamp, rate) in enumerate(((0.05, 12.0, 0.06), (0.3, 3.0, 0.3))):
@@ -531,7 +531,7 @@ def test_fp6v2_kernel_bit_equal_to_the_exact_kernels(dev, ops, B):
     cap = 1 << 20                                  # id-list capacity (FLAG_CAP): [count, ticket, ids..., overflow bitmap]
     assert all(int(v[:2].abs().sum()) == 0 and int(v[2 + cap:].abs().sum()) == 0 for v in ops._FLAG_WORDS.values()), \
         "the fixup launch leaves counter, ticket and overflow bitmap clean"
-    parity(f"fp6v2_vs_fp6_B{B}", neuron_steps=total, spike_mismatches=mism)
+    parity(f"fp6v2_vs_fp6_B{B}_{hw}x{hw}", neuron_steps=total, spike_mismatches=mism)
 
 
 # ------------------------------------------------------------------------------------------------- F8 LIF training
@@ -1259,13 +1259,16 @@ def test_denoiser_mfma_vs_direct_b64_random_tokens(dev, req, name, v2):
     assert float((lm - ld).abs().max()) <= 2e-7
 
 
-@pytest.mark.parametrize("req,name,B", [("fp6", "mfma-fp6x6", 37), ("fp6", "mfma-fp6x6", 3), ("i8", "mfma-i8x4", 20)])
-def test_denoiser_8x8_latent_mfma_vs_direct(dev, req, name, B):
-    """8x8 latents (BASELINE config 4): the fp6 kernel in its row-band form (two items per image: H/2 output rows each,
-    one halo row) and the int8 kernel, against the fp64 direct path -- every layer's spikes bit-equal, logits within 2e-7;
-    B = 37 / 3: ragged and fewer-than-CUs band items."""
+@pytest.mark.parametrize("req,name,B,v2", [("fp6", "mfma-fp6v2", 37, True), ("fp6", "mfma-fp6v2", 3, True),
+                                           ("fp6", "mfma-fp6x6", 37, False), ("fp6", "mfma-fp6x6", 3, False),
+                                           ("i8", "mfma-i8x4", 20, True)])
+def test_denoiser_8x8_latent_mfma_vs_direct(dev, req, name, B, v2):
+    """8x8 latents (BASELINE config 4): the fp6 kernels (second and first generation) in their row-band form (two items per
+    image: H/2 output rows each, one halo row) and the int8 kernel, against the fp64 direct path -- every layer's spikes
+    bit-equal, logits within 2e-7; B = 37 / 3: ragged and fewer-than-CUs band items."""
     den, _ = build_den(synth.CIFAR, dev)
     den.conv_impl_request = req
+    den.use_fp6v2 = v2
     assert den.impl_for(8, 8) == name
     g = torch.Generator().manual_seed(321 + B)
     x_t = torch.randint(0, 128, (B, 1, 8, 8), generator=g)
