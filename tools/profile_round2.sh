@@ -16,3 +16,6 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_VMEM SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d $O/v2_sq2 -- python $R/tools/fp6v2_one.py 512 256 13 > $O/v2_sq2.log 2>&1
 ls -R $O | grep -c csv
 head -c 300 $O/bench_under_prof.json
+# a second trace of the headline measurement alone (per-layer table of profiles/README.md)
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_headline -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_headline_under_prof.json 2> $O/bench_headline_under_prof.err

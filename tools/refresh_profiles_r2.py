@@ -84,5 +84,7 @@ print(json.dumps(out["derived"], indent=1))
 for k, v in t.items():
     print(k, "->", round(v["hbm_bytes_per_launch_corrected"] / 1e6, 1), "MB per launch; algorithmic",
           round(v.get("algorithmic_bytes_per_launch", 0) / 1e6, 1), "MB")
-print(subprocess.run([sys.executable, os.path.join(R, "tools", "summarize_profile.py"), newest("trace/runc/*_kernel_trace.csv")],
-                     capture_output=True, text=True).stdout)
+shutil.copy(newest("trace_headline/runc/*_kernel_stats.csv"), os.path.join(O, "r2_bench_headline_kernel_stats.csv"))
+shutil.copy(os.path.join(P, "bench_headline_under_prof.json"), os.path.join(O, "r2_bench_headline_under_rocprof.json"))
+print(subprocess.run([sys.executable, os.path.join(R, "tools", "summarize_profile.py"),
+                      newest("trace_headline/runc/*_kernel_trace.csv")], capture_output=True, text=True).stdout)

@@ -11,6 +11,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 dur = defaultdict(list)
 k = 0
+layer = 0
 for r in rows:
     name = r["Kernel_Name"]
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
@@ -24,6 +25,14 @@ for r in rows:
     elif "conv3x3_fp6_kernel" in name:      # one symbol for conv2..conv5, in launch order
         name = f"conv3x3_fp6_kernel den.conv{2 + k % 4}"
         k += 1
+    elif "conv3x3_fp6v2_kernel" in name:    # second-generation kernel: same order; its two tail launches follow each one
+        name = f"conv3x3_fp6v2_kernel den.conv{2 + k % 4}"
+        layer = 2 + k % 4
+        k += 1
+    elif "fp6v2_fixup_kernel" in name:
+        name = f"fp6v2_fixup_kernel den.conv{layer}"
+    elif "fp6v2_lastpos_kernel" in name:
+        name = f"fp6v2_lastpos_kernel den.conv{layer}"
     elif "conv3x3_counts_mfma_kernel" in name:
         name = "conv3x3_counts_mfma_kernel den.conv6 (time-collapsed)"
     dur[name.replace("(anonymous namespace)::", "")[:90]].append(d)
