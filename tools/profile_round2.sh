@@ -18,4 +18,4 @@ ls -R $O | grep -c csv
 head -c 300 $O/bench_under_prof.json
 # a second trace of the headline measurement alone (per-layer table of profiles/README.md)
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_headline -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_headline_under_prof.json 2> $O/bench_headline_under_prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_headline -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --dense-only > $O/bench_headline_under_prof.json 2> $O/bench_headline_under_prof.err
