@@ -223,6 +223,15 @@ int spk_den_conv3x3_mfma_fp6v2(const uint8_t* in_s32, int nch, const uint8_t* wq
                                const float* wl1, const int* qtab, const float* bn_a, const float* bn_b, uint8_t* out_s32,
                                uint8_t* out_counts, unsigned* flag_words, int T, int B, int H, int W, int Cout,
                                const int* n_dyn_or_null, spk_stream_t stream);
+/* The same layer restricted to the positions the sampler will read (7x7 only): need = the buffer written by
+ * spk_select_needed(..., R = need_radii) for the same B; radius (1..need_radii) selects the lists this layer computes --
+ * 1 for the layer whose output the logits convolution reads, 2 for the one below it, ...  Listed positions (and the 49th)
+ * receive exactly the spikes of the full call; the other positions of out_s32 / out_counts are left as they were. */
+int spk_den_conv3x3_mfma_fp6v2_listed(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale,
+                                      const double* bias_d, const float* wl1, const int* qtab, const float* bn_a,
+                                      const float* bn_b, uint8_t* out_s32, uint8_t* out_counts, unsigned* flag_words, int T,
+                                      int B, int H, int W, int Cout, const int* n_dyn, const uint8_t* need, int need_radii,
+                                      int radius, spk_stream_t stream);
 /* fp32 spikes [T,B,C,HW] <-> S32 (C % 32 == 0): module boundaries and tests. */
 int spk_spikes_to_s32(const float* spikes, uint8_t* out_s32, int T, int B, int C, int HW, spk_stream_t stream);
 int spk_s32_to_spikes(const uint8_t* in_s32, float* spikes, int T, int B, int C, int HW, spk_stream_t stream);
@@ -271,6 +280,17 @@ int spk_embedding_fwd(const long long* tokens, const float* codebook, float* out
 int spk_select_active(const uint8_t* unmasked, int t, const float* u_or_null, unsigned long long philox_seed,
                       unsigned long long philox_offset, const unsigned long long* philox_state_or_null, int* active_out,
                       int* n_active_out, int B, int HW, spk_stream_t stream);
+/* Positions of the active images that reverse step t needs from each denoiser layer (same `changes` test as above, per
+ * position; R/snn_model/vq_diffusion.py:134-140 reads the denoiser output only there).  need_out: a ZERO-INITIALISED buffer of
+ * spk_select_needed_bytes(B, R) bytes (it stays consistent from call to call); for every radius r = 1..R it receives, per
+ * active slot, the positions within Chebyshev distance r of a change of image active[slot] -- what a stack of r 3x3
+ * convolutions below the logits has to provide (64-byte records: bytes 0..47 ascending positions below 48, padded with the
+ * last entry; byte 48 their number n; byte 49 ceil(n / 8); byte 50 whether position 48 is among them) -- and the slots
+ * grouped by ceil(n / 8), the form spk_den_conv3x3_mfma_fp6v2_listed walks.  7x7 latents, R <= 8. */
+long long spk_select_needed_bytes(int B, int R);
+int spk_select_needed(const uint8_t* unmasked, int t, const float* u_or_null, unsigned long long philox_seed,
+                      unsigned long long philox_offset, const unsigned long long* philox_state_or_null, const int* active,
+                      const int* n_active, uint8_t* need_out, int B, int H, int W, int R, spk_stream_t stream);
 /* cat(x, ones_like(x)*t) of DummyModel.forward, R/snn_model/vq_diffusion.py:195-197 -> fp32 [B,2,h,w].
  * active / n_active (both or neither): slot s of the output is image active[s], s < *n_active. */
 int spk_den_build_input(const float* x_float_or_null, const long long* x_tokens_or_null, const long long* t_vec_or_null,

@@ -69,3 +69,15 @@ __device__ __forceinline__ void spk_dma16s_masked(const void* sbase, unsigned vo
 }
 __device__ __forceinline__ void spk_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned spk_lds_addr(const void* p) { return (unsigned)(size_t)SPK_LDS(p); }
+
+// Layout of the position-list buffer written by spk_select_needed (psample.hip) and read by the listed form of the fp6v2
+// kernel, for B image slots and R radii.  Bytes: [0, 64) header (u32 ticket of the list-building pass); per radius 16 int32
+// (slots per tile-count class 1..6); per radius 6 x B int32 (the slots of each class); per radius B 64-byte records.
+__host__ __device__ inline long long spk_need_off_cnt(int r) { return 64 + (long long)r * 64; }
+__host__ __device__ inline long long spk_need_off_list(int B, int R, int r) {
+  return 64 + (long long)R * 64 + (long long)r * 6 * B * 4;
+}
+__host__ __device__ inline long long spk_need_off_rec(int B, int R, int r) {
+  const long long lists = 64 + (long long)R * 64 + (long long)R * 6 * B * 4;
+  return (lists + 63) / 64 * 64 + (long long)r * B * 64;
+}

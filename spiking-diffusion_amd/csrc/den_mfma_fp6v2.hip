@@ -60,6 +60,9 @@ struct V2Args {
   unsigned flag_cap;                         //  then the overflow bitmap (one bit per neuron; used only beyond cap)
   const int* qtab;                           // quantised weights int32 [Cout][9][Cin] (exact recomputation)
   const int* n_dyn;
+  // position lists (spk_select_needed, one radius): 64-byte record per image slot; the slots by tile count (classes
+  // 1..6 tiles per wave): cls_cnt[k - 1] slots listed in cls_list[(k - 1) * B ..]
+  const uint8_t* need; const int* cls_cnt; const int* cls_list;
   int B, Cout, Cin;
   int gx, nsets;                             // XCD-aware walk (gx > 0) or flat walk (gx == 0)
 };
@@ -80,6 +83,9 @@ struct V2Args {
                                 // 64 = the tail launch leaves the flag bitmap alone (flagged neurons can be counted),
                                 // 128 = every workgroup stamps {s_memtime, s_memrealtime} around its item loop into the id
                                 // list (shader clock under this kernel's own load = d memtime / d memrealtime * 100 MHz)
+#endif
+#ifndef SPK_V2_KMIN
+#define SPK_V2_KMIN 2           // listed positions: an item of fewer tiles per wave still costs about this many (operand copies)
 #endif
 #ifndef SPK_V2_PF
 #define SPK_V2_PF 6             // A fragments requested this many steps ahead of the MFMA that consumes them
@@ -143,15 +149,22 @@ __device__ __forceinline__ void store_tile_spikes(uint8_t* out, uint8_t* out_cnt
 // input rows (one halo row from the other band).  Both bands sit in LDS rows 1 .. H/2 + 1 of a padded image whose rows 0 and
 // H/2 + 2 stay zero; the top band's outputs are centred on LDS rows 1.., the bottom band's on rows 2.. (one row offset added
 // to the fragment addresses per item).  An even position count needs no last-position launch.
-template <int H, int W, int NWV, bool SPLIT = false>
-__global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6v2_kernel(V2Args a) {
+// NTP > 0 (7x7, one wave per SIMD): the row tiles of an item are the positions LISTED for the image (a.need: what the
+// sampler will read at this reverse step, dilated by the layers in between) instead of all 48 -- tile k = list entries 2k,
+// 2k + 1, round-robin over the waves, NTP = ceil(entries / 8) tiles per wave; `slots` are the image slots with that tile
+// count.  Positions outside the list keep whatever the output buffer held: nothing downstream of a listed position reads them.
+template <int H, int W, int NWV, bool SPLIT, int NTP>
+__device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const int il, const int lanes, const int n_images,
+                                           const int* __restrict__ slots) {
+  constexpr bool PRUNE = NTP > 0;
   constexpr int HW = H * W, PW = W + 1;
   constexpr int Hb = SPLIT ? H / 2 : H;                // output rows of an item
   constexpr int Hin = SPLIT ? Hb + 1 : H;              // input rows staged per item
   constexpr int HWb = Hb * W;                          // output positions of an item
   static_assert(SPLIT ? ((H % 2) == 0 && (HWb % (2 * NWV)) == 0)
                       : ((HW & 1) == 1 && ((HW / 2) % NWV) == 0), "whole 32-row tiles on every wave (+ one odd position)");
-  constexpr int NT = (HWb / 2) / NWV;                  // row tiles per wave (7x7: 6 or 3; 8x8 bands: 4)
+  static_assert(!PRUNE || (!SPLIT && NWV == 4 && NTP <= (HWb / 2) / NWV), "position lists: 7x7 items, one wave per SIMD");
+  constexpr int NT = PRUNE ? NTP : (HWb / 2) / NWV;    // row tiles per wave (7x7: 6 or 3; 8x8 bands: 4)
   constexpr int N_AGPR = NWV == 4 ? (3 * NT < 16 ? 3 * NT : 16) : 8;   // (two waves per SIMD: hipcc splits 256 registers 128 / 128)
   constexpr int NPP = (Hin + 2) * PW + 1;              // cells of the zero-bordered LDS image (pitch W + 1: the zero
   constexpr int A_BYTES = NPP * POSB;                  //  column is shared by x = -1 of a row and x = W of the previous)
@@ -168,27 +181,6 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6v2_kernel(V2Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nch = a.nch;
   const int G = a.Cout >> 5;
-  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
-
-  // workgroup -> (channel group g, image lane il, lanes): the group is FIXED for the whole launch.  XCD-aware form:
-  // workgroups k and k + 8 share an XCD and its L2; XCD x owns channel-group set x % nsets (gx consecutive groups, chosen
-  // by the host so that their packed weights stay L2-resident) and image partition x / nsets.
-  int g, il, lanes;
-  {
-    const int k = blockIdx.x;
-    if (a.gx > 0) {
-      const int S = gridDim.x >> 3, x = k & 7, slot = k >> 3;
-      const int npart = 8 / a.nsets, set = x % a.nsets, xi = x / a.nsets, lanes_x = S / a.gx;
-      g = set * a.gx + slot % a.gx;
-      il = xi * lanes_x + slot / a.gx;
-      lanes = npart * lanes_x;
-    } else {
-      g = k % G;
-      il = k / G;
-      lanes = gridDim.x / G;
-    }
-  }
-
   // zero both A images once: the borders stay zero for the whole kernel, interiors are overwritten by DMA
   for (int i = tid; i < 2 * A_BYTES / 16; i += NWV * 64) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();         // no wave's first DMA piece may land in a cell another wave has yet to zero
@@ -199,12 +191,14 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6v2_kernel(V2Args a) {
   const int row = lane & 31, half = lane >> 5;
   const int hsel = (row >> 2) & 1, tt = (row & 3) + 4 * (row >> 3);
   int a_off[NT], a_off1[NT], a_off2[NT];
+  int p_out[NT];                                          // output position of this lane's accumulator rows
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     const int p = 2 * (wave + NWV * i) + hsel;
     a_off[i] = ((p / W) * PW + (p % W)) * POSB + tt * 16;
     a_off1[i] = a_off[i] + half * POSB;
     a_off2[i] = a_off[i] + half * (PW - 2) * POSB;
+    p_out[i] = 2 * (wave + NWV * i) + half;
   }
 
   // DMA piece table (wave-uniform): bits 0..13 source byte offset in the slab, 14..28 LDS byte offset in the image,
@@ -237,10 +231,10 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6v2_kernel(V2Args a) {
   const uint8_t* const wbase = a.wq + (long long)g * nch * W_SLAB;
   // item index -> (image, band); the slab of a band starts (H/2 - 1) rows into the image for the bottom band
   auto aslab_of = [&](int itm, int c) -> const uint8_t* {
-    const int b = SPLIT ? itm >> 1 : itm, band = SPLIT ? itm & 1 : 0;
+    const int b = PRUNE ? slots[itm] : (SPLIT ? itm >> 1 : itm), band = SPLIT ? itm & 1 : 0;
     return a.in0 + ((long long)b * nch + c) * HW * POSB + band * (Hb - 1) * W * POSB;
   };
-  const int nitems = SPLIT ? 2 * Bn : Bn;
+  const int nitems = SPLIT ? 2 * n_images : n_images;
 
   // per-channel constants (the group is fixed: loaded once)
   const int co = g * 32 + (lane & 31);
@@ -263,8 +257,22 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6v2_kernel(V2Args a) {
     for (int q = 0; q < NPA + NPW; ++q) issue_piece(q, as0, wbase, sA_addr, sW_addr);
   }
   for (int itm = il; itm < nitems; itm += lanes) {
-    const int b = SPLIT ? itm >> 1 : itm, band = SPLIT ? itm & 1 : 0;
+    const int b = PRUNE ? slots[itm] : (SPLIT ? itm >> 1 : itm), band = SPLIT ? itm & 1 : 0;
     const int band_off = band * PW * POSB;                // bottom band: fragment addresses one LDS row further down
+    int n_list = 2 * NT * NWV;
+    if constexpr (PRUNE) {
+      const uint8_t* rec = a.need + (long long)b * 64;
+      n_list = __builtin_amdgcn_readfirstlane((int)rec[48]);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int k2 = 2 * (wave + NWV * i);
+        const int p = rec[k2 + hsel];
+        a_off[i] = ((p / W) * PW + (p % W)) * POSB + tt * 16;
+        a_off1[i] = a_off[i] + half * POSB;
+        a_off2[i] = a_off[i] + half * (PW - 2) * POSB;
+        p_out[i] = rec[k2 + half];
+      }
+    }
     v16f acc[NT][3];      // [i][0]: pair 01, [i][1]: pair 23, [i][2]: fifth digit; written (not accumulated) by the first MFMA
     for (int c = 0; c < nch; ++c, ++it) {
       const int buf = it & 1;
@@ -416,15 +424,18 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6v2_kernel(V2Args a) {
         mybits |= s ? (1u << r) : 0u;
       }
       const int ti = wave + NWV * i;
-      const int p = 2 * ti + half + band * HWb;           // accumulator lane half == position within the tile
-      if (flg && !(SPK_V2_DBG & 32)) {
+      // accumulator lane half == position within the tile; a list that does not fill its last tiles repeats its last
+      // position there: computed and dropped
+      const int p = PRUNE ? p_out[i] : 2 * ti + half + band * HWb;
+      const bool listed = !PRUNE || 2 * ti + half < n_list;
+      if (flg && listed && !(SPK_V2_DBG & 32)) {
         const long long n = ((long long)b * a.Cout + co) * HW + p;
         const unsigned idx = atomicAdd(a.flags, 1u);
         if (idx < a.flag_cap) a.flags[2 + idx] = (unsigned)n;
         else atomicOr(a.flags + 2 + a.flag_cap + (n >> 5), 1u << (n & 31));
       }
       const long long rec = (((long long)b * G + g) * HW + p) * POSB;
-      store_tile_spikes(a.out, a.out_cnt, mybits, lane, rec, (((long long)b * G + g) * HW + p) * 32, true);
+      store_tile_spikes(a.out, a.out_cnt, mybits, lane, rec, (((long long)b * G + g) * HW + p) * 32, listed);
       __builtin_amdgcn_sched_barrier(0);
     }
   }   // images
@@ -433,6 +444,84 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6v2_kernel(V2Args a) {
     unsigned long long* o = reinterpret_cast<unsigned long long*>(a.flags + 2) + 2 * blockIdx.x;
     o[0] = __builtin_amdgcn_s_memtime() - dbg_c0;
     o[1] = __builtin_amdgcn_s_memrealtime() - dbg_r0;
+  }
+}
+
+// workgroup -> (channel group g, image lane il, lanes): the group is FIXED for the whole launch.  XCD-aware form:
+// workgroups k and k + 8 share an XCD and its L2; XCD x owns channel-group set x % nsets (gx consecutive groups, chosen
+// by the host so that their packed weights stay L2-resident) and image partition x / nsets.
+__device__ __forceinline__ void fp6v2_wg_map(const V2Args& a, int& g, int& il, int& lanes) {
+  const int k = blockIdx.x, G = a.Cout >> 5;
+  if (a.gx > 0) {
+    const int S = gridDim.x >> 3, x = k & 7, slot = k >> 3;
+    const int npart = 8 / a.nsets, set = x % a.nsets, xi = x / a.nsets, lanes_x = S / a.gx;
+    g = set * a.gx + slot % a.gx;
+    il = xi * lanes_x + slot / a.gx;
+    lanes = npart * lanes_x;
+  } else {
+    g = k % G;
+    il = k / G;
+    lanes = gridDim.x / G;
+  }
+}
+
+template <int H, int W, int NWV, bool SPLIT = false>
+__global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6v2_kernel(V2Args a) {
+  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
+  int g, il, lanes;
+  fp6v2_wg_map(a, g, il, lanes);
+  fp6v2_body<H, W, NWV, SPLIT, 0>(a, g, il, lanes, Bn, nullptr);
+}
+
+// Listed positions: the image lanes of every channel group are divided among the six tile-count classes in proportion to
+// their work (slots x tiles, with a floor for the copy-bound small classes); a workgroup then runs the item loop
+// instantiated for its class on that class's slots.  Every workgroup derives the same division from cls_cnt.
+template <int H, int W>
+__global__ __launch_bounds__(256, 1) void conv3x3_fp6v2_listed_kernel(V2Args a) {
+  constexpr int NC = (H * W / 2) / 4;                    // classes: 1 .. NC tiles per wave
+  int g, il, lanes;
+  fp6v2_wg_map(a, g, il, lanes);
+  int cnt[NC], work[NC], u[NC];
+  int total = 0, nonempty = 0;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    cnt[k] = a.cls_cnt[k];
+    work[k] = cnt[k] * (k + 1 < SPK_V2_KMIN ? SPK_V2_KMIN : k + 1);
+    total += work[k];
+    nonempty += cnt[k] > 0;
+  }
+  if (total == 0) return;
+  // one lane per non-empty class, the rest in proportion, leftovers to the class with the most work per lane
+  int rem = lanes - nonempty, used = 0;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    u[k] = cnt[k] > 0 ? 1 + (int)((long long)rem * work[k] / total) : 0;
+    used += u[k];
+  }
+  for (int left = lanes - used; left > 0; --left) {
+    int best = 0;
+    long long bw = -1, bu = 1;
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+      if (cnt[k] > 0 && (long long)work[k] * bu > bw * u[k]) { bw = work[k]; bu = u[k]; best = k; }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) u[k] += (k == best);
+  }
+  int start = 0, cls = -1, il_c = 0, lanes_c = 1;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    if (il >= start && il < start + u[k]) { cls = k; il_c = il - start; lanes_c = u[k]; }
+    start += u[k];
+  }
+  const int* slots = a.cls_list + (long long)(cls < 0 ? 0 : cls) * a.B;
+  switch (cls) {
+    case 0: fp6v2_body<H, W, 4, false, 1>(a, g, il_c, lanes_c, cnt[0], slots); break;
+    case 1: fp6v2_body<H, W, 4, false, 2>(a, g, il_c, lanes_c, cnt[1], slots); break;
+    case 2: fp6v2_body<H, W, 4, false, 3>(a, g, il_c, lanes_c, cnt[2], slots); break;
+    case 3: fp6v2_body<H, W, 4, false, 4>(a, g, il_c, lanes_c, cnt[3], slots); break;
+    case 4: fp6v2_body<H, W, 4, false, 5>(a, g, il_c, lanes_c, cnt[4], slots); break;
+    case 5: fp6v2_body<H, W, 4, false, 6>(a, g, il_c, lanes_c, cnt[5], slots); break;
+    default: break;
   }
 }
 
@@ -765,19 +854,26 @@ extern "C" long long spk_den_fp6v2_flag_words(int B, int Cout, int H, int W) {
   return 2 + (long long)FLAG_CAP + ((long long)B * Cout * H * W + 31) / 32;
 }
 
-extern "C" int spk_den_conv3x3_mfma_fp6v2(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale,
-                                          const double* bias_d, const float* wl1, const int* qtab, const float* bn_a,
-                                          const float* bn_b, uint8_t* out_s32, uint8_t* out_counts, unsigned* flag_words,
-                                          int T, int B, int H, int W, int Cout, const int* n_dyn_or_null, hipStream_t stream) {
+static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale, const double* bias_d,
+                        const float* wl1, const int* qtab, const float* bn_a, const float* bn_b, uint8_t* out_s32,
+                        uint8_t* out_counts, unsigned* flag_words, int T, int B, int H, int W, int Cout,
+                        const int* n_dyn_or_null, const uint8_t* need, int need_R, int need_r, hipStream_t stream) {
   if (!in_s32 || nch <= 0 || !wq || !scale || !bias_d || !wl1 || !qtab || !bn_a || !bn_b || !out_s32 || !flag_words ||
       B <= 0 || H <= 0 || W <= 0 || Cout <= 0)
     return SPK_ERR_ARG;
   const bool bands = H == 8 && W == 8;
   if (T != T16 || (Cout % 32) || !((H == 7 && W == 7) || bands)) return SPK_ERR_UNSUPPORTED;
+  if (need && (bands || !n_dyn_or_null)) return SPK_ERR_UNSUPPORTED;
   V2Args a;
   a.in0 = in_s32; a.nch = nch; a.wq = wq; a.scale = scale; a.bias = bias_d; a.wl1 = wl1; a.qtab = qtab;
   a.bn_a = bn_a; a.bn_b = bn_b; a.out = out_s32; a.out_cnt = out_counts; a.flags = flag_words; a.flag_cap = FLAG_CAP;
   a.n_dyn = n_dyn_or_null;
+  a.need = nullptr; a.cls_cnt = nullptr; a.cls_list = nullptr;
+  if (need) {
+    a.need = need + spk_need_off_rec(B, need_R, need_r);
+    a.cls_cnt = reinterpret_cast<const int*>(need + spk_need_off_cnt(need_r));
+    a.cls_list = reinterpret_cast<const int*>(need + spk_need_off_list(B, need_R, need_r));
+  }
   a.B = B; a.Cout = Cout; a.Cin = nch * CK;
   const int cus = spk_cu_count();
   const int G = Cout / 32;
@@ -811,7 +907,10 @@ extern "C" int spk_den_conv3x3_mfma_fp6v2(const uint8_t* in_s32, int nch, const 
   // same time: the device lowers its clock by the same 9 % (1.94 vs 2.13 GHz in-kernel) -- the launch is bound by the
   // power the matrix pipe may draw, not by issue slots.  One wave per SIMD (no spills, simpler) stays the default.
   static const bool eight = [] { const char* e = getenv("SPKDIFF_V2_WAVES"); return e && e[0] == '8'; }();
-  if (eight) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 8>), dim3(grid), dim3(512), lds, stream, a);
+  if (need) {
+    if (grid / G < 6) return SPK_ERR_UNSUPPORTED;           // one image lane per tile-count class at least
+    hipLaunchKernelGGL((conv3x3_fp6v2_listed_kernel<7, 7>), dim3(grid), dim3(256), lds, stream, a);
+  } else if (eight) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 8>), dim3(grid), dim3(512), lds, stream, a);
   else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 4>), dim3(grid), dim3(256), lds, stream, a);
   SPK_LAUNCH_CHECK();
   hipLaunchKernelGGL((fp6v2_fixup_kernel<7, 7>), dim3(cus), dim3(1024), 0, stream, a, n_words);
@@ -820,6 +919,25 @@ extern "C" int spk_den_conv3x3_mfma_fp6v2(const uint8_t* in_s32, int nch, const 
   hipLaunchKernelGGL((fp6v2_lastpos_kernel<7, 7>), dim3(n_lp), dim3(256), 0, stream, a);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
+}
+
+extern "C" int spk_den_conv3x3_mfma_fp6v2(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale,
+                                          const double* bias_d, const float* wl1, const int* qtab, const float* bn_a,
+                                          const float* bn_b, uint8_t* out_s32, uint8_t* out_counts, unsigned* flag_words,
+                                          int T, int B, int H, int W, int Cout, const int* n_dyn_or_null, hipStream_t stream) {
+  return fp6v2_launch(in_s32, nch, wq, scale, bias_d, wl1, qtab, bn_a, bn_b, out_s32, out_counts, flag_words, T, B, H, W, Cout,
+                      n_dyn_or_null, nullptr, 0, 0, stream);
+}
+
+extern "C" int spk_den_conv3x3_mfma_fp6v2_listed(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale,
+                                                 const double* bias_d, const float* wl1, const int* qtab, const float* bn_a,
+                                                 const float* bn_b, uint8_t* out_s32, uint8_t* out_counts,
+                                                 unsigned* flag_words, int T, int B, int H, int W, int Cout,
+                                                 const int* n_dyn, const uint8_t* need, int need_radii, int radius,
+                                                 hipStream_t stream) {
+  if (!need || !n_dyn || need_radii <= 0 || need_radii > 8 || radius < 1 || radius > need_radii) return SPK_ERR_ARG;
+  return fp6v2_launch(in_s32, nch, wq, scale, bias_d, wl1, qtab, bn_a, bn_b, out_s32, out_counts, flag_words, T, B, H, W, Cout,
+                      n_dyn, need, need_radii, radius - 1, stream);
 }
 
 extern "C" int spk_spikes_to_s32(const float* spikes, uint8_t* out_s32, int T, int B, int C, int HW, hipStream_t stream) {

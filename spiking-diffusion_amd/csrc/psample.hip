@@ -10,6 +10,7 @@
 // generator in the reference's order), or (b) on-device Philox4x32-10 keyed by (seed, offset)
 // (throughput mode).  One wave per latent position; lanes stride over the K classes; wave reductions by DPP shuffles.
 #include "spk_common.h"
+#include "den_common.h"
 #include "../../include/spkdiff.h"
 #include <math.h>
 
@@ -225,7 +226,104 @@ __global__ __launch_bounds__(1024) void select_active_kernel(const uint8_t* __re
   if (threadIdx.x == 0) *n_active = base_s;
 }
 
+// Which POSITIONS of an active image does reverse step t need from each denoiser layer?  The sampler reads the logits only
+// at the image's `changes` positions C (:134-140); conv6 is 3x3, so the last spiking layer is needed on dilate(C, 1), the
+// one before it on dilate(C, 2), ... (3x3 convolutions, zero padding).  One wave per active slot; record (r - 1, slot)
+// (64 bytes) describes radius r: bytes 0..47 the ascending list of needed positions below 48 (padded with its last entry),
+// byte 48 the list length n, byte 49 its tile-count class ceil(n / 8) (1..6; a 32-row tile is two positions x 16 steps, four
+// waves), byte 50 whether position 48 is needed.  (The last position of an odd latent is computed by the tail launch of the
+// MFMA kernel either way.)  The workgroup that finishes last groups the slots of every radius by class (the MFMA kernel
+// runs one item loop per class) and re-arms the ticket.  Buffer layout: den_common.h.
+__global__ __launch_bounds__(256) void select_needed_kernel(const uint8_t* __restrict__ unmasked, int t,
+                                                            const float* __restrict__ u_in, unsigned long long seed,
+                                                            unsigned long long offset,
+                                                            const unsigned long long* __restrict__ philox_state,
+                                                            const int* __restrict__ active, const int* __restrict__ n_active,
+                                                            uint8_t* __restrict__ need, int B, int H, int W, int R) {
+  __shared__ int s_cnt[8][8];
+  __shared__ int s_last;
+  if (philox_state) { seed = philox_state[0]; offset += philox_state[1]; }
+  const int lane = threadIdx.x & 63, slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int Bn = *n_active < B ? *n_active : B;
+  const int HW = H * W;
+  if (slot < Bn) {
+    const int b = active[slot];
+    bool ch = false;
+    if (lane < HW) {
+      const long long p = (long long)b * HW + lane;
+      if (!unmasked[p]) {
+        float u;
+        if (u_in) u = u_in[p];
+        else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)p, 0u, r); u = u01_open_right(r[0]); }
+        ch = u < 1.0f / (float)t;
+      }
+    }
+    unsigned long long m = __ballot(ch);
+    unsigned long long col0 = 0;
+    const unsigned long long all = HW >= 64 ? ~0ull : ((1ull << HW) - 1ull);
+    for (int y = 0; y < H; ++y) col0 |= 1ull << (y * W);
+    const unsigned long long colL = col0 << (W - 1);
+    for (int r = 1; r <= R; ++r) {
+      const unsigned long long hdil = m | ((m << 1) & ~col0) | ((m >> 1) & ~colL);
+      m = (hdil | (hdil << W) | (hdil >> W)) & all;
+      const unsigned long long ml = m & ((1ull << 48) - 1ull);            // listed: positions 0..47
+      const int n = __popcll(ml);
+      uint8_t* rec = need + spk_need_off_rec(B, R, r - 1) + (long long)slot * 64;
+      if (lane < 48) {
+        if ((ml >> lane) & 1ull) rec[__popcll(ml & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+        const int last = ml ? 63 - __clzll((long long)ml) : 0;
+        if (lane >= n) rec[lane] = (uint8_t)last;
+      }
+      if (lane == 48) rec[48] = (uint8_t)n;
+      if (lane == 49) rec[49] = (uint8_t)(n ? (n + 7) >> 3 : 1);
+      if (lane == 50) rec[50] = (uint8_t)((m >> 48) & 1ull);
+    }
+  }
+  // last workgroup to arrive: slots by class, per radius
+  __threadfence();
+  __syncthreads();
+  unsigned* ticket = reinterpret_cast<unsigned*>(need);
+  if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (threadIdx.x < 64) s_cnt[threadIdx.x >> 3][threadIdx.x & 7] = 0;
+  __syncthreads();
+  for (int r = 0; r < R; ++r) {
+    const uint8_t* recs = need + spk_need_off_rec(B, R, r);
+    int* list = reinterpret_cast<int*>(need + spk_need_off_list(B, R, r));
+    for (int s = threadIdx.x; s < Bn; s += blockDim.x) {
+      int k = (int)__builtin_nontemporal_load(recs + (long long)s * 64 + 49) - 1;
+      k = k < 0 ? 0 : (k > 5 ? 5 : k);
+      list[k * B + atomicAdd(&s_cnt[r][k], 1)] = s;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 * R) {
+    const int r = threadIdx.x >> 3, k = threadIdx.x & 7;
+    reinterpret_cast<int*>(need + spk_need_off_cnt(r))[k] = k < 6 ? s_cnt[r][k] : 0;
+  }
+  if (threadIdx.x == 0) *ticket = 0u;
+}
+
 }  // namespace
+
+extern "C" long long spk_select_needed_bytes(int B, int R) {
+  if (B <= 0 || R <= 0 || R > 8) return -1;
+  return spk_need_off_rec(B, R, R);
+}
+
+extern "C" int spk_select_needed(const uint8_t* unmasked, int t, const float* u_or_null, unsigned long long philox_seed,
+                                 unsigned long long philox_offset, const unsigned long long* philox_state_or_null,
+                                 const int* active, const int* n_active, uint8_t* need_out, int B, int H, int W, int R,
+                                 hipStream_t stream) {
+  if (!unmasked || !active || !n_active || !need_out || t <= 0 || B <= 0 || R <= 0 || R > 8) return SPK_ERR_ARG;
+  if (H != 7 || W != 7) return SPK_ERR_UNSUPPORTED;        // the record format lists positions 0..47 of a 49-position latent
+  hipLaunchKernelGGL(select_needed_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, unmasked, t, u_or_null, philox_seed,
+                     philox_offset, philox_state_or_null, active, n_active, need_out, B, H, W, R);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
 
 extern "C" int spk_select_active(const uint8_t* unmasked, int t, const float* u_or_null, unsigned long long philox_seed,
                                  unsigned long long philox_offset, const unsigned long long* philox_state_or_null,

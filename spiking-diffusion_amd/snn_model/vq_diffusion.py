@@ -87,6 +87,10 @@ class AbsorbingDiffusion(Sampler):
         # images spk_select_active lists for the step (61 % of (image, step) pairs drop out at 100 steps x 49 positions);
         # the sampled tokens are those of the dense loop, draw for draw.
         self.skip_untouched = True
+        # ... and, of a touched image, the logits are read only at the positions that change: with 3x3 layers below them a
+        # layer r levels down is needed within distance r of a change.  True = the MFMA layers of the denoiser compute the
+        # positions spk_select_needed lists for the step (7x7 latents; again the same tokens, draw for draw).
+        self.list_positions = True
 
     # ---- training step (R/snn_model/vq_diffusion.py:56-101,144-147) -------------------------
     def sample_time(self, b, device):
@@ -165,6 +169,7 @@ class AbsorbingDiffusion(Sampler):
         unmasked = torch.zeros((b, 1, h, w), dtype=torch.bool, device=dev)
         skip = self._skip_ok(h, w) and record is None
         act = None
+        need = ops.NeedLists(b, 4, dev) if skip and self._list_ok(h, w) else None
         for t in reversed(range(1, sample_steps + 1)):
             u = q = None
             if noise is not None:
@@ -174,7 +179,9 @@ class AbsorbingDiffusion(Sampler):
             off = base + (sample_steps - t) * (b * h * w * K)
             if skip:
                 act = ops.select_active(unmasked, t, u, seed, off, out=act)
-            with ops.active_set(*(act if skip else (None, None))):
+                if need is not None:
+                    ops.select_needed(unmasked, t, act, need, u, seed, off)
+            with ops.active_set(*(act if skip else (None, None)), need=need):
                 logits = dn.logits_from_tokens(x_t, t)                   # denoiser + reset_net (:128-129)
                 if noise is None and self.noise_source == 'host':
                     q = torch.empty(b * h * w, K).exponential_(1).to(dev)    # multinomial's one-draw fast path (:138)
@@ -185,6 +192,9 @@ class AbsorbingDiffusion(Sampler):
 
     def _skip_ok(self, h, w):
         return bool(self.skip_untouched)            # every kernel family takes the device-side image count
+
+    def _list_ok(self, h, w):
+        return bool(self.list_positions) and (h, w) == (7, 7)
 
     def _philox_key(self):
         draw = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64))
@@ -205,7 +215,8 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
     same (seed, counter base)."""
     dn = self._denoise_fn
     skip = self._skip_ok(h, w)
-    key = (str(dev), b, h, w, K, temp, sample_steps, int(self.mask_id), skip, _weights_key(dn))
+    lists = skip and self._list_ok(h, w)
+    key = (str(dev), b, h, w, K, temp, sample_steps, int(self.mask_id), skip, lists, _weights_key(dn))
     entry = self._graphs.get(key)
     if entry is None:
         if len(self._graphs) >= 2:                              # at most two live graphs per sampler (e.g. dense and
@@ -215,6 +226,7 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
         unmasked = torch.empty((b, 1, h, w), dtype=torch.bool, device=dev)
 
         act = (torch.zeros(b, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)) if skip else None
+        need = ops.NeedLists(b, 4, dev) if lists else None
 
         def body():
             x_t.fill_(int(self.mask_id))
@@ -223,7 +235,9 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
                 off = (sample_steps - t) * (b * h * w * K)
                 if skip:
                     ops.select_active(unmasked, t, None, 0, off, philox_state=state, out=act)
-                with ops.active_set(*(act if skip else (None, None))):
+                    if lists:
+                        ops.select_needed(unmasked, t, act, need, None, 0, off, philox_state=state)
+                with ops.active_set(*(act if skip else (None, None)), need=need):
                     logits = dn.logits_from_tokens(x_t, t)
                     ops.psample_step(logits, x_t, unmasked, t, temp, None, None, 0, off, philox_state=state)
 
@@ -236,9 +250,9 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             body()
-        entry = (graph, state, x_t)
+        entry = (graph, state, x_t, need)                      # (need: kept alive with the graph that reads it)
         self._graphs[key] = entry
-    graph, state, x_t = entry
+    graph, state, x_t = entry[:3]
     state.copy_(torch.tensor([seed, base], dtype=torch.int64), non_blocking=False)
     graph.replay()
     return x_t.clone()
@@ -334,11 +348,13 @@ class DummyModel(nn.Module):
         x = x1
         outs = [x1]
         cnt5 = None
-        for name, blk in (('den.conv2', self.conv2), ('den.conv3', self.conv3), ('den.conv4', self.conv4),
-                          ('den.conv5', self.conv5)):
+        # (inside a position-list scope of the sampler: conv5 feeds the 3x3 logits convolution -> radius 1, conv4 radius 2, ...)
+        for name, blk, radius in (('den.conv2', self.conv2, 4), ('den.conv3', self.conv3, 3), ('den.conv4', self.conv4, 2),
+                                  ('den.conv5', self.conv5, 1)):
             with ops.timed(name):
                 r = blk.run(x, IN_PTC, final='ptc', stateful=stateful, chunk_out=chunk, impl=impl,
-                            want_counts=collapse and blk is self.conv5)
+                            want_counts=collapse and blk is self.conv5,
+                            need_radius=radius if which == 'mfma-fp6v2' and collapse else None)
             x, cnt5 = r['ptc'], r['cnt']
             outs.append(x)
         if record is not None:

@@ -216,7 +216,7 @@ class FusedSequential(nn.Sequential):
         return self.run(x, IN_SEQ, final='f32')['f32']
 
     def run(self, x, in_kind, final='f32', T=None, in1=None, coef=None, apply_tanh=False, want_u8=False,
-            stateful=True, want_pre=False, chunk_out=None, impl='auto', want_counts=False):
+            stateful=True, want_pre=False, chunk_out=None, impl='auto', want_counts=False, need_radius=None):
         """Run all blocks fused.
 
         x: per in_kind (IN_SEQ fp32 [T,B,C,H,W]; IN_TINV fp32 [B,C,H,W] with ``T`` given; IN_PTC u8 [B,H,W,T,C]).
@@ -225,6 +225,7 @@ class FusedSequential(nn.Sequential):
         stateful: honour and update each LIFNode's ``v`` (module semantics); False = fresh state, nothing written.
         chunk_out: channel chunking of the PTC output of the last block (32 = the CPTC layout the int8 MFMA kernel reads,
         ops.CHUNK_C4 = the nibble-packed fp4 layout of the fp6 MFMA kernel).
+        need_radius: see ops.den_conv3x3_mfma_fp6v2 (single-block containers on S32 spikes inside a position-list scope).
         impl: 'auto' uses the MFMA kernel that matches the input layout (CPTC u8 -> int8 planes, C4 -> fp6 planes;
         3x3/s1/p1, T=16), 'direct' never.
         Returns dict(ptc=, f32=, pre=[...], u8=)."""
@@ -259,7 +260,7 @@ class FusedSequential(nn.Sequential):
                                                   'LIF, T=16, 7x7, fresh LIF state, S32 output)')
                     a, b = bn.affine_terms()
                     o = ops.den_conv3x3_mfma_fp6v2(cur, conv._spk_params.get_fp6v2(conv), conv.out_channels, bn_a=a, bn_b=b,
-                                                   want_counts=last and want_counts)
+                                                   want_counts=last and want_counts, need_radius=need_radius)
                     if last and want_counts:
                         out['ptc'], out['cnt'] = o
                     elif last:

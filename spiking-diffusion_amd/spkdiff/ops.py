@@ -19,21 +19,27 @@ MAX_T = 16
 # Set by the sampler around one denoiser call (``with ops.active_set(active, n_active)``): the per-step kernels then
 # process only the images listed by spk_select_active -- ``active`` int32 [B] (slot -> image), ``n_active`` int32 [1],
 # both on the device, so that a captured hipGraph replays with fresh lists.  None = every image (dense).
+# ``need`` (optional, spk_select_needed): the positions of each active image the step will read, per layer depth; the
+# layers that take position lists then compute only those.
 ACTIVE = None
+NEED = None
 
 
 class active_set:
-    def __init__(self, active, n_active):
+    def __init__(self, active, n_active, need=None):
         self.pair = None if active is None else (active, n_active)
+        self.need = need if active is not None else None
 
     def __enter__(self):
-        global ACTIVE
+        global ACTIVE, NEED
         self.prev, ACTIVE = ACTIVE, self.pair
+        self.prev_need, NEED = NEED, self.need
         return self
 
     def __exit__(self, *exc):
-        global ACTIVE
+        global ACTIVE, NEED
         ACTIVE = self.prev
+        NEED = self.prev_need
         return False
 
 
@@ -832,9 +838,12 @@ def _flag_bitmap(device, words):
     return buf
 
 
-def den_conv3x3_mfma_fp6v2(in0, packed, Cout, *, bn_a, bn_b, want_counts=False):
+def den_conv3x3_mfma_fp6v2(in0, packed, Cout, *, bn_a, bn_b, want_counts=False, need_radius=None):
     """in0: S32 spikes [B, C/32, 7, 7, 16, 16] (int8-tagged). Returns S32 spikes [B, Cout/32, 7, 7, 16, 16]
-    (or (spikes, counts u8 [B, Cout/32, 7, 7, 32]) with want_counts).  Fresh LIF state, none written back."""
+    (or (spikes, counts u8 [B, Cout/32, 7, 7, 32]) with want_counts).  Fresh LIF state, none written back.
+    need_radius: inside ``active_set(..., need=NeedLists)`` the layer computes only the positions listed for that radius
+    (1 = the layer the logits convolution reads, 2 = the one below, ...); every other position of the result is
+    unspecified."""
     in0 = _dev(in0, "in0", C4_DTYPE)
     B, nch, H, W, T, rec = in0.shape
     if rec != 16:
@@ -843,6 +852,13 @@ def den_conv3x3_mfma_fp6v2(in0, packed, Cout, *, bn_a, bn_b, want_counts=False):
     out = torch.empty((B, Cout // 32, H, W, T, 16), dtype=C4_DTYPE, device=in0.device)
     cnt = torch.empty((B, Cout // 32, H, W, 32), dtype=torch.uint8, device=in0.device) if want_counts else None
     flags = _flag_bitmap(in0.device, lib.spk_den_fp6v2_flag_words(B, Cout, H, W))
+    if (need_radius is not None and NEED is not None and ACTIVE is not None and (H, W) == (7, 7) and
+            need_radius <= NEED.radii and NEED.batch == B):
+        check(lib.spk_den_conv3x3_mfma_fp6v2_listed(_p(in0), nch, _p(wq), _p(scale), _p(bias_d), _p(wl1), _p(qtab), _p(bn_a),
+                                                    _p(bn_b), _p(out), _p(cnt), _p(flags), T, B, H, W, Cout, _n_dyn(),
+                                                    _p(NEED.buf), NEED.radii, int(need_radius), _stream(in0)),
+              "spk_den_conv3x3_mfma_fp6v2_listed")
+        return (out, cnt) if want_counts else out
     check(lib.spk_den_conv3x3_mfma_fp6v2(_p(in0), nch, _p(wq), _p(scale), _p(bias_d), _p(wl1), _p(qtab), _p(bn_a), _p(bn_b),
                                          _p(out), _p(cnt), _p(flags), T, B, H, W, Cout, _n_dyn(), _stream(in0)),
           "spk_den_conv3x3_mfma_fp6v2")
@@ -1009,6 +1025,39 @@ def psample_step(logits, x_t, unmasked, t, temp=1.0, u=None, q=None, seed=0, off
                                int(offset), _p(philox_state), _p(x0_hat), B, HW, K, _p(act), _p(nact), _stream(logits)),
           "spk_psample_step")
     return x_t, unmasked
+
+
+class NeedLists:
+    """Device buffer of spk_select_needed for ``batch`` image slots and ``radii`` layer depths (zero-initialised once)."""
+    __slots__ = ("buf", "batch", "radii")
+
+    def __init__(self, batch, radii, device):
+        n = lib.spk_select_needed_bytes(int(batch), int(radii))
+        if n <= 0:
+            raise ValueError("spk_select_needed_bytes: bad (batch, radii)")
+        self.buf = torch.zeros(n, dtype=torch.uint8, device=device)
+        self.batch, self.radii = int(batch), int(radii)
+
+    def records(self, radius):
+        """uint8 [B, 64] view of the records of one radius (tests)."""
+        R, B = self.radii, self.batch
+        lists = 64 + R * 64 + R * 6 * B * 4
+        off = (lists + 63) // 64 * 64 + (radius - 1) * B * 64
+        return self.buf[off:off + B * 64].view(B, 64)
+
+
+def select_needed(unmasked, t, active, need, u=None, seed=0, offset=0, philox_state=None):
+    """Positions each active image needs from the layers below the logits at reverse step t (spk_select_needed); ``active``
+    = the pair returned by select_active for the same step, ``need`` a NeedLists for the same batch.  7x7 latents."""
+    B = unmasked.shape[0]
+    H, W = int(unmasked.shape[-2]), int(unmasked.shape[-1])
+    if need.batch != B:
+        raise ValueError("NeedLists was sized for another batch")
+    if u is not None:
+        u = _dev(u, "u", torch.float32)
+    check(lib.spk_select_needed(_p(unmasked), int(t), _p(u), int(seed), int(offset), _p(philox_state), _p(active[0]),
+                                _p(active[1]), _p(need.buf), B, H, W, need.radii, _stream(unmasked)), "spk_select_needed")
+    return need
 
 
 def select_active(unmasked, t, u=None, seed=0, offset=0, philox_state=None, out=None):

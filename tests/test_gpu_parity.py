@@ -534,6 +534,116 @@ def test_fp6v2_kernel_bit_equal_to_the_exact_kernels(dev, ops, B, hw):
     parity(f"fp6v2_vs_fp6_B{B}_{hw}x{hw}", neuron_steps=total, spike_mismatches=mism)
 
 
+def _cpu_need_lists(unmasked, u, t, active, R):
+    """Host restatement of spk_select_needed: per active slot and radius, the sorted positions (< 48) within Chebyshev
+    distance r of a change, and whether position 48 is among them."""
+    import numpy as np
+    out = []
+    for b in active:
+        ch = ((u[b].reshape(7, 7) < np.float32(1.0) / np.float32(t)) & ~unmasked[b].reshape(7, 7))
+        per_r = []
+        m = ch.copy()
+        for r in range(1, R + 1):
+            d = np.zeros_like(m)
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    sh = np.zeros_like(m)
+                    ys = slice(max(0, dy), 7 + min(0, dy)); yd = slice(max(0, -dy), 7 + min(0, -dy))
+                    xs = slice(max(0, dx), 7 + min(0, dx)); xd = slice(max(0, -dx), 7 + min(0, -dx))
+                    sh[yd, xd] = m[ys, xs]
+                    d |= sh
+            m = d
+            flat = np.flatnonzero(m.reshape(-1))
+            per_r.append(([int(p) for p in flat if p < 48], bool(m[6, 6])))
+        out.append(per_r)
+    return out
+
+
+@pytest.mark.parametrize("B,t", [(1, 3), (37, 40), (256, 100), (64, 1)])
+def test_select_needed_position_lists(dev, ops, B, t):
+    """spk_select_needed against a host restatement: records (sorted positions, padding, count, class, last-position
+    flag) for radii 1..4 and the per-class slot lists; two calls on the same buffer (the ticket re-arms itself)."""
+    import numpy as np
+    g = torch.Generator().manual_seed(B * 131 + t)
+    for rep in range(2):
+        unmasked = torch.rand(B, 1, 7, 7, generator=g) < 0.4
+        u = torch.rand(B, 1, 7, 7, generator=g) * (3.0 / t if t > 1 else 1.0)
+        um, ud = unmasked.to(dev), u.to(dev)
+        act = ops.select_active(um, t, ud)
+        if rep == 0:
+            need = ops.NeedLists(B, 4, dev)
+        ops.select_needed(um, t, act, need, ud)
+        torch.cuda.synchronize()
+        n_act = int(act[1].item())
+        active = act[0][:n_act].cpu().tolist()
+        want = _cpu_need_lists(unmasked.numpy(), u.numpy(), t, active, 4)
+        assert n_act == int(((u < 1.0 / t) & ~unmasked).flatten(1).any(1).sum())
+        buf = need.buf.cpu().numpy()
+        R = 4
+        for r in range(1, R + 1):
+            rec = need.records(r).cpu().numpy()
+            classes = [[] for _ in range(6)]
+            for s in range(n_act):
+                lst, last = want[s][r - 1]
+                n = len(lst)
+                assert rec[s, 48] == n and rec[s, 50] == int(last)
+                assert rec[s, :n].tolist() == lst
+                assert all(v == (lst[-1] if n else 0) for v in rec[s, n:48].tolist())
+                k = max(1, (n + 7) // 8)
+                assert rec[s, 49] == k
+                classes[k - 1].append(s)
+            cnt = buf[64 + (r - 1) * 64: 64 + (r - 1) * 64 + 24].view(np.int32)
+            off = 64 + R * 64 + (r - 1) * 6 * B * 4
+            lists = buf[off: off + 6 * B * 4].view(np.int32).reshape(6, B)
+            for k in range(6):
+                assert cnt[k] == len(classes[k])
+                assert sorted(lists[k, :cnt[k]].tolist()) == classes[k]
+        assert int(buf[:4].view(np.uint32)[0]) == 0, "ticket re-armed"
+
+
+@pytest.mark.parametrize("B,t", [(5, 2), (96, 30), (256, 100)])
+def test_fp6v2_listed_positions_equal_the_full_layer(dev, ops, B, t):
+    """spk_den_conv3x3_mfma_fp6v2_listed: on every listed position (and the 49th) spikes and spike counts are bit-equal
+    to the full launch, for each radius / denoiser shape; unlisted positions of the output are left untouched."""
+    g = torch.Generator().manual_seed(77 + B)
+    unmasked = torch.rand(B, 1, 7, 7, generator=g) < 0.5
+    u = torch.rand(B, 1, 7, 7, generator=g) * (2.0 / t)
+    um, ud = unmasked.to(dev), u.to(dev)
+    act = ops.select_active(um, t, ud)
+    need = ops.select_needed(um, t, act, ops.NeedLists(B, 4, dev), ud)
+    n_act = int(act[1].item())
+    assert n_act > 0
+    total = 0
+    for (Cout, Cin), radius in (((128, 64), 4), ((256, 128), 3), ((512, 256), 2), ((256, 512), 1)):
+        w = ((torch.rand(Cout, Cin, 3, 3, generator=g) - 0.5) * 0.1)
+        bias = (torch.rand(Cout, generator=g) - 0.5) * 0.2
+        a = (torch.rand(Cout, generator=g) - 0.3) * 8.0
+        b = (torch.rand(Cout, generator=g) - 0.4) * 1.5
+        spikes = (torch.rand(16, B, Cin, 7, 7, generator=g) < 0.15).float()
+        pk = ops.den_pack_weight_fp6v2(w.to(dev), bias.to(dev))
+        s32 = ops.spikes_to_s32(spikes.to(dev))
+        with ops.active_set(*act):
+            full, cfull = ops.den_conv3x3_mfma_fp6v2(s32, pk, Cout, bn_a=a.to(dev), bn_b=b.to(dev), want_counts=True)
+        with ops.active_set(*act, need=need):
+            part, cpart = ops.den_conv3x3_mfma_fp6v2(s32, pk, Cout, bn_a=a.to(dev), bn_b=b.to(dev), want_counts=True,
+                                                     need_radius=radius)
+        rec = need.records(radius).cpu().numpy()
+        listed = torch.zeros(B, 49, dtype=torch.bool)
+        for s in range(n_act):
+            listed[s, rec[s, :rec[s, 48]].tolist()] = True
+            listed[s, 48] = True
+        assert 0 < int(listed[:n_act, :48].sum()) < n_act * 48 or radius >= 3
+        f = full.cpu().view(B, Cout // 32, 49, 16, 16)
+        q = part.cpu().view(B, Cout // 32, 49, 16, 16)
+        m = listed[:, None, :, None, None].expand_as(f)
+        assert torch.equal(f[m], q[m]), (Cout, Cin, int((f[m] != q[m]).sum()))
+        mc = listed[:, None, :, None].expand(B, Cout // 32, 49, 32)
+        assert torch.equal(cfull.cpu().view(B, Cout // 32, 49, 32)[mc], cpart.cpu().view(B, Cout // 32, 49, 32)[mc])
+        total += int(m.sum()) * 2
+    parity(f"fp6v2_listed_vs_full_B{B}_t{t}", neuron_steps=total, spike_mismatches=0)
+
+
+
 # ------------------------------------------------------------------------------------------------- F8 LIF training
 @pytest.mark.parametrize("det", [False, True])
 def test_f8_lif_training_bptt_vs_reference_fixture(golden_dir, dev, det):
@@ -622,10 +732,11 @@ def test_sampler_skipping_untouched_images_gives_the_same_tokens(dev, steps):
     from snn_model.vq_diffusion import AbsorbingDiffusion
     den, _ = build_den(synth.MNIST, dev)
     out = {}
-    for skip in (False, True):
+    for skip in (False, True, 'lists'):
         ab = AbsorbingDiffusion(den, mask_id=128)
         ab.n_samples = 24
-        ab.skip_untouched = skip
+        ab.skip_untouched = bool(skip)
+        ab.list_positions = skip == 'lists'          # ... and, of the touched images, only the positions the step reads
         torch.manual_seed(1234)
         a = ab.sample(temp=0.9, sample_steps=steps).cpu()
         b = ab.sample(temp=0.9, sample_steps=steps).cpu()          # second replay: next Philox base
@@ -638,8 +749,8 @@ def test_sampler_skipping_untouched_images_gives_the_same_tokens(dev, steps):
         out[skip] = (a, b, c, d)
         assert torch.equal(a, c) and not torch.equal(a, b)
         assert int(a.max()) < 128 and int(b.max()) < 128
-    for x, y in zip(out[False], out[True]):
-        assert torch.equal(x, y)
+    for x, y, z in zip(out[False], out[True], out['lists']):
+        assert torch.equal(x, y) and torch.equal(x, z)
 
 
 # ------------------------------------------------------------------------------------------------- F9 training step
