@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void select_needed_kernel(const uint8_t* __res
     for (int y = 0; y < H; ++y) col0 |= 1ull << (y * W);
     const unsigned long long colL = col0 << (W - 1);
     for (int r = 1; r <= R; ++r) {
-      const unsigned long long hdil = m | ((m << 1) & ~col0) | ((m >> 1) & ~colL);
+      const unsigned long long hdil = (m | ((m << 1) & ~col0) | ((m >> 1) & ~colL)) & all;
       m = (hdil | (hdil << W) | (hdil >> W)) & all;
       const unsigned long long ml = m & ((1ull << 48) - 1ull);            // listed: positions 0..47
       const int n = __popcll(ml);
