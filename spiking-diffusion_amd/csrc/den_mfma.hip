@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(MfmaArgs a) {
 // conv6 has no BN / LIF: logits = (sum_t conv6(s_t)) / T = (conv6_linear(sum_t s_t) + T*bias) / T.  The A operand
 // becomes the per-neuron spike COUNT over T (0..16, exact in int8) and the GEMM loses its factor T in M: rows are
 // (image, position) pairs only.  The work is tiny (~0.6 M MFMAs for B = 256), so the kernel is deliberately simple:
-// one wave per 32-row tile x 16 output channels, operands straight from L2 (counts 4 MB, weights 3.7 MB), no LDS.
+// one workgroup per 32-row tile x 16 output channels, operands straight from L2 (counts 4 MB, weights 3.7 MB).
 // Numerics: sum first, round once -- at least as accurate as the reference's per-step rounding (|diff| <~ 1 ulp).
 struct CntArgs {
   const uint8_t* c0; const uint8_t* c1; int nch0, nch1;
@@ -340,12 +340,17 @@ struct CntArgs {
   const int* n_dyn;     // optional device-side batch count (<= B)
 };
 
+// A wave = one 32-row tile x 16 output channels.  With few rows (the sampler's active set) the launch is bound by the
+// latency of a wave's chain of dependent gathers, not by throughput: the four waves of a workgroup then SPLIT the K chunks
+// of one tile (wave w: chunks w, w + 4, ...) and add their int32 partial sums in LDS (30 -> 17 us at ~100 active images).
 __global__ __launch_bounds__(256) void conv3x3_counts_mfma_kernel(CntArgs a) {
+  __shared__ int red[2][16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int HW = a.H * a.W;
   const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
   const long long nrows = (long long)Bn * HW;
-  const long long tile = (long long)blockIdx.x * 4 + wave;
+  const bool split = nrows <= 32 * 160;                     // (uniform over the launch)
+  const long long tile = split ? (long long)blockIdx.x : (long long)blockIdx.x * 4 + wave;
   if (tile * 32 >= nrows) return;
   const int g = blockIdx.y;
   const int nchunks = a.nch0 + a.nch1;
@@ -355,8 +360,12 @@ __global__ __launch_bounds__(256) void conv3x3_counts_mfma_kernel(CntArgs a) {
   const int b = rvalid ? (int)(R / HW) : 0, p = rvalid ? (int)(R % HW) : 0;
   const int y = p / a.W, x = p % a.W;
   const int boff = (lane & 31) * CK + 16 * (half ^ ((lane >> 4) & 1));
+  if (split) {
+    for (int i = threadIdx.x; i < 2 * 16 * 64; i += 256) (&red[0][0][0])[i] = 0;
+    __syncthreads();
+  }
   v16i acc0 = {0}, acc1 = {0};
-  for (int c = 0; c < nchunks; ++c) {
+  for (int c = split ? wave : 0; c < nchunks; c += split ? 4 : 1) {
     const uint8_t* src = c < a.nch0 ? a.c0 + ((long long)b * a.nch0 + c) * HW * CK
                                     : a.c1 + ((long long)b * a.nch1 + (c - a.nch0)) * HW * CK;
     const int8_t* wsrc = a.wq + ((long long)g * nchunks + c) * W_CHUNK_BYTES + boff;
@@ -373,6 +382,19 @@ __global__ __launch_bounds__(256) void conv3x3_counts_mfma_kernel(CntArgs a) {
       acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b0, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b1, acc1, 0, 0, 0);
     }
+  }
+  if (split) {
+    if (wave != 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        atomicAdd(&red[0][r][lane], acc0[r]);
+        atomicAdd(&red[1][r][lane], acc1[r]);
+      }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] += red[0][r][lane]; acc1[r] += red[1][r][lane]; }
   }
   const int col = lane & 31, ch = col & 15, odd = col >> 4;
   const int co = g * 16 + ch;
@@ -497,7 +519,7 @@ extern "C" int spk_den_conv3x3_counts_mfma(const uint8_t* cnt0, int nch0, const 
   a.c0 = cnt0; a.c1 = cnt1; a.nch0 = nch0; a.nch1 = nch1; a.wq = wq; a.scale = scale; a.bias = bias_d; a.out = out_f32;
   a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.T = T; a.n_dyn = n_dyn_or_null;
   const long long tiles = ((long long)B * H * W + 31) / 32;
-  dim3 grid((unsigned)((tiles + 3) / 4), Cout / 16), blk(256);
+  dim3 grid((unsigned)tiles, Cout / 16), blk(256);
   hipLaunchKernelGGL(conv3x3_counts_mfma_kernel, grid, blk, 0, stream, a);
   SPK_LAUNCH_CHECK();
   return SPK_OK;

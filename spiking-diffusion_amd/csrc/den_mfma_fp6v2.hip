@@ -526,9 +526,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6v2_listed_kernel(V2Args a) 
 }
 
 // ------------------------------------------------------------------------------------------------ tail launches
-// (1) the last position of every image, exactly: one wave = four images x one channel group, two 32-row tiles whose lane
-//     halves are images; the four taps that reach position (H-1, W-1) from inside the image; operands straight from L2;
-//     all six digits (the two sixth-digit tiles of the slab), fp64 recombination.
+// (1) the last position of every image, exactly: one workgroup = two images x one channel group (a 32-row tile whose lane
+//     halves are the images), its waves splitting the K chunks; the four taps that reach position (H-1, W-1) from inside
+//     the image; operands straight from L2; all six digits (the two sixth-digit tiles of the slab), fp64 recombination.
 // (2) the flagged neurons of the main launch, exactly (fixup_neuron / fp6v2_fixup_kernel below).
 __device__ __forceinline__ float exact_preact(double s, double sc, double bi) { return (float)fma(s, sc, bi); }
 
@@ -540,8 +540,13 @@ __global__ __launch_bounds__(256) void fp6v2_lastpos_kernel(V2Args a) {
   const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
   // this launch follows the fixup launch on the stream: the flag counter is reset here for the next layer's main launch
   if (blockIdx.x == 0 && threadIdx.x == 0 && !(SPK_V2_DBG & 64)) a.flags[0] = 0u;
-  // one wave = one 32-row tile = two images (the lane halves) x one channel group
-  const int unit = blockIdx.x * 4 + wave;
+  // one workgroup = one 32-row tile = two images (the lane halves) x one channel group; its four waves split the K chunks
+  // (wave w: chunks w, w + 4, ...) and add their partial sums -- exact integers below 2^24 in fp32, so the order of the
+  // additions does not matter -- in LDS: the launch is bound by the latency of a wave's chain of dependent gathers
+  // (with many units the launch is bound by throughput instead: then every wave takes a unit of its own)
+  __shared__ float red[3][3][16][64];
+  const bool split = ((Bn + 1) >> 1) * G <= 1024;           // (uniform over the launch)
+  const int unit = split ? blockIdx.x : blockIdx.x * 4 + wave;
   const int g = unit % G, b0 = (unit / G) * 2;
   if (b0 >= Bn) return;
   const int row = lane & 31, half = lane >> 5;
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(256) void fp6v2_lastpos_kernel(V2Args a) {
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   const int py = H - 1, px = W - 1;
   const int bA = b0 + hsel;
-  for (int c = 0; c < nch; ++c) {
+  for (int c = split ? wave : 0; c < nch; c += split ? 4 : 1) {
     const uint8_t* wslab = a.wq + ((long long)g * nch + c) * W_SLAB;
     auto ldb = [&](int tile) -> v8i {
       const uint8_t* wt = wslab + tile * WT;
@@ -597,6 +602,22 @@ __global__ __launch_bounds__(256) void fp6v2_lastpos_kernel(V2Args a) {
     const v4i a34 = half ? sp[3] : sp[2];
     mm(acc[2], a01, t18, sc_hi); mm(acc[2], az3, t19, sc_hi); mm(acc[2], a4z, t20, sc_hi);
     mm(acc[2], a01, t23, sc_lo); mm(acc[2], a34, t24, sc_lo);
+  }
+  if (split) {
+    if (wave != 0) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][j][r][lane] = acc[j][r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const int nw = nch < 4 ? nch : 4;                       // waves that had a chunk
+    for (int w = 1; w < nw; ++w)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] += red[w - 1][j][r][lane];
   }
   const int co = g * 32 + (lane & 31);
   const double sc = a.scale[co], bi = a.bias[co];
@@ -895,7 +916,7 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   if (bands) {
     hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 4, true>), dim3(grid), dim3(256), lds, stream, a);
     SPK_LAUNCH_CHECK();
-    hipLaunchKernelGGL((fp6v2_fixup_kernel<8, 8>), dim3(cus), dim3(1024), 0, stream, a, n_words);
+    hipLaunchKernelGGL((fp6v2_fixup_kernel<8, 8>), dim3(2 * cus), dim3(1024), 0, stream, a, n_words);
     SPK_LAUNCH_CHECK();
     // (no last-position launch on an even latent: a one-wave launch resets the flag counter; a memset node in its place
     // made a captured reverse process several times slower)
@@ -913,9 +934,9 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   } else if (eight) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 8>), dim3(grid), dim3(512), lds, stream, a);
   else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 4>), dim3(grid), dim3(256), lds, stream, a);
   SPK_LAUNCH_CHECK();
-  hipLaunchKernelGGL((fp6v2_fixup_kernel<7, 7>), dim3(cus), dim3(1024), 0, stream, a, n_words);
+  hipLaunchKernelGGL((fp6v2_fixup_kernel<7, 7>), dim3(2 * cus), dim3(1024), 0, stream, a, n_words);
   SPK_LAUNCH_CHECK();
-  const int n_lp = (((B + 1) / 2) * G + 3) / 4;
+  const int n_lp = ((B + 1) / 2) * G;
   hipLaunchKernelGGL((fp6v2_lastpos_kernel<7, 7>), dim3(n_lp), dim3(256), 0, stream, a);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
