@@ -91,6 +91,8 @@ class AbsorbingDiffusion(Sampler):
         # layer r levels down is needed within distance r of a change.  True = the MFMA layers of the denoiser compute the
         # positions spk_select_needed lists for the step (7x7 latents; again the same tokens, draw for draw).
         self.list_positions = True
+        self.list_radii = 3                 # layers below the logits that take lists (1: conv5 only ... 4: conv2..conv5;
+                                            # conv2 needs nearly every position anyway: 3 measured fastest)
 
     # ---- training step (R/snn_model/vq_diffusion.py:56-101,144-147) -------------------------
     def sample_time(self, b, device):
@@ -169,7 +171,7 @@ class AbsorbingDiffusion(Sampler):
         unmasked = torch.zeros((b, 1, h, w), dtype=torch.bool, device=dev)
         skip = self._skip_ok(h, w) and record is None
         act = None
-        need = ops.NeedLists(b, 4, dev) if skip and self._list_ok(h, w) else None
+        need = ops.NeedLists(b, int(self.list_radii), dev) if skip and self._list_ok(h, w) else None
         for t in reversed(range(1, sample_steps + 1)):
             u = q = None
             if noise is not None:
@@ -216,7 +218,7 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
     dn = self._denoise_fn
     skip = self._skip_ok(h, w)
     lists = skip and self._list_ok(h, w)
-    key = (str(dev), b, h, w, K, temp, sample_steps, int(self.mask_id), skip, lists, _weights_key(dn))
+    key = (str(dev), b, h, w, K, temp, sample_steps, int(self.mask_id), skip, lists, int(self.list_radii), _weights_key(dn))
     entry = self._graphs.get(key)
     if entry is None:
         if len(self._graphs) >= 2:                              # at most two live graphs per sampler (e.g. dense and
@@ -226,7 +228,7 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
         unmasked = torch.empty((b, 1, h, w), dtype=torch.bool, device=dev)
 
         act = (torch.zeros(b, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)) if skip else None
-        need = ops.NeedLists(b, 4, dev) if lists else None
+        need = ops.NeedLists(b, int(self.list_radii), dev) if lists else None
 
         def body():
             x_t.fill_(int(self.mask_id))

@@ -15,10 +15,11 @@ functional.set_step_mode(net=den, step_mode='m')
 den.load_state_dict(synth.synth_denoiser_state(cfg))
 den.eval()
 res = {}
-for name, skip, lists in (("dense", False, False), ("elim", True, False), ("elim+lists", True, True)):
+for name, skip, lists, radii in (("dense", False, False, 4), ("elim", True, False, 4), ("elim+lists4", True, True, 4),
+                                 ("elim+lists3", True, True, 3), ("elim+lists2", True, True, 2), ("elim+lists1", True, True, 1)):
     ab = AbsorbingDiffusion(den, mask_id=cfg.num_embeddings)
     ab.n_samples = B
-    ab.skip_untouched, ab.list_positions = skip, lists
+    ab.skip_untouched, ab.list_positions, ab.list_radii = skip, lists, radii
     torch.manual_seed(7)
     x = ab.sample(temp=1.0, sample_steps=100)
     torch.cuda.synchronize()
