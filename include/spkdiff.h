@@ -249,11 +249,22 @@ int spk_pack_conv_weight_i8(const float* w, const float* bias, int8_t* wq, doubl
 /* (Conv2d | ConvTranspose2d) over binary spikes (plain PTC u8 [B,H*W,16,Cin], T = 16, Cin % 16 == 0) with exact int8
  * MFMA accumulation, fused with BN + LIF (mode SPK_MODE_LIF -> out_ptc [B,Ho*Wo,16,Cout]) or with the membrane
  * read-out (mode SPK_MODE_MEMOUT: coef[16] -> out_f32 [B,Cout,Ho,Wo] (+tanh), out_u8): Encoder conv2/conv3, Decoder
- * convT1/convT2/convT3 of R/snn_model/vae_model.py:115-124,139-155,186. */
+ * convT1/convT2/convT3 of R/snn_model/vae_model.py:115-124,139-155,186.
+ * SPK_MODE_LIF with coef AND out_f32 given: out_f32 [B,Ho*Wo,Cout] also receives sum_t coef[t] * spike[t] (the input of
+ * spk_readout_collapsed_fwd); out_ptc may then be NULL (the spike frames are not stored). */
 int spk_conv_mfma_fused_fwd(const uint8_t* in_ptc, const int8_t* wq, const double* scale, const double* bias_d,
                             const float* bn_a, const float* bn_b, float* v_inout, uint8_t* out_ptc, const float* coef,
                             float* out_f32, uint8_t* out_u8, int apply_tanh, int mode, int T, int B, int H, int W, int Cin,
                             int Cout, int k, int stride, int pad, int transposed, int out_pad, spk_stream_t stream);
+/* The decoder's linear last layer + membrane read-out (R/snn_model/vae_model.py:152-154,186, R/snn_model/snn_layers.py:36-41)
+ * on time-collapsed spikes:  sum_t coef[t] * (W * s_t + bias) = W * (sum_t coef[t] * s_t) + bias * sum_t coef[t].
+ * x_bpc fp32 [B,H*W,Cin] = sum_t coef[t] * s_t (see spk_conv_mfma_fused_fwd); w = the layer's fp32 weight, Conv2d
+ * [Cout,Cin,k,k] or ConvTranspose2d [Cin,Cout,k,k] (transposed = 1); coef_sum = sum_t coef[t]; stride 1, pad == k / 2.
+ * out_f32 [B,Cout,H,W] (tanh if apply_tanh), out_u8 = uint8(clip(p + 0.5, 0, 1) * 255) (R/main.py:401).  fp32 arithmetic:
+ * equal to the frame-by-frame sum up to fp32 round-off. */
+int spk_readout_collapsed_fwd(const float* x_bpc, const float* w, const float* bias_or_null, float coef_sum, float* out_f32,
+                              uint8_t* out_u8, int apply_tanh, int B, int H, int W, int Cin, int Cout, int k, int pad,
+                              int transposed, spk_stream_t stream);
 
 /* ---- vector quantizer ----------------------------------------------------------------------------------------- */
 /* VectorQuantizer.forward eval up to the codebook gather, R/snn_model/vae_model.py:40-52,87-99.

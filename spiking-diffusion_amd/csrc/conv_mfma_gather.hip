@@ -42,7 +42,7 @@ struct GArgs {
   float* v_io;            // [B][Cout][Ho*Wo] or null
   uint8_t* out_ptc;       // MODE_LIF: PTC [B][Ho*Wo][16][Cout]
   const float* coef;      // MODE_MEMOUT: [16]
-  float* out_f32;         // MODE_MEMOUT: [B][Cout][Ho*Wo]
+  float* out_f32;         // MODE_MEMOUT: [B][Cout][Ho*Wo]; MODE_LIF (optional): [B][Ho*Wo][Cout] = sum_t coef[t] * spike[t]
   uint8_t* out_u8;        // MODE_MEMOUT, optional
   int apply_tanh;
   int B, H, W, Cin, Cout, Ho, Wo, k, stride, pad, transposed;
@@ -183,8 +183,14 @@ __global__ __launch_bounds__(256) void conv_mfma_gather_kernel(GArgs a) {
       mybits |= s ? (1u << r) : 0u;
     }
     if (a.v_io && pos_ok && co_ok) a.v_io[vidx] = v;
+    if (a.out_f32 && pos_ok && co_ok) {                            // time-collapsed spikes for a linear read-out layer
+      float m = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = m + ((mybits >> r) & 1u ? a.coef[r] : 0.f);
+      a.out_f32[((long long)b * HWo + opos) * a.Cout + co] = m;
+    }
     const unsigned bitsv = transpose16_rows_g(mybits, lane);      // lane t of each 16-lane row: 16 channel bits of step t
-    if (pos_ok) {
+    if (pos_ok && a.out_ptc) {
       uint4 o;
       o.x = ((bitsv & 0xfu) * 0x00204081u) & 0x01010101u;
       o.y = (((bitsv >> 4) & 0xfu) * 0x00204081u) & 0x01010101u;
@@ -343,8 +349,14 @@ __device__ __forceinline__ void gather2_body(const GArgs& a, int b, int g, int p
       mybits |= s ? (1u << r) : 0u;
     }
     if (a.v_io && pos_ok && co_ok) a.v_io[vidx] = v;
+    if (a.out_f32 && pos_ok && co_ok) {                            // time-collapsed spikes for a linear read-out layer
+      float m = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = m + ((mybits >> r) & 1u ? a.coef[r] : 0.f);
+      a.out_f32[((long long)b * HWo + opos) * a.Cout + co] = m;
+    }
     const unsigned bitsv = transpose16_rows_g(mybits, lane);
-    if (pos_ok) {
+    if (pos_ok && a.out_ptc) {
       uint4 o;
       o.x = ((bitsv & 0xfu) * 0x00204081u) & 0x01010101u;
       o.y = (((bitsv >> 4) & 0xfu) * 0x00204081u) & 0x01010101u;
@@ -422,6 +434,102 @@ int dispatch_gather2(const GArgs& a, hipStream_t stream) {
   if (a.transposed && a.k == 3 && a.stride == 1 && nch == 1) return launch_gather2<MODE, 3, 1, true, 1>(a, stream);     // dec convT3
   return SPK_ERR_UNSUPPORTED;
 }
+
+
+// ------------------------------------------------------------------------------------------------ collapsed read-out
+// The decoder's last layer is linear and followed by the membrane read-out sum_t coef[t] * x[t]
+// (R/snn_model/vae_model.py:152-154,186; R/snn_model/snn_layers.py:36-41):
+//     sum_t coef[t] * (W * s_t + bias) = W * (sum_t coef[t] * s_t) + bias * sum_t coef[t],
+// so the producing layer hands over m = sum_t coef[t] * s_t (fp32 [B][H*W][Cin], spk_conv_mfma_fused_fwd) and this kernel
+// convolves it ONCE instead of sixteen spike frames: 16x less arithmetic, and the [B][H*W][T][Cin] spike tensor between
+// the two layers is never written or read.  fp32 throughout; the result differs from the frame-by-frame sum by fp32
+// round-off only (~1e-7; pixels are compared at 1e-4).  One workgroup = RB output rows of one image: the RB + k - 1 input
+// rows sit in LDS; a thread = one output pixel x one output channel x half of the input channels.
+constexpr int RO_RB = 4;
+struct ROArgs {
+  const float* x; const float* w; const float* bias; float coef_sum;
+  float* out_f32; uint8_t* out_u8; int apply_tanh;
+  int B, H, W, Cin, Cout, k, pad, transposed;
+};
+
+__global__ __launch_bounds__(256) void readout_collapsed_kernel(ROArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float ro_lds[];
+  const int nband = (a.H + RO_RB - 1) / RO_RB;
+  const int b = blockIdx.x / nband, y0 = (blockIdx.x % nband) * RO_RB;
+  const int KK = a.k * a.k;
+  const int rows = RO_RB + a.k - 1;
+  const int Cp = a.Cin + 4;                                   // row pitch in floats (bank spread)
+  float* sx = ro_lds;                                         // [rows][W][Cp]
+  float* sw = ro_lds + rows * a.W * Cp;                       // [Cout][KK][Cin]  (taps as a plain correlation)
+  for (int i = threadIdx.x; i < a.Cout * KK * a.Cin; i += 256) {
+    const int ci = i % a.Cin, tap = (i / a.Cin) % KK, co = i / (a.Cin * KK);
+    // correlation form: out[y][x] += X[y + dy - pad'][x + dx - pad'] * wc[dy][dx]; a stride-1 transposed convolution is the
+    // correlation with the flipped kernel and pad' = k - 1 - pad
+    const int src_tap = a.transposed ? KK - 1 - tap : tap;
+    sw[i] = a.transposed ? a.w[((long long)ci * a.Cout + co) * KK + src_tap] : a.w[((long long)co * a.Cin + ci) * KK + src_tap];
+  }
+  const int padc = a.transposed ? a.k - 1 - a.pad : a.pad;
+  const int q4 = a.Cin >> 2;
+  for (int i = threadIdx.x; i < rows * a.W * q4; i += 256) {
+    const int c4 = i % q4, xx = (i / q4) % a.W, r = i / (q4 * a.W);
+    const int yy = y0 + r - padc;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (yy >= 0 && yy < a.H) v = *reinterpret_cast<const float4*>(a.x + (((long long)b * a.H + yy) * a.W + xx) * a.Cin + 4 * c4);
+    *reinterpret_cast<float4*>(sx + (r * a.W + xx) * Cp + 4 * c4) = v;
+  }
+  __syncthreads();
+  const int npix = RO_RB * a.W;
+  const int hc = a.Cin >> 1;                                  // input channels per thread
+  for (int u = threadIdx.x >> 1; u < npix * a.Cout; u += 128) {
+    const int part = threadIdx.x & 1;
+    const int co = u / npix, pix = u % npix;
+    const int ry = pix / a.W, ox = pix % a.W;
+    float acc = 0.f;
+    for (int dy = 0; dy < a.k; ++dy) {
+      for (int dx = 0; dx < a.k; ++dx) {
+        const int xx = ox + dx - padc;
+        if (xx < 0 || xx >= a.W) continue;
+        const float* xp = sx + ((ry + dy) * a.W + xx) * Cp + part * hc;
+        const float* wp = sw + (co * KK + dy * a.k + dx) * a.Cin + part * hc;
+        for (int c = 0; c < hc; c += 4) {
+          const float4 xv = *reinterpret_cast<const float4*>(xp + c), wv = *reinterpret_cast<const float4*>(wp + c);
+          acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+        }
+      }
+    }
+    acc += __shfl_xor(acc, 1);
+    const int oy = y0 + ry;
+    if (part == 0 && oy < a.H) {
+      const float m = acc + (a.bias ? a.bias[co] * a.coef_sum : 0.f);
+      const float pv = a.apply_tanh ? tanhf(m) : m;
+      const long long oidx = ((long long)b * a.Cout + co) * a.H * a.W + (long long)oy * a.W + ox;
+      if (a.out_f32) a.out_f32[oidx] = pv;
+      if (a.out_u8) a.out_u8[oidx] = (uint8_t)(fminf(fmaxf(pv + 0.5f, 0.0f), 1.0f) * 255.0f);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int spk_readout_collapsed_fwd(const float* x_bpc, const float* w, const float* bias, float coef_sum,
+                                         float* out_f32, uint8_t* out_u8, int apply_tanh, int B, int H, int W, int Cin,
+                                         int Cout, int k, int pad, int transposed, hipStream_t stream) {
+  if (!x_bpc || !w || (!out_f32 && !out_u8) || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || pad < 0)
+    return SPK_ERR_ARG;
+  if ((k & 1) == 0 || pad != k / 2 || (Cin % 8) != 0) return SPK_ERR_UNSUPPORTED;       // "same" geometry, stride 1
+  const size_t lds = ((size_t)(RO_RB + k - 1) * W * (Cin + 4) + (size_t)Cout * k * k * Cin) * sizeof(float);
+  if (lds > 64 * 1024) return SPK_ERR_UNSUPPORTED;
+  ROArgs a;
+  a.x = x_bpc; a.w = w; a.bias = bias; a.coef_sum = coef_sum; a.out_f32 = out_f32; a.out_u8 = out_u8; a.apply_tanh = apply_tanh;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.k = k; a.pad = pad; a.transposed = transposed;
+  const long long blocks = (long long)B * ((H + RO_RB - 1) / RO_RB);
+  if (blocks > 0x7fffffffLL) return SPK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(readout_collapsed_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+namespace {
 
 // ------------------------------------------------------------------------------------------------ weight packing
 // one block per PADDED output channel (ceil(Cout/16)*16): zero digits / zero bias for the padding channels
@@ -513,7 +621,9 @@ extern "C" int spk_conv_mfma_fused_fwd(const uint8_t* in_ptc, const int8_t* wq, 
   if (blocks > 0x7fffffffLL) return SPK_ERR_UNSUPPORTED;
   dim3 grid((unsigned)blocks), blk(256);
   if (mode == SPK_MODE_LIF) {
-    if (!bn_a || !bn_b || !out_ptc) return SPK_ERR_ARG;
+    // (coef AND out_f32 given: out_f32 receives sum_t coef[t] * spike[t] as [B][Ho*Wo][Cout]; out_ptc may then be null)
+    if (!bn_a || !bn_b || (!out_ptc && !(coef && out_f32)) || (out_f32 && !coef)) return SPK_ERR_ARG;
+    if (!coef) a.out_f32 = nullptr;
     if (dispatch_gather2<SPK_MODE_LIF>(a, stream) == SPK_OK) return SPK_OK;          // compile-time geometry
     hipLaunchKernelGGL(conv_mfma_gather_kernel<SPK_MODE_LIF>, grid, blk, 0, stream, a);
   } else if (mode == SPK_MODE_MEMOUT) {

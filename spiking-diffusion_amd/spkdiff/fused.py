@@ -215,6 +215,16 @@ class FusedSequential(nn.Sequential):
             return x
         return self.run(x, IN_SEQ, final='f32')['f32']
 
+    @staticmethod
+    def _collapsible(block, coef, T):
+        """Can the conv-only read-out ``block`` take time-collapsed spikes (ops.readout_collapsed)?"""
+        conv, bn, lif = block
+        if bn is not None or lif is not None or coef is None or T != 16 or has_hooks(conv):
+            return False
+        geo = conv_geometry(conv)
+        return (geo['stride'] == 1 and geo['k'] % 2 == 1 and geo['pad'] == geo['k'] // 2 and geo['out_pad'] == 0 and
+                conv.in_channels % 8 == 0 and ops.readout_collapsed_supported(conv.in_channels, conv.out_channels, geo['k']))
+
     def run(self, x, in_kind, final='f32', T=None, in1=None, coef=None, apply_tanh=False, want_u8=False,
             stateful=True, want_pre=False, chunk_out=None, impl='auto', want_counts=False, need_radius=None):
         """Run all blocks fused.
@@ -325,6 +335,11 @@ class FusedSequential(nn.Sequential):
                     else:
                         out['f32'] = ops.den_conv3x3_mfma(cur, packed, conv.out_channels, mode=MODE_MEAN, in1=src1)
                     continue
+                if kind == 'collapsed':                      # (see the producing block below)
+                    r = ops.readout_collapsed(cur, conv.weight.detach(), bias, coef, apply_tanh=apply_tanh, want_u8=want_u8,
+                                              k=geo['k'], pad=geo['pad'], transposed=geo['transposed'])
+                    out['f32'], out['u8'] = r['f32'], r['u8']
+                    continue
                 # spiking VQ-VAE layers: gather-MFMA kernel (plain PTC input, T = 16)
                 plain_ptc = kind == IN_PTC and cur.dim() == 5 and src1 is None
                 g_mode = MODE_LIF if lif is not None else (MODE_MEMOUT if final == 'memout' else None)
@@ -346,6 +361,14 @@ class FusedSequential(nn.Sequential):
                                 raise RuntimeError(f'LIFNode state has shape {tuple(lif.v.shape)} but the input implies '
                                                    f'{shape}; call functional.reset_net first')
                             v = lif.v
+                        # a linear read-out layer next (conv-only last block + 'memout'): hand it sum_t coef[t] * spikes[t]
+                        # instead of the spike frames -- one convolution instead of T, no spike tensor in between
+                        if (not last and bi == len(blocks) - 2 and final == 'memout' and impl != 'direct' and
+                                self._collapsible(blocks[-1], coef, T)):
+                            cur = ops.conv_mfma_fused(cur, packed, conv.out_channels, mode=MODE_LIF, bn_a=a, bn_b=b, v=v,
+                                                      collapse_coef=coef, **geo)
+                            kind = 'collapsed'
+                            continue
                         o = ops.conv_mfma_fused(cur, packed, conv.out_channels, mode=MODE_LIF, bn_a=a, bn_b=b, v=v, **geo)
                         if last:
                             out['ptc'] = o

@@ -909,14 +909,22 @@ def pack_conv_weight_i8(w, bias, transposed):
 
 
 def conv_mfma_fused(in_ptc, packed, Cout, *, mode, k, stride, pad, transposed=False, out_pad=0, bn_a=None, bn_b=None,
-                    v=None, coef=None, apply_tanh=False, want_u8=False):
-    """in_ptc u8 [B,H,W,16,Cin] -> LIF: spikes u8 [B,Ho,Wo,16,Cout]; MEMOUT: dict(f32=[B,Cout,Ho,Wo], u8=...)."""
+                    v=None, coef=None, apply_tanh=False, want_u8=False, collapse_coef=None):
+    """in_ptc u8 [B,H,W,16,Cin] -> LIF: spikes u8 [B,Ho,Wo,16,Cout]; MEMOUT: dict(f32=[B,Cout,Ho,Wo], u8=...).
+    LIF with collapse_coef [16]: returns sum_t collapse_coef[t] * spikes[t] as fp32 [B,Ho,Wo,Cout] instead of the spikes
+    (input of readout_collapsed)."""
     in_ptc = _dev(in_ptc, "in_ptc", torch.uint8)
     B, H, W, T, Cin = in_ptc.shape
     Ho, Wo = conv_out_size(H, k, stride, pad, transposed, out_pad), conv_out_size(W, k, stride, pad, transposed, out_pad)
     wq, scale, bias_d = packed
     out_p = out_f = out_u = None
-    if mode == MODE_LIF:
+    if mode == MODE_LIF and collapse_coef is not None:
+        coef = _dev(collapse_coef, "collapse_coef", torch.float32)
+        if coef.numel() != T:
+            raise ValueError("collapse_coef must hold one coefficient per time step")
+        out_f = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=in_ptc.device)
+    elif mode == MODE_LIF:
+        coef = None
         out_p = torch.empty((B, Ho, Wo, T, Cout), dtype=torch.uint8, device=in_ptc.device)
     else:
         out_f = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=in_ptc.device)
@@ -925,7 +933,34 @@ def conv_mfma_fused(in_ptc, packed, Cout, *, mode, k, stride, pad, transposed=Fa
     check(lib.spk_conv_mfma_fused_fwd(_p(in_ptc), _p(wq), _p(scale), _p(bias_d), _p(bn_a), _p(bn_b), _p(v), _p(out_p),
                                       _p(coef), _p(out_f), _p(out_u), int(apply_tanh), mode, T, B, H, W, Cin, Cout, k,
                                       stride, pad, int(transposed), out_pad, _stream(in_ptc)), "spk_conv_mfma_fused_fwd")
-    return out_p if mode == MODE_LIF else {"f32": out_f, "u8": out_u}
+    if mode == MODE_LIF:
+        return out_f if collapse_coef is not None else out_p
+    return {"f32": out_f, "u8": out_u}
+
+
+def readout_collapsed_supported(Cin, Cout, k):
+    return Cin % 8 == 0 and k % 2 == 1 and ((4 + k - 1) * 64 * (Cin + 4) + Cout * k * k * Cin) * 4 <= 64 * 1024
+
+
+def readout_collapsed(x_bhwc, weight, bias, coef, *, apply_tanh=False, want_u8=False, k=3, pad=1, transposed=True):
+    """Linear read-out layer on time-collapsed spikes: x_bhwc fp32 [B,H,W,Cin] = sum_t coef[t] * spikes[t] (conv_mfma_fused
+    with collapse_coef) -> dict(f32=[B,Cout,H,W] = conv(x) + bias * sum(coef) (tanh), u8=...).  Stride 1, 'same' padding."""
+    x = _dev(x_bhwc, "x", torch.float32)
+    B, H, W, Cin = x.shape
+    w = _dev(weight, "weight", torch.float32)
+    Cout = w.shape[1] if transposed else w.shape[0]
+    if W > 64 or not readout_collapsed_supported(Cin, Cout, k):
+        raise NotImplementedError("spk_readout_collapsed_fwd: unsupported geometry")
+    if bias is not None:
+        bias = _dev(bias, "bias", torch.float32)
+    out_f = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+    out_u = torch.empty((B, Cout, H, W), dtype=torch.uint8, device=x.device) if want_u8 else None
+    csum = 0.0
+    for c in coef.detach().reshape(-1).float().cpu().tolist():          # fp32 left-to-right, as torch.sum over T would add
+        csum = float(torch.tensor(csum, dtype=torch.float32) + torch.tensor(c, dtype=torch.float32))
+    check(lib.spk_readout_collapsed_fwd(_p(x), _p(w), _p(bias), float(csum), _p(out_f), _p(out_u), int(apply_tanh), B, H, W,
+                                        Cin, Cout, int(k), int(pad), int(transposed), _stream(x)), "spk_readout_collapsed_fwd")
+    return {"f32": out_f, "u8": out_u}
 
 
 # ---------------------------------------------------------------------------------------------- VQ

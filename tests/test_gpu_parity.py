@@ -644,6 +644,52 @@ def test_fp6v2_listed_positions_equal_the_full_layer(dev, ops, B, t):
 
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,transposed", [(3, 28, 28, 32, 1, True), (2, 32, 32, 32, 3, True), (5, 9, 13, 16, 2, False)])
+def test_collapsed_readout_layer(dev, ops, B, H, W, Cin, Cout, transposed):
+    """spk_readout_collapsed_fwd (the decoder's linear last layer applied ONCE to sum_t coef[t] * spikes[t]) against
+    sum_t coef[t] * conv(spikes[t]) evaluated frame by frame in fp64; and the producing gather-MFMA layer's collapsed
+    output against its own spike frames."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(B * 7 + H)
+    T = 16
+    spikes = (torch.rand(T, B, Cin, H, W, generator=g) < 0.2).float()
+    coef = torch.pow(torch.tensor(0.8), torch.arange(T - 1, -1, -1).float())
+    w = (torch.rand((Cin, Cout, 3, 3) if transposed else (Cout, Cin, 3, 3), generator=g) - 0.5) * 0.4
+    bias = (torch.rand(Cout, generator=g) - 0.5)
+    conv = (lambda x: F.conv_transpose2d(x, w.double(), bias.double(), stride=1, padding=1)) if transposed else \
+           (lambda x: F.conv2d(x, w.double(), bias.double(), stride=1, padding=1))
+    want = sum(coef[t].double() * conv(spikes[t].double()) for t in range(T))
+    x = (spikes * coef.view(T, 1, 1, 1, 1)).sum(0).permute(0, 2, 3, 1).contiguous()          # [B,H,W,Cin]
+    r = ops.readout_collapsed(x.to(dev), w.to(dev), bias.to(dev), coef, apply_tanh=True, want_u8=True, transposed=transposed)
+    err = float((r["f32"].cpu().double() - torch.tanh(want)).abs().max())
+    assert err <= 2e-6, err
+    u8 = (torch.clamp(torch.tanh(want).float() + 0.5, 0, 1) * 255).to(torch.uint8)
+    assert int((r["u8"].cpu().int() - u8.int()).abs().max()) <= 1
+    parity(f"collapsed_readout_{H}x{W}_c{Cout}", max_abs_err=err)
+
+
+def test_gather_layer_collapsed_output_matches_its_spikes(dev, ops):
+    """spk_conv_mfma_fused_fwd with coef + out_f32 in LIF mode: the collapsed tensor equals sum_t coef[t] * (its own spike
+    frames), bit for bit (same fp32 additions in the same order)."""
+    g = torch.Generator().manual_seed(5)
+    B, Cin, Cout, H = 3, 64, 32, 14
+    spikes = (torch.rand(16, B, Cin, H, H, generator=g) < 0.15).float().to(dev)
+    w = ((torch.rand(Cin, Cout, 3, 3, generator=g) - 0.5) * 0.3).to(dev)
+    bias = ((torch.rand(Cout, generator=g) - 0.5) * 0.1).to(dev)
+    a = (torch.rand(Cout, generator=g) * 2 + 0.5).to(dev); b = ((torch.rand(Cout, generator=g) - 0.5)).to(dev)
+    coef = torch.pow(torch.tensor(0.8), torch.arange(15, -1, -1).float()).to(dev)
+    pk = ops.pack_conv_weight_i8(w, bias, True)
+    geo = dict(k=3, stride=2, pad=1, transposed=True, out_pad=1)
+    ptc = ops.spikes_to_ptc(spikes)
+    s = ops.conv_mfma_fused(ptc, pk, Cout, mode=ops.MODE_LIF, bn_a=a, bn_b=b, **geo)           # [B,Ho,Wo,16,Cout] u8
+    c = ops.conv_mfma_fused(ptc, pk, Cout, mode=ops.MODE_LIF, bn_a=a, bn_b=b, collapse_coef=coef, **geo)
+    want = torch.zeros_like(c)
+    for t in range(16):
+        want = want + s[:, :, :, t, :].float() * coef[t]
+    assert torch.equal(c, want) and float(c.max()) > 0
+
+
+
 # ------------------------------------------------------------------------------------------------- F8 LIF training
 @pytest.mark.parametrize("det", [False, True])
 def test_f8_lif_training_bptt_vs_reference_fixture(golden_dir, dev, det):
