@@ -36,7 +36,15 @@ __device__ __forceinline__ unsigned transpose16_rows_g(unsigned x, int lane) {
   return x;
 }
 
+__device__ __forceinline__ unsigned spread8_g(unsigned x) {        // bit k -> nibble k, as the e2m1 code of 1.0 (0x2)
+  x = (x | (x << 12)) & 0x000f000fu;
+  x = (x | (x << 6)) & 0x03030303u;
+  x = (x | (x << 3)) & 0x11111111u;
+  return x << 1;
+}
+
 struct GArgs {
+  uint8_t* out_s32;       // MODE_LIF, optional: nibble-packed "S32" spikes [B][Cout/32][Ho*Wo][16][16 B] (den_mfma_fp6v2.hip)
   const uint8_t* in;      // PTC [B][H*W][16][Cin]
   const int8_t* wq; const double* scale; const double* bias; const float* bn_a; const float* bn_b;
   float* v_io;            // [B][Cout][Ho*Wo] or null
@@ -190,6 +198,13 @@ __global__ __launch_bounds__(256) void conv_mfma_gather_kernel(GArgs a) {
       a.out_f32[((long long)b * HWo + opos) * a.Cout + co] = m;
     }
     const unsigned bitsv = transpose16_rows_g(mybits, lane);      // lane t of each 16-lane row: 16 channel bits of step t
+    if (pos_ok && a.out_s32) {                                     // this task's 16 channels = half of a 32-channel record
+      uint2 o2;
+      o2.x = spread8_g(bitsv & 0xffu);
+      o2.y = spread8_g((bitsv >> 8) & 0xffu);
+      *reinterpret_cast<uint2*>(a.out_s32 + ((((long long)b * (a.Cout >> 5) + (g >> 1)) * HWo + opos) * T16 + (lane & 15)) * 16 +
+                                8 * (g & 1)) = o2;
+    }
     if (pos_ok && a.out_ptc) {
       uint4 o;
       o.x = ((bitsv & 0xfu) * 0x00204081u) & 0x01010101u;
@@ -356,6 +371,13 @@ __device__ __forceinline__ void gather2_body(const GArgs& a, int b, int g, int p
       a.out_f32[((long long)b * HWo + opos) * a.Cout + co] = m;
     }
     const unsigned bitsv = transpose16_rows_g(mybits, lane);
+    if (pos_ok && a.out_s32) {                                     // this task's 16 channels = half of a 32-channel record
+      uint2 o2;
+      o2.x = spread8_g(bitsv & 0xffu);
+      o2.y = spread8_g((bitsv >> 8) & 0xffu);
+      *reinterpret_cast<uint2*>(a.out_s32 + ((((long long)b * (a.Cout >> 5) + (g >> 1)) * HWo + opos) * T16 + (lane & 15)) * 16 +
+                                8 * (g & 1)) = o2;
+    }
     if (pos_ok && a.out_ptc) {
       uint4 o;
       o.x = ((bitsv & 0xfu) * 0x00204081u) & 0x01010101u;
@@ -529,6 +551,36 @@ extern "C" int spk_readout_collapsed_fwd(const float* x_bpc, const float* w, con
   return SPK_OK;
 }
 
+// LIF form with nibble-packed "S32" output (Cout % 32 == 0): the input layout of the fp6 kernels (vae_fp6.hip)
+extern "C" int spk_conv_mfma_fused_lif_s32(const uint8_t* in_ptc, const int8_t* wq, const double* scale, const double* bias_d,
+                                           const float* bn_a, const float* bn_b, float* v_inout, uint8_t* out_s32, int T, int B,
+                                           int H, int W, int Cin, int Cout, int k, int stride, int pad, int transposed,
+                                           int out_pad, hipStream_t stream) {
+  if (!in_ptc || !wq || !scale || !bias_d || !bn_a || !bn_b || !out_s32 || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 ||
+      Cout <= 0 || k <= 0 || stride <= 0 || pad < 0)
+    return SPK_ERR_ARG;
+  if (T != T16 || (Cin % 16) != 0 || (Cout % 32) != 0) return SPK_ERR_UNSUPPORTED;
+  GArgs a;
+  a.out_s32 = out_s32;
+  a.in = in_ptc; a.wq = wq; a.scale = scale; a.bias = bias_d; a.bn_a = bn_a; a.bn_b = bn_b; a.v_io = v_inout;
+  a.out_ptc = nullptr; a.coef = nullptr; a.out_f32 = nullptr; a.out_u8 = nullptr; a.apply_tanh = 0;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.k = k; a.stride = stride; a.pad = pad;
+  a.transposed = transposed;
+  a.Ho = spk_conv_out_size(H, k, stride, pad, transposed, out_pad);
+  a.Wo = spk_conv_out_size(W, k, stride, pad, transposed, out_pad);
+  if (a.Ho <= 0 || a.Wo <= 0) return SPK_ERR_ARG;
+  if (dispatch_gather2<SPK_MODE_LIF>(a, stream) == SPK_OK) return SPK_OK;
+  const int ncls = transposed ? stride * stride : 1;
+  const int Hc0 = transposed ? (a.Ho + stride - 1) / stride : a.Ho;
+  const int Wc0 = transposed ? (a.Wo + stride - 1) / stride : a.Wo;
+  const long long tasks = (long long)B * ncls * (((long long)Hc0 * Wc0 + 3) / 4) * ((Cout + 15) / 16);
+  const long long blocks = (tasks + 3) / 4;
+  if (blocks > 0x7fffffffLL) return SPK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(conv_mfma_gather_kernel<SPK_MODE_LIF>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------ weight packing
@@ -605,6 +657,7 @@ extern "C" int spk_conv_mfma_fused_fwd(const uint8_t* in_ptc, const int8_t* wq, 
     return SPK_ERR_ARG;
   if (T != T16 || (Cin % 16) != 0) return SPK_ERR_UNSUPPORTED;
   GArgs a;
+  a.out_s32 = nullptr;
   a.in = in_ptc; a.wq = wq; a.scale = scale; a.bias = bias_d; a.bn_a = bn_a; a.bn_b = bn_b; a.v_io = v_inout;
   a.out_ptc = out_ptc; a.coef = coef; a.out_f32 = out_f32; a.out_u8 = out_u8; a.apply_tanh = apply_tanh;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.k = k; a.stride = stride; a.pad = pad;

@@ -1,0 +1,411 @@
+// Decoder ConvTranspose2d(64 -> 32, k3, s2, p1, op1) + BN + LIF on the block-scaled fp6 x fp4 MFMA, for the call that feeds
+// the linear read-out layer (R/snn_model/vae_model.py:146-154).  Same arithmetic contract as
+// den_mfma_fp6v2.hip: 29-bit per-channel fixed-point weights as radix-32 digits, adjacent digits sharing an fp32 accumulator
+// through the per-block scales, five digits on the matrix cores, every spike decision certified against a running error
+// bound, the few neurons that come within the bound of the threshold recomputed exactly (all six digits, 64-bit sums, fp64
+// recombination, one rounding) by a tail launch.  Unflagged neurons provably emit the exact path's spikes; the result is the
+// one spk_conv_mfma_fused_fwd produces for the same layer.
+//
+// What differs from the denoiser kernel is the geometry.  A stride-2 transposed convolution is four sub-pixel classes
+// (oy % 2, ox % 2) with 1 / 2 / 2 / 4 contributing taps; the rows of a 32-row MFMA tile are two horizontally adjacent
+// positions of ONE class x 16 time steps, so the tap list of a tile is compile-time.  K is small (2 chunks of 32 channels)
+// and there is one group of 32 output channels: all 45 weight tiles of the group (9 taps x [pair 01, pair 23] x 2 chunks +
+// 9 fifth-digit tiles whose K halves are the two chunks) stay in LDS for the whole launch (68 KB), next to HALF an input
+// image (H/2 + 1 rows, zero column on the right: 60 KB at 14 x 14).  A work item = one image half x one channel group =
+// 4 classes x (H/2 x W/2) tiles; the eight waves of a workgroup (two per SIMD: one multiplies while the other scans) take
+// tiles two at a time -- a weight tile read from LDS serves both.  The layer is bound by the vector work of the LIF scan
+// (16 steps x ~14 instructions per neuron), not by the matrix pipe or memory.
+//
+// Output: this first form emits the time-collapsed spikes m = sum_t coef[t] * s_t (fp32 [B][Ho*Wo][Cout]) that
+// spk_readout_collapsed_fwd consumes -- the spike frames themselves are never stored.
+#include "den_common.h"
+#include "../../include/spkdiff.h"
+#include <math.h>
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int T16 = 16;
+constexpr int POSB = 256;                    // bytes per position and 32-channel chunk: 16 steps x 16 B
+constexpr int WT = 1536;                     // one B tile: 64 lanes x 32 six-bit codes
+constexpr int TPT = 5;                       // tiles per tap: pair01 c0, pair23 c0, pair01 c1, pair23 c1, fifth digit (c0 | c1)
+constexpr int NTILE = 9 * TPT;
+constexpr int W_BYTES = NTILE * WT;          // 69120 per channel group
+constexpr unsigned FLAG_CAP = 1u << 20;
+
+struct TArgs {
+  const uint8_t* in;                         // S32 [B][2][H*W][16][16 B]
+  const uint8_t* wq; const double* scale; const double* bias; const float* bn_a; const float* bn_b; const float* coef;
+  float* out_col;                            // [B][Ho*Wo][Cout]
+  unsigned* flags; unsigned flag_cap; const int* qtab;       // qtab int32 [Cout][9][Cin]
+  int B, Cout, Cin;
+};
+
+template <typename F, int... S>
+__device__ __forceinline__ void tfor_impl(F&& f, std::integer_sequence<int, S...>) {
+  (f(std::integral_constant<int, S>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void tfor(F&& f) {
+  tfor_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+constexpr float CERT_4EPS = 4.0f * 2.38418579e-07f;
+
+template <int H, int W>
+__global__ __launch_bounds__(512, 1) void convT_s2_fp6_kernel(TArgs a) {
+  constexpr int NCH = 2, HB = H / 2, PWc = W + 1, ROWS = HB + 1;
+  constexpr int A_CH = ROWS * PWc * POSB, A_BYTES = NCH * A_CH;
+  constexpr int TPR = W / 2, NTC = HB * TPR;               // tiles per class row / per class and item
+  constexpr int PPR = (W + 3) / 4;                         // 1 KiB DMA pieces per image row
+  constexpr int Ho = 2 * H, Wo = 2 * W;
+  static_assert((H % 2) == 0 && (W % 2) == 0, "even input extents");
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  uint8_t* const sA = lds;
+  uint8_t* const sW = lds + A_BYTES;
+  const unsigned sA_addr = spk_lds_addr(sA);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = a.Cout >> 5;
+  const int g = blockIdx.x % G, il = blockIdx.x / G, lanes = gridDim.x / G;
+
+  {  // the group's weight tiles and a zeroed input slab (its right column and, for the lower half, its last row stay zero)
+    const uint4* src = reinterpret_cast<const uint4*>(a.wq + (long long)g * W_BYTES);
+    for (int i = tid; i < W_BYTES / 16; i += 512) reinterpret_cast<uint4*>(sW)[i] = src[i];
+    for (int i = tid; i < A_BYTES / 16; i += 512) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+
+  const int co = g * 32 + (lane & 31);
+  const float scale_f = (float)a.scale[co], bias_f = (float)a.bias[co];
+  const float bna = a.bn_a[co], bnb = a.bn_b[co];
+  const float Ac = 32.0f * scale_f * bna;                   // z = fma(Q5, Ac, Bc),  Q5 = P01 * 2^15 + P23 * 2^5 + P4
+  const float Bc = fmaf(bias_f, bna, bnb);
+  // certification constant (den_mfma_fp6v2.hip "Certification"): the dropped sixth digit moves a pre-activation by at most
+  // 16 units of 2^-s per active input, at most 4 taps x Cin inputs reach an output of this layer
+  const float E5 = 16.0f * 4.0f * (float)a.Cin * scale_f;
+  const float cE = fabsf(bna) * E5 + 2.0f * 2.38418579e-07f * (fabsf(bnb) + fabsf(Bc)) + 1e-30f;
+  float coef[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) coef[r] = a.coef[r];
+
+  const int row = lane & 31, half = lane >> 5;
+  const int hsel = (row >> 2) & 1, tt = (row & 3) + 4 * (row >> 3);
+  const int sc_a = 0x7f7f7f7f;
+  const int sc_p = half ? (int)0x82828282u : (int)0x87878787u;     // even digit (K half 0) x 2^8, odd digit x 2^3
+  const int sc_4 = (int)0x82828282u;                                // fifth digit x 2^3
+  const unsigned lane16 = (unsigned)lane * 16u;
+
+  for (int itm = il; itm < 2 * a.B; itm += lanes) {
+    const int b = itm >> 1, hb = itm & 1;
+    // ---- stage the input rows hb * HB .. hb * HB + HB of both chunks (row H does not exist: zeros)
+    for (int id = wave; id < NCH * ROWS * PPR; id += 8) {
+      const int c = id / (ROWS * PPR), rr = (id / PPR) % ROWS, px4 = id % PPR;
+      const int iy = hb * HB + rr;
+      if (iy < H) {
+        const int np = (W - 4 * px4) < 4 ? (W - 4 * px4) : 4;
+        const unsigned long long mask = np == 4 ? ~0ull : ((1ull << (16 * np)) - 1ull);
+        const uint8_t* src = a.in + (((long long)b * NCH + c) * H * W + iy * W + 4 * px4) * POSB;
+        spk_dma16s_masked(src, lane16, sA_addr + c * A_CH + (rr * PWc + 4 * px4) * POSB, mask);
+      }
+    }
+    if (hb * HB + ROWS - 1 >= H) {
+      for (int i = tid; i < NCH * W * POSB / 16; i += 512) {
+        const int c = i / (W * POSB / 16), o = i % (W * POSB / 16);
+        reinterpret_cast<uint4*>(sA + c * A_CH + (ROWS - 1) * PWc * POSB)[o] = make_uint4(0, 0, 0, 0);
+      }
+    }
+    spk_dma_wait_all();
+    __syncthreads();
+
+    tfor<4>([&](auto cls_tag) {
+      constexpr int CLS = decltype(cls_tag)::value, PY = CLS >> 1, PX = CLS & 1;
+      const int first = (wave - 2 * CLS) & 7;               // the 49th tile of a class lands on a different wave per class
+      for (int t0 = first; t0 < NTC; t0 += 16) {
+        const int t1 = t0 + 8;
+        const bool v1 = t1 < NTC;
+        const int tl[2] = {t0, v1 ? t1 : t0};
+        int base[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = tl[i] / TPR, j = tl[i] - r * TPR;
+          base[i] = (r * PWc + 2 * j + hsel) * POSB + tt * 16;
+        }
+        v16f acc[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        auto ldb = [&](int tile) -> v8i {
+          const uint8_t* p = sW + tile * WT;
+          const v4i x = *reinterpret_cast<const v4i*>(p + lane * 16);
+          const v2i y = *reinterpret_cast<const v2i*>(p + 1024 + lane * 8);
+          return v8i{x[0], x[1], x[2], x[3], y[0], y[1], 0, 0};
+        };
+        auto mm = [&](v16f& d, const v4i& av, const v8i& bv, int sb) {
+          const v8i a8 = {av[0], av[1], av[2], av[3], 0, 0, 0, 0};
+          d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, bv, d, 4, 2, 0, sc_a, 0, sb);
+        };
+        tfor<9>([&](auto tap_tag) {
+          constexpr int TAP = decltype(tap_tag)::value, KY = TAP / 3, KX = TAP % 3;
+          // oy = 2 iy - 1 + ky: class parity PY takes ky = 1 (iy = qy) when even, ky = 0 (iy = qy + 1) and ky = 2 (iy = qy) when odd
+          constexpr bool ON = (PY == 0 ? KY == 1 : KY != 1) && (PX == 0 ? KX == 1 : KX != 1);
+          if constexpr (ON) {
+            constexpr int DY = (PY == 1 && KY == 0) ? 1 : 0, DX = (PX == 1 && KX == 0) ? 1 : 0;
+            constexpr int TOFF = (DY * PWc + DX) * POSB;
+            v4i av[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              av[i][0] = *reinterpret_cast<const v4i*>(sA + base[i] + TOFF);
+              av[i][1] = *reinterpret_cast<const v4i*>(sA + A_CH + base[i] + TOFF);
+            }
+            const v8i b0 = ldb(TAP * TPT + 0), b1 = ldb(TAP * TPT + 1), b2 = ldb(TAP * TPT + 2), b3 = ldb(TAP * TPT + 3),
+                      b4 = ldb(TAP * TPT + 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              mm(acc[i][0], av[i][0], b0, sc_p);
+              mm(acc[i][1], av[i][0], b1, sc_p);
+              mm(acc[i][0], av[i][1], b2, sc_p);
+              mm(acc[i][1], av[i][1], b3, sc_p);
+              const v4i a4 = half ? av[i][1] : av[i][0];
+              mm(acc[i][2], a4, b4, sc_4);
+            }
+          }
+        });
+        // ---- epilogue: fp32 recombination, BN, LIF scan with certification, time-collapsed output
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float v = 0.f, D = 0.f, m = 0.f;
+          bool flg = false;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float q5 = fmaf(fmaf(acc[i][0][r], 1024.0f, acc[i][1][r]), 32.0f, acc[i][2][r]);
+            const float z = fmaf(q5, Ac, Bc);
+            D = fmaf(fabsf(z) + fabsf(v), CERT_4EPS, fmaf(D, 0.5f, cE));
+            const float h = v + (z - v) * 0.5f;
+            const bool s = h >= 1.0f;
+            flg = flg || (fabsf(h - 1.0f) <= D);
+            v = s ? 0.0f : h;
+            m = m + (s ? coef[r] : 0.f);
+          }
+          if (i == 1 && !v1) continue;
+          const int r_ = tl[i] / TPR, j_ = tl[i] - r_ * TPR;
+          const int oy = 2 * (hb * HB + r_) + PY, ox = 2 * (2 * j_ + half) + PX;   // accumulator lane half == position in the tile
+          const long long pos = ((long long)b * Ho + oy) * Wo + ox;
+          if (flg) {
+            const long long n = pos * a.Cout + co;
+            const unsigned idx = atomicAdd(a.flags, 1u);
+            if (idx < a.flag_cap) a.flags[2 + idx] = (unsigned)n;
+            else atomicOr(a.flags + 2 + a.flag_cap + (n >> 5), 1u << (n & 31));
+          }
+          a.out_col[pos * a.Cout + co] = m;
+        }
+      }
+    });
+    __syncthreads();                                           // everyone is done with the slab before the next copy lands
+  }
+  spk_dma_wait_all();
+}
+
+// One flagged neuron, exactly, by one wave: lane = (time step t, quarter of a 32-channel chunk); every contributing tap and
+// chunk costs one 4-byte read of the spike record and eight quantised weights; 64-bit sums meet through two shuffles, then
+// lane 0 runs the reference's BN and LIF steps on the correctly rounded pre-activations and rewrites the collapsed value.
+template <int H, int W>
+__device__ __forceinline__ void convT_fix_neuron(const TArgs& a, long long n, int lane) {
+  constexpr int Ho = 2 * H, Wo = 2 * W, NCH = 2;
+  const int co = (int)(n % a.Cout);
+  const long long pos = n / a.Cout;
+  const int ox = (int)(pos % Wo), oy = (int)((pos / Wo) % Ho), b = (int)(pos / ((long long)Wo * Ho));
+  const int t = lane & 15, q = lane >> 4;
+  long long part = 0;
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ty = oy + 1 - ky;
+    if (ty < 0 || (ty & 1) || (ty >> 1) >= H) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int tx = ox + 1 - kx;
+      if (tx < 0 || (tx & 1) || (tx >> 1) >= W) continue;
+      const int iy = ty >> 1, ix = tx >> 1, tap = ky * 3 + kx;
+      for (int c = 0; c < NCH; ++c) {
+        const unsigned nib = *reinterpret_cast<const unsigned*>(a.in + ((((long long)b * NCH + c) * H * W + iy * W + ix) * T16 + t) * 16 + 4 * q);
+        const int4* qp = reinterpret_cast<const int4*>(a.qtab + ((long long)co * 9 + tap) * a.Cin + c * 32 + 8 * q);
+        const int4 q0 = qp[0], q1 = qp[1];
+        part += (nib & 0x0000000fu) ? (long long)q0.x : 0ll;
+        part += (nib & 0x000000f0u) ? (long long)q0.y : 0ll;
+        part += (nib & 0x00000f00u) ? (long long)q0.z : 0ll;
+        part += (nib & 0x0000f000u) ? (long long)q0.w : 0ll;
+        part += (nib & 0x000f0000u) ? (long long)q1.x : 0ll;
+        part += (nib & 0x00f00000u) ? (long long)q1.y : 0ll;
+        part += (nib & 0x0f000000u) ? (long long)q1.z : 0ll;
+        part += (nib & 0xf0000000u) ? (long long)q1.w : 0ll;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+    const int lo = __shfl_xor((int)(unsigned)(part & 0xffffffffll), off);
+    const int hi = __shfl_xor((int)(part >> 32), off);
+    part += (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+  }
+  const double sc = a.scale[co], bi = a.bias[co];
+  const float bna = a.bn_a[co], bnb = a.bn_b[co];
+  float v = 0.f, m = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int lo = __shfl((int)(unsigned)(part & 0xffffffffll), r);
+    const int hi = __shfl((int)(part >> 32), r);
+    const long long S = (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+    const float y = (float)fma((double)S, sc, bi);
+    const bool s = spk_lif_step_default(v, fmaf(y, bna, bnb));
+    m = m + (s ? a.coef[r] : 0.f);
+  }
+  if (lane == 0) a.out_col[n] = m;
+}
+
+template <int H, int W>
+__global__ __launch_bounds__(256) void convT_fp6_fixup_kernel(TArgs a, long long n_words) {
+  const int lane = threadIdx.x & 63;
+  const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwv = (long long)gridDim.x * 4;
+  const unsigned count = a.flags[0];
+  const unsigned nlist = count < a.flag_cap ? count : a.flag_cap;
+  for (long long e = wv; e < nlist; e += nwv) convT_fix_neuron<H, W>(a, (long long)a.flags[2 + e], lane);
+  if (count > a.flag_cap) {                  // overflow: the rest sit in the bitmap; every wave scans a share, clearing as it goes
+    unsigned* bm = a.flags + 2 + a.flag_cap;
+    for (long long wi = wv; wi < n_words; wi += nwv) {
+      unsigned wd = bm[wi];
+      if (wd && lane == 0) bm[wi] = 0u;
+      while (wd) {
+        const int bit = __ffs((int)wd) - 1;
+        wd &= wd - 1;
+        convT_fix_neuron<H, W>(a, wi * 32 + bit, lane);
+      }
+    }
+  }
+}
+
+__global__ void convT_fp6_reset_kernel(unsigned* flags) {
+  if (threadIdx.x == 0) flags[0] = 0u;
+}
+
+// one block per output channel: channel maximum -> shift s, every weight -> six balanced radix-32 digits; the per-lane
+// 24-byte B fragments of tile (tap, j): j = 0..3: chunk j / 2, digit pair j % 2 (K half 0: even digit, half 1: odd digit, the
+// same 32 input channels); j = 4: the fifth digit, K half 0 = chunk 0, half 1 = chunk 1.  Also the quantised weights
+// themselves (int32 [Cout][9][Cin]) for the exact recomputation.
+__global__ __launch_bounds__(256) void pack_convT_fp6_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                             uint8_t* __restrict__ wq, double* __restrict__ scale,
+                                                             double* __restrict__ bias_d, int* __restrict__ qtab, int Cout,
+                                                             int Cin) {
+  __shared__ float smax[256];
+  const int co = blockIdx.x, n = Cin * 9;
+  auto wat = [&](int ci, int tap) -> float { return w[((long long)ci * Cout + co) * 9 + tap]; };   // ConvTranspose2d [Cin][Cout][3][3]
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(wat(i / 9, i % 9)));
+  smax[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s]);
+    __syncthreads();
+  }
+  m = smax[0];
+  int e = 0;
+  if (m > 0.f) frexpf(m, &e);
+  const int sh = 29 - e;                      // |w| * 2^sh < 2^29 <= 16.5 * 32^5
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int ci = i / 9, tap = i - 9 * ci;
+    qtab[((long long)co * 9 + tap) * Cin + ci] = (int)rint(ldexp((double)wat(ci, tap), sh));
+  }
+  if (threadIdx.x == 0) { scale[co] = ldexp(1.0, -sh); bias_d[co] = bias ? (double)bias[co] : 0.0; }
+  const int g = co >> 5, col = co & 31;
+  for (int rec = threadIdx.x; rec < NTILE * 2; rec += 256) {
+    const int kh = rec & 1, tau = rec >> 1, tap = tau / TPT, j = tau % TPT;
+    const int chunk = j < 4 ? (j >> 1) : kh, digit = j < 4 ? 2 * (j & 1) + kh : 4;
+    unsigned bits[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 32; ++k) {
+      const int ci = chunk * 32 + k;
+      long long q = ci < Cin ? (long long)rint(ldexp((double)wat(ci, tap), sh)) : 0ll;
+      int dg[6];
+#pragma unroll
+      for (int p = 5; p >= 1; --p) {
+        const int r = (int)(((q + 16) & 31) - 16);
+        dg[p] = r;
+        q = (q - r) >> 5;
+      }
+      dg[0] = (int)q;
+      int d = 0;
+#pragma unroll
+      for (int p = 0; p < 6; ++p) d = (p == digit) ? dg[p] : d;
+      const unsigned code = (d < 0 ? 0x20u : 0u) | (unsigned)(d < 0 ? -d : d);
+      const int bit = 6 * k, wd = bit >> 5, sft = bit & 31;
+#pragma unroll
+      for (int q2 = 0; q2 < 6; ++q2) {
+        if (q2 == wd) bits[q2] |= code << sft;
+        if (q2 == wd + 1 && sft > 26) bits[q2] |= code >> (32 - sft);
+      }
+    }
+    uint8_t* tile = wq + ((long long)g * NTILE + tau) * WT;
+    const int ln = kh * 32 + col;
+    unsigned* d16 = reinterpret_cast<unsigned*>(tile + ln * 16);
+    unsigned* d8 = reinterpret_cast<unsigned*>(tile + 1024 + ln * 8);
+    d16[0] = bits[0]; d16[1] = bits[1]; d16[2] = bits[2]; d16[3] = bits[3];
+    d8[0] = bits[4]; d8[1] = bits[5];
+  }
+}
+
+template <int H, int W>
+int launch_convT(const TArgs& a, long long n_words, hipStream_t stream) {
+  constexpr int A_BYTES = 2 * (H / 2 + 1) * (W + 1) * POSB;
+  const size_t lds = (size_t)A_BYTES + W_BYTES;
+  if (lds > 160 * 1024) return SPK_ERR_UNSUPPORTED;
+  const int cus = spk_cu_count(), G = a.Cout / 32;
+  const int grid = cus >= G ? (cus / G) * G : G;
+  hipLaunchKernelGGL((convT_s2_fp6_kernel<H, W>), dim3(grid), dim3(512), lds, stream, a);
+  SPK_LAUNCH_CHECK();
+  hipLaunchKernelGGL((convT_fp6_fixup_kernel<H, W>), dim3(4 * cus), dim3(256), 0, stream, a, n_words);
+  SPK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(convT_fp6_reset_kernel, dim3(1), dim3(64), 0, stream, a.flags);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+}  // namespace
+
+extern "C" long long spk_convt_fp6_packed_bytes(int Cout, int Cin) {
+  if (Cout <= 0 || Cin != 64 || (Cout % 32)) return -1;
+  return (long long)(Cout / 32) * W_BYTES;
+}
+
+extern "C" int spk_convt_fp6_pack(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d, int* qtab,
+                                  int Cout, int Cin, hipStream_t stream) {
+  if (!w || !wq || !scale || !bias_d || !qtab || Cout <= 0 || Cin <= 0) return SPK_ERR_ARG;
+  if (Cin != 64 || (Cout % 32)) return SPK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(pack_convT_fp6_kernel, dim3(Cout), dim3(256), 0, stream, w, bias, wq, scale, bias_d, qtab, Cout, Cin);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" long long spk_convt_fp6_flag_words(int B, int Cout, int H, int W) {
+  if (B <= 0 || Cout <= 0 || H <= 0 || W <= 0) return -1;
+  return 2 + (long long)FLAG_CAP + ((long long)B * Cout * 4 * H * W + 31) / 32;
+}
+
+extern "C" int spk_convt_fp6_collapsed_fwd(const uint8_t* in_s32, const uint8_t* wq, const double* scale,
+                                           const double* bias_d, const int* qtab, const float* bn_a, const float* bn_b,
+                                           const float* coef, float* out_col, unsigned* flag_words, int T, int B, int H, int W,
+                                           int Cin, int Cout, hipStream_t stream) {
+  if (!in_s32 || !wq || !scale || !bias_d || !qtab || !bn_a || !bn_b || !coef || !out_col || !flag_words || B <= 0)
+    return SPK_ERR_ARG;
+  if (T != T16 || Cin != 64 || (Cout % 32) || B > (1 << 22)) return SPK_ERR_UNSUPPORTED;
+  TArgs a;
+  a.in = in_s32; a.wq = wq; a.scale = scale; a.bias = bias_d; a.bn_a = bn_a; a.bn_b = bn_b; a.coef = coef; a.out_col = out_col;
+  a.flags = flag_words; a.flag_cap = FLAG_CAP; a.qtab = qtab; a.B = B; a.Cout = Cout; a.Cin = Cin;
+  const long long n_words = ((long long)B * Cout * 4 * H * W + 31) / 32;
+  if ((long long)B * Cout * 4 * H * W >= (1ll << 32)) return SPK_ERR_UNSUPPORTED;          // neuron ids are 32-bit
+  if (H == 14 && W == 14) return launch_convT<14, 14>(a, n_words, stream);
+  if (H == 16 && W == 16) return launch_convT<16, 16>(a, n_words, stream);
+  return SPK_ERR_UNSUPPORTED;
+}

@@ -35,7 +35,7 @@ class ConvParams:
     def invalidate(self):
         """Forget every derived form (call after writing weights through ``.data``: that does not bump ``_version``)."""
         self.key = self.key_i8 = None
-        self.key_fp6 = self.key_i8g = self.key_fp6v2 = None
+        self.key_fp6 = self.key_i8g = self.key_fp6v2 = self.key_convT_fp6 = None
 
     def get(self, conv):
         key = (_ver(conv.weight), _ver(conv.bias))
@@ -59,6 +59,14 @@ class ConvParams:
             self.fp6 = ops.den_pack_weight_fp6(conv.weight, conv.bias)
             self.key_fp6 = key
         return self.fp6
+
+    def get_convT_fp6(self, conv):
+        """digit tiles of the decoder's fp6 transposed-convolution kernel (csrc/vae_fp6.hip), built on first use."""
+        key = (_ver(conv.weight), _ver(conv.bias))
+        if key != getattr(self, 'key_convT_fp6', None):
+            self.convT_fp6 = ops.convT_fp6_pack(conv.weight, conv.bias)
+            self.key_convT_fp6 = key
+        return self.convT_fp6
 
     def get_fp6v2(self, conv):
         """digit tiles of the second-generation fp6 kernel (+ scale / bias / L1 norms / an fp32 copy), built on first use."""
@@ -216,6 +224,19 @@ class FusedSequential(nn.Sequential):
         return self.run(x, IN_SEQ, final='f32')['f32']
 
     @staticmethod
+    def _next_convT_fp6(block, cur, geo, T):
+        """Will ``block`` (the one after the layer with geometry ``geo`` applied to the PTC tensor ``cur``) take the fp6
+        transposed-convolution kernel?"""
+        conv, bn, lif = block
+        if bn is None or lif is None or has_hooks(conv) or has_hooks(bn) or has_hooks(lif):
+            return False
+        g2 = conv_geometry(conv)
+        Ho = ops.conv_out_size(cur.shape[1], geo['k'], geo['stride'], geo['pad'], geo['transposed'], geo['out_pad'])
+        Wo = ops.conv_out_size(cur.shape[2], geo['k'], geo['stride'], geo['pad'], geo['transposed'], geo['out_pad'])
+        return ops.convT_fp6_supported(conv.in_channels, conv.out_channels, g2['k'], g2['stride'], g2['pad'], g2['out_pad'],
+                                       g2['transposed'], T, Ho, Wo)
+
+    @staticmethod
     def _collapsible(block, coef, T):
         """Can the conv-only read-out ``block`` take time-collapsed spikes (ops.readout_collapsed)?"""
         conv, bn, lif = block
@@ -259,6 +280,16 @@ class FusedSequential(nn.Sequential):
                 bias = None if conv.bias is None else conv.bias.detach()
                 src1 = in1 if (last and in1 is not None) else None
                 c4 = kind == IN_PTC and cur.dim() == 6 and cur.dtype == ops.C4_DTYPE
+                if (c4 and cur.shape[-1] == 16 and geo['transposed'] and lif is not None and not stateful and
+                        bi == len(blocks) - 2 and final == 'memout' and self._collapsible(blocks[-1], coef, T) and
+                        ops.convT_fp6_supported(conv.in_channels, conv.out_channels, geo['k'], geo['stride'], geo['pad'],
+                                                geo['out_pad'], True, T, cur.shape[2], cur.shape[3])):
+                    # decoder convT2 on the fp6 MFMA, handing the read-out layer its time-collapsed spikes
+                    a, b = bn.affine_terms()
+                    cur = ops.convT_fp6_collapsed(cur, conv._spk_params.get_convT_fp6(conv), conv.out_channels, bn_a=a, bn_b=b,
+                                                  coef=coef)
+                    kind = 'collapsed'
+                    continue
                 if c4 and cur.shape[-1] == 16:               # S32 records: the sampler's second-generation fp6 kernel
                     ok = (impl != 'direct' and lif is not None and not want_pre and src1 is None and not geo['transposed'] and
                           not stateful and
@@ -361,6 +392,14 @@ class FusedSequential(nn.Sequential):
                                 raise RuntimeError(f'LIFNode state has shape {tuple(lif.v.shape)} but the input implies '
                                                    f'{shape}; call functional.reset_net first')
                             v = lif.v
+                        # the next block runs on the fp6 MFMA (decoder convT2, stateless call): it reads nibble-packed spikes
+                        if (not last and not stateful and impl != 'direct' and bi == len(blocks) - 3 and final == 'memout' and
+                                conv.out_channels % 32 == 0 and self._collapsible(blocks[-1], coef, T) and
+                                self._next_convT_fp6(blocks[bi + 1], cur, geo, T)):
+                            cur = ops.conv_mfma_fused(cur, packed, conv.out_channels, mode=MODE_LIF, bn_a=a, bn_b=b, v=None,
+                                                      out_s32=True, **geo)
+                            kind = IN_PTC
+                            continue
                         # a linear read-out layer next (conv-only last block + 'memout'): hand it sum_t coef[t] * spikes[t]
                         # instead of the spike frames -- one convolution instead of T, no spike tensor in between
                         if (not last and bi == len(blocks) - 2 and final == 'memout' and impl != 'direct' and

@@ -909,7 +909,7 @@ def pack_conv_weight_i8(w, bias, transposed):
 
 
 def conv_mfma_fused(in_ptc, packed, Cout, *, mode, k, stride, pad, transposed=False, out_pad=0, bn_a=None, bn_b=None,
-                    v=None, coef=None, apply_tanh=False, want_u8=False, collapse_coef=None):
+                    v=None, coef=None, apply_tanh=False, want_u8=False, collapse_coef=None, out_s32=False):
     """in_ptc u8 [B,H,W,16,Cin] -> LIF: spikes u8 [B,Ho,Wo,16,Cout]; MEMOUT: dict(f32=[B,Cout,Ho,Wo], u8=...).
     LIF with collapse_coef [16]: returns sum_t collapse_coef[t] * spikes[t] as fp32 [B,Ho,Wo,Cout] instead of the spikes
     (input of readout_collapsed)."""
@@ -918,6 +918,13 @@ def conv_mfma_fused(in_ptc, packed, Cout, *, mode, k, stride, pad, transposed=Fa
     Ho, Wo = conv_out_size(H, k, stride, pad, transposed, out_pad), conv_out_size(W, k, stride, pad, transposed, out_pad)
     wq, scale, bias_d = packed
     out_p = out_f = out_u = None
+    if mode == MODE_LIF and out_s32:
+        # nibble-packed "S32" spikes [B, Cout/32, Ho, Wo, 16, 16]: the input layout of the fp6 kernels
+        o = torch.empty((B, Cout // 32, Ho, Wo, T, 16), dtype=C4_DTYPE, device=in_ptc.device)
+        check(lib.spk_conv_mfma_fused_lif_s32(_p(in_ptc), _p(wq), _p(scale), _p(bias_d), _p(bn_a), _p(bn_b), _p(v), _p(o), T, B,
+                                              H, W, Cin, Cout, k, stride, pad, int(transposed), out_pad, _stream(in_ptc)),
+              "spk_conv_mfma_fused_lif_s32")
+        return o
     if mode == MODE_LIF and collapse_coef is not None:
         coef = _dev(collapse_coef, "collapse_coef", torch.float32)
         if coef.numel() != T:
@@ -936,6 +943,55 @@ def conv_mfma_fused(in_ptc, packed, Cout, *, mode, k, stride, pad, transposed=Fa
     if mode == MODE_LIF:
         return out_f if collapse_coef is not None else out_p
     return {"f32": out_f, "u8": out_u}
+
+
+def convT_fp6_supported(Cin, Cout, k, stride, pad, out_pad, transposed, T, H, W):
+    """The fp6 form of the decoder's ConvTranspose2d(64 -> 32 * n, 3, 2, 1, 1) + BN + LIF (csrc/vae_fp6.hip)."""
+    return (transposed and k == 3 and stride == 2 and pad == 1 and out_pad == 1 and T == 16 and Cin == 64 and Cout % 32 == 0 and
+            (H, W) in ((14, 14), (16, 16)))
+
+
+def convT_fp6_pack(w, bias):
+    """ConvTranspose2d weight fp32 [Cin=64, Cout, 3, 3] (+bias) -> (digit tiles, scale f64, bias f64, qtab int32 [Cout,9,Cin])."""
+    w = _dev(w.detach(), "weight", torch.float32)
+    Cin, Cout = int(w.shape[0]), int(w.shape[1])
+    n = lib.spk_convt_fp6_packed_bytes(Cout, Cin)
+    if n <= 0:
+        raise NotImplementedError("spk_convt_fp6_pack: unsupported shape")
+    wq = torch.empty(n, dtype=torch.uint8, device=w.device)
+    scale = torch.empty(Cout, dtype=torch.float64, device=w.device)
+    bias_d = torch.empty(Cout, dtype=torch.float64, device=w.device)
+    qtab = torch.empty((Cout, 9, Cin), dtype=torch.int32, device=w.device)
+    b = None if bias is None else _dev(bias.detach(), "bias", torch.float32)
+    check(lib.spk_convt_fp6_pack(_p(w), _p(b), _p(wq), _p(scale), _p(bias_d), _p(qtab), Cout, Cin, _stream(w)),
+          "spk_convt_fp6_pack")
+    return wq, scale, bias_d, qtab
+
+
+_CONVT_FLAGS = {}
+
+
+def convT_fp6_collapsed(in_s32, packed, Cout, *, bn_a, bn_b, coef):
+    """in_s32: S32 spikes [B, 2, H, W, 16, 16] -> fp32 [B, 2H, 2W, Cout] = sum_t coef[t] * spikes[t] of
+    ConvTranspose2d(64 -> Cout, 3, 2, 1, 1) + BN + LIF from the reset state (the spike frames are not stored)."""
+    in_s32 = _dev(in_s32, "in_s32", C4_DTYPE)
+    B, nch, H, W, T, rec = in_s32.shape
+    if nch != 2 or rec != 16:
+        raise ValueError("S32 spikes of 64 channels expected")
+    wq, scale, bias_d, qtab = packed
+    coef = _dev(coef, "coef", torch.float32)
+    out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=torch.float32, device=in_s32.device)
+    nw = lib.spk_convt_fp6_flag_words(B, Cout, H, W)
+    key = (in_s32.device.index, nw)
+    flags = _CONVT_FLAGS.get(key)
+    if flags is None:
+        if len(_CONVT_FLAGS) > 4:
+            _CONVT_FLAGS.clear()
+        flags = _CONVT_FLAGS[key] = torch.zeros(nw, dtype=torch.int32, device=in_s32.device)
+    check(lib.spk_convt_fp6_collapsed_fwd(_p(in_s32), _p(wq), _p(scale), _p(bias_d), _p(qtab), _p(bn_a), _p(bn_b), _p(coef),
+                                          _p(out), _p(flags), T, B, H, W, 64, Cout, _stream(in_s32)),
+          "spk_convt_fp6_collapsed_fwd")
+    return out
 
 
 def readout_collapsed_supported(Cin, Cout, k):

@@ -690,6 +690,46 @@ def test_gather_layer_collapsed_output_matches_its_spikes(dev, ops):
 
 
 
+@pytest.mark.parametrize("B,hw,Cout", [(1, 14, 32), (5, 14, 32), (37, 14, 32), (3, 16, 32), (4, 14, 64)])
+def test_decoder_convT_fp6_kernel_equals_the_int8_gather_kernel(dev, ops, B, hw, Cout):
+    """spk_convt_fp6_collapsed_fwd (five fp6 digit planes, certified decisions, exact repair) against the int8 gather-MFMA
+    kernel (exact by construction) on the decoder's ConvTranspose2d(64 -> Cout, 3, 2, 1, 1) + BN + LIF: the time-collapsed
+    outputs must be bit-equal (same spikes, same fp32 additions), including large and negative BatchNorm scales; the flag
+    workspace must come back clean.  Also the S32 output of the gather kernel against its u8 spikes."""
+    g = torch.Generator().manual_seed(300 + B + hw)
+    coef = torch.pow(torch.tensor(0.8), torch.arange(15, -1, -1).float()).to(dev)
+    geo = dict(k=3, stride=2, pad=1, transposed=True, out_pad=1)
+    total = mism = 0
+    for trial, (wamp, aamp, rate) in enumerate(((0.08, 10.0, 0.08), (0.4, 2.5, 0.3))):
+        w = ((torch.rand(64, Cout, 3, 3, generator=g) - 0.5) * wamp)
+        w[:, :, 1, 1] *= 3.0
+        bias = (torch.rand(Cout, generator=g) - 0.5) * 0.2
+        a = ((torch.rand(Cout, generator=g) - 0.3) * aamp).to(dev)
+        b = ((torch.rand(Cout, generator=g) - 0.4) * 1.5).to(dev)
+        spikes = (torch.rand(16, B, 64, hw, hw, generator=g) < rate).float().to(dev)
+        wd, bd = w.to(dev), bias.to(dev)
+        ptc = ops.spikes_to_ptc(spikes)
+        want = ops.conv_mfma_fused(ptc, ops.pack_conv_weight_i8(wd, bd, True), Cout, mode=ops.MODE_LIF, bn_a=a, bn_b=b,
+                                   collapse_coef=coef, **geo)
+        got = ops.convT_fp6_collapsed(ops.spikes_to_s32(spikes), ops.convT_fp6_pack(wd, bd), Cout, bn_a=a, bn_b=b, coef=coef)
+        total += want.numel(); mism += int((want != got).sum())
+        assert torch.equal(want, got), (trial, int((want != got).sum()), float((want - got).abs().max()))
+        assert 0.0 < float((want > 0).float().mean()) < 1.0
+    torch.cuda.synchronize()
+    cap = 1 << 20
+    assert all(int(v[:2].abs().sum()) == 0 and int(v[2 + cap:].abs().sum()) == 0 for v in ops._CONVT_FLAGS.values())
+    # the producing layer's S32 output (decoder convT1: 16 -> 64 channels, 7x7 -> 14x14)
+    sp1 = (torch.rand(16, B, 16, 7, 7, generator=g) < 0.3).float().to(dev)
+    w1 = ((torch.rand(16, 64, 3, 3, generator=g) - 0.5) * 0.5).to(dev)
+    a1 = (torch.rand(64, generator=g) * 2 + 0.5).to(dev); b1 = (torch.rand(64, generator=g) - 0.5).to(dev)
+    pk1 = ops.pack_conv_weight_i8(w1, None, True)
+    u8 = ops.conv_mfma_fused(ops.spikes_to_ptc(sp1), pk1, 64, mode=ops.MODE_LIF, bn_a=a1, bn_b=b1, **geo)
+    s32 = ops.conv_mfma_fused(ops.spikes_to_ptc(sp1), pk1, 64, mode=ops.MODE_LIF, bn_a=a1, bn_b=b1, out_s32=True, **geo)
+    assert torch.equal(ops.s32_to_spikes(s32), ops.ptc_to_spikes(u8))
+    parity(f"convT_fp6_vs_int8_B{B}_{hw}x{hw}_c{Cout}", collapsed_values=total, mismatches=mism)
+
+
+
 # ------------------------------------------------------------------------------------------------- F8 LIF training
 @pytest.mark.parametrize("det", [False, True])
 def test_f8_lif_training_bptt_vs_reference_fixture(golden_dir, dev, det):
