@@ -26,7 +26,7 @@
 
 namespace {
 
-typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v6i __attribute__((ext_vector_type(6)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int T16 = 16;
@@ -55,6 +55,9 @@ __device__ __forceinline__ void tfor(F&& f) {
 }
 
 constexpr float CERT_4EPS = 4.0f * 2.38418579e-07f;
+#ifndef SPK_VT_DBG
+#define SPK_VT_DBG 0            // timing experiments only (results are wrong): 1 = no MFMAs, 2 = no LIF scan
+#endif
 
 template <int H, int W>
 __global__ __launch_bounds__(512, 1) void convT_s2_fp6_kernel(TArgs a) {
@@ -83,12 +86,16 @@ __global__ __launch_bounds__(512, 1) void convT_s2_fp6_kernel(TArgs a) {
   const int co = g * 32 + (lane & 31);
   const float scale_f = (float)a.scale[co], bias_f = (float)a.bias[co];
   const float bna = a.bn_a[co], bnb = a.bn_b[co];
-  const float Ac = 32.0f * scale_f * bna;                   // z = fma(Q5, Ac, Bc),  Q5 = P01 * 2^15 + P23 * 2^5 + P4
+  const float Ac = 32.0f * scale_f * bna;                   // z = Q5 * Ac + Bc,  Q5 = P01 * 2^15 + P23 * 2^5 + P4
+  const float Ac0 = Ac * 32768.0f, Ac1 = Ac * 32.0f;        // (powers of two: exact)
   const float Bc = fmaf(bias_f, bna, bnb);
   // certification constant (den_mfma_fp6v2.hip "Certification"): the dropped sixth digit moves a pre-activation by at most
   // 16 units of 2^-s per active input, at most 4 taps x Cin inputs reach an output of this layer
   const float E5 = 16.0f * 4.0f * (float)a.Cin * scale_f;
-  const float cE = fabsf(bna) * E5 + 2.0f * 2.38418579e-07f * (fabsf(bnb) + fabsf(Bc)) + 1e-30f;
+  // ... and the three-term fp32 recombination z = P01 * Ac0 + (P23 * Ac1 + (P4 * Ac + Bc)) rounds its partial sums, which are
+  // bounded by the middle / low digit groups of at most 4 * Cin inputs (|32 d2 + d3| <= 528, |d4| <= 16) rather than by |z|
+  const float part_max = (528.0f * fabsf(Ac1) + 16.0f * fabsf(Ac)) * 4.0f * (float)a.Cin + fabsf(Bc);
+  const float cE = fabsf(bna) * E5 + 2.0f * 2.38418579e-07f * (fabsf(bnb) + fabsf(Bc) + 2.0f * part_max) + 1e-30f;
   float coef[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) coef[r] = a.coef[r];
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(512, 1) void convT_s2_fp6_kernel(TArgs a) {
     spk_dma_wait_all();
     __syncthreads();
 
-    tfor<4>([&](auto cls_tag) {
+    auto run_class = [&](auto cls_tag) __attribute__((always_inline)) {
       constexpr int CLS = decltype(cls_tag)::value, PY = CLS >> 1, PX = CLS & 1;
       const int first = (wave - 2 * CLS) & 7;               // the 49th tile of a class lands on a different wave per class
       for (int t0 = first; t0 < NTC; t0 += 16) {
@@ -142,15 +149,19 @@ __global__ __launch_bounds__(512, 1) void convT_s2_fp6_kernel(TArgs a) {
           for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        auto ldb = [&](int tile) -> v8i {
+        auto ldb = [&](int tile) -> v6i {
           const uint8_t* p = sW + tile * WT;
           const v4i x = *reinterpret_cast<const v4i*>(p + lane * 16);
           const v2i y = *reinterpret_cast<const v2i*>(p + 1024 + lane * 8);
-          return v8i{x[0], x[1], x[2], x[3], y[0], y[1], 0, 0};
+          return v6i{x[0], x[1], x[2], x[3], y[0], y[1]};
         };
-        auto mm = [&](v16f& d, const v4i& av, const v8i& bv, int sb) {
-          const v8i a8 = {av[0], av[1], av[2], av[3], 0, 0, 0, 0};
-          d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, bv, d, 4, 2, 0, sc_a, 0, sb);
+        // (the builtin, not inline assembly: hipcc then places the hazard wait states between an MFMA and the reads of its
+        //  accumulator itself -- an asm form measured slower and raced)
+        auto mm = [&](v16f& d, const v4i& av, const v6i& bv, int sb) {
+          typedef int v8i_ __attribute__((ext_vector_type(8)));
+          const v8i_ a8 = {av[0], av[1], av[2], av[3], 0, 0, 0, 0};
+          const v8i_ b8 = {bv[0], bv[1], bv[2], bv[3], bv[4], bv[5], 0, 0};
+          d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, d, 4, 2, 0, sc_a, 0, sb);
         };
         tfor<9>([&](auto tap_tag) {
           constexpr int TAP = decltype(tap_tag)::value, KY = TAP / 3, KX = TAP % 3;
@@ -165,10 +176,11 @@ __global__ __launch_bounds__(512, 1) void convT_s2_fp6_kernel(TArgs a) {
               av[i][0] = *reinterpret_cast<const v4i*>(sA + base[i] + TOFF);
               av[i][1] = *reinterpret_cast<const v4i*>(sA + A_CH + base[i] + TOFF);
             }
-            const v8i b0 = ldb(TAP * TPT + 0), b1 = ldb(TAP * TPT + 1), b2 = ldb(TAP * TPT + 2), b3 = ldb(TAP * TPT + 3),
+            const v6i b0 = ldb(TAP * TPT + 0), b1 = ldb(TAP * TPT + 1), b2 = ldb(TAP * TPT + 2), b3 = ldb(TAP * TPT + 3),
                       b4 = ldb(TAP * TPT + 4);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+              if (SPK_VT_DBG & 1) { acc[i][0][0] += (float)(av[i][0][0] + av[i][1][1] + b0[0] + b1[1] + b2[2] + b3[3] + b4[4]); continue; }
               mm(acc[i][0], av[i][0], b0, sc_p);
               mm(acc[i][1], av[i][0], b1, sc_p);
               mm(acc[i][0], av[i][1], b2, sc_p);
@@ -181,19 +193,35 @@ __global__ __launch_bounds__(512, 1) void convT_s2_fp6_kernel(TArgs a) {
         // ---- epilogue: fp32 recombination, BN, LIF scan with certification, time-collapsed output
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          float v = 0.f, D = 0.f, m = 0.f;
-          bool flg = false;
+          // certification (den_mfma_fp6v2.hip): D_t = D_{t-1} / 2 + cE + 4 eps (|z_t| + |v_{t-1}|) and |v| <= max |z|, so
+          // D_t <= 2 cE + 16 eps max_t |z_t| for every t: track max |z| and min |h - 1| (two instructions per step instead
+          // of five) and compare once
+          float v = 0.f, m = 0.f, zmax = 0.f, dmin = 3.0e38f;
+          if (SPK_VT_DBG & 2) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float q5 = fmaf(fmaf(acc[i][0][r], 1024.0f, acc[i][1][r]), 32.0f, acc[i][2][r]);
-            const float z = fmaf(q5, Ac, Bc);
-            D = fmaf(fabsf(z) + fabsf(v), CERT_4EPS, fmaf(D, 0.5f, cE));
-            const float h = v + (z - v) * 0.5f;
-            const bool s = h >= 1.0f;
-            flg = flg || (fabsf(h - 1.0f) <= D);
-            v = s ? 0.0f : h;
-            m = m + (s ? coef[r] : 0.f);
+            for (int r = 0; r < 16; ++r) m += acc[i][0][r] + acc[i][1][r] + acc[i][2][r];
+          } else
+#pragma unroll
+          for (int r2 = 0; r2 < 16; r2 += 2) {
+            // the recombination of two steps at a time on the packed fp32 pipe (adjacent accumulator registers)
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const v2f p0 = {acc[i][0][r2], acc[i][0][r2 + 1]}, p1 = {acc[i][1][r2], acc[i][1][r2 + 1]},
+                      p2 = {acc[i][2][r2], acc[i][2][r2 + 1]};
+            const v2f z2 = __builtin_elementwise_fma(p0, (v2f){Ac0, Ac0},
+                           __builtin_elementwise_fma(p1, (v2f){Ac1, Ac1}, __builtin_elementwise_fma(p2, (v2f){Ac, Ac}, (v2f){Bc, Bc})));
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int r = r2 + e;
+              const float z = z2[e];
+              zmax = fmaxf(zmax, fabsf(z));
+              const float h = fmaf(z - v, 0.5f, v);          // == v + (z - v) * 0.5f: the product is exact
+              dmin = fminf(dmin, fabsf(h - 1.0f));
+              const bool s = h >= 1.0f;
+              v = s ? 0.0f : h;
+              m = m + (s ? coef[r] : 0.f);
+            }
           }
+          const bool flg = dmin <= fmaf(zmax, 5.0f * CERT_4EPS, 2.0f * cE);      // (20 eps: a little to spare)
           if (i == 1 && !v1) continue;
           const int r_ = tl[i] / TPR, j_ = tl[i] - r_ * TPR;
           const int oy = 2 * (hb * HB + r_) + PY, ox = 2 * (2 * j_ + half) + PX;   // accumulator lane half == position in the tile
@@ -207,7 +235,18 @@ __global__ __launch_bounds__(512, 1) void convT_s2_fp6_kernel(TArgs a) {
           a.out_col[pos * a.Cout + co] = m;
         }
       }
-    });
+    };
+    // The two waves of a SIMD (w and w + 4) walk the classes in opposite orders: class 3 is four taps of matrix work per
+    // tile, class 0 one, the LIF scan is the same -- so one wave's multiplications meet the other's scan instead of both
+    // queueing for the same pipe.
+    for (int k = 0; k < 4; ++k) {
+      switch ((wave & 1) ? 3 - k : k) {
+        case 0: run_class(std::integral_constant<int, 0>{}); break;
+        case 1: run_class(std::integral_constant<int, 1>{}); break;
+        case 2: run_class(std::integral_constant<int, 2>{}); break;
+        default: run_class(std::integral_constant<int, 3>{}); break;
+      }
+    }
     __syncthreads();                                           // everyone is done with the slab before the next copy lands
   }
   spk_dma_wait_all();
