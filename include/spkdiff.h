@@ -271,20 +271,25 @@ int spk_conv_mfma_fused_lif_s32(const uint8_t* in_ptc, const int8_t* wq, const d
                                 const float* bn_a, const float* bn_b, float* v_inout, uint8_t* out_s32, int T, int B, int H,
                                 int W, int Cin, int Cout, int k, int stride, int pad, int transposed, int out_pad,
                                 spk_stream_t stream);
-/* Decoder ConvTranspose2d(64 -> Cout, k3, s2, p1, op1) + BN + LIF from the reset state on the block-scaled fp6 x fp4 MFMA
- * (R/snn_model/vae_model.py:146-150; csrc/vae_fp6.hip): the same spikes as spk_conv_mfma_fused_fwd -- five digit planes on the
- * matrix cores, certified decisions, exact recomputation of the flagged neurons -- delivered as the time-collapsed tensor
- * out_col fp32 [B][4*H*W][Cout] = sum_t coef[t] * spike[t] for spk_readout_collapsed_fwd.  in_s32: S32 spikes [B][2][H*W][16][16 B];
- * spk_convt_fp6_pack: fp32 weight [64][Cout][3][3] (+bias) -> digit tiles (spk_convt_fp6_packed_bytes), fp64 scale / bias [Cout],
- * qtab int32 [Cout][9][64]; flag_words: zero-initialised u32 workspace of spk_convt_fp6_flag_words(B, Cout, H, W) words, clean
- * again after the call.  SPK_ERR_UNSUPPORTED unless T == 16, Cin == 64, Cout % 32 == 0, (H, W) in {(14, 14), (16, 16)}. */
-long long spk_convt_fp6_packed_bytes(int Cout, int Cin);
-int spk_convt_fp6_pack(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d, int* qtab, int Cout,
-                       int Cin, spk_stream_t stream);
-long long spk_convt_fp6_flag_words(int B, int Cout, int H, int W);
-int spk_convt_fp6_collapsed_fwd(const uint8_t* in_s32, const uint8_t* wq, const double* scale, const double* bias_d,
-                                const int* qtab, const float* bn_a, const float* bn_b, const float* coef, float* out_col,
-                                unsigned* flag_words, int T, int B, int H, int W, int Cin, int Cout, spk_stream_t stream);
+/* The spike-input 3x3 stride-2 layers of the spiking VQ-VAE from the reset state on the block-scaled fp6 x fp4 MFMA
+ * (csrc/vae_fp6.hip): the same spikes as spk_conv_mfma_fused_fwd -- five digit planes on the matrix cores, certified decisions,
+ * exact recomputation of the flagged neurons.  Supported (T == 16, Cout % 32 == 0):
+ *   transposed = 1, Cin = 64, (H, W) in {(14,14), (16,16)}, out_kind 0: Decoder convT2 (R/snn_model/vae_model.py:146-150) -> out =
+ *       fp32 [B][4*H*W][Cout] = sum_t coef[t] * spike[t], the input of spk_readout_collapsed_fwd (the spike frames are not stored);
+ *   transposed = 1, Cin = 16, (H, W) in {(7,7), (8,8)}, out_kind 1: Decoder convT1 (:139-144) -> out = S32 spikes [B][Cout/32][4*H*W][16][16 B];
+ *   transposed = 0, Cin = 32, (H, W) in {(14,14), (16,16)}, out_kind 2: Encoder conv2 (:115-118) -> out = u8 PTC [B][H*W/4][16][Cout].
+ * in_s32: S32 spikes [B][ceil(Cin/32)][H*W][16][16 B] with zero nibbles in the channels beyond Cin (spk_ptc_to_s32 converts u8
+ * PTC spikes).  spk_vae_fp6_pack: fp32 weight (Conv2d [Cout][Cin][3][3] / ConvTranspose2d [Cin][Cout][3][3]) (+bias) -> digit
+ * tiles (spk_vae_fp6_packed_bytes), fp64 scale / bias [Cout], qtab int32 [Cout][9][Cin].  flag_words: zero-initialised u32
+ * workspace of spk_vae_fp6_flag_words(B, Cout, Ho, Wo) words, clean again after the call. */
+long long spk_vae_fp6_packed_bytes(int Cout, int Cin);
+int spk_vae_fp6_pack(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d, int* qtab, int Cout, int Cin,
+                     int transposed, spk_stream_t stream);
+long long spk_vae_fp6_flag_words(int B, int Cout, int Ho, int Wo);
+int spk_ptc_to_s32(const uint8_t* in_ptc, uint8_t* out_s32, int T, int B, int HW, int C, spk_stream_t stream);
+int spk_vae_fp6_fwd(const uint8_t* in_s32, const uint8_t* wq, const double* scale, const double* bias_d, const int* qtab,
+                    const float* bn_a, const float* bn_b, const float* coef_or_null, void* out, int out_kind, unsigned* flag_words,
+                    int T, int B, int H, int W, int Cin, int Cout, int transposed, spk_stream_t stream);
 
 /* ---- vector quantizer ----------------------------------------------------------------------------------------- */
 /* VectorQuantizer.forward eval up to the codebook gather, R/snn_model/vae_model.py:40-52,87-99.

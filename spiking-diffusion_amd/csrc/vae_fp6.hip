@@ -1,23 +1,25 @@
-// Decoder ConvTranspose2d(64 -> 32, k3, s2, p1, op1) + BN + LIF on the block-scaled fp6 x fp4 MFMA, for the call that feeds
-// the linear read-out layer (R/snn_model/vae_model.py:146-154).  Same arithmetic contract as
-// den_mfma_fp6v2.hip: 29-bit per-channel fixed-point weights as radix-32 digits, adjacent digits sharing an fp32 accumulator
-// through the per-block scales, five digits on the matrix cores, every spike decision certified against a running error
+// The spike-input layers of the spiking VQ-VAE on the block-scaled fp6 x fp4 MFMA (R/snn_model/vae_model.py:115-118 Encoder
+// conv2, :139-150 Decoder convT1 / convT2), for calls that start from the reset state.  Same arithmetic
+// contract as den_mfma_fp6v2.hip: 29-bit per-channel fixed-point weights as radix-32 digits, adjacent digits sharing an fp32
+// accumulator through the per-block scales, five digits on the matrix cores, every spike decision certified against an error
 // bound, the few neurons that come within the bound of the threshold recomputed exactly (all six digits, 64-bit sums, fp64
 // recombination, one rounding) by a tail launch.  Unflagged neurons provably emit the exact path's spikes; the result is the
-// one spk_conv_mfma_fused_fwd produces for the same layer.
+// one spk_conv_mfma_fused_fwd (int8 gather kernel) produces for the same layer.
 //
-// What differs from the denoiser kernel is the geometry.  A stride-2 transposed convolution is four sub-pixel classes
-// (oy % 2, ox % 2) with 1 / 2 / 2 / 4 contributing taps; the rows of a 32-row MFMA tile are two horizontally adjacent
-// positions of ONE class x 16 time steps, so the tap list of a tile is compile-time.  K is small (2 chunks of 32 channels)
-// and there is one group of 32 output channels: all 45 weight tiles of the group (9 taps x [pair 01, pair 23] x 2 chunks +
-// 9 fifth-digit tiles whose K halves are the two chunks) stay in LDS for the whole launch (68 KB), next to HALF an input
-// image (H/2 + 1 rows, zero column on the right: 60 KB at 14 x 14).  A work item = one image half x one channel group =
-// 4 classes x (H/2 x W/2) tiles; the eight waves of a workgroup (two per SIMD: one multiplies while the other scans) take
-// tiles two at a time -- a weight tile read from LDS serves both.  The layer is bound by the vector work of the LIF scan
-// (16 steps x ~14 instructions per neuron), not by the matrix pipe or memory.
+// What differs from the denoiser kernel is the geometry: K is small (16 .. 64 input channels = 1 or 2 chunks of 32) and the
+// spatial extent large, so ALL weight tiles of a 32-channel output group stay in LDS for the whole launch (9 taps x [pair 01,
+// pair 23] per chunk + a fifth-digit tile: 40 / 68 KB) next to the input rows of one work item.
+//   GEO 0  ConvTranspose2d(k3, s2, p1, op1): four sub-pixel classes (oy % 2, ox % 2) with 1 / 2 / 2 / 4 contributing taps; the
+//          rows of a 32-row MFMA tile are two consecutive positions of ONE class x 16 time steps, so a tile's tap list is
+//          compile-time.  Item = an image (or its upper / lower half) : class rows + one more input row, zero column on the right.
+//   GEO 1  Conv2d(k3, s2, p1): rows = two consecutive OUTPUT positions; item = an image with a zero row above and a zero column left.
+// The eight waves of a workgroup (two per SIMD) take passes of two tiles -- a weight tile read from LDS serves both -- and the
+// pass list of an item (class-major) is dealt round-robin, so every wave gets a mix of cheap and expensive classes.  These
+// layers are bound by the vector work of the LIF scan (16 steps x ~11 instructions per neuron), not by the matrix pipe or memory.
 //
-// Output: this first form emits the time-collapsed spikes m = sum_t coef[t] * s_t (fp32 [B][Ho*Wo][Cout]) that
-// spk_readout_collapsed_fwd consumes -- the spike frames themselves are never stored.
+// Spikes in: "S32" [B][Cin/32 (rounded up)][H*W][16][16 B] (fp4 nibbles; channels beyond Cin must be zero).  Out: S32, plain u8
+// PTC [B][Ho*Wo][16][Cout], or -- for the layer in front of the linear read-out -- the time-collapsed tensor
+// m = sum_t coef[t] * s_t (fp32 [B][Ho*Wo][Cout], spk_readout_collapsed_fwd): the spike frames are then never stored.
 #include "den_common.h"
 #include "../../include/spkdiff.h"
 #include <math.h>
@@ -27,20 +29,24 @@
 namespace {
 
 typedef int v6i __attribute__((ext_vector_type(6)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int T16 = 16;
 constexpr int POSB = 256;                    // bytes per position and 32-channel chunk: 16 steps x 16 B
 constexpr int WT = 1536;                     // one B tile: 64 lanes x 32 six-bit codes
-constexpr int TPT = 5;                       // tiles per tap: pair01 c0, pair23 c0, pair01 c1, pair23 c1, fifth digit (c0 | c1)
-constexpr int NTILE = 9 * TPT;
-constexpr int W_BYTES = NTILE * WT;          // 69120 per channel group
 constexpr unsigned FLAG_CAP = 1u << 20;
+constexpr int OUT_COLLAPSED = 0, OUT_S32 = 1, OUT_PTC = 2;
+
+__host__ __device__ constexpr int tiles_per_tap(int nch) { return nch == 2 ? 5 : 3; }
+// tile (tap, j): NCH = 2: j = 0..3: chunk j / 2, digit pair j % 2; j = 4: fifth digit, K half 0 = chunk 0, half 1 = chunk 1.
+//                NCH = 1: j = 0, 1: digit pair j; j = 2: fifth digit in K half 0 (half 1 zero).
 
 struct TArgs {
-  const uint8_t* in;                         // S32 [B][2][H*W][16][16 B]
+  const uint8_t* in;                         // S32 [B][NCH][H*W][16][16 B]
   const uint8_t* wq; const double* scale; const double* bias; const float* bn_a; const float* bn_b; const float* coef;
-  float* out_col;                            // [B][Ho*Wo][Cout]
+  void* out;
   unsigned* flags; unsigned flag_cap; const int* qtab;       // qtab int32 [Cout][9][Cin]
   int B, Cout, Cin;
 };
@@ -59,27 +65,44 @@ constexpr float CERT_4EPS = 4.0f * 2.38418579e-07f;
 #define SPK_VT_DBG 0            // timing experiments only (results are wrong): 1 = no MFMAs, 2 = no LIF scan
 #endif
 
-template <int H, int W>
-__global__ __launch_bounds__(512, 1) void convT_s2_fp6_kernel(TArgs a) {
-  constexpr int NCH = 2, HB = H / 2, PWc = W + 1, ROWS = HB + 1;
-  constexpr int A_CH = ROWS * PWc * POSB, A_BYTES = NCH * A_CH;
-  constexpr int TPR = W / 2, NTC = HB * TPR;               // tiles per class row / per class and item
-  constexpr int PPR = (W + 3) / 4;                         // 1 KiB DMA pieces per image row
-  constexpr int Ho = 2 * H, Wo = 2 * W;
-  static_assert((H % 2) == 0 && (W % 2) == 0, "even input extents");
+__device__ __forceinline__ unsigned spread8_v(unsigned x) {        // bit k -> nibble k, as the e2m1 code of 1.0 (0x2)
+  x = (x | (x << 12)) & 0x000f000fu;
+  x = (x | (x << 6)) & 0x03030303u;
+  x = (x | (x << 3)) & 0x11111111u;
+  return x << 1;
+}
+
+template <int GEO, int H, int W>
+struct Geo {
+  static constexpr int Ho = GEO == 0 ? 2 * H : H / 2, Wo = GEO == 0 ? 2 * W : W / 2;
+  static constexpr int KMAX = GEO == 0 ? 4 : 9;                       // taps that can reach one output
+};
+
+template <int GEO, int H, int W, int NCH, int OUT, int SPLIT, bool DB>
+__global__ __launch_bounds__(512, 1) void vae_fp6_kernel(TArgs a) {
+  constexpr int TPT = tiles_per_tap(NCH), W_BYTES = 9 * TPT * WT;
+  constexpr int RQ = GEO == 0 ? H / SPLIT : H / 2;          // rows of positions per item (class rows / output rows)
+  constexpr int CW = GEO == 0 ? W : W / 2;                  // positions per row
+  constexpr int NPOS = RQ * CW, NTC = (NPOS + 1) / 2, NPASS = (NTC + 1) / 2, NCLS = GEO == 0 ? 4 : 1;
+  constexpr int SROWS = GEO == 0 ? RQ + 1 : H + 1, SCOLS = W + 1;
+  constexpr int A_CH = SROWS * SCOLS * POSB, A_BYTES = NCH * A_CH, NBUF = DB ? 2 : 1;
+  constexpr int PPR = (W + 3) / 4;                          // 1 KiB DMA pieces per image row
+  constexpr int DROWS = GEO == 0 ? SROWS : H;               // image rows copied per item
+  constexpr int Ho = Geo<GEO, H, W>::Ho, Wo = Geo<GEO, H, W>::Wo;
+  static_assert(GEO == 0 ? (H % SPLIT) == 0 : ((H % 2) == 0 && (W % 2) == 0 && SPLIT == 1), "item geometry");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   uint8_t* const sA = lds;
-  uint8_t* const sW = lds + A_BYTES;
+  uint8_t* const sW = lds + NBUF * A_BYTES;
   const unsigned sA_addr = spk_lds_addr(sA);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = a.Cout >> 5;
   const int g = blockIdx.x % G, il = blockIdx.x / G, lanes = gridDim.x / G;
 
-  {  // the group's weight tiles and a zeroed input slab (its right column and, for the lower half, its last row stay zero)
+  {  // the group's weight tiles and zeroed input slabs (their borders stay zero for the whole launch)
     const uint4* src = reinterpret_cast<const uint4*>(a.wq + (long long)g * W_BYTES);
     for (int i = tid; i < W_BYTES / 16; i += 512) reinterpret_cast<uint4*>(sW)[i] = src[i];
-    for (int i = tid; i < A_BYTES / 16; i += 512) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < NBUF * A_BYTES / 16; i += 512) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
 
@@ -89,16 +112,17 @@ __global__ __launch_bounds__(512, 1) void convT_s2_fp6_kernel(TArgs a) {
   const float Ac = 32.0f * scale_f * bna;                   // z = Q5 * Ac + Bc,  Q5 = P01 * 2^15 + P23 * 2^5 + P4
   const float Ac0 = Ac * 32768.0f, Ac1 = Ac * 32.0f;        // (powers of two: exact)
   const float Bc = fmaf(bias_f, bna, bnb);
-  // certification constant (den_mfma_fp6v2.hip "Certification"): the dropped sixth digit moves a pre-activation by at most
-  // 16 units of 2^-s per active input, at most 4 taps x Cin inputs reach an output of this layer
-  const float E5 = 16.0f * 4.0f * (float)a.Cin * scale_f;
-  // ... and the three-term fp32 recombination z = P01 * Ac0 + (P23 * Ac1 + (P4 * Ac + Bc)) rounds its partial sums, which are
-  // bounded by the middle / low digit groups of at most 4 * Cin inputs (|32 d2 + d3| <= 528, |d4| <= 16) rather than by |z|
-  const float part_max = (528.0f * fabsf(Ac1) + 16.0f * fabsf(Ac)) * 4.0f * (float)a.Cin + fabsf(Bc);
+  // Certification (den_mfma_fp6v2.hip): the approximate and the exact pre-activation differ by at most cE + 2 eps |z|:
+  // the dropped sixth digit moves a pre-activation by at most 16 units of 2^-s per active input (at most KMAX taps x Cin
+  // inputs reach an output), and the three-term fp32 recombination z = P01 * Ac0 + (P23 * Ac1 + (P4 * Ac + Bc)) rounds partial
+  // sums bounded by the middle / low digit groups (|32 d2 + d3| <= 528, |d4| <= 16 per input) rather than by |z|.
+  const float kin = (float)(Geo<GEO, H, W>::KMAX * a.Cin);
+  const float E5 = 16.0f * kin * scale_f;
+  const float part_max = (528.0f * fabsf(Ac1) + 16.0f * fabsf(Ac)) * kin + fabsf(Bc);
   const float cE = fabsf(bna) * E5 + 2.0f * 2.38418579e-07f * (fabsf(bnb) + fabsf(Bc) + 2.0f * part_max) + 1e-30f;
   float coef[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) coef[r] = a.coef[r];
+  for (int r = 0; r < 16; ++r) coef[r] = OUT == OUT_COLLAPSED ? a.coef[r] : 0.f;
 
   const int row = lane & 31, half = lane >> 5;
   const int hsel = (row >> 2) & 1, tt = (row & 3) + 4 * (row >> 3);
@@ -106,81 +130,94 @@ __global__ __launch_bounds__(512, 1) void convT_s2_fp6_kernel(TArgs a) {
   const int sc_p = half ? (int)0x82828282u : (int)0x87878787u;     // even digit (K half 0) x 2^8, odd digit x 2^3
   const int sc_4 = (int)0x82828282u;                                // fifth digit x 2^3
   const unsigned lane16 = (unsigned)lane * 16u;
+  const int nitems = SPLIT * a.B;
 
-  for (int itm = il; itm < 2 * a.B; itm += lanes) {
-    const int b = itm >> 1, hb = itm & 1;
-    // ---- stage the input rows hb * HB .. hb * HB + HB of both chunks (row H does not exist: zeros)
-    for (int id = wave; id < NCH * ROWS * PPR; id += 8) {
-      const int c = id / (ROWS * PPR), rr = (id / PPR) % ROWS, px4 = id % PPR;
-      const int iy = hb * HB + rr;
+  // copy the input rows of item `itm` into slab `buf` (asynchronous; spk_dma_wait_all + barrier before use)
+  auto stage = [&](int itm, int buf) {
+    const int b = itm / SPLIT, part = itm - b * SPLIT;
+    const unsigned dst0 = sA_addr + buf * A_BYTES;
+    for (int id = wave; id < NCH * DROWS * PPR; id += 8) {
+      const int c = id / (DROWS * PPR), rr = (id / PPR) % DROWS, px4 = id % PPR;
+      const int iy = GEO == 0 ? part * RQ + rr : rr;
       if (iy < H) {
         const int np = (W - 4 * px4) < 4 ? (W - 4 * px4) : 4;
         const unsigned long long mask = np == 4 ? ~0ull : ((1ull << (16 * np)) - 1ull);
         const uint8_t* src = a.in + (((long long)b * NCH + c) * H * W + iy * W + 4 * px4) * POSB;
-        spk_dma16s_masked(src, lane16, sA_addr + c * A_CH + (rr * PWc + 4 * px4) * POSB, mask);
+        const int cell = GEO == 0 ? rr * SCOLS + 4 * px4 : (rr + 1) * SCOLS + 1 + 4 * px4;
+        spk_dma16s_masked(src, lane16, dst0 + c * A_CH + cell * POSB, mask);
       }
     }
-    if (hb * HB + ROWS - 1 >= H) {
+    if (GEO == 0 && part * RQ + SROWS - 1 >= H) {           // the row below the image: zeros
       for (int i = tid; i < NCH * W * POSB / 16; i += 512) {
         const int c = i / (W * POSB / 16), o = i % (W * POSB / 16);
-        reinterpret_cast<uint4*>(sA + c * A_CH + (ROWS - 1) * PWc * POSB)[o] = make_uint4(0, 0, 0, 0);
+        reinterpret_cast<uint4*>(sA + buf * A_BYTES + c * A_CH + (SROWS - 1) * SCOLS * POSB)[o] = make_uint4(0, 0, 0, 0);
       }
     }
+  };
+
+  if (DB && il < nitems) stage(il, 0);
+  int n = 0;
+  for (int itm = il; itm < nitems; itm += lanes, ++n) {
+    const int b = itm / SPLIT, part = itm - b * SPLIT;
+    const int buf = DB ? (n & 1) : 0;
+    if (!DB) stage(itm, 0);
     spk_dma_wait_all();
     __syncthreads();
+    if (DB && itm + lanes < nitems) stage(itm + lanes, buf ^ 1);
+    const uint8_t* const A0 = sA + buf * A_BYTES;
 
-    auto run_class = [&](auto cls_tag) __attribute__((always_inline)) {
+    auto run_pass = [&](auto cls_tag, int k) __attribute__((always_inline)) {
       constexpr int CLS = decltype(cls_tag)::value, PY = CLS >> 1, PX = CLS & 1;
-      const int first = (wave - 2 * CLS) & 7;               // the 49th tile of a class lands on a different wave per class
-      for (int t0 = first; t0 < NTC; t0 += 16) {
-        const int t1 = t0 + 8;
-        const bool v1 = t1 < NTC;
-        const int tl[2] = {t0, v1 ? t1 : t0};
-        int base[2];
+      const int t0 = 2 * k, t1 = 2 * k + 1;
+      const bool v1 = t1 < NTC;
+      const int tl[2] = {t0, v1 ? t1 : t0};
+      int base[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int r = tl[i] / TPR, j = tl[i] - r * TPR;
-          base[i] = (r * PWc + 2 * j + hsel) * POSB + tt * 16;
-        }
-        v16f acc[2][3];
+      for (int i = 0; i < 2; ++i) {
+        int p = 2 * tl[i] + hsel;
+        p = p < NPOS ? p : NPOS - 1;
+        const int ry = p / CW, rx = p - ry * CW;
+        base[i] = (GEO == 0 ? ry * SCOLS + rx : 2 * ry * SCOLS + 2 * rx) * POSB + tt * 16;
+      }
+      v16f acc[2][3];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        auto ldb = [&](int tile) -> v6i {
-          const uint8_t* p = sW + tile * WT;
-          const v4i x = *reinterpret_cast<const v4i*>(p + lane * 16);
-          const v2i y = *reinterpret_cast<const v2i*>(p + 1024 + lane * 8);
-          return v6i{x[0], x[1], x[2], x[3], y[0], y[1]};
-        };
-        // (the builtin, not inline assembly: hipcc then places the hazard wait states between an MFMA and the reads of its
-        //  accumulator itself -- an asm form measured slower and raced)
-        auto mm = [&](v16f& d, const v4i& av, const v6i& bv, int sb) {
-          typedef int v8i_ __attribute__((ext_vector_type(8)));
-          const v8i_ a8 = {av[0], av[1], av[2], av[3], 0, 0, 0, 0};
-          const v8i_ b8 = {bv[0], bv[1], bv[2], bv[3], bv[4], bv[5], 0, 0};
-          d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, d, 4, 2, 0, sc_a, 0, sb);
-        };
-        tfor<9>([&](auto tap_tag) {
-          constexpr int TAP = decltype(tap_tag)::value, KY = TAP / 3, KX = TAP % 3;
-          // oy = 2 iy - 1 + ky: class parity PY takes ky = 1 (iy = qy) when even, ky = 0 (iy = qy + 1) and ky = 2 (iy = qy) when odd
-          constexpr bool ON = (PY == 0 ? KY == 1 : KY != 1) && (PX == 0 ? KX == 1 : KX != 1);
-          if constexpr (ON) {
-            constexpr int DY = (PY == 1 && KY == 0) ? 1 : 0, DX = (PX == 1 && KX == 0) ? 1 : 0;
-            constexpr int TOFF = (DY * PWc + DX) * POSB;
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      auto ldb = [&](int tile) -> v6i {
+        const uint8_t* p = sW + tile * WT;
+        const v4i x = *reinterpret_cast<const v4i*>(p + lane * 16);
+        const v2i y = *reinterpret_cast<const v2i*>(p + 1024 + lane * 8);
+        return v6i{x[0], x[1], x[2], x[3], y[0], y[1]};
+      };
+      // (the builtin, not inline assembly: hipcc then places the hazard wait states between an MFMA and the reads of its
+      //  accumulator itself -- an asm form measured slower and raced)
+      auto mm = [&](v16f& d, const v4i& av, const v6i& bv, int sb) {
+        const v8i a8 = {av[0], av[1], av[2], av[3], 0, 0, 0, 0};
+        const v8i b8 = {bv[0], bv[1], bv[2], bv[3], bv[4], bv[5], 0, 0};
+        d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, d, 4, 2, 0, sc_a, 0, sb);
+      };
+      tfor<9>([&](auto tap_tag) {
+        constexpr int TAP = decltype(tap_tag)::value, KY = TAP / 3, KX = TAP % 3;
+        // GEO 0: oy = 2 iy - 1 + ky: class parity PY takes ky = 1 (iy = qy) when even, ky = 0 (iy = qy + 1) and ky = 2 (iy = qy) when odd
+        constexpr bool ON = GEO == 1 || ((PY == 0 ? KY == 1 : KY != 1) && (PX == 0 ? KX == 1 : KX != 1));
+        if constexpr (ON) {
+          constexpr int DY = GEO == 1 ? KY : ((PY == 1 && KY == 0) ? 1 : 0), DX = GEO == 1 ? KX : ((PX == 1 && KX == 0) ? 1 : 0);
+          constexpr int TOFF = (DY * SCOLS + DX) * POSB;
+          if constexpr (NCH == 2) {
             v4i av[2][2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-              av[i][0] = *reinterpret_cast<const v4i*>(sA + base[i] + TOFF);
-              av[i][1] = *reinterpret_cast<const v4i*>(sA + A_CH + base[i] + TOFF);
+              av[i][0] = *reinterpret_cast<const v4i*>(A0 + base[i] + TOFF);
+              av[i][1] = *reinterpret_cast<const v4i*>(A0 + A_CH + base[i] + TOFF);
             }
             const v6i b0 = ldb(TAP * TPT + 0), b1 = ldb(TAP * TPT + 1), b2 = ldb(TAP * TPT + 2), b3 = ldb(TAP * TPT + 3),
                       b4 = ldb(TAP * TPT + 4);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-              if (SPK_VT_DBG & 1) { acc[i][0][0] += (float)(av[i][0][0] + av[i][1][1] + b0[0] + b1[1] + b2[2] + b3[3] + b4[4]); continue; }
+              if (SPK_VT_DBG & 1) continue;
               mm(acc[i][0], av[i][0], b0, sc_p);
               mm(acc[i][1], av[i][0], b1, sc_p);
               mm(acc[i][0], av[i][1], b2, sc_p);
@@ -188,89 +225,142 @@ __global__ __launch_bounds__(512, 1) void convT_s2_fp6_kernel(TArgs a) {
               const v4i a4 = half ? av[i][1] : av[i][0];
               mm(acc[i][2], a4, b4, sc_4);
             }
-          }
-        });
-        // ---- epilogue: fp32 recombination, BN, LIF scan with certification, time-collapsed output
+          } else {
+            v4i av[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          // certification (den_mfma_fp6v2.hip): D_t = D_{t-1} / 2 + cE + 4 eps (|z_t| + |v_{t-1}|) and |v| <= max |z|, so
-          // D_t <= 2 cE + 16 eps max_t |z_t| for every t: track max |z| and min |h - 1| (two instructions per step instead
-          // of five) and compare once
-          float v = 0.f, m = 0.f, zmax = 0.f, dmin = 3.0e38f;
-          if (SPK_VT_DBG & 2) {
+            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const v4i*>(A0 + base[i] + TOFF);
+            const v6i b0 = ldb(TAP * TPT + 0), b1 = ldb(TAP * TPT + 1), b4 = ldb(TAP * TPT + 2);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) m += acc[i][0][r] + acc[i][1][r] + acc[i][2][r];
-          } else
-#pragma unroll
-          for (int r2 = 0; r2 < 16; r2 += 2) {
-            // the recombination of two steps at a time on the packed fp32 pipe (adjacent accumulator registers)
-            typedef float v2f __attribute__((ext_vector_type(2)));
-            const v2f p0 = {acc[i][0][r2], acc[i][0][r2 + 1]}, p1 = {acc[i][1][r2], acc[i][1][r2 + 1]},
-                      p2 = {acc[i][2][r2], acc[i][2][r2 + 1]};
-            const v2f z2 = __builtin_elementwise_fma(p0, (v2f){Ac0, Ac0},
-                           __builtin_elementwise_fma(p1, (v2f){Ac1, Ac1}, __builtin_elementwise_fma(p2, (v2f){Ac, Ac}, (v2f){Bc, Bc})));
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              const int r = r2 + e;
-              const float z = z2[e];
-              zmax = fmaxf(zmax, fabsf(z));
-              const float h = fmaf(z - v, 0.5f, v);          // == v + (z - v) * 0.5f: the product is exact
-              dmin = fminf(dmin, fabsf(h - 1.0f));
-              const bool s = h >= 1.0f;
-              v = s ? 0.0f : h;
-              m = m + (s ? coef[r] : 0.f);
+            for (int i = 0; i < 2; ++i) {
+              if (SPK_VT_DBG & 1) continue;
+              mm(acc[i][0], av[i], b0, sc_p);
+              mm(acc[i][1], av[i], b1, sc_p);
+              mm(acc[i][2], av[i], b4, sc_4);
             }
           }
-          const bool flg = dmin <= fmaf(zmax, 5.0f * CERT_4EPS, 2.0f * cE);      // (20 eps: a little to spare)
-          if (i == 1 && !v1) continue;
-          const int r_ = tl[i] / TPR, j_ = tl[i] - r_ * TPR;
-          const int oy = 2 * (hb * HB + r_) + PY, ox = 2 * (2 * j_ + half) + PX;   // accumulator lane half == position in the tile
-          const long long pos = ((long long)b * Ho + oy) * Wo + ox;
-          if (flg) {
-            const long long n = pos * a.Cout + co;
-            const unsigned idx = atomicAdd(a.flags, 1u);
-            if (idx < a.flag_cap) a.flags[2 + idx] = (unsigned)n;
-            else atomicOr(a.flags + 2 + a.flag_cap + (n >> 5), 1u << (n & 31));
+        }
+      });
+      // ---- epilogue: fp32 recombination, BN, LIF scan with certification, output
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        // D_t = D_{t-1} / 2 + cE + 4 eps (|z_t| + |v_{t-1}|) and |v| <= max |z|, so D_t <= 2 cE + 16 eps max_t |z_t| for every t:
+        // track max |z| and min |h - 1| (two instructions per step instead of five) and compare once
+        float v = 0.f, m = 0.f, zmax = 0.f, dmin = 3.0e38f;
+        unsigned mybits = 0;
+        if (SPK_VT_DBG & 2) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) m += acc[i][0][r] + acc[i][1][r] + acc[i][2][r];
+        } else
+#pragma unroll
+        for (int r2 = 0; r2 < 16; r2 += 2) {
+          // the recombination of two steps at a time on the packed fp32 pipe (adjacent accumulator registers)
+          const v2f p0 = {acc[i][0][r2], acc[i][0][r2 + 1]}, p1 = {acc[i][1][r2], acc[i][1][r2 + 1]},
+                    p2 = {acc[i][2][r2], acc[i][2][r2 + 1]};
+          const v2f z2 = __builtin_elementwise_fma(p0, (v2f){Ac0, Ac0},
+                         __builtin_elementwise_fma(p1, (v2f){Ac1, Ac1}, __builtin_elementwise_fma(p2, (v2f){Ac, Ac}, (v2f){Bc, Bc})));
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int r = r2 + e;
+            const float z = z2[e];
+            zmax = fmaxf(zmax, fabsf(z));
+            const float h = fmaf(z - v, 0.5f, v);            // == v + (z - v) * 0.5f: the product is exact
+            dmin = fminf(dmin, fabsf(h - 1.0f));
+            const bool s = h >= 1.0f;
+            v = s ? 0.0f : h;
+            if (OUT == OUT_COLLAPSED) m = m + (s ? coef[r] : 0.f);
+            else mybits |= s ? (1u << r) : 0u;
           }
-          a.out_col[pos * a.Cout + co] = m;
+        }
+        const bool flg = dmin <= fmaf(zmax, 5.0f * CERT_4EPS, 2.0f * cE);      // (20 eps: a little to spare)
+        const int p = 2 * tl[i] + half;                       // accumulator lane half == position within the tile
+        const bool ok = (i == 0 || v1) && p < NPOS;
+        const int pc = p < NPOS ? p : NPOS - 1;
+        const int ry = pc / CW, rx = pc - ry * CW;
+        const int oy = GEO == 0 ? 2 * (part * RQ + ry) + PY : ry, ox = GEO == 0 ? 2 * rx + PX : rx;
+        const long long pos = ((long long)b * Ho + oy) * Wo + ox;
+        if (flg && ok) {
+          const long long nid = pos * a.Cout + co;
+          const unsigned idx = atomicAdd(a.flags, 1u);
+          if (idx < a.flag_cap) a.flags[2 + idx] = (unsigned)nid;
+          else atomicOr(a.flags + 2 + a.flag_cap + (nid >> 5), 1u << (nid & 31));
+        }
+        if (OUT == OUT_COLLAPSED) {
+          if (ok) reinterpret_cast<float*>(a.out)[pos * a.Cout + co] = m;
+        } else {
+          // a 16x16 bit transpose per 16-lane row gives lane t the 16 channel bits of step t (den_mfma_fp6v2.hip)
+          const unsigned bitsv = spk_transpose16_rows(mybits, lane);
+          const int t = lane & 15, hi = (lane >> 4) & 1;
+          if (ok && OUT == OUT_S32) {
+            uint2 o;
+            o.x = spread8_v(bitsv & 0xffu);
+            o.y = spread8_v((bitsv >> 8) & 0xffu);
+            uint8_t* rec = reinterpret_cast<uint8_t*>(a.out) + ((((long long)b * G + g) * Ho * Wo + oy * Wo + ox) * T16 + t) * 16;
+            *reinterpret_cast<uint2*>(rec + 8 * hi) = o;
+          }
+          if (ok && OUT == OUT_PTC) {
+            uint4 o;
+            o.x = ((bitsv & 0xfu) * 0x00204081u) & 0x01010101u;
+            o.y = (((bitsv >> 4) & 0xfu) * 0x00204081u) & 0x01010101u;
+            o.z = (((bitsv >> 8) & 0xfu) * 0x00204081u) & 0x01010101u;
+            o.w = (((bitsv >> 12) & 0xfu) * 0x00204081u) & 0x01010101u;
+            *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(a.out) + (pos * T16 + t) * a.Cout + g * 32 + 16 * hi) = o;
+          }
         }
       }
     };
-    // The two waves of a SIMD (w and w + 4) walk the classes in opposite orders: class 3 is four taps of matrix work per
-    // tile, class 0 one, the LIF scan is the same -- so one wave's multiplications meet the other's scan instead of both
-    // queueing for the same pipe.
-    for (int k = 0; k < 4; ++k) {
-      switch ((wave & 1) ? 3 - k : k) {
-        case 0: run_class(std::integral_constant<int, 0>{}); break;
-        case 1: run_class(std::integral_constant<int, 1>{}); break;
-        case 2: run_class(std::integral_constant<int, 2>{}); break;
-        default: run_class(std::integral_constant<int, 3>{}); break;
+
+    for (int P = wave; P < NCLS * NPASS; P += 8) {
+      const int cls = P / NPASS, k = P - cls * NPASS;
+      if constexpr (NCLS == 1) {
+        run_pass(std::integral_constant<int, 0>{}, k);
+      } else {
+        switch (cls) {
+          case 0: run_pass(std::integral_constant<int, 0>{}, k); break;
+          case 1: run_pass(std::integral_constant<int, 1>{}, k); break;
+          case 2: run_pass(std::integral_constant<int, 2>{}, k); break;
+          default: run_pass(std::integral_constant<int, 3>{}, k); break;
+        }
       }
     }
-    __syncthreads();                                           // everyone is done with the slab before the next copy lands
+    if (!DB) __syncthreads();                                  // everyone is done with the slab before the next copy lands
   }
   spk_dma_wait_all();
 }
 
 // One flagged neuron, exactly, by one wave: lane = (time step t, quarter of a 32-channel chunk); every contributing tap and
 // chunk costs one 4-byte read of the spike record and eight quantised weights; 64-bit sums meet through two shuffles, then
-// lane 0 runs the reference's BN and LIF steps on the correctly rounded pre-activations and rewrites the collapsed value.
-template <int H, int W>
-__device__ __forceinline__ void convT_fix_neuron(const TArgs& a, long long n, int lane) {
-  constexpr int Ho = 2 * H, Wo = 2 * W, NCH = 2;
-  const int co = (int)(n % a.Cout);
-  const long long pos = n / a.Cout;
+// the reference's BN and LIF steps run on the correctly rounded pre-activations and the neuron's output is rewritten.
+template <int GEO, int H, int W, int NCH, int OUT>
+__device__ __forceinline__ void vae_fix_neuron(const TArgs& a, long long nid, int lane) {
+  constexpr int Ho = Geo<GEO, H, W>::Ho, Wo = Geo<GEO, H, W>::Wo;
+  const int co = (int)(nid % a.Cout);
+  const long long pos = nid / a.Cout;
   const int ox = (int)(pos % Wo), oy = (int)((pos / Wo) % Ho), b = (int)(pos / ((long long)Wo * Ho));
   const int t = lane & 15, q = lane >> 4;
   long long part = 0;
   for (int ky = 0; ky < 3; ++ky) {
-    const int ty = oy + 1 - ky;
-    if (ty < 0 || (ty & 1) || (ty >> 1) >= H) continue;
+    int iy;
+    if (GEO == 0) {
+      const int ty = oy + 1 - ky;
+      if (ty < 0 || (ty & 1) || (ty >> 1) >= H) continue;
+      iy = ty >> 1;
+    } else {
+      iy = 2 * oy - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+    }
     for (int kx = 0; kx < 3; ++kx) {
-      const int tx = ox + 1 - kx;
-      if (tx < 0 || (tx & 1) || (tx >> 1) >= W) continue;
-      const int iy = ty >> 1, ix = tx >> 1, tap = ky * 3 + kx;
+      int ix;
+      if (GEO == 0) {
+        const int tx = ox + 1 - kx;
+        if (tx < 0 || (tx & 1) || (tx >> 1) >= W) continue;
+        ix = tx >> 1;
+      } else {
+        ix = 2 * ox - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+      }
+      const int tap = ky * 3 + kx;
       for (int c = 0; c < NCH; ++c) {
+        if (c * 32 + 8 * q >= a.Cin) continue;                // (padding channels of the last chunk carry no weights)
         const unsigned nib = *reinterpret_cast<const unsigned*>(a.in + ((((long long)b * NCH + c) * H * W + iy * W + ix) * T16 + t) * 16 + 4 * q);
         const int4* qp = reinterpret_cast<const int4*>(a.qtab + ((long long)co * 9 + tap) * a.Cin + c * 32 + 8 * q);
         const int4 q0 = qp[0], q1 = qp[1];
@@ -294,6 +384,7 @@ __device__ __forceinline__ void convT_fix_neuron(const TArgs& a, long long n, in
   const double sc = a.scale[co], bi = a.bias[co];
   const float bna = a.bn_a[co], bnb = a.bn_b[co];
   float v = 0.f, m = 0.f;
+  unsigned bits = 0;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int lo = __shfl((int)(unsigned)(part & 0xffffffffll), r);
@@ -301,18 +392,32 @@ __device__ __forceinline__ void convT_fix_neuron(const TArgs& a, long long n, in
     const long long S = (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
     const float y = (float)fma((double)S, sc, bi);
     const bool s = spk_lif_step_default(v, fmaf(y, bna, bnb));
-    m = m + (s ? a.coef[r] : 0.f);
+    if (OUT == OUT_COLLAPSED) m = m + (s ? a.coef[r] : 0.f);
+    bits |= s ? (1u << r) : 0u;
   }
-  if (lane == 0) a.out_col[n] = m;
+  if (OUT == OUT_COLLAPSED) {
+    if (lane == 0) reinterpret_cast<float*>(a.out)[nid] = m;
+  } else if (OUT == OUT_S32) {
+    if (lane < 16) {                                          // lane = time step: one nibble of the (position, t) record
+      const int g = co >> 5, G = a.Cout >> 5, byte = (co & 31) >> 1;
+      uint8_t* rec = reinterpret_cast<uint8_t*>(a.out) + ((((long long)b * G + g) * Ho * Wo + oy * Wo + ox) * T16 + lane) * 16;
+      unsigned* wp = reinterpret_cast<unsigned*>(rec + (byte & ~3));
+      const unsigned shw = 8u * (byte & 3) + 4u * (co & 1);
+      atomicAnd(wp, ~(0xFu << shw));
+      if ((bits >> lane) & 1u) atomicOr(wp, 0x2u << shw);
+    }
+  } else {
+    if (lane < 16) reinterpret_cast<uint8_t*>(a.out)[(pos * T16 + lane) * a.Cout + co] = (uint8_t)((bits >> lane) & 1u);
+  }
 }
 
-template <int H, int W>
-__global__ __launch_bounds__(256) void convT_fp6_fixup_kernel(TArgs a, long long n_words) {
+template <int GEO, int H, int W, int NCH, int OUT>
+__global__ __launch_bounds__(256) void vae_fp6_fixup_kernel(TArgs a, long long n_words) {
   const int lane = threadIdx.x & 63;
   const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwv = (long long)gridDim.x * 4;
   const unsigned count = a.flags[0];
   const unsigned nlist = count < a.flag_cap ? count : a.flag_cap;
-  for (long long e = wv; e < nlist; e += nwv) convT_fix_neuron<H, W>(a, (long long)a.flags[2 + e], lane);
+  for (long long e = wv; e < nlist; e += nwv) vae_fix_neuron<GEO, H, W, NCH, OUT>(a, (long long)a.flags[2 + e], lane);
   if (count > a.flag_cap) {                  // overflow: the rest sit in the bitmap; every wave scans a share, clearing as it goes
     unsigned* bm = a.flags + 2 + a.flag_cap;
     for (long long wi = wv; wi < n_words; wi += nwv) {
@@ -321,27 +426,29 @@ __global__ __launch_bounds__(256) void convT_fp6_fixup_kernel(TArgs a, long long
       while (wd) {
         const int bit = __ffs((int)wd) - 1;
         wd &= wd - 1;
-        convT_fix_neuron<H, W>(a, wi * 32 + bit, lane);
+        vae_fix_neuron<GEO, H, W, NCH, OUT>(a, wi * 32 + bit, lane);
       }
     }
   }
 }
 
-__global__ void convT_fp6_reset_kernel(unsigned* flags) {
+__global__ void vae_fp6_reset_kernel(unsigned* flags) {
   if (threadIdx.x == 0) flags[0] = 0u;
 }
 
-// one block per output channel: channel maximum -> shift s, every weight -> six balanced radix-32 digits; the per-lane
-// 24-byte B fragments of tile (tap, j): j = 0..3: chunk j / 2, digit pair j % 2 (K half 0: even digit, half 1: odd digit, the
-// same 32 input channels); j = 4: the fifth digit, K half 0 = chunk 0, half 1 = chunk 1.  Also the quantised weights
-// themselves (int32 [Cout][9][Cin]) for the exact recomputation.
-__global__ __launch_bounds__(256) void pack_convT_fp6_kernel(const float* __restrict__ w, const float* __restrict__ bias,
-                                                             uint8_t* __restrict__ wq, double* __restrict__ scale,
-                                                             double* __restrict__ bias_d, int* __restrict__ qtab, int Cout,
-                                                             int Cin) {
+// one block per output channel: channel maximum -> shift s, every weight -> six balanced radix-32 digits, written as the
+// per-lane 24-byte B fragments of the tiles listed at tiles_per_tap; also the quantised weights themselves (int32
+// [Cout][9][Cin]) for the exact recomputation.  w: Conv2d [Cout][Cin][3][3] or ConvTranspose2d [Cin][Cout][3][3].
+__global__ __launch_bounds__(256) void pack_vae_fp6_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                           uint8_t* __restrict__ wq, double* __restrict__ scale,
+                                                           double* __restrict__ bias_d, int* __restrict__ qtab, int Cout,
+                                                           int Cin, int transposed) {
   __shared__ float smax[256];
   const int co = blockIdx.x, n = Cin * 9;
-  auto wat = [&](int ci, int tap) -> float { return w[((long long)ci * Cout + co) * 9 + tap]; };   // ConvTranspose2d [Cin][Cout][3][3]
+  const int NCH = (Cin + 31) / 32, TPT = tiles_per_tap(NCH);
+  auto wat = [&](int ci, int tap) -> float {
+    return transposed ? w[((long long)ci * Cout + co) * 9 + tap] : w[((long long)co * Cin + ci) * 9 + tap];
+  };
   float m = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(wat(i / 9, i % 9)));
   smax[threadIdx.x] = m;
@@ -360,11 +467,14 @@ __global__ __launch_bounds__(256) void pack_convT_fp6_kernel(const float* __rest
   }
   if (threadIdx.x == 0) { scale[co] = ldexp(1.0, -sh); bias_d[co] = bias ? (double)bias[co] : 0.0; }
   const int g = co >> 5, col = co & 31;
-  for (int rec = threadIdx.x; rec < NTILE * 2; rec += 256) {
+  for (int rec = threadIdx.x; rec < 9 * TPT * 2; rec += 256) {
     const int kh = rec & 1, tau = rec >> 1, tap = tau / TPT, j = tau % TPT;
-    const int chunk = j < 4 ? (j >> 1) : kh, digit = j < 4 ? 2 * (j & 1) + kh : 4;
+    int chunk, digit;
+    bool live = true;
+    if (NCH == 2) { chunk = j < 4 ? (j >> 1) : kh; digit = j < 4 ? 2 * (j & 1) + kh : 4; }
+    else { chunk = 0; digit = j < 2 ? 2 * j + kh : 4; live = j < 2 || kh == 0; }
     unsigned bits[6] = {0, 0, 0, 0, 0, 0};
-    for (int k = 0; k < 32; ++k) {
+    for (int k = 0; k < 32 && live; ++k) {
       const int ci = chunk * 32 + k;
       long long q = ci < Cin ? (long long)rint(ldexp((double)wat(ci, tap), sh)) : 0ll;
       int dg[6];
@@ -386,7 +496,7 @@ __global__ __launch_bounds__(256) void pack_convT_fp6_kernel(const float* __rest
         if (q2 == wd + 1 && sft > 26) bits[q2] |= code >> (32 - sft);
       }
     }
-    uint8_t* tile = wq + ((long long)g * NTILE + tau) * WT;
+    uint8_t* tile = wq + ((long long)g * 9 * TPT + tau) * WT;
     const int ln = kh * 32 + col;
     unsigned* d16 = reinterpret_cast<unsigned*>(tile + ln * 16);
     unsigned* d8 = reinterpret_cast<unsigned*>(tile + 1024 + ln * 8);
@@ -395,56 +505,99 @@ __global__ __launch_bounds__(256) void pack_convT_fp6_kernel(const float* __rest
   }
 }
 
-template <int H, int W>
-int launch_convT(const TArgs& a, long long n_words, hipStream_t stream) {
-  constexpr int A_BYTES = 2 * (H / 2 + 1) * (W + 1) * POSB;
-  const size_t lds = (size_t)A_BYTES + W_BYTES;
+// u8 PTC [B][HW][16][C] -> S32 [B][ceil(C/32)][HW][16][16 B] (channels beyond C: zero nibbles)
+__global__ void ptc_to_s32_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int HW, int C) {
+  const int nch = (C + 31) / 32;
+  const long long total = (long long)B * nch * HW * T16 * 16;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int byte = (int)(i & 15);
+    long long r = i >> 4;
+    const int t = (int)(r % T16); r /= T16;
+    const int p = (int)(r % HW); r /= HW;
+    const int cc = (int)(r % nch);
+    const int b = (int)(r / nch);
+    const int c0 = cc * 32 + 2 * byte;
+    const uint8_t* src = in + (((long long)b * HW + p) * T16 + t) * C;
+    const uint8_t s0 = c0 < C ? src[c0] : 0, s1 = c0 + 1 < C ? src[c0 + 1] : 0;
+    out[i] = (uint8_t)((s0 ? 0x02 : 0) | (s1 ? 0x20 : 0));
+  }
+}
+
+template <int GEO, int H, int W, int NCH, int OUT, int SPLIT, bool DB>
+int launch_vae(const TArgs& a, long long n_words, hipStream_t stream) {
+  constexpr int TPT = tiles_per_tap(NCH);
+  constexpr int SROWS = GEO == 0 ? H / SPLIT + 1 : H + 1;
+  const size_t lds = (size_t)(DB ? 2 : 1) * NCH * SROWS * (W + 1) * POSB + 9 * TPT * WT;
   if (lds > 160 * 1024) return SPK_ERR_UNSUPPORTED;
   const int cus = spk_cu_count(), G = a.Cout / 32;
   const int grid = cus >= G ? (cus / G) * G : G;
-  hipLaunchKernelGGL((convT_s2_fp6_kernel<H, W>), dim3(grid), dim3(512), lds, stream, a);
+  hipLaunchKernelGGL((vae_fp6_kernel<GEO, H, W, NCH, OUT, SPLIT, DB>), dim3(grid), dim3(512), lds, stream, a);
   SPK_LAUNCH_CHECK();
-  hipLaunchKernelGGL((convT_fp6_fixup_kernel<H, W>), dim3(4 * cus), dim3(256), 0, stream, a, n_words);
+  hipLaunchKernelGGL((vae_fp6_fixup_kernel<GEO, H, W, NCH, OUT>), dim3(4 * cus), dim3(256), 0, stream, a, n_words);
   SPK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(convT_fp6_reset_kernel, dim3(1), dim3(64), 0, stream, a.flags);
+  hipLaunchKernelGGL(vae_fp6_reset_kernel, dim3(1), dim3(64), 0, stream, a.flags);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }
 
 }  // namespace
 
-extern "C" long long spk_convt_fp6_packed_bytes(int Cout, int Cin) {
-  if (Cout <= 0 || Cin != 64 || (Cout % 32)) return -1;
-  return (long long)(Cout / 32) * W_BYTES;
+extern "C" long long spk_vae_fp6_packed_bytes(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0 || Cin > 64 || (Cin % 8) || (Cout % 32)) return -1;
+  return (long long)(Cout / 32) * 9 * tiles_per_tap((Cin + 31) / 32) * WT;
 }
 
-extern "C" int spk_convt_fp6_pack(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d, int* qtab,
-                                  int Cout, int Cin, hipStream_t stream) {
+extern "C" int spk_vae_fp6_pack(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d, int* qtab,
+                                int Cout, int Cin, int transposed, hipStream_t stream) {
   if (!w || !wq || !scale || !bias_d || !qtab || Cout <= 0 || Cin <= 0) return SPK_ERR_ARG;
-  if (Cin != 64 || (Cout % 32)) return SPK_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(pack_convT_fp6_kernel, dim3(Cout), dim3(256), 0, stream, w, bias, wq, scale, bias_d, qtab, Cout, Cin);
+  if (Cin > 64 || (Cin % 8) || (Cout % 32)) return SPK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(pack_vae_fp6_kernel, dim3(Cout), dim3(256), 0, stream, w, bias, wq, scale, bias_d, qtab, Cout, Cin,
+                     transposed);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }
 
-extern "C" long long spk_convt_fp6_flag_words(int B, int Cout, int H, int W) {
-  if (B <= 0 || Cout <= 0 || H <= 0 || W <= 0) return -1;
-  return 2 + (long long)FLAG_CAP + ((long long)B * Cout * 4 * H * W + 31) / 32;
+extern "C" long long spk_vae_fp6_flag_words(int B, int Cout, int Ho, int Wo) {
+  if (B <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0) return -1;
+  return 2 + (long long)FLAG_CAP + ((long long)B * Cout * Ho * Wo + 31) / 32;
 }
 
-extern "C" int spk_convt_fp6_collapsed_fwd(const uint8_t* in_s32, const uint8_t* wq, const double* scale,
-                                           const double* bias_d, const int* qtab, const float* bn_a, const float* bn_b,
-                                           const float* coef, float* out_col, unsigned* flag_words, int T, int B, int H, int W,
-                                           int Cin, int Cout, hipStream_t stream) {
-  if (!in_s32 || !wq || !scale || !bias_d || !qtab || !bn_a || !bn_b || !coef || !out_col || !flag_words || B <= 0)
-    return SPK_ERR_ARG;
-  if (T != T16 || Cin != 64 || (Cout % 32) || B > (1 << 22)) return SPK_ERR_UNSUPPORTED;
+extern "C" int spk_ptc_to_s32(const uint8_t* in_ptc, uint8_t* out_s32, int T, int B, int HW, int C, hipStream_t stream) {
+  if (!in_ptc || !out_s32 || B <= 0 || HW <= 0 || C <= 0) return SPK_ERR_ARG;
+  if (T != T16) return SPK_ERR_UNSUPPORTED;
+  const long long total = (long long)B * ((C + 31) / 32) * HW * T16 * 16;
+  const long long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(ptc_to_s32_kernel, dim3((unsigned)(blocks > 65536 ? 65536 : blocks)), dim3(256), 0, stream, in_ptc, out_s32,
+                     B, HW, C);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_vae_fp6_fwd(const uint8_t* in_s32, const uint8_t* wq, const double* scale, const double* bias_d,
+                               const int* qtab, const float* bn_a, const float* bn_b, const float* coef_or_null, void* out,
+                               int out_kind, unsigned* flag_words, int T, int B, int H, int W, int Cin, int Cout, int transposed,
+                               hipStream_t stream) {
+  if (!in_s32 || !wq || !scale || !bias_d || !qtab || !bn_a || !bn_b || !out || !flag_words || B <= 0) return SPK_ERR_ARG;
+  if (out_kind == OUT_COLLAPSED && !coef_or_null) return SPK_ERR_ARG;
+  if (T != T16 || (Cout % 32) || B > (1 << 22)) return SPK_ERR_UNSUPPORTED;
   TArgs a;
-  a.in = in_s32; a.wq = wq; a.scale = scale; a.bias = bias_d; a.bn_a = bn_a; a.bn_b = bn_b; a.coef = coef; a.out_col = out_col;
+  a.in = in_s32; a.wq = wq; a.scale = scale; a.bias = bias_d; a.bn_a = bn_a; a.bn_b = bn_b; a.coef = coef_or_null; a.out = out;
   a.flags = flag_words; a.flag_cap = FLAG_CAP; a.qtab = qtab; a.B = B; a.Cout = Cout; a.Cin = Cin;
-  const long long n_words = ((long long)B * Cout * 4 * H * W + 31) / 32;
-  if ((long long)B * Cout * 4 * H * W >= (1ll << 32)) return SPK_ERR_UNSUPPORTED;          // neuron ids are 32-bit
-  if (H == 14 && W == 14) return launch_convT<14, 14>(a, n_words, stream);
-  if (H == 16 && W == 16) return launch_convT<16, 16>(a, n_words, stream);
+  const int Ho = transposed ? 2 * H : H / 2, Wo = transposed ? 2 * W : W / 2;
+  const long long neurons = (long long)B * Cout * Ho * Wo;
+  if (neurons >= (1ll << 32)) return SPK_ERR_UNSUPPORTED;                                   // neuron ids are 32-bit
+  const long long n_words = (neurons + 31) / 32;
+  if (transposed && Cin == 64 && out_kind == OUT_COLLAPSED) {                                // decoder convT2
+    if (H == 14 && W == 14) return launch_vae<0, 14, 14, 2, OUT_COLLAPSED, 2, false>(a, n_words, stream);
+    if (H == 16 && W == 16) return launch_vae<0, 16, 16, 2, OUT_COLLAPSED, 2, false>(a, n_words, stream);
+  }
+  if (transposed && Cin == 16 && out_kind == OUT_S32) {                                      // decoder convT1
+    if (H == 7 && W == 7) return launch_vae<0, 7, 7, 1, OUT_S32, 1, true>(a, n_words, stream);
+    if (H == 8 && W == 8) return launch_vae<0, 8, 8, 1, OUT_S32, 1, true>(a, n_words, stream);
+  }
+  if (!transposed && Cin == 32 && out_kind == OUT_PTC) {                                     // encoder conv2
+    if (H == 14 && W == 14) return launch_vae<1, 14, 14, 1, OUT_PTC, 1, true>(a, n_words, stream);
+    if (H == 16 && W == 16) return launch_vae<1, 16, 16, 1, OUT_PTC, 1, false>(a, n_words, stream);   // (two slabs do not fit)
+  }
   return SPK_ERR_UNSUPPORTED;
 }

@@ -89,10 +89,11 @@ _SIGS = {
                                           P]),
     "spk_conv_mfma_fused_lif_s32": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                             c_int, c_int, P]),
-    "spk_convt_fp6_packed_bytes": (c_longlong, [c_int, c_int]),
-    "spk_convt_fp6_pack": (c_int, [P, P, P, P, P, P, c_int, c_int, P]),
-    "spk_convt_fp6_flag_words": (c_longlong, [c_int, c_int, c_int, c_int]),
-    "spk_convt_fp6_collapsed_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "spk_vae_fp6_packed_bytes": (c_longlong, [c_int, c_int]),
+    "spk_vae_fp6_pack": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P]),
+    "spk_vae_fp6_flag_words": (c_longlong, [c_int, c_int, c_int, c_int]),
+    "spk_ptc_to_s32": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "spk_vae_fp6_fwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_select_needed_bytes": (c_longlong, [c_int, c_int]),
     "spk_select_needed": (c_int, [P, c_int, P, c_ulonglong, c_ulonglong, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "spk_den_conv3x3_mfma_fp6v2_listed": (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P,

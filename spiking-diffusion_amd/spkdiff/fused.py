@@ -60,11 +60,11 @@ class ConvParams:
             self.key_fp6 = key
         return self.fp6
 
-    def get_convT_fp6(self, conv):
-        """digit tiles of the decoder's fp6 transposed-convolution kernel (csrc/vae_fp6.hip), built on first use."""
+    def get_vae_fp6(self, conv):
+        """digit tiles of the fp6 kernel of the VQ-VAE's stride-2 layers (csrc/vae_fp6.hip), built on first use."""
         key = (_ver(conv.weight), _ver(conv.bias))
         if key != getattr(self, 'key_convT_fp6', None):
-            self.convT_fp6 = ops.convT_fp6_pack(conv.weight, conv.bias)
+            self.convT_fp6 = ops.vae_fp6_pack(conv.weight, conv.bias, isinstance(conv, nn.ConvTranspose2d))
             self.key_convT_fp6 = key
         return self.convT_fp6
 
@@ -224,6 +224,13 @@ class FusedSequential(nn.Sequential):
         return self.run(x, IN_SEQ, final='f32')['f32']
 
     @staticmethod
+    def _vae_kind(conv, geo, T, H, W):
+        if has_hooks(conv):
+            return None
+        return ops.vae_fp6_kind(conv.in_channels, conv.out_channels, geo['k'], geo['stride'], geo['pad'], geo['out_pad'],
+                                geo['transposed'], T, H, W)
+
+    @staticmethod
     def _next_convT_fp6(block, cur, geo, T):
         """Will ``block`` (the one after the layer with geometry ``geo`` applied to the PTC tensor ``cur``) take the fp6
         transposed-convolution kernel?"""
@@ -280,16 +287,23 @@ class FusedSequential(nn.Sequential):
                 bias = None if conv.bias is None else conv.bias.detach()
                 src1 = in1 if (last and in1 is not None) else None
                 c4 = kind == IN_PTC and cur.dim() == 6 and cur.dtype == ops.C4_DTYPE
-                if (c4 and cur.shape[-1] == 16 and geo['transposed'] and lif is not None and not stateful and
-                        bi == len(blocks) - 2 and final == 'memout' and self._collapsible(blocks[-1], coef, T) and
-                        ops.convT_fp6_supported(conv.in_channels, conv.out_channels, geo['k'], geo['stride'], geo['pad'],
-                                                geo['out_pad'], True, T, cur.shape[2], cur.shape[3])):
-                    # decoder convT2 on the fp6 MFMA, handing the read-out layer its time-collapsed spikes
-                    a, b = bn.affine_terms()
-                    cur = ops.convT_fp6_collapsed(cur, conv._spk_params.get_convT_fp6(conv), conv.out_channels, bn_a=a, bn_b=b,
-                                                  coef=coef)
-                    kind = 'collapsed'
-                    continue
+                if c4 and cur.shape[-1] == 16 and lif is not None and not stateful and impl != 'direct' and not want_pre and src1 is None:
+                    # the VQ-VAE's stride-2 layers on the fp6 MFMA (stateless calls; csrc/vae_fp6.hip)
+                    vk = self._vae_kind(conv, geo, T, cur.shape[2], cur.shape[3])
+                    tail_ok = final == 'memout' and self._collapsible(blocks[-1], coef, T)
+                    if vk == ops.VAE_OUT_COLLAPSED and bi == len(blocks) - 2 and tail_ok:
+                        # decoder convT2, handing the read-out layer its time-collapsed spikes
+                        a, b = bn.affine_terms()
+                        cur = ops.vae_fp6_fwd(cur, conv._spk_params.get_vae_fp6(conv), conv.out_channels, bn_a=a, bn_b=b,
+                                              transposed=True, out_kind=vk, coef=coef)
+                        kind = 'collapsed'
+                        continue
+                    if vk == ops.VAE_OUT_PTC and not last:
+                        a, b = bn.affine_terms()                  # encoder conv2: plain u8 PTC out for the 1x1 layer
+                        cur = ops.vae_fp6_fwd(cur, conv._spk_params.get_vae_fp6(conv), conv.out_channels, bn_a=a, bn_b=b,
+                                              transposed=False, out_kind=vk)
+                        kind = IN_PTC
+                        continue
                 if c4 and cur.shape[-1] == 16:               # S32 records: the sampler's second-generation fp6 kernel
                     ok = (impl != 'direct' and lif is not None and not want_pre and src1 is None and not geo['transposed'] and
                           not stateful and
@@ -392,12 +406,17 @@ class FusedSequential(nn.Sequential):
                                 raise RuntimeError(f'LIFNode state has shape {tuple(lif.v.shape)} but the input implies '
                                                    f'{shape}; call functional.reset_net first')
                             v = lif.v
-                        # the next block runs on the fp6 MFMA (decoder convT2, stateless call): it reads nibble-packed spikes
+                        # the next block runs on the fp6 MFMA (decoder convT2, stateless call): it reads nibble-packed spikes;
+                        # this one (decoder convT1) does too where its shape has an instance
                         if (not last and not stateful and impl != 'direct' and bi == len(blocks) - 3 and final == 'memout' and
                                 conv.out_channels % 32 == 0 and self._collapsible(blocks[-1], coef, T) and
                                 self._next_convT_fp6(blocks[bi + 1], cur, geo, T)):
-                            cur = ops.conv_mfma_fused(cur, packed, conv.out_channels, mode=MODE_LIF, bn_a=a, bn_b=b, v=None,
-                                                      out_s32=True, **geo)
+                            if self._vae_kind(conv, geo, T, cur.shape[1], cur.shape[2]) == ops.VAE_OUT_S32:
+                                cur = ops.vae_fp6_fwd(ops.ptc_to_s32(cur), conv._spk_params.get_vae_fp6(conv), conv.out_channels,
+                                                      bn_a=a, bn_b=b, transposed=True, out_kind=ops.VAE_OUT_S32)
+                            else:
+                                cur = ops.conv_mfma_fused(cur, packed, conv.out_channels, mode=MODE_LIF, bn_a=a, bn_b=b, v=None,
+                                                          out_s32=True, **geo)
                             kind = IN_PTC
                             continue
                         # a linear read-out layer next (conv-only last block + 'memout'): hand it sum_t coef[t] * spikes[t]
@@ -439,10 +458,23 @@ class FusedSequential(nn.Sequential):
                             raise RuntimeError(f'LIFNode state has shape {tuple(lif.v.shape)} but the input implies '
                                                f'{(B, conv.out_channels, Ho, Wo)}; call functional.reset_net first')
                         v = lif.v
+                    co_chunk = chunk_out if last else None
+                    if (not last and not stateful and impl != 'direct' and not want_pre and conv.out_channels % 32 == 0 and
+                            blocks[bi + 1][2] is not None):
+                        # the next block runs on the fp6 MFMA (encoder conv2, stateless call): it reads nibble-packed spikes
+                        if kind == IN_PTC:
+                            Hi, Wi = (cur.shape[2], cur.shape[3]) if cur.dim() == 6 else (cur.shape[1], cur.shape[2])
+                        else:
+                            Hi, Wi = cur.shape[-2], cur.shape[-1]
+                        Hn = ops.conv_out_size(Hi, geo['k'], geo['stride'], geo['pad'], geo['transposed'], geo['out_pad'])
+                        Wn = ops.conv_out_size(Wi, geo['k'], geo['stride'], geo['pad'], geo['transposed'], geo['out_pad'])
+                        nconv = blocks[bi + 1][0]
+                        if self._vae_kind(nconv, conv_geometry(nconv), T, Hn, Wn) == ops.VAE_OUT_PTC and bi + 1 < len(blocks) - 1:
+                            co_chunk = ops.CHUNK_S32
                     r = ops.conv_fused(cur, w_packed, bias, in_kind=kind, T=T, mode=MODE_LIF, in1=src1, bn_a=a, bn_b=b,
                                        v=v, want_ptc=(not last) or final in ('ptc', 'both'),
                                        want_f32=last and final in ('f32', 'both'), want_pre=want_pre,
-                                       chunk_out=(chunk_out if last else None), want_counts=last and want_counts, **geo)
+                                       chunk_out=co_chunk, want_counts=last and want_counts, **geo)
                     if want_pre:
                         out['pre'].append(r['pre'])
                     if last:

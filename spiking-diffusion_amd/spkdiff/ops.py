@@ -945,53 +945,93 @@ def conv_mfma_fused(in_ptc, packed, Cout, *, mode, k, stride, pad, transposed=Fa
     return {"f32": out_f, "u8": out_u}
 
 
+VAE_OUT_COLLAPSED, VAE_OUT_S32, VAE_OUT_PTC = 0, 1, 2
+
+
+def vae_fp6_kind(Cin, Cout, k, stride, pad, out_pad, transposed, T, H, W):
+    """Which output form of the fp6 VQ-VAE kernel (csrc/vae_fp6.hip) exists for this 3x3 stride-2 layer on an H x W input:
+    VAE_OUT_COLLAPSED (decoder convT2), VAE_OUT_S32 (decoder convT1), VAE_OUT_PTC (encoder conv2), or None."""
+    if k != 3 or stride != 2 or pad != 1 or T != 16 or Cout % 32:
+        return None
+    if transposed and out_pad == 1 and Cin == 64 and (H, W) in ((14, 14), (16, 16)):
+        return VAE_OUT_COLLAPSED
+    if transposed and out_pad == 1 and Cin == 16 and (H, W) in ((7, 7), (8, 8)):
+        return VAE_OUT_S32
+    if not transposed and Cin == 32 and (H, W) in ((14, 14), (16, 16)):
+        return VAE_OUT_PTC
+    return None
+
+
 def convT_fp6_supported(Cin, Cout, k, stride, pad, out_pad, transposed, T, H, W):
-    """The fp6 form of the decoder's ConvTranspose2d(64 -> 32 * n, 3, 2, 1, 1) + BN + LIF (csrc/vae_fp6.hip)."""
-    return (transposed and k == 3 and stride == 2 and pad == 1 and out_pad == 1 and T == 16 and Cin == 64 and Cout % 32 == 0 and
-            (H, W) in ((14, 14), (16, 16)))
+    return vae_fp6_kind(Cin, Cout, k, stride, pad, out_pad, transposed, T, H, W) == VAE_OUT_COLLAPSED
 
 
-def convT_fp6_pack(w, bias):
-    """ConvTranspose2d weight fp32 [Cin=64, Cout, 3, 3] (+bias) -> (digit tiles, scale f64, bias f64, qtab int32 [Cout,9,Cin])."""
+def vae_fp6_pack(w, bias, transposed):
+    """Conv2d [Cout,Cin,3,3] / ConvTranspose2d [Cin,Cout,3,3] fp32 (+bias) -> (digit tiles, scale f64, bias f64, qtab int32)."""
     w = _dev(w.detach(), "weight", torch.float32)
-    Cin, Cout = int(w.shape[0]), int(w.shape[1])
-    n = lib.spk_convt_fp6_packed_bytes(Cout, Cin)
+    Cin, Cout = (int(w.shape[0]), int(w.shape[1])) if transposed else (int(w.shape[1]), int(w.shape[0]))
+    n = lib.spk_vae_fp6_packed_bytes(Cout, Cin)
     if n <= 0:
-        raise NotImplementedError("spk_convt_fp6_pack: unsupported shape")
+        raise NotImplementedError("spk_vae_fp6_pack: unsupported shape")
     wq = torch.empty(n, dtype=torch.uint8, device=w.device)
     scale = torch.empty(Cout, dtype=torch.float64, device=w.device)
     bias_d = torch.empty(Cout, dtype=torch.float64, device=w.device)
     qtab = torch.empty((Cout, 9, Cin), dtype=torch.int32, device=w.device)
     b = None if bias is None else _dev(bias.detach(), "bias", torch.float32)
-    check(lib.spk_convt_fp6_pack(_p(w), _p(b), _p(wq), _p(scale), _p(bias_d), _p(qtab), Cout, Cin, _stream(w)),
-          "spk_convt_fp6_pack")
-    return wq, scale, bias_d, qtab
+    check(lib.spk_vae_fp6_pack(_p(w), _p(b), _p(wq), _p(scale), _p(bias_d), _p(qtab), Cout, Cin, int(transposed), _stream(w)),
+          "spk_vae_fp6_pack")
+    return wq, scale, bias_d, qtab, Cin
+
+
+def convT_fp6_pack(w, bias):
+    return vae_fp6_pack(w, bias, True)
 
 
 _CONVT_FLAGS = {}
 
 
-def convT_fp6_collapsed(in_s32, packed, Cout, *, bn_a, bn_b, coef):
-    """in_s32: S32 spikes [B, 2, H, W, 16, 16] -> fp32 [B, 2H, 2W, Cout] = sum_t coef[t] * spikes[t] of
-    ConvTranspose2d(64 -> Cout, 3, 2, 1, 1) + BN + LIF from the reset state (the spike frames are not stored)."""
+def ptc_to_s32(ptc):
+    """u8 PTC spikes [B,H,W,16,C] -> S32 [B, ceil(C/32), H, W, 16, 16] (zero nibbles beyond C)."""
+    ptc = _dev(ptc, "ptc", torch.uint8)
+    B, H, W, T, C = ptc.shape
+    o = torch.empty((B, (C + 31) // 32, H, W, T, 16), dtype=C4_DTYPE, device=ptc.device)
+    check(lib.spk_ptc_to_s32(_p(ptc), _p(o), T, B, H * W, C, _stream(ptc)), "spk_ptc_to_s32")
+    return o
+
+
+def vae_fp6_fwd(in_s32, packed, Cout, *, bn_a, bn_b, transposed, out_kind, coef=None):
+    """One spike-input 3x3 stride-2 VQ-VAE layer + BN + LIF from the reset state on the fp6 MFMA (see vae_fp6_kind).
+    in_s32: S32 spikes [B, nch, H, W, 16, 16].  Returns fp32 [B,Ho,Wo,Cout] (collapsed), S32 [B,Cout/32,Ho,Wo,16,16] or u8 PTC
+    [B,Ho,Wo,16,Cout]."""
     in_s32 = _dev(in_s32, "in_s32", C4_DTYPE)
     B, nch, H, W, T, rec = in_s32.shape
-    if nch != 2 or rec != 16:
-        raise ValueError("S32 spikes of 64 channels expected")
-    wq, scale, bias_d, qtab = packed
-    coef = _dev(coef, "coef", torch.float32)
-    out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=torch.float32, device=in_s32.device)
-    nw = lib.spk_convt_fp6_flag_words(B, Cout, H, W)
+    wq, scale, bias_d, qtab, Cin = packed
+    if rec != 16 or nch != (Cin + 31) // 32:
+        raise ValueError("S32 spikes with ceil(Cin / 32) chunks expected")
+    Ho, Wo = (2 * H, 2 * W) if transposed else (H // 2, W // 2)
+    if out_kind == VAE_OUT_COLLAPSED:
+        coef = _dev(coef, "coef", torch.float32)
+        out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=in_s32.device)
+    elif out_kind == VAE_OUT_S32:
+        out = torch.empty((B, Cout // 32, Ho, Wo, T, 16), dtype=C4_DTYPE, device=in_s32.device)
+    else:
+        out = torch.empty((B, Ho, Wo, T, Cout), dtype=torch.uint8, device=in_s32.device)
+    nw = lib.spk_vae_fp6_flag_words(B, Cout, Ho, Wo)
     key = (in_s32.device.index, nw)
     flags = _CONVT_FLAGS.get(key)
     if flags is None:
-        if len(_CONVT_FLAGS) > 4:
+        if len(_CONVT_FLAGS) > 6:
             _CONVT_FLAGS.clear()
         flags = _CONVT_FLAGS[key] = torch.zeros(nw, dtype=torch.int32, device=in_s32.device)
-    check(lib.spk_convt_fp6_collapsed_fwd(_p(in_s32), _p(wq), _p(scale), _p(bias_d), _p(qtab), _p(bn_a), _p(bn_b), _p(coef),
-                                          _p(out), _p(flags), T, B, H, W, 64, Cout, _stream(in_s32)),
-          "spk_convt_fp6_collapsed_fwd")
+    check(lib.spk_vae_fp6_fwd(_p(in_s32), _p(wq), _p(scale), _p(bias_d), _p(qtab), _p(bn_a), _p(bn_b), _p(coef), _p(out),
+                              int(out_kind), _p(flags), T, B, H, W, Cin, Cout, int(transposed), _stream(in_s32)),
+          "spk_vae_fp6_fwd")
     return out
+
+
+def convT_fp6_collapsed(in_s32, packed, Cout, *, bn_a, bn_b, coef):
+    """Decoder convT2: S32 spikes [B, 2, H, W, 16, 16] -> fp32 [B, 2H, 2W, Cout] = sum_t coef[t] * spikes[t]."""
+    return vae_fp6_fwd(in_s32, packed, Cout, bn_a=bn_a, bn_b=bn_b, transposed=True, out_kind=VAE_OUT_COLLAPSED, coef=coef)
 
 
 def readout_collapsed_supported(Cin, Cout, k):

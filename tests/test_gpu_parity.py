@@ -690,44 +690,58 @@ def test_gather_layer_collapsed_output_matches_its_spikes(dev, ops):
 
 
 
-@pytest.mark.parametrize("B,hw,Cout", [(1, 14, 32), (5, 14, 32), (37, 14, 32), (3, 16, 32), (4, 14, 64)])
-def test_decoder_convT_fp6_kernel_equals_the_int8_gather_kernel(dev, ops, B, hw, Cout):
-    """spk_convt_fp6_collapsed_fwd (five fp6 digit planes, certified decisions, exact repair) against the int8 gather-MFMA
-    kernel (exact by construction) on the decoder's ConvTranspose2d(64 -> Cout, 3, 2, 1, 1) + BN + LIF: the time-collapsed
-    outputs must be bit-equal (same spikes, same fp32 additions), including large and negative BatchNorm scales; the flag
-    workspace must come back clean.  Also the S32 output of the gather kernel against its u8 spikes."""
-    g = torch.Generator().manual_seed(300 + B + hw)
+@pytest.mark.parametrize("layer,B,hw,Cout", [("dec2", 1, 14, 32), ("dec2", 5, 14, 32), ("dec2", 37, 14, 32), ("dec2", 3, 16, 32),
+                                             ("dec2", 4, 14, 64), ("dec1", 1, 7, 64), ("dec1", 21, 7, 64), ("dec1", 3, 8, 64),
+                                             ("enc2", 1, 14, 64), ("enc2", 19, 14, 64), ("enc2", 3, 16, 64)])
+def test_vae_fp6_kernel_equals_the_int8_gather_kernel(dev, ops, layer, B, hw, Cout):
+    """spk_vae_fp6_fwd (five fp6 digit planes, certified decisions, exact repair) against the int8 gather-MFMA kernel (exact
+    by construction) on the VQ-VAE's stride-2 spike-input layers -- decoder convT2 (time-collapsed output), decoder convT1
+    (S32 output, Cin = 16 padded to a 32-channel chunk), encoder conv2 (u8 PTC output) -- with random spikes, weights and
+    BatchNorm terms including large and negative scales: outputs must be bit-equal and the flag workspace must come back clean."""
+    g = torch.Generator().manual_seed(300 + B + hw + len(layer))
     coef = torch.pow(torch.tensor(0.8), torch.arange(15, -1, -1).float()).to(dev)
-    geo = dict(k=3, stride=2, pad=1, transposed=True, out_pad=1)
+    transposed = layer != "enc2"
+    Cin = {"dec2": 64, "dec1": 16, "enc2": 32}[layer]
+    kind = {"dec2": ops.VAE_OUT_COLLAPSED, "dec1": ops.VAE_OUT_S32, "enc2": ops.VAE_OUT_PTC}[layer]
+    geo = dict(k=3, stride=2, pad=1, transposed=transposed, out_pad=1 if transposed else 0)
+    assert ops.vae_fp6_kind(Cin, Cout, 3, 2, 1, geo["out_pad"], transposed, 16, hw, hw) == kind
     total = mism = 0
     for trial, (wamp, aamp, rate) in enumerate(((0.08, 10.0, 0.08), (0.4, 2.5, 0.3))):
-        w = ((torch.rand(64, Cout, 3, 3, generator=g) - 0.5) * wamp)
+        w = ((torch.rand((Cin, Cout, 3, 3) if transposed else (Cout, Cin, 3, 3), generator=g) - 0.5) * wamp)
         w[:, :, 1, 1] *= 3.0
         bias = (torch.rand(Cout, generator=g) - 0.5) * 0.2
         a = ((torch.rand(Cout, generator=g) - 0.3) * aamp).to(dev)
         b = ((torch.rand(Cout, generator=g) - 0.4) * 1.5).to(dev)
-        spikes = (torch.rand(16, B, 64, hw, hw, generator=g) < rate).float().to(dev)
+        spikes = (torch.rand(16, B, Cin, hw, hw, generator=g) < rate).float().to(dev)
         wd, bd = w.to(dev), bias.to(dev)
         ptc = ops.spikes_to_ptc(spikes)
-        want = ops.conv_mfma_fused(ptc, ops.pack_conv_weight_i8(wd, bd, True), Cout, mode=ops.MODE_LIF, bn_a=a, bn_b=b,
-                                   collapse_coef=coef, **geo)
-        got = ops.convT_fp6_collapsed(ops.spikes_to_s32(spikes), ops.convT_fp6_pack(wd, bd), Cout, bn_a=a, bn_b=b, coef=coef)
+        pk8 = ops.pack_conv_weight_i8(wd, bd, transposed)
+        s32 = ops.ptc_to_s32(ptc)
+        if Cin % 32 == 0:
+            assert torch.equal(s32, ops.spikes_to_s32(spikes))
+        got = ops.vae_fp6_fwd(s32, ops.vae_fp6_pack(wd, bd, transposed), Cout, bn_a=a, bn_b=b, transposed=transposed,
+                              out_kind=kind, coef=coef if layer == "dec2" else None)
+        if layer == "dec2":
+            want = ops.conv_mfma_fused(ptc, pk8, Cout, mode=ops.MODE_LIF, bn_a=a, bn_b=b, collapse_coef=coef, **geo)
+        else:
+            want = ops.conv_mfma_fused(ptc, pk8, Cout, mode=ops.MODE_LIF, bn_a=a, bn_b=b, **geo)      # u8 [B,Ho,Wo,16,Cout]
+            if layer == "dec1":
+                got, want = ops.s32_to_spikes(got), ops.ptc_to_spikes(want)
         total += want.numel(); mism += int((want != got).sum())
-        assert torch.equal(want, got), (trial, int((want != got).sum()), float((want - got).abs().max()))
+        assert torch.equal(want, got), (layer, trial, int((want != got).sum()))
         assert 0.0 < float((want > 0).float().mean()) < 1.0
     torch.cuda.synchronize()
     cap = 1 << 20
     assert all(int(v[:2].abs().sum()) == 0 and int(v[2 + cap:].abs().sum()) == 0 for v in ops._CONVT_FLAGS.values())
-    # the producing layer's S32 output (decoder convT1: 16 -> 64 channels, 7x7 -> 14x14)
-    sp1 = (torch.rand(16, B, 16, 7, 7, generator=g) < 0.3).float().to(dev)
-    w1 = ((torch.rand(16, 64, 3, 3, generator=g) - 0.5) * 0.5).to(dev)
-    a1 = (torch.rand(64, generator=g) * 2 + 0.5).to(dev); b1 = (torch.rand(64, generator=g) - 0.5).to(dev)
-    pk1 = ops.pack_conv_weight_i8(w1, None, True)
-    u8 = ops.conv_mfma_fused(ops.spikes_to_ptc(sp1), pk1, 64, mode=ops.MODE_LIF, bn_a=a1, bn_b=b1, **geo)
-    s32 = ops.conv_mfma_fused(ops.spikes_to_ptc(sp1), pk1, 64, mode=ops.MODE_LIF, bn_a=a1, bn_b=b1, out_s32=True, **geo)
-    assert torch.equal(ops.s32_to_spikes(s32), ops.ptc_to_spikes(u8))
-    parity(f"convT_fp6_vs_int8_B{B}_{hw}x{hw}_c{Cout}", collapsed_values=total, mismatches=mism)
-
+    if layer == "dec1":          # the int8 kernel's own S32 output form (used when the fp6 kernel has no instance for a shape)
+        sp1 = (torch.rand(16, B, 16, hw, hw, generator=g) < 0.3).float().to(dev)
+        w1 = ((torch.rand(16, 64, 3, 3, generator=g) - 0.5) * 0.5).to(dev)
+        a1 = (torch.rand(64, generator=g) * 2 + 0.5).to(dev); b1 = (torch.rand(64, generator=g) - 0.5).to(dev)
+        pk1 = ops.pack_conv_weight_i8(w1, None, True)
+        u8 = ops.conv_mfma_fused(ops.spikes_to_ptc(sp1), pk1, 64, mode=ops.MODE_LIF, bn_a=a1, bn_b=b1, **geo)
+        s32o = ops.conv_mfma_fused(ops.spikes_to_ptc(sp1), pk1, 64, mode=ops.MODE_LIF, bn_a=a1, bn_b=b1, out_s32=True, **geo)
+        assert torch.equal(ops.s32_to_spikes(s32o), ops.ptc_to_spikes(u8))
+    parity(f"vae_fp6_{layer}_vs_int8_B{B}_{hw}x{hw}_c{Cout}", values=total, mismatches=mism)
 
 
 # ------------------------------------------------------------------------------------------------- F8 LIF training

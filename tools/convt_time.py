@@ -13,7 +13,7 @@ bias = ((torch.rand(32, generator=g) - 0.5) * 0.1).to(dev)
 a = (torch.rand(32, generator=g) * 2 + 0.5).to(dev); b = (torch.rand(32, generator=g) - 0.8).to(dev)
 coef = torch.pow(torch.tensor(0.8), torch.arange(15, -1, -1).float()).to(dev)
 s32 = ops.spikes_to_s32((torch.rand(16, B, 64, 14, 14, generator=g) < 0.05).float().to(dev))
-pk = ops.convT_fp6_pack(w, bias)
+pk = ops.vae_fp6_pack(w, bias, True)
 for _ in range(3):
     out = ops.convT_fp6_collapsed(s32, pk, 32, bn_a=a, bn_b=b, coef=coef)
 torch.cuda.synchronize()
