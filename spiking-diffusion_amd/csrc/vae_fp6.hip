@@ -47,7 +47,9 @@ struct TArgs {
   const uint8_t* in;                         // S32 [B][NCH][H*W][16][16 B]
   const uint8_t* wq; const double* scale; const double* bias; const float* bn_a; const float* bn_b; const float* coef;
   void* out;
-  unsigned* flags; unsigned flag_cap; const int* qtab;       // qtab int32 [Cout][9][Cin]
+  // flags[0]: live count of flagged neurons (zero between calls), flags[1]: the count published by the main launch's last
+  // workgroup for the repair launch, flags[2 .. 2 + cap): their ids, then the overflow bitmap, then the ticket of that hand-over
+  unsigned* flags; unsigned flag_cap; long long ticket_idx; const int* qtab;       // qtab int32 [Cout][9][Cin]
   int B, Cout, Cin;
 };
 
@@ -325,6 +327,18 @@ __global__ __launch_bounds__(512, 1) void vae_fp6_kernel(TArgs a) {
     if (!DB) __syncthreads();                                  // everyone is done with the slab before the next copy lands
   }
   spk_dma_wait_all();
+  // hand-over to the repair launch: the workgroup that finishes last publishes the count and re-arms the live counter (the
+  // workgroups finish at different times, so this ticket costs nothing; a ticket in the repair launch, whose workgroups all
+  // arrive at once, cost 16 us, a separate reset launch 5)
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    if (atomicAdd(a.flags + a.ticket_idx, 1u) == gridDim.x - 1) {
+      a.flags[1] = atomicAdd(a.flags, 0u);
+      a.flags[0] = 0u;
+      a.flags[a.ticket_idx] = 0u;
+    }
+  }
 }
 
 // One flagged neuron, exactly, by one wave: lane = (time step t, quarter of a 32-channel chunk); every contributing tap and
@@ -415,7 +429,7 @@ template <int GEO, int H, int W, int NCH, int OUT>
 __global__ __launch_bounds__(256) void vae_fp6_fixup_kernel(TArgs a, long long n_words) {
   const int lane = threadIdx.x & 63;
   const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwv = (long long)gridDim.x * 4;
-  const unsigned count = a.flags[0];
+  const unsigned count = a.flags[1];
   const unsigned nlist = count < a.flag_cap ? count : a.flag_cap;
   for (long long e = wv; e < nlist; e += nwv) vae_fix_neuron<GEO, H, W, NCH, OUT>(a, (long long)a.flags[2 + e], lane);
   if (count > a.flag_cap) {                  // overflow: the rest sit in the bitmap; every wave scans a share, clearing as it goes
@@ -430,10 +444,6 @@ __global__ __launch_bounds__(256) void vae_fp6_fixup_kernel(TArgs a, long long n
       }
     }
   }
-}
-
-__global__ void vae_fp6_reset_kernel(unsigned* flags) {
-  if (threadIdx.x == 0) flags[0] = 0u;
 }
 
 // one block per output channel: channel maximum -> shift s, every weight -> six balanced radix-32 digits, written as the
@@ -505,21 +515,38 @@ __global__ __launch_bounds__(256) void pack_vae_fp6_kernel(const float* __restri
   }
 }
 
-// u8 PTC [B][HW][16][C] -> S32 [B][ceil(C/32)][HW][16][16 B] (channels beyond C: zero nibbles)
+// u8 PTC [B][HW][16][C] -> S32 [B][ceil(C/32)][HW][16][16 B] (channels beyond C: zero nibbles); one thread per 16-byte record
 __global__ void ptc_to_s32_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int HW, int C) {
   const int nch = (C + 31) / 32;
-  const long long total = (long long)B * nch * HW * T16 * 16;
+  const long long total = (long long)B * nch * HW * T16;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int byte = (int)(i & 15);
-    long long r = i >> 4;
+    long long r = i;
     const int t = (int)(r % T16); r /= T16;
     const int p = (int)(r % HW); r /= HW;
     const int cc = (int)(r % nch);
     const int b = (int)(r / nch);
-    const int c0 = cc * 32 + 2 * byte;
-    const uint8_t* src = in + (((long long)b * HW + p) * T16 + t) * C;
-    const uint8_t s0 = c0 < C ? src[c0] : 0, s1 = c0 + 1 < C ? src[c0 + 1] : 0;
-    out[i] = (uint8_t)((s0 ? 0x02 : 0) | (s1 ? 0x20 : 0));
+    const uint8_t* src = in + (((long long)b * HW + p) * T16 + t) * C + cc * 32;
+    const int nc = C - cc * 32 < 32 ? C - cc * 32 : 32;
+    unsigned w[4] = {0, 0, 0, 0};
+    if ((C & 15) == 0) {                                    // 16 or 32 channels: vector loads
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (16 * h < nc) {
+          const uint4 v = *reinterpret_cast<const uint4*>(src + 16 * h);
+          const unsigned q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {                     // four bytes (0 / 1) -> four nibbles (0 / 2)
+            const unsigned x = q[k] & 0x01010101u;
+            const unsigned n4 = ((x | (x >> 4)) & 0x00ff00ffu);
+            const unsigned n16 = (n4 | (n4 >> 8)) & 0xffffu;
+            w[2 * h + (k >> 1)] |= (n16 << 1) << (16 * (k & 1));
+          }
+        }
+      }
+    } else {
+      for (int c = 0; c < nc; ++c) w[c >> 3] |= (src[c] ? 2u : 0u) << (4 * (c & 7));
+    }
+    *reinterpret_cast<uint4*>(out + i * 16) = make_uint4(w[0], w[1], w[2], w[3]);
   }
 }
 
@@ -534,8 +561,6 @@ int launch_vae(const TArgs& a, long long n_words, hipStream_t stream) {
   hipLaunchKernelGGL((vae_fp6_kernel<GEO, H, W, NCH, OUT, SPLIT, DB>), dim3(grid), dim3(512), lds, stream, a);
   SPK_LAUNCH_CHECK();
   hipLaunchKernelGGL((vae_fp6_fixup_kernel<GEO, H, W, NCH, OUT>), dim3(4 * cus), dim3(256), 0, stream, a, n_words);
-  SPK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(vae_fp6_reset_kernel, dim3(1), dim3(64), 0, stream, a.flags);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }
@@ -559,13 +584,13 @@ extern "C" int spk_vae_fp6_pack(const float* w, const float* bias, uint8_t* wq, 
 
 extern "C" long long spk_vae_fp6_flag_words(int B, int Cout, int Ho, int Wo) {
   if (B <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0) return -1;
-  return 2 + (long long)FLAG_CAP + ((long long)B * Cout * Ho * Wo + 31) / 32;
+  return 2 + (long long)FLAG_CAP + ((long long)B * Cout * Ho * Wo + 31) / 32 + 1;
 }
 
 extern "C" int spk_ptc_to_s32(const uint8_t* in_ptc, uint8_t* out_s32, int T, int B, int HW, int C, hipStream_t stream) {
   if (!in_ptc || !out_s32 || B <= 0 || HW <= 0 || C <= 0) return SPK_ERR_ARG;
   if (T != T16) return SPK_ERR_UNSUPPORTED;
-  const long long total = (long long)B * ((C + 31) / 32) * HW * T16 * 16;
+  const long long total = (long long)B * ((C + 31) / 32) * HW * T16;
   const long long blocks = (total + 255) / 256;
   hipLaunchKernelGGL(ptc_to_s32_kernel, dim3((unsigned)(blocks > 65536 ? 65536 : blocks)), dim3(256), 0, stream, in_ptc, out_s32,
                      B, HW, C);
@@ -587,6 +612,7 @@ extern "C" int spk_vae_fp6_fwd(const uint8_t* in_s32, const uint8_t* wq, const d
   const long long neurons = (long long)B * Cout * Ho * Wo;
   if (neurons >= (1ll << 32)) return SPK_ERR_UNSUPPORTED;                                   // neuron ids are 32-bit
   const long long n_words = (neurons + 31) / 32;
+  a.ticket_idx = 2 + (long long)FLAG_CAP + n_words;
   if (transposed && Cin == 64 && out_kind == OUT_COLLAPSED) {                                // decoder convT2
     if (H == 14 && W == 14) return launch_vae<0, 14, 14, 2, OUT_COLLAPSED, 2, false>(a, n_words, stream);
     if (H == 16 && W == 16) return launch_vae<0, 16, 16, 2, OUT_COLLAPSED, 2, false>(a, n_words, stream);

@@ -1034,6 +1034,9 @@ def convT_fp6_collapsed(in_s32, packed, Cout, *, bn_a, bn_b, coef):
     return vae_fp6_fwd(in_s32, packed, Cout, bn_a=bn_a, bn_b=bn_b, transposed=True, out_kind=VAE_OUT_COLLAPSED, coef=coef)
 
 
+_COEF_SUMS = {}
+
+
 def readout_collapsed_supported(Cin, Cout, k):
     return Cin % 8 == 0 and k % 2 == 1 and ((4 + k - 1) * 64 * (Cin + 4) + Cout * k * k * Cin) * 4 <= 64 * 1024
 
@@ -1051,9 +1054,15 @@ def readout_collapsed(x_bhwc, weight, bias, coef, *, apply_tanh=False, want_u8=F
         bias = _dev(bias, "bias", torch.float32)
     out_f = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
     out_u = torch.empty((B, Cout, H, W), dtype=torch.uint8, device=x.device) if want_u8 else None
-    csum = 0.0
-    for c in coef.detach().reshape(-1).float().cpu().tolist():          # fp32 left-to-right, as torch.sum over T would add
-        csum = float(torch.tensor(csum, dtype=torch.float32) + torch.tensor(c, dtype=torch.float32))
+    ckey = (coef.data_ptr(), coef._version, coef.numel())
+    csum = _COEF_SUMS.get(ckey)
+    if csum is None:                    # (a device -> host copy: once per coefficient tensor, not per call)
+        csum = 0.0
+        for c in coef.detach().reshape(-1).float().cpu().tolist():      # fp32 left-to-right, as torch.sum over T would add
+            csum = float(torch.tensor(csum, dtype=torch.float32) + torch.tensor(c, dtype=torch.float32))
+        if len(_COEF_SUMS) > 16:
+            _COEF_SUMS.clear()
+        _COEF_SUMS[ckey] = csum
     check(lib.spk_readout_collapsed_fwd(_p(x), _p(w), _p(bias), float(csum), _p(out_f), _p(out_u), int(apply_tanh), B, H, W,
                                         Cin, Cout, int(k), int(pad), int(transposed), _stream(x)), "spk_readout_collapsed_fwd")
     return {"f32": out_f, "u8": out_u}
