@@ -278,6 +278,113 @@ __global__ __launch_bounds__(256) void conv_fused_kernel(FusedArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- time-invariant input + BN + LIF, lean form
+// The first layer of the encoder and the spike generator see the SAME frame at every step (R/main.py:309,
+// vae_model.py:54-56): one dot product per neuron, then the 16-step scan.  The generic kernel above carries every mode and
+// layout in one body (1 800 instructions, scalar registers spilled to lanes); this one is the case the pipeline runs --
+// plain convolution, T = 16, Cout a multiple of 16 that divides 256, spikes out as plain u8 PTC or nibble-packed S32 / C4,
+// optional membrane state and spike counts -- with the same arithmetic in the same order (fp64 accumulation over ky, kx,
+// ci; BN fma; the reference's LIF step).  A thread keeps its output channel for the whole launch and walks positions.
+struct TinvArgs {
+  const float* x; const float* wt; const float* bias; const float* bn_a; const float* bn_b;
+  float* v_io; uint8_t* out; uint8_t* out_cnt;
+  int B, Cin, H, W, Cout, Ho, Wo, k, stride, pad;
+  int out_c4;           // 0: u8 PTC [B][HW][16][Cout]; 32 / 64: S32 / C4
+  const int* n_dyn;
+};
+
+// KC > 0: k = KS and Cin = KC are compile-time and the thread's KS * KS * KC weights live in registers
+template <int KS, int KC>
+__global__ __launch_bounds__(256) void tinv_lif_kernel(TinvArgs a) {
+  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
+  const int co = threadIdx.x % a.Cout, pl = threadIdx.x / a.Cout, ppb = 256 / a.Cout;     // positions per block step
+  const int plane = a.Ho * a.Wo;
+  const int npos = Bn * plane;
+  const float al = a.bn_a[co], be = a.bn_b[co];
+  const double b0 = a.bias ? (double)a.bias[co] : 0.0;
+  const int lane = threadIdx.x & 63;
+  constexpr int NW = KC > 0 ? KS * KS * KC : 1;
+  float wreg[NW];
+  if constexpr (KC > 0) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) wreg[i] = a.wt[i * a.Cout + co];            // packed [k*k][Cin][Cout]
+  }
+  const int HWi = a.H * a.W;
+  for (int p0 = blockIdx.x * ppb; p0 < npos; p0 += gridDim.x * ppb) {
+    const int pg = p0 + pl;
+    const bool ok = pg < npos;
+    const int pc = ok ? pg : npos - 1;
+    const int b = pc / plane, op = pc - b * plane;
+    const int oy = op / a.Wo, ox = op - oy * a.Wo;
+    double acc = b0;
+    if constexpr (KC > 0) {
+      const float* xb = a.x + (long long)b * KC * HWi;
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky) {
+        const int iy = oy * a.stride - a.pad + ky;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          const int ix = ox * a.stride - a.pad + kx;
+          const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+          const int off = in ? iy * a.W + ix : 0;
+#pragma unroll
+          for (int ci = 0; ci < KC; ++ci) {
+            // (an out-of-image tap adds an exact zero: same sum as skipping it)
+            const float xv = in ? xb[ci * HWi + off] : 0.0f;
+            acc += (double)xv * (double)wreg[(ky * KS + kx) * KC + ci];
+          }
+        }
+      }
+    } else {
+      for (int ky = 0; ky < a.k; ++ky) {
+        const int iy = oy * a.stride - a.pad + ky;
+        if (iy < 0 || iy >= a.H) continue;
+        for (int kx = 0; kx < a.k; ++kx) {
+          const int ix = ox * a.stride - a.pad + kx;
+          if (ix < 0 || ix >= a.W) continue;
+          const float* wp = a.wt + (long long)(ky * a.k + kx) * a.Cin * a.Cout + co;
+          const float* xp = a.x + ((long long)b * a.Cin * a.H + iy) * a.W + ix;
+          for (int ci = 0; ci < a.Cin; ++ci) acc += (double)xp[(long long)ci * a.H * a.W] * (double)wp[(long long)ci * a.Cout];
+        }
+      }
+    }
+    const float y0 = fmaf((float)acc, al, be);
+    const long long o_bchw = ((long long)b * a.Cout + co) * plane + op;
+    float v = (a.v_io && ok) ? a.v_io[o_bchw] : 0.0f;
+    unsigned mybits = 0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) mybits |= spk_lif_step_default(v, y0) ? (1u << t) : 0u;
+    if (a.v_io && ok) a.v_io[o_bchw] = v;
+    if (a.out_cnt && ok) a.out_cnt[(((long long)b * (a.Cout >> 5) + (co >> 5)) * plane + op) * 32 + (co & 31)] = (uint8_t)__popc(mybits);
+    // lanes are consecutive output channels (Cout % 16 == 0: the 16 lanes of a DPP row are 16 channels of ONE position); a
+    // 16x16 bit transpose per row gives lane t the 16 channel bits of step t
+    const unsigned bitsv = spk_transpose16_rows(mybits, lane);
+    const int tl = lane & 15, co16 = co & ~15;
+    if (!ok) continue;
+    if (a.out_c4) {
+      auto spread8 = [](unsigned x) -> unsigned {        // bit k -> nibble k, as the e2m1 code of 1.0 (0x2)
+        x = (x | (x << 12)) & 0x000f000fu;
+        x = (x | (x << 6)) & 0x03030303u;
+        x = (x | (x << 3)) & 0x11111111u;
+        return x << 1;
+      };
+      uint2 o;
+      o.x = spread8(bitsv & 0xffu);
+      o.y = spread8((bitsv >> 8) & 0xffu);
+      uint8_t* dst = a.out + ((((long long)b * (a.Cout / a.out_c4) + (co16 / a.out_c4)) * plane + op) * 16 + tl) * (a.out_c4 >> 1) +
+                     ((co16 % a.out_c4) >> 1);
+      *reinterpret_cast<uint2*>(dst) = o;
+    } else {
+      uint4 o;
+      o.x = ((bitsv & 0xfu) * 0x00204081u) & 0x01010101u;
+      o.y = (((bitsv >> 4) & 0xfu) * 0x00204081u) & 0x01010101u;
+      o.z = (((bitsv >> 8) & 0xfu) * 0x00204081u) & 0x01010101u;
+      o.w = (((bitsv >> 12) & 0xfu) * 0x00204081u) & 0x01010101u;
+      *reinterpret_cast<uint4*>(a.out + (((long long)b * plane + op) * 16 + tl) * a.Cout + co16) = o;
+    }
+  }
+}
+
 inline int grid_for(long long work_items) {
   long long g = (work_items + 255) / 256;
   const long long cap = 256 * 8 * 8;
@@ -375,6 +482,22 @@ extern "C" int spk_conv_fused_fwd(const void* in0, const uint8_t* in1, int C0, i
   a.Wo = spk_conv_out_size(W, k, stride, pad, transposed, out_pad);
   a.k = k; a.stride = stride; a.pad = pad;
   if (a.Ho <= 0 || a.Wo <= 0) return SPK_ERR_ARG;
+  if (in_kind == SPK_IN_TINV && mode == SPK_MODE_LIF && T == 16 && out_ptc && !out_f32 && !out_pre && (Cout % 16) == 0 &&
+      (256 % Cout) == 0 && (out_c4 || chunk_out == Cout) && (long long)B * a.Ho * a.Wo < (1ll << 30)) {
+    TinvArgs t;
+    t.x = reinterpret_cast<const float*>(in0); t.wt = w_packed; t.bias = bias; t.bn_a = bn_a; t.bn_b = bn_b; t.v_io = v_inout;
+    t.out = out_ptc; t.out_cnt = out_counts; t.B = B; t.Cin = C0; t.H = H; t.W = W; t.Cout = Cout; t.Ho = a.Ho; t.Wo = a.Wo;
+    t.k = k; t.stride = stride; t.pad = pad; t.out_c4 = out_c4; t.n_dyn = n_dyn_or_null;
+    const long long steps = ((long long)B * a.Ho * a.Wo + (256 / Cout) - 1) / (256 / Cout);
+    const long long cap = 256 * 16;
+    const dim3 tg((unsigned)(steps < cap ? steps : cap)), tb(256);
+    if (k == 3 && C0 == 1) hipLaunchKernelGGL((tinv_lif_kernel<3, 1>), tg, tb, 0, stream, t);            // encoder conv1
+    else if (k == 3 && C0 == 3) hipLaunchKernelGGL((tinv_lif_kernel<3, 3>), tg, tb, 0, stream, t);       // ... on RGB
+    else if (k == 3 && C0 == 2) hipLaunchKernelGGL((tinv_lif_kernel<3, 2>), tg, tb, 0, stream, t);       // denoiser conv1
+    else hipLaunchKernelGGL((tinv_lif_kernel<0, 0>), tg, tb, 0, stream, t);                               // (spike generator: 1x1, 16 channels -- measured faster with the weights left in L1)
+    SPK_LAUNCH_CHECK();
+    return SPK_OK;
+  }
   if (in_kind == SPK_IN_TINV) return launch_mode<SPK_IN_TINV, false>(a, mode, stream);
   if (in_kind == SPK_IN_SEQ)
     return transposed ? launch_mode<SPK_IN_SEQ, true>(a, mode, stream) : launch_mode<SPK_IN_SEQ, false>(a, mode, stream);
