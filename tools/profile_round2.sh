@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_under_prof.json 2> $O/bench_under_prof.err
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $O/v2_$c -- python $R/tools/fp6v2_one.py 512 256 13 > $O/v2_$c.log 2>&1
-  rocprofv3 --pmc $c --output-format csv -d $O/encdec_$c -- python $R/tools/vae_bench.py > $O/encdec_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $O/encdec_$c -- python $R/tools/convt_time.py 1024 5 > $O/encdec_$c.log 2>&1
   rocprofv3 --pmc $c --output-format csv -d $O/lif_$c -- python $R/tools/lif_bench.py > $O/lif_$c.log 2>&1
 done
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F6F4 GRBM_GUI_ACTIVE --output-format csv -d $O/v2_sq -- python $R/tools/fp6v2_one.py 512 256 13 > $O/v2_sq.log 2>&1
@@ -19,3 +19,6 @@ head -c 300 $O/bench_under_prof.json
 # a second trace of the headline measurement alone (per-layer table of profiles/README.md)
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_headline -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --dense-only > $O/bench_headline_under_prof.json 2> $O/bench_headline_under_prof.err
+# trace of the encode->decode workload (configs[2]) and of the reverse process with elimination + position lists
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_encdec -- python $R/bench.py --workload encdec --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_encdec_under_prof.json 2> $O/bench_encdec_under_prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_lists -- python $R/tools/listed_time.py 256 2 > $O/listed_time.log 2>&1

@@ -28,6 +28,17 @@ commit = subprocess.run(["git", "-C", R, "rev-parse", "--short", "HEAD"], captur
 shutil.copy(newest("trace/runc/*_kernel_stats.csv"), os.path.join(O, "r2_bench_kernel_stats.csv"))
 shutil.copy(newest("trace/runc/*_domain_stats.csv"), os.path.join(O, "r2_bench_domain_stats.csv"))
 shutil.copy(os.path.join(P, "bench_under_prof.json"), os.path.join(O, "r2_bench_under_rocprof.json"))
+for src, dst in (("trace_headline/runc/*_kernel_stats.csv", "r2_bench_headline_kernel_stats.csv"),
+                 ("trace_encdec/runc/*_kernel_stats.csv", "r2_encdec_kernel_stats.csv"),
+                 ("trace_lists/runc/*_kernel_stats.csv", "r2_lists_kernel_stats.csv")):
+    try:
+        shutil.copy(newest(src), os.path.join(O, dst))
+    except IndexError:
+        pass
+for src, dst in (("bench_headline_under_prof.json", "r2_bench_headline_under_rocprof.json"),
+                 ("bench_encdec_under_prof.json", "r2_encdec_under_rocprof.json"), ("listed_time.log", "r2_lists_listed_time.log")):
+    if os.path.exists(os.path.join(P, src)):
+        shutil.copy(os.path.join(P, src), os.path.join(O, dst))
 names = {"v2_FETCH_SIZE": "r2_conv4_fp6v2_pmc_fetch_size.csv", "v2_WRITE_SIZE": "r2_conv4_fp6v2_pmc_write_size.csv",
          "v2_sq": "r2_conv4_fp6v2_pmc_sq.csv", "v2_sq2": "r2_conv4_fp6v2_pmc_sq2.csv",
          "encdec_FETCH_SIZE": "r2_encdec_pmc_fetch_size.csv", "encdec_WRITE_SIZE": "r2_encdec_pmc_write_size.csv",
@@ -54,9 +65,10 @@ entry("conv3x3_fp6v2_kernel + tail launches (Cout=512,Cin=256,B=256: den.conv4 s
       "den_mfma_fp6v2.hip",
       {"algorithmic_bytes_per_launch": 256 * 49 * 16 * (256 // 2 + 512 // 2) + 16 * 8 * 38912,
        "note": "algorithmic = input spikes (fp4, S32) + output spikes once + packed weights once"})
-entry("vae.dec2: conv_mfma_gather2_kernel<0, 3, 2, true, 2> (decoder convT2 64->32, 14x14 -> 28x28, B=1024)",
-      "r2_encdec_pmc_fetch_size.csv", "r2_encdec_pmc_write_size.csv", ["conv_mfma_gather2_kernel<0, 3, 2, true, 2"],
-      "conv_mfma_gather.hip", {"algorithmic_bytes_per_launch": 1024 * (196 * 16 * 64 + 784 * 16 * 32) + 64 * 32 * 9 * 4})
+entry("vae.dec2: vae_fp6_kernel<0, 14, 14, 2, 0, 2, false> + repair launch (decoder convT2 64->32, 14x14 -> 28x28, B=1024)",
+      "r2_encdec_pmc_fetch_size.csv", "r2_encdec_pmc_write_size.csv", ["vae_fp6_kernel<0, 14, 14, 2", "vae_fp6_fixup_kernel<0, 14, 14, 2"],
+      "vae_fp6.hip", {"algorithmic_bytes_per_launch": 1024 * (196 * 16 * 32 + 784 * 32 * 4) + 45 * 1536,
+                      "note": "algorithmic = S32 input spikes (1/2 B per neuron-step) + fp32 time-collapsed output + packed weights once"})
 entry("lif_fwd_kernel (T=16,N=25.7M)", "r2_lif_pmc_fetch_size.csv", "r2_lif_pmc_write_size.csv", ["lif_fwd_kernel"], "lif.hip",
       {"algorithmic_bytes_per_launch": 8 * 16 * 1024 * 32 * 28 * 28 + 8 * 1024 * 32 * 28 * 28})
 json.dump(t, open(os.path.join(O, "r2_traffic.json"), "w"), indent=1)
