@@ -13,27 +13,34 @@ namespace {
 
 constexpr int VQ_MAX_D = 64;
 
-// block = 256 threads = 4 waves; one wave per latent position; codebook staged in LDS once per block.
+// block = 256 threads = 4 waves; one wave per latent position; the codebook and its squared norms are staged in LDS once
+// per block; a position's read-out vector lives in registers (16 lane broadcasts), so the position loop has no barrier.
+// Distances in fp64 in the reference's order of operations: x2 + e2 - 2 * dot, sums over d ascending.
 __global__ __launch_bounds__(256) void vq_kernel(const uint8_t* __restrict__ z, const float* __restrict__ x_in,
                                                  const float* __restrict__ coef,
                                                  const float* __restrict__ alpha_p, const float* __restrict__ cb,
                                                  long long* __restrict__ idx_out, float* __restrict__ zq_out,
                                                  float* __restrict__ xm_out, int T, int B, int D, int HW, int K) {
   extern __shared__ float lds[];
-  float* s_cb = lds;                         // [K][D+1]
-  float* s_x = s_cb + K * (D + 1);           // [4][VQ_MAX_D]
+  float* s_cb = lds;                                               // [K][D+1]
+  double* s_e2 = reinterpret_cast<double*>(s_cb + ((K * (D + 1) + 1) & ~1));   // [K]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < K * D; i += blockDim.x) s_cb[(i / D) * (D + 1) + (i % D)] = cb[i];
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    double e2 = 0.0;
+    for (int d = 0; d < D; ++d) { const double e = s_cb[k * (D + 1) + d]; e2 += e * e; }
+    s_e2[k] = e2;
+  }
   __syncthreads();
   const float alpha = alpha_p ? alpha_p[0] : 0.f;
   const float one_m_alpha = 1.0f - alpha;
   const long long npos = (long long)B * HW;
-  for (long long p0 = (long long)blockIdx.x * 4; p0 < npos; p0 += (long long)gridDim.x * 4) {
-    const long long p = p0 + wave;
-    const bool live = p < npos;
-    if (live && lane < D && x_in) {
-      s_x[wave * VQ_MAX_D + lane] = x_in[p * D + lane];
-    } else if (live && lane < D) {
+  for (long long p = (long long)blockIdx.x * 4 + wave; p < npos; p += (long long)gridDim.x * 4) {
+    float xl = 0.f;                                                // lane d < D holds x[d]
+    if (lane < D && x_in) {
+      xl = x_in[p * D + lane];
+    } else if (lane < D) {
       const uint8_t* zp = z + p * T * D + lane;
       float m = 0.f, cnt = 0.f;
       for (int t = 0; t < T; ++t) {
@@ -41,26 +48,20 @@ __global__ __launch_bounds__(256) void vq_kernel(const uint8_t* __restrict__ z, 
         m = m + s * coef[t];
         cnt = cnt + s;
       }
-      float x = one_m_alpha * m + (alpha * cnt) / (float)T;
-      s_x[wave * VQ_MAX_D + lane] = x;
-      if (xm_out) xm_out[p * D + lane] = x;
+      xl = one_m_alpha * m + (alpha * cnt) / (float)T;
+      if (xm_out) xm_out[p * D + lane] = xl;
     }
-    __syncthreads();
     double best = 1.0e300;
     int besti = 0x7fffffff;
-    if (live) {
-      double x2 = 0.0;
-      for (int d = 0; d < D; ++d) { double xv = s_x[wave * VQ_MAX_D + d]; x2 += xv * xv; }
-      for (int k = lane; k < K; k += 64) {
-        double e2 = 0.0, dot = 0.0;
-        for (int d = 0; d < D; ++d) {
-          double e = s_cb[k * (D + 1) + d];
-          e2 += e * e;
-          dot += (double)s_x[wave * VQ_MAX_D + d] * e;
-        }
-        double dist = x2 + e2 - 2.0 * dot;
-        if (dist < best) { best = dist; besti = k; }       // k increasing per lane: first minimum kept
-      }
+    double x2 = 0.0;
+    for (int d = 0; d < D; ++d) { const double xv = (double)__shfl(xl, d); x2 += xv * xv; }
+    for (int k0 = 0; k0 < K; k0 += 64) {
+      const int k = k0 + lane;
+      const int kc = k < K ? k : K - 1;
+      double dot = 0.0;
+      for (int d = 0; d < D; ++d) dot += (double)__shfl(xl, d) * (double)s_cb[kc * (D + 1) + d];
+      const double dist = x2 + s_e2[kc] - 2.0 * dot;
+      if (k < K && dist < best) { best = dist; besti = k; }        // k increasing per lane: first minimum kept
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -68,14 +69,11 @@ __global__ __launch_bounds__(256) void vq_kernel(const uint8_t* __restrict__ z, 
       int oi = __shfl_xor(besti, off);
       if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
     }
-    if (live) {
-      if (lane == 0) idx_out[p] = (long long)besti;
-      if (zq_out && lane < D) {
-        const int b = (int)(p / HW), hw = (int)(p % HW);
-        zq_out[((long long)b * D + lane) * HW + hw] = s_cb[besti * (D + 1) + lane];
-      }
+    if (lane == 0) idx_out[p] = (long long)besti;
+    if (zq_out && lane < D) {
+      const int b = (int)(p / HW), hw = (int)(p % HW);
+      zq_out[((long long)b * D + lane) * HW + hw] = s_cb[besti * (D + 1) + lane];
     }
-    __syncthreads();
   }
 }
 
@@ -107,7 +105,7 @@ extern "C" int spk_vq_readout_argmin(const uint8_t* z_ptc, const float* coef, co
   if (!z_ptc || !coef || !alpha || !codebook || !idx_out || T <= 0 || B <= 0 || D <= 0 || D > VQ_MAX_D || HW <= 0 ||
       K <= 0)
     return SPK_ERR_ARG;
-  size_t lds = (size_t)(K * (D + 1) + 4 * VQ_MAX_D) * sizeof(float);
+  size_t lds = (size_t)(((K * (D + 1) + 1) & ~1)) * sizeof(float) + (size_t)K * sizeof(double);
   if (lds > 64 * 1024) return SPK_ERR_UNSUPPORTED;
   long long npos = (long long)B * HW;
   int grid = (int)((npos + 3) / 4);
@@ -122,7 +120,7 @@ extern "C" int spk_vq_argmin(const float* flat_x, const float* codebook, long lo
                              hipStream_t stream) {
   if (!flat_x || !codebook || !idx_out || N <= 0 || N > 0x7fffffff || D <= 0 || D > VQ_MAX_D || K <= 0)
     return SPK_ERR_ARG;
-  size_t lds = (size_t)(K * (D + 1) + 4 * VQ_MAX_D) * sizeof(float);
+  size_t lds = (size_t)(((K * (D + 1) + 1) & ~1)) * sizeof(float) + (size_t)K * sizeof(double);
   if (lds > 64 * 1024) return SPK_ERR_UNSUPPORTED;
   int grid = (int)((N + 3) / 4);
   if (grid > 2048) grid = 2048;

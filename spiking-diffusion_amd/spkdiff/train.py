@@ -1,0 +1,54 @@
+"""Training-loop helpers of the MI355X build (not in the reference).
+
+``GraphedTrainStep`` captures ONE iteration of the reference's diffusion training loop (R/main.py:243-252:
+``abdiff.train_iter(x)['loss']`` -> ``optim.zero_grad()`` -> ``loss.backward()`` -> ``optim.step()`` ->
+``functional.reset_net``) as a hipGraph and replays it per batch.  At the reference's batch of 32 token maps the iteration is
+bound by launch overhead (about 150 launches, 4.3 ms of kernels in 5.5 ms of wall time); the replay removes it.  The random
+draws (``sample_time``, ``q_sample``) are device-side and graph-safe: every replay draws fresh noise from torch's CUDA
+generator.  The optimizer must be constructed with ``capturable=True``."""
+from __future__ import annotations
+
+import torch
+
+
+class GraphedTrainStep:
+    def __init__(self, abdiff, optimizer, example_batch: torch.Tensor, warmup: int = 3):
+        from spikingjelly.activation_based import functional
+        den = abdiff._denoise_fn
+        if not den.training:
+            raise RuntimeError('spkdiff: put the denoiser in train() mode before capturing a training step')
+        if example_batch.device.type != 'cuda':
+            raise RuntimeError('spkdiff: the training step runs on a ROCm device')
+        for g in optimizer.param_groups:
+            if not g.get('capturable', False):
+                raise RuntimeError('spkdiff: construct the optimizer with capturable=True to capture its step')
+        self.abdiff, self.optimizer, self.den = abdiff, optimizer, den
+        self.static_x = example_batch.detach().clone()
+        dev = example_batch.device
+
+        def step():
+            loss = abdiff.train_iter(self.static_x)['loss']
+            loss.backward()
+            optimizer.step()
+            functional.reset_net(net=den)
+            return loss
+
+        # warm-up on a side stream (library algorithm selection, allocator pools, optimizer state), then capture
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                optimizer.zero_grad(set_to_none=True)
+                step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)          # gradients are allocated inside the capture (the graph's pool)
+        with torch.cuda.graph(self.graph):
+            self.loss = step()
+
+    def __call__(self, batch: torch.Tensor) -> torch.Tensor:
+        """One training iteration on ``batch`` (same shape as the example).  Returns the loss tensor (overwritten by the
+        next call)."""
+        self.static_x.copy_(batch)
+        self.graph.replay()
+        return self.loss

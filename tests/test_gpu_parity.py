@@ -745,6 +745,29 @@ def test_vae_fp6_kernel_equals_the_int8_gather_kernel(dev, ops, layer, B, hw, Co
     parity(f"vae_fp6_{layer}_vs_int8_B{B}_{hw}x{hw}_c{Cout}", values=total, mismatches=mism)
 
 
+def test_graphed_training_step_trains(dev):
+    """spkdiff.train.GraphedTrainStep: one captured iteration of the reference's diffusion training loop (train_iter, backward,
+    AdamW, reset_net) replayed per batch -- finite decreasing-on-average loss, parameters move, fresh noise per replay."""
+    from snn_model.vq_diffusion import DummyModel, AbsorbingDiffusion, functional
+    from spkdiff.train import GraphedTrainStep
+    den = DummyModel(1, 128, n_steps=16).cuda(0)
+    functional.set_step_mode(net=den, step_mode='m')
+    den.load_state_dict(synth.synth_denoiser_state(synth.MNIST))
+    den.train()
+    ab = AbsorbingDiffusion(den, mask_id=128)
+    opt = torch.optim.AdamW(den.parameters(), lr=1e-3, weight_decay=0.001, capturable=True)
+    x0 = torch.randint(0, 128, (8, 1, 7, 7), generator=torch.Generator().manual_seed(3)).float().to(dev)
+    w_before = den.conv4[0].weight.detach().clone()
+    step = GraphedTrainStep(ab, opt, x0)
+    losses = [float(step(x0).detach()) for _ in range(12)]
+    assert all(l == l and abs(l) < 1e4 for l in losses)
+    assert len(set(losses)) > 6, "every replay draws its own t and mask"
+    assert float((den.conv4[0].weight.detach() - w_before).abs().max()) > 0
+    with pytest.raises(RuntimeError):
+        GraphedTrainStep(ab, torch.optim.AdamW(den.parameters(), lr=1e-3), x0)
+
+
+
 # ------------------------------------------------------------------------------------------------- F8 LIF training
 @pytest.mark.parametrize("det", [False, True])
 def test_f8_lif_training_bptt_vs_reference_fixture(golden_dir, dev, det):
