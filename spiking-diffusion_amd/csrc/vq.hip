@@ -16,11 +16,14 @@ constexpr int VQ_MAX_D = 64;
 // block = 256 threads = 4 waves; one wave per latent position; the codebook and its squared norms are staged in LDS once
 // per block; a position's read-out vector lives in registers (16 lane broadcasts), so the position loop has no barrier.
 // Distances in fp64 in the reference's order of operations: x2 + e2 - 2 * dot, sums over d ascending.
+// DC > 0: D == DC at compile time (the read-out vector then sits in DC scalar-broadcast registers and the loops unroll)
+template <int DC>
 __global__ __launch_bounds__(256) void vq_kernel(const uint8_t* __restrict__ z, const float* __restrict__ x_in,
                                                  const float* __restrict__ coef,
                                                  const float* __restrict__ alpha_p, const float* __restrict__ cb,
                                                  long long* __restrict__ idx_out, float* __restrict__ zq_out,
-                                                 float* __restrict__ xm_out, int T, int B, int D, int HW, int K) {
+                                                 float* __restrict__ xm_out, int T, int B, int D_rt, int HW, int K) {
+  const int D = DC > 0 ? DC : D_rt;
   extern __shared__ float lds[];
   float* s_cb = lds;                                               // [K][D+1]
   double* s_e2 = reinterpret_cast<double*>(s_cb + ((K * (D + 1) + 1) & ~1));   // [K]
@@ -43,10 +46,20 @@ __global__ __launch_bounds__(256) void vq_kernel(const uint8_t* __restrict__ z, 
     } else if (lane < D) {
       const uint8_t* zp = z + p * T * D + lane;
       float m = 0.f, cnt = 0.f;
-      for (int t = 0; t < T; ++t) {
-        float s = (float)zp[t * D];
-        m = m + s * coef[t];
-        cnt = cnt + s;
+      if (DC > 0 && T == 16) {
+        // all sixteen spike bytes and coefficients are requested before the first is used (a rolled loop waits for each
+        // pair in turn: sixteen dependent round trips per position); the sums keep the reference's order over t
+        float sv[16], cf[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { sv[t] = (float)zp[t * D]; cf[t] = coef[t]; }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { m = m + sv[t] * cf[t]; cnt = cnt + sv[t]; }
+      } else {
+        for (int t = 0; t < T; ++t) {
+          float s = (float)zp[t * D];
+          m = m + s * coef[t];
+          cnt = cnt + s;
+        }
       }
       xl = one_m_alpha * m + (alpha * cnt) / (float)T;
       if (xm_out) xm_out[p * D + lane] = xl;
@@ -54,14 +67,29 @@ __global__ __launch_bounds__(256) void vq_kernel(const uint8_t* __restrict__ z, 
     double best = 1.0e300;
     int besti = 0x7fffffff;
     double x2 = 0.0;
-    for (int d = 0; d < D; ++d) { const double xv = (double)__shfl(xl, d); x2 += xv * xv; }
-    for (int k0 = 0; k0 < K; k0 += 64) {
-      const int k = k0 + lane;
-      const int kc = k < K ? k : K - 1;
-      double dot = 0.0;
-      for (int d = 0; d < D; ++d) dot += (double)__shfl(xl, d) * (double)s_cb[kc * (D + 1) + d];
-      const double dist = x2 + s_e2[kc] - 2.0 * dot;
-      if (k < K && dist < best) { best = dist; besti = k; }        // k increasing per lane: first minimum kept
+    if constexpr (DC > 0) {
+      double xr[DC];
+#pragma unroll
+      for (int d = 0; d < DC; ++d) { xr[d] = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xl), d)); x2 += xr[d] * xr[d]; }
+      for (int k0 = 0; k0 < K; k0 += 64) {
+        const int k = k0 + lane;
+        const int kc = k < K ? k : K - 1;
+        double dot = 0.0;
+#pragma unroll
+        for (int d = 0; d < DC; ++d) dot += xr[d] * (double)s_cb[kc * (DC + 1) + d];
+        const double dist = x2 + s_e2[kc] - 2.0 * dot;
+        if (k < K && dist < best) { best = dist; besti = k; }      // k increasing per lane: first minimum kept
+      }
+    } else {
+      for (int d = 0; d < D; ++d) { const double xv = (double)__shfl(xl, d); x2 += xv * xv; }
+      for (int k0 = 0; k0 < K; k0 += 64) {
+        const int k = k0 + lane;
+        const int kc = k < K ? k : K - 1;
+        double dot = 0.0;
+        for (int d = 0; d < D; ++d) dot += (double)__shfl(xl, d) * (double)s_cb[kc * (D + 1) + d];
+        const double dist = x2 + s_e2[kc] - 2.0 * dot;
+        if (k < K && dist < best) { best = dist; besti = k; }      // k increasing per lane: first minimum kept
+      }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -110,8 +138,12 @@ extern "C" int spk_vq_readout_argmin(const uint8_t* z_ptc, const float* coef, co
   long long npos = (long long)B * HW;
   int grid = (int)((npos + 3) / 4);
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(vq_kernel, dim3(grid), dim3(256), lds, stream, z_ptc, (const float*)nullptr, coef, alpha,
-                     codebook, idx_out, zq_out_bdhw, xm_out, T, B, D, HW, K);
+  if (D == 16)
+    hipLaunchKernelGGL(vq_kernel<16>, dim3(grid), dim3(256), lds, stream, z_ptc, (const float*)nullptr, coef, alpha,
+                       codebook, idx_out, zq_out_bdhw, xm_out, T, B, D, HW, K);
+  else
+    hipLaunchKernelGGL(vq_kernel<0>, dim3(grid), dim3(256), lds, stream, z_ptc, (const float*)nullptr, coef, alpha,
+                       codebook, idx_out, zq_out_bdhw, xm_out, T, B, D, HW, K);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }
@@ -124,7 +156,7 @@ extern "C" int spk_vq_argmin(const float* flat_x, const float* codebook, long lo
   if (lds > 64 * 1024) return SPK_ERR_UNSUPPORTED;
   int grid = (int)((N + 3) / 4);
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(vq_kernel, dim3(grid), dim3(256), lds, stream, (const uint8_t*)nullptr, flat_x,
+  hipLaunchKernelGGL(vq_kernel<0>, dim3(grid), dim3(256), lds, stream, (const uint8_t*)nullptr, flat_x,
                      (const float*)nullptr, (const float*)nullptr, codebook, idx_out, (float*)nullptr, (float*)nullptr,
                      1, (int)N, D, 1, K);
   SPK_LAUNCH_CHECK();
