@@ -47,7 +47,13 @@ constexpr int N_PAIR = 18;                               // tiles 0..17: (tap, d
 constexpr int N_D4 = 5;                                  // tiles 18..22: fifth digit, taps (0,1) (2,3) (4,5) (6,7) (8,-)
 constexpr int N_MAIN = N_PAIR + N_D4;
 constexpr int N_L5 = 2;                                  // tiles 23, 24: sixth digit of taps (0,1) and (3,4), last position only
-constexpr int W_PIECES = (N_MAIN * WT + 1023) / 1024;    // 35 one-KiB DMA pieces
+#ifndef SPK_V2_D4
+#define SPK_V2_D4 0             // 1: the fifth digit is multiplied on the matrix cores as well (23 instead of 18 MFMAs per tile and chunk)
+#endif
+constexpr bool USE_D4 = SPK_V2_D4 != 0;
+constexpr int N_MM = USE_D4 ? N_MAIN : N_PAIR;           // tiles the main launch multiplies (the tail launches read all of them)
+constexpr int NACC = USE_D4 ? 3 : 2;                     // accumulators per row tile
+constexpr int W_PIECES = (N_MM * WT + 1023) / 1024;      // one-KiB DMA pieces per chunk (27 / 35)
 constexpr int W_LDS = W_PIECES * 1024;
 constexpr int W_SLAB = ((N_MAIN + N_L5) * WT + 1023) / 1024 * 1024;   // bytes per (channel group, chunk) in memory
 
@@ -165,15 +171,15 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
                       : ((HW & 1) == 1 && ((HW / 2) % NWV) == 0), "whole 32-row tiles on every wave (+ one odd position)");
   static_assert(!PRUNE || (!SPLIT && NWV == 4 && NTP <= (HWb / 2) / NWV), "position lists: 7x7 items, one wave per SIMD");
   constexpr int NT = PRUNE ? NTP : (HWb / 2) / NWV;    // row tiles per wave (7x7: 6 or 3; 8x8 bands: 4)
-  constexpr int N_AGPR = NWV == 4 ? (3 * NT < 16 ? 3 * NT : 16) : 8;   // (two waves per SIMD: hipcc splits 256 registers 128 / 128)
+  constexpr int N_AGPR = NWV == 4 ? (NACC * NT < 16 ? NACC * NT : 16) : 8;   // (two waves per SIMD: hipcc splits 256 registers 128 / 128)
   constexpr int NPP = (Hin + 2) * PW + 1;              // cells of the zero-bordered LDS image (pitch W + 1: the zero
   constexpr int A_BYTES = NPP * POSB;                  //  column is shared by x = -1 of a row and x = W of the previous)
   constexpr int PPR = (W + 3) / 4;                     // DMA pieces per image row (4 positions per KiB piece)
   constexpr int NA = Hin * PPR;
   constexpr int NPA = (NA + NWV - 1) / NWV;            // A pieces per wave
   constexpr int NPW = (W_PIECES + NWV - 1) / NWV;      // W pieces per wave
-  constexpr int NS_PAIR = 9 * NT, NSTEP = NS_PAIR + N_D4 * NT;
-  static_assert(NWV == 8 || 3 * NT <= 16 || (NT - 1) * 3 <= N_AGPR + 2, "only the last tile may straddle the register files");
+  constexpr int NS_PAIR = 9 * NT, NSTEP = NS_PAIR + (USE_D4 ? N_D4 * NT : 0);
+  static_assert(NWV == 8 || NACC * NT <= 16 || (NT - 1) * NACC <= N_AGPR + 2, "only the last tile may straddle the register files");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   uint8_t* const sA = lds;
   uint8_t* const sW = lds + 2 * A_BYTES;
@@ -242,7 +248,14 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
   const float bna = a.bn_a[co], bnb = a.bn_b[co];
   const float Ac = 32.0f * scale_f * bna;                 // z = fma(Q5, Ac, Bc),  Q5 = P01 * 2^15 + P23 * 2^5 + P4
   const float Bc = fmaf(bias_f, bna, bnb);
-  const float cE = cert_const(bias_f, bna, bnb, Bc, scale_f, a.Cin);
+  // certification constants: five-digit form: cE covers the dropped sixth digit with every input active (cert_const); four-digit
+  // form: cE holds the rounding terms only and cT the dropped digits PER ACTIVE INPUT (|32 d4 + d5| <= 528 units of 2^-s each,
+  // rounded up), multiplied in the epilogue by the number of active inputs of the row -- 5-7x tighter than "every input
+  // active" at the firing rates of the denoiser, which is what lets the fifth digit leave the matrix cores
+  const float cE = USE_D4 ? cert_const(bias_f, bna, bnb, Bc, scale_f, a.Cin)
+                          : 2.0f * 2.38418579e-07f * (fabsf(bnb) + fabsf(Bc)) + 1e-30f;
+  const float cT = 528.0f * scale_f * fabsf(bna) * 1.000001f;
+  const float Ac4 = 1024.0f * scale_f * bna;               // (four-digit form)
 
   const int sc_a = 0x7f7f7f7f;                            // e8m0 block scales: spikes x 1
   const int sc_p = half ? (int)0x82828282u : (int)0x87878787u;   // digit pairs: even digit (K half 0) x 2^8, odd digit x 2^3
@@ -273,7 +286,10 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
         p_out[i] = rec[k2 + half];
       }
     }
-    v16f acc[NT][3];      // [i][0]: pair 01, [i][1]: pair 23, [i][2]: fifth digit; written (not accumulated) by the first MFMA
+    v16f acc[NT][NACC];   // [i][0]: pair 01, [i][1]: pair 23, ([i][2]: fifth digit;) written (not accumulated) by the first MFMA
+    int cnt[NT];          // four-digit form: active inputs of this lane's row (position, step) over all taps and chunks
+#pragma unroll
+    for (int i = 0; i < NT; ++i) cnt[i] = 0;
     for (int c = 0; c < nch; ++c, ++it) {
       const int buf = it & 1;
       spk_dma_wait_all();  // this wave's share of the chunk's DMA has landed ...
@@ -294,11 +310,12 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
         // Step order: blocks of NT steps (one per row tile) -- tap 0, tap 1, D(0), tap 2, tap 3, D(1), ..., tap 8, D(4), where a
         // tap block issues the two digit-pair MFMAs per step and D(q) the single fifth-digit MFMA of taps (2q, 2q + 1).  The
         // one-MFMA blocks sit BETWEEN two-MFMA blocks (six in a row left the fragment prefetch only ~130 cycles ahead).
-        auto blk_is_d = [](int blk) constexpr -> bool { return blk < 12 ? (blk % 3 == 2) : (blk == 13); };
-        auto blk_tap = [](int blk) constexpr -> int { return blk < 12 ? 2 * (blk / 3) + (blk % 3) : 8; };      // tap blocks
+        // (four-digit form, USE_D4 == false: the nine tap blocks only)
+        auto blk_is_d = [](int blk) constexpr -> bool { return USE_D4 && (blk < 12 ? (blk % 3 == 2) : (blk == 13)); };
+        auto blk_tap = [](int blk) constexpr -> int { return !USE_D4 ? blk : (blk < 12 ? 2 * (blk / 3) + (blk % 3) : 8); };   // tap blocks
         auto blk_q = [](int blk) constexpr -> int { return blk < 12 ? blk / 3 : 4; };                          // D blocks
-        constexpr int NBLK = 14;
-        static_assert(NSTEP == NBLK * NT, "14 blocks of NT steps");
+        constexpr int NBLK = USE_D4 ? 14 : 9;
+        static_assert(NSTEP == NBLK * NT, "blocks of NT steps");
         auto lda = [&](auto s_tag) -> v4i {
           constexpr int s = decltype(s_tag)::value;
           constexpr int blk = s / NT, i = s % NT;
@@ -331,10 +348,14 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
           const v4i av = af[s % PF];
           if constexpr (s + PF < NSTEP) af[s % PF] = lda(std::integral_constant<int, s + PF>{});
           constexpr int NPIECES = NPA + NPW;
+          // two copy slots per block (its first step and its middle step): 18 slots for the 11 pieces of the four-digit form
 #define V2_DMA_SLOT()                                                                              \
   do {                                                                                             \
-    if constexpr (i == 0 && blk < NPIECES) {                                                       \
-      if (!(SPK_V2_DBG & 1)) issue_piece(blk, n_aslab, n_wslab, n_dA, n_dW);                       \
+    if constexpr (i == 0 && 2 * blk < NPIECES) {                                                   \
+      if (!(SPK_V2_DBG & 1)) issue_piece(2 * blk, n_aslab, n_wslab, n_dA, n_dW);                   \
+    }                                                                                              \
+    if constexpr (i == (NT > 1 ? NT / 2 : 0) && 2 * blk + 1 < NPIECES) {                           \
+      if (!(SPK_V2_DBG & 1)) issue_piece(2 * blk + 1, n_aslab, n_wslab, n_dA, n_dW);               \
     }                                                                                              \
   } while (0)
           // the next block's weight tiles are requested at the first step of this block
@@ -350,13 +371,18 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
   } while (0)
           if constexpr (!blk_is_d(blk)) {
             constexpr int tap = blk_tap(blk);
+            if constexpr (!USE_D4) {      // active inputs of this lane's row (lanes l and l + 32 hold the same fragment)
+              // (volatile: left to itself hipcc defers the pure popcounts and keeps every fragment of the chunk alive)
+              asm volatile("v_bcnt_u32_b32 %0, %1, %0\n\tv_bcnt_u32_b32 %0, %2, %0\n\tv_bcnt_u32_b32 %0, %3, %0\n\t"
+                           "v_bcnt_u32_b32 %0, %4, %0" : "+v"(cnt[i]) : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]));
+            }
 #define V2_PAIR_MFMA(J)                                                                                      \
   do {                                                                                                        \
     if constexpr (FIRST && tap == 0) {                                                                        \
-      if constexpr (3 * i + (J) < N_AGPR) SPK_MFMA2_Z("a", acc[i][J], av, bp[0][J], sc_a, sc_p);              \
+      if constexpr (NACC * i + (J) < N_AGPR) SPK_MFMA2_Z("a", acc[i][J], av, bp[0][J], sc_a, sc_p);              \
       else SPK_MFMA2_Z("v", acc[i][J], av, bp[0][J], sc_a, sc_p);                                             \
     } else {                                                                                                  \
-      if constexpr (3 * i + (J) < N_AGPR) SPK_MFMA2("a", acc[i][J], av, bp[tap & 1][J], sc_a, sc_p);          \
+      if constexpr (NACC * i + (J) < N_AGPR) SPK_MFMA2("a", acc[i][J], av, bp[tap & 1][J], sc_a, sc_p);          \
       else SPK_MFMA2("v", acc[i][J], av, bp[tap & 1][J], sc_a, sc_p);                                         \
     }                                                                                                         \
   } while (0)
@@ -368,12 +394,14 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
             __builtin_amdgcn_sched_barrier(0);
           } else {
             constexpr int q = blk_q(blk);
-            if constexpr (FIRST && q == 0) {
-              if constexpr (3 * i + 2 < N_AGPR) SPK_MFMA2_Z("a", acc[i][2], av, b4[0], sc_a, sc_4);
-              else SPK_MFMA2_Z("v", acc[i][2], av, b4[0], sc_a, sc_4);
-            } else {
-              if constexpr (3 * i + 2 < N_AGPR) SPK_MFMA2("a", acc[i][2], av, b4[q & 1], sc_a, sc_4);
-              else SPK_MFMA2("v", acc[i][2], av, b4[q & 1], sc_a, sc_4);
+            if constexpr (USE_D4) {
+              if constexpr (FIRST && q == 0) {
+                if constexpr (NACC * i + 2 < N_AGPR) SPK_MFMA2_Z("a", acc[i][NACC - 1], av, b4[0], sc_a, sc_4);
+                else SPK_MFMA2_Z("v", acc[i][NACC - 1], av, b4[0], sc_a, sc_4);
+              } else {
+                if constexpr (NACC * i + 2 < N_AGPR) SPK_MFMA2("a", acc[i][NACC - 1], av, b4[q & 1], sc_a, sc_4);
+                else SPK_MFMA2("v", acc[i][NACC - 1], av, b4[q & 1], sc_a, sc_4);
+              }
             }
             __builtin_amdgcn_sched_barrier(0);
             V2_DMA_SLOT();
@@ -393,8 +421,8 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          if (3 * i + j < N_AGPR) asm volatile("" : "+a"(acc[i][j]));
+        for (int j = 0; j < NACC; ++j) {
+          if (NACC * i + j < N_AGPR) asm volatile("" : "+a"(acc[i][j]));
           sacc += acc[i][j][0];
         }
       if (sacc == 12345.f) a.out[0] = 1;
@@ -407,16 +435,28 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
     for (int k = 0; k < NT; ++k) {
       const int i = k == 0 ? NT - 1 : k - 1;
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
-        if (3 * i + j < N_AGPR) asm volatile("" : "+a"(acc[i][j]));
+      for (int j = 0; j < NACC; ++j)
+        if (NACC * i + j < N_AGPR) asm volatile("" : "+a"(acc[i][j]));
       float v = 0.f, D = 0.f;
       unsigned mybits = 0;
       bool flg = false;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float q5 = fmaf(fmaf(acc[i][0][r], 1024.0f, acc[i][1][r]), 32.0f, acc[i][2][r]);
-        const float z = fmaf(q5, Ac, Bc);
-        D = fmaf(fabsf(z) + fabsf(v), CERT_4EPS, fmaf(D, 0.5f, cE));        // D_t = D_{t-1} / 2 + cE + 4 eps (|z| + |v|)
+        float z, cstep;
+        if constexpr (USE_D4) {
+          const float q5 = fmaf(fmaf(acc[i][0][r], 1024.0f, acc[i][1][r]), 32.0f, acc[i][NACC - 1][r]);
+          z = fmaf(q5, Ac, Bc);
+          cstep = cE;
+        } else {
+          // four digits: z = Q4 * (1024 Ac) + Bc, Q4 = P01 * 2^10 + P23; the dropped digits move it by at most 528 units of
+          // 2^-s per ACTIVE input of this (position, step): the count sits in the A-layout lane of accumulator row r
+          const float q4 = fmaf(acc[i][0][r], 1024.0f, acc[i][1][r]);
+          z = fmaf(q4, Ac4, Bc);
+          const int rowA = (r & 3) + 8 * (r >> 2);                 // (a constant after unrolling)
+          const int c0 = __builtin_amdgcn_readlane(cnt[i], rowA), c1 = __builtin_amdgcn_readlane(cnt[i], rowA + 4);
+          cstep = fmaf((float)(half ? c1 : c0), cT, cE);
+        }
+        D = fmaf(fabsf(z) + fabsf(v), CERT_4EPS, fmaf(D, 0.5f, cstep));     // D_t = D_{t-1} / 2 + c_t + 4 eps (|z| + |v|)
         const float h = v + (z - v) * 0.5f;
         const bool s = h >= 1.0f;
         flg = flg || (fabsf(h - 1.0f) <= D);
@@ -638,11 +678,12 @@ __global__ __launch_bounds__(256) void fp6v2_lastpos_kernel(V2Args a) {
   store_tile_spikes(a.out, a.out_cnt, mybits, lane, cell * POSB, cell * 32, ok);
 }
 
-// (2) One flagged neuron, exactly, by a whole 1024-thread workgroup: thread unit (tap, 32-channel chunk, t) reads ONE 16-byte
-// spike record and the 32 quantised weights of its (channel, tap, chunk) from the int32 table the pack kernel wrote (the
-// same rint(w * 2^s) as the digit tiles), sums the active ones in 64 bits; partial sums meet per time step through two
-// lane shuffles and 16 LDS atomics per wave; thread 0 then runs the exact epilogue (fp64 recombination of the exact sum --
-// the arithmetic of den_mfma_fp6.hip -- the reference's BN and LIF steps) and patches the neuron's 16 spike nibbles and count.
+// (2) One flagged neuron, exactly, by a 256-thread workgroup: thread unit (tap, 32-channel chunk, t) reads ONE 16-byte spike
+// record and the 32 quantised weights of its (channel, tap, chunk) from the int32 table the pack kernel wrote (the same
+// rint(w * 2^s) as the digit tiles) and sums the active ones in 64 bits; partial sums meet per time step through two lane
+// shuffles and 16 LDS atomics per wave; then the first wave runs the exact epilogue in every lane (fp64 recombination of the
+// exact sum -- the arithmetic of den_mfma_fp6.hip -- the reference's BN and LIF steps) and lane t patches the nibble of step t.
+// Eight such workgroups fit a CU: a few thousand flagged neurons are one or two rounds, bound by the L2 reads (18 - 55 KB a neuron).
 template <int H, int W>
 __device__ __forceinline__ void fixup_neuron(const V2Args& a, long long n, unsigned long long* sS, int Bn) {
   constexpr int HW = H * W;
@@ -657,7 +698,7 @@ __device__ __forceinline__ void fixup_neuron(const V2Args& a, long long n, unsig
   __syncthreads();
   long long part = 0;
   const int units = 9 * nch * 16;
-  for (int u = tid; u < units; u += 1024) {
+  for (int u = tid; u < units; u += (int)blockDim.x) {
     const int t = u & 15, cc = (u >> 4) % nch, tap = (u >> 4) / nch;
     const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
     if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
@@ -674,7 +715,7 @@ __device__ __forceinline__ void fixup_neuron(const V2Args& a, long long n, unsig
       part += (nib & 0xf000u) ? (long long)q.w : 0ll;
     }
   }
-  // lanes l, l + 16, l + 32, l + 48 of a wave hold the same time step (t = u & 15, 1024 and 64 are multiples of 16)
+  // lanes l, l + 16, l + 32, l + 48 of a wave hold the same time step (t = u & 15; the block size is a multiple of 64)
 #pragma unroll
   for (int off = 16; off <= 32; off <<= 1) {
     const int lo = __shfl_xor((int)(unsigned)(part & 0xffffffffll), off);
@@ -683,31 +724,32 @@ __device__ __forceinline__ void fixup_neuron(const V2Args& a, long long n, unsig
   }
   if (lane < 16 && part != 0) atomicAdd(&sS[lane], (unsigned long long)part);
   __syncthreads();
-  if (tid == 0) {
+  if (tid < 64) {
     const double sc = a.scale[co], bi = a.bias[co];
     const float bna = a.bn_a[co], bnb = a.bn_b[co];
     float v = 0.f;
-    int cnt = 0;
-    const int g = co >> 5;
-    uint8_t* rec = a.out + ((((long long)b * (a.Cout >> 5) + g) * HW + p) * POSB);
-    const int byte = (co & 31) >> 1;
-    const unsigned shw = 8u * (byte & 3) + 4u * (co & 1);
+    unsigned bits = 0;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const float y = exact_preact((double)(long long)sS[t], sc, bi);
-      const bool s = spk_lif_step_default(v, fmaf(y, bna, bnb));
-      cnt += s ? 1 : 0;
-      unsigned* wp = reinterpret_cast<unsigned*>(rec + t * 16 + (byte & ~3));
-      atomicAnd(wp, ~(0xFu << shw));
-      if (s) atomicOr(wp, 0x2u << shw);
+      bits |= spk_lif_step_default(v, fmaf(y, bna, bnb)) ? (1u << t) : 0u;
     }
-    if (a.out_cnt) a.out_cnt[(((long long)b * (a.Cout >> 5) + g) * HW + p) * 32 + (co & 31)] = (uint8_t)cnt;
+    const int g = co >> 5;
+    if (lane < 16) {
+      uint8_t* rec = a.out + ((((long long)b * (a.Cout >> 5) + g) * HW + p) * POSB);
+      const int byte = (co & 31) >> 1;
+      const unsigned shw = 8u * (byte & 3) + 4u * (co & 1);
+      unsigned* wp = reinterpret_cast<unsigned*>(rec + lane * 16 + (byte & ~3));
+      atomicAnd(wp, ~(0xFu << shw));
+      if ((bits >> lane) & 1u) atomicOr(wp, 0x2u << shw);
+    }
+    if (a.out_cnt && lane == 0) a.out_cnt[(((long long)b * (a.Cout >> 5) + g) * HW + p) * 32 + (co & 31)] = (uint8_t)__popc(bits);
   }
   __syncthreads();
 }
 
 template <int H, int W>
-__global__ __launch_bounds__(1024) void fp6v2_fixup_kernel(V2Args a, long long n_words) {
+__global__ __launch_bounds__(256) void fp6v2_fixup_kernel(V2Args a, long long n_words) {
   __shared__ unsigned long long sS[16];
   if (SPK_V2_DBG & 64) return;
   const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
@@ -916,7 +958,7 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   if (bands) {
     hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 4, true>), dim3(grid), dim3(256), lds, stream, a);
     SPK_LAUNCH_CHECK();
-    hipLaunchKernelGGL((fp6v2_fixup_kernel<8, 8>), dim3(2 * cus), dim3(1024), 0, stream, a, n_words);
+    hipLaunchKernelGGL((fp6v2_fixup_kernel<8, 8>), dim3(8 * cus), dim3(256), 0, stream, a, n_words);
     SPK_LAUNCH_CHECK();
     // (no last-position launch on an even latent: a one-wave launch resets the flag counter; a memset node in its place
     // made a captured reverse process several times slower)
@@ -934,7 +976,7 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   } else if (eight) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 8>), dim3(grid), dim3(512), lds, stream, a);
   else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 4>), dim3(grid), dim3(256), lds, stream, a);
   SPK_LAUNCH_CHECK();
-  hipLaunchKernelGGL((fp6v2_fixup_kernel<7, 7>), dim3(2 * cus), dim3(1024), 0, stream, a, n_words);
+  hipLaunchKernelGGL((fp6v2_fixup_kernel<7, 7>), dim3(8 * cus), dim3(256), 0, stream, a, n_words);
   SPK_LAUNCH_CHECK();
   const int n_lp = ((B + 1) / 2) * G;
   hipLaunchKernelGGL((fp6v2_lastpos_kernel<7, 7>), dim3(n_lp), dim3(256), 0, stream, a);
