@@ -204,10 +204,10 @@ int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, c
                              const float* bn_a, const float* bn_b, float* v_inout, uint8_t* out_c4, uint8_t* out_counts,
                              int T, int B, int H, int W, int Cout, const int* n_dyn_or_null, spk_stream_t stream);
 /* Second-generation form of spk_den_conv3x3_mfma_fp6 for the sampler (7x7 latents, fresh LIF state in, no state out):
- * the SAME spikes bit for bit -- five digit planes on the matrix cores with adjacent digits sharing an accumulator through
- * the per-block scales, fp32 recombination, every spike decision certified against a per-channel margin, and the ~1e-4 of
- * neurons that come closer to the threshold recomputed exactly (all six digits, int64 / fp64) by a tail launch that also
- * finishes the 49th position (csrc/den_mfma_fp6v2.hip).  DummyModel conv2..conv5, R/snn_model/vq_diffusion.py:166-184,201-204.
+ * the SAME spikes bit for bit -- the four leading digits on the matrix cores with adjacent digits sharing an accumulator through
+ * the per-block scales, fp32 recombination, every spike decision certified against a bound on the dropped digits (per counted
+ * active input of the row), and the 1e-4 .. 6e-4 of neurons that come closer to the threshold recomputed exactly (all six
+ * digits, int64 / fp64) by a tail launch; another finishes the 49th position (csrc/den_mfma_fp6v2.hip).  DummyModel conv2..conv5, R/snn_model/vq_diffusion.py:166-184,201-204.
  * Spikes travel as "S32": [B][C/32][H*W][16][16 B] (fp4 nibbles, channel c of a group in byte (c % 32) / 2, low nibble first).
  * spk_den_pack_weight_fp6v2: fp32 [Cout,Cin,3,3] (+bias) -> packed digit tiles (spk_den_packed_weight_fp6v2_bytes), fp64
  * scale / bias [Cout] as for the fp6 kernel, wl1 [Cout] = L1 norm of each channel's quantised weights, and qtab = the

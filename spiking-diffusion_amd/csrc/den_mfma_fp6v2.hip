@@ -9,16 +9,20 @@
 //    fp32 accumulator then holds 32 * D_even + D_odd directly -- an integer below 4608 * 528 < 2^24, still exact.  The
 //    column tile is 32 output channels of one digit pair, so the three values of a neuron-step (pairs 01, 23 and the
 //    fifth digit) sit in ONE lane: no cross-lane exchange in the epilogue, and all 64 lanes scan their own neuron.
-// 2. FIVE DIGITS ON THE MATRIX CORES, THE SIXTH ONLY WHERE IT MATTERS.  The sixth digit moves a pre-activation by at most
-//    E5 = 16 * 9 * Cin * 2^-s (~3e-6).  The main kernel multiplies five digits (23 instead of 27 MFMAs per row tile and
-//    32-channel chunk: the fifth digit pairs two TAPS per instruction), recombines in fp32, and CERTIFIES every spike
-//    decision: every neuron carries a running bound D_t on |h_approx - h_exact| (the dropped digit, the fp32
-//    recombination and every rounding of BN / LIF on either path, see "Certification" below) and is flagged when its
-//    membrane potential ever comes within D_t of the threshold (about 1e-4 of the neurons).  The fixup launch recomputes
-//    the flagged neurons EXACTLY (all six digits as the pack kernel's int32 quantised weights, 64-bit sums, fp64
-//    recombination, one rounding: the arithmetic of den_mfma_fp6.hip) and patches their spikes.  Unflagged neurons provably emit the spikes the exact arithmetic would; flagged ones are the exact
-//    arithmetic.  Membrane potentials are not an output here (fresh state in, nothing written back): callers that carry
-//    LIF state, and the training forward, use den_mfma_fp6.hip.
+// 2. FOUR DIGITS ON THE MATRIX CORES, THE LAST TWO ONLY WHERE THEY MATTER.  The fifth and sixth digit move a pre-activation by
+//    at most 528 units of 2^-s per ACTIVE input.  The main kernel multiplies the four leading digits (18 instead of 27 MFMAs
+//    per row tile and 32-channel chunk: two digit pairs per tap), counts the active inputs of every row while their fragments
+//    pass through its registers (four v_bcnt per fragment), recombines in fp32, and CERTIFIES every spike decision: every
+//    neuron carries a running bound D_t on |h_approx - h_exact| (the dropped digits for the counted inputs of each step, the
+//    fp32 recombination and every rounding of BN / LIF on either path, see "Certification" below) and is flagged when its
+//    membrane potential ever comes within D_t of the threshold (1 - 6e-4 of the neurons at the denoiser's firing rates of
+//    3 - 7 %).  The fixup launch recomputes the flagged neurons EXACTLY (all six digits as the pack kernel's int32 quantised
+//    weights, 64-bit sums, fp64 recombination, one rounding: the arithmetic of den_mfma_fp6.hip) and patches their spikes.
+//    Unflagged neurons provably emit the spikes the exact arithmetic would; flagged ones are the exact arithmetic.  Membrane
+//    potentials are not an output here (fresh state in, nothing written back): callers that carry LIF state, and the
+//    training forward, use den_mfma_fp6.hip.  (-DSPK_V2_D4=1 builds the earlier form: five digits on the matrix cores -- 23
+//    MFMAs, the fifth pairing two taps per instruction -- and a bound that takes every input as active; it flags 2 - 3x fewer
+//    neurons and is 8 - 10 % slower end to end.)
 // 3. A WORK ITEM = one image x 32 output channels, K chunk = 32 input channels: the spike slab of an image is fetched half
 //    as often, a workgroup keeps ONE channel group for the whole launch (its BN / margin constants are loaded once, its
 //    weight slabs stay L2-hot), and two images + two 35 KB weight slabs need 107 KB of LDS.
@@ -98,13 +102,16 @@ struct V2Args {
 #endif
 // accumulator tiles (index 3 * i + j) that live in AGPRs: 16 (256 registers) with one wave per SIMD; all of them with two
 
-// Certification.  The approximate path (five digits, fp32 recombination, folded constants) and the exact path (six digits,
-// fp64 recombination, the reference's BN / LIF operations) run the same LIF recursion on pre-activations that differ by
-//   |z~ - z| <= cE + 2 eps |z|,      cE = |a| E5 + 2 eps (|b| + |Bc|),  E5 = 16 * 9 * Cin * 2^-s  (the dropped digit, every
-//                                                                        input active with the largest residue)
+// Certification.  The approximate path (the leading digits, fp32 recombination, folded constants) and the exact path (six
+// digits, fp64 recombination, the reference's BN / LIF operations) run the same LIF recursion on pre-activations that differ by
+//   |z~_t - z_t| <= c_t + 2 eps |z_t|
+//   four digits:  c_t = |a| * 528 * 2^-s * n_t + 2 eps (|b| + |Bc|),   n_t = active inputs of the row at step t (counted),
+//                 |32 d4 + d5| <= 528 per input;
+//   five digits:  c_t = cE = |a| E5 + 2 eps (|b| + |Bc|),  E5 = 16 * 9 * Cin * 2^-s  (the dropped digit, every input active
+//                 with the largest residue)
 // with eps = 2^-22 (each of the handful of fp32 roundings on either path is <= 2^-24 relative to a quantity bounded by
 // |z|, |b| or |Bc|).  One LIF step h = v + (z - v) / 2 halves the carried difference and adds its own roundings:
-//   dh_t <= dh_{t-1} / 2 + cE / 2 + 2 eps (|z_t| + |v_{t-1}|)
+//   dh_t <= dh_{t-1} / 2 + c_t / 2 + 2 eps (|z_t| + |v_{t-1}|)
 // as long as the spike decisions agreed so far (after a spike both paths restart from v = 0; the bound is simply kept).
 // The epilogue carries D_t = 2 dh_t (a factor 2 to spare) per neuron and flags it when |h_t - 1| <= D_t for some t: every
 // unflagged neuron provably emits the exact path's spikes; flagged ones are recomputed exactly.
