@@ -963,7 +963,9 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   const size_t lds = 2 * ((size_t)a_bytes + W_LDS);
   const long long n_words = ((long long)B * Cout * H * W + 31) / 32;
   if (bands) {
-    hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 4, true>), dim3(grid), dim3(256), lds, stream, a);
+    static const bool eight_b = [] { const char* e = getenv("SPKDIFF_V2_WAVES"); return e && e[0] == '8'; }();
+    if (eight_b) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 8, true>), dim3(grid), dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 4, true>), dim3(grid), dim3(256), lds, stream, a);
     SPK_LAUNCH_CHECK();
     hipLaunchKernelGGL((fp6v2_fixup_kernel<8, 8>), dim3(8 * cus), dim3(256), 0, stream, a, n_words);
     SPK_LAUNCH_CHECK();
@@ -973,10 +975,11 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
     SPK_LAUNCH_CHECK();
     return SPK_OK;
   }
-  // Two waves per SIMD (SPKDIFF_V2_WAVES=8) need 9 % fewer cycles per MFMA (45.6 vs 50.2 on the conv4 shape) and take the
-  // same time: the device lowers its clock by the same 9 % (1.94 vs 2.13 GHz in-kernel) -- the launch is bound by the
-  // power the matrix pipe may draw, not by issue slots.  One wave per SIMD (no spills, simpler) stays the default.
-  static const bool eight = [] { const char* e = getenv("SPKDIFF_V2_WAVES"); return e && e[0] == '8'; }();
+  // Two waves per SIMD are the default since the four-digit form: with 23 MFMAs per tile and chunk they needed 9 % fewer
+  // cycles per MFMA and took the SAME time (the device lowered its clock by those 9 %: the launch was bound by the power the
+  // matrix pipe may draw); with 18 the copies, fragment reads and popcounts of a chunk are no longer hidden behind one wave's
+  // MFMAs, there is power to spare, and the second wave is worth 8 % of the reverse process.  SPKDIFF_V2_WAVES=4: one wave.
+  static const bool eight = [] { const char* e = getenv("SPKDIFF_V2_WAVES"); return !(e && e[0] == '4'); }();
   if (need) {
     if (grid / G < 6) return SPK_ERR_UNSUPPORTED;           // one image lane per tile-count class at least
     hipLaunchKernelGGL((conv3x3_fp6v2_listed_kernel<7, 7>), dim3(grid), dim3(256), lds, stream, a);
