@@ -176,7 +176,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
   constexpr int HWb = Hb * W;                          // output positions of an item
   static_assert(SPLIT ? ((H % 2) == 0 && (HWb % (2 * NWV)) == 0)
                       : ((HW & 1) == 1 && ((HW / 2) % NWV) == 0), "whole 32-row tiles on every wave (+ one odd position)");
-  static_assert(!PRUNE || (!SPLIT && NWV == 4 && NTP <= (HWb / 2) / NWV), "position lists: 7x7 items, one wave per SIMD");
+  static_assert(!PRUNE || (!SPLIT && (NWV == 4 || NWV == 8) && NTP <= (HWb / 2) / NWV), "position lists: 7x7 items");
   constexpr int NT = PRUNE ? NTP : (HWb / 2) / NWV;    // row tiles per wave (7x7: 6 or 3; 8x8 bands: 4)
   constexpr int N_AGPR = NWV == 4 ? (NACC * NT < 16 ? NACC * NT : 16) : 8;   // (two waves per SIMD: hipcc splits 256 registers 128 / 128)
   constexpr int NPP = (Hin + 2) * PW + 1;              // cells of the zero-bordered LDS image (pitch W + 1: the zero
@@ -523,8 +523,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6v2_kernel(V2Args a) {
 // Listed positions: the image lanes of every channel group are divided among the six tile-count classes in proportion to
 // their work (slots x tiles, with a floor for the copy-bound small classes); a workgroup then runs the item loop
 // instantiated for its class on that class's slots.  Every workgroup derives the same division from cls_cnt.
-template <int H, int W>
-__global__ __launch_bounds__(256, 1) void conv3x3_fp6v2_listed_kernel(V2Args a) {
+// (NWV = 8: two waves per SIMD; a class of k tiles per wave of four becomes ceil(k / 2) tiles per wave of eight)
+template <int H, int W, int NWV>
+__global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6v2_listed_kernel(V2Args a) {
   constexpr int NC = (H * W / 2) / 4;                    // classes: 1 .. NC tiles per wave
   int g, il, lanes;
   fp6v2_wg_map(a, g, il, lanes);
@@ -561,14 +562,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp6v2_listed_kernel(V2Args a) 
     start += u[k];
   }
   const int* slots = a.cls_list + (long long)(cls < 0 ? 0 : cls) * a.B;
-  switch (cls) {
-    case 0: fp6v2_body<H, W, 4, false, 1>(a, g, il_c, lanes_c, cnt[0], slots); break;
-    case 1: fp6v2_body<H, W, 4, false, 2>(a, g, il_c, lanes_c, cnt[1], slots); break;
-    case 2: fp6v2_body<H, W, 4, false, 3>(a, g, il_c, lanes_c, cnt[2], slots); break;
-    case 3: fp6v2_body<H, W, 4, false, 4>(a, g, il_c, lanes_c, cnt[3], slots); break;
-    case 4: fp6v2_body<H, W, 4, false, 5>(a, g, il_c, lanes_c, cnt[4], slots); break;
-    case 5: fp6v2_body<H, W, 4, false, 6>(a, g, il_c, lanes_c, cnt[5], slots); break;
-    default: break;
+  if constexpr (NWV == 4) {
+    switch (cls) {
+      case 0: fp6v2_body<H, W, 4, false, 1>(a, g, il_c, lanes_c, cnt[0], slots); break;
+      case 1: fp6v2_body<H, W, 4, false, 2>(a, g, il_c, lanes_c, cnt[1], slots); break;
+      case 2: fp6v2_body<H, W, 4, false, 3>(a, g, il_c, lanes_c, cnt[2], slots); break;
+      case 3: fp6v2_body<H, W, 4, false, 4>(a, g, il_c, lanes_c, cnt[3], slots); break;
+      case 4: fp6v2_body<H, W, 4, false, 5>(a, g, il_c, lanes_c, cnt[4], slots); break;
+      case 5: fp6v2_body<H, W, 4, false, 6>(a, g, il_c, lanes_c, cnt[5], slots); break;
+      default: break;
+    }
+  } else {
+    switch (cls) {
+      case 0: case 1: fp6v2_body<H, W, 8, false, 1>(a, g, il_c, lanes_c, cnt[cls], slots); break;
+      case 2: case 3: fp6v2_body<H, W, 8, false, 2>(a, g, il_c, lanes_c, cnt[cls], slots); break;
+      case 4: case 5: fp6v2_body<H, W, 8, false, 3>(a, g, il_c, lanes_c, cnt[cls], slots); break;
+      default: break;
+    }
   }
 }
 
@@ -963,7 +973,7 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   const size_t lds = 2 * ((size_t)a_bytes + W_LDS);
   const long long n_words = ((long long)B * Cout * H * W + 31) / 32;
   if (bands) {
-    static const bool eight_b = [] { const char* e = getenv("SPKDIFF_V2_WAVES"); return e && e[0] == '8'; }();
+    static const bool eight_b = [] { const char* e = getenv("SPKDIFF_V2_WAVES"); return !(e && e[0] == '4'); }();   // (+4 %)
     if (eight_b) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 8, true>), dim3(grid), dim3(512), lds, stream, a);
     else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 4, true>), dim3(grid), dim3(256), lds, stream, a);
     SPK_LAUNCH_CHECK();
@@ -982,7 +992,8 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   static const bool eight = [] { const char* e = getenv("SPKDIFF_V2_WAVES"); return !(e && e[0] == '4'); }();
   if (need) {
     if (grid / G < 6) return SPK_ERR_UNSUPPORTED;           // one image lane per tile-count class at least
-    hipLaunchKernelGGL((conv3x3_fp6v2_listed_kernel<7, 7>), dim3(grid), dim3(256), lds, stream, a);
+    if (eight) hipLaunchKernelGGL((conv3x3_fp6v2_listed_kernel<7, 7, 8>), dim3(grid), dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL((conv3x3_fp6v2_listed_kernel<7, 7, 4>), dim3(grid), dim3(256), lds, stream, a);
   } else if (eight) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 8>), dim3(grid), dim3(512), lds, stream, a);
   else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 4>), dim3(grid), dim3(256), lds, stream, a);
   SPK_LAUNCH_CHECK();
