@@ -77,8 +77,8 @@ MAIN = "conv3x3_fp6v2_kernel"
 sq = med(os.path.join(O, "r2_conv4_fp6v2_pmc_sq.csv"), MAIN); sq2 = med(os.path.join(O, "r2_conv4_fp6v2_pmc_sq2.csv"), MAIN)
 d = {k: v[0] for k, v in {**sq, **sq2}.items()}
 simds = 256 * 4
-mfma_per_simd = 16 * 8 * 138                      # items x chunks x MFMAs per wave (one wave per SIMD)
-out = {"kernel": "conv3x3_fp6v2_kernel<7,7,4> (main launch of den.conv4: Cout=512,Cin=256,B=256), medians over the launches",
+mfma_per_simd = 16 * 8 * 18 * 6                   # items x chunks x MFMAs per tile and chunk x tiles per SIMD (two waves of three)
+out = {"kernel": "conv3x3_fp6v2_kernel<7,7,8> (main launch of den.conv4: Cout=512,Cin=256,B=256; four digits, two waves per SIMD), medians over the launches",
        "counters": d,
        "derived": {"kernel_cycles_per_XCD (GRBM_GUI_ACTIVE/8)": d["GRBM_GUI_ACTIVE"] / 8,
                    "mfma_busy_cycles_per_SIMD": d["SQ_VALU_MFMA_BUSY_CYCLES"] / simds,
