@@ -178,7 +178,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
                       : ((HW & 1) == 1 && ((HW / 2) % NWV) == 0), "whole 32-row tiles on every wave (+ one odd position)");
   static_assert(!PRUNE || (!SPLIT && (NWV == 4 || NWV == 8) && NTP <= (HWb / 2) / NWV), "position lists: 7x7 items");
   constexpr int NT = PRUNE ? NTP : (HWb / 2) / NWV;    // row tiles per wave (7x7: 6 or 3; 8x8 bands: 4)
-  constexpr int N_AGPR = NWV == 4 ? (NACC * NT < 16 ? NACC * NT : 16) : 8;   // (two waves per SIMD: hipcc splits 256 registers 128 / 128)
+  constexpr int N_AGPR = NWV == 4 ? (NACC * NT < 16 ? NACC * NT : 16) : (NACC * NT < 8 ? NACC * NT : 8);   // (two waves per SIMD: hipcc splits 256 registers 128 / 128)
   constexpr int NPP = (Hin + 2) * PW + 1;              // cells of the zero-bordered LDS image (pitch W + 1: the zero
   constexpr int A_BYTES = NPP * POSB;                  //  column is shared by x = -1 of a row and x = W of the previous)
   constexpr int PPR = (W + 3) / 4;                     // DMA pieces per image row (4 positions per KiB piece)
@@ -988,7 +988,8 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   // Two waves per SIMD are the default since the four-digit form: with 23 MFMAs per tile and chunk they needed 9 % fewer
   // cycles per MFMA and took the SAME time (the device lowered its clock by those 9 %: the launch was bound by the power the
   // matrix pipe may draw); with 18 the copies, fragment reads and popcounts of a chunk are no longer hidden behind one wave's
-  // MFMAs, there is power to spare, and the second wave is worth 8 % of the reverse process.  SPKDIFF_V2_WAVES=4: one wave.
+  // MFMAs, there is power to spare, and the second wave is worth 8 % of the reverse process (a third one -- 12 waves of two
+  // tiles, 84 + 84 registers and 72 B of spills -- loses 5 % again).  SPKDIFF_V2_WAVES=4: one wave.
   static const bool eight = [] { const char* e = getenv("SPKDIFF_V2_WAVES"); return !(e && e[0] == '4'); }();
   if (need) {
     if (grid / G < 6) return SPK_ERR_UNSUPPORTED;           // one image lane per tile-count class at least
