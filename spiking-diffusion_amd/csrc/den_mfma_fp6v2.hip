@@ -67,7 +67,10 @@ struct V2Args {
   const float* bn_a; const float* bn_b;
   uint8_t* out; uint8_t* out_cnt;
   unsigned* flags;                           // ws[0]: number of flagged neurons, ws[1]: unused, ws[2..2+cap): their ids,
-  unsigned flag_cap;                         //  then the overflow bitmap (one bit per neuron; used only beyond cap)
+  unsigned flag_cap;                         //  then the overflow bitmap (one bit per neuron; used only beyond cap), then the
+  long long ticket_idx;                      //  ticket of the hand-over (ws[1] = the count published for the tail launch)
+  int handover;                              // 1: the main launch publishes the count (fp6v2_handover); 0: the tail launches read
+                                             //    ws[0] and the last-position launch, which follows the repair launch, re-arms it
   const int* qtab;                           // quantised weights int32 [Cout][9][Cin] (exact recomputation)
   const int* n_dyn;
   // position lists (spk_select_needed, one radius): 64-byte record per image slot; the slots by tile count (classes
@@ -512,12 +515,31 @@ __device__ __forceinline__ void fp6v2_wg_map(const V2Args& a, int& g, int& il, i
   }
 }
 
+// Hand-over to the tail launch: the workgroup that finishes last publishes the number of flagged neurons (ws[1]) and re-arms
+// the live counter (ws[0]) for the next layer's main launch.  The workgroups of a main launch finish at different times, so
+// this ticket costs nothing -- and the tail launch then needs no ordering between its repair part (which reads the count)
+// and anything that resets it: repair and last position run as ONE launch.
+__device__ __forceinline__ void fp6v2_handover(const V2Args& a) {
+  if (!a.handover) return;
+  // (no fence: every atomicAdd on the counter has RETURNED before its wave reaches the barrier, the count is read back with
+  //  an atomic, and list entries are plain stores read by the next launch -- a __threadfence here cost 4.5 us per launch)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (atomicAdd(a.flags + a.ticket_idx, 1u) == gridDim.x - 1) {
+      a.flags[1] = atomicAdd(a.flags, 0u);
+      if (!(SPK_V2_DBG & 64)) a.flags[0] = 0u;
+      a.flags[a.ticket_idx] = 0u;
+    }
+  }
+}
+
 template <int H, int W, int NWV, bool SPLIT = false>
 __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6v2_kernel(V2Args a) {
   const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
   int g, il, lanes;
   fp6v2_wg_map(a, g, il, lanes);
   fp6v2_body<H, W, NWV, SPLIT, 0>(a, g, il, lanes, Bn, nullptr);
+  fp6v2_handover(a);
 }
 
 // Listed positions: the image lanes of every channel group are divided among the six tile-count classes in proportion to
@@ -538,7 +560,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6v2_listed_kernel(V2Arg
     total += work[k];
     nonempty += cnt[k] > 0;
   }
-  if (total == 0) return;
+  if (total == 0) { fp6v2_handover(a); return; }
   // one lane per non-empty class, the rest in proportion, leftovers to the class with the most work per lane
   int rem = lanes - nonempty, used = 0;
 #pragma unroll
@@ -580,6 +602,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6v2_listed_kernel(V2Arg
       default: break;
     }
   }
+  fp6v2_handover(a);
 }
 
 // ------------------------------------------------------------------------------------------------ tail launches
@@ -589,21 +612,22 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6v2_listed_kernel(V2Arg
 // (2) the flagged neurons of the main launch, exactly (fixup_neuron / fp6v2_fixup_kernel below).
 __device__ __forceinline__ float exact_preact(double s, double sc, double bi) { return (float)fma(s, sc, bi); }
 
-template <int H, int W>
-__global__ __launch_bounds__(256) void fp6v2_lastpos_kernel(V2Args a) {
+// red: ONE [3][16][64] buffer (the partial sums of waves 1 .. 3 pass through it one after the other: the merged tail launch
+// keeps eight workgroups on a CU) or, WIDE, three of them (one barrier: the stand-alone launch of full batches)
+template <int H, int W, bool WIDE>
+__device__ __forceinline__ void fp6v2_lastpos_body(const V2Args& a, const int bid, float (*red)[16][64]) {
   constexpr int HW = H * W;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = a.nch, G = a.Cout >> 5;
   const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
-  // this launch follows the fixup launch on the stream: the flag counter is reset here for the next layer's main launch
-  if (blockIdx.x == 0 && threadIdx.x == 0 && !(SPK_V2_DBG & 64)) a.flags[0] = 0u;
+  // (without the hand-over this launch follows the repair launch on the stream and re-arms the flag counter)
+  if (!a.handover && bid == 0 && threadIdx.x == 0 && !(SPK_V2_DBG & 64)) a.flags[0] = 0u;
   // one workgroup = one 32-row tile = two images (the lane halves) x one channel group; its four waves split the K chunks
   // (wave w: chunks w, w + 4, ...) and add their partial sums -- exact integers below 2^24 in fp32, so the order of the
   // additions does not matter -- in LDS: the launch is bound by the latency of a wave's chain of dependent gathers
   // (with many units the launch is bound by throughput instead: then every wave takes a unit of its own)
-  __shared__ float red[3][3][16][64];
   const bool split = ((Bn + 1) >> 1) * G <= 1024;           // (uniform over the launch)
-  const int unit = split ? blockIdx.x : blockIdx.x * 4 + wave;
+  const int unit = split ? bid : bid * 4 + wave;
   const int g = unit % G, b0 = (unit / G) * 2;
   if (b0 >= Bn) return;
   const int row = lane & 31, half = lane >> 5;
@@ -661,20 +685,41 @@ __global__ __launch_bounds__(256) void fp6v2_lastpos_kernel(V2Args a) {
     mm(acc[2], a01, t23, sc_lo); mm(acc[2], a34, t24, sc_lo);
   }
   if (split) {
-    if (wave != 0) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[wave - 1][j][r][lane] = acc[j][r];
-    }
-    __syncthreads();
-    if (wave != 0) return;
     const int nw = nch < 4 ? nch : 4;                       // waves that had a chunk
-    for (int w = 1; w < nw; ++w)
+    if constexpr (WIDE) {
+      if (wave != 0 && wave < nw) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] += red[w - 1][j][r][lane];
+          for (int r = 0; r < 16; ++r) red[3 * (wave - 1) + j][r][lane] = acc[j][r];
+      }
+      __syncthreads();
+      if (wave == 0) {
+        for (int w = 1; w < nw; ++w)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] += red[3 * (w - 1) + j][r][lane];
+      }
+    } else {
+      for (int w = 1; w < 4; ++w) {
+        if (wave == w && w < nw) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[j][r][lane] = acc[j][r];
+        }
+        __syncthreads();
+        if (wave == 0 && w < nw) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] += red[j][r][lane];
+        }
+        __syncthreads();
+      }
+    }
+    if (wave != 0) return;
   }
   const int co = g * 32 + (lane & 31);
   const double sc = a.scale[co], bi = a.bias[co];
@@ -766,18 +811,18 @@ __device__ __forceinline__ void fixup_neuron(const V2Args& a, long long n, unsig
 }
 
 template <int H, int W>
-__global__ __launch_bounds__(256) void fp6v2_fixup_kernel(V2Args a, long long n_words) {
-  __shared__ unsigned long long sS[16];
+__device__ __forceinline__ void fp6v2_fixup_body(const V2Args& a, long long n_words, const unsigned bid, const unsigned nb,
+                                                 unsigned long long* sS) {
   if (SPK_V2_DBG & 64) return;
   const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
-  const unsigned count = a.flags[0];
+  const unsigned count = a.flags[a.handover ? 1 : 0];       // published by the main launch (fp6v2_handover), or live
   const unsigned nlist = count < a.flag_cap ? count : a.flag_cap;
-  for (unsigned e = blockIdx.x; e < nlist; e += gridDim.x) fixup_neuron<H, W>(a, (long long)a.flags[2 + e], sS, Bn);
+  for (unsigned e = bid; e < nlist; e += nb) fixup_neuron<H, W>(a, (long long)a.flags[2 + e], sS, Bn);
   if (count > a.flag_cap) {
     // overflow path (more than flag_cap flagged neurons): the rest sit in the bitmap; scan a share of it, clear as we go
     unsigned* bm = a.flags + 2 + a.flag_cap;
-    const long long per = (n_words + gridDim.x - 1) / gridDim.x;
-    const long long w0 = (long long)blockIdx.x * per;
+    const long long per = (n_words + nb - 1) / nb;
+    const long long w0 = (long long)bid * per;
     const long long w1 = w0 + per < n_words ? w0 + per : n_words;
     for (long long wi = w0; wi < w1; ++wi) {
       unsigned wv = bm[wi];                                // (uniform over the workgroup)
@@ -790,10 +835,18 @@ __global__ __launch_bounds__(256) void fp6v2_fixup_kernel(V2Args a, long long n_
       }
     }
   }
-}   // (the flag counter is reset by the last-position launch that follows on the stream)
+}
 
-__global__ void fp6v2_reset_kernel(unsigned* flags) {
-  if (threadIdx.x == 0 && !(SPK_V2_DBG & 64)) flags[0] = 0u;
+// The tail launches.  PART 0: workgroups [0, n_lp) compute last positions, the rest repair flagged neurons -- independent work
+// (disjoint outputs, both read only the layer's input), each a chain of dependent L2 reads: in one launch they overlap (the
+// sampler's active-set calls).  PART 1 / 2: repair only / last positions only, each with its own register and LDS budget (full
+// batches, where either part fills the device by itself: the merged form measured 1.3 % slower there).
+template <int H, int W, int PART>
+__global__ __launch_bounds__(256) void fp6v2_tail_kernel(V2Args a, long long n_words, int n_lp) {
+  __shared__ float red[PART == 1 ? 1 : (PART == 2 ? 9 : 3)][16][64];
+  __shared__ unsigned long long sS[16];
+  if (PART == 2 || (PART == 0 && (int)blockIdx.x < n_lp)) fp6v2_lastpos_body<H, W, PART == 2>(a, (int)blockIdx.x, red);
+  else fp6v2_fixup_body<H, W>(a, n_words, blockIdx.x - (unsigned)n_lp, gridDim.x - (unsigned)n_lp, sS);
 }
 
 // ------------------------------------------------------------------------------------------------ weight packing
@@ -931,7 +984,7 @@ constexpr unsigned FLAG_CAP = 1u << 20;        // list capacity; beyond it flagg
 
 extern "C" long long spk_den_fp6v2_flag_words(int B, int Cout, int H, int W) {
   if (B <= 0 || Cout <= 0 || H <= 0 || W <= 0) return -1;
-  return 2 + (long long)FLAG_CAP + ((long long)B * Cout * H * W + 31) / 32;
+  return 2 + (long long)FLAG_CAP + ((long long)B * Cout * H * W + 31) / 32 + 1;
 }
 
 static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale, const double* bias_d,
@@ -972,16 +1025,17 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   const int a_bytes = bands ? ((8 / 2 + 1 + 2) * 9 + 1) * POSB : ((7 + 2) * 8 + 1) * POSB;
   const size_t lds = 2 * ((size_t)a_bytes + W_LDS);
   const long long n_words = ((long long)B * Cout * H * W + 31) / 32;
+  a.ticket_idx = 2 + (long long)FLAG_CAP + n_words;
+  // full 7x7 batches keep the round-1 order (repair launch, then the last-position launch re-arms the counter): the hand-over
+  // costs a barrier and an atomic per workgroup of the main launch (1.2 us), which only the merged tail launch of the
+  // active-set calls (and the launch it saves on even latents) pays back
+  a.handover = (bands || n_dyn_or_null) ? 1 : 0;
   if (bands) {
     static const bool eight_b = [] { const char* e = getenv("SPKDIFF_V2_WAVES"); return !(e && e[0] == '4'); }();   // (+4 %)
     if (eight_b) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 8, true>), dim3(grid), dim3(512), lds, stream, a);
     else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 4, true>), dim3(grid), dim3(256), lds, stream, a);
     SPK_LAUNCH_CHECK();
-    hipLaunchKernelGGL((fp6v2_fixup_kernel<8, 8>), dim3(8 * cus), dim3(256), 0, stream, a, n_words);
-    SPK_LAUNCH_CHECK();
-    // (no last-position launch on an even latent: a one-wave launch resets the flag counter; a memset node in its place
-    // made a captured reverse process several times slower)
-    hipLaunchKernelGGL(fp6v2_reset_kernel, dim3(1), dim3(64), 0, stream, flag_words);
+    hipLaunchKernelGGL((fp6v2_tail_kernel<8, 8, 1>), dim3(8 * cus), dim3(256), 0, stream, a, n_words, 0);   // (even latent: repair only)
     SPK_LAUNCH_CHECK();
     return SPK_OK;
   }
@@ -998,11 +1052,18 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   } else if (eight) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 8>), dim3(grid), dim3(512), lds, stream, a);
   else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 4>), dim3(grid), dim3(256), lds, stream, a);
   SPK_LAUNCH_CHECK();
-  hipLaunchKernelGGL((fp6v2_fixup_kernel<7, 7>), dim3(8 * cus), dim3(256), 0, stream, a, n_words);
-  SPK_LAUNCH_CHECK();
   const int n_lp = ((B + 1) / 2) * G;
-  hipLaunchKernelGGL((fp6v2_lastpos_kernel<7, 7>), dim3(n_lp), dim3(256), 0, stream, a);
-  SPK_LAUNCH_CHECK();
+  if (n_dyn_or_null) {
+    // the sampler's active-set calls: few images, both parts are latency bound -- one launch (-17 us per reverse step)
+    hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7, 0>), dim3(n_lp + 8 * cus), dim3(256), 0, stream, a, n_words, n_lp);
+    SPK_LAUNCH_CHECK();
+  } else {
+    // full batches: both parts fill the device on their own; measured 1 % faster one after the other
+    hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7, 1>), dim3(8 * cus), dim3(256), 0, stream, a, n_words, 0);
+    SPK_LAUNCH_CHECK();
+    hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7, 2>), dim3(n_lp), dim3(256), 0, stream, a, n_words, n_lp);
+    SPK_LAUNCH_CHECK();
+  }
   return SPK_OK;
 }
 

@@ -330,9 +330,10 @@ __global__ __launch_bounds__(512, 1) void vae_fp6_kernel(TArgs a) {
   // hand-over to the repair launch: the workgroup that finishes last publishes the count and re-arms the live counter (the
   // workgroups finish at different times, so this ticket costs nothing; a ticket in the repair launch, whose workgroups all
   // arrive at once, cost 16 us, a separate reset launch 5)
+  // (no fence needed: every atomicAdd on the counter has returned before its wave reaches the barrier, and the count is read
+  //  back with an atomic)
   __syncthreads();
   if (tid == 0) {
-    __threadfence();
     if (atomicAdd(a.flags + a.ticket_idx, 1u) == gridDim.x - 1) {
       a.flags[1] = atomicAdd(a.flags, 0u);
       a.flags[0] = 0u;

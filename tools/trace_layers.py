@@ -13,6 +13,7 @@ for r in rows:
     elif "conv3x3_fp6v2_kernel" in n:
         last = ("main", 2 + k % 4); acc[last].append(d); k += 1
     elif "fp6v2_fixup" in n: acc[(last[0] + "-fixup", last[1])].append(d)
+    elif "fp6v2_tail" in n: acc[(last[0] + "-tail", last[1])].append(d)
     elif "fp6v2_lastpos" in n: acc[(last[0] + "-lastpos", last[1])].append(d)
     else:
         nm = n.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").split("::")[-1][:48]
