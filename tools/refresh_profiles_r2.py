@@ -61,7 +61,7 @@ def entry(key, fetch_csv, write_csv, kernels, src, extra=None):
 
 
 entry("conv3x3_fp6v2_kernel + tail launches (Cout=512,Cin=256,B=256: den.conv4 shape)", "r2_conv4_fp6v2_pmc_fetch_size.csv",
-      "r2_conv4_fp6v2_pmc_write_size.csv", ["conv3x3_fp6v2_kernel", "fp6v2_fixup_kernel", "fp6v2_lastpos_kernel"],
+      "r2_conv4_fp6v2_pmc_write_size.csv", ["conv3x3_fp6v2_kernel", "fp6v2_tail_kernel"],
       "den_mfma_fp6v2.hip",
       {"algorithmic_bytes_per_launch": 256 * 49 * 16 * (256 // 2 + 512 // 2) + 16 * 8 * 38912,
        "note": "algorithmic = input spikes (fp4, S32) + output spikes once + packed weights once"})

@@ -29,6 +29,9 @@ for r in rows:
         name = f"conv3x3_fp6v2_kernel den.conv{2 + k % 4}"
         layer = 2 + k % 4
         k += 1
+    elif "fp6v2_tail_kernel" in name:     # <H, W, PART>: 0 repair + last position, 1 repair only, 2 last position only
+        part = name.split("fp6v2_tail_kernel<")[1].split(">")[0].split(",")[-1].strip()
+        name = f"fp6v2_tail_kernel<{ {'0': 'repair+last position', '1': 'repair', '2': 'last position'}.get(part, part) }> den.conv{layer}"
     elif "fp6v2_fixup_kernel" in name:
         name = f"fp6v2_fixup_kernel den.conv{layer}"
     elif "fp6v2_lastpos_kernel" in name:
