@@ -315,7 +315,7 @@ class DummyModel(nn.Module):
         return 'mfma-i8x4' if ops.den_mfma_supported(128, 64, 3, 1, 1, self.n_steps, h, w) else 'direct-f64'
 
     # the sampler's calls (fresh LIF state, nothing written back) take the second-generation fp6 kernel where it applies
-    # (7x7 latents): the same spikes from five digit planes + certified decisions + exact recomputation of the few neurons
+    # (7x7 latents): the same spikes from the four leading digits + certified decisions + exact recomputation of the few neurons
     # near the threshold (csrc/den_mfma_fp6v2.hip).  False = always the first-generation kernel.
     use_fp6v2 = True
     _last_stateful = False
