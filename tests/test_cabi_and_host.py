@@ -44,6 +44,33 @@ def test_argument_errors_map_to_python_exceptions():
         _lib.check(1, "x")
 
 
+def test_workspace_sizes_and_shape_support_are_host_side():
+    """The size / support queries of the round-2 entry points answer on the host (no GPU): position-list buffer layout,
+    flag workspaces, packed-weight sizes, and which VQ-VAE layer shapes the fp6 kernel family takes."""
+    from spkdiff import _lib, ops
+    lib = _lib.lib
+    B, R = 256, 3
+    lists = 64 + R * 64 + R * 6 * B * 4
+    assert lib.spk_select_needed_bytes(B, R) == (lists + 63) // 64 * 64 + R * B * 64
+    assert lib.spk_select_needed_bytes(0, 3) == -1 and lib.spk_select_needed_bytes(4, 9) == -1
+    cap = 1 << 20
+    assert lib.spk_den_fp6v2_flag_words(2, 64, 7, 7) == 2 + cap + (2 * 64 * 49 + 31) // 32 + 1      # + the hand-over ticket
+    assert lib.spk_vae_fp6_flag_words(2, 32, 28, 28) == 2 + cap + (2 * 32 * 784 + 31) // 32 + 1
+    assert lib.spk_vae_fp6_packed_bytes(32, 64) == 9 * 5 * 1536 and lib.spk_vae_fp6_packed_bytes(64, 16) == 2 * 9 * 3 * 1536
+    assert lib.spk_vae_fp6_packed_bytes(32, 128) == -1 and lib.spk_vae_fp6_packed_bytes(48, 64) == -1
+    # null pointers are argument errors before any launch
+    assert lib.spk_vae_fp6_fwd(None, None, None, None, None, None, None, None, None, 0, None, 16, 1, 14, 14, 64, 32, 1, None) == -1
+    assert lib.spk_select_needed(None, 1, None, 0, 0, None, None, None, None, 1, 7, 7, 3, None) == -1
+    assert lib.spk_readout_collapsed_fwd(None, None, None, 1.0, None, None, 0, 1, 28, 28, 32, 1, 3, 1, 1, None) == -1
+    kind = ops.vae_fp6_kind
+    assert kind(64, 32, 3, 2, 1, 1, True, 16, 14, 14) == ops.VAE_OUT_COLLAPSED        # decoder convT2
+    assert kind(16, 64, 3, 2, 1, 1, True, 16, 7, 7) == ops.VAE_OUT_S32                # decoder convT1
+    assert kind(32, 64, 3, 2, 1, 0, False, 16, 14, 14) == ops.VAE_OUT_PTC             # encoder conv2
+    assert kind(64, 32, 3, 2, 1, 1, True, 4, 14, 14) is None and kind(64, 32, 3, 1, 1, 0, True, 16, 14, 14) is None
+    assert kind(32, 64, 3, 2, 1, 0, False, 16, 12, 12) is None
+    assert ops.readout_collapsed_supported(32, 1, 3) and not ops.readout_collapsed_supported(30, 1, 3)
+
+
 def test_state_dict_keys_match_reference():
     from snn_model.vae_model import SNN_VQVAE, functional
     from snn_model.vq_diffusion import DummyModel, AbsorbingDiffusion
