@@ -173,6 +173,10 @@ template <int H, int W, int NWV, bool SPLIT, int NTP>
 __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const int il, const int lanes, const int n_images,
                                            const int* __restrict__ slots) {
   constexpr bool PRUNE = NTP > 0;
+  // how the four-digit form counts the active inputs of a row: REC: once per input record and chunk for the whole workgroup
+  // (full items: the per-fragment popcounts were 29 % of the launch's vector issue), else per A fragment in the K loop
+  // (listed positions: an item has few fragments, and the per-item passes of REC cost more than they save there: -2.5 %)
+  constexpr bool REC = !USE_D4 && !PRUNE;
   constexpr int HW = H * W, PW = W + 1;
   constexpr int Hb = SPLIT ? H / 2 : H;                // output rows of an item
   constexpr int Hin = SPLIT ? Hb + 1 : H;              // input rows staged per item
@@ -193,12 +197,17 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   uint8_t* const sA = lds;
   uint8_t* const sW = lds + 2 * A_BYTES;
+  // four-digit form: active inputs per input cell and step (s_cin, borders stay zero) and per output position and step (s_row)
+  int* const s_cin = reinterpret_cast<int*>(lds + 2 * A_BYTES + 2 * W_LDS);          // [NPP][16]
+  int* const s_row = s_cin + NPP * 16;                                               // [HWb + 1][16]
   const unsigned sA_addr = spk_lds_addr(sA), sW_addr = sA_addr + 2 * A_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nch = a.nch;
   const int G = a.Cout >> 5;
   // zero both A images once: the borders stay zero for the whole kernel, interiors are overwritten by DMA
   for (int i = tid; i < 2 * A_BYTES / 16; i += NWV * 64) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
+  if (REC)
+    for (int i = tid; i < NPP * 16; i += NWV * 64) s_cin[i] = 0;
   __syncthreads();         // no wave's first DMA piece may land in a cell another wave has yet to zero
 
   // per-lane LDS byte offsets of this wave's A fragments (tile ti = wave + NWV * i), relative to tap (0, 0).
@@ -297,9 +306,20 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
       }
     }
     v16f acc[NT][NACC];   // [i][0]: pair 01, [i][1]: pair 23, ([i][2]: fifth digit;) written (not accumulated) by the first MFMA
-    int cnt[NT];          // four-digit form: active inputs of this lane's row (position, step) over all taps and chunks
+    int cnt[NT];          // !REC: active inputs of this lane's A row (position, step) over all taps and chunks
 #pragma unroll
     for (int i = 0; i < NT; ++i) cnt[i] = 0;
+    // REC: every thread counts the active inputs of NR input records (cell, step) of the item, chunk by chunk
+    constexpr int NREC = Hin * W * 16, NR = (NREC + NWV * 64 - 1) / (NWV * 64);
+    int creg[NR];
+    int rec_off[NR];                                      // LDS byte offset of the record inside a slab; -1: none
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      creg[k] = 0;
+      const int r = tid + k * NWV * 64;
+      const int cl = r >> 4, t = r & 15;
+      rec_off[k] = r < NREC ? (((cl / W) + 1) * PW + 1 + (cl % W)) * POSB + t * 16 : -1;
+    }
     for (int c = 0; c < nch; ++c, ++it) {
       const int buf = it & 1;
       spk_dma_wait_all();  // this wave's share of the chunk's DMA has landed ...
@@ -312,6 +332,16 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
       const unsigned n_dA = sA_addr + (buf ^ 1) * A_BYTES;
       const unsigned n_dW = sW_addr + (buf ^ 1) * W_LDS;
 
+      if constexpr (REC) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          if (rec_off[k] >= 0) {
+            const v4i rv = *reinterpret_cast<const v4i*>(sA + buf * A_BYTES + rec_off[k]);
+            creg[k] += __builtin_popcount((unsigned)rv[0]) + __builtin_popcount((unsigned)rv[1]) +
+                       __builtin_popcount((unsigned)rv[2]) + __builtin_popcount((unsigned)rv[3]);
+          }
+        }
+      }
       auto compute = [&](auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         const uint8_t* A = sA + buf * A_BYTES + band_off;
@@ -381,7 +411,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
   } while (0)
           if constexpr (!blk_is_d(blk)) {
             constexpr int tap = blk_tap(blk);
-            if constexpr (!USE_D4) {      // active inputs of this lane's row (lanes l and l + 32 hold the same fragment)
+            if constexpr (!USE_D4 && !REC) {
               // (volatile: left to itself hipcc defers the pure popcounts and keeps every fragment of the chunk alive)
               asm volatile("v_bcnt_u32_b32 %0, %1, %0\n\tv_bcnt_u32_b32 %0, %2, %0\n\tv_bcnt_u32_b32 %0, %3, %0\n\t"
                            "v_bcnt_u32_b32 %0, %4, %0" : "+v"(cnt[i]) : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]));
@@ -423,6 +453,24 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
       if (c == 0) compute(std::true_type{}); else compute(std::false_type{});
     }   // chunks
 
+    if constexpr (REC) {
+      // publish the record counts, then add the nine taps of every output position: s_row[p][t] = active inputs of row (p, t)
+#pragma unroll
+      for (int k = 0; k < NR; ++k)
+        if (rec_off[k] >= 0) s_cin[(rec_off[k] / POSB) * 16 + ((rec_off[k] % POSB) >> 4)] = creg[k];
+      __syncthreads();
+      for (int e = tid; e < HWb * 16; e += NWV * 64) {
+        const int pp = e >> 4, t = e & 15;
+        const int* c0 = s_cin + (((pp / W) + band) * PW + (pp % W)) * 16 + t;
+        int sum = 0;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) sum += c0[(dy * PW + dx) * 16];
+        s_row[e] = sum;
+      }
+      __syncthreads();
+    }
     // The MFMAs are opaque to hipcc's hazard recognizer: an accumulator may be read 18 wait states after the (16-pass)
     // MFMA that wrote it was issued.
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -450,6 +498,25 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
       float v = 0.f, D = 0.f;
       unsigned mybits = 0;
       bool flg = false;
+      int cntv[16];                                       // four-digit form: active inputs of this lane's rows (its position, step r)
+      if constexpr (!USE_D4 && !REC) {
+        // the count of accumulator row r sits in the A-layout lane (r & 3) + 8 (r >> 2) + 4 half
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rowA = (r & 3) + 8 * (r >> 2);
+          const int c0 = __builtin_amdgcn_readlane(cnt[i], rowA), c1 = __builtin_amdgcn_readlane(cnt[i], rowA + 4);
+          cntv[r] = half ? c1 : c0;
+        }
+      }
+      if constexpr (REC) {
+        const int pl = 2 * (wave + NWV * i) + half;       // position within the item
+        const v4i* rp = reinterpret_cast<const v4i*>(s_row + pl * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const v4i c4 = rp[q];
+          cntv[4 * q] = c4[0]; cntv[4 * q + 1] = c4[1]; cntv[4 * q + 2] = c4[2]; cntv[4 * q + 3] = c4[3];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float z, cstep;
@@ -459,12 +526,10 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
           cstep = cE;
         } else {
           // four digits: z = Q4 * (1024 Ac) + Bc, Q4 = P01 * 2^10 + P23; the dropped digits move it by at most 528 units of
-          // 2^-s per ACTIVE input of this (position, step): the count sits in the A-layout lane of accumulator row r
+          // 2^-s per ACTIVE input of this (position, step): s_row, read above
           const float q4 = fmaf(acc[i][0][r], 1024.0f, acc[i][1][r]);
           z = fmaf(q4, Ac4, Bc);
-          const int rowA = (r & 3) + 8 * (r >> 2);                 // (a constant after unrolling)
-          const int c0 = __builtin_amdgcn_readlane(cnt[i], rowA), c1 = __builtin_amdgcn_readlane(cnt[i], rowA + 4);
-          cstep = fmaf((float)(half ? c1 : c0), cT, cE);
+          cstep = fmaf((float)cntv[r], cT, cE);
         }
         D = fmaf(fabsf(z) + fabsf(v), CERT_4EPS, fmaf(D, 0.5f, cstep));     // D_t = D_{t-1} / 2 + c_t + 4 eps (|z| + |v|)
         const float h = v + (z - v) * 0.5f;
@@ -1023,7 +1088,8 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   }
   if (a.gx == 0) grid = cus >= G ? (cus / G) * G : G;         // flat walk: workgroup k -> group k % G
   const int a_bytes = bands ? ((8 / 2 + 1 + 2) * 9 + 1) * POSB : ((7 + 2) * 8 + 1) * POSB;
-  const size_t lds = 2 * ((size_t)a_bytes + W_LDS);
+  // (+ the active-input counters of the four-digit form: s_cin [cells][16], s_row [positions + 1][16])
+  const size_t lds = 2 * ((size_t)a_bytes + W_LDS) + (size_t)((a_bytes / POSB) + (bands ? 32 : 49) + 1) * 64;
   const long long n_words = ((long long)B * Cout * H * W + 31) / 32;
   a.ticket_idx = 2 + (long long)FLAG_CAP + n_words;
   // full 7x7 batches keep the round-1 order (repair launch, then the last-position launch re-arms the counter): the hand-over
