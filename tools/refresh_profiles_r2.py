@@ -98,5 +98,7 @@ for k, v in t.items():
           round(v.get("algorithmic_bytes_per_launch", 0) / 1e6, 1), "MB")
 shutil.copy(newest("trace_headline/runc/*_kernel_stats.csv"), os.path.join(O, "r2_bench_headline_kernel_stats.csv"))
 shutil.copy(os.path.join(P, "bench_headline_under_prof.json"), os.path.join(O, "r2_bench_headline_under_rocprof.json"))
-print(subprocess.run([sys.executable, os.path.join(R, "tools", "summarize_profile.py"),
-                      newest("trace_headline/runc/*_kernel_trace.csv")], capture_output=True, text=True).stdout)
+per_layer = subprocess.run([sys.executable, os.path.join(R, "tools", "summarize_profile.py"),
+                            newest("trace_headline/runc/*_kernel_trace.csv")], capture_output=True, text=True).stdout
+open(os.path.join(O, "r2_headline_per_layer.md"), "w").write(per_layer)
+print(per_layer)
