@@ -517,26 +517,44 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
           cntv[4 * q] = c4[0]; cntv[4 * q + 1] = c4[1]; cntv[4 * q + 2] = c4[2]; cntv[4 * q + 3] = c4[3];
         }
       }
+      if constexpr (USE_D4) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float z, cstep;
-        if constexpr (USE_D4) {
+        for (int r = 0; r < 16; ++r) {
           const float q5 = fmaf(fmaf(acc[i][0][r], 1024.0f, acc[i][1][r]), 32.0f, acc[i][NACC - 1][r]);
-          z = fmaf(q5, Ac, Bc);
-          cstep = cE;
-        } else {
-          // four digits: z = Q4 * (1024 Ac) + Bc, Q4 = P01 * 2^10 + P23; the dropped digits move it by at most 528 units of
-          // 2^-s per ACTIVE input of this (position, step): s_row, read above
-          const float q4 = fmaf(acc[i][0][r], 1024.0f, acc[i][1][r]);
-          z = fmaf(q4, Ac4, Bc);
-          cstep = fmaf((float)cntv[r], cT, cE);
+          const float z = fmaf(q5, Ac, Bc);
+          D = fmaf(fabsf(z) + fabsf(v), CERT_4EPS, fmaf(D, 0.5f, cE));      // D_t = D_{t-1} / 2 + cE + 4 eps (|z| + |v|)
+          const float h = v + (z - v) * 0.5f;
+          const bool s = h >= 1.0f;
+          flg = flg || (fabsf(h - 1.0f) <= D);
+          v = s ? 0.0f : h;
+          mybits |= s ? (1u << r) : 0u;
         }
-        D = fmaf(fabsf(z) + fabsf(v), CERT_4EPS, fmaf(D, 0.5f, cstep));     // D_t = D_{t-1} / 2 + c_t + 4 eps (|z| + |v|)
-        const float h = v + (z - v) * 0.5f;
-        const bool s = h >= 1.0f;
-        flg = flg || (fabsf(h - 1.0f) <= D);
-        v = s ? 0.0f : h;
-        mybits |= s ? (1u << r) : 0u;
+      } else {
+        // four digits: z = Q4 * (1024 Ac) + Bc, Q4 = P01 * 2^10 + P23 (two steps at a time on the packed fp32 pipe); the dropped
+        // digits move z_t by at most c_t = cE + cT n_t (n_t active inputs of the row).  D_t = D_{t-1} / 2 + c_t + 4 eps (|z_t| +
+        // |v_{t-1}|) and |v| <= max |z| give D_t <= 2 (cE + cT max_t n_t) + 16 eps max_t |z_t| for every t: track max |z|,
+        // max n and min |h - 1| (three instructions per step instead of eight) and compare once
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        float zmax = 0.f, dmin = 3.0e38f;
+        int nmax = 0;
+#pragma unroll
+        for (int r2 = 0; r2 < 16; r2 += 2) {
+          const v2f p0 = {acc[i][0][r2], acc[i][0][r2 + 1]}, p1 = {acc[i][1][r2], acc[i][1][r2 + 1]};
+          const v2f q4 = __builtin_elementwise_fma(p0, (v2f){1024.0f, 1024.0f}, p1);
+          const v2f z2 = __builtin_elementwise_fma(q4, (v2f){Ac4, Ac4}, (v2f){Bc, Bc});
+          nmax = max(nmax, max(cntv[r2], cntv[r2 + 1]));
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float z = z2[e];
+            zmax = fmaxf(zmax, fabsf(z));
+            const float h = fmaf(z - v, 0.5f, v);            // == v + (z - v) * 0.5f: the product is exact (v is not an output here)
+            dmin = fminf(dmin, fabsf(h - 1.0f));
+            const bool s = h >= 1.0f;
+            v = s ? 0.0f : h;
+            mybits |= s ? (1u << (r2 + e)) : 0u;
+          }
+        }
+        flg = dmin <= fmaf(zmax, 5.0f * CERT_4EPS, 2.0f * fmaf((float)nmax, cT, cE));      // (20 eps: a little to spare)
       }
       const int ti = wave + NWV * i;
       // accumulator lane half == position within the tile; a list that does not fill its last tiles repeats its last
