@@ -768,6 +768,44 @@ def test_graphed_training_step_trains(dev):
 
 
 
+def test_full_size_properties_of_the_benchmark_configs(dev, ops):
+    """BASELINE.json's full sizes through properties that do not need the oracle: (configs[1]) the 100-step sample at
+    B = 256 gives the SAME tokens with every image evaluated at every step, with the untouched images eliminated, and
+    with the position lists on top (graph replay, Philox noise); (configs[2]) encode -> decode at B = 1024 through the fp6
+    kernel family gives the code indices of the fp64 direct kernels exactly and their images to fp32 round-off."""
+    from snn_model.vq_diffusion import AbsorbingDiffusion
+    from spkdiff.ops import IN_PTC, IN_TINV
+    den, _ = build_den(synth.MNIST, dev)
+    toks = {}
+    for mode in ("dense", "images", "lists"):
+        ab = AbsorbingDiffusion(den, mask_id=128)
+        ab.n_samples = 256
+        ab.skip_untouched, ab.list_positions = mode != "dense", mode == "lists"
+        torch.manual_seed(2024)
+        toks[mode] = ab.sample(temp=1.0, sample_steps=100).cpu()
+        assert int(toks[mode].max()) < 128
+    assert torch.equal(toks["dense"], toks["images"]) and torch.equal(toks["dense"], toks["lists"])
+    model, _ = build_vae(synth.MNIST, dev)
+    B = 1024
+    img = (torch.rand(B, 1, 28, 28, generator=torch.Generator().manual_seed(42)) - 0.5).to(dev)
+    idx = model.encode_images(img, 16)
+    z_d = model.encoder.snn_convs.run(img, IN_TINV, final='ptc', T=16, stateful=False, impl='direct')['ptc']
+    idx_d, _ = model.vq_layer._quantize_ptc(z_d)
+    assert torch.equal(idx.reshape(-1), idx_d.reshape(-1))
+    pred, u8 = model.decode_tokens(idx, 16)
+    zq = ops.embedding(idx, model.vq_layer.embeddings.weight, nchw_hw=(7, 7))
+    e = model.vq_layer.poisson.run(zq, IN_TINV, final='ptc', T=16, stateful=False)['ptc']
+    rd = model.decoder.snn_convs.run(e, IN_PTC, final='memout', coef=model.memout.coef.flatten(), apply_tanh=True, want_u8=True,
+                                     stateful=False, impl='direct')
+    err = float((pred - rd['f32']).abs().max())
+    assert err <= 5e-6, err                 # the collapsed read-out sums in another order: fp32 round-off over 800 k pixels
+    d8 = (u8.int() - rd['u8'].int()).abs()
+    assert int(d8.max()) <= 1 and float((d8 > 0).float().mean()) < 1e-4          # truncation edges only
+    parity("full_size_properties", sample_B256_100_steps_modes_equal=True, encdec_B1024_index_mismatches=0,
+           encdec_B1024_pred_max_abs_diff_vs_direct=err, encdec_B1024_u8_off_by_one_frac=float((d8 > 0).float().mean()))
+
+
+
 # ------------------------------------------------------------------------------------------------- F8 LIF training
 @pytest.mark.parametrize("det", [False, True])
 def test_f8_lif_training_bptt_vs_reference_fixture(golden_dir, dev, det):
