@@ -100,6 +100,9 @@ struct V2Args {
 #ifndef SPK_V2_KMIN
 #define SPK_V2_KMIN 2           // listed positions: an item of fewer tiles per wave still costs about this many (operand copies)
 #endif
+#ifndef SPK_V2_SPARE
+#define SPK_V2_SPARE 1.0f       // four-digit form: factor on the certification bound (2.0f = the first builds' spare factor)
+#endif
 #ifndef SPK_V2_PF
 #define SPK_V2_PF 6             // A fragments requested this many steps ahead of the MFMA that consumes them
 #endif
@@ -116,7 +119,10 @@ struct V2Args {
 // |z|, |b| or |Bc|).  One LIF step h = v + (z - v) / 2 halves the carried difference and adds its own roundings:
 //   dh_t <= dh_{t-1} / 2 + c_t / 2 + 2 eps (|z_t| + |v_{t-1}|)
 // as long as the spike decisions agreed so far (after a spike both paths restart from v = 0; the bound is simply kept).
-// The epilogue carries D_t = 2 dh_t (a factor 2 to spare) per neuron and flags it when |h_t - 1| <= D_t for some t: every
+// Five digits: the epilogue carries D_t = 2 dh_t (a factor 2 to spare) per neuron and flags it when |h_t - 1| <= D_t for some t.
+// Four digits: the closed form of the same recursion, dh_t <= max c + 8 eps max |z| (|v| <= max |z|), WITHOUT the spare factor --
+// the digit term of c_t is exact (528 is the largest residue there is), eps already holds every rounding 2.5-4 times over, and
+// the number of flagged neurons (the repair launch: 7 % of a dense reverse step) is proportional to the bound.  Every
 // unflagged neuron provably emits the exact path's spikes; flagged ones are recomputed exactly.
 __device__ __forceinline__ float cert_const(float bias_f, float bna, float bnb, float Bc, float scale_f, int Cin) {
   const float E5 = 16.0f * 9.0f * (float)Cin * scale_f;
@@ -533,7 +539,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
         // four digits: z = Q4 * (1024 Ac) + Bc, Q4 = P01 * 2^10 + P23 (two steps at a time on the packed fp32 pipe); the dropped
         // digits move z_t by at most c_t = cE + cT n_t (n_t active inputs of the row).  D_t = D_{t-1} / 2 + c_t + 4 eps (|z_t| +
         // |v_{t-1}|) and |v| <= max |z| give D_t <= 2 (cE + cT max_t n_t) + 16 eps max_t |z_t| for every t: track max |z|,
-        // max n and min |h - 1| (three instructions per step instead of eight) and compare once
+        // max n and min |h - 1| (three instructions per step instead of eight) and compare once, against dh = D / 2
         typedef float v2f __attribute__((ext_vector_type(2)));
         float zmax = 0.f, dmin = 3.0e38f;
         int nmax = 0;
@@ -554,7 +560,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
             mybits |= s ? (1u << (r2 + e)) : 0u;
           }
         }
-        flg = dmin <= fmaf(zmax, 5.0f * CERT_4EPS, 2.0f * fmaf((float)nmax, cT, cE));      // (20 eps: a little to spare)
+        flg = dmin <= SPK_V2_SPARE * fmaf(zmax, 2.5f * CERT_4EPS, fmaf((float)nmax, cT, cE));   // (10 eps for 8: a little to spare)
       }
       const int ti = wave + NWV * i;
       // accumulator lane half == position within the tile; a list that does not fill its last tiles repeats its last

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(512, 1) void vae_fp6_kernel(TArgs a) {
             else mybits |= s ? (1u << r) : 0u;
           }
         }
-        const bool flg = dmin <= fmaf(zmax, 5.0f * CERT_4EPS, 2.0f * cE);      // (20 eps: a little to spare)
+        const bool flg = dmin <= fmaf(zmax, 2.5f * CERT_4EPS, cE);             // dh <= cE + 8 eps max |z| (10 eps: a little to spare)
         const int p = 2 * tl[i] + half;                       // accumulator lane half == position within the tile
         const bool ok = (i == 0 || v1) && p < NPOS;
         const int pc = p < NPOS ? p : NPOS - 1;
