@@ -531,6 +531,98 @@ __global__ __launch_bounds__(256) void readout_collapsed_kernel(ROArgs a) {
   }
 }
 
+// The same read-out for 3x3 kernels and CIN input channels (the decoder's last layer), bound by the LDS reads of the generic
+// form above (two 16-byte reads per four FMAs).  Here a thread computes FOUR adjacent output pixels for a quarter of the input
+// channels: per kernel row the six input columns they share are read once (12 reads) and every weight vector serves four
+// pixels (6 reads): 54 reads per 288 FMAs.  The image rows sit in LDS with one zero column on either side (no edge tests).
+template <int CIN, int RB>
+__global__ __launch_bounds__(256) void readout_collapsed_k3_kernel(ROArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float ro_lds[];
+  constexpr int Cp = CIN + 4, CQ = CIN / 4, ROWS = RB + 2;
+  const int nband = (a.H + RB - 1) / RB;
+  const int b = blockIdx.x / nband, y0 = (blockIdx.x % nband) * RB;
+  const int Wp = a.W + 2;
+  float* sx = ro_lds;                                         // [ROWS][W + 2][Cp]
+  float* sw = ro_lds + ROWS * Wp * Cp;                        // [Cout][9][CIN]  (taps as a plain correlation)
+  for (int i = threadIdx.x; i < a.Cout * 9 * CIN; i += 256) {
+    const int ci = i % CIN, tap = (i / CIN) % 9, co = i / (CIN * 9);
+    const int src_tap = a.transposed ? 8 - tap : tap;
+    sw[i] = a.transposed ? a.w[((long long)ci * a.Cout + co) * 9 + src_tap] : a.w[((long long)co * CIN + ci) * 9 + src_tap];
+  }
+  constexpr int q4 = CIN / 4;
+  // every load of the band is requested before the first LDS write waits for one (W <= 32: at most NLD per thread)
+  constexpr int NLD = (ROWS * 34 * q4 + 255) / 256;
+  const int nld = ROWS * Wp * q4;
+  float4 stg[NLD];
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    const int c4 = i % q4, xc = (i / q4) % Wp, r = i / (q4 * Wp);
+    const int yy = y0 + r - 1, xx = xc - 1;                   // (pad' = 1 either way: pad == 1)
+    const bool ok = i < nld && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+    const float4 ld = *reinterpret_cast<const float4*>(a.x + (ok ? (((long long)b * a.H + yy) * a.W + xx) * CIN + 4 * c4 : 0));
+    stg[j] = ok ? ld : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    const int c4 = i % q4, xc = (i / q4) % Wp, r = i / (q4 * Wp);
+    if (i < nld) *reinterpret_cast<float4*>(sx + (r * Wp + xc) * Cp + 4 * c4) = stg[j];
+  }
+  __syncthreads();
+  const int part = threadIdx.x & 3, u = threadIdx.x >> 2;
+  const int nq = a.W >> 2;
+  const int quad = u % nq, ry = u / nq;
+  const bool active = ry < RB;                                // (no barrier below: idle threads just skip the stores)
+  const int ryc = active ? ry : 0;
+  for (int co = 0; co < a.Cout; ++co) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      float4 xr[6][CQ / 4];
+      const float* xp = sx + ((ryc + dy) * Wp + 4 * quad) * Cp + part * CQ;
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int c = 0; c < CQ / 4; ++c) xr[j][c] = *reinterpret_cast<const float4*>(xp + j * Cp + 4 * c);
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const float* wp = sw + (co * 9 + dy * 3 + dx) * CIN + part * CQ;
+#pragma unroll
+        for (int c = 0; c < CQ / 4; ++c) {
+          const float4 wv = *reinterpret_cast<const float4*>(wp + 4 * c);
+#pragma unroll
+          for (int px = 0; px < 4; ++px) {
+            const float4 xv = xr[px + dx][c];
+            acc[px] = fmaf(xv.x, wv.x, acc[px]); acc[px] = fmaf(xv.y, wv.y, acc[px]);
+            acc[px] = fmaf(xv.z, wv.z, acc[px]); acc[px] = fmaf(xv.w, wv.w, acc[px]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      acc[px] += __shfl_xor(acc[px], 1);
+      acc[px] += __shfl_xor(acc[px], 2);
+    }
+    const int oy = y0 + ry;
+    if (part == 0 && active && oy < a.H) {
+      const float bs = a.bias ? a.bias[co] * a.coef_sum : 0.f;
+      float pv[4];
+      unsigned pk = 0;
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        const float m = acc[px] + bs;
+        pv[px] = a.apply_tanh ? tanhf(m) : m;
+        pk |= (unsigned)(uint8_t)(fminf(fmaxf(pv[px] + 0.5f, 0.0f), 1.0f) * 255.0f) << (8 * px);
+      }
+      const long long oidx = ((long long)b * a.Cout + co) * a.H * a.W + (long long)oy * a.W + 4 * quad;
+      if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + oidx) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+      if (a.out_u8) *reinterpret_cast<unsigned*>(a.out_u8 + oidx) = pk;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int spk_readout_collapsed_fwd(const float* x_bpc, const float* w, const float* bias, float coef_sum,
@@ -544,6 +636,20 @@ extern "C" int spk_readout_collapsed_fwd(const float* x_bpc, const float* w, con
   ROArgs a;
   a.x = x_bpc; a.w = w; a.bias = bias; a.coef_sum = coef_sum; a.out_f32 = out_f32; a.out_u8 = out_u8; a.apply_tanh = apply_tanh;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.k = k; a.pad = pad; a.transposed = transposed;
+  if (k == 3 && Cin == 32 && (W % 4) == 0 && W <= 32 && Cout <= 8) {
+    const bool r7 = (H % 7) == 0;                              // 28 rows: four bands of seven; else bands of eight
+    const int rb = r7 ? 7 : 8;
+    if ((W / 4) * rb * 4 <= 256) {
+      const size_t lds3 = ((size_t)(rb + 2) * (W + 2) * (32 + 4) + (size_t)Cout * 9 * 32) * sizeof(float);
+      const long long nb = (long long)B * ((H + rb - 1) / rb);
+      if (lds3 <= 64 * 1024 && nb <= 0x7fffffffLL) {
+        if (r7) hipLaunchKernelGGL((readout_collapsed_k3_kernel<32, 7>), dim3((unsigned)nb), dim3(256), lds3, stream, a);
+        else hipLaunchKernelGGL((readout_collapsed_k3_kernel<32, 8>), dim3((unsigned)nb), dim3(256), lds3, stream, a);
+        SPK_LAUNCH_CHECK();
+        return SPK_OK;
+      }
+    }
+  }
   const long long blocks = (long long)B * ((H + RO_RB - 1) / RO_RB);
   if (blocks > 0x7fffffffLL) return SPK_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(readout_collapsed_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a);

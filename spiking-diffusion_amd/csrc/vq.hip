@@ -105,6 +105,80 @@ __global__ __launch_bounds__(256) void vq_kernel(const uint8_t* __restrict__ z, 
   }
 }
 
+// D == 16, T == 16, spike input, fp64 codebook in LDS: the launch is a chain of dependent round trips per position (sixteen
+// byte loads, then the distances), so a wave reads out FOUR positions at once (lane = position within the group * 16 + d) and
+// then scans the codebook for each of them from registers.  Same arithmetic and order of operations as vq_kernel.
+__global__ __launch_bounds__(256) void vq16_kernel(const uint8_t* __restrict__ z, const float* __restrict__ coef,
+                                                   const float* __restrict__ alpha_p, const float* __restrict__ cb,
+                                                   long long* __restrict__ idx_out, float* __restrict__ zq_out,
+                                                   float* __restrict__ xm_out, int B, int HW, int K) {
+  constexpr int D = 16, T = 16;
+  extern __shared__ float lds[];
+  double* s_cbd = reinterpret_cast<double*>(lds);                  // [K][D+1]
+  double* s_e2 = s_cbd + K * (D + 1);                              // [K]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < K * D; i += blockDim.x) s_cbd[(i / D) * (D + 1) + (i % D)] = (double)cb[i];
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    double e2 = 0.0;
+    for (int d = 0; d < D; ++d) { const double e = s_cbd[k * (D + 1) + d]; e2 += e * e; }
+    s_e2[k] = e2;
+  }
+  __syncthreads();
+  const float alpha = alpha_p[0], one_m_alpha = 1.0f - alpha;
+  float cf[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) cf[t] = coef[t];
+  const long long npos = (long long)B * HW;
+  const int sub = lane >> 4, dl = lane & 15;
+  for (long long p0 = ((long long)blockIdx.x * 4 + wave) * 4; p0 < npos; p0 += (long long)gridDim.x * 16) {
+    const long long pm = p0 + sub;
+    float xl = 0.f;
+    if (pm < npos) {
+      const uint8_t* zp = z + pm * T * D + dl;
+      float sv[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) sv[t] = (float)zp[t * D];
+      float m = 0.f, cnt = 0.f;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { m = m + sv[t] * cf[t]; cnt = cnt + sv[t]; }
+      xl = one_m_alpha * m + (alpha * cnt) / (float)T;
+      if (xm_out) xm_out[pm * D + dl] = xl;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long p = p0 + j;
+      if (p >= npos) break;                                        // (uniform over the wave)
+      double xr[D], x2 = 0.0;
+#pragma unroll
+      // (products of two fp32 values are exact in fp64: fma(a, b, s) == s + a * b bit for bit, in half the instructions)
+      for (int d = 0; d < D; ++d) { xr[d] = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xl), 16 * j + d)); x2 = fma(xr[d], xr[d], x2); }
+      double best = 1.0e300;
+      int besti = 0x7fffffff;
+      for (int k0 = 0; k0 < K; k0 += 64) {
+        const int k = k0 + lane;
+        const int kc = k < K ? k : K - 1;
+        double dot = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) dot = fma(xr[d], s_cbd[kc * (D + 1) + d], dot);
+        const double dist = x2 + s_e2[kc] - 2.0 * dot;
+        if (k < K && dist < best) { best = dist; besti = k; }      // k increasing per lane: first minimum kept
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off);
+        const int oi = __shfl_xor(besti, off);
+        if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+      }
+      if (lane == 0) idx_out[p] = (long long)besti;
+      if (zq_out && lane < D) {
+        const int b = (int)(p / HW), hw = (int)(p % HW);
+        zq_out[((long long)b * D + lane) * HW + hw] = (float)s_cbd[besti * (D + 1) + lane];
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void embedding_kernel(const long long* __restrict__ tok, const float* __restrict__ cb,
                                                         float* __restrict__ out, long long N, int D, int K, int HW,
                                                         int nchw) {
@@ -138,7 +212,13 @@ extern "C" int spk_vq_readout_argmin(const uint8_t* z_ptc, const float* coef, co
   long long npos = (long long)B * HW;
   int grid = (int)((npos + 3) / 4);
   if (grid > 2048) grid = 2048;
-  if (D == 16)
+  const size_t lds64 = ((size_t)K * (D + 1) + (size_t)K) * sizeof(double);
+  if (D == 16 && T == 16 && lds64 <= 64 * 1024) {
+    int g16 = (int)((npos + 15) / 16);
+    if (g16 > 4096) g16 = 4096;                              // (one group of four positions per wave: the loads of all of them overlap)
+    hipLaunchKernelGGL(vq16_kernel, dim3(g16), dim3(256), lds64, stream, z_ptc, coef, alpha, codebook, idx_out, zq_out_bdhw,
+                       xm_out, B, HW, K);
+  } else if (D == 16)
     hipLaunchKernelGGL(vq_kernel<16>, dim3(grid), dim3(256), lds, stream, z_ptc, (const float*)nullptr, coef, alpha,
                        codebook, idx_out, zq_out_bdhw, xm_out, T, B, D, HW, K);
   else

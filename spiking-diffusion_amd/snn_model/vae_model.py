@@ -49,10 +49,10 @@ class VectorQuantizer(nn.Module):
         )
 
     # -- fused pieces, shared with SNN_VQVAE's end-to-end path ------------------------------------------------
-    def _quantize_ptc(self, z_ptc, want_xm=False):
-        """z_ptc u8 [B,h,w,T,D] -> (indices int64 [B*h*w], quantized fp32 [B,D,h,w])."""
+    def _quantize_ptc(self, z_ptc, want_xm=False, want_zq=True):
+        """z_ptc u8 [B,h,w,T,D] -> (indices int64 [B*h*w], quantized fp32 [B,D,h,w] or None)."""
         idx, zq, xm = ops.vq_readout_argmin(z_ptc, self.memout.coef.flatten(), self.alpha, self.embeddings.weight,
-                                            want_zq=True, want_xm=want_xm)
+                                            want_zq=want_zq, want_xm=want_xm)
         return (idx, zq, xm) if want_xm else (idx, zq)
 
     def _spike_generator(self, zq, T, final='f32'):
@@ -209,7 +209,7 @@ class SNN_VQVAE(nn.Module):
         """images [B,C,H,W] already normalised (images - 0.5) -> code indices [B,h,w]; the T-fold repeat of
         R/main.py:309 / vq_diffusion.py:30 is folded into the first kernel (time-invariant input)."""
         z_ptc = self.encoder.snn_convs.run(images, IN_TINV, final='ptc', T=T, stateful=False)['ptc']
-        idx, _ = self.vq_layer._quantize_ptc(z_ptc)
+        idx, _ = self.vq_layer._quantize_ptc(z_ptc, want_zq=False)      # (indices only: no [B,D,h,w] gather)
         L = images.shape[-1] // 4
         return idx.reshape(images.shape[0], L, L)
 
