@@ -56,6 +56,13 @@ const char* spk_error_string(int code);
 int spk_lif_fwd(const float* x_seq, float* v_inout, void* spike_out, int T, long long N, float tau, float v_threshold,
                 float v_reset, int spike_dtype, spk_stream_t stream);
 
+/* The table behind the time-invariant-input layers (spk_conv_fused_fwd with SPK_IN_TINV and no carried state): the default
+ * neuron (tau 2, v_th 1, v_reset 0: SJ/activation_based/neuron.py:799-811 with the models' constructor arguments,
+ * R/snn_model/vae_model.py:112) driven by a CONSTANT input from v = 0 fires with period p(x); thresholds16[k-1] is the
+ * smallest fp32 input whose first spike comes at step k or earlier, patterns18[p] the sixteen spike bits of period p
+ * (p = 17: none).  Host-side copy-out, no GPU needed: the CPU tests check it against the fp32 recurrence on every float. */
+int spk_lif_const_input_table(float* thresholds16, unsigned* patterns18);
+
 /* ---- stateless step-mode layers ---------------------------------------------------------------------------- */
 
 /* Eval BatchNorm as PyTorch evaluates it (pinned by fixture F7): a = (1/sqrt(var+eps))*gamma, b = fma(-mean,a,beta). */

@@ -19,6 +19,7 @@
 #include "den_common.h"
 #include "../../include/spkdiff.h"
 #include <math.h>
+#include <string.h>
 
 namespace {
 
@@ -310,6 +311,15 @@ __global__ __launch_bounds__(256) void tinv_lif_kernel(TinvArgs a) {
     for (int i = 0; i < NW; ++i) wreg[i] = a.wt[i * a.Cout + co];            // packed [k*k][Cin][Cout]
   }
   const int HWi = a.H * a.W;
+  // stateless calls (v = 0 at step 0): the spike train of a constant input is a table look-up (spk_common.h)
+  __shared__ float s_th[16];
+  __shared__ unsigned s_pat[18];
+  {
+    constexpr unsigned thb[16] = SPK_LIF_CONST_TH_BITS, pat[18] = SPK_LIF_CONST_PATTERNS;
+    if (threadIdx.x < 16) s_th[threadIdx.x] = __uint_as_float(thb[threadIdx.x]);
+    if (threadIdx.x < 18) s_pat[threadIdx.x] = pat[threadIdx.x];
+  }
+  __syncthreads();
   for (int p0 = blockIdx.x * ppb; p0 < npos; p0 += gridDim.x * ppb) {
     const int pg = p0 + pl;
     const bool ok = pg < npos;
@@ -350,11 +360,15 @@ __global__ __launch_bounds__(256) void tinv_lif_kernel(TinvArgs a) {
     }
     const float y0 = fmaf((float)acc, al, be);
     const long long o_bchw = ((long long)b * a.Cout + co) * plane + op;
-    float v = (a.v_io && ok) ? a.v_io[o_bchw] : 0.0f;
     unsigned mybits = 0;
+    if (a.v_io) {                                            // (uniform) carried membrane state: the sixteen steps
+      float v = ok ? a.v_io[o_bchw] : 0.0f;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) mybits |= spk_lif_step_default(v, y0) ? (1u << t) : 0u;
-    if (a.v_io && ok) a.v_io[o_bchw] = v;
+      for (int t = 0; t < 16; ++t) mybits |= spk_lif_step_default(v, y0) ? (1u << t) : 0u;
+      if (ok) a.v_io[o_bchw] = v;
+    } else {
+      mybits = spk_lif_const_input_bits16(y0, s_th, s_pat);
+    }
     if (a.out_cnt && ok) a.out_cnt[(((long long)b * (a.Cout >> 5) + (co >> 5)) * plane + op) * 32 + (co & 31)] = (uint8_t)__popc(mybits);
     // lanes are consecutive output channels (Cout % 16 == 0: the 16 lanes of a DPP row are 16 channels of ONE position); a
     // 16x16 bit transpose per row gives lane t the 16 channel bits of step t
@@ -407,6 +421,14 @@ int launch_mode(const FusedArgs& a, int mode, hipStream_t stream) {
 }
 
 }  // namespace
+
+extern "C" int spk_lif_const_input_table(float* thresholds16, unsigned* patterns18) {
+  if (!thresholds16 || !patterns18) return SPK_ERR_ARG;
+  const unsigned thb[16] = SPK_LIF_CONST_TH_BITS, pat[18] = SPK_LIF_CONST_PATTERNS;
+  for (int i = 0; i < 16; ++i) memcpy(&thresholds16[i], &thb[i], 4);
+  for (int i = 0; i < 18; ++i) patterns18[i] = pat[i];
+  return SPK_OK;
+}
 
 extern "C" int spk_conv_out_size(int in, int k, int stride, int pad, int transposed, int out_pad) {
   return transposed ? (in - 1) * stride - 2 * pad + k + out_pad : (in + 2 * pad - k) / stride + 1;

@@ -40,10 +40,35 @@ __device__ __forceinline__ bool spk_lif_step(float& v, float x, float tau, float
 // Default neuron of the models (tau 2, v_th 1, v_reset 0: R/snn_model/vae_model.py:37,112,...), lean form for the
 // fused epilogues:  h = v + (x - v)/2 ; s = h >= 1 ; v = s ? 0 : h.  Same spikes and the same v as the reference's
 // arithmetic except that a zero membrane potential may keep its sign (-0.0 instead of +0.0), which no later
-// operation can observe (x - (-0) == x - (+0), and torch.equal(-0., +0.) is True).
+// operation can observe (x - (-0) == x - (+0), and torch.equal(-0., +0.) is True), and that an INFINITE h resets to 0 here
+// and to NaN there ((1 - s) * h): pre-activations are finite.
 __device__ __forceinline__ bool spk_lif_step_default(float& v, float x) {
   const float h = v + (x - v) * 0.5f;
   const bool s = h >= 1.0f;
   v = s ? 0.0f : h;
   return s;
+}
+
+// The default neuron under a CONSTANT input x from v = 0 (the layers whose input is the same frame at every step: encoder
+// conv1, the spike generator, the denoiser's conv1).  After a spike the state is v = 0 again, so the train is periodic with
+// the step p(x) of the first spike, and p is a step function of x: p(x) <= k  <=>  x >= theta_k.  The sixteen thresholds
+// below are those of the fp32 recurrence above (h = v + (x - v) * 0.5f, three roundings), found by running it on EVERY float
+// in [0.5, 4) (tests/test_cabi_and_host.py repeats that, 25 M values; x <= 1 and NaN never fire, x >= 2 fires every step):
+// theta_k is the smallest float whose first spike comes at step k or earlier (~ 1 / (1 - 2^-k)).  Sixteen LIF steps become
+// one table look-up: with t = x - 1 (exact in [1, 2]) and k = -ilogb(t), theta_{k+1} - 1 <= 2^-k <= t, so p is k or k + 1.
+#define SPK_LIF_CONST_TH_BITS {0x40000000u, 0x3faaaaabu, 0x3f924925u, 0x3f888889u, 0x3f842108u, 0x3f820821u, 0x3f810204u, \
+                               0x3f808081u, 0x3f804020u, 0x3f802008u, 0x3f801002u, 0x3f800801u, 0x3f800400u, 0x3f800200u, \
+                               0x3f800100u, 0x3f800080u}
+// spike bits (bit t = step t) of a train with period p = 1 .. 16; p = 17: no spike within sixteen steps; entry 0 unused
+#define SPK_LIF_CONST_PATTERNS {0u, 0xffffu, 0xaaaau, 0x4924u, 0x8888u, 0x4210u, 0x0820u, 0x2040u, 0x8080u, 0x0100u, 0x0200u, \
+                                0x0400u, 0x0800u, 0x1000u, 0x2000u, 0x4000u, 0x8000u, 0u}
+// s_th[k - 1] = theta_k (16 floats), s_pat[p] (18 words): LDS copies of the two tables
+__device__ __forceinline__ unsigned spk_lif_const_input_bits16(float x, const float* s_th, const unsigned* s_pat) {
+  const float t = x - 1.0f;
+  int k = 1 - __builtin_amdgcn_frexp_expf(t);              // t = m * 2^e, m in [0.5, 1): ilogb(t) = e - 1
+  k = k < 1 ? 1 : (k > 16 ? 16 : k);
+  int p = x >= s_th[k - 1] ? k : k + 1;
+  p = x >= 2.0f ? 1 : p;
+  p = x > 1.0f ? p : 17;                                    // (also NaN)
+  return s_pat[p];
 }

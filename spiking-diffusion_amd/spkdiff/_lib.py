@@ -57,6 +57,7 @@ _SIGS = {
     "spk_spikes_to_ptc": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_ptc_to_spikes": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_conv_out_size": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "spk_lif_const_input_table": (c_int, [P, P]),
     "spk_pack_conv_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spk_conv_fused_fwd": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int,
                                    c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

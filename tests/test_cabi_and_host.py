@@ -44,6 +44,54 @@ def test_argument_errors_map_to_python_exceptions():
         _lib.check(1, "x")
 
 
+def test_constant_input_lif_table_matches_the_fp32_recurrence_on_every_float():
+    """The time-invariant-input layers replace the sixteen LIF steps of a stateless call by a table look-up
+    (csrc/spk_common.h: spk_lif_const_input_bits16).  The table is checked here against the neuron's fp32 recurrence
+    (SJ/activation_based/neuron.py:799-811: h = v + (x - v) / tau, spike = h >= v_th, hard reset to 0; tau 2, v_th 1) on EVERY
+    float in [0.5, 4) -- 25 M inputs -- with the device function's selection logic restated in numpy; outside that range the
+    train is trivial (x <= 1 or NaN: silent; x >= 2: a spike at every step), checked on samples."""
+    import ctypes
+    import numpy as np
+    from spkdiff import _lib
+    th = np.zeros(16, dtype=np.float32)
+    pat = np.zeros(18, dtype=np.uint32)
+    assert _lib.lib.spk_lif_const_input_table(th.ctypes.data_as(ctypes.c_void_p), pat.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert _lib.lib.spk_lif_const_input_table(None, None) == -1
+    assert np.all(np.diff(th) < 0) and th[0] == 2.0
+
+    def recurrence_bits(x):
+        v = np.zeros_like(x)
+        bits = np.zeros(x.shape, dtype=np.uint32)
+        for t in range(16):
+            h = v + (x - v) * np.float32(0.5)
+            s = h >= np.float32(1.0)
+            bits |= s.astype(np.uint32) << np.uint32(t)
+            v = np.where(s, np.float32(0), h)
+        return bits
+
+    def table_bits(x):
+        with np.errstate(invalid="ignore", over="ignore"):
+            t = x - np.float32(1.0)
+            _, e = np.frexp(t)
+            k = np.clip(1 - e, 1, 16)
+            p = np.where(x >= th[k - 1], k, k + 1)
+            p = np.where(x >= np.float32(2.0), 1, p)
+            p = np.where(x > np.float32(1.0), p, 17)
+        return pat[p]
+
+    n_bad = 0
+    lo, hi = 0x3F000000, 0x40800000                       # [0.5, 4.0)
+    for a in range(lo, hi, 1 << 22):
+        x = np.arange(a, min(a + (1 << 22), hi), dtype=np.uint32).view(np.float32)
+        n_bad += int(np.count_nonzero(recurrence_bits(x) != table_bits(x)))
+    assert n_bad == 0
+    with np.errstate(invalid="ignore", over="ignore"):
+        rng = np.random.default_rng(0)
+        x = rng.integers(0, 1 << 32, size=1 << 20, dtype=np.uint64).astype(np.uint32).view(np.float32)   # any bit pattern
+        x = np.concatenate([x, np.array([0.0, -0.0, 1.0, 2.0, np.inf, -np.inf, np.nan, 3.4e38, 1e-45], dtype=np.float32)])
+        assert np.array_equal(recurrence_bits(x), table_bits(x))
+
+
 def test_workspace_sizes_and_shape_support_are_host_side():
     """The size / support queries of the round-2 entry points answer on the host (no GPU): position-list buffer layout,
     flag workspaces, packed-weight sizes, and which VQ-VAE layer shapes the fp6 kernel family takes."""
