@@ -339,9 +339,12 @@ __global__ __launch_bounds__(256) void tinv_lif_kernel(TinvArgs a) {
           const int off = in ? iy * a.W + ix : 0;
 #pragma unroll
           for (int ci = 0; ci < KC; ++ci) {
-            // (an out-of-image tap adds an exact zero: same sum as skipping it)
-            const float xv = in ? xb[ci * HWi + off] : 0.0f;
-            acc += (double)xv * (double)wreg[(ky * KS + kx) * KC + ci];
+            // (an out-of-image tap adds an exact zero: same sum as skipping it.  Unconditional load from a clamped address +
+            //  select: a load under a per-lane condition makes hipcc branch around it and wait for it alone -- KS * KS * KC
+            //  round trips one after the other, 18 us of the denoiser's conv1 launch)
+            const float ld = xb[ci * HWi + off];
+            const float xv = in ? ld : 0.0f;
+            acc = fma((double)xv, (double)wreg[(ky * KS + kx) * KC + ci], acc);   // (fp32 x fp32 is exact in fp64: == acc + x * w)
           }
         }
       }
