@@ -98,7 +98,9 @@ __global__ __launch_bounds__(256) void psample_kernel(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < KPL; ++j) {
       const int k = lane + 64 * j;
-      l[j] = k < K ? logits[((long long)b * K + k) * HW + hw] / temp : -INFINITY;
+      // (unconditional load from a clamped index + select: hipcc waits for a conditional load on its own)
+      const float lg = logits[((long long)b * K + (k < K ? k : K - 1)) * HW + hw];
+      l[j] = k < K ? lg / temp : -INFINITY;
       mx = fmaxf(mx, l[j]);
     }
     mx = wave_max(mx);
