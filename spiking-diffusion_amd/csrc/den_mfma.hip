@@ -418,6 +418,130 @@ __global__ __launch_bounds__(256) void conv3x3_counts_mfma_kernel(CntArgs a) {
   }
 }
 
+// Full batches: the launch above moves 1.35 GB through the L2 (every wave fetches the 18 KB of weight tiles of each chunk
+// itself: 0.9 GB, and its 9 x 1 KB of count fragments: 0.45 GB) in 40 us -- the L2's 34 TB/s.  The four waves of a workgroup
+// are four row tiles of the SAME channel group: here they share each chunk's weight tiles AND the count records of the (at most
+// four) images their 128 rows lie in through LDS (fetched once per workgroup into registers while the previous chunk is
+// multiplied, written to the other buffer, one barrier per chunk; the nine taps of a row are nine LDS reads).  Same sums, same
+// epilogue.
+__global__ __launch_bounds__(256) void conv3x3_counts_mfma_shared_kernel(CntArgs a) {
+  constexpr int MAXP = 64;                                   // positions per image (the launcher checks H * W <= 64)
+  __shared__ v4i s_w[2][W_CHUNK_BYTES / 16];
+  __shared__ v4i s_a[2][4 * MAXP * 2];                       // the count records of the (up to) four images the 128 rows lie in
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int HW = a.H * a.W;
+  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
+  const long long nrows = (long long)Bn * HW;
+  const long long tile = (long long)blockIdx.x * 4 + wave;
+  const long long R0 = (long long)blockIdx.x * 128;
+  if (R0 >= nrows) return;                                   // (uniform over the workgroup)
+  const int g = blockIdx.y;
+  const int nchunks = a.nch0 + a.nch1;
+  const int row = lane & 31, half = lane >> 5;
+  const long long R = tile * 32 + row;
+  const bool rvalid = R < nrows;
+  const int b = rvalid ? (int)(R / HW) : 0, p = rvalid ? (int)(R % HW) : 0;
+  const int y = p / a.W, x = p % a.W;
+  const int b_lo = (int)(R0 / HW);                           // 128 rows span at most 4 images (H * W >= 43) -- checked by the launcher
+  const int boff16 = ((lane & 31) * CK + 16 * (half ^ ((lane >> 4) & 1))) >> 4;
+  constexpr int NV = W_CHUNK_BYTES / 16, NPRE = (NV + 255) / 256;      // 1152 16-byte vectors per chunk, 5 per thread
+  const v4i* wg = reinterpret_cast<const v4i*>(a.wq + (long long)g * nchunks * W_CHUNK_BYTES);
+  const int na = 4 * HW * 2;                                 // 16-byte vectors of the four images' records per chunk (<= 512)
+  // vector e of the staged records: image b_lo + e / (2 HW), position (e / 2) % HW, half e & 1
+  auto a_src = [&](int c, int e) -> const v4i* {
+    int bi = b_lo + e / (2 * HW);
+    bi = bi < Bn ? bi : Bn - 1;
+    const int rem = e % (2 * HW);
+    const uint8_t* base = c < a.nch0 ? a.c0 + ((long long)bi * a.nch0 + c) * HW * CK
+                                     : a.c1 + ((long long)bi * a.nch1 + (c - a.nch0)) * HW * CK;
+    return reinterpret_cast<const v4i*>(base + rem * 16);
+  };
+  // Register sets S[k & 1] carry chunk k from memory to LDS buffer k & 1: chunk c + 2 is requested while chunk c is multiplied
+  // and chunk c + 1 (requested one iteration earlier) is written to the other buffer -- two chunks in flight per workgroup (a
+  // chunk is 26 KB and an L2 round trip under this load ~1.5 us: one chunk in flight streams the 16 chunks in 24 us).
+  v4i pre[2][NPRE], prea[2][2];
+  auto request = [&](int c, auto s_tag) {
+    constexpr int S = decltype(s_tag)::value;
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      pre[S][j] = wg[(long long)c * NV + (e < NV ? e : NV - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      prea[S][j] = *a_src(c, e < na ? e : na - 1);
+    }
+  };
+  auto deposit = [&](auto s_tag) {
+    constexpr int S = decltype(s_tag)::value;
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      if (e < NV) s_w[S][e] = pre[S][j];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      if (e < na) s_a[S][e] = prea[S][j];
+    }
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  request(0, P0{});
+  if (nchunks > 1) request(1, P1{});
+  deposit(P0{});
+  __syncthreads();
+  // LDS vector index of this lane's fragment for tap (0, 0) shifted by (-1, -1), and the taps that lie inside the image
+  const int a_base = ((b - b_lo) * HW + p) * 2 + half;
+  bool okt[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+    okt[tap] = rvalid && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+  }
+  v16i acc0 = {0}, acc1 = {0};
+  auto step = [&](int c, auto s_tag) {
+    constexpr int S = decltype(s_tag)::value;                // c & 1
+    if (c + 2 < nchunks) request(c + 2, s_tag);              // (set S is free: chunk c sits in LDS buffer S)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int d = ((tap / 3 - 1) * a.W + (tap % 3 - 1)) * 2;
+      const v4i ld = s_a[S][okt[tap] ? a_base + d : 0];
+      const v4i av = okt[tap] ? ld : (v4i){0, 0, 0, 0};
+      const v4i b0 = s_w[S][(tap * 2 + 0) * 64 + boff16];
+      const v4i b1 = s_w[S][(tap * 2 + 1) * 64 + boff16];
+      acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b1, acc1, 0, 0, 0);
+    }
+    if (c + 1 < nchunks) deposit(std::integral_constant<int, 1 - S>{});
+    __syncthreads();     // the next chunk's tiles and records are in place; everyone is done with this chunk's
+  };
+  for (int c = 0; c < nchunks; c += 2) {
+    step(c, P0{});
+    if (c + 1 < nchunks) step(c + 1, P1{});
+  }
+  const int col = lane & 31, ch = col & 15, odd = col >> 4;
+  const int co = g * 16 + ch;
+  const double sc = a.scale[co], bT = a.bias[co] * (double)a.T;
+  const float invT = 1.0f / (float)a.T;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const v2u p01 = __builtin_amdgcn_permlane16_swap((unsigned)acc0[r], (unsigned)acc0[r + 8], false, false);
+    const v2u p23 = __builtin_amdgcn_permlane16_swap((unsigned)acc1[r], (unsigned)acc1[r + 8], false, false);
+    const long long hi = (long long)(int)p01[0] * 256 + (int)p01[1], lo = (long long)(int)p23[0] * 256 + (int)p23[1];
+    const double s = fma((double)hi, 65536.0, (double)lo);
+    const float xsum = (float)fma(s, sc, bT);                       // sum over T of the pre-activations, rounded once
+    const int rr = r + 8 * odd;
+    const int orow = (rr & 3) + 8 * (rr >> 2) + 4 * half;           // accumulator row of register rr
+    const long long Ro = tile * 32 + orow;
+    if (Ro < nrows) {
+      const int ob = (int)(Ro / HW), op = (int)(Ro % HW);
+      a.out[((long long)ob * a.Cout + co) * HW + op] = xsum * invT;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ weight packing
 // one block per output channel: channel maximum -> shift s, then every weight -> 4 balanced base-256 digits
 __global__ __launch_bounds__(256) void pack_i8_kernel(const float* __restrict__ w, const float* __restrict__ bias,
@@ -520,6 +644,13 @@ extern "C" int spk_den_conv3x3_counts_mfma(const uint8_t* cnt0, int nch0, const 
   a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.T = T; a.n_dyn = n_dyn_or_null;
   const long long tiles = ((long long)B * H * W + 31) / 32;
   dim3 grid((unsigned)tiles, Cout / 16), blk(256);
+  // full batches (never the sampler's active-set calls, whose row count is known on the device only): shared weight tiles
+  static const bool shared_w = [] { const char* e = getenv("SPKDIFF_CONV6_SHARED"); return !(e && e[0] == '0'); }();
+  if (!n_dyn_or_null && (long long)B * H * W > 32 * 160 && H * W >= 43 && H * W <= 64 && shared_w) {
+    hipLaunchKernelGGL(conv3x3_counts_mfma_shared_kernel, dim3((unsigned)((tiles + 3) / 4), Cout / 16), blk, 0, stream, a);
+    SPK_LAUNCH_CHECK();
+    return SPK_OK;
+  }
   hipLaunchKernelGGL(conv3x3_counts_mfma_kernel, grid, blk, 0, stream, a);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
