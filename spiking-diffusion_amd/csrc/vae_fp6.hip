@@ -63,6 +63,9 @@ __device__ __forceinline__ void tfor(F&& f) {
 }
 
 constexpr float CERT_4EPS = 4.0f * 2.38418579e-07f;
+#ifndef SPK_VT_EXEC_SCAN
+#define SPK_VT_EXEC_SCAN 1      // 0: the collapsed-output scan handles a spike with compare + selects (the compiler's form)
+#endif
 #ifndef SPK_VT_DBG
 #define SPK_VT_DBG 0            // timing experiments only (results are wrong): 1 = no MFMAs, 2 = no LIF scan
 #endif
@@ -267,10 +270,21 @@ __global__ __launch_bounds__(512, 1) void vae_fp6_kernel(TArgs a) {
             zmax = fmaxf(zmax, fabsf(z));
             const float h = fmaf(z - v, 0.5f, v);            // == v + (z - v) * 0.5f: the product is exact
             dmin = fminf(dmin, fabsf(h - 1.0f));
-            const bool s = h >= 1.0f;
-            v = s ? 0.0f : h;
-            if (OUT == OUT_COLLAPSED) m = m + (s ? coef[r] : 0.f);
-            else mybits |= s ? (1u << r) : 0u;
+            if constexpr (OUT == OUT_COLLAPSED && SPK_VT_EXEC_SCAN) {
+              // spike = h >= 1: reset v and add the step's coefficient UNDER THE SPIKE MASK (v_cmpx narrows exec, two plain
+              // instructions, exec restored): three vector instructions instead of compare + two selects + add (convT2 -5 %;
+              // the spike-bit outputs measured slower in this form -- hipcc keeps their sixteen masks in SGPRs -- and keep the C form)
+              v = h;
+              unsigned long long exec_sv;
+              asm volatile("s_mov_b64 %[sv], exec\n\tv_cmpx_le_f32_e32 1.0, %[v]\n\tv_mov_b32_e32 %[v], 0\n\t"
+                           "v_add_f32_e32 %[m], %[c], %[m]\n\ts_mov_b64 exec, %[sv]"
+                           : [v] "+v"(v), [m] "+v"(m), [sv] "=&s"(exec_sv) : [c] "s"(coef[r]) : "vcc");
+            } else {
+              const bool s = h >= 1.0f;
+              v = s ? 0.0f : h;
+              if (OUT == OUT_COLLAPSED) m = m + (s ? coef[r] : 0.f);
+              else mybits |= s ? (1u << r) : 0u;
+            }
           }
         }
         const bool flg = dmin <= fmaf(zmax, 2.5f * CERT_4EPS, cE);             // dh <= cE + 8 eps max |z| (10 eps: a little to spare)
