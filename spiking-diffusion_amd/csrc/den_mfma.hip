@@ -426,8 +426,11 @@ __global__ __launch_bounds__(256) void conv3x3_counts_mfma_kernel(CntArgs a) {
 // epilogue.
 __global__ __launch_bounds__(256) void conv3x3_counts_mfma_shared_kernel(CntArgs a) {
   constexpr int MAXP = 64;                                   // positions per image (the launcher checks H * W <= 64)
-  __shared__ v4i s_w[2][W_CHUNK_BYTES / 16];
-  __shared__ v4i s_a[2][4 * MAXP * 2];                       // the count records of the (up to) four images the 128 rows lie in
+  // (both arrays are padded to whole 256-thread passes so that every staging store is unconditional, and s_a carries one
+  //  all-zero vector, A_ZERO, that the taps outside the image read: conditional LDS accesses become branches with a wait each)
+  constexpr int A_ZERO = 4 * MAXP * 2;
+  __shared__ v4i s_w[2][5 * 256];
+  __shared__ v4i s_a[2][4 * MAXP * 2 + 8];                   // the count records of the (up to) four images the 128 rows lie in
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int HW = a.H * a.W;
   const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
@@ -447,14 +450,21 @@ __global__ __launch_bounds__(256) void conv3x3_counts_mfma_shared_kernel(CntArgs
   constexpr int NV = W_CHUNK_BYTES / 16, NPRE = (NV + 255) / 256;      // 1152 16-byte vectors per chunk, 5 per thread
   const v4i* wg = reinterpret_cast<const v4i*>(a.wq + (long long)g * nchunks * W_CHUNK_BYTES);
   const int na = 4 * HW * 2;                                 // 16-byte vectors of the four images' records per chunk (<= 512)
-  // vector e of the staged records: image b_lo + e / (2 HW), position (e / 2) % HW, half e & 1
-  auto a_src = [&](int c, int e) -> const v4i* {
+  // vector e of the staged records: image b_lo + e / (2 HW), position (e / 2) % HW, half e & 1 (this thread's two vectors:
+  // image and byte offset are worked out once, not per chunk)
+  int a_img[2], a_rem[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int e = threadIdx.x + 256 * j;
+    e = e < na ? e : na - 1;
     int bi = b_lo + e / (2 * HW);
-    bi = bi < Bn ? bi : Bn - 1;
-    const int rem = e % (2 * HW);
-    const uint8_t* base = c < a.nch0 ? a.c0 + ((long long)bi * a.nch0 + c) * HW * CK
-                                     : a.c1 + ((long long)bi * a.nch1 + (c - a.nch0)) * HW * CK;
-    return reinterpret_cast<const v4i*>(base + rem * 16);
+    a_img[j] = bi < Bn ? bi : Bn - 1;
+    a_rem[j] = (e % (2 * HW)) * 16;
+  }
+  auto a_src = [&](int c, int j) -> const v4i* {
+    const uint8_t* base = c < a.nch0 ? a.c0 + ((long long)a_img[j] * a.nch0 + c) * HW * CK
+                                     : a.c1 + ((long long)a_img[j] * a.nch1 + (c - a.nch0)) * HW * CK;
+    return reinterpret_cast<const v4i*>(base + a_rem[j]);
   };
   // Register sets S[k & 1] carry chunk k from memory to LDS buffer k & 1: chunk c + 2 is requested while chunk c is multiplied
   // and chunk c + 1 (requested one iteration earlier) is written to the other buffer -- two chunks in flight per workgroup (a
@@ -468,26 +478,19 @@ __global__ __launch_bounds__(256) void conv3x3_counts_mfma_shared_kernel(CntArgs
       pre[S][j] = wg[(long long)c * NV + (e < NV ? e : NV - 1)];
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int e = threadIdx.x + 256 * j;
-      prea[S][j] = *a_src(c, e < na ? e : na - 1);
-    }
+    for (int j = 0; j < 2; ++j) prea[S][j] = *a_src(c, j);
   };
   auto deposit = [&](auto s_tag) {
     constexpr int S = decltype(s_tag)::value;
 #pragma unroll
-    for (int j = 0; j < NPRE; ++j) {
-      const int e = threadIdx.x + 256 * j;
-      if (e < NV) s_w[S][e] = pre[S][j];
-    }
+    for (int j = 0; j < NPRE; ++j) s_w[S][threadIdx.x + 256 * j] = pre[S][j];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int e = threadIdx.x + 256 * j;
-      if (e < na) s_a[S][e] = prea[S][j];
-    }
+    for (int j = 0; j < 2; ++j) s_a[S][threadIdx.x + 256 * j] = prea[S][j];
   };
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
+  static_assert(NPRE == 5, "s_w padding");
+  if (threadIdx.x < 2) s_a[threadIdx.x][A_ZERO] = (v4i){0, 0, 0, 0};
   request(0, P0{});
   if (nchunks > 1) request(1, P1{});
   deposit(P0{});
@@ -507,8 +510,7 @@ __global__ __launch_bounds__(256) void conv3x3_counts_mfma_shared_kernel(CntArgs
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int d = ((tap / 3 - 1) * a.W + (tap % 3 - 1)) * 2;
-      const v4i ld = s_a[S][okt[tap] ? a_base + d : 0];
-      const v4i av = okt[tap] ? ld : (v4i){0, 0, 0, 0};
+      const v4i av = s_a[S][okt[tap] ? a_base + d : A_ZERO];
       const v4i b0 = s_w[S][(tap * 2 + 0) * 64 + boff16];
       const v4i b1 = s_w[S][(tap * 2 + 1) * 64 + boff16];
       acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b0, acc0, 0, 0, 0);
