@@ -318,13 +318,16 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
     // REC: every thread counts the active inputs of NR input records (cell, step) of the item, chunk by chunk
     constexpr int NREC = Hin * W * 16, NR = (NREC + NWV * 64 - 1) / (NWV * 64);
     int creg[NR];
-    int rec_off[NR];                                      // LDS byte offset of the record inside a slab; -1: none
+    int rec_off[NR];                                      // LDS byte offset of the record inside a slab; threads without one read
+    bool rec_ok[NR];                                      //  cell 0, a border cell (always zero): an unconditional read (a conditional
+                                                          //  one is a branch with an LDS wait of its own, twice per chunk)
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
       creg[k] = 0;
       const int r = tid + k * NWV * 64;
       const int cl = r >> 4, t = r & 15;
-      rec_off[k] = r < NREC ? (((cl / W) + 1) * PW + 1 + (cl % W)) * POSB + t * 16 : -1;
+      rec_ok[k] = r < NREC;
+      rec_off[k] = rec_ok[k] ? (((cl / W) + 1) * PW + 1 + (cl % W)) * POSB + t * 16 : 0;
     }
     for (int c = 0; c < nch; ++c, ++it) {
       const int buf = it & 1;
@@ -341,11 +344,9 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
       if constexpr (REC) {
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
-          if (rec_off[k] >= 0) {
-            const v4i rv = *reinterpret_cast<const v4i*>(sA + buf * A_BYTES + rec_off[k]);
-            creg[k] += __builtin_popcount((unsigned)rv[0]) + __builtin_popcount((unsigned)rv[1]) +
-                       __builtin_popcount((unsigned)rv[2]) + __builtin_popcount((unsigned)rv[3]);
-          }
+          const v4i rv = *reinterpret_cast<const v4i*>(sA + buf * A_BYTES + rec_off[k]);
+          creg[k] += __builtin_popcount((unsigned)rv[0]) + __builtin_popcount((unsigned)rv[1]) +
+                     __builtin_popcount((unsigned)rv[2]) + __builtin_popcount((unsigned)rv[3]);
         }
       }
       auto compute = [&](auto first_tag) {
@@ -463,7 +464,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
       // publish the record counts, then add the nine taps of every output position: s_row[p][t] = active inputs of row (p, t)
 #pragma unroll
       for (int k = 0; k < NR; ++k)
-        if (rec_off[k] >= 0) s_cin[(rec_off[k] / POSB) * 16 + ((rec_off[k] % POSB) >> 4)] = creg[k];
+        if (rec_ok[k]) s_cin[(rec_off[k] / POSB) * 16 + ((rec_off[k] % POSB) >> 4)] = creg[k];
       __syncthreads();
       for (int e = tid; e < HWb * 16; e += NWV * 64) {
         const int pp = e >> 4, t = e & 15;
