@@ -180,52 +180,71 @@ __global__ void den_input_kernel(const float* __restrict__ xf, const long long* 
 // call and scatters x_0_hat only there (:140): for an image without a change at this step the denoiser output is never
 // read and x_t / unmasked stay as they are.  This kernel evaluates the same test (same u: injected or the same Philox
 // counters as spk_psample_step) per image and writes the ascending list of images with at least one change plus its
-// length; the per-step kernels then run on that list only.  One workgroup: the list must be ordered (deterministic slots).
-// 1024 threads: 4 threads per image (positions q, q + 4, ...) over chunks of 256 images, so that the serial Philox depth is
-// HW / 4; lane q == 0 of each quad carries the image's flag into the ordered compaction.
-__global__ __launch_bounds__(1024) void select_active_kernel(const uint8_t* __restrict__ unmasked, int t,
-                                                             const float* __restrict__ u_in, unsigned long long seed,
-                                                             unsigned long long offset,
-                                                             const unsigned long long* __restrict__ philox_state,
-                                                             int* __restrict__ active, int* __restrict__ n_active, int B, int HW) {
-  __shared__ int wave_cnt[16];
-  __shared__ int base_s;
+// length; the per-step kernels then run on that list only.  The list is ordered (deterministic slots).
+// Eight threads per image (positions q, q + 8, ...: a Philox depth of HW / 8; the `unmasked` bytes of a thread are requested
+// together), one-wave workgroups spread over the CUs; every image's flag goes to active[b], and the workgroup that finishes last
+// (ticket) compacts the flags in place into the ordered list: slots are deterministic.  (The first form ran as ONE 1024-thread
+// workgroup with a chain of conditional loads per thread: 10.7 us per reverse step.)  The ticket is a module variable: calls
+// must not overlap on different streams.
+__device__ unsigned g_select_ticket = 0;
+
+__global__ __launch_bounds__(64) void select_active_kernel(const uint8_t* __restrict__ unmasked, int t,
+                                                           const float* __restrict__ u_in, unsigned long long seed,
+                                                           unsigned long long offset,
+                                                           const unsigned long long* __restrict__ philox_state,
+                                                           int* __restrict__ active, int* __restrict__ n_active, int B, int HW) {
   if (philox_state) { seed = philox_state[0]; offset += philox_state[1]; }
   const float inv_t = 1.0f / (float)t;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int q = threadIdx.x & 3;
-  if (threadIdx.x == 0) base_s = 0;
-  __syncthreads();
-  for (int b0 = 0; b0 < B; b0 += 256) {
-    const int b = b0 + (threadIdx.x >> 2);
-    bool any = false;
-    if (b < B) {
-      for (int hw = q; hw < HW && !any; hw += 4) {
-        const long long p = (long long)b * HW + hw;
-        if (unmasked[p]) continue;
+  const int lane = threadIdx.x;
+  const int gid = blockIdx.x * 64 + lane;
+  const int b = gid >> 3, q = gid & 7;
+  bool any = false;
+  if (b < B) {
+    uint8_t um[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int hw = q + 8 * k;
+      const uint8_t ld = unmasked[(long long)b * HW + (hw < HW ? hw : 0)];
+      um[k] = hw < HW ? ld : (uint8_t)1;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (!um[k]) {
+        const long long p = (long long)b * HW + q + 8 * k;
         float u;
         if (u_in) u = u_in[p];
         else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)p, 0u, r); u = u01_open_right(r[0]); }
-        any = u < inv_t;
+        any = any || (u < inv_t);
       }
     }
-    any = __any_sync_quad(any);
-    const bool flag = any && q == 0;
-    const unsigned long long m = __ballot(flag);
-    if (lane == 0) wave_cnt[wave] = __popcll(m);
-    __syncthreads();
-    int pre = base_s;
-    for (int w = 0; w < wave; ++w) pre += wave_cnt[w];
-    if (flag) active[pre + __popcll(m & ((1ull << lane) - 1ull))] = b;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int tot = 0;
-      for (int w = 0; w < 16; ++w) tot += wave_cnt[w];
-      base_s += tot;
+    for (int hw = q + 64; hw < HW; hw += 8) {                   // (latents beyond 64 positions)
+      const long long p = (long long)b * HW + hw;
+      if (unmasked[p]) continue;
+      float u;
+      if (u_in) u = u_in[p];
+      else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)p, 0u, r); u = u01_open_right(r[0]); }
+      any = any || (u < inv_t);
     }
-    __syncthreads();
   }
-  if (threadIdx.x == 0) *n_active = base_s;
+  int f = any ? 1 : 0;
+  f |= __shfl_xor(f, 1); f |= __shfl_xor(f, 2); f |= __shfl_xor(f, 4);
+  if (q == 0 && b < B) active[b] = f;
+  __threadfence();
+  int last = 0;
+  if (lane == 0) last = atomicAdd(&g_select_ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+  last = __shfl(last, 0);
+  if (!last) return;
+  __threadfence();
+  int base = 0;
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    const int bi = b0 + lane;
+    const int fl = bi < B ? __hip_atomic_load(&active[bi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const unsigned long long m = __ballot(fl != 0);
+    // (every lane of the wave has read its flag before any lane writes: list entries land at or below b0 + lane)
+    if (fl) active[base + __popcll(m & ((1ull << lane) - 1ull))] = bi;
+    base += __popcll(m);
+  }
+  if (lane == 0) { *n_active = base; g_select_ticket = 0u; }
 }
 
 // Which POSITIONS of an active image does reverse step t need from each denoiser layer?  The sampler reads the logits only
@@ -331,8 +350,8 @@ extern "C" int spk_select_active(const uint8_t* unmasked, int t, const float* u_
                                  unsigned long long philox_offset, const unsigned long long* philox_state_or_null,
                                  int* active_out, int* n_active_out, int B, int HW, hipStream_t stream) {
   if (!unmasked || !active_out || !n_active_out || t <= 0 || B <= 0 || HW <= 0) return SPK_ERR_ARG;
-  hipLaunchKernelGGL(select_active_kernel, dim3(1), dim3(1024), 0, stream, unmasked, t, u_or_null, philox_seed, philox_offset,
-                     philox_state_or_null, active_out, n_active_out, B, HW);
+  hipLaunchKernelGGL(select_active_kernel, dim3((B * 8 + 63) / 64), dim3(64), 0, stream, unmasked, t, u_or_null, philox_seed,
+                     philox_offset, philox_state_or_null, active_out, n_active_out, B, HW);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }
