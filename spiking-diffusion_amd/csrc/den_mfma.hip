@@ -646,9 +646,12 @@ extern "C" int spk_den_conv3x3_counts_mfma(const uint8_t* cnt0, int nch0, const 
   a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.T = T; a.n_dyn = n_dyn_or_null;
   const long long tiles = ((long long)B * H * W + 31) / 32;
   dim3 grid((unsigned)tiles, Cout / 16), blk(256);
-  // full batches (never the sampler's active-set calls, whose row count is known on the device only): shared weight tiles
+  // batches of more than 160 row tiles: shared weight tiles and count records
   static const bool shared_w = [] { const char* e = getenv("SPKDIFF_CONV6_SHARED"); return !(e && e[0] == '0'); }();
-  if (!n_dyn_or_null && (long long)B * H * W > 32 * 160 && H * W >= 43 && H * W <= 64 && shared_w) {
+  // (also the sampler's active-set calls: its register-staged stream of two chunks beats the K split of the first kernel even at
+  //  a few dozen images -- elimination + position lists 35.4 -> 34.4 ms; SPKDIFF_CONV6_SHARED_DYN=0: the first kernel there)
+  static const bool shared_dyn = [] { const char* e = getenv("SPKDIFF_CONV6_SHARED_DYN"); return !(e && e[0] == '0'); }();
+  if ((!n_dyn_or_null || shared_dyn) && (long long)B * H * W > 32 * 160 && H * W >= 43 && H * W <= 64 && shared_w) {
     hipLaunchKernelGGL(conv3x3_counts_mfma_shared_kernel, dim3((unsigned)((tiles + 3) / 4), Cout / 16), blk, 0, stream, a);
     SPK_LAUNCH_CHECK();
     return SPK_OK;
