@@ -317,7 +317,8 @@ int spk_embedding_fwd(const long long* tokens, const float* codebook, float* out
 /* Images touched by reverse step t.  R/snn_model/vq_diffusion.py:113-124 computes `changes = (u < 1/t) & ~unmasked`
  * BEFORE the denoiser call and only scatters the sample there (:140): for an image without a change at step t the
  * denoiser output is never read.  Writes the ascending list of images with >= 1 change (active_out [B] int32) and its
- * length (n_active_out [1]); u / Philox arguments exactly as spk_psample_step (same draws).  With sample_steps = 100
+ * length (n_active_out [2] int32: [0] the length, [1] a work word that must be ZERO before the first call and is left zero);
+ * u / Philox arguments exactly as spk_psample_step (same draws).  With sample_steps = 100
  * and 49 positions an image is touched by 39 % of the steps on average: the per-step kernels take the list / count as
  * `active` / `n_dyn` arguments and skip the rest -- the same tokens as the dense loop, fewer evaluations. */
 int spk_select_active(const uint8_t* unmasked, int t, const float* u_or_null, unsigned long long philox_seed,

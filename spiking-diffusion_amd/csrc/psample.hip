@@ -184,9 +184,8 @@ __global__ void den_input_kernel(const float* __restrict__ xf, const long long* 
 // Eight threads per image (positions q, q + 8, ...: a Philox depth of HW / 8; the `unmasked` bytes of a thread are requested
 // together), one-wave workgroups spread over the CUs; every image's flag goes to active[b], and the workgroup that finishes last
 // (ticket) compacts the flags in place into the ordered list: slots are deterministic.  (The first form ran as ONE 1024-thread
-// workgroup with a chain of conditional loads per thread: 10.7 us per reverse step.)  The ticket is a module variable: calls
-// must not overlap on different streams.
-__device__ unsigned g_select_ticket = 0;
+// workgroup with a chain of conditional loads per thread: 10.7 us per reverse step.)  The ticket is n_active[1]: zero before the
+// first call, left zero by every call (the caller's buffer, so calls on different streams with different buffers do not meet).
 
 __global__ __launch_bounds__(64) void select_active_kernel(const uint8_t* __restrict__ unmasked, int t,
                                                            const float* __restrict__ u_in, unsigned long long seed,
@@ -231,7 +230,7 @@ __global__ __launch_bounds__(64) void select_active_kernel(const uint8_t* __rest
   if (q == 0 && b < B) active[b] = f;
   __threadfence();
   int last = 0;
-  if (lane == 0) last = atomicAdd(&g_select_ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+  if (lane == 0) last = atomicAdd(reinterpret_cast<unsigned*>(n_active + 1), 1u) == gridDim.x - 1 ? 1 : 0;
   last = __shfl(last, 0);
   if (!last) return;
   __threadfence();
@@ -244,7 +243,7 @@ __global__ __launch_bounds__(64) void select_active_kernel(const uint8_t* __rest
     if (fl) active[base + __popcll(m & ((1ull << lane) - 1ull))] = bi;
     base += __popcll(m);
   }
-  if (lane == 0) { *n_active = base; g_select_ticket = 0u; }
+  if (lane == 0) { n_active[0] = base; n_active[1] = 0; }
 }
 
 // Which POSITIONS of an active image does reverse step t need from each denoiser layer?  The sampler reads the logits only

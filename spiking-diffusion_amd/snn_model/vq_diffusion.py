@@ -227,7 +227,7 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
         x_t = torch.empty((b, 1, h, w), dtype=torch.int64, device=dev)
         unmasked = torch.empty((b, 1, h, w), dtype=torch.bool, device=dev)
 
-        act = (torch.zeros(b, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)) if skip else None
+        act = (torch.zeros(b, dtype=torch.int32, device=dev), torch.zeros(2, dtype=torch.int32, device=dev)) if skip else None
         need = ops.NeedLists(b, int(self.list_radii), dev) if lists else None
 
         def body():

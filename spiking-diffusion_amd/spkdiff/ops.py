@@ -17,7 +17,7 @@ MAX_T = 16
 
 # ---------------------------------------------------------------------------------------------- active-set batch
 # Set by the sampler around one denoiser call (``with ops.active_set(active, n_active)``): the per-step kernels then
-# process only the images listed by spk_select_active -- ``active`` int32 [B] (slot -> image), ``n_active`` int32 [1],
+# process only the images listed by spk_select_active -- ``active`` int32 [B] (slot -> image), ``n_active`` int32 [2] (count, work word),
 # both on the device, so that a captured hipGraph replays with fresh lists.  None = every image (dense).
 # ``need`` (optional, spk_select_needed): the positions of each active image the step will read, per layer depth; the
 # layers that take position lists then compute only those.
@@ -1202,7 +1202,7 @@ def select_needed(unmasked, t, active, need, u=None, seed=0, offset=0, philox_st
 
 def select_active(unmasked, t, u=None, seed=0, offset=0, philox_state=None, out=None):
     """Images that reverse step t touches (at least one position with u < 1/t still masked): returns (active int32 [B]
-    ascending image list, n_active int32 [1]) on the device; same u / Philox arguments as psample_step."""
+    ascending image list, n_active int32 [2]: count and a work word) on the device; same u / Philox arguments as psample_step."""
     if unmasked.dtype not in (torch.bool, torch.uint8) or not unmasked.is_cuda or not unmasked.is_contiguous():
         raise ValueError("unmasked must be a contiguous bool/uint8 device tensor")
     B = unmasked.shape[0]
@@ -1211,7 +1211,9 @@ def select_active(unmasked, t, u=None, seed=0, offset=0, philox_state=None, out=
         u = _dev(u, "u", torch.float32)
     if out is None:
         out = (torch.empty(B, dtype=torch.int32, device=unmasked.device),
-               torch.empty(1, dtype=torch.int32, device=unmasked.device))
+               torch.zeros(2, dtype=torch.int32, device=unmasked.device))     # [count, work word (zero between calls)]
+    elif out[1].numel() < 2:
+        raise ValueError("n_active needs two int32 words: [count, work word (zero before the first call)]")
     check(lib.spk_select_active(_p(unmasked), int(t), _p(u), int(seed), int(offset), _p(philox_state), _p(out[0]),
                                 _p(out[1]), B, HW, _stream(unmasked)), "spk_select_active")
     return out

@@ -14,7 +14,7 @@ act = ops.select_active(um, t, ud)
 need = ops.NeedLists(B, 4, dev)
 ops.select_needed(um, t, act, need, ud)
 torch.cuda.synchronize()
-n_act = int(act[1].item()); active = act[0][:n_act].cpu().tolist()
+n_act = int(act[1][0].item()); active = act[0][:n_act].cpu().tolist()
 want = _cpu_need_lists(unmasked.numpy(), u.numpy(), t, active, 4)
 for r in range(1, 5):
     rec = need.records(r).cpu().numpy()
