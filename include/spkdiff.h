@@ -345,12 +345,14 @@ int spk_den_build_input(const float* x_float_or_null, const long long* x_tokens_
  * (then Philox4x32-10(seed, offset + index)); philox_state optional device {seed, base offset} pair that overrides
  * the seed and is added to the offset (lets a captured hipGraph draw fresh noise on every replay);
  * x0_hat_out optional int64 [B*HW].  active / n_active (both or neither; not with x0_hat_out): logits hold one slot
- * per active image (slot s = image active[s]); noise, x_t and unmasked stay indexed by image. */
+ * per active image (slot s = image active[s]); noise, x_t and unmasked stay indexed by image.
+ * next_input_b2hw_or_null (not with active): also writes cat(x_t, t - 1) fp32 [B,2,h,w] -- what spk_den_build_input would
+ * produce for the NEXT reverse step (:195-197 with the updated tokens): one launch less per step. */
 int spk_psample_step(const float* logits_bkhw, long long* x_t_inout, uint8_t* unmasked_inout, int t, float temp,
                      const float* u_or_null, const float* q_or_null, unsigned long long philox_seed,
                      unsigned long long philox_offset, const unsigned long long* philox_state_or_null,
                      long long* x0_hat_out_or_null, int B, int HW, int K, const int* active_or_null,
-                     const int* n_active_or_null, spk_stream_t stream);
+                     const int* n_active_or_null, float* next_input_b2hw_or_null, spk_stream_t stream);
 
 /* ---- spike counts (syops report) -------------------------------------------------------------------------------- */
 /* Spikes in a tensor the library emitted, all time steps and time step 0 alone -- the firing rates R/syops/ops.py:14-24

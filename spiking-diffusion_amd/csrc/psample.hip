@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void psample_kernel(const float* __restrict__ 
                                                       const unsigned long long* __restrict__ philox_state,
                                                       long long* __restrict__ x0_hat_out,
                                                       const int* __restrict__ active, const int* __restrict__ n_active,
-                                                      int B, int HW, int K) {
+                                                      int B, int HW, int K, float* __restrict__ next_input, float t_next) {
   // a captured (hipGraph) launch bakes its arguments: the per-call part of the Philox counter then comes from a
   // 2-word device buffer {seed, base offset} the host updates before each replay
   if (philox_state) { seed = philox_state[0]; offset += philox_state[1]; }
@@ -91,7 +91,14 @@ __global__ __launch_bounds__(256) void psample_kernel(const float* __restrict__ 
       float u;
       if (u_in) u = u_in[p];
       else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)p, 0u, r); u = u01_open_right(r[0]); }
-      if (!((u < inv_t) && !unmasked[p])) continue;
+      if (!((u < inv_t) && !unmasked[p])) {
+        // (dense form) the denoiser input of the next reverse step, cat(x_t, t - 1): this position keeps its token
+        if (next_input && lane == 0) {
+          next_input[((long long)b * 2 + 0) * HW + hw] = (float)x_t[p];
+          next_input[((long long)b * 2 + 1) * HW + hw] = t_next;
+        }
+        continue;
+      }
     }
     float l[KPL];
     float mx = -INFINITY;
@@ -155,6 +162,10 @@ __global__ __launch_bounds__(256) void psample_kernel(const float* __restrict__ 
       bool ch = (u < inv_t) && !unmasked[p];
       if (ch) { unmasked[p] = 1; x_t[p] = (long long)besti; }
       if (x0_hat_out) x0_hat_out[p] = (long long)besti;
+      if (next_input && lane == 0) {
+        next_input[((long long)b * 2 + 0) * HW + hw] = ch ? (float)besti : (float)x_t[p];
+        next_input[((long long)b * 2 + 1) * HW + hw] = t_next;
+      }
     }
   }
 }
@@ -371,9 +382,11 @@ extern "C" int spk_psample_step(const float* logits_bkhw, long long* x_t_inout, 
                                 float temp, const float* u_or_null, const float* q_or_null,
                                 unsigned long long philox_seed, unsigned long long philox_offset,
                                 const unsigned long long* philox_state_or_null, long long* x0_hat_out_or_null, int B,
-                                int HW, int K, const int* active_or_null, const int* n_active_or_null, hipStream_t stream) {
+                                int HW, int K, const int* active_or_null, const int* n_active_or_null,
+                                float* next_input_b2hw_or_null, hipStream_t stream) {
   if (!logits_bkhw || !x_t_inout || !unmasked_inout || t <= 0 || !(temp > 0.f) || B <= 0 || HW <= 0 || K <= 0)
     return SPK_ERR_ARG;
+  if (next_input_b2hw_or_null && active_or_null) return SPK_ERR_ARG;      // (the active-set form gathers its input by slot)
   if ((active_or_null == nullptr) != (n_active_or_null == nullptr) || (active_or_null && x0_hat_out_or_null))
     return SPK_ERR_ARG;
   if (K > 64 * 32) return SPK_ERR_UNSUPPORTED;
@@ -383,7 +396,7 @@ extern "C" int spk_psample_step(const float* logits_bkhw, long long* x_t_inout, 
 #define SPK_PSAMPLE_LAUNCH(KPL)                                                                                          \
   hipLaunchKernelGGL(psample_kernel<KPL>, dim3(grid), dim3(256), 0, stream, logits_bkhw, x_t_inout, unmasked_inout, t,   \
                      temp, u_or_null, q_or_null, philox_seed, philox_offset, philox_state_or_null, x0_hat_out_or_null,   \
-                     active_or_null, n_active_or_null, B, HW, K)
+                     active_or_null, n_active_or_null, B, HW, K, next_input_b2hw_or_null, (float)(t - 1))
   if (K <= 256) SPK_PSAMPLE_LAUNCH(4);
   else if (K <= 512) SPK_PSAMPLE_LAUNCH(8);
   else if (K <= 1024) SPK_PSAMPLE_LAUNCH(16);

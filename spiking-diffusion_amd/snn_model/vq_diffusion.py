@@ -230,6 +230,9 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
         act = (torch.zeros(b, dtype=torch.int32, device=dev), torch.zeros(2, dtype=torch.int32, device=dev)) if skip else None
         need = ops.NeedLists(b, int(self.list_radii), dev) if lists else None
 
+        # dense form: every spk_psample_step also writes the next step's denoiser input (one launch less per step)
+        inp = None if skip else torch.empty((b, 2, h, w), dtype=torch.float32, device=dev)
+
         def body():
             x_t.fill_(int(self.mask_id))
             unmasked.zero_()
@@ -239,9 +242,12 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
                     ops.select_active(unmasked, t, None, 0, off, philox_state=state, out=act)
                     if lists:
                         ops.select_needed(unmasked, t, act, need, None, 0, off, philox_state=state)
+                elif t == sample_steps:
+                    ops.den_build_input(x_t, t, out=inp)
                 with ops.active_set(*(act if skip else (None, None)), need=need):
-                    logits = dn.logits_from_tokens(x_t, t)
-                    ops.psample_step(logits, x_t, unmasked, t, temp, None, None, 0, off, philox_state=state)
+                    logits = dn.logits_from_tokens(x_t, t, inp=inp)
+                    ops.psample_step(logits, x_t, unmasked, t, temp, None, None, 0, off, philox_state=state,
+                                     next_input=inp if t > 1 else None)
 
         # warm-up on a side stream (weight packing, BN terms, allocator pools), then capture
         side = torch.cuda.Stream(device=dev)
@@ -252,7 +258,9 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             body()
-        entry = (graph, state, x_t, need)                      # (need: kept alive with the graph that reads it)
+        # every buffer the captured launches address by raw pointer lives as long as the graph: a tensor freed here would
+        # hand its block to the next allocation (another sampler's state, say) while replays keep writing to it
+        entry = (graph, state, x_t, (need, inp, unmasked, act))
         self._graphs[key] = entry
     graph, state, x_t = entry[:3]
     state.copy_(torch.tensor([seed, base], dtype=torch.int64), non_blocking=False)
@@ -426,11 +434,12 @@ class DummyModel(nn.Module):
         return torch.sum(x6, dim=0) / T
 
     @torch.no_grad()
-    def logits_from_tokens(self, x_t, t: int, record=None):
+    def logits_from_tokens(self, x_t, t: int, record=None, inp=None):
         """Sampler fast path: ``self(x_t.float(), full((b,), t))`` followed by ``functional.reset_net(self)``
         (R/snn_model/vq_diffusion.py:128-129) -- every LIF starts from and returns to the reset state, so no
         membrane tensors are read or written."""
         if not self._fused_ok() or self.training:
             raise RuntimeError('spkdiff: DummyModel needs functional.set_step_mode(net, "m") and .eval()')
         functional.reset_net(self)
-        return self._run(ops.den_build_input(x_t, int(t)), stateful=False, record=record)
+        # inp: the input map [B,2,h,w] already on the device (the previous spk_psample_step wrote it): no build launch
+        return self._run(inp if inp is not None else ops.den_build_input(x_t, int(t)), stateful=False, record=record)

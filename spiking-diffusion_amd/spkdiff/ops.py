@@ -1141,8 +1141,10 @@ def den_build_input(x, t, out=None):
     return out
 
 
-def psample_step(logits, x_t, unmasked, t, temp=1.0, u=None, q=None, seed=0, offset=0, x0_hat=None, philox_state=None):
-    """In-place update of x_t (int64) and unmasked (bool/u8) from logits [B,K,h,w]."""
+def psample_step(logits, x_t, unmasked, t, temp=1.0, u=None, q=None, seed=0, offset=0, x0_hat=None, philox_state=None,
+                 next_input=None):
+    """In-place update of x_t (int64) and unmasked (bool/u8) from logits [B,K,h,w].  next_input (dense form only): fp32
+    [B,2,h,w] that receives the denoiser input of the next reverse step, cat(x_t, t - 1)."""
     logits = _dev(logits, "logits", torch.float32)
     B, K = logits.shape[0], logits.shape[1]
     HW = logits[0, 0].numel()
@@ -1161,9 +1163,13 @@ def psample_step(logits, x_t, unmasked, t, temp=1.0, u=None, q=None, seed=0, off
     if philox_state is not None and (philox_state.dtype != torch.int64 or philox_state.numel() != 2):
         raise ValueError("philox_state must be an int64 device tensor {seed, base offset}")
     act, nact = (None, None) if ACTIVE is None else ACTIVE
+    if next_input is not None:
+        next_input = _dev(next_input, "next_input", torch.float32)
+        if next_input.numel() != B * 2 * HW or not next_input.is_contiguous():
+            raise ValueError("next_input must be a contiguous fp32 [B,2,h,w] tensor")
     check(lib.spk_psample_step(_p(logits), _p(x_t), _p(unmasked), int(t), float(temp), _p(u), _p(q), int(seed),
-                               int(offset), _p(philox_state), _p(x0_hat), B, HW, K, _p(act), _p(nact), _stream(logits)),
-          "spk_psample_step")
+                               int(offset), _p(philox_state), _p(x0_hat), B, HW, K, _p(act), _p(nact), _p(next_input),
+                               _stream(logits)), "spk_psample_step")
     return x_t, unmasked
 
 

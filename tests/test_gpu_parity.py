@@ -1862,3 +1862,34 @@ def test_constant_input_lif_lookup_equals_the_scan_on_every_float_around_1_2():
     ref2 = ops.lif_fwd(xs.reshape(1, -1).repeat(16, 1), v_ref, spike_dtype=ops.SPIKE_U8).t()
     assert torch.equal(r2["ptc"][:, 0, :, :, :, 3].reshape(-1, 16), ref2)
     assert torch.equal(v_k[:, 3].reshape(-1), v_ref)
+
+
+@pytest.mark.gpu
+def test_two_live_sampler_graphs_on_one_model_replay_independently(dev):
+    """Two samplers (dense and elimination forms) on ONE denoiser, both replaying captured hipGraphs, interleaved over several
+    seeds: every replay must equal the eager loop.  (Regression: buffers a captured graph addresses by raw pointer -- the
+    `unmasked` mask, the active list -- were released after the capture; their blocks went to the next sampler's allocations
+    and the first graph's replays then wrote into the second one's state.)"""
+    from snn_model.vq_diffusion import AbsorbingDiffusion, DummyModel, functional
+    cfg = synth.MNIST
+    den = DummyModel(1, cfg.num_embeddings).to(dev)
+    functional.set_step_mode(net=den, step_mode='m')
+    den.load_state_dict(synth.synth_denoiser_state(cfg))
+    den.eval()
+
+    def mk(skip, graph):
+        ab = AbsorbingDiffusion(den, mask_id=cfg.num_embeddings)
+        ab.n_samples = 24
+        ab.skip_untouched, ab.use_graph = skip, graph
+        return ab
+    samplers = {"dense_graph": mk(False, True), "elim_graph": mk(True, True), "lists_off_graph": mk(True, True), "eager": mk(False, False)}
+    samplers["lists_off_graph"].list_positions = False
+    bad = 0
+    for seed in range(4):
+        out = {}
+        for name, ab in samplers.items():
+            torch.manual_seed(4321 + seed)
+            out[name] = ab.sample(temp=1.0, sample_steps=40).cpu()
+        bad += sum(int((v != out["eager"]).sum()) for v in out.values())
+    parity("two_live_graphs_one_model", replays=12, token_mismatches=bad)
+    assert bad == 0
