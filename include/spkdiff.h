@@ -354,6 +354,19 @@ int spk_psample_step(const float* logits_bkhw, long long* x_t_inout, uint8_t* un
                      long long* x0_hat_out_or_null, int B, int HW, int K, const int* active_or_null,
                      const int* n_active_or_null, float* next_input_b2hw_or_null, spk_stream_t stream);
 
+/* The noise of one reverse step as spk_psample_step / spk_select_active / spk_select_needed draw it in Philox mode, written
+ * out (parity aid: R/snn_model/vq_diffusion.py:116 `rand_like` -> u, :138 `Categorical.sample()` -> q ~ Exp(1)): u_out [B*HW] =
+ * the uniforms of the `changes` test, q_out [B*HW*K] = the exponentials of the categorical race; same (seed, offset,
+ * philox_state) arguments as the step they belong to.  The oracle run on these must reproduce the Philox-mode tokens. */
+int spk_philox_noise(unsigned long long philox_seed, unsigned long long philox_offset,
+                     const unsigned long long* philox_state_or_null, float* u_out_or_null, float* q_out_or_null, int B, int HW,
+                     int K, spk_stream_t stream);
+
+/* Content checksum of n device tensors in one launch (host-side cache validation; no reference counterpart: the reference
+ * re-reads its weights on every call, this library keeps derived forms of them).  table_dev: device array of n pairs
+ * {address, number of 32-bit words}; out1: one device word.  Order-independent 64-bit sum. */
+int spk_checksum_multi(const unsigned long long* table_dev, int n, unsigned long long* out1, spk_stream_t stream);
+
 /* ---- spike counts (syops report) -------------------------------------------------------------------------------- */
 /* Spikes in a tensor the library emitted, all time steps and time step 0 alone -- the firing rates R/syops/ops.py:14-24
  * (`spike_rate`) and :69-75 (the LIF hook reads output[0]) feed into the ACs / MACs report.  The tensor is read as

@@ -31,7 +31,41 @@ __global__ __launch_bounds__(256) void count_spikes_kernel(const unsigned* __res
   }
   if (threadIdx.x < 3 && s[threadIdx.x][0]) atomicAdd(out + threadIdx.x, s[threadIdx.x][0]);
 }
+
+// Content checksum of a set of tensors (parameters + buffers of a module) in ONE launch: the host layer compares it with the
+// value its derived weight forms (digit planes, folded BN terms, captured graphs) were built from -- writes through `.data`
+// and graph-replayed optimizer steps change the bytes without changing any (pointer, version) pair.
+// Tensor j contributes sum_w (word_w + 1) * mix(j, w) (64-bit wrap-around: order independent, so atomics may land in any order).
+__global__ __launch_bounds__(256) void checksum_multi_kernel(const unsigned long long* __restrict__ table, int n,
+                                                             unsigned long long* __restrict__ out) {
+  unsigned long long acc = 0;
+  for (int j = blockIdx.y; j < n; j += gridDim.y) {
+    const unsigned* d = reinterpret_cast<const unsigned*>(table[2 * j]);
+    const long long n_words = (long long)table[2 * j + 1];
+    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (long long)gridDim.x * blockDim.x) {
+      const unsigned long long m = ((unsigned long long)w + 0x9E3779B97F4A7C15ull * (unsigned long long)(j + 1)) * 0xD1342543DE82EF95ull;
+      acc += ((unsigned long long)d[w] + 1ull) * (m | 1ull);
+    }
+  }
+  __shared__ unsigned long long s[256];
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) s[threadIdx.x] += s[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && s[0]) atomicAdd(out, s[0]);
+}
 }  // namespace
+
+extern "C" int spk_checksum_multi(const unsigned long long* table_dev, int n, unsigned long long* out1, hipStream_t stream) {
+  if (!table_dev || !out1 || n <= 0) return SPK_ERR_ARG;
+  hipError_t e = hipMemsetAsync(out1, 0, sizeof(unsigned long long), stream);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(checksum_multi_kernel, dim3(16, n < 64 ? n : 64), dim3(256), 0, stream, table_dev, n, out1);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
 
 extern "C" int spk_count_spikes(const void* data, long long n_words, long long inner_words, int T, int kind,
                                 unsigned long long* out3, hipStream_t stream) {

@@ -337,7 +337,38 @@ __global__ __launch_bounds__(256) void select_needed_kernel(const uint8_t* __res
   if (threadIdx.x == 0) *ticket = 0u;
 }
 
+// The noise of one reverse step exactly as psample_kernel / select_active_kernel / select_needed_kernel draw it, written
+// out: u[p] (stream 0, counter offset + p) and q[p*K + k] (stream 1, counter offset + p*K + k).  A debug / parity entry:
+// the oracle is run on the dumped noise and must give the tokens of the Philox-mode sampler (the timed configuration).
+__global__ __launch_bounds__(256) void philox_noise_kernel(unsigned long long seed, unsigned long long offset,
+                                                           const unsigned long long* __restrict__ philox_state,
+                                                           float* __restrict__ u_out, float* __restrict__ q_out,
+                                                           long long npos, int K) {
+  if (philox_state) { seed = philox_state[0]; offset += philox_state[1]; }
+  const long long nq = q_out ? npos * K : 0;
+  const long long total = nq > npos ? nq : npos;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    uint32_t r[4];
+    if (u_out && i < npos) { philox4x32(seed, offset + (unsigned long long)i, 0u, r); u_out[i] = u01_open_right(r[0]); }
+    if (i < nq) { philox4x32(seed, offset + (unsigned long long)i, 1u, r); q_out[i] = -logf(u01_open_left(r[0])); }
+  }
+}
+
 }  // namespace
+
+extern "C" int spk_philox_noise(unsigned long long philox_seed, unsigned long long philox_offset,
+                                const unsigned long long* philox_state_or_null, float* u_out_or_null, float* q_out_or_null,
+                                int B, int HW, int K, hipStream_t stream) {
+  if ((!u_out_or_null && !q_out_or_null) || B <= 0 || HW <= 0 || K <= 0) return SPK_ERR_ARG;
+  const long long npos = (long long)B * HW;
+  const long long total = q_out_or_null ? npos * K : npos;
+  long long grid = (total + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(philox_noise_kernel, dim3((int)grid), dim3(256), 0, stream, philox_seed, philox_offset,
+                     philox_state_or_null, u_out_or_null, q_out_or_null, npos, K);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
 
 extern "C" long long spk_select_needed_bytes(int B, int R) {
   if (B <= 0 || R <= 0 || R > 8) return -1;

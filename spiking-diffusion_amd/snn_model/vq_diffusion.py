@@ -18,7 +18,7 @@ from spikingjelly.activation_based import neuron, functional, layer, surrogate, 
 from spikingjelly import visualizing  # noqa: F401
 
 from spkdiff import ops
-from spkdiff.fused import FusedSequential, invalidate_derived, has_hooks
+from spkdiff.fused import FusedSequential, invalidate_derived, has_hooks, derived_epoch, derived_refs
 from spkdiff.ops import IN_PTC, IN_TINV
 
 from .vae_model import *  # noqa: F401,F403  (R/snn_model/vq_diffusion.py:21)
@@ -93,6 +93,12 @@ class AbsorbingDiffusion(Sampler):
         self.list_positions = True
         self.list_radii = 3                 # layers below the logits that take lists (1: conv5 only ... 4: conv2..conv5;
                                             # conv2 needs nearly every position anyway: 3 measured fastest)
+        # Derived weight forms (digit planes, folded BN terms, captured graphs) are keyed on (data_ptr, _version), which
+        # writes through ``.data`` and graph-replayed optimizer steps do not change.  True = every sample() call compares
+        # a content checksum of the denoiser's parameters and buffers (one launch + one 8-byte read-back, ~30 us) with the
+        # one the derived forms were built from and rebuilds them when it differs.
+        self.verify_weights = True
+        self._wsum = None
 
     # ---- training step (R/snn_model/vq_diffusion.py:56-101,144-147) -------------------------
     def sample_time(self, b, device):
@@ -154,19 +160,28 @@ class AbsorbingDiffusion(Sampler):
         seed, base = 0, 0
         if noise is None and self.noise_source == 'philox':
             seed = self._philox_key()
+        self._check_weights(dn)
         if self.use_graph and noise is None and record is None and self.noise_source == 'philox':
+            self._capturing = False
             try:
                 return self._sample_graphed(dev, b, h, w, K, float(temp), int(sample_steps), seed, base)
             except (NotImplementedError, ValueError, TypeError):
                 raise                          # an argument / support error of a kernel, not a capture problem
-            except RuntimeError as e:          # capture refused (e.g. another thread touched the device): same kernels,
-                if 'capture' not in str(e).lower() and 'graph' not in str(e).lower():
+            except RuntimeError as e:
+                # Only a failure raised while the capture block was open is a capture problem (the runtime refused an
+                # operation on a capturing stream, another thread touched the device, ...): same kernels, launched one by
+                # one.  The kernels' own return codes surface as ValueError / NotImplementedError / SpkdiffError with the
+                # entry point's name and propagate.
+                from spkdiff._lib import SpkdiffError
+                if not self._capturing or isinstance(e, SpkdiffError):
                     raise
-                import warnings                # issued one by one
+                import warnings
                 warnings.warn(f'spkdiff: hipGraph capture of the sampler failed ({e}); launching eagerly')
                 self.use_graph = False
                 self._graphs.clear()
                 torch.cuda.synchronize(dev)
+            finally:
+                self._capturing = False
         x_t = torch.full((b, 1, h, w), int(self.mask_id), dtype=torch.int64, device=dev)
         unmasked = torch.zeros((b, 1, h, w), dtype=torch.bool, device=dev)
         skip = self._skip_ok(h, w) and record is None
@@ -207,9 +222,24 @@ class AbsorbingDiffusion(Sampler):
         self._graphs.clear()
         invalidate_derived(self._denoise_fn)
 
+    def _check_weights(self, dn):
+        """Content checksum of the denoiser's floating-point tensors against the one seen by the previous call: a change
+        that left every (data_ptr, _version) pair alone -- ``p.data.copy_(...)``, an optimizer step replayed from a graph
+        -- drops the derived forms and the captured graphs here."""
+        if not self.verify_weights:
+            return
+        ts = [t for t in list(dn.parameters()) + list(dn.buffers()) if t.is_floating_point() and t.is_cuda]
+        ws = self._wsum
+        if ws is None or ws[0].key != tuple((t.data_ptr(), t.numel() * t.element_size()) for t in ts):
+            ws = self._wsum = [ops.TensorChecksum(ts), None]
+        v = ws[0].value()
+        if ws[1] is not None and ws[1] != v:
+            self.invalidate()
+        ws[1] = v
+
 
 def _weights_key(module):
-    return tuple((p.data_ptr(), p._version) for p in list(module.parameters()) + list(module.buffers()))
+    return tuple((p.data_ptr(), p._version) for p in list(module.parameters()) + list(module.buffers())) + derived_epoch(module)
 
 
 def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
@@ -249,18 +279,23 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
                     ops.psample_step(logits, x_t, unmasked, t, temp, None, None, 0, off, philox_state=state,
                                      next_input=inp if t > 1 else None)
 
-        # warm-up on a side stream (weight packing, BN terms, allocator pools), then capture
+        # warm-up on a side stream (weight packing, BN terms, allocator pools, this graph's own flag workspaces), then capture
+        flag_ws = {}
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), ops.flag_scope(flag_ws):
             dn.logits_from_tokens(torch.full((b, 1, h, w), int(self.mask_id), dtype=torch.int64, device=dev), 1)
         torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        self._capturing = True
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"), ops.flag_scope(flag_ws):
             body()
+        self._capturing = False
         # every buffer the captured launches address by raw pointer lives as long as the graph: a tensor freed here would
-        # hand its block to the next allocation (another sampler's state, say) while replays keep writing to it
-        entry = (graph, state, x_t, (need, inp, unmasked, act))
+        # hand its block to the next allocation (another sampler's state, say) while replays keep writing to it.  That
+        # includes the denoiser's derived tensors (packed weights, BN terms: an invalidation re-keys the graph, and until the
+        # stale entry is evicted its memory must not be recycled) and the flag workspaces of the certified kernels.
+        entry = (graph, state, x_t, (need, inp, unmasked, act, flag_ws, derived_refs(dn)))
         self._graphs[key] = entry
     graph, state, x_t = entry[:3]
     state.copy_(torch.tensor([seed, base], dtype=torch.int64), non_blocking=False)

@@ -108,7 +108,12 @@ def invalidate_derived(module):
     """Drop every cached derived form of the parameters below ``module``: packed convolution weights (fp32 / int8 /
     fp6 digit planes), folded BatchNorm terms, captured sampler graphs.  The caches are keyed by ``(data_ptr,
     _version)``, which in-place writes through ``.data`` (``p.data.copy_(ema)``) do NOT change -- call this after such a
-    write.  ``load_state_dict`` and train()/eval() transitions call it on their own."""
+    write.  ``load_state_dict`` and train()/eval() transitions call it on their own, and the sampler compares a content
+    checksum of the denoiser's tensors on every ``sample()`` call (``AbsorbingDiffusion.verify_weights``).
+
+    Every module below ``module`` also gets its ``_derived_epoch`` bumped: a captured graph bakes the ADDRESSES of the
+    derived tensors, so whoever captured one keys it on ``derived_epoch(root)`` and re-captures after an invalidation
+    (the graph entry itself keeps the tensors it addresses alive: ``derived_refs``)."""
     for m in module.modules():
         pr = getattr(m, '_spk_params', None)
         if pr is not None:
@@ -118,6 +123,25 @@ def invalidate_derived(module):
         g = getattr(m, '_graphs', None)
         if isinstance(g, dict):
             g.clear()
+        object.__setattr__(m, '_derived_epoch', getattr(m, '_derived_epoch', 0) + 1)
+
+
+def derived_epoch(module):
+    """Changes whenever derived forms anywhere below ``module`` were dropped (part of every captured graph's key)."""
+    return tuple(getattr(m, '_derived_epoch', 0) for m in module.modules())
+
+
+def derived_refs(module):
+    """References to every derived tensor currently cached below ``module`` (packed weights, BN terms): a captured graph
+    stores this list so that the memory its launches address by raw pointer outlives any later invalidation."""
+    refs = []
+    for m in module.modules():
+        pr = getattr(m, '_spk_params', None)
+        if pr is not None:
+            refs.append(tuple(v for v in vars(pr).values() if v is not None))
+        if isinstance(m, layer.BatchNorm2d) and m._affine_cache is not None:
+            refs.append(m._affine_cache)
+    return refs
 
 
 class FusedSequential(nn.Sequential):

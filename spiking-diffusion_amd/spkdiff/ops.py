@@ -824,18 +824,54 @@ def den_pack_weight_fp6v2(w, bias):
     return wq, scale, bias_d, wl1, qtab
 
 
-_FLAG_WORDS = {}         # (device, words) -> zero-initialised workspace; every call leaves it clean (the fixup launch resets it)
+# Flagged-neuron workspaces of the certified kernels (fp6v2 / vae_fp6: live counter, id list, overflow bitmap, hand-over
+# ticket; zero-initialised, every call leaves them clean).  A workspace must never be shared by launches that can run
+# concurrently: outside a ``flag_scope`` it is keyed by (kind, device, STREAM, words); inside one it belongs to the scope's
+# owner -- a captured graph keeps its scope dict in its cache entry, so the buffers its launches address live as long as the
+# graph and no eager call ever touches them.  Nothing here is ever dropped while a graph may address it.
+_FLAG_DEFAULT = {}
+_FLAG_SCOPE = None
+
+
+class flag_scope:
+    """``with ops.flag_scope(store):`` -- certified kernels launched inside take their flag workspaces from ``store`` (a dict
+    owned by the caller: one per captured graph / call site)."""
+
+    def __init__(self, store):
+        self.store = store
+
+    def __enter__(self):
+        global _FLAG_SCOPE
+        self.prev, _FLAG_SCOPE = _FLAG_SCOPE, self.store
+        return self.store
+
+    def __exit__(self, *exc):
+        global _FLAG_SCOPE
+        _FLAG_SCOPE = self.prev
+        return False
+
+
+def _flag_ws(kind, device, words):
+    store = _FLAG_SCOPE
+    if store is None:
+        key = (kind, str(device), int(torch.cuda.current_stream(device).cuda_stream), int(words))
+        buf = _FLAG_DEFAULT.get(key)
+        if buf is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("spkdiff: first use of a certified-kernel shape during hipGraph capture outside an "
+                                   "ops.flag_scope (its workspace would live in the graph's pool and be shared with eager calls)")
+            buf = _FLAG_DEFAULT[key] = torch.zeros(int(words), dtype=torch.int32, device=device)
+        return buf
+    key = (kind, str(device), int(words))
+    buf = store.get(key)
+    if buf is None:
+        # (inside a capture the memset is captured with it: replays re-zero a buffer the kernels already left clean)
+        buf = store[key] = torch.zeros(int(words), dtype=torch.int32, device=device)
+    return buf
 
 
 def _flag_bitmap(device, words):
-    key = (str(device), int(words))
-    buf = _FLAG_WORDS.get(key)
-    if buf is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("spkdiff: first use of an fp6v2 shape during hipGraph capture (run it once eagerly first)")
-        buf = torch.zeros(int(words), dtype=torch.int32, device=device)
-        _FLAG_WORDS[key] = buf
-    return buf
+    return _flag_ws("den", device, words)
 
 
 def den_conv3x3_mfma_fp6v2(in0, packed, Cout, *, bn_a, bn_b, want_counts=False, need_radius=None):
@@ -854,11 +890,14 @@ def den_conv3x3_mfma_fp6v2(in0, packed, Cout, *, bn_a, bn_b, want_counts=False, 
     flags = _flag_bitmap(in0.device, lib.spk_den_fp6v2_flag_words(B, Cout, H, W))
     if (need_radius is not None and NEED is not None and ACTIVE is not None and (H, W) == (7, 7) and
             need_radius <= NEED.radii and NEED.batch == B):
-        check(lib.spk_den_conv3x3_mfma_fp6v2_listed(_p(in0), nch, _p(wq), _p(scale), _p(bias_d), _p(wl1), _p(qtab), _p(bn_a),
-                                                    _p(bn_b), _p(out), _p(cnt), _p(flags), T, B, H, W, Cout, _n_dyn(),
-                                                    _p(NEED.buf), NEED.radii, int(need_radius), _stream(in0)),
-              "spk_den_conv3x3_mfma_fp6v2_listed")
-        return (out, cnt) if want_counts else out
+        rc = lib.spk_den_conv3x3_mfma_fp6v2_listed(_p(in0), nch, _p(wq), _p(scale), _p(bias_d), _p(wl1), _p(qtab), _p(bn_a),
+                                                   _p(bn_b), _p(out), _p(cnt), _p(flags), T, B, H, W, Cout, _n_dyn(),
+                                                   _p(NEED.buf), NEED.radii, int(need_radius), _stream(in0))
+        if rc != -2:
+            check(rc, "spk_den_conv3x3_mfma_fp6v2_listed")
+            return (out, cnt) if want_counts else out
+        # SPK_ERR_UNSUPPORTED: this device / partition has too few CUs for the per-class division of the listed launch (e.g.
+        # a 32-CU partition with Cout = 512).  The unlisted launch computes a superset of the listed positions: same tokens.
     check(lib.spk_den_conv3x3_mfma_fp6v2(_p(in0), nch, _p(wq), _p(scale), _p(bias_d), _p(wl1), _p(qtab), _p(bn_a), _p(bn_b),
                                          _p(out), _p(cnt), _p(flags), T, B, H, W, Cout, _n_dyn(), _stream(in0)),
           "spk_den_conv3x3_mfma_fp6v2")
@@ -987,9 +1026,6 @@ def convT_fp6_pack(w, bias):
     return vae_fp6_pack(w, bias, True)
 
 
-_CONVT_FLAGS = {}
-
-
 def ptc_to_s32(ptc):
     """u8 PTC spikes [B,H,W,16,C] -> S32 [B, ceil(C/32), H, W, 16, 16] (zero nibbles beyond C)."""
     ptc = _dev(ptc, "ptc", torch.uint8)
@@ -1016,13 +1052,7 @@ def vae_fp6_fwd(in_s32, packed, Cout, *, bn_a, bn_b, transposed, out_kind, coef=
         out = torch.empty((B, Cout // 32, Ho, Wo, T, 16), dtype=C4_DTYPE, device=in_s32.device)
     else:
         out = torch.empty((B, Ho, Wo, T, Cout), dtype=torch.uint8, device=in_s32.device)
-    nw = lib.spk_vae_fp6_flag_words(B, Cout, Ho, Wo)
-    key = (in_s32.device.index, nw)
-    flags = _CONVT_FLAGS.get(key)
-    if flags is None:
-        if len(_CONVT_FLAGS) > 6:
-            _CONVT_FLAGS.clear()
-        flags = _CONVT_FLAGS[key] = torch.zeros(nw, dtype=torch.int32, device=in_s32.device)
+    flags = _flag_ws("vae", in_s32.device, lib.spk_vae_fp6_flag_words(B, Cout, Ho, Wo))
     check(lib.spk_vae_fp6_fwd(_p(in_s32), _p(wq), _p(scale), _p(bias_d), _p(qtab), _p(bn_a), _p(bn_b), _p(coef), _p(out),
                               int(out_kind), _p(flags), T, B, H, W, Cin, Cout, int(transposed), _stream(in_s32)),
           "spk_vae_fp6_fwd")
@@ -1171,6 +1201,41 @@ def psample_step(logits, x_t, unmasked, t, temp=1.0, u=None, q=None, seed=0, off
                                int(offset), _p(philox_state), _p(x0_hat), B, HW, K, _p(act), _p(nact), _p(next_input),
                                _stream(logits)), "spk_psample_step")
     return x_t, unmasked
+
+
+def philox_noise(seed, offset, B, HW, K, device, philox_state=None, want_q=True):
+    """The (u [B*HW], q [B*HW, K]) a Philox-mode reverse step with these (seed, offset, philox_state) arguments draws
+    (spk_philox_noise): parity aid -- the oracle run on the dumped noise must reproduce the Philox-mode tokens."""
+    u = torch.empty(B * HW, dtype=torch.float32, device=device)
+    q = torch.empty((B * HW, K), dtype=torch.float32, device=device) if want_q else None
+    check(lib.spk_philox_noise(int(seed), int(offset), _p(philox_state), _p(u), _p(q), int(B), int(HW), int(K), _stream(u)),
+          "spk_philox_noise")
+    return u, q
+
+
+class TensorChecksum:
+    """Content checksum of a fixed set of device tensors in one launch (spk_checksum_multi): ``value()`` synchronises."""
+
+    def __init__(self, tensors):
+        ts = [t for t in tensors if t is not None and t.is_cuda and t.numel() > 0 and t.is_contiguous()]
+        if not ts:
+            raise ValueError("TensorChecksum: no device tensors")
+        self.key = tuple((t.data_ptr(), t.numel() * t.element_size()) for t in ts)
+        dev = ts[0].device
+        tab = []
+        for t in ts:
+            nb = t.numel() * t.element_size()
+            if nb % 4 or t.data_ptr() % 4:
+                raise NotImplementedError("TensorChecksum: tensors must be whole 4-byte words")
+            tab += [t.data_ptr(), nb // 4]
+        self.table = torch.tensor(tab, dtype=torch.int64).to(dev)
+        self.out = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.n = len(ts)
+        self._keep = ts
+
+    def value(self):
+        check(lib.spk_checksum_multi(_p(self.table), self.n, _p(self.out), _stream(self.out)), "spk_checksum_multi")
+        return int(self.out.item())
 
 
 class NeedLists:

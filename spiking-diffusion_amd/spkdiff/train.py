@@ -10,6 +10,8 @@ from __future__ import annotations
 
 import torch
 
+from .fused import invalidate_derived
+
 
 class GraphedTrainStep:
     def __init__(self, abdiff, optimizer, example_batch: torch.Tensor, warmup: int = 3):
@@ -51,4 +53,7 @@ class GraphedTrainStep:
         next call)."""
         self.static_x.copy_(batch)
         self.graph.replay()
+        # the replayed optimizer step rewrote the weights without touching any tensor's _version: whatever was derived from
+        # them (packed digit planes, folded BN terms, captured sampler graphs of this denoiser) is stale from here on
+        invalidate_derived(self.den)
         return self.loss

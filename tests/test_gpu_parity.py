@@ -529,7 +529,7 @@ def test_fp6v2_kernel_bit_equal_to_the_exact_kernels(dev, ops, B, hw):
             assert 0.001 < float(s1.mean()) < 0.9
     torch.cuda.synchronize()
     cap = 1 << 20                                  # id-list capacity (FLAG_CAP): [count, ticket, ids..., overflow bitmap]
-    assert all(int(v[0]) == 0 and int(v[2 + cap:].abs().sum()) == 0 for v in ops._FLAG_WORDS.values()), \
+    assert all(int(v[0]) == 0 and int(v[2 + cap:].abs().sum()) == 0 for k, v in ops._FLAG_DEFAULT.items() if k[0] == "den"), \
         "live counter, overflow bitmap and hand-over ticket come back clean"
     parity(f"fp6v2_vs_fp6_B{B}_{hw}x{hw}", neuron_steps=total, spike_mismatches=mism)
 
@@ -732,7 +732,7 @@ def test_vae_fp6_kernel_equals_the_int8_gather_kernel(dev, ops, layer, B, hw, Co
         assert 0.0 < float((want > 0).float().mean()) < 1.0
     torch.cuda.synchronize()
     cap = 1 << 20
-    assert all(int(v[0]) == 0 and int(v[2 + cap:].abs().sum()) == 0 for v in ops._CONVT_FLAGS.values()), \
+    assert all(int(v[0]) == 0 and int(v[2 + cap:].abs().sum()) == 0 for k, v in ops._FLAG_DEFAULT.items() if k[0] == "vae"), \
         "live counter, overflow bitmap and hand-over ticket come back clean"
     if layer == "dec1":          # the int8 kernel's own S32 output form (used when the fp6 kernel has no instance for a shape)
         sp1 = (torch.rand(16, B, 16, hw, hw, generator=g) < 0.3).float().to(dev)
@@ -1892,4 +1892,238 @@ def test_two_live_sampler_graphs_on_one_model_replay_independently(dev):
             out[name] = ab.sample(temp=1.0, sample_steps=40).cpu()
         bad += sum(int((v != out["eager"]).sum()) for v in out.values())
     parity("two_live_graphs_one_model", replays=12, token_mismatches=bad)
+    assert bad == 0
+
+
+# ------------------------------------------------------------------------------------------------- round 3: the timed configuration
+def _philox_oracle_tokens(ops, dev, sd, key, B, steps, latent, temp=1.0, K=128):
+    """Run the CPU oracle on the noise the Philox-mode sampler drew: spk_philox_noise dumps (u, q) per reverse step with the
+    (seed, offset) arguments the captured launches use (offset = (steps - t) * B*h*w*K, R/snn_model/vq_diffusion.py:116,134-138)."""
+    HW = latent * latent
+
+    def noise(t):
+        u, q = ops.philox_noise(key, (steps - t) * (B * HW * K), B, HW, K, dev)
+        return u.cpu().view(B, 1, latent, latent), q.cpu()
+    return ref.absorbing_sample(sd, B, K, temp, steps, latent, 16, noise=noise)
+
+
+@pytest.mark.parametrize("B,steps", [(8, 100), (256, 10)])
+def test_timed_configuration_philox_graph_vs_oracle_on_dumped_noise(dev, ops, B, steps):
+    """The configuration bench.py times -- noise_source='philox', the whole reverse process replayed from ONE hipGraph -- pinned
+    to the oracle bit for bit: the noise the device drew is dumped (spk_philox_noise) and fed to the CPU oracle, whose tokens
+    must equal the sampler's in the dense form AND with the untouched-image elimination + position lists; decode within 1e-4."""
+    from snn_model.vq_diffusion import AbsorbingDiffusion
+    den, sd = build_den(synth.MNIST, dev)
+    model, sd_v = build_vae(synth.MNIST, dev)
+    got = {}
+    key = None
+    for name, skip, lists in (("dense", False, False), ("elim+lists", True, True), ("elim", True, False)):
+        ab = AbsorbingDiffusion(den, mask_id=128)
+        ab.n_samples, ab.skip_untouched, ab.list_positions = B, skip, lists
+        assert ab.noise_source == 'philox' and ab.use_graph
+        torch.manual_seed(777)
+        k = ab._philox_key()
+        assert key is None or k == key
+        key = k
+        torch.manual_seed(777)
+        got[name] = ab.sample(temp=1.0, sample_steps=steps)
+        assert len(ab._graphs) == 1, "replayed from a captured hipGraph"
+    want = _philox_oracle_tokens(ops, dev, sd, key, B, steps, 7)
+    bad = {n: int((t.cpu() != want).sum()) for n, t in got.items()}
+    print(f"philox+graph B={B} steps={steps}: token mismatches vs oracle on dumped noise {bad} of {want.numel()}")
+    parity(f"timed_configuration_philox_graph_B{B}_{steps}steps", token_mismatches=bad, tokens=int(want.numel()))
+    assert all(v == 0 for v in bad.values()), bad
+    n = min(B, 16)
+    pred, u8 = model.decode_tokens(got["dense"].reshape(B, 7, 7)[:n].contiguous())
+    opred = ref.decode_tokens(want.reshape(B, 7, 7)[:n], sd_v, 16)
+    err = float((pred.cpu() - opred).abs().max())
+    parity(f"timed_configuration_decode_B{B}", pixel_max_abs_err=err)
+    assert err <= 1e-4
+
+
+def test_philox_noise_entry_matches_what_psample_consumes(dev, ops):
+    """spk_philox_noise == the draws of spk_psample_step / spk_select_active: a step run on injected (dumped) noise equals the
+    same step in Philox mode, including through the philox_state indirection the captured graph uses."""
+    B, K, HW = 64, 128, 49
+    g = torch.Generator().manual_seed(5)
+    logits = (torch.randn(B, K, 7, 7, generator=g) * 2).to(dev)
+    un0 = (torch.rand(B, 1, 7, 7, generator=g) < 0.4).to(dev)
+    x0 = torch.randint(0, K, (B, 1, 7, 7), generator=g).to(dev)
+    state = torch.tensor([991, 4096], dtype=torch.int64, device=dev)
+    for t in (1, 3, 50):
+        off = 12345 * t
+        u, q = ops.philox_noise(0, off, B, HW, K, dev, philox_state=state)
+        u2, q2 = ops.philox_noise(991, off + 4096, B, HW, K, dev)
+        assert torch.equal(u, u2) and torch.equal(q, q2)
+        assert float(u.min()) >= 0 and float(u.max()) < 1 and float(q.min()) > 0
+        xa, una = x0.clone(), un0.clone()
+        ops.psample_step(logits, xa, una, t, 0.9, None, None, 0, off, philox_state=state)
+        xb, unb = x0.clone(), un0.clone()
+        ops.psample_step(logits, xb, unb, t, 0.9, u, q)
+        assert torch.equal(xa, xb) and torch.equal(una, unb)
+        a1 = ops.select_active(un0, t, None, 0, off, philox_state=state)
+        a2 = ops.select_active(un0, t, u)
+        n1, n2 = int(a1[1][0]), int(a2[1][0])
+        assert n1 == n2 and torch.equal(a1[0][:n1], a2[0][:n2])
+
+
+@pytest.mark.parametrize("steps", [12, 100])
+def test_sampler_trajectory_8x8_vs_live_oracle(dev, steps):
+    """BASELINE configs[3] shape: the reverse process on an 8x8 latent (R/snn_model/vq_diffusion.py:103-142 with the 7x7
+    literals generalised), host noise in the reference's order, B = 4, dense and with the untouched-image elimination,
+    against the CPU oracle run live under the same torch.manual_seed."""
+    from snn_model.vq_diffusion import AbsorbingDiffusion
+    den, sd = build_den(synth.CIFAR, dev)
+    bad = {}
+    for name, skip in (("dense", False), ("elim", True)):
+        ab = AbsorbingDiffusion(den, mask_id=128, latent_shape=(8, 8))
+        ab.n_samples, ab.noise_source, ab.skip_untouched = 4, 'host', skip
+        torch.manual_seed(99 + steps)
+        tok = ab.sample(temp=1.0, sample_steps=steps).cpu()
+        torch.manual_seed(99 + steps)
+        want = ref.absorbing_sample(sd, 4, 128, 1.0, steps, 8, 16)
+        bad[name] = int((tok != want).sum())
+    print(f"8x8 trajectory, {steps} steps, B=4: token mismatches {bad} of {want.numel()}")
+    parity(f"trajectory_8x8_{steps}_steps_vs_live_oracle", token_mismatches=bad, tokens=int(want.numel()))
+    assert all(v == 0 for v in bad.values()), bad
+
+
+def test_timed_configuration_8x8_philox_graph_vs_oracle_on_dumped_noise(dev, ops):
+    """The CIFAR-shaped sampler in the form bench.py times (Philox noise, hipGraph) against the oracle on the dumped noise."""
+    from snn_model.vq_diffusion import AbsorbingDiffusion
+    den, sd = build_den(synth.CIFAR, dev)
+    B, steps = 8, 40
+    got = {}
+    for name, skip in (("dense", False), ("elim", True)):
+        ab = AbsorbingDiffusion(den, mask_id=128, latent_shape=(8, 8))
+        ab.n_samples, ab.skip_untouched = B, skip
+        torch.manual_seed(31)
+        key = ab._philox_key()
+        torch.manual_seed(31)
+        got[name] = ab.sample(temp=1.0, sample_steps=steps).cpu()
+    want = _philox_oracle_tokens(ops, dev, sd, key, B, steps, 8)
+    bad = {n: int((t != want).sum()) for n, t in got.items()}
+    parity("timed_configuration_8x8_philox_graph", token_mismatches=bad, tokens=int(want.numel()))
+    assert all(v == 0 for v in bad.values()), bad
+
+
+def test_full_length_full_size_config3_and_config4_shapes(dev):
+    """BASELINE configs[3] (CIFAR-shaped, B = 512) and the per-rank shape of configs[4] (B = 1024) at the benchmark's full
+    length of 100 reverse steps: dense == elimination token for token (size-independent property of R/snn_model/vq_diffusion.py:
+    113-124,140), every position unmasked, tokens in range, decode to uint8."""
+    from snn_model.vq_diffusion import AbsorbingDiffusion
+    for cfg, L, B in ((synth.CIFAR, 8, 512), (synth.MNIST, 7, 1024)):
+        den, _ = build_den(cfg, dev)
+        model, _ = build_vae(cfg, dev)
+        toks = {}
+        for name, skip in (("dense", False), ("elim", True)):
+            ab = AbsorbingDiffusion(den, mask_id=128, latent_shape=(L, L))
+            ab.n_samples, ab.skip_untouched = B, skip
+            torch.manual_seed(8)
+            toks[name] = ab.sample(temp=1.0, sample_steps=100)
+            ab._graphs.clear()
+        n_bad = int((toks["dense"] != toks["elim"]).sum())
+        parity(f"full_length_B{B}_{L}x{L}", dense_vs_elimination_token_mismatches=n_bad, tokens=int(toks["dense"].numel()))
+        assert n_bad == 0
+        tok = toks["dense"]
+        assert tok.shape == (B, 1, L, L) and int(tok.min()) >= 0 and int(tok.max()) < 128
+        pred, u8 = model.decode_tokens(tok.reshape(B, L, L))
+        assert u8.shape == (B, cfg.in_dim, 4 * L, 4 * L) and u8.dtype == torch.uint8 and float(pred.abs().max()) <= 1.0
+        del den, model
+        torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------- round 3: graph / cache lifetimes
+def _eager_tokens(den, B, steps, seed, skip=True):
+    from snn_model.vq_diffusion import AbsorbingDiffusion
+    ab = AbsorbingDiffusion(den, mask_id=128)
+    ab.n_samples, ab.use_graph, ab.skip_untouched = B, False, skip
+    torch.manual_seed(seed)
+    return ab.sample(temp=1.0, sample_steps=steps)
+
+
+def test_sample_train_eval_sample_recaptures_the_graph(dev):
+    """sample (graph) -> train() -> eval() -> sample: the transitions drop the derived tensors the captured launches address;
+    the second sample must re-capture (derived epoch in the graph key) and equal the eager loop."""
+    from snn_model.vq_diffusion import AbsorbingDiffusion
+    den, _ = build_den(synth.MNIST, dev)
+    ab = AbsorbingDiffusion(den, mask_id=128)
+    ab.n_samples = 16
+    torch.manual_seed(1); a = ab.sample(temp=1.0, sample_steps=20)
+    k1 = set(ab._graphs)
+    den.train(); den.eval()
+    junk = [torch.randn(1 << 20, device=dev) for _ in range(8)]          # recycle whatever the invalidation freed
+    torch.manual_seed(1); b = ab.sample(temp=1.0, sample_steps=20)
+    assert set(ab._graphs) != k1, "a new graph was captured after the invalidation"
+    assert torch.equal(a, b) and torch.equal(b, _eager_tokens(den, 16, 20, 1))
+    del junk
+
+
+def test_sample_after_graphed_training_steps_uses_the_new_weights(dev):
+    """R/main.py:243-260 as this library runs it: sample -> N training iterations replayed from a hipGraph (no tensor's
+    _version moves) -> eval -> sample.  The second sample must be the eager sampler's on the TRAINED weights."""
+    from snn_model.vq_diffusion import AbsorbingDiffusion, functional
+    from spkdiff.train import GraphedTrainStep
+    den, _ = build_den(synth.MNIST, dev)
+    ab = AbsorbingDiffusion(den, mask_id=128)
+    ab.n_samples = 16
+    torch.manual_seed(2); before = ab.sample(temp=1.0, sample_steps=20)
+    den.train()
+    opt = torch.optim.AdamW(den.parameters(), lr=5e-3, capturable=True)
+    x0 = torch.randint(0, 128, (16, 1, 7, 7), generator=torch.Generator().manual_seed(3)).float().to(dev)
+    step = GraphedTrainStep(ab, opt, x0)
+    for _ in range(5):
+        step(x0)
+    den.eval()
+    functional.reset_net(den)
+    torch.manual_seed(2); after = ab.sample(temp=1.0, sample_steps=20)
+    want = _eager_tokens(den, 16, 20, 2)
+    assert torch.equal(after, want), "graph-replayed sampler == eager sampler on the trained weights"
+    assert not torch.equal(after, before), "the training steps changed the weights enough to change the sample"
+
+
+def test_data_write_is_noticed_by_the_weights_checksum(dev):
+    """`p.data.copy_(...)` changes no (data_ptr, _version) pair; the sampler's content checksum must notice and rebuild."""
+    from snn_model.vq_diffusion import AbsorbingDiffusion
+    den, _ = build_den(synth.MNIST, dev)
+    ab = AbsorbingDiffusion(den, mask_id=128)
+    ab.n_samples = 16
+    torch.manual_seed(4); a = ab.sample(temp=1.0, sample_steps=20)
+    with torch.no_grad():
+        for name, p in den.named_parameters():
+            if name.endswith('0.weight'):
+                p.data.mul_(1.5)
+    torch.manual_seed(4); b = ab.sample(temp=1.0, sample_steps=20)
+    den2, _ = build_den(synth.MNIST, dev)
+    with torch.no_grad():
+        for name, p in den2.named_parameters():
+            if name.endswith('0.weight'):
+                p.mul_(1.5)
+    want = _eager_tokens(den2, 16, 20, 4)
+    assert torch.equal(b, want) and not torch.equal(a, b)
+
+
+def test_certified_kernel_workspaces_are_per_stream(dev, ops):
+    """Two denoiser calls in flight on two streams must not share a flagged-neuron workspace (the repair pass of one would
+    consume the other's ids): interleaved launches on two streams equal the serial results."""
+    den, _ = build_den(synth.MNIST, dev)
+    g = torch.Generator().manual_seed(6)
+    xs = []
+    for i in range(2):
+        x = torch.randint(0, 128, (96, 1, 7, 7), generator=g)
+        x[torch.rand(96, 1, 7, 7, generator=g) < 0.6] = 128
+        xs.append(x.to(dev))
+    want = [den.logits_from_tokens(x, 30 + i).clone() for i, x in enumerate(xs)]
+    torch.cuda.synchronize()
+    s = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    bad = 0
+    for rep in range(6):
+        got = [None, None]
+        for i in range(2):
+            with torch.cuda.stream(s[i]):
+                got[i] = den.logits_from_tokens(xs[i], 30 + i)
+        torch.cuda.synchronize()
+        bad += sum(int((got[i] != want[i]).sum()) for i in range(2))
+    keys = [k for k in ops._FLAG_DEFAULT if k[0] == "den"]
+    assert len({k[2] for k in keys}) >= 3, "one workspace set per stream"
     assert bad == 0

@@ -22,12 +22,12 @@ for name, Cout, Cin in (("conv4", 512, 256), ("conv5", 256, 512)):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); ops.den_conv3x3_mfma_fp6v2(x, p2, Cout, bn_a=a, bn_b=b); e1.record()
     torch.cuda.synchronize()
-    ws = list(ops._FLAG_WORDS.values())[-1]
+    ws = list(ops._FLAG_DEFAULT.values())[-1]
     st = ws[2:2 + 4 * 256].view(torch.int64).view(256, 2).double().cpu()
     ghz = (st[:, 0] / st[:, 1]) * 0.1
     mf = (B * (Cout // 32) / 256) * (Cin // 32) * 138
     print(f"{name}: launch {e0.elapsed_time(e1) * 1e3:.1f} us (incl. tail launches); in-kernel clock median {float(ghz.median()):.3f} GHz "
           f"(min {float(ghz.min()):.3f}, max {float(ghz.max()):.3f}); workgroup span median {float(st[:, 1].median()) / 100:.1f} us = "
           f"{float(st[:, 0].median()) / mf:.1f} cycles per MFMA (33 = matrix-pipe bound)", flush=True)
-    for v in ops._FLAG_WORDS.values():
+    for v in ops._FLAG_DEFAULT.values():
         v[:2].zero_()

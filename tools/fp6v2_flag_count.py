@@ -18,8 +18,8 @@ log = []
 def hooked(in0, packed, Cout, **kw):
     r = orig(in0, packed, Cout, **kw)
     torch.cuda.synchronize()
-    tot = sum(int(v[0]) for v in ops._FLAG_WORDS.values())
-    for v in ops._FLAG_WORDS.values():
+    tot = sum(int(v[0]) for v in ops._FLAG_DEFAULT.values())
+    for v in ops._FLAG_DEFAULT.values():
         v[:2].zero_()
     log.append((Cout, in0.shape[1] * 32, tot, B * Cout * 49))
     return r

@@ -22,8 +22,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
             y1 = ops.den_conv3x3_mfma_fp6(x1, p1, Cout, bn_a=a, bn_b=b)
             y2 = ops.den_conv3x3_mfma_fp6v2(x2, p2, Cout, bn_a=a, bn_b=b)
         torch.cuda.synchronize()
-        flagged = sum(int(v[0]) for v in ops._FLAG_WORDS.values())      # non-zero only for a -DSPK_V2_DBG=64 build
-        for v in ops._FLAG_WORDS.values():
+        flagged = sum(int(v[0]) for v in ops._FLAG_DEFAULT.values())      # non-zero only for a -DSPK_V2_DBG=64 build
+        for v in ops._FLAG_DEFAULT.values():
             v[:2].zero_()
         s1, s2 = ops.c4_to_spikes(y1), ops.s32_to_spikes(y2)
         mism = int((s1 != s2).sum())
