@@ -230,6 +230,15 @@ int spk_den_conv3x3_mfma_fp6v2(const uint8_t* in_s32, int nch, const uint8_t* wq
                                const float* wl1, const int* qtab, const float* bn_a, const float* bn_b, uint8_t* out_s32,
                                uint8_t* out_counts, unsigned* flag_words, int T, int B, int H, int W, int Cout,
                                const int* n_dyn_or_null, spk_stream_t stream);
+/* Measurement aid: re-run ONE tail part of the last spk_den_conv3x3_mfma_fp6v2 call on the same arguments and workspace --
+ * part 2: the exact recomputation of the neurons that call flagged (flag_words[1] holds their number, the id list is intact;
+ * recomputing them again writes the same spikes), part 4: the last position of every image (7x7).  bench.py times these to
+ * report `repair_ms` / `last_position_ms` per layer; flag_words[1] / (B * Cout * H * W) is the flagged fraction. */
+int spk_den_conv3x3_mfma_fp6v2_part(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale,
+                                    const double* bias_d, const float* wl1, const int* qtab, const float* bn_a,
+                                    const float* bn_b, uint8_t* out_s32, uint8_t* out_counts_or_null, unsigned* flag_words,
+                                    int T, int B, int H, int W, int Cout, const int* n_dyn_or_null, int part,
+                                    spk_stream_t stream);
 /* The same layer restricted to the positions the sampler will read (7x7 only): need = the buffer written by
  * spk_select_needed(..., R = need_radii) for the same B; radius (1..need_radii) selects the lists this layer computes --
  * 1 for the layer whose output the logits convolution reads, 2 for the one below it, ...  Listed positions (and the 49th)

@@ -66,7 +66,8 @@ struct V2Args {
   const uint8_t* wq; const double* scale; const double* bias; const float* wl1;
   const float* bn_a; const float* bn_b;
   uint8_t* out; uint8_t* out_cnt;
-  unsigned* flags;                           // ws[0]: number of flagged neurons, ws[1]: unused, ws[2..2+cap): their ids,
+  unsigned* flags;                           // ws[0]: number of flagged neurons (live), ws[1]: the count of the last finished
+                                             //  launch (published by the hand-over or the re-arming), ws[2..2+cap): their ids,
   unsigned flag_cap;                         //  then the overflow bitmap (one bit per neuron; used only beyond cap), then the
   long long ticket_idx;                      //  ticket of the hand-over (ws[1] = the count published for the tail launch)
   int handover;                              // 1: the main launch publishes the count (fp6v2_handover); 0: the tail launches read
@@ -711,7 +712,7 @@ __device__ __forceinline__ void fp6v2_lastpos_body(const V2Args& a, const int bi
   const int nch = a.nch, G = a.Cout >> 5;
   const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
   // (without the hand-over this launch follows the repair launch on the stream and re-arms the flag counter)
-  if (!a.handover && bid == 0 && threadIdx.x == 0 && !(SPK_V2_DBG & 64)) a.flags[0] = 0u;
+  if (!a.handover && bid == 0 && threadIdx.x == 0 && !(SPK_V2_DBG & 64)) { a.flags[1] = a.flags[0]; a.flags[0] = 0u; }
   // one workgroup = one 32-row tile = two images (the lane halves) x one channel group; its four waves split the K chunks
   // (wave w: chunks w, w + 4, ...) and add their partial sums -- exact integers below 2^24 in fp32, so the order of the
   // additions does not matter -- in LDS: the launch is bound by the latency of a wave's chain of dependent gathers
@@ -1080,7 +1081,8 @@ extern "C" long long spk_den_fp6v2_flag_words(int B, int Cout, int H, int W) {
 static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale, const double* bias_d,
                         const float* wl1, const int* qtab, const float* bn_a, const float* bn_b, uint8_t* out_s32,
                         uint8_t* out_counts, unsigned* flag_words, int T, int B, int H, int W, int Cout,
-                        const int* n_dyn_or_null, const uint8_t* need, int need_R, int need_r, hipStream_t stream) {
+                        const int* n_dyn_or_null, const uint8_t* need, int need_R, int need_r, hipStream_t stream,
+                        int parts = 7) {
   if (!in_s32 || nch <= 0 || !wq || !scale || !bias_d || !wl1 || !qtab || !bn_a || !bn_b || !out_s32 || !flag_words ||
       B <= 0 || H <= 0 || W <= 0 || Cout <= 0)
     return SPK_ERR_ARG;
@@ -1121,6 +1123,20 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   // costs a barrier and an atomic per workgroup of the main launch (1.2 us), which only the merged tail launch of the
   // active-set calls (and the launch it saves on even latents) pays back
   a.handover = (bands || n_dyn_or_null) ? 1 : 0;
+  if (parts != 7) {
+    // measurement / debugging: re-run one tail part of the LAST launch on this workspace.  2 = the exact recomputation of
+    // the neurons that launch flagged (count in ws[1], ids still listed: idempotent), 4 = the last position of every image.
+    if (parts == 2) {
+      a.handover = 1;                                         // (read the published count, leave the live counter alone)
+      if (bands) hipLaunchKernelGGL((fp6v2_tail_kernel<8, 8, 1>), dim3(8 * cus), dim3(256), 0, stream, a, n_words, 0);
+      else hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7, 1>), dim3(8 * cus), dim3(256), 0, stream, a, n_words, 0);
+    } else if (parts == 4 && !bands) {
+      a.handover = 1;                                         // (no re-arming)
+      hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7, 2>), dim3(((B + 1) / 2) * G), dim3(256), 0, stream, a, n_words, ((B + 1) / 2) * G);
+    } else return SPK_ERR_UNSUPPORTED;
+    SPK_LAUNCH_CHECK();
+    return SPK_OK;
+  }
   if (bands) {
     static const bool eight_b = [] { const char* e = getenv("SPKDIFF_V2_WAVES"); return !(e && e[0] == '4'); }();   // (+4 %)
     if (eight_b) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 8, true>), dim3(grid), dim3(512), lds, stream, a);
@@ -1164,6 +1180,16 @@ extern "C" int spk_den_conv3x3_mfma_fp6v2(const uint8_t* in_s32, int nch, const 
                                           int T, int B, int H, int W, int Cout, const int* n_dyn_or_null, hipStream_t stream) {
   return fp6v2_launch(in_s32, nch, wq, scale, bias_d, wl1, qtab, bn_a, bn_b, out_s32, out_counts, flag_words, T, B, H, W, Cout,
                       n_dyn_or_null, nullptr, 0, 0, stream);
+}
+
+extern "C" int spk_den_conv3x3_mfma_fp6v2_part(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale,
+                                               const double* bias_d, const float* wl1, const int* qtab, const float* bn_a,
+                                               const float* bn_b, uint8_t* out_s32, uint8_t* out_counts, unsigned* flag_words,
+                                               int T, int B, int H, int W, int Cout, const int* n_dyn_or_null, int part,
+                                               hipStream_t stream) {
+  if (part != 2 && part != 4) return SPK_ERR_ARG;
+  return fp6v2_launch(in_s32, nch, wq, scale, bias_d, wl1, qtab, bn_a, bn_b, out_s32, out_counts, flag_words, T, B, H, W, Cout,
+                      n_dyn_or_null, nullptr, 0, 0, stream, part);
 }
 
 extern "C" int spk_den_conv3x3_mfma_fp6v2_listed(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale,

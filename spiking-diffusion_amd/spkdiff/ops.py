@@ -901,7 +901,37 @@ def den_conv3x3_mfma_fp6v2(in0, packed, Cout, *, bn_a, bn_b, want_counts=False, 
     check(lib.spk_den_conv3x3_mfma_fp6v2(_p(in0), nch, _p(wq), _p(scale), _p(bias_d), _p(wl1), _p(qtab), _p(bn_a), _p(bn_b),
                                          _p(out), _p(cnt), _p(flags), T, B, H, W, Cout, _n_dyn(), _stream(in0)),
           "spk_den_conv3x3_mfma_fp6v2")
+    if FP6V2_STATS is not None:
+        _fp6v2_stats(in0, packed, Cout, bn_a, bn_b, out, cnt, flags)
     return (out, cnt) if want_counts else out
+
+
+# bench.py's instrumented pass sets this to a list: every fp6v2 layer call then appends (Cout, Cin, flagged neurons,
+# neurons, repair ms, last-position ms) -- the tail parts re-run and timed on their own (spk_den_conv3x3_mfma_fp6v2_part)
+FP6V2_STATS = None
+
+
+def _fp6v2_stats(in0, packed, Cout, bn_a, bn_b, out, cnt, flags):
+    B, nch, H, W, T, _ = in0.shape
+    wq, scale, bias_d, wl1, qtab = packed
+    ms = {}
+    for part in (2, 4):
+        if part == 4 and (H * W) % 2 == 0:
+            ms[part] = 0.0
+            continue
+        evs = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib.spk_den_conv3x3_mfma_fp6v2_part(_p(in0), nch, _p(wq), _p(scale), _p(bias_d), _p(wl1), _p(qtab), _p(bn_a),
+                                                      _p(bn_b), _p(out), _p(cnt), _p(flags), T, B, H, W, Cout, _n_dyn(), part,
+                                                      _stream(in0)), "spk_den_conv3x3_mfma_fp6v2_part")
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        ms[part] = sorted(a.elapsed_time(b) for a, b in evs)[1]
+    FP6V2_STATS.append({"Cout": int(Cout), "Cin": int(nch * 32), "flagged": int(flags[1].item()),
+                        "neurons": int(B * Cout * H * W), "repair_ms": ms[2], "last_position_ms": ms[4]})
 
 
 def spikes_to_s32(s):

@@ -185,6 +185,57 @@ def synth_denoiser_state(cfg: PathConfig = MNIST, seed: int = 4321, calib_batch:
     return {k: v.contiguous() for k, v in sd.items()}
 
 
+def cached_state(kind: str, cfg: PathConfig = MNIST, **kw) -> dict:
+    """``synth_vqvae_state`` / ``synth_denoiser_state`` (kind 'vqvae' / 'denoiser') through a file cache: the calibration pass
+    runs ONCE per node -- the first process to claim the lock generates and publishes (atomic rename), the others wait for
+    the file -- so that the eight ranks of a bench run do not each calibrate on an eighth of the host cores.  The cache key
+    holds every argument and the generator version (crc of this file); a stale or unreadable file is regenerated."""
+    import hashlib
+    import os
+    import tempfile
+    import time
+    fn = {"vqvae": synth_vqvae_state, "denoiser": synth_denoiser_state}[kind]
+    with open(__file__, "rb") as f:
+        ver = zlib.crc32(f.read())
+    key = hashlib.sha256(repr((kind, cfg, sorted(kw.items()), ver, torch.__version__)).encode()).hexdigest()[:20]
+    root = os.environ.get("SPKDIFF_SYNTH_CACHE") or os.path.join(tempfile.gettempdir(), f"spkdiff_synth_{os.getuid()}")
+    os.makedirs(root, exist_ok=True)
+    path, lock = os.path.join(root, key + ".pt"), os.path.join(root, key + ".lock")
+
+    def load():
+        try:
+            return torch.load(path, map_location="cpu", weights_only=True)
+        except Exception:
+            return None
+    sd = load() if os.path.exists(path) else None
+    if sd is not None:
+        return sd
+    try:
+        fd = os.open(lock, os.O_CREAT | os.O_EXCL | os.O_WRONLY)
+        os.close(fd)
+        mine = True
+    except FileExistsError:
+        mine = False
+    if not mine:
+        t0 = time.time()
+        while time.time() - t0 < 600.0:                  # (a crashed generator leaves a stale lock: give up and generate)
+            if os.path.exists(path):
+                sd = load()
+                if sd is not None:
+                    return sd
+            time.sleep(0.2)
+    sd = fn(cfg, **kw)
+    tmp = f"{path}.{os.getpid()}.tmp"
+    torch.save(sd, tmp)
+    os.replace(tmp, path)
+    if mine:
+        try:
+            os.unlink(lock)
+        except OSError:
+            pass
+    return sd
+
+
 def state_checksum(sd: dict) -> str:
     """crc32 over all tensors' bytes in key order (pins fixtures to the generator version)."""
     c = 0

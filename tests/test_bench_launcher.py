@@ -31,6 +31,20 @@ def test_plain_start_with_two_gpus_launches_two_ranks_and_relays_one_line():
     assert d["images"] == 7 and abs(d["max_t"] - 0.2) < 1e-12          # ragged shards gathered; max over ranks
 
 
+def test_eight_ranks_one_line_and_exit_codes():
+    """`bench.py --gpus 8` (the driver's largest run) under the stub worker: eight gloo ranks, ragged global batch, the
+    rank-0-only tail against seven waiting ranks, ONE line with ranks_seen == 8, exit code 0; a failing rank -> non-zero."""
+    p = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--global-batch", "8195"], timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["images"] == 8195 and d["keys_distinct"] is True
+    assert abs(d["max_t"] - 0.8) < 1e-12
+    p = _run(["--gpus", "8"], {"STUB_FAIL": "1"}, timeout=600)
+    assert p.returncode != 0 and p.stdout.strip() == ""
+
+
 def test_rank_failure_is_reported_as_failure():
     p = _run(["--gpus", "2"], {"STUB_FAIL": "1"})
     assert p.returncode != 0 and p.stdout.strip() == ""
