@@ -363,6 +363,21 @@ int spk_psample_step(const float* logits_bkhw, long long* x_t_inout, uint8_t* un
                      long long* x0_hat_out_or_null, int B, int HW, int K, const int* active_or_null,
                      const int* n_active_or_null, float* next_input_b2hw_or_null, spk_stream_t stream);
 
+/* The tail of one DENSE reverse step as one launch per image: conv6 on the spike counts + mean over T (as
+ * spk_den_conv3x3_counts_mfma; R/snn_model/vq_diffusion.py:185-187,205-206), the token update (as spk_psample_step: :113-124,
+ * 134-140, same u / q / Philox arguments and draws) and -- unless x1_s32_out is NULL (last step) -- the first denoiser layer of
+ * the NEXT step on cat(x_t, t - 1) (as spk_conv_fused_fwd on a time-invariant input: :161-165,195-201): S32 spikes
+ * [B][2][HW][16][16 B] and spike counts u8 [B][2][HW][32].  cnt5 [B][8][HW][32] / cnt1 [B][2][HW][32]: spike counts of conv5 /
+ * conv1 of THIS step; wq / scale / bias_d: conv6 packed by spk_den_pack_weight_i8; conv1_w_packed: spk_pack_conv_weight of the
+ * first layer ([9][2][64]); bn1_a / bn1_b: its folded BatchNorm.  logits_out optional fp32 [B][K][H][W].  K = 128, 7x7 or 8x8
+ * latents, 256 + 64 input channels (the reference's architecture); anything else: SPK_ERR_UNSUPPORTED (use the three launches). */
+int spk_den_step_tail(const uint8_t* cnt5, int nch5, const uint8_t* cnt1, int nch1, const int8_t* wq, const double* scale,
+                      const double* bias_d, float* logits_out_or_null, long long* x_t_inout, uint8_t* unmasked_inout, int t,
+                      float temp, const float* u_or_null, const float* q_or_null, unsigned long long philox_seed,
+                      unsigned long long philox_offset, const unsigned long long* philox_state_or_null,
+                      const float* conv1_w_packed_or_null, const float* conv1_bias_or_null, const float* bn1_a,
+                      const float* bn1_b, uint8_t* x1_s32_out_or_null, uint8_t* cnt1_out_or_null, int T, int B, int H, int W,
+                      int K, spk_stream_t stream);
 /* The noise of one reverse step as spk_psample_step / spk_select_active / spk_select_needed draw it in Philox mode, written
  * out (parity aid: R/snn_model/vq_diffusion.py:116 `rand_like` -> u, :138 `Categorical.sample()` -> q ~ Exp(1)): u_out [B*HW] =
  * the uniforms of the `changes` test, q_out [B*HW*K] = the exponentials of the categorical race; same (seed, offset,

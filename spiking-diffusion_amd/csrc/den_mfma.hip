@@ -676,7 +676,9 @@ extern "C" int spk_den_conv3x3_mfma(const uint8_t* in0_cptc, int nch0, const uin
   a.Cout = Cout; a.mode = mode; a.n_dyn = n_dyn_or_null;
   a.dbg = 0;
 #ifdef SPK_MFMA_ABLATION
-  { const char* e = getenv("SPK_MFMA_DEBUG"); a.dbg = e ? atoi(e) : 0; }     // timing experiments only
+  // (timing experiments only; read once per process: the launch path makes no environment look-ups)
+  static const int dbg_env = [] { const char* e = getenv("SPK_MFMA_DEBUG"); return e ? atoi(e) : 0; }();
+  a.dbg = dbg_env;
 #endif
   if (mode == SPK_MODE_LIF) {
     if (!bn_a || !bn_b || !out_cptc) return SPK_ERR_ARG;

@@ -187,6 +187,8 @@ class AbsorbingDiffusion(Sampler):
         skip = self._skip_ok(h, w) and record is None
         act = None
         need = ops.NeedLists(b, int(self.list_radii), dev) if skip and self._list_ok(h, w) else None
+        tail = (not skip) and dn.tail_fusable(h, w)                      # dense loop: the fused step tail (same tokens)
+        pre1 = None
         for t in reversed(range(1, sample_steps + 1)):
             u = q = None
             if noise is not None:
@@ -194,6 +196,14 @@ class AbsorbingDiffusion(Sampler):
             elif self.noise_source == 'host':
                 u = torch.rand(b, 1, h, w).to(dev)                       # rand_like(x_t.float()), drawn first (:116)
             off = base + (sample_steps - t) * (b * h * w * K)
+            if tail:
+                if noise is None and self.noise_source == 'host':
+                    q = torch.empty(b * h * w, K).exponential_(1).to(dev)    # (the denoiser call draws nothing: same order)
+                pre1, logits = dn.sample_step(x_t, unmasked, t, temp, u, q, seed, off, pre1=pre1, want_next=t > 1,
+                                              want_logits=record is not None)
+                if record is not None:
+                    record.append((t, x_t.clone(), unmasked.clone(), logits))
+                continue
             if skip:
                 act = ops.select_active(unmasked, t, u, seed, off, out=act)
                 if need is not None:
@@ -248,7 +258,8 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
     dn = self._denoise_fn
     skip = self._skip_ok(h, w)
     lists = skip and self._list_ok(h, w)
-    key = (str(dev), b, h, w, K, temp, sample_steps, int(self.mask_id), skip, lists, int(self.list_radii), _weights_key(dn))
+    key = (str(dev), b, h, w, K, temp, sample_steps, int(self.mask_id), skip, lists, int(self.list_radii),
+           bool(dn.use_step_tail), _weights_key(dn))
     entry = self._graphs.get(key)
     if entry is None:
         if len(self._graphs) >= 2:                              # at most two live graphs per sampler (e.g. dense and
@@ -260,14 +271,21 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
         act = (torch.zeros(b, dtype=torch.int32, device=dev), torch.zeros(2, dtype=torch.int32, device=dev)) if skip else None
         need = ops.NeedLists(b, int(self.list_radii), dev) if lists else None
 
-        # dense form: every spk_psample_step also writes the next step's denoiser input (one launch less per step)
-        inp = None if skip else torch.empty((b, 2, h, w), dtype=torch.float32, device=dev)
+        # dense form: the fused step tail where the architecture fits (conv6 + token update + the next step's first layer in
+        # one launch), else every spk_psample_step also writes the next step's denoiser input (one launch less per step)
+        tail = (not skip) and dn.tail_fusable(h, w)
+        inp = None if (skip or tail) else torch.empty((b, 2, h, w), dtype=torch.float32, device=dev)
 
         def body():
             x_t.fill_(int(self.mask_id))
             unmasked.zero_()
+            pre1 = None
             for t in reversed(range(1, sample_steps + 1)):
                 off = (sample_steps - t) * (b * h * w * K)
+                if tail:
+                    pre1, _ = dn.sample_step(x_t, unmasked, t, temp, None, None, 0, off, philox_state=state, pre1=pre1,
+                                             want_next=t > 1)
+                    continue
                 if skip:
                     ops.select_active(unmasked, t, None, 0, off, philox_state=state, out=act)
                     if lists:
@@ -376,20 +394,26 @@ class DummyModel(nn.Module):
     def conv_impl(self):
         return self.impl_for(*self._latent_hw, stateful=self._last_stateful)
 
-    def _run(self, inp_b2hw, stateful, record=None):
+    def _trunk(self, inp_b2hw, stateful, record=None, pre1=None):
+        """conv1 .. conv5 on the input map [B,2,h,w] (``pre1 = (spikes, counts)``: the first layer's output is already there --
+        the previous reverse step's tail launch produced it).  Returns (x5, cnt5, x1, cnt1, which, impl, collapse)."""
         T = self.n_steps
         # spikes travel channel-chunked: CPTC (32 u8 channels per chunk) for the int8 kernel, C4 (64 fp4 nibbles per
         # chunk) for the fp6 kernel -- the layout each stages per K chunk
-        self._latent_hw = (int(inp_b2hw.shape[-2]), int(inp_b2hw.shape[-1]))
+        hw = (int(inp_b2hw.shape[-2]), int(inp_b2hw.shape[-1])) if pre1 is None else (int(pre1[0].shape[2]), int(pre1[0].shape[3]))
+        self._latent_hw = hw
         self._last_stateful = bool(stateful)
         which = self.conv_impl
         impl = 'direct' if which == 'direct-f64' else 'auto'
         collapse = which != 'direct-f64' and self.collapse_conv6
         chunk = ops.CHUNK_S32 if which == 'mfma-fp6v2' else (ops.CHUNK_C4 if which == 'mfma-fp6x6' else 32)
-        with ops.timed('den.conv1'):
-            r1 = self.conv1.run(inp_b2hw, IN_TINV, final='ptc', T=T, stateful=stateful, chunk_out=chunk,
-                                want_counts=collapse)
-        x1 = r1['ptc']
+        if pre1 is None:
+            with ops.timed('den.conv1'):
+                r1 = self.conv1.run(inp_b2hw, IN_TINV, final='ptc', T=T, stateful=stateful, chunk_out=chunk,
+                                    want_counts=collapse)
+            x1, cnt1 = r1['ptc'], r1['cnt']
+        else:
+            x1, cnt1 = pre1
         x = x1
         outs = [x1]
         cnt5 = None
@@ -404,15 +428,58 @@ class DummyModel(nn.Module):
             outs.append(x)
         if record is not None:
             record.extend(outs)
+        return x, cnt5, x1, cnt1, which, impl, collapse
+
+    def _conv6_params(self):
+        conv = self.conv6[0]
+        if not hasattr(conv, '_spk_params'):
+            from spkdiff.fused import ConvParams
+            object.__setattr__(conv, '_spk_params', ConvParams())
+        return conv, conv._spk_params.get_i8(conv)
+
+    def _run(self, inp_b2hw, stateful, record=None):
+        T = self.n_steps
+        x, cnt5, x1, cnt1, which, impl, collapse = self._trunk(inp_b2hw, stateful, record)
         with ops.timed('den.conv6'):
-            if collapse and cnt5 is not None and r1['cnt'] is not None:
+            if collapse and cnt5 is not None and cnt1 is not None:
                 # conv6 is linear and followed by the mean over T: convolve the spike COUNTS once instead of T frames
-                conv = self.conv6[0]
-                if not hasattr(conv, '_spk_params'):
-                    from spkdiff.fused import ConvParams
-                    object.__setattr__(conv, '_spk_params', ConvParams())
-                return ops.den_conv3x3_counts(cnt5, conv._spk_params.get_i8(conv), conv.out_channels, T, cnt1=r1['cnt'])
+                conv, packed = self._conv6_params()
+                return ops.den_conv3x3_counts(cnt5, packed, conv.out_channels, T, cnt1=cnt1)
             return self.conv6.run(x, IN_PTC, final='mean', in1=x1, impl=impl)['f32']
+
+    # The dense sampler's step: the tail of a reverse step -- conv6 on the spike counts, the token update and the NEXT step's
+    # first layer -- is ONE launch per image (csrc/step_tail.hip) instead of three launches and a logits round trip through
+    # memory.  False = conv6, spk_psample_step and conv1 as separate launches (same tokens).
+    use_step_tail = True
+
+    def tail_fusable(self, h, w):
+        """Can ``sample_step`` take the fused tail launch on an h x w latent?  (the reference's architecture on the certified
+        fp6 kernel family: 128 classes, 256 + 64 channels into conv6, T = 16, 7x7 or 8x8)"""
+        return (self.use_step_tail and self._fused_ok() and not self.training and not has_hooks(self) and self.collapse_conv6
+                and self.n_steps == 16 and (h, w) in ((7, 7), (8, 8)) and self.conv6[0].out_channels == 128
+                and self.conv6[0].in_channels == 320 and self.conv5[0].out_channels == 256 and self.conv1[0].out_channels == 64
+                and self.conv1[0].in_channels == 2 and self.impl_for(h, w, stateful=False) == 'mfma-fp6v2')
+
+    @torch.no_grad()
+    def sample_step(self, x_t, unmasked, t, temp, u=None, q=None, seed=0, offset=0, philox_state=None, pre1=None,
+                    want_next=True, want_logits=False):
+        """One DENSE reverse step of the sampler on this denoiser (R/snn_model/vq_diffusion.py:113-140 with the call of
+        :128-129 inside): x_t / unmasked are updated in place from the logits of ``self(x_t, t)`` (fresh LIF state, nothing
+        written back).  ``pre1``: the first layer's (spikes, counts) for this step as returned by the previous call;
+        ``want_next``: also evaluate it for step t - 1.  Returns (pre1 for the next step or None, logits or None)."""
+        functional.reset_net(self)
+        inp = None if pre1 is not None else ops.den_build_input(x_t, int(t))
+        x, cnt5, x1, cnt1, which, impl, collapse = self._trunk(inp, False, pre1=pre1)
+        conv6, packed6 = self._conv6_params()
+        conv1, bn1 = self.conv1[0], self.conv1[1]
+        nxt = None
+        if want_next:
+            a1, b1 = bn1.affine_terms()
+            nxt = (conv1._spk_params.get(conv1), None if conv1.bias is None else conv1.bias.detach(), a1, b1)
+        with ops.timed('den.tail'):
+            return ops.den_step_tail(cnt5, cnt1, packed6, x_t, unmasked, int(t), float(temp), T=self.n_steps,
+                                     K=conv6.out_channels, u=u, q=q, seed=seed, offset=offset, philox_state=philox_state,
+                                     conv1=nxt, want_logits=want_logits)
 
     def _run_train(self, x, t):
         """train() mode (R/snn_model/vq_diffusion.py:189-208 with batch-statistics BN and surrogate-gradient LIF): the

@@ -104,6 +104,8 @@ _SIGS = {
     "spk_den_build_input": (c_int, [P, P, P, c_longlong, P, c_int, c_int, P, P, P]),
     "spk_psample_step": (c_int, [P, P, P, c_int, c_float, P, P, c_ulonglong, c_ulonglong, P, P, c_int, c_int, c_int,
                                  P, P, P, P]),
+    "spk_den_step_tail": (c_int, [P, c_int, P, c_int, P, P, P, P, P, P, c_int, c_float, P, P, c_ulonglong, c_ulonglong, P, P, P,
+                                  P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_philox_noise": (c_int, [c_ulonglong, c_ulonglong, P, P, P, c_int, c_int, c_int, P]),
     "spk_checksum_multi": (c_int, [P, c_int, P, P]),
     "spk_clock_probe": (c_int, [P, c_int, c_int, P]),

@@ -1233,6 +1233,39 @@ def psample_step(logits, x_t, unmasked, t, temp=1.0, u=None, q=None, seed=0, off
     return x_t, unmasked
 
 
+def den_step_tail(cnt5, cnt1, packed6, x_t, unmasked, t, temp, *, T, K, u=None, q=None, seed=0, offset=0, philox_state=None,
+                  conv1=None, want_logits=False):
+    """The tail of one dense reverse step as one launch (spk_den_step_tail): conv6 on the spike counts + time mean, the token
+    update of ``psample_step`` (x_t / unmasked in place, same noise arguments) and -- with ``conv1 = (w_packed [9,2,64], bias,
+    bn_a, bn_b)`` -- the first denoiser layer of the next step.  Returns (x1 S32 [B,2,h,w,16,16], cnt1 u8 [B,2,h,w,32]) or None,
+    and the logits fp32 [B,K,h,w] when asked for."""
+    cnt5 = _dev(cnt5, "cnt5", torch.uint8)
+    cnt1 = _dev(cnt1, "cnt1", torch.uint8)
+    B, nch5, H, W, _ = cnt5.shape
+    wq, scale, bias_d = packed6
+    if x_t.dtype != torch.int64 or not x_t.is_contiguous() or x_t.numel() != B * H * W:
+        raise ValueError("x_t must be a contiguous int64 device tensor [B,1,h,w]")
+    if unmasked.dtype not in (torch.bool, torch.uint8) or not unmasked.is_contiguous() or unmasked.numel() != B * H * W:
+        raise ValueError("unmasked must be a contiguous bool/uint8 device tensor [B,1,h,w]")
+    if u is not None:
+        u = _dev(u, "u", torch.float32)
+    if q is not None:
+        q = _dev(q, "q", torch.float32)
+        if q.numel() != B * H * W * K:
+            raise ValueError("q must have B*HW*K entries")
+    logits = torch.empty((B, K, H, W), dtype=torch.float32, device=cnt5.device) if want_logits else None
+    x1 = c1o = w1 = b1 = a1 = bb1 = None
+    if conv1 is not None:
+        w1, b1, a1, bb1 = conv1
+        x1 = torch.empty((B, 2, H, W, T, 16), dtype=C4_DTYPE, device=cnt5.device)
+        c1o = torch.empty((B, 2, H, W, 32), dtype=torch.uint8, device=cnt5.device)
+    check(lib.spk_den_step_tail(_p(cnt5), int(nch5), _p(cnt1), int(cnt1.shape[1]), _p(wq), _p(scale), _p(bias_d), _p(logits),
+                                _p(x_t), _p(unmasked), int(t), float(temp), _p(u), _p(q), int(seed), int(offset),
+                                _p(philox_state), _p(w1), _p(b1), _p(a1), _p(bb1), _p(x1), _p(c1o), int(T), B, H, W, int(K),
+                                _stream(cnt5)), "spk_den_step_tail")
+    return (None if x1 is None else (x1, c1o)), logits
+
+
 def philox_noise(seed, offset, B, HW, K, device, philox_state=None, want_q=True):
     """The (u [B*HW], q [B*HW, K]) a Philox-mode reverse step with these (seed, offset, philox_state) arguments draws
     (spk_philox_noise): parity aid -- the oracle run on the dumped noise must reproduce the Philox-mode tokens."""

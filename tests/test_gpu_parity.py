@@ -2127,3 +2127,78 @@ def test_certified_kernel_workspaces_are_per_stream(dev, ops):
     keys = [k for k in ops._FLAG_DEFAULT if k[0] == "den"]
     assert len({k[2] for k in keys}) >= 3, "one workspace set per stream"
     assert bad == 0
+
+
+# ------------------------------------------------------------------------------------------------- round 3: fused step tail
+@pytest.mark.parametrize("cfg,L,B", [(synth.MNIST, 7, 37), (synth.CIFAR, 8, 19)])
+def test_step_tail_equals_the_three_launches_it_replaces(dev, ops, cfg, L, B):
+    """spk_den_step_tail == spk_den_conv3x3_counts_mfma + spk_psample_step + the first layer's spk_conv_fused_fwd, bit for bit:
+    logits, tokens, unmasked, the next step's conv1 spikes (S32) and spike counts; Philox and injected noise; last step (no
+    successor)."""
+    den, _ = build_den(cfg, dev)
+    g = torch.Generator().manual_seed(17)
+    HW, K = L * L, 128
+    for trial, t in enumerate((57, 3, 1)):
+        x0 = torch.randint(0, K, (B, 1, L, L), generator=g)
+        un0 = torch.rand(B, 1, L, L, generator=g) < 0.5
+        x0[~un0] = K
+        x0, un0 = x0.to(dev), un0.to(dev)
+        inp = ops.den_build_input(x0, t)
+        x5, cnt5, x1, cnt1, which, impl, collapse = den._trunk(inp, False)
+        assert which == 'mfma-fp6v2' and collapse
+        conv6, packed6 = den._conv6_params()
+        logits = ops.den_conv3x3_counts(cnt5, packed6, K, 16, cnt1=cnt1)
+        inject = trial == 1
+        u = q = None
+        if inject:
+            u = torch.rand(B * HW, generator=g).to(dev)
+            q = torch.empty(B * HW, K).exponential_(1, generator=g).to(dev)
+        xa, una = x0.clone(), un0.clone()
+        nxt = torch.empty((B, 2, L, L), dtype=torch.float32, device=dev)
+        ops.psample_step(logits, xa, una, t, 0.9, u, q, seed=4242, offset=1000 * t, next_input=nxt if t > 1 else None)
+        xb, unb = x0.clone(), un0.clone()
+        conv1, bn1 = den.conv1[0], den.conv1[1]
+        a1, b1 = bn1.affine_terms()
+        c1 = (conv1._spk_params.get(conv1), conv1.bias.detach(), a1, b1) if t > 1 else None
+        pre, lg = ops.den_step_tail(cnt5, cnt1, packed6, xb, unb, t, 0.9, T=16, K=K, u=u, q=q, seed=4242, offset=1000 * t,
+                                    conv1=c1, want_logits=True)
+        assert torch.equal(lg, logits), float((lg - logits).abs().max())
+        assert torch.equal(xa, xb) and torch.equal(una, unb)
+        assert int(unb.sum()) > int(un0.sum()) or t > 20
+        if t > 1:
+            r1 = den.conv1.run(nxt, ops.IN_TINV, final='ptc', T=16, stateful=False, chunk_out=ops.CHUNK_S32, want_counts=True)
+            assert torch.equal(pre[0], r1['ptc']) and torch.equal(pre[1], r1['cnt'])
+        else:
+            assert pre is None
+
+
+@pytest.mark.parametrize("cfgname,L", [("mnist", 7), ("cifar", 8)])
+def test_sampler_with_and_without_the_fused_step_tail(dev, cfgname, L):
+    """Dense sampling with the fused tail launch == with the three separate launches: graph replay, eager launches, host noise."""
+    from snn_model.vq_diffusion import AbsorbingDiffusion
+    cfg = synth.MNIST if cfgname == "mnist" else synth.CIFAR
+    den, _ = build_den(cfg, dev)
+    out = {}
+    for tail in (True, False):
+        den.use_step_tail = tail
+        for mode in ("graph", "eager", "host"):
+            ab = AbsorbingDiffusion(den, mask_id=128, latent_shape=(L, L))
+            ab.n_samples, ab.skip_untouched = 21, False
+            ab.use_graph = mode == "graph"
+            ab.noise_source = 'host' if mode == "host" else 'philox'
+            torch.manual_seed(5)
+            out[(tail, mode)] = ab.sample(temp=1.0, sample_steps=30).cpu()
+            if mode == "graph":
+                assert len(ab._graphs) == 1
+    den.use_step_tail = True
+    for mode in ("graph", "eager", "host"):
+        assert torch.equal(out[(True, mode)], out[(False, mode)]), mode
+    assert torch.equal(out[(True, "graph")], out[(True, "eager")])
+    rec = []
+    ab = AbsorbingDiffusion(den, mask_id=128, latent_shape=(L, L))
+    ab.n_samples, ab.noise_source = 5, 'host'
+    torch.manual_seed(6)
+    tok = ab.sample(temp=1.0, sample_steps=8, record=rec)
+    assert len(rec) == 8 and rec[0][3].shape == (5, 128, L, L) and torch.equal(rec[-1][1], tok)
+    lg = den.logits_from_tokens(rec[3][1], rec[4][0])                    # the logits recorded at a step == a plain denoiser call
+    assert torch.equal(lg, rec[4][3])
