@@ -62,7 +62,7 @@ extern "C" int spk_checksum_multi(const unsigned long long* table_dev, int n, un
   if (!table_dev || !out1 || n <= 0) return SPK_ERR_ARG;
   hipError_t e = hipMemsetAsync(out1, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(checksum_multi_kernel, dim3(16, n < 64 ? n : 64), dim3(256), 0, stream, table_dev, n, out1);
+  hipLaunchKernelGGL(checksum_multi_kernel, dim3(128, n < 32 ? n : 32), dim3(256), 0, stream, table_dev, n, out1);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

@@ -27,6 +27,15 @@ constexpr int TW_CHUNK = 9 * 2 * 32 * TCK;        // 18432 B of packed weights p
 constexpr int TNCH = 10;                          // 8 chunks of conv5 counts + 2 of conv1 counts (256 + 64 channels)
 constexpr int TK = 128;                           // classes = conv6 output channels
 constexpr int TLP = TK + 4;                       // LDS pitch of a logits row
+#ifndef SPK_TAIL_PF
+#define SPK_TAIL_PF 8                             // weight tiles are requested this many taps ahead of their MFMAs
+#endif
+#ifndef SPK_TAIL_ROT
+#define SPK_TAIL_ROT 1
+#endif
+#ifndef SPK_TAIL_DBG
+#define SPK_TAIL_DBG 0                            // timing experiments only (wrong results): 1 no K loop, 2 no token update, 4 no conv1
+#endif
 
 struct TailArgs {
   const uint8_t* c5; const uint8_t* c1;           // spike counts u8 [B][8][HW][32], [B][2][HW][32]
@@ -49,6 +58,7 @@ __global__ __launch_bounds__(512, 1) void step_tail_kernel(TailArgs a) {
   __shared__ v4i s_a[TNCH * AV];
   __shared__ float s_logit[64][TLP];
   __shared__ float s_tok[64];
+  __shared__ int s_chg[64];
   __shared__ float s_th[16];
   __shared__ unsigned s_pat[18];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -59,12 +69,16 @@ __global__ __launch_bounds__(512, 1) void step_tail_kernel(TailArgs a) {
   // ---- this wave's weight stream: tile (c, tap, j) = 1 KiB, 16 bytes per lane; requested D taps ahead of their MFMAs
   const int boff = (lane & 31) * TCK + 16 * (half ^ ((lane >> 4) & 1));
   const int8_t* const wg = a.wq + (long long)g * TNCH * TW_CHUNK + boff;
-  constexpr int NIT = TNCH * 9, D = 8;
+  // every workgroup reads the same 1.4 MB of packed weights: workgroups of one XCD (blocks k, k + 8, ...) start at different
+  // chunks so that they do not all ask the L2 for the same lines at the same time (exact integer sums: any order)
+  const int rot = SPK_TAIL_ROT ? (int)((blockIdx.x >> 3) % TNCH) : 0;
+  auto chunk_of = [&](int i) -> int { const int c = i / 9 + rot; return c >= TNCH ? c - TNCH : c; };
+  constexpr int NIT = TNCH * 9, D = SPK_TAIL_PF;
   v4i bq[D][2];
 #pragma unroll
   for (int i = 0; i < D; ++i) {
-    bq[i][0] = *reinterpret_cast<const v4i*>(wg + (i / 9) * TW_CHUNK + ((i % 9) * 2 + 0) * 32 * TCK);
-    bq[i][1] = *reinterpret_cast<const v4i*>(wg + (i / 9) * TW_CHUNK + ((i % 9) * 2 + 1) * 32 * TCK);
+    bq[i][0] = *reinterpret_cast<const v4i*>(wg + chunk_of(i) * TW_CHUNK + ((i % 9) * 2 + 0) * 32 * TCK);
+    bq[i][1] = *reinterpret_cast<const v4i*>(wg + chunk_of(i) * TW_CHUNK + ((i % 9) * 2 + 1) * 32 * TCK);
   }
 
   // ---- the image's count records -> LDS
@@ -75,6 +89,36 @@ __global__ __launch_bounds__(512, 1) void step_tail_kernel(TailArgs a) {
     s_a[c * AV + r] = *reinterpret_cast<const v4i*>(src);
   }
   if (tid < TNCH) s_a[tid * AV + HW * 2] = (v4i){0, 0, 0, 0};
+  // ---- which positions change at this step, and the tokens as they are: one thread per position, up front (fetched row by row
+  //      in the sampling loop these were seven dependent memory round trips per wave)
+  unsigned long long seed = a.seed, offset = a.offset;
+  if (a.philox_state) { seed = a.philox_state[0]; offset += a.philox_state[1]; }
+  const float inv_t = 1.0f / (float)a.t;
+  if (tid < HW) {
+    const long long pi = (long long)b * HW + tid;
+    const uint8_t um = a.unmasked[pi];
+    const long long tk = a.x_t[pi];
+    float u;
+    if (a.u_in) u = a.u_in[pi];
+    else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)pi, 0u, r); u = u01_open_right(r[0]); }
+    s_chg[tid] = ((u < inv_t) && !um) ? 1 : 0;
+    s_tok[tid] = (float)tk;
+  }
+  // ---- per-channel constants of the read-out and of the next step's first layer, requested before the K loop
+  const int col_e = lane & 31, co_e = g * 16 + (col_e & 15);
+  const double sc_e = a.scale[co_e], bT_e = a.bias[co_e] * (double)a.T;
+  float wreg[18];
+  float al1 = 0.f, be1 = 0.f;
+  double b01 = 0.0;
+  if (a.x1_out) {
+#pragma unroll
+    for (int i = 0; i < 18; ++i) wreg[i] = a.w1[i * 64 + lane];        // packed [k * k][Cin = 2][Cout = 64]
+    al1 = a.bn1_a[lane]; be1 = a.bn1_b[lane];
+    b01 = a.b1 ? (double)a.b1[lane] : 0.0;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 18; ++i) wreg[i] = 0.f;
+  }
   {
     constexpr unsigned thb[16] = SPK_LIF_CONST_TH_BITS, pat[18] = SPK_LIF_CONST_PATTERNS;
     if (tid < 16) s_th[tid] = __uint_as_float(thb[tid]);
@@ -101,12 +145,12 @@ __global__ __launch_bounds__(512, 1) void step_tail_kernel(TailArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rt][j][r] = 0;
 #pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const int c = i / 9, tap = i % 9;
+  for (int i = 0; i < ((SPK_TAIL_DBG & 1) ? D : NIT); ++i) {
+    const int c = chunk_of(i), tap = i % 9;
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
     const v4i b0 = bq[i % D][0], b1 = bq[i % D][1];
     if (i + D < NIT) {
-      const int c2 = (i + D) / 9, tap2 = (i + D) % 9;
+      const int c2 = chunk_of(i + D), tap2 = (i + D) % 9;
       bq[i % D][0] = *reinterpret_cast<const v4i*>(wg + c2 * TW_CHUNK + (tap2 * 2 + 0) * 32 * TCK);
       bq[i % D][1] = *reinterpret_cast<const v4i*>(wg + c2 * TW_CHUNK + (tap2 * 2 + 1) * 32 * TCK);
     }
@@ -122,9 +166,9 @@ __global__ __launch_bounds__(512, 1) void step_tail_kernel(TailArgs a) {
 
   // ---- digit recombination (fp64, one rounding), mean over T, logits -> LDS (and to memory on request)
   {
-    const int col = lane & 31, ch = col & 15, odd = col >> 4;
-    const int co = g * 16 + ch;
-    const double sc = a.scale[co], bT = a.bias[co] * (double)a.T;
+    const int odd = col_e >> 4;
+    const int co = co_e;
+    const double sc = sc_e, bT = bT_e;
     const float invT = 1.0f / (float)a.T;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -147,19 +191,9 @@ __global__ __launch_bounds__(512, 1) void step_tail_kernel(TailArgs a) {
   __syncthreads();
 
   // ---- p_sample: wave w takes positions w, w + 8, ...; only positions that change at this step consume a sample (:140)
-  unsigned long long seed = a.seed, offset = a.offset;
-  if (a.philox_state) { seed = a.philox_state[0]; offset += a.philox_state[1]; }
-  const float inv_t = 1.0f / (float)a.t;
-  for (int p = wave; p < HW; p += 8) {
+  for (int p = wave; p < ((SPK_TAIL_DBG & 2) ? 0 : HW); p += 8) {
     const long long pi = (long long)b * HW + p;
-    float u;
-    if (a.u_in) u = a.u_in[pi];
-    else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)pi, 0u, r); u = u01_open_right(r[0]); }
-    const bool change = (u < inv_t) && !a.unmasked[pi];                 // (wave-uniform)
-    if (!change) {
-      if (lane == 0) s_tok[p] = (float)a.x_t[pi];
-      continue;
-    }
+    if (!s_chg[p]) continue;                                            // (wave-uniform; s_tok[p] holds the token it keeps)
     float l[2], e[2];
     float mx = -INFINITY;
 #pragma unroll
@@ -201,17 +235,14 @@ __global__ __launch_bounds__(512, 1) void step_tail_kernel(TailArgs a) {
       s_tok[p] = (float)besti;
     }
   }
-  if (!a.x1_out) return;                                               // (uniform: the last reverse step has no successor)
+  if (!a.x1_out || (SPK_TAIL_DBG & 4)) return;                         // (uniform: the last reverse step has no successor)
   __syncthreads();
 
   // ---- the next step's first layer: conv1(cat(x_t, t - 1)) + BN + LIF from the reset state -> S32 spikes + spike counts
   {
     const int co = lane, pl = wave;                                    // 64 output channels, eight positions per pass
-    float wreg[18];
-#pragma unroll
-    for (int i = 0; i < 18; ++i) wreg[i] = a.w1[i * 64 + co];          // packed [k * k][Cin = 2][Cout = 64]
-    const float al = a.bn1_a[co], be = a.bn1_b[co];
-    const double b0 = a.b1 ? (double)a.b1[co] : 0.0;
+    const float al = al1, be = be1;
+    const double b0 = b01;
     for (int p0 = 0; p0 < HW; p0 += 8) {
       const int opr = p0 + pl;
       const bool ok = opr < HW;

@@ -15,6 +15,8 @@ den = DummyModel(1, cfg.num_embeddings).cuda(0)
 functional.set_step_mode(net=den, step_mode='m')
 den.load_state_dict(synth.synth_denoiser_state(cfg))
 den.eval()
+if os.environ.get('SPKDIFF_NO_TAIL') == '1':          # A/B: the three separate launches instead of the fused step tail
+    den.use_step_tail = False
 res = {}
 for name, skip, lists, radii in (("dense", False, False, 4), ("elim", True, False, 4), ("elim+lists4", True, True, 4),
                                  ("elim+lists3", True, True, 3), ("elim+lists2", True, True, 2), ("elim+lists1", True, True, 1)):
