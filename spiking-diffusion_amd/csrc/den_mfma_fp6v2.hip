@@ -104,6 +104,9 @@ struct V2Args {
 #ifndef SPK_V2_SPARE
 #define SPK_V2_SPARE 1.0f       // four-digit form: factor on the certification bound (2.0f = the first builds' spare factor)
 #endif
+#ifndef SPK_V2_LAG_DEFAULT
+#define SPK_V2_LAG_DEFAULT 0    // 1: full 7x7 batches run the staggered form (conv3x3_fp6v2_lag_kernel); SPKDIFF_V2_LAG=0/1 overrides
+#endif
 #ifndef SPK_V2_PF
 #define SPK_V2_PF 6             // A fragments requested this many steps ahead of the MFMA that consumes them
 #endif
@@ -622,6 +625,299 @@ __device__ __forceinline__ void fp6v2_handover(const V2Args& a) {
       a.flags[a.ticket_idx] = 0u;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------ staggered form (experiment)
+// The two waves of a SIMD run the same program and meet at every chunk barrier, so both reach the item's LIF scan together and
+// the matrix pipe idles for its whole length (19 % of den.conv4).  Here waves 4..7 run ONE CHUNK BEHIND waves 0..3 (MI355X guide,
+// "two waves that run the same program: try a stagger"): the item loop is a sequence of ticks (one barrier each); at tick k the
+// first set multiplies chunk n, the second chunk n - 1, and the copy engine fills chunk n + 1 -- a ring of THREE LDS slots
+// (139 KB).  At an item boundary one set scans while the other still multiplies: the scan's vector work runs beside MFMAs.
+// The active-input counts no longer need workgroup barriers inside the scan: every thread counts the records of the FIRST set's
+// chunk, the sums are published in the tick of that set's last chunk (they stay valid until both sets have scanned), and a wave
+// adds the nine taps of its own tiles' rows itself (32 lanes, a wave-private LDS line).  Full 7x7 items, eight waves, four digits.
+// MEASURED (round 3, B = 256, same box, bit-equal to the default form on every fp6v2 test): den.conv2 / 3 / 4 / 5 launches
+// 55.5 / 137 / 411 / 399 us against 49 / 124 / 390 / 384 us, the dense reverse process 100.6 against 95.1 ms -- 4 - 13 % SLOWER:
+// a wave that scans ALONE issues its 750 vector instructions at half the rate two scanning waves reach together (they hide each
+// other's compare -> select -> subtract latency), and it shares the SIMD's issue slots with the partner's MFMAs; the partner has
+// finished its chunk (54 MFMAs) long before and waits at the tick barrier.  Kept as an opt-in (SPKDIFF_V2_LAG=1) so that the
+// measurement can be repeated; tests/test_gpu_parity.py::test_fp6v2_staggered_form_bit_equal runs it.
+template <int H, int W>
+__device__ __forceinline__ void fp6v2_body_lag(const V2Args& a, const int g, const int il, const int lanes, const int n_images) {
+  static_assert(!USE_D4, "four-digit form");
+  constexpr int NWV = 8, HW = H * W, PW = W + 1, NT = (HW / 2) / NWV, N_AGPR = NACC * NT < 8 ? NACC * NT : 8;
+  static_assert((HW & 1) == 1 && ((HW / 2) % NWV) == 0, "whole 32-row tiles on every wave (+ one odd position)");
+  constexpr int NPP = (H + 2) * PW + 1, A_BYTES = NPP * POSB, PPR = (W + 3) / 4, NA = H * PPR;
+  constexpr int NPA = (NA + NWV - 1) / NWV, NPW = (W_PIECES + NWV - 1) / NWV, NPIECES = NPA + NPW;
+  constexpr int NSTEP = 9 * NT, NRING = 3;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  uint8_t* const sA = lds;
+  uint8_t* const sW = lds + NRING * A_BYTES;
+  int* const s_cin = reinterpret_cast<int*>(lds + NRING * (A_BYTES + W_LDS));       // [NPP][16], borders stay zero
+  int* const s_nw = s_cin + NPP * 16;                                               // [NWV][32]: a wave's row counts of one tile
+  const unsigned sA_addr = spk_lds_addr(sA), sW_addr = sA_addr + NRING * A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nch = a.nch, G = a.Cout >> 5;
+  for (int i = tid; i < NRING * A_BYTES / 16; i += NWV * 64) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < NPP * 16; i += NWV * 64) s_cin[i] = 0;
+  __syncthreads();
+
+  const int row = lane & 31, half = lane >> 5;
+  const int hsel = (row >> 2) & 1, tt = (row & 3) + 4 * (row >> 3);
+  int a_off[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int p = 2 * (wave + NWV * i) + hsel;
+    a_off[i] = ((p / W) * PW + (p % W)) * POSB + tt * 16;
+  }
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const bool late = wave_s >= NWV / 2;                     // the second wave of every SIMD: one tick behind
+  unsigned pa_pk[NPA];
+#pragma unroll
+  for (int j = 0; j < NPA; ++j) {
+    int id = wave_s * NPA + j;
+    id = id < NA ? id : NA - 1;
+    const int y = id / PPR, px = id - y * PPR;
+    const int np = (W - 4 * px) < 4 ? (W - 4 * px) : 4;
+    const unsigned src = (unsigned)((y * W + 4 * px) * POSB), dst = (unsigned)(((y + 1) * PW + 1 + 4 * px) * POSB);
+    pa_pk[j] = src | (dst << 14) | ((unsigned)(np - 1) << 29);
+  }
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const unsigned wave_k = (unsigned)wave_s * 1024u;
+  auto issue_piece = [&](int q, const uint8_t* aslab, const uint8_t* wslab, unsigned dA, unsigned dW) {
+    if (q < NPA) {
+      const unsigned pk = pa_pk[q];
+      const unsigned np = ((pk >> 29) & 3u) + 1u;
+      const unsigned long long mask = np == 4 ? ~0ull : ((1ull << (16 * np)) - 1ull);
+      spk_dma16s_masked(aslab + (pk & 0x3fffu), lane16, dA + ((pk >> 14) & 0x7fffu), mask);
+    } else {
+      unsigned ko = wave_k + 1024u * NWV * (unsigned)(q - NPA);
+      if (NWV * (q - NPA) + NWV - 1 >= W_PIECES) ko = ko < (unsigned)W_PIECES * 1024u ? ko : ko - 1024u * NWV;
+      spk_dma16s(wslab + ko, lane16, dW + ko);
+    }
+  };
+  const uint8_t* const wbase = a.wq + (long long)g * nch * W_SLAB;
+  auto aslab_of = [&](int itm, int c) -> const uint8_t* { return a.in0 + ((long long)itm * nch + c) * HW * POSB; };
+  const int my_items = il < n_images ? (n_images - il + lanes - 1) / lanes : 0;
+
+  const int co = g * 32 + (lane & 31);
+  const float scale_f = (float)a.scale[co], bias_f = (float)a.bias[co];
+  const float bna = a.bn_a[co], bnb = a.bn_b[co];
+  const float Bc = fmaf(bias_f, bna, bnb);
+  const float cE = 2.0f * 2.38418579e-07f * (fabsf(bnb) + fabsf(Bc)) + 1e-30f;
+  const float cT = 528.0f * scale_f * fabsf(bna) * 1.000001f;
+  const float Ac4 = 1024.0f * scale_f * bna;
+  const int sc_a = 0x7f7f7f7f;
+  const int sc_p = half ? (int)0x82828282u : (int)0x87878787u;
+
+  // record counts: thread r counts NR (cell, step) records of the FIRST set's current chunk
+  constexpr int NREC = H * W * 16, NR = (NREC + NWV * 64 - 1) / (NWV * 64);
+  int creg[NR], rec_off[NR];
+  bool rec_ok[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    creg[k] = 0;
+    const int r = tid + k * NWV * 64;
+    const int cl = r >> 4, t = r & 15;
+    rec_ok[k] = r < NREC;
+    rec_off[k] = rec_ok[k] ? (((cl / W) + 1) * PW + 1 + (cl % W)) * POSB + t * 16 : 0;
+  }
+
+  // ---- the tick machine: state of the FIRST set (every wave tracks it: it decides what is copied and counted)
+  int tick = 0;                                            // ticks begun
+  int fk = 0, fph = 0, fslot = 0;                          // first set at this tick: item ordinal, phase (nch = scan), ring slot
+  bool have_next = false;
+  const uint8_t* n_aslab = nullptr; const uint8_t* n_wslab = nullptr;
+  unsigned n_dA = 0, n_dW = 0;
+  if (my_items > 0) {
+    const uint8_t* as0 = aslab_of(il, 0);
+#pragma unroll
+    for (int q = 0; q < NPIECES; ++q) issue_piece(q, as0, wbase, sA_addr, sW_addr);
+  }
+  // One call per tick by EVERY wave: barrier, then (all threads) count the first set's chunk, publish at its last chunk, and
+  // work out what the copy engine fills during this tick (the first set's chunk of the NEXT tick).
+  auto begin_tick = [&]() {
+    spk_dma_wait_all();
+    __syncthreads();
+    const bool f_act = fk < my_items;
+    if (f_act && fph < nch) {
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const v4i rv = *reinterpret_cast<const v4i*>(sA + fslot * A_BYTES + rec_off[k]);
+        creg[k] += __builtin_popcount((unsigned)rv[0]) + __builtin_popcount((unsigned)rv[1]) +
+                   __builtin_popcount((unsigned)rv[2]) + __builtin_popcount((unsigned)rv[3]);
+      }
+      if (fph == nch - 1) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          if (rec_ok[k]) s_cin[(rec_off[k] / POSB) * 16 + ((rec_off[k] % POSB) >> 4)] = creg[k];
+          creg[k] = 0;
+        }
+      }
+    }
+    // the first set's state at the next tick
+    int nk = fk, nph = fph + 1, nslot = fslot;
+    if (nph > nch) { nph = 0; nk = fk + 1; }
+    if (fph < nch) nslot = fslot == NRING - 1 ? 0 : fslot + 1;       // (a scan tick consumes no slot)
+    have_next = f_act && nk < my_items && nph < nch;
+    if (have_next) {
+      n_aslab = aslab_of(il + nk * lanes, nph);
+      n_wslab = wbase + (long long)nph * W_SLAB;
+      n_dA = sA_addr + nslot * A_BYTES;
+      n_dW = sW_addr + nslot * W_LDS;
+    }
+    fk = nk; fph = nph;
+    if (have_next || !f_act) fslot = nslot; else fslot = nslot;
+    ++tick;
+  };
+  auto issue_all = [&]() {
+    if (have_next) {
+#pragma unroll
+      for (int q = 0; q < NPIECES; ++q) issue_piece(q, n_aslab, n_wslab, n_dA, n_dW);
+    }
+  };
+
+  if (late) { begin_tick(); issue_all(); }                 // the second set idles through the first tick
+  int oslot = 0;                                           // this wave's own ring slot (its chunk sequence number mod 3)
+  for (int k = 0; k < my_items; ++k) {
+    const int b = il + k * lanes;
+    v16f acc[NT][NACC];
+    for (int c = 0; c < nch; ++c) {
+      begin_tick();
+      const uint8_t* A = sA + oslot * A_BYTES;
+      const uint8_t* Wb = sW + oslot * W_LDS;
+      auto compute = [&](auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        auto toff = [](int tap) constexpr -> int { return ((tap / 3) * PW + (tap % 3)) * POSB; };
+        auto lda = [&](auto s_tag) -> v4i {
+          constexpr int s = decltype(s_tag)::value;
+          return *reinterpret_cast<const v4i*>(A + a_off[s % NT] + toff(s / NT));
+        };
+        auto ldb = [&](int tile) -> v6i {
+          const uint8_t* p = Wb + tile * WT;
+          const v4i x = *reinterpret_cast<const v4i*>(p + lane * 16);
+          typedef const volatile __attribute__((address_space(3))) v2i* lds_v2i_ptr;
+          const v2i y = *(lds_v2i_ptr)SPK_LDS(p + 1024 + lane * 8);
+          const v6i r = {x[0], x[1], x[2], x[3], y[0], y[1]};
+          return r;
+        };
+        v6i bp[2][2];
+        bp[0][0] = ldb(0); bp[0][1] = ldb(1);
+        constexpr int PF = 4;
+        v4i af[PF];
+        static_for<PF>([&](auto s_tag) { af[decltype(s_tag)::value] = lda(s_tag); });
+        static_for<NSTEP>([&](auto s_tag) {
+          constexpr int s = decltype(s_tag)::value;
+          constexpr int tap = s / NT, i = s % NT;
+          const v4i av = af[s % PF];
+          if constexpr (s + PF < NSTEP) af[s % PF] = lda(std::integral_constant<int, s + PF>{});
+#define V2L_PAIR_MFMA(J)                                                                                    \
+  do {                                                                                                      \
+    if constexpr (FIRST && tap == 0) {                                                                      \
+      if constexpr (NACC * i + (J) < N_AGPR) SPK_MFMA2_Z("a", acc[i][J], av, bp[0][J], sc_a, sc_p);          \
+      else SPK_MFMA2_Z("v", acc[i][J], av, bp[0][J], sc_a, sc_p);                                           \
+    } else {                                                                                                \
+      if constexpr (NACC * i + (J) < N_AGPR) SPK_MFMA2("a", acc[i][J], av, bp[tap & 1][J], sc_a, sc_p);      \
+      else SPK_MFMA2("v", acc[i][J], av, bp[tap & 1][J], sc_a, sc_p);                                       \
+    }                                                                                                       \
+  } while (0)
+          V2L_PAIR_MFMA(0);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (i == 0 && 2 * tap < NPIECES) {
+            if (have_next) issue_piece(2 * tap, n_aslab, n_wslab, n_dA, n_dW);
+          }
+          if constexpr (i == (NT > 1 ? NT / 2 : 0) && 2 * tap + 1 < NPIECES) {
+            if (have_next) issue_piece(2 * tap + 1, n_aslab, n_wslab, n_dA, n_dW);
+          }
+          if constexpr (i == 0 && tap + 1 < 9) {
+            bp[(tap + 1) & 1][0] = ldb(2 * (tap + 1));
+            bp[(tap + 1) & 1][1] = ldb(2 * (tap + 1) + 1);
+          }
+          V2L_PAIR_MFMA(1);
+          __builtin_amdgcn_sched_barrier(0);
+#undef V2L_PAIR_MFMA
+        });
+      };
+      if (c == 0) compute(std::true_type{}); else compute(std::false_type{});
+      oslot = oslot == NRING - 1 ? 0 : oslot + 1;
+    }
+    // ---- this set's scan tick: its copies first, then the epilogue beside the other set's MFMAs
+    begin_tick();
+    issue_all();
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int kk = 0; kk < NT; ++kk) {
+      const int i = kk == 0 ? NT - 1 : kk - 1;
+#pragma unroll
+      for (int j = 0; j < NACC; ++j)
+        if (NACC * i + j < N_AGPR) asm volatile("" : "+a"(acc[i][j]));
+      const int ti = wave + NWV * i;
+      // active inputs of the tile's 32 rows: lane l < 32 adds the nine taps of (position 2 ti + (l >> 4), step l & 15)
+      {
+        const int pp = 2 * ti + ((lane >> 4) & 1), t = lane & 15;
+        const int* c0 = s_cin + ((pp / W) * PW + (pp % W)) * 16 + t;
+        int sum = 0;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) sum += c0[(dy * PW + dx) * 16];
+        if (lane < 32) s_nw[wave * 32 + lane] = sum;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      int cntv[16];
+      {
+        const v4i* rp = reinterpret_cast<const v4i*>(s_nw + wave * 32 + half * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const v4i c4 = rp[q];
+          cntv[4 * q] = c4[0]; cntv[4 * q + 1] = c4[1]; cntv[4 * q + 2] = c4[2]; cntv[4 * q + 3] = c4[3];
+        }
+      }
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      float v = 0.f, zmax = 0.f, dmin = 3.0e38f;
+      unsigned mybits = 0;
+      int nmax = 0;
+#pragma unroll
+      for (int r2 = 0; r2 < 16; r2 += 2) {
+        const v2f p0 = {acc[i][0][r2], acc[i][0][r2 + 1]}, p1 = {acc[i][1][r2], acc[i][1][r2 + 1]};
+        const v2f q4 = __builtin_elementwise_fma(p0, (v2f){1024.0f, 1024.0f}, p1);
+        const v2f z2 = __builtin_elementwise_fma(q4, (v2f){Ac4, Ac4}, (v2f){Bc, Bc});
+        nmax = max(nmax, max(cntv[r2], cntv[r2 + 1]));
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float z = z2[e];
+          zmax = fmaxf(zmax, fabsf(z));
+          const float h = fmaf(z - v, 0.5f, v);
+          dmin = fminf(dmin, fabsf(h - 1.0f));
+          const bool sp = h >= 1.0f;
+          v = sp ? 0.0f : h;
+          mybits |= sp ? (1u << (r2 + e)) : 0u;
+        }
+      }
+      const bool flg = dmin <= SPK_V2_SPARE * fmaf(zmax, 2.5f * CERT_4EPS, fmaf((float)nmax, cT, cE));
+      const int p = 2 * ti + half;
+      if (flg && !(SPK_V2_DBG & 32)) {
+        const long long n = ((long long)b * a.Cout + co) * HW + p;
+        const unsigned idx = atomicAdd(a.flags, 1u);
+        if (idx < a.flag_cap) a.flags[2 + idx] = (unsigned)n;
+        else atomicOr(a.flags + 2 + a.flag_cap + (n >> 5), 1u << (n & 31));
+      }
+      const long long rec = (((long long)b * G + g) * HW + p) * POSB;
+      store_tile_spikes(a.out, a.out_cnt, mybits, lane, rec, (((long long)b * G + g) * HW + p) * 32, true);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (!late) { begin_tick(); issue_all(); }                // the first set waits out the second set's last tick
+  spk_dma_wait_all();
+}
+
+template <int H, int W>
+__global__ __launch_bounds__(512, 1) void conv3x3_fp6v2_lag_kernel(V2Args a) {
+  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
+  int g, il, lanes;
+  fp6v2_wg_map(a, g, il, lanes);
+  fp6v2_body_lag<H, W>(a, g, il, lanes, Bn);
+  fp6v2_handover(a);
 }
 
 template <int H, int W, int NWV, bool SPLIT = false>
@@ -1152,10 +1448,15 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   // MFMAs, there is power to spare, and the second wave is worth 8 % of the reverse process (a third one -- 12 waves of two
   // tiles, 84 + 84 registers and 72 B of spills -- loses 5 % again).  SPKDIFF_V2_WAVES=4: one wave.
   static const bool eight = [] { const char* e = getenv("SPKDIFF_V2_WAVES"); return !(e && e[0] == '4'); }();
+  static const bool lag_form = [] { const char* e = getenv("SPKDIFF_V2_LAG"); return e ? e[0] == '1' : (SPK_V2_LAG_DEFAULT != 0); }();
   if (need) {
     if (grid / G < 6) return SPK_ERR_UNSUPPORTED;           // one image lane per tile-count class at least
     if (eight) hipLaunchKernelGGL((conv3x3_fp6v2_listed_kernel<7, 7, 8>), dim3(grid), dim3(512), lds, stream, a);
     else hipLaunchKernelGGL((conv3x3_fp6v2_listed_kernel<7, 7, 4>), dim3(grid), dim3(256), lds, stream, a);
+  } else if (eight && lag_form) {
+    // (staggered experiment: three ring slots + counters + one 128-byte line per wave)
+    const size_t lds3 = 3 * ((size_t)a_bytes + W_LDS) + (size_t)(a_bytes / POSB) * 64 + 8 * 128;
+    hipLaunchKernelGGL((conv3x3_fp6v2_lag_kernel<7, 7>), dim3(grid), dim3(512), lds3, stream, a);
   } else if (eight) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 8>), dim3(grid), dim3(512), lds, stream, a);
   else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 4>), dim3(grid), dim3(256), lds, stream, a);
   SPK_LAUNCH_CHECK();

@@ -2202,3 +2202,42 @@ def test_sampler_with_and_without_the_fused_step_tail(dev, cfgname, L):
     assert len(rec) == 8 and rec[0][3].shape == (5, 128, L, L) and torch.equal(rec[-1][1], tok)
     lg = den.logits_from_tokens(rec[3][1], rec[4][0])                    # the logits recorded at a step == a plain denoiser call
     assert torch.equal(lg, rec[4][3])
+
+
+def test_fp6v2_staggered_form_bit_equal(dev):
+    """The staggered (one-chunk-lag, three LDS slots) form of the fp6v2 main launch -- a measured, slower alternative kept behind
+    SPKDIFF_V2_LAG=1 (csrc/den_mfma_fp6v2.hip) -- gives the default form's spikes and counts bit for bit.  The library reads the
+    switch once per process, so the check runs in a child process."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch
+sys.path[:0] = [os.path.join(os.environ["SPK_ROOT"], "spiking-diffusion_amd"), os.environ["SPK_ROOT"]]
+from spkdiff import ops
+dev = torch.device("cuda")
+torch.manual_seed(3)
+res = []
+for B, Cout, Cin in ((37, 128, 64), (256, 256, 128), (19, 512, 256), (64, 256, 512)):
+    w = (torch.rand(Cout, Cin, 3, 3, device=dev) - 0.5) * 0.05
+    bias = (torch.rand(Cout, device=dev) - 0.5) * 0.1
+    x = (torch.rand(16, B, Cin, 7, 7, device=dev) < 0.06).float()
+    a = torch.rand(Cout, device=dev) * 8 + 2; b = torch.rand(Cout, device=dev) * 0.8
+    y, c = ops.den_conv3x3_mfma_fp6v2(ops.spikes_to_s32(x), ops.den_pack_weight_fp6v2(w, bias), Cout, bn_a=a, bn_b=b, want_counts=True)
+    torch.cuda.synchronize()
+    res.append((y.cpu(), c.cpu()))
+torch.save(res, sys.argv[1])
+'''
+    import tempfile
+    outs = []
+    with tempfile.TemporaryDirectory() as d:
+        for lag in ("0", "1"):
+            path = os.path.join(d, f"lag{lag}.pt")
+            env = dict(os.environ, SPKDIFF_V2_LAG=lag, SPK_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(torch.load(path))
+    n = 0
+    for (y0, c0), (y1, c1) in zip(*outs):
+        assert torch.equal(y0, y1) and torch.equal(c0, c1)
+        n += y0.numel()
+    parity("fp6v2_staggered_form", bytes_compared=n, mismatches=0)
