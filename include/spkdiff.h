@@ -55,6 +55,12 @@ const char* spk_error_string(int code);
  * spike_dtype 0 = fp32, 1 = u8, 2 = bit-packed u64 words [T, ceil(N/64)] (bit l of word w = neuron 64w+l). */
 int spk_lif_fwd(const float* x_seq, float* v_inout, void* spike_out, int T, long long N, float tau, float v_threshold,
                 float v_reset, int spike_dtype, spk_stream_t stream);
+/* The other eval forms of the reference neuron, SJ/activation_based/neuron.py:827-900 (dispatch :971-1011): soft reset
+ * (v_reset = None there; `v_reset` is ignored), decay_input = False, and -- v_seq_out non-NULL -- the `..._with_v_seq` variants
+ * (membrane potential after every step, fp32 [T, N]).  fp32 spikes; v [N] updated in place. */
+int spk_lif_fwd_ex(const float* x_seq, float* v_inout, float* spike_out_f32, float* v_seq_out_or_null, int T, long long N,
+                   float tau, float v_threshold, float v_reset, int soft_reset, int decay_input, spk_stream_t stream);
+
 
 /* The table behind the time-invariant-input layers (spk_conv_fused_fwd with SPK_IN_TINV and no carried state): the default
  * neuron (tau 2, v_th 1, v_reset 0: SJ/activation_based/neuron.py:799-811 with the models' constructor arguments,

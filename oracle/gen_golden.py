@@ -17,7 +17,8 @@ F10 one VQ-VAE training step (SNN_VQVAE in train() mode: VQ / commitment / PSP /
 F11 the reference's syops report (R/syops) on both models, as shipped and with its conv / bn hooks registered for the
 spikingjelly layer types,
 F12 get_data_for_diff over three batches (membrane state carried from batch to batch, as the reference does),
-F13 the benchmark's own length end to end: 100 reverse steps (B = 8) + decode to uint8 by the real reference.
+F13 the benchmark's own length end to end: 100 reverse steps (B = 8) + decode to uint8 by the real reference,
+F14 the other eval forms of LIFNode (soft reset, decay_input=False, store_v_seq; tau 2 / 3 / 5) with carried state.
 
     python oracle/gen_golden.py f9         # only rewrite the fixtures whose file name starts with "f9"
 """
@@ -141,6 +142,40 @@ def main():
     np.savez_compressed(os.path.join(OUT, "f1_lif.npz"), x_seq=x_seq.numpy(), spikes=b1, spikes_shape=shp,
                         v=v1.numpy(), spikes_carry=b2, v_carry=v2.numpy())
     print("F1 ok: firing rate", float(s1.mean()))
+
+    # ------------------------------------------------------------------ F14 LIF: the other eval forms (soft reset, decay_input=False, v_seq)
+    if True:
+        g = torch.Generator().manual_seed(1414)
+        x14 = torch.randn(16, 777, generator=g) * 1.2 + 0.3
+        f14 = {"x_seq": x14.numpy()}
+        for name, kw in (("soft_decay", dict(v_reset=None, decay_input=True, tau=2.0)),
+                         ("soft_nodecay", dict(v_reset=None, decay_input=False, tau=2.0)),
+                         ("hard_nodecay", dict(v_reset=0.0, decay_input=False, tau=2.0)),
+                         ("hard_decay_vseq", dict(v_reset=0.0, decay_input=True, tau=2.0)),
+                         ("soft_decay_tau3", dict(v_reset=None, decay_input=True, tau=3.0)),
+                         ("soft_nodecay_tau3", dict(v_reset=None, decay_input=False, tau=3.0)),
+                         ("hard_nodecay_tau5_vr", dict(v_reset=-0.25, decay_input=False, tau=5.0, v_threshold=0.8))):
+            node = vm.neuron.LIFNode(surrogate_function=vm.surrogate.ATan(), step_mode="m", store_v_seq=True, **kw).eval()
+            with torch.inference_mode():
+                s_a = node(x14); vs_a = node.v_seq.clone(); v_a = node.v.clone()
+                s_b = node(x14.flip(0)); vs_b = node.v_seq.clone()          # state carried
+                o_a, ov_a, ovs_a = ref.lif_multi_step_ex(x14, 0.0 if kw["v_reset"] is None else kw["v_reset"],
+                                                         kw.get("v_threshold", 1.0), kw["v_reset"], kw["tau"], kw["decay_input"])
+                o_b, _, ovs_b = ref.lif_multi_step_ex(x14.flip(0), ov_a, kw.get("v_threshold", 1.0), kw["v_reset"], kw["tau"],
+                                                      kw["decay_input"])
+            eq(s_a, o_a, f"F14 {name} spikes"); eq(vs_a, ovs_a, f"F14 {name} v_seq"); eq(v_a, ov_a, f"F14 {name} v")
+            eq(s_b, o_b, f"F14 {name} spikes (carry)"); eq(vs_b, ovs_b, f"F14 {name} v_seq (carry)")
+            # without store_v_seq the reference runs the plain jit functions: same spikes
+            node2 = vm.neuron.LIFNode(surrogate_function=vm.surrogate.ATan(), step_mode="m", **kw).eval()
+            with torch.inference_mode():
+                eq(node2(x14), s_a, f"F14 {name} spikes (no v_seq)")
+            bits, shp = pack(s_a)
+            f14[name + "_spikes"] = bits; f14[name + "_v_seq"] = vs_a.numpy()
+            bits, _ = pack(s_b)
+            f14[name + "_spikes_carry"] = bits; f14[name + "_v_seq_carry"] = vs_b.numpy()
+            f14["spikes_shape"] = shp
+            print(f"F14 {name} ok: firing rate {float(s_a.mean()):.3f}")
+        np.savez_compressed(os.path.join(OUT, "f14_lif_forms.npz"), **f14)
 
     # ------------------------------------------------------------------ models
     for tag, cfg, B in (("mnist", synth.MNIST, 16), ("cifar", synth.CIFAR, 4)):

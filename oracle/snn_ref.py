@@ -61,6 +61,37 @@ def lif_multi_step(x_seq: torch.Tensor, v=0.0, v_threshold: float = 1.0, v_reset
     return spike_seq, v
 
 
+def lif_multi_step_ex(x_seq: torch.Tensor, v=0.0, v_threshold: float = 1.0, v_reset=0.0, tau: float = 2.0,
+                      decay_input: bool = True):
+    """The eval-mode multi-step LIF in all four forms of the reference, with the membrane potential after every step:
+    ``jit_eval_multi_step_forward_{hard,soft}_reset_{decay,no_decay}_input_with_v_seq``,
+    SJ/activation_based/neuron.py:813-900 (dispatch :971-1011; ``v_reset=None`` = soft reset).  The operations are the
+    reference's, one for one.  Returns (spike_seq, v_final, v_seq)."""
+    if not torch.is_tensor(v):
+        v = torch.full_like(x_seq[0], float(v))
+    spike_seq = torch.zeros_like(x_seq)
+    v_seq = torch.zeros_like(x_seq)
+    for t in range(x_seq.shape[0]):
+        if v_reset is None:
+            if decay_input:
+                v = v + (x_seq[t] - v) / tau
+            else:
+                v = v * (1. - 1. / tau) + x_seq[t]
+        else:
+            if decay_input:
+                v = v + (x_seq[t] - (v - v_reset)) / tau
+            else:
+                v = v - (v - v_reset) / tau + x_seq[t]
+        spike = (v >= v_threshold).to(x_seq)
+        if v_reset is None:
+            v = v - spike * v_threshold
+        else:
+            v = v_reset * spike + (1. - spike) * v
+        spike_seq[t] = spike
+        v_seq[t] = v
+    return spike_seq, v, v_seq
+
+
 class _ATanSpike(torch.autograd.Function):
     """Heaviside forward, arc-tangent surrogate backward: SJ/activation_based/surrogate.py:664-678
     (``atan_backward``: alpha / 2 / (1 + (pi / 2 * alpha * x)^2) * grad_output)."""

@@ -106,6 +106,43 @@ __global__ __launch_bounds__(256) void lif_fwd_bits_kernel(const float* __restri
   }
 }
 
+
+// The other eval forms of the reference neuron (SJ/activation_based/neuron.py:827-900: soft reset, decay_input = False, and
+// the ..._with_v_seq variants that also return the membrane potential after every step).  Same one-pass structure as
+// lif_fwd_kernel; one neuron per thread (these forms are off the benchmark path), the reference's operations one for one:
+//   charge  decay_input:      v = v + (x - (v - v_reset)) / tau      (hard)      v = v + (x - v) / tau          (soft)
+//           no decay_input:   v = v - (v - v_reset) / tau + x        (hard)      v = v * (1 - 1 / tau) + x      (soft)
+//   reset   hard: v = v_reset * s + (1 - s) * v                      soft: v = v - s * v_th
+// (1 - 1 / tau) is evaluated in double and rounded to fp32, as the scalar of the reference's tensor-scalar product is.
+template <bool SOFT, bool DECAY, bool DIV>
+__global__ __launch_bounds__(256) void lif_fwd_ex_kernel(const float* __restrict__ x, float* __restrict__ v_io,
+                                                         float* __restrict__ out, float* __restrict__ v_seq, int T,
+                                                         long long N, float tau, float inv_tau, float keep, float v_th,
+                                                         float v_reset) {
+  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long long)gridDim.x * blockDim.x) {
+    float v = v_io[n];
+    for (int t = 0; t < T; ++t) {
+      const float xv = __builtin_nontemporal_load(x + (long long)t * N + n);
+      float h;
+      if (DECAY) {
+        const float d = SOFT ? xv - v : xv - (v - v_reset);
+        h = v + (DIV ? d / tau : d * inv_tau);
+      } else if (SOFT) {
+        h = v * keep + xv;
+      } else {
+        const float d = v - v_reset;
+        h = (v - (DIV ? d / tau : d * inv_tau)) + xv;
+      }
+      const bool sp = h >= v_th;
+      const float sf = sp ? 1.0f : 0.0f;
+      v = SOFT ? h - sf * v_th : (sp ? (v_reset + 0.0f * h) : (v_reset * 0.0f + h));
+      out[(long long)t * N + n] = sf;
+      if (v_seq) v_seq[(long long)t * N + n] = v;
+    }
+    v_io[n] = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ BN
 __global__ void bn_prepare_kernel(const float* gamma, const float* beta, const float* mean, const float* var,
                                   float eps, float* a, float* b, int C) {
@@ -246,6 +283,29 @@ extern "C" int spk_lif_fwd(const float* x_seq, float* v_inout, void* spike_out, 
     else     { if (pow2) SPK_LIF_LAUNCH(1, SPK_SPIKE_U8, false);  else SPK_LIF_LAUNCH(1, SPK_SPIKE_U8, true); }
   }
 #undef SPK_LIF_LAUNCH
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_lif_fwd_ex(const float* x_seq, float* v_inout, float* spike_out_f32, float* v_seq_out_or_null, int T,
+                              long long N, float tau, float v_threshold, float v_reset, int soft_reset, int decay_input,
+                              hipStream_t stream) {
+  if (!x_seq || !v_inout || !spike_out_f32 || T <= 0 || N <= 0 || !(tau > 0.f)) return SPK_ERR_ARG;
+  int ex;
+  const bool pow2 = frexpf(tau, &ex) == 0.5f;
+  const float inv_tau = 1.0f / tau, keep = (float)(1.0 - 1.0 / (double)tau);
+  const int grid = grid_for(N);
+#define SPK_LIFX(SOFT, DECAY, DIV)                                                                                   \
+  hipLaunchKernelGGL((lif_fwd_ex_kernel<SOFT, DECAY, DIV>), dim3(grid), dim3(256), 0, stream, x_seq, v_inout,        \
+                     spike_out_f32, v_seq_out_or_null, T, N, tau, inv_tau, keep, v_threshold, v_reset)
+  if (soft_reset) {
+    if (decay_input) { if (pow2) SPK_LIFX(true, true, false); else SPK_LIFX(true, true, true); }
+    else SPK_LIFX(true, false, false);
+  } else {
+    if (decay_input) { if (pow2) SPK_LIFX(false, true, false); else SPK_LIFX(false, true, true); }
+    else { if (pow2) SPK_LIFX(false, false, false); else SPK_LIFX(false, false, true); }
+  }
+#undef SPK_LIFX
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

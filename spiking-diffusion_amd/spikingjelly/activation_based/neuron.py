@@ -34,9 +34,10 @@ class BaseNode(base.MemoryModule):
 
     @store_v_seq.setter
     def store_v_seq(self, value: bool):
-        if value:
-            raise NotImplementedError('spkdiff: store_v_seq is a training/debug feature outside the inference path')
-        self._store_v_seq = False
+        # SJ/activation_based/neuron.py:119-129: the first True registers the `v_seq` memory
+        self._store_v_seq = bool(value)
+        if value and not hasattr(self, 'v_seq'):
+            self.register_memory('v_seq', None)
 
     def extra_repr(self):
         fields = ('v_threshold', 'v_reset', 'detach_reset', 'step_mode', 'backend')
@@ -65,17 +66,21 @@ class LIFNode(BaseNode):
         return super().extra_repr() + f', tau={self.tau}'
 
     def _check_supported(self, x):
-        if self.v_reset is None or not self.decay_input:
-            raise NotImplementedError('spkdiff: only hard reset with decay_input=True (the configuration used by '
-                                      'snn_model) is implemented')
         if x.dtype != torch.float32:
             raise NotImplementedError(x.dtype)
+
+    def _plain(self):
+        """The configuration snn_model uses (hard reset, decay_input, no v_seq): the vectorised spk_lif_fwd kernel."""
+        return self.v_reset is not None and self.decay_input and not self.store_v_seq
 
     def multi_step_forward(self, x_seq: torch.Tensor):
         self._check_supported(x_seq)
         self.v_float_to_tensor(x_seq[0])
         if not self.v.is_contiguous():
             self.v = self.v.contiguous()
+        if self.training and not self._plain():
+            raise NotImplementedError('spkdiff: the BPTT kernel implements hard reset with decay_input=True (the '
+                                      'configuration snn_model trains); the other forms run in eval() mode')
         if self.training:
             # surrogate-gradient BPTT (SURVEY.md §8f item 2): HIP forward that keeps h, HIP backward; the state stays
             # in the autograd graph across calls like the reference's ``self.v = v_seq[-1]``
@@ -86,7 +91,15 @@ class LIFNode(BaseNode):
                                                            self.v_reset, float(self.surrogate_function.alpha),
                                                            self.detach_reset)
             return spike_seq
-        return ops.lif_fwd(x_seq, self.v, self.tau, self.v_threshold, self.v_reset)
+        if self._plain():
+            return ops.lif_fwd(x_seq, self.v, self.tau, self.v_threshold, self.v_reset)
+        # soft reset / decay_input=False / store_v_seq: SJ/activation_based/neuron.py:971-1011 (eval dispatch)
+        spike_seq, v_seq = ops.lif_fwd_ex(x_seq, self.v, self.tau, self.v_threshold, self.v_reset,
+                                          soft_reset=self.v_reset is None, decay_input=self.decay_input,
+                                          want_v_seq=self.store_v_seq)
+        if self.store_v_seq:
+            self.v_seq = v_seq
+        return spike_seq
 
     def single_step_forward(self, x: torch.Tensor):
         return self.multi_step_forward(x.unsqueeze(0))[0]

@@ -37,6 +37,7 @@ _SIGS = {
     "spk_version": (c_int, []),
     "spk_error_string": (c_char_p, [c_int]),
     "spk_lif_fwd": (c_int, [P, P, P, c_int, c_longlong, c_float, c_float, c_float, c_int, P]),
+    "spk_lif_fwd_ex": (c_int, [P, P, P, P, c_int, c_longlong, c_float, c_float, c_float, c_int, c_int, P]),
     "spk_bn_prepare": (c_int, [P, P, P, P, c_float, P, P, c_int, P]),
     "spk_bn_eval_fwd": (c_int, [P, P, P, P, c_longlong, c_int, c_int, P]),
     "spk_conv2d_fwd": (c_int, [P, P, P, P, c_longlong, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

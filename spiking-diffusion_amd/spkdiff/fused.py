@@ -183,7 +183,7 @@ class FusedSequential(nn.Sequential):
             if lif is not None:
                 if lif.step_mode != 'm' or bn.step_mode != 'm' or lif.training or bn.training:
                     return False
-                if (lif.tau != 2.0 or lif.v_threshold != 1.0 or lif.v_reset != 0.0 or not lif.decay_input):
+                if (lif.tau != 2.0 or lif.v_threshold != 1.0 or lif.v_reset != 0.0 or not lif.decay_input or lif.store_v_seq):
                     return False
         return True
 

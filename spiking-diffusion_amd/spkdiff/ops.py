@@ -140,6 +140,23 @@ def lif_fwd(x_seq: torch.Tensor, v: torch.Tensor, tau=2.0, v_threshold=1.0, v_re
     return out
 
 
+def lif_fwd_ex(x_seq: torch.Tensor, v: torch.Tensor, tau=2.0, v_threshold=1.0, v_reset=0.0, soft_reset=False, decay_input=True,
+               want_v_seq=False):
+    """The reference neuron's other eval forms (spk_lif_fwd_ex): soft reset, decay_input=False, v_seq.  Returns
+    (spikes fp32 like x_seq, v_seq or None); v updated in place."""
+    x_seq = _dev(x_seq, "x_seq", torch.float32)
+    v = _dev(v, "v", torch.float32)
+    T, N = x_seq.shape[0], x_seq[0].numel()
+    if v.numel() != N:
+        raise ValueError(f"v has {v.numel()} elements, x_seq[0] has {N}")
+    out = torch.empty_like(x_seq)
+    v_seq = torch.empty_like(x_seq) if want_v_seq else None
+    check(lib.spk_lif_fwd_ex(_p(x_seq), _p(v), _p(out), _p(v_seq), T, N, float(tau), float(v_threshold),
+                             0.0 if v_reset is None else float(v_reset), int(bool(soft_reset)), int(bool(decay_input)),
+                             _stream(x_seq)), "spk_lif_fwd_ex")
+    return out, v_seq
+
+
 # ---------------------------------------------------------------------------------------------- stateless layers
 def lif_train_fwd(x_seq: torch.Tensor, v_init: torch.Tensor, tau=2.0, v_threshold=1.0, v_reset=0.0):
     """Training-mode multi-step LIF (hard reset, decay_input). Returns (spike_seq, h_seq, v_last), all fp32."""

@@ -2241,3 +2241,46 @@ torch.save(res, sys.argv[1])
         assert torch.equal(y0, y1) and torch.equal(c0, c1)
         n += y0.numel()
     parity("fp6v2_staggered_form", bytes_compared=n, mismatches=0)
+
+
+# ------------------------------------------------------------------------------------------------- round 3: the other LIF forms
+LIF_FORMS = [("soft_decay", dict(v_reset=None, decay_input=True, tau=2.0)),
+             ("soft_nodecay", dict(v_reset=None, decay_input=False, tau=2.0)),
+             ("hard_nodecay", dict(v_reset=0.0, decay_input=False, tau=2.0)),
+             ("hard_decay_vseq", dict(v_reset=0.0, decay_input=True, tau=2.0)),
+             ("soft_decay_tau3", dict(v_reset=None, decay_input=True, tau=3.0)),
+             ("soft_nodecay_tau3", dict(v_reset=None, decay_input=False, tau=3.0)),
+             ("hard_nodecay_tau5_vr", dict(v_reset=-0.25, decay_input=False, tau=5.0, v_threshold=0.8))]
+
+
+@pytest.mark.parametrize("name,kw", LIF_FORMS)
+def test_f14_lifnode_other_eval_forms_vs_reference_fixture(golden_dir, dev, name, kw):
+    """neuron.LIFNode with soft reset (v_reset=None), decay_input=False and store_v_seq (SJ/activation_based/neuron.py:813-900,
+    971-1011) on the HIP kernel spk_lif_fwd_ex against the REAL reference's outputs (fixture F14): spikes, v_seq and the
+    state carried into a second call, bit for bit; and without store_v_seq the same spikes."""
+    from spikingjelly.activation_based import neuron, surrogate
+    d = load(golden_dir, "f14_lif_forms.npz")
+    x = torch.from_numpy(d["x_seq"]).to(dev)
+    node = neuron.LIFNode(surrogate_function=surrogate.ATan(), step_mode="m", store_v_seq=True, **kw).eval()
+    with torch.inference_mode():
+        s = node(x); vs = node.v_seq.clone()
+        s2 = node(x.flip(0)); vs2 = node.v_seq.clone()
+    bad = (int((s.cpu() != unpack(d[name + "_spikes"], d["spikes_shape"])).sum()) +
+           int((s2.cpu() != unpack(d[name + "_spikes_carry"], d["spikes_shape"])).sum()))
+    vbad = int((vs.cpu() != torch.from_numpy(d[name + "_v_seq"])).sum()) + int((vs2.cpu() != torch.from_numpy(d[name + "_v_seq_carry"])).sum())
+    parity(f"f14_lif_{name}", spike_mismatches=bad, v_seq_mismatches=vbad, values=int(2 * s.numel()))
+    assert bad == 0 and vbad == 0
+    node.reset()
+    assert node.v_seq is None and isinstance(node.v, float)
+    node2 = neuron.LIFNode(surrogate_function=surrogate.ATan(), step_mode="m", **kw).eval()
+    with torch.inference_mode():
+        assert torch.equal(node2(x), s)
+    # ragged size / other shape against the live oracle
+    g = torch.Generator().manual_seed(9)
+    xr = torch.randn(7, 3, 5, 11, generator=g) * 1.5
+    node3 = neuron.LIFNode(surrogate_function=surrogate.ATan(), step_mode="m", store_v_seq=True, **kw).eval()
+    with torch.inference_mode():
+        s3 = node3(xr.to(dev))
+    o3, ov3, ovs3 = ref.lif_multi_step_ex(xr, 0.0 if kw["v_reset"] is None else kw["v_reset"], kw.get("v_threshold", 1.0),
+                                          kw["v_reset"], kw["tau"], kw["decay_input"])
+    assert torch.equal(s3.cpu(), o3) and torch.equal(node3.v_seq.cpu(), ovs3) and torch.equal(node3.v.cpu(), ov3)

@@ -45,6 +45,31 @@ def test_f1_lif_exact(golden_dir):
     assert torch.equal(v2, torch.from_numpy(d["v_carry"]))
 
 
+LIF_FORMS = [("soft_decay", dict(v_reset=None, decay_input=True, tau=2.0)),
+             ("soft_nodecay", dict(v_reset=None, decay_input=False, tau=2.0)),
+             ("hard_nodecay", dict(v_reset=0.0, decay_input=False, tau=2.0)),
+             ("hard_decay_vseq", dict(v_reset=0.0, decay_input=True, tau=2.0)),
+             ("soft_decay_tau3", dict(v_reset=None, decay_input=True, tau=3.0)),
+             ("soft_nodecay_tau3", dict(v_reset=None, decay_input=False, tau=3.0)),
+             ("hard_nodecay_tau5_vr", dict(v_reset=-0.25, decay_input=False, tau=5.0, v_threshold=0.8))]
+
+
+@pytest.mark.parametrize("name,kw", LIF_FORMS)
+def test_f14_lif_other_eval_forms(golden_dir, name, kw):
+    """F14: soft reset / decay_input=False / v_seq forms of the reference's eval LIF (SJ/activation_based/neuron.py:813-900),
+    state carried across two calls: the oracle against the real reference's outputs, bit for bit."""
+    d = load(golden_dir, "f14_lif_forms.npz")
+    x = torch.from_numpy(d["x_seq"])
+    vth = kw.get("v_threshold", 1.0)
+    s, v, vs = ref.lif_multi_step_ex(x, 0.0 if kw["v_reset"] is None else kw["v_reset"], vth, kw["v_reset"], kw["tau"],
+                                     kw["decay_input"])
+    assert torch.equal(s, unpack(d[name + "_spikes"], d["spikes_shape"]))
+    assert torch.equal(vs, torch.from_numpy(d[name + "_v_seq"]))
+    s2, _, vs2 = ref.lif_multi_step_ex(x.flip(0), v, vth, kw["v_reset"], kw["tau"], kw["decay_input"])
+    assert torch.equal(s2, unpack(d[name + "_spikes_carry"], d["spikes_shape"]))
+    assert torch.equal(vs2, torch.from_numpy(d[name + "_v_seq_carry"]))
+
+
 @pytest.mark.parametrize("det", [False, True])
 def test_f8_lif_training_forward_and_bptt(golden_dir, det):
     """the oracle's training-mode LIF (surrogate-gradient autograd) against the reference's
