@@ -10,7 +10,7 @@ for r in rows:
     n = r["Kernel_Name"]; d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     if "conv3x3_fp6v2_listed" in n:
         last = ("listed", 2 + k % 4); acc[last].append(d); k += 1
-    elif "conv3x3_fp6v2_kernel" in n:
+    elif ("conv3x3_fp6v2_kernel" in n or "conv3x3_fp6v2_lag_kernel" in n):
         last = ("main", 2 + k % 4); acc[last].append(d); k += 1
     elif "fp6v2_fixup" in n: acc[(last[0] + "-fixup", last[1])].append(d)
     elif "fp6v2_tail" in n: acc[(last[0] + "-tail", last[1])].append(d)
