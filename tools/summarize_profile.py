@@ -25,7 +25,7 @@ for r in rows:
     elif "conv3x3_fp6_kernel" in name:      # one symbol for conv2..conv5, in launch order
         name = f"conv3x3_fp6_kernel den.conv{2 + k % 4}"
         k += 1
-    elif ("conv3x3_fp6v2_kernel" in n or "conv3x3_fp6v2_lag_kernel" in n)ame:    # second-generation kernel: same order; its two tail launches follow each one
+    elif ("conv3x3_fp6v2_kernel" in name or "conv3x3_fp6v2_lag_kernel" in name):    # second-generation kernel: same order; its two tail launches follow each one
         name = f"conv3x3_fp6v2_kernel den.conv{2 + k % 4}"
         layer = 2 + k % 4
         k += 1
