@@ -240,7 +240,11 @@ class AbsorbingDiffusion(Sampler):
             return
         ts = [t for t in list(dn.parameters()) + list(dn.buffers()) if t.is_floating_point() and t.is_cuda]
         ws = self._wsum
-        if ws is None or ws[0].key != tuple((t.data_ptr(), t.numel() * t.element_size()) for t in ts):
+        if ws is None or ws[0].key != ops.TensorChecksum.key_of(ts):
+            # (another set of tensors -- e.g. the training path re-laid the weights out channels-last: a new address -- is a
+            #  change by itself: whatever was derived from the old ones is dropped)
+            if ws is not None:
+                self.invalidate()
             ws = self._wsum = [ops.TensorChecksum(ts), None]
         v = ws[0].value()
         if ws[1] is not None and ws[1] != v:

@@ -1296,8 +1296,25 @@ def philox_noise(seed, offset, B, HW, K, device, philox_state=None, want_q=True)
 class TensorChecksum:
     """Content checksum of a fixed set of device tensors in one launch (spk_checksum_multi): ``value()`` synchronises."""
 
+    @staticmethod
+    def select(tensors):
+        """The tensors a checksum covers: device tensors whose numel * itemsize bytes from data_ptr are exactly their
+        elements in SOME order (default or channels-last memory: the sum does not depend on the order)."""
+        out = []
+        for t in tensors:
+            if t is None or not t.is_cuda or t.numel() == 0:
+                continue
+            dense = t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+            if dense:
+                out.append(t)
+        return out
+
+    @staticmethod
+    def key_of(tensors):
+        return tuple((t.data_ptr(), t.numel() * t.element_size()) for t in TensorChecksum.select(tensors))
+
     def __init__(self, tensors):
-        ts = [t for t in tensors if t is not None and t.is_cuda and t.numel() > 0 and t.is_contiguous()]
+        ts = self.select(tensors)
         if not ts:
             raise ValueError("TensorChecksum: no device tensors")
         self.key = tuple((t.data_ptr(), t.numel() * t.element_size()) for t in ts)

@@ -2101,6 +2101,21 @@ def test_data_write_is_noticed_by_the_weights_checksum(dev):
                 p.mul_(1.5)
     want = _eager_tokens(den2, 16, 20, 4)
     assert torch.equal(b, want) and not torch.equal(a, b)
+    # ... also when the training path has re-laid the weights out channels-last (new storage, not default-contiguous)
+    with torch.no_grad():
+        for den_x in (den, den2):
+            for name, p in den_x.named_parameters():
+                if p.dim() == 4:
+                    p.data = p.data.contiguous(memory_format=torch.channels_last)
+    torch.manual_seed(4); c = ab.sample(temp=1.0, sample_steps=20)
+    assert torch.equal(c, b), "same values in another memory layout: same tokens"
+    with torch.no_grad():
+        for den_x in (den, den2):
+            for name, p in den_x.named_parameters():
+                if name.endswith('0.weight'):
+                    p.data.mul_(0.8)
+    torch.manual_seed(4); d = ab.sample(temp=1.0, sample_steps=20)
+    assert torch.equal(d, _eager_tokens(den2, 16, 20, 4)) and not torch.equal(d, c)
 
 
 def test_certified_kernel_workspaces_are_per_stream(dev, ops):
