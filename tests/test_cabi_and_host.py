@@ -222,3 +222,24 @@ def test_oracle_is_not_imported_by_the_product():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_synthetic_checkpoint_cache_is_safe_under_concurrent_ranks(tmp_path):
+    """bench.py's ranks all ask for the same synthetic checkpoints at start-up: the file cache (synth.cached_state) must hand every
+    process the generator's own tensors, whoever wins the race to generate, and leave no lock behind."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, os; sys.path[:0] = [os.path.join(%r, 'spiking-diffusion_amd'), %r]\n"
+            "from spkdiff import synth\n"
+            "print(synth.state_checksum(synth.cached_state('denoiser', synth.MNIST)), "
+            "synth.state_checksum(synth.cached_state('vqvae', synth.CIFAR)))\n" % (root, root))
+    env = dict(os.environ, SPKDIFF_SYNTH_CACHE=str(tmp_path))
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, text=True) for _ in range(4)]
+    outs = [p.communicate(timeout=600)[0].split() for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    from spkdiff import synth
+    want = [synth.state_checksum(synth.synth_denoiser_state(synth.MNIST)), synth.state_checksum(synth.synth_vqvae_state(synth.CIFAR))]
+    assert all(o == want for o in outs), (outs, want)
+    left = sorted(os.listdir(tmp_path))
+    assert len([f for f in left if f.endswith(".pt")]) == 2 and not any(f.endswith((".lock", ".tmp")) for f in left), left
