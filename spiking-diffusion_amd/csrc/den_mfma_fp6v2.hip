@@ -104,6 +104,9 @@ struct V2Args {
 #ifndef SPK_V2_SPARE
 #define SPK_V2_SPARE 1.0f       // four-digit form: factor on the certification bound (2.0f = the first builds' spare factor)
 #endif
+#ifndef SPK_V2_STAGE2
+#define SPK_V2_STAGE2 1         // four-digit form: flagged lanes are re-examined with the per-step running bound (see the epilogue)
+#endif
 #ifndef SPK_V2_LAG_DEFAULT
 #define SPK_V2_LAG_DEFAULT 0    // 1: full 7x7 batches run the staggered form (conv3x3_fp6v2_lag_kernel); SPKDIFF_V2_LAG=0/1 overrides
 #endif
@@ -566,6 +569,32 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
           }
         }
         flg = dmin <= SPK_V2_SPARE * fmaf(zmax, 2.5f * CERT_4EPS, fmaf((float)nmax, cT, cE));   // (10 eps for 8: a little to spare)
+        if (SPK_V2_STAGE2 && __builtin_amdgcn_ballot_w64(flg) != 0ull) {
+          // SECOND STAGE (a wave with a flagged lane: a few percent of the tiles).  The closed form above compares the closest
+          // approach of ANY step with the bound of the WORST step.  The recursion it was derived from is tighter twice over: the
+          // bound of step t only carries the counts of the steps before it, halved once per step (dh_t <= dh_{t-1} / 2 + c_t / 2
+          // + 2 eps (|z_t| + |v_{t-1}|), c_t = cE + cT n_t; 2.5 eps for 2 as above), and each step's |h_t - 1| is compared with
+          // ITS bound.  Flagged only if both stages flag: about half the exact recomputations (the repair launch's time is
+          // proportional to them).  Every lane re-scans (the branch is wave-uniform); accumulators and counts are still live.
+          float v2 = 0.f, dh = 0.f;
+          bool f2 = false;
+#pragma unroll
+          for (int r2 = 0; r2 < 16; r2 += 2) {
+            const v2f p0 = {acc[i][0][r2], acc[i][0][r2 + 1]}, p1 = {acc[i][1][r2], acc[i][1][r2 + 1]};
+            const v2f q4 = __builtin_elementwise_fma(p0, (v2f){1024.0f, 1024.0f}, p1);
+            const v2f z2 = __builtin_elementwise_fma(q4, (v2f){Ac4, Ac4}, (v2f){Bc, Bc});
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const float z = z2[e];
+              const float ct = fmaf((float)cntv[r2 + e], cT, cE);
+              dh = fmaf(fabsf(z) + fabsf(v2), 0.625f * CERT_4EPS, fmaf(dh, 0.5f, 0.5f * ct));
+              const float h = fmaf(z - v2, 0.5f, v2);
+              f2 = f2 || (fabsf(h - 1.0f) <= SPK_V2_SPARE * dh);
+              v2 = h >= 1.0f ? 0.0f : h;
+            }
+          }
+          flg = flg && f2;
+        }
       }
       const int ti = wave + NWV * i;
       // accumulator lane half == position within the tile; a list that does not fill its last tiles repeats its last
