@@ -104,6 +104,12 @@ struct V2Args {
 #ifndef SPK_V2_SPARE
 #define SPK_V2_SPARE 1.0f       // four-digit form: factor on the certification bound (2.0f = the first builds' spare factor)
 #endif
+#ifndef SPK_V2_REC_INLOOP
+#define SPK_V2_REC_INLOOP 1     // record counting inside the K-loop's MFMA stream (0: in front of it, as in round 2)
+#endif
+#ifndef SPK_V2_REC_STEP
+#define SPK_V2_REC_STEP 13      // the step whose gap takes the popcounts (the reads are issued at step 1; 7: no gain, 13: +0.4 %)
+#endif
 #ifndef SPK_V2_STAGE2
 #define SPK_V2_STAGE2 1         // four-digit form: flagged lanes are re-examined with the per-step running bound (see the epilogue)
 #endif
@@ -189,7 +195,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
   // how the four-digit form counts the active inputs of a row: REC: once per input record and chunk for the whole workgroup
   // (full items: the per-fragment popcounts were 29 % of the launch's vector issue), else per A fragment in the K loop
   // (listed positions: an item has few fragments, and the per-item passes of REC cost more than they save there: -2.5 %)
-  constexpr bool REC = !USE_D4 && !PRUNE;
+  constexpr bool REC = !USE_D4 && !PRUNE && !(SPK_V2_DBG & 256);     // (DBG 256: no counting at all -- timing only, wrong flags)
   constexpr int HW = H * W, PW = W + 1;
   constexpr int Hb = SPLIT ? H / 2 : H;                // output rows of an item
   constexpr int Hin = SPLIT ? Hb + 1 : H;              // input rows staged per item
@@ -348,7 +354,10 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
       const unsigned n_dA = sA_addr + (buf ^ 1) * A_BYTES;
       const unsigned n_dW = sW_addr + (buf ^ 1) * W_LDS;
 
-      if constexpr (REC) {
+      // REC: the chunk's record counts.  SPK_V2_REC_INLOOP: the two LDS reads are issued after the chunk's first MFMA step and
+      // their popcounts a few steps later, inside the MFMA stream (in front of it they held the chunk's first MFMA back by an
+      // LDS round trip at every chunk barrier).
+      if constexpr (REC && !SPK_V2_REC_INLOOP) {
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
           const v4i rv = *reinterpret_cast<const v4i*>(sA + buf * A_BYTES + rec_off[k]);
@@ -356,6 +365,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
                      __builtin_popcount((unsigned)rv[2]) + __builtin_popcount((unsigned)rv[3]);
         }
       }
+      v4i rvq[NR];
       auto compute = [&](auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         const uint8_t* A = sA + buf * A_BYTES + band_off;
@@ -425,7 +435,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
   } while (0)
           if constexpr (!blk_is_d(blk)) {
             constexpr int tap = blk_tap(blk);
-            if constexpr (!USE_D4 && !REC) {
+            if constexpr (!USE_D4 && !REC && !(SPK_V2_DBG & 256)) {
               // (volatile: left to itself hipcc defers the pure popcounts and keeps every fragment of the chunk alive)
               asm volatile("v_bcnt_u32_b32 %0, %1, %0\n\tv_bcnt_u32_b32 %0, %2, %0\n\tv_bcnt_u32_b32 %0, %3, %0\n\t"
                            "v_bcnt_u32_b32 %0, %4, %0" : "+v"(cnt[i]) : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]));
@@ -444,6 +454,18 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
             __builtin_amdgcn_sched_barrier(0);
             V2_DMA_SLOT();
             V2_NEXT_TILES();
+            if constexpr (REC && SPK_V2_REC_INLOOP) {
+              if constexpr (s == 1) {
+#pragma unroll
+                for (int k = 0; k < NR; ++k) rvq[k] = *reinterpret_cast<const v4i*>(sA + buf * A_BYTES + rec_off[k]);
+              }
+              if constexpr (s == SPK_V2_REC_STEP) {
+#pragma unroll
+                for (int k = 0; k < NR; ++k)
+                  creg[k] += __builtin_popcount((unsigned)rvq[k][0]) + __builtin_popcount((unsigned)rvq[k][1]) +
+                             __builtin_popcount((unsigned)rvq[k][2]) + __builtin_popcount((unsigned)rvq[k][3]);
+              }
+            }
             V2_PAIR_MFMA(1);
             __builtin_amdgcn_sched_barrier(0);
           } else {
@@ -513,7 +535,10 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
       unsigned mybits = 0;
       bool flg = false;
       int cntv[16];                                       // four-digit form: active inputs of this lane's rows (its position, step r)
-      if constexpr (!USE_D4 && !REC) {
+      if constexpr (SPK_V2_DBG & 256) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cntv[r] = 0;
+      } else if constexpr (!USE_D4 && !REC) {
         // the count of accumulator row r sits in the A-layout lane (r & 3) + 8 (r >> 2) + 4 half
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
