@@ -219,15 +219,17 @@ int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, c
 /* Second-generation form of spk_den_conv3x3_mfma_fp6 for the sampler (7x7 latents, fresh LIF state in, no state out):
  * the SAME spikes bit for bit -- the four leading digits on the matrix cores with adjacent digits sharing an accumulator through
  * the per-block scales, fp32 recombination, every spike decision certified against a bound on the dropped digits (per counted
- * active input of the row), and the 1e-4 .. 6e-4 of neurons that come closer to the threshold recomputed exactly (all six
- * digits, int64 / fp64) by a tail launch; another finishes the 49th position (csrc/den_mfma_fp6v2.hip).  DummyModel conv2..conv5, R/snn_model/vq_diffusion.py:166-184,201-204.
+ * active input of the row; tiles with a flagged lane are re-examined with the per-step running bound), and the ~1e-4 of neurons
+ * that come closer to the threshold recomputed exactly (all six digits, int64 / fp64) by a tail launch; another finishes the 49th
+ * position (csrc/den_mfma_fp6v2.hip).  DummyModel conv2..conv5, R/snn_model/vq_diffusion.py:166-184,201-204.
  * Spikes travel as "S32": [B][C/32][H*W][16][16 B] (fp4 nibbles, channel c of a group in byte (c % 32) / 2, low nibble first).
  * spk_den_pack_weight_fp6v2: fp32 [Cout,Cin,3,3] (+bias) -> packed digit tiles (spk_den_packed_weight_fp6v2_bytes), fp64
  * scale / bias [Cout] as for the fp6 kernel, wl1 [Cout] = L1 norm of each channel's quantised weights, and qtab = the
  * quantised weights themselves as int32 [Cout][9][Cin] (read by the exact recomputation).  flag_words: zero-initialised
  * u32 workspace of spk_den_fp6v2_flag_words(B, Cout, H, W) words (counter, ticket, id list, overflow bitmap); it is clean
- * again when the call's launches have run.
- * SPK_ERR_UNSUPPORTED unless T == 16, H == W == 7, Cout % 32 == 0 (Cin = 32 * nch). */
+ * again when the call's launches have run (word 1 keeps the number of neurons the call flagged, for statistics).  One
+ * workspace per stream: two calls in flight at once must not share it.
+ * SPK_ERR_UNSUPPORTED unless T == 16, H == W == 7 or 8, Cout % 32 == 0 (Cin = 32 * nch). */
 long long spk_den_packed_weight_fp6v2_bytes(int Cout, int Cin);
 int spk_den_pack_weight_fp6v2(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d, float* wl1,
                               int* qtab, int Cout, int Cin, spk_stream_t stream);
