@@ -330,6 +330,17 @@ int spk_vq_argmin(const float* flat_x, const float* codebook, long long* idx_out
 int spk_embedding_fwd(const long long* tokens, const float* codebook, float* out, long long N, int D, int K, int HW,
                       int nchw, spk_stream_t stream);
 
+/* Weight gradient of a 3x3 / stride 1 / pad 1 convolution over a SPIKE input (training step of the denoiser's conv2..conv6,
+ * R/snn_model/vq_diffusion.py:166-187 through autograd; the reference runs the library's fp32 kernels):
+ * gw[co][ky][kx][ci] = sum_{n,y,x} gy[n,co,y,x] * s[n,ci,y+ky-1,x+kx-1] on the bf16 matrix cores -- the spikes are exact in bf16,
+ * the fp32 output gradient is split into three bf16 terms exactly, so only the fp32 accumulation rounds.  gy_cl / spikes_cl:
+ * channels-last fp32 [N = T*B][H*W][C]; gw_out fp32 [Cout][3][3][Cin] (= a channels-last [Cout,Cin,3,3] tensor); ws: scratch of
+ * spk_conv3x3_wgrad_ws_bytes (split-K partial sums, added in a fixed order: deterministic).  7x7 maps, Cout % 128 == 0,
+ * Cin % 32 == 0; otherwise SPK_ERR_UNSUPPORTED (use the framework's operator). */
+long long spk_conv3x3_wgrad_ws_bytes(int N, int Cout, int Cin);
+int spk_conv3x3_wgrad_bf16(const float* gy_cl, const float* spikes_cl, float* ws, long long ws_bytes, float* gw_out, int N, int H,
+                           int W, int Cout, int Cin, spk_stream_t stream);
+
 /* ---- sampler ---------------------------------------------------------------------------------------------------- */
 /* Images touched by reverse step t.  R/snn_model/vq_diffusion.py:113-124 computes `changes = (u < 1/t) & ~unmasked`
  * BEFORE the denoiser call and only scatters the sample there (:140): for an image without a change at step t the

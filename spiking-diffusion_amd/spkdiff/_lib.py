@@ -53,6 +53,8 @@ _SIGS = {
                                      c_float, c_float, c_float, c_float, c_int, P]),
     "spk_den_conv3x3_fp6_raw": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_spikes_nhwc_to_fp4": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "spk_conv3x3_wgrad_ws_bytes": (c_longlong, [c_int, c_int, c_int]),
+    "spk_conv3x3_wgrad_bf16": (c_int, [P, P, P, c_longlong, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_psp": (c_int, [P, P, c_int, c_longlong, c_float, c_int, P]),
     "spk_masked_ce": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     "spk_spikes_to_ptc": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),

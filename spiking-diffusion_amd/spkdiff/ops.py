@@ -770,6 +770,29 @@ def den_conv3x3_fp6_raw(in0, packed, Cout):
     return y
 
 
+def conv3x3_wgrad_supported(Cout, Cin, H, W):
+    return (H, W) == (7, 7) and Cout % 128 == 0 and Cin % 32 == 0
+
+
+# False: the weight gradient of the spike-input convolutions comes from the framework's operator (as in rounds 1-2)
+NATIVE_WGRAD = True
+
+
+def conv3x3_wgrad(gy_cl, spikes_cl, Cout, Cin):
+    """gw [Cout,Cin,3,3] (channels-last memory) of a 3x3 / s1 / p1 convolution from gy [N,Cout,7,7] and BINARY spikes
+    [N,Cin,7,7], both channels-last fp32 (spk_conv3x3_wgrad_bf16: bf16 matrix cores, exact three-term split of gy)."""
+    N = int(gy_cl.shape[0])
+    nb = int(lib.spk_conv3x3_wgrad_ws_bytes(N, int(Cout), int(Cin)))
+    if nb <= 0:
+        raise NotImplementedError("spk_conv3x3_wgrad_bf16: unsupported shape")
+    ws = torch.empty(nb // 4, dtype=torch.float32, device=gy_cl.device)
+    gw = torch.empty((Cout, 3, 3, Cin), dtype=torch.float32, device=gy_cl.device)
+    with timed("train.conv_wrw"):
+        check(lib.spk_conv3x3_wgrad_bf16(_p(gy_cl), _p(spikes_cl), _p(ws), nb, _p(gw), N, 7, 7, int(Cout), int(Cin),
+                                         _stream(gy_cl)), "spk_conv3x3_wgrad_bf16")
+    return gw.permute(0, 3, 1, 2)
+
+
 class SpikeConvTrainFunction(torch.autograd.Function):
     """y = conv3x3(spikes, weight) + bias for BINARY input spikes in training: the forward is the exact
     fp6 x fp4 MFMA convolution (weights re-packed into six radix-32 digit planes each call -- they change every optimizer
@@ -790,9 +813,25 @@ class SpikeConvTrainFunction(torch.autograd.Function):
     def backward(ctx, grad_y):
         s, weight = ctx.saved_tensors
         gy = _cl5(grad_y, "grad_y").flatten(0, 1)
-        gi, gw, gb = torch.ops.aten.convolution_backward(
-            gy, s.flatten(0, 1), weight, [int(weight.shape[0])], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-            [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), bool(ctx.has_bias and ctx.needs_input_grad[2])])
+        s4 = s.flatten(0, 1)
+        Cout, Cin = int(weight.shape[0]), int(weight.shape[1])
+        need_gi, need_gw = bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1])
+        need_gb = bool(ctx.has_bias and ctx.needs_input_grad[2])
+        gw_native = None
+        if (NATIVE_WGRAD and need_gw and tuple(weight.shape[2:]) == (3, 3) and
+                conv3x3_wgrad_supported(Cout, Cin, int(s.shape[3]), int(s.shape[4]))):
+            # the weight gradient multiplies gy by SPIKES: native on the bf16 matrix cores (the data gradient has no spike operand)
+            gw_native = conv3x3_wgrad(gy, s4, Cout, Cin)
+            need_gw = False
+        gi = gw = gb = None
+        if need_gi or need_gw or (need_gb and gw_native is None):
+            gi, gw, gb = torch.ops.aten.convolution_backward(
+                gy, s4, weight, [Cout], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                [need_gi, need_gw, need_gb and gw_native is None])
+        if gw_native is not None:
+            gw = gw_native
+            if need_gb:
+                gb = gy.sum(dim=(0, 2, 3))
         if gi is not None:
             gi = gi.view(s.shape)
         return gi, gw, gb

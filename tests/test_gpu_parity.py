@@ -2299,3 +2299,31 @@ def test_f14_lifnode_other_eval_forms_vs_reference_fixture(golden_dir, dev, name
     o3, ov3, ovs3 = ref.lif_multi_step_ex(xr, 0.0 if kw["v_reset"] is None else kw["v_reset"], kw.get("v_threshold", 1.0),
                                           kw["v_reset"], kw["tau"], kw["decay_input"])
     assert torch.equal(s3.cpu(), o3) and torch.equal(node3.v_seq.cpu(), ovs3) and torch.equal(node3.v.cpu(), ov3)
+
+
+# ------------------------------------------------------------------------------------------------- round 3: native weight gradient
+@pytest.mark.parametrize("N,Cout,Cin", [(7, 128, 64), (64, 256, 128), (37, 512, 256), (16, 256, 512), (5, 128, 320)])
+def test_conv3x3_weight_gradient_bf16_kernel_vs_fp64(dev, ops, N, Cout, Cin):
+    """spk_conv3x3_wgrad_bf16 (spike operand exact in bf16, gy split into three bf16 terms exactly, fp32 accumulation on the
+    matrix cores) against the fp64 weight gradient of the same convolution: relative L2 error at fp32 round-off, and not worse
+    than the framework's fp32 operator."""
+    g = torch.Generator().manual_seed(N + Cout)
+    s = (torch.rand(N, Cin, 7, 7, generator=g) < 0.07).float()
+    gy = torch.randn(N, Cout, 7, 7, generator=g) * torch.rand(Cout, generator=g).view(1, -1, 1, 1) * 1e-3
+    gy[:, ::5] *= 64.0                                                    # mixed magnitudes across channels
+    w = torch.zeros(Cout, Cin, 3, 3)
+    _, want, _ = torch.ops.aten.convolution_backward(gy.double(), s.double(), w.double(), [Cout], [1, 1], [1, 1], [1, 1], False,
+                                                     [0, 0], 1, [False, True, False])
+    s_cl = s.to(dev).contiguous(memory_format=torch.channels_last)
+    gy_cl = gy.to(dev).contiguous(memory_format=torch.channels_last)
+    got = ops.conv3x3_wgrad(gy_cl, s_cl, Cout, Cin)
+    assert got.shape == (Cout, Cin, 3, 3)
+    rel = float((got.cpu().double() - want).norm() / want.norm())
+    _, lib_gw, _ = torch.ops.aten.convolution_backward(gy_cl, s_cl, w.to(dev), [Cout], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                       [False, True, False])
+    rel_lib = float((lib_gw.cpu().double() - want).norm() / want.norm())
+    print(f"wgrad N={N} {Cin}->{Cout}: rel L2 error {rel:.2e} (framework operator {rel_lib:.2e})")
+    parity(f"wgrad_bf16_N{N}_{Cin}_{Cout}", rel_l2_err=rel, rel_l2_err_framework=rel_lib)
+    assert rel <= 2e-6
+    got2 = ops.conv3x3_wgrad(gy_cl, s_cl, Cout, Cin)
+    assert torch.equal(got, got2), "deterministic (partial sums added in a fixed order)"
