@@ -9,15 +9,23 @@
 // the fp32 accumulation of v_mfma_f32_32x32x16_bf16 rounds -- an fp32 GEMM's accuracy at the bf16 rate (3 MFMAs per product
 // tile: 178 GFLOP executed for the 256 -> 512 layer at B = 32).
 //
-// Mapping.  One workgroup = 128 output channels x 32 input channels x all 9 taps (144 accumulator registers per wave: wave w
-// owns output channels 32 w .. 32 w + 31) over a slice of the T*B images (split K; the partial sums of the slices are added in
-// a fixed order by a second launch: deterministic).  K runs image by image: the MFMA's two 8-wide k groups are two IMAGE ROWS
-// (7 positions + one zero), four k steps cover the 7 rows + one zero row (23 % of the products are padding), so that
-//   * the A fragment (gy, one output channel, one image row) is 8 consecutive floats of an LDS image kept [co][row][8], read
-//     as two 16-byte vectors and split into its three bf16 terms in registers (each element is read by exactly one lane);
+// Mapping.  One workgroup (8 waves, two per SIMD) = 128 output channels x 64 input channels x all 9 taps: wave (w, c) owns
+// output channels 32 w .. 32 w + 31 and input channels 32 c .. 32 c + 31 (144 accumulator registers), over a slice of the T*B
+// images (split K; the partial sums of the slices are added in a fixed order by a second launch: deterministic).  K runs image
+// by image: the MFMA's two 8-wide k groups are two IMAGE ROWS (7 positions + one zero), four k steps cover the 7 rows + one
+// zero row (23 % of the products are padding), so that
+//   * the A fragment of one term (gy, one output channel, one image row) is ONE aligned 16-byte read of an LDS image kept
+//     [term][co][row][8] in bf16: the three-term split is done ONCE per element while the tile is deposited (not once per wave
+//     that multiplies it: with the split in the multiply loop the launch was bound by vector-instruction issue, 228 us for the
+//     256 -> 512 layer at B = 32);
 //   * the B fragment of tap (ky, kx) (spikes, one input channel, the row shifted by the tap) is ONE aligned 16-byte read of
 //     an LDS image kept [kx][ci][row + 1][8] in bf16: three copies pre-shifted by kx, zero rows above and below.
-// Images are double buffered: the next image's tiles travel global -> registers while the current one is multiplied.
+// Images are double buffered: the next image's tiles travel global -> registers while the current one is multiplied, and are
+// split / deposited between the k steps.  Measured on the 256 -> 512 layer at B = 32 (512 images, 32 per workgroup; MI355X,
+// rocprofv3): 161 us + 16.5 us for the reduction, the framework's operator 487 us; the MFMA pipe is busy 62 % of the launch
+// (SQ_VALU_MFMA_BUSY_CYCLES).  With fetch and deposit switched off the image loop runs at ~90 % of the MFMA rate; ~30 us of
+// the launch are outside the loop: the first image's latency and the 75 MB of partial sums (2048 waves x 144 accumulator
+// registers: the price of filling 256 CUs with 16 output tiles) written here and read by the reduction.
 #include "spk_common.h"
 #include "den_common.h"
 #include "../../include/spkdiff.h"
@@ -27,22 +35,25 @@ namespace {
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int WG_CO = 128, WG_CI = 32, HW7 = 49;
-constexpr int G_PITCH = 68;                       // floats per output channel in the gy image (64 + 4: 16-byte aligned rows, spread banks)
-constexpr int G_FLOATS = WG_CO * G_PITCH;         // 34 816 B
-constexpr int S_HALFS = 3 * WG_CI * 9 * 8;        // bf16 entries of the spike image: [kx][ci][row + 1][8] = 13 824 B
+constexpr int WG_CO = 128, WG_CI = 64, HW7 = 49, NTHR = 512;
+constexpr int G_PITCH = 56;                       // bf16 entries per output channel and term: 7 rows x 8 (112 B: 16-lane phases of a 16-byte read hit 16 x 4 distinct banks)
+constexpr int G_HALFS = 3 * WG_CO * G_PITCH;      // [term][co][row][8] = 43 008 B
+constexpr int S_PITCH = 72;                       // bf16 entries per input channel and copy: 9 rows x 8 (144 B)
+constexpr int S_HALFS = 3 * WG_CI * S_PITCH;      // [kx][ci][row + 1][8] = 27 648 B
+constexpr int LDS_BYTES = 2 * G_HALFS * 2 + 2 * S_HALFS * 2 + 16;      // + one 16-byte zero vector (the zero row of the A operand)
 
 struct WgArgs {
   const float* gy; const float* s; float* part;
   int TB, Cout, Cin, ksplit;
 };
 
-__global__ __launch_bounds__(256, 1) void wgrad3x3_bf16_kernel(WgArgs a) {
+__global__ __launch_bounds__(NTHR, 1) void wgrad3x3_bf16_kernel(WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  float* const sG = reinterpret_cast<float*>(lds);                                   // [2][G_FLOATS]
-  unsigned short* const sS = reinterpret_cast<unsigned short*>(lds + 2 * G_FLOATS * 4);   // [2][S_HALFS]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n_ci = a.Cin / WG_CI, n_co = a.Cout / WG_CO;
+  unsigned short* const sG = reinterpret_cast<unsigned short*>(lds);                       // [2][G_HALFS]
+  unsigned short* const sS = sG + 2 * G_HALFS;                                            // [2][S_HALFS]
+  const unsigned short* const sZ = sS + 2 * S_HALFS;                                      // 8 zeros
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, ct = tid >> 8;
+  const int n_ci = a.Cin / WG_CI;
   int bid = blockIdx.x;
   const int ks = bid % a.ksplit; bid /= a.ksplit;
   const int tn = bid % n_ci, tm = bid / n_ci;
@@ -50,54 +61,75 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_bf16_kernel(WgArgs a) {
   const int per = (a.TB + a.ksplit - 1) / a.ksplit;
   const int i0 = ks * per, i1 = (i0 + per < a.TB) ? i0 + per : a.TB;
 
-  // zero both buffers once: the pad row / column of the gy image and the border rows / columns of the spike image stay zero
-  for (int i = tid; i < (2 * G_FLOATS * 4 + 2 * S_HALFS * 2) / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+  // zero everything once: the border rows / columns of the spike image and the zero vector stay zero
+  for (int i = tid; i < LDS_BYTES / 16; i += NTHR) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
 
-  // this thread's share of an image: gy tile 49 x 128 floats (element e: position e / 128, channel e % 128), spike tile 49 x 32
-  constexpr int NG = (HW7 * WG_CO + 255) / 256, NS = (HW7 * WG_CI + 255) / 256;      // 25, 7
-  float rg[NG], rs[NS];
+  // this thread's share of an image: whole image ROWS, so that every LDS deposit is one aligned 16-byte write (element-wise
+  // 2-byte deposits kept the LDS pipe busier than the matrix cores).  gy tile: item (channel e % 128, row e / 128) for
+  // e = tid and tid + 512 (896 items); spike tile: item (channel tid % 64, row tid / 64) for tid < 448
+  float rg[2][7], rs[7];
+  const int g_co = tid & 127, g_y0 = tid >> 7, s_ci = tid & 63, s_y = tid >> 6;
+  const bool g_two = tid < 896 - NTHR, s_on = tid < 7 * WG_CI;                           // (both wave-uniform)
+  // addresses = a wave-uniform pointer (image, column x, tile origin: scalar registers) + ONE 32-bit per-thread offset
+  const unsigned g_off = (unsigned)(g_y0 * 7 * a.Cout + g_co), s_off = (unsigned)(s_y * 7 * a.Cin + s_ci);
   auto fetch = [&](int img) {
     const float* g = a.gy + ((long long)img * HW7) * a.Cout + co0;
     const float* sp = a.s + ((long long)img * HW7) * a.Cin + ci0;
 #pragma unroll
-    for (int j = 0; j < NG; ++j) {
-      const int e = tid + 256 * j;
-      const int ec = e < HW7 * WG_CO ? e : HW7 * WG_CO - 1;
-      rg[j] = g[(long long)(ec >> 7) * a.Cout + (ec & 127)];
-    }
+    for (int x = 0; x < 7; ++x) rg[0][x] = (g + x * a.Cout)[g_off];
+    if (g_two) {
 #pragma unroll
-    for (int j = 0; j < NS; ++j) {
-      const int e = tid + 256 * j;
-      const int ec = e < HW7 * WG_CI ? e : HW7 * WG_CI - 1;
-      rs[j] = sp[(long long)(ec >> 5) * a.Cin + (ec & 31)];
+      for (int x = 0; x < 7; ++x) rg[1][x] = (g + (28 + x) * a.Cout)[g_off];
+    }
+    if (s_on) {
+#pragma unroll
+      for (int x = 0; x < 7; ++x) rs[x] = (sp + x * a.Cin)[s_off];
     }
   };
-  auto deposit = [&](int buf) {
-    float* G = sG + buf * G_FLOATS;
-    unsigned short* S = sS + buf * S_HALFS;
+  auto deposit = [&](int buf, int part) {        // part 0 / 1: the gy items, 2: the spike item, -1: all
+    unsigned short* G = sG + buf * G_HALFS + g_co * G_PITCH;
+    unsigned short* S = sS + buf * S_HALFS + s_ci * S_PITCH + (s_y + 1) * 8;
 #pragma unroll
-    for (int j = 0; j < NG; ++j) {
-      const int e = tid + 256 * j;
-      if (e < HW7 * WG_CO) {
-        const int pos = e >> 7, co = e & 127;
-        G[co * G_PITCH + (pos / 7) * 8 + (pos % 7)] = rg[j];
+    for (int j = 0; j < 2; ++j) {
+      if ((part < 0 || part == j) && (j == 0 || g_two)) {
+        // x = hi + mid + lo exactly, each term a bf16 (top 16 bits of an fp32): truncate, subtract (exact), truncate, subtract;
+        // at most 8 significant bits are left for lo: its truncation is exact
+        unsigned h[8], m[8], l[8];
+#pragma unroll
+        for (int x = 0; x < 7; ++x) {
+          h[x] = __float_as_uint(rg[j][x]) & 0xFFFF0000u;
+          const float p = rg[j][x] - __uint_as_float(h[x]);
+          m[x] = __float_as_uint(p) & 0xFFFF0000u;
+          l[x] = __float_as_uint(p - __uint_as_float(m[x]));
+        }
+        h[7] = m[7] = l[7] = 0u;                                                           // column 7: the zero pad
+        v4i vh, vm, vl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          vh[q] = (int)((h[2 * q] >> 16) | h[2 * q + 1]);
+          vm[q] = (int)((m[2 * q] >> 16) | m[2 * q + 1]);
+          vl[q] = (int)((l[2 * q] >> 16) | (l[2 * q + 1] & 0xFFFF0000u));
+        }
+        unsigned short* d = G + (g_y0 + 4 * j) * 8;
+        *reinterpret_cast<v4i*>(d) = vh;
+        *reinterpret_cast<v4i*>(d + WG_CO * G_PITCH) = vm;
+        *reinterpret_cast<v4i*>(d + 2 * WG_CO * G_PITCH) = vl;
       }
     }
+    if ((part < 0 || part == 2) && s_on) {
+      unsigned v[7];
 #pragma unroll
-    for (int j = 0; j < NS; ++j) {
-      const int e = tid + 256 * j;
-      if (e < HW7 * WG_CI) {
-        const int pos = e >> 5, ci = e & 31;
-        const int y = pos / 7, x = pos % 7;
-        const unsigned short v = rs[j] != 0.f ? (unsigned short)0x3F80u : (unsigned short)0u;
-        // copy d (tap column kx = d): entry [row y + 1][xx] holds s(y, xx + d - 1)  ->  this spike lands at xx = x + 1 - d
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          const int xx = x + 1 - d;
-          if (xx >= 0 && xx < 8) S[((d * WG_CI + ci) * 9 + (y + 1)) * 8 + xx] = v;
-        }
-      }
+      for (int x = 0; x < 7; ++x) v[x] = rs[x] != 0.f ? 0x3F80u : 0u;
+      // copy kx: slot xx of row y + 1 holds s(y, xx + kx - 1)
+      const unsigned p12 = v[1] | (v[2] << 16), p34 = v[3] | (v[4] << 16), p56 = v[5] | (v[6] << 16);
+      v4i c0, c1, c2;
+      c0[0] = (int)(v[0] << 16); c0[1] = (int)p12; c0[2] = (int)p34; c0[3] = (int)p56;                 // 0 s0 | s1 s2 | s3 s4 | s5 s6
+      c1[0] = (int)(v[0] | (v[1] << 16)); c1[1] = (int)(v[2] | (v[3] << 16)); c1[2] = (int)(v[4] | (v[5] << 16)); c1[3] = (int)v[6];
+      c2[0] = (int)p12; c2[1] = (int)p34; c2[2] = (int)p56; c2[3] = 0;                                  // s1 s2 | s3 s4 | s5 s6 | 0 0
+      *reinterpret_cast<v4i*>(S) = c0;
+      *reinterpret_cast<v4i*>(S + WG_CI * S_PITCH) = c1;
+      *reinterpret_cast<v4i*>(S + 2 * WG_CI * S_PITCH) = c2;
     }
   };
 
@@ -107,51 +139,49 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_bf16_kernel(WgArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  if (i0 < i1) { fetch(i0); deposit(0); }
+  if (i0 < i1) { fetch(i0); deposit(0, -1); }
   __syncthreads();
   const int row = lane & 31, half = lane >> 5;
   for (int img = i0; img < i1; ++img) {
     const int buf = (img - i0) & 1;
     if (img + 1 < i1) fetch(img + 1);
-    const float* G = sG + buf * G_FLOATS + (wave * 32 + row) * G_PITCH;
-    const unsigned short* S = sS + buf * S_HALFS;
+    const unsigned short* G = sG + buf * G_HALFS + (wave * 32 + row) * G_PITCH;
+    const unsigned short* S = sS + buf * S_HALFS + (ct * 32 + row) * S_PITCH;
+    // 36 (k step, tap) products, the B fragment read three products ahead of its use and the A fragments of the next k step
+    // half a k step ahead (read-then-use in source order left the LDS latency exposed before every tap)
+    auto a_ptr = [&](int kstep, int term) -> const unsigned short* {
+      return (kstep == 3 && half) ? sZ : G + term * WG_CO * G_PITCH + (2 * kstep + half) * 8;     // row 7 = the zero row
+    };
+    auto b_read = [&](int i) -> v4i {
+      const int kstep = i / 9, tap = i % 9, ky = tap / 3, kx = tap % 3;
+      int r = 2 * kstep + half + ky;                        // LDS row of image row y + ky - 1
+      r = r > 8 ? 8 : r;                                    // (only the zero row y = 7 can reach past the image: its A is zero)
+      return *reinterpret_cast<const v4i*>(S + kx * WG_CI * S_PITCH + r * 8);
+    };
+    constexpr int AHEAD = 3;
+    v4i av[2][3], bq[AHEAD + 1];
 #pragma unroll
-    for (int kstep = 0; kstep < 4; ++kstep) {
-      const int y = 2 * kstep + half;                       // the image row of this lane's k group (7 = the zero row)
-      const float4 g0 = *reinterpret_cast<const float4*>(G + y * 8), g1 = *reinterpret_cast<const float4*>(G + y * 8 + 4);
-      const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-      // x = hi + mid + lo exactly, each term a bf16 (top 16 bits of an fp32): truncate, subtract (exact), truncate, subtract
-      unsigned hi[8], mi[8], lo[8];
+    for (int t = 0; t < 3; ++t) av[0][t] = *reinterpret_cast<const v4i*>(a_ptr(0, t));
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const unsigned xb = __float_as_uint(gv[j]);
-        hi[j] = xb & 0xFFFF0000u;
-        const float r1 = gv[j] - __uint_as_float(hi[j]);
-        mi[j] = __float_as_uint(r1) & 0xFFFF0000u;
-        const float r2 = r1 - __uint_as_float(mi[j]);
-        lo[j] = __float_as_uint(r2);                        // at most 8 significant bits are left: the truncation is exact
+    for (int i = 0; i < AHEAD; ++i) bq[i] = b_read(i);
+#pragma unroll
+    for (int i = 0; i < 36; ++i) {
+      const int kstep = i / 9, tap = i % 9;
+      if (i + AHEAD < 36) bq[(i + AHEAD) % (AHEAD + 1)] = b_read(i + AHEAD);
+      asm volatile("" ::: "memory");                        // (keeps every read where it is written: no merging with a later one)
+      if (tap == 4 && kstep < 3) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) av[(kstep + 1) & 1][t] = *reinterpret_cast<const v4i*>(a_ptr(kstep + 1, t));
       }
-      v4i ah, am, al;
+      const v8bf b = __builtin_bit_cast(v8bf, bq[i % (AHEAD + 1)]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        ah[j] = (int)((hi[2 * j] >> 16) | (hi[2 * j + 1] & 0xFFFF0000u));
-        am[j] = (int)((mi[2 * j] >> 16) | (mi[2 * j + 1] & 0xFFFF0000u));
-        al[j] = (int)((lo[2 * j] >> 16) | (lo[2 * j + 1] & 0xFFFF0000u));
-      }
-      const v8bf a_h = __builtin_bit_cast(v8bf, ah), a_m = __builtin_bit_cast(v8bf, am), a_l = __builtin_bit_cast(v8bf, al);
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap % 3;
-        int r = y + ky;                                     // LDS row of image row y + ky - 1
-        r = r > 8 ? 8 : r;                                  // (only the zero row y = 7 can reach past the image: its A is zero)
-        const v4i bv = *reinterpret_cast<const v4i*>(S + ((kx * WG_CI + row) * 9 + r) * 8);
-        const v8bf b = __builtin_bit_cast(v8bf, bv);
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b, acc[tap], 0, 0, 0);
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m, b, acc[tap], 0, 0, 0);
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, b, acc[tap], 0, 0, 0);
-      }
+      for (int t = 0; t < 3; ++t)
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, av[kstep & 1][t]), b, acc[tap], 0, 0, 0);
+      // the next image's deposit rides between the k steps (its vector work next to the matrix cores' rather than in one
+      // block after the loop, where both waves of a SIMD did it at the same time with the MFMA pipe idle)
+      if (tap == 8 && kstep < 3 && img + 1 < i1) deposit(buf ^ 1, kstep);
+      __builtin_amdgcn_sched_barrier(0);                    // source order = issue order, product by product
     }
-    if (img + 1 < i1) deposit(buf ^ 1);
     __syncthreads();
   }
   // partial sums of this slice: part[ks][co][tap][ci]
@@ -161,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_bf16_kernel(WgArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      out[((long long)co * 9 + tap) * a.Cin + ci0 + row] = acc[tap][r];
+      out[((long long)co * 9 + tap) * a.Cin + ci0 + ct * 32 + row] = acc[tap][r];
     }
 }
 
@@ -173,15 +203,20 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
   }
 }
 
+// slices of the image range: one workgroup per CU in ONE round (never a second, partly filled round)
+int wgrad_ksplit(int TB, int Cout, int Cin) {
+  const int tiles = (Cout / WG_CO) * (Cin / WG_CI);
+  int ks = spk_cu_count() / tiles;
+  if (ks > TB) ks = TB;
+  if (ks < 1) ks = 1;
+  return ks;
+}
+
 }  // namespace
 
 extern "C" long long spk_conv3x3_wgrad_ws_bytes(int TB, int Cout, int Cin) {
   if (TB <= 0 || Cout <= 0 || Cin <= 0 || (Cout % WG_CO) || (Cin % WG_CI)) return -1;
-  const int tiles = (Cout / WG_CO) * (Cin / WG_CI);
-  int ks = (spk_cu_count() + tiles - 1) / tiles;
-  if (ks > TB) ks = TB;
-  if (ks < 1) ks = 1;
-  return (long long)ks * Cout * 9 * Cin * 4;
+  return (long long)wgrad_ksplit(TB, Cout, Cin) * Cout * 9 * Cin * 4;
 }
 
 extern "C" int spk_conv3x3_wgrad_bf16(const float* gy_cl, const float* spikes_cl, float* ws, long long ws_bytes,
@@ -189,15 +224,12 @@ extern "C" int spk_conv3x3_wgrad_bf16(const float* gy_cl, const float* spikes_cl
   if (!gy_cl || !spikes_cl || !ws || !gw_out || TB <= 0) return SPK_ERR_ARG;
   if (H != 7 || W != 7 || (Cout % WG_CO) || (Cin % WG_CI)) return SPK_ERR_UNSUPPORTED;
   const int tiles = (Cout / WG_CO) * (Cin / WG_CI);
-  int ks = (spk_cu_count() + tiles - 1) / tiles;
-  if (ks > TB) ks = TB;
-  if (ks < 1) ks = 1;
+  const int ks = wgrad_ksplit(TB, Cout, Cin);
   const long long n = (long long)Cout * 9 * Cin;
   if (ws_bytes < (long long)ks * n * 4) return SPK_ERR_ARG;
   WgArgs a;
   a.gy = gy_cl; a.s = spikes_cl; a.part = ws; a.TB = TB; a.Cout = Cout; a.Cin = Cin; a.ksplit = ks;
-  const size_t lds = 2 * (size_t)G_FLOATS * 4 + 2 * (size_t)S_HALFS * 2;
-  hipLaunchKernelGGL(wgrad3x3_bf16_kernel, dim3(tiles * ks), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(wgrad3x3_bf16_kernel, dim3(tiles * ks), dim3(NTHR), (size_t)LDS_BYTES, stream, a);
   SPK_LAUNCH_CHECK();
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, stream,
                      ws, gw_out, n, ks);
