@@ -91,6 +91,9 @@ struct V2Args {
   asm volatile(SPK_FP6_PRE "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:2"   \
                : "=&" CLS(acc) : "v"(av), "v"(bv), "v"(sa), "v"(sb))
 
+#ifndef SPK_V2_AGPR12
+#define SPK_V2_AGPR12 0         // accumulators in AGPRs with three waves per SIMD (168 registers per wave)
+#endif
 #ifndef SPK_V2_DBG
 #define SPK_V2_DBG 0            // experiments only: 1 = no steady-state DMA, 4 = no epilogue (results are wrong), 32 = zero
                                 // certification margin (nothing flagged: shows what the exact recomputation repairs),
@@ -204,7 +207,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
                       : ((HW & 1) == 1 && ((HW / 2) % NWV) == 0), "whole 32-row tiles on every wave (+ one odd position)");
   static_assert(!PRUNE || (!SPLIT && (NWV == 4 || NWV == 8) && NTP <= (HWb / 2) / NWV), "position lists: 7x7 items");
   constexpr int NT = PRUNE ? NTP : (HWb / 2) / NWV;    // row tiles per wave (7x7: 6 or 3; 8x8 bands: 4)
-  constexpr int N_AGPR = NWV == 4 ? (NACC * NT < 16 ? NACC * NT : 16) : (NACC * NT < 8 ? NACC * NT : 8);   // (two waves per SIMD: hipcc splits 256 registers 128 / 128)
+  constexpr int N_AGPR = NWV == 4 ? (NACC * NT < 16 ? NACC * NT : 16) : NWV == 12 ? SPK_V2_AGPR12 : (NACC * NT < 8 ? NACC * NT : 8);   // (two waves per SIMD: hipcc splits 256 registers 128 / 128)
   constexpr int NPP = (Hin + 2) * PW + 1;              // cells of the zero-bordered LDS image (pitch W + 1: the zero
   constexpr int A_BYTES = NPP * POSB;                  //  column is shared by x = -1 of a row and x = W of the previous)
   constexpr int PPR = (W + 3) / 4;                     // DMA pieces per image row (4 positions per KiB piece)
@@ -212,7 +215,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
   constexpr int NPA = (NA + NWV - 1) / NWV;            // A pieces per wave
   constexpr int NPW = (W_PIECES + NWV - 1) / NWV;      // W pieces per wave
   constexpr int NS_PAIR = 9 * NT, NSTEP = NS_PAIR + (USE_D4 ? N_D4 * NT : 0);
-  static_assert(NWV == 8 || NACC * NT <= 16 || (NT - 1) * NACC <= N_AGPR + 2, "only the last tile may straddle the register files");
+  static_assert(NWV >= 8 || NACC * NT <= 16 || (NT - 1) * NACC <= N_AGPR + 2, "only the last tile may straddle the register files");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   uint8_t* const sA = lds;
   uint8_t* const sW = lds + 2 * A_BYTES;
@@ -1499,9 +1502,13 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   // Two waves per SIMD are the default since the four-digit form: with 23 MFMAs per tile and chunk they needed 9 % fewer
   // cycles per MFMA and took the SAME time (the device lowered its clock by those 9 %: the launch was bound by the power the
   // matrix pipe may draw); with 18 the copies, fragment reads and popcounts of a chunk are no longer hidden behind one wave's
-  // MFMAs, there is power to spare, and the second wave is worth 8 % of the reverse process (a third one -- 12 waves of two
-  // tiles, 84 + 84 registers and 72 B of spills -- loses 5 % again).  SPKDIFF_V2_WAVES=4: one wave.
+  // MFMAs, there is power to spare, and the second wave is worth 8 % of the reverse process.  A third one (SPKDIFF_V2_WAVES=12:
+  // twelve waves of two tiles, 168 registers, accumulators in VGPRs; bit-equal) LOSES 11 % (round 3, same box: den.conv4 launch
+  // 417-466 against 383-387 us, dense reverse process 103.3 against 92.3 ms) although three waves issue vector instructions
+  // 1.4x faster than two (tools/coexec_probe.hip: 2.2 against 3.1 cycles per v_fma_f32): a weight tile read from LDS then
+  // serves two row tiles instead of three and twelve waves meet at every chunk barrier.  SPKDIFF_V2_WAVES=4: one wave.
   static const bool eight = [] { const char* e = getenv("SPKDIFF_V2_WAVES"); return !(e && e[0] == '4'); }();
+  static const bool twelve = [] { const char* e = getenv("SPKDIFF_V2_WAVES"); return e && e[0] == '1' && e[1] == '2'; }();
   static const bool lag_form = [] { const char* e = getenv("SPKDIFF_V2_LAG"); return e ? e[0] == '1' : (SPK_V2_LAG_DEFAULT != 0); }();
   if (need) {
     if (grid / G < 6) return SPK_ERR_UNSUPPORTED;           // one image lane per tile-count class at least
@@ -1511,7 +1518,8 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
     // (staggered experiment: three ring slots + counters + one 128-byte line per wave)
     const size_t lds3 = 3 * ((size_t)a_bytes + W_LDS) + (size_t)(a_bytes / POSB) * 64 + 8 * 128;
     hipLaunchKernelGGL((conv3x3_fp6v2_lag_kernel<7, 7>), dim3(grid), dim3(512), lds3, stream, a);
-  } else if (eight) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 8>), dim3(grid), dim3(512), lds, stream, a);
+  } else if (twelve) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 12>), dim3(grid), dim3(768), lds, stream, a);
+  else if (eight) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 8>), dim3(grid), dim3(512), lds, stream, a);
   else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 4>), dim3(grid), dim3(256), lds, stream, a);
   SPK_LAUNCH_CHECK();
   const int n_lp = ((B + 1) / 2) * G;

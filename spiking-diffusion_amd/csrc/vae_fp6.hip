@@ -66,8 +66,22 @@ constexpr float CERT_4EPS = 4.0f * 2.38418579e-07f;
 #ifndef SPK_VT_EXEC_SCAN
 #define SPK_VT_EXEC_SCAN 1      // 0: the collapsed-output scan handles a spike with compare + selects (the compiler's form)
 #endif
+#ifndef SPK_VT_NWV
+#define SPK_VT_NWV 8            // waves per workgroup (two per SIMD).  Round 3, convT2 at B = 1024 (tools/convt_time.py, same box): 16 waves with
+                                // SPK_VT_TPP=1 (126 registers) 253-255 us against 259-267 (the scan alone 67 -> 40 us: four waves issue vector
+                                // instructions at 2.0 instead of 3.1 cycles each, tools/coexec_probe.hip; the multiply phase, ~150 us, is the same),
+                                // 12 waves 262; the plain stride-2 layer (nine taps) spills at either, so the default stays 8 x 2 tiles
+#endif
+#ifndef SPK_VT_PIPE
+#define SPK_VT_PIPE 0           // 1: software-pipelined LDS reads in the multiply phase (weight tile two steps ahead, next tap's spike
+                                // fragments one tap ahead, schedule pinned); measured equal (264-267 against 267 us): hipcc already defers the
+                                // second tile's MFMAs to after the first tile's scan and runs them back to back from registers
+#endif
+#ifndef SPK_VT_TPP
+#define SPK_VT_TPP 2            // row tiles per pass (a weight tile read from LDS serves all of them)
+#endif
 #ifndef SPK_VT_DBG
-#define SPK_VT_DBG 0            // timing experiments only (results are wrong): 1 = no MFMAs, 2 = no LIF scan
+#define SPK_VT_DBG 0            // timing experiments only (results are wrong): 1 = no MFMAs, 2 = no LIF scan, 4 = no weight-tile reads from LDS
 #endif
 
 __device__ __forceinline__ unsigned spread8_v(unsigned x) {        // bit k -> nibble k, as the e2m1 code of 1.0 (0x2)
@@ -83,12 +97,31 @@ struct Geo {
   static constexpr int KMAX = GEO == 0 ? 4 : 9;                       // taps that can reach one output
 };
 
+// the taps that reach an output of sub-pixel class CLS (transposed convolution: 1 / 2 / 2 / 4 of nine; plain stride 2: all)
+template <int GEO, int CLS>
+__host__ __device__ constexpr bool tap_is_on(int tap) {
+  const int ky = tap / 3, kx = tap % 3, py = CLS >> 1, px = CLS & 1;
+  return GEO == 1 || ((py == 0 ? ky == 1 : ky != 1) && (px == 0 ? kx == 1 : kx != 1));
+}
+template <int GEO, int CLS>
+__host__ __device__ constexpr int n_on_taps() {
+  int n = 0;
+  for (int t = 0; t < 9; ++t) n += tap_is_on<GEO, CLS>(t) ? 1 : 0;
+  return n;
+}
+template <int GEO, int CLS>
+__host__ __device__ constexpr int on_tap(int k) {
+  for (int t = 0; t < 9; ++t)
+    if (tap_is_on<GEO, CLS>(t) && k-- == 0) return t;
+  return 0;
+}
+
 template <int GEO, int H, int W, int NCH, int OUT, int SPLIT, bool DB>
-__global__ __launch_bounds__(512, 1) void vae_fp6_kernel(TArgs a) {
+__global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
   constexpr int TPT = tiles_per_tap(NCH), W_BYTES = 9 * TPT * WT;
   constexpr int RQ = GEO == 0 ? H / SPLIT : H / 2;          // rows of positions per item (class rows / output rows)
   constexpr int CW = GEO == 0 ? W : W / 2;                  // positions per row
-  constexpr int NPOS = RQ * CW, NTC = (NPOS + 1) / 2, NPASS = (NTC + 1) / 2, NCLS = GEO == 0 ? 4 : 1;
+  constexpr int NPOS = RQ * CW, NTC = (NPOS + 1) / 2, TPP = SPK_VT_TPP, NPASS = (NTC + TPP - 1) / TPP, NCLS = GEO == 0 ? 4 : 1;
   constexpr int SROWS = GEO == 0 ? RQ + 1 : H + 1, SCOLS = W + 1;
   constexpr int A_CH = SROWS * SCOLS * POSB, A_BYTES = NCH * A_CH, NBUF = DB ? 2 : 1;
   constexpr int PPR = (W + 3) / 4;                          // 1 KiB DMA pieces per image row
@@ -106,8 +139,8 @@ __global__ __launch_bounds__(512, 1) void vae_fp6_kernel(TArgs a) {
 
   {  // the group's weight tiles and zeroed input slabs (their borders stay zero for the whole launch)
     const uint4* src = reinterpret_cast<const uint4*>(a.wq + (long long)g * W_BYTES);
-    for (int i = tid; i < W_BYTES / 16; i += 512) reinterpret_cast<uint4*>(sW)[i] = src[i];
-    for (int i = tid; i < NBUF * A_BYTES / 16; i += 512) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < W_BYTES / 16; i += SPK_VT_NWV * 64) reinterpret_cast<uint4*>(sW)[i] = src[i];
+    for (int i = tid; i < NBUF * A_BYTES / 16; i += SPK_VT_NWV * 64) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
 
@@ -141,7 +174,7 @@ __global__ __launch_bounds__(512, 1) void vae_fp6_kernel(TArgs a) {
   auto stage = [&](int itm, int buf) {
     const int b = itm / SPLIT, part = itm - b * SPLIT;
     const unsigned dst0 = sA_addr + buf * A_BYTES;
-    for (int id = wave; id < NCH * DROWS * PPR; id += 8) {
+    for (int id = wave; id < NCH * DROWS * PPR; id += SPK_VT_NWV) {
       const int c = id / (DROWS * PPR), rr = (id / PPR) % DROWS, px4 = id % PPR;
       const int iy = GEO == 0 ? part * RQ + rr : rr;
       if (iy < H) {
@@ -153,7 +186,7 @@ __global__ __launch_bounds__(512, 1) void vae_fp6_kernel(TArgs a) {
       }
     }
     if (GEO == 0 && part * RQ + SROWS - 1 >= H) {           // the row below the image: zeros
-      for (int i = tid; i < NCH * W * POSB / 16; i += 512) {
+      for (int i = tid; i < NCH * W * POSB / 16; i += SPK_VT_NWV * 64) {
         const int c = i / (W * POSB / 16), o = i % (W * POSB / 16);
         reinterpret_cast<uint4*>(sA + buf * A_BYTES + c * A_CH + (SROWS - 1) * SCOLS * POSB)[o] = make_uint4(0, 0, 0, 0);
       }
@@ -173,25 +206,26 @@ __global__ __launch_bounds__(512, 1) void vae_fp6_kernel(TArgs a) {
 
     auto run_pass = [&](auto cls_tag, int k) __attribute__((always_inline)) {
       constexpr int CLS = decltype(cls_tag)::value, PY = CLS >> 1, PX = CLS & 1;
-      const int t0 = 2 * k, t1 = 2 * k + 1;
-      const bool v1 = t1 < NTC;
+      const int t0 = TPP * k, t1 = TPP * k + 1;
+      const bool v1 = TPP == 2 && t1 < NTC;
       const int tl[2] = {t0, v1 ? t1 : t0};
-      int base[2];
+      int base[TPP];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < TPP; ++i) {
         int p = 2 * tl[i] + hsel;
         p = p < NPOS ? p : NPOS - 1;
         const int ry = p / CW, rx = p - ry * CW;
         base[i] = (GEO == 0 ? ry * SCOLS + rx : 2 * ry * SCOLS + 2 * rx) * POSB + tt * 16;
       }
-      v16f acc[2][3];
+      v16f acc[TPP][3];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TPP; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
       auto ldb = [&](int tile) -> v6i {
+        if (SPK_VT_DBG & 4) return v6i{lane + tile, lane, tile, 0x11111111, lane * 3, 0x01010101};   // (timing only: no weight reads)
         const uint8_t* p = sW + tile * WT;
         const v4i x = *reinterpret_cast<const v4i*>(p + lane * 16);
         const v2i y = *reinterpret_cast<const v2i*>(p + 1024 + lane * 8);
@@ -204,6 +238,49 @@ __global__ __launch_bounds__(512, 1) void vae_fp6_kernel(TArgs a) {
         const v8i b8 = {bv[0], bv[1], bv[2], bv[3], bv[4], bv[5], 0, 0};
         d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, d, 4, 2, 0, sc_a, 0, sb);
       };
+#if SPK_VT_PIPE
+      // The item's products as ONE compile-time list of steps (an active tap of the class x one weight tile), software pipelined:
+      // the weight tile of step s + PFB and the spike fragments of the NEXT tap are read from LDS while the MFMAs of step s run
+      // (read-all-then-multiply per tap left LDS reads and MFMAs in series: 153 us of the convT2 launch's 269 against ~70 us each).
+      constexpr int NON = n_on_taps<GEO, CLS>(), NSTEP = NON * TPT, PFB = 2, RB = PFB + 1;
+      auto toff = [&](auto k_tag) {
+        constexpr int TAP = on_tap<GEO, CLS>(decltype(k_tag)::value), KY = TAP / 3, KX = TAP % 3;
+        constexpr int DY = GEO == 1 ? KY : ((PY == 1 && KY == 0) ? 1 : 0), DX = GEO == 1 ? KX : ((PX == 1 && KX == 0) ? 1 : 0);
+        return std::integral_constant<int, (DY * SCOLS + DX) * POSB>{};
+      };
+      v4i av[2][TPP][NCH];
+      v6i bq[RB];
+      auto lda = [&](auto k_tag) {
+        constexpr int k = decltype(k_tag)::value, TOFF = decltype(toff(k_tag))::value;
+#pragma unroll
+        for (int i = 0; i < TPP; ++i)
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) av[k & 1][i][c] = *reinterpret_cast<const v4i*>(A0 + c * A_CH + base[i] + TOFF);
+      };
+      lda(std::integral_constant<int, 0>{});
+      tfor<(PFB < NSTEP ? PFB : NSTEP)>([&](auto s_tag) {
+        constexpr int s = decltype(s_tag)::value;
+        bq[s % RB] = ldb(on_tap<GEO, CLS>(s / TPT) * TPT + s % TPT);
+      });
+      tfor<NSTEP>([&](auto s_tag) {
+        constexpr int s = decltype(s_tag)::value, k = s / TPT, j = s % TPT;
+        if constexpr (s + PFB < NSTEP) bq[(s + PFB) % RB] = ldb(on_tap<GEO, CLS>((s + PFB) / TPT) * TPT + (s + PFB) % TPT);
+        if constexpr (j == 1 && k + 1 < NON) lda(std::integral_constant<int, k + 1>{});
+        asm volatile("" ::: "memory");                       // (every read stays where it is written)
+        const v6i bv = bq[s % RB];
+#pragma unroll
+        for (int i = 0; i < TPP; ++i) {
+          if (SPK_VT_DBG & 1) continue;
+          if constexpr (NCH == 2) {
+            if constexpr (j < 4) mm(acc[i][j & 1], av[k & 1][i][j >> 1], bv, sc_p);
+            else mm(acc[i][2], half ? av[k & 1][i][1] : av[k & 1][i][0], bv, sc_4);
+          } else {
+            mm(acc[i][j], av[k & 1][i][0], bv, j < 2 ? sc_p : sc_4);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+#else
       tfor<9>([&](auto tap_tag) {
         constexpr int TAP = decltype(tap_tag)::value, KY = TAP / 3, KX = TAP % 3;
         // GEO 0: oy = 2 iy - 1 + ky: class parity PY takes ky = 1 (iy = qy) when even, ky = 0 (iy = qy + 1) and ky = 2 (iy = qy) when odd
@@ -212,16 +289,16 @@ __global__ __launch_bounds__(512, 1) void vae_fp6_kernel(TArgs a) {
           constexpr int DY = GEO == 1 ? KY : ((PY == 1 && KY == 0) ? 1 : 0), DX = GEO == 1 ? KX : ((PX == 1 && KX == 0) ? 1 : 0);
           constexpr int TOFF = (DY * SCOLS + DX) * POSB;
           if constexpr (NCH == 2) {
-            v4i av[2][2];
+            v4i av[TPP][2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TPP; ++i) {
               av[i][0] = *reinterpret_cast<const v4i*>(A0 + base[i] + TOFF);
               av[i][1] = *reinterpret_cast<const v4i*>(A0 + A_CH + base[i] + TOFF);
             }
             const v6i b0 = ldb(TAP * TPT + 0), b1 = ldb(TAP * TPT + 1), b2 = ldb(TAP * TPT + 2), b3 = ldb(TAP * TPT + 3),
                       b4 = ldb(TAP * TPT + 4);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TPP; ++i) {
               if (SPK_VT_DBG & 1) continue;
               mm(acc[i][0], av[i][0], b0, sc_p);
               mm(acc[i][1], av[i][0], b1, sc_p);
@@ -231,12 +308,12 @@ __global__ __launch_bounds__(512, 1) void vae_fp6_kernel(TArgs a) {
               mm(acc[i][2], a4, b4, sc_4);
             }
           } else {
-            v4i av[2];
+            v4i av[TPP];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const v4i*>(A0 + base[i] + TOFF);
+            for (int i = 0; i < TPP; ++i) av[i] = *reinterpret_cast<const v4i*>(A0 + base[i] + TOFF);
             const v6i b0 = ldb(TAP * TPT + 0), b1 = ldb(TAP * TPT + 1), b4 = ldb(TAP * TPT + 2);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TPP; ++i) {
               if (SPK_VT_DBG & 1) continue;
               mm(acc[i][0], av[i], b0, sc_p);
               mm(acc[i][1], av[i], b1, sc_p);
@@ -245,9 +322,10 @@ __global__ __launch_bounds__(512, 1) void vae_fp6_kernel(TArgs a) {
           }
         }
       });
+#endif
       // ---- epilogue: fp32 recombination, BN, LIF scan with certification, output
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < TPP; ++i) {
         // D_t = D_{t-1} / 2 + cE + 4 eps (|z_t| + |v_{t-1}|) and |v| <= max |z|, so D_t <= 2 cE + 16 eps max_t |z_t| for every t:
         // track max |z| and min |h - 1| (two instructions per step instead of five) and compare once
         float v = 0.f, m = 0.f, zmax = 0.f, dmin = 3.0e38f;
@@ -325,7 +403,7 @@ __global__ __launch_bounds__(512, 1) void vae_fp6_kernel(TArgs a) {
       }
     };
 
-    for (int P = wave; P < NCLS * NPASS; P += 8) {
+    for (int P = wave; P < NCLS * NPASS; P += SPK_VT_NWV) {
       const int cls = P / NPASS, k = P - cls * NPASS;
       if constexpr (NCLS == 1) {
         run_pass(std::integral_constant<int, 0>{}, k);
@@ -573,7 +651,7 @@ int launch_vae(const TArgs& a, long long n_words, hipStream_t stream) {
   if (lds > 160 * 1024) return SPK_ERR_UNSUPPORTED;
   const int cus = spk_cu_count(), G = a.Cout / 32;
   const int grid = cus >= G ? (cus / G) * G : G;
-  hipLaunchKernelGGL((vae_fp6_kernel<GEO, H, W, NCH, OUT, SPLIT, DB>), dim3(grid), dim3(512), lds, stream, a);
+  hipLaunchKernelGGL((vae_fp6_kernel<GEO, H, W, NCH, OUT, SPLIT, DB>), dim3(grid), dim3(SPK_VT_NWV * 64), lds, stream, a);
   SPK_LAUNCH_CHECK();
   hipLaunchKernelGGL((vae_fp6_fixup_kernel<GEO, H, W, NCH, OUT>), dim3(4 * cus), dim3(256), 0, stream, a, n_words);
   SPK_LAUNCH_CHECK();
