@@ -341,6 +341,17 @@ long long spk_conv3x3_wgrad_ws_bytes(int N, int Cout, int Cin);
 int spk_conv3x3_wgrad_bf16(const float* gy_cl, const float* spikes_cl, float* ws, long long ws_bytes, float* gw_out, int N, int H,
                            int W, int Cout, int Cin, spk_stream_t stream);
 
+/* Data gradient of the same convolution (autograd of layer.Conv2d in the training step, R/snn_model/vq_diffusion.py:166-187;
+ * cuDNN's data-gradient kernels in the reference): gi[n][y][x][ci] = sum over (co, ky, kx) of gy[n][y+1-ky][x+1-kx][co] *
+ * w[co][ky][kx][ci], channels-last fp32 tensors (gy [N][49][Cout], w [Cout][3][3][Cin], gi [N][49][Cin]).  Both operands are
+ * split into three bf16 terms exactly and six cross products run on the bf16 matrix cores with fp32 accumulation (what is
+ * dropped is below 2^-24 of a product): an fp32 GEMM's accuracy.  ws: spk_conv3x3_dgrad_ws_bytes(Cout, Cin) bytes (the packed
+ * weight terms, rewritten by every call).  Deterministic.  7x7 maps, Cout % 16 == 0, Cin % 32 == 0; otherwise
+ * SPK_ERR_UNSUPPORTED (use the framework's operator). */
+long long spk_conv3x3_dgrad_ws_bytes(int Cout, int Cin);
+int spk_conv3x3_dgrad_bf16(const float* gy_cl, const float* w_cl, uint8_t* ws, long long ws_bytes, float* gi_out, int N, int H,
+                           int W, int Cout, int Cin, hipStream_t stream);
+
 /* ---- sampler ---------------------------------------------------------------------------------------------------- */
 /* Images touched by reverse step t.  R/snn_model/vq_diffusion.py:113-124 computes `changes = (u < 1/t) & ~unmasked`
  * BEFORE the denoiser call and only scatters the sample there (:140): for an image without a change at step t the

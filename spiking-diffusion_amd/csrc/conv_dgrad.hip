@@ -1,0 +1,249 @@
+// Data gradient of a 3x3 / stride 1 / pad 1 convolution on 7x7 maps, on the bf16 matrix cores with fp32 accuracy
+// (the training step of the denoiser, R/snn_model/vq_diffusion.py:166-187 through autograd; the
+// reference runs cuDNN's data-gradient kernels here):
+//
+//   gi[n][y][x][ci] = sum over (co, ky, kx) of  gy[n][y + 1 - ky][x + 1 - kx][co] * w[co][ky][kx][ci]
+//
+// a GEMM per image with M = 49 positions, N = Cin, K = 9 Cout, both operands dense fp32.  Each operand is split into THREE
+// bf16 terms by truncation (x = x0 + x1 + x2 exactly: 8 + 8 + 8 significant bits) and SIX of the nine cross products are
+// multiplied on v_mfma_f32_32x32x16_bf16 -- (0,0) (0,1) (1,0) (0,2) (2,0) (1,1): every product is exact, what is dropped is
+// below 2^-24 of |g w|, and the fp32 accumulation rounds like an fp32 GEMM's -- against ONE product per element pair on the
+// fp32 matrix instruction at 1/16 of the bf16 rate: 6/16 of its time at equal pipe occupancy.
+//
+// Mapping.  One workgroup = eight images (one per wave) x 32 NT input channels; a wave owns its image's two 32-row position
+// tiles (49 positions + 15 rows computed and dropped) x NT column tiles (32 NT accumulator registers).  K runs in chunks of 16
+// output channels (one MFMA k step) x nine taps:
+//   * the weights of a chunk are pre-packed ONCE per call (dgrad_pack_kernel) as the three bf16 planes in the B-fragment
+//     order [term][tap][k half][ci][8 co], one contiguous 27 NT KB blob per (channel tile, chunk): staging is a flat copy;
+//   * the chunk of each image's gy is split while it is deposited into a zero-bordered 9x9 grid per (term, k half): the A
+//     fragment of tap (ky, kx) is ONE aligned 16-byte read at a constant offset from a per-lane base (no im2col);
+//   * the next chunk's operands travel global -> registers while the current one is multiplied; per tap a wave reads 6 A and
+//     3 NT B fragments for 12 NT MFMAs.
+// No split K: every output is written once, by one wave, in a fixed order (deterministic).
+#include "spk_common.h"
+#include "den_common.h"
+#include "../../include/spkdiff.h"
+
+namespace {
+
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int HW7 = 49, NIMG = 8, NTHR = 512, KC = 16;     // images per workgroup, threads, output channels per chunk
+constexpr int NCELL = 82;                                   // 9 x 9 grid cells per (term, k half) + one spare (keeps images 16 B x 82 apart)
+constexpr int G_IMG = 3 * 2 * NCELL * 16;                   // bytes of one image's chunk in LDS: [term][k half][cell][8 co]
+__host__ __device__ constexpr int w_blob(int nt) { return 3 * 9 * 2 * 32 * nt * 16; }     // bytes of one packed weight chunk
+
+struct DgArgs {
+  const float* gy; const uint8_t* wp; float* gi;
+  int N, Cout, Cin;
+};
+
+// x = x0 + x1 + x2 exactly, each a bf16 (the top 16 bits of an fp32): truncate, subtract (exact), truncate, subtract
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+  h = __float_as_uint(x) & 0xFFFF0000u;
+  const float r1 = x - __uint_as_float(h);
+  m = __float_as_uint(r1) & 0xFFFF0000u;
+  l = __float_as_uint(r1 - __uint_as_float(m));             // at most 8 significant bits are left: its truncation is exact
+}
+
+// w [Cout][9][Cin] fp32 -> blobs [ci tile][chunk][term][tap][k half][ci in tile][8 co] bf16
+__global__ void dgrad_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cout, int Cin, int CI) {
+  const long long n = (long long)Cout * 9 * Cin;
+  const int n_chunks = Cout / KC;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin), tap = (int)((i / Cin) % 9), co = (int)(i / (9LL * Cin));
+    unsigned h, m, l;
+    split3(w[i], h, m, l);
+    const int tile = ci / CI, cil = ci % CI, chunk = co / KC, col = co % KC, kh = col >> 3, e = col & 7;
+    const long long blob = ((long long)tile * n_chunks + chunk) * (3LL * 9 * 2 * CI * 8);
+    const long long o = blob + ((long long)(tap * 2 + kh) * CI + cil) * 8 + e;
+    const long long term = 9LL * 2 * CI * 8;
+    wp[o] = (unsigned short)(h >> 16);
+    wp[o + term] = (unsigned short)(m >> 16);
+    wp[o + 2 * term] = (unsigned short)(l >> 16);
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NTHR, 1) void dgrad3x3_bf16_kernel(DgArgs a) {
+  constexpr int CI = 32 * NT, WB = w_blob(NT);
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  uint8_t* const sW = lds;                                  // [term][tap][k half][ci][8 co] bf16
+  uint8_t* const sG = lds + WB;                             // [image][term][k half][cell][8 co] bf16
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_ct = a.Cin / CI, n_chunks = a.Cout / KC;
+  const int ct = blockIdx.x % n_ct, ig = blockIdx.x / n_ct;
+  const int n0 = ig * NIMG, ci0 = ct * CI;
+
+  // zero the gy grids once: the border cells stay zero for the whole launch, interiors are rewritten by every chunk
+  for (int i = tid; i < NIMG * G_IMG / 16; i += NTHR) reinterpret_cast<uint4*>(sG)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+
+  // staging shares.  gy chunk: 8 images x 49 positions x 4 quarters of 16 channels (item tid + 512 j: image, position, quarter);
+  // weights: a flat copy of WB bytes in 16-byte vectors
+  constexpr int NG = (NIMG * HW7 * 4 + NTHR - 1) / NTHR;    // 4
+  constexpr int NW = (WB / 16 + NTHR - 1) / NTHR;           // 4 / 7
+  v4f rg[NG];                                               // (ext vectors: HIP's uint4 / float4 structs kept these arrays in scratch)
+  v4i rw[NW];
+  int g_src[NG], g_dst[NG];                                 // element offset in gy (without the chunk's channel offset) / LDS byte offset, -1: none
+#pragma unroll
+  for (int j = 0; j < NG; ++j) {
+    const int idx = tid + NTHR * j;
+    const int img = idx / (HW7 * 4), rem = idx % (HW7 * 4), pos = rem >> 2, q = rem & 3;
+    const bool ok = idx < NIMG * HW7 * 4 && n0 + img < a.N;
+    const int nn = n0 + img < a.N ? n0 + img : a.N - 1;
+    g_src[j] = (nn * HW7 + pos) * a.Cout + 4 * q;
+    const int cell = (pos / 7 + 1) * 9 + (pos % 7 + 1);
+    g_dst[j] = ok ? img * G_IMG + ((q >> 1) * NCELL + cell) * 16 + (q & 1) * 8 : -1;
+  }
+  const uint8_t* const wsrc = a.wp + ((long long)ct * n_chunks) * WB;
+  auto fetch = [&](int chunk) {
+    const float* g = a.gy + chunk * KC;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) rg[j] = *reinterpret_cast<const v4f*>(g + g_src[j]);
+    const v4i* wv = reinterpret_cast<const v4i*>(wsrc + (long long)chunk * WB);
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int i = tid + NTHR * j;
+      rw[j] = wv[i < WB / 16 ? i : WB / 16 - 1];
+    }
+  };
+  auto deposit = [&]() {
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      if (g_dst[j] >= 0) {
+        unsigned h[4], m[4], l[4];
+        split3(rg[j][0], h[0], m[0], l[0]); split3(rg[j][1], h[1], m[1], l[1]);
+        split3(rg[j][2], h[2], m[2], l[2]); split3(rg[j][3], h[3], m[3], l[3]);
+        uint8_t* d = sG + g_dst[j];
+        *reinterpret_cast<uint2*>(d) = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
+        *reinterpret_cast<uint2*>(d + 2 * NCELL * 16) = make_uint2((m[0] >> 16) | m[1], (m[2] >> 16) | m[3]);
+        *reinterpret_cast<uint2*>(d + 4 * NCELL * 16) = make_uint2((l[0] >> 16) | (l[1] & 0xFFFF0000u), (l[2] >> 16) | (l[3] & 0xFFFF0000u));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int i = tid + NTHR * j;
+      if (i < WB / 16) reinterpret_cast<v4i*>(sW)[i] = rw[j];
+    }
+  };
+
+  // fragment bases: A row = position 32 mt + (lane % 32) of this wave's image (rows past 48 repeat position 48: computed,
+  // never stored), k half = lane / 32; B column = input channel 32 nt + lane % 32
+  const int row = lane & 31, half = lane >> 5;
+  const uint8_t* a_base[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    int p = 32 * mt + row;
+    p = p < HW7 ? p : HW7 - 1;
+    a_base[mt] = sG + wave * G_IMG + (half * NCELL + (p / 7) * 9 + (p % 7)) * 16;
+  }
+  const uint8_t* const b_base = sW + (half * CI + row) * 16;
+
+  // TWO accumulators per output tile: the leading product (0,0) and the five small ones.  In one accumulator every small
+  // product re-rounds the whole sum (six roundings of size eps |sum| per k step instead of one: 6e-7 relative L2 against fp64
+  // where the framework's fp32 operator has 2e-7); the small products are below 2^-7 of the leading one, so the rounding of
+  // their own sum is negligible and the leading chain is as long as an fp32 GEMM's.
+  v16f acc[2][NT], acs[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[mt][nt][r] = 0.f; acs[mt][nt][r] = 0.f; }
+
+  fetch(0);
+  deposit();
+  __syncthreads();
+  for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    if (chunk + 1 < n_chunks) fetch(chunk + 1);
+    // nine taps: the fragments of tap t + 1 are read while the products of tap t run
+    v4i af[2][2][3], bf[2][NT][3];
+    auto load_tap = [&](int tap, int slot) {
+      // gy position of output (y, x) under tap (ky, kx): (y + 1 - ky, x + 1 - kx) -> grid cell (y + 2 - ky) * 9 + (x + 2 - kx)
+      const int toff = ((2 - tap / 3) * 9 + (2 - tap % 3)) * 16;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) af[slot][mt][t] = *reinterpret_cast<const v4i*>(a_base[mt] + t * 2 * NCELL * 16 + toff);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          bf[slot][nt][t] = *reinterpret_cast<const v4i*>(b_base + ((t * 9 + tap) * 2 * CI + nt * 32) * 16);
+      }
+    };
+    load_tap(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int s = tap & 1;
+      if (tap + 1 < 9) load_tap(tap + 1, s ^ 1);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);                    // all of the next tap's reads are in flight before this tap's MFMAs
+      // the six products (term of gy, term of w): (0,0) (0,1) (1,0) (0,2) (2,0) (1,1)
+      constexpr int TG[6] = {0, 0, 1, 0, 2, 1}, TW[6] = {0, 1, 0, 2, 0, 1};
+#pragma unroll
+      for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            v16f& d = pr == 0 ? acc[mt][nt] : acs[mt][nt];
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, af[s][mt][TG[pr]]),
+                                                        __builtin_bit_cast(v8bf, bf[s][nt][TW[pr]]), d, 0, 0, 0);
+          }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                                        // everyone is done reading this chunk
+    if (chunk + 1 < n_chunks) deposit();
+    __syncthreads();
+  }
+
+  const int n = n0 + wave;
+  if (n < a.N) {
+    float* out = a.gi + (long long)n * HW7 * a.Cin + ci0 + row;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (p < HW7) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) out[(long long)p * a.Cin + nt * 32] = acc[mt][nt][r] + acs[mt][nt][r];
+        }
+      }
+  }
+}
+
+// column tiles per wave.  One: with two accumulators per output tile (below) a second column tile needs 128 accumulator
+// registers and leaves no room for double-buffered fragments (two tiles in ONE accumulator each: 434 us for the 256 -> 512
+// layer at B = 32 with the reads of a tap exposed)
+int dgrad_nt(int, int) { return 1; }
+
+}  // namespace
+
+extern "C" long long spk_conv3x3_dgrad_ws_bytes(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0 || (Cout % KC) || (Cin % 32)) return -1;
+  return (long long)Cout * 9 * Cin * 6;
+}
+
+extern "C" int spk_conv3x3_dgrad_bf16(const float* gy_cl, const float* w_cl, uint8_t* ws, long long ws_bytes, float* gi_out,
+                                      int N, int H, int W, int Cout, int Cin, hipStream_t stream) {
+  if (!gy_cl || !w_cl || !ws || !gi_out || N <= 0) return SPK_ERR_ARG;
+  if (H != 7 || W != 7 || Cout <= 0 || Cin <= 0 || (Cout % KC) || (Cin % 32)) return SPK_ERR_UNSUPPORTED;
+  if ((long long)N * HW7 * Cout >= (1LL << 31)) return SPK_ERR_UNSUPPORTED;      // (32-bit element offsets in the staging table)
+  if (ws_bytes < (long long)Cout * 9 * Cin * 6) return SPK_ERR_ARG;
+  const int nt = dgrad_nt(N, Cin), CI = 32 * nt;
+  const long long n = (long long)Cout * 9 * Cin;
+  hipLaunchKernelGGL(dgrad_pack_kernel, dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, stream,
+                     w_cl, reinterpret_cast<unsigned short*>(ws), Cout, Cin, CI);
+  SPK_LAUNCH_CHECK();
+  DgArgs a;
+  a.gy = gy_cl; a.wp = ws; a.gi = gi_out; a.N = N; a.Cout = Cout; a.Cin = Cin;
+  const int grid = ((N + NIMG - 1) / NIMG) * (Cin / CI);
+  const size_t lds = (size_t)w_blob(nt) + (size_t)NIMG * G_IMG;
+  if (nt == 2) hipLaunchKernelGGL((dgrad3x3_bf16_kernel<2>), dim3(grid), dim3(NTHR), lds, stream, a);
+  else hipLaunchKernelGGL((dgrad3x3_bf16_kernel<1>), dim3(grid), dim3(NTHR), lds, stream, a);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}

@@ -793,6 +793,32 @@ def conv3x3_wgrad(gy_cl, spikes_cl, Cout, Cin):
     return gw.permute(0, 3, 1, 2)
 
 
+def conv3x3_dgrad_supported(Cout, Cin, H, W, N):
+    # (small layers and small batches: the framework's operator is as fast)
+    return (H, W) == (7, 7) and Cout % 16 == 0 and Cin % 32 == 0 and Cout * Cin >= 32768 and N >= 64
+
+
+# False: the data gradient of the spike-input convolutions comes from the framework's operator (as in rounds 1-2)
+NATIVE_DGRAD = True
+
+
+def conv3x3_dgrad(gy_cl, weight, Cin):
+    """gi [N,Cin,7,7] (channels-last memory) of a 3x3 / s1 / p1 convolution from gy [N,Cout,7,7] (channels-last fp32) and the
+    weight [Cout,Cin,3,3] (spk_conv3x3_dgrad_bf16: bf16 matrix cores, both operands split into three bf16 terms exactly, six
+    cross products: fp32 accuracy)."""
+    N, Cout = int(gy_cl.shape[0]), int(gy_cl.shape[1])
+    nb = int(lib.spk_conv3x3_dgrad_ws_bytes(Cout, int(Cin)))
+    if nb <= 0:
+        raise NotImplementedError("spk_conv3x3_dgrad_bf16: unsupported shape")
+    w_cl = weight.detach().contiguous(memory_format=torch.channels_last)        # storage [Cout][3][3][Cin]
+    ws = torch.empty(nb, dtype=torch.uint8, device=gy_cl.device)
+    gi = torch.empty((N, 7, 7, Cin), dtype=torch.float32, device=gy_cl.device)
+    with timed("train.conv_bwd_data"):
+        check(lib.spk_conv3x3_dgrad_bf16(_p(gy_cl), _p(w_cl), _p(ws), nb, _p(gi), N, 7, 7, Cout, int(Cin), _stream(gy_cl)),
+              "spk_conv3x3_dgrad_bf16")
+    return gi.permute(0, 3, 1, 2)
+
+
 class SpikeConvTrainFunction(torch.autograd.Function):
     """y = conv3x3(spikes, weight) + bias for BINARY input spikes in training: the forward is the exact
     fp6 x fp4 MFMA convolution (weights re-packed into six radix-32 digit planes each call -- they change every optimizer
@@ -823,6 +849,11 @@ class SpikeConvTrainFunction(torch.autograd.Function):
             # the weight gradient multiplies gy by SPIKES: native on the bf16 matrix cores (the data gradient has no spike operand)
             gw_native = conv3x3_wgrad(gy, s4, Cout, Cin)
             need_gw = False
+        gi_native = None
+        if (NATIVE_DGRAD and need_gi and tuple(weight.shape[2:]) == (3, 3) and
+                conv3x3_dgrad_supported(Cout, Cin, int(s.shape[3]), int(s.shape[4]), int(gy.shape[0]))):
+            gi_native = conv3x3_dgrad(gy, weight, Cin)
+            need_gi = False
         gi = gw = gb = None
         if need_gi or need_gw or (need_gb and gw_native is None):
             gi, gw, gb = torch.ops.aten.convolution_backward(
@@ -832,8 +863,10 @@ class SpikeConvTrainFunction(torch.autograd.Function):
             gw = gw_native
             if need_gb:
                 gb = gy.sum(dim=(0, 2, 3))
+        if gi_native is not None:
+            gi = gi_native
         if gi is not None:
-            gi = gi.view(s.shape)
+            gi = gi.reshape(s.shape) if gi_native is None else gi.unflatten(0, (s.shape[0], s.shape[1]))
         return gi, gw, gb
 
 
