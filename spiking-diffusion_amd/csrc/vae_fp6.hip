@@ -77,6 +77,11 @@ constexpr float CERT_4EPS = 4.0f * 2.38418579e-07f;
                                 // fragments one tap ahead, schedule pinned); measured equal (264-267 against 267 us): hipcc already defers the
                                 // second tile's MFMAs to after the first tile's scan and runs them back to back from registers
 #endif
+#ifndef SPK_VT_STAGGER
+#define SPK_VT_STAGGER 0        // s_sleep argument (x 64 cycles) of waves 4..7 after every item barrier.  Measured (convT2, B = 1024): 8 / 16 / 24 /
+                                // 32 / 48 -> 273 / 270-274 / 273 / 273 / 275 us against 266-267: a wave that scans while its partner multiplies
+                                // issues its vector instructions at the single-wave rate (6.3 instead of 3.1 cycles): nothing is gained
+#endif
 #ifndef SPK_VT_TPP
 #define SPK_VT_TPP 2            // row tiles per pass (a weight tile read from LDS serves all of them)
 #endif
@@ -202,6 +207,12 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
     spk_dma_wait_all();
     __syncthreads();
     if (DB && itm + lanes < nitems) stage(itm + lanes, buf ^ 1);
+#if SPK_VT_STAGGER > 0
+    // The two waves of a SIMD run the same pass list from the same barrier, so both are in their multiply phase together (each
+    // then sees the matrix pipe at half rate: stamped 65-70 cycles per MFMA) and in their scans together.  The second wave
+    // starts every item this many x 64 cycles late: its multiply phases then fall into the first one's scans.
+    if (wave >= SPK_VT_NWV / 2) __builtin_amdgcn_s_sleep(SPK_VT_STAGGER);
+#endif
     const uint8_t* const A0 = sA + buf * A_BYTES;
 
     auto run_pass = [&](auto cls_tag, int k) __attribute__((always_inline)) {
