@@ -351,6 +351,13 @@ int spk_conv3x3_wgrad_bf16(const float* gy_cl, const float* spikes_cl, float* ws
 long long spk_conv3x3_dgrad_ws_bytes(int Cout, int Cin);
 int spk_conv3x3_dgrad_bf16(const float* gy_cl, const float* w_cl, uint8_t* ws, long long ws_bytes, float* gi_out, int N, int H,
                            int W, int Cout, int Cin, hipStream_t stream);
+/* The same data gradient with TWO fp16 terms per operand and three cross products (half the matrix work): every image's gy
+ * and every input channel's weights are scaled by a power of two that puts their largest magnitude into [2^14, 2^15), x 2^s =
+ * h + m to 2^-23 (h, m: nearest fp16 of the value and of the exact remainder), products (h,h) (h,m) (m,h), fp32 accumulation,
+ * exact descaling.  Values more than 28 binades below their image's / channel's maximum lose relative (not absolute)
+ * precision.  Same arguments, workspace and shapes as spk_conv3x3_dgrad_bf16. */
+int spk_conv3x3_dgrad_f16x2(const float* gy_cl, const float* w_cl, uint8_t* ws, long long ws_bytes, float* gi_out, int N, int H,
+                            int W, int Cout, int Cin, hipStream_t stream);
 
 /* ---- sampler ---------------------------------------------------------------------------------------------------- */
 /* Images touched by reverse step t.  R/snn_model/vq_diffusion.py:113-124 computes `changes = (u < 1/t) & ~unmasked`

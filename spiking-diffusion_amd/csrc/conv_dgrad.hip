@@ -24,6 +24,8 @@
 #include "den_common.h"
 #include "../../include/spkdiff.h"
 
+extern "C" long long spk_conv3x3_dgrad_ws_bytes(int Cout, int Cin);
+
 namespace {
 
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
@@ -32,13 +34,65 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int HW7 = 49, NIMG = 8, NTHR = 512, KC = 16;     // images per workgroup, threads, output channels per chunk
 constexpr int NCELL = 82;                                   // 9 x 9 grid cells per (term, k half) + one spare (keeps images 16 B x 82 apart)
-constexpr int G_IMG = 3 * 2 * NCELL * 16;                   // bytes of one image's chunk in LDS: [term][k half][cell][8 co]
-__host__ __device__ constexpr int w_blob(int nt) { return 3 * 9 * 2 * 32 * nt * 16; }     // bytes of one packed weight chunk
+__host__ __device__ constexpr int g_img(int nterm) { return nterm * 2 * NCELL * 16; }   // bytes of one image's chunk in LDS: [term][k half][cell][8 co]
+__host__ __device__ constexpr int w_blob(int nterm, int nt) { return nterm * 9 * 2 * 32 * nt * 16; }     // bytes of one packed weight chunk
 
 struct DgArgs {
   const float* gy; const uint8_t* wp; float* gi;
+  const unsigned* wmax;                                     // F16 form: bits of max |w| per input channel
   int N, Cout, Cin;
 };
+
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+
+// F16 form.  x 2^s = h + m + (less than 2^-23 |x 2^s|): h = the fp16 nearest to x 2^s, m = the fp16 nearest to the (exact)
+// remainder.  s puts the largest magnitude of the scaled set into [2^14, 2^15): 28 binades below it keep full precision.
+__device__ __forceinline__ float scale_of(unsigned max_bits) {          // 2^s for a set whose largest magnitude has these bits
+  int be = (int)((max_bits >> 23) & 0xFFu);
+  if (be == 0) return 1.0f;                                              // all zero (or denormal): nothing to scale
+  be = be < 32 ? 32 : be;
+  return __uint_as_float((unsigned)(268 - be) << 23);                    // 2^(15 - (be - 126))
+}
+__device__ __forceinline__ float inv_scale_of(unsigned max_bits) {
+  int be = (int)((max_bits >> 23) & 0xFFu);
+  if (be == 0) return 1.0f;
+  be = be < 32 ? 32 : be;
+  return __uint_as_float((unsigned)(be - 14) << 23);                     // 2^-(141 - be)
+}
+__device__ __forceinline__ void split2h(float xs, _Float16& h, _Float16& m) {
+  h = (_Float16)xs;
+  m = (_Float16)(xs - (float)h);
+}
+
+// F16 form, first pre-pass: bits of max |w| per input channel (wmax zeroed by the caller; positive floats order like their bits)
+__global__ void dgrad_wmax_kernel(const float* __restrict__ w, unsigned* __restrict__ wmax, int rows, int Cin) {
+  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ci >= Cin) return;
+  unsigned m = 0;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+    const unsigned b = __float_as_uint(w[(long long)r * Cin + ci]) & 0x7FFFFFFFu;
+    m = b > m ? b : m;
+  }
+  atomicMax(wmax + ci, m);
+}
+
+// F16 form, second pre-pass: w [Cout][9][Cin] fp32 -> blobs [ci tile][chunk][term 2][tap][k half][ci in tile][8 co] fp16 of w 2^s(ci)
+__global__ void dgrad_pack_f16_kernel(const float* __restrict__ w, const unsigned* __restrict__ wmax, _Float16* __restrict__ wp,
+                                      int Cout, int Cin, int CI) {
+  const long long n = (long long)Cout * 9 * Cin;
+  const int n_chunks = Cout / KC;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin), tap = (int)((i / Cin) % 9), co = (int)(i / (9LL * Cin));
+    _Float16 h, m;
+    split2h(w[i] * scale_of(wmax[ci]), h, m);
+    const int tile = ci / CI, cil = ci % CI, chunk = co / KC, col = co % KC, kh = col >> 3, e = col & 7;
+    const long long blob = ((long long)tile * n_chunks + chunk) * (2LL * 9 * 2 * CI * 8);
+    const long long o = blob + ((long long)(tap * 2 + kh) * CI + cil) * 8 + e;
+    wp[o] = h;
+    wp[o + 9LL * 2 * CI * 8] = m;
+  }
+}
 
 // x = x0 + x1 + x2 exactly, each a bf16 (the top 16 bits of an fp32): truncate, subtract (exact), truncate, subtract
 __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
@@ -66,9 +120,10 @@ __global__ void dgrad_pack_kernel(const float* __restrict__ w, unsigned short* _
   }
 }
 
-template <int NT>
-__global__ __launch_bounds__(NTHR, 1) void dgrad3x3_bf16_kernel(DgArgs a) {
-  constexpr int CI = 32 * NT, WB = w_blob(NT);
+template <int NT, bool F16>
+__global__ __launch_bounds__(NTHR, 1) void dgrad3x3_kernel(DgArgs a) {
+  constexpr int NTERM = F16 ? 2 : 3, NPROD = F16 ? 3 : 6;
+  constexpr int CI = 32 * NT, WB = w_blob(NTERM, NT), G_IMG = g_img(NTERM);
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   uint8_t* const sW = lds;                                  // [term][tap][k half][ci][8 co] bf16
   uint8_t* const sG = lds + WB;                             // [image][term][k half][cell][8 co] bf16
@@ -79,6 +134,30 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_bf16_kernel(DgArgs a) {
 
   // zero the gy grids once: the border cells stay zero for the whole launch, interiors are rewritten by every chunk
   for (int i = tid; i < NIMG * G_IMG / 16; i += NTHR) reinterpret_cast<uint4*>(sG)[i] = make_uint4(0, 0, 0, 0);
+  float* const s_scale = reinterpret_cast<float*>(lds + WB + NIMG * G_IMG);            // F16 form: 2^s of the workgroup's images
+  float my_inv = 1.0f;
+  if constexpr (F16) {
+    // this wave's image: largest magnitude of its whole output gradient (49 x Cout values, read once more here)
+    const int nn = n0 + wave < a.N ? n0 + wave : a.N - 1;
+    const v4f* gp = reinterpret_cast<const v4f*>(a.gy + (long long)nn * HW7 * a.Cout);
+    const int n4 = HW7 * a.Cout / 4;
+    unsigned mb = 0;
+    for (int i = lane; i < n4; i += 64) {
+      const v4f v = gp[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned b = __float_as_uint(v[e]) & 0x7FFFFFFFu;
+        mb = b > mb ? b : mb;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned o = (unsigned)__shfl_xor((int)mb, off);
+      mb = o > mb ? o : mb;
+    }
+    if (lane == 0) s_scale[wave] = scale_of(mb);
+    my_inv = inv_scale_of(mb);
+  }
   __syncthreads();
 
   // staging shares.  gy chunk: 8 images x 49 positions x 4 quarters of 16 channels (item tid + 512 j: image, position, quarter);
@@ -88,6 +167,7 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_bf16_kernel(DgArgs a) {
   v4f rg[NG];                                               // (ext vectors: HIP's uint4 / float4 structs kept these arrays in scratch)
   v4i rw[NW];
   int g_src[NG], g_dst[NG];                                 // element offset in gy (without the chunk's channel offset) / LDS byte offset, -1: none
+  float g_scl[NG];                                          // F16 form: 2^s of the item's image
 #pragma unroll
   for (int j = 0; j < NG; ++j) {
     const int idx = tid + NTHR * j;
@@ -97,6 +177,7 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_bf16_kernel(DgArgs a) {
     g_src[j] = (nn * HW7 + pos) * a.Cout + 4 * q;
     const int cell = (pos / 7 + 1) * 9 + (pos % 7 + 1);
     g_dst[j] = ok ? img * G_IMG + ((q >> 1) * NCELL + cell) * 16 + (q & 1) * 8 : -1;
+    g_scl[j] = F16 ? s_scale[idx < NIMG * HW7 * 4 ? img : 0] : 1.0f;
   }
   const uint8_t* const wsrc = a.wp + ((long long)ct * n_chunks) * WB;
   auto fetch = [&](int chunk) {
@@ -113,7 +194,17 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_bf16_kernel(DgArgs a) {
   auto deposit = [&]() {
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-      if (g_dst[j] >= 0) {
+      if (F16) {
+        if (g_dst[j] >= 0) {
+          _Float16 h[4], m[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split2h(rg[j][e] * g_scl[j], h[e], m[e]);
+          typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+          uint8_t* d = sG + g_dst[j];
+          *reinterpret_cast<v4h*>(d) = (v4h){h[0], h[1], h[2], h[3]};
+          *reinterpret_cast<v4h*>(d + 2 * NCELL * 16) = (v4h){m[0], m[1], m[2], m[3]};
+        }
+      } else if (g_dst[j] >= 0) {
         unsigned h[4], m[4], l[4];
         split3(rg[j][0], h[0], m[0], l[0]); split3(rg[j][1], h[1], m[1], l[1]);
         split3(rg[j][2], h[2], m[2], l[2]); split3(rg[j][3], h[3], m[3], l[3]);
@@ -160,12 +251,12 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_bf16_kernel(DgArgs a) {
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
     if (chunk + 1 < n_chunks) fetch(chunk + 1);
     // nine taps: the fragments of tap t + 1 are read while the products of tap t run
-    v4i af[2][2][3], bf[2][NT][3];
+    v4i af[2][2][NTERM], bf[2][NT][NTERM];
     auto load_tap = [&](int tap, int slot) {
       // gy position of output (y, x) under tap (ky, kx): (y + 1 - ky, x + 1 - kx) -> grid cell (y + 2 - ky) * 9 + (x + 2 - kx)
       const int toff = ((2 - tap / 3) * 9 + (2 - tap % 3)) * 16;
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
+      for (int t = 0; t < NTERM; ++t) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) af[slot][mt][t] = *reinterpret_cast<const v4i*>(a_base[mt] + t * 2 * NCELL * 16 + toff);
 #pragma unroll
@@ -180,17 +271,21 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_bf16_kernel(DgArgs a) {
       if (tap + 1 < 9) load_tap(tap + 1, s ^ 1);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);                    // all of the next tap's reads are in flight before this tap's MFMAs
-      // the six products (term of gy, term of w): (0,0) (0,1) (1,0) (0,2) (2,0) (1,1)
+      // the products (term of gy, term of w): (0,0) (0,1) (1,0) [(0,2) (2,0) (1,1): three-term form]
       constexpr int TG[6] = {0, 0, 1, 0, 2, 1}, TW[6] = {0, 1, 0, 2, 0, 1};
 #pragma unroll
-      for (int pr = 0; pr < 6; ++pr)
+      for (int pr = 0; pr < NPROD; ++pr)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             v16f& d = pr == 0 ? acc[mt][nt] : acs[mt][nt];
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, af[s][mt][TG[pr]]),
-                                                        __builtin_bit_cast(v8bf, bf[s][nt][TW[pr]]), d, 0, 0, 0);
+            if constexpr (F16)
+              d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, af[s][mt][TG[pr]]),
+                                                         __builtin_bit_cast(v8h, bf[s][nt][TW[pr]]), d, 0, 0, 0);
+            else
+              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, af[s][mt][TG[pr]]),
+                                                          __builtin_bit_cast(v8bf, bf[s][nt][TW[pr]]), d, 0, 0, 0);
           }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -202,6 +297,9 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_bf16_kernel(DgArgs a) {
   const int n = n0 + wave;
   if (n < a.N) {
     float* out = a.gi + (long long)n * HW7 * a.Cin + ci0 + row;
+    float cinv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) cinv[nt] = F16 ? inv_scale_of(a.wmax[ci0 + nt * 32 + row]) : 1.0f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -209,41 +307,74 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_bf16_kernel(DgArgs a) {
         const int p = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (p < HW7) {
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) out[(long long)p * a.Cin + nt * 32] = acc[mt][nt][r] + acs[mt][nt][r];
+          for (int nt = 0; nt < NT; ++nt) {
+            const float v = acc[mt][nt][r] + acs[mt][nt][r];
+            out[(long long)p * a.Cin + nt * 32] = F16 ? (v * my_inv) * cinv[nt] : v;      // (powers of two: exact)
+          }
         }
       }
   }
 }
 
-// column tiles per wave.  One: with two accumulators per output tile (below) a second column tile needs 128 accumulator
-// registers and leaves no room for double-buffered fragments (two tiles in ONE accumulator each: 434 us for the 256 -> 512
-// layer at B = 32 with the reads of a tap exposed)
-int dgrad_nt(int, int) { return 1; }
+// column tiles per wave.  Three-term form: one -- with two accumulators per output tile a second column tile needs 128
+// accumulator registers and leaves no room for double-buffered fragments (two tiles in ONE accumulator each: 434 us for the
+// 256 -> 512 layer at B = 32 with the reads of a tap exposed).  Two-term form: the count whose (rounds of workgroups over the
+// CUs) x (work per workgroup) is smaller, two on a tie -- measured at B = 32 (one | two tiles, us): 128 input channels 94 | 118,
+// 256: 305 | 253, 512: 292 | 246, 320: 122 | 125.
+int dgrad_nt(bool f16, int N, int Cin) {
+  if (!f16 || (Cin % 64)) return 1;
+  const long long cus = spk_cu_count(), groups = (N + NIMG - 1) / NIMG;
+  const long long r2 = (groups * (Cin / 64) + cus - 1) / cus * 2, r1 = (groups * (Cin / 32) + cus - 1) / cus;
+  return r2 <= r1 ? 2 : 1;
+}
+
+template <bool F16>
+int dgrad_launch(const float* gy_cl, const float* w_cl, uint8_t* ws, long long ws_bytes, float* gi_out, int N, int H, int W,
+                 int Cout, int Cin, hipStream_t stream) {
+  if (!gy_cl || !w_cl || !ws || !gi_out || N <= 0) return SPK_ERR_ARG;
+  if (H != 7 || W != 7 || Cout <= 0 || Cin <= 0 || (Cout % KC) || (Cin % 32)) return SPK_ERR_UNSUPPORTED;
+  if ((long long)N * HW7 * Cout >= (1LL << 31)) return SPK_ERR_UNSUPPORTED;      // (32-bit element offsets in the staging table)
+  if (ws_bytes < spk_conv3x3_dgrad_ws_bytes(Cout, Cin)) return SPK_ERR_ARG;
+  const int nt = dgrad_nt(F16, N, Cin), CI = 32 * nt;
+  const long long n = (long long)Cout * 9 * Cin;
+  const unsigned pack_grid = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  DgArgs a;
+  a.gy = gy_cl; a.wp = ws; a.gi = gi_out; a.N = N; a.Cout = Cout; a.Cin = Cin;
+  a.wmax = reinterpret_cast<const unsigned*>(ws + n * 6);
+  if (F16) {
+    unsigned* wmax = reinterpret_cast<unsigned*>(ws + n * 6);
+    { const hipError_t e = hipMemsetAsync(wmax, 0, (size_t)Cin * 4, stream); if (e != hipSuccess) return (int)e; }
+    hipLaunchKernelGGL(dgrad_wmax_kernel, dim3((Cin + 63) / 64, 64), dim3(64), 0, stream, w_cl, wmax, Cout * 9, Cin);
+    SPK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dgrad_pack_f16_kernel, dim3(pack_grid), dim3(256), 0, stream, w_cl, wmax, reinterpret_cast<_Float16*>(ws),
+                       Cout, Cin, CI);
+  } else {
+    hipLaunchKernelGGL(dgrad_pack_kernel, dim3(pack_grid), dim3(256), 0, stream, w_cl, reinterpret_cast<unsigned short*>(ws), Cout,
+                       Cin, CI);
+  }
+  SPK_LAUNCH_CHECK();
+  const int grid = ((N + NIMG - 1) / NIMG) * (Cin / CI);
+  const size_t lds = (size_t)w_blob(F16 ? 2 : 3, nt) + (size_t)NIMG * g_img(F16 ? 2 : 3) + 64;
+  if (F16 && nt == 2) hipLaunchKernelGGL((dgrad3x3_kernel<2, true>), dim3(grid), dim3(NTHR), lds, stream, a);
+  else if (F16) hipLaunchKernelGGL((dgrad3x3_kernel<1, true>), dim3(grid), dim3(NTHR), lds, stream, a);
+  else hipLaunchKernelGGL((dgrad3x3_kernel<1, false>), dim3(grid), dim3(NTHR), lds, stream, a);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
 
 }  // namespace
 
 extern "C" long long spk_conv3x3_dgrad_ws_bytes(int Cout, int Cin) {
   if (Cout <= 0 || Cin <= 0 || (Cout % KC) || (Cin % 32)) return -1;
-  return (long long)Cout * 9 * Cin * 6;
+  return (long long)Cout * 9 * Cin * 6 + (long long)Cin * 4 + 16;              // packed weight terms + per-channel maxima
 }
 
 extern "C" int spk_conv3x3_dgrad_bf16(const float* gy_cl, const float* w_cl, uint8_t* ws, long long ws_bytes, float* gi_out,
                                       int N, int H, int W, int Cout, int Cin, hipStream_t stream) {
-  if (!gy_cl || !w_cl || !ws || !gi_out || N <= 0) return SPK_ERR_ARG;
-  if (H != 7 || W != 7 || Cout <= 0 || Cin <= 0 || (Cout % KC) || (Cin % 32)) return SPK_ERR_UNSUPPORTED;
-  if ((long long)N * HW7 * Cout >= (1LL << 31)) return SPK_ERR_UNSUPPORTED;      // (32-bit element offsets in the staging table)
-  if (ws_bytes < (long long)Cout * 9 * Cin * 6) return SPK_ERR_ARG;
-  const int nt = dgrad_nt(N, Cin), CI = 32 * nt;
-  const long long n = (long long)Cout * 9 * Cin;
-  hipLaunchKernelGGL(dgrad_pack_kernel, dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, stream,
-                     w_cl, reinterpret_cast<unsigned short*>(ws), Cout, Cin, CI);
-  SPK_LAUNCH_CHECK();
-  DgArgs a;
-  a.gy = gy_cl; a.wp = ws; a.gi = gi_out; a.N = N; a.Cout = Cout; a.Cin = Cin;
-  const int grid = ((N + NIMG - 1) / NIMG) * (Cin / CI);
-  const size_t lds = (size_t)w_blob(nt) + (size_t)NIMG * G_IMG;
-  if (nt == 2) hipLaunchKernelGGL((dgrad3x3_bf16_kernel<2>), dim3(grid), dim3(NTHR), lds, stream, a);
-  else hipLaunchKernelGGL((dgrad3x3_bf16_kernel<1>), dim3(grid), dim3(NTHR), lds, stream, a);
-  SPK_LAUNCH_CHECK();
-  return SPK_OK;
+  return dgrad_launch<false>(gy_cl, w_cl, ws, ws_bytes, gi_out, N, H, W, Cout, Cin, stream);
+}
+
+extern "C" int spk_conv3x3_dgrad_f16x2(const float* gy_cl, const float* w_cl, uint8_t* ws, long long ws_bytes, float* gi_out,
+                                       int N, int H, int W, int Cout, int Cin, hipStream_t stream) {
+  return dgrad_launch<true>(gy_cl, w_cl, ws, ws_bytes, gi_out, N, H, W, Cout, Cin, stream);
 }

@@ -57,6 +57,7 @@ _SIGS = {
     "spk_conv3x3_wgrad_bf16": (c_int, [P, P, P, c_longlong, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_conv3x3_dgrad_ws_bytes": (c_longlong, [c_int, c_int]),
     "spk_conv3x3_dgrad_bf16": (c_int, [P, P, P, c_longlong, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "spk_conv3x3_dgrad_f16x2": (c_int, [P, P, P, c_longlong, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_psp": (c_int, [P, P, c_int, c_longlong, c_float, c_int, P]),
     "spk_masked_ce": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     "spk_spikes_to_ptc": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),

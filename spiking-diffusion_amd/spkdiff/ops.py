@@ -802,7 +802,11 @@ def conv3x3_dgrad_supported(Cout, Cin, H, W, N):
 NATIVE_DGRAD = True
 
 
-def conv3x3_dgrad(gy_cl, weight, Cin):
+# "bf16x3": three bf16 terms per operand, six products (exact splits); "f16x2": two scaled fp16 terms, three products
+DGRAD_FORM = "f16x2"
+
+
+def conv3x3_dgrad(gy_cl, weight, Cin, form=None):
     """gi [N,Cin,7,7] (channels-last memory) of a 3x3 / s1 / p1 convolution from gy [N,Cout,7,7] (channels-last fp32) and the
     weight [Cout,Cin,3,3] (spk_conv3x3_dgrad_bf16: bf16 matrix cores, both operands split into three bf16 terms exactly, six
     cross products: fp32 accuracy)."""
@@ -813,9 +817,11 @@ def conv3x3_dgrad(gy_cl, weight, Cin):
     w_cl = weight.detach().contiguous(memory_format=torch.channels_last)        # storage [Cout][3][3][Cin]
     ws = torch.empty(nb, dtype=torch.uint8, device=gy_cl.device)
     gi = torch.empty((N, 7, 7, Cin), dtype=torch.float32, device=gy_cl.device)
+    form = form or DGRAD_FORM
+    fn, name = ((lib.spk_conv3x3_dgrad_f16x2, "spk_conv3x3_dgrad_f16x2") if form == "f16x2"
+                else (lib.spk_conv3x3_dgrad_bf16, "spk_conv3x3_dgrad_bf16"))
     with timed("train.conv_bwd_data"):
-        check(lib.spk_conv3x3_dgrad_bf16(_p(gy_cl), _p(w_cl), _p(ws), nb, _p(gi), N, 7, 7, Cout, int(Cin), _stream(gy_cl)),
-              "spk_conv3x3_dgrad_bf16")
+        check(fn(_p(gy_cl), _p(w_cl), _p(ws), nb, _p(gi), N, 7, 7, Cout, int(Cin), _stream(gy_cl)), name)
     return gi.permute(0, 3, 1, 2)
 
 

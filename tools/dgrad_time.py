@@ -35,8 +35,9 @@ for name, Cout, Cin in LAYERS:
     w = (torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05).contiguous(memory_format=CL)
     t = 1.0 if os.environ.get("DGRAD_ONLY") else timed(lambda: dgrad(gy, x, w))
     fl = 2.0 * Cout * Cin * 9 * N * 49 / 1e9
-    tn = timed(lambda: ops.conv3x3_dgrad(gy, w, Cin))
-    line = f"{name} {Cin:3d}->{Cout:3d}  {fl:6.1f} GFLOP  native {tn:7.1f} us ({fl / tn * 1e3:6.1f} TFLOP/s) | library {t:7.1f} us ({fl / t * 1e3:6.1f} TFLOP/s)"
+    tn = timed(lambda: ops.conv3x3_dgrad(gy, w, Cin, form="bf16x3"))
+    tf = timed(lambda: ops.conv3x3_dgrad(gy, w, Cin, form="f16x2"))
+    line = f"{name} {Cin:3d}->{Cout:3d}  {fl:6.1f} GFLOP  bf16x3 {tn:7.1f} us ({fl / tn * 1e3:6.1f} TFLOP/s) | f16x2 {tf:7.1f} us ({fl / tf * 1e3:6.1f} TFLOP/s) | library {t:7.1f} us ({fl / t * 1e3:6.1f} TFLOP/s)"
     if Cin == 320 and len(sys.argv) > 2:
         for parts in ((256, 64), (128, 128, 64), (64,) * 5):
             ws, xs, o = [], [], 0

@@ -31,6 +31,11 @@ out = [f"{n_it} steady-state iterations: {tot / n_it / 1e3:.3f} ms of kernels pe
 for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1]))[:24]:
     out.append(f"| `{k}` | {len(v) / n_it:.1f} | {sum(v) / len(v):.1f} | {sum(v) / n_it / 1e3:.3f} | {sum(v) / tot * 100:.1f} |")
 open(sys.argv[2], "w").write("\n".join(out) + "\n")
+# the launch sequence of ONE iteration (the last whole one), in order
+a, b = groups[-2] - start, groups[-1] - start
+with open(sys.argv[2].replace(".md", "_sequence.txt"), "w") as f:
+    for r in seg[a:b]:
+        f.write(f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:8.1f} us  {short(r['Kernel_Name'])}\n")
 print("\n".join(out))
 PY
 rm -rf $O/trace
