@@ -593,44 +593,45 @@ __global__ __launch_bounds__(256) void pack_fp6_kernel(const float* __restrict__
   const int sh = 29 - e;                      // |w| * 2^sh < 2^29 <= 16.5 * 32^5
   if (threadIdx.x == 0) { scale[co] = ldexp(1.0, -sh); bias_d[co] = bias ? (double)bias[co] : 0.0; }
   const int nchunks = Cin / CK, g = co >> 4, ch = co & 15;
-  // one record = the 32 k values of (chunk, tap, k-half)
-  for (int rec = threadIdx.x; rec < nchunks * 18; rec += 256) {
-    const int kh = rec & 1, tap = (rec >> 1) % 9, c = rec / 18;
-    unsigned bits[6][6];
+  // Every thread converts elements to their six digit codes (bytes in LDS, [plane][ci * 9 + tap]); then one thread packs the 16
+  // k values of half a record (96 bits = three words per plane).  (One thread per whole record -- 72 active threads of 256
+  // for the 256 -> 512 layer, each converting 32 elements in double precision -- took 25 us per layer in every training iteration.)
+  extern __shared__ uint8_t codes[];                            // [6][n]
+  for (int i = threadIdx.x; i < n; i += 256) {
+    // |w| 2^sh < 2^29: the scaled value is exact in fp32 and rintf rounds it like the fp64 form did
+    long long q = (long long)rintf(ldexpf(wc[i], sh));
 #pragma unroll
-    for (int p = 0; p < 6; ++p)
-#pragma unroll
-      for (int q = 0; q < 6; ++q) bits[p][q] = 0;
-    for (int j = 0; j < 32; ++j) {
-      const int ci = c * CK + kh * 32 + j;
-      long long q = (long long)rint(ldexp((double)wc[ci * 9 + tap], sh));
-      int dg[6];
-#pragma unroll
-      for (int p = 5; p >= 1; --p) {
-        const int r = (int)(((q + 16) & 31) - 16);
-        dg[p] = r;
-        q = (q - r) >> 5;
-      }
-      dg[0] = (int)q;                          // in [-16, 16]
-      const int bit = 6 * j, wd = bit >> 5, sft = bit & 31;
-#pragma unroll
-      for (int p = 0; p < 6; ++p) {
-        const unsigned code = (dg[p] < 0 ? 0x20u : 0u) | (unsigned)(dg[p] < 0 ? -dg[p] : dg[p]);
-#pragma unroll
-        for (int q2 = 0; q2 < 6; ++q2) {       // static register indexing
-          if (q2 == wd) bits[p][q2] |= code << sft;
-          if (q2 == wd + 1 && sft > 26) bits[p][q2] |= code >> (32 - sft);
-        }
-      }
+    for (int p = 5; p >= 1; --p) {
+      const int r = (int)(((q + 16) & 31) - 16);
+      codes[p * n + i] = (uint8_t)((r < 0 ? 0x20u : 0u) | (unsigned)(r < 0 ? -r : r));
+      q = (q - r) >> 5;
     }
+    const int r0 = (int)q;                                      // in [-16, 16]
+    codes[i] = (uint8_t)((r0 < 0 ? 0x20u : 0u) | (unsigned)(r0 < 0 ? -r0 : r0));
+  }
+  __syncthreads();
+  // one record = the 32 k values of (chunk, tap, k-half); unit = (record, half of it)
+  for (int unit = threadIdx.x; unit < nchunks * 36; unit += 256) {
+    const int hf = unit & 1, rec = unit >> 1, kh = rec & 1, tap = (rec >> 1) % 9, c = rec / 18;
 #pragma unroll
     for (int p = 0; p < 6; ++p) {
+      unsigned long long lo = 0;                                // bits 0..63 of the 96
+      unsigned hi = 0;                                          // bits 64..95
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int ci = c * CK + kh * 32 + hf * 16 + j;
+        const unsigned long long code = codes[p * n + ci * 9 + tap];
+        const int bit = 6 * j;
+        if (bit < 64) lo |= code << bit;
+        if (bit + 6 > 64) hi |= (unsigned)(bit >= 64 ? code << (bit - 64) : code >> (64 - bit));
+      }
       const int ct = p >> 1, ln = kh * 32 + (p & 1) * 16 + ch;
       uint8_t* tile = wq + (long long)(g * nchunks + c) * W_CHUNK_BYTES + (tap * 3 + ct) * W_TILE_BYTES;
       unsigned* d16 = reinterpret_cast<unsigned*>(tile + ln * 16);
       unsigned* d8 = reinterpret_cast<unsigned*>(tile + 1024 + ln * 8);
-      d16[0] = bits[p][0]; d16[1] = bits[p][1]; d16[2] = bits[p][2]; d16[3] = bits[p][3];
-      d8[0] = bits[p][4]; d8[1] = bits[p][5];
+      const unsigned w0 = (unsigned)lo, w1 = (unsigned)(lo >> 32), w2 = hi;
+      if (hf == 0) { d16[0] = w0; d16[1] = w1; d16[2] = w2; }
+      else { d16[3] = w0; d8[0] = w1; d8[1] = w2; }
     }
   }
 }
@@ -674,7 +675,7 @@ extern "C" int spk_den_pack_weight_fp6(const float* w, const float* bias, uint8_
                                        int Cout, int Cin, hipStream_t stream) {
   if (!w || !wq || !scale || !bias_d || Cout <= 0 || Cin <= 0) return SPK_ERR_ARG;
   if ((Cout % 16) || (Cin % CK)) return SPK_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(pack_fp6_kernel, dim3(Cout), dim3(256), 0, stream, w, bias, wq, scale, bias_d, Cout, Cin);
+  hipLaunchKernelGGL(pack_fp6_kernel, dim3(Cout), dim3(256), (size_t)6 * Cin * 9, stream, w, bias, wq, scale, bias_d, Cout, Cin);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }
