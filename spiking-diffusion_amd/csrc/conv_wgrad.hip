@@ -118,9 +118,10 @@ __global__ __launch_bounds__(NTHR, 1) void wgrad3x3_bf16_kernel(WgArgs a) {
       }
     }
     if ((part < 0 || part == 2) && s_on) {
+      // (the bf16 of the value by truncation: exact for spikes and for spike COUNTS up to 256 -- the time-collapsed last layer)
       unsigned v[7];
 #pragma unroll
-      for (int x = 0; x < 7; ++x) v[x] = rs[x] != 0.f ? 0x3F80u : 0u;
+      for (int x = 0; x < 7; ++x) v[x] = __float_as_uint(rs[x]) >> 16;
       // copy kx: slot xx of row y + 1 holds s(y, xx + kx - 1)
       const unsigned p12 = v[1] | (v[2] << 16), p34 = v[3] | (v[4] << 16), p56 = v[5] | (v[6] << 16);
       v4i c0, c1, c2;

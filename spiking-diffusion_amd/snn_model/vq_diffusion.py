@@ -363,6 +363,9 @@ class DummyModel(nn.Module):
     # conv6 + mean over T evaluated as ONE convolution of the per-neuron spike counts (exact linearity; the sum over T
     # is rounded once instead of T times: logits agree with the per-step form to ~1 ulp).  False = per-step form.
     collapse_conv6 = True
+    # training: conv6 + mean over T as ONE autograd operator (ops.SpikeConvMeanTrainFunction): same forward operations, the
+    # backward convolves the output gradient once with the spike counts / once for all steps.  False: two operators.
+    collapse_conv6_backward = True
 
     _latent_hw = (7, 7)        # latent size of the last call (7x7 MNIST-shaped, 8x8 CIFAR-shaped)
 
@@ -504,7 +507,12 @@ class DummyModel(nn.Module):
         else:
             cat = torch.cat((x5, x1), dim=2)
         c6 = self.conv6
-        x6 = c6.train_forward(cat, binary_input=True) if c6._trainable_fused(c6._blocks(), cat) else c6(cat)
+        blocks6 = c6._blocks()
+        if self.collapse_conv6_backward and c6._trainable_fused(blocks6, cat) and c6.exact_conv_fits(blocks6, cat):
+            # conv6 + the time mean as one operator whose backward runs on the spike counts (1/T of the per-step backward)
+            conv = blocks6[0][0]
+            return ops.SpikeConvMeanTrainFunction.apply(cat, conv.weight, conv.bias)
+        x6 = c6.train_forward(cat, binary_input=True) if c6._trainable_fused(blocks6, cat) else c6(cat)
         return torch.sum(x6, dim=0) / T
 
     def invalidate(self):

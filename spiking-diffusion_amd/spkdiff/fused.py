@@ -206,6 +206,20 @@ class FusedSequential(nn.Sequential):
     # exact MFMA forward for spike-input 3x3 convolutions in training (ops.SpikeConvTrainFunction); False = library forward
     exact_train_forward = True
 
+    def exact_conv_fits(self, blocks, x):
+        """True for a single conv-only block whose convolution the exact MFMA training forward takes on spikes x."""
+        if blocks is None or len(blocks) != 1 or blocks[0][2] is not None or blocks[0][1] is not None or not self.exact_train_forward:
+            return False
+        conv = blocks[0][0]
+        w = conv.weight
+        if w.dim() == 4 and not w.is_contiguous(memory_format=torch.channels_last):
+            w.data = w.data.contiguous(memory_format=torch.channels_last)
+        return (isinstance(conv, layer.Conv2d) and conv.groups == 1 and tuple(conv.dilation) == (1, 1)
+                and conv.padding_mode == 'zeros' and conv.kernel_size[0] == conv.kernel_size[1]
+                and ops.den_fp6_supported(conv.out_channels, conv.in_channels, conv.kernel_size[0], conv.stride[0],
+                                          conv.padding[0] if not isinstance(conv.padding, str) else -1, x.shape[0],
+                                          x.shape[3], x.shape[4]))
+
     def train_forward(self, x, binary_input=False):
         """[T,B,C,H,W] -> spikes [T,B,C',H',W'] (or the raw conv output of a conv-only last block), differentiable.
         Convolution: ROCm library operator through torch -- or, when the caller states that x holds spikes

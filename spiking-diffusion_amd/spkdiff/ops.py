@@ -876,6 +876,54 @@ class SpikeConvTrainFunction(torch.autograd.Function):
         return gi, gw, gb
 
 
+class SpikeConvMeanTrainFunction(torch.autograd.Function):
+    """mean over T of conv3x3(spikes_t, weight) + bias -- the denoiser's last layer and its time mean
+    (R/snn_model/vq_diffusion.py:185-187, 205-206) as ONE differentiable operator.  Forward: the exact fp6 x fp4 MFMA convolution
+    of every step and `sum(0) / T`, the operations of the two-operator form.  Backward: every step receives the SAME output
+    gradient g / T, so the weight gradient is sum_b (g_b / T) (x) COUNTS_b (counts = sum_t s_t, 0..T: exact in bf16) and the
+    data gradient is one transposed convolution of g / T repeated over T -- 1/T of the matrix work of the per-step backward and
+    no [T,B,Cout,H,W] gradient tensor.  spikes [T,B,Cin,H,W] in {0,1}; returns [B,Cout,H,W]."""
+
+    @staticmethod
+    def forward(ctx, spikes, weight, bias):
+        s = _cl5(spikes, "spikes")
+        T, Cout = int(s.shape[0]), int(weight.shape[0])
+        with timed("train.conv_fwd_fp6"):
+            y = den_conv3x3_fp6_raw(spikes_cl_to_c4(s), den_pack_weight_fp6(weight, bias), Cout)
+        counts = s.sum(dim=0)                                  # [B,Cin,H,W], channels-last like s
+        ctx.save_for_backward(counts, weight)
+        ctx.has_bias, ctx.T = bias is not None, T
+        return torch.sum(y, dim=0) / T
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        counts, weight = ctx.saved_tensors
+        T, Cout, Cin = ctx.T, int(weight.shape[0]), int(weight.shape[1])
+        B, H, W = int(counts.shape[0]), int(counts.shape[2]), int(counts.shape[3])
+        g = (grad_out / T).contiguous(memory_format=torch.channels_last)     # the gradient of every step's output
+        c = counts.contiguous(memory_format=torch.channels_last)
+        need_gi, need_gw = bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1])
+        need_gb = bool(ctx.has_bias and ctx.needs_input_grad[2])
+        gi = gw = gb = None
+        native = tuple(weight.shape[2:]) == (3, 3) and (H, W) == (7, 7)
+        if need_gw and native and NATIVE_WGRAD and Cout % 128 == 0 and Cin % 64 == 0:
+            gw = conv3x3_wgrad(g, c, Cout, Cin)
+            need_gw = False
+        if need_gi and native and NATIVE_DGRAD and Cout % 16 == 0 and Cin % 32 == 0:
+            gi = conv3x3_dgrad(g, weight, Cin)
+            need_gi = False
+        if need_gi or need_gw:
+            gi2, gw2, _ = torch.ops.aten.convolution_backward(g, c, weight, [Cout], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                              [need_gi, need_gw, False])
+            gi = gi2 if need_gi else gi
+            gw = gw2 if need_gw else gw
+        if need_gb:
+            gb = grad_out.sum(dim=(0, 2, 3))                   # sum over T of g / T
+        if gi is not None:
+            gi = gi.unsqueeze(0).expand((T,) + tuple(gi.shape))
+        return gi, gw, gb
+
+
 def spikes_to_c4(s):
     """fp32 [T,B,C,H,W] -> C4 [B, C/64, H, W, T, 32]."""
     s = _dev(s, "spikes", torch.float32)

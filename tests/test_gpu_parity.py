@@ -2360,3 +2360,33 @@ def test_conv3x3_data_gradient_bf16_kernel_vs_fp64(dev, ops, N, Cout, Cin, form)
     got2 = ops.conv3x3_dgrad(gy_cl, w.to(dev), Cin, form=form)
     assert torch.equal(got, got2), "deterministic"
 
+
+def test_last_layer_and_time_mean_as_one_operator_backward_on_spike_counts(dev, ops):
+    """ops.SpikeConvMeanTrainFunction (conv6 + mean over T; backward = one convolution of g / T with the spike COUNTS and one
+    transposed convolution repeated over T) against the two-operator form (per-step convolution, sum / T, per-step backward):
+    forward bit-equal, gradients equal to fp32 round-off."""
+    T, B, Cin, Cout = 16, 6, 320, 128
+    g = torch.Generator().manual_seed(11)
+    s = (torch.rand(T, B, Cin, 7, 7, generator=g) < 0.08).float().to(dev)
+    w0 = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.02).to(dev).contiguous(memory_format=torch.channels_last)
+    b0 = (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    go = torch.randn(B, Cout, 7, 7, generator=g).to(dev)
+    outs = []
+    for fused in (True, False):
+        sx = s.clone().requires_grad_(True)
+        w = w0.clone().requires_grad_(True)
+        b = b0.clone().requires_grad_(True)
+        if fused:
+            y = ops.SpikeConvMeanTrainFunction.apply(sx, w, b)
+        else:
+            y = torch.sum(ops.SpikeConvTrainFunction.apply(sx, w, b), dim=0) / T
+        y.backward(go)
+        outs.append((y.detach(), sx.grad.detach().clone(), w.grad.detach().clone(), b.grad.detach().clone()))
+    (y1, gs1, gw1, gb1), (y2, gs2, gw2, gb2) = outs
+    assert torch.equal(y1, y2)
+    rel = lambda a, c: float((a.double() - c.double()).norm() / c.double().norm())
+    r_s, r_w, r_b = rel(gs1, gs2), rel(gw1, gw2), rel(gb1, gb2)
+    print(f"collapsed backward vs per-step backward: grad_spikes {r_s:.2e}, grad_weight {r_w:.2e}, grad_bias {r_b:.2e}")
+    parity("conv6_mean_one_operator", grad_spikes_rel=r_s, grad_weight_rel=r_w, grad_bias_rel=r_b)
+    assert gs1.shape == s.shape and r_s <= 1e-6 and r_w <= 1e-6 and r_b <= 1e-6
+
