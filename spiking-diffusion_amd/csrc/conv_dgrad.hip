@@ -66,15 +66,22 @@ __device__ __forceinline__ void split2h(float xs, _Float16& h, _Float16& m) {
 }
 
 // F16 form, first pre-pass: bits of max |w| per input channel (wmax zeroed by the caller; positive floats order like their bits)
-__global__ void dgrad_wmax_kernel(const float* __restrict__ w, unsigned* __restrict__ wmax, int rows, int Cin) {
-  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ci >= Cin) return;
+__global__ __launch_bounds__(256) void dgrad_wmax_kernel(const float* __restrict__ w, unsigned* __restrict__ wmax, int rows, int Cin) {
+  __shared__ unsigned part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int ci = blockIdx.x * 64 + tx;
   unsigned m = 0;
-  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
-    const unsigned b = __float_as_uint(w[(long long)r * Cin + ci]) & 0x7FFFFFFFu;
-    m = b > m ? b : m;
+  if (ci < Cin)
+    for (int r = blockIdx.y * 4 + ty; r < rows; r += gridDim.y * 4) {
+      const unsigned b = __float_as_uint(w[(long long)r * Cin + ci]) & 0x7FFFFFFFu;
+      m = b > m ? b : m;
+    }
+  part[ty][tx] = m;
+  __syncthreads();
+  if (ty == 0 && ci < Cin) {
+    const unsigned a = part[0][tx] > part[1][tx] ? part[0][tx] : part[1][tx], c = part[2][tx] > part[3][tx] ? part[2][tx] : part[3][tx];
+    atomicMax(wmax + ci, a > c ? a : c);
   }
-  atomicMax(wmax + ci, m);
 }
 
 // F16 form, second pre-pass: w [Cout][9][Cin] fp32 -> blobs [ci tile][chunk][term 2][tap][k half][ci in tile][8 co] fp16 of w 2^s(ci)
@@ -344,7 +351,7 @@ int dgrad_launch(const float* gy_cl, const float* w_cl, uint8_t* ws, long long w
   if (F16) {
     unsigned* wmax = reinterpret_cast<unsigned*>(ws + n * 6);
     { const hipError_t e = hipMemsetAsync(wmax, 0, (size_t)Cin * 4, stream); if (e != hipSuccess) return (int)e; }
-    hipLaunchKernelGGL(dgrad_wmax_kernel, dim3((Cin + 63) / 64, 64), dim3(64), 0, stream, w_cl, wmax, Cout * 9, Cin);
+    hipLaunchKernelGGL(dgrad_wmax_kernel, dim3((Cin + 63) / 64, 128), dim3(256), 0, stream, w_cl, wmax, Cout * 9, Cin);
     SPK_LAUNCH_CHECK();
     hipLaunchKernelGGL(dgrad_pack_f16_kernel, dim3(pack_grid), dim3(256), 0, stream, w_cl, wmax, reinterpret_cast<_Float16*>(ws),
                        Cout, Cin, CI);
