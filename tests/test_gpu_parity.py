@@ -2390,3 +2390,34 @@ def test_last_layer_and_time_mean_as_one_operator_backward_on_spike_counts(dev, 
     parity("conv6_mean_one_operator", grad_spikes_rel=r_s, grad_weight_rel=r_w, grad_bias_rel=r_b)
     assert gs1.shape == s.shape and r_s <= 1e-6 and r_w <= 1e-6 and r_b <= 1e-6
 
+
+def test_conv3x3_data_gradient_two_term_form_scales(dev, ops):
+    """spk_conv3x3_dgrad_f16x2 scales every image's gy and every input channel's weights by a power of two: images / channels
+    of very different magnitude keep their own relative accuracy, all-zero images / channels give exact zeros, and values far
+    below their image's maximum cost absolute, not relative, precision."""
+    N, Cout, Cin = 8, 128, 64
+    g = torch.Generator().manual_seed(5)
+    gy = torch.randn(N, Cout, 7, 7, generator=g) * 1e-3
+    gy[0] = 0.0
+    gy[1] *= 1e-20
+    gy[2] *= 1e+12
+    gy[3, ::2] *= 2.0 ** -30                                               # half of the channels 30 binades below the others
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    w[:, 5] = 0.0
+    w[:, 7] *= 1e-12
+    w[:, 9] *= 1e+6
+    x = torch.zeros(N, Cin, 7, 7)
+    want, _, _ = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), [Cout], [1, 1], [1, 1], [1, 1], False,
+                                                     [0, 0], 1, [True, False, False])
+    got = ops.conv3x3_dgrad(gy.to(dev).contiguous(memory_format=torch.channels_last), w.to(dev), Cin, form="f16x2").cpu().double()
+    assert torch.isfinite(got).all()
+    assert float(got[0].abs().max()) == 0.0 and float(got[:, 5].abs().max()) == 0.0
+    worst = 0.0
+    for n in range(1, N):
+        for ci in (0, 7, 9, 33):
+            e = float((got[n, ci] - want[n, ci]).norm() / want[n, ci].norm())
+            worst = max(worst, e)
+    print(f"two-term data gradient, per (image, channel) relative L2 error at most {worst:.2e}")
+    parity("dgrad_f16x2_scales", worst_image_channel_rel_l2=worst)
+    assert worst <= 2e-6
+
