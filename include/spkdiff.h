@@ -337,10 +337,11 @@ int spk_embedding_fwd(const long long* tokens, const float* codebook, float* out
  * channels-last fp32 [N = T*B][H*W][C]; gw_out fp32 [Cout][3][3][Cin] (= a channels-last [Cout,Cin,3,3] tensor); ws: scratch of
  * spk_conv3x3_wgrad_ws_bytes (split-K partial sums, added in a fixed order: deterministic).  7x7 maps, Cout % 128 == 0,
  * Cin % 64 == 0; otherwise SPK_ERR_UNSUPPORTED (use the framework's operator). * The spike operand may also hold small non-negative integers (spike counts up to 256: exact in bf16) -- the time-collapsed
- * backward of the denoiser's last layer. */
+ * backward of the denoiser's last layer. * gb_out_or_null [Cout]: the bias gradient (sum of gy over images and positions), from the same pass over gy.
+ */
 long long spk_conv3x3_wgrad_ws_bytes(int N, int Cout, int Cin);
-int spk_conv3x3_wgrad_bf16(const float* gy_cl, const float* spikes_cl, float* ws, long long ws_bytes, float* gw_out, int N, int H,
-                           int W, int Cout, int Cin, spk_stream_t stream);
+int spk_conv3x3_wgrad_bf16(const float* gy_cl, const float* spikes_cl, float* ws, long long ws_bytes, float* gw_out,
+                           float* gb_out_or_null, int N, int H, int W, int Cout, int Cin, spk_stream_t stream);
 
 /* Data gradient of the same convolution (autograd of layer.Conv2d in the training step, R/snn_model/vq_diffusion.py:166-187;
  * cuDNN's data-gradient kernels in the reference): gi[n][y][x][ci] = sum over (co, ky, kx) of gy[n][y+1-ky][x+1-kx][co] *
@@ -351,14 +352,14 @@ int spk_conv3x3_wgrad_bf16(const float* gy_cl, const float* spikes_cl, float* ws
  * SPK_ERR_UNSUPPORTED (use the framework's operator). */
 long long spk_conv3x3_dgrad_ws_bytes(int Cout, int Cin);
 int spk_conv3x3_dgrad_bf16(const float* gy_cl, const float* w_cl, uint8_t* ws, long long ws_bytes, float* gi_out, int N, int H,
-                           int W, int Cout, int Cin, hipStream_t stream);
+                           int W, int Cout, int Cin, spk_stream_t stream);
 /* The same data gradient with TWO fp16 terms per operand and three cross products (half the matrix work): every image's gy
  * and every input channel's weights are scaled by a power of two that puts their largest magnitude into [2^14, 2^15), x 2^s =
  * h + m to 2^-23 (h, m: nearest fp16 of the value and of the exact remainder), products (h,h) (h,m) (m,h), fp32 accumulation,
  * exact descaling.  Values more than 28 binades below their image's / channel's maximum lose relative (not absolute)
  * precision.  Same arguments, workspace and shapes as spk_conv3x3_dgrad_bf16. */
 int spk_conv3x3_dgrad_f16x2(const float* gy_cl, const float* w_cl, uint8_t* ws, long long ws_bytes, float* gi_out, int N, int H,
-                            int W, int Cout, int Cin, hipStream_t stream);
+                            int W, int Cout, int Cin, spk_stream_t stream);
 
 /* ---- sampler ---------------------------------------------------------------------------------------------------- */
 /* Images touched by reverse step t.  R/snn_model/vq_diffusion.py:113-124 computes `changes = (u < 1/t) & ~unmasked`

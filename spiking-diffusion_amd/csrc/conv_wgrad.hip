@@ -44,6 +44,7 @@ constexpr int LDS_BYTES = 2 * G_HALFS * 2 + 2 * S_HALFS * 2 + 16;      // + one 
 
 struct WgArgs {
   const float* gy; const float* s; float* part;
+  float* part_gb;                                   // [ksplit][Cout] column sums of gy (the bias gradient), or null
   int TB, Cout, Cin, ksplit;
 };
 
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(NTHR, 1) void wgrad3x3_bf16_kernel(WgArgs a) {
   // 2-byte deposits kept the LDS pipe busier than the matrix cores).  gy tile: item (channel e % 128, row e / 128) for
   // e = tid and tid + 512 (896 items); spike tile: item (channel tid % 64, row tid / 64) for tid < 448
   float rg[2][7], rs[7];
+  float gsum[2] = {0.f, 0.f};                       // bias gradient: this thread's rows of gy, summed over its images
   const int g_co = tid & 127, g_y0 = tid >> 7, s_ci = tid & 63, s_y = tid >> 6;
   const bool g_two = tid < 896 - NTHR, s_on = tid < 7 * WG_CI;                           // (both wave-uniform)
   // addresses = a wave-uniform pointer (image, column x, tile origin: scalar registers) + ONE 32-bit per-thread offset
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(NTHR, 1) void wgrad3x3_bf16_kernel(WgArgs a) {
         // x = hi + mid + lo exactly, each term a bf16 (top 16 bits of an fp32): truncate, subtract (exact), truncate, subtract;
         // at most 8 significant bits are left for lo: its truncation is exact
         unsigned h[8], m[8], l[8];
+        gsum[j] += ((rg[j][0] + rg[j][1]) + (rg[j][2] + rg[j][3])) + ((rg[j][4] + rg[j][5]) + rg[j][6]);
 #pragma unroll
         for (int x = 0; x < 7; ++x) {
           h[x] = __float_as_uint(rg[j][x]) & 0xFFFF0000u;
@@ -185,6 +188,20 @@ __global__ __launch_bounds__(NTHR, 1) void wgrad3x3_bf16_kernel(WgArgs a) {
     }
     __syncthreads();
   }
+  // the bias gradient of this slice (workgroups of the first input-channel tile): the seven row sums of a channel meet in LDS
+  // in a fixed order
+  if (a.part_gb && tn == 0) {
+    float* sB = reinterpret_cast<float*>(lds);      // [7 rows][128 channels] (the operand buffers are done)
+    sB[g_y0 * WG_CO + g_co] = gsum[0];
+    if (g_two) sB[(g_y0 + 4) * WG_CO + g_co] = gsum[1];
+    __syncthreads();
+    if (tid < WG_CO) {
+      float t = 0.f;
+#pragma unroll
+      for (int y = 0; y < 7; ++y) t += sB[y * WG_CO + tid];
+      a.part_gb[(long long)ks * a.Cout + co0 + tid] = t;
+    }
+  }
   // partial sums of this slice: part[ks][co][tap][ci]
   float* out = a.part + (long long)ks * a.Cout * 9 * a.Cin;
 #pragma unroll
@@ -196,12 +213,19 @@ __global__ __launch_bounds__(NTHR, 1) void wgrad3x3_bf16_kernel(WgArgs a) {
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, long long n, int ksplit) {
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, long long n, int ksplit,
+                                    const float* __restrict__ part_gb, float* __restrict__ gb, int Cout) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < ksplit; ++k) s += part[(long long)k * n + i];      // fixed order: deterministic
     gw[i] = s;
   }
+  if (gb && blockIdx.x == 0)
+    for (int c = threadIdx.x; c < Cout; c += blockDim.x) {
+      float s = 0.f;
+      for (int k = 0; k < ksplit; ++k) s += part_gb[(long long)k * Cout + c];
+      gb[c] = s;
+    }
 }
 
 // slices of the image range: one workgroup per CU in ONE round (never a second, partly filled round)
@@ -217,23 +241,25 @@ int wgrad_ksplit(int TB, int Cout, int Cin) {
 
 extern "C" long long spk_conv3x3_wgrad_ws_bytes(int TB, int Cout, int Cin) {
   if (TB <= 0 || Cout <= 0 || Cin <= 0 || (Cout % WG_CO) || (Cin % WG_CI)) return -1;
-  return (long long)wgrad_ksplit(TB, Cout, Cin) * Cout * 9 * Cin * 4;
+  return (long long)wgrad_ksplit(TB, Cout, Cin) * ((long long)Cout * 9 * Cin + Cout) * 4;      // weight + bias partial sums
 }
 
 extern "C" int spk_conv3x3_wgrad_bf16(const float* gy_cl, const float* spikes_cl, float* ws, long long ws_bytes,
-                                      float* gw_out, int TB, int H, int W, int Cout, int Cin, hipStream_t stream) {
+                                      float* gw_out, float* gb_out_or_null, int TB, int H, int W, int Cout, int Cin,
+                                      hipStream_t stream) {
   if (!gy_cl || !spikes_cl || !ws || !gw_out || TB <= 0) return SPK_ERR_ARG;
   if (H != 7 || W != 7 || (Cout % WG_CO) || (Cin % WG_CI)) return SPK_ERR_UNSUPPORTED;
   const int tiles = (Cout / WG_CO) * (Cin / WG_CI);
   const int ks = wgrad_ksplit(TB, Cout, Cin);
   const long long n = (long long)Cout * 9 * Cin;
-  if (ws_bytes < (long long)ks * n * 4) return SPK_ERR_ARG;
+  if (ws_bytes < (long long)ks * (n + Cout) * 4) return SPK_ERR_ARG;
   WgArgs a;
-  a.gy = gy_cl; a.s = spikes_cl; a.part = ws; a.TB = TB; a.Cout = Cout; a.Cin = Cin; a.ksplit = ks;
+  a.gy = gy_cl; a.s = spikes_cl; a.part = ws;
+  a.part_gb = gb_out_or_null ? ws + (long long)ks * n : nullptr; a.TB = TB; a.Cout = Cout; a.Cin = Cin; a.ksplit = ks;
   hipLaunchKernelGGL(wgrad3x3_bf16_kernel, dim3(tiles * ks), dim3(NTHR), (size_t)LDS_BYTES, stream, a);
   SPK_LAUNCH_CHECK();
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, stream,
-                     ws, gw_out, n, ks);
+                     ws, gw_out, n, ks, a.part_gb, gb_out_or_null, Cout);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

@@ -54,7 +54,7 @@ _SIGS = {
     "spk_den_conv3x3_fp6_raw": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_spikes_nhwc_to_fp4": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spk_conv3x3_wgrad_ws_bytes": (c_longlong, [c_int, c_int, c_int]),
-    "spk_conv3x3_wgrad_bf16": (c_int, [P, P, P, c_longlong, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "spk_conv3x3_wgrad_bf16": (c_int, [P, P, P, c_longlong, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_conv3x3_dgrad_ws_bytes": (c_longlong, [c_int, c_int]),
     "spk_conv3x3_dgrad_bf16": (c_int, [P, P, P, c_longlong, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_conv3x3_dgrad_f16x2": (c_int, [P, P, P, c_longlong, P, c_int, c_int, c_int, c_int, c_int, P]),

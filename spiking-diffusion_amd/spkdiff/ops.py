@@ -778,7 +778,7 @@ def conv3x3_wgrad_supported(Cout, Cin, H, W):
 NATIVE_WGRAD = True
 
 
-def conv3x3_wgrad(gy_cl, spikes_cl, Cout, Cin):
+def conv3x3_wgrad(gy_cl, spikes_cl, Cout, Cin, want_bias=False):
     """gw [Cout,Cin,3,3] (channels-last memory) of a 3x3 / s1 / p1 convolution from gy [N,Cout,7,7] and BINARY spikes
     [N,Cin,7,7], both channels-last fp32 (spk_conv3x3_wgrad_bf16: bf16 matrix cores, exact three-term split of gy)."""
     N = int(gy_cl.shape[0])
@@ -787,10 +787,11 @@ def conv3x3_wgrad(gy_cl, spikes_cl, Cout, Cin):
         raise NotImplementedError("spk_conv3x3_wgrad_bf16: unsupported shape")
     ws = torch.empty(nb // 4, dtype=torch.float32, device=gy_cl.device)
     gw = torch.empty((Cout, 3, 3, Cin), dtype=torch.float32, device=gy_cl.device)
+    gb = torch.empty(Cout, dtype=torch.float32, device=gy_cl.device) if want_bias else None
     with timed("train.conv_wrw"):
-        check(lib.spk_conv3x3_wgrad_bf16(_p(gy_cl), _p(spikes_cl), _p(ws), nb, _p(gw), N, 7, 7, int(Cout), int(Cin),
+        check(lib.spk_conv3x3_wgrad_bf16(_p(gy_cl), _p(spikes_cl), _p(ws), nb, _p(gw), _p(gb), N, 7, 7, int(Cout), int(Cin),
                                          _stream(gy_cl)), "spk_conv3x3_wgrad_bf16")
-    return gw.permute(0, 3, 1, 2)
+    return (gw.permute(0, 3, 1, 2), gb) if want_bias else gw.permute(0, 3, 1, 2)
 
 
 def conv3x3_dgrad_supported(Cout, Cin, H, W, N):
@@ -853,7 +854,9 @@ class SpikeConvTrainFunction(torch.autograd.Function):
         if (NATIVE_WGRAD and need_gw and tuple(weight.shape[2:]) == (3, 3) and
                 conv3x3_wgrad_supported(Cout, Cin, int(s.shape[3]), int(s.shape[4]))):
             # the weight gradient multiplies gy by SPIKES: native on the bf16 matrix cores (the data gradient has no spike operand)
-            gw_native = conv3x3_wgrad(gy, s4, Cout, Cin)
+            gw_native = conv3x3_wgrad(gy, s4, Cout, Cin, want_bias=need_gb)      # (+ the bias gradient from the same pass)
+            if need_gb:
+                gw_native, gb_native = gw_native
             need_gw = False
         gi_native = None
         if (NATIVE_DGRAD and need_gi and tuple(weight.shape[2:]) == (3, 3) and
@@ -868,7 +871,7 @@ class SpikeConvTrainFunction(torch.autograd.Function):
         if gw_native is not None:
             gw = gw_native
             if need_gb:
-                gb = gy.sum(dim=(0, 2, 3))
+                gb = gb_native
         if gi_native is not None:
             gi = gi_native
         if gi is not None:

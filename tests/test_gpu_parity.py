@@ -2316,8 +2316,11 @@ def test_conv3x3_weight_gradient_bf16_kernel_vs_fp64(dev, ops, N, Cout, Cin):
                                                      [0, 0], 1, [False, True, False])
     s_cl = s.to(dev).contiguous(memory_format=torch.channels_last)
     gy_cl = gy.to(dev).contiguous(memory_format=torch.channels_last)
-    got = ops.conv3x3_wgrad(gy_cl, s_cl, Cout, Cin)
+    got, got_b = ops.conv3x3_wgrad(gy_cl, s_cl, Cout, Cin, want_bias=True)
     assert got.shape == (Cout, Cin, 3, 3)
+    want_b = gy.double().sum(dim=(0, 2, 3))
+    rel_b = float((got_b.cpu().double() - want_b).norm() / want_b.norm())
+    assert rel_b <= 1e-6, rel_b                                          # the bias gradient from the same pass over gy
     rel = float((got.cpu().double() - want).norm() / want.norm())
     _, lib_gw, _ = torch.ops.aten.convolution_backward(gy_cl, s_cl, w.to(dev), [Cout], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                        [False, True, False])
