@@ -243,3 +243,17 @@ def test_synthetic_checkpoint_cache_is_safe_under_concurrent_ranks(tmp_path):
     assert all(o == want for o in outs), (outs, want)
     left = sorted(os.listdir(tmp_path))
     assert len([f for f in left if f.endswith(".pt")]) == 2 and not any(f.endswith((".lock", ".tmp")) for f in left), left
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/spkdiff.h is the boundary a C / cgo / JNI binding includes: it must compile as C without any HIP header."""
+    import shutil, subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "inc.c"
+    src.write_text('#include "spkdiff.h"\nint main(void) { return spk_conv_out_size(7, 3, 1, 1, 0, 0) == 7 ? 0 : 1; }\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
