@@ -1,21 +1,18 @@
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/trainprof; rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python $R/bench.py --workload train --steps 10 --warmup 3 --no-cpu-baseline > $O/log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python $R/bench.py --workload train --eager-train --steps 10 --warmup 3 --no-cpu-baseline > $O/log 2>&1
 tail -1 $O/log | cut -c1-300
 python - "$(ls -t $O/trace/*/*_kernel_trace.csv | head -1)" $O/train_steady_state.md <<'PY'
 # steady state only: the launches after the library's last solver-search kernel (naive_conv_*: MIOpen's find step in warm-up),
-# cut into iterations at the optimizer's multi_tensor_apply launches
+# cut into iterations at the loss kernel (one masked_ce_kernel launch per iteration)
 import collections, csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 last = max((i for i, r in enumerate(rows) if "naive_conv" in r["Kernel_Name"]), default=-1)
 rows = rows[last + 1:]
-opt = [i for i, r in enumerate(rows) if "multi_tensor_apply" in r["Kernel_Name"]]
-# an iteration ends with the optimizer's launches; take whole iterations: from after the first optimizer group to the last one
-groups = [opt[0]]
-for a, b in zip(opt, opt[1:]):
-    if b - a > 20: groups.append(b)
+# an iteration = from one masked_ce_kernel launch (exactly one per iteration, in the loss) to the next
+groups = [i for i, r in enumerate(rows) if "masked_ce_kernel" in r["Kernel_Name"]]
 start, n_it = groups[0], len(groups) - 1
 seg = rows[start:groups[-1]]
 def short(n):
