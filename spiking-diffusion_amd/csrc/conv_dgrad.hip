@@ -11,7 +11,7 @@
 // fp32 matrix instruction at 1/16 of the bf16 rate: 6/16 of its time at equal pipe occupancy.
 //
 // Mapping.  One workgroup = eight images (one per wave) x 32 NT input channels; a wave owns its image's two 32-row position
-// tiles (49 positions + 15 rows computed and dropped) x NT column tiles (32 NT accumulator registers).  K runs in chunks of 16
+// tiles (four image rows of 7 + 1 padding column each; 49 positions + 15 rows computed and dropped) x NT column tiles (32 NT accumulator registers).  K runs in chunks of 16
 // output channels (one MFMA k step) x nine taps:
 //   * the weights of a chunk are pre-packed ONCE per call (dgrad_pack_kernel) as the three bf16 planes in the B-fragment
 //     order [term][tap][k half][ci][8 co], one contiguous 27 NT KB blob per (channel tile, chunk): staging is a flat copy;
@@ -149,13 +149,22 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_kernel(DgArgs a) {
     const v4f* gp = reinterpret_cast<const v4f*>(a.gy + (long long)nn * HW7 * a.Cout);
     const int n4 = HW7 * a.Cout / 4;
     unsigned mb = 0;
-    for (int i = lane; i < n4; i += 64) {
-      const v4f v = gp[i];
+    // (eight loads in flight: one at a time this loop cost a memory round trip per 1 KB -- a quarter of the launch)
+    constexpr int UN = 8;
+    for (int i0 = lane; i0 < n4; i0 += 64 * UN) {
+      v4f v[UN];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const unsigned b = __float_as_uint(v[e]) & 0x7FFFFFFFu;
-        mb = b > mb ? b : mb;
+      for (int u = 0; u < UN; ++u) {
+        const int i = i0 + 64 * u;
+        v[u] = gp[i < n4 ? i : n4 - 1];
       }
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned b = __float_as_uint(v[u][e]) & 0x7FFFFFFFu;
+          mb = b > mb ? b : mb;
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -228,15 +237,21 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_kernel(DgArgs a) {
     }
   };
 
-  // fragment bases: A row = position 32 mt + (lane % 32) of this wave's image (rows past 48 repeat position 48: computed,
-  // never stored), k half = lane / 32; B column = input channel 32 nt + lane % 32
+  // fragment bases: A row r of tile mt = image row 4 mt + r / 8, column r % 8 (column 7 and image row 7 are padding: computed,
+  // never stored), k half = lane / 32; B column = input channel 32 nt + lane % 32.  A 16-lane group = two image rows = grid
+  // cells c .. c + 6 and c + 9 .. c + 15: their 16-byte reads fall into distinct banks, and the two padding lanes take the
+  // two residues left (c + 7, c + 8) -- consecutive positions (32 mt + r, seven per image row) put two lanes of every group
+  // on occupied banks (SQ_LDS_BANK_CONFLICT 32 % of the LDS-active cycles)
   const int row = lane & 31, half = lane >> 5;
   const uint8_t* a_base[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
-    int p = 32 * mt + row;
-    p = p < HW7 ? p : HW7 - 1;
-    a_base[mt] = sG + wave * G_IMG + (half * NCELL + (p / 7) * 9 + (p % 7)) * 16;
+    int y = 4 * mt + (row >> 3);
+    const int x = row & 7;
+    y = y < 7 ? y : 6;
+    int cell = y * 9 + x;                                    // (x = 7: the padding lane reads the row's border cell ...)
+    if (x == 7 && (row & 8)) cell -= 8;                      // (... that of the group's FIRST row + 1 for the second row: residue c + 8)
+    a_base[mt] = sG + wave * G_IMG + (half * NCELL + cell) * 16;
   }
   const uint8_t* const b_base = sW + (half * CI + row) * 16;
 
@@ -311,8 +326,9 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_kernel(DgArgs a) {
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int p = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (p < HW7) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * half, y = 4 * mt + (rr >> 3), x = rr & 7;
+        const int p = y * 7 + x;
+        if (x < 7 && y < 7) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             const float v = acc[mt][nt][r] + acs[mt][nt][r];

@@ -16,7 +16,8 @@ for d in "abc":
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
         if "dgrad3x3" in r["Kernel_Name"]:
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        print(f"{k:32s} {sorted(v)[len(v) // 2]:16.0f}  ({len(v)} launches)")
+            form = "f16x2 " if "true" in r["Kernel_Name"].split("(")[0] or "Lb1" in r["Kernel_Name"] else "bf16x3"
+            acc[(form, r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for k, v in sorted(acc.items()):
+        print(f"{k[0]} {k[1]:32s} {sorted(v)[len(v) // 2]:16.0f}  ({len(v)} launches)")
 PY
