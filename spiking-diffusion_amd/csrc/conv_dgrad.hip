@@ -1,25 +1,36 @@
-// Data gradient of a 3x3 / stride 1 / pad 1 convolution on 7x7 maps, on the bf16 matrix cores with fp32 accuracy
+// Data gradient of a 3x3 / stride 1 / pad 1 convolution on 7x7 maps, on the bf16 / fp16 matrix cores with fp32 accuracy
 // (the training step of the denoiser, R/snn_model/vq_diffusion.py:166-187 through autograd; the
 // reference runs cuDNN's data-gradient kernels here):
 //
 //   gi[n][y][x][ci] = sum over (co, ky, kx) of  gy[n][y + 1 - ky][x + 1 - kx][co] * w[co][ky][kx][ci]
 //
-// a GEMM per image with M = 49 positions, N = Cin, K = 9 Cout, both operands dense fp32.  Each operand is split into THREE
-// bf16 terms by truncation (x = x0 + x1 + x2 exactly: 8 + 8 + 8 significant bits) and SIX of the nine cross products are
-// multiplied on v_mfma_f32_32x32x16_bf16 -- (0,0) (0,1) (1,0) (0,2) (2,0) (1,1): every product is exact, what is dropped is
-// below 2^-24 of |g w|, and the fp32 accumulation rounds like an fp32 GEMM's -- against ONE product per element pair on the
-// fp32 matrix instruction at 1/16 of the bf16 rate: 6/16 of its time at equal pipe occupancy.
+// a GEMM per image with M = 49 positions, N = Cin, K = 9 Cout, both operands dense fp32.  Two forms of one kernel template:
+//   * THREE bf16 terms per operand by truncation (x = x0 + x1 + x2 exactly: 8 + 8 + 8 significant bits), SIX of the nine cross
+//     products on v_mfma_f32_32x32x16_bf16 -- (0,0) (0,1) (1,0) (0,2) (2,0) (1,1): every product is exact, what is dropped is
+//     below 2^-24 of |g w| (spk_conv3x3_dgrad_bf16);
+//   * TWO fp16 terms per operand after a power-of-two scale per image (gy) / per input channel (w) that puts the largest
+//     magnitude into [2^14, 2^15): x 2^s = h + m to 2^-23, THREE products (h,h) (h,m) (m,h) on v_mfma_f32_32x32x16_f16, exact
+//     descaling of the result (spk_conv3x3_dgrad_f16x2: half the matrix work, two thirds of the LDS footprint; the form the
+//     training backward uses).
+// Either way the fp32 accumulation rounds like an fp32 GEMM's -- measured 2-4e-7 relative L2 against fp64 for both, the
+// framework's fp32 operator 2-6e-7 -- against ONE product per element pair on the fp32 matrix instruction at 1/16 of the rate.
+// The leading product and the small ones go to SEPARATE accumulators (see the kernel).
 //
-// Mapping.  One workgroup = eight images (one per wave) x 32 NT input channels; a wave owns its image's two 32-row position
-// tiles (four image rows of 7 + 1 padding column each; 49 positions + 15 rows computed and dropped) x NT column tiles (32 NT accumulator registers).  K runs in chunks of 16
-// output channels (one MFMA k step) x nine taps:
-//   * the weights of a chunk are pre-packed ONCE per call (dgrad_pack_kernel) as the three bf16 planes in the B-fragment
-//     order [term][tap][k half][ci][8 co], one contiguous 27 NT KB blob per (channel tile, chunk): staging is a flat copy;
+// Mapping.  One workgroup = eight images (one per wave) x 32 NT input channels (NT = 1, or 2 in the two-term form where that
+// still fills the CUs); a wave owns its image's two 32-row position tiles (four image rows of 7 + 1 padding column each: 49
+// positions + 15 rows computed and dropped) x NT column tiles.  K runs in chunks of 16 output channels (one MFMA k step) x nine
+// taps:
+//   * the weights of a chunk are pre-packed ONCE per call (dgrad_pack_kernel / dgrad_pack_f16_kernel) as the term planes in the
+//     B-fragment order [term][tap][k half][ci][8 co], one contiguous blob per (channel tile, chunk): staging is a flat copy;
 //   * the chunk of each image's gy is split while it is deposited into a zero-bordered 9x9 grid per (term, k half): the A
 //     fragment of tap (ky, kx) is ONE aligned 16-byte read at a constant offset from a per-lane base (no im2col);
-//   * the next chunk's operands travel global -> registers while the current one is multiplied; per tap a wave reads 6 A and
-//     3 NT B fragments for 12 NT MFMAs.
+//   * the next chunk's operands travel global -> registers while the current one is multiplied, the next tap's fragments
+//     LDS -> registers while the current tap's products run.
 // No split K: every output is written once, by one wave, in a fixed order (deterministic).
+// Measured (B = 32 x T = 16 = 512 images, us, two-term | three-term | framework): 256 -> 128 channels 84 | 96 | 172, 512 -> 256:
+// 235-250 | 355-380 | 570-600, 256 -> 512: 237-253 | 350-374 | 570-610, 128 -> 320: 114 | 131-139 | 170-183.  Phase stamps
+// (profiles/r3_ab_kernel_variants.txt (16)): the two waves of a SIMD run their tap loops one after the other at ~88 % of the
+// MFMA rate; the deposit phase between two barriers is 16 % of a chunk.
 #include "spk_common.h"
 #include "den_common.h"
 #include "../../include/spkdiff.h"
