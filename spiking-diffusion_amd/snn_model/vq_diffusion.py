@@ -490,15 +490,17 @@ class DummyModel(nn.Module):
 
     def _run_train(self, x, t):
         """train() mode (R/snn_model/vq_diffusion.py:189-208 with batch-statistics BN and surrogate-gradient LIF): the
-        convolutions are the ROCm library operator through torch, each block tail is the native fused BN+LIF operator
-        (``FusedSequential.train_forward``).  Membrane state follows the module semantics (kept until reset_net)."""
+        spike-input convolutions run the exact MFMA forward and the native backward (``ops.SpikeConvTrainFunction``; conv6 +
+        the time mean: ``ops.SpikeConvMeanTrainFunction``), conv1 the library operator, each block tail is the native fused
+        BN+LIF operator (``FusedSequential.train_forward``).  Membrane state follows the module semantics (kept until
+        reset_net)."""
         T = self.n_steps
         inp = ops.den_build_input(x.detach(), t)                      # [B,2,h,w]: token ids and step as floats
         h = inp.unsqueeze(0).repeat(T, 1, 1, 1, 1)
         x1 = self.conv1(h)
         x5 = x1
         for blk in (self.conv2, self.conv3, self.conv4, self.conv5):
-            # conv2..conv5 see spikes: exact MFMA forward where the shape fits, library backward
+            # conv2..conv5 see spikes: exact MFMA forward and native backward where the shape fits
             x5 = blk.train_forward(x5, binary_input=True) if blk._trainable_fused(blk._blocks(), x5) else blk(x5)
         if x1.permute(0, 1, 3, 4, 2).is_contiguous() and x5.permute(0, 1, 3, 4, 2).is_contiguous():
             # the fused block tails hand over channels-last spikes: concatenate as 4-D so that the layout survives

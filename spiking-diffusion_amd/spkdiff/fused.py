@@ -223,7 +223,7 @@ class FusedSequential(nn.Sequential):
     def train_forward(self, x, binary_input=False):
         """[T,B,C,H,W] -> spikes [T,B,C',H',W'] (or the raw conv output of a conv-only last block), differentiable.
         Convolution: ROCm library operator through torch -- or, when the caller states that x holds spikes
-        (``binary_input``) and the shape fits, the exact fp6 MFMA forward with the library backward; BN + LIF:
+        (``binary_input``) and the shape fits, the exact fp6 MFMA forward with the native (7x7) or library backward; BN + LIF:
         ops.BNLIFTrainFunction (one native operator)."""
         for conv, bn, lif in self._blocks():
             w = conv.weight

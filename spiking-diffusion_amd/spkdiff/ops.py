@@ -829,8 +829,10 @@ def conv3x3_dgrad(gy_cl, weight, Cin, form=None):
 class SpikeConvTrainFunction(torch.autograd.Function):
     """y = conv3x3(spikes, weight) + bias for BINARY input spikes in training: the forward is the exact
     fp6 x fp4 MFMA convolution (weights re-packed into six radix-32 digit planes each call -- they change every optimizer
-    step -- spikes packed to C4), the backward is the library's (aten convolution_backward: dense fp32 GEMMs with no
-    spike structure to exploit).  spikes [T,B,Cin,H,W] in {0,1}; returns channels-last [T,B,Cout,H,W]."""
+    step -- spikes packed to C4); the backward of the 7x7 layers is native where the shape fits -- weight (+ bias) gradient
+    on the bf16 MFMA with an exact three-term split of gy (spk_conv3x3_wgrad_bf16), data gradient on the fp16 MFMA with both
+    operands as two scaled terms (spk_conv3x3_dgrad_f16x2; DGRAD_FORM selects the three-term bf16 form) -- and the
+    framework's operator otherwise.  spikes [T,B,Cin,H,W] in {0,1}; returns channels-last [T,B,Cout,H,W]."""
 
     @staticmethod
     def forward(ctx, spikes, weight, bias):
