@@ -796,7 +796,8 @@ def conv3x3_wgrad(gy_cl, spikes_cl, Cout, Cin, want_bias=False):
 
 def conv3x3_dgrad_supported(Cout, Cin, H, W, N):
     # (small layers and small batches: the framework's operator is as fast)
-    return (H, W) == (7, 7) and Cout % 16 == 0 and Cin % 32 == 0 and Cout * Cin >= 32768 and N >= 64
+    return ((H, W) == (7, 7) and Cout % 16 == 0 and Cin % 32 == 0 and Cout * Cin >= 32768 and N >= 64
+            and N * 49 * Cout < 2 ** 31)                 # (32-bit element offsets in the kernel's staging table)
 
 
 # False: the data gradient of the spike-input convolutions comes from the framework's operator (as in rounds 1-2)
