@@ -24,8 +24,8 @@
 //     B-fragment order [term][tap][k half][ci][8 co], one contiguous blob per (channel tile, chunk): staging is a flat copy;
 //   * the chunk of each image's gy is split while it is deposited into a zero-bordered 9x9 grid per (term, k half): the A
 //     fragment of tap (ky, kx) is ONE aligned 16-byte read at a constant offset from a per-lane base (no im2col);
-//   * the next chunk's operands travel global -> registers while the current one is multiplied, the next tap's fragments
-//     LDS -> registers while the current tap's products run.
+//   * while a chunk is multiplied the next chunk's weight blob is copied global -> LDS (LDS-DMA, two weight buffers) and its gy
+//     travels global -> registers (it is split on deposit); the next tap's fragments are read while the current tap's products run.
 // No split K: every output is written once, by one wave, in a fixed order (deterministic).
 // Measured (B = 32 x T = 16 = 512 images, us, two-term | three-term | framework): 256 -> 128 channels 84 | 96 | 172, 512 -> 256:
 // 235-250 | 355-380 | 570-600, 256 -> 512: 237-253 | 350-374 | 570-610, 128 -> 320: 114 | 131-139 | 170-183.  Phase stamps
@@ -143,16 +143,19 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_kernel(DgArgs a) {
   constexpr int NTERM = F16 ? 2 : 3, NPROD = F16 ? 3 : 6;
   constexpr int CI = 32 * NT, WB = w_blob(NTERM, NT), G_IMG = g_img(NTERM);
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  uint8_t* const sW = lds;                                  // [term][tap][k half][ci][8 co] bf16
-  uint8_t* const sG = lds + WB;                             // [image][term][k half][cell][8 co] bf16
+  uint8_t* const sW = lds;                                  // [2 buffers][term][tap][k half][ci][8 co]
+  uint8_t* const sG = lds + 2 * WB;                         // [image][term][k half][cell][8 co]
+  const unsigned sW_addr = spk_lds_addr(sW);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lane16 = (unsigned)lane * 16u;
   const int n_ct = a.Cin / CI, n_chunks = a.Cout / KC;
   const int ct = blockIdx.x % n_ct, ig = blockIdx.x / n_ct;
   const int n0 = ig * NIMG, ci0 = ct * CI;
 
   // zero the gy grids once: the border cells stay zero for the whole launch, interiors are rewritten by every chunk
   for (int i = tid; i < NIMG * G_IMG / 16; i += NTHR) reinterpret_cast<uint4*>(sG)[i] = make_uint4(0, 0, 0, 0);
-  float* const s_scale = reinterpret_cast<float*>(lds + WB + NIMG * G_IMG);            // F16 form: 2^s of the workgroup's images
+  float* const s_scale = reinterpret_cast<float*>(lds + 2 * WB + NIMG * G_IMG);            // F16 form: 2^s of the workgroup's images
   float my_inv = 1.0f;
   if constexpr (F16) {
     // this wave's image: largest magnitude of its whole output gradient (49 x Cout values, read once more here)
@@ -190,9 +193,9 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_kernel(DgArgs a) {
   // staging shares.  gy chunk: 8 images x 49 positions x 4 quarters of 16 channels (item tid + 512 j: image, position, quarter);
   // weights: a flat copy of WB bytes in 16-byte vectors
   constexpr int NG = (NIMG * HW7 * 4 + NTHR - 1) / NTHR;    // 4
-  constexpr int NW = (WB / 16 + NTHR - 1) / NTHR;           // 4 / 7
+  constexpr int NPW = (WB / 1024 + 7) / 8;                  // 1 KiB copy pieces of the weight blob per wave
+  static_assert(WB % 1024 == 0, "whole copy pieces");
   v4f rg[NG];                                               // (ext vectors: HIP's uint4 / float4 structs kept these arrays in scratch)
-  v4i rw[NW];
   int g_src[NG], g_dst[NG];                                 // element offset in gy (without the chunk's channel offset) / LDS byte offset, -1: none
   float g_scl[NG];                                          // F16 form: 2^s of the item's image
 #pragma unroll
@@ -211,11 +214,14 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_kernel(DgArgs a) {
     const float* g = a.gy + chunk * KC;
 #pragma unroll
     for (int j = 0; j < NG; ++j) rg[j] = *reinterpret_cast<const v4f*>(g + g_src[j]);
-    const v4i* wv = reinterpret_cast<const v4i*>(wsrc + (long long)chunk * WB);
+    // the weight blob goes straight to the OTHER weight buffer (LDS-DMA, no registers): it was last read two chunks ago
+    const uint8_t* wb = wsrc + (long long)chunk * WB;
+    const unsigned dst = sW_addr + (unsigned)(chunk & 1) * WB;
 #pragma unroll
-    for (int j = 0; j < NW; ++j) {
-      const int i = tid + NTHR * j;
-      rw[j] = wv[i < WB / 16 ? i : WB / 16 - 1];
+    for (int j = 0; j < NPW; ++j) {
+      int pc = wave_s + 8 * j;
+      pc = pc < WB / 1024 ? pc : WB / 1024 - 1;             // (the last round repeats a piece: same bytes to the same place)
+      spk_dma16s(wb + pc * 1024, lane16, dst + pc * 1024);
     }
   };
   auto deposit = [&]() {
@@ -241,11 +247,6 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_kernel(DgArgs a) {
         *reinterpret_cast<uint2*>(d + 4 * NCELL * 16) = make_uint2((l[0] >> 16) | (l[1] & 0xFFFF0000u), (l[2] >> 16) | (l[3] & 0xFFFF0000u));
       }
     }
-#pragma unroll
-    for (int j = 0; j < NW; ++j) {
-      const int i = tid + NTHR * j;
-      if (i < WB / 16) reinterpret_cast<v4i*>(sW)[i] = rw[j];
-    }
   };
 
   // fragment bases: A row r of tile mt = image row 4 mt + r / 8, column r % 8 (column 7 and image row 7 are padding: computed,
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_kernel(DgArgs a) {
     if (x == 7 && (row & 8)) cell -= 8;                      // (... that of the group's FIRST row + 1 for the second row: residue c + 8)
     a_base[mt] = sG + wave * G_IMG + (half * NCELL + cell) * 16;
   }
-  const uint8_t* const b_base = sW + (half * CI + row) * 16;
+  const uint8_t* const b_base0 = sW + (half * CI + row) * 16;
 
   // TWO accumulators per output tile: the leading product (0,0) and the five small ones.  In one accumulator every small
   // product re-rounds the whole sum (six roundings of size eps |sum| per k step instead of one: 6e-7 relative L2 against fp64
@@ -279,10 +280,12 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_kernel(DgArgs a) {
       for (int r = 0; r < 16; ++r) { acc[mt][nt][r] = 0.f; acs[mt][nt][r] = 0.f; }
 
   fetch(0);
+  spk_dma_wait_all();
   deposit();
   __syncthreads();
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
     if (chunk + 1 < n_chunks) fetch(chunk + 1);
+    const uint8_t* const b_base = b_base0 + (chunk & 1) * WB;
     // nine taps: the fragments of tap t + 1 are read while the products of tap t run
     v4i af[2][2][NTERM], bf[2][NT][NTERM];
     auto load_tap = [&](int tap, int slot) {
@@ -322,7 +325,8 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_kernel(DgArgs a) {
           }
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();                                        // everyone is done reading this chunk
+    __syncthreads();                                        // everyone is done reading this chunk's gy
+    spk_dma_wait_all();                                     // this wave's loads and weight pieces of the next chunk have landed
     if (chunk + 1 < n_chunks) deposit();
     __syncthreads();
   }
@@ -388,7 +392,7 @@ int dgrad_launch(const float* gy_cl, const float* w_cl, uint8_t* ws, long long w
   }
   SPK_LAUNCH_CHECK();
   const int grid = ((N + NIMG - 1) / NIMG) * (Cin / CI);
-  const size_t lds = (size_t)w_blob(F16 ? 2 : 3, nt) + (size_t)NIMG * g_img(F16 ? 2 : 3) + 64;
+  const size_t lds = 2 * (size_t)w_blob(F16 ? 2 : 3, nt) + (size_t)NIMG * g_img(F16 ? 2 : 3) + 64;
   if (F16 && nt == 2) hipLaunchKernelGGL((dgrad3x3_kernel<2, true>), dim3(grid), dim3(NTHR), lds, stream, a);
   else if (F16) hipLaunchKernelGGL((dgrad3x3_kernel<1, true>), dim3(grid), dim3(NTHR), lds, stream, a);
   else hipLaunchKernelGGL((dgrad3x3_kernel<1, false>), dim3(grid), dim3(NTHR), lds, stream, a);
