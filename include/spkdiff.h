@@ -348,7 +348,7 @@ int spk_conv3x3_wgrad_bf16(const float* gy_cl, const float* spikes_cl, float* ws
  * w[co][ky][kx][ci], channels-last fp32 tensors (gy [N][49][Cout], w [Cout][3][3][Cin], gi [N][49][Cin]).  Both operands are
  * split into three bf16 terms exactly and six cross products run on the bf16 matrix cores with fp32 accumulation (what is
  * dropped is below 2^-24 of a product): an fp32 GEMM's accuracy.  ws: spk_conv3x3_dgrad_ws_bytes(Cout, Cin) bytes (the packed
- * weight terms, rewritten by every call).  Deterministic.  7x7 maps, Cout % 16 == 0, Cin % 32 == 0; otherwise
+ * weight terms, rewritten by every call).  Deterministic.  7x7 or 8x8 maps (49 -> H * W), Cout % 16 == 0, Cin % 32 == 0; otherwise
  * SPK_ERR_UNSUPPORTED (use the framework's operator). */
 long long spk_conv3x3_dgrad_ws_bytes(int Cout, int Cin);
 int spk_conv3x3_dgrad_bf16(const float* gy_cl, const float* w_cl, uint8_t* ws, long long ws_bytes, float* gi_out, int N, int H,

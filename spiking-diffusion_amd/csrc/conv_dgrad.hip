@@ -1,10 +1,10 @@
-// Data gradient of a 3x3 / stride 1 / pad 1 convolution on 7x7 maps, on the bf16 / fp16 matrix cores with fp32 accuracy
+// Data gradient of a 3x3 / stride 1 / pad 1 convolution on 7x7 or 8x8 maps, on the bf16 / fp16 matrix cores with fp32 accuracy
 // (the training step of the denoiser, R/snn_model/vq_diffusion.py:166-187 through autograd; the
 // reference runs cuDNN's data-gradient kernels here):
 //
 //   gi[n][y][x][ci] = sum over (co, ky, kx) of  gy[n][y + 1 - ky][x + 1 - kx][co] * w[co][ky][kx][ci]
 //
-// a GEMM per image with M = 49 positions, N = Cin, K = 9 Cout, both operands dense fp32.  Two forms of one kernel template:
+// a GEMM per image with M = 49 (or 64) positions, N = Cin, K = 9 Cout, both operands dense fp32.  Two forms of one kernel template:
 //   * THREE bf16 terms per operand by truncation (x = x0 + x1 + x2 exactly: 8 + 8 + 8 significant bits), SIX of the nine cross
 //     products on v_mfma_f32_32x32x16_bf16 -- (0,0) (0,1) (1,0) (0,2) (2,0) (1,1): every product is exact, what is dropped is
 //     below 2^-24 of |g w| (spk_conv3x3_dgrad_bf16);
@@ -17,7 +17,7 @@
 // The leading product and the small ones go to SEPARATE accumulators (see the kernel).
 //
 // Mapping.  One workgroup = eight images (one per wave) x 32 NT input channels (NT = 1, or 2 in the two-term form where that
-// still fills the CUs); a wave owns its image's two 32-row position tiles (four image rows of 7 + 1 padding column each: 49
+// still fills the CUs); a wave owns its image's two 32-row position tiles (four image rows each; 8x8: two full tiles; 7x7: 7 + 1 padding column per row, 49
 // positions + 15 rows computed and dropped) x NT column tiles.  K runs in chunks of 16 output channels (one MFMA k step) x nine
 // taps:
 //   * the weights of a chunk are pre-packed ONCE per call (dgrad_pack_kernel / dgrad_pack_f16_kernel) as the term planes in the
@@ -43,9 +43,10 @@ typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int HW7 = 49, NIMG = 8, NTHR = 512, KC = 16;     // images per workgroup, threads, output channels per chunk
-constexpr int NCELL = 82;                                   // 9 x 9 grid cells per (term, k half) + one spare (keeps images 16 B x 82 apart)
-__host__ __device__ constexpr int g_img(int nterm) { return nterm * 2 * NCELL * 16; }   // bytes of one image's chunk in LDS: [term][k half][cell][8 co]
+constexpr int NIMG = 8, NTHR = 512, KC = 16;               // images per workgroup, threads, output channels per chunk
+// maps of HH x HH positions, HH = 7 (the MNIST-shaped latents) or 8 (the CIFAR-shaped ones: 64 positions = two full tiles)
+__host__ __device__ constexpr int n_cell(int hh) { return (hh + 2) * (hh + 2) + 1; }     // (HH + 2)^2 grid cells per (term, k half) + one spare
+__host__ __device__ constexpr int g_img(int nterm, int hh) { return nterm * 2 * n_cell(hh) * 16; }   // bytes of one image's chunk in LDS: [term][k half][cell][8 co]
 __host__ __device__ constexpr int w_blob(int nterm, int nt) { return nterm * 9 * 2 * 32 * nt * 16; }     // bytes of one packed weight chunk
 
 struct DgArgs {
@@ -138,10 +139,11 @@ __global__ void dgrad_pack_kernel(const float* __restrict__ w, unsigned short* _
   }
 }
 
-template <int NT, bool F16>
+template <int NT, bool F16, int HH>
 __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_kernel(DgArgs a) {
   constexpr int NTERM = F16 ? 2 : 3, NPROD = F16 ? 3 : 6;
-  constexpr int CI = 32 * NT, WB = w_blob(NTERM, NT), G_IMG = g_img(NTERM);
+  constexpr int HW7 = HH * HH, GW = HH + 2, NCELL = n_cell(HH);         // (HW7: positions per map, whatever HH)
+  constexpr int CI = 32 * NT, WB = w_blob(NTERM, NT), G_IMG = g_img(NTERM, HH);
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   uint8_t* const sW = lds;                                  // [2 buffers][term][tap][k half][ci][8 co]
   uint8_t* const sG = lds + 2 * WB;                         // [image][term][k half][cell][8 co]
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_kernel(DgArgs a) {
     const bool ok = idx < NIMG * HW7 * 4 && n0 + img < a.N;
     const int nn = n0 + img < a.N ? n0 + img : a.N - 1;
     g_src[j] = (nn * HW7 + pos) * a.Cout + 4 * q;
-    const int cell = (pos / 7 + 1) * 9 + (pos % 7 + 1);
+    const int cell = (pos / HH + 1) * GW + (pos % HH + 1);
     g_dst[j] = ok ? img * G_IMG + ((q >> 1) * NCELL + cell) * 16 + (q & 1) * 8 : -1;
     g_scl[j] = F16 ? s_scale[idx < NIMG * HW7 * 4 ? img : 0] : 1.0f;
   }
@@ -260,9 +262,9 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_kernel(DgArgs a) {
   for (int mt = 0; mt < 2; ++mt) {
     int y = 4 * mt + (row >> 3);
     const int x = row & 7;
-    y = y < 7 ? y : 6;
-    int cell = y * 9 + x;                                    // (x = 7: the padding lane reads the row's border cell ...)
-    if (x == 7 && (row & 8)) cell -= 8;                      // (... that of the group's FIRST row + 1 for the second row: residue c + 8)
+    y = y < HH ? y : HH - 1;
+    int cell = y * GW + x;                                   // (7x7, x = 7: the padding lane reads the row's border cell ...)
+    if (HH == 7 && x == 7 && (row & 8)) cell -= 8;           // (... that of the group's FIRST row + 1 for the second row: residue c + 8)
     a_base[mt] = sG + wave * G_IMG + (half * NCELL + cell) * 16;
   }
   const uint8_t* const b_base0 = sW + (half * CI + row) * 16;
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_kernel(DgArgs a) {
     v4i af[2][2][NTERM], bf[2][NT][NTERM];
     auto load_tap = [&](int tap, int slot) {
       // gy position of output (y, x) under tap (ky, kx): (y + 1 - ky, x + 1 - kx) -> grid cell (y + 2 - ky) * 9 + (x + 2 - kx)
-      const int toff = ((2 - tap / 3) * 9 + (2 - tap % 3)) * 16;
+      const int toff = ((2 - tap / 3) * GW + (2 - tap % 3)) * 16;
 #pragma unroll
       for (int t = 0; t < NTERM; ++t) {
 #pragma unroll
@@ -342,8 +344,8 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_kernel(DgArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * half, y = 4 * mt + (rr >> 3), x = rr & 7;
-        const int p = y * 7 + x;
-        if (x < 7 && y < 7) {
+        const int p = y * HH + x;
+        if (x < HH && y < HH) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             const float v = acc[mt][nt][r] + acs[mt][nt][r];
@@ -370,8 +372,8 @@ template <bool F16>
 int dgrad_launch(const float* gy_cl, const float* w_cl, uint8_t* ws, long long ws_bytes, float* gi_out, int N, int H, int W,
                  int Cout, int Cin, hipStream_t stream) {
   if (!gy_cl || !w_cl || !ws || !gi_out || N <= 0) return SPK_ERR_ARG;
-  if (H != 7 || W != 7 || Cout <= 0 || Cin <= 0 || (Cout % KC) || (Cin % 32)) return SPK_ERR_UNSUPPORTED;
-  if ((long long)N * HW7 * Cout >= (1LL << 31)) return SPK_ERR_UNSUPPORTED;      // (32-bit element offsets in the staging table)
+  if (H != W || (H != 7 && H != 8) || Cout <= 0 || Cin <= 0 || (Cout % KC) || (Cin % 32)) return SPK_ERR_UNSUPPORTED;
+  if ((long long)N * H * W * Cout >= (1LL << 31)) return SPK_ERR_UNSUPPORTED;    // (32-bit element offsets in the staging table)
   if (ws_bytes < spk_conv3x3_dgrad_ws_bytes(Cout, Cin)) return SPK_ERR_ARG;
   const int nt = dgrad_nt(F16, N, Cin), CI = 32 * nt;
   const long long n = (long long)Cout * 9 * Cin;
@@ -392,10 +394,16 @@ int dgrad_launch(const float* gy_cl, const float* w_cl, uint8_t* ws, long long w
   }
   SPK_LAUNCH_CHECK();
   const int grid = ((N + NIMG - 1) / NIMG) * (Cin / CI);
-  const size_t lds = 2 * (size_t)w_blob(F16 ? 2 : 3, nt) + (size_t)NIMG * g_img(F16 ? 2 : 3) + 64;
-  if (F16 && nt == 2) hipLaunchKernelGGL((dgrad3x3_kernel<2, true>), dim3(grid), dim3(NTHR), lds, stream, a);
-  else if (F16) hipLaunchKernelGGL((dgrad3x3_kernel<1, true>), dim3(grid), dim3(NTHR), lds, stream, a);
-  else hipLaunchKernelGGL((dgrad3x3_kernel<1, false>), dim3(grid), dim3(NTHR), lds, stream, a);
+  const size_t lds = 2 * (size_t)w_blob(F16 ? 2 : 3, nt) + (size_t)NIMG * g_img(F16 ? 2 : 3, H) + 64;
+  if (H == 7) {
+    if (F16 && nt == 2) hipLaunchKernelGGL((dgrad3x3_kernel<2, true, 7>), dim3(grid), dim3(NTHR), lds, stream, a);
+    else if (F16) hipLaunchKernelGGL((dgrad3x3_kernel<1, true, 7>), dim3(grid), dim3(NTHR), lds, stream, a);
+    else hipLaunchKernelGGL((dgrad3x3_kernel<1, false, 7>), dim3(grid), dim3(NTHR), lds, stream, a);
+  } else {
+    if (F16 && nt == 2) hipLaunchKernelGGL((dgrad3x3_kernel<2, true, 8>), dim3(grid), dim3(NTHR), lds, stream, a);
+    else if (F16) hipLaunchKernelGGL((dgrad3x3_kernel<1, true, 8>), dim3(grid), dim3(NTHR), lds, stream, a);
+    else hipLaunchKernelGGL((dgrad3x3_kernel<1, false, 8>), dim3(grid), dim3(NTHR), lds, stream, a);
+  }
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

@@ -796,8 +796,8 @@ def conv3x3_wgrad(gy_cl, spikes_cl, Cout, Cin, want_bias=False):
 
 def conv3x3_dgrad_supported(Cout, Cin, H, W, N):
     # (small layers and small batches: the framework's operator is as fast)
-    return ((H, W) == (7, 7) and Cout % 16 == 0 and Cin % 32 == 0 and Cout * Cin >= 32768 and N >= 64
-            and N * 49 * Cout < 2 ** 31)                 # (32-bit element offsets in the kernel's staging table)
+    return ((H, W) in ((7, 7), (8, 8)) and Cout % 16 == 0 and Cin % 32 == 0 and Cout * Cin >= 32768 and N >= 64
+            and N * H * W * Cout < 2 ** 31)              # (32-bit element offsets in the kernel's staging table)
 
 
 # False: the data gradient of the spike-input convolutions comes from the framework's operator (as in rounds 1-2)
@@ -809,21 +809,21 @@ DGRAD_FORM = "f16x2"
 
 
 def conv3x3_dgrad(gy_cl, weight, Cin, form=None):
-    """gi [N,Cin,7,7] (channels-last memory) of a 3x3 / s1 / p1 convolution from gy [N,Cout,7,7] (channels-last fp32) and the
-    weight [Cout,Cin,3,3] (spk_conv3x3_dgrad_bf16: bf16 matrix cores, both operands split into three bf16 terms exactly, six
-    cross products: fp32 accuracy)."""
-    N, Cout = int(gy_cl.shape[0]), int(gy_cl.shape[1])
+    """gi [N,Cin,H,W] (channels-last memory) of a 3x3 / s1 / p1 convolution from gy [N,Cout,H,W] (channels-last fp32; 7x7 or
+    8x8 maps) and the weight [Cout,Cin,3,3]: spk_conv3x3_dgrad_f16x2 (two scaled fp16 terms per operand, three products) or
+    spk_conv3x3_dgrad_bf16 (three exact bf16 terms, six products); fp32 accuracy either way."""
+    N, Cout, H, W = int(gy_cl.shape[0]), int(gy_cl.shape[1]), int(gy_cl.shape[2]), int(gy_cl.shape[3])
     nb = int(lib.spk_conv3x3_dgrad_ws_bytes(Cout, int(Cin)))
     if nb <= 0:
         raise NotImplementedError("spk_conv3x3_dgrad_bf16: unsupported shape")
     w_cl = weight.detach().contiguous(memory_format=torch.channels_last)        # storage [Cout][3][3][Cin]
     ws = torch.empty(nb, dtype=torch.uint8, device=gy_cl.device)
-    gi = torch.empty((N, 7, 7, Cin), dtype=torch.float32, device=gy_cl.device)
+    gi = torch.empty((N, H, W, Cin), dtype=torch.float32, device=gy_cl.device)
     form = form or DGRAD_FORM
     fn, name = ((lib.spk_conv3x3_dgrad_f16x2, "spk_conv3x3_dgrad_f16x2") if form == "f16x2"
                 else (lib.spk_conv3x3_dgrad_bf16, "spk_conv3x3_dgrad_bf16"))
     with timed("train.conv_bwd_data"):
-        check(fn(_p(gy_cl), _p(w_cl), _p(ws), nb, _p(gi), N, 7, 7, Cout, int(Cin), _stream(gy_cl)), name)
+        check(fn(_p(gy_cl), _p(w_cl), _p(ws), nb, _p(gi), N, H, W, Cout, int(Cin), _stream(gy_cl)), name)
     return gi.permute(0, 3, 1, 2)
 
 
@@ -911,8 +911,8 @@ class SpikeConvMeanTrainFunction(torch.autograd.Function):
         need_gi, need_gw = bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1])
         need_gb = bool(ctx.has_bias and ctx.needs_input_grad[2])
         gi = gw = gb = None
-        native = tuple(weight.shape[2:]) == (3, 3) and (H, W) == (7, 7)
-        if need_gw and native and NATIVE_WGRAD and Cout % 128 == 0 and Cin % 64 == 0:
+        native = tuple(weight.shape[2:]) == (3, 3) and (H, W) in ((7, 7), (8, 8))
+        if need_gw and native and (H, W) == (7, 7) and NATIVE_WGRAD and Cout % 128 == 0 and Cin % 64 == 0:
             gw = conv3x3_wgrad(g, c, Cout, Cin)
             need_gw = False
         if need_gi and native and NATIVE_DGRAD and Cout % 16 == 0 and Cin % 32 == 0:

@@ -2336,29 +2336,30 @@ def test_conv3x3_weight_gradient_bf16_kernel_vs_fp64(dev, ops, N, Cout, Cin):
 @pytest.mark.parametrize("N,Cout,Cin", [(8, 128, 64), (64, 256, 128), (37, 512, 256), (16, 256, 512), (5, 128, 320), (320, 128, 320),
                                         (3, 16, 32)])
 @pytest.mark.parametrize("form", ["bf16x3", "f16x2"])
-def test_conv3x3_data_gradient_bf16_kernel_vs_fp64(dev, ops, N, Cout, Cin, form):
+@pytest.mark.parametrize("HH", [7, 8])
+def test_conv3x3_data_gradient_bf16_kernel_vs_fp64(dev, ops, N, Cout, Cin, form, HH):
     """spk_conv3x3_dgrad_bf16 (both operands split into three bf16 terms exactly, six cross products on the matrix cores, fp32
     accumulation) against the fp64 data gradient of the same convolution: relative L2 error at fp32 round-off, and not worse
     than twice the framework's fp32 operator; borders, ragged image groups, both column-tile forms."""
     g = torch.Generator().manual_seed(N + Cout + Cin)
-    gy = torch.randn(N, Cout, 7, 7, generator=g) * torch.rand(Cout, generator=g).view(1, -1, 1, 1) * 1e-3
+    gy = torch.randn(N, Cout, HH, HH, generator=g) * torch.rand(Cout, generator=g).view(1, -1, 1, 1) * 1e-3
     gy[:, ::5] *= 64.0                                                    # mixed magnitudes across channels
     w = torch.randn(Cout, Cin, 3, 3, generator=g) * (0.5 / (Cin * 9) ** 0.5)
     w[::3] *= 17.0
-    x = torch.zeros(N, Cin, 7, 7)
+    x = torch.zeros(N, Cin, HH, HH)
     want, _, _ = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), [Cout], [1, 1], [1, 1], [1, 1], False,
                                                      [0, 0], 1, [True, False, False])
     gy_cl = gy.to(dev).contiguous(memory_format=torch.channels_last)
     got = ops.conv3x3_dgrad(gy_cl, w.to(dev), Cin, form=form)
-    assert got.shape == (N, Cin, 7, 7)
+    assert got.shape == (N, Cin, HH, HH)
     rel = float((got.cpu().double() - want).norm() / want.norm())
     lib_gi, _, _ = torch.ops.aten.convolution_backward(gy_cl, x.to(dev).contiguous(memory_format=torch.channels_last),
                                                        w.to(dev).contiguous(memory_format=torch.channels_last), [Cout], [1, 1],
                                                        [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])
     rel_lib = float((lib_gi.cpu().double() - want).norm() / want.norm())
     worst = float((got.cpu().double() - want).abs().max() / want.abs().max())
-    print(f"dgrad {form} N={N} {Cout}->{Cin}: rel L2 error {rel:.2e} (framework operator {rel_lib:.2e}), max abs / max |gi| {worst:.2e}")
-    parity(f"dgrad_{form}_N{N}_{Cout}_{Cin}", rel_l2_err=rel, rel_l2_err_framework=rel_lib)
+    print(f"dgrad {form} {HH}x{HH} N={N} {Cout}->{Cin}: rel L2 error {rel:.2e} (framework operator {rel_lib:.2e}), max abs / max |gi| {worst:.2e}")
+    parity(f"dgrad_{form}_{HH}x{HH}_N{N}_{Cout}_{Cin}", rel_l2_err=rel, rel_l2_err_framework=rel_lib)
     assert rel <= 1e-6 and rel <= 2.0 * rel_lib + 1e-7 and worst <= 2e-6
     got2 = ops.conv3x3_dgrad(gy_cl, w.to(dev), Cin, form=form)
     assert torch.equal(got, got2), "deterministic"
