@@ -366,12 +366,13 @@ int spk_conv3x3_dgrad_f16x2(const float* gy_cl, const float* w_cl, uint8_t* ws, 
  * BEFORE the denoiser call and only scatters the sample there (:140): for an image without a change at step t the
  * denoiser output is never read.  Writes the ascending list of images with >= 1 change (active_out [B] int32) and its
  * length (n_active_out [2] int32: [0] the length, [1] a work word that must be ZERO before the first call and is left zero);
- * u / Philox arguments exactly as spk_psample_step (same draws).  With sample_steps = 100
+ * u / Philox arguments exactly as spk_psample_step (same draws; K = the class count of that call: it is the stride of the
+ * counter layout, see spk_psample_step).  With sample_steps = 100
  * and 49 positions an image is touched by 39 % of the steps on average: the per-step kernels take the list / count as
  * `active` / `n_dyn` arguments and skip the rest -- the same tokens as the dense loop, fewer evaluations. */
 int spk_select_active(const uint8_t* unmasked, int t, const float* u_or_null, unsigned long long philox_seed,
                       unsigned long long philox_offset, const unsigned long long* philox_state_or_null, int* active_out,
-                      int* n_active_out, int B, int HW, spk_stream_t stream);
+                      int* n_active_out, int B, int HW, int K, spk_stream_t stream);
 /* Positions of the active images that reverse step t needs from each denoiser layer (same `changes` test as above, per
  * position; R/snn_model/vq_diffusion.py:134-140 reads the denoiser output only there).  need_out: a ZERO-INITIALISED buffer of
  * spk_select_needed_bytes(B, R) bytes (it stays consistent from call to call); for every radius r = 1..R it receives, per
@@ -382,7 +383,7 @@ int spk_select_active(const uint8_t* unmasked, int t, const float* u_or_null, un
 long long spk_select_needed_bytes(int B, int R);
 int spk_select_needed(const uint8_t* unmasked, int t, const float* u_or_null, unsigned long long philox_seed,
                       unsigned long long philox_offset, const unsigned long long* philox_state_or_null, const int* active,
-                      const int* n_active, uint8_t* need_out, int B, int H, int W, int R, spk_stream_t stream);
+                      const int* n_active, uint8_t* need_out, int B, int H, int W, int R, int K, spk_stream_t stream);
 /* cat(x, ones_like(x)*t) of DummyModel.forward, R/snn_model/vq_diffusion.py:195-197 -> fp32 [B,2,h,w].
  * active / n_active (both or neither): slot s of the output is image active[s], s < *n_active. */
 int spk_den_build_input(const float* x_float_or_null, const long long* x_tokens_or_null, const long long* t_vec_or_null,
@@ -390,7 +391,10 @@ int spk_den_build_input(const float* x_float_or_null, const long long* x_tokens_
                         const int* n_active_or_null, spk_stream_t stream);
 /* Loop body of AbsorbingDiffusion.sample after the denoiser call, R/snn_model/vq_diffusion.py:113-124,134-140.
  * logits [B,K,h,w] fp32; x_t int64 [B*HW]; unmasked u8/bool [B*HW]; u [B*HW] / q [B*HW*K] injected noise or NULL
- * (then Philox4x32-10(seed, offset + index)); philox_state optional device {seed, base offset} pair that overrides
+ * (then Philox4x32-10 keyed by seed: position p = image * HW + hw draws u from counter offset + p * K of stream 0 and q_k
+ * from counter offset + p * K + k of stream 1 -- ONE rule for both, so a shard that starts at image b0 of a larger job
+ * passes offset + b0 * HW * K and draws exactly what the whole job would draw for its images: the sample does not depend
+ * on how a batch is split over devices); philox_state optional device {seed, base offset} pair that overrides
  * the seed and is added to the offset (lets a captured hipGraph draw fresh noise on every replay);
  * x0_hat_out optional int64 [B*HW].  active / n_active (both or neither; not with x0_hat_out): logits hold one slot
  * per active image (slot s = image active[s]); noise, x_t and unmasked stay indexed by image.
@@ -409,7 +413,10 @@ int spk_psample_step(const float* logits_bkhw, long long* x_t_inout, uint8_t* un
  * [B][2][HW][16][16 B] and spike counts u8 [B][2][HW][32].  cnt5 [B][8][HW][32] / cnt1 [B][2][HW][32]: spike counts of conv5 /
  * conv1 of THIS step; wq / scale / bias_d: conv6 packed by spk_den_pack_weight_i8; conv1_w_packed: spk_pack_conv_weight of the
  * first layer ([9][2][64]); bn1_a / bn1_b: its folded BatchNorm.  logits_out optional fp32 [B][K][H][W].  K = 128, 7x7 or 8x8
- * latents, 256 + 64 input channels (the reference's architecture); anything else: SPK_ERR_UNSUPPORTED (use the three launches). */
+ * latents, 256 + 64 input channels (the reference's architecture); anything else: SPK_ERR_UNSUPPORTED (use the three launches).
+ * The fused first layer is the time-invariant-input form with the module defaults baked in: T = 16 steps and
+ * LIFNode(tau = 2, v_threshold = 1, v_reset = 0) (R/snn_model/vq_diffusion.py:161-165); with x1_s32_out set any other T is
+ * SPK_ERR_UNSUPPORTED (conv6 alone takes T <= 127). */
 int spk_den_step_tail(const uint8_t* cnt5, int nch5, const uint8_t* cnt1, int nch1, const int8_t* wq, const double* scale,
                       const double* bias_d, float* logits_out_or_null, long long* x_t_inout, uint8_t* unmasked_inout, int t,
                       float temp, const float* u_or_null, const float* q_or_null, unsigned long long philox_seed,

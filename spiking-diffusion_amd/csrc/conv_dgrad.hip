@@ -58,8 +58,15 @@ struct DgArgs {
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 
-// F16 form.  x 2^s = h + m + (less than 2^-23 |x 2^s|): h = the fp16 nearest to x 2^s, m = the fp16 nearest to the (exact)
-// remainder.  s puts the largest magnitude of the scaled set into [2^14, 2^15): 28 binades below it keep full precision.
+// F16 form.  x 2^s = h + m + e: h = the fp16 nearest to x 2^s, m = the fp16 nearest to the (exact) remainder.  s puts the largest
+// magnitude of the scaled set (an image's gy, an input channel's weights) into [2^14, 2^15).  While the remainder is a NORMAL
+// fp16 -- scaled magnitudes down to about 2^-3, i.e. ~17 binades below the set's maximum -- |e| < 2^-22 |x 2^s|: fp32-like
+// relative precision per element.  Below that the remainder falls into fp16's subnormals (lsb 2^-24) and the error becomes
+// ABSOLUTE: |e| <= 2^-25 scaled = 2^-40 of the set's maximum (11 significant bits at 2^-29 of the maximum).  Accuracy is thus
+// relative to the image's / channel's largest element, not per element as in an fp32 operator: an output whose whole 3x3
+// neighbourhood lies more than ~17 binades below its image's maximum loses relative precision accordingly
+// (tests/test_gpu_parity.py::test_data_gradient_forms_wide_dynamic_range_per_element: the three-term bf16 form, whose terms are
+// exact truncations at any magnitude, is the per-element-accurate one).
 __device__ __forceinline__ float scale_of(unsigned max_bits) {          // 2^s for a set whose largest magnitude has these bits
   int be = (int)((max_bits >> 23) & 0xFFu);
   if (be == 0) return 1.0f;                                              // all zero (or denormal): nothing to scale
@@ -395,6 +402,7 @@ int dgrad_launch(const float* gy_cl, const float* w_cl, uint8_t* ws, long long w
   SPK_LAUNCH_CHECK();
   const int grid = ((N + NIMG - 1) / NIMG) * (Cin / CI);
   const size_t lds = 2 * (size_t)w_blob(F16 ? 2 : 3, nt) + (size_t)NIMG * g_img(F16 ? 2 : 3, H) + 64;
+  if ((long long)lds > spk_lds_limit()) return SPK_ERR_UNSUPPORTED;     // (only the workspace has been written so far)
   if (H == 7) {
     if (F16 && nt == 2) hipLaunchKernelGGL((dgrad3x3_kernel<2, true, 7>), dim3(grid), dim3(NTHR), lds, stream, a);
     else if (F16) hipLaunchKernelGGL((dgrad3x3_kernel<1, true, 7>), dim3(grid), dim3(NTHR), lds, stream, a);

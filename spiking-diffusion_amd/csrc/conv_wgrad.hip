@@ -256,6 +256,7 @@ extern "C" int spk_conv3x3_wgrad_bf16(const float* gy_cl, const float* spikes_cl
   WgArgs a;
   a.gy = gy_cl; a.s = spikes_cl; a.part = ws;
   a.part_gb = gb_out_or_null ? ws + (long long)ks * n : nullptr; a.TB = TB; a.Cout = Cout; a.Cin = Cin; a.ksplit = ks;
+  if ((long long)LDS_BYTES > spk_lds_limit()) return SPK_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(wgrad3x3_bf16_kernel, dim3(tiles * ks), dim3(NTHR), (size_t)LDS_BYTES, stream, a);
   SPK_LAUNCH_CHECK();
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, stream,

@@ -37,6 +37,19 @@ static inline int spk_cu_count() {
   return cus;
 }
 
+// LDS a workgroup of the current device may allocate (queried once, like the CU count): launches that ask for more than the
+// 64 KB every device grants check it first and return SPK_ERR_UNSUPPORTED instead of failing inside the launch
+static inline long long spk_lds_limit() {
+  static const long long lim = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0)
+      return (long long)v;
+    return 65536ll;
+  }();
+  return lim;
+}
+
 // LDS-DMA of 16 bytes per lane: LDS[lds_base + lane * 16] = *(gsrc of this lane); lds_base is wave-uniform.
 // Issued as inline assembly on purpose: hipcc treats the builtin (__builtin_amdgcn_global_load_lds) as a FLAT access
 // that may touch LDS, and while one is in flight every LDS wait it inserts degrades to s_waitcnt lgkmcnt(0) -- which

@@ -675,6 +675,7 @@ extern "C" int spk_den_pack_weight_fp6(const float* w, const float* bias, uint8_
                                        int Cout, int Cin, hipStream_t stream) {
   if (!w || !wq || !scale || !bias_d || Cout <= 0 || Cin <= 0) return SPK_ERR_ARG;
   if ((Cout % 16) || (Cin % CK)) return SPK_ERR_UNSUPPORTED;
+  if ((long long)6 * Cin * 9 > spk_lds_limit()) return SPK_ERR_UNSUPPORTED;   // (one channel's six digit planes are staged in LDS)
   hipLaunchKernelGGL(pack_fp6_kernel, dim3(Cout), dim3(256), (size_t)6 * Cin * 9, stream, w, bias, wq, scale, bias_d, Cout, Cin);
   SPK_LAUNCH_CHECK();
   return SPK_OK;

@@ -119,6 +119,17 @@ struct V2Args {
 #ifndef SPK_V2_LAG_DEFAULT
 #define SPK_V2_LAG_DEFAULT 0    // 1: full 7x7 batches run the staggered form (conv3x3_fp6v2_lag_kernel); SPKDIFF_V2_LAG=0/1 overrides
 #endif
+#ifndef SPK_V2_NAGPR8
+#define SPK_V2_NAGPR8 0         // two waves per SIMD: accumulator tiles kept in AGPRs.  0 (round 4): all in VGPRs -- 243 registers, no
+                                // scratch, and the scan reads its operands directly instead of through 32 v_accvgpr_read per tile
+                                // (-8.6 % vector instructions per item; dense reverse process 91.2 / 92.4 -> 90.6 / 90.2 ms on one
+                                // box, profiles/r4_ab_kernel_variants.txt).  8: the round-2/3 form (128 + 105 registers)
+#endif
+#ifndef SPK_V2_MERGE_FULL
+#define SPK_V2_MERGE_FULL 1     // full 7x7 batches also run repair + last position as ONE tail launch (hand-over by the main launch).
+                                // Round 2 measured this 1.3 % slower; with the second certification stage (half the repairs) it is
+                                // 1.6 % FASTER (90.3 / 90.2 against 91.2 / 92.4 ms; both changes: 89.3 / 89.4).  0: two launches
+#endif
 #ifndef SPK_V2_PF
 #define SPK_V2_PF 6             // A fragments requested this many steps ahead of the MFMA that consumes them
 #endif
@@ -207,7 +218,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
                       : ((HW & 1) == 1 && ((HW / 2) % NWV) == 0), "whole 32-row tiles on every wave (+ one odd position)");
   static_assert(!PRUNE || (!SPLIT && (NWV == 4 || NWV == 8) && NTP <= (HWb / 2) / NWV), "position lists: 7x7 items");
   constexpr int NT = PRUNE ? NTP : (HWb / 2) / NWV;    // row tiles per wave (7x7: 6 or 3; 8x8 bands: 4)
-  constexpr int N_AGPR = NWV == 4 ? (NACC * NT < 16 ? NACC * NT : 16) : NWV == 12 ? SPK_V2_AGPR12 : (NACC * NT < 8 ? NACC * NT : 8);   // (two waves per SIMD: hipcc splits 256 registers 128 / 128)
+  constexpr int N_AGPR = NWV == 4 ? (NACC * NT < 16 ? NACC * NT : 16) : NWV == 12 ? SPK_V2_AGPR12 : (NACC * NT < SPK_V2_NAGPR8 ? NACC * NT : SPK_V2_NAGPR8);   // (two waves per SIMD: with any accumulator in AGPRs hipcc splits 256 registers 128 / 128)
   constexpr int NPP = (Hin + 2) * PW + 1;              // cells of the zero-bordered LDS image (pitch W + 1: the zero
   constexpr int A_BYTES = NPP * POSB;                  //  column is shared by x = -1 of a row and x = W of the previous)
   constexpr int PPR = (W + 3) / 4;                     // DMA pieces per image row (4 positions per KiB piece)
@@ -1475,7 +1486,7 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   // full 7x7 batches keep the round-1 order (repair launch, then the last-position launch re-arms the counter): the hand-over
   // costs a barrier and an atomic per workgroup of the main launch (1.2 us), which only the merged tail launch of the
   // active-set calls (and the launch it saves on even latents) pays back
-  a.handover = (bands || n_dyn_or_null) ? 1 : 0;
+  a.handover = (bands || n_dyn_or_null || SPK_V2_MERGE_FULL) ? 1 : 0;
   if (parts != 7) {
     // measurement / debugging: re-run one tail part of the LAST launch on this workspace.  2 = the exact recomputation of
     // the neurons that launch flagged (count in ws[1], ids still listed: idempotent), 4 = the last position of every image.
@@ -1523,7 +1534,7 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 4>), dim3(grid), dim3(256), lds, stream, a);
   SPK_LAUNCH_CHECK();
   const int n_lp = ((B + 1) / 2) * G;
-  if (n_dyn_or_null) {
+  if (n_dyn_or_null || SPK_V2_MERGE_FULL) {
     // the sampler's active-set calls: few images, both parts are latency bound -- one launch (-17 us per reverse step)
     hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7, 0>), dim3(n_lp + 8 * cus), dim3(256), 0, stream, a, n_words, n_lp);
     SPK_LAUNCH_CHECK();

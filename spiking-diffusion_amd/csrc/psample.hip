@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void psample_kernel(const float* __restrict__ 
       // the noise is counter-based / injected per position, so skipping a draw does not move any other)
       float u;
       if (u_in) u = u_in[p];
-      else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)p, 0u, r); u = u01_open_right(r[0]); }
+      else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)p * (unsigned long long)K, 0u, r); u = u01_open_right(r[0]); }
       if (!((u < inv_t) && !unmasked[p])) {
         // (dense form) the denoiser input of the next reverse step, cat(x_t, t - 1): this position keeps its token
         if (next_input && lane == 0) {
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void psample_kernel(const float* __restrict__ 
         u = u_in[p];
       } else {
         uint32_t r[4];
-        philox4x32(seed, offset + (unsigned long long)p, 0u, r);
+        philox4x32(seed, offset + (unsigned long long)p * (unsigned long long)K, 0u, r);
         u = u01_open_right(r[0]);
       }
       bool ch = (u < inv_t) && !unmasked[p];
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64) void select_active_kernel(const uint8_t* __rest
                                                            const float* __restrict__ u_in, unsigned long long seed,
                                                            unsigned long long offset,
                                                            const unsigned long long* __restrict__ philox_state,
-                                                           int* __restrict__ active, int* __restrict__ n_active, int B, int HW) {
+                                                           int* __restrict__ active, int* __restrict__ n_active, int B, int HW, int K) {
   if (philox_state) { seed = philox_state[0]; offset += philox_state[1]; }
   const float inv_t = 1.0f / (float)t;
   const int lane = threadIdx.x;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) void select_active_kernel(const uint8_t* __rest
         const long long p = (long long)b * HW + q + 8 * k;
         float u;
         if (u_in) u = u_in[p];
-        else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)p, 0u, r); u = u01_open_right(r[0]); }
+        else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)p * (unsigned long long)K, 0u, r); u = u01_open_right(r[0]); }
         any = any || (u < inv_t);
       }
     }
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64) void select_active_kernel(const uint8_t* __rest
       if (unmasked[p]) continue;
       float u;
       if (u_in) u = u_in[p];
-      else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)p, 0u, r); u = u01_open_right(r[0]); }
+      else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)p * (unsigned long long)K, 0u, r); u = u01_open_right(r[0]); }
       any = any || (u < inv_t);
     }
   }
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void select_needed_kernel(const uint8_t* __res
                                                             unsigned long long offset,
                                                             const unsigned long long* __restrict__ philox_state,
                                                             const int* __restrict__ active, const int* __restrict__ n_active,
-                                                            uint8_t* __restrict__ need, int B, int H, int W, int R) {
+                                                            uint8_t* __restrict__ need, int B, int H, int W, int R, int K) {
   __shared__ int s_cnt[8][8];
   __shared__ int s_last;
   if (philox_state) { seed = philox_state[0]; offset += philox_state[1]; }
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void select_needed_kernel(const uint8_t* __res
       if (!unmasked[p]) {
         float u;
         if (u_in) u = u_in[p];
-        else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)p, 0u, r); u = u01_open_right(r[0]); }
+        else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)p * (unsigned long long)K, 0u, r); u = u01_open_right(r[0]); }
         ch = u < 1.0f / (float)t;
       }
     }
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void select_needed_kernel(const uint8_t* __res
 }
 
 // The noise of one reverse step exactly as psample_kernel / select_active_kernel / select_needed_kernel draw it, written
-// out: u[p] (stream 0, counter offset + p) and q[p*K + k] (stream 1, counter offset + p*K + k).  A debug / parity entry:
+// out: u[p] (stream 0, counter offset + p*K) and q[p*K + k] (stream 1, counter offset + p*K + k).  A debug / parity entry:
 // the oracle is run on the dumped noise and must give the tokens of the Philox-mode sampler (the timed configuration).
 __global__ __launch_bounds__(256) void philox_noise_kernel(unsigned long long seed, unsigned long long offset,
                                                            const unsigned long long* __restrict__ philox_state,
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void philox_noise_kernel(unsigned long long se
   const long long total = nq > npos ? nq : npos;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     uint32_t r[4];
-    if (u_out && i < npos) { philox4x32(seed, offset + (unsigned long long)i, 0u, r); u_out[i] = u01_open_right(r[0]); }
+    if (u_out && i < npos) { philox4x32(seed, offset + (unsigned long long)i * (unsigned long long)K, 0u, r); u_out[i] = u01_open_right(r[0]); }
     if (i < nq) { philox4x32(seed, offset + (unsigned long long)i, 1u, r); q_out[i] = -logf(u01_open_left(r[0])); }
   }
 }
@@ -340,21 +340,21 @@ extern "C" long long spk_select_needed_bytes(int B, int R) {
 extern "C" int spk_select_needed(const uint8_t* unmasked, int t, const float* u_or_null, unsigned long long philox_seed,
                                  unsigned long long philox_offset, const unsigned long long* philox_state_or_null,
                                  const int* active, const int* n_active, uint8_t* need_out, int B, int H, int W, int R,
-                                 hipStream_t stream) {
-  if (!unmasked || !active || !n_active || !need_out || t <= 0 || B <= 0 || R <= 0 || R > 8) return SPK_ERR_ARG;
+                                 int K, hipStream_t stream) {
+  if (!unmasked || !active || !n_active || !need_out || t <= 0 || B <= 0 || R <= 0 || R > 8 || K <= 0) return SPK_ERR_ARG;
   if (H != 7 || W != 7) return SPK_ERR_UNSUPPORTED;        // the record format lists positions 0..47 of a 49-position latent
   hipLaunchKernelGGL(select_needed_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, unmasked, t, u_or_null, philox_seed,
-                     philox_offset, philox_state_or_null, active, n_active, need_out, B, H, W, R);
+                     philox_offset, philox_state_or_null, active, n_active, need_out, B, H, W, R, K);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }
 
 extern "C" int spk_select_active(const uint8_t* unmasked, int t, const float* u_or_null, unsigned long long philox_seed,
                                  unsigned long long philox_offset, const unsigned long long* philox_state_or_null,
-                                 int* active_out, int* n_active_out, int B, int HW, hipStream_t stream) {
-  if (!unmasked || !active_out || !n_active_out || t <= 0 || B <= 0 || HW <= 0) return SPK_ERR_ARG;
+                                 int* active_out, int* n_active_out, int B, int HW, int K, hipStream_t stream) {
+  if (!unmasked || !active_out || !n_active_out || t <= 0 || B <= 0 || HW <= 0 || K <= 0) return SPK_ERR_ARG;
   hipLaunchKernelGGL(select_active_kernel, dim3((B * 8 + 63) / 64), dim3(64), 0, stream, unmasked, t, u_or_null, philox_seed,
-                     philox_offset, philox_state_or_null, active_out, n_active_out, B, HW);
+                     philox_offset, philox_state_or_null, active_out, n_active_out, B, HW, K);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

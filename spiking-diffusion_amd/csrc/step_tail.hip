@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512, 1) void step_tail_kernel(TailArgs a) {
     const long long tk = a.x_t[pi];
     float u;
     if (a.u_in) u = a.u_in[pi];
-    else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)pi, 0u, r); u = u01_open_right(r[0]); }
+    else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)pi * (unsigned long long)TK, 0u, r); u = u01_open_right(r[0]); }
     s_chg[tid] = ((u < inv_t) && !um) ? 1 : 0;
     s_tok[tid] = (float)tk;
   }
@@ -299,6 +299,9 @@ extern "C" int spk_den_step_tail(const uint8_t* cnt5, int nch5, const uint8_t* c
   if ((x1_s32_out_or_null == nullptr) != (cnt1_out_or_null == nullptr)) return SPK_ERR_ARG;
   if (x1_s32_out_or_null && (!conv1_w_packed_or_null || !bn1_a || !bn1_b)) return SPK_ERR_ARG;
   if (nch5 != 8 || nch1 != 2 || K != TK || T > 127 || !((H == 7 && W == 7) || (H == 8 && W == 8))) return SPK_ERR_UNSUPPORTED;
+  // the fused first layer writes sixteen 16-byte step records per position and scans with the module-default LIF constants
+  // (spk_lif_const_input_bits16): any other step count would write outside x1_s32_out (T < 16) or give wrong spikes (T > 16)
+  if (x1_s32_out_or_null && T != 16) return SPK_ERR_UNSUPPORTED;
   TailArgs a;
   a.c5 = cnt5; a.c1 = cnt1; a.wq = wq; a.scale = scale; a.bias = bias_d; a.logits_out = logits_out_or_null;
   a.x_t = x_t_inout; a.unmasked = unmasked_inout; a.t = t; a.temp = temp; a.u_in = u_or_null; a.q_in = q_or_null;

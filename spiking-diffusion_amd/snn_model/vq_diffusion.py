@@ -73,9 +73,20 @@ class AbsorbingDiffusion(Sampler):
         self.noise_source = 'philox'
         # Philox contract ('philox' mode): every sample() call takes ONE 62-bit draw from torch's global CPU generator as
         # its key, so ``torch.manual_seed(s); sample(); sample()`` gives two different batches and re-seeding repeats
-        # them -- the reference's behaviour -- and two samplers in one process never share a stream.  ``philox_stream``
-        # (default: the RANK of the process) is folded into the key, so ranks seeded alike still draw distinct noise.
+        # them -- the reference's behaviour -- and two samplers in one process never share a stream.
+        # ``noise_layout`` says how the counters are laid out (csrc/psample_common.h; include/spkdiff.h, spk_psample_step):
+        #   'global' (default): counter = step * 2^40 + (GLOBAL image index * h*w + position) * K + class.  The draws of
+        #       image i at step s depend on (key, s, i, position, class) only -- not on the batch size, not on how the batch
+        #       is split over processes: an 8-GPU job, a 1-GPU job and the oracle on the dumped noise give the same tokens for
+        #       the same images (SURVEY.md §8e "parity mode => result independent of G"; the reference draws one batch from
+        #       one stream, R/snn_model/vq_diffusion.py:103-142).  A shard sets ``global_first`` (index of its first image,
+        #       see ``set_shard``); ranks must use the SAME key: seed them alike, or let ``sync_key`` broadcast rank 0's draw.
+        #   'rank': the rounds 1-3 form -- local image index, step stride b*h*w*K, the RANK folded into the key
+        #       (``philox_stream``): ranks seeded alike draw distinct noise, but the sample depends on the split.
         import os
+        self.noise_layout = 'global'
+        self.global_first = 0
+        self.sync_key = True                 # 'global' layout inside an initialised process group: broadcast the key from rank 0
         self.philox_stream = int(os.environ.get('RANK', '0'))
         # Replay the whole reverse process as ONE hipGraph (philox mode, no hooks): the ~800 kernel launches of a
         # 100-step sample are captured once per (batch, steps, temp) and replayed; fresh noise per replay comes from a
@@ -195,7 +206,7 @@ class AbsorbingDiffusion(Sampler):
                 u, q = noise(t)
             elif self.noise_source == 'host':
                 u = torch.rand(b, 1, h, w).to(dev)                       # rand_like(x_t.float()), drawn first (:116)
-            off = base + (sample_steps - t) * (b * h * w * K)
+            off = base + self._step_offset(sample_steps - t, b, h, w, K)
             if tail:
                 if noise is None and self.noise_source == 'host':
                     q = torch.empty(b * h * w, K).exponential_(1).to(dev)    # (the denoiser call draws nothing: same order)
@@ -205,9 +216,9 @@ class AbsorbingDiffusion(Sampler):
                     record.append((t, x_t.clone(), unmasked.clone(), logits))
                 continue
             if skip:
-                act = ops.select_active(unmasked, t, u, seed, off, out=act)
+                act = ops.select_active(unmasked, t, u, seed, off, out=act, K=K)
                 if need is not None:
-                    ops.select_needed(unmasked, t, act, need, u, seed, off)
+                    ops.select_needed(unmasked, t, act, need, u, seed, off, K=K)
             with ops.active_set(*(act if skip else (None, None)), need=need):
                 logits = dn.logits_from_tokens(x_t, t)                   # denoiser + reset_net (:128-129)
                 if noise is None and self.noise_source == 'host':
@@ -223,8 +234,36 @@ class AbsorbingDiffusion(Sampler):
     def _list_ok(self, h, w):
         return bool(self.list_positions) and (h, w) == (7, 7)
 
+    STEP_STRIDE = 1 << 40        # 'global' layout: counters of one reverse step (images * h*w * K of them must fit)
+
+    def set_shard(self, first: int, count: int = None):
+        """This sampler generates images [first, first + count) of a larger job ('global' noise layout): the draws of an
+        image are those the whole job would make for it.  ``count`` (optional) also sets ``n_samples``."""
+        self.global_first = int(first)
+        if count is not None:
+            self.n_samples = int(count)
+        return self
+
+    def _step_offset(self, step_index, b, h, w, K):
+        """Philox counter offset of reverse step number ``step_index`` (0 = the first step taken) for this sampler's shard."""
+        if self.noise_layout == 'global':
+            if (int(self.global_first) + b) * h * w * K > self.STEP_STRIDE:
+                raise ValueError('spkdiff: global noise layout holds 2^40 counters per reverse step')
+            return step_index * self.STEP_STRIDE + int(self.global_first) * h * w * K
+        if self.noise_layout != 'rank':
+            raise ValueError("noise_layout must be 'global' or 'rank'")
+        return step_index * (b * h * w * K)
+
     def _philox_key(self):
         draw = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64))
+        if self.noise_layout == 'global':
+            import torch.distributed as dist
+            if self.sync_key and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dev = next(self._denoise_fn.parameters()).device if dist.get_backend() == 'nccl' else 'cpu'
+                k = torch.tensor([draw], dtype=torch.int64, device=dev)
+                dist.broadcast(k, 0)
+                draw = int(k.item())
+            return draw & 0x7FFFFFFFFFFFFFFF
         return (draw ^ ((int(self.philox_stream) * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF)) & 0x7FFFFFFFFFFFFFFF
 
     def invalidate(self):
@@ -263,7 +302,7 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
     skip = self._skip_ok(h, w)
     lists = skip and self._list_ok(h, w)
     key = (str(dev), b, h, w, K, temp, sample_steps, int(self.mask_id), skip, lists, int(self.list_radii),
-           bool(dn.use_step_tail), _weights_key(dn))
+           bool(dn.use_step_tail), self.noise_layout, int(self.global_first), _weights_key(dn))
     entry = self._graphs.get(key)
     if entry is None:
         if len(self._graphs) >= 2:                              # at most two live graphs per sampler (e.g. dense and
@@ -285,15 +324,15 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
             unmasked.zero_()
             pre1 = None
             for t in reversed(range(1, sample_steps + 1)):
-                off = (sample_steps - t) * (b * h * w * K)
+                off = self._step_offset(sample_steps - t, b, h, w, K)
                 if tail:
                     pre1, _ = dn.sample_step(x_t, unmasked, t, temp, None, None, 0, off, philox_state=state, pre1=pre1,
                                              want_next=t > 1)
                     continue
                 if skip:
-                    ops.select_active(unmasked, t, None, 0, off, philox_state=state, out=act)
+                    ops.select_active(unmasked, t, None, 0, off, philox_state=state, out=act, K=K)
                     if lists:
-                        ops.select_needed(unmasked, t, act, need, None, 0, off, philox_state=state)
+                        ops.select_needed(unmasked, t, act, need, None, 0, off, philox_state=state, K=K)
                 elif t == sample_steps:
                     ops.den_build_input(x_t, t, out=inp)
                 with ops.active_set(*(act if skip else (None, None)), need=need):

@@ -93,7 +93,7 @@ _SIGS = {
     "spk_vq_readout_argmin": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_vq_argmin": (c_int, [P, P, P, c_longlong, c_int, c_int, P]),
     "spk_embedding_fwd": (c_int, [P, P, P, c_longlong, c_int, c_int, c_int, c_int, P]),
-    "spk_select_active": (c_int, [P, c_int, P, c_ulonglong, c_ulonglong, P, P, P, c_int, c_int, P]),
+    "spk_select_active": (c_int, [P, c_int, P, c_ulonglong, c_ulonglong, P, P, P, c_int, c_int, c_int, P]),
     "spk_readout_collapsed_fwd": (c_int, [P, P, P, c_float, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                           P]),
     "spk_conv_mfma_fused_lif_s32": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -104,7 +104,7 @@ _SIGS = {
     "spk_ptc_to_s32": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spk_vae_fp6_fwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_select_needed_bytes": (c_longlong, [c_int, c_int]),
-    "spk_select_needed": (c_int, [P, c_int, P, c_ulonglong, c_ulonglong, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "spk_select_needed": (c_int, [P, c_int, P, c_ulonglong, c_ulonglong, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_den_conv3x3_mfma_fp6v2_listed": (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P,
                                                   P, c_int, c_int, P]),
     "spk_den_build_input": (c_int, [P, P, P, c_longlong, P, c_int, c_int, P, P, P]),

@@ -65,3 +65,34 @@ def sample_images_sharded(generate_local, total: int):
     rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
     lo, hi = shard_range(total, rank, world)
     return gather_images(generate_local(lo, hi), total)
+
+
+def _mix64(x: torch.Tensor) -> torch.Tensor:
+    """splitmix64 finaliser on int64 tensors (two's-complement wrap-around arithmetic)."""
+    x = (x ^ ((x >> 30) & 0x3FFFFFFFF)) * -4658895280553007687        # 0xBF58476D1CE4E5B9
+    x = (x ^ ((x >> 27) & 0x1FFFFFFFFF)) * -7723592293110705685       # 0x94D049BB133111EB
+    return x ^ ((x >> 31) & 0x1FFFFFFFF)
+
+
+def token_checksum(tokens: torch.Tensor, first: int = 0) -> int:
+    """Checksum of the tokens of images [first, first + n) of a job, as a sum over images of a hash of (GLOBAL image index,
+    tokens): the partial sums of any split of the job add up (mod 2^64) to the same number, so an N-rank run, a 1-rank run
+    and the oracle can be compared by one integer.  ``tokens``: integer tensor [n, ...] on any device."""
+    t = tokens.reshape(tokens.shape[0], -1).to(torch.int64)
+    n, m = t.shape
+    w = _mix64(torch.arange(1, m + 1, dtype=torch.int64, device=t.device)) | 1
+    row = ((t + 1) * w).sum(1)
+    idx = torch.arange(first, first + n, dtype=torch.int64, device=t.device)
+    return int(_mix64(row ^ _mix64(idx + 0x1234567)).sum().item())
+
+
+def global_token_checksum(tokens_local: torch.Tensor, first: int) -> int:
+    """``token_checksum`` of the whole job: every rank contributes the partial sum of its shard (one int64 all-reduce, outside
+    any timed region).  Reported as a non-negative 63-bit integer."""
+    part = token_checksum(tokens_local, first)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dev = tokens_local.device if dist.get_backend() == "nccl" else "cpu"
+        v = torch.tensor([part], dtype=torch.int64, device=dev)
+        dist.all_reduce(v)          # int64 sums wrap: the sum mod 2^64 does not depend on the split
+        part = int(v.item())
+    return part & 0x7FFFFFFFFFFFFFFF

@@ -811,7 +811,11 @@ DGRAD_FORM = "f16x2"
 def conv3x3_dgrad(gy_cl, weight, Cin, form=None):
     """gi [N,Cin,H,W] (channels-last memory) of a 3x3 / s1 / p1 convolution from gy [N,Cout,H,W] (channels-last fp32; 7x7 or
     8x8 maps) and the weight [Cout,Cin,3,3]: spk_conv3x3_dgrad_f16x2 (two scaled fp16 terms per operand, three products) or
-    spk_conv3x3_dgrad_bf16 (three exact bf16 terms, six products); fp32 accuracy either way."""
+    spk_conv3x3_dgrad_bf16 (three exact bf16 terms, six products).  Both measure 2-4e-7 relative L2 against fp64 on the training
+    shapes (an fp32 operator: 2-6e-7).  Per ELEMENT they differ: the bf16 form splits every value exactly, whatever its
+    magnitude; the fp16 form scales each image's gy / each input channel's weights by one power of two and keeps fp32-like
+    relative precision only within ~17 binades of that set's maximum (below: an absolute 2^-40 of the maximum) -- choose
+    ``form='bf16x3'`` where a gradient map's magnitudes span more than that inside one image."""
     N, Cout, H, W = int(gy_cl.shape[0]), int(gy_cl.shape[1]), int(gy_cl.shape[2]), int(gy_cl.shape[3])
     nb = int(lib.spk_conv3x3_dgrad_ws_bytes(Cout, int(Cin)))
     if nb <= 0:
@@ -979,7 +983,10 @@ def den_pack_weight_fp6v2(w, bias):
 # owner -- a captured graph keeps its scope dict in its cache entry, so the buffers its launches address live as long as the
 # graph and no eager call ever touches them.  Nothing here is ever dropped while a graph may address it.
 _FLAG_DEFAULT = {}
-_FLAG_SCOPE = None
+# (thread-local: the sampler captures with capture_error_mode='thread_local' precisely so that OTHER threads may use the device
+#  meanwhile -- their certified-kernel calls must keep their own per-stream workspaces, never the capturing thread's scope)
+import threading as _threading
+_FLAG_TLS = _threading.local()
 
 
 class flag_scope:
@@ -990,18 +997,17 @@ class flag_scope:
         self.store = store
 
     def __enter__(self):
-        global _FLAG_SCOPE
-        self.prev, _FLAG_SCOPE = _FLAG_SCOPE, self.store
+        self.prev = getattr(_FLAG_TLS, "store", None)
+        _FLAG_TLS.store = self.store
         return self.store
 
     def __exit__(self, *exc):
-        global _FLAG_SCOPE
-        _FLAG_SCOPE = self.prev
+        _FLAG_TLS.store = self.prev
         return False
 
 
 def _flag_ws(kind, device, words):
-    store = _FLAG_SCOPE
+    store = getattr(_FLAG_TLS, "store", None)
     if store is None:
         key = (kind, str(device), int(torch.cuda.current_stream(device).cuda_stream), int(words))
         buf = _FLAG_DEFAULT.get(key)
@@ -1404,6 +1410,9 @@ def den_step_tail(cnt5, cnt1, packed6, x_t, unmasked, t, temp, *, T, K, u=None, 
             raise ValueError("q must have B*HW*K entries")
     logits = torch.empty((B, K, H, W), dtype=torch.float32, device=cnt5.device) if want_logits else None
     x1 = c1o = w1 = b1 = a1 = bb1 = None
+    if conv1 is not None and int(T) != 16:
+        raise NotImplementedError("spk_den_step_tail: the fused first layer is the T = 16, LIFNode(tau=2, v_threshold=1, "
+                                  "v_reset=0) form; run conv1 as its own launch for other step counts")
     if conv1 is not None:
         w1, b1, a1, bb1 = conv1
         x1 = torch.empty((B, 2, H, W, T, 16), dtype=C4_DTYPE, device=cnt5.device)
@@ -1486,9 +1495,10 @@ class NeedLists:
         return self.buf[off:off + B * 64].view(B, 64)
 
 
-def select_needed(unmasked, t, active, need, u=None, seed=0, offset=0, philox_state=None):
+def select_needed(unmasked, t, active, need, u=None, seed=0, offset=0, philox_state=None, K=128):
     """Positions each active image needs from the layers below the logits at reverse step t (spk_select_needed); ``active``
-    = the pair returned by select_active for the same step, ``need`` a NeedLists for the same batch.  7x7 latents."""
+    = the pair returned by select_active for the same step, ``need`` a NeedLists for the same batch.  7x7 latents.  ``K``:
+    the class count of the step's psample_step call (the stride of the Philox counter layout; unused with injected u)."""
     B = unmasked.shape[0]
     H, W = int(unmasked.shape[-2]), int(unmasked.shape[-1])
     if need.batch != B:
@@ -1496,13 +1506,14 @@ def select_needed(unmasked, t, active, need, u=None, seed=0, offset=0, philox_st
     if u is not None:
         u = _dev(u, "u", torch.float32)
     check(lib.spk_select_needed(_p(unmasked), int(t), _p(u), int(seed), int(offset), _p(philox_state), _p(active[0]),
-                                _p(active[1]), _p(need.buf), B, H, W, need.radii, _stream(unmasked)), "spk_select_needed")
+                                _p(active[1]), _p(need.buf), B, H, W, need.radii, int(K), _stream(unmasked)), "spk_select_needed")
     return need
 
 
-def select_active(unmasked, t, u=None, seed=0, offset=0, philox_state=None, out=None):
+def select_active(unmasked, t, u=None, seed=0, offset=0, philox_state=None, out=None, K=128):
     """Images that reverse step t touches (at least one position with u < 1/t still masked): returns (active int32 [B]
-    ascending image list, n_active int32 [2]: count and a work word) on the device; same u / Philox arguments as psample_step."""
+    ascending image list, n_active int32 [2]: count and a work word) on the device; same u / Philox arguments as psample_step
+    (``K``: that call's class count, the stride of the Philox counter layout; unused with injected u)."""
     if unmasked.dtype not in (torch.bool, torch.uint8) or not unmasked.is_cuda or not unmasked.is_contiguous():
         raise ValueError("unmasked must be a contiguous bool/uint8 device tensor")
     B = unmasked.shape[0]
@@ -1515,5 +1526,5 @@ def select_active(unmasked, t, u=None, seed=0, offset=0, philox_state=None, out=
     elif out[1].numel() < 2:
         raise ValueError("n_active needs two int32 words: [count, work word (zero before the first call)]")
     check(lib.spk_select_active(_p(unmasked), int(t), _p(u), int(seed), int(offset), _p(philox_state), _p(out[0]),
-                                _p(out[1]), B, HW, _stream(unmasked)), "spk_select_active")
+                                _p(out[1]), B, HW, int(K), _stream(unmasked)), "spk_select_active")
     return out

@@ -185,6 +185,57 @@ def synth_denoiser_state(cfg: PathConfig = MNIST, seed: int = 4321, calib_batch:
     return {k: v.contiguous() for k, v in sd.items()}
 
 
+def stroke_images(n: int, seed: int = 2024, img: int = 28, channels: int = 1) -> torch.Tensor:
+    """``n`` procedurally generated digit-like images [n, channels, img, img] in [0, 1] (the value range of the reference's
+    ``ToTensor`` loaders, R/load_dataset_snn.py): two to four pen strokes -- straight segments and quadratic arcs through random
+    control points -- drawn with a soft-edged pen of random width on a black ground.  There is no network and no data set on
+    the build machines: these stand in for MNIST when the models are TRAINED (tools/train_on_strokes.py; the trained weights
+    under checkpoints/ and the ``*_trained`` fixtures come from them).  Deterministic in (n, seed, img): CPU generator, fp32."""
+    g = _gen(seed, f"strokes.{img}")
+    S, P = 4, 12                                              # strokes per image (some switched off), points per stroke
+    ctr = torch.rand(n, S, 3, 2, generator=g) * (img * 0.64) + img * 0.18          # three control points per stroke
+    on = torch.rand(n, S, generator=g) < torch.tensor([1.0, 1.0, 0.6, 0.3])
+    width = 0.7 + 1.1 * torch.rand(n, 1, 1, generator=g)
+    gain = 0.75 + 0.25 * torch.rand(n, 1, 1, generator=g)
+    straight = (torch.rand(n, S, 1, 1, generator=g) < 0.4).float()
+    tt = torch.linspace(0, 1, P).view(1, 1, P, 1)
+    a, b, c = ctr[:, :, 0:1], ctr[:, :, 1:2], ctr[:, :, 2:3]
+    bez = (1 - tt) ** 2 * a + 2 * (1 - tt) * tt * b + tt ** 2 * c
+    lin = (1 - tt) * a + tt * c
+    pts = straight * lin + (1 - straight) * bez               # [n, S, P, 2] polyline vertices
+    p0, p1 = pts[:, :, :-1], pts[:, :, 1:]                    # [n, S, P-1, 2] segments
+    yy, xx = torch.meshgrid(torch.arange(img, dtype=torch.float32), torch.arange(img, dtype=torch.float32), indexing="ij")
+    px = torch.stack((xx, yy), -1).view(1, 1, 1, img * img, 2) + 0.5
+    d = (p1 - p0).unsqueeze(3)
+    rel = px - p0.unsqueeze(3)
+    u = ((rel * d).sum(-1) / (d * d).sum(-1).clamp_min(1e-6)).clamp(0, 1)
+    dist = (rel - u.unsqueeze(-1) * d).norm(dim=-1)           # [n, S, P-1, img*img]
+    dist = dist.masked_fill(~on.view(n, S, 1, 1), 1e9).amin(dim=(1, 2))
+    out = ((width.view(n, 1) + 0.8 - dist) / 1.2).clamp(0, 1) * gain.view(n, 1)
+    out = out.view(n, 1, img, img)
+    if channels > 1:
+        tint = 0.5 + 0.5 * torch.rand(n, channels, 1, 1, generator=g)
+        out = out * tint
+    return out.contiguous()
+
+
+CHECKPOINT_DIR = None     # default: <package root>/checkpoints
+
+
+def trained_state(kind: str, name: str = "mnist_strokes") -> dict:
+    """The TRAINED checkpoint committed under ``checkpoints/`` (kind 'vqvae' / 'denoiser'): weights obtained by running the
+    reference's two training loops (R/main.py:118-146,202-252) with this build's training path on ``stroke_images`` from the
+    synthetic initialisation (tools/train_on_strokes.py has the recipe and the log).  Same keys as the reference's
+    ``model.pth`` / ``diff_model.pth`` (R/main.py:199,286); fp32, bit for bit what the ``*_trained`` fixtures were generated
+    from with the real reference (oracle/gen_golden.py)."""
+    import os
+    import numpy as np
+    root = CHECKPOINT_DIR or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "checkpoints")
+    path = os.path.join(root, f"{name}_{kind}.npz")
+    with np.load(path) as z:
+        return {k: torch.from_numpy(z[k].copy()) for k in z.files}
+
+
 def cached_state(kind: str, cfg: PathConfig = MNIST, **kw) -> dict:
     """``synth_vqvae_state`` / ``synth_denoiser_state`` (kind 'vqvae' / 'denoiser') through a file cache: the calibration pass
     runs ONCE per node -- the first process to claim the lock generates and publishes (atomic rename), the others wait for
@@ -199,7 +250,11 @@ def cached_state(kind: str, cfg: PathConfig = MNIST, **kw) -> dict:
         ver = zlib.crc32(f.read())
     key = hashlib.sha256(repr((kind, cfg, sorted(kw.items()), ver, torch.__version__)).encode()).hexdigest()[:20]
     root = os.environ.get("SPKDIFF_SYNTH_CACHE") or os.path.join(tempfile.gettempdir(), f"spkdiff_synth_{os.getuid()}")
-    os.makedirs(root, exist_ok=True)
+    os.makedirs(root, mode=0o700, exist_ok=True)
+    st = os.stat(root)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+        # a directory somebody else owns or may write to (the default path is predictable): do not trust files found there
+        return fn(cfg, **kw)
     path, lock = os.path.join(root, key + ".pt"), os.path.join(root, key + ".lock")
 
     def load():
@@ -210,19 +265,46 @@ def cached_state(kind: str, cfg: PathConfig = MNIST, **kw) -> dict:
     sd = load() if os.path.exists(path) else None
     if sd is not None:
         return sd
-    try:
-        fd = os.open(lock, os.O_CREAT | os.O_EXCL | os.O_WRONLY)
-        os.close(fd)
-        mine = True
-    except FileExistsError:
-        mine = False
+    def lock_is_stale():
+        # the lock holds its owner's pid: stale when that process is gone, or when the file is older than any generation takes
+        try:
+            with open(lock) as f:
+                pid = int(f.read().strip() or 0)
+            if pid > 0:
+                try:
+                    os.kill(pid, 0)
+                except ProcessLookupError:
+                    return True
+                except PermissionError:
+                    pass
+            return time.time() - os.stat(lock).st_mtime > 300.0
+        except (OSError, ValueError):
+            return False
+
+    def claim():
+        try:
+            fd = os.open(lock, os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o600)
+            os.write(fd, str(os.getpid()).encode())
+            os.close(fd)
+            return True
+        except FileExistsError:
+            return False
+    mine = claim()
     if not mine:
         t0 = time.time()
-        while time.time() - t0 < 600.0:                  # (a crashed generator leaves a stale lock: give up and generate)
+        while time.time() - t0 < 600.0:
             if os.path.exists(path):
                 sd = load()
                 if sd is not None:
                     return sd
+            if lock_is_stale():                          # (a killed generator left its lock behind: take over at once)
+                try:
+                    os.unlink(lock)
+                except OSError:
+                    pass
+                mine = claim()
+                if mine:
+                    break
             time.sleep(0.2)
     sd = fn(cfg, **kw)
     tmp = f"{path}.{os.getpid()}.tmp"

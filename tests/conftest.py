@@ -20,6 +20,17 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of host-side oracle work; skipped unless SPKDIFF_RUN_SLOW=1 "
+                                       "(run once per round through gpurun, log kept under profiles/)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("SPKDIFF_RUN_SLOW") == "1":
+        return
+    skip = pytest.mark.skip(reason="slow: set SPKDIFF_RUN_SLOW=1 (tools/full_size_oracle.sh)")
+    for it in items:
+        if "slow" in it.keywords:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

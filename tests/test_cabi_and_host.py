@@ -108,7 +108,7 @@ def test_workspace_sizes_and_shape_support_are_host_side():
     assert lib.spk_vae_fp6_packed_bytes(32, 128) == -1 and lib.spk_vae_fp6_packed_bytes(48, 64) == -1
     # null pointers are argument errors before any launch
     assert lib.spk_vae_fp6_fwd(None, None, None, None, None, None, None, None, None, 0, None, 16, 1, 14, 14, 64, 32, 1, None) == -1
-    assert lib.spk_select_needed(None, 1, None, 0, 0, None, None, None, None, 1, 7, 7, 3, None) == -1
+    assert lib.spk_select_needed(None, 1, None, 0, 0, None, None, None, None, 1, 7, 7, 3, 128, None) == -1
     assert lib.spk_readout_collapsed_fwd(None, None, None, 1.0, None, None, 0, 1, 28, 28, 32, 1, 3, 1, 1, None) == -1
     kind = ops.vae_fp6_kind
     assert kind(64, 32, 3, 2, 1, 1, True, 16, 14, 14) == ops.VAE_OUT_COLLAPSED        # decoder convT2
@@ -257,3 +257,51 @@ def test_header_is_plain_c(tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
 
+
+
+def test_synth_cache_takes_over_a_stale_lock(tmp_path, monkeypatch):
+    """a generator killed in mid-run left its .lock behind and every later process (all eight bench ranks) waited
+    the full timeout.  The lock now holds its owner's pid: a dead owner is taken over at once."""
+    import hashlib, time, zlib
+    from spkdiff import synth
+    monkeypatch.setenv("SPKDIFF_SYNTH_CACHE", str(tmp_path / "cache"))
+    os.makedirs(tmp_path / "cache", mode=0o700)
+    with open(synth.__file__, "rb") as f:
+        ver = zlib.crc32(f.read())
+    import torch
+    key = hashlib.sha256(repr(("vqvae", synth.MNIST, [], ver, torch.__version__)).encode()).hexdigest()[:20]
+    with open(tmp_path / "cache" / (key + ".lock"), "w") as f:
+        f.write("999999999")                      # no such process
+    t0 = time.time()
+    sd = synth.cached_state("vqvae")
+    assert time.time() - t0 < 60 and "encoder.snn_convs.0.weight" in sd
+    assert not os.path.exists(tmp_path / "cache" / (key + ".lock")) and os.path.exists(tmp_path / "cache" / (key + ".pt"))
+    # a cache directory that others may write to is not trusted (nothing is read from or written to it)
+    os.chmod(tmp_path / "cache", 0o777)
+    os.unlink(tmp_path / "cache" / (key + ".pt"))
+    sd2 = synth.cached_state("vqvae")
+    assert not os.path.exists(tmp_path / "cache" / (key + ".pt"))
+    assert synth.state_checksum(sd) == synth.state_checksum(sd2)
+
+
+def test_flag_scope_is_thread_local():
+    """a flag_scope opened by the capturing thread must not be seen by other threads' certified-kernel calls."""
+    import threading
+    from spkdiff import ops
+    seen = []
+    store = {}
+    with ops.flag_scope(store):
+        assert getattr(ops._FLAG_TLS, "store", None) is store
+        th = threading.Thread(target=lambda: seen.append(getattr(ops._FLAG_TLS, "store", None)))
+        th.start(); th.join()
+    assert seen == [None] and getattr(ops._FLAG_TLS, "store", None) is None
+
+
+def test_stroke_images_are_deterministic_and_image_like():
+    import torch
+    from spkdiff import synth
+    a, b = synth.stroke_images(48, seed=7), synth.stroke_images(48, seed=7)
+    assert torch.equal(a, b) and a.shape == (48, 1, 28, 28) and a.dtype == torch.float32
+    assert 0.0 <= float(a.min()) and float(a.max()) <= 1.0 and 0.03 < float(a.mean()) < 0.3
+    assert not torch.equal(a, synth.stroke_images(48, seed=8))
+    assert synth.stroke_images(4, seed=7, img=32, channels=3).shape == (4, 3, 32, 32)

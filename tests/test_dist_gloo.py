@@ -45,6 +45,29 @@ def _worker(rank, world, port, total, q):
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ok = ok and float(t) == float(world)
+    # 'global' noise layout (host logic; the draws themselves need a device): differently seeded ranks end up with rank 0's
+    # key (sync_key), every rank's counter offsets are those of its images in the whole job, and the per-shard token checksums
+    # add up to the whole job's
+    from snn_model.vq_diffusion import AbsorbingDiffusion, DummyModel
+    ab = AbsorbingDiffusion(DummyModel(1, 128), mask_id=128)
+    ab.set_shard(lo, hi - lo)
+    torch.manual_seed(100 + rank)
+    key = ab._philox_key()
+    keys = [None] * world
+    dist.all_gather_object(keys, key)
+    torch.manual_seed(100)
+    ok = ok and len(set(keys)) == 1 and keys[0] == int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64))
+    ok = ok and ab._step_offset(3, hi - lo, 7, 7, 128) == 3 * (1 << 40) + lo * 49 * 128
+    ab.noise_layout = 'rank'
+    ok = ok and ab._step_offset(3, hi - lo, 7, 7, 128) == 3 * (hi - lo) * 49 * 128
+    torch.manual_seed(100)
+    k_rank = ab._philox_key()
+    allk = [None] * world
+    dist.all_gather_object(allk, k_rank)
+    ok = ok and len(set(allk)) == world                     # rank folded into the key: distinct streams
+    toks = torch.randint(0, 128, (total, 1, 7, 7), generator=torch.Generator().manual_seed(9))
+    whole = sdist.token_checksum(toks, 0) & 0x7FFFFFFFFFFFFFFF
+    ok = ok and sdist.global_token_checksum(toks[lo:hi], lo) == whole
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, bool(ok)))

@@ -1287,7 +1287,15 @@ def test_full_sample_properties_b256(dev):
     ab2.n_samples, ab2.philox_stream = 256, 1
     torch.manual_seed(1)
     tok5 = ab2.sample(temp=1.0, sample_steps=6)
-    assert not torch.equal(tok, tok5), "another rank (philox_stream) seeded alike draws different noise"
+    assert torch.equal(tok, tok5), "'global' layout: the same images of the same job, whichever rank generates them"
+    ab2.set_shard(256, 256)
+    torch.manual_seed(1)
+    assert not torch.equal(tok, ab2.sample(temp=1.0, sample_steps=6)), "the NEXT 256 images of the job are other images"
+    ab2.set_shard(0, 256)
+    ab2.noise_layout = 'rank'
+    torch.manual_seed(1)
+    tok6 = ab2.sample(temp=1.0, sample_steps=6)
+    assert not torch.equal(tok, tok6), "'rank' layout: another rank (philox_stream) seeded alike draws different noise"
     pred, u8 = model.decode_tokens(tok.reshape(256, 7, 7))
     assert pred.shape == (256, 1, 28, 28) and u8.dtype == torch.uint8
     assert float(pred.abs().max()) <= 1.0
@@ -1896,13 +1904,16 @@ def test_two_live_sampler_graphs_on_one_model_replay_independently(dev):
 
 
 # ------------------------------------------------------------------------------------------------- round 3: the timed configuration
-def _philox_oracle_tokens(ops, dev, sd, key, B, steps, latent, temp=1.0, K=128):
+def _philox_oracle_tokens(ops, dev, sd, key, B, steps, latent, temp=1.0, K=128, offset_of=None):
     """Run the CPU oracle on the noise the Philox-mode sampler drew: spk_philox_noise dumps (u, q) per reverse step with the
-    (seed, offset) arguments the captured launches use (offset = (steps - t) * B*h*w*K, R/snn_model/vq_diffusion.py:116,134-138)."""
+    (seed, offset) arguments the captured launches use (``offset_of(step index)`` = AbsorbingDiffusion._step_offset: the
+    'global' layout's step * 2^40 + first image * h*w*K by default; R/snn_model/vq_diffusion.py:116,134-138)."""
     HW = latent * latent
+    if offset_of is None:
+        offset_of = lambda i: i * (1 << 40)
 
     def noise(t):
-        u, q = ops.philox_noise(key, (steps - t) * (B * HW * K), B, HW, K, dev)
+        u, q = ops.philox_noise(key, offset_of(steps - t), B, HW, K, dev)
         return u.cpu().view(B, 1, latent, latent), q.cpu()
     return ref.absorbing_sample(sd, B, K, temp, steps, latent, 16, noise=noise)
 
@@ -1941,6 +1952,44 @@ def test_timed_configuration_philox_graph_vs_oracle_on_dumped_noise(dev, ops, B,
     assert err <= 1e-4
 
 
+@pytest.mark.slow
+def test_bench_line_job_full_size_vs_oracle(dev, ops):
+    """The bench line's OWN job -- B = 256 x 100 reverse steps, Philox noise, one hipGraph replay, dense and elimination + lists --
+    against the CPU oracle on the dumped noise: all 12 544 tokens, then decode within 1e-4 (the other timed-form
+    tests stop at B = 8 x 100 and B = 256 x 10).  Minutes of host work: SPKDIFF_RUN_SLOW=1, once per round through gpurun
+    (tools/full_size_oracle.sh; log under profiles/)."""
+    import time
+    from snn_model.vq_diffusion import AbsorbingDiffusion
+    den, sd = build_den(synth.MNIST, dev)
+    model, sd_v = build_vae(synth.MNIST, dev)
+    B, steps = 256, 100
+    got, key = {}, None
+    for name, skip in (("dense", False), ("elim+lists", True)):
+        ab = AbsorbingDiffusion(den, mask_id=128)
+        ab.n_samples, ab.skip_untouched, ab.list_positions = B, skip, skip
+        torch.manual_seed(42)
+        key = ab._philox_key()
+        torch.manual_seed(42)
+        got[name] = ab.sample(temp=1.0, sample_steps=steps)
+        assert len(ab._graphs) == 1
+    t0 = time.time()
+    want = _philox_oracle_tokens(ops, dev, sd, key, B, steps, 7)
+    dt = time.time() - t0
+    bad = {n: int((t.cpu() != want).sum()) for n, t in got.items()}
+    pred, u8 = model.decode_tokens(got["dense"].reshape(B, 7, 7))
+    opred = ref.decode_tokens(want.reshape(B, 7, 7), sd_v, 16)
+    err = float((pred.cpu() - opred).abs().max())
+    ou8 = ref.to_uint8(opred)
+    px = int((u8.cpu().numpy() != ou8).sum())
+    print(f"FULL SIZE B={B} x {steps} steps (Philox + hipGraph): token mismatches vs oracle {bad} of {want.numel()}; "
+          f"decode max abs err {err:.2e}; uint8 pixels differing {px} of {ou8.size}; oracle took {dt:.0f} s on "
+          f"{torch.get_num_threads()} threads")
+    parity("bench_line_job_full_size_vs_oracle", token_mismatches=bad, tokens=int(want.numel()), pixel_max_abs_err=err,
+           uint8_pixels_differing=px, oracle_seconds=dt)
+    assert all(v == 0 for v in bad.values()), bad
+    assert err <= 1e-4
+
+
 def test_philox_noise_entry_matches_what_psample_consumes(dev, ops):
     """spk_philox_noise == the draws of spk_psample_step / spk_select_active: a step run on injected (dumped) noise equals the
     same step in Philox mode, including through the philox_state indirection the captured graph uses."""
@@ -1961,7 +2010,7 @@ def test_philox_noise_entry_matches_what_psample_consumes(dev, ops):
         xb, unb = x0.clone(), un0.clone()
         ops.psample_step(logits, xb, unb, t, 0.9, u, q)
         assert torch.equal(xa, xb) and torch.equal(una, unb)
-        a1 = ops.select_active(un0, t, None, 0, off, philox_state=state)
+        a1 = ops.select_active(un0, t, None, 0, off, philox_state=state, K=K)
         a2 = ops.select_active(un0, t, u)
         n1, n2 = int(a1[1][0]), int(a2[1][0])
         assert n1 == n2 and torch.equal(a1[0][:n1], a2[0][:n2])
@@ -2005,6 +2054,72 @@ def test_timed_configuration_8x8_philox_graph_vs_oracle_on_dumped_noise(dev, ops
     bad = {n: int((t != want).sum()) for n, t in got.items()}
     parity("timed_configuration_8x8_philox_graph", token_mismatches=bad, tokens=int(want.numel()))
     assert all(v == 0 for v in bad.values()), bad
+
+
+def test_sample_does_not_depend_on_how_the_batch_is_split(dev, ops):
+    """SURVEY.md §8e "parity mode => result independent of G" (the reference draws ONE batch from ONE stream,
+    R/snn_model/vq_diffusion.py:103-142).  'global' noise layout: B = 32 generated as 1 x 32, 2 x 16 and 4 x 8 "virtual ranks"
+    on one device (each a sampler with its own shard, graph-replayed, dense and elimination + lists) gives identical tokens and
+    uint8 images, and equals the CPU oracle on the dumped noise; the 'rank' layout (rounds 1-3) is NOT split-invariant."""
+    from snn_model.vq_diffusion import AbsorbingDiffusion
+    den, sd = build_den(synth.MNIST, dev)
+    model, _ = build_vae(synth.MNIST, dev)
+    B, steps, seed = 32, 30, 2024
+
+    def run(parts, skip, layout='global'):
+        toks = []
+        for r in range(parts):
+            ab = AbsorbingDiffusion(den, mask_id=128)
+            ab.noise_layout, ab.skip_untouched, ab.list_positions = layout, skip, skip
+            ab.philox_stream = r
+            ab.set_shard(r * (B // parts), B // parts)
+            torch.manual_seed(seed)                       # every rank seeded alike
+            toks.append(ab.sample(temp=1.0, sample_steps=steps))
+            assert len(ab._graphs) == 1
+        return torch.cat(toks, 0)
+    ab0 = AbsorbingDiffusion(den, mask_id=128)
+    torch.manual_seed(seed)
+    key = ab0._philox_key()
+    want = _philox_oracle_tokens(ops, dev, sd, key, B, steps, 7)
+    bad = {}
+    ref_u8 = None
+    for parts in (1, 2, 4):
+        for skip in (False, True):
+            tok = run(parts, skip)
+            bad[f"{parts}x{B // parts}{'_elim' if skip else ''}"] = int((tok.cpu() != want).sum())
+            _, u8 = model.decode_tokens(tok.reshape(B, 7, 7))
+            if ref_u8 is None:
+                ref_u8 = u8
+            assert torch.equal(u8, ref_u8)
+    parity("sample_independent_of_split", token_mismatches_vs_oracle=bad, tokens=int(want.numel()))
+    assert all(v == 0 for v in bad.values()), bad
+    # a shard in the middle of a larger job, and a larger job's prefix: same images
+    ab = AbsorbingDiffusion(den, mask_id=128)
+    ab.set_shard(8, 8)
+    torch.manual_seed(seed)
+    assert torch.equal(ab.sample(temp=1.0, sample_steps=steps).cpu(), want[8:16])
+    ab = AbsorbingDiffusion(den, mask_id=128)
+    ab.n_samples = 48
+    torch.manual_seed(seed)
+    assert torch.equal(ab.sample(temp=1.0, sample_steps=steps).cpu()[:B], want)
+    # the rank-folded layout of rounds 1-3 stays available -- and does depend on the split
+    assert not torch.equal(run(2, False, 'rank'), run(1, False, 'rank'))
+
+
+def test_rank_layout_timed_form_vs_oracle_on_dumped_noise(dev, ops):
+    """The rounds 1-3 noise layout ('rank': local image index, step stride b*h*w*K, rank folded into the key) still pins to the
+    oracle on its own dumped noise."""
+    from snn_model.vq_diffusion import AbsorbingDiffusion
+    den, sd = build_den(synth.MNIST, dev)
+    B, steps = 8, 25
+    ab = AbsorbingDiffusion(den, mask_id=128)
+    ab.noise_layout, ab.philox_stream, ab.n_samples = 'rank', 3, B
+    torch.manual_seed(5)
+    key = ab._philox_key()
+    torch.manual_seed(5)
+    tok = ab.sample(temp=1.0, sample_steps=steps).cpu()
+    want = _philox_oracle_tokens(ops, dev, sd, key, B, steps, 7, offset_of=lambda i: i * (B * 49 * 128))
+    assert int((tok != want).sum()) == 0
 
 
 def test_full_length_full_size_config3_and_config4_shapes(dev):
