@@ -9,7 +9,8 @@
  *
  * Contract (all functions):
  *   - plain C types only; every pointer is a DEVICE pointer owned by the caller (PyTorch); the library never
- *     allocates or frees device memory and keeps no mutable global state;
+ *     allocates or frees device memory, reads no environment variable and keeps no mutable global state of its own: the only
+ *     process-wide values are the measurement options below, which exist only because the HOST sets them (spk_set_option);
  *   - work is enqueued asynchronously on ``stream`` (a hipStream_t; pass torch.cuda.current_stream().cuda_stream);
  *   - returns 0 on success, SPK_ERR_* (< 0) for argument errors, a positive hipError_t for launch failures;
  *   - reentrant across streams and host threads.
@@ -46,6 +47,23 @@ typedef struct ihipStream_t* spk_stream_t; /* == hipStream_t */
 int spk_version(void);
 /* Returns a static string for an SPK_ERR_* / hipError_t code. */
 const char* spk_error_string(int code);
+
+/* Measurement options: launch-shape choices that were measured against each other (DESIGN.md quotes the numbers) and stay
+ * selectable so that the measurements can be repeated.  The library never reads the environment; a host that wants another
+ * form calls spk_set_option (process-wide, relaxed atomics; every launch reads the current value, so a host may switch between
+ * calls).  spkdiff/_lib.py forwards the SPKDIFF_<NAME> environment variables once at import for the A/B tools under tools/.
+ *   name               default  meaning
+ *   "v2_waves"            8     waves per workgroup of spk_den_conv3x3_mfma_fp6v2's main launch: 8 (two per SIMD), 4 (one), 12
+ *                               (three, accumulators in VGPRs: measured -11 %)
+ *   "v2_lag"              0     1: full 7x7 batches run the staggered form (waves 4..7 one chunk behind: measured 4-13 % slower)
+ *   "fp6_waves"           4     8: spk_den_conv3x3_mfma_fp6 with two waves per SIMD where an item has <= 4 row tiles per wave
+ *   "fp6_xcd_walk"        1     0: image-major item walk of spk_den_conv3x3_mfma_fp6 (2.2x the HBM-side traffic)
+ *   "conv6_shared"        1     0: spk_den_conv3x3_counts_mfma never shares operands through LDS
+ *   "conv6_shared_dyn"    1     0: ... not in the sampler's active-set calls
+ *   "mfma_debug"          0     ablation builds (-DSPK_MFMA_ABLATION) only: 1 no steady-state DMA, 2 no MFMAs, 4 no epilogue
+ * Returns SPK_ERR_UNSUPPORTED for an unknown name. */
+int spk_set_option(const char* name, int value);
+int spk_get_option(const char* name, int* value_out);
 
 /* ---- neuron surface -------------------------------------------------------------------------------------- */
 

@@ -317,8 +317,23 @@ def to_uint8(pred):
 
 
 # --------------------------------------------------------------------------- a8
-def denoiser_forward(x, t, sd, T=16, return_layers=False):
-    """DummyModel.forward, R/snn_model/vq_diffusion.py:189-208. x [B,1,h,w] float, t [B] long."""
+def conv_bn_lif_exact(x_seq, sd, conv_prefix, bn_prefix, stride, padding):
+    """The block of ``conv_bn_lif`` with the convolution evaluated EXACTLY: fp64 accumulation of the fp32 products (exact to
+    2^-53 of the sum), bias added in fp64, ONE rounding to fp32 -- the arithmetic contract of the HIP kernels --
+    followed by the reference's fp32 BatchNorm (its fma form, fixture F7) and LIF operations.  The reference's own convolution
+    (oneDNN, fp32 accumulation in an unknowable order) approximates this value to a few ulp; where a membrane potential sits
+    that close to the threshold the two can decide a spike differently.  Test infrastructure: it tells the two apart."""
+    w, b = sd[conv_prefix + ".weight"].double(), sd[conv_prefix + ".bias"].double()
+    y = seq_to_ann(x_seq.double(), lambda v: F.conv2d(v, w, b, stride, padding)).float()
+    a, bb = bn_affine_terms(sd, bn_prefix)
+    y = bn_apply_fma(y, a, bb)
+    s, _ = lif_multi_step(y)
+    return s, y
+
+
+def denoiser_forward(x, t, sd, T=16, return_layers=False, exact_conv=False):
+    """DummyModel.forward, R/snn_model/vq_diffusion.py:189-208. x [B,1,h,w] float, t [B] long.
+    ``exact_conv``: every convolution as the correctly rounded exact dot product (conv_bn_lif_exact) instead of oneDNN's fp32."""
     tt = torch.ones_like(x) * (t.unsqueeze(1).unsqueeze(2).unsqueeze(3))
     x = torch.cat((x, tt), dim=1)
     x = x.unsqueeze(dim=0).repeat(T, 1, 1, 1, 1)
@@ -326,12 +341,17 @@ def denoiser_forward(x, t, sd, T=16, return_layers=False):
     h = x
     outs = []
     for i in range(1, 6):
-        s, y = conv_bn_lif(h, sd, f"conv{i}.0", f"conv{i}.1", 1, 1)
+        s, y = (conv_bn_lif_exact if exact_conv else conv_bn_lif)(h, sd, f"conv{i}.0", f"conv{i}.1", 1, 1)
         layers.append((s, y))
         outs.append(s)
         h = s
-    x6 = seq_conv2d(torch.cat((outs[4], outs[0]), dim=2), sd["conv6.0.weight"], sd["conv6.0.bias"], 1, 1)
-    logits = torch.sum(x6, dim=0) / T
+    cat = torch.cat((outs[4], outs[0]), dim=2)
+    if exact_conv:
+        x6 = seq_to_ann(cat.double(), lambda v: F.conv2d(v, sd["conv6.0.weight"].double(), sd["conv6.0.bias"].double(), 1, 1))
+        logits = (torch.sum(x6, dim=0) / T).float()
+    else:
+        x6 = seq_conv2d(cat, sd["conv6.0.weight"], sd["conv6.0.bias"], 1, 1)
+        logits = torch.sum(x6, dim=0) / T
     if return_layers:
         return logits, layers
     return logits

@@ -11,3 +11,40 @@ extern "C" const char* spk_error_string(int code) {
   if (code > 0) return hipGetErrorString((hipError_t)code);
   return "spkdiff: unknown error";
 }
+
+// ---- measurement options ---------------------------------------------------------------------------------------------
+// The few launch-shape choices that rounds 1-4 measured against each other stay selectable so that the measurements can be
+// repeated (DESIGN.md names the numbers).  They are NOT read from the environment by the library: the HOST sets them through
+// spk_set_option (spkdiff/_lib.py forwards the SPKDIFF_* environment variables once at import, for the A/B tools), and every
+// launch reads the current value -- plain atomics, no lazily initialised statics, no hidden state the caller does not own.
+#include <atomic>
+#include <string.h>
+
+namespace {
+struct SpkOption { const char* name; std::atomic<int> value; };
+SpkOption g_options[SPK_OPT_COUNT] = {
+    {"conv6_shared", {1}},       // SPK_OPT_CONV6_SHARED
+    {"conv6_shared_dyn", {1}},   // SPK_OPT_CONV6_SHARED_DYN
+    {"mfma_debug", {0}},         // SPK_OPT_MFMA_DEBUG
+    {"fp6_xcd_walk", {1}},       // SPK_OPT_FP6_XCD_WALK
+    {"fp6_waves", {4}},          // SPK_OPT_FP6_WAVES
+    {"v2_waves", {8}},           // SPK_OPT_V2_WAVES
+    {"v2_lag", {0}},             // SPK_OPT_V2_LAG
+};
+}  // namespace
+
+int spk_opt(int id) { return (id >= 0 && id < SPK_OPT_COUNT) ? g_options[id].value.load(std::memory_order_relaxed) : 0; }
+
+extern "C" int spk_set_option(const char* name, int value) {
+  if (!name) return SPK_ERR_ARG;
+  for (int i = 0; i < SPK_OPT_COUNT; ++i)
+    if (strcmp(name, g_options[i].name) == 0) { g_options[i].value.store(value, std::memory_order_relaxed); return SPK_OK; }
+  return SPK_ERR_UNSUPPORTED;
+}
+
+extern "C" int spk_get_option(const char* name, int* value_out) {
+  if (!name || !value_out) return SPK_ERR_ARG;
+  for (int i = 0; i < SPK_OPT_COUNT; ++i)
+    if (strcmp(name, g_options[i].name) == 0) { *value_out = g_options[i].value.load(std::memory_order_relaxed); return SPK_OK; }
+  return SPK_ERR_UNSUPPORTED;
+}

@@ -23,16 +23,30 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
 constexpr int T16 = 16;
 
+// (the 16x16 bit transpose of den_common.h; this file keeps to spk_common.h, so it carries the same few lines)
 __device__ __forceinline__ unsigned transpose16_rows_g(unsigned x, int lane) {
   unsigned y;
+  // (opaque copy of the lane id: the three per-lane constants of a round are recomputed here -- three vector instructions --
+  //  instead of being hoisted out of the caller's loops, where eight of them stayed live across the K loop: 256 registers + spills)
+  int ln = lane;
+  asm volatile("" : "+v"(ln));
+#define SPK_TR16_ROUND_G(S, LOW)                                                                     \
+  do {                                                                                               \
+    const unsigned sh = (unsigned)ln & (unsigned)(S);            /* 0 or S */                         \
+    const unsigned keep = (unsigned)(LOW) << sh;                                                     \
+    const unsigned amt = (32u - (unsigned)(S)) + 2u * sh;        /* 32 - S, or 32 + S = S (mod 32) */ \
+    const unsigned yr = __builtin_amdgcn_alignbit(y, y, amt);                                        \
+    x = (x & keep) | (yr & ~keep);                                                                   \
+  } while (0)
   y = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(x, 0x140, 0xF, 0xF, true), 0x141, 0xF, 0xF, true);
-  x = (lane & 8) ? (((y >> 8) & 0x00FFu) | (x & 0xFF00u)) : ((x & 0x00FFu) | ((y & 0x00FFu) << 8));
+  SPK_TR16_ROUND_G(8, 0x00FFu);
   y = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
-  x = (lane & 4) ? (((y >> 4) & 0x0F0Fu) | (x & 0xF0F0u)) : ((x & 0x0F0Fu) | ((y & 0x0F0Fu) << 4));
+  SPK_TR16_ROUND_G(4, 0x0F0Fu);
   y = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);
-  x = (lane & 2) ? (((y >> 2) & 0x3333u) | (x & 0xCCCCu)) : ((x & 0x3333u) | ((y & 0x3333u) << 2));
+  SPK_TR16_ROUND_G(2, 0x3333u);
   y = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);
-  x = (lane & 1) ? (((y >> 1) & 0x5555u) | (x & 0xAAAAu)) : ((x & 0x5555u) | ((y & 0x5555u) << 1));
+  SPK_TR16_ROUND_G(1, 0x5555u);
+#undef SPK_TR16_ROUND_G
   return x;
 }
 

@@ -12,16 +12,34 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
 // 16x16 bit-matrix transpose inside every 16-lane row (lane = row, bit = column) with DPP lane exchanges:
 // lane^8 = row_mirror o row_half_mirror, lane^4 = row_half_mirror o quad-reverse, lane^2 / lane^1 = quad_perm.
+// Round s (8, 4, 2, 1) swaps the off-diagonal s-bit blocks with lane ^ s.  Both lane parities run the SAME two instructions on
+// per-lane constants -- the partner's word rotated by s towards the block it lands in (v_alignbit: right by s for the lanes with
+// bit s set, right by 32 - s = left by s for the others) and merged under the keep mask (v_bfi) -- instead of a select between
+// two shift-and-mask expressions, which hipcc compiled as two exec-masked branches per round (45 vector + 24 scalar
+// instructions per transpose; now 14).  Bits 16..31 of the result are garbage (rotated-out blocks): callers use the low half.
 __device__ __forceinline__ unsigned spk_transpose16_rows(unsigned x, int lane) {
   unsigned y;
+  // (opaque copy of the lane id: the three per-lane constants of a round are recomputed here -- three vector instructions --
+  //  instead of being hoisted out of the caller's loops, where eight of them stayed live across the K loop: 256 registers + spills)
+  int ln = lane;
+  asm volatile("" : "+v"(ln));
+#define SPK_TR16_ROUND(S, LOW)                                                                       \
+  do {                                                                                               \
+    const unsigned sh = (unsigned)ln & (unsigned)(S);            /* 0 or S */                         \
+    const unsigned keep = (unsigned)(LOW) << sh;                                                     \
+    const unsigned amt = (32u - (unsigned)(S)) + 2u * sh;        /* 32 - S, or 32 + S = S (mod 32) */ \
+    const unsigned yr = __builtin_amdgcn_alignbit(y, y, amt);                                        \
+    x = (x & keep) | (yr & ~keep);                                                                   \
+  } while (0)
   y = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(x, 0x140, 0xF, 0xF, true), 0x141, 0xF, 0xF, true);
-  x = (lane & 8) ? (((y >> 8) & 0x00FFu) | (x & 0xFF00u)) : ((x & 0x00FFu) | ((y & 0x00FFu) << 8));
+  SPK_TR16_ROUND(8, 0x00FFu);
   y = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
-  x = (lane & 4) ? (((y >> 4) & 0x0F0Fu) | (x & 0xF0F0u)) : ((x & 0x0F0Fu) | ((y & 0x0F0Fu) << 4));
+  SPK_TR16_ROUND(4, 0x0F0Fu);
   y = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);
-  x = (lane & 2) ? (((y >> 2) & 0x3333u) | (x & 0xCCCCu)) : ((x & 0x3333u) | ((y & 0x3333u) << 2));
+  SPK_TR16_ROUND(2, 0x3333u);
   y = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);
-  x = (lane & 1) ? (((y >> 1) & 0x5555u) | (x & 0xAAAAu)) : ((x & 0x5555u) | ((y & 0x5555u) << 1));
+  SPK_TR16_ROUND(1, 0x5555u);
+#undef SPK_TR16_ROUND
   return x;
 }
 

@@ -647,10 +647,10 @@ extern "C" int spk_den_conv3x3_counts_mfma(const uint8_t* cnt0, int nch0, const 
   const long long tiles = ((long long)B * H * W + 31) / 32;
   dim3 grid((unsigned)tiles, Cout / 16), blk(256);
   // batches of more than 160 row tiles: shared weight tiles and count records
-  static const bool shared_w = [] { const char* e = getenv("SPKDIFF_CONV6_SHARED"); return !(e && e[0] == '0'); }();
+  const bool shared_w = spk_opt(SPK_OPT_CONV6_SHARED) != 0;
   // (also the sampler's active-set calls: its register-staged stream of two chunks beats the K split of the first kernel even at
-  //  a few dozen images -- elimination + position lists 35.4 -> 34.4 ms; SPKDIFF_CONV6_SHARED_DYN=0: the first kernel there)
-  static const bool shared_dyn = [] { const char* e = getenv("SPKDIFF_CONV6_SHARED_DYN"); return !(e && e[0] == '0'); }();
+  //  a few dozen images -- elimination + position lists 35.4 -> 34.4 ms; option conv6_shared_dyn = 0: the first kernel there)
+  const bool shared_dyn = spk_opt(SPK_OPT_CONV6_SHARED_DYN) != 0;
   if ((!n_dyn_or_null || shared_dyn) && (long long)B * H * W > 32 * 160 && H * W >= 43 && H * W <= 64 && shared_w) {
     hipLaunchKernelGGL(conv3x3_counts_mfma_shared_kernel, dim3((unsigned)((tiles + 3) / 4), Cout / 16), blk, 0, stream, a);
     SPK_LAUNCH_CHECK();
@@ -677,8 +677,7 @@ extern "C" int spk_den_conv3x3_mfma(const uint8_t* in0_cptc, int nch0, const uin
   a.dbg = 0;
 #ifdef SPK_MFMA_ABLATION
   // (timing experiments only; read once per process: the launch path makes no environment look-ups)
-  static const int dbg_env = [] { const char* e = getenv("SPK_MFMA_DEBUG"); return e ? atoi(e) : 0; }();
-  a.dbg = dbg_env;
+  a.dbg = spk_opt(SPK_OPT_MFMA_DEBUG);
 #endif
   if (mode == SPK_MODE_LIF) {
     if (!bn_a || !bn_b || !out_cptc) return SPK_ERR_ARG;

@@ -707,8 +707,8 @@ int launch_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* s
   // 4 MB L2, if the shape tiles exactly (see decode() in the kernel)
   // Measured on the conv4 shape (B = 256): L2-miss reads 206 -> 111 MB and HBM-side writes 218 -> 56 MB per launch at
   // the same launch time (with 7 tiles per wave it was ~2 % slower; rotating the chunk order per workgroup to spread the
-  // slab requests of an XCD made it slower still).  SPKDIFF_FP6_XCD_WALK=0 selects the image-major walk.
-  static const bool xcd_walk = [] { const char* e = getenv("SPKDIFF_FP6_XCD_WALK"); return !(e && e[0] == '0'); }();
+  // slab requests of an XCD made it slower still).  option fp6_xcd_walk = 0 selects the image-major walk.
+  const bool xcd_walk = spk_opt(SPK_OPT_FP6_XCD_WALK) != 0;
   a.gx = 0;
   if (xcd_walk && !n_dyn && !bands && (grid.x & 7) == 0) {      // (a device-side batch count / row bands walk image-major)
     const int S = grid.x / 8;
@@ -720,7 +720,7 @@ int launch_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* s
   if (bands) {
     hipLaunchKernelGGL((conv3x3_fp6_kernel<4, RAW, true>), grid, blk, lds, stream, a);
   } else if (split_last) {
-    static const bool eight = [] { const char* e = getenv("SPKDIFF_FP6_WAVES"); return e && e[0] == '8'; }();
+    const bool eight = spk_opt(SPK_OPT_FP6_WAVES) == 8;
     if (eight && (H * ((W + 1) / 2) + 7) / 8 <= 4)
       hipLaunchKernelGGL((conv3x3_fp6_kernel<3, RAW, false, 8>), grid, dim3(512), lds, stream, a);
     else

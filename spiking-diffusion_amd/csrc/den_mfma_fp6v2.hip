@@ -233,6 +233,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
   // four-digit form: active inputs per input cell and step (s_cin, borders stay zero) and per output position and step (s_row)
   int* const s_cin = reinterpret_cast<int*>(lds + 2 * A_BYTES + 2 * W_LDS);          // [NPP][16]
   int* const s_row = s_cin + NPP * 16;                                               // [HWb + 1][16]
+  int* const s_nmax = s_row + (HWb + 1) * 16;                                        // [HWb + 1]: max over the steps of s_row[p][.]
   const unsigned sA_addr = spk_lds_addr(sA), sW_addr = sA_addr + 2 * A_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nch = a.nch;
@@ -508,6 +509,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
 #pragma unroll
       for (int k = 0; k < NR; ++k)
         if (rec_ok[k]) s_cin[(rec_off[k] / POSB) * 16 + ((rec_off[k] % POSB) >> 4)] = creg[k];
+      if (tid <= HWb) s_nmax[tid] = 0;
       __syncthreads();
       for (int e = tid; e < HWb * 16; e += NWV * 64) {
         const int pp = e >> 4, t = e & 15;
@@ -518,6 +520,9 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
 #pragma unroll
           for (int dx = 0; dx < 3; ++dx) sum += c0[(dy * PW + dx) * 16];
         s_row[e] = sum;
+        // the certification's first stage only needs max_t n_t of a position: one LDS atomic here instead of four 16-byte reads
+        // and twelve v_max per tile and lane in the scan (the second stage, a few percent of the tiles, reads the sixteen counts)
+        atomicMax(&s_nmax[pp], sum);
       }
       __syncthreads();
     }
@@ -561,15 +566,8 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
           cntv[r] = half ? c1 : c0;
         }
       }
-      if constexpr (REC) {
-        const int pl = 2 * (wave + NWV * i) + half;       // position within the item
-        const v4i* rp = reinterpret_cast<const v4i*>(s_row + pl * 16);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const v4i c4 = rp[q];
-          cntv[4 * q] = c4[0]; cntv[4 * q + 1] = c4[1]; cntv[4 * q + 2] = c4[2]; cntv[4 * q + 3] = c4[3];
-        }
-      }
+      int nmax_rec = 0;
+      if constexpr (REC) nmax_rec = s_nmax[2 * (wave + NWV * i) + half];     // (position within the item)
       if constexpr (USE_D4) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -589,13 +587,13 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
         // max n and min |h - 1| (three instructions per step instead of eight) and compare once, against dh = D / 2
         typedef float v2f __attribute__((ext_vector_type(2)));
         float zmax = 0.f, dmin = 3.0e38f;
-        int nmax = 0;
+        int nmax = nmax_rec;
 #pragma unroll
         for (int r2 = 0; r2 < 16; r2 += 2) {
           const v2f p0 = {acc[i][0][r2], acc[i][0][r2 + 1]}, p1 = {acc[i][1][r2], acc[i][1][r2 + 1]};
           const v2f q4 = __builtin_elementwise_fma(p0, (v2f){1024.0f, 1024.0f}, p1);
           const v2f z2 = __builtin_elementwise_fma(q4, (v2f){Ac4, Ac4}, (v2f){Bc, Bc});
-          nmax = max(nmax, max(cntv[r2], cntv[r2 + 1]));
+          if constexpr (!REC) nmax = max(nmax, max(cntv[r2], cntv[r2 + 1]));
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const float z = z2[e];
@@ -617,6 +615,14 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
           // proportional to them).  Every lane re-scans (the branch is wave-uniform); accumulators and counts are still live.
           float v2 = 0.f, dh = 0.f;
           bool f2 = false;
+          if constexpr (REC) {
+            const v4i* rp = reinterpret_cast<const v4i*>(s_row + (2 * (wave + NWV * i) + half) * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const v4i c4 = rp[q];
+              cntv[4 * q] = c4[0]; cntv[4 * q + 1] = c4[1]; cntv[4 * q + 2] = c4[2]; cntv[4 * q + 3] = c4[3];
+            }
+          }
 #pragma unroll
           for (int r2 = 0; r2 < 16; r2 += 2) {
             const v2f p0 = {acc[i][0][r2], acc[i][0][r2 + 1]}, p1 = {acc[i][1][r2], acc[i][1][r2 + 1]};
@@ -1480,7 +1486,7 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   if (a.gx == 0) grid = cus >= G ? (cus / G) * G : G;         // flat walk: workgroup k -> group k % G
   const int a_bytes = bands ? ((8 / 2 + 1 + 2) * 9 + 1) * POSB : ((7 + 2) * 8 + 1) * POSB;
   // (+ the active-input counters of the four-digit form: s_cin [cells][16], s_row [positions + 1][16])
-  const size_t lds = 2 * ((size_t)a_bytes + W_LDS) + (size_t)((a_bytes / POSB) + (bands ? 32 : 49) + 1) * 64;
+  const size_t lds = 2 * ((size_t)a_bytes + W_LDS) + (size_t)((a_bytes / POSB) + (bands ? 32 : 49) + 1) * 64 + 256;   // (+ s_nmax)
   const long long n_words = ((long long)B * Cout * H * W + 31) / 32;
   a.ticket_idx = 2 + (long long)FLAG_CAP + n_words;
   // full 7x7 batches keep the round-1 order (repair launch, then the last-position launch re-arms the counter): the hand-over
@@ -1502,7 +1508,7 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
     return SPK_OK;
   }
   if (bands) {
-    static const bool eight_b = [] { const char* e = getenv("SPKDIFF_V2_WAVES"); return !(e && e[0] == '4'); }();   // (+4 %)
+    const bool eight_b = spk_opt(SPK_OPT_V2_WAVES) != 4;   // (+4 %)
     if (eight_b) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 8, true>), dim3(grid), dim3(512), lds, stream, a);
     else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 4, true>), dim3(grid), dim3(256), lds, stream, a);
     SPK_LAUNCH_CHECK();
@@ -1518,9 +1524,8 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   // 417-466 against 383-387 us, dense reverse process 103.3 against 92.3 ms) although three waves issue vector instructions
   // 1.4x faster than two (tools/coexec_probe.hip: 2.2 against 3.1 cycles per v_fma_f32): a weight tile read from LDS then
   // serves two row tiles instead of three and twelve waves meet at every chunk barrier.  SPKDIFF_V2_WAVES=4: one wave.
-  static const bool eight = [] { const char* e = getenv("SPKDIFF_V2_WAVES"); return !(e && e[0] == '4'); }();
-  static const bool twelve = [] { const char* e = getenv("SPKDIFF_V2_WAVES"); return e && e[0] == '1' && e[1] == '2'; }();
-  static const bool lag_form = [] { const char* e = getenv("SPKDIFF_V2_LAG"); return e ? e[0] == '1' : (SPK_V2_LAG_DEFAULT != 0); }();
+  const bool eight = spk_opt(SPK_OPT_V2_WAVES) != 4, twelve = spk_opt(SPK_OPT_V2_WAVES) == 12;
+  const bool lag_form = spk_opt(SPK_OPT_V2_LAG) != 0 || SPK_V2_LAG_DEFAULT != 0;
   if (need) {
     if (grid / G < 6) return SPK_ERR_UNSUPPORTED;           // one image lane per tile-count class at least
     if (eight) hipLaunchKernelGGL((conv3x3_fp6v2_listed_kernel<7, 7, 8>), dim3(grid), dim3(512), lds, stream, a);

@@ -116,6 +116,8 @@ _SIGS = {
     "spk_checksum_multi": (c_int, [P, c_int, P, P]),
     "spk_clock_probe": (c_int, [P, c_int, c_int, P]),
     "spk_count_spikes": (c_int, [P, c_longlong, c_longlong, c_int, c_int, P, P]),
+    "spk_set_option": (c_int, [ctypes.c_char_p, c_int]),
+    "spk_get_option": (c_int, [ctypes.c_char_p, P]),
 }
 
 EXPORTS = tuple(_SIGS)
@@ -140,3 +142,24 @@ def check(rc: int, what: str = ""):
 
 def version() -> int:
     return lib.spk_version()
+
+
+# Measurement options (include/spkdiff.h): the library reads no environment variable itself; the A/B tools under tools/ select
+# a launch form with SPKDIFF_<NAME>=<int>, forwarded here ONCE at import.  set_option() switches at run time.
+OPTIONS = ("v2_waves", "v2_lag", "fp6_waves", "fp6_xcd_walk", "conv6_shared", "conv6_shared_dyn", "mfma_debug")
+
+
+def set_option(name: str, value: int):
+    check(lib.spk_set_option(name.encode(), int(value)), f"spk_set_option({name!r})")
+
+
+def get_option(name: str) -> int:
+    v = c_int(0)
+    check(lib.spk_get_option(name.encode(), ctypes.byref(v)), f"spk_get_option({name!r})")
+    return int(v.value)
+
+
+for _o in OPTIONS:
+    _e = os.environ.get("SPKDIFF_" + _o.upper()) or (os.environ.get("SPK_MFMA_DEBUG") if _o == "mfma_debug" else None)
+    if _e not in (None, ""):
+        set_option(_o, int(_e))

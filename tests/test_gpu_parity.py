@@ -43,9 +43,21 @@ def ops():
     return o
 
 
-def build_vae(cfg, dev, T=16):
+# Fixtures on TRAINED weights (round 4; oracle/gen_golden_trained.py, checkpoints/): tag "mnist_trained" selects them
+def trained(tag):
+    return tag.endswith("_trained")
+
+
+def fixture_file(kind, tag):
+    """kind 'f3_encode' / 'f4_decode' / 'f5_denoiser' -> file name for a tag ('mnist', 'cifar', 'mnist_trained')."""
+    if trained(tag):
+        return f"{kind.replace('_', 't_', 1)}_{tag}.npz"
+    return f"{kind}_{tag}.npz"
+
+
+def build_vae(cfg, dev, T=16, weights='synth'):
     from snn_model.vae_model import SNN_VQVAE, functional
-    sd = synth.synth_vqvae_state(cfg)
+    sd = synth.trained_state('vqvae') if weights == 'trained' else synth.synth_vqvae_state(cfg)
     if T != 16:
         sd = dict(sd)
         sd["vq_layer.memout.coef"] = synth.memout_coef(T)
@@ -56,9 +68,9 @@ def build_vae(cfg, dev, T=16):
     return m.cuda(0).eval(), sd
 
 
-def build_den(cfg, dev):
+def build_den(cfg, dev, weights='synth'):
     from snn_model.vq_diffusion import DummyModel, functional
-    sd = synth.synth_denoiser_state(cfg)
+    sd = synth.trained_state('denoiser') if weights == 'trained' else synth.synth_denoiser_state(cfg)
     d = DummyModel(1, cfg.num_embeddings).cuda(0)
     functional.set_step_mode(net=d, step_mode='m')
     d.load_state_dict(sd)
@@ -251,11 +263,11 @@ def test_f2_fused_layers_teacher_forced(golden_dir, dev, ops):
 
 
 # ------------------------------------------------------------------------------------------------- F3 encode
-@pytest.mark.parametrize("tag,cfg", [("mnist", synth.MNIST), ("cifar", synth.CIFAR)])
+@pytest.mark.parametrize("tag,cfg", [("mnist", synth.MNIST), ("cifar", synth.CIFAR), ("mnist_trained", synth.MNIST)])
 def test_f3_encode_decode_end_to_end(golden_dir, dev, tag, cfg):
     from snn_model.vae_model import functional
-    d = load(golden_dir, f"f3_encode_{tag}.npz")
-    model, sd = build_vae(cfg, dev)
+    d = load(golden_dir, fixture_file("f3_encode", tag))
+    model, sd = build_vae(cfg, dev, weights='trained' if trained(tag) else 'synth')
     assert synth.state_checksum(sd) == str(d["weights_crc"])
     images = torch.from_numpy(d["images"])
     B = images.shape[0]
@@ -323,11 +335,11 @@ def test_vq_argmin_and_quantize(dev):
 
 
 # ------------------------------------------------------------------------------------------------- F4 decode glue
-@pytest.mark.parametrize("tag,cfg", [("mnist", synth.MNIST), ("cifar", synth.CIFAR)])
+@pytest.mark.parametrize("tag,cfg", [("mnist", synth.MNIST), ("cifar", synth.CIFAR), ("mnist_trained", synth.MNIST)])
 def test_f4_decode_glue(golden_dir, dev, tag, cfg):
     from snn_model.vae_model import functional
-    d = load(golden_dir, f"f4_decode_{tag}.npz")
-    model, sd = build_vae(cfg, dev)
+    d = load(golden_dir, fixture_file("f4_decode", tag))
+    model, sd = build_vae(cfg, dev, weights='trained' if trained(tag) else 'synth')
     tokens = torch.from_numpy(d["tokens"])
     want = torch.from_numpy(d["pred"])
     # (1) the reference's own call sequence, R/main.py:388-401, on the drop-in modules
@@ -357,12 +369,12 @@ def test_f4_decode_glue(golden_dir, dev, tag, cfg):
 
 
 # ------------------------------------------------------------------------------------------------- F5 denoiser
-@pytest.mark.parametrize("tag,cfg", [("mnist", synth.MNIST), ("cifar", synth.CIFAR)])
+@pytest.mark.parametrize("tag,cfg", [("mnist", synth.MNIST), ("cifar", synth.CIFAR), ("mnist_trained", synth.MNIST)])
 def test_f5_denoiser(golden_dir, dev, ops, tag, cfg):
     from spkdiff.ops import IN_PTC, IN_TINV
     from snn_model.vq_diffusion import functional
-    d = load(golden_dir, f"f5_denoiser_{tag}.npz")
-    den, sd = build_den(cfg, dev)
+    d = load(golden_dir, fixture_file("f5_denoiser", tag))
+    den, sd = build_den(cfg, dev, weights='trained' if trained(tag) else 'synth')
     assert synth.state_checksum(sd) == str(d["weights_crc"])
     x_t = torch.from_numpy(d["x_t"])
     t = torch.from_numpy(d["t"])
@@ -388,7 +400,9 @@ def test_f5_denoiser(golden_dir, dev, ops, tag, cfg):
     report_tf = report
     s5 = unpack(d["s5_bits"], d["s5_shape"]); s1 = unpack(d["s1_bits"], d["s1_shape"])
     lg = den.conv6.run(ops.spikes_to_ptc(s5.to(dev)), IN_PTC, final='mean', in1=ops.spikes_to_ptc(s1.to(dev)))['f32']
-    assert float((lg.cpu() - want_logits).abs().max()) <= 1e-5, "conv6 + time mean on the reference's spikes"
+    # (trained weights: conv6's weights reach 4.4 and the logits tens -- the same few ulp are a larger absolute number)
+    tol5 = 2e-6 * (1.0 + want_logits.abs()) if trained(tag) else torch.full_like(want_logits, 1e-5)
+    assert bool(((lg.cpu() - want_logits).abs() <= tol5).all()), "conv6 + time mean on the reference's spikes"
     # (2) end to end through the module API (spike flips may cascade: SURVEY.md §7) -- report, and bound loosely
     with torch.inference_mode():
         logits = den(x_t.float().to(dev), t=t.to(dev))
@@ -403,17 +417,27 @@ def test_f5_denoiser(golden_dir, dev, ops, tag, cfg):
     print(f"F5 {tag} end-to-end logits: max abs diff {float(diff.max()):.3e}, within 1e-4: {frac_close:.5f}")
     parity("f5_denoiser_" + tag, logits_max_abs_diff=float(diff.max()), frac_within_1e_4=frac_close,
            teacher_forced_mismatches={k: v[0] for k, v in report_tf.items()})
-    assert float(diff.max()) <= 1e-6, "end-to-end logits (measured 8.9e-8 / 6.0e-8: no spike flips against the reference)"
+    if trained(tag):
+        # the reference's fp32 convolutions and the exact arithmetic agree on every spike of this fixture (oracle, exact_conv):
+        # what remains is the rounding of conv6's 2 880-term sums, relative to logits of magnitude ~10
+        lg_x, lay_x = ref.denoiser_forward(x_t.float(), t, sd, 16, return_layers=True, exact_conv=True)
+        dx = (logits.cpu() - lg_x).abs()
+        parity("f5_denoiser_" + tag + "_vs_exact_conv_oracle", logits_max_abs_diff=float(dx.max()),
+               logits_max_abs=float(want_logits.abs().max()))
+        assert bool((dx <= 1e-6 * (1.0 + lg_x.abs())).all()), "logits == the exact-convolution oracle's to one rounding"
+        assert bool((diff <= 2e-6 * (1.0 + want_logits.abs())).all())
+    else:
+        assert float(diff.max()) <= 1e-6, "end-to-end logits (measured 8.9e-8 / 6.0e-8: no spike flips against the reference)"
 
 
-@pytest.mark.parametrize("tag,cfg", [("mnist", synth.MNIST), ("cifar", synth.CIFAR)])
+@pytest.mark.parametrize("tag,cfg", [("mnist", synth.MNIST), ("cifar", synth.CIFAR), ("mnist_trained", synth.MNIST)])
 def test_f5_denoiser_mfma_int8_kernel(golden_dir, dev, ops, tag, cfg):
     """conv2..conv6 on the matrix cores (four exact int8 digit planes) against the golden spikes (teacher forced),
     and bit-for-bit against the fp64-accumulating direct kernel: both are the correctly rounded exact dot product."""
     from spkdiff.ops import IN_PTC
     from snn_model.vq_diffusion import functional
-    d = load(golden_dir, f"f5_denoiser_{tag}.npz")
-    den, sd = build_den(cfg, dev)
+    d = load(golden_dir, fixture_file("f5_denoiser", tag))
+    den, sd = build_den(cfg, dev, weights='trained' if trained(tag) else 'synth')
     den.conv_impl_request = 'i8'
     assert den.conv_impl == 'mfma-i8x4'
     spikes = {i: unpack(d[f"s{i}_bits"], d[f"s{i}_shape"]) for i in range(1, 6)}
@@ -436,10 +460,16 @@ def test_f5_denoiser_mfma_int8_kernel(golden_dir, dev, ops, tag, cfg):
     x5 = ops.spikes_to_ptc(spikes[5].to(dev), chunk=32); x1 = ops.spikes_to_ptc(spikes[1].to(dev), chunk=32)
     lg = den.conv6.run(x5, IN_PTC, final='mean', in1=x1)['f32'].cpu()
     lg_d = den.conv6.run(x5, IN_PTC, final='mean', in1=x1, impl='direct')['f32'].cpu()
-    assert float((lg - torch.from_numpy(d["logits"])).abs().max()) <= 1e-5
+    wl = torch.from_numpy(d["logits"])
+    assert bool(((lg - wl).abs() <= (2e-6 * (1.0 + wl.abs()) if trained(tag) else 1e-5)).all())
     # weights below 2^-7 of their channel's maximum are fixed-point rounded at 2^-30 of that maximum (den_mfma.hip):
     # a pre-activation may then round to the neighbouring fp32 value; bound: a few percent of logits, by <= 1 ulp
-    assert float((lg != lg_d).float().mean()) <= 0.03 and float((lg - lg_d).abs().max()) <= 6e-8
+    # (trained weights: 16 % of conv6's weights lie below 2^-6 of their channel's maximum and the logits reach tens: an ulp is
+    #  up to 2e-6 there and more sums land on a rounding boundary)
+    ulp = 2.0 ** (torch.floor(torch.log2(lg_d.abs().clamp_min(1e-30))) - 23)
+    parity("f5_int8_conv6_vs_direct_" + tag, frac_differing=float((lg != lg_d).float().mean()),
+           max_diff_in_ulp=float(((lg - lg_d).abs() / ulp).max()))
+    assert float((lg != lg_d).float().mean()) <= (0.10 if trained(tag) else 0.03) and bool(((lg - lg_d).abs() <= ulp).all())
     # module semantics on the MFMA path: state carried across forwards without reset == direct path, then reset
     x_t = torch.from_numpy(d["x_t"]).float().to(dev); t = torch.from_numpy(d["t"]).to(dev)
     with torch.inference_mode():
@@ -449,21 +479,23 @@ def test_f5_denoiser_mfma_int8_kernel(golden_dir, dev, ops, tag, cfg):
         b1 = den(x_t, t=t); b2 = den(x_t, t=t)
         functional.reset_net(den)
         den.conv_impl_request = 'auto'
-    assert float((a1 - b1).abs().max()) <= 1e-6 and float((a2 - b2).abs().max()) <= 1e-6
+    tol_ab = 2e-6 * (1.0 + b1.abs()) if trained(tag) else torch.full_like(b1, 1e-6)
+    assert bool(((a1 - b1).abs() <= tol_ab).all()) and bool(((a2 - b2).abs() <= 2e-6 * (1.0 + b2.abs()) + 1e-6).all())
     assert not torch.equal(a1, a2), "second call starts from the carried membrane potentials"
 
 
-def test_f5_denoiser_mfma_fp6_kernel(golden_dir, dev, ops):
+@pytest.mark.parametrize("tag", ["mnist", "mnist_trained"])
+def test_f5_denoiser_mfma_fp6_kernel(golden_dir, dev, ops, tag):
     """conv2..conv5 on the block-scaled fp6 x fp4 MFMA (six exact radix-32 digit planes, C4 nibble-packed spikes)
     against the golden spikes (teacher forced) and bit-for-bit against the fp64-accumulating direct kernel; spike
     counts, carried membrane state and the whole-call logits against the direct path."""
     from spkdiff.ops import IN_PTC
     from snn_model.vq_diffusion import functional
-    d = load(golden_dir, "f5_denoiser_mnist.npz")
-    den, sd = build_den(synth.MNIST, dev)
+    d = load(golden_dir, fixture_file("f5_denoiser", tag))
+    den, sd = build_den(synth.MNIST, dev, weights='trained' if trained(tag) else 'synth')
     assert den.impl_for(7, 7, stateful=True) == 'mfma-fp6x6' and den.impl_for(7, 7) == 'mfma-fp6v2'
     spikes = {i: unpack(d[f"s{i}_bits"], d[f"s{i}_shape"]) for i in range(1, 6)}
-    report = {}
+    report, got_all = {}, {}
     for i, blk in enumerate((den.conv2, den.conv3, den.conv4, den.conv5), 2):
         frag = unpack(d[f"frag{i}_bits"], d[f"s{i}_shape"]).bool()
         x_4 = ops.spikes_to_c4(spikes[i - 1].to(dev))
@@ -477,12 +509,17 @@ def test_f5_denoiser_mfma_fp6_kernel(golden_dir, dev, ops):
         report[f"conv{i}"] = (int(bad.sum()), int(frag.sum()), int((got != direct).sum()))
         assert not bool((bad & ~frag).any()), f"conv{i} (fp6 MFMA): spike differs outside the fragile set"
         assert torch.equal(got, direct), f"conv{i}: fp6 MFMA path != fp64 direct path"
+        got_all[i] = got
         cnt = r['cnt'].cpu()                                   # [B, C/32, H, W, 32] == sum over T of the spikes
         B, C, H, W = got.shape[1:]
         want_cnt = got.sum(0).reshape(B, C // 32, 32, H, W).permute(0, 1, 3, 4, 2)
         assert torch.equal(cnt.float(), want_cnt)
-    print("F5 mnist fp6-MFMA teacher-forced (mismatch vs golden, fragile, mismatch vs direct):", report)
-    parity("f5_fp6_mfma_mnist", mismatch_vs_golden={k: v[0] for k, v in report.items()},
+    print(f"F5 {tag} fp6-MFMA teacher-forced (mismatch vs golden, fragile, mismatch vs direct):", report)
+    # the sampler's kernel (four digits + certification + exact repair) on the same inputs: the six-plane kernel's spikes again
+    for i, blk in enumerate((den.conv2, den.conv3, den.conv4, den.conv5), 2):
+        r2 = blk.run(ops.spikes_to_s32(spikes[i - 1].to(dev)), IN_PTC, final='ptc', stateful=False, chunk_out=ops.CHUNK_S32)
+        assert torch.equal(ops.s32_to_spikes(r2['ptc']).cpu(), got_all[i]), f"conv{i}: fp6v2 != six-plane kernel"
+    parity("f5_fp6_mfma_" + tag, mismatch_vs_golden={k: v[0] for k, v in report.items()},
            mismatch_vs_direct={k: v[2] for k, v in report.items()})
     x_t = torch.from_numpy(d["x_t"]).float().to(dev); t = torch.from_numpy(d["t"]).to(dev)
     with torch.inference_mode():
@@ -492,8 +529,9 @@ def test_f5_denoiser_mfma_fp6_kernel(golden_dir, dev, ops):
         b1 = den(x_t, t=t); b2 = den(x_t, t=t)
         functional.reset_net(den)
         den.conv_impl_request = 'auto'
-    assert float((a1 - torch.from_numpy(d["logits"]).to(dev)).abs().max()) <= 1e-5
-    assert float((a1 - b1).abs().max()) <= 1e-6 and float((a2 - b2).abs().max()) <= 1e-6
+    wl = torch.from_numpy(d["logits"]).to(dev)
+    assert bool(((a1 - wl).abs() <= (2e-6 * (1.0 + wl.abs()) if trained(tag) else 1e-5)).all())
+    assert bool(((a1 - b1).abs() <= 1e-6 * (1.0 + b1.abs())).all()) and bool(((a2 - b2).abs() <= 1e-6 * (1.0 + b2.abs())).all())
     assert not torch.equal(a1, a2), "second call starts from the carried membrane potentials"
 
 
@@ -532,6 +570,82 @@ def test_fp6v2_kernel_bit_equal_to_the_exact_kernels(dev, ops, B, hw):
     assert all(int(v[0]) == 0 and int(v[2 + cap:].abs().sum()) == 0 for k, v in ops._FLAG_DEFAULT.items() if k[0] == "den"), \
         "live counter, overflow bitmap and hand-over ticket come back clean"
     parity(f"fp6v2_vs_fp6_B{B}_{hw}x{hw}", neuron_steps=total, spike_mismatches=mism)
+
+
+@pytest.mark.parametrize("Cout,Cin", [(128, 64), (256, 512)])
+def test_mfma_kernels_wide_dynamic_range_weights(dev, ops, Cout, Cin):
+    """The one regime the exactness claim of the MFMA kernels has a caveat for: weights far below their channel's
+    maximum are rounded at 2^-29 (fp6 digits) / 2^-30 (int8 digits) of that maximum.  Weights here span 2^-20 .. 1 of the channel
+    maximum log-uniformly (synthetic N(0, sigma) weights span ~2^-8), one channel is all but dead (largest weight 1e-12), one has
+    a single outlier 2^18 above the rest, BatchNorm scales reach +-28.  Claims checked:
+      * fp6v2 (four digits + certification + exact repair) == the six-plane fp6 kernel, bit for bit (same quantised weights);
+      * each MFMA family differs from the fp64 direct kernel (TRUE fp32 weights, fp64 sums) only at neuron-steps whose exact
+        membrane potential lies within the quantisation bound of the threshold:  |h - 1| <= |a| * n_active * 2^-29 * max|w_c|
+        (+ fp32 round-off), n_active = active inputs of the row -- and the spikes are the exact arithmetic's ON THE QUANTISED
+        weights (CPU oracle in fp64 on rint(w * 2^s) / 2^s), which is the contract."""
+    from spkdiff.ops import IN_PTC, MODE_LIF
+    g = torch.Generator().manual_seed(77 + Cout)
+    B, H, W = 6, 7, 7
+    mag = torch.exp2(-20.0 * torch.rand(Cout, Cin, 3, 3, generator=g))
+    w = mag * torch.sign(torch.rand(Cout, Cin, 3, 3, generator=g) - 0.5) * (0.02 + 0.3 * torch.rand(Cout, 1, 1, 1, generator=g))
+    w[3] *= 1e-12 / w[3].abs().max()                                   # a near-dead channel
+    w[5] *= 2.0 ** -18
+    w[5, 7, 1, 1] = 0.4                                                # one outlier 2^18 above the rest of its channel
+    bias = (torch.rand(Cout, generator=g) - 0.5) * 0.2
+    a = (torch.rand(Cout, generator=g) - 0.3) * 40.0
+    b = (torch.rand(Cout, generator=g) - 0.2) * 1.5
+    spikes = (torch.rand(16, B, Cin, H, W, generator=g) < 0.05).float()
+    wd, biasd, ad, bd, sd = w.to(dev), bias.to(dev), a.to(dev), b.to(dev), spikes.to(dev)
+    o2 = ops.den_conv3x3_mfma_fp6v2(ops.spikes_to_s32(sd), ops.den_pack_weight_fp6v2(wd, biasd), Cout, bn_a=ad, bn_b=bd)
+    o1 = ops.den_conv3x3_mfma_fp6(ops.spikes_to_c4(sd), ops.den_pack_weight_fp6(wd, biasd), Cout, bn_a=ad, bn_b=bd)
+    x_c = ops.spikes_to_ptc(sd, chunk=32)
+    o8 = ops.den_conv3x3_mfma(x_c, ops.den_pack_weight_i8(wd, biasd), Cout, mode=MODE_LIF, bn_a=ad, bn_b=bd)
+    od = ops.conv_fused(x_c, ops.pack_conv_weight(wd, False), biasd, in_kind=IN_PTC, T=16, mode=MODE_LIF, k=3, stride=1, pad=1,
+                        bn_a=ad, bn_b=bd, want_f32=True)['f32']
+    s_v2, s_fp6, s_i8, s_dir = (ops.s32_to_spikes(o2).cpu(), ops.c4_to_spikes(o1).cpu(), ops.ptc_to_spikes(o8).cpu(), od.cpu())
+    assert torch.equal(s_v2, s_fp6), "fp6v2 == six-plane kernel (same quantised weights): bit for bit"
+
+    # CPU: exact pre-activations for the true weights and for the two quantisations, the reference's fp32 BN (fma form) and LIF
+    def spikes_of(wq):
+        y = torch.nn.functional.conv2d(spikes.flatten(0, 1).double(), wq.double(), bias.double(), 1, 1).float()
+        z = (y.double() * a.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1)).float().view(16, B, Cout, H, W)
+        v = torch.zeros_like(z[0]); out = []; hs = []
+        for t in range(16):
+            h = v + (z[t] - v) * 0.5
+            sp = h >= 1.0
+            hs.append(h); out.append(sp.float()); v = torch.where(sp, torch.zeros_like(h), h)
+        return torch.stack(out), torch.stack(hs)
+
+    def quantise(bits):
+        m = w.flatten(1).abs().amax(1)
+        e = torch.ceil(torch.log2(m.double())).clamp_min(-200)           # m <= 2^e  (frexp: m = f 2^e, f in [0.5, 1))
+        e = torch.where(torch.exp2(e) == m.double(), e + 1, e)
+        sh = (bits - e).view(-1, 1, 1, 1)
+        return (torch.round(w.double() * torch.exp2(sh)) / torch.exp2(sh)).float()
+    s_true, h_true = spikes_of(w)
+    n_act = torch.nn.functional.conv2d(spikes.flatten(0, 1), torch.ones(1, Cin, 3, 3), None, 1, 1).view(16, B, 1, H, W)
+    wmax = w.flatten(1).abs().amax(1).view(1, 1, Cout, 1, 1)
+    rep = {}
+    for name, got, bits in (("fp6", s_fp6, 29), ("i8", s_i8, 30), ("direct", s_dir, None)):
+        if bits is None:
+            want, bound = s_true, torch.zeros_like(h_true)
+        else:
+            want, _ = spikes_of(quantise(bits))
+            bound = a.abs().view(1, 1, Cout, 1, 1) * n_act * wmax * 2.0 ** -bits
+        bad_q = got != want                                                 # vs the exact arithmetic on the kernel's own weights
+        bad_t = got != s_true                                               # vs the exact arithmetic on the true weights
+        # a decision may differ from the true-weight result only after some step came within the bound of the threshold
+        near = ((h_true - 1.0).abs() <= 2.0 * bound + 4e-6 * (1.0 + h_true.abs())).float().cummax(0).values.bool()
+        rep[name] = dict(vs_own_weights=int(bad_q.sum()), vs_true_weights=int(bad_t.sum()),
+                         unexplained=int((bad_t & ~near).sum()), near=int(near.sum()))
+        assert int((bad_t & ~near).sum()) == 0, (name, rep[name])
+        # against the exact arithmetic on its own weights a kernel may differ only inside fp32 round-off of the threshold
+        tiny = ((h_true - 1.0).abs() <= 4e-6 * (1.0 + h_true.abs()) + 2.0 * bound).float().cummax(0).values.bool()
+        assert int((bad_q & ~tiny).sum()) == 0, (name, rep[name])
+    print(f"wide dynamic range {Cout}x{Cin}: firing {float(s_true.mean()):.3f}; mismatching neuron-steps of {s_true.numel()}:", rep)
+    parity(f"mfma_wide_dynamic_range_{Cout}x{Cin}", neuron_steps=int(s_true.numel()), firing=float(s_true.mean()), **rep)
+    assert 0.002 < float(s_true.mean()) < 0.6
+    assert bool((s_fp6[:, :, 3] == s_dir[:, :, 3]).all()), "the near-dead channel: its bias and BatchNorm terms decide alone"
 
 
 def _cpu_need_lists(unmasked, u, t, active, R):
@@ -1733,15 +1847,16 @@ def test_get_data_for_diff_matches_reference_fixture_f12(golden_dir, dev):
     assert all(torch.equal(a, b) for a, b in zip(got, live))
 
 
-def test_f13_sample_100_steps_and_decode_vs_reference_fixture(golden_dir, dev):
+@pytest.mark.parametrize("tag", ["mnist", "mnist_trained"])
+def test_f13_sample_100_steps_and_decode_vs_reference_fixture(golden_dir, dev, tag):
     """The benchmark's own length, end to end (VERDICT r1 missing #3): 100 reverse steps, B = 8, noise drawn on the host in
     the reference's order under torch.manual_seed(1313), then the decode glue of R/main.py:388-401 down to uint8.  F13
     holds what the REAL reference classes produced (R/snn_model/vq_diffusion.py:103-142): tokens must be equal, decoded
     pixels within 1e-4, uint8 equal away from truncation edges."""
     from snn_model.vq_diffusion import AbsorbingDiffusion
-    d = load(golden_dir, "f13_sample_100_steps.npz")
-    den, sdd = build_den(synth.MNIST, dev)
-    model, sdv = build_vae(synth.MNIST, dev)
+    d = load(golden_dir, "f13t_sample_trained.npz" if trained(tag) else "f13_sample_100_steps.npz")
+    den, sdd = build_den(synth.MNIST, dev, weights='trained' if trained(tag) else 'synth')
+    model, sdv = build_vae(synth.MNIST, dev, weights='trained' if trained(tag) else 'synth')
     assert synth.state_checksum(sdd) == str(d["weights_crc_den"]) and synth.state_checksum(sdv) == str(d["weights_crc_vae"])
     B, steps = int(d["B"]), int(d["steps"])
     out = {}
@@ -1758,7 +1873,7 @@ def test_f13_sample_100_steps_and_decode_vs_reference_fixture(golden_dir, dev):
     safe = d["u8_edge_dist"] > 1e-3
     u8_bad = int((u8.cpu().numpy()[safe] != d["u8"][safe]).sum())
     u8_bad_all = int((u8.cpu().numpy() != d["u8"]).sum())
-    parity("f13_sample_100_steps_decode", token_mismatches=n_bad, tokens=int(want.numel()), pred_max_abs_err=err,
+    parity("f13_sample_100_steps_decode_" + tag, token_mismatches=n_bad, tokens=int(want.numel()), pred_max_abs_err=err,
            u8_mismatches_away_from_edges=u8_bad, u8_mismatches_all=u8_bad_all, pixels=int(d["u8"].size),
            elimination_same_tokens=bool(torch.equal(out[True], tok)))
     assert n_bad == 0, "100-step trajectory differs from the reference"
@@ -1955,38 +2070,109 @@ def test_timed_configuration_philox_graph_vs_oracle_on_dumped_noise(dev, ops, B,
 @pytest.mark.slow
 def test_bench_line_job_full_size_vs_oracle(dev, ops):
     """The bench line's OWN job -- B = 256 x 100 reverse steps, Philox noise, one hipGraph replay, dense and elimination + lists --
-    against the CPU oracle on the dumped noise: all 12 544 tokens, then decode within 1e-4 (the other timed-form
-    tests stop at B = 8 x 100 and B = 256 x 10).  Minutes of host work: SPKDIFF_RUN_SLOW=1, once per round through gpurun
-    (tools/full_size_oracle.sh; log under profiles/)."""
+    against the CPU oracle on the dumped noise: all 12 544 tokens (the other timed-form tests stop at
+    B = 8 x 100 and B = 256 x 10).  Minutes of host work: SPKDIFF_RUN_SLOW=1, once per round through gpurun
+    (tools/full_size_oracle.sh; log under profiles/).
+
+    At this size -- 2.4e10 neuron-steps -- the oracle's own arithmetic shows: it convolves with oneDNN in fp32 (an accumulation
+    order nobody controls), the HIP kernels return the correctly rounded EXACT dot product, and a handful of membrane potentials
+    land within an ulp or two of the threshold, where the two decide a spike differently (SURVEY.md §7 "threshold discontinuity":
+    the reference flips such spikes against its own fp64 evaluation).  Round 4 measured 2 of 12 544 tokens.  The test therefore
+    does not stop at the count: every image whose tokens differ is traced to the FIRST reverse step at which the two
+    trajectories part (samples are independent, the inputs of that step are identical on both sides), and there
+      (1) the HIP logits equal the oracle's logits with every convolution evaluated exactly (fp64 sums, one rounding),
+      (2) the fp32 oracle differs from that exact evaluation in at least one spike, and only at neuron-steps whose exact membrane
+          potential is within 1e-5 of the threshold (its own fragile set),
+      (3) the token update on the exact logits with the dumped noise gives the HIP tokens of that step.
+    I.e. the HIP path is the exact arithmetic; the difference is the reference's rounding, not the kernels'."""
     import time
     from snn_model.vq_diffusion import AbsorbingDiffusion
     den, sd = build_den(synth.MNIST, dev)
     model, sd_v = build_vae(synth.MNIST, dev)
-    B, steps = 256, 100
+    B, steps, K = 256, 100, 128
     got, key = {}, None
     for name, skip in (("dense", False), ("elim+lists", True)):
-        ab = AbsorbingDiffusion(den, mask_id=128)
+        ab = AbsorbingDiffusion(den, mask_id=K)
         ab.n_samples, ab.skip_untouched, ab.list_positions = B, skip, skip
         torch.manual_seed(42)
         key = ab._philox_key()
         torch.manual_seed(42)
         got[name] = ab.sample(temp=1.0, sample_steps=steps)
         assert len(ab._graphs) == 1
+    assert torch.equal(got["dense"], got["elim+lists"])
+    # the same job step by step (eager launches, same Philox draws) with every step's state recorded
+    ab = AbsorbingDiffusion(den, mask_id=K)
+    ab.n_samples, ab.use_graph = B, False
+    rec_h = []
+    torch.manual_seed(42)
+    tok_e = ab.sample(temp=1.0, sample_steps=steps, record=rec_h)
+    assert torch.equal(tok_e, got["dense"]), "graph replay == eager launches"
+    rec_h = [(t, x.cpu(), u.cpu(), lg.cpu()) for t, x, u, lg in rec_h]
+    HW = 49
+    noise_cache = {}
+
+    def noise(t):
+        u, q = ops.philox_noise(key, (steps - t) * (1 << 40), B, HW, K, dev)
+        noise_cache[t] = (u.cpu().view(B, 1, 7, 7), q.cpu())
+        return noise_cache[t]
+    rec_o = []
     t0 = time.time()
-    want = _philox_oracle_tokens(ops, dev, sd, key, B, steps, 7)
+    want = ref.absorbing_sample(sd, B, K, 1.0, steps, 7, 16, noise=noise, record=rec_o)
     dt = time.time() - t0
-    bad = {n: int((t.cpu() != want).sum()) for n, t in got.items()}
+    bad = int((got["dense"].cpu() != want).sum())
+    bad_images = sorted(set(torch.nonzero((got["dense"].cpu() != want).flatten(1).any(1)).flatten().tolist()))
+    report = []
+    for b in bad_images:
+        k = next(i for i in range(steps) if not torch.equal(rec_h[i][1][b], rec_o[i][1][b]))
+        t = rec_h[k][0]
+        x_in = rec_h[k - 1][1][b:b + 1] if k > 0 else torch.full((1, 1, 7, 7), K, dtype=torch.int64)
+        un_in = rec_h[k - 1][2][b:b + 1] if k > 0 else torch.zeros((1, 1, 7, 7), dtype=torch.bool)
+        if k > 0:
+            assert torch.equal(x_in, rec_o[k - 1][1][b:b + 1]), "identical inputs at the step where the trajectories part"
+        tt = torch.full((1,), t, dtype=torch.long)
+        with torch.inference_mode():
+            lg32, lay32 = ref.denoiser_forward(x_in.float(), tt, sd, 16, return_layers=True)
+            lgx, layx = ref.denoiser_forward(x_in.float(), tt, sd, 16, return_layers=True, exact_conv=True)
+            if all(torch.equal(a[0], c[0]) for a, c in zip(lay32, layx)) and k > 0:
+                # (oneDNN may block a batch of one differently from the batch of 256 the trajectory ran with: repeat the fp32
+                #  evaluation on the whole batch of that step and take this image's slice)
+                _, lay_all = ref.denoiser_forward(rec_o[k - 1][1].float(), torch.full((B,), t, dtype=torch.long), sd, 16,
+                                                  return_layers=True)
+                lay32 = [(a[:, b:b + 1].clone(), y[:, b:b + 1].clone()) for a, y in lay_all]
+                del lay_all
+        lg_hip = rec_h[k][3][b:b + 1]
+        d_hip = float((lg_hip - lgx).abs().max())
+        assert bool(((lg_hip - lgx).abs() <= 2e-6 * (1.0 + lgx.abs())).all()), f"image {b}: HIP logits != exact-convolution oracle"
+        flips, worst = 0, 0.0
+        for li, ((s32, _), (sx, yx)) in enumerate(zip(lay32, layx), 1):
+            diff = s32 != sx
+            if bool(diff.any()):
+                v = torch.zeros_like(yx[0]); hs = []
+                for ts in range(16):
+                    h = v + (yx[ts] - v) * 0.5
+                    hs.append(h); v = torch.where(h >= 1.0, torch.zeros_like(h), h)
+                m = (torch.stack(hs) - 1.0).abs()[diff]
+                first = int(torch.nonzero(diff.flatten(1).any(1)).min())           # earlier flips change later inputs: first step
+                flips += int(diff.sum()); worst = max(worst, float((torch.stack(hs)[first] - 1.0).abs()[diff[first]].max()))
+                assert float((torch.stack(hs)[first] - 1.0).abs()[diff[first]].max()) <= 1e-5, \
+                    f"image {b} conv{li}: the fp32 oracle flips a spike that is NOT near the threshold"
+                break                                                              # later layers see different inputs
+        assert flips > 0, f"image {b}: tokens differ although the fp32 oracle and the exact evaluation agree on every spike"
+        u, q = noise_cache[t]
+        xs, _ = ref.p_sample_step(x_in, un_in, lgx.permute(0, 2, 3, 1), t, 1.0, u[b:b + 1], q[b * HW:(b + 1) * HW])
+        assert torch.equal(xs, rec_h[k][1][b:b + 1]), f"image {b}: exact logits + dumped noise != HIP tokens of step {t}"
+        report.append(dict(image=b, reverse_step=t, oracle_spike_flips_in_first_differing_layer=flips,
+                           flipped_neuron_margin=worst, hip_vs_exact_logits=d_hip))
+    # decode parity on the HIP tokens themselves (the oracle decodes the same tokens)
     pred, u8 = model.decode_tokens(got["dense"].reshape(B, 7, 7))
-    opred = ref.decode_tokens(want.reshape(B, 7, 7), sd_v, 16)
+    opred = ref.decode_tokens(got["dense"].cpu().reshape(B, 7, 7), sd_v, 16)
     err = float((pred.cpu() - opred).abs().max())
-    ou8 = ref.to_uint8(opred)
-    px = int((u8.cpu().numpy() != ou8).sum())
-    print(f"FULL SIZE B={B} x {steps} steps (Philox + hipGraph): token mismatches vs oracle {bad} of {want.numel()}; "
-          f"decode max abs err {err:.2e}; uint8 pixels differing {px} of {ou8.size}; oracle took {dt:.0f} s on "
-          f"{torch.get_num_threads()} threads")
-    parity("bench_line_job_full_size_vs_oracle", token_mismatches=bad, tokens=int(want.numel()), pixel_max_abs_err=err,
-           uint8_pixels_differing=px, oracle_seconds=dt)
-    assert all(v == 0 for v in bad.values()), bad
+    print(f"FULL SIZE B={B} x {steps} steps (Philox + hipGraph, dense == elimination + lists): {bad} of {want.numel()} tokens differ "
+          f"from the fp32 CPU oracle, in {len(bad_images)} image(s); each traced to the oracle's own rounding: {report}; decode of the "
+          f"HIP tokens vs oracle decode: max abs err {err:.2e}; oracle took {dt:.0f} s on {torch.get_num_threads()} threads")
+    parity("bench_line_job_full_size_vs_oracle", token_mismatches_vs_fp32_oracle=bad, images_affected=len(bad_images),
+           tokens=int(want.numel()), traced_to_oracle_rounding=report, decode_max_abs_err=err, oracle_seconds=dt)
+    assert bad <= 16 and len(bad_images) <= 4, "a handful at most (2.4e10 neuron-steps; round 4 measured 2 tokens in 1-2 images)"
     assert err <= 1e-4
 
 
@@ -2334,42 +2520,44 @@ def test_sampler_with_and_without_the_fused_step_tail(dev, cfgname, L):
     assert torch.equal(lg, rec[4][3])
 
 
-def test_fp6v2_staggered_form_bit_equal(dev):
-    """The staggered (one-chunk-lag, three LDS slots) form of the fp6v2 main launch -- a measured, slower alternative kept behind
-    SPKDIFF_V2_LAG=1 (csrc/den_mfma_fp6v2.hip) -- gives the default form's spikes and counts bit for bit.  The library reads the
-    switch once per process, so the check runs in a child process."""
-    import subprocess
-    import sys
-    code = r'''
-import os, sys, torch
-sys.path[:0] = [os.path.join(os.environ["SPK_ROOT"], "spiking-diffusion_amd"), os.environ["SPK_ROOT"]]
-from spkdiff import ops
-dev = torch.device("cuda")
-torch.manual_seed(3)
-res = []
-for B, Cout, Cin in ((37, 128, 64), (256, 256, 128), (19, 512, 256), (64, 256, 512)):
-    w = (torch.rand(Cout, Cin, 3, 3, device=dev) - 0.5) * 0.05
-    bias = (torch.rand(Cout, device=dev) - 0.5) * 0.1
-    x = (torch.rand(16, B, Cin, 7, 7, device=dev) < 0.06).float()
-    a = torch.rand(Cout, device=dev) * 8 + 2; b = torch.rand(Cout, device=dev) * 0.8
-    y, c = ops.den_conv3x3_mfma_fp6v2(ops.spikes_to_s32(x), ops.den_pack_weight_fp6v2(w, bias), Cout, bn_a=a, bn_b=b, want_counts=True)
-    torch.cuda.synchronize()
-    res.append((y.cpu(), c.cpu()))
-torch.save(res, sys.argv[1])
-'''
-    import tempfile
-    outs = []
-    with tempfile.TemporaryDirectory() as d:
-        for lag in ("0", "1"):
-            path = os.path.join(d, f"lag{lag}.pt")
-            env = dict(os.environ, SPKDIFF_V2_LAG=lag, SPK_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-            r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
-            assert r.returncode == 0, r.stderr[-2000:]
-            outs.append(torch.load(path))
+def test_fp6v2_staggered_form_bit_equal(dev, ops):
+    """The measured alternatives of the fp6v2 main launch kept behind spk_set_option (include/spkdiff.h) -- the staggered
+    (one-chunk-lag, three LDS slots) form "v2_lag", one and three waves per SIMD "v2_waves" = 4 / 12 -- give the default form's
+    spikes and counts bit for bit.  The library reads no environment variable: the host switches between calls."""
+    from spkdiff import _lib
+    torch.manual_seed(3)
+    cases = []
+    for B, Cout, Cin in ((37, 128, 64), (256, 256, 128), (19, 512, 256), (64, 256, 512)):
+        w = (torch.rand(Cout, Cin, 3, 3, device=dev) - 0.5) * 0.05
+        bias = (torch.rand(Cout, device=dev) - 0.5) * 0.1
+        x = (torch.rand(16, B, Cin, 7, 7, device=dev) < 0.06).float()
+        a = torch.rand(Cout, device=dev) * 8 + 2
+        b = torch.rand(Cout, device=dev) * 0.8
+        cases.append((ops.spikes_to_s32(x), ops.den_pack_weight_fp6v2(w, bias), Cout, a, b))
+
+    def run():
+        out = []
+        for xs, pk, Cout, a, b in cases:
+            y, c = ops.den_conv3x3_mfma_fp6v2(xs, pk, Cout, bn_a=a, bn_b=b, want_counts=True)
+            out.append((y.clone(), c.clone()))
+        torch.cuda.synchronize()
+        return out
+    assert (_lib.get_option("v2_waves"), _lib.get_option("v2_lag")) == (8, 0)
+    with pytest.raises(NotImplementedError):
+        _lib.set_option("no_such_option", 1)
+    base = run()
     n = 0
-    for (y0, c0), (y1, c1) in zip(*outs):
-        assert torch.equal(y0, y1) and torch.equal(c0, c1)
-        n += y0.numel()
+    try:
+        for name, value in (("v2_lag", 1), ("v2_waves", 4), ("v2_waves", 12)):
+            _lib.set_option(name, value)
+            got = run()
+            _lib.set_option(name, 8 if name == "v2_waves" else 0)
+            for (y0, c0), (y1, c1) in zip(base, got):
+                assert torch.equal(y0, y1) and torch.equal(c0, c1), (name, value)
+                n += y0.numel()
+    finally:
+        _lib.set_option("v2_waves", 8)
+        _lib.set_option("v2_lag", 0)
     parity("fp6v2_staggered_form", bytes_compared=n, mismatches=0)
 
 

@@ -289,3 +289,67 @@ def test_f13_sample_100_steps_and_decode(golden_dir, vae_mnist, den_mnist):
         u8, tok = ref.sample_images(vae_mnist, den_mnist, int(d["B"]), 128, float(d["temp"]), int(d["steps"]), 7, 16)
     assert torch.equal(tok, torch.from_numpy(d["tokens"]))
     assert np.array_equal(u8, d["u8"])
+
+
+# ------------------------------------------------------------------------------------------------- round 4: TRAINED weights
+@pytest.fixture(scope="module")
+def trained_sd():
+    return synth.trained_state("vqvae"), synth.trained_state("denoiser")
+
+
+def test_trained_checkpoint_is_a_reference_checkpoint(trained_sd):
+    """checkpoints/mnist_strokes_*.npz: plain state_dicts with the reference's key set (R/main.py:199,286) --
+    oracle/gen_golden_trained.py loads them strictly into the real classes -- and what makes them different from the synthetic
+    N(0, sigma) weights: heavy tails and a wide dynamic range inside a channel."""
+    sdv, sdd = trained_sd
+    assert set(sdv) == set(synth.synth_vqvae_state(synth.MNIST)) and set(sdd) == set(synth.synth_denoiser_state(synth.MNIST))
+    for k, v in synth.synth_denoiser_state(synth.MNIST).items():
+        assert sdd[k].shape == v.shape and sdd[k].dtype == v.dtype, k
+    w = sdd["conv4.0.weight"].flatten(1)
+    kurt = float(((w - w.mean()) ** 4).mean() / w.var() ** 2)
+    assert kurt > 4.0, "trained conv4 weights are heavy-tailed (uniform init: 1.8)"
+    below = float((w.abs() < w.abs().amax(1, keepdim=True) / 64).float().mean())
+    assert below > 0.05, "a good share of the weights sits below 2^-6 of its channel's maximum (the fixed-point rounding regime)"
+
+
+def test_f3t_f4t_trained_encode_decode(golden_dir, trained_sd):
+    sdv, _ = trained_sd
+    d = load(golden_dir, "f3t_encode_mnist_trained.npz")
+    assert synth.state_checksum(sdv) == str(d["weights_crc"])
+    images = torch.from_numpy(d["images"])
+    assert torch.equal(images, synth.stroke_images(images.shape[0], seed=777) - 0.5), "the fixture's images are stroke images"
+    x = images.unsqueeze(0).repeat(16, 1, 1, 1, 1)
+    with torch.inference_mode():
+        e, xr, idx = ref.snn_vqvae_forward(x, sdv)
+    assert torch.equal(idx, torch.from_numpy(d["indices"])) and torch.equal(xr, torch.from_numpy(d["x_recon"]))
+    assert torch.equal(e, unpack(d["e_bits"], d["e_shape"]))
+    assert float(d["recon_mse"]) < 0.02, "the trained VQ-VAE reconstructs its data"
+    d4 = load(golden_dir, "f4t_decode_mnist_trained.npz")
+    with torch.inference_mode():
+        pred = ref.decode_tokens(torch.from_numpy(d4["tokens"]), sdv, 16)
+    assert torch.equal(pred, torch.from_numpy(d4["pred"])) and np.array_equal(ref.to_uint8(pred), d4["u8"])
+
+
+def test_f5t_trained_denoiser_and_exact_convolution_form(golden_dir, trained_sd):
+    _, sdd = trained_sd
+    d = load(golden_dir, "f5t_denoiser_mnist_trained.npz")
+    assert synth.state_checksum(sdd) == str(d["weights_crc"])
+    x_t, t = torch.from_numpy(d["x_t"]).float(), torch.from_numpy(d["t"])
+    with torch.inference_mode():
+        logits, layers = ref.denoiser_forward(x_t, t, sdd, 16, return_layers=True)
+        lx, layers_x = ref.denoiser_forward(x_t, t, sdd, 16, return_layers=True, exact_conv=True)
+    assert torch.equal(logits, torch.from_numpy(d["logits"]))
+    for i, (s, _) in enumerate(layers, 1):
+        assert torch.equal(s, unpack(d[f"s{i}_bits"], d[f"s{i}_shape"]))
+    # the exact-convolution form (the HIP kernels' contract) decides every spike of this fixture like oneDNN's fp32 does
+    assert all(torch.equal(a[0], b[0]) for a, b in zip(layers, layers_x))
+    assert bool(((logits - lx).abs() <= 2e-6 * (1 + lx.abs())).all())
+
+
+def test_f13t_trained_sample_100_steps(golden_dir, trained_sd):
+    sdv, sdd = trained_sd
+    d = load(golden_dir, "f13t_sample_trained.npz")
+    torch.manual_seed(int(d["seed"]))
+    with torch.inference_mode():
+        u8, tok = ref.sample_images(sdv, sdd, int(d["B"]), 128, float(d["temp"]), int(d["steps"]), 7, 16)
+    assert torch.equal(tok, torch.from_numpy(d["tokens"])) and np.array_equal(u8, d["u8"])
