@@ -17,8 +17,22 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 // bit s set, right by 32 - s = left by s for the others) and merged under the keep mask (v_bfi) -- instead of a select between
 // two shift-and-mask expressions, which hipcc compiled as two exec-masked branches per round (45 vector + 24 scalar
 // instructions per transpose; now 14).  Bits 16..31 of the result are garbage (rotated-out blocks): callers use the low half.
+#ifndef SPK_TR16_OLD
+#define SPK_TR16_OLD 0          // 1: the rounds 1-3 form (a select between two shift-and-mask expressions per round), for A/B runs
+#endif
 __device__ __forceinline__ unsigned spk_transpose16_rows(unsigned x, int lane) {
   unsigned y;
+#if SPK_TR16_OLD
+  y = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(x, 0x140, 0xF, 0xF, true), 0x141, 0xF, 0xF, true);
+  x = (lane & 8) ? (((y >> 8) & 0x00FFu) | (x & 0xFF00u)) : ((x & 0x00FFu) | ((y & 0x00FFu) << 8));
+  y = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
+  x = (lane & 4) ? (((y >> 4) & 0x0F0Fu) | (x & 0xF0F0u)) : ((x & 0x0F0Fu) | ((y & 0x0F0Fu) << 4));
+  y = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);
+  x = (lane & 2) ? (((y >> 2) & 0x3333u) | (x & 0xCCCCu)) : ((x & 0x3333u) | ((y & 0x3333u) << 2));
+  y = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);
+  x = (lane & 1) ? (((y >> 1) & 0x5555u) | (x & 0xAAAAu)) : ((x & 0x5555u) | ((y & 0x5555u) << 1));
+  return x;
+#else
   // (opaque copy of the lane id: the three per-lane constants of a round are recomputed here -- three vector instructions --
   //  instead of being hoisted out of the caller's loops, where eight of them stayed live across the K loop: 256 registers + spills)
   int ln = lane;
@@ -41,6 +55,7 @@ __device__ __forceinline__ unsigned spk_transpose16_rows(unsigned x, int lane) {
   SPK_TR16_ROUND(1, 0x5555u);
 #undef SPK_TR16_ROUND
   return x;
+#endif
 }
 
 // CU count of the current device, queried once (a constant of the machine; keeps device queries out of hipGraph capture)

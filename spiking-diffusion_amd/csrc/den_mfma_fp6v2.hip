@@ -130,6 +130,10 @@ struct V2Args {
                                 // Round 2 measured this 1.3 % slower; with the second certification stage (half the repairs) it is
                                 // 1.6 % FASTER (90.3 / 90.2 against 91.2 / 92.4 ms; both changes: 89.3 / 89.4).  0: two launches
 #endif
+#ifndef SPK_V2_NMAX_LDS
+#define SPK_V2_NMAX_LDS 1       // the first certification stage reads max_t n_t of its position from LDS (one atomic per (position, step)
+                                // in the per-item count pass) instead of sixteen counts + twelve v_max per tile and lane.  0: rounds 2-3
+#endif
 #ifndef SPK_V2_PF
 #define SPK_V2_PF 6             // A fragments requested this many steps ahead of the MFMA that consumes them
 #endif
@@ -522,7 +526,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
         s_row[e] = sum;
         // the certification's first stage only needs max_t n_t of a position: one LDS atomic here instead of four 16-byte reads
         // and twelve v_max per tile and lane in the scan (the second stage, a few percent of the tiles, reads the sixteen counts)
-        atomicMax(&s_nmax[pp], sum);
+        if (SPK_V2_NMAX_LDS) atomicMax(&s_nmax[pp], sum);
       }
       __syncthreads();
     }
@@ -567,7 +571,15 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
         }
       }
       int nmax_rec = 0;
-      if constexpr (REC) nmax_rec = s_nmax[2 * (wave + NWV * i) + half];     // (position within the item)
+      if constexpr (REC && SPK_V2_NMAX_LDS) nmax_rec = s_nmax[2 * (wave + NWV * i) + half];     // (position within the item)
+      if constexpr (REC && !SPK_V2_NMAX_LDS) {
+        const v4i* rp = reinterpret_cast<const v4i*>(s_row + (2 * (wave + NWV * i) + half) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const v4i c4 = rp[q];
+          cntv[4 * q] = c4[0]; cntv[4 * q + 1] = c4[1]; cntv[4 * q + 2] = c4[2]; cntv[4 * q + 3] = c4[3];
+        }
+      }
       if constexpr (USE_D4) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -593,7 +605,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
           const v2f p0 = {acc[i][0][r2], acc[i][0][r2 + 1]}, p1 = {acc[i][1][r2], acc[i][1][r2 + 1]};
           const v2f q4 = __builtin_elementwise_fma(p0, (v2f){1024.0f, 1024.0f}, p1);
           const v2f z2 = __builtin_elementwise_fma(q4, (v2f){Ac4, Ac4}, (v2f){Bc, Bc});
-          if constexpr (!REC) nmax = max(nmax, max(cntv[r2], cntv[r2 + 1]));
+          if constexpr (!REC || !SPK_V2_NMAX_LDS) nmax = max(nmax, max(cntv[r2], cntv[r2 + 1]));
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const float z = z2[e];
@@ -615,7 +627,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
           // proportional to them).  Every lane re-scans (the branch is wave-uniform); accumulators and counts are still live.
           float v2 = 0.f, dh = 0.f;
           bool f2 = false;
-          if constexpr (REC) {
+          if constexpr (REC && SPK_V2_NMAX_LDS) {
             const v4i* rp = reinterpret_cast<const v4i*>(s_row + (2 * (wave + NWV * i) + half) * 16);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
