@@ -130,6 +130,15 @@ struct V2Args {
                                 // Round 2 measured this 1.3 % slower; with the second certification stage (half the repairs) it is
                                 // 1.6 % FASTER (90.3 / 90.2 against 91.2 / 92.4 ms; both changes: 89.3 / 89.4).  0: two launches
 #endif
+#ifndef SPK_V2_MASKSTORE
+#define SPK_V2_MASKSTORE 0      // 1: the sixteen spike decisions of a tile stay what the compare makes them -- 64-bit lane masks in
+                                // SGPRs, i.e. ALREADY transposed -- and reach the lanes that store them through 32 v_writelane + one
+                                // v_permlane16_swap instead of a per-lane word (24 instructions) + spk_transpose16_rows (14 + the
+                                // exchanges).  Built, bit-equal on every fp6v2 test, and measured (round 4, three alternating passes on
+                                // one box): 90.47 / 90.73 / 90.46 ms per dense reverse process against 90.41 / 90.35 / 90.15 -- 0.2 %
+                                // SLOWER (a v_writelane costs a full vector issue slot plus the hazard nop hipcc puts around inline
+                                // assembly): not adopted
+#endif
 #ifndef SPK_V2_NMAX_LDS
 #define SPK_V2_NMAX_LDS 1       // the first certification stage reads max_t n_t of its position from LDS (one atomic per (position, step)
                                 // in the per-item count pass) instead of sixteen counts + twelve v_max per tile and lane.  0: rounds 2-3
@@ -187,6 +196,36 @@ __device__ __forceinline__ void store_tile_spikes(uint8_t* out, uint8_t* out_cnt
                                                   long long cnt_base, bool ok) {
   const unsigned bitsv = spk_transpose16_rows(mybits, lane);
   if (out_cnt && ok) out_cnt[cnt_base + (lane & 31)] = (uint8_t)__popc(mybits);
+  if (ok) {
+    uint2 o;
+    o.x = spread8(bitsv & 0xffu);
+    o.y = spread8((bitsv >> 8) & 0xffu);
+    *reinterpret_cast<uint2*>(out + rec_base + (lane & 15) * 16 + 8 * ((lane >> 4) & 1)) = o;
+  }
+}
+
+// The same store from the sixteen step masks of the scan (mk[t]: bit L = lane L's neuron spiked at step t; lanes 0..31 = the
+// tile's first position, 32..63 its second): lane (16 j + t) stores the 16-channel piece j of step t = bits [16 j, 16 j + 16)
+// of mk[t].  v_writelane puts the low word of mk[t] into lane t and the high word into lane 32 + t, v_permlane16_swap copies rows
+// 0 / 2 of the register into rows 1 / 3, and every lane picks its half-word.
+__device__ __forceinline__ void store_tile_masks(uint8_t* out, const unsigned long long (&mk)[16], int lane, long long rec_base,
+                                                 bool ok) {
+  unsigned x = 0;
+  // (this clang has no writelane builtin; the masks are wave-uniform values hipcc keeps in SGPRs, the lane index is a constant)
+#define SPK_WRITELANE(X, VAL, LANE) asm("v_writelane_b32 %0, %1, %2" : "+v"(X) : "s"(VAL), "i"(LANE))
+#define SPK_WL_STEP(T)                                                          \
+  do {                                                                          \
+    const unsigned lo_ = (unsigned)mk[T], hi_ = (unsigned)(mk[T] >> 32);        \
+    SPK_WRITELANE(x, lo_, T);                                                   \
+    SPK_WRITELANE(x, hi_, 32 + T);                                              \
+  } while (0)
+  SPK_WL_STEP(0); SPK_WL_STEP(1); SPK_WL_STEP(2); SPK_WL_STEP(3); SPK_WL_STEP(4); SPK_WL_STEP(5); SPK_WL_STEP(6); SPK_WL_STEP(7);
+  SPK_WL_STEP(8); SPK_WL_STEP(9); SPK_WL_STEP(10); SPK_WL_STEP(11); SPK_WL_STEP(12); SPK_WL_STEP(13); SPK_WL_STEP(14); SPK_WL_STEP(15);
+#undef SPK_WL_STEP
+#undef SPK_WRITELANE
+  typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+  const v2u_ sw = __builtin_amdgcn_permlane16_swap(x, x, false, false);       // rows 1 / 3 <- rows 0 / 2
+  const unsigned bitsv = sw[0] >> (16u * ((unsigned)(lane >> 4) & 1u));
   if (ok) {
     uint2 o;
     o.x = spread8(bitsv & 0xffu);
@@ -556,6 +595,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
         if (NACC * i + j < N_AGPR) asm volatile("" : "+a"(acc[i][j]));
       float v = 0.f, D = 0.f;
       unsigned mybits = 0;
+      unsigned long long mk[16];                          // (SPK_V2_MASKSTORE: the step masks of the four-digit scan)
       bool flg = false;
       int cntv[16];                                       // four-digit form: active inputs of this lane's rows (its position, step r)
       if constexpr (SPK_V2_DBG & 256) {
@@ -600,6 +640,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
         typedef float v2f __attribute__((ext_vector_type(2)));
         float zmax = 0.f, dmin = 3.0e38f;
         int nmax = nmax_rec;
+        bool sp[16];
 #pragma unroll
         for (int r2 = 0; r2 < 16; r2 += 2) {
           const v2f p0 = {acc[i][0][r2], acc[i][0][r2 + 1]}, p1 = {acc[i][1][r2], acc[i][1][r2 + 1]};
@@ -614,7 +655,16 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
             dmin = fminf(dmin, fabsf(h - 1.0f));
             const bool s = h >= 1.0f;
             v = s ? 0.0f : h;
-            mybits |= s ? (1u << (r2 + e)) : 0u;
+            if constexpr (SPK_V2_MASKSTORE) sp[r2 + e] = s;
+            else mybits |= s ? (1u << (r2 + e)) : 0u;
+          }
+        }
+        if constexpr (SPK_V2_MASKSTORE) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mk[r] = __builtin_amdgcn_ballot_w64(sp[r]);
+          if (a.out_cnt) {                                   // (conv5 only: the per-neuron spike counts conv6 reads)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mybits += sp[r] ? 1u : 0u;          // here: the COUNT, not the bit word
           }
         }
         flg = dmin <= SPK_V2_SPARE * fmaf(zmax, 2.5f * CERT_4EPS, fmaf((float)nmax, cT, cE));   // (10 eps for 8: a little to spare)
@@ -665,7 +715,12 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
         else atomicOr(a.flags + 2 + a.flag_cap + (n >> 5), 1u << (n & 31));
       }
       const long long rec = (((long long)b * G + g) * HW + p) * POSB;
-      store_tile_spikes(a.out, a.out_cnt, mybits, lane, rec, (((long long)b * G + g) * HW + p) * 32, listed);
+      if constexpr (SPK_V2_MASKSTORE && !USE_D4) {
+        if (a.out_cnt && listed) a.out_cnt[(((long long)b * G + g) * HW + p) * 32 + (lane & 31)] = (uint8_t)mybits;
+        store_tile_masks(a.out, mk, lane, rec, listed);
+      } else {
+        store_tile_spikes(a.out, a.out_cnt, mybits, lane, rec, (((long long)b * G + g) * HW + p) * 32, listed);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   }   // images
