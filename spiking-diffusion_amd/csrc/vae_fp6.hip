@@ -1,14 +1,19 @@
 // The spike-input layers of the spiking VQ-VAE on the block-scaled fp6 x fp4 MFMA (R/snn_model/vae_model.py:115-118 Encoder
 // conv2, :139-150 Decoder convT1 / convT2), for calls that start from the reset state.  Same arithmetic
 // contract as den_mfma_fp6v2.hip: 29-bit per-channel fixed-point weights as radix-32 digits, adjacent digits sharing an fp32
-// accumulator through the per-block scales, five digits on the matrix cores, every spike decision certified against an error
-// bound, the few neurons that come within the bound of the threshold recomputed exactly (all six digits, 64-bit sums, fp64
-// recombination, one rounding) by a tail launch.  Unflagged neurons provably emit the exact path's spikes; the result is the
-// one spk_conv_mfma_fused_fwd (int8 gather kernel) produces for the same layer.
+// accumulator through the per-block scales, every spike decision certified against an error bound, the few neurons that come
+// within the bound of the threshold recomputed exactly (all six digits, 64-bit sums, fp64 recombination, one rounding) by a
+// tail launch.  Unflagged neurons provably emit the exact path's spikes; the result is the one spk_conv_mfma_fused_fwd (int8
+// gather kernel) produces for the same layer.  Round 4: FOUR digits on the matrix cores (SPK_VT_D4: two accumulators per tile,
+// 4 / 2 instead of 5 / 3 MFMAs and weight-tile reads per tap and chunk) behind the COUNTED bound of den_mfma_fp6v2.hip -- the
+// active inputs of every input record are popcounted once per item, then per class and output position the maximum over the
+// steps of the sum over the class's taps multiplies the per-input bound of the two dropped digits.  Measured at B = 1024 (same
+// box, alternating): convT2 0.246-0.249 -> 0.222-0.228 ms, conv2 (nine taps; no longer spills) 0.118-0.127 -> 0.075-0.084 ms,
+// encode -> decode 1.41-1.43 -> 1.57-1.58 M images/s; 0 mismatches against the int8 gather kernel over 7.2e8 neuron-steps.
 //
 // What differs from the denoiser kernel is the geometry: K is small (16 .. 64 input channels = 1 or 2 chunks of 32) and the
 // spatial extent large, so ALL weight tiles of a 32-channel output group stay in LDS for the whole launch (9 taps x [pair 01,
-// pair 23] per chunk + a fifth-digit tile: 40 / 68 KB) next to the input rows of one work item.
+// pair 23] per chunk: 27 / 54 KB; the fifth-digit tiles of the packed format stay in memory) next to the input rows of one item.
 //   GEO 0  ConvTranspose2d(k3, s2, p1, op1): four sub-pixel classes (oy % 2, ox % 2) with 1 / 2 / 2 / 4 contributing taps; the
 //          rows of a 32-row MFMA tile are two consecutive positions of ONE class x 16 time steps, so a tile's tap list is
 //          compile-time.  Item = an image (or its upper / lower half) : class rows + one more input row, zero column on the right.
@@ -67,10 +72,11 @@ constexpr float CERT_4EPS = 4.0f * 2.38418579e-07f;
 #define SPK_VT_EXEC_SCAN 1      // 0: the collapsed-output scan handles a spike with compare + selects (the compiler's form)
 #endif
 #ifndef SPK_VT_NWV
-#define SPK_VT_NWV 8            // waves per workgroup (two per SIMD).  Round 3, convT2 at B = 1024 (tools/convt_time.py, same box): 16 waves with
-                                // SPK_VT_TPP=1 (126 registers) 253-255 us against 259-267 (the scan alone 67 -> 40 us: four waves issue vector
-                                // instructions at 2.0 instead of 3.1 cycles each, tools/coexec_probe.hip; the multiply phase, ~150 us, is the same),
-                                // 12 waves 262; the plain stride-2 layer (nine taps) spills at either, so the default stays 8 x 2 tiles
+#define SPK_VT_NWV 16           // waves per workgroup.  Round 4: SIXTEEN (four per SIMD) with one tile per pass: the four-digit form needs ~100
+                                // registers at SPK_VT_TPP = 1, four waves issue vector instructions at 2.0 instead of 3.1 cycles each
+                                // (tools/coexec_probe.hip) and overlap one another's multiply phases: encode -> decode at B = 1024
+                                // 1.577 -> 1.632-1.640 M images/s, convT2 0.225 -> 0.213 ms (same box; 12 waves: 1.61 M).  Round 3 (five
+                                // digits): 16 waves x 1 tile 253-255 us against 259-267 for convT2 and spills in the nine-tap layer
 #endif
 #ifndef SPK_VT_PIPE
 #define SPK_VT_PIPE 0           // 1: software-pipelined LDS reads in the multiply phase (weight tile two steps ahead, next tap's spike
@@ -82,8 +88,19 @@ constexpr float CERT_4EPS = 4.0f * 2.38418579e-07f;
                                 // 32 / 48 -> 273 / 270-274 / 273 / 273 / 275 us against 266-267: a wave that scans while its partner multiplies
                                 // issues its vector instructions at the single-wave rate (6.3 instead of 3.1 cycles): nothing is gained
 #endif
+#ifndef SPK_VT_D4
+#define SPK_VT_D4 1             // round 4: FOUR digits on the matrix cores (two accumulators per tile, 4 / 2 instead of 5 / 3 MFMAs and
+                                // weight-tile reads per tap) behind the COUNTED certification bound of den_mfma_fp6v2.hip: the two dropped
+                                // digits move a pre-activation by at most 528 units of 2^-s per ACTIVE input, and the active inputs of
+                                // every output row are counted once per item (popcounts of the input records, then per class and
+                                // position the maximum over the steps of the sum over the class's taps).  0: five digits, static bound
+#endif
 #ifndef SPK_VT_TPP
-#define SPK_VT_TPP 2            // row tiles per pass (a weight tile read from LDS serves all of them)
+#define SPK_VT_TPP (SPK_VT_NWV >= 12 ? 1 : 2)   // row tiles per pass (a weight tile read from LDS serves all of them)
+#endif
+#ifndef SPK_VT_TPP_T
+#define SPK_VT_TPP_T SPK_VT_TPP // ... of the transposed (1 / 2 / 2 / 4-tap) layers.  Round 4 (four digits): three tiles per pass fit (256 registers,
+                                // 16 B of scratch) and measure the same as two (dec2 0.2275 against 0.2219 / 0.2249 ms): two
 #endif
 #ifndef SPK_VT_DBG
 #define SPK_VT_DBG 0            // timing experiments only (results are wrong): 1 = no MFMAs, 2 = no LIF scan, 4 = no weight-tile reads from LDS
@@ -124,9 +141,12 @@ __host__ __device__ constexpr int on_tap(int k) {
 template <int GEO, int H, int W, int NCH, int OUT, int SPLIT, bool DB>
 __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
   constexpr int TPT = tiles_per_tap(NCH), W_BYTES = 9 * TPT * WT;
+  constexpr int TPL = SPK_VT_D4 ? TPT - 1 : TPT;            // tiles per tap kept in LDS (the fifth-digit tile stays in memory)
+  constexpr int WL_BYTES = 9 * TPL * WT;
   constexpr int RQ = GEO == 0 ? H / SPLIT : H / 2;          // rows of positions per item (class rows / output rows)
   constexpr int CW = GEO == 0 ? W : W / 2;                  // positions per row
-  constexpr int NPOS = RQ * CW, NTC = (NPOS + 1) / 2, TPP = SPK_VT_TPP, NPASS = (NTC + TPP - 1) / TPP, NCLS = GEO == 0 ? 4 : 1;
+  constexpr int NPOS = RQ * CW, NTC = (NPOS + 1) / 2, TPP = GEO == 0 ? SPK_VT_TPP_T : SPK_VT_TPP, NPASS = (NTC + TPP - 1) / TPP,
+                NCLS = GEO == 0 ? 4 : 1;
   constexpr int SROWS = GEO == 0 ? RQ + 1 : H + 1, SCOLS = W + 1;
   constexpr int A_CH = SROWS * SCOLS * POSB, A_BYTES = NCH * A_CH, NBUF = DB ? 2 : 1;
   constexpr int PPR = (W + 3) / 4;                          // 1 KiB DMA pieces per image row
@@ -136,6 +156,11 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   uint8_t* const sA = lds;
   uint8_t* const sW = lds + NBUF * A_BYTES;
+  // four-digit form: active inputs per input cell and step (u8, borders zero) and, per class and position, their maximum over
+  // the steps of the sum over the class's taps
+  constexpr int NCELL = SROWS * SCOLS;
+  uint8_t* const s_cin = lds + NBUF * A_BYTES + WL_BYTES;                       // [NCELL][16]
+  int* const s_nmax = reinterpret_cast<int*>(s_cin + ((NCELL * 16 + 15) & ~15));   // [NCLS][NPOS]
   const unsigned sA_addr = spk_lds_addr(sA);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -144,7 +169,10 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
 
   {  // the group's weight tiles and zeroed input slabs (their borders stay zero for the whole launch)
     const uint4* src = reinterpret_cast<const uint4*>(a.wq + (long long)g * W_BYTES);
-    for (int i = tid; i < W_BYTES / 16; i += SPK_VT_NWV * 64) reinterpret_cast<uint4*>(sW)[i] = src[i];
+    for (int i = tid; i < WL_BYTES / 16; i += SPK_VT_NWV * 64) {
+      const int tile = i / (WT / 16), o = i - tile * (WT / 16);
+      reinterpret_cast<uint4*>(sW)[i] = src[((tile / TPL) * TPT + tile % TPL) * (WT / 16) + o];
+    }
     for (int i = tid; i < NBUF * A_BYTES / 16; i += SPK_VT_NWV * 64) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
@@ -162,7 +190,12 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
   const float kin = (float)(Geo<GEO, H, W>::KMAX * a.Cin);
   const float E5 = 16.0f * kin * scale_f;
   const float part_max = (528.0f * fabsf(Ac1) + 16.0f * fabsf(Ac)) * kin + fabsf(Bc);
-  const float cE = fabsf(bna) * E5 + 2.0f * 2.38418579e-07f * (fabsf(bnb) + fabsf(Bc) + 2.0f * part_max) + 1e-30f;
+  const float cE = SPK_VT_D4 ? 2.0f * 2.38418579e-07f * (fabsf(bnb) + fabsf(Bc)) + 1e-30f
+                             : fabsf(bna) * E5 + 2.0f * 2.38418579e-07f * (fabsf(bnb) + fabsf(Bc) + 2.0f * part_max) + 1e-30f;
+  // four digits (den_mfma_fp6v2.hip, "Certification"): z = Q4 * Ac4 + Bc, Q4 = P01 * 2^10 + P23; the dropped digits move z_t by at
+  // most cT * n_t (|32 d4 + d5| <= 528 units of 2^-s per active input), every fp32 rounding is inside the eps terms
+  const float cT = 528.0f * scale_f * fabsf(bna) * 1.000001f;
+  const float Ac4 = 1024.0f * scale_f * bna;
   float coef[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) coef[r] = OUT == OUT_COLLAPSED ? a.coef[r] : 0.f;
@@ -215,11 +248,59 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
 #endif
     const uint8_t* const A0 = sA + buf * A_BYTES;
 
+    if constexpr (SPK_VT_D4) {
+      // (A) active inputs of every input record (cell, step), summed over the chunks: a spike is the nibble 0x2 = one set bit
+      for (int r = tid; r < NCELL * 16; r += SPK_VT_NWV * 64) {
+        int n = 0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const v4i q = *reinterpret_cast<const v4i*>(A0 + c * A_CH + r * 16);
+          n += __builtin_popcount((unsigned)q[0]) + __builtin_popcount((unsigned)q[1]) + __builtin_popcount((unsigned)q[2]) +
+               __builtin_popcount((unsigned)q[3]);
+        }
+        s_cin[r] = (uint8_t)n;                                 // <= 64
+      }
+      __syncthreads();
+      // (B) per class and output position: max over the steps of the sum over the class's taps (what the bound multiplies cT by)
+      for (int e = tid; e < NCLS * NPOS; e += SPK_VT_NWV * 64) {
+        const int cls = e / NPOS, p = e - cls * NPOS, ry = p / CW, rx = p - ry * CW;
+        const int cell0 = GEO == 0 ? ry * SCOLS + rx : 2 * ry * SCOLS + 2 * rx;
+        const int py = cls >> 1, px = cls & 1;
+        unsigned lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};   // sixteen 16-bit sums (even / odd bytes of the four words)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int ky = tap / 3, kx = tap % 3;
+          const bool on = GEO == 1 || ((py == 0 ? ky == 1 : ky != 1) && (px == 0 ? kx == 1 : kx != 1));
+          const int dy = GEO == 1 ? ky : ((py == 1 && ky == 0) ? 1 : 0), dx = GEO == 1 ? kx : ((px == 1 && kx == 0) ? 1 : 0);
+          if (on) {
+            const v4i q = *reinterpret_cast<const v4i*>(s_cin + (cell0 + dy * SCOLS + dx) * 16);
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+              lo[w4] += (unsigned)q[w4] & 0x00ff00ffu;
+              hi[w4] += ((unsigned)q[w4] >> 8) & 0x00ff00ffu;
+            }
+          }
+        }
+        unsigned mx = 0;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) {
+          mx = max(mx, max(lo[w4] & 0xffffu, lo[w4] >> 16));
+          mx = max(mx, max(hi[w4] & 0xffffu, hi[w4] >> 16));
+        }
+        s_nmax[e] = (int)mx;
+      }
+      __syncthreads();
+    }
+
     auto run_pass = [&](auto cls_tag, int k) __attribute__((always_inline)) {
       constexpr int CLS = decltype(cls_tag)::value, PY = CLS >> 1, PX = CLS & 1;
-      const int t0 = TPP * k, t1 = TPP * k + 1;
-      const bool v1 = TPP == 2 && t1 < NTC;
-      const int tl[2] = {t0, v1 ? t1 : t0};
+      int tl[TPP];                                         // tiles of the pass; one past the end repeats the first (computed, dropped)
+      bool tv[TPP];
+#pragma unroll
+      for (int i = 0; i < TPP; ++i) {
+        tv[i] = TPP * k + i < NTC;
+        tl[i] = tv[i] ? TPP * k + i : TPP * k;
+      }
       int base[TPP];
 #pragma unroll
       for (int i = 0; i < TPP; ++i) {
@@ -228,11 +309,12 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
         const int ry = p / CW, rx = p - ry * CW;
         base[i] = (GEO == 0 ? ry * SCOLS + rx : 2 * ry * SCOLS + 2 * rx) * POSB + tt * 16;
       }
-      v16f acc[TPP][3];
+      constexpr int NACC = SPK_VT_D4 ? 2 : 3;
+      v16f acc[TPP][NACC];
 #pragma unroll
       for (int i = 0; i < TPP; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < NACC; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
       auto ldb = [&](int tile) -> v6i {
@@ -250,6 +332,7 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
         d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, d, 4, 2, 0, sc_a, 0, sb);
       };
 #if SPK_VT_PIPE
+      static_assert(!SPK_VT_D4, "the software-pipelined experiment was written for the five-digit tile list");
       // The item's products as ONE compile-time list of steps (an active tap of the class x one weight tile), software pipelined:
       // the weight tile of step s + PFB and the spike fragments of the NEXT tap are read from LDS while the MFMAs of step s run
       // (read-all-then-multiply per tap left LDS reads and MFMAs in series: 153 us of the convT2 launch's 269 against ~70 us each).
@@ -306,8 +389,9 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
               av[i][0] = *reinterpret_cast<const v4i*>(A0 + base[i] + TOFF);
               av[i][1] = *reinterpret_cast<const v4i*>(A0 + A_CH + base[i] + TOFF);
             }
-            const v6i b0 = ldb(TAP * TPT + 0), b1 = ldb(TAP * TPT + 1), b2 = ldb(TAP * TPT + 2), b3 = ldb(TAP * TPT + 3),
-                      b4 = ldb(TAP * TPT + 4);
+            const v6i b0 = ldb(TAP * TPL + 0), b1 = ldb(TAP * TPL + 1), b2 = ldb(TAP * TPL + 2), b3 = ldb(TAP * TPL + 3);
+            v6i b4 = b0;
+            if constexpr (!SPK_VT_D4) b4 = ldb(TAP * TPL + 4);
 #pragma unroll
             for (int i = 0; i < TPP; ++i) {
               if (SPK_VT_DBG & 1) continue;
@@ -315,20 +399,24 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
               mm(acc[i][1], av[i][0], b1, sc_p);
               mm(acc[i][0], av[i][1], b2, sc_p);
               mm(acc[i][1], av[i][1], b3, sc_p);
-              const v4i a4 = half ? av[i][1] : av[i][0];
-              mm(acc[i][2], a4, b4, sc_4);
+              if constexpr (!SPK_VT_D4) {
+                const v4i a4 = half ? av[i][1] : av[i][0];
+                mm(acc[i][NACC - 1], a4, b4, sc_4);
+              }
             }
           } else {
             v4i av[TPP];
 #pragma unroll
             for (int i = 0; i < TPP; ++i) av[i] = *reinterpret_cast<const v4i*>(A0 + base[i] + TOFF);
-            const v6i b0 = ldb(TAP * TPT + 0), b1 = ldb(TAP * TPT + 1), b4 = ldb(TAP * TPT + 2);
+            const v6i b0 = ldb(TAP * TPL + 0), b1 = ldb(TAP * TPL + 1);
+            v6i b4 = b0;
+            if constexpr (!SPK_VT_D4) b4 = ldb(TAP * TPL + 2);
 #pragma unroll
             for (int i = 0; i < TPP; ++i) {
               if (SPK_VT_DBG & 1) continue;
               mm(acc[i][0], av[i], b0, sc_p);
               mm(acc[i][1], av[i], b1, sc_p);
-              mm(acc[i][2], av[i], b4, sc_4);
+              if constexpr (!SPK_VT_D4) mm(acc[i][NACC - 1], av[i], b4, sc_4);
             }
           }
         }
@@ -343,15 +431,21 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
         unsigned mybits = 0;
         if (SPK_VT_DBG & 2) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) m += acc[i][0][r] + acc[i][1][r] + acc[i][2][r];
+          for (int r = 0; r < 16; ++r) m += acc[i][0][r] + acc[i][1][r] + acc[i][NACC - 1][r];
         } else
 #pragma unroll
         for (int r2 = 0; r2 < 16; r2 += 2) {
           // the recombination of two steps at a time on the packed fp32 pipe (adjacent accumulator registers)
           const v2f p0 = {acc[i][0][r2], acc[i][0][r2 + 1]}, p1 = {acc[i][1][r2], acc[i][1][r2 + 1]},
-                    p2 = {acc[i][2][r2], acc[i][2][r2 + 1]};
-          const v2f z2 = __builtin_elementwise_fma(p0, (v2f){Ac0, Ac0},
-                         __builtin_elementwise_fma(p1, (v2f){Ac1, Ac1}, __builtin_elementwise_fma(p2, (v2f){Ac, Ac}, (v2f){Bc, Bc})));
+                    p2 = {acc[i][NACC - 1][r2], acc[i][NACC - 1][r2 + 1]};
+          v2f z2;
+          if constexpr (SPK_VT_D4) {
+            const v2f q4 = __builtin_elementwise_fma(p0, (v2f){1024.0f, 1024.0f}, p1);
+            z2 = __builtin_elementwise_fma(q4, (v2f){Ac4, Ac4}, (v2f){Bc, Bc});
+          } else {
+            z2 = __builtin_elementwise_fma(p0, (v2f){Ac0, Ac0},
+                 __builtin_elementwise_fma(p1, (v2f){Ac1, Ac1}, __builtin_elementwise_fma(p2, (v2f){Ac, Ac}, (v2f){Bc, Bc})));
+          }
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const int r = r2 + e;
@@ -376,10 +470,12 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
             }
           }
         }
-        const bool flg = dmin <= fmaf(zmax, 2.5f * CERT_4EPS, cE);             // dh <= cE + 8 eps max |z| (10 eps: a little to spare)
         const int p = 2 * tl[i] + half;                       // accumulator lane half == position within the tile
-        const bool ok = (i == 0 || v1) && p < NPOS;
+        const bool ok = tv[i] && p < NPOS;
         const int pc = p < NPOS ? p : NPOS - 1;
+        // dh <= c + 8 eps max |z| (10 eps: a little to spare); c = cE (five digits, every input active) or cE + cT max_t n_t
+        const float cb = SPK_VT_D4 ? fmaf((float)s_nmax[CLS * NPOS + pc], cT, cE) : cE;
+        const bool flg = dmin <= fmaf(zmax, 2.5f * CERT_4EPS, cb);
         const int ry = pc / CW, rx = pc - ry * CW;
         const int oy = GEO == 0 ? 2 * (part * RQ + ry) + PY : ry, ox = GEO == 0 ? 2 * rx + PX : rx;
         const long long pos = ((long long)b * Ho + oy) * Wo + ox;
@@ -656,9 +752,12 @@ __global__ void ptc_to_s32_kernel(const uint8_t* __restrict__ in, uint8_t* __res
 
 template <int GEO, int H, int W, int NCH, int OUT, int SPLIT, bool DB>
 int launch_vae(const TArgs& a, long long n_words, hipStream_t stream) {
-  constexpr int TPT = tiles_per_tap(NCH);
+  constexpr int TPT = tiles_per_tap(NCH), TPL = SPK_VT_D4 ? TPT - 1 : TPT;
   constexpr int SROWS = GEO == 0 ? H / SPLIT + 1 : H + 1;
-  const size_t lds = (size_t)(DB ? 2 : 1) * NCH * SROWS * (W + 1) * POSB + 9 * TPT * WT;
+  constexpr int NPOS = GEO == 0 ? (H / SPLIT) * W : (H / 2) * (W / 2), NCLS = GEO == 0 ? 4 : 1;
+  // (+ the four-digit form's counters: u8 [cells][16] and int [classes][positions])
+  const size_t lds = (size_t)(DB ? 2 : 1) * NCH * SROWS * (W + 1) * POSB + 9 * TPL * WT +
+                     (SPK_VT_D4 ? (size_t)((SROWS * (W + 1) * 16 + 15) & ~15) + (size_t)NCLS * NPOS * 4 : 0);
   if (lds > 160 * 1024) return SPK_ERR_UNSUPPORTED;
   const int cus = spk_cu_count(), G = a.Cout / 32;
   const int grid = cus >= G ? (cus / G) * G : G;
