@@ -2672,6 +2672,41 @@ def test_conv3x3_data_gradient_bf16_kernel_vs_fp64(dev, ops, N, Cout, Cin, form,
     assert torch.equal(got, got2), "deterministic"
 
 
+def test_data_gradient_forms_wide_dynamic_range_per_element(dev, ops):
+    """whole-tensor relative L2 cannot see what the two-term fp16 form does to small elements.  One image's gy spans
+    2^-34 .. 1 (rows of the map scaled by 2^-(6 y)), so the outputs of the lower rows are sums of terms far below the image's
+    maximum.  Per ELEMENT, against fp64 and relative to the sum of |terms| of that output (what an fp32 operator's error is
+    relative to): the three-term bf16 form (exact truncations at any magnitude) stays at fp32 round-off everywhere; the two-term
+    fp16 form (one power-of-two scale per image / per input channel, default of the training backward) does so only within ~17
+    binades of the image's maximum and keeps an ABSOLUTE 2^-38 of (image maximum x channel weight sum) below -- which is what
+    csrc/conv_dgrad.hip and ops.conv3x3_dgrad now say."""
+    N, Cout, Cin, HH = 64, 64, 64, 7
+    g = torch.Generator().manual_seed(5)
+    gy = torch.randn(N, Cout, HH, HH, generator=g) * torch.exp2(-6.0 * torch.arange(HH).float()).view(1, 1, HH, 1)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    x = torch.zeros(N, Cin, HH, HH)
+    want, _, _ = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), [Cout], [1, 1], [1, 1], [1, 1], False,
+                                                     [0, 0], 1, [True, False, False])
+    mag, _, _ = torch.ops.aten.convolution_backward(gy.double().abs(), x.double(), w.double().abs(), [Cout], [1, 1], [1, 1], [1, 1],
+                                                    False, [0, 0], 1, [True, False, False])          # sum of |terms| per output
+    gy_cl = gy.to(dev).contiguous(memory_format=torch.channels_last)
+    rep = {}
+    for form in ("bf16x3", "f16x2"):
+        got = ops.conv3x3_dgrad(gy_cl, w.to(dev), Cin, form=form).cpu().double()
+        per_elem = ((got - want).abs() / mag.clamp_min(1e-300))                                      # [N, Cin, 7, 7]
+        by_row = per_elem.amax(dim=(0, 1, 3))                                                        # worst per map row y
+        rep[form] = [float(v) for v in by_row]
+    print("per-element error / sum|terms| by map row (row y carries gy ~ 2^-(6 y)):", {k: [f"{v:.1e}" for v in r] for k, r in rep.items()})
+    parity("dgrad_forms_wide_dynamic_range_per_element", **rep)
+    assert max(rep["bf16x3"]) <= 1e-6, "three exact bf16 terms: fp32 round-off per element at every magnitude"
+    assert max(rep["f16x2"][:3]) <= 1e-6, "two scaled fp16 terms: fp32 round-off within ~17 binades of the image's maximum"
+    # below that the error is absolute: 2^-40 of the image's maximum per gy term (the remainder term has gone subnormal)
+    wsum = float(w.abs().sum(dim=(0, 2, 3)).max())
+    amax = float(gy.abs().amax())
+    got = ops.conv3x3_dgrad(gy_cl, w.to(dev), Cin, form="f16x2").cpu().double()
+    assert float((got - want).abs().max()) <= 2.0 ** -38 * amax * wsum + 1e-6 * float(mag.max())
+
+
 def test_last_layer_and_time_mean_as_one_operator_backward_on_spike_counts(dev, ops):
     """ops.SpikeConvMeanTrainFunction (conv6 + mean over T; backward = one convolution of g / T with the spike COUNTS and one
     transposed convolution repeated over T) against the two-operator form (per-step convolution, sum / T, per-step backward):
