@@ -18,11 +18,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------ LIF
 // One thread owns VEC consecutive neurons and walks T with stride N.  Loads of a chunk of TU steps are
 // issued back to back (TU x 16 B in flight per lane) before the dependent scan consumes them.
+#ifndef SPK_LIF_TU
+#define SPK_LIF_TU 8            // time steps whose loads are in flight together (x 16 B per lane)
+#endif
+#ifndef SPK_LIF_BLOCK
+#define SPK_LIF_BLOCK 256
+#endif
+#ifndef SPK_LIF_GRID_PER_CU
+#define SPK_LIF_GRID_PER_CU 32  // workgroups per CU at most (grid-stride beyond)
+#endif
+#ifndef SPK_LIF_NT
+#define SPK_LIF_NT 3            // bit 0: non-temporal loads, bit 1: non-temporal stores
+#endif
 template <int VEC, int OUT, bool DIV>
-__global__ __launch_bounds__(256) void lif_fwd_kernel(const float* __restrict__ x, float* __restrict__ v_io,
+__global__ __launch_bounds__(SPK_LIF_BLOCK) void lif_fwd_kernel(const float* __restrict__ x, float* __restrict__ v_io,
                                                       void* __restrict__ out, int T, long long N, float tau,
                                                       float inv_tau, float v_th, float v_reset) {
-  constexpr int TU = 8;
+  constexpr int TU = SPK_LIF_TU;
   const long long ngroups = (N + VEC - 1) / VEC;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups;
        g += (long long)gridDim.x * blockDim.x) {
@@ -41,7 +53,8 @@ __global__ __launch_bounds__(256) void lif_fwd_kernel(const float* __restrict__ 
         if (t0 + i < T) {
           const float* p = x + (long long)(t0 + i) * N + n0;
           if constexpr (VEC == 4) {
-            f32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+            f32x4 t4 = (SPK_LIF_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p))
+                                        : *reinterpret_cast<const f32x4*>(p);
             xv[i][0] = t4.x; xv[i][1] = t4.y; xv[i][2] = t4.z; xv[i][3] = t4.w;
           } else {
             xv[i][0] = __builtin_nontemporal_load(p);
@@ -59,7 +72,8 @@ __global__ __launch_bounds__(256) void lif_fwd_kernel(const float* __restrict__ 
             float* po = reinterpret_cast<float*>(out) + o;
             if constexpr (VEC == 4) {
               f32x4 r = {s[0] ? 1.f : 0.f, s[1] ? 1.f : 0.f, s[2] ? 1.f : 0.f, s[3] ? 1.f : 0.f};
-              __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(po));
+              if (SPK_LIF_NT & 2) __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(po));
+              else *reinterpret_cast<f32x4*>(po) = r;
             } else {
               po[0] = s[0] ? 1.f : 0.f;
             }
@@ -247,6 +261,12 @@ inline int grid_for(long long work_items) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+inline int lif_grid(long long work_items) {
+  long long g = (work_items + SPK_LIF_BLOCK - 1) / SPK_LIF_BLOCK;
+  const long long cap = 256ll * SPK_LIF_GRID_PER_CU;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
 }  // namespace
 
 extern "C" int spk_lif_fwd(const float* x_seq, float* v_inout, void* spike_out, int T, long long N, float tau,
@@ -273,7 +293,7 @@ extern "C" int spk_lif_fwd(const float* x_seq, float* v_inout, void* spike_out, 
   const uintptr_t al = (uintptr_t)x_seq | (uintptr_t)v_inout | (uintptr_t)spike_out;
   const bool vec = (N % 4 == 0) && (al % 16 == 0);
 #define SPK_LIF_LAUNCH(VEC, OUT, DIV)                                                                              \
-  hipLaunchKernelGGL((lif_fwd_kernel<VEC, OUT, DIV>), dim3(grid_for((N + VEC - 1) / VEC)), dim3(256), 0, stream, \
+  hipLaunchKernelGGL((lif_fwd_kernel<VEC, OUT, DIV>), dim3(lif_grid((N + VEC - 1) / VEC)), dim3(SPK_LIF_BLOCK), 0, stream, \
                      x_seq, v_inout, spike_out, T, N, tau, inv_tau, v_threshold, v_reset)
   if (vec) {
     if (f32) { if (pow2) SPK_LIF_LAUNCH(4, SPK_SPIKE_F32, false); else SPK_LIF_LAUNCH(4, SPK_SPIKE_F32, true); }
