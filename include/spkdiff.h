@@ -134,6 +134,17 @@ int spk_bn_lif_train_bwd(const float* grad_spike_seq, const float* grad_v_last, 
                          float* grad_y, float* grad_gamma, float* grad_beta, float* grad_v_init, void* ws,
                          long long ws_bytes, int T, int B, int C, int HW, float tau, float v_threshold, float v_reset,
                          float alpha, int detach_reset, spk_stream_t stream);
+/* The same backward with the layout of grad_spike_seq spelled out (in floats): grad_step_stride = 0 when every step receives
+ * the SAME gradient -- the spikes in front of the denoiser's last layer do: its time mean hands g / T to every step
+ * (R/snn_model/vq_diffusion.py:205-206) -- and grad_row_pitch >= C for a channel slice of a wider channels-last tensor (the x5 / x1
+ * halves of cat(x5, x1), :205).  The gradient is read where autograd left it instead of being expanded and copied first.
+ * spk_bn_lif_train_bwd == grad_step_stride B*HW*C, grad_row_pitch C. */
+int spk_bn_lif_train_bwd_strided(const float* grad_spike_seq, long long grad_step_stride, long long grad_row_pitch,
+                                 const float* grad_v_last, const float* y, const float* gamma, const float* beta,
+                                 const float* save_mean, const float* save_invstd, const float* v_init, float* grad_y,
+                                 float* grad_gamma, float* grad_beta, float* grad_v_init, void* ws, long long ws_bytes, int T,
+                                 int B, int C, int HW, float tau, float v_threshold, float v_reset, float alpha,
+                                 int detach_reset, spk_stream_t stream);
 /* Training forward of a denoiser convolution on spike input (layer.Conv2d 'm' mode in train(), SJ/activation_based/layer.py:164-173,
  * for conv2..conv5 of DummyModel, R/snn_model/vq_diffusion.py:166-184): the exact fp6 x fp4 MFMA convolution of
  * spk_den_conv3x3_mfma_fp6 with the pre-activations (conv + bias, correctly rounded fp32 of the exact dot product) written
@@ -143,6 +154,10 @@ int spk_bn_lif_train_bwd(const float* grad_spike_seq, const float* grad_v_last, 
 int spk_den_conv3x3_fp6_raw(const uint8_t* in_c4, int nch, const uint8_t* wq, const double* scale, const double* bias_d,
                             float* pre_nhwc, int T, int B, int H, int W, int Cout, spk_stream_t stream);
 int spk_spikes_nhwc_to_fp4(const float* spikes_nhwc, uint8_t* out_c4, int T, int B, int C, int HW, spk_stream_t stream);
+/* The same conversion with the per-neuron spike counts over T as a by-product: counts_nhwc fp32 [B][HW][C] (channels-last) -- what
+ * the last layer's weight gradient is convolved with in the training step (its time mean hands every step the same gradient). */
+int spk_spikes_nhwc_to_fp4_counts(const float* spikes_nhwc, uint8_t* out_c4, float* counts_nhwc, int T, int B, int C, int HW,
+                                  spk_stream_t stream);
 
 /* Masked cross-entropy of AbsorbingDiffusion._train_loss (R/snn_model/vq_diffusion.py:85-88: F.cross_entropy with
  * ignore_index=-1, reduction='none') and its gradient in one pass.  logits / dlogits [B,K,HW] fp32; target [B,HW] fp32
@@ -227,6 +242,10 @@ long long spk_den_packed_weight_fp6_bytes(int Cout, int Cin);
  * scale and fp64 bias. */
 int spk_den_pack_weight_fp6(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d, int Cout,
                             int Cin, spk_stream_t stream);
+/* The same packing of a weight stored in the channels-last memory format, [Cout][3][3][Cin] (how the training path keeps its
+ * convolution parameters, R/main.py:226-252 with NHWC library kernels): no layout copy in front of the per-iteration packing. */
+int spk_den_pack_weight_fp6_cl(const float* w_channels_last, const float* bias, uint8_t* wq, double* scale, double* bias_d,
+                               int Cout, int Cin, spk_stream_t stream);
 /* in_c4: nch chunks of 64 channels; out_c4 [B][Cout/64][h*w][16][32]; v_inout / out_counts as in spk_den_conv3x3_mfma.
  * SPK_ERR_UNSUPPORTED unless T == 16, Cout % 64 == 0 and the latent fits one of the kernel's LDS plans (up to 7x8 as
  * one item per image and channel group, 8x8 as two row bands).
@@ -378,6 +397,16 @@ int spk_conv3x3_dgrad_bf16(const float* gy_cl, const float* w_cl, uint8_t* ws, l
  * precision.  Same arguments, workspace and shapes as spk_conv3x3_dgrad_bf16. */
 int spk_conv3x3_dgrad_f16x2(const float* gy_cl, const float* w_cl, uint8_t* ws, long long ws_bytes, float* gi_out, int N, int H,
                             int W, int Cout, int Cin, spk_stream_t stream);
+
+/* Weight and bias gradient of a 3x3 / stride 1 / pad 1 convolution with FEW input channels (Cin <= 4) and a dense fp32 input: the
+ * denoiser's first layer in the training step (cat(x_t, t): two channels, R/snn_model/vq_diffusion.py:161-165,195-201; what
+ * loss.backward() computes through layer.Conv2d, R/main.py:226-252).  gy_cl channels-last [N][H*W][Cout], in_nchw [N][Cin][H][W];
+ * gw_out [Cout][3][3][Cin] (weight_channels_last = 1, the storage the training path keeps its weights in) or [Cout][Cin][3][3];
+ * gb_out optional [Cout].  ws: spk_conv3x3_wgrad_small_ws_bytes(...) bytes; deterministic (fixed-order partial sums, fp64). */
+long long spk_conv3x3_wgrad_small_ws_bytes(int N, int H, int W, int Cout, int Cin);
+int spk_conv3x3_wgrad_small(const float* gy_cl, const float* in_nchw, float* ws, long long ws_bytes, float* gw_out,
+                            float* gb_out_or_null, int N, int H, int W, int Cout, int Cin, int weight_channels_last,
+                            spk_stream_t stream);
 
 /* ---- sampler ---------------------------------------------------------------------------------------------------- */
 /* Images touched by reverse step t.  R/snn_model/vq_diffusion.py:113-124 computes `changes = (u < 1/t) & ~unmasked`

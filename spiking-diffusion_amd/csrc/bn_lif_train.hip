@@ -34,6 +34,7 @@ constexpr int NW = TPB / 64;
 struct Geo {
   int T, R, C;                    // time steps, rows (B * HW) per step, channels
   int S;                          // row slices (gridDim.y); a wave walks rows  (blockIdx.y * NW + wave) + k * NW * S
+  long long gs_ts, gs_pitch;      // layout of grad_spike_seq in floats: step stride (0 = the same gradient at every step) and row pitch
 };
 
 // per-(slice, channel) partial of two doubles: waves of a block are reduced in LDS in a fixed order
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(TPB) void bn_lif_bwd1_kernel(const float* __restric
       for (int t = 0; t < SPK_MAX_T; ++t) {
         if (t < g.T) {
           yv[t] = y[n + t * ts];
-          gsv[t] = grad_s[n + t * ts];
+          gsv[t] = grad_s[(long long)r * g.gs_pitch + c + t * g.gs_ts];
         }
       }
 #pragma unroll
@@ -244,6 +245,7 @@ template <> struct Vec<4> { typedef float type __attribute__((ext_vector_type(4)
 
 struct GeoV {
   int T, R, C, S, Q, RPB;         // Q = C / VEC threads per row, RPB = 256 / Q rows per workgroup step
+  long long gs_ts, gs_pitch;      // layout of grad_spike_seq in floats (see Geo)
 };
 
 template <int VEC>
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(TPB) void bn_lif_bwd1_v_kernel(const float* __restr
     vf yy[SPK_MAX_T], hh[SPK_MAX_T], gs[SPK_MAX_T];
 #pragma unroll
     for (int t = 0; t < SPK_MAX_T; ++t) {
-      if (t < g.T) { yy[t] = yv[n + t * ts]; gs[t] = gsv[n + t * ts]; }
+      if (t < g.T) { yy[t] = yv[n + t * ts]; gs[t] = gsv[((long long)r * g.gs_pitch + t * g.gs_ts) / VEC + q]; }
     }
     vf v;
     if (v_init) v = reinterpret_cast<const vf*>(v_init)[n];
@@ -465,9 +467,9 @@ inline int vec_for(int C, int want) {
   return 1;
 }
 
-inline GeoV geo_v(int T, int R, int C, int vec, int S) {
+inline GeoV geo_v(int T, int R, int C, int vec, int S, long long gs_ts = -1, long long gs_pitch = -1) {
   const int Q = C / vec, RPB = TPB / Q;
-  return GeoV{T, R, C, S, Q, RPB};
+  return GeoV{T, R, C, S, Q, RPB, gs_ts < 0 ? (long long)R * C : gs_ts, gs_pitch < 0 ? (long long)C : gs_pitch};
 }
 
 // row slices of the scalar form: enough waves to fill 256 CUs several times over, never more than one row per wave
@@ -532,7 +534,7 @@ extern "C" int spk_bn_lif_train_fwd(const float* y, const float* gamma, const fl
                          v_init, spike_seq, v_out, g, tau, v_threshold, v_reset);
   } else {
     const int S = slices(R, C);
-    const Geo g{T, R, C, S};
+    const Geo g{T, R, C, S, (long long)R * C, (long long)C};
     const dim3 grid((C + 63) / 64, S);
     hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(TPB), 0, stream, y, (double*)ws, g);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + NW - 1) / NW), dim3(TPB), 0, stream, (const double*)ws, S, C, M, eps,
@@ -544,7 +546,8 @@ extern "C" int spk_bn_lif_train_fwd(const float* y, const float* gamma, const fl
   return SPK_OK;
 }
 
-extern "C" int spk_bn_lif_train_bwd(const float* grad_spike_seq, const float* grad_v_last, const float* y, const float* gamma,
+static int bn_lif_train_bwd_impl(const float* grad_spike_seq, long long gs_ts, long long gs_pitch, const float* grad_v_last,
+                                 const float* y, const float* gamma,
                                     const float* beta, const float* save_mean, const float* save_invstd, const float* v_init,
                                     float* grad_y, float* grad_gamma, float* grad_beta, float* grad_v_init, void* ws,
                                     long long ws_bytes, int T, int B, int C, int HW, float tau, float v_threshold,
@@ -555,15 +558,17 @@ extern "C" int spk_bn_lif_train_bwd(const float* grad_spike_seq, const float* gr
   if (ws_bytes < spk_bn_lif_train_ws_bytes(B, C, HW)) return SPK_ERR_ARG;
   const int R = B * HW;
   const float inv_M = (float)(1.0 / ((double)T * R));
+  if (gs_ts < 0 || gs_pitch < C) return SPK_ERR_ARG;
   const bool al = aligned16(y) && aligned16(grad_spike_seq) && aligned16(grad_y) && (!v_init || aligned16(v_init)) &&
-                  (!grad_v_last || aligned16(grad_v_last)) && (!grad_v_init || aligned16(grad_v_init));
+                  (!grad_v_last || aligned16(grad_v_last)) && (!grad_v_init || aligned16(grad_v_init)) && (gs_ts % 4) == 0 &&
+                  (gs_pitch % 4) == 0;
   // the BPTT pass keeps y, h and grad_s of T steps per channel in registers: 2 channels per thread; the rest 4
   const int vec1 = al ? vec_for(C, 2) : 1, vec2 = al ? vec_for(C, 4) : 1;
 #define SPK_BWD1_ARGS grad_spike_seq, grad_v_last, y, gamma, beta, save_mean, save_invstd, v_init, grad_y, grad_v_init, (double*)ws
   int S;
   if (vec1 == 2) {
     S = slices_v(R, C, 2);
-    const GeoV g = geo_v(T, R, C, 2, S);
+    const GeoV g = geo_v(T, R, C, 2, S, gs_ts, gs_pitch);
     if (detach_reset)
       hipLaunchKernelGGL((bn_lif_bwd1_v_kernel<2, true>), dim3(S), dim3(TPB), 0, stream, SPK_BWD1_ARGS, g, tau, v_threshold,
                          v_reset, alpha);
@@ -572,7 +577,7 @@ extern "C" int spk_bn_lif_train_bwd(const float* grad_spike_seq, const float* gr
                          v_reset, alpha);
   } else {
     S = slices(R, C);
-    const Geo g{T, R, C, S};
+    const Geo g{T, R, C, S, gs_ts, gs_pitch};
     const dim3 grid((C + 63) / 64, S);
     if (detach_reset)
       hipLaunchKernelGGL(bn_lif_bwd1_kernel<true>, grid, dim3(TPB), 0, stream, SPK_BWD1_ARGS, g, tau, v_threshold, v_reset, alpha);
@@ -593,10 +598,35 @@ extern "C" int spk_bn_lif_train_bwd(const float* grad_spike_seq, const float* gr
                          grad_beta, grad_y, g, inv_M);
   } else {
     const int S2 = slices(R, C);
-    const Geo g{T, R, C, S2};
+    const Geo g{T, R, C, S2, (long long)R * C, (long long)C};
     hipLaunchKernelGGL(bn_bwd2_kernel, dim3((C + 63) / 64, S2), dim3(TPB), 0, stream, y, gamma, save_mean, save_invstd,
                        grad_gamma, grad_beta, grad_y, g, inv_M);
   }
   SPK_LAUNCH_CHECK();
   return SPK_OK;
+}
+
+extern "C" int spk_bn_lif_train_bwd(const float* grad_spike_seq, const float* grad_v_last, const float* y, const float* gamma,
+                                    const float* beta, const float* save_mean, const float* save_invstd, const float* v_init,
+                                    float* grad_y, float* grad_gamma, float* grad_beta, float* grad_v_init, void* ws,
+                                    long long ws_bytes, int T, int B, int C, int HW, float tau, float v_threshold,
+                                    float v_reset, float alpha, int detach_reset, hipStream_t stream) {
+  return bn_lif_train_bwd_impl(grad_spike_seq, (long long)B * HW * C, (long long)C, grad_v_last, y, gamma, beta, save_mean,
+                               save_invstd, v_init, grad_y, grad_gamma, grad_beta, grad_v_init, ws, ws_bytes, T, B, C, HW, tau,
+                               v_threshold, v_reset, alpha, detach_reset, stream);
+}
+
+// The same backward with the layout of grad_spike_seq spelled out (floats): step stride -- 0 when every step receives the
+// SAME gradient, as the spikes in front of the denoiser's last layer do (its time mean hands g / T to every step:
+// R/snn_model/vq_diffusion.py:205-206) -- and row pitch >= C (a channel slice of a wider channels-last tensor: the x5 / x1 halves
+// of cat(x5, x1), :205).  The gradient is then read where autograd left it instead of being expanded and copied first.
+extern "C" int spk_bn_lif_train_bwd_strided(const float* grad_spike_seq, long long grad_step_stride, long long grad_row_pitch,
+                                            const float* grad_v_last, const float* y, const float* gamma, const float* beta,
+                                            const float* save_mean, const float* save_invstd, const float* v_init, float* grad_y,
+                                            float* grad_gamma, float* grad_beta, float* grad_v_init, void* ws, long long ws_bytes,
+                                            int T, int B, int C, int HW, float tau, float v_threshold, float v_reset, float alpha,
+                                            int detach_reset, hipStream_t stream) {
+  return bn_lif_train_bwd_impl(grad_spike_seq, grad_step_stride, grad_row_pitch, grad_v_last, y, gamma, beta, save_mean,
+                               save_invstd, v_init, grad_y, grad_gamma, grad_beta, grad_v_init, ws, ws_bytes, T, B, C, HW, tau,
+                               v_threshold, v_reset, alpha, detach_reset, stream);
 }

@@ -213,25 +213,47 @@ __global__ __launch_bounds__(NTHR, 1) void wgrad3x3_bf16_kernel(WgArgs a) {
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, long long n, int ksplit,
-                                    const float* __restrict__ part_gb, float* __restrict__ gb, int Cout) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < ksplit; ++k) s += part[(long long)k * n + i];      // fixed order: deterministic
-    gw[i] = s;
-  }
-  if (gb && blockIdx.x == 0)
-    for (int c = threadIdx.x; c < Cout; c += blockDim.x) {
-      float s = 0.f;
-      for (int k = 0; k < ksplit; ++k) s += part_gb[(long long)k * Cout + c];
-      gb[c] = s;
+// 64 consecutive outputs x 4 groups of slices per workgroup: every thread adds its quarter of the slices in four independent
+// chains (a thread that walked all 128 slices of the small layer alone took 75 us: one memory latency per slice), the groups meet
+// in LDS; every sum has ONE fixed order: deterministic
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, long long n,
+                                                           int ksplit, const float* __restrict__ part_gb, float* __restrict__ gb,
+                                                           int Cout) {
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int per = (ksplit + 3) / 4, k0 = grp * per, k1 = k0 + per < ksplit ? k0 + per : ksplit;
+  for (long long base = (long long)blockIdx.x * 64; base < n + Cout; base += (long long)gridDim.x * 64) {
+    // outputs [0, n): the weight gradient; [n, n + Cout): the bias gradient (its partial sums live behind the weight's)
+    const long long i = base + lane;
+    const bool is_w = i < n, live = i < n + (gb ? Cout : 0);
+    const float* src = is_w ? part + i : part_gb + (i - n);
+    const long long stride = is_w ? n : Cout;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (live) {
+      int k = k0;
+      for (; k + 3 < k1; k += 4) {
+        a0 += src[(long long)k * stride]; a1 += src[(long long)(k + 1) * stride];
+        a2 += src[(long long)(k + 2) * stride]; a3 += src[(long long)(k + 3) * stride];
+      }
+      for (; k < k1; ++k) a0 += src[(long long)k * stride];
     }
+    sh[grp][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (grp == 0 && live) {
+      const float t = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+      if (is_w) gw[i] = t; else gb[i - n] = t;
+    }
+    __syncthreads();
+  }
 }
 
 // slices of the image range: one workgroup per CU in ONE round (never a second, partly filled round)
 int wgrad_ksplit(int TB, int Cout, int Cin) {
   const int tiles = (Cout / WG_CO) * (Cin / WG_CI);
   int ks = spk_cu_count() / tiles;
+  // a single output tile (the 64 -> 128 layer): 256 slices would write and re-read 256 x 295 KB of partial sums for 11 GFLOP of
+  // matrix work (measured 90 us against the library's 52); 128 slices halve that traffic at twice the (short) multiply time
+  if (tiles == 1 && ks > 128) ks = 128;
   if (ks > TB) ks = TB;
   if (ks < 1) ks = 1;
   return ks;
@@ -259,7 +281,7 @@ extern "C" int spk_conv3x3_wgrad_bf16(const float* gy_cl, const float* spikes_cl
   if ((long long)LDS_BYTES > spk_lds_limit()) return SPK_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(wgrad3x3_bf16_kernel, dim3(tiles * ks), dim3(NTHR), (size_t)LDS_BYTES, stream, a);
   SPK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + Cout + 63) / 64 > 8192 ? 8192 : (n + Cout + 63) / 64)), dim3(256), 0, stream,
                      ws, gw_out, n, ks, a.part_gb, gb_out_or_null, Cout);
   SPK_LAUNCH_CHECK();
   return SPK_OK;

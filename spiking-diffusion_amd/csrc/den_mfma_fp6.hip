@@ -575,10 +575,10 @@ __global__ __launch_bounds__(256) void conv3x3_fp6_lastpos_kernel(Fp6Args a) {
 // is padded to whole KiB DMA pieces)
 __global__ __launch_bounds__(256) void pack_fp6_kernel(const float* __restrict__ w, const float* __restrict__ bias,
                                                        uint8_t* __restrict__ wq, double* __restrict__ scale,
-                                                       double* __restrict__ bias_d, int Cout, int Cin) {
+                                                       double* __restrict__ bias_d, int Cout, int Cin, int w_cl) {
   __shared__ float smax[256];
   const int co = blockIdx.x, n = Cin * 9;
-  const float* wc = w + (long long)co * n;
+  const float* wc = w + (long long)co * n;     // w_cl: the channel's weights are stored [3][3][Cin] (channels-last memory format)
   float m = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(wc[i]));
   smax[threadIdx.x] = m;
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256) void pack_fp6_kernel(const float* __restrict__
   extern __shared__ uint8_t codes[];                            // [6][n]
   for (int i = threadIdx.x; i < n; i += 256) {
     // |w| 2^sh < 2^29: the scaled value is exact in fp32 and rintf rounds it like the fp64 form did
-    long long q = (long long)rintf(ldexpf(wc[i], sh));
+    long long q = (long long)rintf(ldexpf(wc[w_cl ? (i % 9) * Cin + i / 9 : i], sh));
 #pragma unroll
     for (int p = 5; p >= 1; --p) {
       const int r = (int)(((q + 16) & 31) - 16);
@@ -671,14 +671,28 @@ extern "C" long long spk_den_packed_weight_fp6_bytes(int Cout, int Cin) {
   return (long long)(Cout / 16) * (Cin / CK) * W_CHUNK_BYTES;
 }
 
-extern "C" int spk_den_pack_weight_fp6(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d,
-                                       int Cout, int Cin, hipStream_t stream) {
+static int pack_weight_fp6(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d, int Cout, int Cin,
+                           int w_cl, hipStream_t stream) {
   if (!w || !wq || !scale || !bias_d || Cout <= 0 || Cin <= 0) return SPK_ERR_ARG;
   if ((Cout % 16) || (Cin % CK)) return SPK_ERR_UNSUPPORTED;
   if ((long long)6 * Cin * 9 > spk_lds_limit()) return SPK_ERR_UNSUPPORTED;   // (one channel's six digit planes are staged in LDS)
-  hipLaunchKernelGGL(pack_fp6_kernel, dim3(Cout), dim3(256), (size_t)6 * Cin * 9, stream, w, bias, wq, scale, bias_d, Cout, Cin);
+  hipLaunchKernelGGL(pack_fp6_kernel, dim3(Cout), dim3(256), (size_t)6 * Cin * 9, stream, w, bias, wq, scale, bias_d, Cout, Cin,
+                     w_cl);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
+}
+
+extern "C" int spk_den_pack_weight_fp6(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d,
+                                       int Cout, int Cin, hipStream_t stream) {
+  return pack_weight_fp6(w, bias, wq, scale, bias_d, Cout, Cin, 0, stream);
+}
+
+// the same packing of a weight kept in the channels-last memory format, [Cout][3][3][Cin] -- what the training path keeps its
+// convolution parameters in (the library's NHWC kernels and the native gradients read and write that layout): packed every
+// iteration, it cost a layout copy per layer and iteration in front of this launch
+extern "C" int spk_den_pack_weight_fp6_cl(const float* w_cl, const float* bias, uint8_t* wq, double* scale, double* bias_d,
+                                          int Cout, int Cin, hipStream_t stream) {
+  return pack_weight_fp6(w_cl, bias, wq, scale, bias_d, Cout, Cin, 1, stream);
 }
 
 namespace {
@@ -775,6 +789,45 @@ __global__ void spikes_nhwc_to_fp4_kernel(const float* __restrict__ s, uint8_t* 
   }
 }
 }  // namespace
+
+namespace {
+// the same conversion with the per-neuron spike COUNTS over T as a by-product (fp32 [B][HW][C], channels-last): one thread = 4
+// consecutive channels of one (b, hw) for all T steps.  The training step's last layer convolves its weight gradient with these
+// counts (ops.SpikeConvMeanTrainFunction); they were a separate reduction over the [T,B,320,7,7] spike tensor (32 us at B = 32).
+__global__ void spikes_nhwc_to_fp4_counts_kernel(const float* __restrict__ s, uint8_t* __restrict__ o, float* __restrict__ cnt,
+                                                 int T, int B, int C, int HW) {
+  const int Q = C / 4;
+  const long long total = (long long)B * HW * Q, plane = (long long)B * HW * Q;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % Q);
+    const long long row = i / Q;                       // b * HW + hw
+    const int hw = (int)(row % HW), b = (int)(row / HW);
+    const int c = q * 4;
+    uint8_t* dst = o + (((long long)b * (C >> 6) + (c >> 6)) * HW + hw) * T * 32 + ((c & 63) >> 1);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < T; ++t) {
+      const float4 v = reinterpret_cast<const float4*>(s)[t * plane + i];
+      const unsigned w = (v.x != 0.f ? 0x2u : 0u) | (v.y != 0.f ? 0x20u : 0u) | (v.z != 0.f ? 0x200u : 0u) |
+                         (v.w != 0.f ? 0x2000u : 0u);
+      acc.x += v.x != 0.f ? 1.f : 0.f; acc.y += v.y != 0.f ? 1.f : 0.f;
+      acc.z += v.z != 0.f ? 1.f : 0.f; acc.w += v.w != 0.f ? 1.f : 0.f;
+      *reinterpret_cast<uint16_t*>(dst + t * 32) = (uint16_t)w;
+    }
+    reinterpret_cast<float4*>(cnt)[i] = acc;
+  }
+}
+}  // namespace
+
+extern "C" int spk_spikes_nhwc_to_fp4_counts(const float* spikes_nhwc, uint8_t* out_c4, float* counts_nhwc, int T, int B, int C,
+                                             int HW, hipStream_t stream) {
+  if (!spikes_nhwc || !out_c4 || !counts_nhwc || T <= 0 || B <= 0 || C <= 0 || HW <= 0) return SPK_ERR_ARG;
+  if (C % 64) return SPK_ERR_UNSUPPORTED;
+  const long long total = (long long)B * HW * (C / 4);
+  hipLaunchKernelGGL(spikes_nhwc_to_fp4_counts_kernel, dim3(spk_blocks(total, 256) > 65536 ? 65536 : spk_blocks(total, 256)),
+                     dim3(256), 0, stream, spikes_nhwc, out_c4, counts_nhwc, T, B, C, HW);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
 
 extern "C" int spk_spikes_nhwc_to_fp4(const float* spikes_nhwc, uint8_t* out_c4, int T, int B, int C, int HW,
                                       hipStream_t stream) {

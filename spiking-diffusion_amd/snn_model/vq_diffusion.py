@@ -536,17 +536,23 @@ class DummyModel(nn.Module):
         T = self.n_steps
         inp = ops.den_build_input(x.detach(), t)                      # [B,2,h,w]: token ids and step as floats
         h = inp.unsqueeze(0).repeat(T, 1, 1, 1, 1)
-        x1 = self.conv1(h)
-        x5 = x1
-        for blk in (self.conv2, self.conv3, self.conv4, self.conv5):
-            # conv2..conv5 see spikes: exact MFMA forward and native backward where the shape fits
-            x5 = blk.train_forward(x5, binary_input=True) if blk._trainable_fused(blk._blocks(), x5) else blk(x5)
-        if x1.permute(0, 1, 3, 4, 2).is_contiguous() and x5.permute(0, 1, 3, 4, 2).is_contiguous():
-            # the fused block tails hand over channels-last spikes: concatenate as 4-D so that the layout survives
-            cat = torch.cat((x5.flatten(0, 1), x1.flatten(0, 1)), dim=1)
-            cat = cat.view((T, x1.shape[1]) + tuple(cat.shape[1:]))
-        else:
-            cat = torch.cat((x5, x1), dim=2)
+        nbt = []                                                      # the five BatchNorm step counters: ONE launch at the end
+        for blk in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5):
+            object.__setattr__(blk, '_nbt_sink', nbt)
+        try:
+            x1 = self.conv1(h)
+            x5 = x1
+            for blk in (self.conv2, self.conv3, self.conv4, self.conv5):
+                # conv2..conv5 see spikes: exact MFMA forward and native backward where the shape fits
+                x5 = blk.train_forward(x5, binary_input=True) if blk._trainable_fused(blk._blocks(), x5) else blk(x5)
+        finally:
+            for blk in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5):
+                object.__setattr__(blk, '_nbt_sink', None)
+        if nbt:
+            torch._foreach_add_(nbt, 1)
+        # (the fused block tails hand over channels-last spikes: the operator concatenates the 4-D views so that the layout
+        #  survives, and its backward hands the two halves of the gradient on as views)
+        cat = ops.CatChannelsFunction.apply(x5, x1)
         c6 = self.conv6
         blocks6 = c6._blocks()
         if self.collapse_conv6_backward and c6._trainable_fused(blocks6, cat) and c6.exact_conv_fits(blocks6, cat):

@@ -51,8 +51,11 @@ _SIGS = {
                                      c_int, c_float, c_float, c_float, P]),
     "spk_bn_lif_train_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_longlong, c_int, c_int, c_int, c_int,
                                      c_float, c_float, c_float, c_float, c_int, P]),
+    "spk_bn_lif_train_bwd_strided": (c_int, [P, c_longlong, c_longlong, P, P, P, P, P, P, P, P, P, P, P, P, c_longlong, c_int,
+                                             c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, P]),
     "spk_den_conv3x3_fp6_raw": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_spikes_nhwc_to_fp4": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "spk_spikes_nhwc_to_fp4_counts": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "spk_conv3x3_wgrad_ws_bytes": (c_longlong, [c_int, c_int, c_int]),
     "spk_conv3x3_wgrad_bf16": (c_int, [P, P, P, c_longlong, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_conv3x3_dgrad_ws_bytes": (c_longlong, [c_int, c_int]),
@@ -74,6 +77,7 @@ _SIGS = {
                                      c_int, P, P]),
     "spk_den_packed_weight_fp6_bytes": (c_longlong, [c_int, c_int]),
     "spk_den_pack_weight_fp6": (c_int, [P, P, P, P, P, c_int, c_int, P]),
+    "spk_den_pack_weight_fp6_cl": (c_int, [P, P, P, P, P, c_int, c_int, P]),
     "spk_den_conv3x3_mfma_fp6": (c_int, [P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "spk_den_packed_weight_fp6v2_bytes": (c_longlong, [c_int, c_int]),
     "spk_den_pack_weight_fp6v2": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),
@@ -116,6 +120,8 @@ _SIGS = {
     "spk_checksum_multi": (c_int, [P, c_int, P, P]),
     "spk_clock_probe": (c_int, [P, c_int, c_int, P]),
     "spk_count_spikes": (c_int, [P, c_longlong, c_longlong, c_int, c_int, P, P]),
+    "spk_conv3x3_wgrad_small_ws_bytes": (c_longlong, [c_int, c_int, c_int, c_int, c_int]),
+    "spk_conv3x3_wgrad_small": (c_int, [P, P, P, c_longlong, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_set_option": (c_int, [ctypes.c_char_p, c_int]),
     "spk_get_option": (c_int, [ctypes.c_char_p, P]),
 }

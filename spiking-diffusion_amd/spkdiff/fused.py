@@ -248,7 +248,11 @@ class FusedSequential(nn.Sequential):
             x, lif.v = ops.BNLIFTrainFunction.apply(x, bn.weight, bn.bias, v0, bn.running_mean, bn.running_var,
                                                     bn.momentum, bn.eps, lif.tau, lif.v_threshold, lif.v_reset,
                                                     float(lif.surrogate_function.alpha), lif.detach_reset)
-            bn.num_batches_tracked.add_(1)
+            sink = getattr(self, '_nbt_sink', None)
+            if sink is not None:
+                sink.append(bn.num_batches_tracked)   # (the caller bumps all counters of the model with one launch)
+            else:
+                bn.num_batches_tracked.add_(1)
         return x
 
     def forward(self, x):

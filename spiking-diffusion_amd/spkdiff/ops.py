@@ -282,7 +282,21 @@ class BNLIFTrainFunction(torch.autograd.Function):
         tau, v_threshold, v_reset, alpha, detach_reset = ctx.cfg
         T, B, C = int(y.shape[0]), int(y.shape[1]), int(y.shape[2])
         HW = int(y.shape[3] * y.shape[4])
-        gs = _empty_cl(y.shape, y.device).zero_() if grad_s is None else _cl5(grad_s, "grad_spike_seq")
+        # grad_s as autograd left it: a dense channels-last tensor, or -- in front of the denoiser's last layer -- ONE [B,C,H,W]
+        # gradient broadcast over T (stride 0) and / or a channel slice of a wider channels-last tensor (cat(x5, x1) backward):
+        # the kernel takes the step stride and the row pitch instead of an expanded copy (25.7 MB for conv5's spikes at B = 32)
+        gs_ts, gs_pitch = B * HW * C, C
+        gs = None
+        if grad_s is not None and grad_s.is_cuda and grad_s.dtype == torch.float32 and grad_s.dim() == 5:
+            st = grad_s.stride()
+            Hh, Ww = int(y.shape[3]), int(y.shape[4])
+            pitch = st[4]
+            if (st[2] == 1 and st[3] == Ww * pitch and st[1] == Hh * Ww * pitch and pitch >= C and pitch % 4 == 0 and
+                    st[0] in (0, B * Hh * Ww * pitch) and st[0] % 4 == 0 and grad_s.data_ptr() % 16 == 0 and
+                    (st[0] == 0 or pitch != C)):
+                gs, gs_ts, gs_pitch = grad_s, int(st[0]), int(pitch)
+        if gs is None:
+            gs = _empty_cl(y.shape, y.device).zero_() if grad_s is None else _cl5(grad_s, "grad_spike_seq")
         gv = _cl4(grad_v_last, "grad_v_last")
         ws = torch.empty(int(lib.spk_bn_lif_train_ws_bytes(B, C, HW)), dtype=torch.uint8, device=y.device)
         gy = _empty_cl(y.shape, y.device)
@@ -290,10 +304,10 @@ class BNLIFTrainFunction(torch.autograd.Function):
         gb = torch.empty(C, dtype=torch.float32, device=y.device)
         gv0 = _empty_cl(y.shape[1:], y.device) if (v0 is not None and ctx.needs_input_grad[3]) else None
         with timed("train.bn_lif_bwd"):
-            check(lib.spk_bn_lif_train_bwd(_p(gs), _p(gv), _p(y), _p(g), _p(b), _p(mean), _p(invstd), _p(v0), _p(gy),
-                                           _p(gg), _p(gb), _p(gv0), _p(ws), ws.numel(), T, B, C, HW, float(tau),
-                                           float(v_threshold), float(v_reset), float(alpha), int(bool(detach_reset)),
-                                           _stream(y)), "spk_bn_lif_train_bwd")
+            check(lib.spk_bn_lif_train_bwd_strided(_p(gs), int(gs_ts), int(gs_pitch), _p(gv), _p(y), _p(g), _p(b), _p(mean),
+                                                   _p(invstd), _p(v0), _p(gy), _p(gg), _p(gb), _p(gv0), _p(ws), ws.numel(), T, B,
+                                                   C, HW, float(tau), float(v_threshold), float(v_reset), float(alpha),
+                                                   int(bool(detach_reset)), _stream(y)), "spk_bn_lif_train_bwd_strided")
         return (gy, gg if g is not None else None, gb if b is not None else None, gv0) + (None,) * 9
 
 
@@ -412,11 +426,33 @@ class ExactConvTrainFunction(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         stride, pad, transposed, out_pad, has_bias = ctx.cfg
         cout = int(weight.shape[1] if transposed else weight.shape[0])
+        if (NATIVE_WGRAD and not transposed and not ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and stride == 1 and
+                pad == 1 and tuple(weight.shape[2:]) == (3, 3) and int(weight.shape[1]) <= 4 and x.dim() == 4):
+            # few input channels, dense input, no input gradient wanted: the denoiser's first layer (spk_conv3x3_wgrad_small)
+            return (None,) + conv3x3_wgrad_small(grad_y, x, weight, has_bias and ctx.needs_input_grad[2]) + (None,) * 4
         gi, gw, gb = torch.ops.aten.convolution_backward(
             grad_y.contiguous(), x.contiguous(), weight, [cout], [stride, stride], [pad, pad], [1, 1], transposed,
             [out_pad, out_pad], 1,
             [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), bool(has_bias and ctx.needs_input_grad[2])])
         return gi, gw, gb, None, None, None, None
+
+
+def conv3x3_wgrad_small(grad_y, x, weight, want_bias):
+    """(gw, gb) of a 3x3 / s1 / p1 convolution with <= 4 input channels from gy [N,Cout,H,W] and the dense input x [N,Cin,H,W]
+    (spk_conv3x3_wgrad_small); gw comes in the memory format of ``weight`` (channels-last while training)."""
+    N, Cout, H, W = (int(v) for v in grad_y.shape)
+    Cin = int(x.shape[1])
+    gy = grad_y if grad_y.is_contiguous(memory_format=torch.channels_last) else grad_y.contiguous(memory_format=torch.channels_last)
+    xin = _dev(x.detach(), "x", torch.float32)
+    cl = weight.dim() == 4 and weight.is_contiguous(memory_format=torch.channels_last) and not weight.is_contiguous()
+    gw = torch.empty_like(weight, memory_format=torch.channels_last if cl else torch.contiguous_format)
+    gb = torch.empty(Cout, dtype=torch.float32, device=gy.device) if want_bias else None
+    nb = int(lib.spk_conv3x3_wgrad_small_ws_bytes(N, H, W, Cout, Cin))
+    ws = torch.empty(nb, dtype=torch.uint8, device=gy.device)
+    with timed("train.conv_bwd_weight"):
+        check(lib.spk_conv3x3_wgrad_small(_p(gy), _p(xin), _p(ws), nb, _p(gw), _p(gb), N, H, W, Cout, Cin, int(cl), _stream(gy)),
+              "spk_conv3x3_wgrad_small")
+    return gw, gb
 
 
 # Training forward of a stand-alone convolution: exact direct kernel up to this many multiply-accumulates per call (its fp64
@@ -721,7 +757,11 @@ def den_fp6_supported(Cout, Cin, k, stride, pad, T, H, W):
 
 def den_pack_weight_fp6(w, bias):
     """[Cout,Cin,3,3] fp32 -> (e2m3 digit planes u8, fp64 scale [Cout], fp64 bias [Cout])."""
-    w = _dev(w.detach(), "weight", torch.float32)
+    wd = w.detach()
+    # a channels-last weight (the training path's parameter format) is packed as stored: no layout copy per layer and iteration
+    cl = (wd.is_cuda and wd.dtype == torch.float32 and wd.dim() == 4 and tuple(wd.shape[2:]) == (3, 3) and not wd.is_contiguous()
+          and wd.is_contiguous(memory_format=torch.channels_last))
+    w = wd if cl else _dev(wd, "weight", torch.float32)
     Cout, Cin = w.shape[0], w.shape[1]
     nbytes = lib.spk_den_packed_weight_fp6_bytes(Cout, Cin)
     if nbytes < 0:
@@ -730,8 +770,8 @@ def den_pack_weight_fp6(w, bias):
     scale = torch.empty(Cout, dtype=torch.float64, device=w.device)
     bias_d = torch.empty(Cout, dtype=torch.float64, device=w.device)
     b = None if bias is None else _dev(bias.detach(), "bias", torch.float32)
-    check(lib.spk_den_pack_weight_fp6(_p(w), _p(b), _p(wq), _p(scale), _p(bias_d), Cout, Cin, _stream(w)),
-          "spk_den_pack_weight_fp6")
+    check((lib.spk_den_pack_weight_fp6_cl if cl else lib.spk_den_pack_weight_fp6)(
+        _p(w), _p(b), _p(wq), _p(scale), _p(bias_d), Cout, Cin, _stream(w)), "spk_den_pack_weight_fp6")
     return wq, scale, bias_d
 
 
@@ -759,6 +799,16 @@ def spikes_cl_to_c4(s):
     return o
 
 
+def spikes_cl_to_c4_counts(s):
+    """spikes_cl_to_c4 + the spike counts over T, fp32 [B,C,H,W] (channels-last memory), from the same pass."""
+    s = _cl5(s, "spikes")
+    T, B, C, H, W = s.shape
+    o = torch.empty((B, C // 64, H, W, T, 32), dtype=C4_DTYPE, device=s.device)
+    cnt = _empty_cl((B, C, H, W), s.device)
+    check(lib.spk_spikes_nhwc_to_fp4_counts(_p(s), _p(o), _p(cnt), T, B, C, H * W, _stream(s)), "spk_spikes_nhwc_to_fp4_counts")
+    return o, cnt
+
+
 def den_conv3x3_fp6_raw(in0, packed, Cout):
     """in0: C4 spikes [B, C/64, H, W, 16, 32] -> exact pre-activations fp32 [T,B,Cout,H,W], channels-last memory."""
     in0 = _dev(in0, "in0", C4_DTYPE)
@@ -771,7 +821,7 @@ def den_conv3x3_fp6_raw(in0, packed, Cout):
 
 
 def conv3x3_wgrad_supported(Cout, Cin, H, W):
-    return (H, W) == (7, 7) and Cout % 128 == 0 and Cin % 64 == 0 and Cout * Cin >= 32768   # (smaller layers: the framework's operator is as fast)
+    return (H, W) == (7, 7) and Cout % 128 == 0 and Cin % 64 == 0
 
 
 # False: the weight gradient of the spike-input convolutions comes from the framework's operator (as in rounds 1-2)
@@ -795,8 +845,8 @@ def conv3x3_wgrad(gy_cl, spikes_cl, Cout, Cin, want_bias=False):
 
 
 def conv3x3_dgrad_supported(Cout, Cin, H, W, N):
-    # (small layers and small batches: the framework's operator is as fast)
-    return ((H, W) in ((7, 7), (8, 8)) and Cout % 16 == 0 and Cin % 32 == 0 and Cout * Cin >= 32768 and N >= 64
+    # (small batches: the framework's operator is as fast)
+    return ((H, W) in ((7, 7), (8, 8)) and Cout % 16 == 0 and Cin % 32 == 0 and Cout * Cin >= 8192 and N >= 64
             and N * H * W * Cout < 2 ** 31)              # (32-bit element offsets in the kernel's staging table)
 
 
@@ -886,6 +936,26 @@ class SpikeConvTrainFunction(torch.autograd.Function):
         return gi, gw, gb
 
 
+class CatChannelsFunction(torch.autograd.Function):
+    """cat((a, b), dim=2) of two [T,B,C,H,W] spike trains (R/snn_model/vq_diffusion.py:205).  Forward: the framework's cat, on the
+    4-D views when both operands are channels-last (so that the layout survives).  Backward: two channel SLICES of the incoming
+    gradient, as views -- the gradient in front of the last layer is one [B,C,H,W] tensor broadcast over T (stride 0), which the
+    reshape in the framework's own backward of flatten + cat + view had to expand and copy (32 MB at B = 32) before slicing."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.ca = int(a.shape[2])
+        T = int(a.shape[0])
+        if a.permute(0, 1, 3, 4, 2).is_contiguous() and b.permute(0, 1, 3, 4, 2).is_contiguous():
+            cat = torch.cat((a.flatten(0, 1), b.flatten(0, 1)), dim=1)
+            return cat.view((T, a.shape[1]) + tuple(cat.shape[1:]))
+        return torch.cat((a, b), dim=2)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :, :ctx.ca], g[:, :, ctx.ca:]
+
+
 class SpikeConvMeanTrainFunction(torch.autograd.Function):
     """mean over T of conv3x3(spikes_t, weight) + bias -- the denoiser's last layer and its time mean
     (R/snn_model/vq_diffusion.py:185-187, 205-206) as ONE differentiable operator.  Forward: the exact fp6 x fp4 MFMA convolution
@@ -899,8 +969,8 @@ class SpikeConvMeanTrainFunction(torch.autograd.Function):
         s = _cl5(spikes, "spikes")
         T, Cout = int(s.shape[0]), int(weight.shape[0])
         with timed("train.conv_fwd_fp6"):
-            y = den_conv3x3_fp6_raw(spikes_cl_to_c4(s), den_pack_weight_fp6(weight, bias), Cout)
-        counts = s.sum(dim=0)                                  # [B,Cin,H,W], channels-last like s
+            c4, counts = spikes_cl_to_c4_counts(s)             # counts [B,Cin,H,W], channels-last like s: same pass as the packing
+            y = den_conv3x3_fp6_raw(c4, den_pack_weight_fp6(weight, bias), Cout)
         ctx.save_for_backward(counts, weight)
         ctx.has_bias, ctx.T = bias is not None, T
         return torch.sum(y, dim=0) / T

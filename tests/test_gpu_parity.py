@@ -2767,3 +2767,68 @@ def test_conv3x3_data_gradient_two_term_form_scales(dev, ops):
     parity("dgrad_f16x2_scales", worst_image_channel_rel_l2=worst)
     assert worst <= 2e-6
 
+
+
+# ------------------------------------------------------------------------------------------------- round 4: training-step glue made native
+@pytest.mark.parametrize("N,Cin,Cout,HH,cl", [(512, 2, 64, 7, True), (37, 3, 128, 8, False), (5, 1, 96, 7, True)])
+def test_small_input_weight_gradient_kernel_vs_fp64(dev, ops, N, Cin, Cout, HH, cl):
+    """spk_conv3x3_wgrad_small (the denoiser's first layer in the training step: two input channels, dense input) against the fp64
+    weight / bias gradient of the same convolution; both weight memory formats; deterministic."""
+    g = torch.Generator().manual_seed(N + Cout)
+    gy = torch.randn(N, Cout, HH, HH, generator=g) * 1e-2
+    x = torch.randn(N, Cin, HH, HH, generator=g) * 3.0
+    w = torch.zeros(Cout, Cin, 3, 3)
+    _, gw64, gb64 = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), [Cout], [1, 1], [1, 1], [1, 1], False,
+                                                        [0, 0], 1, [False, True, True])
+    wd = w.to(dev).contiguous(memory_format=torch.channels_last) if cl else w.to(dev)
+    gw, gb = ops.conv3x3_wgrad_small(gy.to(dev), x.to(dev), wd, True)
+    assert gw.shape == w.shape and (gw.is_contiguous(memory_format=torch.channels_last) if cl and Cin > 1 else True)
+    rel = float((gw.cpu().double() - gw64).norm() / gw64.norm())
+    relb = float((gb.cpu().double() - gb64).norm() / gb64.norm())
+    parity(f"wgrad_small_N{N}_{Cin}_{Cout}", rel_l2_err=rel, bias_rel_l2_err=relb)
+    assert rel <= 3e-7 and relb <= 3e-7
+    gw2, gb2 = ops.conv3x3_wgrad_small(gy.to(dev), x.to(dev), wd, True)
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+
+
+def test_bn_lif_backward_reads_broadcast_and_pitched_gradients(dev, ops):
+    """spk_bn_lif_train_bwd_strided: the gradient of the spikes in front of the denoiser's last layer arrives as ONE [B,C,H,W]
+    tensor broadcast over T and as a channel slice of cat(x5, x1)'s wider gradient; reading it in place gives, bit for bit, what
+    the expanded dense copy gives."""
+    T, B, C, H, W, Cw = 16, 6, 64, 7, 7, 96
+    g = torch.Generator().manual_seed(3)
+    y = torch.randn(T, B, C, H, W, generator=g).to(dev)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(C, generator=g)).to(dev)
+    wide = torch.randn(B, Cw, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for mode in ("view", "dense"):
+        yy = y.clone().requires_grad_(True)
+        ga, be = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        s, v_last = ops.BNLIFTrainFunction.apply(yy, ga, be, None, rm, rv, 0.1, 1e-5, 2.0, 1.0, 0.0, 2.0, False)
+        gs = wide[:, 16:16 + C].unsqueeze(0).expand(T, B, C, H, W)          # stride 0 over T, row pitch 96 > 64
+        assert gs.stride(0) == 0 and gs.stride(4) == Cw
+        if mode == "dense":
+            gs = gs.contiguous()
+        s.backward(gs)
+        outs.append((yy.grad.clone(), ga.grad.clone(), be.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_fp6_weight_packing_reads_channels_last_weights(dev, ops):
+    """spk_den_pack_weight_fp6_cl == spk_den_pack_weight_fp6 on the same values (the training path keeps its weights channels-last);
+    the packing pass that also counts spikes == the plain one + sum over T."""
+    g = torch.Generator().manual_seed(9)
+    w = (torch.randn(128, 64, 3, 3, generator=g) * 0.05).to(dev)
+    b = torch.randn(128, generator=g).to(dev)
+    p0 = ops.den_pack_weight_fp6(w, b)
+    p1 = ops.den_pack_weight_fp6(w.contiguous(memory_format=torch.channels_last), b)
+    assert torch.equal(p0[1], p1[1]) and torch.equal(p0[2], p1[2])             # scales, biases (the slabs carry unwritten padding)
+    s = (torch.rand(16, 5, 64, 7, 7, generator=g) < 0.07).float().to(dev)
+    s = s.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)            # channels-last memory
+    c4, cnt = ops.spikes_cl_to_c4_counts(s)
+    assert torch.equal(c4, ops.spikes_cl_to_c4(s)) and torch.equal(cnt, s.sum(0))
+    y0, y1 = ops.den_conv3x3_fp6_raw(c4, p0, 128), ops.den_conv3x3_fp6_raw(c4, p1, 128)
+    assert torch.equal(y0, y1) and float(y0.abs().max()) > 0
