@@ -471,6 +471,11 @@ int spk_den_step_tail(const uint8_t* cnt5, int nch5, const uint8_t* cnt1, int nc
                       const float* conv1_w_packed_or_null, const float* conv1_bias_or_null, const float* bn1_a,
                       const float* bn1_b, uint8_t* x1_s32_out_or_null, uint8_t* cnt1_out_or_null, int T, int B, int H, int W,
                       int K, spk_stream_t stream);
+/* q_sample of the diffusion training step, R/snn_model/vq_diffusion.py:61-75: mask = u < t[b] / num_timesteps (fp32, as there);
+ * x_t = mask ? mask_id : x_0;  x_0_ignore = mask ? x_0 : -1 (the loss's ignore index).  x0 / u / outputs fp32 [B*HW], t int64 [B],
+ * mask_out optional u8.  u is the caller's draw (torch.rand_like in the reference's order). */
+int spk_q_sample(const float* x0, const long long* t, const float* u, float* x_t_out, float* x0_ignore_out,
+                 uint8_t* mask_out_or_null, int B, int HW, int num_timesteps, float mask_id, spk_stream_t stream);
 /* The noise of one reverse step as spk_psample_step / spk_select_active / spk_select_needed draw it in Philox mode, written
  * out (parity aid: R/snn_model/vq_diffusion.py:116 `rand_like` -> u, :138 `Categorical.sample()` -> q ~ Exp(1)): u_out [B*HW] =
  * the uniforms of the `changes` test, q_out [B*HW*K] = the exponentials of the categorical race; same (seed, offset,

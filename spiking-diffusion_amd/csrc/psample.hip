@@ -318,6 +318,33 @@ __global__ __launch_bounds__(256) void philox_noise_kernel(unsigned long long se
 
 }  // namespace
 
+namespace {
+// q_sample of the training step (R/snn_model/vq_diffusion.py:61-75): mask = u < t[b] / num_timesteps; x_t = mask ? mask_id : x_0;
+// x_0_ignore = mask ? x_0 : -1.  One launch for what the module sequence spends eight on (expand, float, divide, compare, two
+// fills, two selects); the uniforms u stay the framework's draw (rand_like), so the RNG stream is the reference's.
+__global__ void q_sample_kernel(const float* __restrict__ x0, const long long* __restrict__ t, const float* __restrict__ u,
+                                float* __restrict__ x_t, float* __restrict__ x0_ignore, uint8_t* __restrict__ mask, int B, int HW,
+                                float num_timesteps, float mask_id) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * HW) return;
+  const int b = i / HW;
+  const bool m = u[i] < (float)t[b] / num_timesteps;
+  const float x = x0[i];
+  x_t[i] = m ? mask_id : x;
+  x0_ignore[i] = m ? x : -1.0f;
+  if (mask) mask[i] = m ? 1 : 0;
+}
+}  // namespace
+
+extern "C" int spk_q_sample(const float* x0, const long long* t, const float* u, float* x_t_out, float* x0_ignore_out,
+                            uint8_t* mask_out_or_null, int B, int HW, int num_timesteps, float mask_id, hipStream_t stream) {
+  if (!x0 || !t || !u || !x_t_out || !x0_ignore_out || B <= 0 || HW <= 0 || num_timesteps <= 0) return SPK_ERR_ARG;
+  hipLaunchKernelGGL(q_sample_kernel, dim3((B * HW + 255) / 256), dim3(256), 0, stream, x0, t, u, x_t_out, x0_ignore_out,
+                     mask_out_or_null, B, HW, (float)num_timesteps, mask_id);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
 extern "C" int spk_philox_noise(unsigned long long philox_seed, unsigned long long philox_offset,
                                 const unsigned long long* philox_state_or_null, float* u_out_or_null, float* q_out_or_null,
                                 int B, int HW, int K, hipStream_t stream) {

@@ -121,6 +121,9 @@ class AbsorbingDiffusion(Sampler):
         """Mask each token of x_0 [B,1,h,w] with probability t/T.  Returns (x_t, x_0_ignore, mask): masked positions
         hold ``mask_id`` in x_t, unmasked positions hold -1 (the loss's ignore index) in x_0_ignore."""
         b = x_0.shape[0]
+        if x_0.is_cuda and x_0.dtype == torch.float32 and t.is_cuda and t.dtype == torch.int64 and x_0.dim() == 4:
+            # one native launch after the framework's draw (same RNG call, same order as the reference's rand_like)
+            return ops.q_sample(x_0, t, torch.rand_like(x_0), self.num_timesteps, self.mask_id)
         t_mask = t.reshape(b, 1, 1, 1).expand(b, 1, x_0.shape[2], x_0.shape[3])
         mask = torch.rand_like(x_0.float()) < (t_mask.float() / self.num_timesteps)
         x_t = torch.where(mask, torch.full_like(x_0, self.mask_id), x_0)

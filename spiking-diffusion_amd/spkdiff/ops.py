@@ -274,6 +274,9 @@ class BNLIFTrainFunction(torch.autograd.Function):
                                            _stream(y)), "spk_bn_lif_train_fwd")
         ctx.save_for_backward(y, g, b, mean, invstd, v0)
         ctx.cfg = (tau, v_threshold, v_reset, alpha, detach_reset)
+        # v_last usually ends in lif.v and nowhere in the loss: without this autograd materialises a zero gradient for it on every
+        # backward (a fill + a layout copy per block and iteration); the kernel takes a null pointer for "no gradient"
+        ctx.set_materialize_grads(False)
         return s, v_last
 
     @staticmethod
@@ -287,6 +290,8 @@ class BNLIFTrainFunction(torch.autograd.Function):
         # the kernel takes the step stride and the row pitch instead of an expanded copy (25.7 MB for conv5's spikes at B = 32)
         gs_ts, gs_pitch = B * HW * C, C
         gs = None
+        if grad_s is None and grad_v_last is None:
+            return (None,) * 13
         if grad_s is not None and grad_s.is_cuda and grad_s.dtype == torch.float32 and grad_s.dim() == 5:
             st = grad_s.stride()
             Hh, Ww = int(y.shape[3]), int(y.shape[4])
@@ -1492,6 +1497,23 @@ def den_step_tail(cnt5, cnt1, packed6, x_t, unmasked, t, temp, *, T, K, u=None, 
                                 _p(philox_state), _p(w1), _p(b1), _p(a1), _p(bb1), _p(x1), _p(c1o), int(T), B, H, W, int(K),
                                 _stream(cnt5)), "spk_den_step_tail")
     return (None if x1 is None else (x1, c1o)), logits
+
+
+def q_sample(x_0, t, u, num_timesteps, mask_id):
+    """(x_t, x_0_ignore, mask) of R/snn_model/vq_diffusion.py:61-75 from x_0 fp32 [B,1,h,w], t int64 [B] and the uniforms u
+    (spk_q_sample: one launch)."""
+    x0 = _dev(x_0, "x_0", torch.float32)
+    uu = _dev(u, "u", torch.float32)
+    tt = t.contiguous()
+    if tt.dtype != torch.int64 or not tt.is_cuda:
+        raise ValueError("t must be an int64 device tensor")
+    B = int(x0.shape[0])
+    HW = x0[0].numel()
+    x_t, ign = torch.empty_like(x0), torch.empty_like(x0)
+    mask = torch.empty(x0.shape, dtype=torch.bool, device=x0.device)
+    check(lib.spk_q_sample(_p(x0), _p(tt), _p(uu), _p(x_t), _p(ign), _p(mask), B, HW, int(num_timesteps), float(mask_id),
+                           _stream(x0)), "spk_q_sample")
+    return x_t, ign, mask
 
 
 def philox_noise(seed, offset, B, HW, K, device, philox_state=None, want_q=True):
