@@ -26,9 +26,17 @@ def main():
     class _Den(torch.nn.Module):
         num_embeddings = 128
     ab = AbsorbingDiffusion(_Den(), mask_id=128)
+    # 'global' noise layout (default): ONE key per job -- rank 0's draw, broadcast (ranks seeded differently here on purpose);
+    # 'rank' layout: the rank folded into the key, distinct streams for ranks seeded alike
+    torch.manual_seed(1000 + rank)
     key = torch.tensor([ab._philox_key()], dtype=torch.int64)
     keys = [torch.zeros_like(key) for _ in range(world)]
     dist.all_gather(keys, key)
+    ab.noise_layout = 'rank'
+    torch.manual_seed(7)
+    rkey = torch.tensor([ab._philox_key()], dtype=torch.int64)
+    rkeys = [torch.zeros_like(rkey) for _ in range(world)]
+    dist.all_gather(rkeys, rkey)
     lo, hi = sdist.shard_range(args.global_batch or args.batch or 256 * world, rank, world)
     imgs = sdist.gather_images(torch.full((hi - lo, 1, 2, 2), rank, dtype=torch.uint8), args.global_batch)
     t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
@@ -37,7 +45,8 @@ def main():
     if rank == 0:
         print("noise before the line")
         print(json.dumps({"metric": "stub", "n_gpus": world, "ranks_seen": dist.get_world_size(),
-                          "keys_distinct": len({int(k) for k in keys}) == world, "images": int(imgs.shape[0]),
+                          "keys_distinct": len({int(k) for k in rkeys}) == world,
+                          "job_key_shared": len({int(k) for k in keys}) == 1, "images": int(imgs.shape[0]),
                           "max_t": float(t), "steps": args.steps, "warmup": args.warmup}))
     dist.destroy_process_group()
 

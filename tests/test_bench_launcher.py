@@ -27,7 +27,8 @@ def test_plain_start_with_two_gpus_launches_two_ranks_and_relays_one_line():
     assert len(lines) == 1, p.stdout                       # exactly one line on stdout: the result
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 3 and d["warmup"] == 1
-    assert d["keys_distinct"] is True, "ranks seeded alike must still draw distinct Philox keys"
+    assert d["job_key_shared"] is True, "'global' noise layout: every rank works under the job's ONE Philox key (rank 0's draw)"
+    assert d["keys_distinct"] is True, "'rank' layout: ranks seeded alike must still draw distinct Philox keys"
     assert d["images"] == 7 and abs(d["max_t"] - 0.2) < 1e-12          # ragged shards gathered; max over ranks
 
 
@@ -39,7 +40,7 @@ def test_eight_ranks_one_line_and_exit_codes():
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["images"] == 8195 and d["keys_distinct"] is True
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["images"] == 8195 and d["keys_distinct"] is True and d["job_key_shared"] is True
     assert abs(d["max_t"] - 0.8) < 1e-12
     p = _run(["--gpus", "8"], {"STUB_FAIL": "1"}, timeout=600)
     assert p.returncode != 0 and p.stdout.strip() == ""
