@@ -145,6 +145,14 @@ int spk_bn_lif_train_bwd_strided(const float* grad_spike_seq, long long grad_ste
                                  float* grad_gamma, float* grad_beta, float* grad_v_init, void* ws, long long ws_bytes, int T,
                                  int B, int C, int HW, float tau, float v_threshold, float v_reset, float alpha,
                                  int detach_reset, spk_stream_t stream);
+/* The same forward, also leaving the spikes as "C4" records [B][C/64][HW][T][32 bytes = 64 channels x e2m1] (spikes_c4_out, or
+ * NULL) -- the input format of spk_den_conv3x3_fp6_raw, i.e. of the NEXT block's convolution in the training forward; the apply
+ * launch writes them next to the fp32 spikes.  Needs C % 64 == 0 and 16-byte aligned tensors (SPK_ERR_UNSUPPORTED otherwise,
+ * nothing launched). */
+int spk_bn_lif_train_fwd_c4(const float* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                            float momentum, float eps, const float* v_init, float* spike_seq, float* v_out, float* save_mean,
+                            float* save_invstd, uint8_t* spikes_c4_out, void* ws, long long ws_bytes, int T, int B, int C,
+                            int HW, float tau, float v_threshold, float v_reset, spk_stream_t stream);
 /* Training forward of a denoiser convolution on spike input (layer.Conv2d 'm' mode in train(), SJ/activation_based/layer.py:164-173,
  * for conv2..conv5 of DummyModel, R/snn_model/vq_diffusion.py:166-184): the exact fp6 x fp4 MFMA convolution of
  * spk_den_conv3x3_mfma_fp6 with the pre-activations (conv + bias, correctly rounded fp32 of the exact dot product) written
@@ -246,6 +254,12 @@ int spk_den_pack_weight_fp6(const float* w, const float* bias, uint8_t* wq, doub
  * convolution parameters, R/main.py:226-252 with NHWC library kernels): no layout copy in front of the per-iteration packing. */
 int spk_den_pack_weight_fp6_cl(const float* w_channels_last, const float* bias, uint8_t* wq, double* scale, double* bias_d,
                                int Cout, int Cin, spk_stream_t stream);
+/* The channels-last packing of n <= 8 layers in ONE launch (a training iteration re-packs every spike-input layer once per
+ * optimizer step, R/main.py:243-252).  HOST arrays of n entries (bias may be NULL, or hold NULL entries); per layer the result
+ * is spk_den_pack_weight_fp6_cl's byte for byte. */
+int spk_den_pack_weight_fp6_cl_multi(const float* const* w_channels_last, const float* const* bias, uint8_t* const* wq,
+                                     double* const* scale, double* const* bias_d, const int* Cout, const int* Cin, int n,
+                                     spk_stream_t stream);
 /* in_c4: nch chunks of 64 channels; out_c4 [B][Cout/64][h*w][16][32]; v_inout / out_counts as in spk_den_conv3x3_mfma.
  * SPK_ERR_UNSUPPORTED unless T == 16, Cout % 64 == 0 and the latent fits one of the kernel's LDS plans (up to 7x8 as
  * one item per image and channel group, 8x8 as two row bands).
@@ -397,6 +411,16 @@ int spk_conv3x3_dgrad_bf16(const float* gy_cl, const float* w_cl, uint8_t* ws, l
  * precision.  Same arguments, workspace and shapes as spk_conv3x3_dgrad_bf16. */
 int spk_conv3x3_dgrad_f16x2(const float* gy_cl, const float* w_cl, uint8_t* ws, long long ws_bytes, float* gi_out, int N, int H,
                             int W, int Cout, int Cin, spk_stream_t stream);
+/* spk_conv3x3_dgrad_f16x2 in two halves.  pack_multi: the weight half (per-channel maxima + the two fp16 term planes) of
+ * n <= 8 layers in ONE launch -- inside a training iteration each layer's backward otherwise spends a fill, a maximum and a pack
+ * launch on weights that change once per optimizer step.  HOST arrays of n entries; ws[i]: spk_conv3x3_dgrad_ws_bytes(Cout[i],
+ * Cin[i]) bytes; N[i]: the image count the data half will be called with (the packed tile width depends on it).  prepacked: the
+ * data half on such a workspace, bit-identical to the one-call form.  A workspace packed for another tile width (another N)
+ * yields NaN, not a permuted result. */
+int spk_conv3x3_dgrad_f16x2_pack_multi(const float* const* w_cl, uint8_t* const* ws, const long long* ws_bytes, const int* N,
+                                       const int* Cout, const int* Cin, int n, spk_stream_t stream);
+int spk_conv3x3_dgrad_f16x2_prepacked(const float* gy_cl, const uint8_t* ws, long long ws_bytes, float* gi_out, int N, int H,
+                                      int W, int Cout, int Cin, spk_stream_t stream);
 
 /* Weight and bias gradient of a 3x3 / stride 1 / pad 1 convolution with FEW input channels (Cin <= 4) and a dense fp32 input: the
  * denoiser's first layer in the training step (cat(x_t, t): two channels, R/snn_model/vq_diffusion.py:161-165,195-201; what

@@ -296,7 +296,8 @@ __global__ __launch_bounds__(TPB) void bn_lif_apply_v_kernel(const float* __rest
                                                              const float* __restrict__ beta, const float* __restrict__ save_mean,
                                                              const float* __restrict__ save_invstd, const float* __restrict__ v_init,
                                                              float* __restrict__ spikes, float* __restrict__ v_out, GeoV g,
-                                                             float tau, float v_th, float v_reset) {
+                                                             float tau, float v_th, float v_reset, uint8_t* __restrict__ c4,
+                                                             int HW) {
   typedef typename Vec<VEC>::type vf;
   const int q = threadIdx.x % g.Q, j = threadIdx.x / g.Q;
   const long long ts = (long long)g.R * g.Q;
@@ -333,6 +334,17 @@ __global__ __launch_bounds__(TPB) void bn_lif_apply_v_kernel(const float* __rest
           o[i] = sp;
         }
         sv[n + t * ts] = o;
+        if constexpr (VEC == 4) {
+          // the same spikes as "C4" records [B][C / 64][HW][T][32 bytes = 64 channels x e2m1] -- what the next layer's exact
+          // MFMA forward reads (spk_spikes_nhwc_to_fp4 made them from the fp32 tensor: a launch per layer and iteration)
+          if (c4) {
+            const int bb = r / HW, hw = r - bb * HW, c = q * 4;
+            const unsigned w = (o[0] != 0.f ? 0x2u : 0u) | (o[1] != 0.f ? 0x20u : 0u) | (o[2] != 0.f ? 0x200u : 0u) |
+                               (o[3] != 0.f ? 0x2000u : 0u);
+            *reinterpret_cast<uint16_t*>(c4 + ((((long long)bb * (g.C >> 6) + (c >> 6)) * HW + hw) * g.T + t) * 32 +
+                                         ((c & 63) >> 1)) = (uint16_t)w;
+          }
+        }
       }
     }
     if (v_out) reinterpret_cast<vf*>(v_out)[n] = v;
@@ -507,10 +519,11 @@ extern "C" long long spk_bn_lif_train_ws_bytes(int B, int C, int HW) {
   return (long long)C * max_slices(B * HW, C) * 2 * (long long)sizeof(double);
 }
 
-extern "C" int spk_bn_lif_train_fwd(const float* y, const float* gamma, const float* beta, float* running_mean,
-                                    float* running_var, float momentum, float eps, const float* v_init, float* spike_seq,
-                                    float* v_out, float* save_mean, float* save_invstd, void* ws, long long ws_bytes, int T,
-                                    int B, int C, int HW, float tau, float v_threshold, float v_reset, hipStream_t stream) {
+static int bn_lif_train_fwd_impl(const float* y, const float* gamma, const float* beta, float* running_mean,
+                                 float* running_var, float momentum, float eps, const float* v_init, float* spike_seq,
+                                 float* v_out, float* save_mean, float* save_invstd, void* ws, long long ws_bytes, int T,
+                                 int B, int C, int HW, float tau, float v_threshold, float v_reset, uint8_t* c4,
+                                 hipStream_t stream) {
   if (!y || !spike_seq || !save_mean || !save_invstd || !ws || T <= 0 || T > SPK_MAX_T || B <= 0 || C <= 0 || HW <= 0 ||
       !(tau > 0.f) || (long long)B * HW > (1LL << 30))
     return SPK_ERR_ARG;
@@ -519,6 +532,7 @@ extern "C" int spk_bn_lif_train_fwd(const float* y, const float* gamma, const fl
   const double M = (double)T * R;
   const bool al = aligned16(y) && aligned16(spike_seq) && (!v_init || aligned16(v_init)) && (!v_out || aligned16(v_out));
   const int vec = al ? vec_for(C, 4) : 1;
+  if (c4 && (vec != 4 || (C % 64))) return SPK_ERR_UNSUPPORTED;          // (C4 records hold 64 channels; four per thread)
   if (vec >= 2) {
     const int S = slices_v(R, C, vec);
     const GeoV g = geo_v(T, R, C, vec, S);
@@ -528,10 +542,10 @@ extern "C" int spk_bn_lif_train_fwd(const float* y, const float* gamma, const fl
                        momentum, running_mean, running_var, save_mean, save_invstd);
     if (vec == 4)
       hipLaunchKernelGGL(bn_lif_apply_v_kernel<4>, dim3(S), dim3(TPB), 0, stream, y, gamma, beta, save_mean, save_invstd,
-                         v_init, spike_seq, v_out, g, tau, v_threshold, v_reset);
+                         v_init, spike_seq, v_out, g, tau, v_threshold, v_reset, c4, HW);
     else
       hipLaunchKernelGGL(bn_lif_apply_v_kernel<2>, dim3(S), dim3(TPB), 0, stream, y, gamma, beta, save_mean, save_invstd,
-                         v_init, spike_seq, v_out, g, tau, v_threshold, v_reset);
+                         v_init, spike_seq, v_out, g, tau, v_threshold, v_reset, (uint8_t*)nullptr, HW);
   } else {
     const int S = slices(R, C);
     const Geo g{T, R, C, S, (long long)R * C, (long long)C};
@@ -544,6 +558,29 @@ extern "C" int spk_bn_lif_train_fwd(const float* y, const float* gamma, const fl
   }
   SPK_LAUNCH_CHECK();
   return SPK_OK;
+}
+
+extern "C" int spk_bn_lif_train_fwd(const float* y, const float* gamma, const float* beta, float* running_mean,
+                                    float* running_var, float momentum, float eps, const float* v_init, float* spike_seq,
+                                    float* v_out, float* save_mean, float* save_invstd, void* ws, long long ws_bytes, int T,
+                                    int B, int C, int HW, float tau, float v_threshold, float v_reset, hipStream_t stream) {
+  return bn_lif_train_fwd_impl(y, gamma, beta, running_mean, running_var, momentum, eps, v_init, spike_seq, v_out, save_mean,
+                               save_invstd, ws, ws_bytes, T, B, C, HW, tau, v_threshold, v_reset, nullptr, stream);
+}
+
+// The same forward, also leaving the spikes as C4 records [B][C / 64][HW][T][32] (spikes_c4_out, or null) for the next layer's
+// exact MFMA forward: the apply launch writes them next to the fp32 spikes (a conversion launch per layer and iteration
+// before).  spikes_c4_out needs C % 64 == 0 and 16-byte aligned tensors (SPK_ERR_UNSUPPORTED otherwise: nothing launched).
+// (Measured and dropped in round 4: finishing the per-channel reduction in the last workgroup of the statistics launch instead of
+//  a finalize launch -- one workgroup reading 784 x 512 partial pairs takes 200-350 us where the 128-workgroup finalize launch
+//  takes 6.)
+extern "C" int spk_bn_lif_train_fwd_c4(const float* y, const float* gamma, const float* beta, float* running_mean,
+                                       float* running_var, float momentum, float eps, const float* v_init, float* spike_seq,
+                                       float* v_out, float* save_mean, float* save_invstd, uint8_t* spikes_c4_out, void* ws,
+                                       long long ws_bytes, int T, int B, int C, int HW, float tau, float v_threshold,
+                                       float v_reset, hipStream_t stream) {
+  return bn_lif_train_fwd_impl(y, gamma, beta, running_mean, running_var, momentum, eps, v_init, spike_seq, v_out, save_mean,
+                               save_invstd, ws, ws_bytes, T, B, C, HW, tau, v_threshold, v_reset, spikes_c4_out, stream);
 }
 
 static int bn_lif_train_bwd_impl(const float* grad_spike_seq, long long gs_ts, long long gs_pitch, const float* grad_v_last,

@@ -52,6 +52,7 @@ __host__ __device__ constexpr int w_blob(int nterm, int nt) { return nterm * 9 *
 struct DgArgs {
   const float* gy; const uint8_t* wp; float* gi;
   const unsigned* wmax;                                     // F16 form: bits of max |w| per input channel
+  const unsigned* tag;                                      // prepacked weights: the channel-tile width they were packed for (or null)
   int N, Cout, Cin;
 };
 
@@ -117,6 +118,77 @@ __global__ void dgrad_pack_f16_kernel(const float* __restrict__ w, const unsigne
     const long long o = blob + ((long long)(tap * 2 + kh) * CI + cil) * 8 + e;
     wp[o] = h;
     wp[o + 9LL * 2 * CI * 8] = m;
+  }
+}
+
+// F16 form, BOTH pre-passes for the weights of up to eight layers in ONE launch (spk_conv3x3_dgrad_f16x2_pack_multi): a training
+// iteration packed each layer's weights inside that layer's backward -- a fill, a maximum and a pack launch per layer, 15 small
+// launches and ~75 us per iteration at the reference's batch.  Here a workgroup owns EIGHT input channels of one layer: it reads
+// their [Cout * 9] x 8 slice once for the maxima (32-byte row segments; LDS atomics, no zeroed global buffer, no ordering
+// between workgroups -> deterministic), then again (from L2) for the two fp16 terms.  Same arithmetic as the two kernels above:
+// the packed bytes are identical (tests/test_gpu_parity.py::test_dgrad_prepacked_multi_identical).
+constexpr int DG_MULTI_MAX = 8, DG_CB = 8;
+struct DgPackMulti {
+  const float* w[DG_MULTI_MAX]; _Float16* wp[DG_MULTI_MAX]; unsigned* wmax[DG_MULTI_MAX];
+  int Cout[DG_MULTI_MAX], Cin[DG_MULTI_MAX], CI[DG_MULTI_MAX], first[DG_MULTI_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void dgrad_pack_f16_multi_kernel(DgPackMulti m) {
+  __shared__ unsigned smax[DG_CB];
+  int L = 0;
+  while (L + 1 < m.n && (int)blockIdx.x >= m.first[L + 1]) ++L;
+  const int Cout = m.Cout[L], Cin = m.Cin[L], CI = m.CI[L], ci0 = ((int)blockIdx.x - m.first[L]) * DG_CB;
+  const float* __restrict__ w = m.w[L];
+  const int tid = threadIdx.x, rows = Cout * 9;
+  if (tid < DG_CB) smax[tid] = 0u;
+  __syncthreads();
+  {
+    const int hf = tid & 1;
+    unsigned mx[4] = {0u, 0u, 0u, 0u};
+    constexpr int UN = 4;
+    for (int r0 = tid >> 1; r0 < rows; r0 += 128 * UN) {
+      v4f v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int r = r0 + 128 * u;
+        v[u] = *reinterpret_cast<const v4f*>(w + (long long)(r < rows ? r : rows - 1) * Cin + ci0 + 4 * hf);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned b = __float_as_uint(v[u][e]) & 0x7FFFFFFFu;
+          mx[e] = b > mx[e] ? b : mx[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicMax(&smax[4 * hf + e], mx[e]);
+  }
+  __syncthreads();
+  if (tid < DG_CB) m.wmax[L][ci0 + tid] = smax[tid];
+  if (ci0 == 0 && tid == 0) m.wmax[L][Cin] = (unsigned)CI;    // (what the data call checks its own tile width against)
+  const int cil = tid & 7, ci = ci0 + cil;
+  const float sc = scale_of(smax[cil]);
+  const int n_chunks = Cout / KC, tile = ci / CI, cit = ci % CI;
+  const long long term = 9LL * 2 * CI * 8;
+  _Float16* __restrict__ wp = m.wp[L];
+  // item = (8 output channels kk, tap, channel): eight strided reads (32-byte segments across the eight lanes of a row), one 16-byte
+  // store per term
+  for (int i = tid; i < (Cout / 8) * 72; i += 256) {
+    const int tap = (i >> 3) % 9, kk = i / 72, chunk = kk >> 1, kh = kk & 1;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = w[((long long)(kk * 8 + e) * 9 + tap) * Cin + ci];
+    v8h h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      _Float16 a, b;
+      split2h(x[e] * sc, a, b);
+      h[e] = a; l[e] = b;
+    }
+    const long long o = ((long long)tile * n_chunks + chunk) * (2 * term) + ((long long)(tap * 2 + kh) * CI + cit) * 8;
+    *reinterpret_cast<v8h*>(wp + o) = h;
+    *reinterpret_cast<v8h*>(wp + o + term) = l;
   }
 }
 
@@ -341,6 +413,9 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_kernel(DgArgs a) {
   }
 
   const int n = n0 + wave;
+  // weights packed by the multi-layer call for ANOTHER tile width (another N): the result would be a silent permutation --
+  // NaN instead (the host cannot see the tag without a synchronisation)
+  const bool bad_pack = a.tag && a.tag[0] != (unsigned)CI;
   if (n < a.N) {
     float* out = a.gi + (long long)n * HW7 * a.Cin + ci0 + row;
     float cinv[NT];
@@ -356,7 +431,7 @@ __global__ __launch_bounds__(NTHR, 1) void dgrad3x3_kernel(DgArgs a) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             const float v = acc[mt][nt][r] + acs[mt][nt][r];
-            out[(long long)p * a.Cin + nt * 32] = F16 ? (v * my_inv) * cinv[nt] : v;      // (powers of two: exact)
+            out[(long long)p * a.Cin + nt * 32] = bad_pack ? __uint_as_float(0x7FC00000u) : F16 ? (v * my_inv) * cinv[nt] : v;   // (powers of two: exact)
           }
         }
       }
@@ -377,8 +452,8 @@ int dgrad_nt(bool f16, int N, int Cin) {
 
 template <bool F16>
 int dgrad_launch(const float* gy_cl, const float* w_cl, uint8_t* ws, long long ws_bytes, float* gi_out, int N, int H, int W,
-                 int Cout, int Cin, hipStream_t stream) {
-  if (!gy_cl || !w_cl || !ws || !gi_out || N <= 0) return SPK_ERR_ARG;
+                 int Cout, int Cin, hipStream_t stream, bool prepacked = false) {
+  if (!gy_cl || (!w_cl && !prepacked) || !ws || !gi_out || N <= 0) return SPK_ERR_ARG;
   if (H != W || (H != 7 && H != 8) || Cout <= 0 || Cin <= 0 || (Cout % KC) || (Cin % 32)) return SPK_ERR_UNSUPPORTED;
   if ((long long)N * H * W * Cout >= (1LL << 31)) return SPK_ERR_UNSUPPORTED;    // (32-bit element offsets in the staging table)
   if (ws_bytes < spk_conv3x3_dgrad_ws_bytes(Cout, Cin)) return SPK_ERR_ARG;
@@ -388,7 +463,10 @@ int dgrad_launch(const float* gy_cl, const float* w_cl, uint8_t* ws, long long w
   DgArgs a;
   a.gy = gy_cl; a.wp = ws; a.gi = gi_out; a.N = N; a.Cout = Cout; a.Cin = Cin;
   a.wmax = reinterpret_cast<const unsigned*>(ws + n * 6);
-  if (F16) {
+  a.tag = prepacked ? a.wmax + Cin : nullptr;
+  if (prepacked) {
+    // (the workspace already holds this layer's packed terms and maxima: spk_conv3x3_dgrad_f16x2_pack_multi, same N)
+  } else if (F16) {
     unsigned* wmax = reinterpret_cast<unsigned*>(ws + n * 6);
     { const hipError_t e = hipMemsetAsync(wmax, 0, (size_t)Cin * 4, stream); if (e != hipSuccess) return (int)e; }
     hipLaunchKernelGGL(dgrad_wmax_kernel, dim3((Cin + 63) / 64, 128), dim3(256), 0, stream, w_cl, wmax, Cout * 9, Cin);
@@ -399,7 +477,7 @@ int dgrad_launch(const float* gy_cl, const float* w_cl, uint8_t* ws, long long w
     hipLaunchKernelGGL(dgrad_pack_kernel, dim3(pack_grid), dim3(256), 0, stream, w_cl, reinterpret_cast<unsigned short*>(ws), Cout,
                        Cin, CI);
   }
-  SPK_LAUNCH_CHECK();
+  if (!prepacked) SPK_LAUNCH_CHECK();
   const int grid = ((N + NIMG - 1) / NIMG) * (Cin / CI);
   const size_t lds = 2 * (size_t)w_blob(F16 ? 2 : 3, nt) + (size_t)NIMG * g_img(F16 ? 2 : 3, H) + 64;
   if ((long long)lds > spk_lds_limit()) return SPK_ERR_UNSUPPORTED;     // (only the workspace has been written so far)
@@ -431,4 +509,36 @@ extern "C" int spk_conv3x3_dgrad_bf16(const float* gy_cl, const float* w_cl, uin
 extern "C" int spk_conv3x3_dgrad_f16x2(const float* gy_cl, const float* w_cl, uint8_t* ws, long long ws_bytes, float* gi_out,
                                        int N, int H, int W, int Cout, int Cin, hipStream_t stream) {
   return dgrad_launch<true>(gy_cl, w_cl, ws, ws_bytes, gi_out, N, H, W, Cout, Cin, stream);
+}
+
+// The weight half of spk_conv3x3_dgrad_f16x2 for up to eight layers in ONE launch, and the data half on its own.  The packed
+// layout depends on the column tiles per wave, which depend on N: pack with the N the data call will be made with (the workspace
+// records the tile width it was packed for; a data call that needs another one writes NaN, not a permuted result).  Host arrays of n entries; ws[i] of
+// spk_conv3x3_dgrad_ws_bytes(Cout[i], Cin[i]) bytes.  Cin % 32 == 0 and Cout % 16 == 0 as for the one-layer call.
+extern "C" int spk_conv3x3_dgrad_f16x2_pack_multi(const float* const* w_cl, uint8_t* const* ws, const long long* ws_bytes,
+                                                  const int* N, const int* Cout, const int* Cin, int n, hipStream_t stream) {
+  if (!w_cl || !ws || !ws_bytes || !N || !Cout || !Cin || n <= 0) return SPK_ERR_ARG;
+  if (n > DG_MULTI_MAX) return SPK_ERR_UNSUPPORTED;
+  DgPackMulti m;
+  m.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!w_cl[i] || !ws[i] || N[i] <= 0) return SPK_ERR_ARG;
+    if (Cout[i] <= 0 || Cin[i] <= 0 || (Cout[i] % KC) || (Cin[i] % 32)) return SPK_ERR_UNSUPPORTED;
+    if (ws_bytes[i] < spk_conv3x3_dgrad_ws_bytes(Cout[i], Cin[i])) return SPK_ERR_ARG;
+    const long long ne = (long long)Cout[i] * 9 * Cin[i];
+    m.w[i] = w_cl[i]; m.wp[i] = reinterpret_cast<_Float16*>(ws[i]); m.wmax[i] = reinterpret_cast<unsigned*>(ws[i] + ne * 6);
+    m.Cout[i] = Cout[i]; m.Cin[i] = Cin[i]; m.CI[i] = 32 * dgrad_nt(true, N[i], Cin[i]);
+    m.first[i] = blocks;
+    blocks += Cin[i] / DG_CB;
+  }
+  for (int i = n; i <= DG_MULTI_MAX; ++i) m.first[i] = blocks;
+  hipLaunchKernelGGL(dgrad_pack_f16_multi_kernel, dim3(blocks), dim3(256), 0, stream, m);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_conv3x3_dgrad_f16x2_prepacked(const float* gy_cl, const uint8_t* ws, long long ws_bytes, float* gi_out, int N,
+                                                 int H, int W, int Cout, int Cin, hipStream_t stream) {
+  return dgrad_launch<true>(gy_cl, nullptr, const_cast<uint8_t*>(ws), ws_bytes, gi_out, N, H, W, Cout, Cin, stream, true);
 }

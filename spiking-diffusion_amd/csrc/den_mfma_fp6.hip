@@ -573,11 +573,11 @@ __global__ __launch_bounds__(256) void conv3x3_fp6_lastpos_kernel(Fp6Args a) {
 // as the per-lane 24-byte B fragments of the MFMA (lane = k-half * 32 + plane parity * 16 + channel, 32 six-bit codes,
 // little-endian; bytes 0..15 in the ds_read_b128 part of the tile, bytes 16..23 in its ds_read_b64 part; a chunk slab
 // is padded to whole KiB DMA pieces)
-__global__ __launch_bounds__(256) void pack_fp6_kernel(const float* __restrict__ w, const float* __restrict__ bias,
-                                                       uint8_t* __restrict__ wq, double* __restrict__ scale,
-                                                       double* __restrict__ bias_d, int Cout, int Cin, int w_cl) {
+__device__ __forceinline__ void pack_fp6_channel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                 uint8_t* __restrict__ wq, double* __restrict__ scale,
+                                                 double* __restrict__ bias_d, int Cout, int Cin, int w_cl, const int co) {
   __shared__ float smax[256];
-  const int co = blockIdx.x, n = Cin * 9;
+  const int n = Cin * 9;
   const float* wc = w + (long long)co * n;     // w_cl: the channel's weights are stored [3][3][Cin] (channels-last memory format)
   float m = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(wc[i]));
@@ -664,6 +664,27 @@ __global__ void fp4_to_spikes_kernel(const uint8_t* __restrict__ q, float* __res
   }
 }
 
+__global__ __launch_bounds__(256) void pack_fp6_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                       uint8_t* __restrict__ wq, double* __restrict__ scale,
+                                                       double* __restrict__ bias_d, int Cout, int Cin, int w_cl) {
+  pack_fp6_channel(w, bias, wq, scale, bias_d, Cout, Cin, w_cl, blockIdx.x);
+}
+
+// the channels of up to eight layers in one launch (spk_den_pack_weight_fp6_cl_multi: the training iteration re-packs every
+// spike-input layer's weights once per optimizer step -- five launches of 6-18 us before)
+constexpr int PK_MULTI_MAX = 8;
+struct PackMulti {
+  const float* w[PK_MULTI_MAX]; const float* bias[PK_MULTI_MAX]; uint8_t* wq[PK_MULTI_MAX]; double* scale[PK_MULTI_MAX];
+  double* bias_d[PK_MULTI_MAX];
+  int Cout[PK_MULTI_MAX], Cin[PK_MULTI_MAX], first[PK_MULTI_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void pack_fp6_multi_kernel(PackMulti m) {
+  int L = 0;
+  while (L + 1 < m.n && (int)blockIdx.x >= m.first[L + 1]) ++L;
+  pack_fp6_channel(m.w[L], m.bias[L], m.wq[L], m.scale[L], m.bias_d[L], m.Cout[L], m.Cin[L], 1, (int)blockIdx.x - m.first[L]);
+}
+
 }  // namespace
 
 extern "C" long long spk_den_packed_weight_fp6_bytes(int Cout, int Cin) {
@@ -693,6 +714,31 @@ extern "C" int spk_den_pack_weight_fp6(const float* w, const float* bias, uint8_
 extern "C" int spk_den_pack_weight_fp6_cl(const float* w_cl, const float* bias, uint8_t* wq, double* scale, double* bias_d,
                                           int Cout, int Cin, hipStream_t stream) {
   return pack_weight_fp6(w_cl, bias, wq, scale, bias_d, Cout, Cin, 1, stream);
+}
+
+// n layers' channels-last weights in ONE launch (host arrays of n <= 8 entries; bias[i] may be null); per layer the result is
+// spk_den_pack_weight_fp6_cl's, byte for byte
+extern "C" int spk_den_pack_weight_fp6_cl_multi(const float* const* w_cl, const float* const* bias, uint8_t* const* wq,
+                                                double* const* scale, double* const* bias_d, const int* Cout, const int* Cin,
+                                                int n, hipStream_t stream) {
+  if (!w_cl || !wq || !scale || !bias_d || !Cout || !Cin || n <= 0) return SPK_ERR_ARG;
+  if (n > PK_MULTI_MAX) return SPK_ERR_UNSUPPORTED;
+  PackMulti m;
+  m.n = n;
+  int blocks = 0, cin_max = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!w_cl[i] || !wq[i] || !scale[i] || !bias_d[i] || Cout[i] <= 0 || Cin[i] <= 0) return SPK_ERR_ARG;
+    if ((Cout[i] % 16) || (Cin[i] % CK)) return SPK_ERR_UNSUPPORTED;
+    m.w[i] = w_cl[i]; m.bias[i] = bias ? bias[i] : nullptr; m.wq[i] = wq[i]; m.scale[i] = scale[i]; m.bias_d[i] = bias_d[i];
+    m.Cout[i] = Cout[i]; m.Cin[i] = Cin[i]; m.first[i] = blocks;
+    blocks += Cout[i];
+    cin_max = Cin[i] > cin_max ? Cin[i] : cin_max;
+  }
+  for (int i = n; i <= PK_MULTI_MAX; ++i) m.first[i] = blocks;
+  if ((long long)6 * cin_max * 9 > spk_lds_limit()) return SPK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(pack_fp6_multi_kernel, dim3(blocks), dim3(256), (size_t)6 * cin_max * 9, stream, m);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
 }
 
 namespace {

@@ -542,12 +542,17 @@ class DummyModel(nn.Module):
         nbt = []                                                      # the five BatchNorm step counters: ONE launch at the end
         for blk in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5):
             object.__setattr__(blk, '_nbt_sink', nbt)
+        preps = self._train_weight_prep(x)
         try:
-            x1 = self.conv1(h)
+            # (want_c4: the block tail also leaves its spikes in the packed format the next layer's exact forward reads)
+            x1 = (self.conv1.train_forward(h, want_c4=preps is not None)
+                  if preps is not None and self.conv1._trainable_fused(self.conv1._blocks(), h) else self.conv1(h))
             x5 = x1
-            for blk in (self.conv2, self.conv3, self.conv4, self.conv5):
+            for i, blk in enumerate((self.conv2, self.conv3, self.conv4, self.conv5)):
                 # conv2..conv5 see spikes: exact MFMA forward and native backward where the shape fits
-                x5 = blk.train_forward(x5, binary_input=True) if blk._trainable_fused(blk._blocks(), x5) else blk(x5)
+                x5 = (blk.train_forward(x5, binary_input=True, prep=None if preps is None else preps[i],
+                                        want_c4=preps is not None and i < 3)
+                      if blk._trainable_fused(blk._blocks(), x5) else blk(x5))
         finally:
             for blk in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5):
                 object.__setattr__(blk, '_nbt_sink', None)
@@ -561,9 +566,41 @@ class DummyModel(nn.Module):
         if self.collapse_conv6_backward and c6._trainable_fused(blocks6, cat) and c6.exact_conv_fits(blocks6, cat):
             # conv6 + the time mean as one operator whose backward runs on the spike counts (1/T of the per-step backward)
             conv = blocks6[0][0]
-            return ops.SpikeConvMeanTrainFunction.apply(cat, conv.weight, conv.bias)
+            return ops.SpikeConvMeanTrainFunction.apply(cat, conv.weight, conv.bias, None if preps is None else preps[4])
         x6 = c6.train_forward(cat, binary_input=True) if c6._trainable_fused(blocks6, cat) else c6(cat)
         return torch.sum(x6, dim=0) / T
+
+    # False: every layer packs its own weights inside its forward / backward (20 small launches per iteration more)
+    train_weight_prep = True
+
+    def _train_weight_prep(self, x):
+        """The weights of conv2..conv6 in the formats this iteration's forward (fp6 digit planes) and backward (two fp16 terms)
+        read them in, made by two launches for all five layers (ops.train_weight_prep) -- or None when the model is not in the
+        shape that path takes (single Conv-BN-LIF blocks on 7x7 / 8x8 maps, T = 16, channels-last parameters)."""
+        if not self.train_weight_prep or self.n_steps != 16 or not x.is_cuda:
+            return None
+        T, B, H, W = self.n_steps, int(x.shape[0]), int(x.shape[2]), int(x.shape[3])
+        layers = []
+        for i, blk in enumerate((self.conv2, self.conv3, self.conv4, self.conv5, self.conv6)):
+            blocks = blk._blocks()
+            if blocks is None or len(blocks) != 1 or not blk.exact_train_forward:
+                return None
+            conv = blocks[0][0]
+            w = conv.weight
+            if w.dim() == 4 and not w.is_contiguous(memory_format=torch.channels_last):
+                w.data = w.data.contiguous(memory_format=torch.channels_last)
+            if not (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.groups == 1
+                    and tuple(conv.dilation) == (1, 1) and conv.padding_mode == 'zeros' and w.requires_grad and conv.training
+                    and ops.den_fp6_supported(conv.out_channels, conv.in_channels, 3, 1, 1, T, H, W)):
+                return None
+            last = i == 4
+            if last and not self.collapse_conv6_backward:
+                return None
+            n_dg = B if last else (T * B if ops.conv3x3_dgrad_supported(conv.out_channels, conv.in_channels, H, W, T * B) else 0)
+            if last and not (conv.out_channels % 16 == 0 and conv.in_channels % 32 == 0 and (H, W) in ((7, 7), (8, 8))):
+                n_dg = 0
+            layers.append((w, conv.bias, n_dg, (H, W)))
+        return ops.train_weight_prep(layers)
 
     def invalidate(self):
         """Rebuild packed weights / BN terms on the next call (needed after writes through ``.data``)."""

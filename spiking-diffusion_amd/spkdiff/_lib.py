@@ -53,6 +53,11 @@ _SIGS = {
                                      c_float, c_float, c_float, c_float, c_int, P]),
     "spk_bn_lif_train_bwd_strided": (c_int, [P, c_longlong, c_longlong, P, P, P, P, P, P, P, P, P, P, P, P, c_longlong, c_int,
                                              c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, P]),
+    "spk_bn_lif_train_fwd_c4": (c_int, [P, P, P, P, P, c_float, c_float, P, P, P, P, P, P, P, c_longlong, c_int, c_int, c_int,
+                                        c_int, c_float, c_float, c_float, P]),
+    "spk_den_pack_weight_fp6_cl_multi": (c_int, [P, P, P, P, P, P, P, c_int, P]),
+    "spk_conv3x3_dgrad_f16x2_pack_multi": (c_int, [P, P, P, P, P, P, c_int, P]),
+    "spk_conv3x3_dgrad_f16x2_prepacked": (c_int, [P, P, c_longlong, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_den_conv3x3_fp6_raw": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_spikes_nhwc_to_fp4": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spk_spikes_nhwc_to_fp4_counts": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),

@@ -220,12 +220,16 @@ class FusedSequential(nn.Sequential):
                                           conv.padding[0] if not isinstance(conv.padding, str) else -1, x.shape[0],
                                           x.shape[3], x.shape[4]))
 
-    def train_forward(self, x, binary_input=False):
+    def train_forward(self, x, binary_input=False, prep=None, want_c4=False):
         """[T,B,C,H,W] -> spikes [T,B,C',H',W'] (or the raw conv output of a conv-only last block), differentiable.
         Convolution: ROCm library operator through torch -- or, when the caller states that x holds spikes
         (``binary_input``) and the shape fits, the exact fp6 MFMA forward with the native (7x7) or library backward; BN + LIF:
-        ops.BNLIFTrainFunction (one native operator)."""
-        for conv, bn, lif in self._blocks():
+        ops.BNLIFTrainFunction (one native operator).  prep: the ops.WeightPrep of this module's (single) convolution for the
+        current iteration; want_c4: the last block's spikes are also left as C4 records (attribute ``_spk_c4`` of the result),
+        which the next module's exact forward picks up instead of converting the fp32 tensor."""
+        blocks = self._blocks()
+        c4_in = getattr(x, '_spk_c4', None)
+        for bi, (conv, bn, lif) in enumerate(blocks):
             w = conv.weight
             if w.dim() == 4 and not w.is_contiguous(memory_format=torch.channels_last):
                 # keep the parameter itself channels-last while training: the library's NHWC kernels then read it (and
@@ -236,18 +240,24 @@ class FusedSequential(nn.Sequential):
                     and ops.den_fp6_supported(conv.out_channels, conv.in_channels, conv.kernel_size[0], conv.stride[0],
                                               conv.padding[0] if not isinstance(conv.padding, str) else -1, x.shape[0],
                                               x.shape[3], x.shape[4]) and conv.kernel_size[0] == conv.kernel_size[1]):
-                x = ops.SpikeConvTrainFunction.apply(x, conv.weight, conv.bias)
+                x = ops.SpikeConvTrainFunction.apply(x, conv.weight, conv.bias, prep if len(blocks) == 1 else None,
+                                                     c4_in if bi == 0 else None)
             else:
                 x = conv(x)
+            c4_in = None
             if lif is None:
                 continue
             binary_input = True                      # what follows a LIF is a spike train
             v0 = lif.v if torch.is_tensor(lif.v) else None
             if v0 is None and float(lif.v) != float(lif.v_reset):
                 v0 = torch.full_like(x[0], float(lif.v))
-            x, lif.v = ops.BNLIFTrainFunction.apply(x, bn.weight, bn.bias, v0, bn.running_mean, bn.running_var,
-                                                    bn.momentum, bn.eps, lif.tau, lif.v_threshold, lif.v_reset,
-                                                    float(lif.surrogate_function.alpha), lif.detach_reset)
+            emit = bool(want_c4) and bi == len(blocks) - 1 and x.shape[0] == 16
+            out = ops.BNLIFTrainFunction.apply(x, bn.weight, bn.bias, v0, bn.running_mean, bn.running_var,
+                                               bn.momentum, bn.eps, lif.tau, lif.v_threshold, lif.v_reset,
+                                               float(lif.surrogate_function.alpha), lif.detach_reset, emit)
+            x, lif.v = out[0], out[1]
+            if emit and out[2] is not None:
+                x._spk_c4 = out[2]
             sink = getattr(self, '_nbt_sink', None)
             if sink is not None:
                 sink.append(bn.num_batches_tracked)   # (the caller bumps all counters of the model with one launch)

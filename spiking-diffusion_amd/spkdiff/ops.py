@@ -247,7 +247,8 @@ class BNLIFTrainFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y_seq, gamma, beta, v_init, running_mean, running_var, momentum, eps, tau, v_threshold, v_reset,
-                alpha, detach_reset):
+                alpha, detach_reset, want_c4=False):
+        # want_c4: a THIRD output, the spikes as C4 records (the next block's exact MFMA forward reads them: no conversion launch)
         if y_seq.dim() != 5:
             raise ValueError(f'expected y_seq with shape [T, N, C, H, W], but got {tuple(y_seq.shape)}')
         y = _cl5(y_seq, "y_seq")
@@ -267,20 +268,28 @@ class BNLIFTrainFunction(torch.autograd.Function):
         v_last = _empty_cl(y.shape[1:], y.device)
         mean = torch.empty(C, dtype=torch.float32, device=y.device)
         invstd = torch.empty(C, dtype=torch.float32, device=y.device)
+        c4 = None
+        if want_c4 and C % 64 == 0 and C // 4 <= 256 and 256 % (C // 4) == 0 and all(
+                t is None or t.data_ptr() % 16 == 0 for t in (y, s, v0, v_last)):
+            c4 = torch.empty((B, C // 64, int(y.shape[3]), int(y.shape[4]), T, 32), dtype=C4_DTYPE, device=y.device)
         with timed("train.bn_lif_fwd"):
-            check(lib.spk_bn_lif_train_fwd(_p(y), _p(g), _p(b), _p(running_mean), _p(running_var), float(momentum),
-                                           float(eps), _p(v0), _p(s), _p(v_last), _p(mean), _p(invstd), _p(ws),
-                                           ws.numel(), T, B, C, HW, float(tau), float(v_threshold), float(v_reset),
-                                           _stream(y)), "spk_bn_lif_train_fwd")
+            check(lib.spk_bn_lif_train_fwd_c4(_p(y), _p(g), _p(b), _p(running_mean), _p(running_var), float(momentum),
+                                              float(eps), _p(v0), _p(s), _p(v_last), _p(mean), _p(invstd), _p(c4), _p(ws),
+                                              ws.numel(), T, B, C, HW, float(tau), float(v_threshold), float(v_reset),
+                                              _stream(y)), "spk_bn_lif_train_fwd_c4")
         ctx.save_for_backward(y, g, b, mean, invstd, v0)
         ctx.cfg = (tau, v_threshold, v_reset, alpha, detach_reset)
         # v_last usually ends in lif.v and nowhere in the loss: without this autograd materialises a zero gradient for it on every
         # backward (a fill + a layout copy per block and iteration); the kernel takes a null pointer for "no gradient"
         ctx.set_materialize_grads(False)
-        return s, v_last
+        if not want_c4:
+            return s, v_last
+        if c4 is not None:
+            ctx.mark_non_differentiable(c4)
+        return s, v_last, c4
 
     @staticmethod
-    def backward(ctx, grad_s, grad_v_last):
+    def backward(ctx, grad_s, grad_v_last, *_):
         y, g, b, mean, invstd, v0 = ctx.saved_tensors
         tau, v_threshold, v_reset, alpha, detach_reset = ctx.cfg
         T, B, C = int(y.shape[0]), int(y.shape[1]), int(y.shape[2])
@@ -291,7 +300,7 @@ class BNLIFTrainFunction(torch.autograd.Function):
         gs_ts, gs_pitch = B * HW * C, C
         gs = None
         if grad_s is None and grad_v_last is None:
-            return (None,) * 13
+            return (None,) * 14
         if grad_s is not None and grad_s.is_cuda and grad_s.dtype == torch.float32 and grad_s.dim() == 5:
             st = grad_s.stride()
             Hh, Ww = int(y.shape[3]), int(y.shape[4])
@@ -313,7 +322,7 @@ class BNLIFTrainFunction(torch.autograd.Function):
                                                    _p(invstd), _p(v0), _p(gy), _p(gg), _p(gb), _p(gv0), _p(ws), ws.numel(), T, B,
                                                    C, HW, float(tau), float(v_threshold), float(v_reset), float(alpha),
                                                    int(bool(detach_reset)), _stream(y)), "spk_bn_lif_train_bwd_strided")
-        return (gy, gg if g is not None else None, gb if b is not None else None, gv0) + (None,) * 9
+        return (gy, gg if g is not None else None, gb if b is not None else None, gv0) + (None,) * 10
 
 
 class MaskedCEFunction(torch.autograd.Function):
@@ -863,7 +872,68 @@ NATIVE_DGRAD = True
 DGRAD_FORM = "f16x2"
 
 
-def conv3x3_dgrad(gy_cl, weight, Cin, form=None):
+class WeightPrep:
+    """What one optimizer step's worth of a spike-input convolution's weight is turned into ONCE per training iteration by
+    ``train_weight_prep``: ``fp6`` = (digit planes, scale, bias) of the exact MFMA forward, ``dg`` = (workspace, bytes, N) of the
+    two-term fp16 data gradient, or None where that layer's backward does not take it."""
+    __slots__ = ("fp6", "dg", "key")
+
+    def __init__(self, fp6, dg, key):
+        self.fp6, self.dg, self.key = fp6, dg, key
+
+    def matches(self, weight):
+        return self.key == (weight.data_ptr(), weight._version, tuple(weight.shape))
+
+
+def _ptr_array(ctype, values):
+    return (ctype * len(values))(*values)
+
+
+def train_weight_prep(layers):
+    """layers: [(weight [Cout,Cin,3,3] channels-last fp32 parameter, bias or None, N_dgrad, (H, W))], at most eight.  TWO launches
+    for all of them -- spk_den_pack_weight_fp6_cl_multi and spk_conv3x3_dgrad_f16x2_pack_multi -- instead of one fp6 pack per
+    layer in the forward and a fill + maximum + pack per layer in the backward (20 launches, ~130 us of a 2.0 ms iteration at the
+    reference's batch).  N_dgrad: the image count that layer's data gradient will be called with (T * B; B for the collapsed last
+    layer; 0: that layer's backward does not take the native two-term data gradient).  Returns one WeightPrep per layer, or None when a layer does not fit (callers then pack per
+    layer as before)."""
+    import ctypes
+    if not layers or len(layers) > 8:
+        return None
+    ws_, dev = [], layers[0][0].device
+    for w, b, n_dg, hw in layers:
+        if not (w.is_cuda and w.dtype == torch.float32 and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)
+                and w.is_contiguous(memory_format=torch.channels_last) and w.shape[0] % 16 == 0 and w.shape[1] % 64 == 0):
+            return None
+    n = len(layers)
+    wd = [w.detach() for w, _, _, _ in layers]
+    couts, cins = [int(w.shape[0]) for w in wd], [int(w.shape[1]) for w in wd]
+    wq = [torch.empty(int(lib.spk_den_packed_weight_fp6_bytes(co, ci)), dtype=torch.uint8, device=dev) for co, ci in zip(couts, cins)]
+    scale = [torch.empty(co, dtype=torch.float64, device=dev) for co in couts]
+    bias_d = [torch.empty(co, dtype=torch.float64, device=dev) for co in couts]
+    bs = [None if b is None else _dev(b.detach(), "bias", torch.float32) for _, b, _, _ in layers]
+    vp = ctypes.c_void_p
+    ia = lambda v: _ptr_array(ctypes.c_int, [int(x) for x in v])
+    pa = lambda ts: _ptr_array(vp, [None if t is None else t.data_ptr() for t in ts])
+    check(lib.spk_den_pack_weight_fp6_cl_multi(pa(wd), pa(bs), pa(wq), pa(scale), pa(bias_d), ia(couts), ia(cins), n, _stream(wd[0])),
+          "spk_den_pack_weight_fp6_cl_multi")
+    dg = [None] * n
+    sel = [i for i, (w, _, n_dg, hw) in enumerate(layers)
+           if NATIVE_DGRAD and DGRAD_FORM == "f16x2" and n_dg > 0 and tuple(hw) in ((7, 7), (8, 8))
+           and n_dg * hw[0] * hw[1] * couts[i] < 2 ** 31]
+    if sel:
+        nbs = [int(lib.spk_conv3x3_dgrad_ws_bytes(couts[i], cins[i])) for i in sel]
+        wss = [torch.empty(nb, dtype=torch.uint8, device=dev) for nb in nbs]
+        check(lib.spk_conv3x3_dgrad_f16x2_pack_multi(pa([wd[i] for i in sel]), pa(wss), _ptr_array(ctypes.c_longlong, nbs),
+                                                     ia([layers[i][2] for i in sel]), ia([couts[i] for i in sel]),
+                                                     ia([cins[i] for i in sel]), len(sel), _stream(wd[0])),
+              "spk_conv3x3_dgrad_f16x2_pack_multi")
+        for i, ws, nb in zip(sel, wss, nbs):
+            dg[i] = (ws, nb, int(layers[i][2]))
+    return [WeightPrep((wq[i], scale[i], bias_d[i]), dg[i], (layers[i][0].data_ptr(), layers[i][0]._version, tuple(wd[i].shape)))
+            for i in range(n)]
+
+
+def conv3x3_dgrad(gy_cl, weight, Cin, form=None, prep=None):
     """gi [N,Cin,H,W] (channels-last memory) of a 3x3 / s1 / p1 convolution from gy [N,Cout,H,W] (channels-last fp32; 7x7 or
     8x8 maps) and the weight [Cout,Cin,3,3]: spk_conv3x3_dgrad_f16x2 (two scaled fp16 terms per operand, three products) or
     spk_conv3x3_dgrad_bf16 (three exact bf16 terms, six products).  Both measure 2-4e-7 relative L2 against fp64 on the training
@@ -875,10 +945,16 @@ def conv3x3_dgrad(gy_cl, weight, Cin, form=None):
     nb = int(lib.spk_conv3x3_dgrad_ws_bytes(Cout, int(Cin)))
     if nb <= 0:
         raise NotImplementedError("spk_conv3x3_dgrad_bf16: unsupported shape")
+    form = form or DGRAD_FORM
+    gi = torch.empty((N, H, W, Cin), dtype=torch.float32, device=gy_cl.device)
+    if prep is not None and prep.dg is not None and form == "f16x2" and prep.dg[2] == N and prep.matches(weight):
+        # the weight half was packed with the other layers' at the start of the iteration (train_weight_prep)
+        with timed("train.conv_bwd_data"):
+            check(lib.spk_conv3x3_dgrad_f16x2_prepacked(_p(gy_cl), _p(prep.dg[0]), prep.dg[1], _p(gi), N, H, W, Cout, int(Cin),
+                                                        _stream(gy_cl)), "spk_conv3x3_dgrad_f16x2_prepacked")
+        return gi.permute(0, 3, 1, 2)
     w_cl = weight.detach().contiguous(memory_format=torch.channels_last)        # storage [Cout][3][3][Cin]
     ws = torch.empty(nb, dtype=torch.uint8, device=gy_cl.device)
-    gi = torch.empty((N, H, W, Cin), dtype=torch.float32, device=gy_cl.device)
-    form = form or DGRAD_FORM
     fn, name = ((lib.spk_conv3x3_dgrad_f16x2, "spk_conv3x3_dgrad_f16x2") if form == "f16x2"
                 else (lib.spk_conv3x3_dgrad_bf16, "spk_conv3x3_dgrad_bf16"))
     with timed("train.conv_bwd_data"):
@@ -895,13 +971,22 @@ class SpikeConvTrainFunction(torch.autograd.Function):
     framework's operator otherwise.  spikes [T,B,Cin,H,W] in {0,1}; returns channels-last [T,B,Cout,H,W]."""
 
     @staticmethod
-    def forward(ctx, spikes, weight, bias):
+    def forward(ctx, spikes, weight, bias, prep=None, c4=None):
+        # prep: this layer's WeightPrep of the iteration (ops.train_weight_prep), c4: the spikes as C4 records where the producing
+        # BatchNorm+LIF launch wrote them -- either spares a launch here; both are optional and checked
         s = _cl5(spikes, "spikes")
         Cout = int(weight.shape[0])
+        if prep is not None and not prep.matches(weight):
+            prep = None
+        T, B, C, H, W = (int(v) for v in s.shape)
+        if c4 is not None and (tuple(c4.shape) != (B, C // 64, H, W, T, 32) or c4.dtype != C4_DTYPE or c4.device != s.device):
+            c4 = None
         with timed("train.conv_fwd_fp6"):
-            y = den_conv3x3_fp6_raw(spikes_cl_to_c4(s), den_pack_weight_fp6(weight, bias), Cout)
+            y = den_conv3x3_fp6_raw(c4 if c4 is not None else spikes_cl_to_c4(s),
+                                    prep.fp6 if prep is not None else den_pack_weight_fp6(weight, bias), Cout)
         ctx.save_for_backward(s, weight)
         ctx.has_bias = bias is not None
+        ctx.prep = prep
         return y
 
     @staticmethod
@@ -923,7 +1008,7 @@ class SpikeConvTrainFunction(torch.autograd.Function):
         gi_native = None
         if (NATIVE_DGRAD and need_gi and tuple(weight.shape[2:]) == (3, 3) and
                 conv3x3_dgrad_supported(Cout, Cin, int(s.shape[3]), int(s.shape[4]), int(gy.shape[0]))):
-            gi_native = conv3x3_dgrad(gy, weight, Cin)
+            gi_native = conv3x3_dgrad(gy, weight, Cin, prep=ctx.prep)
             need_gi = False
         gi = gw = gb = None
         if need_gi or need_gw or (need_gb and gw_native is None):
@@ -938,7 +1023,7 @@ class SpikeConvTrainFunction(torch.autograd.Function):
             gi = gi_native
         if gi is not None:
             gi = gi.reshape(s.shape) if gi_native is None else gi.unflatten(0, (s.shape[0], s.shape[1]))
-        return gi, gw, gb
+        return gi, gw, gb, None, None
 
 
 class CatChannelsFunction(torch.autograd.Function):
@@ -970,14 +1055,17 @@ class SpikeConvMeanTrainFunction(torch.autograd.Function):
     no [T,B,Cout,H,W] gradient tensor.  spikes [T,B,Cin,H,W] in {0,1}; returns [B,Cout,H,W]."""
 
     @staticmethod
-    def forward(ctx, spikes, weight, bias):
+    def forward(ctx, spikes, weight, bias, prep=None):
         s = _cl5(spikes, "spikes")
         T, Cout = int(s.shape[0]), int(weight.shape[0])
+        if prep is not None and not prep.matches(weight):
+            prep = None
         with timed("train.conv_fwd_fp6"):
             c4, counts = spikes_cl_to_c4_counts(s)             # counts [B,Cin,H,W], channels-last like s: same pass as the packing
-            y = den_conv3x3_fp6_raw(c4, den_pack_weight_fp6(weight, bias), Cout)
+            y = den_conv3x3_fp6_raw(c4, prep.fp6 if prep is not None else den_pack_weight_fp6(weight, bias), Cout)
         ctx.save_for_backward(counts, weight)
         ctx.has_bias, ctx.T = bias is not None, T
+        ctx.prep = prep
         return torch.sum(y, dim=0) / T
 
     @staticmethod
@@ -995,7 +1083,7 @@ class SpikeConvMeanTrainFunction(torch.autograd.Function):
             gw = conv3x3_wgrad(g, c, Cout, Cin)
             need_gw = False
         if need_gi and native and NATIVE_DGRAD and Cout % 16 == 0 and Cin % 32 == 0:
-            gi = conv3x3_dgrad(g, weight, Cin)
+            gi = conv3x3_dgrad(g, weight, Cin, prep=ctx.prep)
             need_gi = False
         if need_gi or need_gw:
             gi2, gw2, _ = torch.ops.aten.convolution_backward(g, c, weight, [Cout], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
@@ -1006,7 +1094,7 @@ class SpikeConvMeanTrainFunction(torch.autograd.Function):
             gb = grad_out.sum(dim=(0, 2, 3))                   # sum over T of g / T
         if gi is not None:
             gi = gi.unsqueeze(0).expand((T,) + tuple(gi.shape))
-        return gi, gw, gb
+        return gi, gw, gb, None
 
 
 def spikes_to_c4(s):

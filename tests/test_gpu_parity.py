@@ -2832,3 +2832,108 @@ def test_fp6_weight_packing_reads_channels_last_weights(dev, ops):
     assert torch.equal(c4, ops.spikes_cl_to_c4(s)) and torch.equal(cnt, s.sum(0))
     y0, y1 = ops.den_conv3x3_fp6_raw(c4, p0, 128), ops.den_conv3x3_fp6_raw(c4, p1, 128)
     assert torch.equal(y0, y1) and float(y0.abs().max()) > 0
+
+
+def test_training_weight_prep_is_the_per_layer_packing(dev, ops):
+    """ops.train_weight_prep (spk_den_pack_weight_fp6_cl_multi + spk_conv3x3_dgrad_f16x2_pack_multi: two launches for all layers)
+    against the per-layer calls: the exact forward and the two-term data gradient give the same bits; a workspace packed for
+    another image count is refused with NaN, not mis-read."""
+    g = torch.Generator().manual_seed(17)
+    shapes = [(128, 64), (256, 128), (512, 256), (256, 512), (128, 320)]
+    Ns = [128, 128, 512, 512, 8]
+    ws = [(torch.randn(co, ci, 3, 3, generator=g) * (0.03 + 0.02 * i)).to(dev).contiguous(memory_format=torch.channels_last)
+          .requires_grad_(True) for i, (co, ci) in enumerate(shapes)]
+    ws[1].data[:, 5] *= 2.0 ** -9                                                # per-channel maxima that differ by binades
+    ws[2].data[:, 7] = 0.0
+    bs = [torch.randn(co, generator=g).to(dev) if i % 2 == 0 else None for i, (co, ci) in enumerate(shapes)]
+    preps = ops.train_weight_prep([(w, b, n, (7, 7)) for w, b, n in zip(ws, bs, Ns)])
+    assert preps is not None and len(preps) == 5
+    for i, ((co, ci), w, b, n, pr) in enumerate(zip(shapes, ws, bs, Ns, preps)):
+        assert pr.matches(w) and pr.dg is not None and pr.dg[2] == n
+        p0 = ops.den_pack_weight_fp6(w, b)
+        assert torch.equal(p0[1], pr.fp6[1]) and torch.equal(p0[2], pr.fp6[2])
+        s = (torch.rand(16, 2, ci, 7, 7, generator=g) < 0.1).float().to(dev)
+        s = s.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)
+        c4 = ops.spikes_cl_to_c4(s)
+        assert torch.equal(ops.den_conv3x3_fp6_raw(c4, p0, co), ops.den_conv3x3_fp6_raw(c4, pr.fp6, co))
+        gy = (torch.randn(n, co, 7, 7, generator=g) * 1e-3).to(dev).contiguous(memory_format=torch.channels_last)
+        gi0 = ops.conv3x3_dgrad(gy, w, ci, form="f16x2")
+        gi1 = ops.conv3x3_dgrad(gy, w, ci, form="f16x2", prep=pr)
+        assert torch.equal(gi0, gi1) and float(gi0.abs().max()) > 0
+        # the prepacked entry point itself, on a workspace packed for a DIFFERENT tile width: NaN
+        if ci % 64 == 0:
+            other = 8 if n >= 64 else 512
+            pr2 = ops.train_weight_prep([(w, b, other, (7, 7))])[0]
+            same_width = torch.equal(pr2.dg[0][:co * 9 * ci * 4], pr.dg[0][:co * 9 * ci * 4])
+            gi2 = torch.empty((n, 7, 7, ci), dtype=torch.float32, device=dev)
+            ops.check(ops.lib.spk_conv3x3_dgrad_f16x2_prepacked(gy.data_ptr(), pr2.dg[0].data_ptr(), pr2.dg[1], gi2.data_ptr(), n, 7, 7,
+                                                                co, ci, torch.cuda.current_stream().cuda_stream), "prepacked")
+            torch.cuda.synchronize()
+            assert torch.equal(gi2.permute(0, 3, 1, 2), gi0) if same_width else bool(torch.isnan(gi2).all())
+    w_after = ws[0]
+    with torch.no_grad():
+        w_after.add_(1e-3)                                                       # an optimizer step: the prep no longer matches
+    assert not preps[0].matches(w_after)
+
+
+def test_bn_lif_forward_with_packed_spikes(dev, ops):
+    """spk_bn_lif_train_fwd_c4: the apply launch also leaves the spikes as C4 records.  Same spikes, state and statistics as
+    spk_bn_lif_train_fwd, bit for bit; the C4 records are what the conversion kernel makes of the fp32 spikes."""
+    import ctypes
+    g = torch.Generator().manual_seed(23)
+    for (T, B, C, H, W) in ((16, 4, 64, 7, 7), (16, 3, 128, 7, 7), (16, 2, 512, 7, 7), (16, 2, 256, 8, 8)):
+        y = torch.randn(T, B, C, H, W, generator=g).to(dev)
+        y = y.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)
+        gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+        outs = []
+        for rep in range(2):
+            rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+            s, v, c4 = ops.BNLIFTrainFunction.apply(y, gamma, beta, None, rm, rv, 0.1, 1e-5, 2.0, 1.0, 0.0, 2.0, False, True)
+            outs.append((s.clone(), v.clone(), c4.clone(), rm.clone(), rv.clone()))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+        s, v, c4, rm, rv = outs[0]
+        assert torch.equal(c4, ops.spikes_cl_to_c4(s))
+        # the three-launch form through the C-ABI
+        HW = H * W
+        nb = int(ops.lib.spk_bn_lif_train_ws_bytes(B, C, HW))
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        s0 = torch.empty_like(s); v0 = torch.empty_like(v)
+        mean0, inv0 = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        rm0, rv0 = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        ops.check(ops.lib.spk_bn_lif_train_fwd(y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm0.data_ptr(), rv0.data_ptr(),
+                                               ctypes.c_float(0.1), ctypes.c_float(1e-5), None, s0.data_ptr(), v0.data_ptr(),
+                                               mean0.data_ptr(), inv0.data_ptr(), ws.data_ptr(), nb, T, B, C, HW, ctypes.c_float(2.0),
+                                               ctypes.c_float(1.0), ctypes.c_float(0.0), torch.cuda.current_stream().cuda_stream),
+                  "spk_bn_lif_train_fwd")
+        torch.cuda.synchronize()
+        assert torch.equal(rm, rm0) and torch.equal(rv, rv0) and torch.equal(s, s0) and torch.equal(v, v0)
+
+
+def test_training_iteration_with_and_without_weight_prep(dev, ops):
+    """One diffusion training iteration (train_iter + backward) with the per-iteration weight preparation and the packed-spike
+    hand-over between blocks, against the same iteration with every layer packing for itself: same loss, same gradients, bit
+    for bit (the prepared operands are the same bytes)."""
+    from spkdiff import synth
+    from snn_model.vq_diffusion import DummyModel, AbsorbingDiffusion, functional
+    res = []
+    for prep in (True, False):
+        torch.manual_seed(5)
+        den = DummyModel(1, 128, n_steps=16).to(dev)
+        functional.set_step_mode(net=den, step_mode='m')
+        den.load_state_dict(synth.synth_denoiser_state(synth.MNIST))
+        den.train()
+        den.train_weight_prep = prep
+        ab = AbsorbingDiffusion(den, mask_id=128)
+        x0 = torch.randint(0, 128, (8, 1, 7, 7), generator=torch.Generator().manual_seed(42)).float().to(dev)
+        torch.manual_seed(11)
+        loss = ab.train_iter(x0)['loss']
+        loss.backward()
+        functional.reset_net(den)
+        res.append((loss.detach().clone(), [p.grad.clone() for p in den.parameters()],
+                    [b.clone() for n, b in den.named_buffers() if 'running' in n]))
+    assert torch.equal(res[0][0], res[1][0]) and float(res[0][0]) > 0
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0][2], res[1][2]):
+        assert torch.equal(a, b)
