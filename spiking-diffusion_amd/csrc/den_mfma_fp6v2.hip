@@ -143,6 +143,13 @@ struct V2Args {
 #define SPK_V2_NMAX_LDS 1       // the first certification stage reads max_t n_t of its position from LDS (one atomic per (position, step)
                                 // in the per-item count pass) instead of sixteen counts + twelve v_max per tile and lane.  0: rounds 2-3
 #endif
+#ifndef SPK_V2_LP_PAIRS
+#define SPK_V2_LP_PAIRS 1       // last-position part of the tail launch: image pairs (32-row tiles) per unit.  2 halves the weight-tile
+                                // reads (327 -> 164 MB through L2 for the 256 -> 512 layer at B = 256) and needs 146 + 96 registers
+                                // (two waves per SIMD instead of three, for the repair part of the same launch too): measured
+                                // +1.8 % on the dense reverse process (86.8 -> 88.4 ms, same box, profiles/r4_ab_kernel_variants.txt)
+                                // -- the launch is bound by the depth of its chains of dependent reads, not by L2 bandwidth
+#endif
 #ifndef SPK_V2_PF
 #define SPK_V2_PF 6             // A fragments requested this many steps ahead of the MFMA that consumes them
 #endif
@@ -1144,32 +1151,36 @@ __device__ __forceinline__ float exact_preact(double s, double sc, double bi) { 
 // keeps eight workgroups on a CU) or, WIDE, three of them (one barrier: the stand-alone launch of full batches)
 template <int H, int W, bool WIDE>
 __device__ __forceinline__ void fp6v2_lastpos_body(const V2Args& a, const int bid, float (*red)[16][64]) {
-  constexpr int HW = H * W;
+  constexpr int HW = H * W, NP = SPK_V2_LP_PAIRS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = a.nch, G = a.Cout >> 5;
   const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
   // (without the hand-over this launch follows the repair launch on the stream and re-arms the flag counter)
   if (!a.handover && bid == 0 && threadIdx.x == 0 && !(SPK_V2_DBG & 64)) { a.flags[1] = a.flags[0]; a.flags[0] = 0u; }
-  // one workgroup = one 32-row tile = two images (the lane halves) x one channel group; its four waves split the K chunks
+  // one unit = NP 32-row tiles = NP image pairs (the lane halves of a tile are the two images) x one channel group: the
+  // weight tiles of a chunk are read ONCE for all of them (with one pair per unit the launch moved 327 MB of weight tiles
+  // through L2 for the 256 -> 512 layer at B = 256: bound by that).  The four waves of a workgroup split the K chunks
   // (wave w: chunks w, w + 4, ...) and add their partial sums -- exact integers below 2^24 in fp32, so the order of the
-  // additions does not matter -- in LDS: the launch is bound by the latency of a wave's chain of dependent gathers
+  // additions does not matter -- in LDS: few units are bound by the latency of a wave's chain of dependent gathers
   // (with many units the launch is bound by throughput instead: then every wave takes a unit of its own)
-  const bool split = ((Bn + 1) >> 1) * G <= 1024;           // (uniform over the launch)
+  const int n_units = ((Bn + 2 * NP - 1) / (2 * NP)) * G;
+  const bool split = n_units <= 1024;                       // (uniform over the launch)
   const int unit = split ? bid : bid * 4 + wave;
-  const int g = unit % G, b0 = (unit / G) * 2;
+  const int g = unit % G, b0 = (unit / G) * 2 * NP;
   if (b0 >= Bn) return;
   const int row = lane & 31, half = lane >> 5;
   const int hsel = (row >> 2) & 1, tt = (row & 3) + 4 * (row >> 3);
   const int sc_a = 0x7f7f7f7f;
   const int sc_p = half ? (int)0x82828282u : (int)0x87878787u;
   const int sc_hi = (int)0x87878787u, sc_lo = (int)0x82828282u;
-  v16f acc[3];
+  v16f acc[NP][3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
+  for (int q = 0; q < NP; ++q)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][j][r] = 0.f;
   const int py = H - 1, px = W - 1;
-  const int bA = b0 + hsel;
   for (int c = split ? wave : 0; c < nch; c += split ? 4 : 1) {
     const uint8_t* wslab = a.wq + ((long long)g * nch + c) * W_SLAB;
     auto ldb = [&](int tile) -> v8i {
@@ -1179,14 +1190,18 @@ __device__ __forceinline__ void fp6v2_lastpos_body(const V2Args& a, const int bi
       return v8i{bx[0], bx[1], bx[2], bx[3], by[0], by[1], 0, 0};
     };
     // spikes of the four contributing taps (0, 1, 3, 4)
-    v4i sp[4];
+    v4i sp[NP][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int tap = (u >> 1) * 3 + (u & 1);
-      const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
-      sp[u] = v4i{0, 0, 0, 0};
-      if (bA < Bn)
-        sp[u] = *reinterpret_cast<const v4i*>(a.in0 + (((long long)bA * nch + c) * HW + yy * W + xx) * POSB + tt * 16);
+    for (int q = 0; q < NP; ++q) {
+      const int bA = b0 + 2 * q + hsel;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int tap = (u >> 1) * 3 + (u & 1);
+        const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+        sp[q][u] = v4i{0, 0, 0, 0};
+        if (bA < Bn)
+          sp[q][u] = *reinterpret_cast<const v4i*>(a.in0 + (((long long)bA * nch + c) * HW + yy * W + xx) * POSB + tt * 16);
+      }
     }
     // all thirteen weight tiles of the chunk are requested before the first MFMA waits
     v8i bt[8];
@@ -1202,70 +1217,83 @@ __device__ __forceinline__ void fp6v2_lastpos_body(const V2Args& a, const int bi
     };
     const v4i zero = {0, 0, 0, 0};
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { mm(acc[0], sp[u], bt[2 * u], sc_p); mm(acc[1], sp[u], bt[2 * u + 1], sc_p); }   // digit pairs 01, 23
-    // fifth digit (x 32) and sixth digit into acc[2] = 32 * D4 + D5: tiles 18 (taps 0|1), 19 (2|3), 20 (4|5) and the
-    // sixth-digit tiles 23 (taps 0|1), 24 (taps 3|4); taps 2 and 5 lie outside the image: zero spikes
-    const v4i a01 = half ? sp[1] : sp[0];
-    const v4i az3 = half ? sp[2] : zero;
-    const v4i a4z = half ? zero : sp[3];
-    const v4i a34 = half ? sp[3] : sp[2];
-    mm(acc[2], a01, t18, sc_hi); mm(acc[2], az3, t19, sc_hi); mm(acc[2], a4z, t20, sc_hi);
-    mm(acc[2], a01, t23, sc_lo); mm(acc[2], a34, t24, sc_lo);
+    for (int q = 0; q < NP; ++q) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { mm(acc[q][0], sp[q][u], bt[2 * u], sc_p); mm(acc[q][1], sp[q][u], bt[2 * u + 1], sc_p); }   // digit pairs 01, 23
+      // fifth digit (x 32) and sixth digit into acc[2] = 32 * D4 + D5: tiles 18 (taps 0|1), 19 (2|3), 20 (4|5) and the
+      // sixth-digit tiles 23 (taps 0|1), 24 (taps 3|4); taps 2 and 5 lie outside the image: zero spikes
+      const v4i a01 = half ? sp[q][1] : sp[q][0];
+      const v4i az3 = half ? sp[q][2] : zero;
+      const v4i a4z = half ? zero : sp[q][3];
+      const v4i a34 = half ? sp[q][3] : sp[q][2];
+      mm(acc[q][2], a01, t18, sc_hi); mm(acc[q][2], az3, t19, sc_hi); mm(acc[q][2], a4z, t20, sc_hi);
+      mm(acc[q][2], a01, t23, sc_lo); mm(acc[q][2], a34, t24, sc_lo);
+    }
   }
   if (split) {
     const int nw = nch < 4 ? nch : 4;                       // waves that had a chunk
     if constexpr (WIDE) {
-      if (wave != 0 && wave < nw) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) red[3 * (wave - 1) + j][r][lane] = acc[j][r];
-      }
-      __syncthreads();
-      if (wave == 0) {
-        for (int w = 1; w < nw; ++w)
+      for (int q = 0; q < NP; ++q) {
+        if (q) __syncthreads();
+        if (wave != 0 && wave < nw) {
 #pragma unroll
           for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] += red[3 * (w - 1) + j][r][lane];
+            for (int r = 0; r < 16; ++r) red[3 * (wave - 1) + j][r][lane] = acc[q][j][r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+          for (int w = 1; w < nw; ++w)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[q][j][r] += red[3 * (w - 1) + j][r][lane];
+        }
       }
     } else {
-      for (int w = 1; w < 4; ++w) {
-        if (wave == w && w < nw) {
 #pragma unroll
-          for (int j = 0; j < 3; ++j)
+      for (int q = 0; q < NP; ++q)
+        for (int w = 1; w < 4; ++w) {
+          if (wave == w && w < nw) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[j][r][lane] = acc[j][r];
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) red[j][r][lane] = acc[q][j][r];
+          }
+          __syncthreads();
+          if (wave == 0 && w < nw) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[q][j][r] += red[j][r][lane];
+          }
+          __syncthreads();
         }
-        __syncthreads();
-        if (wave == 0 && w < nw) {
-#pragma unroll
-          for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] += red[j][r][lane];
-        }
-        __syncthreads();
-      }
     }
     if (wave != 0) return;
   }
   const int co = g * 32 + (lane & 31);
   const double sc = a.scale[co], bi = a.bias[co];
   const float bna = a.bn_a[co], bnb = a.bn_b[co];
-  const int b = b0 + half;                                  // accumulator lane half == image within the tile's pair
-  const bool ok = b < Bn;
-  float v = 0.f;
-  unsigned mybits = 0;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const double s1 = fma((double)acc[0][r], 1024.0, (double)acc[1][r]);       // exact
-    const double s = fma(s1, 1024.0, (double)acc[2][r]);                       // exact: |s| < 2^43
-    const float y = exact_preact(s, sc, bi);                                   // the one rounding to fp32
-    const bool sp1 = spk_lif_step_default(v, fmaf(y, bna, bnb)) && ok;
-    mybits |= sp1 ? (1u << r) : 0u;
+  for (int q = 0; q < NP; ++q) {
+    const int b = b0 + 2 * q + half;                        // accumulator lane half == image within the tile's pair
+    const bool ok = b < Bn;
+    if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;  // (a ragged last unit: no image in this pair)
+    float v = 0.f;
+    unsigned mybits = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const double s1 = fma((double)acc[q][0][r], 1024.0, (double)acc[q][1][r]);    // exact
+      const double s = fma(s1, 1024.0, (double)acc[q][2][r]);                       // exact: |s| < 2^43
+      const float y = exact_preact(s, sc, bi);                                      // the one rounding to fp32
+      const bool sp1 = spk_lif_step_default(v, fmaf(y, bna, bnb)) && ok;
+      mybits |= sp1 ? (1u << r) : 0u;
+    }
+    const long long cell = ((long long)(ok ? b : 0) * G + g) * HW + (HW - 1);
+    store_tile_spikes(a.out, a.out_cnt, mybits, lane, cell * POSB, cell * 32, ok);
   }
-  const long long cell = ((long long)(ok ? b : 0) * G + g) * HW + (HW - 1);
-  store_tile_spikes(a.out, a.out_cnt, mybits, lane, cell * POSB, cell * 32, ok);
 }
 
 // (2) One flagged neuron, exactly, by a 256-thread workgroup: thread unit (tap, 32-channel chunk, t) reads ONE 16-byte spike
@@ -1569,7 +1597,8 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
       else hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7, 1>), dim3(8 * cus), dim3(256), 0, stream, a, n_words, 0);
     } else if (parts == 4 && !bands) {
       a.handover = 1;                                         // (no re-arming)
-      hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7, 2>), dim3(((B + 1) / 2) * G), dim3(256), 0, stream, a, n_words, ((B + 1) / 2) * G);
+      const int n_lp4 = ((B + 2 * SPK_V2_LP_PAIRS - 1) / (2 * SPK_V2_LP_PAIRS)) * G;
+      hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7, 2>), dim3(n_lp4), dim3(256), 0, stream, a, n_words, n_lp4);
     } else return SPK_ERR_UNSUPPORTED;
     SPK_LAUNCH_CHECK();
     return SPK_OK;
@@ -1605,7 +1634,7 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   else if (eight) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 8>), dim3(grid), dim3(512), lds, stream, a);
   else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 4>), dim3(grid), dim3(256), lds, stream, a);
   SPK_LAUNCH_CHECK();
-  const int n_lp = ((B + 1) / 2) * G;
+  const int n_lp = ((B + 2 * SPK_V2_LP_PAIRS - 1) / (2 * SPK_V2_LP_PAIRS)) * G;
   if (n_dyn_or_null || SPK_V2_MERGE_FULL) {
     // the sampler's active-set calls: few images, both parts are latency bound -- one launch (-17 us per reverse step)
     hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7, 0>), dim3(n_lp + 8 * cus), dim3(256), 0, stream, a, n_words, n_lp);
