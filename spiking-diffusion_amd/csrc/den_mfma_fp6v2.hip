@@ -150,6 +150,11 @@ struct V2Args {
                                 // +1.8 % on the dense reverse process (86.8 -> 88.4 ms, same box, profiles/r4_ab_kernel_variants.txt)
                                 // -- the launch is bound by the depth of its chains of dependent reads, not by L2 bandwidth
 #endif
+#ifndef SPK_V2_LP_SPLIT_MAX
+#define SPK_V2_LP_SPLIT_MAX 512    // last-position part: up to this many units the four waves of a workgroup split a unit's K chunks
+                                   // (1024 until round 4; same box, dense / elimination / lists, ms per 100-step sample at B = 256:
+                                   //  1024: 88.0 / 43.5 / 34.2, 512: 87.4 / 43.3 / 34.1, 256 and 0: 87.4 / 44.3 / 35.2)
+#endif
 #ifndef SPK_V2_PF
 #define SPK_V2_PF 6             // A fragments requested this many steps ahead of the MFMA that consumes them
 #endif
@@ -1164,7 +1169,7 @@ __device__ __forceinline__ void fp6v2_lastpos_body(const V2Args& a, const int bi
   // additions does not matter -- in LDS: few units are bound by the latency of a wave's chain of dependent gathers
   // (with many units the launch is bound by throughput instead: then every wave takes a unit of its own)
   const int n_units = ((Bn + 2 * NP - 1) / (2 * NP)) * G;
-  const bool split = n_units <= 1024;                       // (uniform over the launch)
+  const bool split = n_units <= SPK_V2_LP_SPLIT_MAX;        // (uniform over the launch)
   const int unit = split ? bid : bid * 4 + wave;
   const int g = unit % G, b0 = (unit / G) * 2 * NP;
   if (b0 >= Bn) return;
