@@ -35,12 +35,20 @@ namespace {
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int WG_CO = 128, WG_CI = 64, HW7 = 49, NTHR = 512;
-constexpr int G_PITCH = 56;                       // bf16 entries per output channel and term: 7 rows x 8 (112 B: 16-lane phases of a 16-byte read hit 16 x 4 distinct banks)
-constexpr int G_HALFS = 3 * WG_CO * G_PITCH;      // [term][co][row][8] = 43 008 B
-constexpr int S_PITCH = 72;                       // bf16 entries per input channel and copy: 9 rows x 8 (144 B)
-constexpr int S_HALFS = 3 * WG_CI * S_PITCH;      // [kx][ci][row + 1][8] = 27 648 B
-constexpr int LDS_BYTES = 2 * G_HALFS * 2 + 2 * S_HALFS * 2 + 16;      // + one 16-byte zero vector (the zero row of the A operand)
+constexpr int WG_CO = 128, WG_CI = 64, NTHR = 512;
+// Maps of HH x HH positions, HH = 7 (MNIST-shaped latents) or 8 (CIFAR-shaped: the 64 positions fill the four k steps exactly,
+// no zero column / zero row).  LDS images:
+//   gy     [term][co][row][8] bf16.  7x7: 7 rows, pitch 112 B (the 16-lane phases of a 16-byte read hit 16 x 4 distinct banks).
+//          8x8: 8 rows = 128 B, which alone would put every second channel on the same banks -- row r of channel co sits in
+//          slot r ^ ((co >> 1) & 7) (16 consecutive channels x one row: 16 distinct (parity, slot) pairs); a 144-byte pitch
+//          does not fit (2 x 3 x 128 x 144 + the spike images > 160 KB)
+//   spikes [kx][ci][row + 1][8] bf16, zero rows above and below.  7x7: 9 rows, pitch 144 B.  8x8: 10 rows, pitch 160 B, which
+//          repeats its bank pattern every 8 channels: the rows of channels with bit 3 set are rotated by one slot
+__host__ __device__ constexpr int g_pitch(int hh) { return hh == 7 ? 56 : 64; }
+__host__ __device__ constexpr int s_pitch(int hh) { return hh == 7 ? 72 : 80; }
+__host__ __device__ constexpr int g_halfs(int hh) { return 3 * WG_CO * g_pitch(hh); }      // 7x7: 43 008 B, 8x8: 49 152 B
+__host__ __device__ constexpr int s_halfs(int hh) { return 3 * WG_CI * s_pitch(hh); }      // 7x7: 27 648 B, 8x8: 30 720 B
+__host__ __device__ constexpr int lds_bytes(int hh) { return 2 * g_halfs(hh) * 2 + 2 * s_halfs(hh) * 2 + 16; }   // + one 16-byte zero vector
 
 struct WgArgs {
   const float* gy; const float* s; float* part;
@@ -48,7 +56,10 @@ struct WgArgs {
   int TB, Cout, Cin, ksplit;
 };
 
+template <int HH>
 __global__ __launch_bounds__(NTHR, 1) void wgrad3x3_bf16_kernel(WgArgs a) {
+  constexpr int HW7 = HH * HH, G_PITCH = g_pitch(HH), S_PITCH = s_pitch(HH), G_HALFS = g_halfs(HH), S_HALFS = s_halfs(HH),
+                LDS_BYTES = lds_bytes(HH);                     // (HW7: positions per map, whatever HH)
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   unsigned short* const sG = reinterpret_cast<unsigned short*>(lds);                       // [2][G_HALFS]
   unsigned short* const sS = sG + 2 * G_HALFS;                                            // [2][S_HALFS]
@@ -69,44 +80,49 @@ __global__ __launch_bounds__(NTHR, 1) void wgrad3x3_bf16_kernel(WgArgs a) {
   // this thread's share of an image: whole image ROWS, so that every LDS deposit is one aligned 16-byte write (element-wise
   // 2-byte deposits kept the LDS pipe busier than the matrix cores).  gy tile: item (channel e % 128, row e / 128) for
   // e = tid and tid + 512 (896 items); spike tile: item (channel tid % 64, row tid / 64) for tid < 448
-  float rg[2][7], rs[7];
+  // (8x8: 1024 gy items = two per thread, 512 spike items = one per thread)
+  float rg[2][HH], rs[HH];
   float gsum[2] = {0.f, 0.f};                       // bias gradient: this thread's rows of gy, summed over its images
   const int g_co = tid & 127, g_y0 = tid >> 7, s_ci = tid & 63, s_y = tid >> 6;
-  const bool g_two = tid < 896 - NTHR, s_on = tid < 7 * WG_CI;                           // (both wave-uniform)
+  const bool g_two = tid < HH * WG_CO - NTHR, s_on = tid < HH * WG_CI;                   // (both wave-uniform)
   // addresses = a wave-uniform pointer (image, column x, tile origin: scalar registers) + ONE 32-bit per-thread offset
-  const unsigned g_off = (unsigned)(g_y0 * 7 * a.Cout + g_co), s_off = (unsigned)(s_y * 7 * a.Cin + s_ci);
+  const unsigned g_off = (unsigned)(g_y0 * HH * a.Cout + g_co), s_off = (unsigned)(s_y * HH * a.Cin + s_ci);
+  const int g_swz = HH == 8 ? (g_co >> 1) & 7 : 0;            // 8x8: slot of row r = r ^ g_swz (see above)
+  const int s_rot = HH == 8 ? (s_ci >> 3) & 1 : 0;            // 8x8: slot of row r = (r + s_rot) mod 10
   auto fetch = [&](int img) {
     const float* g = a.gy + ((long long)img * HW7) * a.Cout + co0;
     const float* sp = a.s + ((long long)img * HW7) * a.Cin + ci0;
 #pragma unroll
-    for (int x = 0; x < 7; ++x) rg[0][x] = (g + x * a.Cout)[g_off];
+    for (int x = 0; x < HH; ++x) rg[0][x] = (g + x * a.Cout)[g_off];
     if (g_two) {
 #pragma unroll
-      for (int x = 0; x < 7; ++x) rg[1][x] = (g + (28 + x) * a.Cout)[g_off];
+      for (int x = 0; x < HH; ++x) rg[1][x] = (g + (4 * HH + x) * a.Cout)[g_off];
     }
     if (s_on) {
 #pragma unroll
-      for (int x = 0; x < 7; ++x) rs[x] = (sp + x * a.Cin)[s_off];
+      for (int x = 0; x < HH; ++x) rs[x] = (sp + x * a.Cin)[s_off];
     }
   };
   auto deposit = [&](int buf, int part) {        // part 0 / 1: the gy items, 2: the spike item, -1: all
     unsigned short* G = sG + buf * G_HALFS + g_co * G_PITCH;
-    unsigned short* S = sS + buf * S_HALFS + s_ci * S_PITCH + (s_y + 1) * 8;
+    const int s_slot = HH == 8 ? (s_y + 1 + s_rot) % 10 : s_y + 1;
+    unsigned short* S = sS + buf * S_HALFS + s_ci * S_PITCH + s_slot * 8;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if ((part < 0 || part == j) && (j == 0 || g_two)) {
         // x = hi + mid + lo exactly, each term a bf16 (top 16 bits of an fp32): truncate, subtract (exact), truncate, subtract;
         // at most 8 significant bits are left for lo: its truncation is exact
         unsigned h[8], m[8], l[8];
-        gsum[j] += ((rg[j][0] + rg[j][1]) + (rg[j][2] + rg[j][3])) + ((rg[j][4] + rg[j][5]) + rg[j][6]);
+        if constexpr (HH == 7) gsum[j] += ((rg[j][0] + rg[j][1]) + (rg[j][2] + rg[j][3])) + ((rg[j][4] + rg[j][5]) + rg[j][6]);
+        else gsum[j] += ((rg[j][0] + rg[j][1]) + (rg[j][2] + rg[j][3])) + ((rg[j][4] + rg[j][5]) + (rg[j][6] + rg[j][HH - 1]));
 #pragma unroll
-        for (int x = 0; x < 7; ++x) {
+        for (int x = 0; x < HH; ++x) {
           h[x] = __float_as_uint(rg[j][x]) & 0xFFFF0000u;
           const float p = rg[j][x] - __uint_as_float(h[x]);
           m[x] = __float_as_uint(p) & 0xFFFF0000u;
           l[x] = __float_as_uint(p - __uint_as_float(m[x]));
         }
-        h[7] = m[7] = l[7] = 0u;                                                           // column 7: the zero pad
+        if constexpr (HH == 7) h[7] = m[7] = l[7] = 0u;                                    // column 7: the zero pad
         v4i vh, vm, vl;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -114,7 +130,7 @@ __global__ __launch_bounds__(NTHR, 1) void wgrad3x3_bf16_kernel(WgArgs a) {
           vm[q] = (int)((m[2 * q] >> 16) | m[2 * q + 1]);
           vl[q] = (int)((l[2 * q] >> 16) | (l[2 * q + 1] & 0xFFFF0000u));
         }
-        unsigned short* d = G + (g_y0 + 4 * j) * 8;
+        unsigned short* d = G + ((g_y0 + 4 * j) ^ g_swz) * 8;
         *reinterpret_cast<v4i*>(d) = vh;
         *reinterpret_cast<v4i*>(d + WG_CO * G_PITCH) = vm;
         *reinterpret_cast<v4i*>(d + 2 * WG_CO * G_PITCH) = vl;
@@ -122,15 +138,17 @@ __global__ __launch_bounds__(NTHR, 1) void wgrad3x3_bf16_kernel(WgArgs a) {
     }
     if ((part < 0 || part == 2) && s_on) {
       // (the bf16 of the value by truncation: exact for spikes and for spike COUNTS up to 256 -- the time-collapsed last layer)
-      unsigned v[7];
+      unsigned v[8];
 #pragma unroll
-      for (int x = 0; x < 7; ++x) v[x] = __float_as_uint(rs[x]) >> 16;
+      for (int x = 0; x < HH; ++x) v[x] = __float_as_uint(rs[x]) >> 16;
+      if constexpr (HH == 7) v[7] = 0u;
       // copy kx: slot xx of row y + 1 holds s(y, xx + kx - 1)
       const unsigned p12 = v[1] | (v[2] << 16), p34 = v[3] | (v[4] << 16), p56 = v[5] | (v[6] << 16);
       v4i c0, c1, c2;
       c0[0] = (int)(v[0] << 16); c0[1] = (int)p12; c0[2] = (int)p34; c0[3] = (int)p56;                 // 0 s0 | s1 s2 | s3 s4 | s5 s6
-      c1[0] = (int)(v[0] | (v[1] << 16)); c1[1] = (int)(v[2] | (v[3] << 16)); c1[2] = (int)(v[4] | (v[5] << 16)); c1[3] = (int)v[6];
-      c2[0] = (int)p12; c2[1] = (int)p34; c2[2] = (int)p56; c2[3] = 0;                                  // s1 s2 | s3 s4 | s5 s6 | 0 0
+      c1[0] = (int)(v[0] | (v[1] << 16)); c1[1] = (int)(v[2] | (v[3] << 16)); c1[2] = (int)(v[4] | (v[5] << 16));
+      c1[3] = (int)(v[6] | (v[7] << 16));                                                               // (7x7: s6 0)
+      c2[0] = (int)p12; c2[1] = (int)p34; c2[2] = (int)p56; c2[3] = (int)v[7];                          // s1 s2 | s3 s4 | s5 s6 | s7 0 (7x7: 0 0)
       *reinterpret_cast<v4i*>(S) = c0;
       *reinterpret_cast<v4i*>(S + WG_CI * S_PITCH) = c1;
       *reinterpret_cast<v4i*>(S + 2 * WG_CI * S_PITCH) = c2;
@@ -153,13 +171,20 @@ __global__ __launch_bounds__(NTHR, 1) void wgrad3x3_bf16_kernel(WgArgs a) {
     const unsigned short* S = sS + buf * S_HALFS + (ct * 32 + row) * S_PITCH;
     // 36 (k step, tap) products, the B fragment read three products ahead of its use and the A fragments of the next k step
     // half a k step ahead (read-then-use in source order left the LDS latency exposed before every tap)
+    const int a_swz = HH == 8 ? ((wave * 32 + row) >> 1) & 7 : 0, b_rot = HH == 8 ? ((ct * 32 + row) >> 3) & 1 : 0;
     auto a_ptr = [&](int kstep, int term) -> const unsigned short* {
+      if constexpr (HH == 8) return G + term * WG_CO * G_PITCH + ((2 * kstep + half) ^ a_swz) * 8;
       return (kstep == 3 && half) ? sZ : G + term * WG_CO * G_PITCH + (2 * kstep + half) * 8;     // row 7 = the zero row
     };
     auto b_read = [&](int i) -> v4i {
       const int kstep = i / 9, tap = i % 9, ky = tap / 3, kx = tap % 3;
       int r = 2 * kstep + half + ky;                        // LDS row of image row y + ky - 1
-      r = r > 8 ? 8 : r;                                    // (only the zero row y = 7 can reach past the image: its A is zero)
+      if constexpr (HH == 8) {
+        r += b_rot;                                         // rows 0 .. 9, rotated by one slot for channels with bit 3 set
+        r = r >= 10 ? r - 10 : r;
+      } else {
+        r = r > 8 ? 8 : r;                                  // (only the zero row y = 7 can reach past the image: its A is zero)
+      }
       return *reinterpret_cast<const v4i*>(S + kx * WG_CI * S_PITCH + r * 8);
     };
     constexpr int AHEAD = 3;
@@ -191,14 +216,14 @@ __global__ __launch_bounds__(NTHR, 1) void wgrad3x3_bf16_kernel(WgArgs a) {
   // the bias gradient of this slice (workgroups of the first input-channel tile): the seven row sums of a channel meet in LDS
   // in a fixed order
   if (a.part_gb && tn == 0) {
-    float* sB = reinterpret_cast<float*>(lds);      // [7 rows][128 channels] (the operand buffers are done)
+    float* sB = reinterpret_cast<float*>(lds);      // [HH rows][128 channels] (the operand buffers are done)
     sB[g_y0 * WG_CO + g_co] = gsum[0];
     if (g_two) sB[(g_y0 + 4) * WG_CO + g_co] = gsum[1];
     __syncthreads();
     if (tid < WG_CO) {
       float t = 0.f;
 #pragma unroll
-      for (int y = 0; y < 7; ++y) t += sB[y * WG_CO + tid];
+      for (int y = 0; y < HH; ++y) t += sB[y * WG_CO + tid];
       a.part_gb[(long long)ks * a.Cout + co0 + tid] = t;
     }
   }
@@ -270,7 +295,7 @@ extern "C" int spk_conv3x3_wgrad_bf16(const float* gy_cl, const float* spikes_cl
                                       float* gw_out, float* gb_out_or_null, int TB, int H, int W, int Cout, int Cin,
                                       hipStream_t stream) {
   if (!gy_cl || !spikes_cl || !ws || !gw_out || TB <= 0) return SPK_ERR_ARG;
-  if (H != 7 || W != 7 || (Cout % WG_CO) || (Cin % WG_CI)) return SPK_ERR_UNSUPPORTED;
+  if (H != W || (H != 7 && H != 8) || (Cout % WG_CO) || (Cin % WG_CI)) return SPK_ERR_UNSUPPORTED;
   const int tiles = (Cout / WG_CO) * (Cin / WG_CI);
   const int ks = wgrad_ksplit(TB, Cout, Cin);
   const long long n = (long long)Cout * 9 * Cin;
@@ -278,8 +303,9 @@ extern "C" int spk_conv3x3_wgrad_bf16(const float* gy_cl, const float* spikes_cl
   WgArgs a;
   a.gy = gy_cl; a.s = spikes_cl; a.part = ws;
   a.part_gb = gb_out_or_null ? ws + (long long)ks * n : nullptr; a.TB = TB; a.Cout = Cout; a.Cin = Cin; a.ksplit = ks;
-  if ((long long)LDS_BYTES > spk_lds_limit()) return SPK_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(wgrad3x3_bf16_kernel, dim3(tiles * ks), dim3(NTHR), (size_t)LDS_BYTES, stream, a);
+  if ((long long)lds_bytes(H) > spk_lds_limit()) return SPK_ERR_UNSUPPORTED;
+  if (H == 7) hipLaunchKernelGGL(wgrad3x3_bf16_kernel<7>, dim3(tiles * ks), dim3(NTHR), (size_t)lds_bytes(7), stream, a);
+  else hipLaunchKernelGGL(wgrad3x3_bf16_kernel<8>, dim3(tiles * ks), dim3(NTHR), (size_t)lds_bytes(8), stream, a);
   SPK_LAUNCH_CHECK();
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + Cout + 63) / 64 > 8192 ? 8192 : (n + Cout + 63) / 64)), dim3(256), 0, stream,
                      ws, gw_out, n, ks, a.part_gb, gb_out_or_null, Cout);

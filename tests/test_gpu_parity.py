@@ -2610,13 +2610,14 @@ def test_f14_lifnode_other_eval_forms_vs_reference_fixture(golden_dir, dev, name
 
 # ------------------------------------------------------------------------------------------------- round 3: native weight gradient
 @pytest.mark.parametrize("N,Cout,Cin", [(7, 128, 64), (64, 256, 128), (37, 512, 256), (16, 256, 512), (5, 128, 320)])
-def test_conv3x3_weight_gradient_bf16_kernel_vs_fp64(dev, ops, N, Cout, Cin):
+@pytest.mark.parametrize("HH", [7, 8])
+def test_conv3x3_weight_gradient_bf16_kernel_vs_fp64(dev, ops, N, Cout, Cin, HH):
     """spk_conv3x3_wgrad_bf16 (spike operand exact in bf16, gy split into three bf16 terms exactly, fp32 accumulation on the
     matrix cores) against the fp64 weight gradient of the same convolution: relative L2 error at fp32 round-off, and not worse
-    than the framework's fp32 operator."""
+    than the framework's fp32 operator.  7x7 (MNIST-shaped latents) and 8x8 maps (CIFAR-shaped: round 4)."""
     g = torch.Generator().manual_seed(N + Cout)
-    s = (torch.rand(N, Cin, 7, 7, generator=g) < 0.07).float()
-    gy = torch.randn(N, Cout, 7, 7, generator=g) * torch.rand(Cout, generator=g).view(1, -1, 1, 1) * 1e-3
+    s = (torch.rand(N, Cin, HH, HH, generator=g) < 0.07).float()
+    gy = torch.randn(N, Cout, HH, HH, generator=g) * torch.rand(Cout, generator=g).view(1, -1, 1, 1) * 1e-3
     gy[:, ::5] *= 64.0                                                    # mixed magnitudes across channels
     w = torch.zeros(Cout, Cin, 3, 3)
     _, want, _ = torch.ops.aten.convolution_backward(gy.double(), s.double(), w.double(), [Cout], [1, 1], [1, 1], [1, 1], False,
@@ -2632,11 +2633,32 @@ def test_conv3x3_weight_gradient_bf16_kernel_vs_fp64(dev, ops, N, Cout, Cin):
     _, lib_gw, _ = torch.ops.aten.convolution_backward(gy_cl, s_cl, w.to(dev), [Cout], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                        [False, True, False])
     rel_lib = float((lib_gw.cpu().double() - want).norm() / want.norm())
-    print(f"wgrad N={N} {Cin}->{Cout}: rel L2 error {rel:.2e} (framework operator {rel_lib:.2e})")
-    parity(f"wgrad_bf16_N{N}_{Cin}_{Cout}", rel_l2_err=rel, rel_l2_err_framework=rel_lib)
+    print(f"wgrad {HH}x{HH} N={N} {Cin}->{Cout}: rel L2 error {rel:.2e} (framework operator {rel_lib:.2e})")
+    parity(f"wgrad_bf16_{HH}x{HH}_N{N}_{Cin}_{Cout}", rel_l2_err=rel, rel_l2_err_framework=rel_lib)
     assert rel <= 2e-6
     got2 = ops.conv3x3_wgrad(gy_cl, s_cl, Cout, Cin)
     assert torch.equal(got, got2), "deterministic (partial sums added in a fixed order)"
+
+
+@pytest.mark.parametrize("HH", [7, 8])
+def test_conv3x3_weight_gradient_impulses(dev, ops, HH):
+    """One spike and one unit output gradient at a time: gw[co, ci, ky, kx] = 1 exactly where (y_s, x_s) = (y_g + ky - 1, x_g + kx - 1)
+    and 0 elsewhere -- every (position, tap) pair of the map, every LDS row / column slot of the kernel's shifted spike copies
+    and (8x8) swizzled gradient rows, channels on both sides of the swizzle periods."""
+    Cout, Cin = 128, 64
+    cases = [(yg, xg, co, ci) for yg, xg, co, ci in
+             [(0, 0, 0, 0), (HH - 1, HH - 1, 127, 63), (0, HH - 1, 3, 9), (HH - 1, 0, 66, 40), (3, 4, 17, 8), (HH - 2, 1, 2, 15),
+              (1, HH - 2, 5, 56), (4, 3, 127, 24)]]
+    for yg, xg, co, ci in cases:
+        for ys in range(max(0, yg - 1), min(HH, yg + 2)):
+            for xs in range(max(0, xg - 1), min(HH, xg + 2)):
+                s = torch.zeros(2, Cin, HH, HH); gy = torch.zeros(2, Cout, HH, HH)
+                s[1, ci, ys, xs] = 1.0; gy[1, co, yg, xg] = 1.0
+                got = ops.conv3x3_wgrad(gy.to(dev).contiguous(memory_format=torch.channels_last),
+                                        s.to(dev).contiguous(memory_format=torch.channels_last), Cout, Cin).cpu()
+                want = torch.zeros(Cout, Cin, 3, 3)
+                want[co, ci, ys - yg + 1, xs - xg + 1] = 1.0
+                assert torch.equal(got, want), (HH, yg, xg, ys, xs, co, ci, got.nonzero().tolist())
 
 
 # ------------------------------------------------------------------------------------------------- round 3: native data gradient
