@@ -386,10 +386,11 @@ int spk_embedding_fwd(const long long* tokens, const float* codebook, float* out
  * gw[co][ky][kx][ci] = sum_{n,y,x} gy[n,co,y,x] * s[n,ci,y+ky-1,x+kx-1] on the bf16 matrix cores -- the spikes are exact in bf16,
  * the fp32 output gradient is split into three bf16 terms exactly, so only the fp32 accumulation rounds.  gy_cl / spikes_cl:
  * channels-last fp32 [N = T*B][H*W][C]; gw_out fp32 [Cout][3][3][Cin] (= a channels-last [Cout,Cin,3,3] tensor); ws: scratch of
- * spk_conv3x3_wgrad_ws_bytes (split-K partial sums, added in a fixed order: deterministic).  7x7 maps, Cout % 128 == 0,
- * Cin % 64 == 0; otherwise SPK_ERR_UNSUPPORTED (use the framework's operator). * The spike operand may also hold small non-negative integers (spike counts up to 256: exact in bf16) -- the time-collapsed
- * backward of the denoiser's last layer. * gb_out_or_null [Cout]: the bias gradient (sum of gy over images and positions), from the same pass over gy.
- */
+ * spk_conv3x3_wgrad_ws_bytes (split-K partial sums, added in a fixed order: deterministic).  7x7 or 8x8 maps (H == W),
+ * Cout % 128 == 0, Cin % 64 == 0; otherwise SPK_ERR_UNSUPPORTED (use the framework's operator).
+ * The spike operand may also hold small non-negative integers (spike counts up to 256: exact in bf16) -- the time-collapsed
+ * backward of the denoiser's last layer.
+ * gb_out_or_null [Cout]: the bias gradient (sum of gy over images and positions), from the same pass over gy. */
 long long spk_conv3x3_wgrad_ws_bytes(int N, int Cout, int Cin);
 int spk_conv3x3_wgrad_bf16(const float* gy_cl, const float* spikes_cl, float* ws, long long ws_bytes, float* gw_out,
                            float* gb_out_or_null, int N, int H, int W, int Cout, int Cin, spk_stream_t stream);
