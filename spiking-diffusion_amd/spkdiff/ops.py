@@ -902,7 +902,7 @@ def train_weight_prep(layers):
     import ctypes
     if not layers or len(layers) > 8:
         return None
-    ws_, dev = [], layers[0][0].device
+    dev = layers[0][0].device
     for w, b, n_dg, hw in layers:
         if not (w.is_cuda and w.dtype == torch.float32 and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)
                 and w.is_contiguous(memory_format=torch.channels_last) and w.shape[0] % 16 == 0 and w.shape[1] % 64 == 0):
