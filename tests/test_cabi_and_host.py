@@ -305,3 +305,40 @@ def test_stroke_images_are_deterministic_and_image_like():
     assert 0.0 <= float(a.min()) and float(a.max()) <= 1.0 and 0.03 < float(a.mean()) < 0.3
     assert not torch.equal(a, synth.stroke_images(48, seed=8))
     assert synth.stroke_images(4, seed=7, img=32, channels=3).shape == (4, 3, 32, 32)
+
+
+def test_round4_training_entry_points_check_their_arguments_on_the_host():
+    """The training entry points added in round 4 reject bad arguments before any launch (no GPU): the multi-layer weight
+    packing (null tables, more than eight layers, a layer whose channel counts the kernels do not take), the prepacked data
+    gradient, the BatchNorm+LIF forward that also writes packed spikes, the small-input weight gradient, q_sample."""
+    import ctypes
+    from spkdiff import _lib
+    lib = _lib.lib
+    nine = (ctypes.c_void_p * 9)(*([1] * 9))
+    i9 = (ctypes.c_int * 9)(*([64] * 9))
+    l9 = (ctypes.c_longlong * 9)(*([1 << 30] * 9))
+    assert lib.spk_den_pack_weight_fp6_cl_multi(None, None, None, None, None, None, None, 1, None) == -1
+    assert lib.spk_den_pack_weight_fp6_cl_multi(nine, None, nine, nine, nine, i9, i9, 0, None) == -1
+    assert lib.spk_den_pack_weight_fp6_cl_multi(nine, None, nine, nine, nine, i9, i9, 9, None) == -2       # more than eight layers
+    bad = (ctypes.c_int * 1)(48)                                                                            # Cin % 64 != 0
+    assert lib.spk_den_pack_weight_fp6_cl_multi(nine, None, nine, nine, nine, i9, bad, 1, None) == -2
+    assert lib.spk_conv3x3_dgrad_f16x2_pack_multi(None, None, None, None, None, None, 1, None) == -1
+    assert lib.spk_conv3x3_dgrad_f16x2_pack_multi(nine, nine, l9, i9, i9, i9, 9, None) == -2
+    assert lib.spk_conv3x3_dgrad_f16x2_pack_multi(nine, nine, l9, i9, i9, bad, 1, None) == -2               # Cin % 32 != 0
+    small = (ctypes.c_longlong * 1)(16)
+    assert lib.spk_conv3x3_dgrad_f16x2_pack_multi(nine, nine, small, i9, i9, i9, 1, None) == -1             # workspace too small
+    assert lib.spk_conv3x3_dgrad_f16x2_prepacked(None, None, 0, None, 8, 7, 7, 64, 64, None) == -1
+    assert lib.spk_conv3x3_dgrad_f16x2_prepacked(1, 1, 1 << 30, 1, 8, 7, 9, 64, 64, None) == -2             # not a 7x7 / 8x8 map
+    assert lib.spk_conv3x3_wgrad_bf16(1, 1, 1, 1 << 40, 1, None, 8, 9, 9, 128, 64, None) == -2              # 9x9 maps
+    assert lib.spk_conv3x3_wgrad_bf16(1, 1, 1, 16, 1, None, 8, 8, 8, 128, 64, None) == -1                   # workspace too small
+    assert lib.spk_conv3x3_wgrad_ws_bytes(512, 128, 64) > 0 and lib.spk_conv3x3_wgrad_ws_bytes(512, 100, 64) == -1
+    f = ctypes.c_float
+    assert lib.spk_bn_lif_train_fwd_c4(None, None, None, None, None, f(0.1), f(1e-5), None, None, None, None, None, None, None, 0,
+                                       16, 2, 64, 49, f(2.0), f(1.0), f(0.0), None) == -1
+    # packed spikes need whole 64-channel records: refused before anything is launched
+    ws = lib.spk_bn_lif_train_ws_bytes(2, 48, 49)
+    assert ws > 0
+    assert lib.spk_bn_lif_train_fwd_c4(16, None, None, None, None, f(0.1), f(1e-5), None, 16, None, 16, 16, 16, 16, ws,
+                                       16, 2, 48, 49, f(2.0), f(1.0), f(0.0), None) == -2
+    assert lib.spk_q_sample(None, None, None, None, None, None, 4, 49, 100, 128, None) == -1
+    assert lib.spk_conv3x3_wgrad_small(None, None, None, 0, None, None, 8, 7, 7, 64, 2, 1, None) == -1
