@@ -21,12 +21,15 @@ for case in range(cases):
     N = rng.choice([1, 3, 8, 9, 31, 64, 100, 257, 512])
     Cout = 16 * rng.randint(1, 32)
     Cin = 32 * rng.randint(1, 16)
+    if case % 3 == 0:                                  # (shapes the weight-gradient kernel takes: every third case)
+        Cout, Cin = 128 * rng.randint(1, 4), 64 * rng.randint(1, 8)
+    HH = rng.choice([7, 8])                            # MNIST-shaped and CIFAR-shaped maps
     g = torch.Generator().manual_seed(case)
     mag = 10.0 ** rng.uniform(-8, 2)
-    gy = torch.randn(N, Cout, 7, 7, generator=g) * torch.rand(Cout, generator=g).view(1, -1, 1, 1) * mag
+    gy = torch.randn(N, Cout, HH, HH, generator=g) * torch.rand(Cout, generator=g).view(1, -1, 1, 1) * mag
     w = torch.randn(Cout, Cin, 3, 3, generator=g) * (10.0 ** rng.uniform(-4, 1))
-    s = (torch.rand(N, Cin, 7, 7, generator=g) < rng.uniform(0.01, 0.5)).float()
-    cnt = torch.randint(0, 17, (N, Cin, 7, 7), generator=g).float()
+    s = (torch.rand(N, Cin, HH, HH, generator=g) < rng.uniform(0.01, 0.5)).float()
+    cnt = torch.randint(0, 17, (N, Cin, HH, HH), generator=g).float()
     gy_d, w_d = gy.to(dev).contiguous(memory_format=CL), w.to(dev)
     want_gi = bwd(gy.double(), s.double(), w.double(), [True, False, False])[0]
     lib_gi = bwd(gy_d, s.to(dev).contiguous(memory_format=CL), w_d.contiguous(memory_format=CL), [True, False, False])[0].cpu().double()
@@ -46,6 +49,6 @@ for case in range(cases):
             worst[name] = max(worst[name], e)
             ratio[name] = max(ratio[name], e / max(el, 1e-12))
             assert e <= 2e-6, (name, N, Cout, Cin, e)
-print(f"{cases} random cases (N 1..512, Cout 16..512, Cin 32..512, magnitudes 1e-8..1e2): worst relative L2 error against fp64")
+print(f"{cases} random cases (N 1..512, Cout 16..512, Cin 32..512, 7x7 and 8x8 maps, magnitudes 1e-8..1e2): worst relative L2 error against fp64")
 for k in worst:
     print(f"  {k:14s} {worst[k]:.2e}   (at most {ratio[k]:.2f}x the framework operator's error on the same case)")

@@ -1,0 +1,14 @@
+#!/bin/bash
+# the stress record of profiles/r4_stress.txt (one box)
+R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
+cd $R
+run() { echo "== $*"; "$@" 2>/dev/null | tail -6; }
+{
+run python tools/fp6v2_stress.py 200 32
+run python tools/vae_fp6_stress.py 100 8
+run python tools/modes_stress.py 30 256
+SPKDIFF_V2_LAG=1 run python tools/fp6v2_stress.py 40 32
+SPKDIFF_V2_WAVES=12 run python tools/fp6v2_stress.py 40 32
+run python tools/backward_stress.py 90 7
+} > gpurun_out/r4_stress_final.txt 2>&1
+cat gpurun_out/r4_stress_final.txt
