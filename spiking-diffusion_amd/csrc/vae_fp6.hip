@@ -102,6 +102,11 @@ constexpr float CERT_4EPS = 4.0f * 2.38418579e-07f;
 #define SPK_VT_TPP_T SPK_VT_TPP // ... of the transposed (1 / 2 / 2 / 4-tap) layers.  Round 4 (four digits): three tiles per pass fit (256 registers,
                                 // 16 B of scratch) and measure the same as two (dec2 0.2275 against 0.2219 / 0.2249 ms): two
 #endif
+#ifndef SPK_VT_HOIST
+#define SPK_VT_HOIST 1          // the weight fragments of a class's FIRST tap stay in registers over the wave's passes of that class within an
+                                // item (24 registers with two chunks, 12 with one): the multiply phase of these layers is bound by LDS reads,
+                                // 1.5 KB of weight fragments per MFMA (profiles/r4_ab_kernel_variants.txt (11)); 0: every pass reads them
+#endif
 #ifndef SPK_VT_DBG
 #define SPK_VT_DBG 0            // timing experiments only (results are wrong): 1 = no MFMAs, 2 = no LIF scan, 4 = no weight-tile reads from LDS
 #endif
@@ -292,8 +297,10 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
       __syncthreads();
     }
 
-    auto run_pass = [&](auto cls_tag, int k) __attribute__((always_inline)) {
+    // hb: the weight fragments of the class's first tap, read once per class by the caller (SPK_VT_HOIST)
+    auto run_pass = [&](auto cls_tag, int k, const v6i (&hb)[NCH * 2]) __attribute__((always_inline)) {
       constexpr int CLS = decltype(cls_tag)::value, PY = CLS >> 1, PX = CLS & 1;
+      constexpr int TAP0 = on_tap<GEO, CLS>(0);
       int tl[TPP];                                         // tiles of the pass; one past the end repeats the first (computed, dropped)
       bool tv[TPP];
 #pragma unroll
@@ -389,7 +396,9 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
               av[i][0] = *reinterpret_cast<const v4i*>(A0 + base[i] + TOFF);
               av[i][1] = *reinterpret_cast<const v4i*>(A0 + A_CH + base[i] + TOFF);
             }
-            const v6i b0 = ldb(TAP * TPL + 0), b1 = ldb(TAP * TPL + 1), b2 = ldb(TAP * TPL + 2), b3 = ldb(TAP * TPL + 3);
+            constexpr bool HB = SPK_VT_HOIST && SPK_VT_D4 && TAP == TAP0;
+            const v6i b0 = HB ? hb[0] : ldb(TAP * TPL + 0), b1 = HB ? hb[1] : ldb(TAP * TPL + 1),
+                      b2 = HB ? hb[2] : ldb(TAP * TPL + 2), b3 = HB ? hb[3] : ldb(TAP * TPL + 3);
             v6i b4 = b0;
             if constexpr (!SPK_VT_D4) b4 = ldb(TAP * TPL + 4);
 #pragma unroll
@@ -408,7 +417,8 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
             v4i av[TPP];
 #pragma unroll
             for (int i = 0; i < TPP; ++i) av[i] = *reinterpret_cast<const v4i*>(A0 + base[i] + TOFF);
-            const v6i b0 = ldb(TAP * TPL + 0), b1 = ldb(TAP * TPL + 1);
+            constexpr bool HB = SPK_VT_HOIST && SPK_VT_D4 && TAP == TAP0;
+            const v6i b0 = HB ? hb[0] : ldb(TAP * TPL + 0), b1 = HB ? hb[1] : ldb(TAP * TPL + 1);
             v6i b4 = b0;
             if constexpr (!SPK_VT_D4) b4 = ldb(TAP * TPL + 2);
 #pragma unroll
@@ -510,19 +520,28 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
       }
     };
 
-    for (int P = wave; P < NCLS * NPASS; P += SPK_VT_NWV) {
-      const int cls = P / NPASS, k = P - cls * NPASS;
-      if constexpr (NCLS == 1) {
-        run_pass(std::integral_constant<int, 0>{}, k);
-      } else {
-        switch (cls) {
-          case 0: run_pass(std::integral_constant<int, 0>{}, k); break;
-          case 1: run_pass(std::integral_constant<int, 1>{}, k); break;
-          case 2: run_pass(std::integral_constant<int, 2>{}, k); break;
-          default: run_pass(std::integral_constant<int, 3>{}, k); break;
+    // the item's passes, class-major, dealt round-robin over the waves (every wave gets a mix of cheap and expensive classes); a
+    // wave's passes of one class follow one another, so the class's first-tap weight fragments are read once for all of them
+    tfor<NCLS>([&](auto cls_tag) {
+      constexpr int CLS = decltype(cls_tag)::value, TAP0 = on_tap<GEO, CLS>(0);
+      int P = CLS * NPASS + ((wave - CLS * NPASS) % SPK_VT_NWV + SPK_VT_NWV) % SPK_VT_NWV;     // first P >= CLS * NPASS with P = wave (mod NWV)
+      if (P < (CLS + 1) * NPASS) {
+        v6i hb[NCH * 2];
+        if constexpr (SPK_VT_HOIST && SPK_VT_D4 && !SPK_VT_PIPE) {
+#pragma unroll
+          for (int j = 0; j < NCH * 2; ++j) {
+            const uint8_t* p = sW + (TAP0 * TPL + j) * WT;
+            const v4i x = *reinterpret_cast<const v4i*>(p + lane * 16);
+            const v2i y = *reinterpret_cast<const v2i*>(p + 1024 + lane * 8);
+            hb[j] = v6i{x[0], x[1], x[2], x[3], y[0], y[1]};
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < NCH * 2; ++j) hb[j] = v6i{0, 0, 0, 0, 0, 0};
         }
+        for (; P < (CLS + 1) * NPASS; P += SPK_VT_NWV) run_pass(cls_tag, P - CLS * NPASS, hb);
       }
-    }
+    });
     if (!DB) __syncthreads();                                  // everyone is done with the slab before the next copy lands
   }
   spk_dma_wait_all();
