@@ -470,10 +470,10 @@ def conv3x3_wgrad_small(grad_y, x, weight, want_bias):
 
 
 # Training forward of a stand-alone convolution: exact direct kernel up to this many multiply-accumulates per call (its fp64
-# accumulation is not a matrix-core kernel), the library operator beyond.  Round 4: 4e9 -> 2.5e8 -- at the reference's batch of 32
-# the VQ-VAE's 64 -> 32 transposed convolution (1.85e9) took 2.4 ms of a 5.4 ms training iteration in the exact kernel
-# (profiles/r4_train_vqvae.md); the fixtures' batch of 4 stays exact
-EXACT_TRAIN_FORWARD_MACS = 250_000_000
+# accumulation is not a matrix-core kernel), the library operator beyond.  Round 4: 4e9 -> 1e8 -- at the reference's batch of 32
+# the VQ-VAE's 64 -> 32 transposed convolution (1.85e9) took 2.4 ms of a 5.4 ms training iteration in the exact kernel, the
+# 16 -> 64 one (2.3e8) 0.33 ms (profiles/r4_train_vqvae.md)
+EXACT_TRAIN_FORWARD_MACS = 100_000_000
 
 
 def memout(x_seq, coef):
