@@ -143,6 +143,12 @@ struct V2Args {
 #define SPK_V2_NMAX_LDS 1       // the first certification stage reads max_t n_t of its position from LDS (one atomic per (position, step)
                                 // in the per-item count pass) instead of sixteen counts + twelve v_max per tile and lane.  0: rounds 2-3
 #endif
+#ifndef SPK_V2_SIGNBITS
+#define SPK_V2_SIGNBITS 1       // the sixteen spike bits of a lane are shifted in from the sign of h - 1 (h - 1 exists for the certification: one
+                                // v_alignbit per step, one bit reversal per tile) instead of sixteen selects on the compare masks + eight
+                                // three-way ORs: -23 vector instructions and -4 hazard nops per tile; dense reverse process 88.84 -> 88.33 ms
+                                // (same box, two passes, bit-equal: profiles/r4_ab_kernel_variants.txt (13)).  0: the select form
+#endif
 #ifndef SPK_V2_LP_PAIRS
 #define SPK_V2_LP_PAIRS 1       // last-position part of the tail launch: image pairs (32-row tiles) per unit.  2 halves the weight-tile
                                 // reads (327 -> 164 MB through L2 for the 256 -> 512 layer at B = 256) and needs 146 + 96 registers
@@ -664,10 +670,12 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
             const float z = z2[e];
             zmax = fmaxf(zmax, fabsf(z));
             const float h = fmaf(z - v, 0.5f, v);            // == v + (z - v) * 0.5f: the product is exact (v is not an output here)
-            dmin = fminf(dmin, fabsf(h - 1.0f));
+            const float hm = h - 1.0f;
+            dmin = fminf(dmin, fabsf(hm));
             const bool s = h >= 1.0f;
             v = s ? 0.0f : h;
             if constexpr (SPK_V2_MASKSTORE) sp[r2 + e] = s;
+            else if constexpr (SPK_V2_SIGNBITS) mybits = __builtin_amdgcn_alignbit(mybits, __float_as_uint(hm), 31);   // (mybits << 1) | sign(h - 1)
             else mybits |= s ? (1u << (r2 + e)) : 0u;
           }
         }
@@ -679,6 +687,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
             for (int r = 0; r < 16; ++r) mybits += sp[r] ? 1u : 0u;          // here: the COUNT, not the bit word
           }
         }
+        if constexpr (SPK_V2_SIGNBITS && !SPK_V2_MASKSTORE) mybits = ~(__builtin_bitreverse32(mybits) >> 16) & 0xffffu;   // bit r = NOT sign(h_r - 1)
         flg = dmin <= SPK_V2_SPARE * fmaf(zmax, 2.5f * CERT_4EPS, fmaf((float)nmax, cT, cE));   // (10 eps for 8: a little to spare)
         if (SPK_V2_STAGE2 && __builtin_amdgcn_ballot_w64(flg) != 0ull) {
           // SECOND STAGE (a wave with a flagged lane: a few percent of the tiles).  The closed form above compares the closest

@@ -102,6 +102,11 @@ constexpr float CERT_4EPS = 4.0f * 2.38418579e-07f;
 #define SPK_VT_TPP_T SPK_VT_TPP // ... of the transposed (1 / 2 / 2 / 4-tap) layers.  Round 4 (four digits): three tiles per pass fit (256 registers,
                                 // 16 B of scratch) and measure the same as two (dec2 0.2275 against 0.2219 / 0.2249 ms): two
 #endif
+#ifndef SPK_VT_SIGNBITS
+#define SPK_VT_SIGNBITS 1       // spike-bit outputs: the sixteen bits of a lane shifted in from the sign of h - 1 (den_mfma_fp6v2.hip, SPK_V2_SIGNBITS):
+                                // same speed here (encode -> decode 1.667-1.685 against 1.677-1.678 M images/s), ten registers fewer in the
+                                // spike-bit layers and no scratch left in the CIFAR-shaped 8x8 -> 16x16 layer.  0: the select form
+#endif
 #ifndef SPK_VT_HOIST
 #define SPK_VT_HOIST 1          // the weight fragments of a class's FIRST tap stay in registers over the wave's passes of that class within an
                                 // item (24 registers with two chunks, 12 with one): the multiply phase of these layers is bound by LDS reads,
@@ -462,7 +467,8 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
             const float z = z2[e];
             zmax = fmaxf(zmax, fabsf(z));
             const float h = fmaf(z - v, 0.5f, v);            // == v + (z - v) * 0.5f: the product is exact
-            dmin = fminf(dmin, fabsf(h - 1.0f));
+            const float hm = h - 1.0f;
+            dmin = fminf(dmin, fabsf(hm));
             if constexpr (OUT == OUT_COLLAPSED && SPK_VT_EXEC_SCAN) {
               // spike = h >= 1: reset v and add the step's coefficient UNDER THE SPIKE MASK (v_cmpx narrows exec, two plain
               // instructions, exec restored): three vector instructions instead of compare + two selects + add (convT2 -5 %;
@@ -476,9 +482,13 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
               const bool s = h >= 1.0f;
               v = s ? 0.0f : h;
               if (OUT == OUT_COLLAPSED) m = m + (s ? coef[r] : 0.f);
+              else if constexpr (SPK_VT_SIGNBITS) mybits = __builtin_amdgcn_alignbit(mybits, __float_as_uint(hm), 31);   // (mybits << 1) | sign(h - 1)
               else mybits |= s ? (1u << r) : 0u;
             }
           }
+        }
+        if constexpr (SPK_VT_SIGNBITS && OUT != OUT_COLLAPSED) {
+          if (!(SPK_VT_DBG & 2)) mybits = ~(__builtin_bitreverse32(mybits) >> 16) & 0xffffu;      // bit r = NOT sign(h_r - 1)
         }
         const int p = 2 * tl[i] + half;                       // accumulator lane half == position within the tile
         const bool ok = tv[i] && p < NPOS;
