@@ -229,6 +229,8 @@ class FusedSequential(nn.Sequential):
         which the next module's exact forward picks up instead of converting the fp32 tensor."""
         blocks = self._blocks()
         c4_in = getattr(x, '_spk_c4', None)
+        if c4_in is not None:                          # (packed spikes, version of x they were made from): stale after an in-place write
+            c4_in = c4_in[0] if c4_in[1] == x._version else None
         for bi, (conv, bn, lif) in enumerate(blocks):
             w = conv.weight
             if w.dim() == 4 and not w.is_contiguous(memory_format=torch.channels_last):
@@ -257,7 +259,7 @@ class FusedSequential(nn.Sequential):
                                                float(lif.surrogate_function.alpha), lif.detach_reset, emit)
             x, lif.v = out[0], out[1]
             if emit and out[2] is not None:
-                x._spk_c4 = out[2]
+                x._spk_c4 = (out[2], x._version)
             sink = getattr(self, '_nbt_sink', None)
             if sink is not None:
                 sink.append(bn.num_batches_tracked)   # (the caller bumps all counters of the model with one launch)

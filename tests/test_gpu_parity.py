@@ -2966,3 +2966,29 @@ def test_training_iteration_with_and_without_weight_prep(dev, ops):
         assert torch.equal(a, b)
     for a, b in zip(res[0][2], res[1][2]):
         assert torch.equal(a, b)
+
+
+def test_packed_spike_hand_over_between_training_blocks(dev, ops):
+    """FusedSequential.train_forward(want_c4=True) leaves the block's spikes as C4 records next to the fp32 tensor (tagged with
+    the tensor's version) for the next block's exact forward: they are what the conversion kernel makes of the fp32 spikes, the
+    next block gives the same result with and without them, and the fp32 tensor cannot be rewritten in place behind them
+    (autograd refuses in-place writes to this operator's outputs)."""
+    from snn_model.vq_diffusion import DummyModel, functional
+    torch.manual_seed(3)
+    den = DummyModel(1, 128, n_steps=16).to(dev)
+    functional.set_step_mode(net=den, step_mode='m')
+    den.load_state_dict(synth.synth_denoiser_state(synth.MNIST))
+    den.train()
+    h = torch.randn(16, 4, 2, 7, 7, device=dev)
+    x1 = den.conv1.train_forward(h, want_c4=True)
+    c4, ver = x1._spk_c4
+    assert ver == x1._version and torch.equal(c4, ops.spikes_cl_to_c4(x1.detach()))
+    y_fast = den.conv2.train_forward(x1, binary_input=True).detach().clone()
+    functional.reset_net(den)
+    x1c = den.conv1.train_forward(h, want_c4=False)
+    assert getattr(x1c, '_spk_c4', None) is None
+    y_ref = den.conv2.train_forward(x1c, binary_input=True).detach()
+    assert torch.equal(y_fast, y_ref) and float(y_ref.abs().max()) > 0
+    with pytest.raises(RuntimeError):
+        x1.mul_(0.0)
+    functional.reset_net(den)
