@@ -86,7 +86,14 @@ class AbsorbingDiffusion(Sampler):
         import os
         self.noise_layout = 'global'
         self.global_first = 0
-        self.sync_key = True                 # 'global' layout inside an initialised process group: broadcast the key from rank 0
+        # The key broadcast is a COLLECTIVE, so it is opt-in: it happens only in a sampler that ``set_shard`` declared a shard of a
+        # multi-rank job (every rank of the job then calls sample()).  A sampler that never called set_shard inside an initialised
+        # process group (a preview on rank 0 during DDP training, or old-style per-rank sampling) takes no collective and folds the
+        # rank into its key, as rounds 1-3 did: no deadlock, and ranks seeded alike still draw distinct images (one warning).
+        self.sync_key = True                 # set_shard + 'global' layout + world_size > 1: broadcast the key from rank 0
+        self._shard_set = False
+        self._warned_unsharded = False
+        self.last_key = None
         self.philox_stream = int(os.environ.get('RANK', '0'))
         # Replay the whole reverse process as ONE hipGraph (philox mode, no hooks): the ~800 kernel launches of a
         # 100-step sample are captured once per (batch, steps, temp) and replayed; fresh noise per replay comes from a
@@ -174,6 +181,7 @@ class AbsorbingDiffusion(Sampler):
         seed, base = 0, 0
         if noise is None and self.noise_source == 'philox':
             seed = self._philox_key()
+            self.last_key = seed               # (read-only record: bench.py compares it across ranks after a timed region)
         self._check_weights(dn)
         if self.use_graph and noise is None and record is None and self.noise_source == 'philox':
             self._capturing = False
@@ -243,6 +251,7 @@ class AbsorbingDiffusion(Sampler):
         """This sampler generates images [first, first + count) of a larger job ('global' noise layout): the draws of an
         image are those the whole job would make for it.  ``count`` (optional) also sets ``n_samples``."""
         self.global_first = int(first)
+        self._shard_set = True
         if count is not None:
             self.n_samples = int(count)
         return self
@@ -261,11 +270,20 @@ class AbsorbingDiffusion(Sampler):
         draw = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64))
         if self.noise_layout == 'global':
             import torch.distributed as dist
-            if self.sync_key and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                dev = next(self._denoise_fn.parameters()).device if dist.get_backend() == 'nccl' else 'cpu'
-                k = torch.tensor([draw], dtype=torch.int64, device=dev)
-                dist.broadcast(k, 0)
-                draw = int(k.item())
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                if not self._shard_set:
+                    if not self._warned_unsharded:
+                        import warnings
+                        warnings.warn("spkdiff: sample() inside a process group without set_shard(): no key broadcast, the rank "
+                                      "is folded into the key (per-rank images).  Call set_shard(first, count) on every rank "
+                                      "(spkdiff.dist.sample_images_sharded(..., sampler=ab) does) for one split-independent job.")
+                        self._warned_unsharded = True
+                    return (draw ^ ((int(dist.get_rank()) * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF)) & 0x7FFFFFFFFFFFFFFF
+                if self.sync_key:
+                    dev = next(self._denoise_fn.parameters()).device if dist.get_backend() == 'nccl' else 'cpu'
+                    k = torch.tensor([draw], dtype=torch.int64, device=dev)
+                    dist.broadcast(k, 0)
+                    draw = int(k.item())
             return draw & 0x7FFFFFFFFFFFFFFF
         return (draw ^ ((int(self.philox_stream) * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF)) & 0x7FFFFFFFFFFFFFFF
 

@@ -156,6 +156,15 @@ def version() -> int:
     return lib.spk_version()
 
 
+# The signatures declared above are those of include/spkdiff.h at this version.  A stale libspkdiff.so or an SPKDIFF_LIB A/B
+# variant built from another header would take arguments at the wrong positions (silently wrong results): refuse it here.
+EXPECTED_VERSION = 101
+if version() != EXPECTED_VERSION:
+    raise ImportError(f"spkdiff: {LIB_PATH} reports C-ABI version {version()}, this binding declares version "
+                      f"{EXPECTED_VERSION} (include/spkdiff.h SPK_VERSION). Rebuild the library: make -C "
+                      f"{os.path.join(os.path.dirname(_HERE), 'csrc')}")
+
+
 # Measurement options (include/spkdiff.h): the library reads no environment variable itself; the A/B tools under tools/ select
 # a launch form with SPKDIFF_<NAME>=<int>, forwarded here ONCE at import.  set_option() switches at run time.
 OPTIONS = ("v2_waves", "v2_lag", "fp6_waves", "fp6_xcd_walk", "conv6_shared", "conv6_shared_dyn", "mfma_debug")

@@ -59,11 +59,18 @@ def gather_images(local_u8: torch.Tensor, total: int | None = None) -> torch.Ten
     return torch.cat(parts, 0)
 
 
-def sample_images_sharded(generate_local, total: int):
+def sample_images_sharded(generate_local, total: int, sampler=None):
     """``generate_local(lo, hi)`` -> uint8 [hi-lo, C, H, W] on this rank's device; returns all ``total`` images
-    on every rank (rank order == sample order)."""
+    on every rank (rank order == sample order).
+
+    ``sampler``: the ``AbsorbingDiffusion`` that ``generate_local`` samples from.  When given, ``sampler.set_shard(lo, hi - lo)``
+    is called here, which is what makes the ranks one job ('global' noise layout: shared key, counters on the GLOBAL image index --
+    the images do not depend on the split).  Without it ``generate_local`` MUST call ``set_shard(lo, hi - lo)`` itself: a sampler
+    that never did draws per-rank noise (and warns)."""
     rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
     lo, hi = shard_range(total, rank, world)
+    if sampler is not None:
+        sampler.set_shard(lo, hi - lo)
     return gather_images(generate_local(lo, hi), total)
 
 
@@ -90,7 +97,7 @@ def global_token_checksum(tokens_local: torch.Tensor, first: int) -> int:
     """``token_checksum`` of the whole job: every rank contributes the partial sum of its shard (one int64 all-reduce, outside
     any timed region).  Reported as a non-negative 63-bit integer."""
     part = token_checksum(tokens_local, first)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():        # (also at one rank: the collective path is the tested path)
         dev = tokens_local.device if dist.get_backend() == "nccl" else "cpu"
         v = torch.tensor([part], dtype=torch.int64, device=dev)
         dist.all_reduce(v)          # int64 sums wrap: the sum mod 2^64 does not depend on the split

@@ -441,8 +441,11 @@ class ExactConvTrainFunction(torch.autograd.Function):
         stride, pad, transposed, out_pad, has_bias = ctx.cfg
         cout = int(weight.shape[1] if transposed else weight.shape[0])
         if (NATIVE_WGRAD and not transposed and not ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and stride == 1 and
-                pad == 1 and tuple(weight.shape[2:]) == (3, 3) and int(weight.shape[1]) <= 4 and x.dim() == 4):
-            # few input channels, dense input, no input gradient wanted: the denoiser's first layer (spk_conv3x3_wgrad_small)
+                pad == 1 and tuple(weight.shape[2:]) == (3, 3) and int(weight.shape[1]) <= 4 and x.dim() == 4 and
+                lib.spk_conv3x3_wgrad_small_ws_bytes(int(x.shape[0]), int(x.shape[2]), int(x.shape[3]), cout,
+                                                     int(weight.shape[1])) > 0):
+            # few input channels, dense input, no input gradient wanted: the denoiser's first layer (spk_conv3x3_wgrad_small:
+            # maps up to 8x8 -- larger ones answer the workspace query with -1 and take the framework's operator below)
             return (None,) + conv3x3_wgrad_small(grad_y, x, weight, has_bias and ctx.needs_input_grad[2]) + (None,) * 4
         gi, gw, gb = torch.ops.aten.convolution_backward(
             grad_y.contiguous(), x.contiguous(), weight, [cout], [stride, stride], [pad, pad], [1, 1], transposed,
@@ -462,6 +465,9 @@ def conv3x3_wgrad_small(grad_y, x, weight, want_bias):
     gw = torch.empty_like(weight, memory_format=torch.channels_last if cl else torch.contiguous_format)
     gb = torch.empty(Cout, dtype=torch.float32, device=gy.device) if want_bias else None
     nb = int(lib.spk_conv3x3_wgrad_small_ws_bytes(N, H, W, Cout, Cin))
+    if nb <= 0:
+        raise NotImplementedError(f"spk_conv3x3_wgrad_small: unsupported shape N={N} H={H} W={W} Cout={Cout} Cin={Cin} "
+                                  "(maps of at most 64 positions, at most 4 input channels)")
     ws = torch.empty(nb, dtype=torch.uint8, device=gy.device)
     with timed("train.conv_bwd_weight"):
         check(lib.spk_conv3x3_wgrad_small(_p(gy), _p(xin), _p(ws), nb, _p(gw), _p(gb), N, H, W, Cout, Cin, int(cl), _stream(gy)),

@@ -277,7 +277,9 @@ def cached_state(kind: str, cfg: PathConfig = MNIST, **kw) -> dict:
                     return True
                 except PermissionError:
                     pass
-            return time.time() - os.stat(lock).st_mtime > 300.0
+            # (a live owner touches its lock every 10 s -- see the heartbeat below -- so the age bound is independent of how
+            #  long a generation takes: 8 ranks calibrating on cores / 8 threads each can exceed any fixed bound)
+            return time.time() - os.stat(lock).st_mtime > 120.0
         except (OSError, ValueError):
             return False
 
@@ -288,6 +290,14 @@ def cached_state(kind: str, cfg: PathConfig = MNIST, **kw) -> dict:
             os.close(fd)
             return True
         except FileExistsError:
+            return False
+
+    def owns():
+        # after unlink + claim two waiters may have raced (one unlinking the other's fresh lock): the pid in the file decides
+        try:
+            with open(lock) as f:
+                return int(f.read().strip() or 0) == os.getpid()
+        except (OSError, ValueError):
             return False
     mine = claim()
     if not mine:
@@ -304,9 +314,28 @@ def cached_state(kind: str, cfg: PathConfig = MNIST, **kw) -> dict:
                     pass
                 mine = claim()
                 if mine:
+                    time.sleep(0.05)
+                    mine = owns()
+                if mine:
                     break
             time.sleep(0.2)
-    sd = fn(cfg, **kw)
+    stop = None
+    if mine:
+        import threading
+        stop = threading.Event()
+
+        def heartbeat():
+            while not stop.wait(10.0):
+                try:
+                    os.utime(lock, None)
+                except OSError:
+                    return
+        threading.Thread(target=heartbeat, daemon=True).start()
+    try:
+        sd = fn(cfg, **kw)
+    finally:
+        if stop is not None:
+            stop.set()
     tmp = f"{path}.{os.getpid()}.tmp"
     torch.save(sd, tmp)
     os.replace(tmp, path)

@@ -28,6 +28,8 @@ def main():
     ab = AbsorbingDiffusion(_Den(), mask_id=128)
     # 'global' noise layout (default): ONE key per job -- rank 0's draw, broadcast (ranks seeded differently here on purpose);
     # 'rank' layout: the rank folded into the key, distinct streams for ranks seeded alike
+    lo0, hi0 = sdist.shard_range(args.global_batch or args.batch or 256 * world, rank, world)
+    ab.set_shard(lo0, hi0 - lo0)                            # a shard of one job: the key broadcast is opt-in through set_shard
     torch.manual_seed(1000 + rank)
     key = torch.tensor([ab._philox_key()], dtype=torch.int64)
     keys = [torch.zeros_like(key) for _ in range(world)]

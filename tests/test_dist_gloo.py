@@ -50,7 +50,23 @@ def _worker(rank, world, port, total, q):
     # add up to the whole job's
     from snn_model.vq_diffusion import AbsorbingDiffusion, DummyModel
     ab = AbsorbingDiffusion(DummyModel(1, 128), mask_id=128)
-    ab.set_shard(lo, hi - lo)
+    # a sampler that never declared a shard takes NO collective inside a process group (rank 0 alone may call it: a preview
+    # during DDP training must not hang) and folds the rank into its key (ranks seeded alike still draw distinct images)
+    import warnings
+    torch.manual_seed(5)
+    with warnings.catch_warnings(record=True) as wrn:
+        warnings.simplefilter("always")
+        if rank == 0:
+            ab._philox_key()                                 # only rank 0: would block forever if it were a broadcast
+        torch.manual_seed(5)
+        k_un = ab._philox_key()
+    ok = ok and any("set_shard" in str(x.message) for x in wrn)
+    kun = [None] * world
+    dist.all_gather_object(kun, k_un)
+    ok = ok and len(set(kun)) == world
+    # sample_images_sharded(..., sampler=ab) declares the shard itself
+    sdist.sample_images_sharded(lambda a, b: _fake_images(a, b), total, sampler=ab)
+    ok = ok and ab._shard_set and ab.global_first == lo and ab.n_samples == hi - lo
     torch.manual_seed(100 + rank)
     key = ab._philox_key()
     keys = [None] * world

@@ -1109,6 +1109,26 @@ def test_spike_conv_train_forward_exact_and_library_backward(dev, ops, B, cin, c
         assert _rel_l2(got.cpu(), want) <= 1e-5, _rel_l2(got.cpu(), want)
 
 
+@pytest.mark.parametrize("hw,cin", [((28, 28), 1), ((32, 32), 3), ((7, 7), 2), ((8, 8), 4)])
+def test_exact_conv_train_backward_small_cin_any_map_size(dev, ops, hw, cin):
+    """ops.ExactConvTrainFunction.backward sends 3x3 / s1 / p1 layers with <= 4 input channels and no input gradient
+    to spk_conv3x3_wgrad_small, whose maps hold at most 64 positions (the denoiser's first layer).  A generic first layer on a
+    28x28 or 32x32 input answers the workspace query with -1: it must take the framework's operator, not crash."""
+    g = torch.Generator().manual_seed(hw[0] * 10 + cin)
+    x = torch.randn(6, cin, *hw, generator=g)
+    w = torch.randn(16, cin, 3, 3, generator=g) * 0.2
+    b = torch.randn(16, generator=g) * 0.1
+    gy = torch.randn(6, 16, *hw, generator=g)
+    wo, bo = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    (torch.nn.functional.conv2d(x.double(), wo, bo, 1, 1) * gy.double()).sum().backward()
+    small = ops.lib.spk_conv3x3_wgrad_small_ws_bytes(6, hw[0], hw[1], 16, cin) > 0
+    assert small == (hw[0] * hw[1] <= 64)
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = ops.ExactConvTrainFunction.apply(x.to(dev), wd, bd, 1, 1, False, 0)
+    (y * gy.to(dev)).sum().backward()
+    assert _rel_l2(wd.grad.cpu().double(), wo.grad) <= 1e-5 and _rel_l2(bd.grad.cpu().double(), bo.grad) <= 1e-5
+
+
 @pytest.mark.parametrize("B,K,hw", [(4, 128, (7, 7)), (3, 128, (8, 8)), (2, 10, (3, 5))])
 def test_masked_ce_vs_torch(dev, ops, B, K, hw):
     """spk_masked_ce: cross-entropy with ignore_index=-1 and its gradient, against torch's F.cross_entropy on CPU
