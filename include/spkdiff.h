@@ -58,6 +58,8 @@ const char* spk_error_string(int code);
  *   "v2_waves"            8     waves per workgroup of spk_den_conv3x3_mfma_fp6v2's main launch: 8 (two per SIMD), 4 (one), 12
  *                               (three, accumulators in VGPRs: measured -11 %)
  *   "v2_lag"              0     1: full 7x7 batches run the staggered form (waves 4..7 one chunk behind: measured 4-13 % slower)
+ *   "v2_duo"              1     full 7x7 batches: two independent four-wave workgroups per CU on half-image items (one workgroup's
+ *                               LIF scan runs beside the other's MFMAs); 0: one eight-wave workgroup per CU (rounds 2-4)
  *   "fp6_waves"           4     8: spk_den_conv3x3_mfma_fp6 with two waves per SIMD where an item has <= 4 row tiles per wave
  *   "fp6_xcd_walk"        1     0: image-major item walk of spk_den_conv3x3_mfma_fp6 (2.2x the HBM-side traffic)
  *   "conv6_shared"        1     0: spk_den_conv3x3_counts_mfma never shares operands through LDS
@@ -280,7 +282,8 @@ int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, c
  * scale / bias [Cout] as for the fp6 kernel, wl1 [Cout] = L1 norm of each channel's quantised weights, and qtab = the
  * quantised weights themselves as int32 [Cout][9][Cin] (read by the exact recomputation).  flag_words: zero-initialised
  * u32 workspace of spk_den_fp6v2_flag_words(B, Cout, H, W) words (counter, ticket, id list, overflow bitmap); it is clean
- * again when the call's launches have run (word 1 keeps the number of neurons the call flagged, for statistics).  One
+ * again when the call's launches have run (word 1 keeps the number of neurons the call flagged, for statistics; the last 2048
+ * words are per-CU arrival counters of the two-workgroups-per-CU launch form, of which only the parity is read: never reset).  One
  * workspace per stream: two calls in flight at once must not share it.
  * SPK_ERR_UNSUPPORTED unless T == 16, H == W == 7 or 8, Cout % 32 == 0 (Cin = 32 * nch). */
 long long spk_den_packed_weight_fp6v2_bytes(int Cout, int Cin);

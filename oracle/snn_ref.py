@@ -523,12 +523,13 @@ def p_sample_step(x_t, unmasked, logits_bhwk, t, temp=1.0, u=None, q=None):
 
 
 def absorbing_sample(sd, n_samples, mask_id, temp=1.0, sample_steps=49, latent=7, T=16,
-                     noise=None, record=None):
+                     noise=None, record=None, exact_conv=False):
     """AbsorbingDiffusion.sample, R/snn_model/vq_diffusion.py:103-142 (device literal dropped).
 
     RNG consumption order per step (probe-verified): B*h*w uniforms, then
     B*h*w*K exponentials, both from the global CPU generator unless ``noise`` (a callable
-    step -> (u, q)) injects them.  ``record`` (a list) receives (t, x_t, unmasked, logits)."""
+    step -> (u, q)) injects them.  ``record`` (a list) receives (t, x_t, unmasked, logits).
+    ``exact_conv``: the denoiser's convolutions as correctly rounded exact dot products (``denoiser_forward``)."""
     b = int(n_samples)
     x_t = torch.ones(b, 1, latent, latent).long() * mask_id
     unmasked = torch.zeros_like(x_t).bool()
@@ -538,7 +539,7 @@ def absorbing_sample(sd, n_samples, mask_id, temp=1.0, sample_steps=49, latent=7
             u = torch.rand_like(x_t.float())          # drawn BEFORE the denoiser call (:116)
         else:
             u, q_inj = noise(t)
-        logits = denoiser_forward(x_t.float(), tt, sd, T).permute(0, 2, 3, 1)
+        logits = denoiser_forward(x_t.float(), tt, sd, T, exact_conv=exact_conv).permute(0, 2, 3, 1)
         x_t, unmasked = p_sample_step(x_t, unmasked, logits, t, temp, u, None if noise is None else q_inj)
         if record is not None:
             record.append((t, x_t.clone(), unmasked.clone(), logits.clone()))

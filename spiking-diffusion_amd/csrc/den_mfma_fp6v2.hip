@@ -79,6 +79,9 @@ struct V2Args {
   const uint8_t* need; const int* cls_cnt; const int* cls_list;
   int B, Cout, Cin;
   int gx, nsets;                             // XCD-aware walk (gx > 0) or flat walk (gx == 0)
+  unsigned long long* dbg_out;               // (-DSPK_V2_DUO_DBG builds: per-workgroup time stamps; otherwise null)
+  unsigned* cu_slots;                        // duo form: one arrival counter per CU (2048 words behind the ticket)
+  int duo_delay;                             // duo form: head start of a CU's first workgroup over its second, in 10 ns ticks (0: none)
 };
 
 #ifndef SPK_FP6_PRE
@@ -787,6 +790,359 @@ __device__ __forceinline__ void fp6v2_handover(const V2Args& a) {
       a.flags[a.ticket_idx] = 0u;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------ two workgroups per CU ("duo", round 5)
+// The eight waves of the form above share every chunk barrier, so both waves of a SIMD reach an item's LIF scan together and the
+// matrix pipe idles for its whole length (mfma_coexec_fraction_of_busy 0.024, 16 % of the reverse process); a wave that scans
+// alone issues a vector instruction every ~6 cycles whatever its partner does, and one wave's vector instructions are free beside
+// the other wave's MFMAs (tools/coexec_probe.hip, rows M|V).  What couples the two waves is the barrier, not the hardware.  Here a
+// CU runs TWO INDEPENDENT WORKGROUPS of four waves (one per SIMD each, 256 registers): each has its own barriers, its own LDS and
+// its own item stream, so while one scans (or waits at a barrier, or for a copy) the other's MFMAs have the pipe to themselves --
+// and once the two are half an item apart they stay there: each period a workgroup spends T_scan alone on the vector unit while
+// its partner runs MFMAs at the full rate (see fp6v2_duo_phase for how they get apart).
+//   * Item = HALF an image (positions 0..23 or 24..47 = 12 row tiles, three per wave: today's register budget) x 32 output
+//     channels; the 49th position stays the tail launch's.  A half needs five input rows (0..4 / 2..6): one zero-bordered LDS image
+//     of 7 x 8 + 1 cells serves both halves (row 0 / row 6 are the true border of the top / bottom half).
+//   * LDS per workgroup must stay under 80 KB.  The two image buffers take 29 KB; a double-buffered 27 KB weight slab does not fit
+//     beside them.  A chunk's weight tiles are consumed tap by tap and never re-read, so they live in a RING of NSLOT thirds (three
+//     taps = six tiles = 9 KB): a chunk is three STAGES of 18 MFMAs per wave, one barrier each; during stage n the copy engine
+//     fills the slot stage n - 1 released with the third of stage n + NSLOT - 1 (NSLOT = 4: 71 KB per workgroup).
+//   * Copies complete in issue order per wave, so a stage's barrier waits with s_waitcnt vmcnt(K): everything but the pieces of
+//     the last two stages (K = the smallest count over the four waves' piece shares: waves with more pieces wait for a little more
+//     than they must).  The image slab of the next chunk is issued in stage 0 only (three stages before its first use).  The
+//     epilogue's stores share the counter and may retire out of order with the copies: the first barrier of every item drains it.
+#ifndef SPK_V2_DUO_SLOTS
+#define SPK_V2_DUO_SLOTS 4
+#endif
+#ifndef SPK_V2_DUO_DBG
+#define SPK_V2_DUO_DBG 0        // 1: every workgroup stamps s_memrealtime at the start of each item's K loop and of its scan into a.dbg_out
+#endif
+constexpr int DUO_NSLOT = SPK_V2_DUO_SLOTS;
+constexpr int DUO_W3 = 6 * WT;                            // one third of a chunk's weight tiles: three taps x two digit pairs
+constexpr int DUO_HIN = 5, DUO_HWB = 24;
+constexpr int DUO_NPP = (DUO_HIN + 2) * 8 + 1;            // (7x7: pitch W + 1 = 8)
+constexpr int DUO_A_BYTES = DUO_NPP * POSB;
+constexpr size_t DUO_LDS = 2 * (size_t)DUO_A_BYTES + (size_t)DUO_NSLOT * DUO_W3 + (size_t)(DUO_NPP * 16 + (DUO_HWB + 1) * 16 + DUO_HWB + 1) * 4;
+static_assert(DUO_LDS <= 80 * 1024, "two workgroups per CU");
+
+template <int H, int W>
+__device__ __forceinline__ void fp6v2_body_duo(const V2Args& a, const int g, const int il, const int lanes, const int n_images) {
+  static_assert(H == 7 && W == 7 && !USE_D4 && N_MM == N_PAIR, "7x7 latents, four-digit form");
+  constexpr int NWV = 4, NT = 3, HW = H * W, PW = W + 1;
+  constexpr int HWb = DUO_HWB, Hin = DUO_HIN, NPP = DUO_NPP, A_BYTES = DUO_A_BYTES;
+  constexpr int PPR = (W + 3) / 4, NA = Hin * PPR;     // ten image pieces per chunk
+  constexpr int NSLOT = DUO_NSLOT, W3 = DUO_W3;
+  static_assert(W3 == 9 * 1024 && NA == 10 && (NSLOT == 4 || NSLOT == 5), "piece shares below");
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  uint8_t* const sA = lds;
+  uint8_t* const sW = lds + 2 * A_BYTES;
+  int* const s_cin = reinterpret_cast<int*>(lds + 2 * A_BYTES + NSLOT * W3);        // [NPP][16]
+  int* const s_row = s_cin + NPP * 16;                                               // [HWb + 1][16]
+  int* const s_nmax = s_row + (HWb + 1) * 16;                                        // [HWb + 1]
+  const unsigned sA_addr = spk_lds_addr(sA), sW_addr = sA_addr + 2 * A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nch = a.nch;
+  const int G = a.Cout >> 5;
+  for (int i = tid; i < 2 * A_BYTES / 16; i += NWV * 64) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < NPP * 16; i += NWV * 64) s_cin[i] = 0;
+  __syncthreads();
+
+  const int row = lane & 31, half = lane >> 5;
+  const int hsel = (row >> 2) & 1, tt = (row & 3) + 4 * (row >> 3);
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  // image pieces of this wave: ids wave, wave + 4 and (waves 2, 3) 8 + wave - 2; weight pieces of a third: wave, wave + 4 and
+  // (wave 0) 8.  Shares per stage (waves 0..3): stage 0: 5 4 5 5, stages 1 and 2: 3 2 2 2.
+  unsigned pa_pk[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    int id = j < 2 ? wave_s + 4 * j : 8 + (wave_s & 1);
+    const int y = id / PPR, px = id - y * PPR;
+    const int np = (W - 4 * px) < 4 ? (W - 4 * px) : 4;
+    const unsigned src = (unsigned)((y * W + 4 * px) * POSB), dst = (unsigned)(((y + 1) * PW + 1 + 4 * px) * POSB);
+    pa_pk[j] = src | (dst << 14) | ((unsigned)(np - 1) << 29);
+  }
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto issue_A = [&](int q, const uint8_t* aslab, unsigned dA) {
+    if (q == 2 && wave_s < 2) return;
+    const unsigned pk = pa_pk[q];
+    const unsigned np = ((pk >> 29) & 3u) + 1u;
+    const unsigned long long mask = np == 4 ? ~0ull : ((1ull << (16 * np)) - 1ull);
+    spk_dma16s_masked(aslab + (pk & 0x3fffu), lane16, dA + ((pk >> 14) & 0x7fffu), mask);
+  };
+  auto issue_W = [&](int q, const uint8_t* wthird, unsigned dW) {
+    if (q == 2 && wave_s != 0) return;
+    const unsigned ko = ((unsigned)wave_s + 4u * (unsigned)q) * 1024u;
+    spk_dma16s(wthird + ko, lane16, dW + ko);
+  };
+  const uint8_t* const wbase = a.wq + (long long)g * nch * W_SLAB;
+  // item -> (image, half); the slab of the bottom half starts two rows into the image
+  auto aslab_of = [&](int itm, int c) -> const uint8_t* {
+    return a.in0 + ((long long)(itm >> 1) * nch + c) * HW * POSB + (itm & 1) * 2 * W * POSB;
+  };
+  const int nitems = 2 * n_images;
+
+  const int co = g * 32 + (lane & 31);
+  const float scale_f = (float)a.scale[co], bias_f = (float)a.bias[co];
+  const float bna = a.bn_a[co], bnb = a.bn_b[co];
+  const float Bc = fmaf(bias_f, bna, bnb);
+  const float cE = 2.0f * 2.38418579e-07f * (fabsf(bnb) + fabsf(Bc)) + 1e-30f;
+  const float cT = 528.0f * scale_f * fabsf(bna) * 1.000001f;
+  const float Ac4 = 1024.0f * scale_f * bna;
+  const int sc_a = 0x7f7f7f7f;
+  const int sc_p = half ? (int)0x82828282u : (int)0x87878787u;
+
+  // input records (cell, step) of an item counted by this thread, chunk by chunk
+  constexpr int NREC = Hin * W * 16, NR = (NREC + NWV * 64 - 1) / (NWV * 64);
+  int rec_off[NR];
+  bool rec_ok[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const int r = tid + k * NWV * 64;
+    const int cl = r >> 4, t = r & 15;
+    rec_ok[k] = r < NREC;
+    rec_off[k] = rec_ok[k] ? (((cl / W) + 1) * PW + 1 + (cl % W)) * POSB + t * 16 : 0;
+  }
+
+  int it = 0;                                             // running chunk counter: image buffer it & 1, stage number 3 it + st
+  if (il < nitems) {
+    const uint8_t* as0 = aslab_of(il, 0);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) issue_A(q, as0, sA_addr);
+#pragma unroll
+    for (int st = 0; st < 3; ++st)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) issue_W(q, wbase + st * W3, sW_addr + st * W3);
+  }
+  for (int itm = il; itm < nitems; itm += lanes) {
+    const int b = itm >> 1, hid = itm & 1;
+    int a_off[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int p = 2 * (wave + NWV * i) + hsel + hid * HWb;
+      a_off[i] = (((p / W) - 2 * hid) * PW + (p % W)) * POSB + tt * 16;
+    }
+    if (SPK_V2_DUO_DBG && tid == 0 && a.dbg_out) a.dbg_out[(long long)blockIdx.x * 64 + 2 * ((itm - il) / lanes)] = __builtin_amdgcn_s_memrealtime();
+    v16f acc[NT][NACC];
+    int creg[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) creg[k] = 0;
+    for (int c = 0; c < nch; ++c, ++it) {
+      const int buf = it & 1;
+      int nb = itm, nc = c + 1;
+      if (nc == nch) { nc = 0; nb = itm + lanes; }
+      const bool have_next = nb < nitems;                 // otherwise the last chunk is copied once more (never read)
+      const uint8_t* n_aslab = aslab_of(have_next ? nb : itm, have_next ? nc : c);
+      const uint8_t* n_wslab = wbase + (long long)(have_next ? nc : c) * W_SLAB;
+      const unsigned n_dA = sA_addr + (buf ^ 1) * A_BYTES;
+      const int n3 = 3 * it;
+      v4i rvq[NR];
+      auto compute = [&](auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const uint8_t* A = sA + buf * A_BYTES;
+        auto toff = [](int tap) constexpr -> int { return ((tap / 3) * PW + (tap % 3)) * POSB; };
+        auto lda = [&](auto s_tag) -> v4i {
+          constexpr int s = decltype(s_tag)::value;
+          return *reinterpret_cast<const v4i*>(A + a_off[s % NT] + toff(s / NT));
+        };
+        const uint8_t* Wb = sW;                            // (set at every stage barrier)
+        auto ldb = [&](int tile) -> v6i {
+          const uint8_t* p = Wb + tile * WT;
+          const v4i x = *reinterpret_cast<const v4i*>(p + lane * 16);
+          typedef const volatile __attribute__((address_space(3))) v2i* lds_v2i_ptr;
+          const v2i y = *(lds_v2i_ptr)SPK_LDS(p + 1024 + lane * 8);
+          const v6i r = {x[0], x[1], x[2], x[3], y[0], y[1]};
+          return r;
+        };
+        v6i bp[2][2];
+        constexpr int PF = 4, NSTEP = 9 * NT;
+        v4i af[PF];
+        static_for<NSTEP>([&](auto s_tag) {
+          constexpr int s = decltype(s_tag)::value;
+          constexpr int tap = s / NT, i = s % NT, st = tap / 3, ss = s % (3 * NT);        // ss: step within the stage
+          if constexpr (ss == 0) {
+            // stage barrier: this stage's third (issued three stages ago) and, at stage 0, the chunk's image slab have landed
+            if constexpr (FIRST && st == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            else if constexpr (st == 0) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+            const int slot = NSLOT == 4 ? ((n3 + st) & 3) : ((n3 + st) % NSLOT);
+            Wb = sW + slot * W3;
+            bp[tap & 1][0] = ldb(0); bp[tap & 1][1] = ldb(1);
+            if constexpr (st == 0) static_for<PF>([&](auto p_tag) { af[decltype(p_tag)::value] = lda(p_tag); });
+          }
+          const v4i av = af[s % PF];
+          if constexpr (s + PF < NSTEP) af[s % PF] = lda(std::integral_constant<int, s + PF>{});
+          if constexpr (FIRST && tap == 0) SPK_MFMA2_Z("v", acc[i][0], av, bp[0][0], sc_a, sc_p);
+          else SPK_MFMA2("v", acc[i][0], av, bp[tap & 1][0], sc_a, sc_p);
+          __builtin_amdgcn_sched_barrier(0);
+          // copies of this stage: the third of stage n + NSLOT - 1 into the slot stage n - 1 released; stage 0: the next chunk's image
+          if constexpr (ss < 3) {
+            const int dslot = NSLOT == 4 ? ((n3 + st + 3) & 3) : ((n3 + st + NSLOT - 1) % NSLOT);
+            // (NSLOT == 4: the third belongs to the NEXT chunk, same stage index)
+            issue_W(ss, n_wslab + st * W3, sW_addr + dslot * W3);
+          } else if constexpr (st == 0 && ss < 6) {
+            issue_A(ss - 3, n_aslab, n_dA);
+          }
+          if constexpr (i == 0 && (tap % 3) != 2) {
+            bp[(tap + 1) & 1][0] = ldb(2 * ((tap + 1) % 3));
+            bp[(tap + 1) & 1][1] = ldb(2 * ((tap + 1) % 3) + 1);
+          }
+          if constexpr (s == 1) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k) rvq[k] = *reinterpret_cast<const v4i*>(sA + buf * A_BYTES + rec_off[k]);
+          }
+          if constexpr (s == 7) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k)
+              creg[k] += __builtin_popcount((unsigned)rvq[k][0]) + __builtin_popcount((unsigned)rvq[k][1]) +
+                         __builtin_popcount((unsigned)rvq[k][2]) + __builtin_popcount((unsigned)rvq[k][3]);
+          }
+          if constexpr (FIRST && tap == 0) SPK_MFMA2_Z("v", acc[i][1], av, bp[0][1], sc_a, sc_p);
+          else SPK_MFMA2("v", acc[i][1], av, bp[tap & 1][1], sc_a, sc_p);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      };
+      if (c == 0) compute(std::true_type{}); else compute(std::false_type{});
+    }   // chunks
+
+    if (SPK_V2_DUO_DBG && tid == 0 && a.dbg_out) a.dbg_out[(long long)blockIdx.x * 64 + 2 * ((itm - il) / lanes) + 1] = __builtin_amdgcn_s_memrealtime();
+    // publish the record counts, then add the nine taps of every output position: s_row[p][t] = active inputs of row (p, t)
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+      if (rec_ok[k]) s_cin[(rec_off[k] / POSB) * 16 + ((rec_off[k] % POSB) >> 4)] = creg[k];
+    if (tid <= HWb) s_nmax[tid] = 0;
+    __syncthreads();
+    for (int e = tid; e < HWb * 16; e += NWV * 64) {
+      const int pp = e >> 4, t = e & 15;
+      const int p = pp + hid * HWb;
+      const int* c0 = s_cin + (((p / W) - 2 * hid) * PW + (p % W)) * 16 + t;
+      int sum = 0;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) sum += c0[(dy * PW + dx) * 16];
+      s_row[e] = sum;
+      atomicMax(&s_nmax[pp], sum);
+    }
+    __syncthreads();
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (SPK_V2_DBG & 4) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) sacc += acc[i][j][0];
+      if (sacc == 12345.f) a.out[0] = 1;
+      continue;
+    }
+    // ---------------- epilogue: the four-digit scan of fp6v2_body (fp32 recombination, BN, LIF, certification in two stages)
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      const int i = k == 0 ? NT - 1 : k - 1;
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      float v = 0.f, zmax = 0.f, dmin = 3.0e38f;
+      unsigned mybits = 0;
+      const int pp = 2 * (wave + NWV * i) + half;          // position within the item
+      const int nmax = s_nmax[pp];
+#pragma unroll
+      for (int r2 = 0; r2 < 16; r2 += 2) {
+        const v2f p0 = {acc[i][0][r2], acc[i][0][r2 + 1]}, p1 = {acc[i][1][r2], acc[i][1][r2 + 1]};
+        const v2f q4 = __builtin_elementwise_fma(p0, (v2f){1024.0f, 1024.0f}, p1);
+        const v2f z2 = __builtin_elementwise_fma(q4, (v2f){Ac4, Ac4}, (v2f){Bc, Bc});
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float z = z2[e];
+          zmax = fmaxf(zmax, fabsf(z));
+          const float h = fmaf(z - v, 0.5f, v);
+          const float hm = h - 1.0f;
+          dmin = fminf(dmin, fabsf(hm));
+          v = h >= 1.0f ? 0.0f : h;
+          mybits = __builtin_amdgcn_alignbit(mybits, __float_as_uint(hm), 31);
+        }
+      }
+      mybits = ~(__builtin_bitreverse32(mybits) >> 16) & 0xffffu;
+      bool flg = dmin <= SPK_V2_SPARE * fmaf(zmax, 2.5f * CERT_4EPS, fmaf((float)nmax, cT, cE));
+      if (SPK_V2_STAGE2 && __builtin_amdgcn_ballot_w64(flg) != 0ull) {
+        float v2 = 0.f, dh = 0.f;
+        bool f2 = false;
+        int cntv[16];
+        const v4i* rp = reinterpret_cast<const v4i*>(s_row + pp * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const v4i c4 = rp[q];
+          cntv[4 * q] = c4[0]; cntv[4 * q + 1] = c4[1]; cntv[4 * q + 2] = c4[2]; cntv[4 * q + 3] = c4[3];
+        }
+#pragma unroll
+        for (int r2 = 0; r2 < 16; r2 += 2) {
+          const v2f p0 = {acc[i][0][r2], acc[i][0][r2 + 1]}, p1 = {acc[i][1][r2], acc[i][1][r2 + 1]};
+          const v2f q4 = __builtin_elementwise_fma(p0, (v2f){1024.0f, 1024.0f}, p1);
+          const v2f z2 = __builtin_elementwise_fma(q4, (v2f){Ac4, Ac4}, (v2f){Bc, Bc});
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float z = z2[e];
+            const float ct = fmaf((float)cntv[r2 + e], cT, cE);
+            dh = fmaf(fabsf(z) + fabsf(v2), 0.625f * CERT_4EPS, fmaf(dh, 0.5f, 0.5f * ct));
+            const float h = fmaf(z - v2, 0.5f, v2);
+            f2 = f2 || (fabsf(h - 1.0f) <= SPK_V2_SPARE * dh);
+            v2 = h >= 1.0f ? 0.0f : h;
+          }
+        }
+        flg = flg && f2;
+      }
+      const int p = pp + hid * HWb;
+      if (flg && !(SPK_V2_DBG & 32)) {
+        const long long n = ((long long)b * a.Cout + co) * HW + p;
+        const unsigned idx = atomicAdd(a.flags, 1u);
+        if (idx < a.flag_cap) a.flags[2 + idx] = (unsigned)n;
+        else atomicOr(a.flags + 2 + a.flag_cap + (n >> 5), 1u << (n & 31));
+      }
+      const long long rec = (((long long)b * G + g) * HW + p) * POSB;
+      store_tile_spikes(a.out, a.out_cnt, mybits, lane, rec, (((long long)b * G + g) * HW + p) * 32, true);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }   // items
+  spk_dma_wait_all();
+}
+
+// Getting the two workgroups of a CU half an item apart.  Left alone they start together and STAY together: two scans that overlap
+// pull each other in (the lag halves with every item), whereas two that do not overlap keep their distance (each gets T_scan of
+// the pipe to itself per period, whatever the lag).  So the SECOND workgroup to arrive on a CU waits `duo_delay` ticks before its
+// first item -- during which the first one has the matrix pipe to itself, so nothing idles -- and from then on the pair is
+// stable.  Arrival order: one counter per CU (keyed by XCC / SE / SH / CU id from the hardware registers), never reset: any two
+// consecutive arrivals on a CU differ in parity, whatever earlier launches left in the counter.
+constexpr int DUO_CU_SLOTS = 2048;
+__device__ __forceinline__ void fp6v2_duo_phase(const V2Args& a) {
+  if (a.duo_delay <= 0 && !SPK_V2_DUO_DBG) return;
+  __shared__ int s_late;
+  if (threadIdx.x == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned key = (((xcc & 7u) * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u + ((hw >> 8) & 15u);
+    s_late = (int)(atomicAdd(a.cu_slots + key, 1u) & 1u);
+    if (SPK_V2_DUO_DBG && a.dbg_out) {
+      a.dbg_out[(long long)blockIdx.x * 64 + 62] = key;
+      a.dbg_out[(long long)blockIdx.x * 64 + 63] = (unsigned long long)s_late;
+    }
+    if (a.duo_delay <= 0) s_late = 0;
+  }
+  __syncthreads();
+  if (s_late) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)a.duo_delay) __builtin_amdgcn_s_sleep(16);
+  }
+}
+
+// HIP's second launch-bound argument is the minimum number of waves per execution unit: two -> 256 registers, and with
+// <= 80 KB of LDS two of these workgroups share a CU.
+template <int H, int W>
+__global__ __launch_bounds__(256, 2) void conv3x3_fp6v2_duo_kernel(V2Args a) {
+  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
+  int g, il, lanes;
+  fp6v2_wg_map(a, g, il, lanes);
+  fp6v2_duo_phase(a);
+  fp6v2_body_duo<H, W>(a, g, il, lanes, Bn);
+  fp6v2_handover(a);
 }
 
 // ------------------------------------------------------------------------------------------------ staggered form (experiment)
@@ -1554,7 +1910,7 @@ constexpr unsigned FLAG_CAP = 1u << 20;        // list capacity; beyond it flagg
 
 extern "C" long long spk_den_fp6v2_flag_words(int B, int Cout, int H, int W) {
   if (B <= 0 || Cout <= 0 || H <= 0 || W <= 0) return -1;
-  return 2 + (long long)FLAG_CAP + ((long long)B * Cout * H * W + 31) / 32 + 1;
+  return 2 + (long long)FLAG_CAP + ((long long)B * Cout * H * W + 31) / 32 + 1 + DUO_CU_SLOTS;   // (+ ticket, + the duo form's CU counters)
 }
 
 static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale, const double* bias_d,
@@ -1572,6 +1928,7 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   a.in0 = in_s32; a.nch = nch; a.wq = wq; a.scale = scale; a.bias = bias_d; a.wl1 = wl1; a.qtab = qtab;
   a.bn_a = bn_a; a.bn_b = bn_b; a.out = out_s32; a.out_cnt = out_counts; a.flags = flag_words; a.flag_cap = FLAG_CAP;
   a.n_dyn = n_dyn_or_null;
+  a.dbg_out = nullptr; a.cu_slots = nullptr; a.duo_delay = 0;
   a.need = nullptr; a.cls_cnt = nullptr; a.cls_list = nullptr;
   if (need) {
     a.need = need + spk_need_off_rec(B, need_R, need_r);
@@ -1584,14 +1941,19 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   // XCD-aware walk: the largest power-of-two group count per XCD whose packed weights fit ~1.5 MB of its 4 MB L2
   int grid = 0;
   a.gx = 0; a.nsets = 1;
-  if ((cus & 7) == 0) {
-    const int S = cus / 8;
+  // (wgs: workgroups of the launch -- one per CU, or two for the duo form; returns the grid, 0 if the XCD-aware walk does not fit)
+  auto xcd_walk = [&](V2Args& v, int wgs) -> int {
+    v.gx = 0; v.nsets = 1;
+    if ((wgs & 7) != 0) return 0;
+    const int S = wgs / 8;
     int gx = 1;
     while (gx * 2 <= G && gx * 2 <= S && (long long)gx * 2 * nch * W_SLAB <= 1536 * 1024) gx *= 2;
     while (G / gx > 8 && gx * 2 <= G && gx * 2 <= S) gx *= 2;
     const int nsets = G / gx;
-    if (G % gx == 0 && nsets <= 8 && 8 % nsets == 0 && S % gx == 0) { a.gx = gx; a.nsets = nsets; grid = cus; }
-  }
+    if (G % gx == 0 && nsets <= 8 && 8 % nsets == 0 && S % gx == 0) { v.gx = gx; v.nsets = nsets; return wgs; }
+    return 0;
+  };
+  grid = xcd_walk(a, cus);
   if (a.gx == 0) grid = cus >= G ? (cus / G) * G : G;         // flat walk: workgroup k -> group k % G
   const int a_bytes = bands ? ((8 / 2 + 1 + 2) * 9 + 1) * POSB : ((7 + 2) * 8 + 1) * POSB;
   // (+ the active-input counters of the four-digit form: s_cin [cells][16], s_row [positions + 1][16])
@@ -1640,6 +2002,18 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
     if (grid / G < 6) return SPK_ERR_UNSUPPORTED;           // one image lane per tile-count class at least
     if (eight) hipLaunchKernelGGL((conv3x3_fp6v2_listed_kernel<7, 7, 8>), dim3(grid), dim3(512), lds, stream, a);
     else hipLaunchKernelGGL((conv3x3_fp6v2_listed_kernel<7, 7, 4>), dim3(grid), dim3(256), lds, stream, a);
+  } else if (eight && !lag_form && !twelve && spk_opt(SPK_OPT_V2_DUO) != 0 && (long long)DUO_LDS <= spk_lds_limit()) {
+    // round 5: two independent four-wave workgroups per CU on half-image items (fp6v2_body_duo)
+    V2Args ad = a;
+    ad.cu_slots = flag_words + a.ticket_idx + 1;
+    // v2_duo: 1 = half an item of head start for a CU's first workgroup (one wave alone: nch chunks x 54 MFMAs x ~35 cycles at
+    // ~2 GHz ~ nch x 95 ticks of 10 ns), 2 = none (the pair starts together), >= 16: that many ticks per chunk
+    const int dmode = spk_opt(SPK_OPT_V2_DUO);
+    ad.duo_delay = dmode == 2 ? 0 : (dmode >= 16 ? dmode : 95) * nch;
+    if (SPK_V2_DUO_DBG) ad.dbg_out = reinterpret_cast<unsigned long long*>(flag_words + 2 + FLAG_CAP / 2);   // (upper half of the id list)
+    int grid2 = xcd_walk(ad, 2 * cus);
+    if (grid2 == 0) grid2 = 2 * cus >= G ? (2 * cus / G) * G : G;
+    hipLaunchKernelGGL((conv3x3_fp6v2_duo_kernel<7, 7>), dim3(grid2), dim3(256), DUO_LDS, stream, ad);
   } else if (eight && lag_form) {
     // (staggered experiment: three ring slots + counters + one 128-byte line per wave)
     const size_t lds3 = 3 * ((size_t)a_bytes + W_LDS) + (size_t)(a_bytes / POSB) * 64 + 8 * 128;

@@ -571,9 +571,56 @@ def test_fp6v2_kernel_bit_equal_to_the_exact_kernels(dev, ops, B, hw):
             assert 0.001 < float(s1.mean()) < 0.9
     torch.cuda.synchronize()
     cap = 1 << 20                                  # id-list capacity (FLAG_CAP): [count, ticket, ids..., overflow bitmap]
-    assert all(int(v[0]) == 0 and int(v[2 + cap:].abs().sum()) == 0 for k, v in ops._FLAG_DEFAULT.items() if k[0] == "den"), \
+    # (the last 2048 words are the duo form's per-CU arrival counters: never reset by design, only their parity is read)
+    assert all(int(v[0]) == 0 and int(v[2 + cap:-2048].abs().sum()) == 0 for k, v in ops._FLAG_DEFAULT.items() if k[0] == "den"), \
         "live counter, overflow bitmap and hand-over ticket come back clean"
     parity(f"fp6v2_vs_fp6_B{B}_{hw}x{hw}", neuron_steps=total, spike_mismatches=mism)
+
+
+@pytest.mark.parametrize("B", [1, 5, 64, 256])
+def test_fp6v2_duo_form_bit_equal_to_the_one_workgroup_form(dev, ops, B):
+    """Round 5: full 7x7 batches run two independent four-wave workgroups per CU on half-image items (fp6v2_body_duo: weight thirds
+    in a ring, counted s_waitcnt, per-CU arrival parity + head start).  Same arithmetic, another schedule: every layer shape, with
+    the head start (v2_duo = 1), without it (2) and with a long one (400 ticks per chunk), must give the spikes AND the spike counts
+    of the one-workgroup form (v2_duo = 0) bit for bit -- also through the active-set path (a device-side image count below B)."""
+    from spkdiff import _lib
+    g = torch.Generator().manual_seed(500 + B)
+    prev = _lib.get_option("v2_duo")
+    total = 0
+    try:
+        for Cout, Cin in ((128, 64), (256, 128), (512, 256), (256, 512)):
+            w = ((torch.rand(Cout, Cin, 3, 3, generator=g) - 0.5) * 0.05).to(dev)
+            bias = ((torch.rand(Cout, generator=g) - 0.5) * 0.1).to(dev)
+            x = (torch.rand(16, B, Cin, 7, 7, generator=g) < 0.05).float().to(dev)
+            a = (torch.rand(Cout, generator=g) * 8 + 2).to(dev)
+            b = (torch.rand(Cout, generator=g) * 0.8).to(dev)
+            pk, xs = ops.den_pack_weight_fp6v2(w, bias), ops.spikes_to_s32(x)
+            outs = {}
+            for mode in (0, 1, 2, 400):
+                _lib.set_option("v2_duo", mode)
+                for rep in range(2):                          # (twice: the ring / arrival counters carry over between launches)
+                    o, c = ops.den_conv3x3_mfma_fp6v2(xs, pk, Cout, bn_a=a, bn_b=b, want_counts=True)
+                outs[mode] = (o.clone(), c.clone())
+            for mode in (1, 2, 400):
+                assert torch.equal(outs[mode][0], outs[0][0]) and torch.equal(outs[mode][1], outs[0][1]), (Cout, Cin, mode)
+            assert 0.001 < float(ops.s32_to_spikes(outs[0][0]).mean()) < 0.9
+            total += outs[0][0].numel() * 2
+            if B >= 5:
+                # the sampler's active-set calls: only the first n image slots are computed (n read on the device)
+                n = B // 2 + 1
+                active = torch.arange(B, dtype=torch.int32, device=dev)
+                n_act = torch.tensor([n, 0], dtype=torch.int32, device=dev)
+                res = {}
+                for mode in (0, 1):
+                    _lib.set_option("v2_duo", mode)
+                    with ops.active_set(active, n_act):
+                        o, c = ops.den_conv3x3_mfma_fp6v2(xs, pk, Cout, bn_a=a, bn_b=b, want_counts=True)
+                    res[mode] = (o[:n].clone(), c[:n].clone())
+                assert torch.equal(res[1][0], res[0][0]) and torch.equal(res[1][1], res[0][1]), (Cout, Cin, "active set")
+                assert torch.equal(res[1][0], outs[0][0][:n]), "the first n images of the full batch"
+    finally:
+        _lib.set_option("v2_duo", prev)
+    parity(f"fp6v2_duo_vs_one_workgroup_B{B}", neuron_steps=total, spike_mismatches=0)
 
 
 @pytest.mark.parametrize("Cout,Cin", [(128, 64), (256, 512)])
@@ -2103,6 +2150,47 @@ def test_timed_configuration_philox_graph_vs_oracle_on_dumped_noise(dev, ops, B,
     err = float((pred.cpu() - opred).abs().max())
     parity(f"timed_configuration_decode_B{B}", pixel_max_abs_err=err)
     assert err <= 1e-4
+
+
+def test_f15_bench_job_tokens_vs_fixture(golden_dir, dev):
+    """The bench line's OWN job in the driver's suite: the FIRST and the LAST timed batch of the default
+    ``python bench.py`` (seed 42, --steps 20 --warmup 5: draws #8 and #27 of torch's CPU generator are their keys; B = 256, 100
+    reverse steps, Philox noise, one hipGraph replay, dense) against tests/golden/f15_bench_job_tokens.npz -- the fp32 CPU oracle
+    on the dumped noise of exactly these batches (oracle/gen_f15_bench_job.py; R/snn_model/vq_diffusion.py:103-142).  Required:
+    token equality on every image outside the fixture's recorded fragile set (images where the oracle's own fp32 convolution
+    rounding flips a spike whose exact membrane potential sits on the threshold: margin recorded), and inside it equality with
+    the oracle evaluated with exact convolutions.  GPU side: two graph replays."""
+    from snn_model.vq_diffusion import AbsorbingDiffusion
+    from spkdiff import dist as sdist
+    z = load(golden_dir, "f15_bench_job_tokens.npz")
+    seed, warmup, steps, B, sample_steps, T, setup = (int(v) for v in z["config"])
+    den, sd = build_den(synth.MNIST, dev)
+    assert synth.state_checksum(sd) == bytes(z["weights_checksum"]).decode(), "the fixture was generated for other weights"
+    rep = {}
+    for tag, skip in (("first", setup + warmup), ("last", setup + warmup + steps - 1)):
+        ab = AbsorbingDiffusion(den, mask_id=128)
+        ab.n_samples, ab.skip_untouched, ab.sync_key = B, False, False
+        ab.set_shard(0, B)
+        torch.manual_seed(seed)
+        for _ in range(skip):
+            ab._philox_key()
+        hip = ab.sample(temp=1.0, sample_steps=sample_steps).cpu().reshape(B, -1)
+        assert int(ab.last_key) == int(z[tag + "_key"][0]), "the key of the bench job's batch"
+        want = torch.from_numpy(z[tag + "_tokens_oracle"].astype(np.int64))
+        eq = (hip == want).all(1)
+        frag = [int(b) for b in z[tag + "_fragile_images"]]
+        exact = torch.from_numpy(z[tag + "_fragile_tokens_exact"].astype(np.int64))
+        stray = [int(i) for i in torch.nonzero(~eq).flatten().tolist() if int(i) not in frag]
+        frag_ok = [bool(torch.equal(hip[b], exact[j])) for j, b in enumerate(frag)]
+        cs = [sdist.token_checksum(hip[i:i + 1], i) for i in range(B)]
+        cs_eq = sum(int(c == int(w)) for c, w in zip(cs, z[tag + "_image_checksum"]))
+        rep[tag] = dict(images_equal=int(eq.sum()), images=B, tokens_differing=int((hip != want).sum()), fragile=frag,
+                        fragile_equal_exact_convolution_oracle=frag_ok, fragile_margins=[float(m) for m in z[tag + "_fragile_margin"]],
+                        image_checksums_equal=cs_eq, stray=stray)
+        assert not stray, f"{tag}: images {stray} differ from the fp32 oracle outside the recorded fragile set"
+        assert all(frag_ok), f"{tag}: a fragile image differs from the exact-convolution oracle: {frag} {frag_ok}"
+        assert int(eq.sum()) >= B - len(frag) and cs_eq == int(eq.sum())
+    parity("f15_bench_job_tokens", **rep)
 
 
 @pytest.mark.slow
