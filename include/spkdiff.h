@@ -282,8 +282,9 @@ int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, c
  * scale / bias [Cout] as for the fp6 kernel, wl1 [Cout] = L1 norm of each channel's quantised weights, and qtab = the
  * quantised weights themselves as int32 [Cout][9][Cin] (read by the exact recomputation).  flag_words: zero-initialised
  * u32 workspace of spk_den_fp6v2_flag_words(B, Cout, H, W) words (counter, ticket, id list, overflow bitmap); it is clean
- * again when the call's launches have run (word 1 keeps the number of neurons the call flagged, for statistics; the last 2048
- * words are per-CU arrival counters of the two-workgroups-per-CU launch form, of which only the parity is read: never reset).  One
+ * again when the call's launches have run (word 1 keeps the number of neurons the call flagged, for statistics; behind the ticket
+ * sit 2048 per-CU arrival counters of the two-workgroups-per-CU launch form -- only their parity is read: never reset -- and its 128
+ * item-claim counters, zero again after the call).  One
  * workspace per stream: two calls in flight at once must not share it.
  * SPK_ERR_UNSUPPORTED unless T == 16, H == W == 7 or 8, Cout % 32 == 0 (Cin = 32 * nch). */
 long long spk_den_packed_weight_fp6v2_bytes(int Cout, int Cin);

@@ -81,6 +81,7 @@ struct V2Args {
   int gx, nsets;                             // XCD-aware walk (gx > 0) or flat walk (gx == 0)
   unsigned long long* dbg_out;               // (-DSPK_V2_DUO_DBG builds: per-workgroup time stamps; otherwise null)
   unsigned* cu_slots;                        // duo form: one arrival counter per CU (2048 words behind the ticket)
+  unsigned* item_ctr;                        // duo form: item claim counters, one per (channel group, XCD partition): 128 words behind them
   int duo_delay;                             // duo form: head start of a CU's first workgroup over its second, in 10 ns ticks (0: none)
 };
 
@@ -813,7 +814,18 @@ __device__ __forceinline__ void fp6v2_handover(const V2Args& a) {
 //     than they must).  The image slab of the next chunk is issued in stage 0 only (three stages before its first use).  The
 //     epilogue's stores share the counter and may retire out of order with the copies: the first barrier of every item drains it.
 #ifndef SPK_V2_DUO_SLOTS
-#define SPK_V2_DUO_SLOTS 4
+#define SPK_V2_DUO_SLOTS 5      // thirds in the weight ring.  5: the third of stage n + 1 has landed at the barrier of stage n, so the first
+                                // tap's fragments of a stage are read during the stage before (no LDS round trip behind a stage barrier);
+                                // 4: the first build (71 KB instead of 80 KB of LDS; every stage starts with an exposed fragment read)
+#endif
+#ifndef SPK_V2_DUO_STEAL
+#define SPK_V2_DUO_STEAL 1      // 1: the workgroups that share a channel group (and an XCD partition) CLAIM their items from one counter
+                                // instead of owning a fixed stride: the matrix pipe serves the older wave of a SIMD first, so the two
+                                // workgroups of a CU run at different speeds (17 against 27 us per item) and a fixed split left the slower
+                                // one alone for the last fifth of the launch (profiles/r5_ab_duo_first_build.txt)
+#endif
+#ifndef SPK_V2_DUO_PRIO
+#define SPK_V2_DUO_PRIO 1       // 1: s_setprio 1 in the K loop, 0 in the scan: the scanning wave's vector instructions fill gaps only
 #endif
 #ifndef SPK_V2_DUO_DBG
 #define SPK_V2_DUO_DBG 0        // 1: every workgroup stamps s_memrealtime at the start of each item's K loop and of its scan into a.dbg_out
@@ -827,13 +839,17 @@ constexpr size_t DUO_LDS = 2 * (size_t)DUO_A_BYTES + (size_t)DUO_NSLOT * DUO_W3 
 static_assert(DUO_LDS <= 80 * 1024, "two workgroups per CU");
 
 template <int H, int W>
-__device__ __forceinline__ void fp6v2_body_duo(const V2Args& a, const int g, const int il, const int lanes, const int n_images) {
+__device__ __forceinline__ void fp6v2_body_duo(const V2Args& a, const int g, const int il, const int lanes, const int n_images,
+                                               const int part, const int npart) {
   static_assert(H == 7 && W == 7 && !USE_D4 && N_MM == N_PAIR, "7x7 latents, four-digit form");
   constexpr int NWV = 4, NT = 3, HW = H * W, PW = W + 1;
   constexpr int HWb = DUO_HWB, Hin = DUO_HIN, NPP = DUO_NPP, A_BYTES = DUO_A_BYTES;
   constexpr int PPR = (W + 3) / 4, NA = Hin * PPR;     // ten image pieces per chunk
   constexpr int NSLOT = DUO_NSLOT, W3 = DUO_W3;
   static_assert(W3 == 9 * 1024 && NA == 10 && (NSLOT == 4 || NSLOT == 5), "piece shares below");
+  constexpr bool AHEAD = NSLOT == 5;                   // fragments of a stage's first tap are read during the previous stage
+  constexpr bool STEAL = SPK_V2_DUO_STEAL != 0;
+  __shared__ int s_claim[2];
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   uint8_t* const sA = lds;
   uint8_t* const sW = lds + 2 * A_BYTES;
@@ -904,17 +920,37 @@ __device__ __forceinline__ void fp6v2_body_duo(const V2Args& a, const int g, con
     rec_off[k] = rec_ok[k] ? (((cl / W) + 1) * PW + 1 + (cl % W)) * POSB + t * 16 : 0;
   }
 
-  int it = 0;                                             // running chunk counter: image buffer it & 1, stage number 3 it + st
-  if (il < nitems) {
-    const uint8_t* as0 = aslab_of(il, 0);
+  int it = 0;                                             // running chunk counter: image buffer it & 1
+  int slot = NSLOT - 1;                                   // ring slot of the current stage (stage number mod NSLOT; stepped at every stage barrier)
+  // STEAL: the items of this workgroup's partition are part, part + npart, part + 2 npart, ...; the workgroups of the partition
+  // (same channel group, same XCD set) claim them from one counter, the next one at the start of the current one (its first
+  // barrier drains the memory counter anyway, so the atomic's return costs nothing and the copies of the next item's first
+  // chunk know their source in time).  Otherwise: il, il + lanes, ...
+  unsigned* const ctr = STEAL ? a.item_ctr + (g * npart + part) : nullptr;
+  auto item_of = [&](int k) -> int { return STEAL ? part + npart * k : il + lanes * k; };
+  int cur = 0;
+  if (STEAL) {
+    if (tid == 0) s_claim[0] = (int)atomicAdd(ctr, 1u);
+    __syncthreads();
+    cur = __builtin_amdgcn_readfirstlane(s_claim[0]);
+  }
+  if (item_of(cur) < nitems) {
+    const uint8_t* as0 = aslab_of(item_of(cur), 0);
 #pragma unroll
     for (int q = 0; q < 3; ++q) issue_A(q, as0, sA_addr);
 #pragma unroll
     for (int st = 0; st < 3; ++st)
 #pragma unroll
       for (int q = 0; q < 3; ++q) issue_W(q, wbase + st * W3, sW_addr + st * W3);
+    if constexpr (NSLOT == 5) {                           // (stage 0 issues the third of stage 4: stage 3 = the second chunk's first third goes here)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) issue_W(q, wbase + (long long)(1 % nch) * W_SLAB, sW_addr + 3 * W3);
+    }
   }
-  for (int itm = il; itm < nitems; itm += lanes) {
+  for (int kk = 0; item_of(cur) < nitems; ++kk) {
+    const int itm = item_of(cur);
+    int nxt = cur + 1;                                    // (STEAL: read back from LDS behind the item's first barrier)
+    if (STEAL && tid == 0) s_claim[(kk + 1) & 1] = (int)atomicAdd(ctr, 1u);
     const int b = itm >> 1, hid = itm & 1;
     int a_off[NT];
 #pragma unroll
@@ -922,7 +958,8 @@ __device__ __forceinline__ void fp6v2_body_duo(const V2Args& a, const int g, con
       const int p = 2 * (wave + NWV * i) + hsel + hid * HWb;
       a_off[i] = (((p / W) - 2 * hid) * PW + (p % W)) * POSB + tt * 16;
     }
-    if (SPK_V2_DUO_DBG && tid == 0 && a.dbg_out) a.dbg_out[(long long)blockIdx.x * 64 + 2 * ((itm - il) / lanes)] = __builtin_amdgcn_s_memrealtime();
+    if (SPK_V2_DUO_DBG && tid == 0 && a.dbg_out && kk < 31) a.dbg_out[(long long)blockIdx.x * 64 + 2 * kk] = __builtin_amdgcn_s_memrealtime();
+    if (SPK_V2_DUO_PRIO) __builtin_amdgcn_s_setprio(1);
     v16f acc[NT][NACC];
     int creg[NR];
 #pragma unroll
@@ -930,12 +967,13 @@ __device__ __forceinline__ void fp6v2_body_duo(const V2Args& a, const int g, con
     for (int c = 0; c < nch; ++c, ++it) {
       const int buf = it & 1;
       int nb = itm, nc = c + 1;
-      if (nc == nch) { nc = 0; nb = itm + lanes; }
+      if (nc == nch) { nc = 0; nb = item_of(nxt); }       // (c > 0 here or nch == 1: nxt is the claimed one by then, see below)
       const bool have_next = nb < nitems;                 // otherwise the last chunk is copied once more (never read)
       const uint8_t* n_aslab = aslab_of(have_next ? nb : itm, have_next ? nc : c);
-      const uint8_t* n_wslab = wbase + (long long)(have_next ? nc : c) * W_SLAB;
+      // (weight slabs depend on the chunk index only; thirds copied for a chunk that never comes land in free slots)
+      const uint8_t* n_wslab = wbase + (long long)(c + 1 == nch ? 0 : c + 1) * W_SLAB;
+      const uint8_t* n2_wslab = wbase + (long long)((c + 2) % nch) * W_SLAB;
       const unsigned n_dA = sA_addr + (buf ^ 1) * A_BYTES;
-      const int n3 = 3 * it;
       v4i rvq[NR];
       auto compute = [&](auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
@@ -946,6 +984,14 @@ __device__ __forceinline__ void fp6v2_body_duo(const V2Args& a, const int g, con
           return *reinterpret_cast<const v4i*>(A + a_off[s % NT] + toff(s / NT));
         };
         const uint8_t* Wb = sW;                            // (set at every stage barrier)
+        auto ldb_at = [&](const uint8_t* base, int tile) -> v6i {
+          const uint8_t* p = base + tile * WT;
+          const v4i x = *reinterpret_cast<const v4i*>(p + lane * 16);
+          typedef const volatile __attribute__((address_space(3))) v2i* lds_v2i_ptr;
+          const v2i y = *(lds_v2i_ptr)SPK_LDS(p + 1024 + lane * 8);
+          const v6i r = {x[0], x[1], x[2], x[3], y[0], y[1]};
+          return r;
+        };
         auto ldb = [&](int tile) -> v6i {
           const uint8_t* p = Wb + tile * WT;
           const v4i x = *reinterpret_cast<const v4i*>(p + lane * 16);
@@ -961,13 +1007,15 @@ __device__ __forceinline__ void fp6v2_body_duo(const V2Args& a, const int g, con
           constexpr int s = decltype(s_tag)::value;
           constexpr int tap = s / NT, i = s % NT, st = tap / 3, ss = s % (3 * NT);        // ss: step within the stage
           if constexpr (ss == 0) {
-            // stage barrier: this stage's third (issued three stages ago) and, at stage 0, the chunk's image slab have landed
+            // stage barrier: everything but this wave's copies of the last two stages has landed -- this stage's third, the
+            // chunk's image slab at stage 0 and (five slots) the next stage's third -- and the slot of the stage before is free
             if constexpr (FIRST && st == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             else if constexpr (st == 0) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-            const int slot = NSLOT == 4 ? ((n3 + st) & 3) : ((n3 + st) % NSLOT);
+            if constexpr (FIRST && st == 0 && STEAL) nxt = __builtin_amdgcn_readfirstlane(s_claim[(kk + 1) & 1]);
+            slot = slot == NSLOT - 1 ? 0 : slot + 1;
             Wb = sW + slot * W3;
-            bp[tap & 1][0] = ldb(0); bp[tap & 1][1] = ldb(1);
+            if constexpr (!AHEAD || st == 0) { bp[tap & 1][0] = ldb(0); bp[tap & 1][1] = ldb(1); }
             if constexpr (st == 0) static_for<PF>([&](auto p_tag) { af[decltype(p_tag)::value] = lda(p_tag); });
           }
           const v4i av = af[s % PF];
@@ -977,15 +1025,24 @@ __device__ __forceinline__ void fp6v2_body_duo(const V2Args& a, const int g, con
           __builtin_amdgcn_sched_barrier(0);
           // copies of this stage: the third of stage n + NSLOT - 1 into the slot stage n - 1 released; stage 0: the next chunk's image
           if constexpr (ss < 3) {
-            const int dslot = NSLOT == 4 ? ((n3 + st + 3) & 3) : ((n3 + st + NSLOT - 1) % NSLOT);
-            // (NSLOT == 4: the third belongs to the NEXT chunk, same stage index)
-            issue_W(ss, n_wslab + st * W3, sW_addr + dslot * W3);
+            // the slot the previous stage released takes the third of stage n + NSLOT - 1: four slots: this stage's third of the
+            // NEXT chunk; five: the next stage's third of the next chunk (stage 2: stage 0 of the chunk after it)
+            const int dslot = slot == 0 ? NSLOT - 1 : slot - 1;
+            if constexpr (NSLOT == 4) issue_W(ss, n_wslab + st * W3, sW_addr + dslot * W3);
+            else if constexpr (st < 2) issue_W(ss, n_wslab + (st + 1) * W3, sW_addr + dslot * W3);
+            else issue_W(ss, n2_wslab, sW_addr + dslot * W3);
           } else if constexpr (st == 0 && ss < 6) {
             issue_A(ss - 3, n_aslab, n_dA);
           }
           if constexpr (i == 0 && (tap % 3) != 2) {
             bp[(tap + 1) & 1][0] = ldb(2 * ((tap + 1) % 3));
             bp[(tap + 1) & 1][1] = ldb(2 * ((tap + 1) % 3) + 1);
+          }
+          if constexpr (AHEAD && i == 0 && (tap % 3) == 2 && st < 2) {
+            // the first tap of the next stage (its third landed before this stage's barrier)
+            const uint8_t* Wn = sW + (slot == NSLOT - 1 ? 0 : slot + 1) * W3;
+            bp[(tap + 1) & 1][0] = ldb_at(Wn, 0);
+            bp[(tap + 1) & 1][1] = ldb_at(Wn, 1);
           }
           if constexpr (s == 1) {
 #pragma unroll
@@ -1005,7 +1062,8 @@ __device__ __forceinline__ void fp6v2_body_duo(const V2Args& a, const int g, con
       if (c == 0) compute(std::true_type{}); else compute(std::false_type{});
     }   // chunks
 
-    if (SPK_V2_DUO_DBG && tid == 0 && a.dbg_out) a.dbg_out[(long long)blockIdx.x * 64 + 2 * ((itm - il) / lanes) + 1] = __builtin_amdgcn_s_memrealtime();
+    if (SPK_V2_DUO_PRIO) __builtin_amdgcn_s_setprio(0);
+    if (SPK_V2_DUO_DBG && tid == 0 && a.dbg_out && kk < 31) a.dbg_out[(long long)blockIdx.x * 64 + 2 * kk + 1] = __builtin_amdgcn_s_memrealtime();
     // publish the record counts, then add the nine taps of every output position: s_row[p][t] = active inputs of row (p, t)
 #pragma unroll
     for (int k = 0; k < NR; ++k)
@@ -1033,6 +1091,7 @@ __device__ __forceinline__ void fp6v2_body_duo(const V2Args& a, const int g, con
 #pragma unroll
         for (int j = 0; j < NACC; ++j) sacc += acc[i][j][0];
       if (sacc == 12345.f) a.out[0] = 1;
+      cur = nxt;
       continue;
     }
     // ---------------- epilogue: the four-digit scan of fp6v2_body (fp32 recombination, BN, LIF, certification in two stages)
@@ -1100,6 +1159,7 @@ __device__ __forceinline__ void fp6v2_body_duo(const V2Args& a, const int g, con
       store_tile_spikes(a.out, a.out_cnt, mybits, lane, rec, (((long long)b * G + g) * HW + p) * 32, true);
       __builtin_amdgcn_sched_barrier(0);
     }
+    cur = nxt;
   }   // items
   spk_dma_wait_all();
 }
@@ -1110,7 +1170,7 @@ __device__ __forceinline__ void fp6v2_body_duo(const V2Args& a, const int g, con
 // first item -- during which the first one has the matrix pipe to itself, so nothing idles -- and from then on the pair is
 // stable.  Arrival order: one counter per CU (keyed by XCC / SE / SH / CU id from the hardware registers), never reset: any two
 // consecutive arrivals on a CU differ in parity, whatever earlier launches left in the counter.
-constexpr int DUO_CU_SLOTS = 2048;
+constexpr int DUO_CU_SLOTS = 2048, DUO_ITEM_CTRS = 128;
 __device__ __forceinline__ void fp6v2_duo_phase(const V2Args& a) {
   if (a.duo_delay <= 0 && !SPK_V2_DUO_DBG) return;
   __shared__ int s_late;
@@ -1140,9 +1200,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fp6v2_duo_kernel(V2Args a) {
   const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
   int g, il, lanes;
   fp6v2_wg_map(a, g, il, lanes);
+  // item partition of this workgroup: the XCD-aware walk gives XCD x the channel-group set x % nsets and the image partition
+  // x / nsets (of 8 / nsets); the flat walk has one partition
+  const int npart = a.gx > 0 ? 8 / a.nsets : 1;
+  const int part = a.gx > 0 ? ((int)blockIdx.x & 7) / a.nsets : 0;
   fp6v2_duo_phase(a);
-  fp6v2_body_duo<H, W>(a, g, il, lanes, Bn);
-  fp6v2_handover(a);
+  fp6v2_body_duo<H, W>(a, g, il, lanes, Bn, part, npart);
+  // (hand-over as above; the last workgroup also re-arms the claim counters for the next launch on this workspace)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (atomicAdd(a.flags + a.ticket_idx, 1u) == gridDim.x - 1) {
+      a.flags[1] = atomicAdd(a.flags, 0u);
+      if (!(SPK_V2_DBG & 64)) a.flags[0] = 0u;
+      a.flags[a.ticket_idx] = 0u;
+      for (int i = 0; i < DUO_ITEM_CTRS; ++i) a.item_ctr[i] = 0u;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ staggered form (experiment)
@@ -1910,7 +1983,7 @@ constexpr unsigned FLAG_CAP = 1u << 20;        // list capacity; beyond it flagg
 
 extern "C" long long spk_den_fp6v2_flag_words(int B, int Cout, int H, int W) {
   if (B <= 0 || Cout <= 0 || H <= 0 || W <= 0) return -1;
-  return 2 + (long long)FLAG_CAP + ((long long)B * Cout * H * W + 31) / 32 + 1 + DUO_CU_SLOTS;   // (+ ticket, + the duo form's CU counters)
+  return 2 + (long long)FLAG_CAP + ((long long)B * Cout * H * W + 31) / 32 + 1 + DUO_CU_SLOTS + DUO_ITEM_CTRS;   // (+ ticket, + the duo form's CU and item-claim counters)
 }
 
 static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale, const double* bias_d,
@@ -1928,7 +2001,7 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   a.in0 = in_s32; a.nch = nch; a.wq = wq; a.scale = scale; a.bias = bias_d; a.wl1 = wl1; a.qtab = qtab;
   a.bn_a = bn_a; a.bn_b = bn_b; a.out = out_s32; a.out_cnt = out_counts; a.flags = flag_words; a.flag_cap = FLAG_CAP;
   a.n_dyn = n_dyn_or_null;
-  a.dbg_out = nullptr; a.cu_slots = nullptr; a.duo_delay = 0;
+  a.dbg_out = nullptr; a.cu_slots = nullptr; a.item_ctr = nullptr; a.duo_delay = 0;
   a.need = nullptr; a.cls_cnt = nullptr; a.cls_list = nullptr;
   if (need) {
     a.need = need + spk_need_off_rec(B, need_R, need_r);
@@ -2002,14 +2075,19 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
     if (grid / G < 6) return SPK_ERR_UNSUPPORTED;           // one image lane per tile-count class at least
     if (eight) hipLaunchKernelGGL((conv3x3_fp6v2_listed_kernel<7, 7, 8>), dim3(grid), dim3(512), lds, stream, a);
     else hipLaunchKernelGGL((conv3x3_fp6v2_listed_kernel<7, 7, 4>), dim3(grid), dim3(256), lds, stream, a);
-  } else if (eight && !lag_form && !twelve && spk_opt(SPK_OPT_V2_DUO) != 0 && (long long)DUO_LDS <= spk_lds_limit()) {
+  } else if (eight && !lag_form && !twelve && nch >= 2 && G * 8 <= DUO_ITEM_CTRS && spk_opt(SPK_OPT_V2_DUO) != 0 &&
+             (long long)DUO_LDS <= spk_lds_limit()) {
     // round 5: two independent four-wave workgroups per CU on half-image items (fp6v2_body_duo)
     V2Args ad = a;
     ad.cu_slots = flag_words + a.ticket_idx + 1;
-    // v2_duo: 1 = half an item of head start for a CU's first workgroup (one wave alone: nch chunks x 54 MFMAs x ~35 cycles at
-    // ~2 GHz ~ nch x 95 ticks of 10 ns), 2 = none (the pair starts together), >= 16: that many ticks per chunk
+    ad.item_ctr = ad.cu_slots + DUO_CU_SLOTS;
+    ad.handover = 1;                                          // (the duo kernel always publishes the count: merged tail launch below)
+    // v2_duo: 1 = the pair of a CU starts together (measured: the older wave of a SIMD gets the matrix pipe first, the two run at
+    // different speeds and their scans fall into each other's K loops by themselves: 0.77 - 0.80 of the scan time with or without
+    // a head start, profiles/r5_ab_duo_first_build.txt); >= 16: a head start of that many 10 ns ticks per chunk for a CU's first
+    // workgroup (fp6v2_duo_phase)
     const int dmode = spk_opt(SPK_OPT_V2_DUO);
-    ad.duo_delay = dmode == 2 ? 0 : (dmode >= 16 ? dmode : 95) * nch;
+    ad.duo_delay = dmode >= 16 ? dmode * nch : 0;
     if (SPK_V2_DUO_DBG) ad.dbg_out = reinterpret_cast<unsigned long long*>(flag_words + 2 + FLAG_CAP / 2);   // (upper half of the id list)
     int grid2 = xcd_walk(ad, 2 * cus);
     if (grid2 == 0) grid2 = 2 * cus >= G ? (2 * cus / G) * G : G;

@@ -571,8 +571,10 @@ def test_fp6v2_kernel_bit_equal_to_the_exact_kernels(dev, ops, B, hw):
             assert 0.001 < float(s1.mean()) < 0.9
     torch.cuda.synchronize()
     cap = 1 << 20                                  # id-list capacity (FLAG_CAP): [count, ticket, ids..., overflow bitmap]
-    # (the last 2048 words are the duo form's per-CU arrival counters: never reset by design, only their parity is read)
-    assert all(int(v[0]) == 0 and int(v[2 + cap:-2048].abs().sum()) == 0 for k, v in ops._FLAG_DEFAULT.items() if k[0] == "den"), \
+    # (behind the ticket: the duo form's 2048 per-CU arrival counters -- never reset by design, only their parity is read -- and
+    #  its 128 item-claim counters, which the launch's last workgroup zeroes again)
+    assert all(int(v[0]) == 0 and int(v[2 + cap:-(2048 + 128)].abs().sum()) == 0 and int(v[-128:].abs().sum()) == 0
+               for k, v in ops._FLAG_DEFAULT.items() if k[0] == "den"), \
         "live counter, overflow bitmap and hand-over ticket come back clean"
     parity(f"fp6v2_vs_fp6_B{B}_{hw}x{hw}", neuron_steps=total, spike_mismatches=mism)
 
@@ -581,7 +583,7 @@ def test_fp6v2_kernel_bit_equal_to_the_exact_kernels(dev, ops, B, hw):
 def test_fp6v2_duo_form_bit_equal_to_the_one_workgroup_form(dev, ops, B):
     """Round 5: full 7x7 batches run two independent four-wave workgroups per CU on half-image items (fp6v2_body_duo: weight thirds
     in a ring, counted s_waitcnt, per-CU arrival parity + head start).  Same arithmetic, another schedule: every layer shape, with
-    the head start (v2_duo = 1), without it (2) and with a long one (400 ticks per chunk), must give the spikes AND the spike counts
+    no head start (v2_duo = 1), a head start of 95 and of 400 ticks per chunk, must give the spikes AND the spike counts
     of the one-workgroup form (v2_duo = 0) bit for bit -- also through the active-set path (a device-side image count below B)."""
     from spkdiff import _lib
     g = torch.Generator().manual_seed(500 + B)
@@ -596,12 +598,12 @@ def test_fp6v2_duo_form_bit_equal_to_the_one_workgroup_form(dev, ops, B):
             b = (torch.rand(Cout, generator=g) * 0.8).to(dev)
             pk, xs = ops.den_pack_weight_fp6v2(w, bias), ops.spikes_to_s32(x)
             outs = {}
-            for mode in (0, 1, 2, 400):
+            for mode in (0, 1, 95, 400):
                 _lib.set_option("v2_duo", mode)
                 for rep in range(2):                          # (twice: the ring / arrival counters carry over between launches)
                     o, c = ops.den_conv3x3_mfma_fp6v2(xs, pk, Cout, bn_a=a, bn_b=b, want_counts=True)
                 outs[mode] = (o.clone(), c.clone())
-            for mode in (1, 2, 400):
+            for mode in (1, 95, 400):
                 assert torch.equal(outs[mode][0], outs[0][0]) and torch.equal(outs[mode][1], outs[0][1]), (Cout, Cin, mode)
             assert 0.001 < float(ops.s32_to_spikes(outs[0][0]).mean()) < 0.9
             total += outs[0][0].numel() * 2

@@ -26,12 +26,19 @@ torch.cuda.synchronize()
 buf = next(iter(ops._FLAG_DEFAULT.values()))
 cap = 1 << 20
 raw = buf[2 + cap // 2: 2 + cap // 2 + 512 * 64 * 2].cpu().numpy().view(np.uint64).reshape(512, 64).astype(np.int64)
-nit = int(((raw[:, :62] != 0).sum(1) // 2).max())
-t0 = raw[:, 0].min()
-ks = (raw[:, 1:2 * nit:2] - raw[:, 0:2 * nit:2])              # K-loop ticks per item
-sc = (raw[:, 2:2 * nit:2] - raw[:, 1:2 * nit - 1:2])          # scan (+ count pass) ticks per item
-print(f"items per workgroup {nit}; K loop {ks.mean() / 100:.2f} us (min {ks.min() / 100:.2f}, max {ks.max() / 100:.2f}); "
-      f"scan {sc.mean() / 100:.2f} us (min {sc.min() / 100:.2f}, max {sc.max() / 100:.2f}); span {(raw[:, :2 * nit].max() - t0) / 100:.1f} us")
+nits = ((raw[:, :62] != 0).sum(1) // 2).astype(int)
+t0 = raw[:, 0][raw[:, 0] > 0].min()
+ks, sc, ends = [], [], []
+for w in range(512):
+    n = nits[w]
+    if n == 0:
+        continue
+    ks += list(raw[w, 1:2 * n:2] - raw[w, 0:2 * n:2])
+    sc += list(raw[w, 2:2 * n:2] - raw[w, 1:2 * n - 1:2])
+    ends.append(raw[w, 2 * n - 1])
+ks, sc = np.array(ks), np.array(sc)
+print(f"items per workgroup {nits.min()}..{nits.max()} (mean {nits.mean():.1f}); K loop {ks.mean() / 100:.2f} us (min {ks.min() / 100:.2f}, max {ks.max() / 100:.2f}); "
+      f"scan {sc.mean() / 100:.2f} us (min {sc.min() / 100:.2f}, max {sc.max() / 100:.2f}); last scan starts {(np.min(ends) - t0) / 100:.1f} .. {(np.max(ends) - t0) / 100:.1f} us")
 keys, late = raw[:, 62], raw[:, 63]
 fr = []
 for k in np.unique(keys):
@@ -40,10 +47,10 @@ for k in np.unique(keys):
         continue
     for me, other in ((wg[0], wg[1]), (wg[1], wg[0])):
         tot = ins = 0
-        for i in range(nit - 1):
+        for i in range(nits[me] - 1):
             s0, s1 = raw[me, 2 * i + 1], raw[me, 2 * i + 2]
             tot += s1 - s0
-            for j in range(nit):
+            for j in range(nits[other]):
                 k0, k1 = raw[other, 2 * j], raw[other, 2 * j + 1]
                 ins += max(0, min(s1, k1) - max(s0, k0))
         fr.append(ins / max(tot, 1))
@@ -51,4 +58,4 @@ print(f"CUs with exactly two workgroups: {len(fr) // 2} of {len(np.unique(keys))
       f"scan time inside the partner's K loops: mean {np.mean(fr):.2f}, 10th pct {np.percentile(fr, 10):.2f}, 90th {np.percentile(fr, 90):.2f}")
 wg = np.nonzero(keys == keys[0])[0][:2]
 for g in wg:
-    print(f"wg {g} (parity {late[g]}):", " ".join(f"{(v - t0) / 100:.1f}" for v in raw[g, :2 * nit]))
+    print(f"wg {g} (parity {late[g]}):", " ".join(f"{(v - t0) / 100:.1f}" for v in raw[g, :2 * nits[g]]))
