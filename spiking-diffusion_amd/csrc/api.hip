@@ -30,7 +30,8 @@ SpkOption g_options[SPK_OPT_COUNT] = {
     {"fp6_waves", {4}},          // SPK_OPT_FP6_WAVES
     {"v2_waves", {8}},           // SPK_OPT_V2_WAVES
     {"v2_lag", {0}},             // SPK_OPT_V2_LAG
-    {"v2_duo", {1}},             // SPK_OPT_V2_DUO
+    {"v2_duo", {0}},             // SPK_OPT_V2_DUO
+    {"v2_defer", {1}},           // SPK_OPT_V2_DEFER
 };
 }  // namespace
 

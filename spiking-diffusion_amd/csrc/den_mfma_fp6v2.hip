@@ -82,6 +82,7 @@ struct V2Args {
   unsigned long long* dbg_out;               // (-DSPK_V2_DUO_DBG builds: per-workgroup time stamps; otherwise null)
   unsigned* cu_slots;                        // duo form: one arrival counter per CU (2048 words behind the ticket)
   unsigned* item_ctr;                        // duo form: item claim counters, one per (channel group, XCD partition): 128 words behind them
+  float* zstage;                             // deferred-scan form: 96 KB per workgroup (an item's pre-activations between two K loops)
   int duo_delay;                             // duo form: head start of a CU's first workgroup over its second, in 10 ns ticks (0: none)
 };
 
@@ -1171,6 +1172,7 @@ __device__ __forceinline__ void fp6v2_body_duo(const V2Args& a, const int g, con
 // stable.  Arrival order: one counter per CU (keyed by XCC / SE / SH / CU id from the hardware registers), never reset: any two
 // consecutive arrivals on a CU differ in parity, whatever earlier launches left in the counter.
 constexpr int DUO_CU_SLOTS = 2048, DUO_ITEM_CTRS = 128;
+constexpr int ZSTAGE_WORDS_PER_WG = 8 * 3 * 16 * 64;     // eight waves x three tiles x sixteen steps x 64 lanes (fp32): 96 KB
 __device__ __forceinline__ void fp6v2_duo_phase(const V2Args& a) {
   if (a.duo_delay <= 0 && !SPK_V2_DUO_DBG) return;
   __shared__ int s_late;
@@ -1216,6 +1218,385 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fp6v2_duo_kernel(V2Args a) {
       for (int i = 0; i < DUO_ITEM_CTRS; ++i) a.item_ctr[i] = 0u;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------ deferred scan (round 5)
+// What the duo experiment taught (profiles/r5_ab_duo_*.txt): two INDEPENDENT waves on a SIMD do not add up -- the matrix pipe
+// serves the older wave first, a wave on its own is bound by its instruction issue (~47 cycles per MFMA where the pipe needs 35),
+// and two of them co-running reach 75 % of the pipe, no better than the lock-step pair with its exposed scan.  The lock-step
+// pair DOES keep the pipe 89 % busy inside the K loop, and one wave's vector instructions are free beside MFMAs up to four per
+// MFMA, also when both waves of a SIMD issue them (tools/coexec_probe.hip, rows MV).  So the scan moves INTO the K loop of the
+// same waves -- the next item's: software pipelining across items.
+//   * Two accumulator generations do not fit (2 x 96 of 256 registers), and neither do 48 recombined pre-activations: hipcc
+//     needs ~220 registers for the K loop as it is, spilled 150 dwords with them in VGPRs, split the file 128 / 128 with them in
+//     AGPRs, and with "amdgpu-agpr-alloc" forced through the IR still evicted half of them to scratch (reloads behind
+//     s_waitcnt vmcnt(0) inside the K loop).  So an item's pre-activations z_t (the two packed fmas per step pair the scan always
+//     started with) take the one road that costs no registers: 12 KB per wave to a per-workgroup STAGING slab in memory (L2 /
+//     MALL resident: 25 MB for the whole device, rewritten every item), and come back one tile at a time -- tile k is loaded
+//     late in chunk k (before the chunk barrier's own s_waitcnt vmcnt(0), so the load costs no wait of its own), scanned during
+//     chunk k + 1 (one LIF step per K-loop step, 7 vector instructions beside 4 MFMAs of the pair of waves), finished
+//     (certification, flags, transpose, stores) at the end of that chunk.  Needs >= 4 chunks (conv3 .. conv5).
+//   * The active-input counts of item i (s_cin -> s_row, s_nmax) are needed by its certification only: the records are published
+//     at the end of item i, the nine-tap sums are formed during chunk 0 of item i + 1 behind its barrier (no barriers of their
+//     own any more), two buffers by item parity.
+//   * What is left between two K loops: the MFMA drain, 48 packed fmas, 12 stores and two LDS writes per thread.
+// The last item of a workgroup has no successor: it is scanned the round-2 way (counts pass with two barriers, then the scan).
+// Same arithmetic, same instruction sequence per neuron: bit-equal to fp6v2_body (tests: ..._deferred_scan_bit_equal...).
+struct ScanState { float v, zmax, dmin; unsigned bits; };
+__device__ __forceinline__ void defer_lif_step(ScanState& st, const float z) {
+  st.zmax = fmaxf(st.zmax, fabsf(z));
+  const float h = fmaf(z - st.v, 0.5f, st.v);
+  const float hm = h - 1.0f;
+  st.dmin = fminf(st.dmin, fabsf(hm));
+  st.v = h >= 1.0f ? 0.0f : h;
+  st.bits = __builtin_amdgcn_alignbit(st.bits, __float_as_uint(hm), 31);
+}
+
+// certification + flags + stores of one scanned tile; z[] still holds its sixteen pre-activations (second stage)
+__device__ __forceinline__ void defer_finish(const V2Args& a, ScanState& st, const float4* zq, const int nmax, const int* s_row_p,
+                                             const float cT, const float cE, const int b, const int co, const int g, const int G,
+                                             const int HW, const int p, const int lane) {
+  const unsigned mybits = ~(__builtin_bitreverse32(st.bits) >> 16) & 0xffffu;
+  bool flg = st.dmin <= SPK_V2_SPARE * fmaf(st.zmax, 2.5f * CERT_4EPS, fmaf((float)nmax, cT, cE));
+  if (SPK_V2_STAGE2 && __builtin_amdgcn_ballot_w64(flg) != 0ull) {
+    float v2 = 0.f, dh = 0.f;
+    bool f2 = false;
+    // (a wave with a flagged lane, a few percent of the tiles: the sixteen pre-activations come back from the staging slab)
+    const v4i* rp = reinterpret_cast<const v4i*>(s_row_p);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const v4i c4 = rp[q];
+      const float4 z4 = zq[q * 64];
+      const float z[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ct = fmaf((float)c4[e], cT, cE);
+        dh = fmaf(fabsf(z[e]) + fabsf(v2), 0.625f * CERT_4EPS, fmaf(dh, 0.5f, 0.5f * ct));
+        const float h = fmaf(z[e] - v2, 0.5f, v2);
+        f2 = f2 || (fabsf(h - 1.0f) <= SPK_V2_SPARE * dh);
+        v2 = h >= 1.0f ? 0.0f : h;
+      }
+    }
+    flg = flg && f2;
+  }
+  if (flg && !(SPK_V2_DBG & 32)) {
+    const long long n = ((long long)b * a.Cout + co) * HW + p;
+    const unsigned idx = atomicAdd(a.flags, 1u);
+    if (idx < a.flag_cap) a.flags[2 + idx] = (unsigned)n;
+    else atomicOr(a.flags + 2 + a.flag_cap + (n >> 5), 1u << (n & 31));
+  }
+  const long long rec = (((long long)b * G + g) * HW + p) * POSB;
+  store_tile_spikes(a.out, a.out_cnt, mybits, lane, rec, (((long long)b * G + g) * HW + p) * 32, true);
+}
+
+template <int H, int W>
+__device__ __forceinline__ void fp6v2_body_defer(const V2Args& a, const int g, const int il, const int lanes, const int n_images) {
+  static_assert(H == 7 && W == 7 && !USE_D4 && N_MM == N_PAIR, "7x7 latents, four-digit form");
+  constexpr int NWV = 8, NT = 3, HW = H * W, PW = W + 1;
+  constexpr int NPP = (H + 2) * PW + 1, A_BYTES = NPP * POSB;
+  constexpr int PPR = (W + 3) / 4, NA = H * PPR, NPA = (NA + NWV - 1) / NWV, NPW = (W_PIECES + NWV - 1) / NWV;
+  constexpr int NSTEP = 9 * NT, NPIECES = NPA + NPW, PF = 4;
+  constexpr int ROWS = HW + 1;                             // s_row / s_nmax rows per parity buffer
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  uint8_t* const sA = lds;
+  uint8_t* const sW = lds + 2 * A_BYTES;
+  int* const s_cin = reinterpret_cast<int*>(lds + 2 * A_BYTES + 2 * W_LDS);          // [NPP][16]
+  int* const s_row = s_cin + NPP * 16;                                               // [2][ROWS][16]
+  int* const s_nmax = s_row + 2 * ROWS * 16;                                         // [2][ROWS]
+  const unsigned sA_addr = spk_lds_addr(sA), sW_addr = sA_addr + 2 * A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nch = a.nch;
+  const int G = a.Cout >> 5;
+  for (int i = tid; i < 2 * A_BYTES / 16; i += NWV * 64) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < NPP * 16; i += NWV * 64) s_cin[i] = 0;
+  if (tid < 2 * ROWS) s_nmax[tid] = 0;
+  __syncthreads();
+
+  const int row = lane & 31, half = lane >> 5;
+  const int hsel = (row >> 2) & 1, tt = (row & 3) + 4 * (row >> 3);
+  int a_off[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int p = 2 * (wave + NWV * i) + hsel;
+    a_off[i] = ((p / W) * PW + (p % W)) * POSB + tt * 16;
+  }
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  unsigned pa_pk[NPA];
+#pragma unroll
+  for (int j = 0; j < NPA; ++j) {
+    int id = wave_s * NPA + j;
+    id = id < NA ? id : NA - 1;
+    const int y = id / PPR, px = id - y * PPR;
+    const int np = (W - 4 * px) < 4 ? (W - 4 * px) : 4;
+    const unsigned src = (unsigned)((y * W + 4 * px) * POSB), dst = (unsigned)(((y + 1) * PW + 1 + 4 * px) * POSB);
+    pa_pk[j] = src | (dst << 14) | ((unsigned)(np - 1) << 29);
+  }
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const unsigned wave_k = (unsigned)wave_s * 1024u;
+  auto issue_piece = [&](int q, const uint8_t* aslab, const uint8_t* wslab, unsigned dA, unsigned dW) {
+    if (q < NPA) {
+      const unsigned pk = pa_pk[q];
+      const unsigned np = ((pk >> 29) & 3u) + 1u;
+      const unsigned long long mask = np == 4 ? ~0ull : ((1ull << (16 * np)) - 1ull);
+      spk_dma16s_masked(aslab + (pk & 0x3fffu), lane16, dA + ((pk >> 14) & 0x7fffu), mask);
+    } else {
+      unsigned ko = wave_k + 1024u * NWV * (unsigned)(q - NPA);
+      if (NWV * (q - NPA) + NWV - 1 >= W_PIECES) ko = ko < (unsigned)W_PIECES * 1024u ? ko : ko - 1024u * NWV;
+      spk_dma16s(wslab + ko, lane16, dW + ko);
+    }
+  };
+  const uint8_t* const wbase = a.wq + (long long)g * nch * W_SLAB;
+  auto aslab_of = [&](int itm, int c) -> const uint8_t* { return a.in0 + ((long long)itm * nch + c) * HW * POSB; };
+  const int nitems = n_images;
+
+  const int co = g * 32 + (lane & 31);
+  const float scale_f = (float)a.scale[co], bias_f = (float)a.bias[co];
+  const float bna = a.bn_a[co], bnb = a.bn_b[co];
+  const float Bc = fmaf(bias_f, bna, bnb);
+  const float cE = 2.0f * 2.38418579e-07f * (fabsf(bnb) + fabsf(Bc)) + 1e-30f;
+  const float cT = 528.0f * scale_f * fabsf(bna) * 1.000001f;
+  const float Ac4 = 1024.0f * scale_f * bna;
+  const int sc_a = 0x7f7f7f7f;
+  const int sc_p = half ? (int)0x82828282u : (int)0x87878787u;
+
+  constexpr int NREC = H * W * 16, NR = (NREC + NWV * 64 - 1) / (NWV * 64);
+  int rec_off[NR];
+  bool rec_ok[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const int r = tid + k * NWV * 64;
+    const int cl = r >> 4, t = r & 15;
+    rec_ok[k] = r < NREC;
+    rec_off[k] = rec_ok[k] ? (((cl / W) + 1) * PW + 1 + (cl % W)) * POSB + t * 16 : 0;
+  }
+  // nine-tap sums of the published record counts: entry e = (position, step); this thread takes e = tid and tid + 512
+  auto row_sum_addr = [&](int e) -> const int* { return s_cin + (((e >> 4) / W) * PW + ((e >> 4) % W)) * 16 + (e & 15); };
+
+  // staging slab of this workgroup: [wave][tile][step quad][lane] float4 (a wave's store / load instruction moves 1 KB)
+  float4* const zst = reinterpret_cast<float4*>(a.zstage) + ((long long)blockIdx.x * NWV + wave) * (NT * 4 * 64) + lane;
+  float zt[16];                                           // the tile being scanned (loaded late in the chunk before)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zt[r] = 0.f;
+  bool have_old = false;
+  int old_b = 0, par = 0;                                 // par: parity buffer that will take the counts of the CURRENT item
+
+  int it = 0;
+  if (il < nitems) {
+    const uint8_t* as0 = aslab_of(il, 0);
+#pragma unroll
+    for (int q = 0; q < NPIECES; ++q) issue_piece(q, as0, wbase, sA_addr, sW_addr);
+  }
+  for (int itm = il; itm < nitems; itm += lanes) {
+    const int b = itm;
+    const bool last_item = itm + lanes >= nitems;
+    v16f acc[NT][NACC];
+    int creg[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) creg[k] = 0;
+    ScanState ss = {0.f, 0.f, 3.0e38f, 0u};
+    for (int c = 0; c < nch; ++c, ++it) {
+      const int buf = it & 1;
+      spk_dma_wait_all();
+      __syncthreads();
+      int nb = itm, nc = c + 1;
+      if (nc == nch) { nc = 0; nb = itm + lanes; }
+      const bool have_next = nb < nitems;
+      const uint8_t* n_aslab = aslab_of(have_next ? nb : itm, have_next ? nc : c);
+      const uint8_t* n_wslab = wbase + (long long)(have_next ? nc : c) * W_SLAB;
+      const unsigned n_dA = sA_addr + (buf ^ 1) * A_BYTES;
+      const unsigned n_dW = sW_addr + (buf ^ 1) * W_LDS;
+      const int opar = par ^ 1;                           // the previous item's counts
+      // which tile of the previous item this chunk scans (wave-uniform): chunk k + 1 <-> tile k
+      const int scan_k = (have_old && c >= 1 && c <= NT) ? c - 1 : -1;
+      const int load_k = (have_old && c < NT) ? c : -1;   // tile loaded late in this chunk for the next one
+      if (scan_k >= 0) {
+        ss.v = 0.f; ss.zmax = 0.f; ss.dmin = 3.0e38f; ss.bits = 0u;
+        // (the loads of the chunk before were waited for by the barrier above; this tells the compiler so BEFORE the chunk's
+        //  copies are in flight -- its own wait in front of the first use would otherwise count them too)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(zt[r]));
+      }
+      v4i rvq[NR];
+      int rs[9];                                          // (chunk 0: the nine taps of one of this thread's two row sums)
+      auto compute = [&](auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const uint8_t* A = sA + buf * A_BYTES;
+        const uint8_t* Wb = sW + buf * W_LDS;
+        auto toff = [](int tap) constexpr -> int { return ((tap / 3) * PW + (tap % 3)) * POSB; };
+        auto lda = [&](auto s_tag) -> v4i {
+          constexpr int s = decltype(s_tag)::value;
+          return *reinterpret_cast<const v4i*>(A + a_off[s % NT] + toff(s / NT));
+        };
+        auto ldb = [&](int tile) -> v6i {
+          const uint8_t* p = Wb + tile * WT;
+          const v4i x = *reinterpret_cast<const v4i*>(p + lane * 16);
+          typedef const volatile __attribute__((address_space(3))) v2i* lds_v2i_ptr;
+          const v2i y = *(lds_v2i_ptr)SPK_LDS(p + 1024 + lane * 8);
+          const v6i r = {x[0], x[1], x[2], x[3], y[0], y[1]};
+          return r;
+        };
+        v6i bp[2][2];
+        bp[0][0] = ldb(0); bp[0][1] = ldb(1);
+        v4i af[PF];
+        static_for<PF>([&](auto s_tag) { af[decltype(s_tag)::value] = lda(s_tag); });
+        static_for<NSTEP>([&](auto s_tag) {
+          constexpr int s = decltype(s_tag)::value;
+          constexpr int tap = s / NT, i = s % NT;
+          const v4i av = af[s % PF];
+          if constexpr (s + PF < NSTEP) af[s % PF] = lda(std::integral_constant<int, s + PF>{});
+          if constexpr (FIRST && tap == 0) SPK_MFMA2_Z("v", acc[i][0], av, bp[0][0], sc_a, sc_p);
+          else SPK_MFMA2("v", acc[i][0], av, bp[tap & 1][0], sc_a, sc_p);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (i == 0 && 2 * tap < NPIECES) issue_piece(2 * tap, n_aslab, n_wslab, n_dA, n_dW);
+          if constexpr (i == 1 && 2 * tap + 1 < NPIECES) issue_piece(2 * tap + 1, n_aslab, n_wslab, n_dA, n_dW);
+          if constexpr (i == 0 && tap + 1 < 9) {
+            bp[(tap + 1) & 1][0] = ldb(2 * (tap + 1));
+            bp[(tap + 1) & 1][1] = ldb(2 * (tap + 1) + 1);
+          }
+          if constexpr (s == 1) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k) rvq[k] = *reinterpret_cast<const v4i*>(sA + buf * A_BYTES + rec_off[k]);
+          }
+          if constexpr (s == SPK_V2_REC_STEP) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k)
+              creg[k] += __builtin_popcount((unsigned)rvq[k][0]) + __builtin_popcount((unsigned)rvq[k][1]) +
+                         __builtin_popcount((unsigned)rvq[k][2]) + __builtin_popcount((unsigned)rvq[k][3]);
+          }
+          if constexpr (FIRST) {
+            // chunk 0: the previous item's counts.  Its records were published before this chunk's barrier: read the nine taps
+            // of this thread's two (position, step) entries, sum them a few steps later, publish sum and per-position maximum
+            // (buffer opar; the scans read it from the next chunk's barrier on) and clear the other buffer's maxima.
+            // (an opaque copy of the thread id: the entry addresses are recomputed here -- a few integer instructions -- instead
+            //  of being hoisted out of the item loop, spilled, and reloaded behind an s_waitcnt vmcnt(0) that would wait for
+            //  this chunk's copies)
+            if constexpr (s == 3 || s == 12) {
+              constexpr int j = s == 3 ? 0 : 1;
+              int t_ = tid;
+              asm volatile("" : "+v"(t_));
+              if (have_old && (j == 0 || t_ + 512 < (HW - 1) * 16)) {
+                const int* c0 = row_sum_addr(t_ + 512 * j);
+#pragma unroll
+                for (int d = 0; d < 9; ++d) rs[d] = c0[((d / 3) * PW + (d % 3)) * 16];
+              }
+            }
+            if constexpr (s == 9 || s == 18) {
+              constexpr int j = s == 9 ? 0 : 1;
+              int t_ = tid;
+              asm volatile("" : "+v"(t_));
+              if (have_old && (j == 0 || t_ + 512 < (HW - 1) * 16)) {
+                const int e = t_ + 512 * j;
+                int sum = 0;
+#pragma unroll
+                for (int d = 0; d < 9; ++d) sum += rs[d];
+                s_row[opar * ROWS * 16 + e] = sum;
+                atomicMax(&s_nmax[opar * ROWS + (e >> 4)], sum);
+              }
+            }
+            if constexpr (s == 20) {
+              int t_ = tid;
+              asm volatile("" : "+v"(t_));
+              if (t_ < ROWS) s_nmax[par * ROWS + t_] = 0;
+            }
+          } else {
+            // chunks 1 .. 3: one LIF step of the previous item's tile scan_k per K-loop step (steps 2 .. 17)
+            if constexpr (s >= 2 && s <= 17) {
+              if (scan_k >= 0) defer_lif_step(ss, zt[s - 2]);
+            }
+          }
+          if constexpr (s == 19) {
+            // the tile the NEXT chunk scans: zt is dead from here on (the finish below reads the slab again if it must), the
+            // loads are in flight for the rest of the chunk and are covered by the chunk barrier's s_waitcnt vmcnt(0)
+            if (load_k >= 0) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float4 z4 = zst[(load_k * 4 + q) * 64];
+                zt[4 * q] = z4.x; zt[4 * q + 1] = z4.y; zt[4 * q + 2] = z4.z; zt[4 * q + 3] = z4.w;
+              }
+            }
+          }
+          if constexpr (FIRST && tap == 0) SPK_MFMA2_Z("v", acc[i][1], av, bp[0][1], sc_a, sc_p);
+          else SPK_MFMA2("v", acc[i][1], av, bp[tap & 1][1], sc_a, sc_p);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      };
+      if (c == 0) compute(std::true_type{}); else compute(std::false_type{});
+      // the finish of the scanned tile (certification against its position's counts, flags, transpose, stores) at the end of the
+      // chunk: the K loop's fragment registers are dead here (inside the loop the finish spilled 150 registers)
+      if (scan_k >= 0) {
+        const int ti = wave + NWV * scan_k, pp = 2 * ti + half;
+        const int nmax = s_nmax[opar * ROWS + pp];
+        const int* srp = s_row + opar * ROWS * 16 + pp * 16;
+        defer_finish(a, ss, zst + scan_k * 4 * 64, nmax, srp, cT, cE, old_b, co, g, G, HW, pp, lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }   // chunks
+
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    // recombination: z_t = (P01 * 1024 + P23) * (1024 Ac) + Bc  (the first four instructions per step pair of the round-2 scan),
+    // out to the staging slab (the last item, scanned right below, reads them back from there too: one code path, and no
+    // moment at which accumulators and pre-activations are both in registers)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float z4[4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; e2 += 2) {
+          const int r2 = 4 * q + e2;
+          const v2f p0 = {acc[i][0][r2], acc[i][0][r2 + 1]}, p1 = {acc[i][1][r2], acc[i][1][r2 + 1]};
+          const v2f q4 = __builtin_elementwise_fma(p0, (v2f){1024.0f, 1024.0f}, p1);
+          const v2f z2 = __builtin_elementwise_fma(q4, (v2f){Ac4, Ac4}, (v2f){Bc, Bc});
+          z4[e2] = z2[0]; z4[e2 + 1] = z2[1];
+        }
+        zst[(i * 4 + q) * 64] = make_float4(z4[0], z4[1], z4[2], z4[3]);
+      }
+    }
+    // publish this item's record counts (summed behind the next chunk-0 barrier -- or right here for the last item)
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+      if (rec_ok[k]) s_cin[(rec_off[k] / POSB) * 16 + ((rec_off[k] % POSB) >> 4)] = creg[k];
+    old_b = b;
+    have_old = true;
+    par ^= 1;
+    if (last_item) {
+      // no successor to hide behind: counts pass with its two barriers, then the three tile scans back to back (round-2 order)
+      const int opar = par ^ 1;
+      __syncthreads();
+      for (int e = tid; e < (HW - 1) * 16; e += NWV * 64) {
+        const int* c0 = row_sum_addr(e);
+        int sum = 0;
+#pragma unroll
+        for (int d = 0; d < 9; ++d) sum += c0[((d / 3) * PW + (d % 3)) * 16];
+        s_row[opar * ROWS * 16 + e] = sum;
+        atomicMax(&s_nmax[opar * ROWS + (e >> 4)], sum);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        ScanState s2 = {0.f, 0.f, 3.0e38f, 0u};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 z4 = zst[(k * 4 + q) * 64];
+          defer_lif_step(s2, z4.x); defer_lif_step(s2, z4.y); defer_lif_step(s2, z4.z); defer_lif_step(s2, z4.w);
+        }
+        const int pp = 2 * (wave + NWV * k) + half;
+        defer_finish(a, s2, zst + k * 4 * 64, s_nmax[opar * ROWS + pp], s_row + opar * ROWS * 16 + pp * 16, cT, cE, old_b, co, g, G, HW, pp, lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }   // items
+  spk_dma_wait_all();
+}
+
+template <int H, int W>
+__global__ __launch_bounds__(512, 1) void conv3x3_fp6v2_defer_kernel(V2Args a) {
+  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
+  int g, il, lanes;
+  fp6v2_wg_map(a, g, il, lanes);
+  fp6v2_body_defer<H, W>(a, g, il, lanes, Bn);
+  fp6v2_handover(a);
 }
 
 // ------------------------------------------------------------------------------------------------ staggered form (experiment)
@@ -1983,7 +2364,8 @@ constexpr unsigned FLAG_CAP = 1u << 20;        // list capacity; beyond it flagg
 
 extern "C" long long spk_den_fp6v2_flag_words(int B, int Cout, int H, int W) {
   if (B <= 0 || Cout <= 0 || H <= 0 || W <= 0) return -1;
-  return 2 + (long long)FLAG_CAP + ((long long)B * Cout * H * W + 31) / 32 + 1 + DUO_CU_SLOTS + DUO_ITEM_CTRS;   // (+ ticket, + the duo form's CU and item-claim counters)
+  return 2 + (long long)FLAG_CAP + ((long long)B * Cout * H * W + 31) / 32 + 1 + DUO_CU_SLOTS + DUO_ITEM_CTRS +   // (+ ticket, + the duo form's CU and item-claim counters,
+         (long long)spk_cu_count() * ZSTAGE_WORDS_PER_WG;                                      //  + the deferred-scan form's staging slabs)
 }
 
 static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale, const double* bias_d,
@@ -2001,7 +2383,7 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   a.in0 = in_s32; a.nch = nch; a.wq = wq; a.scale = scale; a.bias = bias_d; a.wl1 = wl1; a.qtab = qtab;
   a.bn_a = bn_a; a.bn_b = bn_b; a.out = out_s32; a.out_cnt = out_counts; a.flags = flag_words; a.flag_cap = FLAG_CAP;
   a.n_dyn = n_dyn_or_null;
-  a.dbg_out = nullptr; a.cu_slots = nullptr; a.item_ctr = nullptr; a.duo_delay = 0;
+  a.dbg_out = nullptr; a.cu_slots = nullptr; a.item_ctr = nullptr; a.duo_delay = 0; a.zstage = nullptr;
   a.need = nullptr; a.cls_cnt = nullptr; a.cls_list = nullptr;
   if (need) {
     a.need = need + spk_need_off_rec(B, need_R, need_r);
@@ -2075,6 +2457,11 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
     if (grid / G < 6) return SPK_ERR_UNSUPPORTED;           // one image lane per tile-count class at least
     if (eight) hipLaunchKernelGGL((conv3x3_fp6v2_listed_kernel<7, 7, 8>), dim3(grid), dim3(512), lds, stream, a);
     else hipLaunchKernelGGL((conv3x3_fp6v2_listed_kernel<7, 7, 4>), dim3(grid), dim3(256), lds, stream, a);
+  } else if (eight && !lag_form && !twelve && nch >= 4 && spk_opt(SPK_OPT_V2_DEFER) != 0 && spk_opt(SPK_OPT_V2_DUO) == 0) {
+    // round 5: the scan of an item runs inside the next item's K loop (fp6v2_body_defer); two count buffers by item parity
+    const size_t lds_d = 2 * ((size_t)a_bytes + W_LDS) + (size_t)((a_bytes / POSB) * 16 + 2 * 50 * 16 + 2 * 50) * 4;
+    a.zstage = reinterpret_cast<float*>(flag_words + a.ticket_idx + 1 + DUO_CU_SLOTS + DUO_ITEM_CTRS);
+    hipLaunchKernelGGL((conv3x3_fp6v2_defer_kernel<7, 7>), dim3(grid), dim3(512), lds_d, stream, a);
   } else if (eight && !lag_form && !twelve && nch >= 2 && G * 8 <= DUO_ITEM_CTRS && spk_opt(SPK_OPT_V2_DUO) != 0 &&
              (long long)DUO_LDS <= spk_lds_limit()) {
     // round 5: two independent four-wave workgroups per CU on half-image items (fp6v2_body_duo)

@@ -102,8 +102,9 @@ def test_workspace_sizes_and_shape_support_are_host_side():
     assert lib.spk_select_needed_bytes(B, R) == (lists + 63) // 64 * 64 + R * B * 64
     assert lib.spk_select_needed_bytes(0, 3) == -1 and lib.spk_select_needed_bytes(4, 9) == -1
     cap = 1 << 20
-    # (+ the hand-over ticket, + the duo form's 2048 per-CU arrival counters and 128 item-claim counters)
-    assert lib.spk_den_fp6v2_flag_words(2, 64, 7, 7) == 2 + cap + (2 * 64 * 49 + 31) // 32 + 1 + 2048 + 128
+    # (+ the hand-over ticket, + the duo form's 2048 per-CU arrival counters and 128 item-claim counters, + the deferred-scan
+    #  form's staging slabs: 96 KB per workgroup = per CU; the CU count falls back to 256 without a device)
+    assert lib.spk_den_fp6v2_flag_words(2, 64, 7, 7) == 2 + cap + (2 * 64 * 49 + 31) // 32 + 1 + 2048 + 128 + 256 * 24576
     assert lib.spk_vae_fp6_flag_words(2, 32, 28, 28) == 2 + cap + (2 * 32 * 784 + 31) // 32 + 1
     assert lib.spk_vae_fp6_packed_bytes(32, 64) == 9 * 5 * 1536 and lib.spk_vae_fp6_packed_bytes(64, 16) == 2 * 9 * 3 * 1536
     assert lib.spk_vae_fp6_packed_bytes(32, 128) == -1 and lib.spk_vae_fp6_packed_bytes(48, 64) == -1

@@ -571,12 +571,60 @@ def test_fp6v2_kernel_bit_equal_to_the_exact_kernels(dev, ops, B, hw):
             assert 0.001 < float(s1.mean()) < 0.9
     torch.cuda.synchronize()
     cap = 1 << 20                                  # id-list capacity (FLAG_CAP): [count, ticket, ids..., overflow bitmap]
-    # (behind the ticket: the duo form's 2048 per-CU arrival counters -- never reset by design, only their parity is read -- and
-    #  its 128 item-claim counters, which the launch's last workgroup zeroes again)
-    assert all(int(v[0]) == 0 and int(v[2 + cap:-(2048 + 128)].abs().sum()) == 0 and int(v[-128:].abs().sum()) == 0
-               for k, v in ops._FLAG_DEFAULT.items() if k[0] == "den"), \
+    # (behind the ticket: the duo form's 2048 per-CU arrival counters -- never reset by design, only their parity is read --, its
+    #  128 item-claim counters, which the launch's last workgroup zeroes again, and the deferred-scan form's staging slabs)
+    def clean(v):
+        t = 2 + cap + (v.numel() - 2 - cap - 1 - 2048 - 128 - 256 * 24576) + 1        # end of bitmap + ticket
+        return int(v[0]) == 0 and int(v[2 + cap:t].abs().sum()) == 0 and int(v[t + 2048:t + 2048 + 128].abs().sum()) == 0
+    assert all(clean(v) for k, v in ops._FLAG_DEFAULT.items() if k[0] == "den"), \
         "live counter, overflow bitmap and hand-over ticket come back clean"
     parity(f"fp6v2_vs_fp6_B{B}_{hw}x{hw}", neuron_steps=total, spike_mismatches=mism)
+
+
+@pytest.mark.parametrize("B", [1, 3, 64, 256, 300])
+def test_fp6v2_deferred_scan_bit_equal_to_the_scan_between_k_loops(dev, ops, B):
+    """Round 5 (the default for layers of >= 4 chunks): the LIF scan of an item runs inside the K loop of the same waves' next item
+    (fp6v2_body_defer: pre-activations through a staging slab, counts summed behind the next item's first barrier, the last item of
+    a workgroup scanned the old way).  Same arithmetic in another order of events: spikes AND spike counts must equal the
+    round-2..4 form (v2_defer = 0) bit for bit -- workgroups with one item, with several, with none (B = 1, 3), ragged last rounds
+    (B = 300 over 256 workgroups), repeated launches on one workspace, and through the active-set path."""
+    from spkdiff import _lib
+    g = torch.Generator().manual_seed(900 + B)
+    prev = _lib.get_option("v2_defer")
+    total = 0
+    try:
+        for Cout, Cin in ((256, 128), (512, 256), (256, 512), (128, 64)):
+            w = ((torch.rand(Cout, Cin, 3, 3, generator=g) - 0.5) * 0.05).to(dev)
+            bias = ((torch.rand(Cout, generator=g) - 0.5) * 0.1).to(dev)
+            x = (torch.rand(16, B, Cin, 7, 7, generator=g) < 0.05).float().to(dev)
+            a = (torch.rand(Cout, generator=g) * 8 + 2).to(dev)
+            b = (torch.rand(Cout, generator=g) * 0.8).to(dev)
+            pk, xs = ops.den_pack_weight_fp6v2(w, bias), ops.spikes_to_s32(x)
+            outs = {}
+            for mode in (0, 1):
+                _lib.set_option("v2_defer", mode)
+                for rep in range(2):
+                    o, c = ops.den_conv3x3_mfma_fp6v2(xs, pk, Cout, bn_a=a, bn_b=b, want_counts=True)
+                outs[mode] = (o.clone(), c.clone())
+            nbad = int((outs[1][0] != outs[0][0]).sum())
+            assert nbad == 0 and torch.equal(outs[1][1], outs[0][1]), (Cout, Cin, nbad)
+            assert 0.001 < float(ops.s32_to_spikes(outs[0][0]).mean()) < 0.9
+            total += outs[0][0].numel() * 2
+            if B >= 3:
+                n = B // 2 + 1
+                active = torch.arange(B, dtype=torch.int32, device=dev)
+                n_act = torch.tensor([n, 0], dtype=torch.int32, device=dev)
+                res = {}
+                for mode in (0, 1):
+                    _lib.set_option("v2_defer", mode)
+                    with ops.active_set(active, n_act):
+                        o, c = ops.den_conv3x3_mfma_fp6v2(xs, pk, Cout, bn_a=a, bn_b=b, want_counts=True)
+                    res[mode] = (o[:n].clone(), c[:n].clone())
+                assert torch.equal(res[1][0], res[0][0]) and torch.equal(res[1][1], res[0][1]), (Cout, Cin, "active set")
+                assert torch.equal(res[1][0], outs[0][0][:n]), "the first n images of the full batch"
+    finally:
+        _lib.set_option("v2_defer", prev)
+    parity(f"fp6v2_deferred_scan_vs_scan_between_k_loops_B{B}", neuron_steps=total, spike_mismatches=0)
 
 
 @pytest.mark.parametrize("B", [1, 5, 64, 256])
