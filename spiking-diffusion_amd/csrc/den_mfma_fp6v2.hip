@@ -1393,7 +1393,7 @@ __device__ __forceinline__ void fp6v2_body_defer(const V2Args& a, const int g, c
     int creg[NR];
 #pragma unroll
     for (int k = 0; k < NR; ++k) creg[k] = 0;
-    ScanState ss = {0.f, 0.f, 3.0e38f, 0u};
+    ScanState ss = {0.f, 0.f, 3.0e38f, 0u}, sf = ss;
     for (int c = 0; c < nch; ++c, ++it) {
       const int buf = it & 1;
       spk_dma_wait_all();
@@ -1409,6 +1409,17 @@ __device__ __forceinline__ void fp6v2_body_defer(const V2Args& a, const int g, c
       // which tile of the previous item this chunk scans (wave-uniform): chunk k + 1 <-> tile k
       const int scan_k = (have_old && c >= 1 && c <= NT) ? c - 1 : -1;
       const int load_k = (have_old && c < NT) ? c : -1;   // tile loaded late in this chunk for the next one
+      // The finish of the tile scanned during the chunk BEFORE (certification against its position's counts, flags, transpose,
+      // stores) comes first thing behind the barrier: no fragment registers are live yet (inside the K loop the finish pushed
+      // hipcc to 310 registers), and the stores -- they share the memory counter with the copies, so the next chunk barrier's
+      // s_waitcnt vmcnt(0) waits for them -- have a whole chunk to retire (at a chunk's END they cost every barrier a store
+      // latency: +36 % on the launch, profiles/r5_ab_defer_first_build.txt).
+      if (have_old && c >= 2 && c <= NT + 1) {
+        const int fk = c - 2;
+        const int ti = wave + NWV * fk, pp = 2 * ti + half;
+        defer_finish(a, sf, zst + fk * 4 * 64, s_nmax[opar * ROWS + pp], s_row + opar * ROWS * 16 + pp * 16, cT, cE, old_b, co, g, G, HW, pp, lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (scan_k >= 0) {
         ss.v = 0.f; ss.zmax = 0.f; ss.dmin = 3.0e38f; ss.bits = 0u;
         // (the loads of the chunk before were waited for by the barrier above; this tells the compiler so BEFORE the chunk's
@@ -1417,7 +1428,6 @@ __device__ __forceinline__ void fp6v2_body_defer(const V2Args& a, const int g, c
         for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(zt[r]));
       }
       v4i rvq[NR];
-      int rs[9];                                          // (chunk 0: the nine taps of one of this thread's two row sums)
       auto compute = [&](auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         const uint8_t* A = sA + buf * A_BYTES;
@@ -1475,20 +1485,12 @@ __device__ __forceinline__ void fp6v2_body_defer(const V2Args& a, const int g, c
               int t_ = tid;
               asm volatile("" : "+v"(t_));
               if (have_old && (j == 0 || t_ + 512 < (HW - 1) * 16)) {
-                const int* c0 = row_sum_addr(t_ + 512 * j);
-#pragma unroll
-                for (int d = 0; d < 9; ++d) rs[d] = c0[((d / 3) * PW + (d % 3)) * 16];
-              }
-            }
-            if constexpr (s == 9 || s == 18) {
-              constexpr int j = s == 9 ? 0 : 1;
-              int t_ = tid;
-              asm volatile("" : "+v"(t_));
-              if (have_old && (j == 0 || t_ + 512 < (HW - 1) * 16)) {
+                // (read, sum and publish in one place: nine tap values held over a few steps were the first thing hipcc spilled)
                 const int e = t_ + 512 * j;
+                const int* c0 = row_sum_addr(e);
                 int sum = 0;
 #pragma unroll
-                for (int d = 0; d < 9; ++d) sum += rs[d];
+                for (int d = 0; d < 9; ++d) sum += c0[((d / 3) * PW + (d % 3)) * 16];
                 s_row[opar * ROWS * 16 + e] = sum;
                 atomicMax(&s_nmax[opar * ROWS + (e >> 4)], sum);
               }
@@ -1505,7 +1507,7 @@ __device__ __forceinline__ void fp6v2_body_defer(const V2Args& a, const int g, c
             }
           }
           if constexpr (s == 19) {
-            // the tile the NEXT chunk scans: zt is dead from here on (the finish below reads the slab again if it must), the
+            // the tile the NEXT chunk scans: zt is dead from here on (the finish reads the slab again if it must), the
             // loads are in flight for the rest of the chunk and are covered by the chunk barrier's s_waitcnt vmcnt(0)
             if (load_k >= 0) {
 #pragma unroll
@@ -1521,16 +1523,15 @@ __device__ __forceinline__ void fp6v2_body_defer(const V2Args& a, const int g, c
         });
       };
       if (c == 0) compute(std::true_type{}); else compute(std::false_type{});
-      // the finish of the scanned tile (certification against its position's counts, flags, transpose, stores) at the end of the
-      // chunk: the K loop's fragment registers are dead here (inside the loop the finish spilled 150 registers)
-      if (scan_k >= 0) {
-        const int ti = wave + NWV * scan_k, pp = 2 * ti + half;
-        const int nmax = s_nmax[opar * ROWS + pp];
-        const int* srp = s_row + opar * ROWS * 16 + pp * 16;
-        defer_finish(a, ss, zst + scan_k * 4 * 64, nmax, srp, cT, cE, old_b, co, g, G, HW, pp, lane);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      if (scan_k >= 0) sf = ss;                           // (finished behind the next barrier)
     }   // chunks
+    if (have_old && nch == NT + 1) {
+      // four chunks: the third tile's scan ended with the item's last chunk
+      const int fk = NT - 1, opar = par ^ 1;
+      const int ti = wave + NWV * fk, pp = 2 * ti + half;
+      defer_finish(a, sf, zst + fk * 4 * 64, s_nmax[opar * ROWS + pp], s_row + opar * ROWS * 16 + pp * 16, cT, cE, old_b, co, g, G, HW, pp, lane);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     // recombination: z_t = (P01 * 1024 + P23) * (1024 Ac) + Bc  (the first four instructions per step pair of the round-2 scan),
