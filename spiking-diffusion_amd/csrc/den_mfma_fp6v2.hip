@@ -1303,6 +1303,8 @@ __device__ __forceinline__ void fp6v2_body_defer(const V2Args& a, const int g, c
   int* const s_cin = reinterpret_cast<int*>(lds + 2 * A_BYTES + 2 * W_LDS);          // [NPP][16]
   int* const s_row = s_cin + NPP * 16;                                               // [2][ROWS][16]
   int* const s_nmax = s_row + 2 * ROWS * 16;                                         // [2][ROWS]
+  // the tile a wave scans during a chunk: [step quad][lane] float4, 4 KB per wave, filled by four LDS-DMA pieces during the chunk before
+  uint8_t* const s_z = lds + 2 * A_BYTES + 2 * W_LDS + ((NPP * 16 + 2 * ROWS * 16 + 2 * ROWS) * 4 + 15) / 16 * 16;
   const unsigned sA_addr = spk_lds_addr(sA), sW_addr = sA_addr + 2 * A_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nch = a.nch;
@@ -1372,11 +1374,11 @@ __device__ __forceinline__ void fp6v2_body_defer(const V2Args& a, const int g, c
   // nine-tap sums of the published record counts: entry e = (position, step); this thread takes e = tid and tid + 512
   auto row_sum_addr = [&](int e) -> const int* { return s_cin + (((e >> 4) / W) * PW + ((e >> 4) % W)) * 16 + (e & 15); };
 
-  // staging slab of this workgroup: [wave][tile][step quad][lane] float4 (a wave's store / load instruction moves 1 KB)
+  // staging slab of this workgroup: [wave][tile][step quad][lane] float4 (a wave's store / copy instruction moves 1 KB)
   float4* const zst = reinterpret_cast<float4*>(a.zstage) + ((long long)blockIdx.x * NWV + wave) * (NT * 4 * 64) + lane;
-  float zt[16];                                           // the tile being scanned (loaded late in the chunk before)
-#pragma unroll
-  for (int r = 0; r < 16; ++r) zt[r] = 0.f;
+  const uint8_t* const zst_w = reinterpret_cast<const uint8_t*>(a.zstage) + ((long long)blockIdx.x * NWV + wave_s) * (NT * 4 * 1024);
+  const float4* const zl = reinterpret_cast<const float4*>(s_z + wave * 4096) + lane;      // this lane's quads: zl[q * 64]
+  const unsigned zl_addr = spk_lds_addr(s_z) + (unsigned)wave_s * 4096u;
   bool have_old = false;
   int old_b = 0, par = 0;                                 // par: parity buffer that will take the counts of the CURRENT item
 
@@ -1420,14 +1422,9 @@ __device__ __forceinline__ void fp6v2_body_defer(const V2Args& a, const int g, c
         defer_finish(a, sf, zst + fk * 4 * 64, s_nmax[opar * ROWS + pp], s_row + opar * ROWS * 16 + pp * 16, cT, cE, old_b, co, g, G, HW, pp, lane);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (scan_k >= 0) {
-        ss.v = 0.f; ss.zmax = 0.f; ss.dmin = 3.0e38f; ss.bits = 0u;
-        // (the loads of the chunk before were waited for by the barrier above; this tells the compiler so BEFORE the chunk's
-        //  copies are in flight -- its own wait in front of the first use would otherwise count them too)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(zt[r]));
-      }
+      if (scan_k >= 0) { ss.v = 0.f; ss.zmax = 0.f; ss.dmin = 3.0e38f; ss.bits = 0u; }
       v4i rvq[NR];
+      float4 zq[2];                                       // (the quad being scanned and the next one)
       auto compute = [&](auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         const uint8_t* A = sA + buf * A_BYTES;
@@ -1501,20 +1498,29 @@ __device__ __forceinline__ void fp6v2_body_defer(const V2Args& a, const int g, c
               if (t_ < ROWS) s_nmax[par * ROWS + t_] = 0;
             }
           } else {
-            // chunks 1 .. 3: one LIF step of the previous item's tile scan_k per K-loop step (steps 2 .. 17)
-            if constexpr (s >= 2 && s <= 17) {
-              if (scan_k >= 0) defer_lif_step(ss, zt[s - 2]);
+            // chunks 1 .. 3: one LIF step of the previous item's tile scan_k per K-loop step (steps 2 .. 17); its pre-activations
+            // sit in this wave's LDS tile (copied there during the chunk before), read one quad (four steps) ahead
+            if constexpr (s >= 1 && s <= 17) {
+              if (scan_k >= 0) {
+                if constexpr (s == 1) zq[0] = zl[0];
+                if constexpr (s >= 2) {
+                  constexpr int r = s - 2, q = r / 4, e = r % 4;
+                  if constexpr (e == 0 && q < 3) zq[(q + 1) & 1] = zl[(q + 1) * 64];
+                  const float4 z4 = zq[q & 1];
+                  defer_lif_step(ss, e == 0 ? z4.x : e == 1 ? z4.y : e == 2 ? z4.z : z4.w);
+                }
+              }
             }
           }
-          if constexpr (s == 19) {
-            // the tile the NEXT chunk scans: zt is dead from here on (the finish reads the slab again if it must), the
-            // loads are in flight for the rest of the chunk and are covered by the chunk barrier's s_waitcnt vmcnt(0)
+          if constexpr (s >= 19 && s <= 22) {
+            // the tile the NEXT chunk scans: four 1 KB pieces from the staging slab into this wave's LDS tile (the scan above is
+            // done with it).  LDS-DMA like every other copy of the kernel: no registers, invisible to the compiler's wait
+            // insertion, landed by the chunk barrier's s_waitcnt vmcnt(0).  (As ordinary loads into sixteen registers hipcc put
+            // s_waitcnt vmcnt in the middle of the next chunk -- in front of the first reuse of one of those registers -- which
+            // waited for that chunk's copies too: +28 % on the launch, profiles/r5_ab_defer_builds.txt.)
             if (load_k >= 0) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const float4 z4 = zst[(load_k * 4 + q) * 64];
-                zt[4 * q] = z4.x; zt[4 * q + 1] = z4.y; zt[4 * q + 2] = z4.z; zt[4 * q + 3] = z4.w;
-              }
+              constexpr int q = s - 19;
+              spk_dma16s(zst_w + (load_k * 4 + q) * 1024, lane16, zl_addr + q * 1024);
             }
           }
           if constexpr (FIRST && tap == 0) SPK_MFMA2_Z("v", acc[i][1], av, bp[0][1], sc_a, sc_p);
@@ -2460,7 +2466,7 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
     else hipLaunchKernelGGL((conv3x3_fp6v2_listed_kernel<7, 7, 4>), dim3(grid), dim3(256), lds, stream, a);
   } else if (eight && !lag_form && !twelve && nch >= 4 && spk_opt(SPK_OPT_V2_DEFER) != 0 && spk_opt(SPK_OPT_V2_DUO) == 0) {
     // round 5: the scan of an item runs inside the next item's K loop (fp6v2_body_defer); two count buffers by item parity
-    const size_t lds_d = 2 * ((size_t)a_bytes + W_LDS) + (size_t)((a_bytes / POSB) * 16 + 2 * 50 * 16 + 2 * 50) * 4;
+    const size_t lds_d = 2 * ((size_t)a_bytes + W_LDS) + ((size_t)((a_bytes / POSB) * 16 + 2 * 50 * 16 + 2 * 50) * 4 + 15) / 16 * 16 + 8 * 4096;
     a.zstage = reinterpret_cast<float*>(flag_words + a.ticket_idx + 1 + DUO_CU_SLOTS + DUO_ITEM_CTRS);
     hipLaunchKernelGGL((conv3x3_fp6v2_defer_kernel<7, 7>), dim3(grid), dim3(512), lds_d, stream, a);
   } else if (eight && !lag_form && !twelve && nch >= 2 && G * 8 <= DUO_ITEM_CTRS && spk_opt(SPK_OPT_V2_DUO) != 0 &&
