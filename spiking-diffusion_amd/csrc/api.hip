@@ -31,7 +31,7 @@ SpkOption g_options[SPK_OPT_COUNT] = {
     {"v2_waves", {8}},           // SPK_OPT_V2_WAVES
     {"v2_lag", {0}},             // SPK_OPT_V2_LAG
     {"v2_duo", {0}},             // SPK_OPT_V2_DUO
-    {"v2_defer", {1}},           // SPK_OPT_V2_DEFER
+    {"v2_defer", {0}},           // SPK_OPT_V2_DEFER
 };
 }  // namespace
 

@@ -1242,6 +1242,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fp6v2_duo_kernel(V2Args a) {
 //   * What is left between two K loops: the MFMA drain, 48 packed fmas, 12 stores and two LDS writes per thread.
 // The last item of a workgroup has no successor: it is scanned the round-2 way (counts pass with two barriers, then the scan).
 // Same arithmetic, same instruction sequence per neuron: bit-equal to fp6v2_body (tests: ..._deferred_scan_bit_equal...).
+#ifndef SPK_V2_DEFER_DBG
+#define SPK_V2_DEFER_DBG 0      // timing experiments only (results are wrong): 1 = no staging stores, 2 = no finish, 4 = no LIF steps in the K loop,
+                                // 8 = no copies of the next tile, 16 = no counts pass
+#endif
 struct ScanState { float v, zmax, dmin; unsigned bits; };
 __device__ __forceinline__ void defer_lif_step(ScanState& st, const float z) {
   st.zmax = fmaxf(st.zmax, fabsf(z));
@@ -1416,7 +1420,7 @@ __device__ __forceinline__ void fp6v2_body_defer(const V2Args& a, const int g, c
       // hipcc to 310 registers), and the stores -- they share the memory counter with the copies, so the next chunk barrier's
       // s_waitcnt vmcnt(0) waits for them -- have a whole chunk to retire (at a chunk's END they cost every barrier a store
       // latency: +36 % on the launch, profiles/r5_ab_defer_first_build.txt).
-      if (have_old && c >= 2 && c <= NT + 1) {
+      if (have_old && c >= 2 && c <= NT + 1 && !(SPK_V2_DEFER_DBG & 2)) {
         const int fk = c - 2;
         const int ti = wave + NWV * fk, pp = 2 * ti + half;
         defer_finish(a, sf, zst + fk * 4 * 64, s_nmax[opar * ROWS + pp], s_row + opar * ROWS * 16 + pp * 16, cT, cE, old_b, co, g, G, HW, pp, lane);
@@ -1481,7 +1485,7 @@ __device__ __forceinline__ void fp6v2_body_defer(const V2Args& a, const int g, c
               constexpr int j = s == 3 ? 0 : 1;
               int t_ = tid;
               asm volatile("" : "+v"(t_));
-              if (have_old && (j == 0 || t_ + 512 < (HW - 1) * 16)) {
+              if (have_old && (j == 0 || t_ + 512 < (HW - 1) * 16) && !(SPK_V2_DEFER_DBG & 16)) {
                 // (read, sum and publish in one place: nine tap values held over a few steps were the first thing hipcc spilled)
                 const int e = t_ + 512 * j;
                 const int* c0 = row_sum_addr(e);
@@ -1500,7 +1504,7 @@ __device__ __forceinline__ void fp6v2_body_defer(const V2Args& a, const int g, c
           } else {
             // chunks 1 .. 3: one LIF step of the previous item's tile scan_k per K-loop step (steps 2 .. 17); its pre-activations
             // sit in this wave's LDS tile (copied there during the chunk before), read one quad (four steps) ahead
-            if constexpr (s >= 1 && s <= 17) {
+            if constexpr (s >= 1 && s <= 17 && !(SPK_V2_DEFER_DBG & 4)) {
               if (scan_k >= 0) {
                 if constexpr (s == 1) zq[0] = zl[0];
                 if constexpr (s >= 2) {
@@ -1518,7 +1522,7 @@ __device__ __forceinline__ void fp6v2_body_defer(const V2Args& a, const int g, c
             // insertion, landed by the chunk barrier's s_waitcnt vmcnt(0).  (As ordinary loads into sixteen registers hipcc put
             // s_waitcnt vmcnt in the middle of the next chunk -- in front of the first reuse of one of those registers -- which
             // waited for that chunk's copies too: +28 % on the launch, profiles/r5_ab_defer_builds.txt.)
-            if (load_k >= 0) {
+            if (load_k >= 0 && !(SPK_V2_DEFER_DBG & 8)) {
               constexpr int q = s - 19;
               spk_dma16s(zst_w + (load_k * 4 + q) * 1024, lane16, zl_addr + q * 1024);
             }
@@ -1531,7 +1535,7 @@ __device__ __forceinline__ void fp6v2_body_defer(const V2Args& a, const int g, c
       if (c == 0) compute(std::true_type{}); else compute(std::false_type{});
       if (scan_k >= 0) sf = ss;                           // (finished behind the next barrier)
     }   // chunks
-    if (have_old && nch == NT + 1) {
+    if (have_old && nch == NT + 1 && !(SPK_V2_DEFER_DBG & 2)) {
       // four chunks: the third tile's scan ended with the item's last chunk
       const int fk = NT - 1, opar = par ^ 1;
       const int ti = wave + NWV * fk, pp = 2 * ti + half;
@@ -1557,7 +1561,8 @@ __device__ __forceinline__ void fp6v2_body_defer(const V2Args& a, const int g, c
           const v2f z2 = __builtin_elementwise_fma(q4, (v2f){Ac4, Ac4}, (v2f){Bc, Bc});
           z4[e2] = z2[0]; z4[e2 + 1] = z2[1];
         }
-        zst[(i * 4 + q) * 64] = make_float4(z4[0], z4[1], z4[2], z4[3]);
+        if (!(SPK_V2_DEFER_DBG & 1)) zst[(i * 4 + q) * 64] = make_float4(z4[0], z4[1], z4[2], z4[3]);
+        else if (z4[0] + z4[1] + z4[2] + z4[3] == 12345.f) a.out[0] = 1;
       }
     }
     // publish this item's record counts (summed behind the next chunk-0 barrier -- or right here for the last item)
