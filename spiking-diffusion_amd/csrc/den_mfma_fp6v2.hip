@@ -1220,28 +1220,36 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fp6v2_duo_kernel(V2Args a) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------ deferred scan (round 5)
+// ------------------------------------------------------------------------------------------------ deferred scan (round 5, experiment)
 // What the duo experiment taught (profiles/r5_ab_duo_*.txt): two INDEPENDENT waves on a SIMD do not add up -- the matrix pipe
 // serves the older wave first, a wave on its own is bound by its instruction issue (~47 cycles per MFMA where the pipe needs 35),
 // and two of them co-running reach 75 % of the pipe, no better than the lock-step pair with its exposed scan.  The lock-step
 // pair DOES keep the pipe 89 % busy inside the K loop, and one wave's vector instructions are free beside MFMAs up to four per
-// MFMA, also when both waves of a SIMD issue them (tools/coexec_probe.hip, rows MV).  So the scan moves INTO the K loop of the
-// same waves -- the next item's: software pipelining across items.
+// MFMA, also when both waves of a SIMD issue them (tools/coexec_probe.hip, rows MV).  So here the scan moves INTO the K loop of
+// the same waves -- the next item's: software pipelining across items.
 //   * Two accumulator generations do not fit (2 x 96 of 256 registers), and neither do 48 recombined pre-activations: hipcc
-//     needs ~220 registers for the K loop as it is, spilled 150 dwords with them in VGPRs, split the file 128 / 128 with them in
+//     wants ~220 registers for the K loop as it is, spilled 150 dwords with them in VGPRs, split the file 128 / 128 with them in
 //     AGPRs, and with "amdgpu-agpr-alloc" forced through the IR still evicted half of them to scratch (reloads behind
 //     s_waitcnt vmcnt(0) inside the K loop).  So an item's pre-activations z_t (the two packed fmas per step pair the scan always
-//     started with) take the one road that costs no registers: 12 KB per wave to a per-workgroup STAGING slab in memory (L2 /
-//     MALL resident: 25 MB for the whole device, rewritten every item), and come back one tile at a time -- tile k is loaded
-//     late in chunk k (before the chunk barrier's own s_waitcnt vmcnt(0), so the load costs no wait of its own), scanned during
-//     chunk k + 1 (one LIF step per K-loop step, 7 vector instructions beside 4 MFMAs of the pair of waves), finished
-//     (certification, flags, transpose, stores) at the end of that chunk.  Needs >= 4 chunks (conv3 .. conv5).
+//     started with) go 12 KB per wave to a per-workgroup STAGING slab in memory (25 MB for the whole device, rewritten every
+//     item) and come back one tile at a time: tile k is copied into the wave's 4 KB LDS tile late in chunk k (LDS-DMA like every
+//     other copy: no registers, landed by the chunk barrier's s_waitcnt vmcnt(0)), scanned during chunk k + 1 (one LIF step per
+//     K-loop step, 7 vector instructions beside 4 MFMAs of the pair of waves) and finished (certification, flags, transpose,
+//     stores) first thing behind the barrier of chunk k + 2, where no fragment register is live.  Needs >= 4 chunks.
 //   * The active-input counts of item i (s_cin -> s_row, s_nmax) are needed by its certification only: the records are published
 //     at the end of item i, the nine-tap sums are formed during chunk 0 of item i + 1 behind its barrier (no barriers of their
 //     own any more), two buffers by item parity.
 //   * What is left between two K loops: the MFMA drain, 48 packed fmas, 12 stores and two LDS writes per thread.
 // The last item of a workgroup has no successor: it is scanned the round-2 way (counts pass with two barriers, then the scan).
-// Same arithmetic, same instruction sequence per neuron: bit-equal to fp6v2_body (tests: ..._deferred_scan_bit_equal...).
+// Same arithmetic, same instruction sequence per neuron: bit-equal to fp6v2_body (test_fp6v2_deferred_scan_bit_equal_...).
+// MEASURED (B = 256, same box, three builds: profiles/r5_ab_defer_builds.txt): den.conv3 / 4 / 5 launches 156 / 456 / 400 us
+// against 113 / 370 / 360 -- 11 - 38 % SLOWER.  With every deferred part switched off (-DSPK_V2_DEFER_DBG=31) the same loop
+// structure runs conv4 in 331 us: the scan between two K loops costs the round-4 form 8 % of the launch, not the 16 % the
+// no-epilogue ablation had suggested, and each deferred part costs more than it hides -- the staging stores 4.5 us per item (the
+// chunk barrier's s_waitcnt vmcnt(0) waits for them: stores share the memory counter with the copies), the LIF steps inside the
+// K loop 3.5 us per item (a 7-instruction dependent chain holds the in-order wave's next MFMA back, in both waves of the SIMD
+// at once), the finishes another 3 - 4.  Off by default (option v2_defer); kept with its test so that the measurement can be
+// repeated.
 #ifndef SPK_V2_DEFER_DBG
 #define SPK_V2_DEFER_DBG 0      // timing experiments only (results are wrong): 1 = no staging stores, 2 = no finish, 4 = no LIF steps in the K loop,
                                 // 8 = no copies of the next tile, 16 = no counts pass

@@ -583,7 +583,7 @@ def test_fp6v2_kernel_bit_equal_to_the_exact_kernels(dev, ops, B, hw):
 
 @pytest.mark.parametrize("B", [1, 3, 64, 256, 300])
 def test_fp6v2_deferred_scan_bit_equal_to_the_scan_between_k_loops(dev, ops, B):
-    """Round 5 (the default for layers of >= 4 chunks): the LIF scan of an item runs inside the K loop of the same waves' next item
+    """Round 5 (an opt-in, v2_defer = 1; measured slower than the default): the LIF scan of an item runs inside the K loop of the same waves' next item
     (fp6v2_body_defer: pre-activations through a staging slab, counts summed behind the next item's first barrier, the last item of
     a workgroup scanned the old way).  Same arithmetic in another order of events: spikes AND spike counts must equal the
     round-2..4 form (v2_defer = 0) bit for bit -- workgroups with one item, with several, with none (B = 1, 3), ragged last rounds
@@ -629,7 +629,7 @@ def test_fp6v2_deferred_scan_bit_equal_to_the_scan_between_k_loops(dev, ops, B):
 
 @pytest.mark.parametrize("B", [1, 5, 64, 256])
 def test_fp6v2_duo_form_bit_equal_to_the_one_workgroup_form(dev, ops, B):
-    """Round 5: full 7x7 batches run two independent four-wave workgroups per CU on half-image items (fp6v2_body_duo: weight thirds
+    """Round 5 (an opt-in, v2_duo = 1; measured slower than the default): two independent four-wave workgroups per CU on half-image items (fp6v2_body_duo: weight thirds
     in a ring, counted s_waitcnt, per-CU arrival parity + head start).  Same arithmetic, another schedule: every layer shape, with
     no head start (v2_duo = 1), a head start of 95 and of 400 ticks per chunk, must give the spikes AND the spike counts
     of the one-workgroup form (v2_duo = 0) bit for bit -- also through the active-set path (a device-side image count below B)."""
