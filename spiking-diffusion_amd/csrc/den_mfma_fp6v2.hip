@@ -814,6 +814,16 @@ __device__ __forceinline__ void fp6v2_handover(const V2Args& a) {
 //     the last two stages (K = the smallest count over the four waves' piece shares: waves with more pieces wait for a little more
 //     than they must).  The image slab of the next chunk is issued in stage 0 only (three stages before its first use).  The
 //     epilogue's stores share the counter and may retire out of order with the copies: the first barrier of every item drains it.
+// MEASURED (B = 256, same box, two builds: profiles/r5_ab_duo_first_build.txt, r5_ab_duo_second_build.txt; bit-equal to the
+// one-workgroup form on every shape, test_fp6v2_duo_form_bit_equal_...): den.conv4 380 - 400 us against 362 - 382, the dense reverse
+// process 90.0 / 95.6 ms against 85.8 / 91.8 -- 4 - 5 % SLOWER, although the phase picture (tools/duo_phase.py, s_memrealtime
+// stamps per item) shows what was asked for: 0.77 - 0.89 of a workgroup's scan time lies inside its partner's K loops, with or
+// without a head start.  What stops it: the matrix pipe serves the OLDER wave of a SIMD first (per item 17 us for one workgroup
+// of a CU, 27 us for the other: the first build left the slower one alone for the last fifth of the launch; item claiming fixed
+// that, not the rate), a wave alone issues an MFMA every ~47 cycles (it is bound by its own instruction issue: ~6.5 instructions
+// per MFMA at one per ~5 cycles), and two co-running waves of different workgroups reach one per ~44 cycles of the pipe where
+// the lock-step pair of the one-workgroup form reaches one per 39.5 inside its K loop -- 75 % of the pipe over the launch either
+// way.  Off by default (option v2_duo); kept with its test and the phase tool so that the measurement can be repeated.
 #ifndef SPK_V2_DUO_SLOTS
 #define SPK_V2_DUO_SLOTS 5      // thirds in the weight ring.  5: the third of stage n + 1 has landed at the barrier of stage n, so the first
                                 // tap's fragments of a stage are read during the stage before (no LDS round trip behind a stage barrier);
