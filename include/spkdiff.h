@@ -391,6 +391,24 @@ int spk_vq_argmin(const float* flat_x, const float* codebook, long long* idx_out
 int spk_embedding_fwd(const long long* tokens, const float* codebook, float* out, long long N, int D, int K, int HW,
                       int nchw, spk_stream_t stream);
 
+/* Training branch of VectorQuantizer.forward, R/snn_model/vae_model.py:61-85 (through autograd in the reference: ~40 element-wise,
+ * reduce and embedding-backward launches), csrc/vq_train.hip.  Rows are the NHWC positions (N = B * HW).
+ * spk_vq_train_readout: x_seq fp32 [T,B,D,HW] -> xm [N,D] = (1 - alpha) * sum_t x[t] * coef[t] + alpha * sum_t x[t] / T and
+ *   dxa [N,D] = d xm / d alpha.  (The code search on xm is spk_vq_argmin.)
+ * spk_vq_train_quant: out_bdhw fp32 [B,D,HW] = xm + (E[idx] - xm) (the straight-through value) and loss_out[0] =
+ *   mse(q, xm) + beta * mse(xm, q).  ws: spk_vq_train_ws_bytes() bytes, zero-initialised once, clean again after every call.
+ * spk_vq_train_bwd: gout_bdhw = dL/d out, gloss_or_null [1] = dL/d loss (device) -> gx_seq [T,B,D,HW], galpha_out [1],
+ *   gcodebook_out [K,D] (one workgroup per code, fixed summation order).  SPK_ERR_UNSUPPORTED for D > 64. */
+long long spk_vq_train_ws_bytes(void);
+int spk_vq_train_readout(const float* x_seq, const float* coef, const float* alpha, float* xm_out, float* dxa_out, int T, int B,
+                         int D, int HW, spk_stream_t stream);
+int spk_vq_train_quant(const float* xm, const long long* idx, const float* codebook, float* out_bdhw, float* loss_out, float beta,
+                       void* ws, long long N, int D, int HW, spk_stream_t stream);
+int spk_vq_train_bwd(const float* gout_bdhw, const float* gloss_or_null, const float* xm, const long long* idx,
+                     const float* codebook, const float* dxa, const float* coef, const float* alpha, float beta, float* gx_seq,
+                     float* galpha_out, float* gcodebook_out, void* ws, int T, long long N, int D, int HW, int K,
+                     spk_stream_t stream);
+
 /* Weight gradient of a 3x3 / stride 1 / pad 1 convolution over a SPIKE input (training step of the denoiser's conv2..conv6,
  * R/snn_model/vq_diffusion.py:166-187 through autograd; the reference runs the library's fp32 kernels):
  * gw[co][ky][kx][ci] = sum_{n,y,x} gy[n,co,y,x] * s[n,ci,y+ky-1,x+kx-1] on the bf16 matrix cores -- the spikes are exact in bf16,

@@ -42,6 +42,7 @@ class VectorQuantizer(nn.Module):
         self.psp = PSP()
         self.alpha = nn.Parameter(torch.tensor(0.5))
         self.embeddings = nn.Embedding(self.num_embeddings, self.embedding_dim)
+        self.fused_train = True              # training branch: ops.VQTrainFunction (False: the same algebra op by op through autograd)
         self.poisson = FusedSequential(
             layer.Conv2d(in_channels=embedding_dim, out_channels=embedding_dim, kernel_size=1),
             layer.BatchNorm2d(embedding_dim),
@@ -78,16 +79,22 @@ class VectorQuantizer(nn.Module):
         if not torch.is_grad_enabled():
             _training_oos('VectorQuantizer.forward in train() mode without autograd')
         T = x.shape[0]
-        x_memout = (1 - self.alpha) * self.memout(x) + self.alpha * torch.sum(x, dim=0) / self.num_step
-        x_memout = x_memout.permute(0, 2, 3, 1).contiguous()
-        flat_x = x_memout.reshape(-1, self.embedding_dim)
-        encoding_indices = self.get_code_indices(flat_x.detach())
-        quantized = F.embedding(encoding_indices, self.embeddings.weight).view_as(x_memout)
-        q_latent_loss = F.mse_loss(quantized, x_memout.detach())
-        e_latent_loss = F.mse_loss(x_memout, quantized.detach())
-        loss_1 = q_latent_loss + self.commitment_cost * e_latent_loss
-        quantized = x_memout + (quantized - x_memout).detach()           # straight-through estimator
-        quantized = quantized.permute(0, 3, 1, 2).contiguous()
+        if self.fused_train and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and T == self.memout.coef.numel():
+            # read-out, code search, q / e latent losses, straight-through value: three native launches forward, one backward
+            # (ops.VQTrainFunction; the module-by-module algebra below is the same arithmetic through autograd)
+            quantized, loss_1 = ops.VQTrainFunction.apply(x, self.memout.coef, self.alpha, self.embeddings.weight,
+                                                          self.commitment_cost)
+        else:
+            x_memout = (1 - self.alpha) * self.memout(x) + self.alpha * torch.sum(x, dim=0) / self.num_step
+            x_memout = x_memout.permute(0, 2, 3, 1).contiguous()
+            flat_x = x_memout.reshape(-1, self.embedding_dim)
+            encoding_indices = self.get_code_indices(flat_x.detach())
+            quantized = F.embedding(encoding_indices, self.embeddings.weight).view_as(x_memout)
+            q_latent_loss = F.mse_loss(quantized, x_memout.detach())
+            e_latent_loss = F.mse_loss(x_memout, quantized.detach())
+            loss_1 = q_latent_loss + self.commitment_cost * e_latent_loss
+            quantized = x_memout + (quantized - x_memout).detach()           # straight-through estimator
+            quantized = quantized.permute(0, 3, 1, 2).contiguous()
         quantized = torch.unsqueeze(quantized, dim=0).repeat(T, 1, 1, 1, 1)
         quantized = self.poisson(quantized)
         # psp(x.detach()) and psp(x).detach() are the same numbers: each filter runs once

@@ -1484,6 +1484,61 @@ def vq_argmin(flat_x, codebook):
     return idx
 
 
+_VQ_TRAIN_WS = {}
+
+
+def _vq_train_ws(device):
+    ws = _VQ_TRAIN_WS.get(device)
+    if ws is None:
+        ws = _VQ_TRAIN_WS[device] = torch.zeros(int(lib.spk_vq_train_ws_bytes()), dtype=torch.uint8, device=device)
+    return ws
+
+
+class VQTrainFunction(torch.autograd.Function):
+    """Training branch of VectorQuantizer.forward up to the spike generator (R/snn_model/vae_model.py:61-78): read-out, code
+    search, VQ + commitment loss and the straight-through value as three launches (spk_vq_train_readout, spk_vq_argmin,
+    spk_vq_train_quant); the backward -- gradients of the encoder spikes, of alpha and of the codebook -- is one
+    (spk_vq_train_bwd: the codebook rows are summed by one workgroup per code in a fixed order).
+    apply(x_seq [T,B,D,h,w], coef [T], alpha [] , codebook [K,D], beta) -> (quantized [B,D,h,w], loss_1 [])."""
+
+    @staticmethod
+    def forward(ctx, x_seq, coef, alpha, codebook, beta):
+        x = _dev(x_seq.detach(), "x_seq", torch.float32)
+        T, B, D, h, w = x.shape
+        HW, N = h * w, B * h * w
+        cf = _dev(coef.detach().flatten(), "coef", torch.float32)
+        al = _dev(alpha.detach().reshape(1), "alpha", torch.float32)
+        E = _dev(codebook.detach(), "codebook", torch.float32)
+        xm = torch.empty((N, D), dtype=torch.float32, device=x.device)
+        dxa = torch.empty_like(xm)
+        check(lib.spk_vq_train_readout(_p(x), _p(cf), _p(al), _p(xm), _p(dxa), T, B, D, HW, _stream(x)), "spk_vq_train_readout")
+        idx = vq_argmin(xm, E)
+        out = torch.empty((B, D, h, w), dtype=torch.float32, device=x.device)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        check(lib.spk_vq_train_quant(_p(xm), _p(idx), _p(E), _p(out), _p(loss), float(beta), _p(_vq_train_ws(x.device)), N, D, HW,
+                                     _stream(x)), "spk_vq_train_quant")
+        ctx.save_for_backward(xm, idx, E, dxa, cf, al)
+        ctx.cfg = (T, B, D, h, w, float(beta), tuple(alpha.shape))
+        ctx.mark_non_differentiable(idx)
+        ctx.indices = idx
+        return out, loss
+
+    @staticmethod
+    def backward(ctx, g_out, g_loss):
+        xm, idx, E, dxa, cf, al = ctx.saved_tensors
+        T, B, D, h, w, beta, ashape = ctx.cfg
+        N, K = B * h * w, E.shape[0]
+        go = torch.zeros((B, D, h, w), dtype=torch.float32, device=xm.device) if g_out is None else g_out.contiguous()
+        gl = None if g_loss is None else g_loss.reshape(1).contiguous()
+        gx = torch.empty((T, B, D, h, w), dtype=torch.float32, device=xm.device)
+        ga = torch.empty(1, dtype=torch.float32, device=xm.device)
+        gE = torch.empty_like(E)
+        with timed("train.vq_bwd"):
+            check(lib.spk_vq_train_bwd(_p(go), _p(gl), _p(xm), _p(idx), _p(E), _p(dxa), _p(cf), _p(al), beta, _p(gx), _p(ga), _p(gE),
+                                       _p(_vq_train_ws(xm.device)), T, N, D, h * w, K, _stream(xm)), "spk_vq_train_bwd")
+        return gx, None, ga.reshape(ashape), gE, None
+
+
 def embedding(tokens, codebook, nchw_hw=None):
     """nn.Embedding lookup; nchw_hw=(h,w) writes [B,D,h,w] for tokens [B,h,w]."""
     tokens = _dev(tokens, "tokens", torch.int64)

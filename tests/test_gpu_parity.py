@@ -1389,6 +1389,46 @@ def test_psp_filter_and_adjoint_vs_oracle(dev, ops, shape):
     assert float((xd.grad.cpu() - xo.grad).abs().max()) <= 1e-5 * float(xo.grad.abs().max())
 
 
+@pytest.mark.parametrize("B,hw,D,K", [(4, 7, 16, 128), (32, 7, 16, 128), (3, 8, 16, 128), (2, 5, 8, 37)])
+def test_vq_train_function_vs_op_by_op_autograd(dev, ops, B, hw, D, K):
+    """ops.VQTrainFunction (spk_vq_train_readout / spk_vq_argmin / spk_vq_train_quant forward, spk_vq_train_bwd backward) against
+    the same algebra written op by op through autograd -- the reference's lines, R/snn_model/vae_model.py:61-78: read-out, nearest
+    code, q / e latent losses, straight-through estimator.  Same indices, same values; gradients of the spikes, of alpha and of
+    the codebook (fixed-order sums instead of the framework's atomics) to fp32 round-off."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(B * 100 + hw)
+    T = 16
+    x = (torch.rand(T, B, D, hw, hw, generator=g) < 0.3).float().to(dev)
+    coef = torch.pow(torch.tensor(0.8), torch.arange(T - 1, -1, -1).float()).to(dev)
+    E0 = (torch.randn(K, D, generator=g) * 0.7).to(dev)
+    gq = torch.randn(B, D, hw, hw, generator=g).to(dev)
+    res = {}
+    for mode in ("fused", "autograd"):
+        xs = x.clone().requires_grad_(True)
+        alpha = torch.tensor(0.37, device=dev, requires_grad=True)
+        E = E0.clone().requires_grad_(True)
+        if mode == "fused":
+            q, loss = ops.VQTrainFunction.apply(xs, coef, alpha, E, 0.25)
+        else:
+            xm = (1 - alpha) * torch.sum(xs * coef.view(T, 1, 1, 1, 1), dim=0) + alpha * torch.sum(xs, dim=0) / T
+            xm = xm.permute(0, 2, 3, 1).contiguous()
+            idx = ops.vq_argmin(xm.reshape(-1, D).detach(), E)
+            qq = F.embedding(idx, E).view_as(xm)
+            loss = F.mse_loss(qq, xm.detach()) + 0.25 * F.mse_loss(xm, qq.detach())
+            q = (xm + (qq - xm).detach()).permute(0, 3, 1, 2).contiguous()
+        ((q * gq).sum() + 3.0 * loss).backward()
+        res[mode] = (q.detach(), loss.detach(), xs.grad, alpha.grad, E.grad)
+    qa, la, gxa, gaa, gEa = res["autograd"]
+    qf, lf, gxf, gaf, gEf = res["fused"]
+    assert float((qf - qa).abs().max()) <= 1e-6 * (1 + float(qa.abs().max()))
+    assert abs(float(lf) - float(la)) <= 2e-6 * abs(float(la))
+    assert _rel_l2(gxf, gxa) <= 2e-6 and _rel_l2(gEf, gEa) <= 2e-6
+    assert abs(float(gaf) - float(gaa)) <= 2e-5 * (abs(float(gaa)) + 1e-3)
+    parity(f"vq_train_function_B{B}_{hw}x{hw}_D{D}_K{K}", loss_rel=abs(float(lf) - float(la)) / abs(float(la)),
+           grad_x_rel_l2=_rel_l2(gxf, gxa), grad_codebook_rel_l2=_rel_l2(gEf, gEa),
+           grad_alpha_rel=abs(float(gaf) - float(gaa)) / (abs(float(gaa)) + 1e-12))
+
+
 def test_f10_vqvae_train_step_vs_reference_fixture(golden_dir, dev):
     """SURVEY §8f item 2 (second half): SNN_VQVAE.forward in train() mode and (loss_eq + loss_rec).backward() as
     R/main.py:136-142 runs it -- library (transposed) convolutions, native BatchNorm+LIF block tails, membrane read-out,

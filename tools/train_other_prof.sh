@@ -10,7 +10,7 @@ import collections, csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # iterations: cut at a kernel that runs exactly once per iteration (the loss kernel / the codebook's gradient)
-key = "masked_ce_kernel" if sys.argv[3] == "diff8x8" else "embedding_backward"
+key = "masked_ce_kernel" if sys.argv[3] == "diff8x8" else "vq_train_bwd_kernel"
 cuts = [i for i, r in enumerate(rows) if key in r["Kernel_Name"]]
 n_it = 8
 seg = rows[cuts[-n_it - 1]:cuts[-1]]
