@@ -404,6 +404,20 @@ int spk_vq_train_readout(const float* x_seq, const float* coef, const float* alp
                          int D, int HW, spk_stream_t stream);
 int spk_vq_train_quant(const float* xm, const long long* idx, const float* codebook, float* out_bdhw, float* loss_out, float beta,
                        void* ws, long long N, int D, int HW, spk_stream_t stream);
+/* The PSP losses of the same branch, R/snn_model/vae_model.py:79-84: loss_out[0] = mean((psp(q) - psp(x))^2) * (1 + beta) over dense
+ * [T][N] fp32 tensors (both filters in registers, nothing stored), and its backward: gq_seq = dL/dq, gx_seq = dL/dx (the commitment
+ * factor beta on x) from gloss [1] (device) through the adjoint filters -- one launch each.  ws as for spk_vq_train_quant.
+ * spk_psp_loss_bwd: SPK_ERR_UNSUPPORTED for T > 16. */
+int spk_psp_loss_fwd(const float* q_seq, const float* x_seq, float* loss_out, float beta, float tau_s, void* ws, int T, long long N,
+                     spk_stream_t stream);
+int spk_psp_loss_bwd(const float* q_seq, const float* x_seq, const float* gloss, float* gq_seq, float* gx_seq, float beta,
+                     float tau_s, int T, long long N, spk_stream_t stream);
+/* Reconstruction loss of SNN_VQVAE.forward in training, R/snn_model/vae_model.py:189-196: xr_out [N] = tanh(sum_t y[t] * coef[t]),
+ * loss_out[0] = mean((xr - image)^2) over N = B*C*H*W elements (one launch), and gy_seq [T][N] = dL/dy from gloss [1] (one launch). */
+int spk_recon_loss_fwd(const float* y_seq, const float* coef, const float* image, float* xr_out, float* loss_out, void* ws, int T,
+                       long long N, spk_stream_t stream);
+int spk_recon_loss_bwd(const float* xr, const float* image, const float* coef, const float* gloss, float* gy_seq, int T, long long N,
+                       spk_stream_t stream);
 int spk_vq_train_bwd(const float* gout_bdhw, const float* gloss_or_null, const float* xm, const long long* idx,
                      const float* codebook, const float* dxa, const float* coef, const float* alpha, float beta, float* gx_seq,
                      float* galpha_out, float* gcodebook_out, void* ws, int T, long long N, int D, int HW, int K,

@@ -160,6 +160,95 @@ __global__ __launch_bounds__(256) void vq_train_bwd_kernel(const float* __restri
   }
 }
 
+// PSP losses of the same branch (R/snn_model/vae_model.py:79-84; filter: R/snn_model/snn_layers.py:12-26):
+//   loss_2 = mean((psp(q) - sg(psp(x)))^2) + beta * mean((sg(psp(q)) - psp(x))^2),   syn_t = syn_{t-1} + (in_t - syn_{t-1}) / tau_s.
+// Forward: both filters run in registers, nothing but the sum of squares leaves the launch.  Backward: the filters are run
+// again (T differences kept in registers), then both adjoint filters backwards over t: g_q[t] and g_x[t] in one launch.
+template <int TMAX>
+__global__ __launch_bounds__(256) void psp_loss_fwd_kernel(const float* __restrict__ q, const float* __restrict__ x,
+                                                           float* __restrict__ loss, float beta, float tau, double* ws_part,
+                                                           unsigned* ticket, int T, long long N) {
+  __shared__ double red[256];
+  double part = 0.0;
+  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long long)gridDim.x * blockDim.x) {
+    float sq = 0.f, sx = 0.f;
+    for (int t = 0; t < T; ++t) {
+      sq = sq + (q[(long long)t * N + n] - sq) / tau;
+      sx = sx + (x[(long long)t * N + n] - sx) / tau;
+      const float d = sq - sx;
+      part += (double)(d * d);
+    }
+  }
+  double tot = 0.0;
+  if (vt_block_sum(part, red, ws_part, ticket, tot)) {
+    const float m = (float)(tot / ((double)T * (double)N));
+    loss[0] = m + beta * m;
+  }
+}
+
+template <int TMAX>
+__global__ __launch_bounds__(256) void psp_loss_bwd_kernel(const float* __restrict__ q, const float* __restrict__ x,
+                                                           const float* __restrict__ gloss, float* __restrict__ gq,
+                                                           float* __restrict__ gx, float beta, float tau, int T, long long N) {
+  const float inv_tau = 1.0f / tau, carry = 1.0f - inv_tau;
+  const float c = gloss[0] * (2.0f / ((float)T * (float)N));
+  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long long)gridDim.x * blockDim.x) {
+    float d[TMAX];
+    float sq = 0.f, sx = 0.f;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+      if (t < T) {
+        sq = sq + (q[(long long)t * N + n] - sq) / tau;
+        sx = sx + (x[(long long)t * N + n] - sx) / tau;
+        d[t] = sq - sx;
+      }
+    }
+    float aq = 0.f, ax = 0.f;                               // the adjoint filters (spk_psp, backward)
+#pragma unroll
+    for (int i = 0; i < TMAX; ++i) {
+      const int t = TMAX - 1 - i;
+      if (t < T) {
+        const float Gq = aq + c * d[t], Gx = ax - (beta * c) * d[t];
+        gq[(long long)t * N + n] = Gq * inv_tau;
+        gx[(long long)t * N + n] = Gx * inv_tau;
+        aq = Gq * carry;
+        ax = Gx * carry;
+      }
+    }
+  }
+}
+
+// Reconstruction loss of SNN_VQVAE.forward in training (R/snn_model/vae_model.py:189-196): x_recon = tanh(sum_t y[t] * coef[t]),
+// loss = mean((x_recon - image)^2); backward g_y[t] = g_loss * 2 (x_recon - image) / N * (1 - x_recon^2) * coef[t].
+__global__ __launch_bounds__(256) void recon_loss_fwd_kernel(const float* __restrict__ y, const float* __restrict__ coef,
+                                                             const float* __restrict__ img, float* __restrict__ xr,
+                                                             float* __restrict__ loss, double* ws_part, unsigned* ticket, int T,
+                                                             long long N) {
+  __shared__ double red[256];
+  double part = 0.0;
+  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long long)gridDim.x * blockDim.x) {
+    float m = 0.f;
+    for (int t = 0; t < T; ++t) m = m + y[(long long)t * N + n] * coef[t];
+    const float r = tanhf(m);
+    xr[n] = r;
+    const float d = r - img[n];
+    part += (double)(d * d);
+  }
+  double tot = 0.0;
+  if (vt_block_sum(part, red, ws_part, ticket, tot)) loss[0] = (float)(tot / (double)N);
+}
+
+__global__ __launch_bounds__(256) void recon_loss_bwd_kernel(const float* __restrict__ xr, const float* __restrict__ img,
+                                                             const float* __restrict__ coef, const float* __restrict__ gloss,
+                                                             float* __restrict__ gy, int T, long long N) {
+  const float c = gloss[0] * (2.0f / (float)N);
+  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long long)gridDim.x * blockDim.x) {
+    const float r = xr[n];
+    const float g = (c * (r - img[n])) * (1.0f - r * r);
+    for (int t = 0; t < T; ++t) gy[(long long)t * N + n] = g * coef[t];
+  }
+}
+
 static int vt_blocks(long long n) {
   long long g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > VT_MAX_BLOCKS ? VT_MAX_BLOCKS : g));
@@ -202,6 +291,46 @@ extern "C" int spk_vq_train_bwd(const float* gout_bdhw, const float* gloss_or_nu
   const int nb_x = vt_blocks(N * D);
   hipLaunchKernelGGL(vq_train_bwd_kernel, dim3(nb_x + K), dim3(256), 0, stream, gout_bdhw, gloss_or_null, xm, idx, codebook, dxa,
                      coef, alpha, beta, gx_seq, galpha_out, gcodebook_out, part, ticket, nb_x, T, N, D, HW, K);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_psp_loss_fwd(const float* q_seq, const float* x_seq, float* loss_out, float beta, float tau_s, void* ws, int T,
+                                long long N, hipStream_t stream) {
+  if (!q_seq || !x_seq || !loss_out || !ws || T <= 0 || N <= 0 || !(tau_s > 0.f)) return SPK_ERR_ARG;
+  double* part = reinterpret_cast<double*>(ws);
+  unsigned* ticket = reinterpret_cast<unsigned*>(part + VT_MAX_BLOCKS);
+  hipLaunchKernelGGL((psp_loss_fwd_kernel<16>), dim3(vt_blocks(N)), dim3(256), 0, stream, q_seq, x_seq, loss_out, beta, tau_s, part,
+                     ticket, T, N);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_psp_loss_bwd(const float* q_seq, const float* x_seq, const float* gloss, float* gq_seq, float* gx_seq, float beta,
+                                float tau_s, int T, long long N, hipStream_t stream) {
+  if (!q_seq || !x_seq || !gloss || !gq_seq || !gx_seq || T <= 0 || N <= 0 || !(tau_s > 0.f)) return SPK_ERR_ARG;
+  if (T > 16) return SPK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((psp_loss_bwd_kernel<16>), dim3(vt_blocks(N)), dim3(256), 0, stream, q_seq, x_seq, gloss, gq_seq, gx_seq, beta,
+                     tau_s, T, N);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_recon_loss_fwd(const float* y_seq, const float* coef, const float* image, float* xr_out, float* loss_out, void* ws,
+                                  int T, long long N, hipStream_t stream) {
+  if (!y_seq || !coef || !image || !xr_out || !loss_out || !ws || T <= 0 || N <= 0) return SPK_ERR_ARG;
+  double* part = reinterpret_cast<double*>(ws);
+  unsigned* ticket = reinterpret_cast<unsigned*>(part + VT_MAX_BLOCKS);
+  hipLaunchKernelGGL(recon_loss_fwd_kernel, dim3(vt_blocks(N)), dim3(256), 0, stream, y_seq, coef, image, xr_out, loss_out, part,
+                     ticket, T, N);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+extern "C" int spk_recon_loss_bwd(const float* xr, const float* image, const float* coef, const float* gloss, float* gy_seq, int T,
+                                  long long N, hipStream_t stream) {
+  if (!xr || !image || !coef || !gloss || !gy_seq || T <= 0 || N <= 0) return SPK_ERR_ARG;
+  hipLaunchKernelGGL(recon_loss_bwd_kernel, dim3(vt_blocks(N)), dim3(256), 0, stream, xr, image, coef, gloss, gy_seq, T, N);
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

@@ -97,11 +97,15 @@ class VectorQuantizer(nn.Module):
             quantized = quantized.permute(0, 3, 1, 2).contiguous()
         quantized = torch.unsqueeze(quantized, dim=0).repeat(T, 1, 1, 1, 1)
         quantized = self.poisson(quantized)
-        # psp(x.detach()) and psp(x).detach() are the same numbers: each filter runs once
-        pq, px = self.psp(quantized), self.psp(x)
-        q_latent_loss_2 = torch.mean((pq - px.detach()) ** 2)
-        e_latent_loss_2 = torch.mean((pq.detach() - px) ** 2)
-        loss_2 = q_latent_loss_2 + self.commitment_cost * e_latent_loss_2
+        if self.fused_train and quantized.is_cuda and quantized.shape == x.shape and T <= 16:
+            # both PSP filters, both mean squares and their backward: one launch each way (ops.PSPLossFunction)
+            loss_2 = ops.PSPLossFunction.apply(quantized, x, self.commitment_cost, float(self.psp.tau_s))
+        else:
+            # psp(x.detach()) and psp(x).detach() are the same numbers: each filter runs once
+            pq, px = self.psp(quantized), self.psp(x)
+            q_latent_loss_2 = torch.mean((pq - px.detach()) ** 2)
+            e_latent_loss_2 = torch.mean((pq.detach() - px) ** 2)
+            loss_2 = q_latent_loss_2 + self.commitment_cost * e_latent_loss_2
         return quantized, loss_1 + loss_2
 
     def get_code_indices(self, flat_x):
@@ -190,8 +194,12 @@ class SNN_VQVAE(nn.Module):
                 _training_oos('SNN_VQVAE.forward in train() mode without autograd')
             z = self.encoder(x)
             e, e_q_loss = self.vq_layer(z)
-            x_recon = torch.tanh(self.memout(self.decoder(e)))
-            real_recon_loss = F.mse_loss(x_recon, image)
+            y = self.decoder(e)
+            if self.vq_layer.fused_train and y.is_cuda and y.shape[1:] == image.shape and image.dtype == torch.float32:
+                real_recon_loss = ops.ReconLossFunction.apply(y, self.memout.coef, image)      # read-out + tanh + mse: one launch
+            else:
+                x_recon = torch.tanh(self.memout(y))
+                real_recon_loss = F.mse_loss(x_recon, image)
             return e_q_loss, real_recon_loss / self.data_variance, real_recon_loss
         T = x.shape[0]
         enc = self.encoder.snn_convs

@@ -105,6 +105,10 @@ _SIGS = {
     "spk_vq_train_ws_bytes": (c_longlong, []),
     "spk_vq_train_readout": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "spk_vq_train_quant": (c_int, [P, P, P, P, P, c_float, P, c_longlong, c_int, c_int, P]),
+    "spk_psp_loss_fwd": (c_int, [P, P, P, c_float, c_float, P, c_int, c_longlong, P]),
+    "spk_psp_loss_bwd": (c_int, [P, P, P, P, P, c_float, c_float, c_int, c_longlong, P]),
+    "spk_recon_loss_fwd": (c_int, [P, P, P, P, P, P, c_int, c_longlong, P]),
+    "spk_recon_loss_bwd": (c_int, [P, P, P, P, P, c_int, c_longlong, P]),
     "spk_vq_train_bwd": (c_int, [P, P, P, P, P, P, P, P, c_float, P, P, P, P, c_int, c_longlong, c_int, c_int, c_int, P]),
     "spk_select_active": (c_int, [P, c_int, P, c_ulonglong, c_ulonglong, P, P, P, c_int, c_int, c_int, P]),
     "spk_readout_collapsed_fwd": (c_int, [P, P, P, c_float, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

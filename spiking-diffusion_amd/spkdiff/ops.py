@@ -1539,6 +1539,71 @@ class VQTrainFunction(torch.autograd.Function):
         return gx, None, ga.reshape(ashape), gE, None
 
 
+class PSPLossFunction(torch.autograd.Function):
+    """loss_2 of VectorQuantizer.forward (R/snn_model/vae_model.py:79-84): mean((psp(q) - sg(psp(x)))^2) + beta * mean((sg(psp(q)) -
+    psp(x))^2) over spike tensors [T, ...] -- one launch forward (spk_psp_loss_fwd: both filters in registers), one backward
+    (spk_psp_loss_bwd: both adjoint filters) instead of four filter launches and ~16 element-wise / reduce launches.
+    apply(q_seq, x_seq, beta, tau_s) -> loss []."""
+
+    @staticmethod
+    def forward(ctx, q_seq, x_seq, beta, tau_s):
+        q = _dev(q_seq.detach(), "q_seq", torch.float32)
+        x = _dev(x_seq.detach(), "x_seq", torch.float32)
+        if q.shape != x.shape:
+            raise ValueError(f"PSP loss: shapes {tuple(q.shape)} and {tuple(x.shape)} differ")
+        T, N = q.shape[0], q[0].numel()
+        if T > 16:
+            raise NotImplementedError("spk_psp_loss: at most 16 time steps")
+        loss = torch.empty((), dtype=torch.float32, device=q.device)
+        check(lib.spk_psp_loss_fwd(_p(q), _p(x), _p(loss), float(beta), float(tau_s), _p(_vq_train_ws(q.device)), T, N, _stream(q)),
+              "spk_psp_loss_fwd")
+        ctx.save_for_backward(q, x)
+        ctx.cfg = (float(beta), float(tau_s))
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        q, x = ctx.saved_tensors
+        beta, tau_s = ctx.cfg
+        T, N = q.shape[0], q[0].numel()
+        gq, gx = torch.empty_like(q), torch.empty_like(x)
+        with timed("train.psp_loss_bwd"):
+            check(lib.spk_psp_loss_bwd(_p(q), _p(x), _p(g_loss.reshape(1).contiguous()), _p(gq), _p(gx), beta, tau_s, T, N, _stream(q)),
+                  "spk_psp_loss_bwd")
+        return gq, gx, None, None
+
+
+class ReconLossFunction(torch.autograd.Function):
+    """mse_loss(tanh(memout(y)), image) of SNN_VQVAE.forward in training (R/snn_model/vae_model.py:189-196): read-out, tanh and the
+    mean square as one launch, the gradient of the decoder's output as another (spk_recon_loss_fwd / _bwd).
+    apply(y_seq [T,B,C,H,W], coef [T], image [B,C,H,W]) -> loss []."""
+
+    @staticmethod
+    def forward(ctx, y_seq, coef, image):
+        y = _dev(y_seq.detach(), "y_seq", torch.float32)
+        img = _dev(image.detach(), "image", torch.float32)
+        cf = _dev(coef.detach().flatten(), "coef", torch.float32)
+        T, N = y.shape[0], y[0].numel()
+        if img.numel() != N or cf.numel() != T:
+            raise ValueError(f"recon loss: y {tuple(y.shape)}, image {tuple(img.shape)}, coef {tuple(cf.shape)}")
+        xr = torch.empty_like(img)
+        loss = torch.empty((), dtype=torch.float32, device=y.device)
+        check(lib.spk_recon_loss_fwd(_p(y), _p(cf), _p(img), _p(xr), _p(loss), _p(_vq_train_ws(y.device)), T, N, _stream(y)),
+              "spk_recon_loss_fwd")
+        ctx.save_for_backward(xr, img, cf)
+        ctx.shape = tuple(y.shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        xr, img, cf = ctx.saved_tensors
+        gy = torch.empty(ctx.shape, dtype=torch.float32, device=xr.device)
+        with timed("train.recon_loss_bwd"):
+            check(lib.spk_recon_loss_bwd(_p(xr), _p(img), _p(cf), _p(g_loss.reshape(1).contiguous()), _p(gy), ctx.shape[0], xr.numel(),
+                                         _stream(xr)), "spk_recon_loss_bwd")
+        return gy, None, None
+
+
 def embedding(tokens, codebook, nchw_hw=None):
     """nn.Embedding lookup; nchw_hw=(h,w) writes [B,D,h,w] for tokens [B,h,w]."""
     tokens = _dev(tokens, "tokens", torch.int64)

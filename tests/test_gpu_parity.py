@@ -1429,6 +1429,55 @@ def test_vq_train_function_vs_op_by_op_autograd(dev, ops, B, hw, D, K):
            grad_alpha_rel=abs(float(gaf) - float(gaa)) / (abs(float(gaa)) + 1e-12))
 
 
+@pytest.mark.parametrize("shape", [(16, 4, 16, 7, 7), (16, 32, 16, 7, 7), (9, 3, 5, 3, 3)])
+def test_psp_loss_function_vs_op_by_op_autograd(dev, ops, shape):
+    """ops.PSPLossFunction (spk_psp_loss_fwd / _bwd) against the reference's lines through autograd and the stand-alone filter
+    (R/snn_model/vae_model.py:79-84): the same loss and the same gradients of both spike tensors to fp32 round-off."""
+    g = torch.Generator().manual_seed(shape[1] * 7 + shape[0])
+    q0 = (torch.rand(*shape, generator=g) < 0.2).float().to(dev)
+    x0 = (torch.rand(*shape, generator=g) < 0.3).float().to(dev)
+    res = {}
+    for mode in ("fused", "autograd"):
+        q, x = q0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+        if mode == "fused":
+            loss = ops.PSPLossFunction.apply(q, x, 0.25, 2.0)
+        else:
+            pq, px = ops.PSPFunction.apply(q, 2.0), ops.PSPFunction.apply(x, 2.0)
+            loss = torch.mean((pq - px.detach()) ** 2) + 0.25 * torch.mean((pq.detach() - px) ** 2)
+        (loss * 1.7).backward()
+        res[mode] = (loss.detach(), q.grad, x.grad)
+    la, gqa, gxa = res["autograd"]
+    lf, gqf, gxf = res["fused"]
+    assert abs(float(lf) - float(la)) <= 2e-6 * abs(float(la))
+    assert _rel_l2(gqf, gqa) <= 2e-6 and _rel_l2(gxf, gxa) <= 2e-6
+    parity(f"psp_loss_function_{'x'.join(map(str, shape))}", loss_rel=abs(float(lf) - float(la)) / abs(float(la)),
+           grad_q_rel_l2=_rel_l2(gqf, gqa), grad_x_rel_l2=_rel_l2(gxf, gxa))
+
+
+@pytest.mark.parametrize("shape", [(16, 4, 1, 28, 28), (16, 3, 3, 32, 32), (5, 2, 1, 6, 7)])
+def test_recon_loss_function_vs_op_by_op_autograd(dev, ops, shape):
+    """ops.ReconLossFunction (spk_recon_loss_fwd / _bwd) against mse_loss(tanh(memout(y)), image) through autograd
+    (R/snn_model/vae_model.py:189-196)."""
+    import torch.nn.functional as F
+    T = shape[0]
+    g = torch.Generator().manual_seed(T * 11 + shape[1])
+    y0 = (torch.randn(*shape, generator=g) * 0.4).to(dev)
+    img = (torch.rand(*shape[1:], generator=g) - 0.5).to(dev)
+    coef = torch.pow(torch.tensor(0.8), torch.arange(T - 1, -1, -1).float()).to(dev)
+    res = {}
+    for mode in ("fused", "autograd"):
+        y = y0.clone().requires_grad_(True)
+        if mode == "fused":
+            loss = ops.ReconLossFunction.apply(y, coef, img)
+        else:
+            loss = F.mse_loss(torch.tanh(torch.sum(y * coef.view(T, 1, 1, 1, 1), dim=0)), img)
+        (loss * 2.5).backward()
+        res[mode] = (loss.detach(), y.grad)
+    assert abs(float(res["fused"][0]) - float(res["autograd"][0])) <= 3e-6 * abs(float(res["autograd"][0]))
+    assert _rel_l2(res["fused"][1], res["autograd"][1]) <= 3e-6
+    parity(f"recon_loss_function_{'x'.join(map(str, shape))}", grad_rel_l2=_rel_l2(res["fused"][1], res["autograd"][1]))
+
+
 def test_f10_vqvae_train_step_vs_reference_fixture(golden_dir, dev):
     """SURVEY §8f item 2 (second half): SNN_VQVAE.forward in train() mode and (loss_eq + loss_rec).backward() as
     R/main.py:136-142 runs it -- library (transposed) convolutions, native BatchNorm+LIF block tails, membrane read-out,
