@@ -166,6 +166,9 @@ struct V2Args {
                                    // (1024 until round 4; same box, dense / elimination / lists, ms per 100-step sample at B = 256:
                                    //  1024: 88.0 / 43.5 / 34.2, 512: 87.4 / 43.3 / 34.1, 256 and 0: 87.4 / 44.3 / 35.2)
 #endif
+#ifndef SPK_V2_AHEAD
+#define SPK_V2_AHEAD 1          // round 5: the chunk barrier four steps before the end of the chunk, the next chunk's first fragments read behind it
+#endif
 #ifndef SPK_V2_PF
 #define SPK_V2_PF 6             // A fragments requested this many steps ahead of the MFMA that consumes them
 #endif
@@ -276,6 +279,13 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
   // (full items: the per-fragment popcounts were 29 % of the launch's vector issue), else per A fragment in the K loop
   // (listed positions: an item has few fragments, and the per-item passes of REC cost more than they save there: -2.5 %)
   constexpr bool REC = !USE_D4 && !PRUNE && !(SPK_V2_DBG & 256);     // (DBG 256: no counting at all -- timing only, wrong flags)
+  // AH (round 5): the chunk barrier sits four steps BEFORE the end of the chunk instead of at its start.  Every read of the
+  // current buffers has been issued by then (the last spike fragment at step NSTEP - 5, the last weight tile at the first step of
+  // tap 7), so that barrier both publishes the next chunk's copies and releases the current buffers -- and the four steps behind
+  // it read the next chunk's first fragments: no LDS round trip in front of a chunk's first MFMA any more (it cost both waves of
+  // a SIMD ~150 cycles per chunk, 128 chunks per workgroup).  The first chunk of an item still starts with its reads (the
+  // fragment registers must not live through the epilogue).  Two waves per SIMD, full items.
+  constexpr bool AH = SPK_V2_AHEAD && NWV == 8 && !PRUNE && !USE_D4;
   constexpr int HW = H * W, PW = W + 1;
   constexpr int Hb = SPLIT ? H / 2 : H;                // output rows of an item
   constexpr int Hin = SPLIT ? Hb + 1 : H;              // input rows staged per item
@@ -387,6 +397,10 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
     const uint8_t* as0 = aslab_of(il, 0);
 #pragma unroll
     for (int q = 0; q < NPA + NPW; ++q) issue_piece(q, as0, wbase, sA_addr, sW_addr);
+    if constexpr (AH) {                                   // (the only chunk whose copies no mid-chunk barrier has waited for)
+      spk_dma_wait_all();
+      __syncthreads();
+    }
   }
   for (int itm = il; itm < nitems; itm += lanes) {
     const int b = PRUNE ? slots[itm] : (SPLIT ? itm >> 1 : itm), band = SPLIT ? itm & 1 : 0;
@@ -423,10 +437,15 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
       rec_ok[k] = r < NREC;
       rec_off[k] = rec_ok[k] ? (((cl / W) + 1) * PW + 1 + (cl % W)) * POSB + t * 16 : 0;
     }
+    constexpr int PFX = NWV == 4 ? SPK_V2_PF : 4;
+    v6i bp[2][2];                                         // digit-pair tiles of tap parity [tap & 1][pair]   (AH: carried over the
+    v4i af[PFX];                                          //  chunks of an item: a chunk's last steps fill them for the next one)
     for (int c = 0; c < nch; ++c, ++it) {
       const int buf = it & 1;
-      spk_dma_wait_all();  // this wave's share of the chunk's DMA has landed ...
-      __syncthreads();     // ... and so has everyone else's; everyone is done with the other buffer
+      if constexpr (!AH) {
+        spk_dma_wait_all();  // this wave's share of the chunk's DMA has landed ...
+        __syncthreads();     // ... and so has everyone else's; everyone is done with the other buffer
+      }
       int nb = itm, nc = c + 1;
       if (nc == nch) { nc = 0; nb = itm + lanes; }
       const bool have_next = nb < nitems;                 // otherwise the last chunk is copied once more (never read)
@@ -481,17 +500,31 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
           const v6i r = {x[0], x[1], x[2], x[3], y[0], y[1]};
           return r;
         };
-        v6i bp[2][2];                                     // digit-pair tiles of tap parity [tap & 1][pair]
         v6i b4[2];                                        // fifth-digit tiles [q & 1]
-        bp[0][0] = ldb(0); bp[0][1] = ldb(1);
-        constexpr int PF = NWV == 4 ? SPK_V2_PF : 4;
-        v4i af[PF];
-        static_for<PF>([&](auto s_tag) { af[decltype(s_tag)::value] = lda(s_tag); });
+        constexpr int PF = PFX;
+        if constexpr (!AH || FIRST) {
+          bp[0][0] = ldb(0); bp[0][1] = ldb(1);
+          static_for<PF>([&](auto s_tag) { af[decltype(s_tag)::value] = lda(s_tag); });
+        }
+        // AH: the next chunk's buffers (this item's; the last chunk of an item reads nothing ahead)
+        const uint8_t* An = sA + (buf ^ 1) * A_BYTES + band_off;
+        const uint8_t* Wn = sW + (buf ^ 1) * W_LDS;
+        const bool ahead = AH && c + 1 < nch;
         static_for<NSTEP>([&](auto s_tag) {
           constexpr int s = decltype(s_tag)::value;
           constexpr int blk = s / NT, i = s % NT;
+          if constexpr (AH && s == NSTEP - PF) {
+            // every read of this chunk's buffers is issued; this wave's copies of the next chunk have landed: the chunk barrier
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+          }
           const v4i av = af[s % PF];
           if constexpr (s + PF < NSTEP) af[s % PF] = lda(std::integral_constant<int, s + PF>{});
+          else if constexpr (AH) {
+            // the slot just consumed takes the next chunk's step with the same slot number: steps NSTEP - 4 .. NSTEP - 1 free slots
+            // (NSTEP - 4) % 4 ..., i.e. the next chunk's steps s' with s' % 4 == s % 4
+            constexpr int k = s % PF;                         // (PF == 4: next step k lives in slot k)
+            if (ahead) af[k] = *reinterpret_cast<const v4i*>(An + a_off[k % NT] + toff(blk_tap(k / NT)));
+          }
           constexpr int NPIECES = NPA + NPW;
           // two copy slots per block (its first step and its middle step): 18 slots for the 11 pieces of the four-digit form
 #define V2_DMA_SLOT()                                                                              \
@@ -549,6 +582,19 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
             }
             V2_PAIR_MFMA(1);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (AH && s == NSTEP - 1) {
+              if (ahead) {
+                auto ldb_n = [&](int tile) -> v6i {
+                  const uint8_t* p = Wn + tile * WT;
+                  const v4i x = *reinterpret_cast<const v4i*>(p + lane * 16);
+                  typedef const volatile __attribute__((address_space(3))) v2i* lds_v2i_ptr;
+                  const v2i y = *(lds_v2i_ptr)SPK_LDS(p + 1024 + lane * 8);
+                  const v6i r = {x[0], x[1], x[2], x[3], y[0], y[1]};
+                  return r;
+                };
+                bp[0][0] = ldb_n(0); bp[0][1] = ldb_n(1);
+              }
+            }
           } else {
             constexpr int q = blk_q(blk);
             if constexpr (USE_D4) {
