@@ -1,6 +1,7 @@
 #!/bin/bash
-# the stress record of profiles/r4_stress.txt (one box)
+# the stress record of profiles/<tag>_stress.txt (one box): usage tools/stress.sh [tag=r5]
 R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
+TAG=${1:-r5}
 cd $R
 run() { echo "== $*"; "$@" 2>/dev/null | tail -6; }
 {
@@ -9,6 +10,8 @@ run python tools/vae_fp6_stress.py 100 8
 run python tools/modes_stress.py 30 256
 SPKDIFF_V2_LAG=1 run python tools/fp6v2_stress.py 40 32
 SPKDIFF_V2_WAVES=12 run python tools/fp6v2_stress.py 40 32
+SPKDIFF_V2_DUO=1 run python tools/fp6v2_stress.py 40 32
+SPKDIFF_V2_DEFER=1 run python tools/fp6v2_stress.py 40 32
 run python tools/backward_stress.py 90 7
-} > gpurun_out/r4_stress_final.txt 2>&1
-cat gpurun_out/r4_stress_final.txt
+} > gpurun_out/${TAG}_stress_final.txt 2>&1
+cat gpurun_out/${TAG}_stress_final.txt
