@@ -64,6 +64,8 @@ const char* spk_error_string(int code);
  *   "v2_defer"            0     1: full 7x7 batches, layers of >= 4 chunks: the LIF scan of an item runs inside the K loop of the same
  *                               waves' next item (software pipelining across items: measured 11-40 % slower, profiles/r5_ab_defer_builds.txt);
  *                               0: scan between two K loops (rounds 2-4)
+ *   "v2_lps"              1     7x7 latents: the tail launch's last-position part shares a chunk's weight tiles through LDS (eight images per
+ *                               workgroup); 0: every image pair reads them from L2 (rounds 2-4)
  *   "fp6_waves"           4     8: spk_den_conv3x3_mfma_fp6 with two waves per SIMD where an item has <= 4 row tiles per wave
  *   "fp6_xcd_walk"        1     0: image-major item walk of spk_den_conv3x3_mfma_fp6 (2.2x the HBM-side traffic)
  *   "conv6_shared"        1     0: spk_den_conv3x3_counts_mfma never shares operands through LDS

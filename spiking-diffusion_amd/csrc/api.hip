@@ -32,6 +32,7 @@ SpkOption g_options[SPK_OPT_COUNT] = {
     {"v2_lag", {0}},             // SPK_OPT_V2_LAG
     {"v2_duo", {0}},             // SPK_OPT_V2_DUO
     {"v2_defer", {0}},           // SPK_OPT_V2_DEFER
+    {"v2_lps", {1}},             // SPK_OPT_V2_LPS
 };
 }  // namespace
 

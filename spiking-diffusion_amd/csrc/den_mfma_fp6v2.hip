@@ -2293,16 +2293,146 @@ __device__ __forceinline__ void fp6v2_fixup_body(const V2Args& a, long long n_wo
   }
 }
 
+// (1b) Round 5: the last position with the weight tiles SHARED through LDS.  fp6v2_lastpos_body reads the thirteen tiles of every
+// chunk straight from L2 per image pair: 320 MB per launch for the 256 -> 512 layer at B = 256, which is what its ~20 us are.
+// Here a workgroup takes FOUR image pairs of one channel group -- a wave each, every wave walks all the chunks -- and a chunk's
+// thirteen tiles (19.5 KB: the four contributing taps' digit pairs, three fifth-digit tiles, two sixth-digit tiles; four runs
+// of the slab) come in ONCE per workgroup by LDS-DMA, double-buffered (39 KB), one barrier per chunk: 80 MB.  No partial sums
+// cross waves; the epilogue is the exact one of fp6v2_lastpos_body.
+constexpr int LPS_TILES = 13, LPS_BUF = LPS_TILES * WT;                  // 19 968 B per chunk
+constexpr size_t LPS_LDS = 2 * (size_t)LPS_BUF;
+template <int H, int W>
+__device__ __forceinline__ void fp6v2_lastpos_shared_body(const V2Args& a, const int bid) {
+  constexpr int HW = H * W;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = a.nch, G = a.Cout >> 5;
+  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
+  const int g = bid % G, b0 = (bid / G) * 8;
+  if (b0 >= Bn) return;                                     // (uniform over the workgroup)
+  const int row = lane & 31, half = lane >> 5;
+  const int hsel = (row >> 2) & 1, tt = (row & 3) + 4 * (row >> 3);
+  const int sc_a = 0x7f7f7f7f;
+  const int sc_p = half ? (int)0x82828282u : (int)0x87878787u;
+  const int sc_hi = (int)0x87878787u, sc_lo = (int)0x82828282u;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lds_addr = spk_lds_addr(lds), lane16 = (unsigned)lane * 16u;
+  // the slab's four runs -> twenty pieces (one of them half a piece), five per wave: piece k of the wave = 5 * wave + k
+  auto issue_chunk = [&](int c, int buf) {
+    const uint8_t* slab = a.wq + ((long long)g * nch + c) * W_SLAB;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int pc = 5 * wave_s + k;                        // 0..19
+      // pieces 0..5: tiles 0..3; 6..11: tiles 6..9; 12..16: tiles 18..20 (16 = the half piece); 17..19: tiles 23, 24
+      const int src = pc < 6 ? pc * 1024 : pc < 12 ? 6 * WT + (pc - 6) * 1024 : pc < 17 ? 18 * WT + (pc - 12) * 1024
+                                                                                        : 23 * WT + (pc - 17) * 1024;
+      const int dst = pc < 6 ? pc * 1024 : pc < 12 ? 4 * WT + (pc - 6) * 1024 : pc < 17 ? 8 * WT + (pc - 12) * 1024
+                                                                                        : 11 * WT + (pc - 17) * 1024;
+      const unsigned long long mask = pc == 16 ? 0xffffffffull : ~0ull;
+      spk_dma16s_masked(slab + src, lane16, lds_addr + (unsigned)(buf * LPS_BUF + dst), mask);
+    }
+  };
+  const int py = H - 1, px = W - 1;
+  const int bA = b0 + 2 * wave + hsel;                      // the image whose rows this lane feeds (A layout)
+  auto load_spikes = [&](int c, v4i (&sp)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int tap = (u >> 1) * 3 + (u & 1);
+      const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+      sp[u] = v4i{0, 0, 0, 0};
+      if (bA < Bn) sp[u] = *reinterpret_cast<const v4i*>(a.in0 + (((long long)bA * nch + c) * HW + yy * W + xx) * POSB + tt * 16);
+    }
+  };
+  v16f acc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  v4i sp[4], spn[4];
+  issue_chunk(0, 0);
+  load_spikes(0, sp);
+  for (int c = 0; c < nch; ++c) {
+    const int buf = c & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of chunk c (and its spike fragments) are in
+    __syncthreads();                                        // everyone's are; everyone is done with the other buffer
+    if (c + 1 < nch) { issue_chunk(c + 1, buf ^ 1); load_spikes(c + 1, spn); }
+    const uint8_t* Wb = lds + buf * LPS_BUF;
+    // (the assembly form of the main kernel: four- and six-register operands; the builtin wants eight-register tuples padded
+    //  with zeros for both, which is what pushed this body past 168 registers)
+    auto ldb = [&](int tile) -> v6i {
+      const uint8_t* wt = Wb + tile * WT;
+      const v4i bx = *reinterpret_cast<const v4i*>(wt + lane * 16);
+      const v2i by = *reinterpret_cast<const v2i*>(wt + 1024 + lane * 8);
+      return v6i{bx[0], bx[1], bx[2], bx[3], by[0], by[1]};
+    };
+    auto mm = [&](v16f& d, const v4i& av, const v6i& bv, int sb) { SPK_MFMA2("v", d, av, bv, sc_a, sb); };
+    // (fences: at most four tiles in flight -- left alone hipcc requests all thirteen first: 188 registers, two workgroups per CU)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const v6i t0 = ldb(2 * u), t1 = ldb(2 * u + 1);
+      mm(acc[0], sp[u], t0, sc_p); mm(acc[1], sp[u], t1, sc_p);
+      if (u & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    const v4i zero = {0, 0, 0, 0};
+    const v4i a01 = half ? sp[1] : sp[0];
+    const v4i az3 = half ? sp[2] : zero;
+    const v4i a4z = half ? zero : sp[3];
+    const v4i a34 = half ? sp[3] : sp[2];
+    {
+      const v6i t8 = ldb(8), t9 = ldb(9), t10 = ldb(10);
+      mm(acc[2], a01, t8, sc_hi); mm(acc[2], az3, t9, sc_hi); mm(acc[2], a4z, t10, sc_hi);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const v6i t11 = ldb(11), t12 = ldb(12);
+      mm(acc[2], a01, t11, sc_lo); mm(acc[2], a34, t12, sc_lo);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 < nch) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sp[u] = spn[u];
+    }
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");        // (the MFMAs are opaque to the hazard recognizer: accumulator reads below)
+  const int co = g * 32 + (lane & 31);
+  const double sc = a.scale[co], bi = a.bias[co];
+  const float bna = a.bn_a[co], bnb = a.bn_b[co];
+  const int b = b0 + 2 * wave + half;                       // accumulator lane half == image within the pair
+  const bool ok = b < Bn;
+  if (__builtin_amdgcn_ballot_w64(ok) == 0ull) return;
+  float v = 0.f;
+  unsigned mybits = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const double s1 = fma((double)acc[0][r], 1024.0, (double)acc[1][r]);
+    const double s2 = fma(s1, 1024.0, (double)acc[2][r]);
+    const float y = exact_preact(s2, sc, bi);
+    const bool sp1 = spk_lif_step_default(v, fmaf(y, bna, bnb)) && ok;
+    mybits |= sp1 ? (1u << r) : 0u;
+  }
+  const long long cell = ((long long)(ok ? b : 0) * G + g) * HW + (HW - 1);
+  store_tile_spikes(a.out, a.out_cnt, mybits, lane, cell * POSB, cell * 32, ok);
+}
+
 // The tail launches.  PART 0: workgroups [0, n_lp) compute last positions, the rest repair flagged neurons -- independent work
 // (disjoint outputs, both read only the layer's input), each a chain of dependent L2 reads: in one launch they overlap (the
 // sampler's active-set calls).  PART 1 / 2: repair only / last positions only, each with its own register and LDS budget (full
 // batches, where either part fills the device by itself: the merged form measured 1.3 % slower there).
+// PART 3 (round 5): PART 0 with the last positions of fp6v2_lastpos_shared_body (39 KB of dynamic LDS per workgroup: four per CU).
+// (HIP's second launch-bound argument = waves per SIMD the kernel must leave room for: four workgroups of PART 3 per CU -> 128 registers;
+//  one address spills, outside the chunk loop)
 template <int H, int W, int PART>
-__global__ __launch_bounds__(256) void fp6v2_tail_kernel(V2Args a, long long n_words, int n_lp) {
-  __shared__ float red[PART == 1 ? 1 : (PART == 2 ? 9 : 3)][16][64];
+__global__ __launch_bounds__(256, PART == 3 ? 4 : 1) void fp6v2_tail_kernel(V2Args a, long long n_words, int n_lp) {
+  __shared__ float red[(PART == 1 || PART == 3) ? 1 : (PART == 2 ? 9 : 3)][16][64];
   __shared__ unsigned long long sS[16];
-  if (PART == 2 || (PART == 0 && (int)blockIdx.x < n_lp)) fp6v2_lastpos_body<H, W, PART == 2>(a, (int)blockIdx.x, red);
-  else fp6v2_fixup_body<H, W>(a, n_words, blockIdx.x - (unsigned)n_lp, gridDim.x - (unsigned)n_lp, sS);
+  if constexpr (PART == 3) {
+    if ((int)blockIdx.x < n_lp) { if constexpr ((H * W) & 1) fp6v2_lastpos_shared_body<H, W>(a, (int)blockIdx.x); }
+    else fp6v2_fixup_body<H, W>(a, n_words, blockIdx.x - (unsigned)n_lp, gridDim.x - (unsigned)n_lp, sS);
+    (void)red;
+  } else {
+    if (PART == 2 || (PART == 0 && (int)blockIdx.x < n_lp)) fp6v2_lastpos_body<H, W, PART == 2>(a, (int)blockIdx.x, red);
+    else fp6v2_fixup_body<H, W>(a, n_words, blockIdx.x - (unsigned)n_lp, gridDim.x - (unsigned)n_lp, sS);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ weight packing
@@ -2564,7 +2694,12 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 4>), dim3(grid), dim3(256), lds, stream, a);
   SPK_LAUNCH_CHECK();
   const int n_lp = ((B + 2 * SPK_V2_LP_PAIRS - 1) / (2 * SPK_V2_LP_PAIRS)) * G;
-  if (n_dyn_or_null || SPK_V2_MERGE_FULL) {
+  if ((n_dyn_or_null || SPK_V2_MERGE_FULL) && spk_opt(SPK_OPT_V2_LPS) != 0 && nch >= 2 && (long long)LPS_LDS + 4096 <= spk_lds_limit()) {
+    // round 5: last positions with LDS-shared weight tiles (eight images per workgroup), repairs beside them (four workgroups per CU)
+    const int n_lps = ((B + 7) / 8) * G;
+    hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7, 3>), dim3(n_lps + 4 * cus), dim3(256), LPS_LDS, stream, a, n_words, n_lps);
+    SPK_LAUNCH_CHECK();
+  } else if (n_dyn_or_null || SPK_V2_MERGE_FULL) {
     // the sampler's active-set calls: few images, both parts are latency bound -- one launch (-17 us per reverse step)
     hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7, 0>), dim3(n_lp + 8 * cus), dim3(256), 0, stream, a, n_words, n_lp);
     SPK_LAUNCH_CHECK();

@@ -22,7 +22,7 @@
 
 // measurement options (api.hip: spk_set_option / spk_get_option; include/spkdiff.h lists them)
 enum { SPK_OPT_CONV6_SHARED = 0, SPK_OPT_CONV6_SHARED_DYN, SPK_OPT_MFMA_DEBUG, SPK_OPT_FP6_XCD_WALK, SPK_OPT_FP6_WAVES,
-       SPK_OPT_V2_WAVES, SPK_OPT_V2_LAG, SPK_OPT_V2_DUO, SPK_OPT_V2_DEFER, SPK_OPT_COUNT };
+       SPK_OPT_V2_WAVES, SPK_OPT_V2_LAG, SPK_OPT_V2_DUO, SPK_OPT_V2_DEFER, SPK_OPT_V2_LPS, SPK_OPT_COUNT };
 int spk_opt(int id);
 
 static inline int spk_blocks(long long n, int threads) { return (int)((n + threads - 1) / threads); }

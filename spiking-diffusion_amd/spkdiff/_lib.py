@@ -175,7 +175,7 @@ if version() != EXPECTED_VERSION:
 
 # Measurement options (include/spkdiff.h): the library reads no environment variable itself; the A/B tools under tools/ select
 # a launch form with SPKDIFF_<NAME>=<int>, forwarded here ONCE at import.  set_option() switches at run time.
-OPTIONS = ("v2_waves", "v2_lag", "v2_duo", "v2_defer", "fp6_waves", "fp6_xcd_walk", "conv6_shared", "conv6_shared_dyn", "mfma_debug")
+OPTIONS = ("v2_waves", "v2_lag", "v2_duo", "v2_defer", "v2_lps", "fp6_waves", "fp6_xcd_walk", "conv6_shared", "conv6_shared_dyn", "mfma_debug")
 
 
 def set_option(name: str, value: int):
