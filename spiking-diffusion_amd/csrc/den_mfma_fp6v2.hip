@@ -2694,8 +2694,11 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 4>), dim3(grid), dim3(256), lds, stream, a);
   SPK_LAUNCH_CHECK();
   const int n_lp = ((B + 2 * SPK_V2_LP_PAIRS - 1) / (2 * SPK_V2_LP_PAIRS)) * G;
-  if ((n_dyn_or_null || SPK_V2_MERGE_FULL) && spk_opt(SPK_OPT_V2_LPS) != 0 && nch >= 2 && (long long)LPS_LDS + 4096 <= spk_lds_limit()) {
-    // round 5: last positions with LDS-shared weight tiles (eight images per workgroup), repairs beside them (four workgroups per CU)
+  if (!n_dyn_or_null && SPK_V2_MERGE_FULL && spk_opt(SPK_OPT_V2_LPS) != 0 && nch >= 2 && (long long)LPS_LDS + 4096 <= spk_lds_limit()) {
+    // round 5, full batches: last positions with LDS-shared weight tiles (eight images per workgroup), repairs beside them (four
+    // workgroups per CU).  Same box, B = 256: den.conv4 / conv5 launches 386 / 373 -> 380 / 369 us, dense reverse process 91.6 -> 90.9 ms
+    // (profiles/r5_ab_kernel_variants.txt (3)).  The sampler's active-set calls keep the form below: with few images the shared
+    // form has too few units (elimination + lists 33.6 -> 34.7 ms)
     const int n_lps = ((B + 7) / 8) * G;
     hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7, 3>), dim3(n_lps + 4 * cus), dim3(256), LPS_LDS, stream, a, n_words, n_lps);
     SPK_LAUNCH_CHECK();
