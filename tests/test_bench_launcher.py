@@ -68,3 +68,42 @@ def test_refuses_more_gpus_than_the_node_has():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True,
                        text=True, timeout=300)
     assert p.returncode != 0 and "exposes" in p.stderr and p.stdout.strip() == ""
+
+
+def test_bench_oracle_fixture_check_logic():
+    """bench.py's ``oracle_fixture`` object, host logic only: tokens equal to the committed F15 fixture give
+    ok = True with the recorded fragile image reported; a batch whose key is not the fixture's is "not comparable"; a token changed in
+    an image OUTSIDE the fragile set makes the check fail; the fragile image may carry the exact-convolution oracle's tokens."""
+    import argparse
+    import importlib.util
+    import numpy as np
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    z = np.load(bench.F15_FIXTURE, allow_pickle=False)
+    seed, warmup, steps, B, sample_steps, T, _ = (int(v) for v in z["config"])
+    args = argparse.Namespace(sample_steps=sample_steps, T=T)
+    first = torch.from_numpy(z["first_tokens_oracle"].astype(np.int64)).reshape(B, 1, 7, 7)
+    last = torch.from_numpy(z["last_tokens_oracle"].astype(np.int64)).reshape(B, 1, 7, 7).clone()
+    frag = [int(b) for b in z["last_fragile_images"]]
+    for j, b in enumerate(frag):                                   # what the HIP path produces there: the exact-convolution tokens
+        last[b] = torch.from_numpy(z["last_fragile_tokens_exact"][j].astype(np.int64)).reshape(1, 7, 7)
+    keys = (int(z["first_key"][0]), int(z["last_key"][0]))
+    r = bench.oracle_fixture_check(args, B, {"first": (first, keys[0]), "last": (last, keys[1])})
+    assert r["applicable"] and r["ok"], r
+    assert r["first_timed_batch"]["images_equal"] == f"{B}/{B}"
+    assert r["last_timed_batch"]["images_equal"] == f"{B - len(frag)}/{B}"
+    assert all(f["equals_exact_convolution_oracle"] for f in r["last_timed_batch"]["fragile"])
+    # another key (another seed / --steps / --warmup): nothing to compare with
+    r2 = bench.oracle_fixture_check(args, B, {"first": (first, keys[0] + 1), "last": (last, keys[1] + 1)})
+    assert not r2["applicable"] and not r2["first_timed_batch"]["comparable"]
+    # a wrong token outside the fragile set
+    bad = first.clone()
+    victim = next(i for i in range(B) if i not in frag)
+    bad[victim, 0, 3, 3] = (bad[victim, 0, 3, 3] + 1) % 128
+    r3 = bench.oracle_fixture_check(args, B, {"first": (bad, keys[0]), "last": (last, keys[1])})
+    assert r3["applicable"] and not r3["ok"] and r3["first_timed_batch"]["images_differing_outside_the_fragile_set"] == [victim]
+    # another batch size than the fixture's
+    assert not bench.oracle_fixture_check(args, 128, {"first": (first[:128], keys[0]), "last": (last[:128], keys[1])})["applicable"]
