@@ -169,6 +169,9 @@ struct V2Args {
 #ifndef SPK_V2_AHEAD
 #define SPK_V2_AHEAD 1          // round 5: the chunk barrier four steps before the end of the chunk, the next chunk's first fragments read behind it
 #endif
+#ifndef SPK_V2_NBUF
+#define SPK_V2_NBUF 3           // slab buffers of the AHEAD form: 3 = copies issued two chunks ahead (147 KB of LDS), 2 = one chunk ahead
+#endif
 #ifndef SPK_V2_PF
 #define SPK_V2_PF 6             // A fragments requested this many steps ahead of the MFMA that consumes them
 #endif
@@ -282,10 +285,13 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
   // AH (round 5): the chunk barrier sits four steps BEFORE the end of the chunk instead of at its start.  Every read of the
   // current buffers has been issued by then (the last spike fragment at step NSTEP - 5, the last weight tile at the first step of
   // tap 7), so that barrier both publishes the next chunk's copies and releases the current buffers -- and the four steps behind
-  // it read the next chunk's first fragments: no LDS round trip in front of a chunk's first MFMA any more (it cost both waves of
-  // a SIMD ~150 cycles per chunk, 128 chunks per workgroup).  The first chunk of an item still starts with its reads (the
-  // fragment registers must not live through the epilogue).  Two waves per SIMD, full items.
-  constexpr bool AH = SPK_V2_AHEAD && NWV == 8 && !PRUNE && !USE_D4;
+  // it read the next chunk's first fragments: no LDS round trip in front of a chunk's first MFMA any more.  The first chunk of an
+  // item still starts with its reads (the fragment registers must not live through the epilogue).
+  // THREE slab buffers (NBUF = 3, 147 KB of LDS): the copies of chunk c + 2 are issued during chunk c and have two chunk times to
+  // land; with two buffers they had to land within ~16 K-loop steps (1.1 us), and the barrier waited for them -- the no-copy
+  // ablation ran den.conv4 / conv5 5 / 10 % faster (profiles/r5_ab_kernel_variants.txt (4)).  The barrier then waits with
+  // s_waitcnt vmcnt(pieces of this chunk): copies complete in issue order; the first chunk of an item drains the counter (the
+  // epilogue's stores share it and may retire out of order).
   constexpr int HW = H * W, PW = W + 1;
   constexpr int Hb = SPLIT ? H / 2 : H;                // output rows of an item
   constexpr int Hin = SPLIT ? Hb + 1 : H;              // input rows staged per item
@@ -303,19 +309,22 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
   constexpr int NPW = (W_PIECES + NWV - 1) / NWV;      // W pieces per wave
   constexpr int NS_PAIR = 9 * NT, NSTEP = NS_PAIR + (USE_D4 ? N_D4 * NT : 0);
   static_assert(NWV >= 8 || NACC * NT <= 16 || (NT - 1) * NACC <= N_AGPR + 2, "only the last tile may straddle the register files");
+  // AH (round 5, two waves per SIMD on full items): chunk barrier four steps before the chunk's end + THREE slab buffers, see below
+  constexpr bool AH = SPK_V2_AHEAD && NWV == 8 && !PRUNE && !USE_D4;
+  constexpr int NBUF = AH ? SPK_V2_NBUF : 2;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   uint8_t* const sA = lds;
-  uint8_t* const sW = lds + 2 * A_BYTES;
+  uint8_t* const sW = lds + NBUF * A_BYTES;
   // four-digit form: active inputs per input cell and step (s_cin, borders stay zero) and per output position and step (s_row)
-  int* const s_cin = reinterpret_cast<int*>(lds + 2 * A_BYTES + 2 * W_LDS);          // [NPP][16]
+  int* const s_cin = reinterpret_cast<int*>(lds + NBUF * A_BYTES + NBUF * W_LDS);    // [NPP][16]
   int* const s_row = s_cin + NPP * 16;                                               // [HWb + 1][16]
   int* const s_nmax = s_row + (HWb + 1) * 16;                                        // [HWb + 1]: max over the steps of s_row[p][.]
-  const unsigned sA_addr = spk_lds_addr(sA), sW_addr = sA_addr + 2 * A_BYTES;
+  const unsigned sA_addr = spk_lds_addr(sA), sW_addr = sA_addr + NBUF * A_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nch = a.nch;
   const int G = a.Cout >> 5;
-  // zero both A images once: the borders stay zero for the whole kernel, interiors are overwritten by DMA
-  for (int i = tid; i < 2 * A_BYTES / 16; i += NWV * 64) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
+  // zero the A images once: the borders stay zero for the whole kernel, interiors are overwritten by DMA
+  for (int i = tid; i < NBUF * A_BYTES / 16; i += NWV * 64) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
   if (REC)
     for (int i = tid; i < NPP * 16; i += NWV * 64) s_cin[i] = 0;
   __syncthreads();         // no wave's first DMA piece may land in a cell another wave has yet to zero
@@ -393,11 +402,20 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
   unsigned long long dbg_c0 = 0, dbg_r0 = 0;
   if (SPK_V2_DBG & 128) { dbg_c0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
   int it = 0;                                             // running chunk counter: LDS buffer = it & 1
+  int bi = 0;                                             // (NBUF 3: the current chunk's buffer, it mod 3)
   if (il < nitems) {
     const uint8_t* as0 = aslab_of(il, 0);
 #pragma unroll
     for (int q = 0; q < NPA + NPW; ++q) issue_piece(q, as0, wbase, sA_addr, sW_addr);
-    if constexpr (AH) {                                   // (the only chunk whose copies no mid-chunk barrier has waited for)
+    if constexpr (AH) {                                   // (the only chunks whose copies no chunk barrier has waited for)
+      if constexpr (NBUF == 3) {
+        // the second chunk of the stream as well: chunk 1 of this item, or chunk 0 of the next
+        const bool two = nch > 1 || il + lanes < nitems;
+        const uint8_t* as1 = nch > 1 ? aslab_of(il, 1) : aslab_of(two ? il + lanes : il, 0);
+        const uint8_t* ws1 = wbase + (long long)(nch > 1 ? 1 : 0) * W_SLAB;
+#pragma unroll
+        for (int q = 0; q < NPA + NPW; ++q) issue_piece(q, as1, ws1, sA_addr + A_BYTES, sW_addr + W_LDS);
+      }
       spk_dma_wait_all();
       __syncthreads();
     }
@@ -441,18 +459,25 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
     v6i bp[2][2];                                         // digit-pair tiles of tap parity [tap & 1][pair]   (AH: carried over the
     v4i af[PFX];                                          //  chunks of an item: a chunk's last steps fill them for the next one)
     for (int c = 0; c < nch; ++c, ++it) {
-      const int buf = it & 1;
+      const int buf = NBUF == 3 ? bi : (it & 1);
+      const int buf1 = NBUF == 3 ? (bi == 2 ? 0 : bi + 1) : (buf ^ 1);          // the next chunk's buffers
+      const int buf2 = NBUF == 3 ? (bi == 0 ? 2 : bi - 1) : (buf ^ 1);          // where this chunk's copies go (NBUF 3: chunk + 2)
+      if constexpr (NBUF == 3) bi = buf1;
       if constexpr (!AH) {
         spk_dma_wait_all();  // this wave's share of the chunk's DMA has landed ...
         __syncthreads();     // ... and so has everyone else's; everyone is done with the other buffer
       }
       int nb = itm, nc = c + 1;
       if (nc == nch) { nc = 0; nb = itm + lanes; }
+      if constexpr (NBUF == 3) {                          // (the chunk after that)
+        nc = nc + 1;
+        if (nc == nch) { nc = 0; nb = nb + lanes; }
+      }
       const bool have_next = nb < nitems;                 // otherwise the last chunk is copied once more (never read)
       const uint8_t* n_aslab = aslab_of(have_next ? nb : itm, have_next ? nc : c);
       const uint8_t* n_wslab = wbase + (long long)(have_next ? nc : c) * W_SLAB;
-      const unsigned n_dA = sA_addr + (buf ^ 1) * A_BYTES;
-      const unsigned n_dW = sW_addr + (buf ^ 1) * W_LDS;
+      const unsigned n_dA = sA_addr + buf2 * A_BYTES;
+      const unsigned n_dW = sW_addr + buf2 * W_LDS;
 
       // REC: the chunk's record counts.  SPK_V2_REC_INLOOP: the two LDS reads are issued after the chunk's first MFMA step and
       // their popcounts a few steps later, inside the MFMA stream (in front of it they held the chunk's first MFMA back by an
@@ -507,15 +532,20 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
           static_for<PF>([&](auto s_tag) { af[decltype(s_tag)::value] = lda(s_tag); });
         }
         // AH: the next chunk's buffers (this item's; the last chunk of an item reads nothing ahead)
-        const uint8_t* An = sA + (buf ^ 1) * A_BYTES + band_off;
-        const uint8_t* Wn = sW + (buf ^ 1) * W_LDS;
+        const uint8_t* An = sA + buf1 * A_BYTES + band_off;
+        const uint8_t* Wn = sW + buf1 * W_LDS;
         const bool ahead = AH && c + 1 < nch;
         static_for<NSTEP>([&](auto s_tag) {
           constexpr int s = decltype(s_tag)::value;
           constexpr int blk = s / NT, i = s % NT;
           if constexpr (AH && s == NSTEP - PF) {
             // every read of this chunk's buffers is issued; this wave's copies of the next chunk have landed: the chunk barrier
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (NBUF == 3 && !FIRST) {
+              static_assert(NPA + NPW <= 15, "vmcnt immediate");
+              asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NPA + NPW) : "memory");     // (this chunk's pieces may still fly)
+            } else {
+              asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            }
           }
           const v4i av = af[s % PF];
           if constexpr (s + PF < NSTEP) af[s % PF] = lda(std::integral_constant<int, s + PF>{});
@@ -2619,6 +2649,8 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   const int a_bytes = bands ? ((8 / 2 + 1 + 2) * 9 + 1) * POSB : ((7 + 2) * 8 + 1) * POSB;
   // (+ the active-input counters of the four-digit form: s_cin [cells][16], s_row [positions + 1][16])
   const size_t lds = 2 * ((size_t)a_bytes + W_LDS) + (size_t)((a_bytes / POSB) + (bands ? 32 : 49) + 1) * 64 + 256;   // (+ s_nmax)
+  // (the eight-wave kernels of full items keep SPK_V2_NBUF slab buffers)
+  const size_t lds8 = lds + (SPK_V2_AHEAD && !USE_D4 ? (size_t)(SPK_V2_NBUF - 2) * ((size_t)a_bytes + W_LDS) : 0);
   const long long n_words = ((long long)B * Cout * H * W + 31) / 32;
   a.ticket_idx = 2 + (long long)FLAG_CAP + n_words;
   // full 7x7 batches keep the round-1 order (repair launch, then the last-position launch re-arms the counter): the hand-over
@@ -2642,7 +2674,7 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   }
   if (bands) {
     const bool eight_b = spk_opt(SPK_OPT_V2_WAVES) != 4;   // (+4 %)
-    if (eight_b) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 8, true>), dim3(grid), dim3(512), lds, stream, a);
+    if (eight_b) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 8, true>), dim3(grid), dim3(512), lds8, stream, a);
     else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 4, true>), dim3(grid), dim3(256), lds, stream, a);
     SPK_LAUNCH_CHECK();
     hipLaunchKernelGGL((fp6v2_tail_kernel<8, 8, 1>), dim3(8 * cus), dim3(256), 0, stream, a, n_words, 0);   // (even latent: repair only)
@@ -2690,7 +2722,7 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
     const size_t lds3 = 3 * ((size_t)a_bytes + W_LDS) + (size_t)(a_bytes / POSB) * 64 + 8 * 128;
     hipLaunchKernelGGL((conv3x3_fp6v2_lag_kernel<7, 7>), dim3(grid), dim3(512), lds3, stream, a);
   } else if (twelve) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 12>), dim3(grid), dim3(768), lds, stream, a);
-  else if (eight) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 8>), dim3(grid), dim3(512), lds, stream, a);
+  else if (eight) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 8>), dim3(grid), dim3(512), lds8, stream, a);
   else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 4>), dim3(grid), dim3(256), lds, stream, a);
   SPK_LAUNCH_CHECK();
   const int n_lp = ((B + 2 * SPK_V2_LP_PAIRS - 1) / (2 * SPK_V2_LP_PAIRS)) * G;
