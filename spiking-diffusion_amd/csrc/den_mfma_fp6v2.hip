@@ -170,7 +170,10 @@ struct V2Args {
 #define SPK_V2_AHEAD 1          // round 5: the chunk barrier four steps before the end of the chunk, the next chunk's first fragments read behind it
 #endif
 #ifndef SPK_V2_NBUF
-#define SPK_V2_NBUF 3           // slab buffers of the AHEAD form: 3 = copies issued two chunks ahead (147 KB of LDS), 2 = one chunk ahead
+#define SPK_V2_NBUF 2           // slab buffers of the AHEAD form: 2 = copies issued one chunk ahead; 3 = two chunks ahead (147 KB of LDS, the chunk
+                                // barrier waits with a counted s_waitcnt): built because the no-copy ablation runs den.conv4 / conv5 5 / 10 %
+                                // faster, and measured 1 % SLOWER (same box: conv4 376 against 373 us, dense 91.3 against 90.3 ms;
+                                // profiles/r5_ab_kernel_variants.txt (4), (5)) -- what the copies cost is not the wait for their landing
 #endif
 #ifndef SPK_V2_PF
 #define SPK_V2_PF 6             // A fragments requested this many steps ahead of the MFMA that consumes them
@@ -287,11 +290,9 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
   // tap 7), so that barrier both publishes the next chunk's copies and releases the current buffers -- and the four steps behind
   // it read the next chunk's first fragments: no LDS round trip in front of a chunk's first MFMA any more.  The first chunk of an
   // item still starts with its reads (the fragment registers must not live through the epilogue).
-  // THREE slab buffers (NBUF = 3, 147 KB of LDS): the copies of chunk c + 2 are issued during chunk c and have two chunk times to
-  // land; with two buffers they had to land within ~16 K-loop steps (1.1 us), and the barrier waited for them -- the no-copy
-  // ablation ran den.conv4 / conv5 5 / 10 % faster (profiles/r5_ab_kernel_variants.txt (4)).  The barrier then waits with
-  // s_waitcnt vmcnt(pieces of this chunk): copies complete in issue order; the first chunk of an item drains the counter (the
-  // epilogue's stores share it and may retire out of order).
+  // SPK_V2_NBUF = 3 (an experiment, off): three slab buffers, the copies of chunk c + 2 issued during chunk c, the barrier waiting
+  // with s_waitcnt vmcnt(pieces of this chunk) -- copies complete in issue order; the first chunk of an item drains the counter
+  // (the epilogue's stores share it and may retire out of order).  1 % slower than two buffers, see the knob.
   constexpr int HW = H * W, PW = W + 1;
   constexpr int Hb = SPLIT ? H / 2 : H;                // output rows of an item
   constexpr int Hin = SPLIT ? Hb + 1 : H;              // input rows staged per item
