@@ -477,6 +477,35 @@ int spk_conv3x3_wgrad_small(const float* gy_cl, const float* in_nchw, float* ws,
                             float* gb_out_or_null, int N, int H, int W, int Cout, int Cin, int weight_channels_last,
                             spk_stream_t stream);
 
+/* Training convolutions of the spiking VQ-VAE (R/snn_model/vae_model.py:101-159 under loss.backward(), R/main.py:118-146; cuDNN's
+ * forward / data-gradient / weight-gradient kernels in the reference): channels-last fp32 tensors ([N][H][W][C]) on the fp32 matrix
+ * cores (v_mfma_f32_32x32x2_f32: fp32 products and accumulation, no operand narrowed).  csrc/conv_train.hip.
+ *
+ * spk_conv_train_gather: out[N][Ho][Wo][Cout] (+ bias) from in[N][Hi][Wi][Cred] and a k x k weight tensor addressed through three
+ * element strides, W(tap, c, co) = w[tap * w_tap + c * w_red + co * w_out]:
+ *   form 0: out[n, o, co] = sum over (tap, c) of in[n, o * stride + k - pad, c] * W(tap, c, co)       -- layer.Conv2d forward
+ *           (SJ/activation_based/layer.py:164-173), the data gradient of layer.ConvTranspose2d;
+ *   form 1: out[n, o, co] = sum over the taps with (o + pad - k) % stride == 0 and c of in[n, (o + pad - k) / stride, c] *
+ *           W(tap, c, co)  -- layer.ConvTranspose2d forward (layer.py:316-325), the data gradient of layer.Conv2d; sub-pixel
+ *           classes are separate tile rows, structural zeros are not multiplied.
+ * Matrix path: Cred % 8 == 0, Cred <= 64, 2 <= Cout <= 64, the class's weight taps within 150 KB of LDS; vector kernels for
+ * Cred == 1 (form 0, Cout % 4 == 0) and Cout == 1 (Cred 8 / 16 / 32 / 64; form 1 only with stride 1).  spk_conv_train_gather_supported
+ * answers 1 / 0; an unsupported call returns SPK_ERR_UNSUPPORTED (the host then takes the framework's operator). */
+int spk_conv_train_gather_supported(int Cred, int Cout, int k, int stride, int form);
+int spk_conv_train_gather(const float* in_cl, const float* w, const float* bias_or_null, float* out_cl, int N, int Hi, int Wi,
+                          int Cred, int Ho, int Wo, int Cout, int k, int stride, int pad, int form, long long w_tap,
+                          long long w_red, long long w_out, spk_stream_t stream);
+/* Weight (and bias) gradient of the same layers: D(tap, cu, cv) = sum over (n, q) of u[n, q * stride - pad + k, cu] * v[n, q, cv],
+ * written to gw_out[tap * g_tap + cu * g_u + cv * g_v].  layer.Conv2d: u = the layer's input, v = gy; layer.ConvTranspose2d:
+ * u = gy, v = the layer's input (u is the tensor on the finer grid).  bias_from: 0 none, 1: gb_out[cv] = column sums of v, 2:
+ * gb_out[cu] = column sums of u.  Every workgroup owns a range of positions; a second launch adds the partial tiles in index order
+ * (deterministic).  2 <= Cu, Cv <= 64 (k * k * ceil(Cu / 32) * ceil(Cv / 32) <= 36 tiles), or Cu == 1 with Cv % 4 == 0
+ * (vector kernel).  ws: spk_conv_train_wgrad_ws_bytes(...) bytes (-1: unsupported shape). */
+long long spk_conv_train_wgrad_ws_bytes(int N, int Hv, int Wv, int Cu, int Cv, int k);
+int spk_conv_train_wgrad(const float* u_cl, const float* v_cl, float* ws, long long ws_bytes, float* gw_out, float* gb_out_or_null,
+                         int N, int Hu, int Wu, int Cu, int Hv, int Wv, int Cv, int k, int stride, int pad, long long g_tap,
+                         long long g_u, long long g_v, int bias_from, spk_stream_t stream);
+
 /* ---- sampler ---------------------------------------------------------------------------------------------------- */
 /* Images touched by reverse step t.  R/snn_model/vq_diffusion.py:113-124 computes `changes = (u < 1/t) & ~unmasked`
  * BEFORE the denoiser call and only scatters the sample there (:140): for an image without a change at step t the

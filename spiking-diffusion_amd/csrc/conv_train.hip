@@ -1,0 +1,680 @@
+// Training convolutions of the spiking VQ-VAE (R/snn_model/vae_model.py:101-159: stride-2 Conv2d, 1x1 Conv2d, stride-2 and
+// stride-1 ConvTranspose2d; what R/main.py:118-146 runs through cuDNN forward and backward): forward, data gradient and weight
+// gradient of channels-last fp32 tensors on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: fp32 products, fp32 accumulation --
+// the arithmetic of an fp32 GEMM, no operand is narrowed), SURVEY.md §8 f2.
+//
+// Every one of the four data-path operators is ONE of two gathers over a "class grid" q:
+//   form 0 (regular):     out[n, q, co] = sum over (tap, c) of in[n, q * s + (k - pad), c] * W[tap][c][co]
+//       = Conv2d forward, ConvTranspose2d data gradient
+//   form 1 (transposed):  out[n, s * q + p, co] = sum over the taps k with (p + pad - k) % s == 0 and c of
+//                                                 in[n, q + (p + pad - k) / s, c] * W[tap][c][co]      (p = sub-pixel class)
+//       = ConvTranspose2d forward, Conv2d data gradient
+// with the weight tensor addressed through three strides (tap, reduced channel, output channel), so that Conv2d's
+// [Cout][k][k][Cin] and ConvTranspose2d's [Cin][k][k][Cout] storage (channels-last parameters, spkdiff/fused.py) and both
+// transpositions are the same code.  A workgroup stages its class's weight taps in LDS once, in B-fragment order
+// ([tap][c / 8][c / 4 % 2][co][c % 4]: one 16-byte read = the B operands of four MFMAs), and walks 64-row groups of output
+// positions: a lane reads 16 bytes of its row's input record per eight reduced channels (the A operands of the same four
+// MFMAs; the K order inside a group of eight is a permutation both operands share), so a tap costs one global and one LDS read
+// per four to eight MFMAs.  Rows of a tile share the tap list (sub-pixel classes are separate grid rows): no multiplication
+// by structural zeros in the transposed form.
+//
+// Weight gradient: D[tap][cu][cv] = sum over (n, q) of U[n, q * s - pad + k][cu] * V[n, q][cv]  (Conv2d: U = input, V = gy;
+// ConvTranspose2d: U = gy, V = input -- the tensor on the finer grid is U).  Rows = cv, columns = cu, K = positions; the 32x32 tiles
+// (tap, cu / 32, cv / 32) are dealt to the four waves of a workgroup, every workgroup owns a contiguous range of positions and writes
+// its partial tiles, and a second launch adds the partials in a fixed order (deterministic) and scatters them through the
+// gradient's strides; the bias gradient (a column sum of gy) rides along in both launches.
+//
+// One-channel sides (the 1 -> 32 first layer and the 32 -> 1 last layer) are vector kernels: there is no matrix in them.
+#include "spk_common.h"
+#include "../../include/spkdiff.h"
+
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int MAX_TAPS = 16;                       // k <= 4
+constexpr int GATHER_LDS_MAX = 150 * 1024;
+
+struct GArgs {
+  const float* in; const float* w; const float* bias; float* out;
+  int N, Hi, Wi, Cred, Ho, Wo, Cout;
+  int k, stride, pad, form;
+  long long w_tap, w_red, w_out;
+};
+
+// taps of sub-pixel class (py, px): index into the k x k kernel and the input offset of the tap
+struct TapList { int n; int tap[MAX_TAPS], dy[MAX_TAPS], dx[MAX_TAPS]; };
+
+__device__ __forceinline__ void build_taps(TapList& tl, int k, int stride, int pad, int form, int py, int px) {
+  int n = 0;
+  for (int ky = 0; ky < k; ++ky)
+    for (int kx = 0; kx < k; ++kx) {
+      int dy, dx;
+      bool ok = true;
+      if (!form) { dy = ky - pad; dx = kx - pad; }
+      else {
+        const int ty = py + pad - ky, tx = px + pad - kx;
+        ok = (ty % stride == 0) && (tx % stride == 0);
+        dy = ty / stride; dx = tx / stride;
+      }
+      if (ok && n < MAX_TAPS) { tl.tap[n] = ky * k + kx; tl.dy[n] = dy; tl.dx[n] = dx; ++n; }
+    }
+  tl.n = n;
+}
+
+// J = Cred / 8, CN = column tiles (32 output channels each) of a wave, RM = row tiles (32 output positions each) of a wave.
+// blockIdx.y = first column tile of the workgroup (the host splits the column tiles over workgroups when the layer has too few
+// rows to fill the chip otherwise).  A workgroup stages ALL k * k taps once and walks (sub-pixel class, row group) items: the
+// classes of the transposed form have 1 .. ceil(k / s)^2 taps each, so a workgroup per class would leave the chip waiting for
+// the largest class.
+constexpr int MAX_CLASSES = 16;                     // stride <= 4
+struct ClassTab { int ncls, cs; int first[MAX_CLASSES + 1]; int Qh[MAX_CLASSES], Qw[MAX_CLASSES]; TapList tl[MAX_CLASSES]; };
+
+template <int J, int CN, int RM>
+__global__ __launch_bounds__(256, 2) void conv_train_gather_kernel(GArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float4 sB[];       // [tap][J][2][CN * 32]
+  __shared__ ClassTab ct;
+  constexpr int CP = CN * 32, CRED = J * 8, ROWS = RM * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cs = a.form ? a.stride : 1;            // output step per class-grid step
+  const int ai = a.form ? 1 : a.stride;            // input step per class-grid step
+  const int co0 = blockIdx.y * CP;                 // first output channel of this workgroup
+  if (tid == 0) {
+    ct.ncls = cs * cs; ct.cs = cs;
+    int first = 0;
+    for (int c = 0; c < cs * cs; ++c) {
+      const int py = c / cs, px = c % cs;
+      build_taps(ct.tl[c], a.k, a.stride, a.pad, a.form, py, px);
+      ct.Qh[c] = (a.Ho - py + cs - 1) / cs;
+      ct.Qw[c] = (a.Wo - px + cs - 1) / cs;
+      ct.first[c] = first;
+      first += (int)(((long long)a.N * ct.Qh[c] * ct.Qw[c] + ROWS - 1) / ROWS);
+    }
+    ct.first[cs * cs] = first;
+  }
+  const int ntap = a.k * a.k;
+  for (int e = tid; e < ntap * CRED * CP; e += 256) {
+    const int co = e % CP, r = e / CP, c = r % CRED, t = r / CRED;
+    const float v = co0 + co < a.Cout ? a.w[t * a.w_tap + c * a.w_red + (co0 + co) * a.w_out] : 0.f;
+    reinterpret_cast<float*>(sB)[((((t * J + (c >> 3)) * 2 + ((c >> 2) & 1)) * CP + co) << 2) + (c & 3)] = v;
+  }
+  __syncthreads();
+
+  const int nitems = ct.first[cs * cs];
+  const int r = lane & 31, h = lane >> 5;
+  for (int item = blockIdx.x * 4 + wave; item < nitems; item += gridDim.x * 4) {
+    int cls = 0;
+    while (item >= ct.first[cls + 1]) ++cls;
+    const TapList& tl = ct.tl[cls];
+    const int py = cls / cs, px = cls % cs;
+    const int Qh = ct.Qh[cls], Qw = ct.Qw[cls];
+    const long long M = (long long)a.N * Qh * Qw;
+    const int gi = item - ct.first[cls];
+    const int nt = tl.n;
+    int n_[RM], qy_[RM], qx_[RM], opos[RM];
+    bool rv[RM];
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm) {
+      const long long R = (long long)gi * ROWS + rm * 32 + r;
+      rv[rm] = R < M;
+      const int Rc = rv[rm] ? (int)R : 0;
+      qx_[rm] = Rc % Qw;
+      const int t = Rc / Qw;
+      qy_[rm] = t % Qh;
+      n_[rm] = t / Qh;
+      opos[rm] = rv[rm] ? (n_[rm] * a.Ho + qy_[rm] * cs + py) * a.Wo + qx_[rm] * cs + px : -1;
+    }
+    v16f acc[RM][CN];
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+      for (int cn = 0; cn < CN; ++cn)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[rm][cn][i] = 0.f;
+    float4 A[2][RM][J];                             // [buffer][row tile][j]: the next tap's records are requested before this tap's MFMAs
+    auto load_a = [&](int t, float4 (&dst)[RM][J]) {
+      const int dy = tl.dy[t], dx = tl.dx[t];
+#pragma unroll
+      for (int rm = 0; rm < RM; ++rm) {
+        const int iy = qy_[rm] * ai + dy, ix = qx_[rm] * ai + dx;
+        const bool ok = rv[rm] && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
+        const float4* p = reinterpret_cast<const float4*>(a.in + (((long long)n_[rm] * a.Hi + iy) * a.Wi + ix) * CRED + 4 * h);
+#pragma unroll
+        for (int j = 0; j < J; ++j) dst[rm][j] = ok ? p[2 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    auto mma = [&](int t, const float4 (&src)[RM][J]) {
+      const int tap = tl.tap[t];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        float4 B[CN];
+#pragma unroll
+        for (int cn = 0; cn < CN; ++cn) B[cn] = sB[((tap * J + j) * 2 + h) * CP + cn * 32 + r];
+        // consecutive MFMAs write different accumulators
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+            for (int cn = 0; cn < CN; ++cn) {
+              const float av = q == 0 ? src[rm][j].x : q == 1 ? src[rm][j].y : q == 2 ? src[rm][j].z : src[rm][j].w;
+              const float bv = q == 0 ? B[cn].x : q == 1 ? B[cn].y : q == 2 ? B[cn].z : B[cn].w;
+              acc[rm][cn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[rm][cn], 0, 0, 0);
+            }
+      }
+    };
+    if (nt > 0) load_a(0, A[0]);
+    int t = 0;
+    for (; t + 1 < nt; t += 2) {
+      load_a(t + 1, A[1]);
+      mma(t, A[0]);
+      if (t + 2 < nt) load_a(t + 2, A[0]);
+      mma(t + 1, A[1]);
+    }
+    if (t < nt) mma(t, A[0]);
+
+    // D[i][j]: j = lane & 31, i = 8 * (reg / 4) + 4 * (lane / 32) + reg % 4
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm) {
+      int orow[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) orow[i] = __shfl(opos[rm], 8 * (i >> 2) + 4 * h + (i & 3));
+#pragma unroll
+      for (int cn = 0; cn < CN; ++cn) {
+        const int co = co0 + cn * 32 + r;
+        const float bv = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+        if (co < a.Cout) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (orow[i] >= 0) a.out[(long long)orow[i] * a.Cout + co] = acc[rm][cn][i] + bv;
+        }
+      }
+    }
+  }
+}
+
+// ---- one output channel (the 32 -> 1 read-out layer): LP = Cred / 4 lanes per output position, 16 bytes per lane and tap ----
+template <int LP>
+__global__ __launch_bounds__(256) void conv_train_c1out_kernel(GArgs a) {
+  __shared__ float4 sW[MAX_TAPS * LP];
+  const int tid = threadIdx.x;
+  const int nt = a.k * a.k;
+  for (int e = tid; e < nt * LP * 4; e += 256) {
+    const int c = e % (LP * 4), t = e / (LP * 4);
+    reinterpret_cast<float*>(sW)[e] = a.w[t * a.w_tap + c * a.w_red];
+  }
+  __syncthreads();
+  const int cq = tid % LP;
+  const long long M = (long long)a.N * a.Ho * a.Wo;
+  const float b0 = a.bias ? a.bias[0] : 0.f;
+  const int sgn = a.form ? -1 : 1, ai = a.form ? 1 : a.stride;
+  constexpr int PER = 256 / LP;
+  const long long ngroups = (M + PER - 1) / PER;    // every lane of a position group takes part in the exchange below
+  for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const long long P = g * PER + tid / LP;
+    const bool pv = P < M;
+    const int Pc = pv ? (int)P : 0;
+    const int ox = Pc % a.Wo, t2 = Pc / a.Wo, oy = t2 % a.Ho, n = t2 / a.Ho;
+    float acc = 0.f;
+    for (int ky = 0; ky < a.k; ++ky) {
+      const int iy = oy * ai + sgn * (ky - a.pad);
+      if (iy < 0 || iy >= a.Hi) continue;
+      for (int kx = 0; kx < a.k; ++kx) {
+        const int ix = ox * ai + sgn * (kx - a.pad);
+        if (ix < 0 || ix >= a.Wi) continue;
+        const float4 x = *reinterpret_cast<const float4*>(a.in + (((long long)n * a.Hi + iy) * a.Wi + ix) * (LP * 4) + 4 * cq);
+        const float4 w = sW[(ky * a.k + kx) * LP + cq];
+        acc = fmaf(x.x, w.x, acc); acc = fmaf(x.y, w.y, acc); acc = fmaf(x.z, w.z, acc); acc = fmaf(x.w, w.w, acc);
+      }
+    }
+#pragma unroll
+    for (int m = LP / 2; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+    if (pv && cq == 0) a.out[P] = acc + b0;
+  }
+}
+
+// ---- one reduced channel (the 1 -> 32 first layer forward, the read-out layer's data gradient): regular form ----
+__global__ __launch_bounds__(256) void conv_train_c1in_kernel(GArgs a) {
+  extern __shared__ float sW1[];                    // [tap][Cout]
+  const int tid = threadIdx.x, C = a.Cout, CQ = C >> 2;
+  const int nt = a.k * a.k;
+  for (int e = tid; e < nt * C; e += 256) sW1[e] = a.w[(e / C) * a.w_tap + (e % C) * a.w_out];
+  __syncthreads();
+  const long long M = (long long)a.N * a.Ho * a.Wo * CQ;
+  for (long long e = (long long)blockIdx.x * 256 + tid; e < M; e += (long long)gridDim.x * 256) {
+    const int cq = (int)(e % CQ);
+    const int P = (int)(e / CQ);
+    const int ox = P % a.Wo, t2 = P / a.Wo, oy = t2 % a.Ho, n = t2 / a.Ho;
+    float4 acc = a.bias ? *reinterpret_cast<const float4*>(a.bias + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ky = 0; ky < a.k; ++ky) {
+      const int iy = oy * a.stride + ky - a.pad;
+      if (iy < 0 || iy >= a.Hi) continue;
+      for (int kx = 0; kx < a.k; ++kx) {
+        const int ix = ox * a.stride + kx - a.pad;
+        if (ix < 0 || ix >= a.Wi) continue;
+        const float x = a.in[((long long)n * a.Hi + iy) * a.Wi + ix];
+        const float4 w = *reinterpret_cast<const float4*>(sW1 + (ky * a.k + kx) * C + 4 * cq);
+        acc.x = fmaf(x, w.x, acc.x); acc.y = fmaf(x, w.y, acc.y); acc.z = fmaf(x, w.z, acc.z); acc.w = fmaf(x, w.w, acc.w);
+      }
+    }
+    *reinterpret_cast<float4*>(a.out + (long long)P * C + 4 * cq) = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+struct WArgs {
+  const float* u; const float* v; float* part;
+  int N, Hu, Wu, Cu, Hv, Wv, Cv;
+  int k, stride, pad;
+  int bias_from;                                    // 0: none, 1: column sums of v, 2: column sums of u
+  int nwg, psize;                                   // workgroups, floats per workgroup in `part`
+  float* gw; float* gb;
+  long long g_tap, g_u, g_v;
+};
+
+// NTW = tiles per wave (tile ti = (wave & 3) + 4 * i; ti = (tap * CUT + cut) * CVT + cvt).  SPLIT = 2: eight waves, waves 4..7 take
+// the second half of the workgroup's positions and their tiles are added to those of waves 0..3 through LDS (a fixed order) --
+// twice the loads in flight per CU for the same number of partial tiles.  UNR steps (two positions each) are requested before
+// the first of their MFMAs: one step's operands are ~10 dword loads per lane, and without the unrolling the loop runs at the
+// latency of one load per five MFMAs.
+template <int NTW, int SPLIT>
+__global__ __launch_bounds__(256 * SPLIT) void conv_train_wgrad_kernel(WArgs a) {
+  constexpr int UNR = NTW <= 5 ? 4 : 2;
+  extern __shared__ __attribute__((aligned(16))) float s_x[];        // SPLIT 2: [4 waves][NTW][16][64] floats; bias sums: 256 floats
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wq = wave & 3, part_id = wave >> 2;
+  const int CUT = (a.Cu + 31) >> 5, CVT = (a.Cv + 31) >> 5;
+  const int ntile = a.k * a.k * CUT * CVT;
+  const long long Ms = (long long)a.N * a.Hv * a.Wv;
+  const long long per = ((Ms + a.nwg - 1) / a.nwg + 2 * SPLIT - 1) / (2 * SPLIT) * (2 * SPLIT);   // even halves
+  const long long w0 = (long long)blockIdx.x * per;
+  const long long p0 = w0 + part_id * (per / SPLIT);
+  long long p1 = p0 + per / SPLIT;
+  p1 = p1 < Ms ? p1 : Ms;
+  const int rc = lane & 31, kk = lane >> 5;
+  int t_dy[NTW], t_dx[NTW], t_cu[NTW], t_cv[NTW];
+  bool t_ok[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    const int ti = wq + 4 * i;
+    t_ok[i] = ti < ntile;
+    const int tc = t_ok[i] ? ti : 0;
+    const int cvt = tc % CVT, r2 = tc / CVT, cut = r2 % CUT, tap = r2 / CUT;
+    t_dy[i] = tap / a.k - a.pad;
+    t_dx[i] = tap % a.k - a.pad;
+    t_cu[i] = cut * 32 + rc;
+    t_cv[i] = cvt * 32 + rc;
+  }
+  const bool a_shared = (4 % CVT) == 0;              // every tile of a wave has the same row tile: one A operand per step
+  v16f acc[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  if (p0 < p1) {
+    long long p = p0 + kk;
+    int qx = (int)(p % a.Wv);
+    long long t2 = p / a.Wv;
+    int qy = (int)(t2 % a.Hv), n = (int)(t2 / a.Hv);
+    for (; p - kk < p1; p += 2 * UNR) {
+      float av[UNR][NTW], bv[UNR][NTW];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const long long pu = p + 2 * u;
+        const bool pv = pu < p1;
+        const float* vrow = a.v + pu * a.Cv;
+        const int by = qy * a.stride, bx = qx * a.stride;
+        const float* urow = a.u + (((long long)n * a.Hu + by) * a.Wu + bx) * a.Cu;
+        if (a_shared) {
+          const float x = (pv && t_cv[0] < a.Cv) ? vrow[t_cv[0]] : 0.f;
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) av[u][i] = x;
+        } else {
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) av[u][i] = (pv && t_ok[i] && t_cv[i] < a.Cv) ? vrow[t_cv[i]] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+          const int iy = by + t_dy[i], ix = bx + t_dx[i];
+          const bool ok = pv && t_ok[i] && t_cu[i] < a.Cu && iy >= 0 && iy < a.Hu && ix >= 0 && ix < a.Wu;
+          bv[u][i] = ok ? urow[(t_dy[i] * a.Wu + t_dx[i]) * a.Cu + t_cu[i]] : 0.f;
+        }
+        qx += 2;
+        while (qx >= a.Wv) {
+          qx -= a.Wv;
+          if (++qy >= a.Hv) { qy = 0; ++n; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][i], acc[i], 0, 0, 0);
+    }
+  }
+  if (SPLIT == 2) {
+    if (part_id == 1) {
+#pragma unroll
+      for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_x[((wq * NTW + i) * 16 + r) * 64 + lane] = acc[i][r];
+    }
+    __syncthreads();
+    if (part_id == 0) {
+#pragma unroll
+      for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] += s_x[((wq * NTW + i) * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  float* part = a.part + (long long)blockIdx.x * a.psize;
+  if (part_id == 0) {
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+      if (t_ok[i]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[(long long)(wq + 4 * i) * 1024 + r * 64 + lane] = acc[i][r];
+      }
+  }
+  // bias gradient: column sums of this workgroup's slice of gy
+  if (a.bias_from) {
+    constexpr int NT = 256 * SPLIT;
+    const float* g = a.bias_from == 1 ? a.v : a.u;
+    const int C = a.bias_from == 1 ? a.Cv : a.Cu;
+    const long long Mg = a.bias_from == 1 ? Ms : (long long)a.N * a.Hu * a.Wu;
+    const long long perg = (Mg + a.nwg - 1) / a.nwg;
+    const long long g0 = (long long)blockIdx.x * perg;
+    long long g1 = g0 + perg;
+    g1 = g1 < Mg ? g1 : Mg;
+    const int RL = NT / C;                           // (C <= 64; threads beyond RL * C idle)
+    const int c = tid % C, rl = tid / C;
+    float s = 0.f;
+    if (rl < RL)
+      for (long long row = g0 + rl; row < g1; row += RL) s += g[row * C + c];
+    s_x[tid] = s;
+    __syncthreads();
+    if (tid < C) {
+      float tot = 0.f;
+      for (int q = 0; q < RL; ++q) tot += s_x[q * C + tid];
+      part[(long long)ntile * 1024 + tid] = tot;
+    }
+  }
+}
+
+// adds the partials of all workgroups and scatters: tiles (MODE 0) or plain [tap][c] rows (MODE 1).  Eight threads per output
+// element take every eighth workgroup's partial and are added in thread order: a fixed order, and loads that do not wait for
+// one another.
+template <int MODE>
+__global__ __launch_bounds__(256) void conv_train_wgrad_reduce_kernel(WArgs a) {
+  __shared__ float s_q[256];
+  const int CUT = (a.Cu + 31) >> 5, CVT = (a.Cv + 31) >> 5;
+  const int nt = a.k * a.k;
+  const int E = MODE == 0 ? nt * a.Cu * a.Cv : nt * a.Cv;
+  const int CB = a.bias_from == 0 ? 0 : (a.bias_from == 1 ? a.Cv : a.Cu);
+  const int el = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;
+  long long src = 0;
+  float* dst = nullptr;
+  if (e < E) {
+    if (MODE == 0) {
+      const int cu = e % a.Cu, r2 = e / a.Cu, cv = r2 % a.Cv, tap = r2 / a.Cv;
+      const int ti = (tap * CUT + (cu >> 5)) * CVT + (cv >> 5);
+      const int row = cv & 31, col = cu & 31;
+      src = (long long)ti * 1024 + ((row >> 3) * 4 + (row & 3)) * 64 + col + 32 * ((row >> 2) & 1);
+      dst = a.gw + tap * a.g_tap + cu * a.g_u + cv * a.g_v;
+    } else {
+      const int cv = e % a.Cv, tap = e / a.Cv;
+      src = e;
+      dst = a.gw + tap * a.g_tap + cv * a.g_v;
+    }
+  } else if (e < E + CB) {
+    src = (MODE == 0 ? (long long)nt * CUT * CVT * 1024 : (long long)E) + (e - E);
+    dst = a.gb + (e - E);
+  }
+  float s = 0.f;
+  if (dst)
+    for (int w = q; w < a.nwg; w += 8) s += a.part[(long long)w * a.psize + src];
+  s_q[threadIdx.x] = s;
+  __syncthreads();
+  if (q == 0 && dst) {
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += s_q[k * 32 + el];
+    *dst = tot;
+  }
+}
+
+// one-channel U (the first layer's input, the read-out layer's gy): D[tap][cv] = sum over (n, q) of u[n, q * s - pad + k] * V[n, q][cv]
+__global__ __launch_bounds__(256) void conv_train_c1_wgrad_kernel(WArgs a) {
+  extern __shared__ float s_acc[];                  // [256 / CQ][(nt + 1) * Cv]
+  const int tid = threadIdx.x, C = a.Cv, CQ = C >> 2, RL = 256 / CQ;
+  const int nt = a.k * a.k;
+  const int cq = tid % CQ, rl = tid / CQ;
+  const long long Ms = (long long)a.N * a.Hv * a.Wv;
+  const long long per = (Ms + a.nwg - 1) / a.nwg;
+  const long long p0 = (long long)blockIdx.x * per;
+  long long p1 = p0 + per;
+  p1 = p1 < Ms ? p1 : Ms;
+  float4 acc[MAX_TAPS];
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  float usum = 0.f;
+  for (int t = 0; t < MAX_TAPS; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long long p = p0 + rl; p < p1; p += RL) {
+    const int qx = (int)(p % a.Wv);
+    const long long t2 = p / a.Wv;
+    const int qy = (int)(t2 % a.Hv), n = (int)(t2 / a.Hv);
+    const float4 g = *reinterpret_cast<const float4*>(a.v + p * C + 4 * cq);
+    bsum.x += g.x; bsum.y += g.y; bsum.z += g.z; bsum.w += g.w;
+#pragma unroll
+    for (int t = 0; t < MAX_TAPS; ++t) {
+      if (t < nt) {
+        const int iy = qy * a.stride - a.pad + t / a.k, ix = qx * a.stride - a.pad + t % a.k;
+        const bool ok = iy >= 0 && iy < a.Hu && ix >= 0 && ix < a.Wu;
+        const float x = ok ? a.u[((long long)n * a.Hu + iy) * a.Wu + ix] : 0.f;
+        acc[t].x = fmaf(x, g.x, acc[t].x); acc[t].y = fmaf(x, g.y, acc[t].y);
+        acc[t].z = fmaf(x, g.z, acc[t].z); acc[t].w = fmaf(x, g.w, acc[t].w);
+      }
+    }
+  }
+  if (a.bias_from == 2) {                           // column sum of the one-channel tensor: its own slice, one thread row
+    const long long Mu = (long long)a.N * a.Hu * a.Wu;
+    const long long peru = (Mu + a.nwg - 1) / a.nwg;
+    const long long u0 = (long long)blockIdx.x * peru;
+    long long u1 = u0 + peru;
+    u1 = u1 < Mu ? u1 : Mu;
+    for (long long q = u0 + tid; q < u1; q += 256) usum += a.u[q];
+  }
+  // workgroup reduction in a fixed order
+  const int W = (nt + 1) * C;
+#pragma unroll
+  for (int t = 0; t < MAX_TAPS; ++t)
+    if (t < nt) *reinterpret_cast<float4*>(s_acc + rl * W + t * C + 4 * cq) = acc[t];
+  *reinterpret_cast<float4*>(s_acc + rl * W + nt * C + 4 * cq) = bsum;
+  __syncthreads();
+  float* part = a.part + (long long)blockIdx.x * a.psize;
+  for (int e = tid; e < W; e += 256) {
+    float s = 0.f;
+    for (int q = 0; q < RL; ++q) s += s_acc[q * W + e];
+    if (e < nt * C) part[e] = s;
+    else if (a.bias_from == 1) part[e] = s;
+  }
+  if (a.bias_from == 2) {
+    __syncthreads();
+    s_acc[tid] = usum;
+    __syncthreads();
+    if (tid == 0) {
+      float s = 0.f;
+      for (int q = 0; q < 256; ++q) s += s_acc[q];
+      part[nt * C] = s;
+    }
+  }
+}
+
+int gather_kind(int Cred, int Cout, int k, int stride, int form) {
+  if (k < 1 || k * k > MAX_TAPS || stride < 1 || Cred < 1 || Cout < 1) return 0;
+  if (Cred == 1) return (!form && (Cout % 4) == 0 && k * k * Cout * 4 <= 64 * 1024) ? 3 : 0;
+  if (Cout == 1) {
+    if (form && stride != 1) return 0;
+    return (Cred == 8 || Cred == 16 || Cred == 32 || Cred == 64) ? 2 : 0;
+  }
+  if (Cred % 8 != 0 || Cred > 64 || Cout > 64) return 0;
+  const int CP = (Cout + 31) / 32 * 32;
+  if (stride > 4 || (long long)k * k * Cred * CP * 4 > GATHER_LDS_MAX) return 0;
+  return 1;
+}
+
+template <int J, int CN, int RM>
+void launch_gather(const GArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_train_gather_kernel<J, CN, RM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  hipLaunchKernelGGL((conv_train_gather_kernel<J, CN, RM>), grid, dim3(256), lds, s, a);
+}
+template <int J>
+void launch_gather_j(const GArgs& a, int CN, int RM, dim3 grid, size_t lds, hipStream_t s) {
+  if (CN == 2) launch_gather<J, 2, 2>(a, grid, lds, s);
+  else if (RM == 2) launch_gather<J, 1, 2>(a, grid, lds, s);
+  else launch_gather<J, 1, 1>(a, grid, lds, s);
+}
+
+}  // namespace
+
+extern "C" int spk_conv_train_gather_supported(int Cred, int Cout, int k, int stride, int form) {
+  return gather_kind(Cred, Cout, k, stride, form) != 0;
+}
+
+extern "C" int spk_conv_train_gather(const float* in_cl, const float* w, const float* bias_or_null, float* out_cl, int N, int Hi,
+                                     int Wi, int Cred, int Ho, int Wo, int Cout, int k, int stride, int pad, int form,
+                                     long long w_tap, long long w_red, long long w_out, spk_stream_t stream) {
+  if (!in_cl || !w || !out_cl || N <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || pad < 0) return SPK_ERR_ARG;
+  const int kind = gather_kind(Cred, Cout, k, stride, form);
+  if (!kind) return SPK_ERR_UNSUPPORTED;
+  if ((long long)N * Ho * Wo >= (1ll << 31) / 64 * 64 || (long long)N * Hi * Wi >= (1ll << 31)) return SPK_ERR_UNSUPPORTED;
+  GArgs a{in_cl, w, bias_or_null, out_cl, N, Hi, Wi, Cred, Ho, Wo, Cout, k, stride, pad, form, w_tap, w_red, w_out};
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long long M = (long long)N * Ho * Wo;
+  if (kind == 3) {
+    const long long work = M * (Cout / 4);
+    const int blocks = (int)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
+    hipLaunchKernelGGL(conv_train_c1in_kernel, dim3(blocks), dim3(256), (size_t)k * k * Cout * 4, s, a);
+  } else if (kind == 2) {
+    const int LP = Cred / 4, per = 256 / LP;
+    const int blocks = (int)((M + per - 1) / per < 8192 ? (M + per - 1) / per : 8192);
+    if (LP == 2) hipLaunchKernelGGL(conv_train_c1out_kernel<2>, dim3(blocks), dim3(256), 0, s, a);
+    else if (LP == 4) hipLaunchKernelGGL(conv_train_c1out_kernel<4>, dim3(blocks), dim3(256), 0, s, a);
+    else if (LP == 8) hipLaunchKernelGGL(conv_train_c1out_kernel<8>, dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv_train_c1out_kernel<16>, dim3(blocks), dim3(256), 0, s, a);
+  } else {
+    const int cs = form ? stride : 1;
+    if (cs * cs > MAX_CLASSES) return SPK_ERR_UNSUPPORTED;
+    const int CNT = (Cout + 31) / 32, J = Cred / 8;
+    // 64-row x all-column items when there are at least two per SIMD; otherwise 32 rows x one column tile (more, smaller items)
+    long long items64 = 0, items32 = 0;
+    for (int c = 0; c < cs * cs; ++c) {
+      const long long Mc = (long long)N * ((Ho - c / cs + cs - 1) / cs) * ((Wo - c % cs + cs - 1) / cs);
+      items64 += (Mc + 63) / 64;
+      items32 += (Mc + 31) / 32;
+    }
+    const bool big = items64 >= 2048;
+    const int CN = big ? CNT : 1, RM = big ? 2 : 1;
+    const long long items = big ? items64 : items32;
+    const int gy = big ? 1 : CNT;
+    const size_t lds = (size_t)k * k * Cred * CN * 32 * 4;
+    int gx = (int)((items + 3) / 4);
+    const int cap = 512 / gy;                                        // two workgroups per CU
+    gx = gx < cap ? gx : cap;
+    dim3 grid(gx, gy);
+    switch (J) {
+      case 1: launch_gather_j<1>(a, CN, RM, grid, lds, s); break;
+      case 2: launch_gather_j<2>(a, CN, RM, grid, lds, s); break;
+      case 3: launch_gather_j<3>(a, CN, RM, grid, lds, s); break;
+      case 4: launch_gather_j<4>(a, CN, RM, grid, lds, s); break;
+      case 5: launch_gather_j<5>(a, CN, RM, grid, lds, s); break;
+      case 6: launch_gather_j<6>(a, CN, RM, grid, lds, s); break;
+      case 7: launch_gather_j<7>(a, CN, RM, grid, lds, s); break;
+      default: launch_gather_j<8>(a, CN, RM, grid, lds, s); break;
+    }
+  }
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}
+
+namespace {
+int wgrad_kind(int Cu, int Cv, int k) {
+  if (k < 1 || k * k > MAX_TAPS || Cu < 1 || Cv < 1) return 0;
+  if (Cu == 1) return (Cv % 4 == 0 && Cv <= 64 && 256 % (Cv / 4) == 0) ? 2 : 0;
+  if (Cu > 64 || Cv > 64) return 0;
+  const int ntile = k * k * ((Cu + 31) / 32) * ((Cv + 31) / 32);
+  return ntile <= 36 ? 1 : 0;
+}
+int wgrad_nwg(int kind, long long Ms) {
+  long long n = kind == 1 ? (Ms + 63) / 64 : (Ms + 255) / 256;      // at least 64 positions per workgroup
+  const int cap = 256;
+  return (int)(n < 1 ? 1 : (n < cap ? n : cap));
+}
+int wgrad_psize(int kind, int Cu, int Cv, int k) {
+  if (kind == 1) return k * k * ((Cu + 31) / 32) * ((Cv + 31) / 32) * 1024 + 64;
+  return (k * k + 1) * Cv + 4;
+}
+}  // namespace
+
+extern "C" long long spk_conv_train_wgrad_ws_bytes(int N, int Hv, int Wv, int Cu, int Cv, int k) {
+  const int kind = wgrad_kind(Cu, Cv, k);
+  if (!kind || N <= 0 || Hv <= 0 || Wv <= 0) return -1;
+  const long long Ms = (long long)N * Hv * Wv;
+  return (long long)wgrad_nwg(kind, Ms) * wgrad_psize(kind, Cu, Cv, k) * 4;
+}
+
+extern "C" int spk_conv_train_wgrad(const float* u_cl, const float* v_cl, float* ws, long long ws_bytes, float* gw_out,
+                                    float* gb_out_or_null, int N, int Hu, int Wu, int Cu, int Hv, int Wv, int Cv, int k, int stride,
+                                    int pad, long long g_tap, long long g_u, long long g_v, int bias_from, spk_stream_t stream) {
+  if (!u_cl || !v_cl || !ws || !gw_out || N <= 0 || Hu <= 0 || Wu <= 0 || Hv <= 0 || Wv <= 0 || stride < 1 || pad < 0 ||
+      bias_from < 0 || bias_from > 2)
+    return SPK_ERR_ARG;
+  const int kind = wgrad_kind(Cu, Cv, k);
+  if (!kind) return SPK_ERR_UNSUPPORTED;
+  if ((long long)N * Hu * Wu >= (1ll << 31) || (long long)N * Hv * Wv >= (1ll << 31)) return SPK_ERR_UNSUPPORTED;
+  if (ws_bytes < spk_conv_train_wgrad_ws_bytes(N, Hv, Wv, Cu, Cv, k)) return SPK_ERR_ARG;
+  if (!gb_out_or_null) bias_from = 0;
+  const long long Ms = (long long)N * Hv * Wv;
+  WArgs a{u_cl, v_cl, ws, N, Hu, Wu, Cu, Hv, Wv, Cv, k, stride, pad, bias_from, wgrad_nwg(kind, Ms), wgrad_psize(kind, Cu, Cv, k),
+          gw_out, gb_out_or_null, g_tap, g_u, g_v};
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (kind == 1) {
+    const int ntile = k * k * ((Cu + 31) / 32) * ((Cv + 31) / 32);
+    const int ntw = (ntile + 3) / 4;
+#define SPK_WG_LAUNCH(N_, S_)                                                                                          \
+  do {                                                                                                                 \
+    const size_t lds_ = (S_) == 2 ? (size_t)4 * (N_) * 16 * 64 * 4 : 2048;                                             \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_train_wgrad_kernel<N_, S_>),                         \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                                  \
+    hipLaunchKernelGGL((conv_train_wgrad_kernel<N_, S_>), dim3(a.nwg), dim3(256 * (S_)), lds_, s, a);                  \
+  } while (0)
+    switch (ntw) {
+      case 1: SPK_WG_LAUNCH(1, 2); break;
+      case 2: SPK_WG_LAUNCH(2, 2); break;
+      case 3: SPK_WG_LAUNCH(3, 2); break;
+      case 4: SPK_WG_LAUNCH(4, 2); break;
+      case 5: SPK_WG_LAUNCH(5, 2); break;
+      case 6: SPK_WG_LAUNCH(6, 1); break;
+      case 7: SPK_WG_LAUNCH(7, 1); break;
+      case 8: SPK_WG_LAUNCH(8, 1); break;
+      default: SPK_WG_LAUNCH(9, 1); break;
+    }
+#undef SPK_WG_LAUNCH
+    SPK_LAUNCH_CHECK();
+    const int CB = bias_from == 0 ? 0 : (bias_from == 1 ? Cv : Cu);
+    const int E = k * k * Cu * Cv + CB;
+    hipLaunchKernelGGL(conv_train_wgrad_reduce_kernel<0>, dim3((E + 31) / 32), dim3(256), 0, s, a);
+  } else {
+    const int RL = 256 / (Cv / 4);
+    const size_t lds = (size_t)RL * (k * k + 1) * Cv * 4;
+    if (lds > 64 * 1024) return SPK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(conv_train_c1_wgrad_kernel, dim3(a.nwg), dim3(256), lds < 1024 ? 1024 : lds, s, a);
+    SPK_LAUNCH_CHECK();
+    const int CB = bias_from == 0 ? 0 : (bias_from == 1 ? Cv : 1);
+    const int E = k * k * Cv + CB;
+    hipLaunchKernelGGL(conv_train_wgrad_reduce_kernel<1>, dim3((E + 31) / 32), dim3(256), 0, s, a);
+  }
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
+}

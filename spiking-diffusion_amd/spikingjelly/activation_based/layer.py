@@ -4,10 +4,11 @@ Surface of SJ/activation_based/layer.py:125-173, :276-325, :423-465, :900-922.  
 layers (parameters, ``state_dict`` keys and constructors are torch's), but ``forward`` runs the HIP kernels of
 ``libspkdiff.so``; in 'm' mode T is folded into the batch exactly like ``functional.seq_to_ann_forward``.
 
-Training: when a module is in train() mode with autograd enabled, a convolution runs its exact
-direct kernel forward (small layers; the library operator beyond ops.EXACT_TRAIN_FORWARD_MACS) with the framework's
-convolution backward, and a stand-alone batch-norm runs as the ROCm library operator through torch -- the same split as
-the reference, whose training uses cuDNN for these and a native kernel pair for the neuron.  The
+Training: when a module is in train() mode with autograd enabled, a convolution runs forward and
+backward on this library's fp32 matrix-core training kernels (ops.NativeConvTrainFunction, csrc/conv_train.hip).  Shapes
+those kernels do not take (and every layer when ops.NATIVE_TRAIN_FORWARD is off: the parity runs) run the exact direct kernel
+forward up to ops.EXACT_TRAIN_FORWARD_MACS multiply-accumulates and the framework's operator beyond, with the native backward
+where it fits and the framework's otherwise; a stand-alone batch-norm runs as the ROCm library operator through torch.  The
 native training operators of this build are the surrogate-gradient LIF and the fused BatchNorm+LIF block tail
 (``spkdiff.ops.LIFTrainFunction`` / ``BNLIFTrainFunction``), which ``snn_model`` uses for its Conv-BN-LIF blocks.
 """
@@ -74,7 +75,10 @@ class Conv2d(nn.Conv2d, base.StepModule):
         if _library_path(self, y):
             k, st, pd = self.kernel_size[0], _one(self.stride, 'stride'), _one(self.padding, 'padding')
             macs = y.shape[0] * self.out_channels * self.in_channels * k * k * (y.shape[2] // st) * (y.shape[3] // st)
-            if macs <= ops.EXACT_TRAIN_FORWARD_MACS:
+            if ops.NATIVE_TRAIN_FORWARD and ops.conv_train_supported(y.shape, self.weight, st, pd, False, 0, y.requires_grad,
+                                                                     forward=True):
+                y = ops.NativeConvTrainFunction.apply(y, self.weight, self.bias, st, pd, False, 0)
+            elif macs <= ops.EXACT_TRAIN_FORWARD_MACS:
                 y = ops.ExactConvTrainFunction.apply(y, self.weight, self.bias, st, pd, False, 0)
             else:
                 y = F.conv2d(y, self.weight, self.bias, self.stride, self.padding)
@@ -100,6 +104,9 @@ class ConvTranspose2d(nn.ConvTranspose2d, base.StepModule):
             k, st, pd = self.kernel_size[0], _one(self.stride, 'stride'), _one(self.padding, 'padding')
             op = _one(self.output_padding, 'output_padding')
             macs = y.shape[0] * self.out_channels * self.in_channels * k * k * y.shape[2] * y.shape[3]
+            if ops.NATIVE_TRAIN_FORWARD and ops.conv_train_supported(y.shape, self.weight, st, pd, True, op, y.requires_grad,
+                                                                     forward=True):
+                return _unfold(ops.NativeConvTrainFunction.apply(y, self.weight, self.bias, st, pd, True, op), prefix)
             if macs <= ops.EXACT_TRAIN_FORWARD_MACS:
                 return _unfold(ops.ExactConvTrainFunction.apply(y, self.weight, self.bias, st, pd, True, op), prefix)
             return _unfold(F.conv_transpose2d(y, self.weight, self.bias, self.stride, self.padding,

@@ -135,6 +135,10 @@ _SIGS = {
     "spk_count_spikes": (c_int, [P, c_longlong, c_longlong, c_int, c_int, P, P]),
     "spk_conv3x3_wgrad_small_ws_bytes": (c_longlong, [c_int, c_int, c_int, c_int, c_int]),
     "spk_conv3x3_wgrad_small": (c_int, [P, P, P, c_longlong, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "spk_conv_train_gather_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "spk_conv_train_gather": (c_int, [P, P, P, P] + [c_int] * 11 + [c_longlong] * 3 + [P]),
+    "spk_conv_train_wgrad_ws_bytes": (c_longlong, [c_int] * 6),
+    "spk_conv_train_wgrad": (c_int, [P, P, P, c_longlong, P, P] + [c_int] * 10 + [c_longlong] * 3 + [c_int, P]),
     "spk_q_sample": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_float, P]),
     "spk_set_option": (c_int, [ctypes.c_char_p, c_int]),
     "spk_get_option": (c_int, [ctypes.c_char_p, P]),

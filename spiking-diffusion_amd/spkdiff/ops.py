@@ -447,11 +447,126 @@ class ExactConvTrainFunction(torch.autograd.Function):
             # few input channels, dense input, no input gradient wanted: the denoiser's first layer (spk_conv3x3_wgrad_small:
             # maps up to 8x8 -- larger ones answer the workspace query with -1 and take the framework's operator below)
             return (None,) + conv3x3_wgrad_small(grad_y, x, weight, has_bias and ctx.needs_input_grad[2]) + (None,) * 4
+        needs = (bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), bool(has_bias and ctx.needs_input_grad[2]))
+        if conv_train_supported(x.shape, weight, stride, pad, transposed, out_pad, needs[0]):
+            # the native data / weight gradients of csrc/conv_train.hip (the VQ-VAE's stride-2, 1x1 and transposed layers)
+            return conv_train_backward(grad_y, x, weight, stride, pad, transposed, out_pad, needs) + (None,) * 4
         gi, gw, gb = torch.ops.aten.convolution_backward(
             grad_y.contiguous(), x.contiguous(), weight, [cout], [stride, stride], [pad, pad], [1, 1], transposed,
-            [out_pad, out_pad], 1,
-            [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), bool(has_bias and ctx.needs_input_grad[2])])
+            [out_pad, out_pad], 1, list(needs))
         return gi, gw, gb, None, None, None, None
+
+
+# ---- native training convolutions (csrc/conv_train.hip): the VQ-VAE's stride-2 / 1x1 / transposed layers ---------------------
+NATIVE_TRAIN_CONV = True        # False: the framework's (library) convolution backward, as in rounds 3-4
+NATIVE_TRAIN_FORWARD = True     # False: exact direct kernel / library forward by ops.EXACT_TRAIN_FORWARD_MACS (the parity runs)
+
+
+def _conv_w_strides(weight, transposed):
+    """(tap, cin, cout) element strides of a convolution weight as stored ([Cout,Cin,k,k] / [Cin,Cout,k,k], contiguous or
+    channels-last), or None when the taps are not k*k equally spaced elements."""
+    st, k = weight.stride(), int(weight.shape[2])
+    if weight.dim() != 4 or weight.shape[2] != weight.shape[3] or (k > 1 and st[2] != k * st[3]):
+        return None
+    tap = int(st[3]) if k > 1 else 0
+    return (tap, int(st[0]), int(st[1])) if transposed else (tap, int(st[1]), int(st[0]))
+
+
+def _conv_train_geometry(xshape, weight, stride, pad, transposed, out_pad):
+    N, Cin, Hi, Wi = (int(v) for v in xshape)
+    k = int(weight.shape[2])
+    Cout = int(weight.shape[1] if transposed else weight.shape[0])
+    Ho, Wo = (conv_out_size(Hi, k, stride, pad, transposed, out_pad), conv_out_size(Wi, k, stride, pad, transposed, out_pad))
+    return N, Cin, Hi, Wi, Cout, Ho, Wo, k
+
+
+def conv_train_supported(xshape, weight, stride, pad, transposed, out_pad, need_gi=True, forward=False):
+    """Do the native training kernels take this layer (backward: data gradient if wanted + weight gradient; forward=True: the
+    forward as well)?"""
+    if not NATIVE_TRAIN_CONV or len(xshape) != 4 or weight.dim() != 4 or not weight.is_cuda or weight.dtype != torch.float32:
+        return False
+    if _conv_w_strides(weight, transposed) is None or int(weight.shape[1 if not transposed else 0]) != int(xshape[1]):
+        return False
+    N, Cin, Hi, Wi, Cout, Ho, Wo, k = _conv_train_geometry(xshape, weight, stride, pad, transposed, out_pad)
+    if transposed and (out_pad >= stride or (Hi - 1) * stride - 2 * pad + k + out_pad != Ho):
+        return False
+    f_fwd, f_bwd = (1, 0) if transposed else (0, 1)
+    if forward and not lib.spk_conv_train_gather_supported(Cin, Cout, k, stride, f_fwd):
+        return False
+    if need_gi and not lib.spk_conv_train_gather_supported(Cout, Cin, k, stride, f_bwd):
+        return False
+    if transposed:          # u = gy (finer grid), v = the input
+        return lib.spk_conv_train_wgrad_ws_bytes(N, Hi, Wi, Cout, Cin, k) > 0
+    return lib.spk_conv_train_wgrad_ws_bytes(N, Ho, Wo, Cin, Cout, k) > 0
+
+
+def conv_train_forward(x, weight, bias, stride, pad, transposed, out_pad):
+    """y [N,Cout,Ho,Wo] (channels-last memory) = conv2d / conv_transpose2d(x, weight) + bias on the fp32 matrix cores
+    (spk_conv_train_gather)."""
+    xin = _cl4(x.detach(), "x")
+    w = weight.detach()
+    N, Cin, Hi, Wi, Cout, Ho, Wo, k = _conv_train_geometry(xin.shape, w, stride, pad, transposed, out_pad)
+    tap, s_ci, s_co = _conv_w_strides(w, transposed)
+    y = _empty_cl((N, Cout, Ho, Wo), xin.device)
+    b = None if bias is None else _dev(bias.detach(), "bias", torch.float32)
+    with timed("train.conv_fwd"):
+        check(lib.spk_conv_train_gather(_p(xin), _p(w), _p(b), _p(y), N, Hi, Wi, Cin, Ho, Wo, Cout, k, stride, pad,
+                                        1 if transposed else 0, tap, s_ci, s_co, _stream(xin)), "spk_conv_train_gather")
+    return y
+
+
+def conv_train_backward(grad_y, x, weight, stride, pad, transposed, out_pad, needs):
+    """(gi, gw, gb) of a convolution layer from gy (any layout; converted to channels-last if it is not), the saved input and
+    the weight: spk_conv_train_gather in the transposed role + spk_conv_train_wgrad.  gw in the memory format of ``weight``."""
+    gy = _cl4(grad_y, "grad_y")
+    xin = _cl4(x.detach(), "x")
+    w = weight.detach()
+    N, Cin, Hi, Wi, Cout, Ho, Wo, k = _conv_train_geometry(xin.shape, w, stride, pad, transposed, out_pad)
+    tap, s_ci, s_co = _conv_w_strides(w, transposed)
+    st = _stream(gy)
+    gi = gw = gb = None
+    if needs[0]:
+        gi = _empty_cl((N, Cin, Hi, Wi), gy.device)
+        with timed("train.conv_bwd_data"):
+            check(lib.spk_conv_train_gather(_p(gy), _p(w), None, _p(gi), N, Ho, Wo, Cout, Hi, Wi, Cin, k, stride, pad,
+                                            0 if transposed else 1, tap, s_co, s_ci, st), "spk_conv_train_gather")
+    if needs[1] or needs[2]:
+        gw = torch.empty_like(w)
+        assert gw.stride() == w.stride()
+        gb = torch.empty(Cout, dtype=torch.float32, device=gy.device) if needs[2] else None
+        if transposed:
+            u, v, Hu, Wu, Cu, Hv, Wv, Cv, g_u, g_v, bf = gy, xin, Ho, Wo, Cout, Hi, Wi, Cin, s_co, s_ci, 2
+        else:
+            u, v, Hu, Wu, Cu, Hv, Wv, Cv, g_u, g_v, bf = xin, gy, Hi, Wi, Cin, Ho, Wo, Cout, s_ci, s_co, 1
+        nb = int(lib.spk_conv_train_wgrad_ws_bytes(N, Hv, Wv, Cu, Cv, k))
+        ws = torch.empty(nb, dtype=torch.uint8, device=gy.device)
+        with timed("train.conv_bwd_weight"):
+            check(lib.spk_conv_train_wgrad(_p(u), _p(v), _p(ws), nb, _p(gw), _p(gb), N, Hu, Wu, Cu, Hv, Wv, Cv, k, stride, pad,
+                                           tap, g_u, g_v, bf if gb is not None else 0, st), "spk_conv_train_wgrad")
+        if not needs[1]:
+            gw = None
+    return gi, gw, gb
+
+
+class NativeConvTrainFunction(torch.autograd.Function):
+    """y = conv2d / conv_transpose2d(x, weight) + bias in training, forward and backward on this library's fp32 matrix-core
+    kernels (csrc/conv_train.hip): the stride-2, 1x1 and transposed layers of the spiking VQ-VAE
+    (R/snn_model/vae_model.py:101-159; cuDNN in the reference).  Tensors are channels-last in memory (what the BatchNorm+LIF
+    block tails produce and consume); another layout is converted."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, transposed, out_pad):
+        y = conv_train_forward(x, weight, bias, stride, pad, transposed, out_pad)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (int(stride), int(pad), bool(transposed), int(out_pad), bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, weight = ctx.saved_tensors
+        stride, pad, transposed, out_pad, has_bias = ctx.cfg
+        needs = (bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), bool(has_bias and ctx.needs_input_grad[2]))
+        return conv_train_backward(grad_y, x, weight, stride, pad, transposed, out_pad, needs) + (None,) * 4
 
 
 def conv3x3_wgrad_small(grad_y, x, weight, want_bias):
