@@ -32,6 +32,19 @@ namespace {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
+#ifndef CT_STAGE_A
+#define CT_STAGE_A 0                               // 1: the gather kernel's input records go through a per-wave LDS transpose (coalesced 16-byte
+#endif                                             // requests: LPR lanes per row instead of one).  Built because "lane = row" touches 32 - 64 cache
+                                                   // lines per request; measured SLOWER (same box, N = 512: dec.convT2 forward 80.3 against 66.0 us,
+                                                   // sum of the ten matrix-path launches of a VQ-VAE iteration 289 against 265 us,
+                                                   // profiles/r5_ab_conv_train.txt): the LDS tiles cost a workgroup per CU, and the address unit
+                                                   // was not what set the pace (the no-load ablation, CT_DBG 4, runs the same launch in 72 us)
+#ifndef CT_BIG_ITEMS
+#define CT_BIG_ITEMS 2048                          // a wave takes all column tiles of its 32 rows from this many items on (below: one column tile)
+#endif
+#ifndef CT_DBG
+#define CT_DBG 0                                   // timing experiments only (results are wrong): 1 wgrad without operand loads, 2 wgrad without
+#endif                                             // MFMAs, 4 gather without input loads, 8 gather without MFMAs, 16 gather without stores
 constexpr int MAX_TAPS = 16;                       // k <= 4
 constexpr int GATHER_LDS_MAX = 150 * 1024;
 
@@ -71,10 +84,12 @@ constexpr int MAX_CLASSES = 16;                     // stride <= 4
 struct ClassTab { int ncls, cs; int first[MAX_CLASSES + 1]; int Qh[MAX_CLASSES], Qw[MAX_CLASSES]; TapList tl[MAX_CLASSES]; };
 
 template <int J, int CN, int RM>
-__global__ __launch_bounds__(256, 2) void conv_train_gather_kernel(GArgs a) {
+__global__ __launch_bounds__(512) void conv_train_gather_kernel(GArgs a) {
+  constexpr int NTH = 512, NWV = 8;                 // eight waves share one staged weight image
   extern __shared__ __attribute__((aligned(16))) float4 sB[];       // [tap][J][2][CN * 32]
   __shared__ ClassTab ct;
   constexpr int CP = CN * 32, CRED = J * 8, ROWS = RM * 32;
+  constexpr bool STAGE = CT_STAGE_A && (J == 1 || J == 2 || J == 4 || J == 8);       // (a power of two lanes per row)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cs = a.form ? a.stride : 1;            // output step per class-grid step
   const int ai = a.form ? 1 : a.stride;            // input step per class-grid step
@@ -93,16 +108,64 @@ __global__ __launch_bounds__(256, 2) void conv_train_gather_kernel(GArgs a) {
     ct.first[cs * cs] = first;
   }
   const int ntap = a.k * a.k;
-  for (int e = tid; e < ntap * CRED * CP; e += 256) {
-    const int co = e % CP, r = e / CP, c = r % CRED, t = r / CRED;
-    const float v = co0 + co < a.Cout ? a.w[t * a.w_tap + c * a.w_red + (co0 + co) * a.w_out] : 0.f;
-    reinterpret_cast<float*>(sB)[((((t * J + (c >> 3)) * 2 + ((c >> 2) & 1)) * CP + co) << 2) + (c & 3)] = v;
+  float4* const sA = sB + ntap * J * 2 * CP;          // STAGE: [8 waves][32 rows][Cred / 4] operand tiles behind the weights
+  // staging: 16-byte loads along whichever weight dimension is contiguous, SB requests in flight per thread (the weights are
+  // L2-resident; one request at a time cost 30+ us per launch)
+  constexpr int SB = 6;
+  const bool al = ((reinterpret_cast<uintptr_t>(a.w) & 15) == 0) && (a.w_tap & 3) == 0;
+  if (al && a.w_red == 1 && (a.w_out & 3) == 0) {
+    // four consecutive reduced channels = one LDS slot
+    const int total = ntap * CP * (CRED / 4);
+    for (int e0 = tid; e0 < total; e0 += NTH * SB) {
+      float4 v[SB];
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        const int e = e0 + u * NTH;
+        const int c4 = e % (CRED / 4), r = e / (CRED / 4), co = r % CP, t = r / CP;
+        v[u] = (e < total && co0 + co < a.Cout) ? *reinterpret_cast<const float4*>(a.w + t * a.w_tap + (co0 + co) * a.w_out + 4 * c4)
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        const int e = e0 + u * NTH;
+        const int c4 = e % (CRED / 4), r = e / (CRED / 4), co = r % CP, t = r / CP;
+        if (e < total) sB[((t * J + (c4 >> 1)) * 2 + (c4 & 1)) * CP + co] = v[u];
+      }
+    }
+  } else if (al && a.w_out == 1 && (a.w_red & 3) == 0 && (a.Cout & 3) == 0) {
+    // four consecutive output channels = component c % 4 of four neighbouring LDS slots
+    const int total = ntap * CRED * (CP / 4);
+    for (int e0 = tid; e0 < total; e0 += NTH * SB) {
+      float4 v[SB];
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        const int e = e0 + u * NTH;
+        const int q4 = e % (CP / 4), r = e / (CP / 4), c = r % CRED, t = r / CRED;
+        v[u] = (e < total && co0 + 4 * q4 < a.Cout) ? *reinterpret_cast<const float4*>(a.w + t * a.w_tap + c * a.w_red + co0 + 4 * q4)
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        const int e = e0 + u * NTH;
+        const int q4 = e % (CP / 4), r = e / (CP / 4), c = r % CRED, t = r / CRED;
+        if (e < total) {
+          float* d = reinterpret_cast<float*>(sB) + ((((t * J + (c >> 3)) * 2 + ((c >> 2) & 1)) * CP + 4 * q4) << 2) + (c & 3);
+          d[0] = v[u].x; d[4] = v[u].y; d[8] = v[u].z; d[12] = v[u].w;
+        }
+      }
+    }
+  } else {
+    for (int e = tid; e < ntap * CRED * CP; e += NTH) {
+      const int co = e % CP, r = e / CP, c = r % CRED, t = r / CRED;
+      const float v = co0 + co < a.Cout ? a.w[t * a.w_tap + c * a.w_red + (co0 + co) * a.w_out] : 0.f;
+      reinterpret_cast<float*>(sB)[((((t * J + (c >> 3)) * 2 + ((c >> 2) & 1)) * CP + co) << 2) + (c & 3)] = v;
+    }
   }
   __syncthreads();
 
   const int nitems = ct.first[cs * cs];
   const int r = lane & 31, h = lane >> 5;
-  for (int item = blockIdx.x * 4 + wave; item < nitems; item += gridDim.x * 4) {
+  for (int item = blockIdx.x * NWV + wave; item < nitems; item += gridDim.x * NWV) {
     int cls = 0;
     while (item >= ct.first[cls + 1]) ++cls;
     const TapList& tl = ct.tl[cls];
@@ -159,19 +222,63 @@ __global__ __launch_bounds__(256, 2) void conv_train_gather_kernel(GArgs a) {
             for (int cn = 0; cn < CN; ++cn) {
               const float av = q == 0 ? src[rm][j].x : q == 1 ? src[rm][j].y : q == 2 ? src[rm][j].z : src[rm][j].w;
               const float bv = q == 0 ? B[cn].x : q == 1 ? B[cn].y : q == 2 ? B[cn].z : B[cn].w;
-              acc[rm][cn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[rm][cn], 0, 0, 0);
+              if (CT_DBG & 8) acc[rm][cn][0] += av + bv;
+              else acc[rm][cn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[rm][cn], 0, 0, 0);
             }
       }
     };
-    if (nt > 0) load_a(0, A[0]);
-    int t = 0;
-    for (; t + 1 < nt; t += 2) {
-      load_a(t + 1, A[1]);
-      mma(t, A[0]);
-      if (t + 2 < nt) load_a(t + 2, A[0]);
-      mma(t + 1, A[1]);
+    if constexpr (STAGE) {
+      // Coalesced requests + a per-wave LDS transpose.  With "lane = row" a 16-byte request per lane touches 32 - 64 cache lines
+      // per instruction and the CU's one texture-address unit, not the matrix pipe, set the pace (measured: 2x the MFMA time).
+      // Here LPR = Cred / 4 consecutive lanes cover one row's record (8 full lines per instruction), the wave writes the 32 rows
+      // to its own LDS tile (chunks XOR-swizzled by row: conflict-free both ways) and reads its operands back row-wise.  LDS
+      // operations of a wave execute in order; the asm statements only keep the compiler from reordering across them.
+      static_assert(RM == 1, "staged form: one row tile per wave");
+      constexpr int LPR = 2 * J, RPI = 64 / LPR, SH = LPR >= 8 ? 0 : (LPR == 4 ? 1 : 2), MASK = LPR >= 8 ? 7 : LPR - 1;
+      float4* const sAw = sA + wave * (32 * LPR);
+      const int wrow = lane / LPR, wchunk = lane % LPR;
+      float4 G[J];
+      auto gload = [&](int t) {
+        const int iy = qy_[0] * ai + tl.dy[t], ix = qx_[0] * ai + tl.dx[t];
+        const bool ok = rv[0] && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
+        const int off = ok ? ((n_[0] * a.Hi + iy) * a.Wi + ix) * CRED : -1;
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+          const int o = __shfl(off, i * RPI + wrow);
+          if (CT_DBG & 4) G[i] = make_float4((float)o, 1.f, 2.f, (float)lane);
+          else
+          G[i] = o >= 0 ? *reinterpret_cast<const float4*>(a.in + o + 4 * wchunk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      };
+      auto stage = [&]() {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < J; ++i) {
+          const int row = i * RPI + wrow;
+          sAw[row * LPR + (wchunk ^ ((row >> SH) & MASK))] = G[i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < J; ++j) A[0][0][j] = sAw[r * LPR + ((2 * j + h) ^ ((r >> SH) & MASK))];
+        asm volatile("" ::: "memory");
+      };
+      if (nt > 0) gload(0);
+      for (int t = 0; t < nt; ++t) {
+        stage();
+        if (t + 1 < nt) gload(t + 1);
+        mma(t, A[0]);
+      }
+    } else {
+      if (nt > 0) load_a(0, A[0]);
+      int t = 0;
+      for (; t + 1 < nt; t += 2) {
+        load_a(t + 1, A[1]);
+        mma(t, A[0]);
+        if (t + 2 < nt) load_a(t + 2, A[0]);
+        mma(t + 1, A[1]);
+      }
+      if (t < nt) mma(t, A[0]);
     }
-    if (t < nt) mma(t, A[0]);
 
     // D[i][j]: j = lane & 31, i = 8 * (reg / 4) + 4 * (lane / 32) + reg % 4
 #pragma unroll
@@ -186,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void conv_train_gather_kernel(GArgs a) {
         if (co < a.Cout) {
 #pragma unroll
           for (int i = 0; i < 16; ++i)
-            if (orow[i] >= 0) a.out[(long long)orow[i] * a.Cout + co] = acc[rm][cn][i] + bv;
+            if (orow[i] >= 0 && (!(CT_DBG & 16) || acc[rm][cn][i] == 12345.f)) a.out[(long long)orow[i] * a.Cout + co] = acc[rm][cn][i] + bv;
         }
       }
     }
@@ -286,11 +393,12 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_train_wgrad_kernel(WArgs a) 
   const int CUT = (a.Cu + 31) >> 5, CVT = (a.Cv + 31) >> 5;
   const int ntile = a.k * a.k * CUT * CVT;
   const long long Ms = (long long)a.N * a.Hv * a.Wv;
-  const long long per = ((Ms + a.nwg - 1) / a.nwg + 2 * SPLIT - 1) / (2 * SPLIT) * (2 * SPLIT);   // even halves
-  const long long w0 = (long long)blockIdx.x * per;
-  const long long p0 = w0 + part_id * (per / SPLIT);
-  long long p1 = p0 + per / SPLIT;
-  p1 = p1 < Ms ? p1 : Ms;
+  // rows of the v grid (n, qy) are dealt to the (workgroup, half) parts: a wave's position loop then runs along one row, where
+  // a tile's operand address moves by a constant and only the row's two ends need a bounds test
+  const int NR = a.N * a.Hv;
+  const int rows_per = (NR + a.nwg * SPLIT - 1) / (a.nwg * SPLIT);
+  const int r0 = (blockIdx.x * SPLIT + part_id) * rows_per;
+  const int r1 = r0 + rows_per < NR ? r0 + rows_per : NR;
   const int rc = lane & 31, kk = lane >> 5;
   int t_dy[NTW], t_dx[NTW], t_cu[NTW], t_cv[NTW];
   bool t_ok[NTW];
@@ -311,44 +419,58 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_train_wgrad_kernel(WArgs a) 
   for (int i = 0; i < NTW; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  if (p0 < p1) {
-    long long p = p0 + kk;
-    int qx = (int)(p % a.Wv);
-    long long t2 = p / a.Wv;
-    int qy = (int)(t2 % a.Hv), n = (int)(t2 / a.Hv);
-    for (; p - kk < p1; p += 2 * UNR) {
+  bool cu_ok[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) cu_ok[i] = t_ok[i] && t_cu[i] < a.Cu;
+  const int sCu = a.stride * a.Cu;
+  for (int row = r0; row < r1; ++row) {
+    const int n = row / a.Hv, qy = row - n * a.Hv;   // (wave-uniform)
+    const float* vb = a.v + (long long)row * a.Wv * a.Cv;
+    const float* ub[NTW];
+    bool rok[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      const int iy = qy * a.stride + t_dy[i];
+      rok[i] = cu_ok[i] && iy >= 0 && iy < a.Hu;
+      ub[i] = a.u + (((long long)n * a.Hu + iy) * a.Wu + t_dx[i]) * a.Cu + t_cu[i];
+    }
+    for (int qx0 = 0; qx0 < a.Wv; qx0 += 2 * UNR) {
       float av[UNR][NTW], bv[UNR][NTW];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
-        const long long pu = p + 2 * u;
-        const bool pv = pu < p1;
-        const float* vrow = a.v + pu * a.Cv;
-        const int by = qy * a.stride, bx = qx * a.stride;
-        const float* urow = a.u + (((long long)n * a.Hu + by) * a.Wu + bx) * a.Cu;
-        if (a_shared) {
-          const float x = (pv && t_cv[0] < a.Cv) ? vrow[t_cv[0]] : 0.f;
+        if (qx0 + 2 * u < a.Wv) {                    // (wave-uniform: the last batch of a row may be short)
+          const int qx = qx0 + 2 * u + kk;
+          const bool pv = qx < a.Wv;
+          const int xo = qx * sCu, xb = qx * a.stride;
+          if (CT_DBG & 1) {
 #pragma unroll
-          for (int i = 0; i < NTW; ++i) av[u][i] = x;
-        } else {
+            for (int i = 0; i < NTW; ++i) { av[u][i] = (float)(lane + u); bv[u][i] = (float)(qx + i); }
+            continue;
+          }
+          if (a_shared) {
+            const float x = (pv && t_cv[0] < a.Cv) ? vb[qx * a.Cv + t_cv[0]] : 0.f;
 #pragma unroll
-          for (int i = 0; i < NTW; ++i) av[u][i] = (pv && t_ok[i] && t_cv[i] < a.Cv) ? vrow[t_cv[i]] : 0.f;
-        }
+            for (int i = 0; i < NTW; ++i) av[u][i] = x;
+          } else {
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) {
-          const int iy = by + t_dy[i], ix = bx + t_dx[i];
-          const bool ok = pv && t_ok[i] && t_cu[i] < a.Cu && iy >= 0 && iy < a.Hu && ix >= 0 && ix < a.Wu;
-          bv[u][i] = ok ? urow[(t_dy[i] * a.Wu + t_dx[i]) * a.Cu + t_cu[i]] : 0.f;
-        }
-        qx += 2;
-        while (qx >= a.Wv) {
-          qx -= a.Wv;
-          if (++qy >= a.Hv) { qy = 0; ++n; }
+            for (int i = 0; i < NTW; ++i) av[u][i] = (pv && t_ok[i] && t_cv[i] < a.Cv) ? vb[qx * a.Cv + t_cv[i]] : 0.f;
+          }
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) {
+            const int ix = xb + t_dx[i];
+            bv[u][i] = (pv && rok[i] && ix >= 0 && ix < a.Wu) ? ub[i][xo] : 0.f;
+          }
         }
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u)
+        if (qx0 + 2 * u < a.Wv) {
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][i], acc[i], 0, 0, 0);
+          for (int i = 0; i < NTW; ++i) {
+            if (CT_DBG & 2) acc[i][0] += av[u][i] + bv[u][i];
+            else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][i], acc[i], 0, 0, 0);
+          }
+        }
     }
   }
   if (SPLIT == 2) {
@@ -386,12 +508,45 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_train_wgrad_kernel(WArgs a) 
     const long long g0 = (long long)blockIdx.x * perg;
     long long g1 = g0 + perg;
     g1 = g1 < Mg ? g1 : Mg;
-    const int RL = NT / C;                           // (C <= 64; threads beyond RL * C idle)
-    const int c = tid % C, rl = tid / C;
-    float s = 0.f;
-    if (rl < RL)
-      for (long long row = g0 + rl; row < g1; row += RL) s += g[row * C + c];
-    s_x[tid] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int RL, c;
+    if ((C & 3) == 0) {
+      // 16-byte loads, four rows in flight per thread (one request at a time made this loop the longest part of the launch)
+      const int CQ = C >> 2;
+      RL = NT / CQ;
+      const int cq = tid % CQ, rl = tid / CQ;
+      c = cq;
+      if (rl < RL) {
+        long long row = g0 + rl;
+        for (; row + 3 * RL < g1; row += 4 * RL) {
+          const float4 x0 = *reinterpret_cast<const float4*>(g + row * C + 4 * cq);
+          const float4 x1 = *reinterpret_cast<const float4*>(g + (row + RL) * C + 4 * cq);
+          const float4 x2 = *reinterpret_cast<const float4*>(g + (row + 2 * RL) * C + 4 * cq);
+          const float4 x3 = *reinterpret_cast<const float4*>(g + (row + 3 * RL) * C + 4 * cq);
+          s0 += x0.x; s1 += x0.y; s2 += x0.z; s3 += x0.w;
+          s0 += x1.x; s1 += x1.y; s2 += x1.z; s3 += x1.w;
+          s0 += x2.x; s1 += x2.y; s2 += x2.z; s3 += x2.w;
+          s0 += x3.x; s1 += x3.y; s2 += x3.z; s3 += x3.w;
+        }
+        for (; row < g1; row += RL) {
+          const float4 x0 = *reinterpret_cast<const float4*>(g + row * C + 4 * cq);
+          s0 += x0.x; s1 += x0.y; s2 += x0.z; s3 += x0.w;
+        }
+      }
+      __syncthreads();                               // (SPLIT 2: s_x held the second half's tiles)
+      if (rl < RL) {
+        s_x[(rl * CQ + cq) * 4 + 0] = s0; s_x[(rl * CQ + cq) * 4 + 1] = s1;
+        s_x[(rl * CQ + cq) * 4 + 2] = s2; s_x[(rl * CQ + cq) * 4 + 3] = s3;
+      }
+    } else {
+      RL = NT / C;                                   // (C <= 64; threads beyond RL * C idle)
+      c = tid % C;
+      const int rl = tid / C;
+      if (rl < RL)
+        for (long long row = g0 + rl; row < g1; row += RL) s0 += g[row * C + c];
+      __syncthreads();
+      if (rl < RL) s_x[rl * C + c] = s0;
+    }
     __syncthreads();
     if (tid < C) {
       float tot = 0.f;
@@ -406,13 +561,14 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_train_wgrad_kernel(WArgs a) 
 // one another.
 template <int MODE>
 __global__ __launch_bounds__(256) void conv_train_wgrad_reduce_kernel(WArgs a) {
+  constexpr int TPE = MODE == 0 ? 8 : 32, EPB = 256 / TPE;          // threads per element, elements per block
   __shared__ float s_q[256];
   const int CUT = (a.Cu + 31) >> 5, CVT = (a.Cv + 31) >> 5;
   const int nt = a.k * a.k;
   const int E = MODE == 0 ? nt * a.Cu * a.Cv : nt * a.Cv;
   const int CB = a.bias_from == 0 ? 0 : (a.bias_from == 1 ? a.Cv : a.Cu);
-  const int el = threadIdx.x & 31, q = threadIdx.x >> 5;
-  const int e = blockIdx.x * 32 + el;
+  const int el = threadIdx.x % EPB, q = threadIdx.x / EPB;
+  const int e = blockIdx.x * EPB + el;
   long long src = 0;
   float* dst = nullptr;
   if (e < E) {
@@ -432,14 +588,21 @@ __global__ __launch_bounds__(256) void conv_train_wgrad_reduce_kernel(WArgs a) {
     dst = a.gb + (e - E);
   }
   float s = 0.f;
-  if (dst)
-    for (int w = q; w < a.nwg; w += 8) s += a.part[(long long)w * a.psize + src];
+  if (dst) {
+    int w = q;
+    for (; w + 3 * TPE < a.nwg; w += 4 * TPE) {                      // four requests in flight, added in index order
+      const float x0 = a.part[(long long)w * a.psize + src], x1 = a.part[(long long)(w + TPE) * a.psize + src];
+      const float x2 = a.part[(long long)(w + 2 * TPE) * a.psize + src], x3 = a.part[(long long)(w + 3 * TPE) * a.psize + src];
+      s += x0; s += x1; s += x2; s += x3;
+    }
+    for (; w < a.nwg; w += TPE) s += a.part[(long long)w * a.psize + src];
+  }
   s_q[threadIdx.x] = s;
   __syncthreads();
   if (q == 0 && dst) {
     float tot = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) tot += s_q[k * 32 + el];
+    for (int k = 0; k < TPE; ++k) tot += s_q[k * EPB + el];
     *dst = tot;
   }
 }
@@ -519,7 +682,7 @@ int gather_kind(int Cred, int Cout, int k, int stride, int form) {
   }
   if (Cred % 8 != 0 || Cred > 64 || Cout > 64) return 0;
   const int CP = (Cout + 31) / 32 * 32;
-  if (stride > 4 || (long long)k * k * Cred * CP * 4 > GATHER_LDS_MAX) return 0;
+  if (stride > 4 || (long long)k * k * Cred * 32 * 4 + (CT_STAGE_A ? 8 * 32 * Cred * 4 : 0) > GATHER_LDS_MAX) return 0;    // (one column tile per workgroup always fits then)
   return 1;
 }
 
@@ -527,12 +690,11 @@ template <int J, int CN, int RM>
 void launch_gather(const GArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_train_gather_kernel<J, CN, RM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
-  hipLaunchKernelGGL((conv_train_gather_kernel<J, CN, RM>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_train_gather_kernel<J, CN, RM>), grid, dim3(512), lds, s, a);
 }
 template <int J>
 void launch_gather_j(const GArgs& a, int CN, int RM, dim3 grid, size_t lds, hipStream_t s) {
-  if (CN == 2) launch_gather<J, 2, 2>(a, grid, lds, s);
-  else if (RM == 2) launch_gather<J, 1, 2>(a, grid, lds, s);
+  if (CN == 2) launch_gather<J, 2, 1>(a, grid, lds, s);
   else launch_gather<J, 1, 1>(a, grid, lds, s);
 }
 
@@ -548,7 +710,7 @@ extern "C" int spk_conv_train_gather(const float* in_cl, const float* w, const f
   if (!in_cl || !w || !out_cl || N <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || pad < 0) return SPK_ERR_ARG;
   const int kind = gather_kind(Cred, Cout, k, stride, form);
   if (!kind) return SPK_ERR_UNSUPPORTED;
-  if ((long long)N * Ho * Wo >= (1ll << 31) / 64 * 64 || (long long)N * Hi * Wi >= (1ll << 31)) return SPK_ERR_UNSUPPORTED;
+  if ((long long)N * Ho * Wo >= (1ll << 31) / 64 * 64 || (long long)N * Hi * Wi * Cred >= (1ll << 31)) return SPK_ERR_UNSUPPORTED;
   GArgs a{in_cl, w, bias_or_null, out_cl, N, Hi, Wi, Cred, Ho, Wo, Cout, k, stride, pad, form, w_tap, w_red, w_out};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const long long M = (long long)N * Ho * Wo;
@@ -567,20 +729,19 @@ extern "C" int spk_conv_train_gather(const float* in_cl, const float* w, const f
     const int cs = form ? stride : 1;
     if (cs * cs > MAX_CLASSES) return SPK_ERR_UNSUPPORTED;
     const int CNT = (Cout + 31) / 32, J = Cred / 8;
-    // 64-row x all-column items when there are at least two per SIMD; otherwise 32 rows x one column tile (more, smaller items)
-    long long items64 = 0, items32 = 0;
-    for (int c = 0; c < cs * cs; ++c) {
-      const long long Mc = (long long)N * ((Ho - c / cs + cs - 1) / cs) * ((Wo - c % cs + cs - 1) / cs);
-      items64 += (Mc + 63) / 64;
-      items32 += (Mc + 31) / 32;
-    }
-    const bool big = items64 >= 2048;
-    const int CN = big ? CNT : 1, RM = big ? 2 : 1;
-    const long long items = big ? items64 : items32;
+    // items of 32 rows x all column tiles when there are at least four per SIMD; otherwise 32 rows x one column tile
+    long long items = 0;
+    for (int c = 0; c < cs * cs; ++c)
+      items += ((long long)N * ((Ho - c / cs + cs - 1) / cs) * ((Wo - c % cs + cs - 1) / cs) + 31) / 32;
+    const bool staged = CT_STAGE_A && (J == 1 || J == 2 || J == 4 || J == 8);
+    const size_t lds_a = staged ? (size_t)8 * 32 * Cred * 4 : 0;
+    const bool big = CNT == 1 || (items >= CT_BIG_ITEMS && (size_t)k * k * Cred * CNT * 32 * 4 + lds_a <= 160 * 1024);
+    const int CN = big ? CNT : 1, RM = 1;
     const int gy = big ? 1 : CNT;
-    const size_t lds = (size_t)k * k * Cred * CN * 32 * 4;
-    int gx = (int)((items + 3) / 4);
-    const int cap = 512 / gy;                                        // two workgroups per CU
+    const size_t lds = (size_t)k * k * Cred * CN * 32 * 4 + lds_a;
+    int gx = (int)((items + 7) / 8);
+    const int per_cu = lds > 76 * 1024 ? 1 : 2;                      // workgroups per CU that fit the LDS
+    const int cap = 256 * per_cu / gy > 0 ? 256 * per_cu / gy : 1;
     gx = gx < cap ? gx : cap;
     dim3 grid(gx, gy);
     switch (J) {
@@ -607,8 +768,8 @@ int wgrad_kind(int Cu, int Cv, int k) {
   return ntile <= 36 ? 1 : 0;
 }
 int wgrad_nwg(int kind, long long Ms) {
-  long long n = kind == 1 ? (Ms + 63) / 64 : (Ms + 255) / 256;      // at least 64 positions per workgroup
-  const int cap = 256;
+  long long n = kind == 1 ? (Ms + 63) / 64 : (Ms + 255) / 256;      // at least 64 / 256 positions per workgroup
+  const int cap = kind == 1 ? 256 : 2048;                           // (vector kernel: tiny partials, latency-bound position loop)
   return (int)(n < 1 ? 1 : (n < cap ? n : cap));
 }
 int wgrad_psize(int kind, int Cu, int Cv, int k) {
@@ -644,7 +805,7 @@ extern "C" int spk_conv_train_wgrad(const float* u_cl, const float* v_cl, float*
     const int ntw = (ntile + 3) / 4;
 #define SPK_WG_LAUNCH(N_, S_)                                                                                          \
   do {                                                                                                                 \
-    const size_t lds_ = (S_) == 2 ? (size_t)4 * (N_) * 16 * 64 * 4 : 2048;                                             \
+    const size_t lds_ = (S_) == 2 ? (size_t)4 * (N_) * 16 * 64 * 4 : 8192;                                             \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_train_wgrad_kernel<N_, S_>),                         \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                                  \
     hipLaunchKernelGGL((conv_train_wgrad_kernel<N_, S_>), dim3(a.nwg), dim3(256 * (S_)), lds_, s, a);                  \
@@ -673,7 +834,7 @@ extern "C" int spk_conv_train_wgrad(const float* u_cl, const float* v_cl, float*
     SPK_LAUNCH_CHECK();
     const int CB = bias_from == 0 ? 0 : (bias_from == 1 ? Cv : 1);
     const int E = k * k * Cv + CB;
-    hipLaunchKernelGGL(conv_train_wgrad_reduce_kernel<1>, dim3((E + 31) / 32), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(conv_train_wgrad_reduce_kernel<1>, dim3((E + 7) / 8), dim3(256), 0, s, a);
   }
   SPK_LAUNCH_CHECK();
   return SPK_OK;

@@ -1344,6 +1344,7 @@ def test_train_iter_fused_vs_module_by_module_and_optimizer_step(dev):
     #  algorithm by algorithm -- can flip a spike the exact fused forward does not: the comparison runs them exactly)
     from spkdiff import ops as _ops
     keep, _ops.EXACT_TRAIN_FORWARD_MACS = _ops.EXACT_TRAIN_FORWARD_MACS, 1 << 62
+    keep_n, _ops.NATIVE_TRAIN_FORWARD = _ops.NATIVE_TRAIN_FORWARD, False
     try:
         for blk in (den.conv1, den.conv2, den.conv3, den.conv4, den.conv5):
             for m in blk:
@@ -1351,7 +1352,7 @@ def test_train_iter_fused_vs_module_by_module_and_optimizer_step(dev):
             outs.append(h)
         x6 = den.conv6[0](torch.cat((outs[4], outs[0]), dim=2))
     finally:
-        _ops.EXACT_TRAIN_FORWARD_MACS = keep
+        _ops.EXACT_TRAIN_FORWARD_MACS, _ops.NATIVE_TRAIN_FORWARD = keep, keep_n
     loss2 = ab._loss_from_logits(x6.sum(0) / 16, x0i, t); loss2.backward()
     assert abs(float(loss.detach()) - float(loss2.detach())) <= 1e-3 * float(loss2.detach())
     for k, p in den.named_parameters():
@@ -1491,14 +1492,16 @@ def test_f10_vqvae_train_step_vs_reference_fixture(golden_dir, dev):
     model.data_variance = torch.from_numpy(d["data_variance"]).to(dev)
     model.train()
     img = torch.from_numpy(d["images"]).to(dev)
-    # (the parity run keeps every convolution on the exact forward kernel: above ops.EXACT_TRAIN_FORWARD_MACS the library operator
-    #  would run, whose fp32 rounding depends on the algorithm it picks on the box; the loop further down runs the default split)
+    # (the parity run keeps every convolution on the exact forward kernel -- the correctly rounded dot product, box-independent;
+    #  its backward is the native data / weight gradient of csrc/conv_train.hip.  The default path -- native fp32 matrix-core
+    #  forward as well -- is compared with the same fixture further down)
     from spkdiff import ops as _ops
     keep, _ops.EXACT_TRAIN_FORWARD_MACS = _ops.EXACT_TRAIN_FORWARD_MACS, 1 << 62
+    keep_n, _ops.NATIVE_TRAIN_FORWARD = _ops.NATIVE_TRAIN_FORWARD, False
     try:
         leq, lrec, lreal = model(img.unsqueeze(0).repeat(16, 1, 1, 1, 1), img)
     finally:
-        _ops.EXACT_TRAIN_FORWARD_MACS = keep
+        _ops.EXACT_TRAIN_FORWARD_MACS, _ops.NATIVE_TRAIN_FORWARD = keep, keep_n
     (leq + lrec).backward()
     rel = {k: abs(float(v.detach()) - float(d[k])) / float(d[k]) for k, v in
            (("loss_eq", leq), ("loss_rec", lrec), ("real_loss_rec", lreal))}
@@ -1519,6 +1522,20 @@ def test_f10_vqvae_train_step_vs_reference_fixture(golden_dir, dev):
             want = torch.from_numpy(d[k])
             assert float(((st[k[5:]].cpu() - want).abs() / (1 + want.abs())).max()) <= 1e-4, k
     functional.reset_net(model)
+    # the DEFAULT training path (forward on the native fp32 matrix-core kernels too) against the same fixture, same bars
+    model.load_state_dict(sd)
+    model.zero_grad()
+    leq2, lrec2, lreal2 = model(img.unsqueeze(0).repeat(16, 1, 1, 1, 1), img)
+    (leq2 + lrec2).backward()
+    rel2 = {k: abs(float(v.detach()) - float(d[k])) / float(d[k]) for k, v in
+            (("loss_eq", leq2), ("loss_rec", lrec2), ("real_loss_rec", lreal2))}
+    gerr2 = {k[5:]: round(_rel_l2(dict(model.named_parameters())[k[5:]].grad.cpu(), torch.from_numpy(d[k])), 6)
+             for k in d.files if k.startswith("grad.") and float(np.linalg.norm(d[k])) > 1e-6}
+    print("F10 (native forward) measured: loss rel err", rel2, "grad rel L2", gerr2)
+    parity("f10_native_forward", loss_rel=max(rel2.values()), grad_rel_l2_max=max(gerr2.values()))
+    assert max(rel2.values()) <= 2e-2 and max(gerr2.values()) <= 5e-2, (rel2, gerr2)
+    functional.reset_net(model)
+    model.load_state_dict(sd)
     # the reference's loop body (R/main.py:136-146) runs and moves the weights; inference still works afterwards
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.001)
     for _ in range(2):

@@ -1,0 +1,22 @@
+# SQ counters of the conv_train kernels on the largest layer (dec.convT2), two --pmc passes (no trace flags)
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+O=$R/gpurun_out/r5b_ctpmc; rm -rf $O; mkdir -p $O
+export CT_ONLY=dec.convT2
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/sq1 -- python $R/tools/conv_train_time.py 512 nolib > $O/sq1.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS --output-format csv -d $O/sq2 -- python $R/tools/conv_train_time.py 512 nolib > $O/sq2.log 2>&1
+python - $O <<'PY'
+import csv, glob, sys, collections
+O = sys.argv[1]
+for d in ("sq1", "sq2"):
+    f = glob.glob(f"{O}/{d}/*/*counter_collection.csv")
+    if not f:
+        print(d, "no csv", glob.glob(f"{O}/{d}/*/*")); continue
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f[0])):
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        if "conv_train" in k:
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        print(k, {c: sorted(x)[len(x) // 2] for c, x in v.items()})
+PY
