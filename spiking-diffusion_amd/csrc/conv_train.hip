@@ -39,11 +39,18 @@ typedef float v16f __attribute__((ext_vector_type(16)));
                                                    // sum of the ten matrix-path launches of a VQ-VAE iteration 289 against 265 us,
                                                    // profiles/r5_ab_conv_train.txt): the LDS tiles cost a workgroup per CU, and the address unit
                                                    // was not what set the pace (the no-load ablation, CT_DBG 4, runs the same launch in 72 us)
+#ifndef CT_WGRAD_LDS
+#define CT_WGRAD_LDS 1                             // 0: the weight gradient always reads its operands from global memory (the first form)
+#endif
+#ifndef CT_WL_UNROLL
+#define CT_WL_UNROLL 1
+#endif
 #ifndef CT_BIG_ITEMS
 #define CT_BIG_ITEMS 2048                          // a wave takes all column tiles of its 32 rows from this many items on (below: one column tile)
 #endif
 #ifndef CT_DBG
-#define CT_DBG 0                                   // timing experiments only (results are wrong): 1 wgrad without operand loads, 2 wgrad without
+#define CT_DBG 0                                   // timing experiments only (results are wrong; 32 / 64 / 128: the LDS-staged weight gradient without
+                                                   // its bias sums / MFMAs / global requests): 1 wgrad without operand loads, 2 wgrad without
 #endif                                             // MFMAs, 4 gather without input loads, 8 gather without MFMAs, 16 gather without stores
 constexpr int MAX_TAPS = 16;                       // k <= 4
 constexpr int GATHER_LDS_MAX = 150 * 1024;
@@ -556,6 +563,208 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_train_wgrad_kernel(WArgs a) 
   }
 }
 
+// The same weight gradient with its operands staged through LDS (the default where the tiles fit).  A block = RB rows of the
+// coarse grid: their v records ([RB][Wv + 1][Cv], the extra column zero: the odd position of a row's last step) and, for every row,
+// the k input rows of u it meets ([RB * k][Wv * s + k][Cu], zero columns for x < 0 and x >= Wu, zero rows for y outside the map):
+// 16-byte requests along the channels-last records, issued a block ahead into registers and written to the other buffer behind
+// the block's MFMAs (one barrier per block).  The MFMA loop then reads one dword per operand from LDS at base(tile) + step offset:
+// no bounds test, no 64-bit address and no global request inside it (the direct form above spends 17 vector instructions per MFMA
+// and runs at 20 % of the matrix pipe).  Two halves of four waves with their own buffers, added through LDS as above.
+constexpr int WL_MAXCH = 8;
+struct WLGeo { int RB, WP, nb, rows_per, svb, sub, nv4, nu4; };     // svb / sub: floats per v / u buffer; nv4 / nu4: 16-byte chunks per block
+
+template <int NTW>
+__global__ __launch_bounds__(512) void conv_train_wgrad_lds_kernel(WArgs a, WLGeo g) {
+  extern __shared__ __attribute__((aligned(16))) float s_l[];        // [half][buffer]{v, u}; aliased by the combine tiles and the bias sums
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wq = wave & 3, half = wave >> 2, th = tid & 255;
+  const int CUT = (a.Cu + 31) >> 5, CVT = (a.Cv + 31) >> 5;
+  const int ntile = a.k * a.k * CUT * CVT;
+  const int rc = lane & 31, kk = lane >> 5;
+  const int NR = a.N * a.Hv;
+  const int r0 = (blockIdx.x * 2 + half) * g.rows_per;
+  const int r1 = r0 + g.rows_per < NR ? r0 + g.rows_per : NR;
+  const int bufsz = g.svb + g.sub;
+  float* const sh = s_l + half * 2 * bufsz;
+  // zero both buffers of this half once: the padding columns are never written again
+  for (int i = th; i < 2 * bufsz / 4; i += 256) reinterpret_cast<float4*>(sh)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // this thread's chunks of a block: [0, nv4) v records, [nv4, nv4 + nu4) u records
+  const int vq = a.Wv * a.Cv / 4, uq = a.Wu * a.Cu / 4;             // 16-byte chunks per v row / u row
+  int ch_lds[WL_MAXCH], ch_src[WL_MAXCH], ch_row[WL_MAXCH], ch_ky[WL_MAXCH];   // LDS float offset in a buffer, float offset in the source row, r, ky
+  bool ch_u[WL_MAXCH], ch_ok[WL_MAXCH];
+#pragma unroll
+  for (int c = 0; c < WL_MAXCH; ++c) {
+    const int e = th + c * 256;
+    ch_ok[c] = e < g.nv4 + g.nu4;
+    ch_u[c] = e >= g.nv4;
+    if (!ch_u[c]) {
+      const int r = e / vq, q = e - r * vq;
+      ch_row[c] = r; ch_ky[c] = 0; ch_src[c] = 4 * q;
+      ch_lds[c] = r * (a.Wv + 1) * a.Cv + 4 * q;
+    } else {
+      const int e2 = e - g.nv4;
+      const int rk = e2 / uq, q = e2 - rk * uq;
+      ch_row[c] = rk / a.k; ch_ky[c] = rk % a.k; ch_src[c] = 4 * q;
+      ch_lds[c] = g.svb + (rk * g.WP + a.pad) * a.Cu + 4 * q;
+    }
+  }
+  int t_b[NTW], t_cv[NTW];
+  bool t_ok[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    const int ti = wq + 4 * i;
+    t_ok[i] = ti < ntile;
+    const int tc = t_ok[i] ? ti : 0;
+    const int cvt = tc % CVT, r2 = tc / CVT, cut = r2 % CUT, tap = r2 / CUT;
+    int cu = cut * 32 + rc;
+    cu = cu < a.Cu ? cu : 0;                         // (columns beyond Cu are never read back by the reduce launch)
+    t_b[i] = g.svb + ((tap / a.k) * g.WP + tap % a.k) * a.Cu + cu;
+    int cv = cvt * 32 + rc;
+    t_cv[i] = cv < a.Cv ? cv : 0;
+  }
+  const bool a_shared = (4 % CVT) == 0;
+  v16f acc[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  float4 st[WL_MAXCH];
+  auto request = [&](int b) {                        // block b of this half -> registers
+    const int row0 = r0 + b * g.RB;
+    int ubase[4];                                    // (wave-uniform) first input row of block row r: n * Hu + qy * s - pad
+    int qys[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + r;
+      const int n = row / a.Hv, qy = row - n * a.Hv;
+      qys[r] = qy * a.stride - a.pad;
+      ubase[r] = n * a.Hu + qys[r];
+    }
+#pragma unroll
+    for (int c = 0; c < WL_MAXCH; ++c) {
+      st[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ch_ok[c]) {
+        const int r = ch_row[c];
+        const int row = row0 + r;
+        if (!ch_u[c]) {
+          if (row < r1) st[c] = *reinterpret_cast<const float4*>(a.v + (long long)row * a.Wv * a.Cv + ch_src[c]);
+        } else {
+          const int ub = r == 0 ? ubase[0] : r == 1 ? ubase[1] : r == 2 ? ubase[2] : ubase[3];
+          const int iy = (r == 0 ? qys[0] : r == 1 ? qys[1] : r == 2 ? qys[2] : qys[3]) + ch_ky[c];
+          if (row < r1 && iy >= 0 && iy < a.Hu)
+            st[c] = *reinterpret_cast<const float4*>(a.u + (long long)(ub + ch_ky[c]) * a.Wu * a.Cu + ch_src[c]);
+        }
+      }
+    }
+  };
+  auto deposit = [&](int buf) {
+    float* d = sh + buf * bufsz;
+#pragma unroll
+    for (int c = 0; c < WL_MAXCH; ++c)
+      if (ch_ok[c]) *reinterpret_cast<float4*>(d + ch_lds[c]) = st[c];
+  };
+  const int SR = (a.Wv + 1) >> 1;
+  const int sCu = a.stride * a.Cu;
+  __syncthreads();                                   // (the zero fill)
+  request(0);
+  deposit(0);
+  __syncthreads();
+  for (int b = 0; b < g.nb; ++b) {
+    const bool more = r0 + (b + 1) * g.RB < r1;
+    if (more && !(CT_DBG & 128)) request(b + 1);
+    const float* sv = sh + (b & 1) * bufsz;
+    if (r0 + b * g.RB < r1) {
+      for (int r = 0; r < g.RB; ++r) {
+        const int vo = r * (a.Wv + 1) * a.Cv + kk * a.Cv, uo = r * a.k * g.WP * a.Cu + kk * sCu;
+#pragma unroll CT_WL_UNROLL
+        for (int s2 = 0; s2 < SR; ++s2) {
+          const float* pv = sv + vo + 2 * s2 * a.Cv;
+          const float* pu = sv + uo + 2 * s2 * sCu;
+          float av[NTW], bv[NTW];
+          if (a_shared) {
+            const float x = pv[t_cv[0]];
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) av[i] = x;
+          } else {
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) av[i] = pv[t_cv[i]];
+          }
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) bv[i] = pu[t_b[i]];
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) {
+            if (CT_DBG & 64) acc[i][0] += av[i] + bv[i];
+            else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc[i], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (more) deposit((b + 1) & 1);
+    else if (r0 + b * g.RB < r1) {
+      // rows beyond this half's range must read as zero in a later (empty) block: nothing to do -- empty blocks are skipped above
+    }
+    __syncthreads();
+  }
+  // second half's tiles through LDS (aliases the operand buffers: every wave is behind the last block's barrier)
+  float* const s_x = s_l;
+  if (half == 1) {
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_x[((wq * NTW + i) * 16 + r) * 64 + lane] = acc[i][r];
+  }
+  __syncthreads();
+  float* part = a.part + (long long)blockIdx.x * a.psize;
+  if (half == 0) {
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+      if (t_ok[i]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[(long long)(wq + 4 * i) * 1024 + r * 64 + lane] = acc[i][r] + s_x[((wq * NTW + i) * 16 + r) * 64 + lane];
+      }
+  }
+  if (a.bias_from && !(CT_DBG & 32)) {
+    __syncthreads();
+    constexpr int NT = 512;
+    const float* gq = a.bias_from == 1 ? a.v : a.u;
+    const int C = a.bias_from == 1 ? a.Cv : a.Cu;    // (C % 4 == 0 on this path)
+    const long long Mg = a.bias_from == 1 ? (long long)NR * a.Wv : (long long)a.N * a.Hu * a.Wu;
+    const long long perg = (Mg + a.nwg - 1) / a.nwg;
+    const long long g0 = (long long)blockIdx.x * perg;
+    long long g1 = g0 + perg;
+    g1 = g1 < Mg ? g1 : Mg;
+    const int CQ = C >> 2, RL = NT / CQ;
+    const int cq = tid % CQ, rl = tid / CQ;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (rl < RL) {
+      long long row = g0 + rl;
+      for (; row + 3 * RL < g1; row += 4 * RL) {
+        const float4 x0 = *reinterpret_cast<const float4*>(gq + row * C + 4 * cq);
+        const float4 x1 = *reinterpret_cast<const float4*>(gq + (row + RL) * C + 4 * cq);
+        const float4 x2 = *reinterpret_cast<const float4*>(gq + (row + 2 * RL) * C + 4 * cq);
+        const float4 x3 = *reinterpret_cast<const float4*>(gq + (row + 3 * RL) * C + 4 * cq);
+        s0 += x0.x; s1 += x0.y; s2 += x0.z; s3 += x0.w;
+        s0 += x1.x; s1 += x1.y; s2 += x1.z; s3 += x1.w;
+        s0 += x2.x; s1 += x2.y; s2 += x2.z; s3 += x2.w;
+        s0 += x3.x; s1 += x3.y; s2 += x3.z; s3 += x3.w;
+      }
+      for (; row < g1; row += RL) {
+        const float4 x0 = *reinterpret_cast<const float4*>(gq + row * C + 4 * cq);
+        s0 += x0.x; s1 += x0.y; s2 += x0.z; s3 += x0.w;
+      }
+      s_x[(rl * CQ + cq) * 4 + 0] = s0; s_x[(rl * CQ + cq) * 4 + 1] = s1;
+      s_x[(rl * CQ + cq) * 4 + 2] = s2; s_x[(rl * CQ + cq) * 4 + 3] = s3;
+    }
+    __syncthreads();
+    if (tid < C) {
+      float tot = 0.f;
+      for (int q = 0; q < RL; ++q) tot += s_x[q * C + tid];
+      part[(long long)ntile * 1024 + tid] = tot;
+    }
+  }
+}
+
 // adds the partials of all workgroups and scatters: tiles (MODE 0) or plain [tap][c] rows (MODE 1).  Eight threads per output
 // element take every eighth workgroup's partial and are added in thread order: a fixed order, and loads that do not wait for
 // one another.
@@ -803,6 +1012,46 @@ extern "C" int spk_conv_train_wgrad(const float* u_cl, const float* v_cl, float*
   if (kind == 1) {
     const int ntile = k * k * ((Cu + 31) / 32) * ((Cv + 31) / 32);
     const int ntw = (ntile + 3) / 4;
+    // LDS-staged form where its tiles fit (Cu, Cv multiples of 4, 16-byte aligned tensors, at most WL_MAXCH chunks per thread and block)
+    bool lds_form = false;
+    if (CT_WGRAD_LDS && ntw <= 5 && (Cu & 3) == 0 && (Cv & 3) == 0 && ((reinterpret_cast<uintptr_t>(u_cl) | reinterpret_cast<uintptr_t>(v_cl)) & 15) == 0) {
+      WLGeo g{};
+      g.WP = Wv * stride + k;
+      if (g.WP >= Wu + pad) {                        // (the row image holds every input column)
+        const int NR = N * Hv;
+        g.rows_per = (NR + a.nwg * 2 - 1) / (a.nwg * 2);
+        const size_t comb = (size_t)4 * ntw * 16 * 64 * 4;
+        for (int RB = 4; RB >= 1 && !lds_form; --RB) {
+          if (RB > 1 && (RB - 1) * Wv >= 24) continue;               // no more rows than ~24 positions need
+          g.RB = RB;
+          g.svb = RB * (Wv + 1) * Cv;
+          g.sub = RB * k * g.WP * Cu;
+          g.nv4 = RB * Wv * Cv / 4;
+          g.nu4 = RB * k * Wu * Cu / 4;
+          const size_t need = (size_t)4 * (g.svb + g.sub) * 4;
+          if (need <= 150 * 1024 && g.nv4 + g.nu4 <= 256 * WL_MAXCH) {
+            g.nb = (g.rows_per + RB - 1) / RB;
+            const size_t lds_ = need > comb ? need : comb;
+#define SPK_WL_LAUNCH(N_)                                                                                              \
+  do {                                                                                                                 \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_train_wgrad_lds_kernel<N_>),                         \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                                  \
+    hipLaunchKernelGGL((conv_train_wgrad_lds_kernel<N_>), dim3(a.nwg), dim3(512), lds_, s, a, g);                      \
+  } while (0)
+            switch (ntw) {
+              case 1: SPK_WL_LAUNCH(1); break;
+              case 2: SPK_WL_LAUNCH(2); break;
+              case 3: SPK_WL_LAUNCH(3); break;
+              case 4: SPK_WL_LAUNCH(4); break;
+              default: SPK_WL_LAUNCH(5); break;
+            }
+#undef SPK_WL_LAUNCH
+            lds_form = true;
+          }
+        }
+      }
+    }
+    if (!lds_form) {
 #define SPK_WG_LAUNCH(N_, S_)                                                                                          \
   do {                                                                                                                 \
     const size_t lds_ = (S_) == 2 ? (size_t)4 * (N_) * 16 * 64 * 4 : 8192;                                             \
@@ -822,6 +1071,7 @@ extern "C" int spk_conv_train_wgrad(const float* u_cl, const float* v_cl, float*
       default: SPK_WG_LAUNCH(9, 1); break;
     }
 #undef SPK_WG_LAUNCH
+    }
     SPK_LAUNCH_CHECK();
     const int CB = bias_from == 0 ? 0 : (bias_from == 1 ? Cv : Cu);
     const int E = k * k * Cu * Cv + CB;
