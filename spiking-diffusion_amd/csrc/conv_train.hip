@@ -890,15 +890,18 @@ int gather_kind(int Cred, int Cout, int k, int stride, int form) {
     return (Cred == 8 || Cred == 16 || Cred == 32 || Cred == 64) ? 2 : 0;
   }
   if (Cred % 8 != 0 || Cred > 64 || Cout > 64) return 0;
-  const int CP = (Cout + 31) / 32 * 32;
   if (stride > 4 || (long long)k * k * Cred * 32 * 4 + (CT_STAGE_A ? 8 * 32 * Cred * 4 : 0) > GATHER_LDS_MAX) return 0;    // (one column tile per workgroup always fits then)
   return 1;
 }
 
 template <int J, int CN, int RM>
 void launch_gather(const GArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_train_gather_kernel<J, CN, RM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
+  static bool once = false;                          // (the opt-in to > 64 KB of dynamic LDS: per instantiation, outside any stream capture)
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_train_gather_kernel<J, CN, RM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              152 * 1024);
+    once = true;
+  }
   hipLaunchKernelGGL((conv_train_gather_kernel<J, CN, RM>), grid, dim3(512), lds, s, a);
 }
 template <int J>
@@ -944,7 +947,7 @@ extern "C" int spk_conv_train_gather(const float* in_cl, const float* w, const f
       items += ((long long)N * ((Ho - c / cs + cs - 1) / cs) * ((Wo - c % cs + cs - 1) / cs) + 31) / 32;
     const bool staged = CT_STAGE_A && (J == 1 || J == 2 || J == 4 || J == 8);
     const size_t lds_a = staged ? (size_t)8 * 32 * Cred * 4 : 0;
-    const bool big = CNT == 1 || (items >= CT_BIG_ITEMS && (size_t)k * k * Cred * CNT * 32 * 4 + lds_a <= 160 * 1024);
+    const bool big = CNT == 1 || (items >= CT_BIG_ITEMS && (size_t)k * k * Cred * CNT * 32 * 4 + lds_a <= 150 * 1024);
     const int CN = big ? CNT : 1, RM = 1;
     const int gy = big ? 1 : CNT;
     const size_t lds = (size_t)k * k * Cred * CN * 32 * 4 + lds_a;
@@ -1034,8 +1037,12 @@ extern "C" int spk_conv_train_wgrad(const float* u_cl, const float* v_cl, float*
             const size_t lds_ = need > comb ? need : comb;
 #define SPK_WL_LAUNCH(N_)                                                                                              \
   do {                                                                                                                 \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_train_wgrad_lds_kernel<N_>),                         \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                                  \
+    static bool once_ = false;                                                                                         \
+    if (!once_) {                                                                                                      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_train_wgrad_lds_kernel<N_>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);                               \
+      once_ = true;                                                                                                    \
+    }                                                                                                                  \
     hipLaunchKernelGGL((conv_train_wgrad_lds_kernel<N_>), dim3(a.nwg), dim3(512), lds_, s, a, g);                      \
   } while (0)
             switch (ntw) {
@@ -1055,8 +1062,12 @@ extern "C" int spk_conv_train_wgrad(const float* u_cl, const float* v_cl, float*
 #define SPK_WG_LAUNCH(N_, S_)                                                                                          \
   do {                                                                                                                 \
     const size_t lds_ = (S_) == 2 ? (size_t)4 * (N_) * 16 * 64 * 4 : 8192;                                             \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_train_wgrad_kernel<N_, S_>),                         \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                                  \
+    static bool once_ = false;                                                                                         \
+    if (!once_) {                                                                                                      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_train_wgrad_kernel<N_, S_>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);                               \
+      once_ = true;                                                                                                    \
+    }                                                                                                                  \
     hipLaunchKernelGGL((conv_train_wgrad_kernel<N_, S_>), dim3(a.nwg), dim3(256 * (S_)), lds_, s, a);                  \
   } while (0)
     switch (ntw) {

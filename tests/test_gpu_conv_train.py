@@ -131,3 +131,41 @@ def test_unsupported_shapes_fall_back_to_the_framework(dev, ops):
     y = m(x)
     y.sum().backward()
     assert tuple(y.shape) == (2, 4, 32, 16, 16) and m.weight.grad is not None
+
+
+def test_graphed_vqvae_training_step_equals_the_eager_loop(dev):
+    """spkdiff.train.GraphedVQVAETrainStep: one captured iteration of the reference's VQ-VAE training loop (R/main.py:118-146:
+    forward in train() mode, loss_eq + loss_rec, backward, AdamW, reset_net) replayed per batch gives the losses and the weights
+    of the same iterations run launch by launch (every kernel of the iteration is deterministic), and the losses fall."""
+    from snn_model.vae_model import SNN_VQVAE, functional
+    from spkdiff import synth
+    from spkdiff.train import GraphedVQVAETrainStep
+    imgs = [(synth.stroke_images(8, 5 + i) - 0.5).to(dev) for i in range(6)]
+
+    def make():
+        m = SNN_VQVAE(1, 16, 128, 0.08).to(dev)
+        functional.set_step_mode(net=m, step_mode='m')
+        m.load_state_dict(synth.synth_vqvae_state(synth.MNIST))
+        m.train()
+        return m, torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.001, fused=True, capturable=True)
+
+    m1, o1 = make()
+    eager = []
+    for x in [imgs[0]] * 3 + imgs:                     # (the three warm-up iterations of the captured form, then six batches)
+        a, b, c = m1(x.unsqueeze(0).repeat(16, 1, 1, 1, 1), x)
+        o1.zero_grad(); (a + b).backward(); o1.step(); functional.reset_net(m1)
+        eager.append((float(a.detach()), float(b.detach()), float(c.detach())))
+    m2, o2 = make()
+    step = GraphedVQVAETrainStep(m2, o2, imgs[0], 16, warmup=3)
+    got = [tuple(float(v.detach()) for v in step(x)) for x in imgs]
+    for g, w in zip(got, eager[3:]):
+        assert all(abs(gv - wv) <= 1e-5 * (1 + abs(wv)) for gv, wv in zip(g, w)), (g, w)
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert float((p1.detach() - p2.detach()).abs().max()) <= 1e-6 * (1 + float(p1.detach().abs().max())), k
+    with pytest.raises(RuntimeError):
+        GraphedVQVAETrainStep(m2, torch.optim.AdamW(m2.parameters(), lr=1e-3), imgs[0])
+    m2.eval()
+    with torch.inference_mode():                       # the captured optimizer steps are visible to the inference path
+        _, xr, idx = m2(imgs[0].unsqueeze(0).repeat(16, 1, 1, 1, 1), imgs[0])
+    functional.reset_net(m2)
+    assert xr.shape == (8, 1, 28, 28) and bool(torch.isfinite(xr).all())
