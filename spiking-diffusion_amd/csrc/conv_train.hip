@@ -42,9 +42,12 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #ifndef CT_WGRAD_LDS
 #define CT_WGRAD_LDS 1                             // 0: the weight gradient always reads its operands from global memory (the first form)
 #endif
-#ifndef CT_WL_UNROLL
-#define CT_WL_UNROLL 1
-#endif
+#ifndef CT_WL_PINGPONG
+#define CT_WL_PINGPONG 0                           // 1: LDS-staged weight gradient with the two halves of a workgroup alternating between their MFMA
+#endif                                             // phase and their request / LDS-write phase (one buffer per half, two barriers per block).  Built
+                                                   // because the in-step form's parts add up; measured SLOWER (same box: dec.convT2 109.5 against 87.2 us,
+                                                   // enc.conv2 46.8 against 40.6, dec.convT1 53.9 against 45.7): a wave alone on its SIMD does not
+                                                   // issue its MFMAs twice as fast -- every step waits for its own LDS reads with nobody to fill in
 #ifndef CT_BIG_ITEMS
 #define CT_BIG_ITEMS 2048                          // a wave takes all column tiles of its 32 rows from this many items on (below: one column tile)
 #endif
@@ -585,9 +588,10 @@ __global__ __launch_bounds__(512) void conv_train_wgrad_lds_kernel(WArgs a, WLGe
   const int r0 = (blockIdx.x * 2 + half) * g.rows_per;
   const int r1 = r0 + g.rows_per < NR ? r0 + g.rows_per : NR;
   const int bufsz = g.svb + g.sub;
-  float* const sh = s_l + half * 2 * bufsz;
+  constexpr int NBUF = CT_WL_PINGPONG ? 1 : 2;
+  float* const sh = s_l + half * NBUF * bufsz;
   // zero both buffers of this half once: the padding columns are never written again
-  for (int i = th; i < 2 * bufsz / 4; i += 256) reinterpret_cast<float4*>(sh)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = th; i < NBUF * bufsz / 4; i += 256) reinterpret_cast<float4*>(sh)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   // this thread's chunks of a block: [0, nv4) v records, [nv4, nv4 + nu4) u records
   const int vq = a.Wv * a.Cv / 4, uq = a.Wu * a.Cu / 4;             // 16-byte chunks per v row / u row
   int ch_lds[WL_MAXCH], ch_src[WL_MAXCH], ch_row[WL_MAXCH], ch_ky[WL_MAXCH];   // LDS float offset in a buffer, float offset in the source row, r, ky
@@ -667,44 +671,65 @@ __global__ __launch_bounds__(512) void conv_train_wgrad_lds_kernel(WArgs a, WLGe
   const int SR = (a.Wv + 1) >> 1;
   const int sCu = a.stride * a.Cu;
   __syncthreads();                                   // (the zero fill)
-  request(0);
-  deposit(0);
-  __syncthreads();
-  for (int b = 0; b < g.nb; ++b) {
-    const bool more = r0 + (b + 1) * g.RB < r1;
-    if (more && !(CT_DBG & 128)) request(b + 1);
-    const float* sv = sh + (b & 1) * bufsz;
-    if (r0 + b * g.RB < r1) {
-      for (int r = 0; r < g.RB; ++r) {
-        const int vo = r * (a.Wv + 1) * a.Cv + kk * a.Cv, uo = r * a.k * g.WP * a.Cu + kk * sCu;
-#pragma unroll CT_WL_UNROLL
-        for (int s2 = 0; s2 < SR; ++s2) {
-          const float* pv = sv + vo + 2 * s2 * a.Cv;
-          const float* pu = sv + uo + 2 * s2 * sCu;
-          float av[NTW], bv[NTW];
-          if (a_shared) {
-            const float x = pv[t_cv[0]];
+  auto compute = [&](const float* sv) {
+    for (int r = 0; r < g.RB; ++r) {
+      const int vo = r * (a.Wv + 1) * a.Cv + kk * a.Cv, uo = r * a.k * g.WP * a.Cu + kk * sCu;
+      for (int s2 = 0; s2 < SR; ++s2) {
+        const float* pv = sv + vo + 2 * s2 * a.Cv;
+        const float* pu = sv + uo + 2 * s2 * sCu;
+        float av[NTW], bv[NTW];
+        if (a_shared) {
+          const float x = pv[t_cv[0]];
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) av[i] = x;
-          } else {
+          for (int i = 0; i < NTW; ++i) av[i] = x;
+        } else {
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) av[i] = pv[t_cv[i]];
-          }
+          for (int i = 0; i < NTW; ++i) av[i] = pv[t_cv[i]];
+        }
 #pragma unroll
-          for (int i = 0; i < NTW; ++i) bv[i] = pu[t_b[i]];
+        for (int i = 0; i < NTW; ++i) bv[i] = pu[t_b[i]];
 #pragma unroll
-          for (int i = 0; i < NTW; ++i) {
-            if (CT_DBG & 64) acc[i][0] += av[i] + bv[i];
-            else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc[i], 0, 0, 0);
-          }
+        for (int i = 0; i < NTW; ++i) {
+          if (CT_DBG & 64) acc[i][0] += av[i] + bv[i];
+          else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc[i], 0, 0, 0);
         }
       }
     }
-    if (more) deposit((b + 1) & 1);
-    else if (r0 + b * g.RB < r1) {
-      // rows beyond this half's range must read as zero in a later (empty) block: nothing to do -- empty blocks are skipped above
-    }
+  };
+  if (CT_WL_PINGPONG) {
+    // ONE buffer per half and two barriers per block: while half 0 multiplies block b, half 1 writes its block b to LDS and
+    // requests the next one; then they swap.  The two waves of a SIMD are never in their MFMA phase together (together they
+    // only share the pipe: the phase takes twice as long), and a half's requests / LDS writes run beside the other half's MFMAs
+    // instead of in front of its own.  (Off by default: see the knob.)
+    request(0);
+    if (half == 0) deposit(0);
     __syncthreads();
+    for (int b = 0; b < g.nb; ++b) {
+      const bool cur = r0 + b * g.RB < r1, more = r0 + (b + 1) * g.RB < r1;
+      if (half == 0) {
+        if (more && !(CT_DBG & 128)) request(b + 1);
+        if (cur) compute(sh);
+      } else if (cur) deposit(0);
+      __syncthreads();
+      if (half == 0) {
+        if (more) deposit(0);
+      } else {
+        if (more && !(CT_DBG & 128)) request(b + 1);
+        if (cur) compute(sh);
+      }
+      __syncthreads();
+    }
+  } else {
+    request(0);
+    deposit(0);
+    __syncthreads();
+    for (int b = 0; b < g.nb; ++b) {
+      const bool more = r0 + (b + 1) * g.RB < r1;
+      if (more && !(CT_DBG & 128)) request(b + 1);
+      if (r0 + b * g.RB < r1) compute(sh + (b & 1) * bufsz);
+      if (more) deposit((b + 1) & 1);
+      __syncthreads();
+    }
   }
   // second half's tiles through LDS (aliases the operand buffers: every wave is behind the last block's barrier)
   float* const s_x = s_l;
@@ -1031,7 +1056,7 @@ extern "C" int spk_conv_train_wgrad(const float* u_cl, const float* v_cl, float*
           g.sub = RB * k * g.WP * Cu;
           g.nv4 = RB * Wv * Cv / 4;
           g.nu4 = RB * k * Wu * Cu / 4;
-          const size_t need = (size_t)4 * (g.svb + g.sub) * 4;
+          const size_t need = (size_t)(CT_WL_PINGPONG ? 2 : 4) * (g.svb + g.sub) * 4;
           if (need <= 150 * 1024 && g.nv4 + g.nu4 <= 256 * WL_MAXCH) {
             g.nb = (g.rows_per + RB - 1) / RB;
             const size_t lds_ = need > comb ? need : comb;

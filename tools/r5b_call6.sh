@@ -1,7 +1,8 @@
 R=$GRAFT_REPO_ROOT
 cd $R
-for v in "" ct_dbg32 ct_dbg64 ct_dbg128 ct_dbg224; do
+timeout 900 python -m pytest tests/test_gpu_conv_train.py -x -q 2>&1 | tail -3
+for v in "" ct_pp0; do
   echo "== variant '$v'"
   if [ -n "$v" ]; then export SPKDIFF_LIB=$R/spiking-diffusion_amd/spkdiff/variants/$v.so; fi
-  python tools/conv_train_time.py 512 nolib 2>/dev/null | grep -E "conv2|convT2"
+  python tools/conv_train_time.py 512 nolib 2>/dev/null
 done
