@@ -48,6 +48,12 @@ typedef float v16f __attribute__((ext_vector_type(16)));
                                                    // because the in-step form's parts add up; measured SLOWER (same box: dec.convT2 109.5 against 87.2 us,
                                                    // enc.conv2 46.8 against 40.6, dec.convT1 53.9 against 45.7): a wave alone on its SIMD does not
                                                    // issue its MFMAs twice as fast -- every step waits for its own LDS reads with nobody to fill in
+#ifndef CT_SUBPIXEL
+#define CT_SUBPIXEL 0                              // 1: the stride-2 transposed form takes ALL FOUR sub-pixel classes of 32 coarse positions per item
+                                                   // (conv_train_gather_sub_kernel).  Built to amortise the per-item index arithmetic; measured SLOWER
+                                                   // (same box, us per call: dec.convT2 forward 69.1 against 64.4, enc.conv2 data gradient 35.6 against
+                                                   // 29.6, dec.convT1 forward 33.0 against 23.4): 182 registers put one workgroup on a CU instead of two
+#endif
 #ifndef CT_BIG_ITEMS
 #define CT_BIG_ITEMS 2048                          // a wave takes all column tiles of its 32 rows from this many items on (below: one column tile)
 #endif
@@ -68,7 +74,7 @@ struct GArgs {
 // taps of sub-pixel class (py, px): index into the k x k kernel and the input offset of the tap
 struct TapList { int n; int tap[MAX_TAPS], dy[MAX_TAPS], dx[MAX_TAPS]; };
 
-__device__ __forceinline__ void build_taps(TapList& tl, int k, int stride, int pad, int form, int py, int px) {
+__host__ __device__ inline void build_taps(TapList& tl, int k, int stride, int pad, int form, int py, int px) {
   int n = 0;
   for (int ky = 0; ky < k; ++ky)
     for (int kx = 0; kx < k; ++kx) {
@@ -85,40 +91,12 @@ __device__ __forceinline__ void build_taps(TapList& tl, int k, int stride, int p
   tl.n = n;
 }
 
-// J = Cred / 8, CN = column tiles (32 output channels each) of a wave, RM = row tiles (32 output positions each) of a wave.
-// blockIdx.y = first column tile of the workgroup (the host splits the column tiles over workgroups when the layer has too few
-// rows to fill the chip otherwise).  A workgroup stages ALL k * k taps once and walks (sub-pixel class, row group) items: the
-// classes of the transposed form have 1 .. ceil(k / s)^2 taps each, so a workgroup per class would leave the chip waiting for
-// the largest class.
-constexpr int MAX_CLASSES = 16;                     // stride <= 4
-struct ClassTab { int ncls, cs; int first[MAX_CLASSES + 1]; int Qh[MAX_CLASSES], Qw[MAX_CLASSES]; TapList tl[MAX_CLASSES]; };
-
-template <int J, int CN, int RM>
-__global__ __launch_bounds__(512) void conv_train_gather_kernel(GArgs a) {
-  constexpr int NTH = 512, NWV = 8;                 // eight waves share one staged weight image
-  extern __shared__ __attribute__((aligned(16))) float4 sB[];       // [tap][J][2][CN * 32]
-  __shared__ ClassTab ct;
-  constexpr int CP = CN * 32, CRED = J * 8, ROWS = RM * 32;
-  constexpr bool STAGE = CT_STAGE_A && (J == 1 || J == 2 || J == 4 || J == 8);       // (a power of two lanes per row)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cs = a.form ? a.stride : 1;            // output step per class-grid step
-  const int ai = a.form ? 1 : a.stride;            // input step per class-grid step
-  const int co0 = blockIdx.y * CP;                 // first output channel of this workgroup
-  if (tid == 0) {
-    ct.ncls = cs * cs; ct.cs = cs;
-    int first = 0;
-    for (int c = 0; c < cs * cs; ++c) {
-      const int py = c / cs, px = c % cs;
-      build_taps(ct.tl[c], a.k, a.stride, a.pad, a.form, py, px);
-      ct.Qh[c] = (a.Ho - py + cs - 1) / cs;
-      ct.Qw[c] = (a.Wo - px + cs - 1) / cs;
-      ct.first[c] = first;
-      first += (int)(((long long)a.N * ct.Qh[c] * ct.Qw[c] + ROWS - 1) / ROWS);
-    }
-    ct.first[cs * cs] = first;
-  }
+// All k * k weight taps of the workgroup's CN column tiles into LDS in B-fragment order ([tap][c / 8][c / 4 % 2][co][c % 4]).
+template <int J, int CN, int NTH>
+__device__ __forceinline__ void stage_weights(const GArgs& a, float4* sB, const int co0, const int tid) {
+  constexpr int CP = CN * 32, CRED = J * 8;
   const int ntap = a.k * a.k;
-  float4* const sA = sB + ntap * J * 2 * CP;          // STAGE: [8 waves][32 rows][Cred / 4] operand tiles behind the weights
+  if (CT_DBG & 256) return;                        // (timing experiment: no weight staging)
   // staging: 16-byte loads along whichever weight dimension is contiguous, SB requests in flight per thread (the weights are
   // L2-resident; one request at a time cost 30+ us per launch)
   constexpr int SB = 6;
@@ -171,7 +149,52 @@ __global__ __launch_bounds__(512) void conv_train_gather_kernel(GArgs a) {
       reinterpret_cast<float*>(sB)[((((t * J + (c >> 3)) * 2 + ((c >> 2) & 1)) * CP + co) << 2) + (c & 3)] = v;
     }
   }
+}
+
+// J = Cred / 8, CN = column tiles (32 output channels each) of a wave, RM = row tiles (32 output positions each) of a wave.
+// blockIdx.y = first column tile of the workgroup (the host splits the column tiles over workgroups when the layer has too few
+// rows to fill the chip otherwise).  A workgroup stages ALL k * k taps once and walks (sub-pixel class, row group) items: the
+// classes of the transposed form have 1 .. ceil(k / s)^2 taps each, so a workgroup per class would leave the chip waiting for
+// the largest class.
+constexpr int MAX_CLASSES = 4;                      // (transposed form: stride <= 2; the table travels as a kernel argument)
+struct ClassTab { int ncls, cs; int first[MAX_CLASSES + 1]; int Qh[MAX_CLASSES], Qw[MAX_CLASSES]; TapList tl[MAX_CLASSES]; };
+
+// (the class / tap tables are built on the host: one thread building them in front of a workgroup barrier took 5.6 us of a 55 us launch)
+inline void build_class_tab(ClassTab& ct, const GArgs& a, int rows) {
+  const int cs = a.form ? a.stride : 1;
+  ct.ncls = cs * cs; ct.cs = cs;
+  int first = 0;
+  for (int c = 0; c < cs * cs; ++c) {
+    const int py = c / cs, px = c % cs;
+    build_taps(ct.tl[c], a.k, a.stride, a.pad, a.form, py, px);
+    ct.Qh[c] = (a.Ho - py + cs - 1) / cs;
+    ct.Qw[c] = (a.Wo - px + cs - 1) / cs;
+    ct.first[c] = first;
+    first += (int)(((long long)a.N * ct.Qh[c] * ct.Qw[c] + rows - 1) / rows);
+  }
+  for (int c = cs * cs; c <= MAX_CLASSES; ++c) ct.first[c] = first;
+}
+
+template <int J, int CN, int RM>
+__global__ __launch_bounds__(512) void conv_train_gather_kernel(GArgs a, ClassTab ct_arg) {
+  constexpr int NTH = 512, NWV = 8;                 // eight waves share one staged weight image
+  extern __shared__ __attribute__((aligned(16))) float4 sB[];       // [tap][J][2][CN * 32]
+  __shared__ ClassTab ct;                           // (LDS copy of the host-built table: published by the barrier behind the weight staging)
+  if (threadIdx.x < sizeof(ClassTab) / 4) reinterpret_cast<int*>(&ct)[threadIdx.x] = reinterpret_cast<const int*>(&ct_arg)[threadIdx.x];
+  constexpr int CP = CN * 32, CRED = J * 8, ROWS = RM * 32;
+  constexpr bool STAGE = CT_STAGE_A && (J == 1 || J == 2 || J == 4 || J == 8);       // (a power of two lanes per row)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cs = a.form ? a.stride : 1;            // output step per class-grid step
+  const int ai = a.form ? 1 : a.stride;            // input step per class-grid step
+  const int co0 = blockIdx.y * CP;                 // first output channel of this workgroup
+  unsigned long long stamp[4] = {0, 0, 0, 0};      // (CT_DBG 512: s_memrealtime at start / tables built / weights staged / items done -> a.out)
+  if (CT_DBG & 512) stamp[0] = __builtin_amdgcn_s_memrealtime();
+  const int ntap = a.k * a.k;
+  float4* const sA = sB + ntap * J * 2 * CP;          // STAGE: [8 waves][32 rows][Cred / 4] operand tiles behind the weights
+  if (CT_DBG & 512) stamp[1] = __builtin_amdgcn_s_memrealtime();
+  stage_weights<J, CN, NTH>(a, sB, co0, tid);
   __syncthreads();
+  if (CT_DBG & 512) stamp[2] = __builtin_amdgcn_s_memrealtime();
 
   const int nitems = ct.first[cs * cs];
   const int r = lane & 31, h = lane >> 5;
@@ -304,6 +327,139 @@ __global__ __launch_bounds__(512) void conv_train_gather_kernel(GArgs a) {
 #pragma unroll
           for (int i = 0; i < 16; ++i)
             if (orow[i] >= 0 && (!(CT_DBG & 16) || acc[rm][cn][i] == 12345.f)) a.out[(long long)orow[i] * a.Cout + co] = acc[rm][cn][i] + bv;
+        }
+      }
+    }
+  }
+  if (CT_DBG & 512) {
+    __syncthreads();
+    stamp[3] = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(a.out) + 4 * (blockIdx.y * gridDim.x + blockIdx.x);
+      o[0] = stamp[0]; o[1] = stamp[1]; o[2] = stamp[2]; o[3] = stamp[3];
+    }
+  }
+}
+
+// The transposed form at stride 2 with ALL FOUR sub-pixel classes of a coarse position in one item.  Class (py, px) of coarse
+// position q reads in[q + d] for the taps with (p + pad - k) even, d = (p + pad - k) / 2: over the four classes the k * k taps meet
+// only a handful of DISTINCT offsets d (four for k = 3: every input record feeds one tap of up to four classes).  An item = 32 coarse
+// positions: per distinct offset one 16-byte-per-lane read of the input records and, for every class that has a tap there, the
+// 4 J MFMAs of that tap into the class's accumulator -- 9 taps x 4 J MFMAs per four input tiles and ONE set of index arithmetic,
+// where the class-per-item form above spends a tile, a prologue and an epilogue per 1 - 4 taps (550 vector instructions per 72
+// MFMAs: 28 % of the matrix pipe, profiles/r5_ab_conv_train.txt (2)).
+constexpr int SUB_MAXOFF = 9;
+struct SubTab { int noff; int dy[SUB_MAXOFF], dx[SUB_MAXOFF]; int tap[SUB_MAXOFF][4]; };
+
+inline void build_sub_tab(SubTab& tb, const GArgs& a) {
+  int n = 0;
+  for (int c = 0; c < 4; ++c) {
+    const int py = c >> 1, px = c & 1;
+    for (int ky = 0; ky < a.k; ++ky)
+      for (int kx = 0; kx < a.k; ++kx) {
+        const int ty = py + a.pad - ky, tx = px + a.pad - kx;
+        if ((ty & 1) || (tx & 1)) continue;
+        const int dy = ty / 2, dx = tx / 2;
+        int o = 0;
+        while (o < n && !(tb.dy[o] == dy && tb.dx[o] == dx)) ++o;
+        if (o == n) {
+          tb.dy[n] = dy; tb.dx[n] = dx;
+          for (int q = 0; q < 4; ++q) tb.tap[n][q] = -1;
+          ++n;
+        }
+        tb.tap[o][c] = ky * a.k + kx;
+      }
+  }
+  tb.noff = n;
+}
+
+template <int J, int CN>
+__global__ __launch_bounds__(512) void conv_train_gather_sub_kernel(GArgs a, SubTab tb) {
+  constexpr int NTH = 512, NWV = 8;
+  extern __shared__ __attribute__((aligned(16))) float4 sB[];       // [tap][J][2][CN * 32]
+  constexpr int CP = CN * 32, CRED = J * 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int co0 = blockIdx.y * CP;
+  stage_weights<J, CN, NTH>(a, sB, co0, tid);
+  __syncthreads();
+
+  const int Qh = (a.Ho + 1) >> 1, Qw = (a.Wo + 1) >> 1;
+  const long long M = (long long)a.N * Qh * Qw;
+  const int nitems = (int)((M + 31) / 32);
+  const int r = lane & 31, h = lane >> 5;
+  const int noff = tb.noff;
+  for (int item = blockIdx.x * NWV + wave; item < nitems; item += gridDim.x * NWV) {
+    const long long R = (long long)item * 32 + r;
+    const bool rv = R < M;
+    const int Rc = rv ? (int)R : 0;
+    const int qx = Rc % Qw, t1 = Rc / Qw, qy = t1 % Qh, n = t1 / Qh;
+    const int opos = rv ? (n * a.Ho + 2 * qy) * a.Wo + 2 * qx : -1;           // class (0, 0); class (py, px) is py * Wo + px further
+    const int edge = (2 * qy + 1 < a.Ho ? 1 : 0) | (2 * qx + 1 < a.Wo ? 2 : 0);   // bit 0: the odd row exists, bit 1: the odd column
+    v16f acc[4][CN];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int cn = 0; cn < CN; ++cn)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][cn][i] = 0.f;
+    float4 A[2][J];
+    auto load_a = [&](int o, float4 (&dst)[J]) {
+      const int iy = qy + tb.dy[o], ix = qx + tb.dx[o];
+      const bool ok = rv && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
+      const float4* p = reinterpret_cast<const float4*>(a.in + (((long long)n * a.Hi + iy) * a.Wi + ix) * CRED + 4 * h);
+#pragma unroll
+      for (int j = 0; j < J; ++j) dst[j] = ok ? p[2 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto mma = [&](int o, const float4 (&src)[J]) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int tap = tb.tap[o][c];                  // (wave-uniform)
+        if (tap < 0) continue;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          float4 B[CN];
+#pragma unroll
+          for (int cn = 0; cn < CN; ++cn) B[cn] = sB[((tap * J + j) * 2 + h) * CP + cn * 32 + r];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int cn = 0; cn < CN; ++cn) {
+              const float av = q == 0 ? src[j].x : q == 1 ? src[j].y : q == 2 ? src[j].z : src[j].w;
+              const float bv = q == 0 ? B[cn].x : q == 1 ? B[cn].y : q == 2 ? B[cn].z : B[cn].w;
+              acc[c][cn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[c][cn], 0, 0, 0);
+            }
+        }
+      }
+    };
+    if (noff > 0) load_a(0, A[0]);
+    int o = 0;
+    for (; o + 1 < noff; o += 2) {
+      load_a(o + 1, A[1]);
+      mma(o, A[0]);
+      if (o + 2 < noff) load_a(o + 2, A[0]);
+      mma(o + 1, A[1]);
+    }
+    if (o < noff) mma(o, A[0]);
+
+    int orow[16], oedge[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int src = 8 * (i >> 2) + 4 * h + (i & 3);
+      orow[i] = __shfl(opos, src);
+      oedge[i] = __shfl(edge, src);
+    }
+#pragma unroll
+    for (int cn = 0; cn < CN; ++cn) {
+      const int co = co0 + cn * 32 + r;
+      if (co < a.Cout) {
+        const float bv = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int need = (c >> 1) | ((c & 1) << 1);                 // the edge bits class c needs
+          float* const oc = a.out + ((long long)(c >> 1) * a.Wo + (c & 1)) * a.Cout + co;
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (orow[i] >= 0 && (oedge[i] & need) == need) oc[(long long)orow[i] * a.Cout] = acc[c][cn][i] + bv;
         }
       }
     }
@@ -915,7 +1071,7 @@ int gather_kind(int Cred, int Cout, int k, int stride, int form) {
     return (Cred == 8 || Cred == 16 || Cred == 32 || Cred == 64) ? 2 : 0;
   }
   if (Cred % 8 != 0 || Cred > 64 || Cout > 64) return 0;
-  if (stride > 4 || (long long)k * k * Cred * 32 * 4 + (CT_STAGE_A ? 8 * 32 * Cred * 4 : 0) > GATHER_LDS_MAX) return 0;    // (one column tile per workgroup always fits then)
+  if (stride > 4 || (form && stride > 2) || (long long)k * k * Cred * 32 * 4 + (CT_STAGE_A ? 8 * 32 * Cred * 4 : 0) > GATHER_LDS_MAX) return 0;    // (one column tile per workgroup always fits then)
   return 1;
 }
 
@@ -927,7 +1083,9 @@ void launch_gather(const GArgs& a, dim3 grid, size_t lds, hipStream_t s) {
                               152 * 1024);
     once = true;
   }
-  hipLaunchKernelGGL((conv_train_gather_kernel<J, CN, RM>), grid, dim3(512), lds, s, a);
+  ClassTab ct;
+  build_class_tab(ct, a, RM * 32);
+  hipLaunchKernelGGL((conv_train_gather_kernel<J, CN, RM>), grid, dim3(512), lds, s, a, ct);
 }
 template <int J>
 void launch_gather_j(const GArgs& a, int CN, int RM, dim3 grid, size_t lds, hipStream_t s) {
@@ -966,6 +1124,37 @@ extern "C" int spk_conv_train_gather(const float* in_cl, const float* w, const f
     const int cs = form ? stride : 1;
     if (cs * cs > MAX_CLASSES) return SPK_ERR_UNSUPPORTED;
     const int CNT = (Cout + 31) / 32, J = Cred / 8;
+    if (CT_SUBPIXEL && form && stride == 2 && k <= 3 && (J == 1 || J == 2 || J == 4 || J == 8)) {
+      // all four sub-pixel classes of 32 coarse positions per item
+      const long long items = ((long long)N * ((Ho + 1) / 2) * ((Wo + 1) / 2) + 31) / 32;
+      const bool big = CNT == 1 || (items >= CT_BIG_ITEMS / 4 && (size_t)k * k * Cred * CNT * 32 * 4 <= 150 * 1024);
+      const int CN = big ? CNT : 1, gy = big ? 1 : CNT;
+      const size_t lds = (size_t)k * k * Cred * CN * 32 * 4;
+      int gx = (int)((items + 7) / 8);
+      const int per_cu = lds > 76 * 1024 ? 1 : 2;
+      const int cap = 256 * per_cu / gy > 0 ? 256 * per_cu / gy : 1;
+      gx = gx < cap ? gx : cap;
+      SubTab tb;
+      build_sub_tab(tb, a);
+#define SPK_SUB_LAUNCH(J_, CN_)                                                                                        \
+  do {                                                                                                                 \
+    static bool once_ = false;                                                                                         \
+    if (!once_) {                                                                                                      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_train_gather_sub_kernel<J_, CN_>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);                               \
+      once_ = true;                                                                                                    \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((conv_train_gather_sub_kernel<J_, CN_>), dim3(gx, gy), dim3(512), lds, s, a, tb);               \
+  } while (0)
+      if (CN == 2) {
+        if (J == 1) SPK_SUB_LAUNCH(1, 2); else if (J == 2) SPK_SUB_LAUNCH(2, 2); else if (J == 4) SPK_SUB_LAUNCH(4, 2); else SPK_SUB_LAUNCH(8, 2);
+      } else {
+        if (J == 1) SPK_SUB_LAUNCH(1, 1); else if (J == 2) SPK_SUB_LAUNCH(2, 1); else if (J == 4) SPK_SUB_LAUNCH(4, 1); else SPK_SUB_LAUNCH(8, 1);
+      }
+#undef SPK_SUB_LAUNCH
+      SPK_LAUNCH_CHECK();
+      return SPK_OK;
+    }
     // items of 32 rows x all column tiles when there are at least four per SIMD; otherwise 32 rows x one column tile
     long long items = 0;
     for (int c = 0; c < cs * cs; ++c)

@@ -531,18 +531,18 @@ def conv_train_backward(grad_y, x, weight, stride, pad, transposed, out_pad, nee
             check(lib.spk_conv_train_gather(_p(gy), _p(w), None, _p(gi), N, Ho, Wo, Cout, Hi, Wi, Cin, k, stride, pad,
                                             0 if transposed else 1, tap, s_co, s_ci, st), "spk_conv_train_gather")
     if needs[1] or needs[2]:
-        gw = torch.empty_like(w)
-        assert gw.stride() == w.stride()
+        gw = torch.empty_like(w)                     # (the memory format of a dense weight is preserved; the kernel takes gw's own strides)
+        g_tap, g_ci, g_co = _conv_w_strides(gw, transposed)
         gb = torch.empty(Cout, dtype=torch.float32, device=gy.device) if needs[2] else None
         if transposed:
-            u, v, Hu, Wu, Cu, Hv, Wv, Cv, g_u, g_v, bf = gy, xin, Ho, Wo, Cout, Hi, Wi, Cin, s_co, s_ci, 2
+            u, v, Hu, Wu, Cu, Hv, Wv, Cv, g_u, g_v, bf = gy, xin, Ho, Wo, Cout, Hi, Wi, Cin, g_co, g_ci, 2
         else:
-            u, v, Hu, Wu, Cu, Hv, Wv, Cv, g_u, g_v, bf = xin, gy, Hi, Wi, Cin, Ho, Wo, Cout, s_ci, s_co, 1
+            u, v, Hu, Wu, Cu, Hv, Wv, Cv, g_u, g_v, bf = xin, gy, Hi, Wi, Cin, Ho, Wo, Cout, g_ci, g_co, 1
         nb = int(lib.spk_conv_train_wgrad_ws_bytes(N, Hv, Wv, Cu, Cv, k))
         ws = torch.empty(nb, dtype=torch.uint8, device=gy.device)
         with timed("train.conv_bwd_weight"):
             check(lib.spk_conv_train_wgrad(_p(u), _p(v), _p(ws), nb, _p(gw), _p(gb), N, Hu, Wu, Cu, Hv, Wv, Cv, k, stride, pad,
-                                           tap, g_u, g_v, bf if gb is not None else 0, st), "spk_conv_train_wgrad")
+                                           g_tap, g_u, g_v, bf if gb is not None else 0, st), "spk_conv_train_wgrad")
         if not needs[1]:
             gw = None
     return gi, gw, gb
