@@ -311,6 +311,8 @@ __global__ __launch_bounds__(256) void tinv_lif_kernel(TinvArgs a) {
     for (int i = 0; i < NW; ++i) wreg[i] = a.wt[i * a.Cout + co];            // packed [k*k][Cin][Cout]
   }
   const int HWi = a.H * a.W;
+  const bool small_idx = npos < (1 << 24);
+  const float inv_plane = 1.0f / (float)plane, inv_wo = 1.0f / (float)a.Wo;
   // stateless calls (v = 0 at step 0): the spike train of a constant input is a table look-up (spk_common.h)
   __shared__ float s_th[16];
   __shared__ unsigned s_pat[18];
@@ -324,8 +326,20 @@ __global__ __launch_bounds__(256) void tinv_lif_kernel(TinvArgs a) {
     const int pg = p0 + pl;
     const bool ok = pg < npos;
     const int pc = ok ? pg : npos - 1;
-    const int b = pc / plane, op = pc - b * plane;
-    const int oy = op / a.Wo, ox = op - oy * a.Wo;
+    // (quotients by reciprocal multiplication + one correction step: exact for operands below 2^24; a 32-bit integer division
+    //  is ~40 vector instructions, two of them were a quarter of this kernel's work per neuron)
+    int b, op, oy, ox;
+    if (small_idx) {
+      b = (int)((float)pc * inv_plane);
+      op = pc - b * plane;
+      if (op < 0) { --b; op += plane; } else if (op >= plane) { ++b; op -= plane; }
+      oy = (int)((float)op * inv_wo);
+      ox = op - oy * a.Wo;
+      if (ox < 0) { --oy; ox += a.Wo; } else if (ox >= a.Wo) { ++oy; ox -= a.Wo; }
+    } else {
+      b = pc / plane; op = pc - b * plane;
+      oy = op / a.Wo; ox = op - oy * a.Wo;
+    }
     double acc = b0;
     if constexpr (KC > 0) {
       const float* xb = a.x + (long long)b * KC * HWi;
