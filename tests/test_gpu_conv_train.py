@@ -43,6 +43,9 @@ ODD_SHAPES = [
     (16, 32, 3, 1, 1, True, 0, 6, 5, False),       # stride-1 transposed layer on the matrix path
     (64, 64, 3, 1, 1, False, 0, 7, 4, True),       # 144 KB of weight taps in LDS (one workgroup per CU)
     (1, 8, 3, 1, 1, False, 0, 6, 3, False),        # one reduced channel, stride 1
+    (16, 16, 3, 2, 1, True, 0, 5, 3, False),       # 9x9 output of a 5x5 input: the odd sub-pixel classes are one row / column short
+    (8, 8, 1, 2, 0, False, 0, 6, 2, False),        # 1x1 / stride 2: three of the four classes of its data gradient have no tap (zeros)
+    (32, 32, 3, 2, 1, False, 0, 28, 2, True),      # 28x28 maps: the weight gradient's operand rows do not fit LDS four rows at a time
 ]
 
 
