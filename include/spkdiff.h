@@ -488,9 +488,10 @@ int spk_conv3x3_wgrad_small(const float* gy_cl, const float* in_nchw, float* ws,
  *   form 1: out[n, o, co] = sum over the taps with (o + pad - k) % stride == 0 and c of in[n, (o + pad - k) / stride, c] *
  *           W(tap, c, co)  -- layer.ConvTranspose2d forward (layer.py:316-325), the data gradient of layer.Conv2d; sub-pixel
  *           classes are separate tile rows, structural zeros are not multiplied.
- * Matrix path: Cred % 8 == 0, Cred <= 64, 2 <= Cout <= 64, the class's weight taps within 150 KB of LDS; vector kernels for
- * Cred == 1 (form 0, Cout % 4 == 0) and Cout == 1 (Cred 8 / 16 / 32 / 64; form 1 only with stride 1).  spk_conv_train_gather_supported
- * answers 1 / 0; an unsupported call returns SPK_ERR_UNSUPPORTED (the host then takes the framework's operator). */
+ * Matrix path: Cred % 8 == 0, Cred <= 64, 2 <= Cout <= 64, stride <= 4 (form 1: <= 2), the k * k weight taps of one 32-channel column
+ * tile within 150 KB of LDS; vector kernels for Cred == 1 (form 0, Cout % 4 == 0) and Cout == 1 (Cred 8 / 16 / 32 / 64; form 1 only with
+ * stride 1).  N * Ho * Wo and N * Hi * Wi * Cred below 2^31.  spk_conv_train_gather_supported answers 1 / 0; an unsupported call returns
+ * SPK_ERR_UNSUPPORTED (the host then takes the framework's operator).  Deterministic; capturable in a hipGraph. */
 int spk_conv_train_gather_supported(int Cred, int Cout, int k, int stride, int form);
 int spk_conv_train_gather(const float* in_cl, const float* w, const float* bias_or_null, float* out_cl, int N, int Hi, int Wi,
                           int Cred, int Ho, int Wo, int Cout, int k, int stride, int pad, int form, long long w_tap,
