@@ -42,6 +42,9 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #ifndef CT_WGRAD_LDS
 #define CT_WGRAD_LDS 1                             // 0: the weight gradient always reads its operands from global memory (the first form)
 #endif
+#ifndef CT_WL_FUSE_BIAS
+#define CT_WL_FUSE_BIAS 1                          // LDS-staged weight gradient: bias column sums from the staged rows (0: a second pass over gy)
+#endif
 #ifndef CT_WL_PINGPONG
 #define CT_WL_PINGPONG 0                           // 1: LDS-staged weight gradient with the two halves of a workgroup alternating between their MFMA
 #endif                                             // phase and their request / LDS-write phase (one buffer per half, two barriers per block).  Built
@@ -841,7 +844,27 @@ __global__ __launch_bounds__(512) void conv_train_wgrad_lds_kernel(WArgs a, WLGe
   const int SR = (a.Wv + 1) >> 1;
   const int sCu = a.stride * a.Cu;
   __syncthreads();                                   // (the zero fill)
+  // bias gradient from the staged rows (every gy row passes through LDS exactly once: as a v row, or -- gy on the finer grid -- as
+  // the input rows ky in [pad, pad + s) of its coarse row): no second pass over gy in global memory (9 us of an 87 us launch)
+  const int Cb = a.bias_from == 1 ? a.Cv : a.Cu;
+  const bool fuse_bias = CT_WL_FUSE_BIAS && a.bias_from != 0 && (256 % Cb) == 0 &&
+                         (a.bias_from == 1 || (a.k >= a.pad + a.stride && a.Hu == a.stride * a.Hv));
+  float bsum = 0.f;
+  auto bias_rows = [&](const float* sv) {
+    if (a.bias_from == 1) {
+      const int n = g.RB * (a.Wv + 1) * a.Cv;
+      for (int e = th; e < n; e += 256) bsum += sv[e];
+    } else {
+      const int n = g.WP * a.Cu;
+      for (int r = 0; r < g.RB; ++r)
+        for (int ky = a.pad; ky < a.pad + a.stride; ++ky) {
+          const float* row = sv + g.svb + (r * a.k + ky) * n;
+          for (int e = th; e < n; e += 256) bsum += row[e];
+        }
+    }
+  };
   auto compute = [&](const float* sv) {
+    if (fuse_bias) bias_rows(sv);
     for (int r = 0; r < g.RB; ++r) {
       const int vo = r * (a.Wv + 1) * a.Cv + kk * a.Cv, uo = r * a.k * g.WP * a.Cu + kk * sCu;
       for (int s2 = 0; s2 < SR; ++s2) {
@@ -919,7 +942,16 @@ __global__ __launch_bounds__(512) void conv_train_wgrad_lds_kernel(WArgs a, WLGe
         for (int r = 0; r < 16; ++r) part[(long long)(wq + 4 * i) * 1024 + r * 64 + lane] = acc[i][r] + s_x[((wq * NTW + i) * 16 + r) * 64 + lane];
       }
   }
-  if (a.bias_from && !(CT_DBG & 32)) {
+  if (fuse_bias && !(CT_DBG & 32)) {
+    __syncthreads();
+    s_x[tid] = bsum;                                 // (tid & 255) % Cb is the thread's channel, in either half
+    __syncthreads();
+    if (tid < Cb) {
+      float tot = 0.f;
+      for (int q = tid; q < 512; q += Cb) tot += s_x[q];
+      part[(long long)ntile * 1024 + tid] = tot;
+    }
+  } else if (a.bias_from && !(CT_DBG & 32)) {
     __syncthreads();
     constexpr int NT = 512;
     const float* gq = a.bias_from == 1 ? a.v : a.u;
