@@ -1234,7 +1234,7 @@ extern "C" int spk_conv_train_gather(const float* in_cl, const float* w, const f
 namespace {
 int wgrad_kind(int Cu, int Cv, int k) {
   if (k < 1 || k * k > MAX_TAPS || Cu < 1 || Cv < 1) return 0;
-  if (Cu == 1) return (Cv % 4 == 0 && Cv <= 64 && 256 % (Cv / 4) == 0) ? 2 : 0;
+  if (Cu == 1) return (Cv % 4 == 0 && Cv <= 64 && 256 % (Cv / 4) == 0 && (256 / (Cv / 4)) * (k * k + 1) * Cv * 4 <= 64 * 1024) ? 2 : 0;
   if (Cu > 64 || Cv > 64) return 0;
   const int ntile = k * k * ((Cu + 31) / 32) * ((Cv + 31) / 32);
   return ntile <= 36 ? 1 : 0;

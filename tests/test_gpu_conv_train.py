@@ -172,3 +172,35 @@ def test_graphed_vqvae_training_step_equals_the_eager_loop(dev):
         _, xr, idx = m2(imgs[0].unsqueeze(0).repeat(16, 1, 1, 1, 1), imgs[0])
     functional.reset_net(m2)
     assert xr.shape == (8, 1, 28, 28) and bool(torch.isfinite(xr).all())
+
+
+def test_native_and_framework_convolutions_give_the_same_training_step(dev, ops):
+    """ops.NATIVE_TRAIN_CONV = False restores the framework's convolutions (rounds 3-4): one VQ-VAE training step either way -- same
+    losses to fp32 round-off, gradients within 1e-4 relative L2 (a neuron-step may flip between two fp32 summation orders)."""
+    from snn_model.vae_model import SNN_VQVAE, functional
+    from spkdiff import synth
+    img = (synth.stroke_images(4, 9) - 0.5).to(dev)
+    res = []
+    for native in (True, False):
+        keep = ops.NATIVE_TRAIN_CONV
+        ops.NATIVE_TRAIN_CONV = native
+        try:
+            m = SNN_VQVAE(1, 16, 128, 0.08).to(dev)
+            functional.set_step_mode(net=m, step_mode='m')
+            m.load_state_dict(synth.synth_vqvae_state(synth.MNIST))
+            m.train()
+            a, b, c = m(img.unsqueeze(0).repeat(16, 1, 1, 1, 1), img)
+            (a + b).backward()
+            res.append(((float(a.detach()), float(b.detach()), float(c.detach())),
+                        {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
+            functional.reset_net(m)
+        finally:
+            ops.NATIVE_TRAIN_CONV = keep
+    (l1, g1), (l2, g2) = res
+    assert all(abs(x - y) <= 1e-3 * (1 + abs(y)) for x, y in zip(l1, l2)), (l1, l2)
+    assert set(g1) == set(g2)
+    for k in g1:
+        if float(g2[k].norm()) > 1e-4:
+            assert _rel_l2(g1[k].cpu(), g2[k].cpu()) <= 2e-2, (k, _rel_l2(g1[k].cpu(), g2[k].cpu()))
+        else:                                   # (a convolution bias in front of a batch-statistics BN: round-off on either side)
+            assert float((g1[k] - g2[k]).abs().max()) <= 5e-5, k
