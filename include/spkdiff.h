@@ -489,8 +489,8 @@ int spk_conv3x3_wgrad_small(const float* gy_cl, const float* in_nchw, float* ws,
  *           W(tap, c, co)  -- layer.ConvTranspose2d forward (layer.py:316-325), the data gradient of layer.Conv2d; sub-pixel
  *           classes are separate tile rows, structural zeros are not multiplied.
  * Matrix path: Cred % 8 == 0, Cred <= 64, 2 <= Cout <= 64, stride <= 4 (form 1: <= 2), the k * k weight taps of one 32-channel column
- * tile within 150 KB of LDS; vector kernels for Cred == 1 (form 0, Cout % 4 == 0) and Cout == 1 (Cred 8 / 16 / 32 / 64; form 1 only with
- * stride 1).  N * Ho * Wo and N * Hi * Wi * Cred below 2^31.  spk_conv_train_gather_supported answers 1 / 0; an unsupported call returns
+ * tile within 150 KB of LDS; vector kernels for Cred <= 4 (form 0, Cout % 4 == 0: the first layer on grey or RGB images, the read-out
+ * layer's data gradient) and Cout <= 4 (Cred 8 / 16 / 32 / 64; form 1 only with stride 1: the read-out layer).  N * Ho * Wo and N * Hi * Wi * Cred below 2^31.  spk_conv_train_gather_supported answers 1 / 0; an unsupported call returns
  * SPK_ERR_UNSUPPORTED (the host then takes the framework's operator).  Deterministic; capturable in a hipGraph. */
 int spk_conv_train_gather_supported(int Cred, int Cout, int k, int stride, int form);
 int spk_conv_train_gather(const float* in_cl, const float* w, const float* bias_or_null, float* out_cl, int N, int Hi, int Wi,
@@ -500,8 +500,8 @@ int spk_conv_train_gather(const float* in_cl, const float* w, const float* bias_
  * written to gw_out[tap * g_tap + cu * g_u + cv * g_v].  layer.Conv2d: u = the layer's input, v = gy; layer.ConvTranspose2d:
  * u = gy, v = the layer's input (u is the tensor on the finer grid).  bias_from: 0 none, 1: gb_out[cv] = column sums of v, 2:
  * gb_out[cu] = column sums of u.  Every workgroup owns a range of positions; a second launch adds the partial tiles in index order
- * (deterministic).  2 <= Cu, Cv <= 64 (k * k * ceil(Cu / 32) * ceil(Cv / 32) <= 36 tiles), or Cu == 1 with Cv % 4 == 0
- * (vector kernel).  ws: spk_conv_train_wgrad_ws_bytes(...) bytes (-1: unsupported shape). */
+ * (deterministic).  5 <= Cu <= 64, Cv <= 64 (k * k * ceil(Cu / 32) * ceil(Cv / 32) <= 36 tiles), or Cu <= 4 with Cv in {4, 8, 16, 32, 64}
+ * (vector kernel; k <= 3 unless Cu == 1).  ws: spk_conv_train_wgrad_ws_bytes(...) bytes (-1: unsupported shape). */
 long long spk_conv_train_wgrad_ws_bytes(int N, int Hv, int Wv, int Cu, int Cv, int k);
 int spk_conv_train_wgrad(const float* u_cl, const float* v_cl, float* ws, long long ws_bytes, float* gw_out, float* gb_out_or_null,
                          int N, int Hu, int Wu, int Cu, int Hv, int Wv, int Cv, int k, int stride, int pad, long long g_tap,

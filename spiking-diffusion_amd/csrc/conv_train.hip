@@ -469,24 +469,26 @@ __global__ __launch_bounds__(512) void conv_train_gather_sub_kernel(GArgs a, Sub
   }
 }
 
-// ---- one output channel (the 32 -> 1 read-out layer): LP = Cred / 4 lanes per output position, 16 bytes per lane and tap ----
+// ---- one to four output channels (the 32 -> 1 read-out layer; 32 -> 3 on RGB): LP = Cred / 4 lanes per output position ----
 // (The two one-channel gather kernels walk ROWS of the output grid -- the row's image and y are wave-uniform, a thread's x and channel
 //  quad come from its index by a shift or one small division -- and read every tap UNCONDITIONALLY from a clamped address, with a
 //  select: a load under a per-lane condition makes hipcc branch around it and wait for it alone, k * k round trips one after the
 //  other.  Measured, kernel time under rocprofv3: the read-out forward 34.9 -> 29.6 us, the one-reduced-channel form unchanged.)
-template <int LP>
+template <int LP, int CO>
 __global__ __launch_bounds__(256) void conv_train_c1out_kernel(GArgs a) {
-  __shared__ float4 sW[MAX_TAPS * LP];
+  __shared__ float4 sW[MAX_TAPS * CO * LP];        // [tap][co][Cred / 4]
   const int tid = threadIdx.x;
   const int nt = a.k * a.k;
-  for (int e = tid; e < nt * LP * 4; e += 256) {
-    const int c = e % (LP * 4), t = e / (LP * 4);
-    reinterpret_cast<float*>(sW)[e] = a.w[t * a.w_tap + c * a.w_red];
+  for (int e = tid; e < nt * CO * LP * 4; e += 256) {
+    const int c = e % (LP * 4), r = e / (LP * 4), co = r % CO, t = r / CO;
+    reinterpret_cast<float*>(sW)[e] = a.w[t * a.w_tap + c * a.w_red + co * a.w_out];
   }
   __syncthreads();
   constexpr int PER = 256 / LP;                     // positions of a row per pass
   const int cq = tid % LP, xl = tid / LP;
-  const float b0 = a.bias ? a.bias[0] : 0.f;
+  float b0[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) b0[co] = a.bias ? a.bias[co] : 0.f;
   const int sgn = a.form ? -1 : 1, ai = a.form ? 1 : a.stride;
   const int rows = a.N * a.Ho;
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
@@ -495,7 +497,9 @@ __global__ __launch_bounds__(256) void conv_train_c1out_kernel(GArgs a) {
     for (int x0 = 0; x0 < a.Wo; x0 += PER) {        // (every lane of a position group takes part in the exchange below)
       const int ox = x0 + xl;
       const bool pv = ox < a.Wo;
-      float acc = 0.f;
+      float acc[CO];
+#pragma unroll
+      for (int co = 0; co < CO; ++co) acc[co] = 0.f;
       for (int ky = 0; ky < a.k; ++ky) {
         const int iy = oy * ai + sgn * (ky - a.pad);
         const bool yok = iy >= 0 && iy < a.Hi;     // (uniform)
@@ -506,29 +510,40 @@ __global__ __launch_bounds__(256) void conv_train_c1out_kernel(GArgs a) {
           const bool ok = pv && yok && ix >= 0 && ix < a.Wi;
           const int ixc = ok ? ix : 0;
           const float4 ld = *reinterpret_cast<const float4*>(inb + ((long long)iyc * a.Wi + ixc) * (LP * 4));
-          const float4 w = sW[(ky * a.k + kx) * LP + cq];
           const float4 x = ok ? ld : make_float4(0.f, 0.f, 0.f, 0.f);
-          acc = fmaf(x.x, w.x, acc); acc = fmaf(x.y, w.y, acc); acc = fmaf(x.z, w.z, acc); acc = fmaf(x.w, w.w, acc);
+#pragma unroll
+          for (int co = 0; co < CO; ++co) {
+            const float4 w = sW[((ky * a.k + kx) * CO + co) * LP + cq];
+            acc[co] = fmaf(x.x, w.x, acc[co]); acc[co] = fmaf(x.y, w.y, acc[co]);
+            acc[co] = fmaf(x.z, w.z, acc[co]); acc[co] = fmaf(x.w, w.w, acc[co]);
+          }
         }
       }
 #pragma unroll
-      for (int m = LP / 2; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
-      if (pv && cq == 0) a.out[(long long)row * a.Wo + ox] = acc + b0;
+      for (int co = 0; co < CO; ++co) {
+#pragma unroll
+        for (int m = LP / 2; m >= 1; m >>= 1) acc[co] += __shfl_xor(acc[co], m);
+        if (pv && cq == 0) a.out[((long long)row * a.Wo + ox) * CO + co] = acc[co] + b0[co];
+      }
     }
   }
 }
 
-// ---- one reduced channel (the 1 -> 32 first layer forward, the read-out layer's data gradient): regular form ----
+// ---- one to four reduced channels (the 1 -> 32 / 3 -> 32 first layer forward, the read-out layer's data gradient): regular form ----
+template <int CR>
 __global__ __launch_bounds__(256) void conv_train_c1in_kernel(GArgs a) {
-  extern __shared__ float sW1[];                    // [tap][Cout]
+  extern __shared__ float sW1[];                    // [tap][ci][Cout]
   const int tid = threadIdx.x, C = a.Cout, CQ = C >> 2;
   const int nt = a.k * a.k;
-  for (int e = tid; e < nt * C; e += 256) sW1[e] = a.w[(e / C) * a.w_tap + (e % C) * a.w_out];
+  for (int e = tid; e < nt * CR * C; e += 256) {
+    const int c = e % C, r = e / C, ci = r % CR, t = r / CR;
+    sW1[e] = a.w[t * a.w_tap + ci * a.w_red + c * a.w_out];
+  }
   __syncthreads();
   const int rows = a.N * a.Ho, per_row = a.Wo * CQ;
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const int n = row / a.Ho, oy = row - n * a.Ho;  // (wave-uniform)
-    const float* inb = a.in + (long long)n * a.Hi * a.Wi;
+    const float* inb = a.in + (long long)n * a.Hi * a.Wi * CR;
     for (int idx = tid; idx < per_row; idx += 256) {
       const int ox = idx / CQ, cq = idx - ox * CQ;
       float4 acc = a.bias ? *reinterpret_cast<const float4*>(a.bias + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -540,10 +555,14 @@ __global__ __launch_bounds__(256) void conv_train_c1in_kernel(GArgs a) {
         for (int kx = 0; kx < a.k; ++kx) {
           const int ix = ox * a.stride + kx - a.pad;
           const bool ok = yok && ix >= 0 && ix < a.Wi;
-          const float ld = inb[iyc * a.Wi + (ok ? ix : 0)];
-          const float x = ok ? ld : 0.f;
-          const float4 w = *reinterpret_cast<const float4*>(sW1 + (ky * a.k + kx) * C + 4 * cq);
-          acc.x = fmaf(x, w.x, acc.x); acc.y = fmaf(x, w.y, acc.y); acc.z = fmaf(x, w.z, acc.z); acc.w = fmaf(x, w.w, acc.w);
+          const float* ip = inb + (iyc * a.Wi + (ok ? ix : 0)) * CR;
+#pragma unroll
+          for (int ci = 0; ci < CR; ++ci) {
+            const float ld = ip[ci];
+            const float x = ok ? ld : 0.f;
+            const float4 w = *reinterpret_cast<const float4*>(sW1 + ((ky * a.k + kx) * CR + ci) * C + 4 * cq);
+            acc.x = fmaf(x, w.x, acc.x); acc.y = fmaf(x, w.y, acc.y); acc.z = fmaf(x, w.z, acc.z); acc.w = fmaf(x, w.w, acc.w);
+          }
         }
       }
       *reinterpret_cast<float4*>(a.out + ((long long)row * a.Wo + ox) * C + 4 * cq) = acc;
@@ -1001,7 +1020,7 @@ __global__ __launch_bounds__(256) void conv_train_wgrad_reduce_kernel(WArgs a) {
   __shared__ float s_q[256];
   const int CUT = (a.Cu + 31) >> 5, CVT = (a.Cv + 31) >> 5;
   const int nt = a.k * a.k;
-  const int E = MODE == 0 ? nt * a.Cu * a.Cv : nt * a.Cv;
+  const int E = nt * a.Cu * a.Cv;
   const int CB = a.bias_from == 0 ? 0 : (a.bias_from == 1 ? a.Cv : a.Cu);
   const int el = threadIdx.x % EPB, q = threadIdx.x / EPB;
   const int e = blockIdx.x * EPB + el;
@@ -1015,9 +1034,9 @@ __global__ __launch_bounds__(256) void conv_train_wgrad_reduce_kernel(WArgs a) {
       src = (long long)ti * 1024 + ((row >> 3) * 4 + (row & 3)) * 64 + col + 32 * ((row >> 2) & 1);
       dst = a.gw + tap * a.g_tap + cu * a.g_u + cv * a.g_v;
     } else {
-      const int cv = e % a.Cv, tap = e / a.Cv;
+      const int cv = e % a.Cv, r2 = e / a.Cv, cu = r2 % a.Cu, tap = r2 / a.Cu;
       src = e;
-      dst = a.gw + tap * a.g_tap + cv * a.g_v;
+      dst = a.gw + tap * a.g_tap + cu * a.g_u + cv * a.g_v;
     }
   } else if (e < E + CB) {
     src = (MODE == 0 ? (long long)nt * CUT * CVT * 1024 : (long long)E) + (e - E);
@@ -1043,12 +1062,14 @@ __global__ __launch_bounds__(256) void conv_train_wgrad_reduce_kernel(WArgs a) {
   }
 }
 
-// one-channel U (the first layer's input, the read-out layer's gy): D[tap][cv] = sum over (n, q) of u[n, q * s - pad + k] * V[n, q][cv]
+// one to four channels in U (the first layer's input, the read-out layer's gy): D[tap][cu][cv] = sum over (n, q) of
+// u[n, q * s - pad + k][cu] * V[n, q][cv].  NTM = the largest tap count the instantiation holds accumulators for.
+template <int CU, int NTM>
 __global__ __launch_bounds__(256) void conv_train_c1_wgrad_kernel(WArgs a) {
-  extern __shared__ float s_acc[];                  // [256 / CQ][(nt + 1) * Cv]
-  const int tid = threadIdx.x, C = a.Cv, CQ = C >> 2, RL = 256 / CQ;
+  extern __shared__ float s_acc[];                  // [4 waves][(nt * CU + 1) * Cv]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, C = a.Cv, CQ = C >> 2, RL = 256 / CQ;
   const int nt = a.k * a.k;
-  const int cq = tid % CQ, rl = tid / CQ;
+  const int cq = tid % CQ, rl = tid / CQ;           // (CQ is a power of two <= 16: lanes l, l + CQ, ... of a wave share a channel quad)
   // (positions, not rows, are dealt to the threads: a row-wise walk leaves 256 / (Cv / 4) - Wv thread rows idle -- measured 60 against
   //  41 us per launch on the two layers that use this kernel)
   const long long Ms = (long long)a.N * a.Hv * a.Wv;
@@ -1056,10 +1077,13 @@ __global__ __launch_bounds__(256) void conv_train_c1_wgrad_kernel(WArgs a) {
   const long long p0 = (long long)blockIdx.x * per;
   long long p1 = p0 + per;
   p1 = p1 < Ms ? p1 : Ms;
-  float4 acc[MAX_TAPS];
+  float4 acc[NTM * CU];
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-  float usum = 0.f;
-  for (int t = 0; t < MAX_TAPS; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float usum[CU];
+#pragma unroll
+  for (int i = 0; i < CU; ++i) usum[i] = 0.f;
+#pragma unroll
+  for (int t = 0; t < NTM * CU; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (long long p = p0 + rl; p < p1; p += RL) {
     const int qx = (int)(p % a.Wv);
     const long long t2 = p / a.Wv;
@@ -1067,54 +1091,71 @@ __global__ __launch_bounds__(256) void conv_train_c1_wgrad_kernel(WArgs a) {
     const float4 g = *reinterpret_cast<const float4*>(a.v + p * C + 4 * cq);
     bsum.x += g.x; bsum.y += g.y; bsum.z += g.z; bsum.w += g.w;
 #pragma unroll
-    for (int t = 0; t < MAX_TAPS; ++t) {
+    for (int t = 0; t < NTM; ++t) {
       if (t < nt) {
         const int iy = qy * a.stride - a.pad + t / a.k, ix = qx * a.stride - a.pad + t % a.k;
         const bool ok = iy >= 0 && iy < a.Hu && ix >= 0 && ix < a.Wu;
-        const float x = ok ? a.u[((long long)n * a.Hu + iy) * a.Wu + ix] : 0.f;
-        acc[t].x = fmaf(x, g.x, acc[t].x); acc[t].y = fmaf(x, g.y, acc[t].y);
-        acc[t].z = fmaf(x, g.z, acc[t].z); acc[t].w = fmaf(x, g.w, acc[t].w);
+        const float* up = a.u + (((long long)n * a.Hu + (ok ? iy : 0)) * a.Wu + (ok ? ix : 0)) * CU;
+#pragma unroll
+        for (int cu = 0; cu < CU; ++cu) {
+          const float ld = up[cu];
+          const float x = ok ? ld : 0.f;
+          float4& d = acc[t * CU + cu];
+          d.x = fmaf(x, g.x, d.x); d.y = fmaf(x, g.y, d.y); d.z = fmaf(x, g.z, d.z); d.w = fmaf(x, g.w, d.w);
+        }
       }
     }
   }
-  if (a.bias_from == 2) {                           // column sum of the one-channel tensor: its own slice, one thread row
+  if (a.bias_from == 2) {                           // column sums of the few-channel tensor: its own slice
     const long long Mu = (long long)a.N * a.Hu * a.Wu;
     const long long peru = (Mu + a.nwg - 1) / a.nwg;
     const long long u0 = (long long)blockIdx.x * peru;
     long long u1 = u0 + peru;
     u1 = u1 < Mu ? u1 : Mu;
-    for (long long q = u0 + tid; q < u1; q += 256) usum += a.u[q];
-  }
-  // workgroup reduction in a fixed order
-  const int W = (nt + 1) * C;
+    for (long long q = u0 + tid; q < u1; q += 256) {
 #pragma unroll
-  for (int t = 0; t < MAX_TAPS; ++t)
-    if (t < nt) *reinterpret_cast<float4*>(s_acc + rl * W + t * C + 4 * cq) = acc[t];
-  *reinterpret_cast<float4*>(s_acc + rl * W + nt * C + 4 * cq) = bsum;
+      for (int cu = 0; cu < CU; ++cu) usum[cu] += a.u[q * CU + cu];
+    }
+  }
+  // workgroup reduction in a fixed order: lanes of a wave that share a channel quad by exchanges, the four waves through LDS
+  const int W = (nt * CU + 1) * C;
+  auto wave_sum4 = [&](float4& v) {
+    for (int m = CQ; m < 64; m <<= 1) {
+      v.x += __shfl_xor(v.x, m); v.y += __shfl_xor(v.y, m); v.z += __shfl_xor(v.z, m); v.w += __shfl_xor(v.w, m);
+    }
+  };
+#pragma unroll
+  for (int t = 0; t < NTM * CU; ++t)
+    if (t < nt * CU) {
+      wave_sum4(acc[t]);
+      if (lane < CQ) *reinterpret_cast<float4*>(s_acc + wave * W + t * C + 4 * cq) = acc[t];
+    }
+  wave_sum4(bsum);
+  if (lane < CQ) *reinterpret_cast<float4*>(s_acc + wave * W + nt * CU * C + 4 * cq) = bsum;
   __syncthreads();
   float* part = a.part + (long long)blockIdx.x * a.psize;
   for (int e = tid; e < W; e += 256) {
-    float s = 0.f;
-    for (int q = 0; q < RL; ++q) s += s_acc[q * W + e];
-    if (e < nt * C) part[e] = s;
+    const float s = ((s_acc[e] + s_acc[W + e]) + s_acc[2 * W + e]) + s_acc[3 * W + e];
+    if (e < nt * CU * C) part[e] = s;
     else if (a.bias_from == 1) part[e] = s;
   }
   if (a.bias_from == 2) {
     __syncthreads();
-    s_acc[tid] = usum;
+#pragma unroll
+    for (int cu = 0; cu < CU; ++cu) s_acc[cu * 256 + tid] = usum[cu];
     __syncthreads();
-    if (tid == 0) {
+    if (tid < CU) {
       float s = 0.f;
-      for (int q = 0; q < 256; ++q) s += s_acc[q];
-      part[nt * C] = s;
+      for (int q = 0; q < 256; ++q) s += s_acc[tid * 256 + q];
+      part[nt * CU * C + tid] = s;
     }
   }
 }
 
 int gather_kind(int Cred, int Cout, int k, int stride, int form) {
   if (k < 1 || k * k > MAX_TAPS || stride < 1 || Cred < 1 || Cout < 1) return 0;
-  if (Cred == 1) return (!form && (Cout % 4) == 0 && k * k * Cout * 4 <= 64 * 1024) ? 3 : 0;
-  if (Cout == 1) {
+  if (Cred <= 4) return (!form && (Cout % 4) == 0 && k * k * Cred * Cout * 4 <= 64 * 1024) ? 3 : 0;
+  if (Cout <= 4) {
     if (form && stride != 1) return 0;
     return (Cred == 8 || Cred == 16 || Cred == 32 || Cred == 64) ? 2 : 0;
   }
@@ -1158,14 +1199,24 @@ extern "C" int spk_conv_train_gather(const float* in_cl, const float* w, const f
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (kind == 3) {
     const int rows = N * Ho;
-    hipLaunchKernelGGL(conv_train_c1in_kernel, dim3(rows < 8192 ? rows : 8192), dim3(256), (size_t)k * k * Cout * 4, s, a);
+    const dim3 gr(rows < 8192 ? rows : 8192);
+    const size_t ldsw = (size_t)k * k * Cred * Cout * 4;
+    if (Cred == 1) hipLaunchKernelGGL(conv_train_c1in_kernel<1>, gr, dim3(256), ldsw, s, a);
+    else if (Cred == 2) hipLaunchKernelGGL(conv_train_c1in_kernel<2>, gr, dim3(256), ldsw, s, a);
+    else if (Cred == 3) hipLaunchKernelGGL(conv_train_c1in_kernel<3>, gr, dim3(256), ldsw, s, a);
+    else hipLaunchKernelGGL(conv_train_c1in_kernel<4>, gr, dim3(256), ldsw, s, a);
   } else if (kind == 2) {
     const int LP = Cred / 4;
     const int blocks = N * Ho < 8192 ? N * Ho : 8192;
-    if (LP == 2) hipLaunchKernelGGL(conv_train_c1out_kernel<2>, dim3(blocks), dim3(256), 0, s, a);
-    else if (LP == 4) hipLaunchKernelGGL(conv_train_c1out_kernel<4>, dim3(blocks), dim3(256), 0, s, a);
-    else if (LP == 8) hipLaunchKernelGGL(conv_train_c1out_kernel<8>, dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(conv_train_c1out_kernel<16>, dim3(blocks), dim3(256), 0, s, a);
+#define SPK_C1OUT(LP_)                                                                                                 \
+  do {                                                                                                                 \
+    if (Cout == 1) hipLaunchKernelGGL((conv_train_c1out_kernel<LP_, 1>), dim3(blocks), dim3(256), 0, s, a);            \
+    else if (Cout == 2) hipLaunchKernelGGL((conv_train_c1out_kernel<LP_, 2>), dim3(blocks), dim3(256), 0, s, a);       \
+    else if (Cout == 3) hipLaunchKernelGGL((conv_train_c1out_kernel<LP_, 3>), dim3(blocks), dim3(256), 0, s, a);       \
+    else hipLaunchKernelGGL((conv_train_c1out_kernel<LP_, 4>), dim3(blocks), dim3(256), 0, s, a);                      \
+  } while (0)
+    if (LP == 2) SPK_C1OUT(2); else if (LP == 4) SPK_C1OUT(4); else if (LP == 8) SPK_C1OUT(8); else SPK_C1OUT(16);
+#undef SPK_C1OUT
   } else {
     const int cs = form ? stride : 1;
     if (cs * cs > MAX_CLASSES) return SPK_ERR_UNSUPPORTED;
@@ -1234,7 +1285,11 @@ extern "C" int spk_conv_train_gather(const float* in_cl, const float* w, const f
 namespace {
 int wgrad_kind(int Cu, int Cv, int k) {
   if (k < 1 || k * k > MAX_TAPS || Cu < 1 || Cv < 1) return 0;
-  if (Cu == 1) return (Cv % 4 == 0 && Cv <= 64 && 256 % (Cv / 4) == 0 && (256 / (Cv / 4)) * (k * k + 1) * Cv * 4 <= 64 * 1024) ? 2 : 0;
+  if (Cu <= 4) {
+    const int CQ = Cv / 4;
+    const bool cq_ok = Cv % 4 == 0 && (CQ == 1 || CQ == 2 || CQ == 4 || CQ == 8 || CQ == 16);
+    return (cq_ok && (Cu == 1 || k <= 3) && 4 * (k * k * Cu + 1) * Cv * 4 <= 64 * 1024) ? 2 : 0;
+  }
   if (Cu > 64 || Cv > 64) return 0;
   const int ntile = k * k * ((Cu + 31) / 32) * ((Cv + 31) / 32);
   return ntile <= 36 ? 1 : 0;
@@ -1246,7 +1301,7 @@ int wgrad_nwg(int kind, long long Ms) {
 }
 int wgrad_psize(int kind, int Cu, int Cv, int k) {
   if (kind == 1) return k * k * ((Cu + 31) / 32) * ((Cv + 31) / 32) * 1024 + 64;
-  return (k * k + 1) * Cv + 4;
+  return (k * k * Cu + 1) * Cv + 8;
 }
 }  // namespace
 
@@ -1348,13 +1403,16 @@ extern "C" int spk_conv_train_wgrad(const float* u_cl, const float* v_cl, float*
     const int E = k * k * Cu * Cv + CB;
     hipLaunchKernelGGL(conv_train_wgrad_reduce_kernel<0>, dim3((E + 31) / 32), dim3(256), 0, s, a);
   } else {
-    const int RL = 256 / (Cv / 4);
-    const size_t lds = (size_t)RL * (k * k + 1) * Cv * 4;
+    size_t lds = (size_t)4 * (k * k * Cu + 1) * Cv * 4;
     if (lds > 64 * 1024) return SPK_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(conv_train_c1_wgrad_kernel, dim3(a.nwg), dim3(256), lds < 1024 ? 1024 : lds, s, a);
+    lds = lds < (size_t)Cu * 1024 ? (size_t)Cu * 1024 : lds;
+    if (Cu == 1) hipLaunchKernelGGL((conv_train_c1_wgrad_kernel<1, MAX_TAPS>), dim3(a.nwg), dim3(256), lds, s, a);
+    else if (Cu == 2) hipLaunchKernelGGL((conv_train_c1_wgrad_kernel<2, 9>), dim3(a.nwg), dim3(256), lds, s, a);
+    else if (Cu == 3) hipLaunchKernelGGL((conv_train_c1_wgrad_kernel<3, 9>), dim3(a.nwg), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_train_c1_wgrad_kernel<4, 9>), dim3(a.nwg), dim3(256), lds, s, a);
     SPK_LAUNCH_CHECK();
-    const int CB = bias_from == 0 ? 0 : (bias_from == 1 ? Cv : 1);
-    const int E = k * k * Cv + CB;
+    const int CB = bias_from == 0 ? 0 : (bias_from == 1 ? Cv : Cu);
+    const int E = k * k * Cu * Cv + CB;
     hipLaunchKernelGGL(conv_train_wgrad_reduce_kernel<1>, dim3((E + 7) / 8), dim3(256), 0, s, a);
   }
   SPK_LAUNCH_CHECK();

@@ -46,6 +46,9 @@ ODD_SHAPES = [
     (16, 16, 3, 2, 1, True, 0, 5, 3, False),       # 9x9 output of a 5x5 input: the odd sub-pixel classes are one row / column short
     (8, 8, 1, 2, 0, False, 0, 6, 2, False),        # 1x1 / stride 2: three of the four classes of its data gradient have no tap (zeros)
     (32, 32, 3, 2, 1, False, 0, 28, 2, True),      # 28x28 maps: the weight gradient's operand rows do not fit LDS four rows at a time
+    (3, 32, 3, 2, 1, False, 0, 16, 4, False),      # the first layer on RGB (CIFAR-shaped model): three reduced channels, vector kernels
+    (32, 3, 3, 1, 1, True, 0, 16, 4, True),        # the read-out layer on RGB: three output channels
+    (2, 16, 3, 1, 1, False, 0, 7, 5, False),       # two reduced channels at stride 1 (the denoiser's first layer shape)
 ]
 
 
@@ -63,7 +66,7 @@ def test_native_conv_train_forward_and_backward_vs_fp64_autograd(dev, ops, cfg, 
     gy = torch.randn(yo.shape, generator=g)
     (yo * gy.double()).sum().backward()
 
-    need_gi = not (cin == 1 and st > 1)            # (the first layer's image input takes no gradient)
+    need_gi = not (cin <= 4 and st > 1)            # (the first layer's image input takes no gradient)
     assert ops.conv_train_supported(x.shape, w.to(dev), st, pd, tr, op, need_gi, forward=True), "shape not taken by the native kernels"
     xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(need_gi)
     wd = w.to(dev)
@@ -124,13 +127,14 @@ def test_exact_forward_with_native_backward(dev, ops):
 
 
 def test_unsupported_shapes_fall_back_to_the_framework(dev, ops):
-    """Three input channels (CIFAR's first layer), 128 output channels, dilation: not taken -- the modules then call the framework's
-    operator and training still runs."""
+    """Five input channels, 128 output channels: not taken -- the modules then call the framework's operator and training still runs.
+    (Three input channels -- CIFAR's first layer -- ARE taken: the few-channel vector kernels.)"""
     from spikingjelly.activation_based import layer
-    assert not ops.conv_train_supported((4, 3, 32, 32), torch.empty(32, 3, 3, 3, device=dev), 2, 1, False, 0, False, forward=True)
+    assert ops.conv_train_supported((4, 3, 32, 32), torch.empty(32, 3, 3, 3, device=dev), 2, 1, False, 0, False, forward=True)
+    assert not ops.conv_train_supported((4, 5, 32, 32), torch.empty(32, 5, 3, 3, device=dev), 2, 1, False, 0, False, forward=True)
     assert not ops.conv_train_supported((4, 64, 8, 8), torch.empty(128, 64, 3, 3, device=dev), 1, 1, False, 0, True, forward=True)
-    m = layer.Conv2d(3, 32, 3, 2, 1, step_mode='m').to(dev).train()
-    x = torch.randn(2, 4, 3, 32, 32, device=dev)
+    m = layer.Conv2d(5, 32, 3, 2, 1, step_mode='m').to(dev).train()
+    x = torch.randn(2, 4, 5, 32, 32, device=dev)
     y = m(x)
     y.sum().backward()
     assert tuple(y.shape) == (2, 4, 32, 16, 16) and m.weight.grad is not None

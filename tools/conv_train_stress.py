@@ -29,8 +29,8 @@ while done < ncase:
     st = ri(1, 2) if tr else ri(1, 3)
     pd = ri(0, min(2, k - 1)) if k > 1 else 0
     op = ri(0, st - 1) if tr else 0
-    cin = [1, 8, 16, 24, 32, 40, 48, 64][ri(0, 7)]
-    cout = [1, 4, 8, 16, 20, 32, 33, 48, 64][ri(0, 8)]
+    cin = [1, 2, 3, 4, 8, 16, 24, 32, 40, 48, 64][ri(0, 10)]
+    cout = [1, 2, 3, 4, 8, 16, 20, 32, 33, 48, 64][ri(0, 10)]
     H, W, N = ri(max(k, 2), 17), ri(max(k, 2), 17), ri(1, 9)
     wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
     w = torch.randn(*wshape, generator=g) * 0.2
@@ -72,8 +72,8 @@ while done < ncase:
         errs["gb"] = rel(bd.grad.cpu(), bo.grad)
     for kk, v in errs.items():
         worst[kk] = max(worst[kk], v)
-        assert v <= 5e-6, (tag, kk, v)
+        assert v <= (3e-5 if kk == "gb" else 5e-6), (tag, kk, v)    # (gb: an fp32 sum of random signs against its own small total)
     kinds[("T" if tr else "C") + ("1in" if cin == 1 else "1out" if cout == 1 else "mm")] = kinds.get(("T" if tr else "C") + ("1in" if cin == 1 else "1out" if cout == 1 else "mm"), 0) + 1
     done += 1
-print(f"conv_train_stress: {done} random cases within 5e-6 of fp64 (worst relative L2: {worst}); {skipped} drawn shapes not taken by the native "
+print(f"conv_train_stress: {done} random cases within 5e-6 of fp64 (bias gradient 3e-5) (worst relative L2: {worst}); {skipped} drawn shapes not taken by the native "
       f"kernels (framework's operator); by kind {kinds}")
