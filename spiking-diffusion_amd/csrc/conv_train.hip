@@ -1084,18 +1084,24 @@ __global__ __launch_bounds__(256) void conv_train_c1_wgrad_kernel(WArgs a) {
   for (int i = 0; i < CU; ++i) usum[i] = 0.f;
 #pragma unroll
   for (int t = 0; t < NTM * CU; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // (the position's (n, qy, qx) is decoded once and then stepped: two 64-bit divisions per trip were a third of this loop)
+  int qx, qy, n;
+  {
+    const long long pf = p0 + rl;
+    qx = (int)(pf % a.Wv);
+    const long long t2 = pf / a.Wv;
+    qy = (int)(t2 % a.Hv); n = (int)(t2 / a.Hv);
+  }
   for (long long p = p0 + rl; p < p1; p += RL) {
-    const int qx = (int)(p % a.Wv);
-    const long long t2 = p / a.Wv;
-    const int qy = (int)(t2 % a.Hv), n = (int)(t2 / a.Hv);
     const float4 g = *reinterpret_cast<const float4*>(a.v + p * C + 4 * cq);
     bsum.x += g.x; bsum.y += g.y; bsum.z += g.z; bsum.w += g.w;
+    const float* un = a.u + (long long)n * a.Hu * a.Wu * CU;
 #pragma unroll
     for (int t = 0; t < NTM; ++t) {
       if (t < nt) {
         const int iy = qy * a.stride - a.pad + t / a.k, ix = qx * a.stride - a.pad + t % a.k;
         const bool ok = iy >= 0 && iy < a.Hu && ix >= 0 && ix < a.Wu;
-        const float* up = a.u + (((long long)n * a.Hu + (ok ? iy : 0)) * a.Wu + (ok ? ix : 0)) * CU;
+        const float* up = un + ((ok ? iy : 0) * a.Wu + (ok ? ix : 0)) * CU;
 #pragma unroll
         for (int cu = 0; cu < CU; ++cu) {
           const float ld = up[cu];
@@ -1104,6 +1110,11 @@ __global__ __launch_bounds__(256) void conv_train_c1_wgrad_kernel(WArgs a) {
           d.x = fmaf(x, g.x, d.x); d.y = fmaf(x, g.y, d.y); d.z = fmaf(x, g.z, d.z); d.w = fmaf(x, g.w, d.w);
         }
       }
+    }
+    qx += RL;
+    while (qx >= a.Wv) {
+      qx -= a.Wv;
+      if (++qy >= a.Hv) { qy = 0; ++n; }
     }
   }
   if (a.bias_from == 2) {                           // column sums of the few-channel tensor: its own slice
