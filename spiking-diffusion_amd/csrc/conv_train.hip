@@ -42,6 +42,9 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #ifndef CT_WGRAD_LDS
 #define CT_WGRAD_LDS 1                             // 0: the weight gradient always reads its operands from global memory (the first form)
 #endif
+#ifndef CT_C1W_CAP
+#define CT_C1W_CAP 1024                            // workgroups of the few-channel weight gradient (at most)
+#endif
 #ifndef CT_WL_FUSE_BIAS
 #define CT_WL_FUSE_BIAS 1                          // LDS-staged weight gradient: bias column sums from the staged rows (0: a second pass over gy)
 #endif
@@ -1307,7 +1310,7 @@ int wgrad_kind(int Cu, int Cv, int k) {
 }
 int wgrad_nwg(int kind, long long Ms) {
   long long n = kind == 1 ? (Ms + 63) / 64 : (Ms + 255) / 256;      // at least 64 / 256 positions per workgroup
-  const int cap = kind == 1 ? 256 : 2048;                           // (vector kernel: tiny partials, latency-bound position loop)
+  const int cap = kind == 1 ? 256 : CT_C1W_CAP;                     // (vector kernel: tiny partials, latency-bound position loop)
   return (int)(n < 1 ? 1 : (n < cap ? n : cap));
 }
 int wgrad_psize(int kind, int Cu, int Cv, int k) {
