@@ -42,6 +42,9 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #ifndef CT_WGRAD_LDS
 #define CT_WGRAD_LDS 1                             // 0: the weight gradient always reads its operands from global memory (the first form)
 #endif
+#ifndef CT_C1_ROWS_CAP
+#define CT_C1_ROWS_CAP 4096                        // workgroups of the few-channel gather kernels (at most; each walks output rows)
+#endif
 #ifndef CT_C1W_CAP
 #define CT_C1W_CAP 1024                            // workgroups of the few-channel weight gradient (at most)
 #endif
@@ -1213,7 +1216,7 @@ extern "C" int spk_conv_train_gather(const float* in_cl, const float* w, const f
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (kind == 3) {
     const int rows = N * Ho;
-    const dim3 gr(rows < 8192 ? rows : 8192);
+    const dim3 gr(rows < CT_C1_ROWS_CAP ? rows : CT_C1_ROWS_CAP);
     const size_t ldsw = (size_t)k * k * Cred * Cout * 4;
     if (Cred == 1) hipLaunchKernelGGL(conv_train_c1in_kernel<1>, gr, dim3(256), ldsw, s, a);
     else if (Cred == 2) hipLaunchKernelGGL(conv_train_c1in_kernel<2>, gr, dim3(256), ldsw, s, a);
@@ -1221,7 +1224,7 @@ extern "C" int spk_conv_train_gather(const float* in_cl, const float* w, const f
     else hipLaunchKernelGGL(conv_train_c1in_kernel<4>, gr, dim3(256), ldsw, s, a);
   } else if (kind == 2) {
     const int LP = Cred / 4;
-    const int blocks = N * Ho < 8192 ? N * Ho : 8192;
+    const int blocks = N * Ho < CT_C1_ROWS_CAP ? N * Ho : CT_C1_ROWS_CAP;
 #define SPK_C1OUT(LP_)                                                                                                 \
   do {                                                                                                                 \
     if (Cout == 1) hipLaunchKernelGGL((conv_train_c1out_kernel<LP_, 1>), dim3(blocks), dim3(256), 0, s, a);            \
