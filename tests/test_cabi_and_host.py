@@ -344,3 +344,41 @@ def test_round4_training_entry_points_check_their_arguments_on_the_host():
                                        16, 2, 48, 49, f(2.0), f(1.0), f(0.0), None) == -2
     assert lib.spk_q_sample(None, None, None, None, None, None, 4, 49, 100, 128, None) == -1
     assert lib.spk_conv3x3_wgrad_small(None, None, None, 0, None, None, 8, 7, 7, 64, 2, 1, None) == -1
+
+
+def test_training_convolution_entry_points_reject_and_accept_on_the_host():
+    """csrc/conv_train.hip: the support queries and the argument checks run on the host (no launch): the six layers of the MNIST
+    model and the first / read-out layers of the RGB model are taken in every direction they are used, shapes outside the limits
+    are refused with SPK_ERR_UNSUPPORTED (the host then calls the framework's operator), null pointers / short workspaces with
+    SPK_ERR_ARG."""
+    from spkdiff import _lib
+    lib = _lib.lib
+    sup, wsb = lib.spk_conv_train_gather_supported, lib.spk_conv_train_wgrad_ws_bytes
+    # (Cin, Cout, k, stride, transposed, N, Hi, Ho): forward form, backward form, weight-gradient operands
+    layers = [(1, 32, 3, 2, False, 512, 28, 14), (32, 64, 3, 2, False, 512, 14, 7), (64, 16, 1, 1, False, 512, 7, 7),
+              (16, 64, 3, 2, True, 512, 7, 14), (64, 32, 3, 2, True, 512, 14, 28), (32, 1, 3, 1, True, 512, 28, 28),
+              (3, 32, 3, 2, False, 512, 32, 16), (32, 3, 3, 1, True, 512, 32, 32)]
+    for cin, cout, k, s, tr, n, hi, ho in layers:
+        assert sup(cin, cout, k, s, 1 if tr else 0) == 1, (cin, cout)
+        if cin > 4:                                          # (the image input of a first layer takes no gradient)
+            assert sup(cout, cin, k, s, 0 if tr else 1) == 1, (cin, cout)
+        if tr:
+            assert wsb(n, hi, hi, cout, cin, k) > 0, (cin, cout)
+        else:
+            assert wsb(n, ho, ho, cin, cout, k) > 0, (cin, cout)
+    assert sup(5, 32, 3, 2, 0) == 0 and sup(64, 128, 3, 1, 0) == 0 and sup(128, 64, 3, 1, 0) == 0      # 5 / 128 channels
+    assert sup(32, 32, 5, 1, 0) == 0                         # 25 taps
+    assert sup(32, 32, 3, 3, 1) == 0 and sup(32, 32, 3, 3, 0) == 1                                     # transposed form: stride <= 2
+    assert sup(32, 1, 3, 2, 1) == 0                          # one output channel, transposed form at stride 2
+    assert wsb(512, 7, 7, 128, 64, 3) == -1 and wsb(0, 7, 7, 32, 32, 3) == -1 and wsb(512, 7, 7, 64, 1, 3) > 0
+    assert wsb(8, 6, 6, 1, 64, 4) > 0 and wsb(8, 6, 6, 2, 64, 4) == -1 and wsb(8, 6, 6, 2, 20, 3) == -1   # few-channel form: k <= 3 beyond one channel, Cv / 4 a power of two
+    import ctypes
+    ll = ctypes.c_longlong
+    assert lib.spk_conv_train_gather(None, None, None, None, 8, 7, 7, 32, 7, 7, 32, 3, 1, 1, 0, ll(32), ll(1), ll(288), None) == -1
+    assert lib.spk_conv_train_gather(16, 16, None, 16, 8, 7, 7, 5, 7, 7, 32, 3, 1, 1, 0, ll(5), ll(1), ll(45), None) == -2
+    assert lib.spk_conv_train_wgrad(None, None, None, ll(0), None, None, 8, 7, 7, 32, 7, 7, 32, 3, 1, 1, ll(32), ll(1), ll(288), 1,
+                                    None) == -1
+    assert lib.spk_conv_train_wgrad(16, 16, 16, ll(16), 16, None, 8, 7, 7, 32, 7, 7, 32, 3, 1, 1, ll(32), ll(1), ll(288), 0,
+                                    None) == -1      # workspace too small
+    assert lib.spk_conv_train_wgrad(16, 16, 16, ll(1 << 40), 16, None, 8, 7, 7, 128, 7, 7, 32, 3, 1, 1, ll(32), ll(1), ll(288), 0,
+                                    None) == -2
