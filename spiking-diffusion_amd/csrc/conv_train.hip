@@ -27,6 +27,7 @@
 // One-channel sides (the 1 -> 32 first layer and the 32 -> 1 last layer) are vector kernels: there is no matrix in them.
 #include "spk_common.h"
 #include "../../include/spkdiff.h"
+#include <mutex>
 
 namespace {
 
@@ -1183,12 +1184,13 @@ int gather_kind(int Cred, int Cout, int k, int stride, int form) {
 
 template <int J, int CN, int RM>
 void launch_gather(const GArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  static bool once = false;                          // (the opt-in to > 64 KB of dynamic LDS: per instantiation, outside any stream capture)
-  if (!once) {
+  // (the opt-in to > 64 KB of dynamic LDS: once per instantiation -- thread-safe -- and outside any stream capture: the warm-up
+  //  iterations in front of a capture make the first call)
+  static std::once_flag once;
+  std::call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_train_gather_kernel<J, CN, RM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               152 * 1024);
-    once = true;
-  }
+  });
   ClassTab ct;
   build_class_tab(ct, a, RM * 32);
   hipLaunchKernelGGL((conv_train_gather_kernel<J, CN, RM>), grid, dim3(512), lds, s, a, ct);
@@ -1252,12 +1254,11 @@ extern "C" int spk_conv_train_gather(const float* in_cl, const float* w, const f
       build_sub_tab(tb, a);
 #define SPK_SUB_LAUNCH(J_, CN_)                                                                                        \
   do {                                                                                                                 \
-    static bool once_ = false;                                                                                         \
-    if (!once_) {                                                                                                      \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_train_gather_sub_kernel<J_, CN_>),                 \
+    static std::once_flag once_;                                                                                       \
+    std::call_once(once_, [] {                                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_train_gather_sub_kernel<J_, CN_>),                                                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);                               \
-      once_ = true;                                                                                                    \
-    }                                                                                                                  \
+    });                                                                                                                \
     hipLaunchKernelGGL((conv_train_gather_sub_kernel<J_, CN_>), dim3(gx, gy), dim3(512), lds, s, a, tb);               \
   } while (0)
       if (CN == 2) {
@@ -1369,12 +1370,11 @@ extern "C" int spk_conv_train_wgrad(const float* u_cl, const float* v_cl, float*
             const size_t lds_ = need > comb ? need : comb;
 #define SPK_WL_LAUNCH(N_)                                                                                              \
   do {                                                                                                                 \
-    static bool once_ = false;                                                                                         \
-    if (!once_) {                                                                                                      \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_train_wgrad_lds_kernel<N_>),                       \
+    static std::once_flag once_;                                                                                       \
+    std::call_once(once_, [] {                                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_train_wgrad_lds_kernel<N_>),                                                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);                               \
-      once_ = true;                                                                                                    \
-    }                                                                                                                  \
+    });                                                                                                                \
     hipLaunchKernelGGL((conv_train_wgrad_lds_kernel<N_>), dim3(a.nwg), dim3(512), lds_, s, a, g);                      \
   } while (0)
             switch (ntw) {
@@ -1394,12 +1394,11 @@ extern "C" int spk_conv_train_wgrad(const float* u_cl, const float* v_cl, float*
 #define SPK_WG_LAUNCH(N_, S_)                                                                                          \
   do {                                                                                                                 \
     const size_t lds_ = (S_) == 2 ? (size_t)4 * (N_) * 16 * 64 * 4 : 8192;                                             \
-    static bool once_ = false;                                                                                         \
-    if (!once_) {                                                                                                      \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_train_wgrad_kernel<N_, S_>),                       \
+    static std::once_flag once_;                                                                                       \
+    std::call_once(once_, [] {                                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_train_wgrad_kernel<N_, S_>),                                                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);                               \
-      once_ = true;                                                                                                    \
-    }                                                                                                                  \
+    });                                                                                                                \
     hipLaunchKernelGGL((conv_train_wgrad_kernel<N_, S_>), dim3(a.nwg), dim3(256 * (S_)), lds_, s, a);                  \
   } while (0)
     switch (ntw) {
