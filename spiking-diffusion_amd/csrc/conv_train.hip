@@ -11,20 +11,24 @@
 //       = ConvTranspose2d forward, Conv2d data gradient
 // with the weight tensor addressed through three strides (tap, reduced channel, output channel), so that Conv2d's
 // [Cout][k][k][Cin] and ConvTranspose2d's [Cin][k][k][Cout] storage (channels-last parameters, spkdiff/fused.py) and both
-// transpositions are the same code.  A workgroup stages its class's weight taps in LDS once, in B-fragment order
-// ([tap][c / 8][c / 4 % 2][co][c % 4]: one 16-byte read = the B operands of four MFMAs), and walks 64-row groups of output
-// positions: a lane reads 16 bytes of its row's input record per eight reduced channels (the A operands of the same four
-// MFMAs; the K order inside a group of eight is a permutation both operands share), so a tap costs one global and one LDS read
-// per four to eight MFMAs.  Rows of a tile share the tap list (sub-pixel classes are separate grid rows): no multiplication
-// by structural zeros in the transposed form.
+// transpositions are the same code.  A workgroup (eight waves) stages ALL k * k weight taps of its column tiles in LDS once, in
+// B-fragment order ([tap][c / 8][c / 4 % 2][co][c % 4]: one 16-byte read = the B operands of four MFMAs; the class / tap tables come
+// from the host as a kernel argument), and its waves walk items of 32 output positions of one sub-pixel class: a lane reads 16
+// bytes of its row's input record per eight reduced channels (the A operands of the same four MFMAs; the K order inside a group
+// of eight is a permutation both operands share), the next tap's records requested before this tap's MFMAs.  Rows of a tile share
+// the tap list: no multiplication by structural zeros in the transposed form.
 //
 // Weight gradient: D[tap][cu][cv] = sum over (n, q) of U[n, q * s - pad + k][cu] * V[n, q][cv]  (Conv2d: U = input, V = gy;
 // ConvTranspose2d: U = gy, V = input -- the tensor on the finer grid is U).  Rows = cv, columns = cu, K = positions; the 32x32 tiles
-// (tap, cu / 32, cv / 32) are dealt to the four waves of a workgroup, every workgroup owns a contiguous range of positions and writes
-// its partial tiles, and a second launch adds the partials in a fixed order (deterministic) and scatters them through the
-// gradient's strides; the bias gradient (a column sum of gy) rides along in both launches.
+// (tap, cu / 32, cv / 32) are dealt to four waves, a workgroup owns a range of coarse-grid rows and stages their operand rows through
+// LDS a block ahead (conv_train_wgrad_lds_kernel; the direct-from-global form conv_train_wgrad_kernel takes the shapes whose rows do not
+// fit), two halves of four waves whose tiles are added through LDS, and a second launch adds the workgroups' partial tiles in index
+// order (deterministic) and scatters them through the gradient's strides; the bias gradient (a column sum of gy) comes from the staged
+// rows.
 //
-// One-channel sides (the 1 -> 32 first layer and the 32 -> 1 last layer) are vector kernels: there is no matrix in them.
+// Sides of one to four channels (the 1 -> 32 / 3 -> 32 first layer, the 32 -> 1 / 32 -> 3 read-out layer) are vector kernels: there is no
+// matrix in them.  Every variant that was built and measured slower stays behind a knob below, with its numbers
+// (profiles/r5_ab_conv_train.txt holds the A/B records, ablations, counters and phase stamps).
 #include "spk_common.h"
 #include "../../include/spkdiff.h"
 #include <mutex>
