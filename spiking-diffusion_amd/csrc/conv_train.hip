@@ -255,6 +255,8 @@ __global__ __launch_bounds__(512) void conv_train_gather_kernel(GArgs a, ClassTa
     };
     auto mma = [&](int t, const float4 (&src)[RM][J]) {
       const int tap = tl.tap[t];
+      // (reading the weight fragments of step j + 1 in front of the MFMAs of step j behind scheduling barriers was measured SLOWER --
+      //  dec.convT2 forward 78 against 61 us: the barriers also pin the input requests; left to hipcc)
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         float4 B[CN];
@@ -893,30 +895,43 @@ __global__ __launch_bounds__(512) void conv_train_wgrad_lds_kernel(WArgs a, WLGe
         }
     }
   };
+  // (the operands of step s + 1 are read from LDS BEFORE the MFMAs of step s are issued, and the scheduler is told to keep it that way:
+  //  left alone hipcc put every ds_read directly in front of its MFMA with a wait between them -- an LDS round trip per MFMA, the matrix
+  //  pipe 31 % busy)
   auto compute = [&](const float* sv) {
     if (fuse_bias) bias_rows(sv);
-    for (int r = 0; r < g.RB; ++r) {
-      const int vo = r * (a.Wv + 1) * a.Cv + kk * a.Cv, uo = r * a.k * g.WP * a.Cu + kk * sCu;
-      for (int s2 = 0; s2 < SR; ++s2) {
-        const float* pv = sv + vo + 2 * s2 * a.Cv;
-        const float* pu = sv + uo + 2 * s2 * sCu;
-        float av[NTW], bv[NTW];
-        if (a_shared) {
-          const float x = pv[t_cv[0]];
+    auto fetch = [&](int r, int s2, float (&av)[NTW], float (&bv)[NTW]) {
+      const float* pv = sv + r * (a.Wv + 1) * a.Cv + kk * a.Cv + 2 * s2 * a.Cv;
+      const float* pu = sv + r * a.k * g.WP * a.Cu + kk * sCu + 2 * s2 * sCu;
+      if (a_shared) {
+        const float x = pv[t_cv[0]];
 #pragma unroll
-          for (int i = 0; i < NTW; ++i) av[i] = x;
-        } else {
+        for (int i = 0; i < NTW; ++i) av[i] = x;
+      } else {
 #pragma unroll
-          for (int i = 0; i < NTW; ++i) av[i] = pv[t_cv[i]];
-        }
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) bv[i] = pu[t_b[i]];
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) {
-          if (CT_DBG & 64) acc[i][0] += av[i] + bv[i];
-          else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc[i], 0, 0, 0);
-        }
+        for (int i = 0; i < NTW; ++i) av[i] = pv[t_cv[i]];
       }
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) bv[i] = pu[t_b[i]];
+    };
+    float av0[NTW], bv0[NTW], av1[NTW], bv1[NTW];
+    const int nstep = g.RB * SR;
+    fetch(0, 0, av0, bv0);
+    int r = 0, s2 = 0;
+    for (int st = 0; st < nstep; ++st) {
+      int s2n = s2 + 1, rn = r;
+      if (s2n == SR) { s2n = 0; ++rn; }
+      if (st + 1 < nstep) fetch(rn, s2n, av1, bv1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        if (CT_DBG & 64) acc[i][0] += av0[i] + bv0[i];
+        else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[i], bv0[i], acc[i], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) { av0[i] = av1[i]; bv0[i] = bv1[i]; }
+      r = rn; s2 = s2n;
     }
   };
   if (CT_WL_PINGPONG) {
