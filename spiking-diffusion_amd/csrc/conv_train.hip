@@ -831,7 +831,6 @@ __global__ __launch_bounds__(512) void conv_train_wgrad_lds_kernel(WArgs a, WLGe
     int cv = cvt * 32 + rc;
     t_cv[i] = cv < a.Cv ? cv : 0;
   }
-  const bool a_shared = (4 % CVT) == 0;
   v16f acc[NTW];
 #pragma unroll
   for (int i = 0; i < NTW; ++i)
@@ -900,38 +899,39 @@ __global__ __launch_bounds__(512) void conv_train_wgrad_lds_kernel(WArgs a, WLGe
   //  pipe 31 % busy)
   auto compute = [&](const float* sv) {
     if (fuse_bias) bias_rows(sv);
-    auto fetch = [&](int r, int s2, float (&av)[NTW], float (&bv)[NTW]) {
+    // (Cv <= 64: at most two row tiles, and tiles wq, wq + 4, ... of a wave share theirs -- ONE A operand per step)
+    auto fetch = [&](int r, int s2, float& av, float (&bv)[NTW]) {
       const float* pv = sv + r * (a.Wv + 1) * a.Cv + kk * a.Cv + 2 * s2 * a.Cv;
       const float* pu = sv + r * a.k * g.WP * a.Cu + kk * sCu + 2 * s2 * sCu;
-      if (a_shared) {
-        const float x = pv[t_cv[0]];
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) av[i] = x;
-      } else {
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) av[i] = pv[t_cv[i]];
-      }
+      av = pv[t_cv[0]];
 #pragma unroll
       for (int i = 0; i < NTW; ++i) bv[i] = pu[t_b[i]];
     };
-    float av0[NTW], bv0[NTW], av1[NTW], bv1[NTW];
+    // two register sets, no copies between them (a copy of a just-read value is a wait for the read in front of the MFMAs)
+    float av0, bv0[NTW], av1, bv1[NTW];
     const int nstep = g.RB * SR;
-    fetch(0, 0, av0, bv0);
     int r = 0, s2 = 0;
-    for (int st = 0; st < nstep; ++st) {
-      int s2n = s2 + 1, rn = r;
-      if (s2n == SR) { s2n = 0; ++rn; }
-      if (st + 1 < nstep) fetch(rn, s2n, av1, bv1);
-      __builtin_amdgcn_sched_barrier(0);
+    auto advance = [&]() { if (++s2 == SR) { s2 = 0; ++r; } };
+    auto multiply = [&](const float av, const float (&bv)[NTW]) {
 #pragma unroll
       for (int i = 0; i < NTW; ++i) {
-        if (CT_DBG & 64) acc[i][0] += av0[i] + bv0[i];
-        else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[i], bv0[i], acc[i], 0, 0, 0);
+        if (CT_DBG & 64) acc[i][0] += av + bv[i];
+        else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[i], acc[i], 0, 0, 0);
       }
+    };
+    fetch(0, 0, av0, bv0);
+    advance();
+    // (the reads are unconditional -- one step past the block reads LDS words nobody uses: a conditional read is a control-flow join, and
+    //  hipcc waits for EVERY outstanding LDS read at a join, i.e. for the prefetch it has just issued)
+    for (int st = 0; st < nstep; st += 2) {
+      fetch(r, s2, av1, bv1); advance();
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < NTW; ++i) { av0[i] = av1[i]; bv0[i] = bv1[i]; }
-      r = rn; s2 = s2n;
+      multiply(av0, bv0);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(r, s2, av0, bv0); advance();
+      __builtin_amdgcn_sched_barrier(0);
+      if (st + 1 < nstep) multiply(av1, bv1);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   if (CT_WL_PINGPONG) {
