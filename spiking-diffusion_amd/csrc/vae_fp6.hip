@@ -112,6 +112,10 @@ constexpr float CERT_4EPS = 4.0f * 2.38418579e-07f;
                                 // item (24 registers with two chunks, 12 with one): the multiply phase of these layers is bound by LDS reads,
                                 // 1.5 KB of weight fragments per MFMA (profiles/r4_ab_kernel_variants.txt (11)); 0: every pass reads them
 #endif
+#ifndef SPK_VT_NHOLD
+#define SPK_VT_NHOLD 1          // how many of a class's leading taps are held that way (SPK_VT_HOIST).  All four taps of the four-tap class need
+                                // 96 registers with two chunks: twelve waves (168 registers each) hold three, sixteen (128) hold one
+#endif
 #ifndef SPK_VT_DBG
 #define SPK_VT_DBG 0            // timing experiments only (results are wrong): 1 = no MFMAs, 2 = no LIF scan, 4 = no weight-tile reads from LDS
 #endif
@@ -148,8 +152,34 @@ __host__ __device__ constexpr int on_tap(int k) {
   return 0;
 }
 
+#ifndef SPK_VT_DYN
+#define SPK_VT_DYN 1            // round 5: the passes of an item are HANDED OUT (an LDS counter, class-major order kept) instead of dealt
+                                // round-robin.  tools/vae_phase.py: of the four waves of a SIMD the oldest issues its scan's vector
+                                // instructions first -- waves 0-3 scan a pass in 1 280 cycles, waves 12-15 in 2 410 -- so with equal
+                                // shares the first four waited 31 % of the launch at the item's end barrier (mean over the waves: 19 %)
+#endif
+#ifndef SPK_VT_PRIO
+#define SPK_VT_PRIO 0           // s_setprio of a wave in its multiply phase (0 in the scan): the MFMAs and their LDS reads go first
+#endif
+#ifndef SPK_VT_STAMP
+#define SPK_VT_STAMP 0          // 1 (timing builds only): workgroup 0 accumulates shader-clock cycles per wave and phase into g_vt_stamp
+                                // (spk_vt_stamps reads and clears it; tools/vae_phase.py)
+#endif
+#if SPK_VT_STAMP
+__device__ unsigned long long g_vt_stamp[SPK_VT_NWV][8];
+#define VT_CLK() ((long long)__builtin_readcyclecounter())
+#define VT_ACC(slot, t0) do { const long long t1_ = VT_CLK(); st_acc[slot] += t1_ - (t0); (t0) = t1_; } while (0)
+#else
+#define VT_ACC(slot, t0) do { } while (0)
+#endif
+
 template <int GEO, int H, int W, int NCH, int OUT, int SPLIT, bool DB>
 __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
+#if SPK_VT_STAMP
+  long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // 0 stage+wait+barrier, 1 popcount phases, 2 multiply, 3 scan+store, 4 end barrier, 5 hold reads, 6 passes
+  long long st_t = VT_CLK();
+  const long long st_begin = st_t;
+#endif
   constexpr int TPT = tiles_per_tap(NCH), W_BYTES = 9 * TPT * WT;
   constexpr int TPL = SPK_VT_D4 ? TPT - 1 : TPT;            // tiles per tap kept in LDS (the fifth-digit tile stays in memory)
   constexpr int WL_BYTES = 9 * TPL * WT;
@@ -171,6 +201,8 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
   constexpr int NCELL = SROWS * SCOLS;
   uint8_t* const s_cin = lds + NBUF * A_BYTES + WL_BYTES;                       // [NCELL][16]
   int* const s_nmax = reinterpret_cast<int*>(s_cin + ((NCELL * 16 + 15) & ~15));   // [NCLS][NPOS]
+  constexpr bool DYN = SPK_VT_DYN && GEO == 0;              // (the 25 passes of the plain stride-2 layer's item: dealt; handed out it measured 3 us slower)
+  int* const s_ctr = SPK_VT_D4 ? s_nmax + NCLS * NPOS : reinterpret_cast<int*>(s_cin);   // the item's next pass (SPK_VT_DYN)
   const unsigned sA_addr = spk_lds_addr(sA);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -250,6 +282,13 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
     spk_dma_wait_all();
     __syncthreads();
     if (DB && itm + lanes < nitems) stage(itm + lanes, buf ^ 1);
+    if constexpr (DYN) {
+      // (every wave took its last pass number of the previous item before the barrier above; the first one of this item is taken
+      //  behind the barriers of the counting phases below)
+      if (tid == 0) *s_ctr = SPK_VT_NWV;
+      if constexpr (!SPK_VT_D4) __syncthreads();
+    }
+    VT_ACC(0, st_t);
 #if SPK_VT_STAGGER > 0
     // The two waves of a SIMD run the same pass list from the same barrier, so both are in their multiply phase together (each
     // then sees the matrix pipe at half rate: stamped 65-70 cycles per MFMA) and in their scans together.  The second wave
@@ -301,11 +340,17 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
       }
       __syncthreads();
     }
+    VT_ACC(1, st_t);
 
     // hb: the weight fragments of the class's first tap, read once per class by the caller (SPK_VT_HOIST)
-    auto run_pass = [&](auto cls_tag, int k, const v6i (&hb)[NCH * 2]) __attribute__((always_inline)) {
+    auto run_pass = [&](auto cls_tag, int k, const v6i (&hb)[SPK_VT_NHOLD][NCH * 2]) __attribute__((always_inline)) {
       constexpr int CLS = decltype(cls_tag)::value, PY = CLS >> 1, PX = CLS & 1;
-      constexpr int TAP0 = on_tap<GEO, CLS>(0);
+      constexpr int NHELD = n_on_taps<GEO, CLS>() < SPK_VT_NHOLD ? n_on_taps<GEO, CLS>() : SPK_VT_NHOLD;
+      auto held_slot = [](int tap) constexpr {                // which held set carries this tap's fragments (-1: none)
+        for (int h = 0; h < NHELD; ++h)
+          if (on_tap<GEO, CLS>(h) == tap) return h;
+        return -1;
+      };
       int tl[TPP];                                         // tiles of the pass; one past the end repeats the first (computed, dropped)
       bool tv[TPP];
 #pragma unroll
@@ -321,6 +366,7 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
         const int ry = p / CW, rx = p - ry * CW;
         base[i] = (GEO == 0 ? ry * SCOLS + rx : 2 * ry * SCOLS + 2 * rx) * POSB + tt * 16;
       }
+      if (SPK_VT_PRIO) __builtin_amdgcn_s_setprio(SPK_VT_PRIO);
       constexpr int NACC = SPK_VT_D4 ? 2 : 3;
       v16f acc[TPP][NACC];
 #pragma unroll
@@ -401,9 +447,11 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
               av[i][0] = *reinterpret_cast<const v4i*>(A0 + base[i] + TOFF);
               av[i][1] = *reinterpret_cast<const v4i*>(A0 + A_CH + base[i] + TOFF);
             }
-            constexpr bool HB = SPK_VT_HOIST && SPK_VT_D4 && TAP == TAP0;
-            const v6i b0 = HB ? hb[0] : ldb(TAP * TPL + 0), b1 = HB ? hb[1] : ldb(TAP * TPL + 1),
-                      b2 = HB ? hb[2] : ldb(TAP * TPL + 2), b3 = HB ? hb[3] : ldb(TAP * TPL + 3);
+            constexpr int HS = held_slot(TAP);
+            constexpr bool HB = SPK_VT_HOIST && SPK_VT_D4 && HS >= 0;
+            constexpr int HQ = HB ? HS : 0;
+            const v6i b0 = HB ? hb[HQ][0] : ldb(TAP * TPL + 0), b1 = HB ? hb[HQ][1] : ldb(TAP * TPL + 1),
+                      b2 = HB ? hb[HQ][2] : ldb(TAP * TPL + 2), b3 = HB ? hb[HQ][3] : ldb(TAP * TPL + 3);
             v6i b4 = b0;
             if constexpr (!SPK_VT_D4) b4 = ldb(TAP * TPL + 4);
 #pragma unroll
@@ -422,8 +470,10 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
             v4i av[TPP];
 #pragma unroll
             for (int i = 0; i < TPP; ++i) av[i] = *reinterpret_cast<const v4i*>(A0 + base[i] + TOFF);
-            constexpr bool HB = SPK_VT_HOIST && SPK_VT_D4 && TAP == TAP0;
-            const v6i b0 = HB ? hb[0] : ldb(TAP * TPL + 0), b1 = HB ? hb[1] : ldb(TAP * TPL + 1);
+            constexpr int HS = held_slot(TAP);
+            constexpr bool HB = SPK_VT_HOIST && SPK_VT_D4 && HS >= 0;
+            constexpr int HQ = HB ? HS : 0;
+            const v6i b0 = HB ? hb[HQ][0] : ldb(TAP * TPL + 0), b1 = HB ? hb[HQ][1] : ldb(TAP * TPL + 1);
             v6i b4 = b0;
             if constexpr (!SPK_VT_D4) b4 = ldb(TAP * TPL + 2);
 #pragma unroll
@@ -436,6 +486,15 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
           }
         }
       });
+#endif
+      if (SPK_VT_PRIO) __builtin_amdgcn_s_setprio(0);
+#if SPK_VT_STAMP
+      {
+        float sink = acc[0][0][15] + acc[0][NACC - 1][15];
+        asm volatile("" : "+v"(sink));
+        VT_ACC(2, st_t);
+        st_acc[6] += 1;
+      }
 #endif
       // ---- epilogue: fp32 recombination, BN, LIF scan with certification, output
 #pragma unroll
@@ -528,33 +587,64 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
           }
         }
       }
+      VT_ACC(3, st_t);
     };
 
     // the item's passes, class-major, dealt round-robin over the waves (every wave gets a mix of cheap and expensive classes); a
     // wave's passes of one class follow one another, so the class's first-tap weight fragments are read once for all of them
+    [[maybe_unused]] int Pdyn = wave;                          // (SPK_VT_DYN) the wave's pass: the first NWV are dealt, the rest handed out
     tfor<NCLS>([&](auto cls_tag) {
-      constexpr int CLS = decltype(cls_tag)::value, TAP0 = on_tap<GEO, CLS>(0);
-      int P = CLS * NPASS + ((wave - CLS * NPASS) % SPK_VT_NWV + SPK_VT_NWV) % SPK_VT_NWV;     // first P >= CLS * NPASS with P = wave (mod NWV)
+      constexpr int CLS = decltype(cls_tag)::value;
+      constexpr int NHELD = n_on_taps<GEO, CLS>() < SPK_VT_NHOLD ? n_on_taps<GEO, CLS>() : SPK_VT_NHOLD;
+      int P = DYN ? Pdyn : CLS * NPASS + ((wave - CLS * NPASS) % SPK_VT_NWV + SPK_VT_NWV) % SPK_VT_NWV;   // static: first P >= CLS * NPASS with P = wave (mod NWV)
       if (P < (CLS + 1) * NPASS) {
-        v6i hb[NCH * 2];
+        v6i hb[SPK_VT_NHOLD][NCH * 2];
+#pragma unroll
+        for (int h = 0; h < SPK_VT_NHOLD; ++h)
+#pragma unroll
+          for (int j = 0; j < NCH * 2; ++j) hb[h][j] = v6i{0, 0, 0, 0, 0, 0};
         if constexpr (SPK_VT_HOIST && SPK_VT_D4 && !SPK_VT_PIPE) {
+          tfor<NHELD>([&](auto h_tag) {
+            constexpr int h = decltype(h_tag)::value, TAPH = on_tap<GEO, CLS>(h);
 #pragma unroll
-          for (int j = 0; j < NCH * 2; ++j) {
-            const uint8_t* p = sW + (TAP0 * TPL + j) * WT;
-            const v4i x = *reinterpret_cast<const v4i*>(p + lane * 16);
-            const v2i y = *reinterpret_cast<const v2i*>(p + 1024 + lane * 8);
-            hb[j] = v6i{x[0], x[1], x[2], x[3], y[0], y[1]};
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < NCH * 2; ++j) hb[j] = v6i{0, 0, 0, 0, 0, 0};
+            for (int j = 0; j < NCH * 2; ++j) {
+              const uint8_t* p = sW + (TAPH * TPL + j) * WT;
+              const v4i x = *reinterpret_cast<const v4i*>(p + lane * 16);
+              const v2i y = *reinterpret_cast<const v2i*>(p + 1024 + lane * 8);
+              hb[h][j] = v6i{x[0], x[1], x[2], x[3], y[0], y[1]};
+            }
+          });
         }
-        for (; P < (CLS + 1) * NPASS; P += SPK_VT_NWV) run_pass(cls_tag, P - CLS * NPASS, hb);
+#if SPK_VT_STAMP
+        {
+          int sink = hb[0][0][0];
+          asm volatile("" : "+v"(sink));
+          VT_ACC(5, st_t);
+        }
+#endif
+        if constexpr (DYN) {
+          while (P < (CLS + 1) * NPASS) {
+            int nxt = 0;
+            if (lane == 0) nxt = atomicAdd(s_ctr, 1);          // (requested before the pass, read behind it)
+            run_pass(cls_tag, P - CLS * NPASS, hb);
+            P = __builtin_amdgcn_readfirstlane(nxt);
+          }
+          Pdyn = P;
+        } else {
+          for (; P < (CLS + 1) * NPASS; P += SPK_VT_NWV) run_pass(cls_tag, P - CLS * NPASS, hb);
+        }
       }
     });
     if (!DB) __syncthreads();                                  // everyone is done with the slab before the next copy lands
+    VT_ACC(4, st_t);
   }
   spk_dma_wait_all();
+#if SPK_VT_STAMP
+  if (blockIdx.x == 0 && lane == 0) {
+    for (int k = 0; k < 7; ++k) atomicAdd(&g_vt_stamp[wave][k], (unsigned long long)st_acc[k]);
+    atomicAdd(&g_vt_stamp[wave][7], (unsigned long long)(VT_CLK() - st_begin));
+  }
+#endif
   // hand-over to the repair launch: the workgroup that finishes last publishes the count and re-arms the live counter (the
   // workgroups finish at different times, so this ticket costs nothing; a ticket in the repair launch, whose workgroups all
   // arrive at once, cost 16 us, a separate reset launch 5)
@@ -786,7 +876,7 @@ int launch_vae(const TArgs& a, long long n_words, hipStream_t stream) {
   constexpr int NPOS = GEO == 0 ? (H / SPLIT) * W : (H / 2) * (W / 2), NCLS = GEO == 0 ? 4 : 1;
   // (+ the four-digit form's counters: u8 [cells][16] and int [classes][positions])
   const size_t lds = (size_t)(DB ? 2 : 1) * NCH * SROWS * (W + 1) * POSB + 9 * TPL * WT +
-                     (SPK_VT_D4 ? (size_t)((SROWS * (W + 1) * 16 + 15) & ~15) + (size_t)NCLS * NPOS * 4 : 0);
+                     (SPK_VT_D4 ? (size_t)((SROWS * (W + 1) * 16 + 15) & ~15) + (size_t)NCLS * NPOS * 4 : 0) + 16;
   if (lds > 160 * 1024) return SPK_ERR_UNSUPPORTED;
   const int cus = spk_cu_count(), G = a.Cout / 32;
   const int grid = cus >= G ? (cus / G) * G : G;
@@ -846,7 +936,13 @@ extern "C" int spk_vae_fp6_fwd(const uint8_t* in_s32, const uint8_t* wq, const d
   const long long n_words = (neurons + 31) / 32;
   a.ticket_idx = 2 + (long long)FLAG_CAP + n_words;
   if (transposed && Cin == 64 && out_kind == OUT_COLLAPSED) {                                // decoder convT2
-    if (H == 14 && W == 14) return launch_vae<0, 14, 14, 2, OUT_COLLAPSED, 2, false>(a, n_words, stream);
+#ifndef SPK_VT_T2_SPLIT
+#define SPK_VT_T2_SPLIT 2       // items per image of the 14x14 -> 28x28 layer: 2 = half images, one input slab (two do not fit beside the weights);
+                                // 7 = two class rows per item, two slabs (the copy of the next item runs under this one's passes): 231 against
+                                // 195 us -- 28 items per workgroup pay the counting phases' barriers 28 times (15 % of the launch) and the waves
+                                // then wait for one another at the item's first barrier instead (profiles/r5_ab_kernel_variants.txt (7))
+#endif
+    if (H == 14 && W == 14) return launch_vae<0, 14, 14, 2, OUT_COLLAPSED, SPK_VT_T2_SPLIT, (SPK_VT_T2_SPLIT > 2)>(a, n_words, stream);
     if (H == 16 && W == 16) return launch_vae<0, 16, 16, 2, OUT_COLLAPSED, 2, false>(a, n_words, stream);
   }
   if (transposed && Cin == 16 && out_kind == OUT_S32) {                                      // decoder convT1
@@ -859,3 +955,14 @@ extern "C" int spk_vae_fp6_fwd(const uint8_t* in_s32, const uint8_t* wq, const d
   }
   return SPK_ERR_UNSUPPORTED;
 }
+
+#if SPK_VT_STAMP
+// (timing builds only) the accumulated phase cycles of workgroup 0, [wave][8]; cleared on read
+extern "C" int spk_vt_stamps(unsigned long long* out, int* n_waves) {
+  unsigned long long z[SPK_VT_NWV][8] = {};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vt_stamp), sizeof(z)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_vt_stamp), z, sizeof(z)) != hipSuccess) return -1;
+  *n_waves = SPK_VT_NWV;
+  return 0;
+}
+#endif
