@@ -83,6 +83,9 @@ constexpr float CERT_4EPS = 4.0f * 2.38418579e-07f;
                                 // fragments one tap ahead, schedule pinned); measured equal (264-267 against 267 us): hipcc already defers the
                                 // second tile's MFMAs to after the first tile's scan and runs them back to back from registers
 #endif
+#ifndef SPK_VT_PFB
+#define SPK_VT_PFB 2            // (SPK_VT_PIPE) how many steps ahead a weight tile is requested
+#endif
 #ifndef SPK_VT_STAGGER
 #define SPK_VT_STAGGER 0        // s_sleep argument (x 64 cycles) of waves 4..7 after every item barrier.  Measured (convT2, B = 1024): 8 / 16 / 24 /
                                 // 32 / 48 -> 273 / 270-274 / 273 / 273 / 275 us against 266-267: a wave that scans while its partner multiplies
@@ -390,15 +393,21 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
         d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, d, 4, 2, 0, sc_a, 0, sb);
       };
 #if SPK_VT_PIPE
-      static_assert(!SPK_VT_D4, "the software-pipelined experiment was written for the five-digit tile list");
-      // The item's products as ONE compile-time list of steps (an active tap of the class x one weight tile), software pipelined:
-      // the weight tile of step s + PFB and the spike fragments of the NEXT tap are read from LDS while the MFMAs of step s run
-      // (read-all-then-multiply per tap left LDS reads and MFMAs in series: 153 us of the convT2 launch's 269 against ~70 us each).
-      constexpr int NON = n_on_taps<GEO, CLS>(), NSTEP = NON * TPT, PFB = 2, RB = PFB + 1;
+      // The pass's products as ONE compile-time list of steps (an active tap of the class x one weight tile), software pipelined:
+      // the weight tile of step s + PFB and the spike fragments of the NEXT tap are requested from LDS while the MFMAs of step s run
+      // (tap by tap -- read, wait, multiply -- a pass spends 1 000 - 1 500 cycles on 288 cycles of matrix time: tools/vae_phase.py).
+      // Steps of a held tap (SPK_VT_HOIST) take their tile from hb and request nothing.
+      constexpr int NON = n_on_taps<GEO, CLS>(), TS = TPL, NSTEP = NON * TS, PFB = SPK_VT_PFB, RB = PFB + 1;
       auto toff = [&](auto k_tag) {
         constexpr int TAP = on_tap<GEO, CLS>(decltype(k_tag)::value), KY = TAP / 3, KX = TAP % 3;
         constexpr int DY = GEO == 1 ? KY : ((PY == 1 && KY == 0) ? 1 : 0), DX = GEO == 1 ? KX : ((PX == 1 && KX == 0) ? 1 : 0);
         return std::integral_constant<int, (DY * SCOLS + DX) * POSB>{};
+      };
+      auto step_held = [](int st) constexpr {                 // the held set of step st's tap (-1: its tile comes from LDS)
+        if (!(SPK_VT_HOIST && SPK_VT_D4)) return -1;
+        for (int h = 0; h < NHELD; ++h)
+          if (h == st / TS) return h;                          // (the held taps are the class's leading ones)
+        return -1;
       };
       v4i av[2][TPP][NCH];
       v6i bq[RB];
@@ -411,23 +420,25 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
       };
       lda(std::integral_constant<int, 0>{});
       tfor<(PFB < NSTEP ? PFB : NSTEP)>([&](auto s_tag) {
-        constexpr int s = decltype(s_tag)::value;
-        bq[s % RB] = ldb(on_tap<GEO, CLS>(s / TPT) * TPT + s % TPT);
+        constexpr int st = decltype(s_tag)::value;
+        if constexpr (step_held(st) < 0) bq[st % RB] = ldb(on_tap<GEO, CLS>(st / TS) * TPL + st % TS);
       });
       tfor<NSTEP>([&](auto s_tag) {
-        constexpr int s = decltype(s_tag)::value, k = s / TPT, j = s % TPT;
-        if constexpr (s + PFB < NSTEP) bq[(s + PFB) % RB] = ldb(on_tap<GEO, CLS>((s + PFB) / TPT) * TPT + (s + PFB) % TPT);
-        if constexpr (j == 1 && k + 1 < NON) lda(std::integral_constant<int, k + 1>{});
+        constexpr int st = decltype(s_tag)::value, k = st / TS, j = st % TS;
+        if constexpr (st + PFB < NSTEP && step_held(st + PFB) < 0)
+          bq[(st + PFB) % RB] = ldb(on_tap<GEO, CLS>((st + PFB) / TS) * TPL + (st + PFB) % TS);
+        if constexpr (j == 0 && k + 1 < NON) lda(std::integral_constant<int, k + 1>{});
         asm volatile("" ::: "memory");                       // (every read stays where it is written)
-        const v6i bv = bq[s % RB];
+        constexpr int HS = step_held(st);
+        const v6i bv = HS >= 0 ? hb[HS >= 0 ? HS : 0][j] : bq[st % RB];
 #pragma unroll
         for (int i = 0; i < TPP; ++i) {
           if (SPK_VT_DBG & 1) continue;
           if constexpr (NCH == 2) {
             if constexpr (j < 4) mm(acc[i][j & 1], av[k & 1][i][j >> 1], bv, sc_p);
-            else mm(acc[i][2], half ? av[k & 1][i][1] : av[k & 1][i][0], bv, sc_4);
+            else mm(acc[i][NACC - 1], half ? av[k & 1][i][1] : av[k & 1][i][0], bv, sc_4);
           } else {
-            mm(acc[i][j], av[k & 1][i][0], bv, j < 2 ? sc_p : sc_4);
+            mm(acc[i][j < 2 ? j : NACC - 1], av[k & 1][i][0], bv, j < 2 ? sc_p : sc_4);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -603,7 +614,7 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
         for (int h = 0; h < SPK_VT_NHOLD; ++h)
 #pragma unroll
           for (int j = 0; j < NCH * 2; ++j) hb[h][j] = v6i{0, 0, 0, 0, 0, 0};
-        if constexpr (SPK_VT_HOIST && SPK_VT_D4 && !SPK_VT_PIPE) {
+        if constexpr (SPK_VT_HOIST && SPK_VT_D4) {
           tfor<NHELD>([&](auto h_tag) {
             constexpr int h = decltype(h_tag)::value, TAPH = on_tap<GEO, CLS>(h);
 #pragma unroll
