@@ -161,6 +161,10 @@ __host__ __device__ constexpr int on_tap(int k) {
                                 // instructions first -- waves 0-3 scan a pass in 1 280 cycles, waves 12-15 in 2 410 -- so with equal
                                 // shares the first four waited 31 % of the launch at the item's end barrier (mean over the waves: 19 %)
 #endif
+#ifndef SPK_VT_PREFETCH
+#define SPK_VT_PREFETCH 0       // 1 (single-slab layers): one dword of every 128-byte line of the NEXT item's input rows is requested at the start of
+                                // this item's passes, so that the copy behind the end barrier finds them in the L2
+#endif
 #ifndef SPK_VT_PRIO
 #define SPK_VT_PRIO 0           // s_setprio of a wave in its multiply phase (0 in the scan): the MFMAs and their LDS reads go first
 #endif
@@ -344,6 +348,17 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
       __syncthreads();
     }
     VT_ACC(1, st_t);
+    if constexpr (SPK_VT_PREFETCH && !DB) {
+      if (itm + lanes < nitems) {
+        const int nb_ = (itm + lanes) / SPLIT, np_ = (itm + lanes) - nb_ * SPLIT;
+        const int iy0 = GEO == 0 ? np_ * RQ : 0;
+        const int nrows = (iy0 + DROWS <= H ? DROWS : H - iy0), lpc = nrows * (W * POSB / 128);   // rows are contiguous within a chunk
+        for (int l = tid; l < NCH * lpc; l += SPK_VT_NWV * 64) {
+          const int c = l / lpc, o = l - c * lpc;
+          (void)*reinterpret_cast<const volatile unsigned*>(a.in + (((long long)nb_ * NCH + c) * H * W + iy0 * W) * POSB + (long long)o * 128);
+        }
+      }
+    }
 
     // hb: the weight fragments of the class's first tap, read once per class by the caller (SPK_VT_HOIST)
     auto run_pass = [&](auto cls_tag, int k, const v6i (&hb)[SPK_VT_NHOLD][NCH * 2]) __attribute__((always_inline)) {
