@@ -29,9 +29,10 @@ extern "C" {
 
 typedef struct ihipStream_t* spk_stream_t; /* == hipStream_t */
 
-#define SPK_VERSION 101 /* 0.1.1 -- bumped whenever an exported signature changes (round 4 inserted `int K` before the stream of
-                           * spk_select_active / spk_select_needed); spkdiff/_lib.py refuses a library whose spk_version()
-                           * differs from the signatures it declares */
+#define SPK_VERSION 102 /* 0.1.2 -- bumped whenever an exported signature changes or entry points are added (round 4 inserted `int K`
+                           * before the stream of spk_select_active / spk_select_needed: 101; round 5 added the VectorQuantizer's
+                           * training branch and the training convolutions: 102); spkdiff/_lib.py refuses a library whose
+                           * spk_version() differs from the signatures it declares */
 
 /* fused-kernel epilogue modes (spk_conv_fused_fwd) */
 #define SPK_CHUNK_C4 (-64) /* chunk_out value: fp4 nibble-packed output, 64 channels per chunk */

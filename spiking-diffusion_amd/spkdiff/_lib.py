@@ -170,7 +170,7 @@ def version() -> int:
 
 # The signatures declared above are those of include/spkdiff.h at this version.  A stale libspkdiff.so or an SPKDIFF_LIB A/B
 # variant built from another header would take arguments at the wrong positions (silently wrong results): refuse it here.
-EXPECTED_VERSION = 101
+EXPECTED_VERSION = 102
 if version() != EXPECTED_VERSION:
     raise ImportError(f"spkdiff: {LIB_PATH} reports C-ABI version {version()}, this binding declares version "
                       f"{EXPECTED_VERSION} (include/spkdiff.h SPK_VERSION). Rebuild the library: make -C "
