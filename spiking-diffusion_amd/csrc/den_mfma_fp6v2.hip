@@ -84,6 +84,7 @@ struct V2Args {
   unsigned* item_ctr;                        // duo form: item claim counters, one per (channel group, XCD partition): 128 words behind them
   float* zstage;                             // deferred-scan form: 96 KB per workgroup (an item's pre-activations between two K loops)
   int duo_delay;                             // duo form: head start of a CU's first workgroup over its second, in 10 ns ticks (0: none)
+  int fix_lds;                               // tail launches: 1 = the repair stages a neuron's 9 x Cin weights in (dynamic) LDS (SPK_V2_FIX_LDS)
 };
 
 #ifndef SPK_FP6_PRE
@@ -147,6 +148,15 @@ struct V2Args {
 #ifndef SPK_V2_NMAX_LDS
 #define SPK_V2_NMAX_LDS 1       // the first certification stage reads max_t n_t of its position from LDS (one atomic per (position, step)
                                 // in the per-item count pass) instead of sixteen counts + twelve v_max per tile and lane.  0: rounds 2-3
+#endif
+#ifndef SPK_V2_FIX_LDS
+#define SPK_V2_FIX_LDS 0        // 1 (built in round 5, measured SLOWER, off): the exact repair of a flagged neuron stages the neuron's 9 x Cin
+                                // quantised weights in LDS once (coalesced) and a lane = (step t, quarter of a 32-channel chunk) takes 4 bytes of
+                                // the spike record and eight weights from LDS -- 54 KB instead of 332 KB of requests through the CU's texture
+                                // path per neuron of the 512-channel layers.  Same box, two passes, bit-equal: den.conv5 launches 376.5 / 375.8
+                                // against 355.5 / 356.7 us, den.conv4 374.7 / 374.5 against 367.1 / 367.8, dense reverse process 89.7 / 89.4
+                                // against 88.2 / 88.0 ms: the copy + barrier per neuron cost more than the sixteen-fold weight requests, which
+                                // the L1 serves (profiles/r5_ab_kernel_variants.txt (8))
 #endif
 #ifndef SPK_V2_SIGNBITS
 #define SPK_V2_SIGNBITS 1       // the sixteen spike bits of a lane are shifted in from the sign of h - 1 (h - 1 exists for the certification: one
@@ -2234,7 +2244,7 @@ __device__ __forceinline__ void fp6v2_lastpos_body(const V2Args& a, const int bi
 // exact sum -- the arithmetic of den_mfma_fp6.hip -- the reference's BN and LIF steps) and lane t patches the nibble of step t.
 // Eight such workgroups fit a CU: a few thousand flagged neurons are one or two rounds, bound by the L2 reads (18 - 55 KB a neuron).
 template <int H, int W>
-__device__ __forceinline__ void fixup_neuron(const V2Args& a, long long n, unsigned long long* sS, int Bn) {
+__device__ __forceinline__ void fixup_neuron(const V2Args& a, long long n, unsigned long long* sS, int* sQ, int Bn) {
   constexpr int HW = H * W;
   const int tid = threadIdx.x, lane = tid & 63;
   const int nch = a.nch, Cin = a.Cin;
@@ -2244,24 +2254,48 @@ __device__ __forceinline__ void fixup_neuron(const V2Args& a, long long n, unsig
   if (b >= Bn) return;                                     // (uniform over the workgroup)
   const int py = p / W, px = p % W;
   if (tid < 16) sS[tid] = 0ull;
-  __syncthreads();
   long long part = 0;
-  const int units = 9 * nch * 16;
-  for (int u = tid; u < units; u += (int)blockDim.x) {
-    const int t = u & 15, cc = (u >> 4) % nch, tap = (u >> 4) / nch;
-    const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
-    if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-    const uint4 sp = *reinterpret_cast<const uint4*>(a.in0 + (((long long)b * nch + cc) * HW + yy * W + xx) * POSB + t * 16);
-    const int4* qp = reinterpret_cast<const int4*>(a.qtab + ((long long)co * 9 + tap) * Cin + cc * 32);
-    const unsigned w4[4] = {sp.x, sp.y, sp.z, sp.w};
+  if (SPK_V2_FIX_LDS && a.fix_lds) {
+    // the channel's weights, once per neuron: [9][Cin] int32 (the previous neuron's readers are behind its last barrier)
+    const int4* src = reinterpret_cast<const int4*>(a.qtab + (long long)co * 9 * Cin);
+    for (int i = tid; i < 9 * Cin / 4; i += (int)blockDim.x) reinterpret_cast<int4*>(sQ)[i] = src[i];
+    __syncthreads();
+    const int wave = tid >> 6, nwv = (int)blockDim.x >> 6, t = lane & 15, q = lane >> 4;
+    for (int pr = wave; pr < 9 * nch; pr += nwv) {          // a wave: one (tap, chunk) per trip; lane = (t, channels 8 q .. 8 q + 7)
+      const int cc = pr % nch, tap = pr / nch;
+      const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+      const unsigned nib = *reinterpret_cast<const unsigned*>(a.in0 + (((long long)b * nch + cc) * HW + yy * W + xx) * POSB + t * 16 + 4 * q);
+      const int4* qp = reinterpret_cast<const int4*>(sQ + tap * Cin + cc * 32 + 8 * q);
+      const int4 q0 = qp[0], q1 = qp[1];
+      part += (nib & 0x0000000fu) ? (long long)q0.x : 0ll;
+      part += (nib & 0x000000f0u) ? (long long)q0.y : 0ll;
+      part += (nib & 0x00000f00u) ? (long long)q0.z : 0ll;
+      part += (nib & 0x0000f000u) ? (long long)q0.w : 0ll;
+      part += (nib & 0x000f0000u) ? (long long)q1.x : 0ll;
+      part += (nib & 0x00f00000u) ? (long long)q1.y : 0ll;
+      part += (nib & 0x0f000000u) ? (long long)q1.z : 0ll;
+      part += (nib & 0xf0000000u) ? (long long)q1.w : 0ll;
+    }
+  } else {
+    __syncthreads();
+    const int units = 9 * nch * 16;
+    for (int u = tid; u < units; u += (int)blockDim.x) {
+      const int t = u & 15, cc = (u >> 4) % nch, tap = (u >> 4) / nch;
+      const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+      const uint4 sp = *reinterpret_cast<const uint4*>(a.in0 + (((long long)b * nch + cc) * HW + yy * W + xx) * POSB + t * 16);
+      const int4* qp = reinterpret_cast<const int4*>(a.qtab + ((long long)co * 9 + tap) * Cin + cc * 32);
+      const unsigned w4[4] = {sp.x, sp.y, sp.z, sp.w};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int4 q = qp[j];
-      const unsigned nib = w4[j >> 1] >> (16 * (j & 1));     // four nibbles: channels 4j .. 4j + 3
-      part += (nib & 0x000fu) ? (long long)q.x : 0ll;
-      part += (nib & 0x00f0u) ? (long long)q.y : 0ll;
-      part += (nib & 0x0f00u) ? (long long)q.z : 0ll;
-      part += (nib & 0xf000u) ? (long long)q.w : 0ll;
+      for (int j = 0; j < 8; ++j) {
+        const int4 q = qp[j];
+        const unsigned nib = w4[j >> 1] >> (16 * (j & 1));     // four nibbles: channels 4j .. 4j + 3
+        part += (nib & 0x000fu) ? (long long)q.x : 0ll;
+        part += (nib & 0x00f0u) ? (long long)q.y : 0ll;
+        part += (nib & 0x0f00u) ? (long long)q.z : 0ll;
+        part += (nib & 0xf000u) ? (long long)q.w : 0ll;
+      }
     }
   }
   // lanes l, l + 16, l + 32, l + 48 of a wave hold the same time step (t = u & 15; the block size is a multiple of 64)
@@ -2299,12 +2333,12 @@ __device__ __forceinline__ void fixup_neuron(const V2Args& a, long long n, unsig
 
 template <int H, int W>
 __device__ __forceinline__ void fp6v2_fixup_body(const V2Args& a, long long n_words, const unsigned bid, const unsigned nb,
-                                                 unsigned long long* sS) {
+                                                 unsigned long long* sS, int* sQ) {
   if (SPK_V2_DBG & 64) return;
   const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
   const unsigned count = a.flags[a.handover ? 1 : 0];       // published by the main launch (fp6v2_handover), or live
   const unsigned nlist = count < a.flag_cap ? count : a.flag_cap;
-  for (unsigned e = bid; e < nlist; e += nb) fixup_neuron<H, W>(a, (long long)a.flags[2 + e], sS, Bn);
+  for (unsigned e = bid; e < nlist; e += nb) fixup_neuron<H, W>(a, (long long)a.flags[2 + e], sS, sQ, Bn);
   if (count > a.flag_cap) {
     // overflow path (more than flag_cap flagged neurons): the rest sit in the bitmap; scan a share of it, clear as we go
     unsigned* bm = a.flags + 2 + a.flag_cap;
@@ -2318,7 +2352,7 @@ __device__ __forceinline__ void fp6v2_fixup_body(const V2Args& a, long long n_wo
       while (wv) {
         const int bit = __ffs((int)wv) - 1;
         wv &= wv - 1;
-        fixup_neuron<H, W>(a, wi * 32 + bit, sS, Bn);
+        fixup_neuron<H, W>(a, wi * 32 + bit, sS, sQ, Bn);
       }
     }
   }
@@ -2456,13 +2490,15 @@ template <int H, int W, int PART>
 __global__ __launch_bounds__(256, PART == 3 ? 4 : 1) void fp6v2_tail_kernel(V2Args a, long long n_words, int n_lp) {
   __shared__ float red[(PART == 1 || PART == 3) ? 1 : (PART == 2 ? 9 : 3)][16][64];
   __shared__ unsigned long long sS[16];
+  extern __shared__ __attribute__((aligned(16))) uint8_t tail_lds[];          // repair: the neuron's weights (SPK_V2_FIX_LDS); PART 3: the shared tiles
+  int* const sQ = reinterpret_cast<int*>(tail_lds);
   if constexpr (PART == 3) {
     if ((int)blockIdx.x < n_lp) { if constexpr ((H * W) & 1) fp6v2_lastpos_shared_body<H, W>(a, (int)blockIdx.x); }
-    else fp6v2_fixup_body<H, W>(a, n_words, blockIdx.x - (unsigned)n_lp, gridDim.x - (unsigned)n_lp, sS);
+    else fp6v2_fixup_body<H, W>(a, n_words, blockIdx.x - (unsigned)n_lp, gridDim.x - (unsigned)n_lp, sS, sQ);
     (void)red;
   } else {
     if (PART == 2 || (PART == 0 && (int)blockIdx.x < n_lp)) fp6v2_lastpos_body<H, W, PART == 2>(a, (int)blockIdx.x, red);
-    else fp6v2_fixup_body<H, W>(a, n_words, blockIdx.x - (unsigned)n_lp, gridDim.x - (unsigned)n_lp, sS);
+    else fp6v2_fixup_body<H, W>(a, n_words, blockIdx.x - (unsigned)n_lp, gridDim.x - (unsigned)n_lp, sS, sQ);
   }
 }
 
@@ -2628,6 +2664,9 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
     a.cls_list = reinterpret_cast<const int*>(need + spk_need_off_list(B, need_R, need_r));
   }
   a.B = B; a.Cout = Cout; a.Cin = nch * CK;
+  const size_t fix_bytes = (size_t)9 * a.Cin * 4;             // (18 KB for the 512-channel layers)
+  a.fix_lds = SPK_V2_FIX_LDS && fix_bytes <= LPS_LDS ? 1 : 0;
+  const size_t fix_lds = a.fix_lds ? fix_bytes : 0;
   const int cus = spk_cu_count();
   const int G = Cout / 32;
   // XCD-aware walk: the largest power-of-two group count per XCD whose packed weights fit ~1.5 MB of its 4 MB L2
@@ -2663,8 +2702,8 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
     // the neurons that launch flagged (count in ws[1], ids still listed: idempotent), 4 = the last position of every image.
     if (parts == 2) {
       a.handover = 1;                                         // (read the published count, leave the live counter alone)
-      if (bands) hipLaunchKernelGGL((fp6v2_tail_kernel<8, 8, 1>), dim3(8 * cus), dim3(256), 0, stream, a, n_words, 0);
-      else hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7, 1>), dim3(8 * cus), dim3(256), 0, stream, a, n_words, 0);
+      if (bands) hipLaunchKernelGGL((fp6v2_tail_kernel<8, 8, 1>), dim3(8 * cus), dim3(256), fix_lds, stream, a, n_words, 0);
+      else hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7, 1>), dim3(8 * cus), dim3(256), fix_lds, stream, a, n_words, 0);
     } else if (parts == 4 && !bands) {
       a.handover = 1;                                         // (no re-arming)
       const int n_lp4 = ((B + 2 * SPK_V2_LP_PAIRS - 1) / (2 * SPK_V2_LP_PAIRS)) * G;
@@ -2678,7 +2717,7 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
     if (eight_b) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 8, true>), dim3(grid), dim3(512), lds8, stream, a);
     else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 4, true>), dim3(grid), dim3(256), lds, stream, a);
     SPK_LAUNCH_CHECK();
-    hipLaunchKernelGGL((fp6v2_tail_kernel<8, 8, 1>), dim3(8 * cus), dim3(256), 0, stream, a, n_words, 0);   // (even latent: repair only)
+    hipLaunchKernelGGL((fp6v2_tail_kernel<8, 8, 1>), dim3(8 * cus), dim3(256), fix_lds, stream, a, n_words, 0);   // (even latent: repair only)
     SPK_LAUNCH_CHECK();
     return SPK_OK;
   }
@@ -2737,11 +2776,11 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
     SPK_LAUNCH_CHECK();
   } else if (n_dyn_or_null || SPK_V2_MERGE_FULL) {
     // the sampler's active-set calls: few images, both parts are latency bound -- one launch (-17 us per reverse step)
-    hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7, 0>), dim3(n_lp + 8 * cus), dim3(256), 0, stream, a, n_words, n_lp);
+    hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7, 0>), dim3(n_lp + 8 * cus), dim3(256), fix_lds, stream, a, n_words, n_lp);
     SPK_LAUNCH_CHECK();
   } else {
     // full batches: both parts fill the device on their own; measured 1 % faster one after the other
-    hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7, 1>), dim3(8 * cus), dim3(256), 0, stream, a, n_words, 0);
+    hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7, 1>), dim3(8 * cus), dim3(256), fix_lds, stream, a, n_words, 0);
     SPK_LAUNCH_CHECK();
     hipLaunchKernelGGL((fp6v2_tail_kernel<7, 7, 2>), dim3(n_lp), dim3(256), 0, stream, a, n_words, n_lp);
     SPK_LAUNCH_CHECK();
