@@ -294,6 +294,36 @@ struct TinvArgs {
   const int* n_dyn;
 };
 
+// the sixteen spike bits of a neuron -> counts + the layer's output format.  Lanes are consecutive output channels (Cout % 16 == 0: the 16
+// lanes of a DPP row are 16 channels of ONE position); a 16x16 bit transpose per row gives lane t the 16 channel bits of step t
+__device__ __forceinline__ void tinv_store(const TinvArgs& a, unsigned mybits, int b, int op, int co, int lane, bool ok, int plane) {
+  if (a.out_cnt && ok) a.out_cnt[(((long long)b * (a.Cout >> 5) + (co >> 5)) * plane + op) * 32 + (co & 31)] = (uint8_t)__popc(mybits);
+  const unsigned bitsv = spk_transpose16_rows(mybits, lane);
+  const int tl = lane & 15, co16 = co & ~15;
+  if (!ok) return;
+  if (a.out_c4) {
+    auto spread8 = [](unsigned x) -> unsigned {        // bit k -> nibble k, as the e2m1 code of 1.0 (0x2)
+      x = (x | (x << 12)) & 0x000f000fu;
+      x = (x | (x << 6)) & 0x03030303u;
+      x = (x | (x << 3)) & 0x11111111u;
+      return x << 1;
+    };
+    uint2 o;
+    o.x = spread8(bitsv & 0xffu);
+    o.y = spread8((bitsv >> 8) & 0xffu);
+    uint8_t* dst = a.out + ((((long long)b * (a.Cout / a.out_c4) + (co16 / a.out_c4)) * plane + op) * 16 + tl) * (a.out_c4 >> 1) +
+                   ((co16 % a.out_c4) >> 1);
+    *reinterpret_cast<uint2*>(dst) = o;
+  } else {
+    uint4 o;
+    o.x = ((bitsv & 0xfu) * 0x00204081u) & 0x01010101u;
+    o.y = (((bitsv >> 4) & 0xfu) * 0x00204081u) & 0x01010101u;
+    o.z = (((bitsv >> 8) & 0xfu) * 0x00204081u) & 0x01010101u;
+    o.w = (((bitsv >> 12) & 0xfu) * 0x00204081u) & 0x01010101u;
+    *reinterpret_cast<uint4*>(a.out + (((long long)b * plane + op) * 16 + tl) * a.Cout + co16) = o;
+  }
+}
+
 // KC > 0: k = KS and Cin = KC are compile-time and the thread's KS * KS * KC weights live in registers
 template <int KS, int KC>
 __global__ __launch_bounds__(256) void tinv_lif_kernel(TinvArgs a) {
@@ -386,32 +416,77 @@ __global__ __launch_bounds__(256) void tinv_lif_kernel(TinvArgs a) {
     } else {
       mybits = spk_lif_const_input_bits16(y0, s_th, s_pat);
     }
-    if (a.out_cnt && ok) a.out_cnt[(((long long)b * (a.Cout >> 5) + (co >> 5)) * plane + op) * 32 + (co & 31)] = (uint8_t)__popc(mybits);
-    // lanes are consecutive output channels (Cout % 16 == 0: the 16 lanes of a DPP row are 16 channels of ONE position); a
-    // 16x16 bit transpose per row gives lane t the 16 channel bits of step t
-    const unsigned bitsv = spk_transpose16_rows(mybits, lane);
-    const int tl = lane & 15, co16 = co & ~15;
-    if (!ok) continue;
-    if (a.out_c4) {
-      auto spread8 = [](unsigned x) -> unsigned {        // bit k -> nibble k, as the e2m1 code of 1.0 (0x2)
-        x = (x | (x << 12)) & 0x000f000fu;
-        x = (x | (x << 6)) & 0x03030303u;
-        x = (x | (x << 3)) & 0x11111111u;
-        return x << 1;
-      };
-      uint2 o;
-      o.x = spread8(bitsv & 0xffu);
-      o.y = spread8((bitsv >> 8) & 0xffu);
-      uint8_t* dst = a.out + ((((long long)b * (a.Cout / a.out_c4) + (co16 / a.out_c4)) * plane + op) * 16 + tl) * (a.out_c4 >> 1) +
-                     ((co16 % a.out_c4) >> 1);
-      *reinterpret_cast<uint2*>(dst) = o;
-    } else {
-      uint4 o;
-      o.x = ((bitsv & 0xfu) * 0x00204081u) & 0x01010101u;
-      o.y = (((bitsv >> 4) & 0xfu) * 0x00204081u) & 0x01010101u;
-      o.z = (((bitsv >> 8) & 0xfu) * 0x00204081u) & 0x01010101u;
-      o.w = (((bitsv >> 12) & 0xfu) * 0x00204081u) & 0x01010101u;
-      *reinterpret_cast<uint4*>(a.out + (((long long)b * plane + op) * 16 + tl) * a.Cout + co16) = o;
+    tinv_store(a, mybits, b, op, co, lane, ok, plane);
+  }
+}
+
+// Round 5: the same layer with the per-POSITION work done once per position.  In tinv_lif_kernel a thread is a (position, channel) pair
+// and every one of the Cout lanes of a position repeats its index arithmetic, bounds tests, pixel requests and fp32 -> fp64 conversions:
+// 225 vector instructions per wave and pair of positions for 18 multiply-adds each (rocprofv3 --pmc: 22.6 M vector instructions per launch
+// of the encoder's first layer at B = 1024).  Here 128 threads of the block first take one position each of a chunk of 128 -- indices,
+// KS * KS * KC pixels, converted -- and leave them in LDS as doubles; then every thread keeps its channel, walks the chunk's positions and
+// reads a position's pixels with broadcast LDS reads.  Same arithmetic in the same order (fp64 accumulation over ky, kx, ci from the bias;
+// an out-of-image tap adds an exact zero).  Stateless calls only (v = 0 at step 0: the spike train is the table look-up).
+template <int KS, int KC>
+__global__ __launch_bounds__(256) void tinv_lif_staged_kernel(TinvArgs a) {
+  constexpr int NX = KS * KS * KC, PB = 128;
+  __shared__ double sX[PB][NX];
+  __shared__ int sB[PB], sOp[PB];
+  __shared__ float s_th[16];
+  __shared__ unsigned s_pat[18];
+  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
+  const int co = threadIdx.x % a.Cout, pl = threadIdx.x / a.Cout, ppb = 256 / a.Cout;
+  const int plane = a.Ho * a.Wo;
+  const int npos = Bn * plane;
+  const float al = a.bn_a[co], be = a.bn_b[co];
+  const double b0 = a.bias ? (double)a.bias[co] : 0.0;
+  const int lane = threadIdx.x & 63;
+  double wreg[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) wreg[i] = (double)a.wt[i * a.Cout + co];      // packed [k*k][Cin][Cout]
+  const int HWi = a.H * a.W;
+  {
+    constexpr unsigned thb[16] = SPK_LIF_CONST_TH_BITS, pat[18] = SPK_LIF_CONST_PATTERNS;
+    if (threadIdx.x < 16) s_th[threadIdx.x] = __uint_as_float(thb[threadIdx.x]);
+    if (threadIdx.x < 18) s_pat[threadIdx.x] = pat[threadIdx.x];
+  }
+  for (int c0 = blockIdx.x * PB; c0 < npos; c0 += gridDim.x * PB) {
+    __syncthreads();                                         // the previous chunk's readers are done (first trip: the tables are in)
+    if (threadIdx.x < PB) {
+      const int pg = c0 + (int)threadIdx.x;
+      const int pc = pg < npos ? pg : npos - 1;
+      const int b = pc / plane, op = pc - b * plane;
+      const int oy = op / a.Wo, ox = op - oy * a.Wo;
+      sB[threadIdx.x] = b; sOp[threadIdx.x] = op;
+      const float* xb = a.x + (long long)b * KC * HWi;
+      float xv[NX];
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky) {
+        const int iy = oy * a.stride - a.pad + ky;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          const int ix = ox * a.stride - a.pad + kx;
+          const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+          const int off = in ? iy * a.W + ix : 0;
+#pragma unroll
+          for (int ci = 0; ci < KC; ++ci) {
+            const float ld = xb[ci * HWi + off];             // (unconditional request from a clamped address + select, as above)
+            xv[(ky * KS + kx) * KC + ci] = in ? ld : 0.0f;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) sX[threadIdx.x][i] = (double)xv[i];
+    }
+    __syncthreads();
+    for (int j = pl; j < PB; j += ppb) {
+      const bool ok = c0 + j < npos;
+      double acc = b0;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) acc = fma(sX[j][i], wreg[i], acc);          // (fp32 x fp32 is exact in fp64: == acc + x * w)
+      const float y0 = fmaf((float)acc, al, be);
+      const unsigned mybits = spk_lif_const_input_bits16(y0, s_th, s_pat);
+      tinv_store(a, mybits, sB[j], sOp[j], co, lane, ok, plane);
     }
   }
 }
@@ -530,7 +605,16 @@ extern "C" int spk_conv_fused_fwd(const void* in0, const uint8_t* in1, int C0, i
     const long long steps = ((long long)B * a.Ho * a.Wo + (256 / Cout) - 1) / (256 / Cout);
     const long long cap = 256 * 16;
     const dim3 tg((unsigned)(steps < cap ? steps : cap)), tb(256);
-    if (k == 3 && C0 == 1) hipLaunchKernelGGL((tinv_lif_kernel<3, 1>), tg, tb, 0, stream, t);            // encoder conv1
+#ifndef SPK_TINV_STAGED
+#define SPK_TINV_STAGED 1       // 1: stateless 3x3 calls take tinv_lif_staged_kernel (per-position work once per position, pixels through LDS)
+#endif
+    const long long chunks = ((long long)B * a.Ho * a.Wo + 127) / 128;
+    const dim3 sg((unsigned)(chunks < 256 * 8 ? chunks : 256 * 8));
+    if (SPK_TINV_STAGED && k == 3 && C0 == 1 && !v_inout) hipLaunchKernelGGL((tinv_lif_staged_kernel<3, 1>), sg, tb, 0, stream, t);
+    else if (SPK_TINV_STAGED && k == 3 && C0 == 3 && !v_inout) hipLaunchKernelGGL((tinv_lif_staged_kernel<3, 3>), sg, tb, 0, stream, t);
+    else if (SPK_TINV_STAGED && k == 3 && C0 == 2 && !v_inout) hipLaunchKernelGGL((tinv_lif_staged_kernel<3, 2>), sg, tb, 0, stream, t);
+    else if (SPK_TINV_STAGED && k == 1 && C0 == 16 && !v_inout) hipLaunchKernelGGL((tinv_lif_staged_kernel<1, 16>), sg, tb, 0, stream, t);   // spike generator
+    else if (k == 3 && C0 == 1) hipLaunchKernelGGL((tinv_lif_kernel<3, 1>), tg, tb, 0, stream, t);       // encoder conv1
     else if (k == 3 && C0 == 3) hipLaunchKernelGGL((tinv_lif_kernel<3, 3>), tg, tb, 0, stream, t);       // ... on RGB
     else if (k == 3 && C0 == 2) hipLaunchKernelGGL((tinv_lif_kernel<3, 2>), tg, tb, 0, stream, t);       // denoiser conv1
     else hipLaunchKernelGGL((tinv_lif_kernel<0, 0>), tg, tb, 0, stream, t);                               // (spike generator: 1x1, 16 channels -- measured faster with the weights left in L1)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # same-box A/B of library variants on the encode -> decode path (BASELINE configs[2], B = 1024): end-to-end rate (alternating passes),
 # the vae_fp6 launches under rocprofv3 --kernel-trace --stats, and the vae_fp6-against-int8 equality tests per variant.
-# usage: tools/vae_ab.sh <label>=<lib.so | default> ...
+# usage: [VAE_AB_KERNELS=vae_fp6,tinv_lif,...] tools/vae_ab.sh <label>=<lib.so | default> ...
 R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
 O=$R/gpurun_out/vae_ab; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -21,7 +21,8 @@ for spec in "$@"; do
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*_kernel_stats.csv")[0]
 for r in csv.DictReader(open(f)):
-    if "vae_fp6" in r["Name"]:
+    import os
+    if any(k in r["Name"] for k in os.environ.get("VAE_AB_KERNELS", "vae_fp6").split(",")):
         print("   %-60s calls %4s avg %8.1f" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
   (cd $R && python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "vae_fp6 or f3_ or f4_ or f2_" 2>&1 | grep -v PARITY | tail -1)
