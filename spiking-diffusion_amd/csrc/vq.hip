@@ -215,7 +215,10 @@ extern "C" int spk_vq_readout_argmin(const uint8_t* z_ptc, const float* coef, co
   const size_t lds64 = ((size_t)K * (D + 1) + (size_t)K) * sizeof(double);
   if (D == 16 && T == 16 && lds64 <= 64 * 1024) {
     int g16 = (int)((npos + 15) / 16);
-    if (g16 > 4096) g16 = 4096;                              // (one group of four positions per wave: the loads of all of them overlap)
+#ifndef SPK_VQ16_GRID
+#define SPK_VQ16_GRID 4096
+#endif
+    if (g16 > SPK_VQ16_GRID) g16 = SPK_VQ16_GRID;            // (one group of four positions per wave: the loads of all of them overlap)
     hipLaunchKernelGGL(vq16_kernel, dim3(g16), dim3(256), lds64, stream, z_ptc, coef, alpha, codebook, idx_out, zq_out_bdhw,
                        xm_out, B, HW, K);
   } else if (D == 16)
