@@ -549,13 +549,16 @@ __global__ __launch_bounds__(256) void readout_collapsed_kernel(ROArgs a) {
 // form above (two 16-byte reads per four FMAs).  Here a thread computes FOUR adjacent output pixels for a quarter of the input
 // channels: per kernel row the six input columns they share are read once (12 reads) and every weight vector serves four
 // pixels (6 reads): 54 reads per 288 FMAs.  The image rows sit in LDS with one zero column on either side (no edge tests).
-template <int CIN, int RB>
+// (WC: the image width as a compile-time constant, 0 = a.W: with a runtime width the two index decodes per staged chunk are integer
+//  divisions by a runtime value, ~80 vector instructions each -- rocprofv3 --pmc counted 16.9 M vector instructions per launch at B = 1024
+//  for 3.6 M wave-FMAs)
+template <int CIN, int RB, int WC>
 __global__ __launch_bounds__(256) void readout_collapsed_k3_kernel(ROArgs a) {
   extern __shared__ __attribute__((aligned(16))) float ro_lds[];
   constexpr int Cp = CIN + 4, CQ = CIN / 4, ROWS = RB + 2;
   const int nband = (a.H + RB - 1) / RB;
   const int b = blockIdx.x / nband, y0 = (blockIdx.x % nband) * RB;
-  const int Wp = a.W + 2;
+  const int Wp = (WC ? WC : a.W) + 2;
   float* sx = ro_lds;                                         // [ROWS][W + 2][Cp]
   float* sw = ro_lds + ROWS * Wp * Cp;                        // [Cout][9][CIN]  (taps as a plain correlation)
   for (int i = threadIdx.x; i < a.Cout * 9 * CIN; i += 256) {
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(256) void readout_collapsed_k3_kernel(ROArgs a) {
   }
   __syncthreads();
   const int part = threadIdx.x & 3, u = threadIdx.x >> 2;
-  const int nq = a.W >> 2;
+  const int nq = (WC ? WC : a.W) >> 2;
   const int quad = u % nq, ry = u / nq;
   const bool active = ry < RB;                                // (no barrier below: idle threads just skip the stores)
   const int ryc = active ? ry : 0;
@@ -657,8 +660,10 @@ extern "C" int spk_readout_collapsed_fwd(const float* x_bpc, const float* w, con
       const size_t lds3 = ((size_t)(rb + 2) * (W + 2) * (32 + 4) + (size_t)Cout * 9 * 32) * sizeof(float);
       const long long nb = (long long)B * ((H + rb - 1) / rb);
       if (lds3 <= 64 * 1024 && nb <= 0x7fffffffLL) {
-        if (r7) hipLaunchKernelGGL((readout_collapsed_k3_kernel<32, 7>), dim3((unsigned)nb), dim3(256), lds3, stream, a);
-        else hipLaunchKernelGGL((readout_collapsed_k3_kernel<32, 8>), dim3((unsigned)nb), dim3(256), lds3, stream, a);
+        if (r7 && W == 28) hipLaunchKernelGGL((readout_collapsed_k3_kernel<32, 7, 28>), dim3((unsigned)nb), dim3(256), lds3, stream, a);
+        else if (r7) hipLaunchKernelGGL((readout_collapsed_k3_kernel<32, 7, 0>), dim3((unsigned)nb), dim3(256), lds3, stream, a);
+        else if (W == 32) hipLaunchKernelGGL((readout_collapsed_k3_kernel<32, 8, 32>), dim3((unsigned)nb), dim3(256), lds3, stream, a);
+        else hipLaunchKernelGGL((readout_collapsed_k3_kernel<32, 8, 0>), dim3((unsigned)nb), dim3(256), lds3, stream, a);
         SPK_LAUNCH_CHECK();
         return SPK_OK;
       }
