@@ -464,7 +464,12 @@ int dispatch_gather2(const GArgs& a, hipStream_t stream) {
   const int nch = (a.Cin + 31) / 32;
   if (a.pad != a.k / 2 || a.B > 16000) return SPK_ERR_UNSUPPORTED;
   if (!a.transposed && a.k == 3 && a.stride == 2 && nch == 1) return launch_gather2<MODE, 3, 2, false, 1>(a, stream);   // enc conv2
-  if (!a.transposed && a.k == 1 && a.stride == 1 && nch == 2) return launch_gather2<MODE, 1, 1, false, 2, 3>(a, stream);   // enc conv3
+#ifndef SPK_G2_OCC_C3
+#define SPK_G2_OCC_C3 6         // waves per SIMD the 1x1 layer's register allocation leaves room for: its tasks are one dependent round trip each, the
+                                // launch is waves in flight.  3 (round 3: 90 registers, five waves) / 6 (80 registers, 8 dwords of scratch) / 8 (64
+                                // registers, 629 dwords of scratch): 43.7 / 35.8 / 580 us at B = 1024 (profiles/r5_ab_kernel_variants.txt (9))
+#endif
+  if (!a.transposed && a.k == 1 && a.stride == 1 && nch == 2) return launch_gather2<MODE, 1, 1, false, 2, SPK_G2_OCC_C3>(a, stream);   // enc conv3
   if (a.transposed && a.k == 3 && a.stride == 2 && nch == 1) return launch_gather2<MODE, 3, 2, true, 1, 3>(a, stream);     // dec convT1
   if (a.transposed && a.k == 3 && a.stride == 2 && nch == 2) return launch_gather2<MODE, 3, 2, true, 2, 3>(a, stream);     // dec convT2
   if (a.transposed && a.k == 3 && a.stride == 1 && nch == 1) return launch_gather2<MODE, 3, 1, true, 1>(a, stream);     // dec convT3
