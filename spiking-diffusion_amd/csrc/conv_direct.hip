@@ -427,9 +427,12 @@ __global__ __launch_bounds__(256) void tinv_lif_kernel(TinvArgs a) {
 // KS * KS * KC pixels, converted -- and leave them in LDS as doubles; then every thread keeps its channel, walks the chunk's positions and
 // reads a position's pixels with broadcast LDS reads.  Same arithmetic in the same order (fp64 accumulation over ky, kx, ci from the bias;
 // an out-of-image tap adds an exact zero).  Stateless calls only (v = 0 at step 0: the spike train is the table look-up).
+#ifndef SPK_TINV_PB
+#define SPK_TINV_PB 64          // positions per chunk (<= 256): 32 / 64 / 128 / 256 measured below (profiles/r5_ab_kernel_variants.txt (9))
+#endif
 template <int KS, int KC>
 __global__ __launch_bounds__(256) void tinv_lif_staged_kernel(TinvArgs a) {
-  constexpr int NX = KS * KS * KC, PB = 128;
+  constexpr int NX = KS * KS * KC, PB = SPK_TINV_PB;
   __shared__ double sX[PB][NX];
   __shared__ int sB[PB], sOp[PB];
   __shared__ float s_th[16];
@@ -608,7 +611,7 @@ extern "C" int spk_conv_fused_fwd(const void* in0, const uint8_t* in1, int C0, i
 #ifndef SPK_TINV_STAGED
 #define SPK_TINV_STAGED 1       // 1: stateless 3x3 calls take tinv_lif_staged_kernel (per-position work once per position, pixels through LDS)
 #endif
-    const long long chunks = ((long long)B * a.Ho * a.Wo + 127) / 128;
+    const long long chunks = ((long long)B * a.Ho * a.Wo + SPK_TINV_PB - 1) / SPK_TINV_PB;
     const dim3 sg((unsigned)(chunks < 256 * 8 ? chunks : 256 * 8));
     if (SPK_TINV_STAGED && k == 3 && C0 == 1 && !v_inout) hipLaunchKernelGGL((tinv_lif_staged_kernel<3, 1>), sg, tb, 0, stream, t);
     else if (SPK_TINV_STAGED && k == 3 && C0 == 3 && !v_inout) hipLaunchKernelGGL((tinv_lif_staged_kernel<3, 3>), sg, tb, 0, stream, t);
