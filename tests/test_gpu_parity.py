@@ -2229,6 +2229,25 @@ def test_constant_input_lif_lookup_equals_the_scan_on_every_float_around_1_2():
 
 
 @pytest.mark.gpu
+def test_staged_time_invariant_layer_equals_the_stepwise_kernel():
+    """tinv_lif_staged_kernel (round 5: a chunk's positions staged once in LDS, every thread keeps its channel; stateless calls of the 3x3
+    first layers and of the 1x1 spike generator) against tinv_lif_kernel running the sixteen steps (the same call with a carried membrane
+    state of zeros): ragged shapes -- partial chunks, both strides, 1 / 2 / 3 input channels, 16 / 32 / 64 output channels -- bit for bit."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("tinv_stress", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "tinv_stress.py"))
+    ts = importlib.util.module_from_spec(spec); spec.loader.exec_module(ts)
+    g = torch.Generator().manual_seed(5)
+    dev = torch.device("cuda")
+    bad = tot = 0
+    for _ in range(40):
+        m, e, _f = ts.one_case(g, dev)
+        bad += m; tot += e
+    parity("tinv_staged_vs_stepwise", spikes=tot, mismatches=bad)
+    assert bad == 0
+
+
+@pytest.mark.gpu
 def test_two_live_sampler_graphs_on_one_model_replay_independently(dev):
     """Two samplers (dense and elimination forms) on ONE denoiser, both replaying captured hipGraphs, interleaved over several
     seeds: every replay must equal the eager loop.  (Regression: buffers a captured graph addresses by raw pointer -- the

@@ -13,5 +13,6 @@ SPKDIFF_V2_WAVES=12 run python tools/fp6v2_stress.py 40 32
 SPKDIFF_V2_DUO=1 run python tools/fp6v2_stress.py 40 32
 SPKDIFF_V2_DEFER=1 run python tools/fp6v2_stress.py 40 32
 run python tools/backward_stress.py 90 7
+run python tools/tinv_stress.py 400 1
 } > gpurun_out/${TAG}_stress_final.txt 2>&1
 cat gpurun_out/${TAG}_stress_final.txt
