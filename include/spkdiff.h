@@ -29,9 +29,9 @@ extern "C" {
 
 typedef struct ihipStream_t* spk_stream_t; /* == hipStream_t */
 
-#define SPK_VERSION 102 /* 0.1.2 -- bumped whenever an exported signature changes or entry points are added (round 4 inserted `int K`
+#define SPK_VERSION 103 /* 0.1.3 -- bumped whenever an exported signature changes or entry points are added (round 4 inserted `int K`
                            * before the stream of spk_select_active / spk_select_needed: 101; round 5 added the VectorQuantizer's
-                           * training branch and the training convolutions: 102); spkdiff/_lib.py refuses a library whose
+                           * training branch and the training convolutions: 102, the token-table spike generator: 103); spkdiff/_lib.py refuses a library whose
                            * spk_version() differs from the signatures it declares */
 
 /* fused-kernel epilogue modes (spk_conv_fused_fwd) */
@@ -375,6 +375,16 @@ int spk_vae_fp6_pack(const float* w, const float* bias, uint8_t* wq, double* sca
                      int transposed, spk_stream_t stream);
 long long spk_vae_fp6_flag_words(int B, int Cout, int Ho, int Wo);
 int spk_ptc_to_s32(const uint8_t* in_ptc, uint8_t* out_s32, int T, int B, int HW, int C, spk_stream_t stream);
+/* The decoder's front end by token (R/main.py:388-392, R/snn_model/vae_model.py:54-56,66-71: embedding look-up, repeat(T), the 'poisson'
+ * spike generator = 1x1 Conv2d + BN + LIF from the reset state): the generator's input at a position is one of the K codebook rows, so
+ * its spike train is one of K patterns per output channel.  One call = a K-row pattern table (the arithmetic of spk_conv_fused_fwd's
+ * time-invariant form: fp64 dot product from the bias, BN fma, sixteen LIF steps; an out-of-range token embeds as NaN: no spikes) and
+ * the S32 spikes [n_positions][16][16 B] of the positions' tokens -- the input layout of spk_vae_fp6_fwd (Cout 16 or 32, T == 16).
+ * w_packed: [1][D][Cout] (spk_pack_conv_weight); table_ws: spk_spikegen_table_bytes(K, Cout) bytes of scratch. */
+long long spk_spikegen_table_bytes(int K, int Cout);
+int spk_spikegen_tokens_s32(const long long* tokens, const float* codebook, const float* w_packed, const float* bias, const float* bn_a,
+                            const float* bn_b, unsigned short* table_ws, uint8_t* out_s32, int T, long long n_positions, int K, int D,
+                            int Cout, spk_stream_t stream);
 int spk_vae_fp6_fwd(const uint8_t* in_s32, const uint8_t* wq, const double* scale, const double* bias_d, const int* qtab,
                     const float* bn_a, const float* bn_b, const float* coef_or_null, void* out, int out_kind, unsigned* flag_words,
                     int T, int B, int H, int W, int Cin, int Cout, int transposed, spk_stream_t stream);

@@ -494,6 +494,81 @@ __global__ __launch_bounds__(256) void tinv_lif_staged_kernel(TinvArgs a) {
   }
 }
 
+// Round 5: the decoder's front end -- embedding gather, spike generator (1x1 convolution of the code vector + BN + LIF from the reset state
+// on a constant input) and the nibble packing of its spikes -- as a table look-up by TOKEN.  The generator's input at a position is one of
+// the K codebook rows, so its sixteen-step spike train per output channel is one of K patterns: spikegen_table_kernel computes them with
+// the arithmetic of tinv_lif_kernel (fp64 dot product over the code's components from the bias, BN fma, the constant-input look-up; row K
+// = an out-of-range token, whose embedding is NaN: no spikes), spikegen_expand_kernel writes a position's S32 records from its token's row.
+// Replaces three launches (embedding 6 us, generator 12 us, PTC -> S32 6 us at B = 1024) and 13 MB of intermediate spikes.
+__global__ __launch_bounds__(256) void spikegen_table_kernel(const float* __restrict__ cb, const float* __restrict__ wt, const float* __restrict__ bias,
+                                                             const float* __restrict__ bn_a, const float* __restrict__ bn_b,
+                                                             unsigned short* __restrict__ table, int K, int D, int Cout) {
+  __shared__ float s_th[16];
+  __shared__ unsigned s_pat[18];
+  {
+    constexpr unsigned thb[16] = SPK_LIF_CONST_TH_BITS, pat[18] = SPK_LIF_CONST_PATTERNS;
+    if (threadIdx.x < 16) s_th[threadIdx.x] = __uint_as_float(thb[threadIdx.x]);
+    if (threadIdx.x < 18) s_pat[threadIdx.x] = pat[threadIdx.x];
+  }
+  __syncthreads();
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (K + 1) * Cout; i += gridDim.x * blockDim.x) {
+    const int k = i / Cout, co = i - k * Cout;
+    double acc = bias ? (double)bias[co] : 0.0;
+    for (int c0 = 0; c0 < D; c0 += 16) {                     // (sixteen components requested at once; beyond D: exact zeros)
+      float xv[16], wv[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int ci = c0 + j;
+        const bool in = ci < D;
+        const float xl = cb[(k < K ? k : 0) * D + (in ? ci : 0)], wl = wt[(in ? ci : 0) * Cout + co];      // packed [1][D][Cout]
+        xv[j] = in ? (k < K ? xl : __builtin_nanf("")) : 0.0f;
+        wv[j] = in ? wl : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (c0 + j < D) acc = fma((double)xv[j], (double)wv[j], acc);
+    }
+    const float y0 = fmaf((float)acc, bn_a[co], bn_b[co]);
+    table[i] = (unsigned short)spk_lif_const_input_bits16(y0, s_th, s_pat);
+  }
+}
+
+template <int COUT>
+__global__ __launch_bounds__(256) void spikegen_expand_kernel(const long long* __restrict__ tok, const unsigned short* __restrict__ table,
+                                                              uint8_t* __restrict__ out, long long npos, int K) {
+  auto spread8 = [](unsigned x) -> unsigned {          // bit k -> nibble k, as the e2m1 code of 1.0 (0x2)
+    x = (x | (x << 12)) & 0x000f000fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return x << 1;
+  };
+  const long long total = npos * 16;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i >> 4;
+    const int t = (int)(i & 15);
+    const long long tk = tok[p];
+    const int row = (tk >= 0 && tk < K) ? (int)tk : K;
+    const uint4* rp = reinterpret_cast<const uint4*>(table + (long long)row * COUT);     // COUT u16 patterns: 32 / 64 bytes
+    unsigned mask = 0;
+#pragma unroll
+    for (int q = 0; q < COUT / 8; ++q) {
+      const uint4 v = rp[q];
+      const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        mask |= ((w4[j] >> t) & 1u) << (8 * q + 2 * j);
+        mask |= ((w4[j] >> (16 + t)) & 1u) << (8 * q + 2 * j + 1);
+      }
+    }
+    uint4 o;
+    o.x = spread8(mask & 0xffu);
+    o.y = spread8((mask >> 8) & 0xffu);
+    o.z = COUT > 16 ? spread8((mask >> 16) & 0xffu) : 0u;
+    o.w = COUT > 16 ? spread8((mask >> 24) & 0xffu) : 0u;
+    *reinterpret_cast<uint4*>(out + i * 16) = o;                                          // [position][t][16 B]
+  }
+}
+
 inline int grid_for(long long work_items) {
   long long g = (work_items + 255) / 256;
   const long long cap = 256 * 8 * 8;
@@ -628,4 +703,26 @@ extern "C" int spk_conv_fused_fwd(const void* in0, const uint8_t* in1, int C0, i
   if (in_kind == SPK_IN_SEQ)
     return transposed ? launch_mode<SPK_IN_SEQ, true>(a, mode, stream) : launch_mode<SPK_IN_SEQ, false>(a, mode, stream);
   return transposed ? launch_mode<SPK_IN_PTC, true>(a, mode, stream) : launch_mode<SPK_IN_PTC, false>(a, mode, stream);
+}
+
+extern "C" long long spk_spikegen_table_bytes(int K, int Cout) {
+  if (K <= 0 || (Cout != 16 && Cout != 32)) return -1;
+  return (long long)(K + 1) * Cout * 2;
+}
+
+extern "C" int spk_spikegen_tokens_s32(const long long* tokens, const float* codebook, const float* w_packed, const float* bias,
+                                       const float* bn_a, const float* bn_b, unsigned short* table_ws, uint8_t* out_s32, int T,
+                                       long long n_positions, int K, int D, int Cout, hipStream_t stream) {
+  if (!tokens || !codebook || !w_packed || !bn_a || !bn_b || !table_ws || !out_s32 || n_positions <= 0 || K <= 0 || D <= 0)
+    return SPK_ERR_ARG;
+  if (T != 16 || (Cout != 16 && Cout != 32)) return SPK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(spikegen_table_kernel, dim3(((K + 1) * Cout + 255) / 256), dim3(256), 0, stream, codebook, w_packed, bias, bn_a, bn_b,
+                     table_ws, K, D, Cout);
+  SPK_LAUNCH_CHECK();
+  const long long blocks = (n_positions * 16 + 255) / 256;
+  const dim3 g((unsigned)(blocks < 256 * 32 ? blocks : 256 * 32));
+  if (Cout == 16) hipLaunchKernelGGL((spikegen_expand_kernel<16>), g, dim3(256), 0, stream, tokens, table_ws, out_s32, n_positions, K);
+  else hipLaunchKernelGGL((spikegen_expand_kernel<32>), g, dim3(256), 0, stream, tokens, table_ws, out_s32, n_positions, K);
+  SPK_LAUNCH_CHECK();
+  return SPK_OK;
 }

@@ -170,6 +170,9 @@ class Decoder(nn.Module):
         return self.snn_convs(x)
 
 
+SPIKEGEN_BY_TOKEN = True     # decode_tokens: the spike generator as a per-token pattern table (False: embedding + generator + packing launches)
+
+
 class SNN_VQVAE(nn.Module):
     """VQ-VAE"""
 
@@ -228,13 +231,31 @@ class SNN_VQVAE(nn.Module):
         L = images.shape[-1] // 4
         return idx.reshape(images.shape[0], L, L)
 
+    def _decoder_takes_s32(self, T, h, w):
+        """Will the decoder's first layer take nibble-packed spikes (the fp6 transposed-convolution kernel, csrc/vae_fp6.hip)?"""
+        blocks = self.decoder.snn_convs._blocks()
+        if blocks is None or len(blocks) < 3 or T != 16:
+            return False
+        conv = blocks[-3][0]
+        from spkdiff.fused import conv_geometry, has_hooks
+        if has_hooks(conv) or len(blocks) != 3:
+            return False
+        geo = conv_geometry(conv)
+        return ops.vae_fp6_kind(conv.in_channels, conv.out_channels, geo['k'], geo['stride'], geo['pad'], geo['out_pad'],
+                                geo['transposed'], T, h, w) == ops.VAE_OUT_S32
+
     @torch.no_grad()
     def decode_tokens(self, tokens, T=16, want_u8=True):
         """tokens int64 [B,h,w] -> (pred fp32 [B,C,H,W] in (-1,1), uint8 image): the glue of R/main.py:388-401 as
         three launches (embedding gather, spike generator, fused decoder + read-out + tanh + uint8)."""
         B, h, w = tokens.shape
-        zq = ops.embedding(tokens, self.vq_layer.embeddings.weight, nchw_hw=(h, w))
-        e_ptc = self.vq_layer.poisson.run(zq, IN_TINV, final='ptc', T=T, stateful=False)['ptc']
+        e_ptc = None
+        if SPIKEGEN_BY_TOKEN and self._decoder_takes_s32(T, h, w):
+            # embedding + spike generator + nibble packing as a per-token pattern table (csrc/conv_direct.hip, spk_spikegen_tokens_s32)
+            e_ptc = self.vq_layer.poisson.tokens_to_s32(tokens, self.vq_layer.embeddings.weight, T=T)
+        if e_ptc is None:
+            zq = ops.embedding(tokens, self.vq_layer.embeddings.weight, nchw_hw=(h, w))
+            e_ptc = self.vq_layer.poisson.run(zq, IN_TINV, final='ptc', T=T, stateful=False)['ptc']
         r = self.decoder.snn_convs.run(e_ptc, IN_PTC, final='memout', coef=self.memout.coef.flatten(), apply_tanh=True,
                                        want_u8=want_u8, stateful=False)
         return r['f32'], r['u8']

@@ -119,6 +119,8 @@ _SIGS = {
     "spk_vae_fp6_pack": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "spk_vae_fp6_flag_words": (c_longlong, [c_int, c_int, c_int, c_int]),
     "spk_ptc_to_s32": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "spk_spikegen_table_bytes": (c_longlong, [c_int, c_int]),
+    "spk_spikegen_tokens_s32": (c_int, [P, P, P, P, P, P, P, P, c_int, c_longlong, c_int, c_int, c_int, P]),
     "spk_vae_fp6_fwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_select_needed_bytes": (c_longlong, [c_int, c_int]),
     "spk_select_needed": (c_int, [P, c_int, P, c_ulonglong, c_ulonglong, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
@@ -170,7 +172,7 @@ def version() -> int:
 
 # The signatures declared above are those of include/spkdiff.h at this version.  A stale libspkdiff.so or an SPKDIFF_LIB A/B
 # variant built from another header would take arguments at the wrong positions (silently wrong results): refuse it here.
-EXPECTED_VERSION = 102
+EXPECTED_VERSION = 103
 if version() != EXPECTED_VERSION:
     raise ImportError(f"spkdiff: {LIB_PATH} reports C-ABI version {version()}, this binding declares version "
                       f"{EXPECTED_VERSION} (include/spkdiff.h SPK_VERSION). Rebuild the library: make -C "

@@ -298,6 +298,18 @@ class FusedSequential(nn.Sequential):
                                        g2['transposed'], T, Ho, Wo)
 
     @staticmethod
+    def _next_convT_fp6_hw(block, H, W, geo, T):
+        """_next_convT_fp6 for a layer whose input map is H x W (S32 input: the map sits in dims 2, 3)."""
+        conv, bn, lif = block
+        if bn is None or lif is None or has_hooks(conv) or has_hooks(bn) or has_hooks(lif):
+            return False
+        g2 = conv_geometry(conv)
+        Ho = ops.conv_out_size(H, geo['k'], geo['stride'], geo['pad'], geo['transposed'], geo['out_pad'])
+        Wo = ops.conv_out_size(W, geo['k'], geo['stride'], geo['pad'], geo['transposed'], geo['out_pad'])
+        return ops.convT_fp6_supported(conv.in_channels, conv.out_channels, g2['k'], g2['stride'], g2['pad'], g2['out_pad'],
+                                       g2['transposed'], T, Ho, Wo)
+
+    @staticmethod
     def _collapsible(block, coef, T):
         """Can the conv-only read-out ``block`` take time-collapsed spikes (ops.readout_collapsed)?"""
         conv, bn, lif = block
@@ -306,6 +318,27 @@ class FusedSequential(nn.Sequential):
         geo = conv_geometry(conv)
         return (geo['stride'] == 1 and geo['k'] % 2 == 1 and geo['pad'] == geo['k'] // 2 and geo['out_pad'] == 0 and
                 conv.in_channels % 8 == 0 and ops.readout_collapsed_supported(conv.in_channels, conv.out_channels, geo['k']))
+
+    def tokens_to_s32(self, tokens, codebook, T=16):
+        """The spike generator container (one 1x1 Conv2d + BN + LIF block) applied to the code vectors of ``tokens`` [B,h,w], as
+        nibble-packed S32 spikes [B,1,h,w,16,16] by the per-token pattern table (ops.spikegen_tokens_s32): embedding look-up,
+        repeat(T), convolution, BN, LIF from the reset state and the PTC -> S32 packing in two launches.  None when the container
+        is not that block in fused-eval configuration (the caller then takes the layer-by-layer path)."""
+        blocks = self._blocks()
+        if not self._fusable(blocks) or len(blocks) != 1 or T != 16 or not tokens.is_cuda:
+            return None
+        conv, bn, lif = blocks[0]
+        if bn is None or lif is None or has_hooks(conv) or has_hooks(bn) or has_hooks(lif) or isinstance(conv, nn.ConvTranspose2d):
+            return None
+        geo = conv_geometry(conv)
+        if (geo['k'] != 1 or geo['stride'] != 1 or geo['pad'] != 0 or conv.out_channels not in (16, 32) or
+                conv.in_channels != codebook.shape[1]):
+            return None
+        if not hasattr(conv, '_spk_params'):
+            object.__setattr__(conv, '_spk_params', ConvParams())
+        a, b = bn.affine_terms()
+        bias = None if conv.bias is None else conv.bias.detach()
+        return ops.spikegen_tokens_s32(tokens, codebook, conv._spk_params.get(conv), bias, a, b, T=T)
 
     def run(self, x, in_kind, final='f32', T=None, in1=None, coef=None, apply_tanh=False, want_u8=False,
             stateful=True, want_pre=False, chunk_out=None, impl='auto', want_counts=False, need_radius=None):
@@ -351,6 +384,14 @@ class FusedSequential(nn.Sequential):
                         cur = ops.vae_fp6_fwd(cur, conv._spk_params.get_vae_fp6(conv), conv.out_channels, bn_a=a, bn_b=b,
                                               transposed=True, out_kind=vk, coef=coef)
                         kind = 'collapsed'
+                        continue
+                    if (vk == ops.VAE_OUT_S32 and bi == len(blocks) - 3 and tail_ok and conv.out_channels % 32 == 0 and
+                            self._next_convT_fp6_hw(blocks[bi + 1], cur.shape[2], cur.shape[3], geo, T)):
+                        # decoder convT1 fed nibble-packed spikes directly (the token-table spike generator)
+                        a, b = bn.affine_terms()
+                        cur = ops.vae_fp6_fwd(cur, conv._spk_params.get_vae_fp6(conv), conv.out_channels, bn_a=a, bn_b=b,
+                                              transposed=True, out_kind=ops.VAE_OUT_S32)
+                        kind = IN_PTC
                         continue
                     if vk == ops.VAE_OUT_PTC and not last:
                         a, b = bn.affine_terms()                  # encoder conv2: plain u8 PTC out for the 1x1 layer

@@ -1737,6 +1737,32 @@ def embedding(tokens, codebook, nchw_hw=None):
     return out
 
 
+_SPIKEGEN_WS = {}
+
+
+def spikegen_tokens_s32(tokens, codebook, w_packed, bias, bn_a, bn_b, T=16):
+    """tokens int64 [B,h,w] -> S32 spikes [B,1,h,w,16,16] of the spike generator (embedding + 1x1 conv + BN + LIF from the reset state on
+    the repeated code vector), by a per-token pattern table (spk_spikegen_tokens_s32).  w_packed: [1][D][Cout], Cout 16 or 32."""
+    tokens = _dev(tokens, "tokens", torch.int64)
+    codebook = _dev(codebook.detach(), "codebook", torch.float32)
+    K, D = codebook.shape
+    kk, Cin, Cout = w_packed.shape
+    if kk != 1 or Cin != D:
+        raise ValueError("a 1x1 generator over the code vector expected")
+    nbytes = lib.spk_spikegen_table_bytes(K, Cout)
+    if nbytes < 0 or T != 16:
+        raise NotImplementedError("spikegen_tokens_s32: Cout 16 or 32, T = 16")
+    key = (tokens.device, K, Cout)
+    ws = _SPIKEGEN_WS.get(key)
+    if ws is None:
+        ws = _SPIKEGEN_WS[key] = torch.empty(nbytes // 2, dtype=torch.int16, device=tokens.device)
+    B, h, w = tokens.shape
+    out = torch.empty((B, 1, h, w, T, 16), dtype=C4_DTYPE, device=tokens.device)
+    check(lib.spk_spikegen_tokens_s32(_p(tokens), _p(codebook), _p(w_packed), _p(bias), _p(bn_a), _p(bn_b), _p(ws), _p(out), T,
+                                      tokens.numel(), K, D, Cout, _stream(tokens)), "spk_spikegen_tokens_s32")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- sampler
 def den_build_input(x, t, out=None):
     """x: float [B,1,h,w] or int64 tokens; t: int64 [B] tensor or python int -> fp32 [B,2,h,w]."""

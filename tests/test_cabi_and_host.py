@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, n), f"{n} declared in include/spkdiff.h but not exported by libspkdiff.so"
         assert n in _lib.EXPORTS, f"{n} has no ctypes signature in spkdiff/_lib.py"
     assert set(_lib.EXPORTS) == set(names)
-    assert _lib.version() == _lib.EXPECTED_VERSION == 102
+    assert _lib.version() == _lib.EXPECTED_VERSION == 103
     assert _lib.lib.spk_error_string(-1).decode().startswith("spkdiff: invalid argument")
 
 

@@ -2248,6 +2248,44 @@ def test_staged_time_invariant_layer_equals_the_stepwise_kernel():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name", ["mnist", "cifar"])
+def test_spike_generator_by_token_table_equals_the_layer_by_layer_front_end(dev, cfg_name):
+    """decode_tokens' front end as a per-token pattern table (spk_spikegen_tokens_s32: embedding + 1x1 conv + BN + LIF from the reset
+    state + nibble packing in two launches) against the three launches it replaces (R/main.py:388-392, vae_model.py:54-56,66-71):
+    the S32 spikes bit for bit -- every token of the codebook, an out-of-range token (NaN embedding: no spikes) -- and the decoded
+    images of both paths equal."""
+    from snn_model import vae_model
+    from spkdiff import ops as O
+    from spkdiff.ops import IN_TINV
+    cfg = synth.MNIST if cfg_name == "mnist" else synth.CIFAR
+    model, _sd = build_vae(cfg, dev)
+    K, L = cfg.num_embeddings, cfg.latent
+    g = torch.Generator().manual_seed(3)
+    tokens = torch.randint(0, K, (5, L, L), generator=g)
+    tokens.view(-1)[:K] = torch.arange(K)                          # (5 L^2 >= 245 > K = 128: every code occurs)
+    tokens = tokens.to(dev)
+    s32 = model.vq_layer.poisson.tokens_to_s32(tokens, model.vq_layer.embeddings.weight, T=16)
+    assert s32 is not None
+    zq = O.embedding(tokens, model.vq_layer.embeddings.weight, nchw_hw=(L, L))
+    ptc = model.vq_layer.poisson.run(zq, IN_TINV, final='ptc', T=16, stateful=False)['ptc']
+    assert torch.equal(s32.view(torch.uint8), O.ptc_to_s32(ptc).view(torch.uint8))
+    bad_tok = tokens.clone(); bad_tok[0, 0, 0] = K; bad_tok[1, 1, 1] = -1
+    s32b = model.vq_layer.poisson.tokens_to_s32(bad_tok, model.vq_layer.embeddings.weight, T=16)
+    zqb = O.embedding(bad_tok, model.vq_layer.embeddings.weight, nchw_hw=(L, L))
+    ptcb = model.vq_layer.poisson.run(zqb, IN_TINV, final='ptc', T=16, stateful=False)['ptc']
+    assert torch.equal(s32b.view(torch.uint8), O.ptc_to_s32(ptcb).view(torch.uint8))
+    assert vae_model.SPIKEGEN_BY_TOKEN
+    f_t, u_t = model.decode_tokens(tokens, 16)
+    try:
+        vae_model.SPIKEGEN_BY_TOKEN = False
+        f_l, u_l = model.decode_tokens(tokens, 16)
+    finally:
+        vae_model.SPIKEGEN_BY_TOKEN = True
+    parity("spikegen_by_token_" + cfg_name, tokens=int(tokens.numel()), pixels_differing=int((u_t != u_l).sum()))
+    assert torch.equal(u_t, u_l) and torch.equal(f_t, f_l)
+
+
+@pytest.mark.gpu
 def test_two_live_sampler_graphs_on_one_model_replay_independently(dev):
     """Two samplers (dense and elimination forms) on ONE denoiser, both replaying captured hipGraphs, interleaved over several
     seeds: every replay must equal the eager loop.  (Regression: buffers a captured graph addresses by raw pointer -- the
