@@ -380,11 +380,12 @@ int spk_ptc_to_s32(const uint8_t* in_ptc, uint8_t* out_s32, int T, int B, int HW
  * its spike train is one of K patterns per output channel.  One call = a K-row pattern table (the arithmetic of spk_conv_fused_fwd's
  * time-invariant form: fp64 dot product from the bias, BN fma, sixteen LIF steps; an out-of-range token embeds as NaN: no spikes) and
  * the S32 spikes [n_positions][16][16 B] of the positions' tokens -- the input layout of spk_vae_fp6_fwd (Cout 16 or 32, T == 16).
- * w_packed: [1][D][Cout] (spk_pack_conv_weight); table_ws: spk_spikegen_table_bytes(K, Cout) bytes of scratch. */
+ * w_packed: [1][D][Cout] (spk_pack_conv_weight); table_ws: spk_spikegen_table_bytes(K, Cout) bytes, written when build_table != 0 and
+ * only read otherwise (the caller keeps it while codebook, weights and BN terms are unchanged). */
 long long spk_spikegen_table_bytes(int K, int Cout);
 int spk_spikegen_tokens_s32(const long long* tokens, const float* codebook, const float* w_packed, const float* bias, const float* bn_a,
-                            const float* bn_b, unsigned short* table_ws, uint8_t* out_s32, int T, long long n_positions, int K, int D,
-                            int Cout, spk_stream_t stream);
+                            const float* bn_b, unsigned short* table_ws, int build_table, uint8_t* out_s32, int T, long long n_positions,
+                            int K, int D, int Cout, spk_stream_t stream);
 int spk_vae_fp6_fwd(const uint8_t* in_s32, const uint8_t* wq, const double* scale, const double* bias_d, const int* qtab,
                     const float* bn_a, const float* bn_b, const float* coef_or_null, void* out, int out_kind, unsigned* flag_words,
                     int T, int B, int H, int W, int Cin, int Cout, int transposed, spk_stream_t stream);

@@ -711,14 +711,16 @@ extern "C" long long spk_spikegen_table_bytes(int K, int Cout) {
 }
 
 extern "C" int spk_spikegen_tokens_s32(const long long* tokens, const float* codebook, const float* w_packed, const float* bias,
-                                       const float* bn_a, const float* bn_b, unsigned short* table_ws, uint8_t* out_s32, int T,
-                                       long long n_positions, int K, int D, int Cout, hipStream_t stream) {
+                                       const float* bn_a, const float* bn_b, unsigned short* table_ws, int build_table,
+                                       uint8_t* out_s32, int T, long long n_positions, int K, int D, int Cout, hipStream_t stream) {
   if (!tokens || !codebook || !w_packed || !bn_a || !bn_b || !table_ws || !out_s32 || n_positions <= 0 || K <= 0 || D <= 0)
     return SPK_ERR_ARG;
   if (T != 16 || (Cout != 16 && Cout != 32)) return SPK_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(spikegen_table_kernel, dim3(((K + 1) * Cout + 255) / 256), dim3(256), 0, stream, codebook, w_packed, bias, bn_a, bn_b,
-                     table_ws, K, D, Cout);
-  SPK_LAUNCH_CHECK();
+  if (build_table) {                                          // (0: table_ws still holds the table of these weights and this codebook)
+    hipLaunchKernelGGL(spikegen_table_kernel, dim3(((K + 1) * Cout + 255) / 256), dim3(256), 0, stream, codebook, w_packed, bias, bn_a, bn_b,
+                       table_ws, K, D, Cout);
+    SPK_LAUNCH_CHECK();
+  }
   const long long blocks = (n_positions * 16 + 255) / 256;
   const dim3 g((unsigned)(blocks < 256 * 32 ? blocks : 256 * 32));
   if (Cout == 16) hipLaunchKernelGGL((spikegen_expand_kernel<16>), g, dim3(256), 0, stream, tokens, table_ws, out_s32, n_positions, K);

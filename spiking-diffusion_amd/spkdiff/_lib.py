@@ -120,7 +120,7 @@ _SIGS = {
     "spk_vae_fp6_flag_words": (c_longlong, [c_int, c_int, c_int, c_int]),
     "spk_ptc_to_s32": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spk_spikegen_table_bytes": (c_longlong, [c_int, c_int]),
-    "spk_spikegen_tokens_s32": (c_int, [P, P, P, P, P, P, P, P, c_int, c_longlong, c_int, c_int, c_int, P]),
+    "spk_spikegen_tokens_s32": (c_int, [P, P, P, P, P, P, P, c_int, P, c_int, c_longlong, c_int, c_int, c_int, P]),
     "spk_vae_fp6_fwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_select_needed_bytes": (c_longlong, [c_int, c_int]),
     "spk_select_needed": (c_int, [P, c_int, P, c_ulonglong, c_ulonglong, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

@@ -338,7 +338,10 @@ class FusedSequential(nn.Sequential):
             object.__setattr__(conv, '_spk_params', ConvParams())
         a, b = bn.affine_terms()
         bias = None if conv.bias is None else conv.bias.detach()
-        return ops.spikegen_tokens_s32(tokens, codebook, conv._spk_params.get(conv), bias, a, b, T=T)
+        packed = conv._spk_params.get(conv)
+        # (the table is kept while the parameter versions that went into it are unchanged -- the policy of every prepared-weight cache here)
+        key = (id(self), conv._spk_params.key, bn._affine_cache[0], _ver(codebook))
+        return ops.spikegen_tokens_s32(tokens, codebook, packed, bias, a, b, T=T, table_key=key)
 
     def run(self, x, in_kind, final='f32', T=None, in1=None, coef=None, apply_tanh=False, want_u8=False,
             stateful=True, want_pre=False, chunk_out=None, impl='auto', want_counts=False, need_radius=None):

@@ -1740,9 +1740,11 @@ def embedding(tokens, codebook, nchw_hw=None):
 _SPIKEGEN_WS = {}
 
 
-def spikegen_tokens_s32(tokens, codebook, w_packed, bias, bn_a, bn_b, T=16):
+def spikegen_tokens_s32(tokens, codebook, w_packed, bias, bn_a, bn_b, T=16, table_key=None):
     """tokens int64 [B,h,w] -> S32 spikes [B,1,h,w,16,16] of the spike generator (embedding + 1x1 conv + BN + LIF from the reset state on
-    the repeated code vector), by a per-token pattern table (spk_spikegen_tokens_s32).  w_packed: [1][D][Cout], Cout 16 or 32."""
+    the repeated code vector), by a per-token pattern table (spk_spikegen_tokens_s32).  w_packed: [1][D][Cout], Cout 16 or 32.
+    table_key: anything that changes whenever codebook, weights or BN terms do (the callers' parameter-version tuples); the table of
+    the previous call is reused while it is equal (None: rebuilt every call)."""
     tokens = _dev(tokens, "tokens", torch.int64)
     codebook = _dev(codebook.detach(), "codebook", torch.float32)
     K, D = codebook.shape
@@ -1753,13 +1755,16 @@ def spikegen_tokens_s32(tokens, codebook, w_packed, bias, bn_a, bn_b, T=16):
     if nbytes < 0 or T != 16:
         raise NotImplementedError("spikegen_tokens_s32: Cout 16 or 32, T = 16")
     key = (tokens.device, K, Cout)
-    ws = _SPIKEGEN_WS.get(key)
-    if ws is None:
-        ws = _SPIKEGEN_WS[key] = torch.empty(nbytes // 2, dtype=torch.int16, device=tokens.device)
+    ent = _SPIKEGEN_WS.get(key)
+    if ent is None:
+        ent = _SPIKEGEN_WS[key] = [torch.empty(nbytes // 2, dtype=torch.int16, device=tokens.device), None]
+    ws = ent[0]
+    build = table_key is None or ent[1] != table_key or torch.cuda.is_current_stream_capturing()
+    ent[1] = table_key
     B, h, w = tokens.shape
     out = torch.empty((B, 1, h, w, T, 16), dtype=C4_DTYPE, device=tokens.device)
-    check(lib.spk_spikegen_tokens_s32(_p(tokens), _p(codebook), _p(w_packed), _p(bias), _p(bn_a), _p(bn_b), _p(ws), _p(out), T,
-                                      tokens.numel(), K, D, Cout, _stream(tokens)), "spk_spikegen_tokens_s32")
+    check(lib.spk_spikegen_tokens_s32(_p(tokens), _p(codebook), _p(w_packed), _p(bias), _p(bn_a), _p(bn_b), _p(ws), int(build), _p(out),
+                                      T, tokens.numel(), K, D, Cout, _stream(tokens)), "spk_spikegen_tokens_s32")
     return out
 
 

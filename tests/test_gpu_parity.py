@@ -2283,6 +2283,17 @@ def test_spike_generator_by_token_table_equals_the_layer_by_layer_front_end(dev,
         vae_model.SPIKEGEN_BY_TOKEN = True
     parity("spikegen_by_token_" + cfg_name, tokens=int(tokens.numel()), pixels_differing=int((u_t != u_l).sum()))
     assert torch.equal(u_t, u_l) and torch.equal(f_t, f_l)
+    # the table is kept across calls while the parameters are unchanged: an in-place update of any of them must rebuild it
+    gen_conv = model.vq_layer.poisson[0]
+    with torch.no_grad():
+        gen_conv.weight.mul_(1.37)
+        model.vq_layer.embeddings.weight.add_(0.01)
+        model.vq_layer.poisson[1].running_mean.add_(0.02)
+    s32c = model.vq_layer.poisson.tokens_to_s32(tokens, model.vq_layer.embeddings.weight, T=16)
+    zqc = O.embedding(tokens, model.vq_layer.embeddings.weight, nchw_hw=(L, L))
+    ptcc = model.vq_layer.poisson.run(zqc, IN_TINV, final='ptc', T=16, stateful=False)['ptc']
+    assert torch.equal(s32c.view(torch.uint8), O.ptc_to_s32(ptcc).view(torch.uint8))
+    assert not torch.equal(s32c.view(torch.uint8), s32.view(torch.uint8))
 
 
 @pytest.mark.gpu
