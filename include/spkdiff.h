@@ -9,8 +9,9 @@
  *
  * Contract (all functions):
  *   - plain C types only; every pointer is a DEVICE pointer owned by the caller (PyTorch); the library never
- *     allocates or frees device memory, reads no environment variable and keeps no mutable global state of its own: the only
- *     process-wide values are the measurement options below, which exist only because the HOST sets them (spk_set_option);
+ *     allocates or frees device memory, reads no environment variable and keeps no mutable global state (the launch-shape
+ *     options of earlier rounds are compile-time constants here; only a `make variants` build -- include/spkdiff_variants.h --
+ *     keeps them settable, for repeating the recorded A/B measurements);
  *   - work is enqueued asynchronously on ``stream`` (a hipStream_t; pass torch.cuda.current_stream().cuda_stream);
  *   - returns 0 on success, SPK_ERR_* (< 0) for argument errors, a positive hipError_t for launch failures;
  *   - reentrant across streams and host threads.
@@ -29,9 +30,10 @@ extern "C" {
 
 typedef struct ihipStream_t* spk_stream_t; /* == hipStream_t */
 
-#define SPK_VERSION 103 /* 0.1.3 -- bumped whenever an exported signature changes or entry points are added (round 4 inserted `int K`
+#define SPK_VERSION 104 /* 0.1.4 -- bumped whenever an exported signature changes or entry points are added (round 4 inserted `int K`
                            * before the stream of spk_select_active / spk_select_needed: 101; round 5 added the VectorQuantizer's
-                           * training branch and the training convolutions: 102, the token-table spike generator: 103); spkdiff/_lib.py refuses a library whose
+                           * training branch and the training convolutions: 102, the token-table spike generator: 103; round 6: `int flag_cap` in front of the
+                           * stream of the four certified-kernel entry points, spk_set_option / spk_get_option left the shipped library: 104); spkdiff/_lib.py refuses a library whose
                            * spk_version() differs from the signatures it declares */
 
 /* fused-kernel epilogue modes (spk_conv_fused_fwd) */
@@ -51,30 +53,6 @@ int spk_version(void);
 /* Returns a static string for an SPK_ERR_* / hipError_t code. */
 const char* spk_error_string(int code);
 
-/* Measurement options: launch-shape choices that were measured against each other (DESIGN.md quotes the numbers) and stay
- * selectable so that the measurements can be repeated.  The library never reads the environment; a host that wants another
- * form calls spk_set_option (process-wide, relaxed atomics; every launch reads the current value, so a host may switch between
- * calls).  spkdiff/_lib.py forwards the SPKDIFF_<NAME> environment variables once at import for the A/B tools under tools/.
- *   name               default  meaning
- *   "v2_waves"            8     waves per workgroup of spk_den_conv3x3_mfma_fp6v2's main launch: 8 (two per SIMD), 4 (one), 12
- *                               (three, accumulators in VGPRs: measured -11 %)
- *   "v2_lag"              0     1: full 7x7 batches run the staggered form (waves 4..7 one chunk behind: measured 4-13 % slower)
- *   "v2_duo"              0     1: full 7x7 batches run two independent four-wave workgroups per CU on half-image items (one workgroup's
- *                               LIF scan beside the other's MFMAs: measured 4-5 % slower, profiles/r5_ab_duo_*.txt); >= 16: with a head
- *                               start of that many 10 ns ticks per chunk for a CU's first workgroup
- *   "v2_defer"            0     1: full 7x7 batches, layers of >= 4 chunks: the LIF scan of an item runs inside the K loop of the same
- *                               waves' next item (software pipelining across items: measured 11-40 % slower, profiles/r5_ab_defer_builds.txt);
- *                               0: scan between two K loops (rounds 2-4)
- *   "v2_lps"              1     7x7 latents: the tail launch's last-position part shares a chunk's weight tiles through LDS (eight images per
- *                               workgroup); 0: every image pair reads them from L2 (rounds 2-4)
- *   "fp6_waves"           4     8: spk_den_conv3x3_mfma_fp6 with two waves per SIMD where an item has <= 4 row tiles per wave
- *   "fp6_xcd_walk"        1     0: image-major item walk of spk_den_conv3x3_mfma_fp6 (2.2x the HBM-side traffic)
- *   "conv6_shared"        1     0: spk_den_conv3x3_counts_mfma never shares operands through LDS
- *   "conv6_shared_dyn"    1     0: ... not in the sampler's active-set calls
- *   "mfma_debug"          0     ablation builds (-DSPK_MFMA_ABLATION) only: 1 no steady-state DMA, 2 no MFMAs, 4 no epilogue
- * Returns SPK_ERR_UNSUPPORTED for an unknown name. */
-int spk_set_option(const char* name, int value);
-int spk_get_option(const char* name, int* value_out);
 
 /* ---- neuron surface -------------------------------------------------------------------------------------- */
 
@@ -289,10 +267,11 @@ int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, c
  * scale / bias [Cout] as for the fp6 kernel, wl1 [Cout] = L1 norm of each channel's quantised weights, and qtab = the
  * quantised weights themselves as int32 [Cout][9][Cin] (read by the exact recomputation).  flag_words: zero-initialised
  * u32 workspace of spk_den_fp6v2_flag_words(B, Cout, H, W) words (counter, ticket, id list, overflow bitmap); it is clean
- * again when the call's launches have run (word 1 keeps the number of neurons the call flagged, for statistics; behind the ticket
- * sit 2048 per-CU arrival counters of the two-workgroups-per-CU launch form -- only their parity is read: never reset -- and its 128
- * item-claim counters, zero again after the call).  One
+ * again when the call's launches have run (word 1 keeps the number of neurons the call flagged, for statistics).  One
  * workspace per stream: two calls in flight at once must not share it.
+ * flag_cap: how many flagged neurons the id list takes before the rest go to the overflow bitmap, which the tail launch scans and
+ * clears (< 0 or > 2^20: the whole list of 2^20 entries -- what every product call passes).  The workspace layout does not depend on
+ * it; the parity suite passes 64 and 0 so that the overflow path runs (tests/test_gpu_parity.py::test_flag_overflow_*).
  * SPK_ERR_UNSUPPORTED unless T == 16, H == W == 7 or 8, Cout % 32 == 0 (Cin = 32 * nch). */
 long long spk_den_packed_weight_fp6v2_bytes(int Cout, int Cin);
 int spk_den_pack_weight_fp6v2(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d, float* wl1,
@@ -301,7 +280,7 @@ long long spk_den_fp6v2_flag_words(int B, int Cout, int H, int W);
 int spk_den_conv3x3_mfma_fp6v2(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale, const double* bias_d,
                                const float* wl1, const int* qtab, const float* bn_a, const float* bn_b, uint8_t* out_s32,
                                uint8_t* out_counts, unsigned* flag_words, int T, int B, int H, int W, int Cout,
-                               const int* n_dyn_or_null, spk_stream_t stream);
+                               const int* n_dyn_or_null, int flag_cap, spk_stream_t stream);
 /* Measurement aid: re-run ONE tail part of the last spk_den_conv3x3_mfma_fp6v2 call on the same arguments and workspace --
  * part 2: the exact recomputation of the neurons that call flagged (flag_words[1] holds their number, the id list is intact;
  * recomputing them again writes the same spikes), part 4: the last position of every image (7x7).  bench.py times these to
@@ -310,7 +289,7 @@ int spk_den_conv3x3_mfma_fp6v2_part(const uint8_t* in_s32, int nch, const uint8_
                                     const double* bias_d, const float* wl1, const int* qtab, const float* bn_a,
                                     const float* bn_b, uint8_t* out_s32, uint8_t* out_counts_or_null, unsigned* flag_words,
                                     int T, int B, int H, int W, int Cout, const int* n_dyn_or_null, int part,
-                                    spk_stream_t stream);
+                                    int flag_cap, spk_stream_t stream);
 /* The same layer restricted to the positions the sampler will read (7x7 only): need = the buffer written by
  * spk_select_needed(..., R = need_radii) for the same B; radius (1..need_radii) selects the lists this layer computes --
  * 1 for the layer whose output the logits convolution reads, 2 for the one below it, ...  Listed positions (and the 49th)
@@ -319,7 +298,7 @@ int spk_den_conv3x3_mfma_fp6v2_listed(const uint8_t* in_s32, int nch, const uint
                                       const double* bias_d, const float* wl1, const int* qtab, const float* bn_a,
                                       const float* bn_b, uint8_t* out_s32, uint8_t* out_counts, unsigned* flag_words, int T,
                                       int B, int H, int W, int Cout, const int* n_dyn, const uint8_t* need, int need_radii,
-                                      int radius, spk_stream_t stream);
+                                      int radius, int flag_cap, spk_stream_t stream);
 /* fp32 spikes [T,B,C,HW] <-> S32 (C % 32 == 0): module boundaries and tests. */
 int spk_spikes_to_s32(const float* spikes, uint8_t* out_s32, int T, int B, int C, int HW, spk_stream_t stream);
 int spk_s32_to_spikes(const uint8_t* in_s32, float* spikes, int T, int B, int C, int HW, spk_stream_t stream);
@@ -369,7 +348,8 @@ int spk_conv_mfma_fused_lif_s32(const uint8_t* in_ptc, const int8_t* wq, const d
  * in_s32: S32 spikes [B][ceil(Cin/32)][H*W][16][16 B] with zero nibbles in the channels beyond Cin (spk_ptc_to_s32 converts u8
  * PTC spikes).  spk_vae_fp6_pack: fp32 weight (Conv2d [Cout][Cin][3][3] / ConvTranspose2d [Cin][Cout][3][3]) (+bias) -> digit
  * tiles (spk_vae_fp6_packed_bytes), fp64 scale / bias [Cout], qtab int32 [Cout][9][Cin].  flag_words: zero-initialised u32
- * workspace of spk_vae_fp6_flag_words(B, Cout, Ho, Wo) words, clean again after the call. */
+ * workspace of spk_vae_fp6_flag_words(B, Cout, Ho, Wo) words, clean again after the call; flag_cap as for
+ * spk_den_conv3x3_mfma_fp6v2 (< 0: the whole id list). */
 long long spk_vae_fp6_packed_bytes(int Cout, int Cin);
 int spk_vae_fp6_pack(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d, int* qtab, int Cout, int Cin,
                      int transposed, spk_stream_t stream);
@@ -388,7 +368,7 @@ int spk_spikegen_tokens_s32(const long long* tokens, const float* codebook, cons
                             int K, int D, int Cout, spk_stream_t stream);
 int spk_vae_fp6_fwd(const uint8_t* in_s32, const uint8_t* wq, const double* scale, const double* bias_d, const int* qtab,
                     const float* bn_a, const float* bn_b, const float* coef_or_null, void* out, int out_kind, unsigned* flag_words,
-                    int T, int B, int H, int W, int Cin, int Cout, int transposed, spk_stream_t stream);
+                    int T, int B, int H, int W, int Cin, int Cout, int transposed, int flag_cap, spk_stream_t stream);
 
 /* ---- vector quantizer ----------------------------------------------------------------------------------------- */
 /* VectorQuantizer.forward eval up to the codebook gather, R/snn_model/vae_model.py:40-52,87-99.

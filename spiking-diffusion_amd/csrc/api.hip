@@ -1,6 +1,9 @@
 // Library identity and error strings.
 #include "spk_common.h"
 #include "../../include/spkdiff.h"
+#if SPK_V2_VARIANTS
+#include "../../include/spkdiff_variants.h"
+#endif
 
 extern "C" int spk_version(void) { return SPK_VERSION; }
 
@@ -12,27 +15,24 @@ extern "C" const char* spk_error_string(int code) {
   return "spkdiff: unknown error";
 }
 
-// ---- measurement options ---------------------------------------------------------------------------------------------
-// The few launch-shape choices that rounds 1-4 measured against each other stay selectable so that the measurements can be
-// repeated (DESIGN.md names the numbers).  They are NOT read from the environment by the library: the HOST sets them through
-// spk_set_option (spkdiff/_lib.py forwards the SPKDIFF_* environment variables once at import, for the A/B tools), and every
-// launch reads the current value -- plain atomics, no lazily initialised statics, no hidden state the caller does not own.
+#if SPK_V2_VARIANTS
+// ---- measurement options (variant builds only: `make variants`, include/spkdiff_variants.h) ------------------------------------
+// The launch-shape choices that rounds 1-5 measured against each other stay selectable in THIS build so that the measurements can
+// be repeated (DESIGN.md names the numbers); the shipped library folds them to their defaults at compile time (spk_common.h) and
+// exports neither entry point.  Not read from the environment: the HOST sets them through spk_set_option (spkdiff/_lib.py forwards
+// the SPKDIFF_* environment variables once at import, for the A/B tools), and every launch reads the current value.
 #include <atomic>
 #include <string.h>
 
 namespace {
 struct SpkOption { const char* name; std::atomic<int> value; };
+constexpr int kDefaults[SPK_OPT_COUNT] = SPK_OPT_DEFAULT_VALUES;
 SpkOption g_options[SPK_OPT_COUNT] = {
-    {"conv6_shared", {1}},       // SPK_OPT_CONV6_SHARED
-    {"conv6_shared_dyn", {1}},   // SPK_OPT_CONV6_SHARED_DYN
-    {"mfma_debug", {0}},         // SPK_OPT_MFMA_DEBUG
-    {"fp6_xcd_walk", {1}},       // SPK_OPT_FP6_XCD_WALK
-    {"fp6_waves", {4}},          // SPK_OPT_FP6_WAVES
-    {"v2_waves", {8}},           // SPK_OPT_V2_WAVES
-    {"v2_lag", {0}},             // SPK_OPT_V2_LAG
-    {"v2_duo", {0}},             // SPK_OPT_V2_DUO
-    {"v2_defer", {0}},           // SPK_OPT_V2_DEFER
-    {"v2_lps", {1}},             // SPK_OPT_V2_LPS
+    {"conv6_shared", {kDefaults[SPK_OPT_CONV6_SHARED]}},         {"conv6_shared_dyn", {kDefaults[SPK_OPT_CONV6_SHARED_DYN]}},
+    {"mfma_debug", {kDefaults[SPK_OPT_MFMA_DEBUG]}},             {"fp6_xcd_walk", {kDefaults[SPK_OPT_FP6_XCD_WALK]}},
+    {"fp6_waves", {kDefaults[SPK_OPT_FP6_WAVES]}},               {"v2_waves", {kDefaults[SPK_OPT_V2_WAVES]}},
+    {"v2_lag", {kDefaults[SPK_OPT_V2_LAG]}},                     {"v2_duo", {kDefaults[SPK_OPT_V2_DUO]}},
+    {"v2_defer", {kDefaults[SPK_OPT_V2_DEFER]}},                 {"v2_lps", {kDefaults[SPK_OPT_V2_LPS]}},
 };
 }  // namespace
 
@@ -51,3 +51,4 @@ extern "C" int spk_get_option(const char* name, int* value_out) {
     if (strcmp(name, g_options[i].name) == 0) { *value_out = g_options[i].value.load(std::memory_order_relaxed); return SPK_OK; }
   return SPK_ERR_UNSUPPORTED;
 }
+#endif

@@ -61,6 +61,12 @@ constexpr int W_PIECES = (N_MM * WT + 1023) / 1024;      // one-KiB DMA pieces p
 constexpr int W_LDS = W_PIECES * 1024;
 constexpr int W_SLAB = ((N_MAIN + N_L5) * WT + 1023) / 1024 * 1024;   // bytes per (channel group, chunk) in memory
 
+// Workspace layout (spk_den_fp6v2_flag_words): ws[0] live count of flagged neurons, ws[1] the count published for the tail launch,
+// ws[2 .. 2 + FLAG_CAP) their ids, then the overflow bitmap (one bit per neuron of the layer), then the hand-over ticket.  The id list
+// holds the first `flag_cap` <= FLAG_CAP flagged neurons of a launch (a per-call argument: the parity suite runs the overflow path with
+// 64 and 0); every further one sets its bit in the bitmap, which the tail launch scans and clears.  The LAYOUT never depends on flag_cap.
+constexpr unsigned FLAG_CAP = 1u << 20;
+
 struct V2Args {
   const uint8_t* in0; int nch;               // S32 spikes, nch = Cin / 32
   const uint8_t* wq; const double* scale; const double* bias; const float* wl1;
@@ -825,7 +831,7 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
         const long long n = ((long long)b * a.Cout + co) * HW + p;
         const unsigned idx = atomicAdd(a.flags, 1u);
         if (idx < a.flag_cap) a.flags[2 + idx] = (unsigned)n;
-        else atomicOr(a.flags + 2 + a.flag_cap + (n >> 5), 1u << (n & 31));
+        else atomicOr(a.flags + 2 + FLAG_CAP + (n >> 5), 1u << (n & 31));
       }
       const long long rec = (((long long)b * G + g) * HW + p) * POSB;
       if constexpr (SPK_V2_MASKSTORE && !USE_D4) {
@@ -881,1133 +887,10 @@ __device__ __forceinline__ void fp6v2_handover(const V2Args& a) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------ two workgroups per CU ("duo", round 5)
-// The eight waves of the form above share every chunk barrier, so both waves of a SIMD reach an item's LIF scan together and the
-// matrix pipe idles for its whole length (mfma_coexec_fraction_of_busy 0.024, 16 % of the reverse process); a wave that scans
-// alone issues a vector instruction every ~6 cycles whatever its partner does, and one wave's vector instructions are free beside
-// the other wave's MFMAs (tools/coexec_probe.hip, rows M|V).  What couples the two waves is the barrier, not the hardware.  Here a
-// CU runs TWO INDEPENDENT WORKGROUPS of four waves (one per SIMD each, 256 registers): each has its own barriers, its own LDS and
-// its own item stream, so while one scans (or waits at a barrier, or for a copy) the other's MFMAs have the pipe to themselves --
-// and once the two are half an item apart they stay there: each period a workgroup spends T_scan alone on the vector unit while
-// its partner runs MFMAs at the full rate (see fp6v2_duo_phase for how they get apart).
-//   * Item = HALF an image (positions 0..23 or 24..47 = 12 row tiles, three per wave: today's register budget) x 32 output
-//     channels; the 49th position stays the tail launch's.  A half needs five input rows (0..4 / 2..6): one zero-bordered LDS image
-//     of 7 x 8 + 1 cells serves both halves (row 0 / row 6 are the true border of the top / bottom half).
-//   * LDS per workgroup must stay under 80 KB.  The two image buffers take 29 KB; a double-buffered 27 KB weight slab does not fit
-//     beside them.  A chunk's weight tiles are consumed tap by tap and never re-read, so they live in a RING of NSLOT thirds (three
-//     taps = six tiles = 9 KB): a chunk is three STAGES of 18 MFMAs per wave, one barrier each; during stage n the copy engine
-//     fills the slot stage n - 1 released with the third of stage n + NSLOT - 1 (NSLOT = 4: 71 KB per workgroup).
-//   * Copies complete in issue order per wave, so a stage's barrier waits with s_waitcnt vmcnt(K): everything but the pieces of
-//     the last two stages (K = the smallest count over the four waves' piece shares: waves with more pieces wait for a little more
-//     than they must).  The image slab of the next chunk is issued in stage 0 only (three stages before its first use).  The
-//     epilogue's stores share the counter and may retire out of order with the copies: the first barrier of every item drains it.
-// MEASURED (B = 256, same box, two builds: profiles/r5_ab_duo_first_build.txt, r5_ab_duo_second_build.txt; bit-equal to the
-// one-workgroup form on every shape, test_fp6v2_duo_form_bit_equal_...): den.conv4 380 - 400 us against 362 - 382, the dense reverse
-// process 90.0 / 95.6 ms against 85.8 / 91.8 -- 4 - 5 % SLOWER, although the phase picture (tools/duo_phase.py, s_memrealtime
-// stamps per item) shows what was asked for: 0.77 - 0.89 of a workgroup's scan time lies inside its partner's K loops, with or
-// without a head start.  What stops it: the matrix pipe serves the OLDER wave of a SIMD first (per item 17 us for one workgroup
-// of a CU, 27 us for the other: the first build left the slower one alone for the last fifth of the launch; item claiming fixed
-// that, not the rate), a wave alone issues an MFMA every ~47 cycles (it is bound by its own instruction issue: ~6.5 instructions
-// per MFMA at one per ~5 cycles), and two co-running waves of different workgroups reach one per ~44 cycles of the pipe where
-// the lock-step pair of the one-workgroup form reaches one per 39.5 inside its K loop -- 75 % of the pipe over the launch either
-// way.  Off by default (option v2_duo); kept with its test and the phase tool so that the measurement can be repeated.
-#ifndef SPK_V2_DUO_SLOTS
-#define SPK_V2_DUO_SLOTS 5      // thirds in the weight ring.  5: the third of stage n + 1 has landed at the barrier of stage n, so the first
-                                // tap's fragments of a stage are read during the stage before (no LDS round trip behind a stage barrier);
-                                // 4: the first build (71 KB instead of 80 KB of LDS; every stage starts with an exposed fragment read)
+#if SPK_V2_VARIANTS
+#include "variants/fp6v2_forms.inc"      // duo / deferred-scan / staggered forms (measured slower; not in the shipped library)
 #endif
-#ifndef SPK_V2_DUO_STEAL
-#define SPK_V2_DUO_STEAL 1      // 1: the workgroups that share a channel group (and an XCD partition) CLAIM their items from one counter
-                                // instead of owning a fixed stride: the matrix pipe serves the older wave of a SIMD first, so the two
-                                // workgroups of a CU run at different speeds (17 against 27 us per item) and a fixed split left the slower
-                                // one alone for the last fifth of the launch (profiles/r5_ab_duo_first_build.txt)
-#endif
-#ifndef SPK_V2_DUO_PRIO
-#define SPK_V2_DUO_PRIO 1       // 1: s_setprio 1 in the K loop, 0 in the scan: the scanning wave's vector instructions fill gaps only
-#endif
-#ifndef SPK_V2_DUO_DBG
-#define SPK_V2_DUO_DBG 0        // 1: every workgroup stamps s_memrealtime at the start of each item's K loop and of its scan into a.dbg_out
-#endif
-constexpr int DUO_NSLOT = SPK_V2_DUO_SLOTS;
-constexpr int DUO_W3 = 6 * WT;                            // one third of a chunk's weight tiles: three taps x two digit pairs
-constexpr int DUO_HIN = 5, DUO_HWB = 24;
-constexpr int DUO_NPP = (DUO_HIN + 2) * 8 + 1;            // (7x7: pitch W + 1 = 8)
-constexpr int DUO_A_BYTES = DUO_NPP * POSB;
-constexpr size_t DUO_LDS = 2 * (size_t)DUO_A_BYTES + (size_t)DUO_NSLOT * DUO_W3 + (size_t)(DUO_NPP * 16 + (DUO_HWB + 1) * 16 + DUO_HWB + 1) * 4;
-static_assert(DUO_LDS <= 80 * 1024, "two workgroups per CU");
 
-template <int H, int W>
-__device__ __forceinline__ void fp6v2_body_duo(const V2Args& a, const int g, const int il, const int lanes, const int n_images,
-                                               const int part, const int npart) {
-  static_assert(H == 7 && W == 7 && !USE_D4 && N_MM == N_PAIR, "7x7 latents, four-digit form");
-  constexpr int NWV = 4, NT = 3, HW = H * W, PW = W + 1;
-  constexpr int HWb = DUO_HWB, Hin = DUO_HIN, NPP = DUO_NPP, A_BYTES = DUO_A_BYTES;
-  constexpr int PPR = (W + 3) / 4, NA = Hin * PPR;     // ten image pieces per chunk
-  constexpr int NSLOT = DUO_NSLOT, W3 = DUO_W3;
-  static_assert(W3 == 9 * 1024 && NA == 10 && (NSLOT == 4 || NSLOT == 5), "piece shares below");
-  constexpr bool AHEAD = NSLOT == 5;                   // fragments of a stage's first tap are read during the previous stage
-  constexpr bool STEAL = SPK_V2_DUO_STEAL != 0;
-  __shared__ int s_claim[2];
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  uint8_t* const sA = lds;
-  uint8_t* const sW = lds + 2 * A_BYTES;
-  int* const s_cin = reinterpret_cast<int*>(lds + 2 * A_BYTES + NSLOT * W3);        // [NPP][16]
-  int* const s_row = s_cin + NPP * 16;                                               // [HWb + 1][16]
-  int* const s_nmax = s_row + (HWb + 1) * 16;                                        // [HWb + 1]
-  const unsigned sA_addr = spk_lds_addr(sA), sW_addr = sA_addr + 2 * A_BYTES;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nch = a.nch;
-  const int G = a.Cout >> 5;
-  for (int i = tid; i < 2 * A_BYTES / 16; i += NWV * 64) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
-  for (int i = tid; i < NPP * 16; i += NWV * 64) s_cin[i] = 0;
-  __syncthreads();
-
-  const int row = lane & 31, half = lane >> 5;
-  const int hsel = (row >> 2) & 1, tt = (row & 3) + 4 * (row >> 3);
-  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  // image pieces of this wave: ids wave, wave + 4 and (waves 2, 3) 8 + wave - 2; weight pieces of a third: wave, wave + 4 and
-  // (wave 0) 8.  Shares per stage (waves 0..3): stage 0: 5 4 5 5, stages 1 and 2: 3 2 2 2.
-  unsigned pa_pk[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    int id = j < 2 ? wave_s + 4 * j : 8 + (wave_s & 1);
-    const int y = id / PPR, px = id - y * PPR;
-    const int np = (W - 4 * px) < 4 ? (W - 4 * px) : 4;
-    const unsigned src = (unsigned)((y * W + 4 * px) * POSB), dst = (unsigned)(((y + 1) * PW + 1 + 4 * px) * POSB);
-    pa_pk[j] = src | (dst << 14) | ((unsigned)(np - 1) << 29);
-  }
-  const unsigned lane16 = (unsigned)lane * 16u;
-  auto issue_A = [&](int q, const uint8_t* aslab, unsigned dA) {
-    if (q == 2 && wave_s < 2) return;
-    const unsigned pk = pa_pk[q];
-    const unsigned np = ((pk >> 29) & 3u) + 1u;
-    const unsigned long long mask = np == 4 ? ~0ull : ((1ull << (16 * np)) - 1ull);
-    spk_dma16s_masked(aslab + (pk & 0x3fffu), lane16, dA + ((pk >> 14) & 0x7fffu), mask);
-  };
-  auto issue_W = [&](int q, const uint8_t* wthird, unsigned dW) {
-    if (q == 2 && wave_s != 0) return;
-    const unsigned ko = ((unsigned)wave_s + 4u * (unsigned)q) * 1024u;
-    spk_dma16s(wthird + ko, lane16, dW + ko);
-  };
-  const uint8_t* const wbase = a.wq + (long long)g * nch * W_SLAB;
-  // item -> (image, half); the slab of the bottom half starts two rows into the image
-  auto aslab_of = [&](int itm, int c) -> const uint8_t* {
-    return a.in0 + ((long long)(itm >> 1) * nch + c) * HW * POSB + (itm & 1) * 2 * W * POSB;
-  };
-  const int nitems = 2 * n_images;
-
-  const int co = g * 32 + (lane & 31);
-  const float scale_f = (float)a.scale[co], bias_f = (float)a.bias[co];
-  const float bna = a.bn_a[co], bnb = a.bn_b[co];
-  const float Bc = fmaf(bias_f, bna, bnb);
-  const float cE = 2.0f * 2.38418579e-07f * (fabsf(bnb) + fabsf(Bc)) + 1e-30f;
-  const float cT = 528.0f * scale_f * fabsf(bna) * 1.000001f;
-  const float Ac4 = 1024.0f * scale_f * bna;
-  const int sc_a = 0x7f7f7f7f;
-  const int sc_p = half ? (int)0x82828282u : (int)0x87878787u;
-
-  // input records (cell, step) of an item counted by this thread, chunk by chunk
-  constexpr int NREC = Hin * W * 16, NR = (NREC + NWV * 64 - 1) / (NWV * 64);
-  int rec_off[NR];
-  bool rec_ok[NR];
-#pragma unroll
-  for (int k = 0; k < NR; ++k) {
-    const int r = tid + k * NWV * 64;
-    const int cl = r >> 4, t = r & 15;
-    rec_ok[k] = r < NREC;
-    rec_off[k] = rec_ok[k] ? (((cl / W) + 1) * PW + 1 + (cl % W)) * POSB + t * 16 : 0;
-  }
-
-  int it = 0;                                             // running chunk counter: image buffer it & 1
-  int slot = NSLOT - 1;                                   // ring slot of the current stage (stage number mod NSLOT; stepped at every stage barrier)
-  // STEAL: the items of this workgroup's partition are part, part + npart, part + 2 npart, ...; the workgroups of the partition
-  // (same channel group, same XCD set) claim them from one counter, the next one at the start of the current one (its first
-  // barrier drains the memory counter anyway, so the atomic's return costs nothing and the copies of the next item's first
-  // chunk know their source in time).  Otherwise: il, il + lanes, ...
-  unsigned* const ctr = STEAL ? a.item_ctr + (g * npart + part) : nullptr;
-  auto item_of = [&](int k) -> int { return STEAL ? part + npart * k : il + lanes * k; };
-  int cur = 0;
-  if (STEAL) {
-    if (tid == 0) s_claim[0] = (int)atomicAdd(ctr, 1u);
-    __syncthreads();
-    cur = __builtin_amdgcn_readfirstlane(s_claim[0]);
-  }
-  if (item_of(cur) < nitems) {
-    const uint8_t* as0 = aslab_of(item_of(cur), 0);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) issue_A(q, as0, sA_addr);
-#pragma unroll
-    for (int st = 0; st < 3; ++st)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) issue_W(q, wbase + st * W3, sW_addr + st * W3);
-    if constexpr (NSLOT == 5) {                           // (stage 0 issues the third of stage 4: stage 3 = the second chunk's first third goes here)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) issue_W(q, wbase + (long long)(1 % nch) * W_SLAB, sW_addr + 3 * W3);
-    }
-  }
-  for (int kk = 0; item_of(cur) < nitems; ++kk) {
-    const int itm = item_of(cur);
-    int nxt = cur + 1;                                    // (STEAL: read back from LDS behind the item's first barrier)
-    if (STEAL && tid == 0) s_claim[(kk + 1) & 1] = (int)atomicAdd(ctr, 1u);
-    const int b = itm >> 1, hid = itm & 1;
-    int a_off[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int p = 2 * (wave + NWV * i) + hsel + hid * HWb;
-      a_off[i] = (((p / W) - 2 * hid) * PW + (p % W)) * POSB + tt * 16;
-    }
-    if (SPK_V2_DUO_DBG && tid == 0 && a.dbg_out && kk < 31) a.dbg_out[(long long)blockIdx.x * 64 + 2 * kk] = __builtin_amdgcn_s_memrealtime();
-    if (SPK_V2_DUO_PRIO) __builtin_amdgcn_s_setprio(1);
-    v16f acc[NT][NACC];
-    int creg[NR];
-#pragma unroll
-    for (int k = 0; k < NR; ++k) creg[k] = 0;
-    for (int c = 0; c < nch; ++c, ++it) {
-      const int buf = it & 1;
-      int nb = itm, nc = c + 1;
-      if (nc == nch) { nc = 0; nb = item_of(nxt); }       // (c > 0 here or nch == 1: nxt is the claimed one by then, see below)
-      const bool have_next = nb < nitems;                 // otherwise the last chunk is copied once more (never read)
-      const uint8_t* n_aslab = aslab_of(have_next ? nb : itm, have_next ? nc : c);
-      // (weight slabs depend on the chunk index only; thirds copied for a chunk that never comes land in free slots)
-      const uint8_t* n_wslab = wbase + (long long)(c + 1 == nch ? 0 : c + 1) * W_SLAB;
-      const uint8_t* n2_wslab = wbase + (long long)((c + 2) % nch) * W_SLAB;
-      const unsigned n_dA = sA_addr + (buf ^ 1) * A_BYTES;
-      v4i rvq[NR];
-      auto compute = [&](auto first_tag) {
-        constexpr bool FIRST = decltype(first_tag)::value;
-        const uint8_t* A = sA + buf * A_BYTES;
-        auto toff = [](int tap) constexpr -> int { return ((tap / 3) * PW + (tap % 3)) * POSB; };
-        auto lda = [&](auto s_tag) -> v4i {
-          constexpr int s = decltype(s_tag)::value;
-          return *reinterpret_cast<const v4i*>(A + a_off[s % NT] + toff(s / NT));
-        };
-        const uint8_t* Wb = sW;                            // (set at every stage barrier)
-        auto ldb_at = [&](const uint8_t* base, int tile) -> v6i {
-          const uint8_t* p = base + tile * WT;
-          const v4i x = *reinterpret_cast<const v4i*>(p + lane * 16);
-          typedef const volatile __attribute__((address_space(3))) v2i* lds_v2i_ptr;
-          const v2i y = *(lds_v2i_ptr)SPK_LDS(p + 1024 + lane * 8);
-          const v6i r = {x[0], x[1], x[2], x[3], y[0], y[1]};
-          return r;
-        };
-        auto ldb = [&](int tile) -> v6i {
-          const uint8_t* p = Wb + tile * WT;
-          const v4i x = *reinterpret_cast<const v4i*>(p + lane * 16);
-          typedef const volatile __attribute__((address_space(3))) v2i* lds_v2i_ptr;
-          const v2i y = *(lds_v2i_ptr)SPK_LDS(p + 1024 + lane * 8);
-          const v6i r = {x[0], x[1], x[2], x[3], y[0], y[1]};
-          return r;
-        };
-        v6i bp[2][2];
-        constexpr int PF = 4, NSTEP = 9 * NT;
-        v4i af[PF];
-        static_for<NSTEP>([&](auto s_tag) {
-          constexpr int s = decltype(s_tag)::value;
-          constexpr int tap = s / NT, i = s % NT, st = tap / 3, ss = s % (3 * NT);        // ss: step within the stage
-          if constexpr (ss == 0) {
-            // stage barrier: everything but this wave's copies of the last two stages has landed -- this stage's third, the
-            // chunk's image slab at stage 0 and (five slots) the next stage's third -- and the slot of the stage before is free
-            if constexpr (FIRST && st == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            else if constexpr (st == 0) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-            if constexpr (FIRST && st == 0 && STEAL) nxt = __builtin_amdgcn_readfirstlane(s_claim[(kk + 1) & 1]);
-            slot = slot == NSLOT - 1 ? 0 : slot + 1;
-            Wb = sW + slot * W3;
-            if constexpr (!AHEAD || st == 0) { bp[tap & 1][0] = ldb(0); bp[tap & 1][1] = ldb(1); }
-            if constexpr (st == 0) static_for<PF>([&](auto p_tag) { af[decltype(p_tag)::value] = lda(p_tag); });
-          }
-          const v4i av = af[s % PF];
-          if constexpr (s + PF < NSTEP) af[s % PF] = lda(std::integral_constant<int, s + PF>{});
-          if constexpr (FIRST && tap == 0) SPK_MFMA2_Z("v", acc[i][0], av, bp[0][0], sc_a, sc_p);
-          else SPK_MFMA2("v", acc[i][0], av, bp[tap & 1][0], sc_a, sc_p);
-          __builtin_amdgcn_sched_barrier(0);
-          // copies of this stage: the third of stage n + NSLOT - 1 into the slot stage n - 1 released; stage 0: the next chunk's image
-          if constexpr (ss < 3) {
-            // the slot the previous stage released takes the third of stage n + NSLOT - 1: four slots: this stage's third of the
-            // NEXT chunk; five: the next stage's third of the next chunk (stage 2: stage 0 of the chunk after it)
-            const int dslot = slot == 0 ? NSLOT - 1 : slot - 1;
-            if constexpr (NSLOT == 4) issue_W(ss, n_wslab + st * W3, sW_addr + dslot * W3);
-            else if constexpr (st < 2) issue_W(ss, n_wslab + (st + 1) * W3, sW_addr + dslot * W3);
-            else issue_W(ss, n2_wslab, sW_addr + dslot * W3);
-          } else if constexpr (st == 0 && ss < 6) {
-            issue_A(ss - 3, n_aslab, n_dA);
-          }
-          if constexpr (i == 0 && (tap % 3) != 2) {
-            bp[(tap + 1) & 1][0] = ldb(2 * ((tap + 1) % 3));
-            bp[(tap + 1) & 1][1] = ldb(2 * ((tap + 1) % 3) + 1);
-          }
-          if constexpr (AHEAD && i == 0 && (tap % 3) == 2 && st < 2) {
-            // the first tap of the next stage (its third landed before this stage's barrier)
-            const uint8_t* Wn = sW + (slot == NSLOT - 1 ? 0 : slot + 1) * W3;
-            bp[(tap + 1) & 1][0] = ldb_at(Wn, 0);
-            bp[(tap + 1) & 1][1] = ldb_at(Wn, 1);
-          }
-          if constexpr (s == 1) {
-#pragma unroll
-            for (int k = 0; k < NR; ++k) rvq[k] = *reinterpret_cast<const v4i*>(sA + buf * A_BYTES + rec_off[k]);
-          }
-          if constexpr (s == 7) {
-#pragma unroll
-            for (int k = 0; k < NR; ++k)
-              creg[k] += __builtin_popcount((unsigned)rvq[k][0]) + __builtin_popcount((unsigned)rvq[k][1]) +
-                         __builtin_popcount((unsigned)rvq[k][2]) + __builtin_popcount((unsigned)rvq[k][3]);
-          }
-          if constexpr (FIRST && tap == 0) SPK_MFMA2_Z("v", acc[i][1], av, bp[0][1], sc_a, sc_p);
-          else SPK_MFMA2("v", acc[i][1], av, bp[tap & 1][1], sc_a, sc_p);
-          __builtin_amdgcn_sched_barrier(0);
-        });
-      };
-      if (c == 0) compute(std::true_type{}); else compute(std::false_type{});
-    }   // chunks
-
-    if (SPK_V2_DUO_PRIO) __builtin_amdgcn_s_setprio(0);
-    if (SPK_V2_DUO_DBG && tid == 0 && a.dbg_out && kk < 31) a.dbg_out[(long long)blockIdx.x * 64 + 2 * kk + 1] = __builtin_amdgcn_s_memrealtime();
-    // publish the record counts, then add the nine taps of every output position: s_row[p][t] = active inputs of row (p, t)
-#pragma unroll
-    for (int k = 0; k < NR; ++k)
-      if (rec_ok[k]) s_cin[(rec_off[k] / POSB) * 16 + ((rec_off[k] % POSB) >> 4)] = creg[k];
-    if (tid <= HWb) s_nmax[tid] = 0;
-    __syncthreads();
-    for (int e = tid; e < HWb * 16; e += NWV * 64) {
-      const int pp = e >> 4, t = e & 15;
-      const int p = pp + hid * HWb;
-      const int* c0 = s_cin + (((p / W) - 2 * hid) * PW + (p % W)) * 16 + t;
-      int sum = 0;
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) sum += c0[(dy * PW + dx) * 16];
-      s_row[e] = sum;
-      atomicMax(&s_nmax[pp], sum);
-    }
-    __syncthreads();
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    if (SPK_V2_DBG & 4) {
-      float sacc = 0.f;
-#pragma unroll
-      for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int j = 0; j < NACC; ++j) sacc += acc[i][j][0];
-      if (sacc == 12345.f) a.out[0] = 1;
-      cur = nxt;
-      continue;
-    }
-    // ---------------- epilogue: the four-digit scan of fp6v2_body (fp32 recombination, BN, LIF, certification in two stages)
-#pragma unroll
-    for (int k = 0; k < NT; ++k) {
-      const int i = k == 0 ? NT - 1 : k - 1;
-      typedef float v2f __attribute__((ext_vector_type(2)));
-      float v = 0.f, zmax = 0.f, dmin = 3.0e38f;
-      unsigned mybits = 0;
-      const int pp = 2 * (wave + NWV * i) + half;          // position within the item
-      const int nmax = s_nmax[pp];
-#pragma unroll
-      for (int r2 = 0; r2 < 16; r2 += 2) {
-        const v2f p0 = {acc[i][0][r2], acc[i][0][r2 + 1]}, p1 = {acc[i][1][r2], acc[i][1][r2 + 1]};
-        const v2f q4 = __builtin_elementwise_fma(p0, (v2f){1024.0f, 1024.0f}, p1);
-        const v2f z2 = __builtin_elementwise_fma(q4, (v2f){Ac4, Ac4}, (v2f){Bc, Bc});
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const float z = z2[e];
-          zmax = fmaxf(zmax, fabsf(z));
-          const float h = fmaf(z - v, 0.5f, v);
-          const float hm = h - 1.0f;
-          dmin = fminf(dmin, fabsf(hm));
-          v = h >= 1.0f ? 0.0f : h;
-          mybits = __builtin_amdgcn_alignbit(mybits, __float_as_uint(hm), 31);
-        }
-      }
-      mybits = ~(__builtin_bitreverse32(mybits) >> 16) & 0xffffu;
-      bool flg = dmin <= SPK_V2_SPARE * fmaf(zmax, 2.5f * CERT_4EPS, fmaf((float)nmax, cT, cE));
-      if (SPK_V2_STAGE2 && __builtin_amdgcn_ballot_w64(flg) != 0ull) {
-        float v2 = 0.f, dh = 0.f;
-        bool f2 = false;
-        int cntv[16];
-        const v4i* rp = reinterpret_cast<const v4i*>(s_row + pp * 16);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const v4i c4 = rp[q];
-          cntv[4 * q] = c4[0]; cntv[4 * q + 1] = c4[1]; cntv[4 * q + 2] = c4[2]; cntv[4 * q + 3] = c4[3];
-        }
-#pragma unroll
-        for (int r2 = 0; r2 < 16; r2 += 2) {
-          const v2f p0 = {acc[i][0][r2], acc[i][0][r2 + 1]}, p1 = {acc[i][1][r2], acc[i][1][r2 + 1]};
-          const v2f q4 = __builtin_elementwise_fma(p0, (v2f){1024.0f, 1024.0f}, p1);
-          const v2f z2 = __builtin_elementwise_fma(q4, (v2f){Ac4, Ac4}, (v2f){Bc, Bc});
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const float z = z2[e];
-            const float ct = fmaf((float)cntv[r2 + e], cT, cE);
-            dh = fmaf(fabsf(z) + fabsf(v2), 0.625f * CERT_4EPS, fmaf(dh, 0.5f, 0.5f * ct));
-            const float h = fmaf(z - v2, 0.5f, v2);
-            f2 = f2 || (fabsf(h - 1.0f) <= SPK_V2_SPARE * dh);
-            v2 = h >= 1.0f ? 0.0f : h;
-          }
-        }
-        flg = flg && f2;
-      }
-      const int p = pp + hid * HWb;
-      if (flg && !(SPK_V2_DBG & 32)) {
-        const long long n = ((long long)b * a.Cout + co) * HW + p;
-        const unsigned idx = atomicAdd(a.flags, 1u);
-        if (idx < a.flag_cap) a.flags[2 + idx] = (unsigned)n;
-        else atomicOr(a.flags + 2 + a.flag_cap + (n >> 5), 1u << (n & 31));
-      }
-      const long long rec = (((long long)b * G + g) * HW + p) * POSB;
-      store_tile_spikes(a.out, a.out_cnt, mybits, lane, rec, (((long long)b * G + g) * HW + p) * 32, true);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    cur = nxt;
-  }   // items
-  spk_dma_wait_all();
-}
-
-// Getting the two workgroups of a CU half an item apart.  Left alone they start together and STAY together: two scans that overlap
-// pull each other in (the lag halves with every item), whereas two that do not overlap keep their distance (each gets T_scan of
-// the pipe to itself per period, whatever the lag).  So the SECOND workgroup to arrive on a CU waits `duo_delay` ticks before its
-// first item -- during which the first one has the matrix pipe to itself, so nothing idles -- and from then on the pair is
-// stable.  Arrival order: one counter per CU (keyed by XCC / SE / SH / CU id from the hardware registers), never reset: any two
-// consecutive arrivals on a CU differ in parity, whatever earlier launches left in the counter.
-constexpr int DUO_CU_SLOTS = 2048, DUO_ITEM_CTRS = 128;
-constexpr int ZSTAGE_WORDS_PER_WG = 8 * 3 * 16 * 64;     // eight waves x three tiles x sixteen steps x 64 lanes (fp32): 96 KB
-__device__ __forceinline__ void fp6v2_duo_phase(const V2Args& a) {
-  if (a.duo_delay <= 0 && !SPK_V2_DUO_DBG) return;
-  __shared__ int s_late;
-  if (threadIdx.x == 0) {
-    unsigned hw, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    const unsigned key = (((xcc & 7u) * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u + ((hw >> 8) & 15u);
-    s_late = (int)(atomicAdd(a.cu_slots + key, 1u) & 1u);
-    if (SPK_V2_DUO_DBG && a.dbg_out) {
-      a.dbg_out[(long long)blockIdx.x * 64 + 62] = key;
-      a.dbg_out[(long long)blockIdx.x * 64 + 63] = (unsigned long long)s_late;
-    }
-    if (a.duo_delay <= 0) s_late = 0;
-  }
-  __syncthreads();
-  if (s_late) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)a.duo_delay) __builtin_amdgcn_s_sleep(16);
-  }
-}
-
-// HIP's second launch-bound argument is the minimum number of waves per execution unit: two -> 256 registers, and with
-// <= 80 KB of LDS two of these workgroups share a CU.
-template <int H, int W>
-__global__ __launch_bounds__(256, 2) void conv3x3_fp6v2_duo_kernel(V2Args a) {
-  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
-  int g, il, lanes;
-  fp6v2_wg_map(a, g, il, lanes);
-  // item partition of this workgroup: the XCD-aware walk gives XCD x the channel-group set x % nsets and the image partition
-  // x / nsets (of 8 / nsets); the flat walk has one partition
-  const int npart = a.gx > 0 ? 8 / a.nsets : 1;
-  const int part = a.gx > 0 ? ((int)blockIdx.x & 7) / a.nsets : 0;
-  fp6v2_duo_phase(a);
-  fp6v2_body_duo<H, W>(a, g, il, lanes, Bn, part, npart);
-  // (hand-over as above; the last workgroup also re-arms the claim counters for the next launch on this workspace)
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    if (atomicAdd(a.flags + a.ticket_idx, 1u) == gridDim.x - 1) {
-      a.flags[1] = atomicAdd(a.flags, 0u);
-      if (!(SPK_V2_DBG & 64)) a.flags[0] = 0u;
-      a.flags[a.ticket_idx] = 0u;
-      for (int i = 0; i < DUO_ITEM_CTRS; ++i) a.item_ctr[i] = 0u;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ deferred scan (round 5, experiment)
-// What the duo experiment taught (profiles/r5_ab_duo_*.txt): two INDEPENDENT waves on a SIMD do not add up -- the matrix pipe
-// serves the older wave first, a wave on its own is bound by its instruction issue (~47 cycles per MFMA where the pipe needs 35),
-// and two of them co-running reach 75 % of the pipe, no better than the lock-step pair with its exposed scan.  The lock-step
-// pair DOES keep the pipe 89 % busy inside the K loop, and one wave's vector instructions are free beside MFMAs up to four per
-// MFMA, also when both waves of a SIMD issue them (tools/coexec_probe.hip, rows MV).  So here the scan moves INTO the K loop of
-// the same waves -- the next item's: software pipelining across items.
-//   * Two accumulator generations do not fit (2 x 96 of 256 registers), and neither do 48 recombined pre-activations: hipcc
-//     wants ~220 registers for the K loop as it is, spilled 150 dwords with them in VGPRs, split the file 128 / 128 with them in
-//     AGPRs, and with "amdgpu-agpr-alloc" forced through the IR still evicted half of them to scratch (reloads behind
-//     s_waitcnt vmcnt(0) inside the K loop).  So an item's pre-activations z_t (the two packed fmas per step pair the scan always
-//     started with) go 12 KB per wave to a per-workgroup STAGING slab in memory (25 MB for the whole device, rewritten every
-//     item) and come back one tile at a time: tile k is copied into the wave's 4 KB LDS tile late in chunk k (LDS-DMA like every
-//     other copy: no registers, landed by the chunk barrier's s_waitcnt vmcnt(0)), scanned during chunk k + 1 (one LIF step per
-//     K-loop step, 7 vector instructions beside 4 MFMAs of the pair of waves) and finished (certification, flags, transpose,
-//     stores) first thing behind the barrier of chunk k + 2, where no fragment register is live.  Needs >= 4 chunks.
-//   * The active-input counts of item i (s_cin -> s_row, s_nmax) are needed by its certification only: the records are published
-//     at the end of item i, the nine-tap sums are formed during chunk 0 of item i + 1 behind its barrier (no barriers of their
-//     own any more), two buffers by item parity.
-//   * What is left between two K loops: the MFMA drain, 48 packed fmas, 12 stores and two LDS writes per thread.
-// The last item of a workgroup has no successor: it is scanned the round-2 way (counts pass with two barriers, then the scan).
-// Same arithmetic, same instruction sequence per neuron: bit-equal to fp6v2_body (test_fp6v2_deferred_scan_bit_equal_...).
-// MEASURED (B = 256, same box, three builds: profiles/r5_ab_defer_builds.txt): den.conv3 / 4 / 5 launches 156 / 456 / 400 us
-// against 113 / 370 / 360 -- 11 - 38 % SLOWER.  With every deferred part switched off (-DSPK_V2_DEFER_DBG=31) the same loop
-// structure runs conv4 in 331 us: the scan between two K loops costs the round-4 form 8 % of the launch, not the 16 % the
-// no-epilogue ablation had suggested, and each deferred part costs more than it hides -- the staging stores 4.5 us per item (the
-// chunk barrier's s_waitcnt vmcnt(0) waits for them: stores share the memory counter with the copies), the LIF steps inside the
-// K loop 3.5 us per item (a 7-instruction dependent chain holds the in-order wave's next MFMA back, in both waves of the SIMD
-// at once), the finishes another 3 - 4.  Off by default (option v2_defer); kept with its test so that the measurement can be
-// repeated.
-#ifndef SPK_V2_DEFER_DBG
-#define SPK_V2_DEFER_DBG 0      // timing experiments only (results are wrong): 1 = no staging stores, 2 = no finish, 4 = no LIF steps in the K loop,
-                                // 8 = no copies of the next tile, 16 = no counts pass
-#endif
-struct ScanState { float v, zmax, dmin; unsigned bits; };
-__device__ __forceinline__ void defer_lif_step(ScanState& st, const float z) {
-  st.zmax = fmaxf(st.zmax, fabsf(z));
-  const float h = fmaf(z - st.v, 0.5f, st.v);
-  const float hm = h - 1.0f;
-  st.dmin = fminf(st.dmin, fabsf(hm));
-  st.v = h >= 1.0f ? 0.0f : h;
-  st.bits = __builtin_amdgcn_alignbit(st.bits, __float_as_uint(hm), 31);
-}
-
-// certification + flags + stores of one scanned tile; z[] still holds its sixteen pre-activations (second stage)
-__device__ __forceinline__ void defer_finish(const V2Args& a, ScanState& st, const float4* zq, const int nmax, const int* s_row_p,
-                                             const float cT, const float cE, const int b, const int co, const int g, const int G,
-                                             const int HW, const int p, const int lane) {
-  const unsigned mybits = ~(__builtin_bitreverse32(st.bits) >> 16) & 0xffffu;
-  bool flg = st.dmin <= SPK_V2_SPARE * fmaf(st.zmax, 2.5f * CERT_4EPS, fmaf((float)nmax, cT, cE));
-  if (SPK_V2_STAGE2 && __builtin_amdgcn_ballot_w64(flg) != 0ull) {
-    float v2 = 0.f, dh = 0.f;
-    bool f2 = false;
-    // (a wave with a flagged lane, a few percent of the tiles: the sixteen pre-activations come back from the staging slab)
-    const v4i* rp = reinterpret_cast<const v4i*>(s_row_p);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const v4i c4 = rp[q];
-      const float4 z4 = zq[q * 64];
-      const float z[4] = {z4.x, z4.y, z4.z, z4.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float ct = fmaf((float)c4[e], cT, cE);
-        dh = fmaf(fabsf(z[e]) + fabsf(v2), 0.625f * CERT_4EPS, fmaf(dh, 0.5f, 0.5f * ct));
-        const float h = fmaf(z[e] - v2, 0.5f, v2);
-        f2 = f2 || (fabsf(h - 1.0f) <= SPK_V2_SPARE * dh);
-        v2 = h >= 1.0f ? 0.0f : h;
-      }
-    }
-    flg = flg && f2;
-  }
-  if (flg && !(SPK_V2_DBG & 32)) {
-    const long long n = ((long long)b * a.Cout + co) * HW + p;
-    const unsigned idx = atomicAdd(a.flags, 1u);
-    if (idx < a.flag_cap) a.flags[2 + idx] = (unsigned)n;
-    else atomicOr(a.flags + 2 + a.flag_cap + (n >> 5), 1u << (n & 31));
-  }
-  const long long rec = (((long long)b * G + g) * HW + p) * POSB;
-  store_tile_spikes(a.out, a.out_cnt, mybits, lane, rec, (((long long)b * G + g) * HW + p) * 32, true);
-}
-
-template <int H, int W>
-__device__ __forceinline__ void fp6v2_body_defer(const V2Args& a, const int g, const int il, const int lanes, const int n_images) {
-  static_assert(H == 7 && W == 7 && !USE_D4 && N_MM == N_PAIR, "7x7 latents, four-digit form");
-  constexpr int NWV = 8, NT = 3, HW = H * W, PW = W + 1;
-  constexpr int NPP = (H + 2) * PW + 1, A_BYTES = NPP * POSB;
-  constexpr int PPR = (W + 3) / 4, NA = H * PPR, NPA = (NA + NWV - 1) / NWV, NPW = (W_PIECES + NWV - 1) / NWV;
-  constexpr int NSTEP = 9 * NT, NPIECES = NPA + NPW, PF = 4;
-  constexpr int ROWS = HW + 1;                             // s_row / s_nmax rows per parity buffer
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  uint8_t* const sA = lds;
-  uint8_t* const sW = lds + 2 * A_BYTES;
-  int* const s_cin = reinterpret_cast<int*>(lds + 2 * A_BYTES + 2 * W_LDS);          // [NPP][16]
-  int* const s_row = s_cin + NPP * 16;                                               // [2][ROWS][16]
-  int* const s_nmax = s_row + 2 * ROWS * 16;                                         // [2][ROWS]
-  // the tile a wave scans during a chunk: [step quad][lane] float4, 4 KB per wave, filled by four LDS-DMA pieces during the chunk before
-  uint8_t* const s_z = lds + 2 * A_BYTES + 2 * W_LDS + ((NPP * 16 + 2 * ROWS * 16 + 2 * ROWS) * 4 + 15) / 16 * 16;
-  const unsigned sA_addr = spk_lds_addr(sA), sW_addr = sA_addr + 2 * A_BYTES;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nch = a.nch;
-  const int G = a.Cout >> 5;
-  for (int i = tid; i < 2 * A_BYTES / 16; i += NWV * 64) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
-  for (int i = tid; i < NPP * 16; i += NWV * 64) s_cin[i] = 0;
-  if (tid < 2 * ROWS) s_nmax[tid] = 0;
-  __syncthreads();
-
-  const int row = lane & 31, half = lane >> 5;
-  const int hsel = (row >> 2) & 1, tt = (row & 3) + 4 * (row >> 3);
-  int a_off[NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    const int p = 2 * (wave + NWV * i) + hsel;
-    a_off[i] = ((p / W) * PW + (p % W)) * POSB + tt * 16;
-  }
-  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  unsigned pa_pk[NPA];
-#pragma unroll
-  for (int j = 0; j < NPA; ++j) {
-    int id = wave_s * NPA + j;
-    id = id < NA ? id : NA - 1;
-    const int y = id / PPR, px = id - y * PPR;
-    const int np = (W - 4 * px) < 4 ? (W - 4 * px) : 4;
-    const unsigned src = (unsigned)((y * W + 4 * px) * POSB), dst = (unsigned)(((y + 1) * PW + 1 + 4 * px) * POSB);
-    pa_pk[j] = src | (dst << 14) | ((unsigned)(np - 1) << 29);
-  }
-  const unsigned lane16 = (unsigned)lane * 16u;
-  const unsigned wave_k = (unsigned)wave_s * 1024u;
-  auto issue_piece = [&](int q, const uint8_t* aslab, const uint8_t* wslab, unsigned dA, unsigned dW) {
-    if (q < NPA) {
-      const unsigned pk = pa_pk[q];
-      const unsigned np = ((pk >> 29) & 3u) + 1u;
-      const unsigned long long mask = np == 4 ? ~0ull : ((1ull << (16 * np)) - 1ull);
-      spk_dma16s_masked(aslab + (pk & 0x3fffu), lane16, dA + ((pk >> 14) & 0x7fffu), mask);
-    } else {
-      unsigned ko = wave_k + 1024u * NWV * (unsigned)(q - NPA);
-      if (NWV * (q - NPA) + NWV - 1 >= W_PIECES) ko = ko < (unsigned)W_PIECES * 1024u ? ko : ko - 1024u * NWV;
-      spk_dma16s(wslab + ko, lane16, dW + ko);
-    }
-  };
-  const uint8_t* const wbase = a.wq + (long long)g * nch * W_SLAB;
-  auto aslab_of = [&](int itm, int c) -> const uint8_t* { return a.in0 + ((long long)itm * nch + c) * HW * POSB; };
-  const int nitems = n_images;
-
-  const int co = g * 32 + (lane & 31);
-  const float scale_f = (float)a.scale[co], bias_f = (float)a.bias[co];
-  const float bna = a.bn_a[co], bnb = a.bn_b[co];
-  const float Bc = fmaf(bias_f, bna, bnb);
-  const float cE = 2.0f * 2.38418579e-07f * (fabsf(bnb) + fabsf(Bc)) + 1e-30f;
-  const float cT = 528.0f * scale_f * fabsf(bna) * 1.000001f;
-  const float Ac4 = 1024.0f * scale_f * bna;
-  const int sc_a = 0x7f7f7f7f;
-  const int sc_p = half ? (int)0x82828282u : (int)0x87878787u;
-
-  constexpr int NREC = H * W * 16, NR = (NREC + NWV * 64 - 1) / (NWV * 64);
-  int rec_off[NR];
-  bool rec_ok[NR];
-#pragma unroll
-  for (int k = 0; k < NR; ++k) {
-    const int r = tid + k * NWV * 64;
-    const int cl = r >> 4, t = r & 15;
-    rec_ok[k] = r < NREC;
-    rec_off[k] = rec_ok[k] ? (((cl / W) + 1) * PW + 1 + (cl % W)) * POSB + t * 16 : 0;
-  }
-  // nine-tap sums of the published record counts: entry e = (position, step); this thread takes e = tid and tid + 512
-  auto row_sum_addr = [&](int e) -> const int* { return s_cin + (((e >> 4) / W) * PW + ((e >> 4) % W)) * 16 + (e & 15); };
-
-  // staging slab of this workgroup: [wave][tile][step quad][lane] float4 (a wave's store / copy instruction moves 1 KB)
-  float4* const zst = reinterpret_cast<float4*>(a.zstage) + ((long long)blockIdx.x * NWV + wave) * (NT * 4 * 64) + lane;
-  const uint8_t* const zst_w = reinterpret_cast<const uint8_t*>(a.zstage) + ((long long)blockIdx.x * NWV + wave_s) * (NT * 4 * 1024);
-  const float4* const zl = reinterpret_cast<const float4*>(s_z + wave * 4096) + lane;      // this lane's quads: zl[q * 64]
-  const unsigned zl_addr = spk_lds_addr(s_z) + (unsigned)wave_s * 4096u;
-  bool have_old = false;
-  int old_b = 0, par = 0;                                 // par: parity buffer that will take the counts of the CURRENT item
-
-  int it = 0;
-  if (il < nitems) {
-    const uint8_t* as0 = aslab_of(il, 0);
-#pragma unroll
-    for (int q = 0; q < NPIECES; ++q) issue_piece(q, as0, wbase, sA_addr, sW_addr);
-  }
-  for (int itm = il; itm < nitems; itm += lanes) {
-    const int b = itm;
-    const bool last_item = itm + lanes >= nitems;
-    v16f acc[NT][NACC];
-    int creg[NR];
-#pragma unroll
-    for (int k = 0; k < NR; ++k) creg[k] = 0;
-    ScanState ss = {0.f, 0.f, 3.0e38f, 0u}, sf = ss;
-    for (int c = 0; c < nch; ++c, ++it) {
-      const int buf = it & 1;
-      spk_dma_wait_all();
-      __syncthreads();
-      int nb = itm, nc = c + 1;
-      if (nc == nch) { nc = 0; nb = itm + lanes; }
-      const bool have_next = nb < nitems;
-      const uint8_t* n_aslab = aslab_of(have_next ? nb : itm, have_next ? nc : c);
-      const uint8_t* n_wslab = wbase + (long long)(have_next ? nc : c) * W_SLAB;
-      const unsigned n_dA = sA_addr + (buf ^ 1) * A_BYTES;
-      const unsigned n_dW = sW_addr + (buf ^ 1) * W_LDS;
-      const int opar = par ^ 1;                           // the previous item's counts
-      // which tile of the previous item this chunk scans (wave-uniform): chunk k + 1 <-> tile k
-      const int scan_k = (have_old && c >= 1 && c <= NT) ? c - 1 : -1;
-      const int load_k = (have_old && c < NT) ? c : -1;   // tile loaded late in this chunk for the next one
-      // The finish of the tile scanned during the chunk BEFORE (certification against its position's counts, flags, transpose,
-      // stores) comes first thing behind the barrier: no fragment registers are live yet (inside the K loop the finish pushed
-      // hipcc to 310 registers), and the stores -- they share the memory counter with the copies, so the next chunk barrier's
-      // s_waitcnt vmcnt(0) waits for them -- have a whole chunk to retire (at a chunk's END they cost every barrier a store
-      // latency: +36 % on the launch, profiles/r5_ab_defer_first_build.txt).
-      if (have_old && c >= 2 && c <= NT + 1 && !(SPK_V2_DEFER_DBG & 2)) {
-        const int fk = c - 2;
-        const int ti = wave + NWV * fk, pp = 2 * ti + half;
-        defer_finish(a, sf, zst + fk * 4 * 64, s_nmax[opar * ROWS + pp], s_row + opar * ROWS * 16 + pp * 16, cT, cE, old_b, co, g, G, HW, pp, lane);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (scan_k >= 0) { ss.v = 0.f; ss.zmax = 0.f; ss.dmin = 3.0e38f; ss.bits = 0u; }
-      v4i rvq[NR];
-      float4 zq[2];                                       // (the quad being scanned and the next one)
-      auto compute = [&](auto first_tag) {
-        constexpr bool FIRST = decltype(first_tag)::value;
-        const uint8_t* A = sA + buf * A_BYTES;
-        const uint8_t* Wb = sW + buf * W_LDS;
-        auto toff = [](int tap) constexpr -> int { return ((tap / 3) * PW + (tap % 3)) * POSB; };
-        auto lda = [&](auto s_tag) -> v4i {
-          constexpr int s = decltype(s_tag)::value;
-          return *reinterpret_cast<const v4i*>(A + a_off[s % NT] + toff(s / NT));
-        };
-        auto ldb = [&](int tile) -> v6i {
-          const uint8_t* p = Wb + tile * WT;
-          const v4i x = *reinterpret_cast<const v4i*>(p + lane * 16);
-          typedef const volatile __attribute__((address_space(3))) v2i* lds_v2i_ptr;
-          const v2i y = *(lds_v2i_ptr)SPK_LDS(p + 1024 + lane * 8);
-          const v6i r = {x[0], x[1], x[2], x[3], y[0], y[1]};
-          return r;
-        };
-        v6i bp[2][2];
-        bp[0][0] = ldb(0); bp[0][1] = ldb(1);
-        v4i af[PF];
-        static_for<PF>([&](auto s_tag) { af[decltype(s_tag)::value] = lda(s_tag); });
-        static_for<NSTEP>([&](auto s_tag) {
-          constexpr int s = decltype(s_tag)::value;
-          constexpr int tap = s / NT, i = s % NT;
-          const v4i av = af[s % PF];
-          if constexpr (s + PF < NSTEP) af[s % PF] = lda(std::integral_constant<int, s + PF>{});
-          if constexpr (FIRST && tap == 0) SPK_MFMA2_Z("v", acc[i][0], av, bp[0][0], sc_a, sc_p);
-          else SPK_MFMA2("v", acc[i][0], av, bp[tap & 1][0], sc_a, sc_p);
-          __builtin_amdgcn_sched_barrier(0);
-          if constexpr (i == 0 && 2 * tap < NPIECES) issue_piece(2 * tap, n_aslab, n_wslab, n_dA, n_dW);
-          if constexpr (i == 1 && 2 * tap + 1 < NPIECES) issue_piece(2 * tap + 1, n_aslab, n_wslab, n_dA, n_dW);
-          if constexpr (i == 0 && tap + 1 < 9) {
-            bp[(tap + 1) & 1][0] = ldb(2 * (tap + 1));
-            bp[(tap + 1) & 1][1] = ldb(2 * (tap + 1) + 1);
-          }
-          if constexpr (s == 1) {
-#pragma unroll
-            for (int k = 0; k < NR; ++k) rvq[k] = *reinterpret_cast<const v4i*>(sA + buf * A_BYTES + rec_off[k]);
-          }
-          if constexpr (s == SPK_V2_REC_STEP) {
-#pragma unroll
-            for (int k = 0; k < NR; ++k)
-              creg[k] += __builtin_popcount((unsigned)rvq[k][0]) + __builtin_popcount((unsigned)rvq[k][1]) +
-                         __builtin_popcount((unsigned)rvq[k][2]) + __builtin_popcount((unsigned)rvq[k][3]);
-          }
-          if constexpr (FIRST) {
-            // chunk 0: the previous item's counts.  Its records were published before this chunk's barrier: read the nine taps
-            // of this thread's two (position, step) entries, sum them a few steps later, publish sum and per-position maximum
-            // (buffer opar; the scans read it from the next chunk's barrier on) and clear the other buffer's maxima.
-            // (an opaque copy of the thread id: the entry addresses are recomputed here -- a few integer instructions -- instead
-            //  of being hoisted out of the item loop, spilled, and reloaded behind an s_waitcnt vmcnt(0) that would wait for
-            //  this chunk's copies)
-            if constexpr (s == 3 || s == 12) {
-              constexpr int j = s == 3 ? 0 : 1;
-              int t_ = tid;
-              asm volatile("" : "+v"(t_));
-              if (have_old && (j == 0 || t_ + 512 < (HW - 1) * 16) && !(SPK_V2_DEFER_DBG & 16)) {
-                // (read, sum and publish in one place: nine tap values held over a few steps were the first thing hipcc spilled)
-                const int e = t_ + 512 * j;
-                const int* c0 = row_sum_addr(e);
-                int sum = 0;
-#pragma unroll
-                for (int d = 0; d < 9; ++d) sum += c0[((d / 3) * PW + (d % 3)) * 16];
-                s_row[opar * ROWS * 16 + e] = sum;
-                atomicMax(&s_nmax[opar * ROWS + (e >> 4)], sum);
-              }
-            }
-            if constexpr (s == 20) {
-              int t_ = tid;
-              asm volatile("" : "+v"(t_));
-              if (t_ < ROWS) s_nmax[par * ROWS + t_] = 0;
-            }
-          } else {
-            // chunks 1 .. 3: one LIF step of the previous item's tile scan_k per K-loop step (steps 2 .. 17); its pre-activations
-            // sit in this wave's LDS tile (copied there during the chunk before), read one quad (four steps) ahead
-            if constexpr (s >= 1 && s <= 17 && !(SPK_V2_DEFER_DBG & 4)) {
-              if (scan_k >= 0) {
-                if constexpr (s == 1) zq[0] = zl[0];
-                if constexpr (s >= 2) {
-                  constexpr int r = s - 2, q = r / 4, e = r % 4;
-                  if constexpr (e == 0 && q < 3) zq[(q + 1) & 1] = zl[(q + 1) * 64];
-                  const float4 z4 = zq[q & 1];
-                  defer_lif_step(ss, e == 0 ? z4.x : e == 1 ? z4.y : e == 2 ? z4.z : z4.w);
-                }
-              }
-            }
-          }
-          if constexpr (s >= 19 && s <= 22) {
-            // the tile the NEXT chunk scans: four 1 KB pieces from the staging slab into this wave's LDS tile (the scan above is
-            // done with it).  LDS-DMA like every other copy of the kernel: no registers, invisible to the compiler's wait
-            // insertion, landed by the chunk barrier's s_waitcnt vmcnt(0).  (As ordinary loads into sixteen registers hipcc put
-            // s_waitcnt vmcnt in the middle of the next chunk -- in front of the first reuse of one of those registers -- which
-            // waited for that chunk's copies too: +28 % on the launch, profiles/r5_ab_defer_builds.txt.)
-            if (load_k >= 0 && !(SPK_V2_DEFER_DBG & 8)) {
-              constexpr int q = s - 19;
-              spk_dma16s(zst_w + (load_k * 4 + q) * 1024, lane16, zl_addr + q * 1024);
-            }
-          }
-          if constexpr (FIRST && tap == 0) SPK_MFMA2_Z("v", acc[i][1], av, bp[0][1], sc_a, sc_p);
-          else SPK_MFMA2("v", acc[i][1], av, bp[tap & 1][1], sc_a, sc_p);
-          __builtin_amdgcn_sched_barrier(0);
-        });
-      };
-      if (c == 0) compute(std::true_type{}); else compute(std::false_type{});
-      if (scan_k >= 0) sf = ss;                           // (finished behind the next barrier)
-    }   // chunks
-    if (have_old && nch == NT + 1 && !(SPK_V2_DEFER_DBG & 2)) {
-      // four chunks: the third tile's scan ended with the item's last chunk
-      const int fk = NT - 1, opar = par ^ 1;
-      const int ti = wave + NWV * fk, pp = 2 * ti + half;
-      defer_finish(a, sf, zst + fk * 4 * 64, s_nmax[opar * ROWS + pp], s_row + opar * ROWS * 16 + pp * 16, cT, cE, old_b, co, g, G, HW, pp, lane);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    // recombination: z_t = (P01 * 1024 + P23) * (1024 Ac) + Bc  (the first four instructions per step pair of the round-2 scan),
-    // out to the staging slab (the last item, scanned right below, reads them back from there too: one code path, and no
-    // moment at which accumulators and pre-activations are both in registers)
-    typedef float v2f __attribute__((ext_vector_type(2)));
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float z4[4];
-#pragma unroll
-        for (int e2 = 0; e2 < 4; e2 += 2) {
-          const int r2 = 4 * q + e2;
-          const v2f p0 = {acc[i][0][r2], acc[i][0][r2 + 1]}, p1 = {acc[i][1][r2], acc[i][1][r2 + 1]};
-          const v2f q4 = __builtin_elementwise_fma(p0, (v2f){1024.0f, 1024.0f}, p1);
-          const v2f z2 = __builtin_elementwise_fma(q4, (v2f){Ac4, Ac4}, (v2f){Bc, Bc});
-          z4[e2] = z2[0]; z4[e2 + 1] = z2[1];
-        }
-        if (!(SPK_V2_DEFER_DBG & 1)) zst[(i * 4 + q) * 64] = make_float4(z4[0], z4[1], z4[2], z4[3]);
-        else if (z4[0] + z4[1] + z4[2] + z4[3] == 12345.f) a.out[0] = 1;
-      }
-    }
-    // publish this item's record counts (summed behind the next chunk-0 barrier -- or right here for the last item)
-#pragma unroll
-    for (int k = 0; k < NR; ++k)
-      if (rec_ok[k]) s_cin[(rec_off[k] / POSB) * 16 + ((rec_off[k] % POSB) >> 4)] = creg[k];
-    old_b = b;
-    have_old = true;
-    par ^= 1;
-    if (last_item) {
-      // no successor to hide behind: counts pass with its two barriers, then the three tile scans back to back (round-2 order)
-      const int opar = par ^ 1;
-      __syncthreads();
-      for (int e = tid; e < (HW - 1) * 16; e += NWV * 64) {
-        const int* c0 = row_sum_addr(e);
-        int sum = 0;
-#pragma unroll
-        for (int d = 0; d < 9; ++d) sum += c0[((d / 3) * PW + (d % 3)) * 16];
-        s_row[opar * ROWS * 16 + e] = sum;
-        atomicMax(&s_nmax[opar * ROWS + (e >> 4)], sum);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < NT; ++k) {
-        ScanState s2 = {0.f, 0.f, 3.0e38f, 0u};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 z4 = zst[(k * 4 + q) * 64];
-          defer_lif_step(s2, z4.x); defer_lif_step(s2, z4.y); defer_lif_step(s2, z4.z); defer_lif_step(s2, z4.w);
-        }
-        const int pp = 2 * (wave + NWV * k) + half;
-        defer_finish(a, s2, zst + k * 4 * 64, s_nmax[opar * ROWS + pp], s_row + opar * ROWS * 16 + pp * 16, cT, cE, old_b, co, g, G, HW, pp, lane);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }   // items
-  spk_dma_wait_all();
-}
-
-template <int H, int W>
-__global__ __launch_bounds__(512, 1) void conv3x3_fp6v2_defer_kernel(V2Args a) {
-  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
-  int g, il, lanes;
-  fp6v2_wg_map(a, g, il, lanes);
-  fp6v2_body_defer<H, W>(a, g, il, lanes, Bn);
-  fp6v2_handover(a);
-}
-
-// ------------------------------------------------------------------------------------------------ staggered form (experiment)
-// The two waves of a SIMD run the same program and meet at every chunk barrier, so both reach the item's LIF scan together and
-// the matrix pipe idles for its whole length (19 % of den.conv4).  Here waves 4..7 run ONE CHUNK BEHIND waves 0..3 (MI355X guide,
-// "two waves that run the same program: try a stagger"): the item loop is a sequence of ticks (one barrier each); at tick k the
-// first set multiplies chunk n, the second chunk n - 1, and the copy engine fills chunk n + 1 -- a ring of THREE LDS slots
-// (139 KB).  At an item boundary one set scans while the other still multiplies: the scan's vector work runs beside MFMAs.
-// The active-input counts no longer need workgroup barriers inside the scan: every thread counts the records of the FIRST set's
-// chunk, the sums are published in the tick of that set's last chunk (they stay valid until both sets have scanned), and a wave
-// adds the nine taps of its own tiles' rows itself (32 lanes, a wave-private LDS line).  Full 7x7 items, eight waves, four digits.
-// MEASURED (round 3, B = 256, same box, bit-equal to the default form on every fp6v2 test): den.conv2 / 3 / 4 / 5 launches
-// 55.5 / 137 / 411 / 399 us against 49 / 124 / 390 / 384 us, the dense reverse process 100.6 against 95.1 ms -- 4 - 13 % SLOWER:
-// a wave that scans ALONE issues its 750 vector instructions at half the rate two scanning waves reach together (they hide each
-// other's compare -> select -> subtract latency), and it shares the SIMD's issue slots with the partner's MFMAs; the partner has
-// finished its chunk (54 MFMAs) long before and waits at the tick barrier.  Kept as an opt-in (SPKDIFF_V2_LAG=1) so that the
-// measurement can be repeated; tests/test_gpu_parity.py::test_fp6v2_staggered_form_bit_equal runs it.
-template <int H, int W>
-__device__ __forceinline__ void fp6v2_body_lag(const V2Args& a, const int g, const int il, const int lanes, const int n_images) {
-  static_assert(!USE_D4, "four-digit form");
-  constexpr int NWV = 8, HW = H * W, PW = W + 1, NT = (HW / 2) / NWV, N_AGPR = NACC * NT < 8 ? NACC * NT : 8;
-  static_assert((HW & 1) == 1 && ((HW / 2) % NWV) == 0, "whole 32-row tiles on every wave (+ one odd position)");
-  constexpr int NPP = (H + 2) * PW + 1, A_BYTES = NPP * POSB, PPR = (W + 3) / 4, NA = H * PPR;
-  constexpr int NPA = (NA + NWV - 1) / NWV, NPW = (W_PIECES + NWV - 1) / NWV, NPIECES = NPA + NPW;
-  constexpr int NSTEP = 9 * NT, NRING = 3;
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  uint8_t* const sA = lds;
-  uint8_t* const sW = lds + NRING * A_BYTES;
-  int* const s_cin = reinterpret_cast<int*>(lds + NRING * (A_BYTES + W_LDS));       // [NPP][16], borders stay zero
-  int* const s_nw = s_cin + NPP * 16;                                               // [NWV][32]: a wave's row counts of one tile
-  const unsigned sA_addr = spk_lds_addr(sA), sW_addr = sA_addr + NRING * A_BYTES;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nch = a.nch, G = a.Cout >> 5;
-  for (int i = tid; i < NRING * A_BYTES / 16; i += NWV * 64) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
-  for (int i = tid; i < NPP * 16; i += NWV * 64) s_cin[i] = 0;
-  __syncthreads();
-
-  const int row = lane & 31, half = lane >> 5;
-  const int hsel = (row >> 2) & 1, tt = (row & 3) + 4 * (row >> 3);
-  int a_off[NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    const int p = 2 * (wave + NWV * i) + hsel;
-    a_off[i] = ((p / W) * PW + (p % W)) * POSB + tt * 16;
-  }
-  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  const bool late = wave_s >= NWV / 2;                     // the second wave of every SIMD: one tick behind
-  unsigned pa_pk[NPA];
-#pragma unroll
-  for (int j = 0; j < NPA; ++j) {
-    int id = wave_s * NPA + j;
-    id = id < NA ? id : NA - 1;
-    const int y = id / PPR, px = id - y * PPR;
-    const int np = (W - 4 * px) < 4 ? (W - 4 * px) : 4;
-    const unsigned src = (unsigned)((y * W + 4 * px) * POSB), dst = (unsigned)(((y + 1) * PW + 1 + 4 * px) * POSB);
-    pa_pk[j] = src | (dst << 14) | ((unsigned)(np - 1) << 29);
-  }
-  const unsigned lane16 = (unsigned)lane * 16u;
-  const unsigned wave_k = (unsigned)wave_s * 1024u;
-  auto issue_piece = [&](int q, const uint8_t* aslab, const uint8_t* wslab, unsigned dA, unsigned dW) {
-    if (q < NPA) {
-      const unsigned pk = pa_pk[q];
-      const unsigned np = ((pk >> 29) & 3u) + 1u;
-      const unsigned long long mask = np == 4 ? ~0ull : ((1ull << (16 * np)) - 1ull);
-      spk_dma16s_masked(aslab + (pk & 0x3fffu), lane16, dA + ((pk >> 14) & 0x7fffu), mask);
-    } else {
-      unsigned ko = wave_k + 1024u * NWV * (unsigned)(q - NPA);
-      if (NWV * (q - NPA) + NWV - 1 >= W_PIECES) ko = ko < (unsigned)W_PIECES * 1024u ? ko : ko - 1024u * NWV;
-      spk_dma16s(wslab + ko, lane16, dW + ko);
-    }
-  };
-  const uint8_t* const wbase = a.wq + (long long)g * nch * W_SLAB;
-  auto aslab_of = [&](int itm, int c) -> const uint8_t* { return a.in0 + ((long long)itm * nch + c) * HW * POSB; };
-  const int my_items = il < n_images ? (n_images - il + lanes - 1) / lanes : 0;
-
-  const int co = g * 32 + (lane & 31);
-  const float scale_f = (float)a.scale[co], bias_f = (float)a.bias[co];
-  const float bna = a.bn_a[co], bnb = a.bn_b[co];
-  const float Bc = fmaf(bias_f, bna, bnb);
-  const float cE = 2.0f * 2.38418579e-07f * (fabsf(bnb) + fabsf(Bc)) + 1e-30f;
-  const float cT = 528.0f * scale_f * fabsf(bna) * 1.000001f;
-  const float Ac4 = 1024.0f * scale_f * bna;
-  const int sc_a = 0x7f7f7f7f;
-  const int sc_p = half ? (int)0x82828282u : (int)0x87878787u;
-
-  // record counts: thread r counts NR (cell, step) records of the FIRST set's current chunk
-  constexpr int NREC = H * W * 16, NR = (NREC + NWV * 64 - 1) / (NWV * 64);
-  int creg[NR], rec_off[NR];
-  bool rec_ok[NR];
-#pragma unroll
-  for (int k = 0; k < NR; ++k) {
-    creg[k] = 0;
-    const int r = tid + k * NWV * 64;
-    const int cl = r >> 4, t = r & 15;
-    rec_ok[k] = r < NREC;
-    rec_off[k] = rec_ok[k] ? (((cl / W) + 1) * PW + 1 + (cl % W)) * POSB + t * 16 : 0;
-  }
-
-  // ---- the tick machine: state of the FIRST set (every wave tracks it: it decides what is copied and counted)
-  int tick = 0;                                            // ticks begun
-  int fk = 0, fph = 0, fslot = 0;                          // first set at this tick: item ordinal, phase (nch = scan), ring slot
-  bool have_next = false;
-  const uint8_t* n_aslab = nullptr; const uint8_t* n_wslab = nullptr;
-  unsigned n_dA = 0, n_dW = 0;
-  if (my_items > 0) {
-    const uint8_t* as0 = aslab_of(il, 0);
-#pragma unroll
-    for (int q = 0; q < NPIECES; ++q) issue_piece(q, as0, wbase, sA_addr, sW_addr);
-  }
-  // One call per tick by EVERY wave: barrier, then (all threads) count the first set's chunk, publish at its last chunk, and
-  // work out what the copy engine fills during this tick (the first set's chunk of the NEXT tick).
-  auto begin_tick = [&]() {
-    spk_dma_wait_all();
-    __syncthreads();
-    const bool f_act = fk < my_items;
-    if (f_act && fph < nch) {
-#pragma unroll
-      for (int k = 0; k < NR; ++k) {
-        const v4i rv = *reinterpret_cast<const v4i*>(sA + fslot * A_BYTES + rec_off[k]);
-        creg[k] += __builtin_popcount((unsigned)rv[0]) + __builtin_popcount((unsigned)rv[1]) +
-                   __builtin_popcount((unsigned)rv[2]) + __builtin_popcount((unsigned)rv[3]);
-      }
-      if (fph == nch - 1) {
-#pragma unroll
-        for (int k = 0; k < NR; ++k) {
-          if (rec_ok[k]) s_cin[(rec_off[k] / POSB) * 16 + ((rec_off[k] % POSB) >> 4)] = creg[k];
-          creg[k] = 0;
-        }
-      }
-    }
-    // the first set's state at the next tick
-    int nk = fk, nph = fph + 1, nslot = fslot;
-    if (nph > nch) { nph = 0; nk = fk + 1; }
-    if (fph < nch) nslot = fslot == NRING - 1 ? 0 : fslot + 1;       // (a scan tick consumes no slot)
-    have_next = f_act && nk < my_items && nph < nch;
-    if (have_next) {
-      n_aslab = aslab_of(il + nk * lanes, nph);
-      n_wslab = wbase + (long long)nph * W_SLAB;
-      n_dA = sA_addr + nslot * A_BYTES;
-      n_dW = sW_addr + nslot * W_LDS;
-    }
-    fk = nk; fph = nph;
-    if (have_next || !f_act) fslot = nslot; else fslot = nslot;
-    ++tick;
-  };
-  auto issue_all = [&]() {
-    if (have_next) {
-#pragma unroll
-      for (int q = 0; q < NPIECES; ++q) issue_piece(q, n_aslab, n_wslab, n_dA, n_dW);
-    }
-  };
-
-  if (late) { begin_tick(); issue_all(); }                 // the second set idles through the first tick
-  int oslot = 0;                                           // this wave's own ring slot (its chunk sequence number mod 3)
-  for (int k = 0; k < my_items; ++k) {
-    const int b = il + k * lanes;
-    v16f acc[NT][NACC];
-    for (int c = 0; c < nch; ++c) {
-      begin_tick();
-      const uint8_t* A = sA + oslot * A_BYTES;
-      const uint8_t* Wb = sW + oslot * W_LDS;
-      auto compute = [&](auto first_tag) {
-        constexpr bool FIRST = decltype(first_tag)::value;
-        auto toff = [](int tap) constexpr -> int { return ((tap / 3) * PW + (tap % 3)) * POSB; };
-        auto lda = [&](auto s_tag) -> v4i {
-          constexpr int s = decltype(s_tag)::value;
-          return *reinterpret_cast<const v4i*>(A + a_off[s % NT] + toff(s / NT));
-        };
-        auto ldb = [&](int tile) -> v6i {
-          const uint8_t* p = Wb + tile * WT;
-          const v4i x = *reinterpret_cast<const v4i*>(p + lane * 16);
-          typedef const volatile __attribute__((address_space(3))) v2i* lds_v2i_ptr;
-          const v2i y = *(lds_v2i_ptr)SPK_LDS(p + 1024 + lane * 8);
-          const v6i r = {x[0], x[1], x[2], x[3], y[0], y[1]};
-          return r;
-        };
-        v6i bp[2][2];
-        bp[0][0] = ldb(0); bp[0][1] = ldb(1);
-        constexpr int PF = 4;
-        v4i af[PF];
-        static_for<PF>([&](auto s_tag) { af[decltype(s_tag)::value] = lda(s_tag); });
-        static_for<NSTEP>([&](auto s_tag) {
-          constexpr int s = decltype(s_tag)::value;
-          constexpr int tap = s / NT, i = s % NT;
-          const v4i av = af[s % PF];
-          if constexpr (s + PF < NSTEP) af[s % PF] = lda(std::integral_constant<int, s + PF>{});
-#define V2L_PAIR_MFMA(J)                                                                                    \
-  do {                                                                                                      \
-    if constexpr (FIRST && tap == 0) {                                                                      \
-      if constexpr (NACC * i + (J) < N_AGPR) SPK_MFMA2_Z("a", acc[i][J], av, bp[0][J], sc_a, sc_p);          \
-      else SPK_MFMA2_Z("v", acc[i][J], av, bp[0][J], sc_a, sc_p);                                           \
-    } else {                                                                                                \
-      if constexpr (NACC * i + (J) < N_AGPR) SPK_MFMA2("a", acc[i][J], av, bp[tap & 1][J], sc_a, sc_p);      \
-      else SPK_MFMA2("v", acc[i][J], av, bp[tap & 1][J], sc_a, sc_p);                                       \
-    }                                                                                                       \
-  } while (0)
-          V2L_PAIR_MFMA(0);
-          __builtin_amdgcn_sched_barrier(0);
-          if constexpr (i == 0 && 2 * tap < NPIECES) {
-            if (have_next) issue_piece(2 * tap, n_aslab, n_wslab, n_dA, n_dW);
-          }
-          if constexpr (i == (NT > 1 ? NT / 2 : 0) && 2 * tap + 1 < NPIECES) {
-            if (have_next) issue_piece(2 * tap + 1, n_aslab, n_wslab, n_dA, n_dW);
-          }
-          if constexpr (i == 0 && tap + 1 < 9) {
-            bp[(tap + 1) & 1][0] = ldb(2 * (tap + 1));
-            bp[(tap + 1) & 1][1] = ldb(2 * (tap + 1) + 1);
-          }
-          V2L_PAIR_MFMA(1);
-          __builtin_amdgcn_sched_barrier(0);
-#undef V2L_PAIR_MFMA
-        });
-      };
-      if (c == 0) compute(std::true_type{}); else compute(std::false_type{});
-      oslot = oslot == NRING - 1 ? 0 : oslot + 1;
-    }
-    // ---- this set's scan tick: its copies first, then the epilogue beside the other set's MFMAs
-    begin_tick();
-    issue_all();
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#pragma unroll
-    for (int kk = 0; kk < NT; ++kk) {
-      const int i = kk == 0 ? NT - 1 : kk - 1;
-#pragma unroll
-      for (int j = 0; j < NACC; ++j)
-        if (NACC * i + j < N_AGPR) asm volatile("" : "+a"(acc[i][j]));
-      const int ti = wave + NWV * i;
-      // active inputs of the tile's 32 rows: lane l < 32 adds the nine taps of (position 2 ti + (l >> 4), step l & 15)
-      {
-        const int pp = 2 * ti + ((lane >> 4) & 1), t = lane & 15;
-        const int* c0 = s_cin + ((pp / W) * PW + (pp % W)) * 16 + t;
-        int sum = 0;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx) sum += c0[(dy * PW + dx) * 16];
-        if (lane < 32) s_nw[wave * 32 + lane] = sum;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      int cntv[16];
-      {
-        const v4i* rp = reinterpret_cast<const v4i*>(s_nw + wave * 32 + half * 16);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const v4i c4 = rp[q];
-          cntv[4 * q] = c4[0]; cntv[4 * q + 1] = c4[1]; cntv[4 * q + 2] = c4[2]; cntv[4 * q + 3] = c4[3];
-        }
-      }
-      typedef float v2f __attribute__((ext_vector_type(2)));
-      float v = 0.f, zmax = 0.f, dmin = 3.0e38f;
-      unsigned mybits = 0;
-      int nmax = 0;
-#pragma unroll
-      for (int r2 = 0; r2 < 16; r2 += 2) {
-        const v2f p0 = {acc[i][0][r2], acc[i][0][r2 + 1]}, p1 = {acc[i][1][r2], acc[i][1][r2 + 1]};
-        const v2f q4 = __builtin_elementwise_fma(p0, (v2f){1024.0f, 1024.0f}, p1);
-        const v2f z2 = __builtin_elementwise_fma(q4, (v2f){Ac4, Ac4}, (v2f){Bc, Bc});
-        nmax = max(nmax, max(cntv[r2], cntv[r2 + 1]));
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const float z = z2[e];
-          zmax = fmaxf(zmax, fabsf(z));
-          const float h = fmaf(z - v, 0.5f, v);
-          dmin = fminf(dmin, fabsf(h - 1.0f));
-          const bool sp = h >= 1.0f;
-          v = sp ? 0.0f : h;
-          mybits |= sp ? (1u << (r2 + e)) : 0u;
-        }
-      }
-      const bool flg = dmin <= SPK_V2_SPARE * fmaf(zmax, 2.5f * CERT_4EPS, fmaf((float)nmax, cT, cE));
-      const int p = 2 * ti + half;
-      if (flg && !(SPK_V2_DBG & 32)) {
-        const long long n = ((long long)b * a.Cout + co) * HW + p;
-        const unsigned idx = atomicAdd(a.flags, 1u);
-        if (idx < a.flag_cap) a.flags[2 + idx] = (unsigned)n;
-        else atomicOr(a.flags + 2 + a.flag_cap + (n >> 5), 1u << (n & 31));
-      }
-      const long long rec = (((long long)b * G + g) * HW + p) * POSB;
-      store_tile_spikes(a.out, a.out_cnt, mybits, lane, rec, (((long long)b * G + g) * HW + p) * 32, true);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  if (!late) { begin_tick(); issue_all(); }                // the first set waits out the second set's last tick
-  spk_dma_wait_all();
-}
-
-template <int H, int W>
-__global__ __launch_bounds__(512, 1) void conv3x3_fp6v2_lag_kernel(V2Args a) {
-  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
-  int g, il, lanes;
-  fp6v2_wg_map(a, g, il, lanes);
-  fp6v2_body_lag<H, W>(a, g, il, lanes, Bn);
-  fp6v2_handover(a);
-}
 
 template <int H, int W, int NWV, bool SPLIT = false>
 __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6v2_kernel(V2Args a) {
@@ -2341,7 +1224,7 @@ __device__ __forceinline__ void fp6v2_fixup_body(const V2Args& a, long long n_wo
   for (unsigned e = bid; e < nlist; e += nb) fixup_neuron<H, W>(a, (long long)a.flags[2 + e], sS, sQ, Bn);
   if (count > a.flag_cap) {
     // overflow path (more than flag_cap flagged neurons): the rest sit in the bitmap; scan a share of it, clear as we go
-    unsigned* bm = a.flags + 2 + a.flag_cap;
+    unsigned* bm = a.flags + 2 + FLAG_CAP;
     const long long per = (n_words + nb - 1) / nb;
     const long long w0 = (long long)bid * per;
     const long long w1 = w0 + per < n_words ? w0 + per : n_words;
@@ -2633,18 +1516,19 @@ extern "C" int spk_den_pack_weight_fp6v2(const float* w, const float* bias, uint
   return SPK_OK;
 }
 
-constexpr unsigned FLAG_CAP = 1u << 20;        // list capacity; beyond it flagged neurons go to the bitmap (slow path)
-
 extern "C" long long spk_den_fp6v2_flag_words(int B, int Cout, int H, int W) {
   if (B <= 0 || Cout <= 0 || H <= 0 || W <= 0) return -1;
-  return 2 + (long long)FLAG_CAP + ((long long)B * Cout * H * W + 31) / 32 + 1 + DUO_CU_SLOTS + DUO_ITEM_CTRS +   // (+ ticket, + the duo form's CU and item-claim counters,
-         (long long)spk_cu_count() * ZSTAGE_WORDS_PER_WG;                                      //  + the deferred-scan form's staging slabs)
+  long long words = 2 + (long long)FLAG_CAP + ((long long)B * Cout * H * W + 31) / 32 + 1;   // (+ ticket)
+#if SPK_V2_VARIANTS
+  words += DUO_CU_SLOTS + DUO_ITEM_CTRS + (long long)spk_cu_count() * ZSTAGE_WORDS_PER_WG;   // duo counters, deferred-scan staging slabs
+#endif
+  return words;
 }
 
 static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale, const double* bias_d,
                         const float* wl1, const int* qtab, const float* bn_a, const float* bn_b, uint8_t* out_s32,
                         uint8_t* out_counts, unsigned* flag_words, int T, int B, int H, int W, int Cout,
-                        const int* n_dyn_or_null, const uint8_t* need, int need_R, int need_r, hipStream_t stream,
+                        const int* n_dyn_or_null, const uint8_t* need, int need_R, int need_r, int flag_cap, hipStream_t stream,
                         int parts = 7) {
   if (!in_s32 || nch <= 0 || !wq || !scale || !bias_d || !wl1 || !qtab || !bn_a || !bn_b || !out_s32 || !flag_words ||
       B <= 0 || H <= 0 || W <= 0 || Cout <= 0)
@@ -2654,7 +1538,8 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   if (need && (bands || !n_dyn_or_null)) return SPK_ERR_UNSUPPORTED;
   V2Args a;
   a.in0 = in_s32; a.nch = nch; a.wq = wq; a.scale = scale; a.bias = bias_d; a.wl1 = wl1; a.qtab = qtab;
-  a.bn_a = bn_a; a.bn_b = bn_b; a.out = out_s32; a.out_cnt = out_counts; a.flags = flag_words; a.flag_cap = FLAG_CAP;
+  a.bn_a = bn_a; a.bn_b = bn_b; a.out = out_s32; a.out_cnt = out_counts; a.flags = flag_words;
+  a.flag_cap = flag_cap < 0 || (unsigned)flag_cap > FLAG_CAP ? FLAG_CAP : (unsigned)flag_cap;   // (< 0: the whole list)
   a.n_dyn = n_dyn_or_null;
   a.dbg_out = nullptr; a.cu_slots = nullptr; a.item_ctr = nullptr; a.duo_delay = 0; a.zstage = nullptr;
   a.need = nullptr; a.cls_cnt = nullptr; a.cls_list = nullptr;
@@ -2713,9 +1598,11 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
     return SPK_OK;
   }
   if (bands) {
-    const bool eight_b = spk_opt(SPK_OPT_V2_WAVES) != 4;   // (+4 %)
-    if (eight_b) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 8, true>), dim3(grid), dim3(512), lds8, stream, a);
-    else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 4, true>), dim3(grid), dim3(256), lds, stream, a);
+#if SPK_V2_VARIANTS
+    if (spk_opt(SPK_OPT_V2_WAVES) == 4) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 4, true>), dim3(grid), dim3(256), lds, stream, a);
+    else
+#endif
+    hipLaunchKernelGGL((conv3x3_fp6v2_kernel<8, 8, 8, true>), dim3(grid), dim3(512), lds8, stream, a);   // (eight waves: +4 % over four)
     SPK_LAUNCH_CHECK();
     hipLaunchKernelGGL((fp6v2_tail_kernel<8, 8, 1>), dim3(8 * cus), dim3(256), fix_lds, stream, a, n_words, 0);   // (even latent: repair only)
     SPK_LAUNCH_CHECK();
@@ -2729,6 +1616,7 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   // 417-466 against 383-387 us, dense reverse process 103.3 against 92.3 ms) although three waves issue vector instructions
   // 1.4x faster than two (tools/coexec_probe.hip: 2.2 against 3.1 cycles per v_fma_f32): a weight tile read from LDS then
   // serves two row tiles instead of three and twelve waves meet at every chunk barrier.  SPKDIFF_V2_WAVES=4: one wave.
+#if SPK_V2_VARIANTS
   const bool eight = spk_opt(SPK_OPT_V2_WAVES) != 4, twelve = spk_opt(SPK_OPT_V2_WAVES) == 12;
   const bool lag_form = spk_opt(SPK_OPT_V2_LAG) != 0 || SPK_V2_LAG_DEFAULT != 0;
   if (need) {
@@ -2764,6 +1652,13 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   } else if (twelve) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 12>), dim3(grid), dim3(768), lds, stream, a);
   else if (eight) hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 8>), dim3(grid), dim3(512), lds8, stream, a);
   else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 4>), dim3(grid), dim3(256), lds, stream, a);
+#else
+  // (the four- and twelve-wave, staggered, duo and deferred-scan forms are `make variants` builds: csrc/variants/fp6v2_forms.inc)
+  if (need) {
+    if (grid / G < 6) return SPK_ERR_UNSUPPORTED;           // one image lane per tile-count class at least
+    hipLaunchKernelGGL((conv3x3_fp6v2_listed_kernel<7, 7, 8>), dim3(grid), dim3(512), lds, stream, a);
+  } else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 8>), dim3(grid), dim3(512), lds8, stream, a);
+#endif
   SPK_LAUNCH_CHECK();
   const int n_lp = ((B + 2 * SPK_V2_LP_PAIRS - 1) / (2 * SPK_V2_LP_PAIRS)) * G;
   if (!n_dyn_or_null && SPK_V2_MERGE_FULL && spk_opt(SPK_OPT_V2_LPS) != 0 && nch >= 2 && (long long)LPS_LDS + 4096 <= spk_lds_limit()) {
@@ -2791,19 +1686,20 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
 extern "C" int spk_den_conv3x3_mfma_fp6v2(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale,
                                           const double* bias_d, const float* wl1, const int* qtab, const float* bn_a,
                                           const float* bn_b, uint8_t* out_s32, uint8_t* out_counts, unsigned* flag_words,
-                                          int T, int B, int H, int W, int Cout, const int* n_dyn_or_null, hipStream_t stream) {
+                                          int T, int B, int H, int W, int Cout, const int* n_dyn_or_null, int flag_cap,
+                                          hipStream_t stream) {
   return fp6v2_launch(in_s32, nch, wq, scale, bias_d, wl1, qtab, bn_a, bn_b, out_s32, out_counts, flag_words, T, B, H, W, Cout,
-                      n_dyn_or_null, nullptr, 0, 0, stream);
+                      n_dyn_or_null, nullptr, 0, 0, flag_cap, stream);
 }
 
 extern "C" int spk_den_conv3x3_mfma_fp6v2_part(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale,
                                                const double* bias_d, const float* wl1, const int* qtab, const float* bn_a,
                                                const float* bn_b, uint8_t* out_s32, uint8_t* out_counts, unsigned* flag_words,
                                                int T, int B, int H, int W, int Cout, const int* n_dyn_or_null, int part,
-                                               hipStream_t stream) {
+                                               int flag_cap, hipStream_t stream) {
   if (part != 2 && part != 4) return SPK_ERR_ARG;
   return fp6v2_launch(in_s32, nch, wq, scale, bias_d, wl1, qtab, bn_a, bn_b, out_s32, out_counts, flag_words, T, B, H, W, Cout,
-                      n_dyn_or_null, nullptr, 0, 0, stream, part);
+                      n_dyn_or_null, nullptr, 0, 0, flag_cap, stream, part);
 }
 
 extern "C" int spk_den_conv3x3_mfma_fp6v2_listed(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale,
@@ -2811,10 +1707,10 @@ extern "C" int spk_den_conv3x3_mfma_fp6v2_listed(const uint8_t* in_s32, int nch,
                                                  const float* bn_b, uint8_t* out_s32, uint8_t* out_counts,
                                                  unsigned* flag_words, int T, int B, int H, int W, int Cout,
                                                  const int* n_dyn, const uint8_t* need, int need_radii, int radius,
-                                                 hipStream_t stream) {
+                                                 int flag_cap, hipStream_t stream) {
   if (!need || !n_dyn || need_radii <= 0 || need_radii > 8 || radius < 1 || radius > need_radii) return SPK_ERR_ARG;
   return fp6v2_launch(in_s32, nch, wq, scale, bias_d, wl1, qtab, bn_a, bn_b, out_s32, out_counts, flag_words, T, B, H, W, Cout,
-                      n_dyn, need, need_radii, radius - 1, stream);
+                      n_dyn, need, need_radii, radius - 1, flag_cap, stream);
 }
 
 extern "C" int spk_spikes_to_s32(const float* spikes, uint8_t* out_s32, int T, int B, int C, int HW, hipStream_t stream) {

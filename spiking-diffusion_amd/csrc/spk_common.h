@@ -20,10 +20,21 @@
     if (e__ != hipSuccess) return (int)e__;                  \
   } while (0)
 
-// measurement options (api.hip: spk_set_option / spk_get_option; include/spkdiff.h lists them)
+// Launch-shape choices that earlier rounds measured against each other.  In the shipped library they are COMPILE-TIME CONSTANTS
+// (spk_opt folds to the default: no process-wide state, include/spkdiff.h's contract); only a -DSPK_V2_VARIANTS=1 build
+// (`make variants`, include/spkdiff_variants.h) keeps them settable through spk_set_option so that the A/B measurements can be repeated.
+#ifndef SPK_V2_VARIANTS
+#define SPK_V2_VARIANTS 0
+#endif
 enum { SPK_OPT_CONV6_SHARED = 0, SPK_OPT_CONV6_SHARED_DYN, SPK_OPT_MFMA_DEBUG, SPK_OPT_FP6_XCD_WALK, SPK_OPT_FP6_WAVES,
        SPK_OPT_V2_WAVES, SPK_OPT_V2_LAG, SPK_OPT_V2_DUO, SPK_OPT_V2_DEFER, SPK_OPT_V2_LPS, SPK_OPT_COUNT };
+#define SPK_OPT_DEFAULT_VALUES {1, 1, 0, 1, 4, 8, 0, 0, 0, 1}
+#if SPK_V2_VARIANTS
 int spk_opt(int id);
+#else
+constexpr int SPK_OPT_DEFAULTS[SPK_OPT_COUNT] = SPK_OPT_DEFAULT_VALUES;
+constexpr int spk_opt(int id) { return SPK_OPT_DEFAULTS[id]; }
+#endif
 
 static inline int spk_blocks(long long n, int threads) { return (int)((n + threads - 1) / threads); }
 

@@ -588,7 +588,7 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
           const long long nid = pos * a.Cout + co;
           const unsigned idx = atomicAdd(a.flags, 1u);
           if (idx < a.flag_cap) a.flags[2 + idx] = (unsigned)nid;
-          else atomicOr(a.flags + 2 + a.flag_cap + (nid >> 5), 1u << (nid & 31));
+          else atomicOr(a.flags + 2 + FLAG_CAP + (nid >> 5), 1u << (nid & 31));
         }
         if (OUT == OUT_COLLAPSED) {
           if (ok) reinterpret_cast<float*>(a.out)[pos * a.Cout + co] = m;
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(256) void vae_fp6_fixup_kernel(TArgs a, long long n
   const unsigned nlist = count < a.flag_cap ? count : a.flag_cap;
   for (long long e = wv; e < nlist; e += nwv) vae_fix_neuron<GEO, H, W, NCH, OUT>(a, (long long)a.flags[2 + e], lane);
   if (count > a.flag_cap) {                  // overflow: the rest sit in the bitmap; every wave scans a share, clearing as it goes
-    unsigned* bm = a.flags + 2 + a.flag_cap;
+    unsigned* bm = a.flags + 2 + FLAG_CAP;
     for (long long wi = wv; wi < n_words; wi += nwv) {
       unsigned wd = bm[wi];
       if (wd && lane == 0) bm[wi] = 0u;
@@ -949,13 +949,14 @@ extern "C" int spk_ptc_to_s32(const uint8_t* in_ptc, uint8_t* out_s32, int T, in
 extern "C" int spk_vae_fp6_fwd(const uint8_t* in_s32, const uint8_t* wq, const double* scale, const double* bias_d,
                                const int* qtab, const float* bn_a, const float* bn_b, const float* coef_or_null, void* out,
                                int out_kind, unsigned* flag_words, int T, int B, int H, int W, int Cin, int Cout, int transposed,
-                               hipStream_t stream) {
+                               int flag_cap, hipStream_t stream) {
   if (!in_s32 || !wq || !scale || !bias_d || !qtab || !bn_a || !bn_b || !out || !flag_words || B <= 0) return SPK_ERR_ARG;
   if (out_kind == OUT_COLLAPSED && !coef_or_null) return SPK_ERR_ARG;
   if (T != T16 || (Cout % 32) || B > (1 << 22)) return SPK_ERR_UNSUPPORTED;
   TArgs a;
   a.in = in_s32; a.wq = wq; a.scale = scale; a.bias = bias_d; a.bn_a = bn_a; a.bn_b = bn_b; a.coef = coef_or_null; a.out = out;
-  a.flags = flag_words; a.flag_cap = FLAG_CAP; a.qtab = qtab; a.B = B; a.Cout = Cout; a.Cin = Cin;
+  a.flags = flag_words; a.qtab = qtab; a.B = B; a.Cout = Cout; a.Cin = Cin;
+  a.flag_cap = flag_cap < 0 || (unsigned)flag_cap > FLAG_CAP ? FLAG_CAP : (unsigned)flag_cap;   // id-list entries used (< 0: all); layout fixed
   const int Ho = transposed ? 2 * H : H / 2, Wo = transposed ? 2 * W : W / 2;
   const long long neurons = (long long)B * Cout * Ho * Wo;
   if (neurons >= (1ll << 32)) return SPK_ERR_UNSUPPORTED;                                   // neuron ids are 32-bit

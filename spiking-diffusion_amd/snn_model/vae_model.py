@@ -5,8 +5,9 @@ Counterpart of R/snn_model/vae_model.py:22-196 -- same class names, constructor 
 keys, so R/main.py's test/sampling section runs against it unchanged.  The eval branches run on
 ``libspkdiff.so`` (fused Conv+BN+LIF kernels, VQ argmin kernel).  The training branches (VQ / commitment / PSP /
 reconstruction losses, straight-through estimator: vae_model.py:61-85,189-196) run in train()
-mode with autograd: library (transposed) convolutions through torch, native BatchNorm+LIF block tails
-(``spk_bn_lif_train_*``), membrane read-out, code search and PSP filter (``spk_psp``).
+mode with autograd: native convolutions forward and backward (``csrc/conv_train.hip``, fp32 matrix cores; shapes it does not
+cover take the framework's operator), native BatchNorm+LIF block tails (``spk_bn_lif_train_*``), and the VectorQuantizer's
+read-out / code search / losses, the PSP losses and the reconstruction loss as fused operators (``csrc/vq_train.hip``).
 
 Re-exported names match what ``from snn_model.vae_model import *`` gives R/main.py (``functional`` in particular,
 R/main.py:101-107,317).
@@ -19,7 +20,7 @@ from spikingjelly.activation_based import neuron, functional, layer, surrogate, 
 from spikingjelly import visualizing  # noqa: F401
 
 from spkdiff import ops
-from spkdiff.fused import FusedSequential, has_hooks
+from spkdiff.fused import FusedSequential, has_hooks, derived_epoch
 from spkdiff.ops import IN_PTC, IN_SEQ, IN_TINV
 
 from .snn_layers import *  # noqa: F401,F403
@@ -79,7 +80,8 @@ class VectorQuantizer(nn.Module):
         if not torch.is_grad_enabled():
             _training_oos('VectorQuantizer.forward in train() mode without autograd')
         T = x.shape[0]
-        if self.fused_train and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and T == self.memout.coef.numel():
+        if (self.fused_train and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and T == self.memout.coef.numel()
+                and self.embedding_dim <= ops.VQ_TRAIN_MAX_D):       # (spk_vq_train_bwd keeps a code vector in registers: D <= 64)
             # read-out, code search, q / e latent losses, straight-through value: three native launches forward, one backward
             # (ops.VQTrainFunction; the module-by-module algebra below is the same arithmetic through autograd)
             quantized, loss_1 = ops.VQTrainFunction.apply(x, self.memout.coef, self.alpha, self.embeddings.weight,
@@ -252,7 +254,8 @@ class SNN_VQVAE(nn.Module):
         e_ptc = None
         if SPIKEGEN_BY_TOKEN and self._decoder_takes_s32(T, h, w):
             # embedding + spike generator + nibble packing as a per-token pattern table (csrc/conv_direct.hip, spk_spikegen_tokens_s32)
-            e_ptc = self.vq_layer.poisson.tokens_to_s32(tokens, self.vq_layer.embeddings.weight, T=T)
+            e_ptc = self.vq_layer.poisson.tokens_to_s32(tokens, self.vq_layer.embeddings.weight, T=T,
+                                                        epoch=derived_epoch(self.vq_layer))
         if e_ptc is None:
             zq = ops.embedding(tokens, self.vq_layer.embeddings.weight, nchw_hw=(h, w))
             e_ptc = self.vq_layer.poisson.run(zq, IN_TINV, final='ptc', T=T, stateful=False)['ptc']

@@ -87,9 +87,9 @@ _SIGS = {
     "spk_den_packed_weight_fp6v2_bytes": (c_longlong, [c_int, c_int]),
     "spk_den_pack_weight_fp6v2": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),
     "spk_den_fp6v2_flag_words": (c_longlong, [c_int, c_int, c_int, c_int]),
-    "spk_den_conv3x3_mfma_fp6v2": (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "spk_den_conv3x3_mfma_fp6v2": (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
     "spk_den_conv3x3_mfma_fp6v2_part": (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_int,
-                                                P]),
+                                                c_int, P]),
     "spk_spikes_to_s32": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spk_s32_to_spikes": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spk_spikes_to_fp4": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
@@ -121,11 +121,11 @@ _SIGS = {
     "spk_ptc_to_s32": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "spk_spikegen_table_bytes": (c_longlong, [c_int, c_int]),
     "spk_spikegen_tokens_s32": (c_int, [P, P, P, P, P, P, P, c_int, P, c_int, c_longlong, c_int, c_int, c_int, P]),
-    "spk_vae_fp6_fwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "spk_vae_fp6_fwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_select_needed_bytes": (c_longlong, [c_int, c_int]),
     "spk_select_needed": (c_int, [P, c_int, P, c_ulonglong, c_ulonglong, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "spk_den_conv3x3_mfma_fp6v2_listed": (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P,
-                                                  P, c_int, c_int, P]),
+                                                  P, c_int, c_int, c_int, P]),
     "spk_den_build_input": (c_int, [P, P, P, c_longlong, P, c_int, c_int, P, P, P]),
     "spk_psample_step": (c_int, [P, P, P, c_int, c_float, P, P, c_ulonglong, c_ulonglong, P, P, c_int, c_int, c_int,
                                  P, P, P, P]),
@@ -142,6 +142,9 @@ _SIGS = {
     "spk_conv_train_wgrad_ws_bytes": (c_longlong, [c_int] * 6),
     "spk_conv_train_wgrad": (c_int, [P, P, P, c_longlong, P, P] + [c_int] * 10 + [c_longlong] * 3 + [c_int, P]),
     "spk_q_sample": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_float, P]),
+}
+# `make variants` builds only (include/spkdiff_variants.h): the shipped library exports neither and keeps no process-wide state
+_VARIANT_SIGS = {
     "spk_set_option": (c_int, [ctypes.c_char_p, c_int]),
     "spk_get_option": (c_int, [ctypes.c_char_p, P]),
 }
@@ -152,6 +155,12 @@ for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)      # AttributeError here = header/library mismatch: fail loudly
     _fn.restype = _res
     _fn.argtypes = _args
+HAS_OPTIONS = hasattr(lib, "spk_set_option")          # True only for a variants build loaded through SPKDIFF_LIB
+if HAS_OPTIONS:
+    for _name, (_res, _args) in _VARIANT_SIGS.items():
+        _fn = getattr(lib, _name)
+        _fn.restype = _res
+        _fn.argtypes = _args
 
 
 def check(rc: int, what: str = ""):
@@ -172,23 +181,33 @@ def version() -> int:
 
 # The signatures declared above are those of include/spkdiff.h at this version.  A stale libspkdiff.so or an SPKDIFF_LIB A/B
 # variant built from another header would take arguments at the wrong positions (silently wrong results): refuse it here.
-EXPECTED_VERSION = 103
+EXPECTED_VERSION = 104
 if version() != EXPECTED_VERSION:
     raise ImportError(f"spkdiff: {LIB_PATH} reports C-ABI version {version()}, this binding declares version "
                       f"{EXPECTED_VERSION} (include/spkdiff.h SPK_VERSION). Rebuild the library: make -C "
                       f"{os.path.join(os.path.dirname(_HERE), 'csrc')}")
 
 
-# Measurement options (include/spkdiff.h): the library reads no environment variable itself; the A/B tools under tools/ select
-# a launch form with SPKDIFF_<NAME>=<int>, forwarded here ONCE at import.  set_option() switches at run time.
+# Measurement options (include/spkdiff_variants.h): settable only in a `make variants` library (SPKDIFF_LIB=.../variants/
+# libspkdiff_variants.so); the A/B tools under tools/ select a launch form with SPKDIFF_<NAME>=<int>, forwarded here ONCE at import.
+# The shipped library has the defaults compiled in: set_option raises NotImplementedError there.
 OPTIONS = ("v2_waves", "v2_lag", "v2_duo", "v2_defer", "v2_lps", "fp6_waves", "fp6_xcd_walk", "conv6_shared", "conv6_shared_dyn", "mfma_debug")
+OPTION_DEFAULTS = {"conv6_shared": 1, "conv6_shared_dyn": 1, "mfma_debug": 0, "fp6_xcd_walk": 1, "fp6_waves": 4, "v2_waves": 8,
+                   "v2_lag": 0, "v2_duo": 0, "v2_defer": 0, "v2_lps": 1}
 
 
 def set_option(name: str, value: int):
+    if not HAS_OPTIONS:
+        raise NotImplementedError(f"spkdiff: option {name!r} is a compile-time constant of the shipped library; build "
+                                  "`make -C spiking-diffusion_amd/csrc variants` and load it through SPKDIFF_LIB")
     check(lib.spk_set_option(name.encode(), int(value)), f"spk_set_option({name!r})")
 
 
 def get_option(name: str) -> int:
+    if not HAS_OPTIONS:
+        if name not in OPTION_DEFAULTS:
+            raise NotImplementedError(f"spkdiff: unknown option {name!r}")
+        return OPTION_DEFAULTS[name]
     v = c_int(0)
     check(lib.spk_get_option(name.encode(), ctypes.byref(v)), f"spk_get_option({name!r})")
     return int(v.value)

@@ -123,6 +123,10 @@ def invalidate_derived(module):
         g = getattr(m, '_graphs', None)
         if isinstance(g, dict):
             g.clear()
+        tab = getattr(m, '_spikegen_tab', None)
+        if isinstance(tab, dict):                   # the per-token spike-pattern tables of a spike generator (tokens_to_s32):
+            for ent in tab.values():                # contents unknown from here on; the buffer stays (a captured graph may address it)
+                ent[1] = ent[2] = None
         object.__setattr__(m, '_derived_epoch', getattr(m, '_derived_epoch', 0) + 1)
 
 
@@ -319,11 +323,14 @@ class FusedSequential(nn.Sequential):
         return (geo['stride'] == 1 and geo['k'] % 2 == 1 and geo['pad'] == geo['k'] // 2 and geo['out_pad'] == 0 and
                 conv.in_channels % 8 == 0 and ops.readout_collapsed_supported(conv.in_channels, conv.out_channels, geo['k']))
 
-    def tokens_to_s32(self, tokens, codebook, T=16):
+    def tokens_to_s32(self, tokens, codebook, T=16, epoch=()):
         """The spike generator container (one 1x1 Conv2d + BN + LIF block) applied to the code vectors of ``tokens`` [B,h,w], as
         nibble-packed S32 spikes [B,1,h,w,16,16] by the per-token pattern table (ops.spikegen_tokens_s32): embedding look-up,
         repeat(T), convolution, BN, LIF from the reset state and the PTC -> S32 packing in two launches.  None when the container
-        is not that block in fused-eval configuration (the caller then takes the layer-by-layer path)."""
+        is not that block in fused-eval configuration (the caller then takes the layer-by-layer path).
+        epoch: the caller's ``derived_epoch`` of whatever owns ``codebook`` (it lives outside this container): together with this
+        container's own epoch it makes ``invalidate_derived`` -- the one signal for writes that bump no ``_version`` (``.data`` copies,
+        graph replays of an in-graph optimizer) -- reach the table."""
         blocks = self._blocks()
         if not self._fusable(blocks) or len(blocks) != 1 or T != 16 or not tokens.is_cuda:
             return None
@@ -339,9 +346,12 @@ class FusedSequential(nn.Sequential):
         a, b = bn.affine_terms()
         bias = None if conv.bias is None else conv.bias.detach()
         packed = conv._spk_params.get(conv)
-        # (the table is kept while the parameter versions that went into it are unchanged -- the policy of every prepared-weight cache here)
-        key = (id(self), conv._spk_params.key, bn._affine_cache[0], _ver(codebook))
-        return ops.spikegen_tokens_s32(tokens, codebook, packed, bias, a, b, T=T, table_key=key)
+        # the table is kept while the parameter versions that went into it AND the invalidation epochs are unchanged; the buffer
+        # belongs to this container (no table is shared between models)
+        key = (conv._spk_params.key, bn._affine_cache[0], _ver(codebook), derived_epoch(self), tuple(epoch))
+        if not isinstance(getattr(self, '_spikegen_tab', None), dict):
+            object.__setattr__(self, '_spikegen_tab', {})
+        return ops.spikegen_tokens_s32(tokens, codebook, packed, bias, a, b, T=T, table_key=key, table_slot=self._spikegen_tab)
 
     def run(self, x, in_kind, final='f32', T=None, in1=None, coef=None, apply_tanh=False, want_u8=False,
             stateful=True, want_pre=False, chunk_out=None, impl='auto', want_counts=False, need_radius=None):

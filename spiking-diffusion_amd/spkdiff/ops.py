@@ -732,6 +732,7 @@ IN_PTC, IN_TINV, IN_SEQ = 0, 1, 2
 # "C4" spike tensors (fp4 e2m1 nibbles, 64 channels per 32-byte record: [B, C/64, H, W, 16, 32]) carry dtype int8 so that
 # they cannot be mistaken for the u8 CPTC layout of the same shape
 CHUNK_C4 = -64
+VQ_TRAIN_MAX_D = 64          # csrc/vq_train.hip VT_MAX_D: the fused VQ training operators keep one code vector per thread
 CHUNK_S32 = -32          # "S32": the same nibbles in 32-channel records [B, C/32, H, W, 16, 16] (fp6v2 kernel)
 C4_DTYPE = torch.int8
 
@@ -1316,6 +1317,12 @@ def _flag_bitmap(device, words):
     return _flag_ws("den", device, words)
 
 
+# How many flagged neurons the id list of a certified-kernel call takes before the rest go to the overflow bitmap (the `flag_cap`
+# argument of spk_den_conv3x3_mfma_fp6v2* / spk_vae_fp6_fwd).  -1 = the whole list (2^20 entries): every product call.  The parity
+# suite sets 64 and 0 so that whole samplers / decoders run on the overflow path (tests: test_flag_overflow_*).
+FLAG_CAP = -1
+
+
 def den_conv3x3_mfma_fp6v2(in0, packed, Cout, *, bn_a, bn_b, want_counts=False, need_radius=None):
     """in0: S32 spikes [B, C/32, 7, 7, 16, 16] (int8-tagged). Returns S32 spikes [B, Cout/32, 7, 7, 16, 16]
     (or (spikes, counts u8 [B, Cout/32, 7, 7, 32]) with want_counts).  Fresh LIF state, none written back.
@@ -1334,14 +1341,14 @@ def den_conv3x3_mfma_fp6v2(in0, packed, Cout, *, bn_a, bn_b, want_counts=False, 
             need_radius <= NEED.radii and NEED.batch == B):
         rc = lib.spk_den_conv3x3_mfma_fp6v2_listed(_p(in0), nch, _p(wq), _p(scale), _p(bias_d), _p(wl1), _p(qtab), _p(bn_a),
                                                    _p(bn_b), _p(out), _p(cnt), _p(flags), T, B, H, W, Cout, _n_dyn(),
-                                                   _p(NEED.buf), NEED.radii, int(need_radius), _stream(in0))
+                                                   _p(NEED.buf), NEED.radii, int(need_radius), int(FLAG_CAP), _stream(in0))
         if rc != -2:
             check(rc, "spk_den_conv3x3_mfma_fp6v2_listed")
             return (out, cnt) if want_counts else out
         # SPK_ERR_UNSUPPORTED: this device / partition has too few CUs for the per-class division of the listed launch (e.g.
         # a 32-CU partition with Cout = 512).  The unlisted launch computes a superset of the listed positions: same tokens.
     check(lib.spk_den_conv3x3_mfma_fp6v2(_p(in0), nch, _p(wq), _p(scale), _p(bias_d), _p(wl1), _p(qtab), _p(bn_a), _p(bn_b),
-                                         _p(out), _p(cnt), _p(flags), T, B, H, W, Cout, _n_dyn(), _stream(in0)),
+                                         _p(out), _p(cnt), _p(flags), T, B, H, W, Cout, _n_dyn(), int(FLAG_CAP), _stream(in0)),
           "spk_den_conv3x3_mfma_fp6v2")
     if FP6V2_STATS is not None:
         _fp6v2_stats(in0, packed, Cout, bn_a, bn_b, out, cnt, flags)
@@ -1367,7 +1374,7 @@ def _fp6v2_stats(in0, packed, Cout, bn_a, bn_b, out, cnt, flags):
             e0.record()
             check(lib.spk_den_conv3x3_mfma_fp6v2_part(_p(in0), nch, _p(wq), _p(scale), _p(bias_d), _p(wl1), _p(qtab), _p(bn_a),
                                                       _p(bn_b), _p(out), _p(cnt), _p(flags), T, B, H, W, Cout, _n_dyn(), part,
-                                                      _stream(in0)), "spk_den_conv3x3_mfma_fp6v2_part")
+                                                      int(FLAG_CAP), _stream(in0)), "spk_den_conv3x3_mfma_fp6v2_part")
             e1.record()
             evs.append((e0, e1))
         torch.cuda.synchronize()
@@ -1526,7 +1533,7 @@ def vae_fp6_fwd(in_s32, packed, Cout, *, bn_a, bn_b, transposed, out_kind, coef=
         out = torch.empty((B, Ho, Wo, T, Cout), dtype=torch.uint8, device=in_s32.device)
     flags = _flag_ws("vae", in_s32.device, lib.spk_vae_fp6_flag_words(B, Cout, Ho, Wo))
     check(lib.spk_vae_fp6_fwd(_p(in_s32), _p(wq), _p(scale), _p(bias_d), _p(qtab), _p(bn_a), _p(bn_b), _p(coef), _p(out),
-                              int(out_kind), _p(flags), T, B, H, W, Cin, Cout, int(transposed), _stream(in_s32)),
+                              int(out_kind), _p(flags), T, B, H, W, Cin, Cout, int(transposed), int(FLAG_CAP), _stream(in_s32)),
           "spk_vae_fp6_fwd")
     return out
 
@@ -1737,14 +1744,14 @@ def embedding(tokens, codebook, nchw_hw=None):
     return out
 
 
-_SPIKEGEN_WS = {}
-
-
-def spikegen_tokens_s32(tokens, codebook, w_packed, bias, bn_a, bn_b, T=16, table_key=None):
+def spikegen_tokens_s32(tokens, codebook, w_packed, bias, bn_a, bn_b, T=16, table_key=None, table_slot=None):
     """tokens int64 [B,h,w] -> S32 spikes [B,1,h,w,16,16] of the spike generator (embedding + 1x1 conv + BN + LIF from the reset state on
     the repeated code vector), by a per-token pattern table (spk_spikegen_tokens_s32).  w_packed: [1][D][Cout], Cout 16 or 32.
-    table_key: anything that changes whenever codebook, weights or BN terms do (the callers' parameter-version tuples); the table of
-    the previous call is reused while it is equal (None: rebuilt every call)."""
+    table_slot: a dict OWNED BY THE CALLER's module (one per spike generator: no table is shared between models) that keeps the table
+    buffer per (device, K, Cout) with the key and the stream of its last eager build.  table_key: anything that changes whenever
+    codebook, weights or BN terms do (parameter versions + the owner's invalidation epoch); the slot's table is reused while the key
+    AND the stream are equal.  A call under stream capture always builds (the replay then rebuilds from the live parameters) and leaves
+    the slot marked unknown, as does any call without a key or slot."""
     tokens = _dev(tokens, "tokens", torch.int64)
     codebook = _dev(codebook.detach(), "codebook", torch.float32)
     K, D = codebook.shape
@@ -1754,17 +1761,25 @@ def spikegen_tokens_s32(tokens, codebook, w_packed, bias, bn_a, bn_b, T=16, tabl
     nbytes = lib.spk_spikegen_table_bytes(K, Cout)
     if nbytes < 0 or T != 16:
         raise NotImplementedError("spikegen_tokens_s32: Cout 16 or 32, T = 16")
-    key = (tokens.device, K, Cout)
-    ent = _SPIKEGEN_WS.get(key)
+    stream = _stream(tokens)
+    capturing = torch.cuda.is_current_stream_capturing()
+    ent = None
+    if table_slot is not None:
+        skey = (tokens.device, K, Cout)
+        ent = table_slot.get(skey)
+        if ent is None:
+            ent = table_slot[skey] = [torch.empty(nbytes // 2, dtype=torch.int16, device=tokens.device), None, None]
     if ent is None:
-        ent = _SPIKEGEN_WS[key] = [torch.empty(nbytes // 2, dtype=torch.int16, device=tokens.device), None]
-    ws = ent[0]
-    build = table_key is None or ent[1] != table_key or torch.cuda.is_current_stream_capturing()
-    ent[1] = table_key
+        ws, build = torch.empty(nbytes // 2, dtype=torch.int16, device=tokens.device), True
+    else:
+        ws = ent[0]
+        build = capturing or table_key is None or ent[1] != table_key or ent[2] != stream
+        # what the buffer holds is only known after an EAGER build on this stream; a captured launch has not run yet
+        ent[1], ent[2] = (None, None) if (capturing or table_key is None) else (table_key, stream)
     B, h, w = tokens.shape
     out = torch.empty((B, 1, h, w, T, 16), dtype=C4_DTYPE, device=tokens.device)
     check(lib.spk_spikegen_tokens_s32(_p(tokens), _p(codebook), _p(w_packed), _p(bias), _p(bn_a), _p(bn_b), _p(ws), int(build), _p(out),
-                                      T, tokens.numel(), K, D, Cout, _stream(tokens)), "spk_spikegen_tokens_s32")
+                                      T, tokens.numel(), K, D, Cout, stream), "spk_spikegen_tokens_s32")
     return out
 
 

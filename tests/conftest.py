@@ -20,6 +20,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "variants: launch forms that exist only in the `make variants` library (tests/variants/; "
+                                       "SPKDIFF_LIB=.../libspkdiff_variants.so on a GPU box)")
     config.addinivalue_line("markers", "slow: minutes of host-side oracle work; skipped unless SPKDIFF_RUN_SLOW=1 "
                                        "(run once per round through gpurun, log kept under profiles/)")
 

@@ -26,7 +26,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, n), f"{n} declared in include/spkdiff.h but not exported by libspkdiff.so"
         assert n in _lib.EXPORTS, f"{n} has no ctypes signature in spkdiff/_lib.py"
     assert set(_lib.EXPORTS) == set(names)
-    assert _lib.version() == _lib.EXPECTED_VERSION == 103
+    assert _lib.version() == _lib.EXPECTED_VERSION == 104
+    # the shipped library keeps no process-wide state: the option entry points exist only in a `make variants` build
+    # (include/spkdiff_variants.h), and its launch-shape options read as their compiled-in defaults
+    if not os.environ.get("SPKDIFF_LIB"):
+        assert not _lib.HAS_OPTIONS and not hasattr(_lib.lib, "spk_set_option") and not hasattr(_lib.lib, "spk_get_option")
+        assert _lib.get_option("v2_waves") == 8 and _lib.get_option("v2_duo") == 0
+        with pytest.raises(NotImplementedError):
+            _lib.set_option("v2_duo", 1)
     assert _lib.lib.spk_error_string(-1).decode().startswith("spkdiff: invalid argument")
 
 
@@ -102,14 +109,15 @@ def test_workspace_sizes_and_shape_support_are_host_side():
     assert lib.spk_select_needed_bytes(B, R) == (lists + 63) // 64 * 64 + R * B * 64
     assert lib.spk_select_needed_bytes(0, 3) == -1 and lib.spk_select_needed_bytes(4, 9) == -1
     cap = 1 << 20
-    # (+ the hand-over ticket, + the duo form's 2048 per-CU arrival counters and 128 item-claim counters, + the deferred-scan
-    #  form's staging slabs: 96 KB per workgroup = per CU; the CU count falls back to 256 without a device)
-    assert lib.spk_den_fp6v2_flag_words(2, 64, 7, 7) == 2 + cap + (2 * 64 * 49 + 31) // 32 + 1 + 2048 + 128 + 256 * 24576
+    # (count, published count, id list, overflow bitmap, hand-over ticket; a `make variants` library adds the duo form's
+    #  counters and the deferred-scan form's staging slabs behind the ticket)
+    extra = (2048 + 128 + 256 * 24576) if _lib.HAS_OPTIONS else 0
+    assert lib.spk_den_fp6v2_flag_words(2, 64, 7, 7) == 2 + cap + (2 * 64 * 49 + 31) // 32 + 1 + extra
     assert lib.spk_vae_fp6_flag_words(2, 32, 28, 28) == 2 + cap + (2 * 32 * 784 + 31) // 32 + 1
     assert lib.spk_vae_fp6_packed_bytes(32, 64) == 9 * 5 * 1536 and lib.spk_vae_fp6_packed_bytes(64, 16) == 2 * 9 * 3 * 1536
     assert lib.spk_vae_fp6_packed_bytes(32, 128) == -1 and lib.spk_vae_fp6_packed_bytes(48, 64) == -1
     # null pointers are argument errors before any launch
-    assert lib.spk_vae_fp6_fwd(None, None, None, None, None, None, None, None, None, 0, None, 16, 1, 14, 14, 64, 32, 1, None) == -1
+    assert lib.spk_vae_fp6_fwd(None, None, None, None, None, None, None, None, None, 0, None, 16, 1, 14, 14, 64, 32, 1, -1, None) == -1
     assert lib.spk_select_needed(None, 1, None, 0, 0, None, None, None, None, 1, 7, 7, 3, 128, None) == -1
     assert lib.spk_readout_collapsed_fwd(None, None, None, 1.0, None, None, 0, 1, 28, 28, 32, 1, 3, 1, 1, None) == -1
     kind = ops.vae_fp6_kind
