@@ -974,7 +974,7 @@ def test_flag_overflow_path_fp6v2_small_capacity(dev, ops, B, hw, form):
 
 @pytest.mark.parametrize("layer,B,hw", [("dec2", 9, 14), ("dec2", 3, 16), ("dec1", 21, 7), ("dec1", 3, 8), ("enc2", 19, 14), ("enc2", 3, 16)])
 def test_flag_overflow_path_vae_fp6_small_capacity(dev, ops, layer, B, hw):
-    """The same branch of spk_vae_fp6_fwd (csrc/vae_fp6.hip vae_fp6_fixup_kernel): id-list capacities 64 and 0 against the default
+    """The same branch of spk_vae_fp6_fwd (csrc/vae_fp6.hip vae_fp6_fixup_kernel): id-list capacities 8 and 0 against the default
     capacity and against the int8 gather kernel (exact by construction), all three output kinds; workspace clean afterwards.
     R/snn_model/vae_model.py:101-159."""
     from spkdiff import _lib
@@ -1007,7 +1007,7 @@ def test_flag_overflow_path_vae_fp6_small_capacity(dev, ops, layer, B, hw):
                 if layer == "dec1":
                     want = ops.ptc_to_spikes(want)
             words = int(_lib.lib.spk_vae_fp6_flag_words(B, Cout, Ho, Ho))
-            for cap in (-1, 64, 0):
+            for cap in (-1, 8, 0):
                 ops.FLAG_CAP = cap
                 for rep in range(2):
                     got = ops.vae_fp6_fwd(s32, pk, Cout, bn_a=a, bn_b=b, transposed=transposed, out_kind=kind,
@@ -1021,12 +1021,54 @@ def test_flag_overflow_path_vae_fp6_small_capacity(dev, ops, layer, B, hw):
                 bad = int((want != got).sum())
                 total += want.numel(); mism += bad
                 assert bad == 0, (layer, trial, cap, bad)
-            assert flagged[(trial, -1)] == flagged[(trial, 64)] == flagged[(trial, 0)] > 0, flagged
+            assert flagged[(trial, -1)] == flagged[(trial, 8)] == flagged[(trial, 0)] > 0, flagged
     finally:
         ops.FLAG_CAP = -1
-    assert max(flagged.values()) > 64, flagged
+    assert max(flagged.values()) > 8, ("the id list of 8 must overflow for this test to mean anything", flagged)
     parity(f"flag_overflow_vae_fp6_{layer}_B{B}_{hw}x{hw}", values=total, mismatches=mism,
            flagged_per_trial={str(k[0]): v for k, v in flagged.items() if k[1] == -1})
+
+
+@pytest.mark.parametrize("layer,B,hw", [("dec2", 64, 14), ("dec1", 128, 7), ("enc2", 512, 14)])
+def test_flag_overflow_path_vae_fp6_real_capacity_adversarial_layer(dev, ops, layer, B, hw):
+    """spk_vae_fp6_fwd with the REAL id-list capacity (2^20) overflowed: BatchNorm scale ~ 0 and shift 2, so that every membrane
+    potential sits within a few ulp of the threshold (see the denoiser-layer test below) -- 1.6 M neurons per launch, nearly all
+    flagged; against the int8 gather kernel (exact by construction), bit for bit; workspace clean.  R/snn_model/vae_model.py:101-159."""
+    from spkdiff import _lib
+    g = torch.Generator().manual_seed(6300 + B)
+    coef = torch.pow(torch.tensor(0.8), torch.arange(15, -1, -1).float()).to(dev)
+    transposed = layer != "enc2"
+    Cin, Cout = {"dec2": (64, 32), "dec1": (16, 64), "enc2": (32, 64)}[layer]
+    kind = {"dec2": ops.VAE_OUT_COLLAPSED, "dec1": ops.VAE_OUT_S32, "enc2": ops.VAE_OUT_PTC}[layer]
+    geo = dict(k=3, stride=2, pad=1, transposed=transposed, out_pad=1 if transposed else 0)
+    Ho = 2 * hw if transposed else hw // 2
+    w = ((torch.rand((Cin, Cout, 3, 3) if transposed else (Cout, Cin, 3, 3), generator=g) - 0.5) * 0.2).to(dev)
+    bias = ((torch.rand(Cout, generator=g) - 0.5) * 0.2).to(dev)
+    a = (2e-6 * (torch.rand(Cout, generator=g) + 0.5) * torch.sign(torch.rand(Cout, generator=g) - 0.3)).to(dev)
+    b = torch.full((Cout,), 2.0).to(dev)
+    spikes = (torch.rand(16, B, Cin, hw, hw, generator=g) < 0.1).float().to(dev)
+    ptc = ops.spikes_to_ptc(spikes)
+    s32 = ops.ptc_to_s32(ptc)
+    for rep in range(2):
+        got = ops.vae_fp6_fwd(s32, ops.vae_fp6_pack(w, bias, transposed), Cout, bn_a=a, bn_b=b, transposed=transposed, out_kind=kind,
+                              coef=coef if layer == "dec2" else None)
+    torch.cuda.synchronize()
+    words = int(_lib.lib.spk_vae_fp6_flag_words(B, Cout, Ho, Ho))
+    ws = [v for k, v in ops._FLAG_DEFAULT.items() if k[0] == "vae" and k[3] == words][-1]
+    nfl = int(ws[1])
+    pk8 = ops.pack_conv_weight_i8(w, bias, transposed)
+    if layer == "dec2":
+        want = ops.conv_mfma_fused(ptc, pk8, Cout, mode=ops.MODE_LIF, bn_a=a, bn_b=b, collapse_coef=coef, **geo)
+    else:
+        want = ops.conv_mfma_fused(ptc, pk8, Cout, mode=ops.MODE_LIF, bn_a=a, bn_b=b, **geo)
+        if layer == "dec1":
+            got, want = ops.s32_to_spikes(got), ops.ptc_to_spikes(want)
+    bad = int((want != got).sum())
+    parity(f"flag_overflow_vae_fp6_real_capacity_{layer}_B{B}", neurons=B * Cout * Ho * Ho, flagged=nfl, id_list_capacity=FLAG_LIST,
+           mismatches=bad)
+    assert nfl > FLAG_LIST, (nfl, "the layer must overflow the real id list")
+    assert bad == 0, bad
+    assert flag_ws_clean(ws), "workspace not clean after an overflowing launch"
 
 
 @pytest.mark.parametrize("hw,gamma", [(7, 0.0), (7, 2e-6), (8, 2e-6)])
