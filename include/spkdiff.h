@@ -549,9 +549,11 @@ int spk_psample_step(const float* logits_bkhw, long long* x_t_inout, uint8_t* un
  * 134-140, same u / q / Philox arguments and draws) and -- unless x1_s32_out is NULL (last step) -- the first denoiser layer of
  * the NEXT step on cat(x_t, t - 1) (as spk_conv_fused_fwd on a time-invariant input: :161-165,195-201): S32 spikes
  * [B][2][HW][16][16 B] and spike counts u8 [B][2][HW][32].  cnt5 [B][8][HW][32] / cnt1 [B][2][HW][32]: spike counts of conv5 /
- * conv1 of THIS step; wq / scale / bias_d: conv6 packed by spk_den_pack_weight_i8; conv1_w_packed: spk_pack_conv_weight of the
- * first layer ([9][2][64]); bn1_a / bn1_b: its folded BatchNorm.  logits_out optional fp32 [B][K][H][W].  K = 128, 7x7 or 8x8
- * latents, 256 + 64 input channels (the reference's architecture); anything else: SPK_ERR_UNSUPPORTED (use the three launches).
+ * conv1 of THIS step; wq / scale / bias_d: conv6 packed by spk_den_pack_weight_i8 with its output channels zero-padded to
+ * ceil16(K) (any --codebook_size, R/main.py:58: classes >= K are masked in the sampling exactly as spk_psample_step masks them);
+ * conv1_w_packed: spk_pack_conv_weight of the first layer ([9][2][64]); bn1_a / bn1_b: its folded BatchNorm.  logits_out optional
+ * fp32 [B][K][H][W].  1 <= K <= 512, 7x7 or 8x8 latents, 256 + 64 input channels (the reference's architecture); anything
+ * else: SPK_ERR_UNSUPPORTED (use the three launches).
  * The fused first layer is the time-invariant-input form with the module defaults baked in: T = 16 steps and
  * LIFNode(tau = 2, v_threshold = 1, v_reset = 0) (R/snn_model/vq_diffusion.py:161-165); with x1_s32_out set any other T is
  * SPK_ERR_UNSUPPORTED (conv6 alone takes T <= 127). */

@@ -4,7 +4,9 @@
 //   p_sample              R/snn_model/vq_diffusion.py:113-124,134-140   (the arithmetic of psample.hip, same noise draws)
 //   conv1 + BN + LIF of the NEXT step's input cat(x_t, t - 1)   :161-165,195-201   (the arithmetic of tinv_lif_kernel)
 //
-// One workgroup = one image, eight waves = the eight 16-channel groups of the 128 logits.  The 64 (padded) rows of an image are
+// One workgroup = one image, eight waves; wave w owns the 16-channel groups w, w + 8, ... of the logits (the reference's default
+// codebook of 128 classes: one group per wave; round 6: any --codebook_size up to 512, R/main.py:58 -- conv6's output channels are
+// zero-padded to a multiple of 16 in the packed weights, classes >= K are masked in the sampling).  The 64 (padded) rows of an image are
 // two 32-row MFMA tiles; wave w multiplies both by the four int8 digit planes of its channel group (v_mfma_i32_32x32x32_i8,
 // exact int32 sums, the packed weights of spk_den_pack_weight_i8 streamed from L2 eight taps ahead), the image's count records
 // (15 - 20 KB) sit in LDS for the whole launch.  The logits of the image meet in LDS (never in HBM unless the caller asks for
@@ -25,8 +27,7 @@ namespace {
 constexpr int TCK = 32;                           // channels per K chunk
 constexpr int TW_CHUNK = 9 * 2 * 32 * TCK;        // 18432 B of packed weights per (channel group, chunk)
 constexpr int TNCH = 10;                          // 8 chunks of conv5 counts + 2 of conv1 counts (256 + 64 channels)
-constexpr int TK = 128;                           // classes = conv6 output channels
-constexpr int TLP = TK + 4;                       // LDS pitch of a logits row
+constexpr int TK_MAX = 512;                       // classes = conv6 output channels (KG = groups per wave = ceil(K / 128) <= 4)
 #ifndef SPK_TAIL_PF
 #define SPK_TAIL_PF 8                             // weight tiles are requested this many taps ahead of their MFMAs
 #endif
@@ -48,27 +49,34 @@ struct TailArgs {
   uint8_t* x1_out; uint8_t* cnt1_out;             // S32 spikes [B][2][HW][16][16 B], counts u8 [B][2][HW][32]
   float t_next;
   int B, T;
+  int K, ng;                                      // classes; 16-channel groups of the padded logits (ceil(K / 16))
 };
 
-template <int H, int W>
+// KG = channel groups per wave (1: K <= 128, the reference's default; 2 .. 4: K <= 256 / 384 / 512)
+template <int H, int W, int KG>
 __global__ __launch_bounds__(512, 1) void step_tail_kernel(TailArgs a) {
   constexpr int HW = H * W;
   static_assert(HW <= 64, "an image is at most two 32-row tiles");
   constexpr int AV = HW * 2 + 1;                  // 16-byte vectors of a chunk's count records + one zero vector
+  constexpr int TLP = 128 * KG + 4;               // LDS pitch of a logits row
+  constexpr int NJ = 2 * KG;                      // classes per lane in the sampling (64 * NJ >= padded K)
   __shared__ v4i s_a[TNCH * AV];
-  __shared__ float s_logit[64][TLP];
+  extern __shared__ __attribute__((aligned(16))) float s_logit_dyn[];   // [64][TLP]
+  float (*s_logit)[TLP] = reinterpret_cast<float (*)[TLP]>(s_logit_dyn);
   __shared__ float s_tok[64];
   __shared__ int s_chg[64];
   __shared__ float s_th[16];
   __shared__ unsigned s_pat[18];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
-  const int g = wave;                             // channel group of this wave
+  const int K = a.K, ng = a.ng;
   const int row = lane & 31, half = lane >> 5;
 
   // ---- this wave's weight stream: tile (c, tap, j) = 1 KiB, 16 bytes per lane; requested D taps ahead of their MFMAs
   const int boff = (lane & 31) * TCK + 16 * (half ^ ((lane >> 4) & 1));
-  const int8_t* const wg = a.wq + (long long)g * TNCH * TW_CHUNK + boff;
+  // (the first group's stream starts here, ahead of the count records; a wave without a group -- K < 128 -- streams group 0's
+  //  first tiles and drops them)
+  const int8_t* wg = a.wq + (long long)(wave < ng ? wave : 0) * TNCH * TW_CHUNK + boff;
   // every workgroup reads the same 1.4 MB of packed weights: workgroups of one XCD (blocks k, k + 8, ...) start at different
   // chunks so that they do not all ask the L2 for the same lines at the same time (exact integer sums: any order)
   const int rot = SPK_TAIL_ROT ? (int)((blockIdx.x >> 3) % TNCH) : 0;
@@ -100,13 +108,12 @@ __global__ __launch_bounds__(512, 1) void step_tail_kernel(TailArgs a) {
     const long long tk = a.x_t[pi];
     float u;
     if (a.u_in) u = a.u_in[pi];
-    else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)pi * (unsigned long long)TK, 0u, r); u = u01_open_right(r[0]); }
+    else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)pi * (unsigned long long)K, 0u, r); u = u01_open_right(r[0]); }
     s_chg[tid] = ((u < inv_t) && !um) ? 1 : 0;
     s_tok[tid] = (float)tk;
   }
-  // ---- per-channel constants of the read-out and of the next step's first layer, requested before the K loop
-  const int col_e = lane & 31, co_e = g * 16 + (col_e & 15);
-  const double sc_e = a.scale[co_e], bT_e = a.bias[co_e] * (double)a.T;
+  // ---- per-channel constants of the next step's first layer, requested before the K loop
+  const int col_e = lane & 31;
   float wreg[18];
   float al1 = 0.f, be1 = 0.f;
   double b01 = 0.0;
@@ -137,54 +144,69 @@ __global__ __launch_bounds__(512, 1) void step_tail_kernel(TailArgs a) {
     y_[rt] = p / W; x_[rt] = p % W;
     a_base[rt] = p * 2 + half;
   }
-  v16i acc[2][2];
+#pragma unroll 1
+  for (int gi = 0; gi < KG; ++gi) {
+    const int g = wave + 8 * gi;                    // channel group of this pass (wave-uniform)
+    if (g >= ng) break;
+    const int co_e = g * 16 + (col_e & 15);
+    const double sc_e = a.scale[co_e], bT_e = a.bias[co_e] * (double)a.T;
+    if (gi > 0) {                                   // (the first group's stream was started ahead of the count records)
+      wg = a.wq + (long long)g * TNCH * TW_CHUNK + boff;
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[rt][j][r] = 0;
-#pragma unroll
-  for (int i = 0; i < ((SPK_TAIL_DBG & 1) ? D : NIT); ++i) {
-    const int c = chunk_of(i), tap = i % 9;
-    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-    const v4i b0 = bq[i % D][0], b1 = bq[i % D][1];
-    if (i + D < NIT) {
-      const int c2 = chunk_of(i + D), tap2 = (i + D) % 9;
-      bq[i % D][0] = *reinterpret_cast<const v4i*>(wg + c2 * TW_CHUNK + (tap2 * 2 + 0) * 32 * TCK);
-      bq[i % D][1] = *reinterpret_cast<const v4i*>(wg + c2 * TW_CHUNK + (tap2 * 2 + 1) * 32 * TCK);
+      for (int i = 0; i < D; ++i) {
+        bq[i][0] = *reinterpret_cast<const v4i*>(wg + chunk_of(i) * TW_CHUNK + ((i % 9) * 2 + 0) * 32 * TCK);
+        bq[i][1] = *reinterpret_cast<const v4i*>(wg + chunk_of(i) * TW_CHUNK + ((i % 9) * 2 + 1) * 32 * TCK);
+      }
     }
+    v16i acc[2][2];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      const int yy = y_[rt] + dy, xx = x_[rt] + dx;
-      const bool ok = rv[rt] && yy >= 0 && yy < H && xx >= 0 && xx < W;
-      const v4i av = s_a[c * AV + (ok ? a_base[rt] + (dy * W + dx) * 2 : HW * 2)];
-      acc[rt][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b0, acc[rt][0], 0, 0, 0);
-      acc[rt][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b1, acc[rt][1], 0, 0, 0);
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][j][r] = 0;
+#pragma unroll
+    for (int i = 0; i < ((SPK_TAIL_DBG & 1) ? D : NIT); ++i) {
+      const int c = chunk_of(i), tap = i % 9;
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+      const v4i b0 = bq[i % D][0], b1 = bq[i % D][1];
+      if (i + D < NIT) {
+        const int c2 = chunk_of(i + D), tap2 = (i + D) % 9;
+        bq[i % D][0] = *reinterpret_cast<const v4i*>(wg + c2 * TW_CHUNK + (tap2 * 2 + 0) * 32 * TCK);
+        bq[i % D][1] = *reinterpret_cast<const v4i*>(wg + c2 * TW_CHUNK + (tap2 * 2 + 1) * 32 * TCK);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int yy = y_[rt] + dy, xx = x_[rt] + dx;
+        const bool ok = rv[rt] && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const v4i av = s_a[c * AV + (ok ? a_base[rt] + (dy * W + dx) * 2 : HW * 2)];
+        acc[rt][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b0, acc[rt][0], 0, 0, 0);
+        acc[rt][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b1, acc[rt][1], 0, 0, 0);
+      }
     }
-  }
 
-  // ---- digit recombination (fp64, one rounding), mean over T, logits -> LDS (and to memory on request)
-  {
-    const int odd = col_e >> 4;
-    const int co = co_e;
-    const double sc = sc_e, bT = bT_e;
-    const float invT = 1.0f / (float)a.T;
+    // ---- digit recombination (fp64, one rounding), mean over T, logits -> LDS (and to memory on request)
+    {
+      const int odd = col_e >> 4;
+      const int co = co_e;
+      const double sc = sc_e, bT = bT_e;
+      const float invT = 1.0f / (float)a.T;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+      for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const v2u p01 = __builtin_amdgcn_permlane16_swap((unsigned)acc[rt][0][r], (unsigned)acc[rt][0][r + 8], false, false);
-        const v2u p23 = __builtin_amdgcn_permlane16_swap((unsigned)acc[rt][1][r], (unsigned)acc[rt][1][r + 8], false, false);
-        const long long hi = (long long)(int)p01[0] * 256 + (int)p01[1], lo = (long long)(int)p23[0] * 256 + (int)p23[1];
-        const double s = fma((double)hi, 65536.0, (double)lo);
-        const float xsum = (float)fma(s, sc, bT);
-        const int rr = r + 8 * odd;
-        const int orow = (rr & 3) + 8 * (rr >> 2) + 4 * half;
-        const int op = rt * 32 + orow;
-        const float lg = xsum * invT;
-        s_logit[op][co] = lg;
-        if (a.logits_out && op < HW) a.logits_out[((long long)b * TK + co) * HW + op] = lg;
+        for (int r = 0; r < 8; ++r) {
+          const v2u p01 = __builtin_amdgcn_permlane16_swap((unsigned)acc[rt][0][r], (unsigned)acc[rt][0][r + 8], false, false);
+          const v2u p23 = __builtin_amdgcn_permlane16_swap((unsigned)acc[rt][1][r], (unsigned)acc[rt][1][r + 8], false, false);
+          const long long hi = (long long)(int)p01[0] * 256 + (int)p01[1], lo = (long long)(int)p23[0] * 256 + (int)p23[1];
+          const double s = fma((double)hi, 65536.0, (double)lo);
+          const float xsum = (float)fma(s, sc, bT);
+          const int rr = r + 8 * odd;
+          const int orow = (rr & 3) + 8 * (rr >> 2) + 4 * half;
+          const int op = rt * 32 + orow;
+          const float lg = xsum * invT;
+          s_logit[op][co] = lg;
+          if (a.logits_out && op < HW && co < K) a.logits_out[((long long)b * K + co) * HW + op] = lg;
+        }
       }
     }
   }
@@ -194,34 +216,42 @@ __global__ __launch_bounds__(512, 1) void step_tail_kernel(TailArgs a) {
   for (int p = wave; p < ((SPK_TAIL_DBG & 2) ? 0 : HW); p += 8) {
     const long long pi = (long long)b * HW + p;
     if (!s_chg[p]) continue;                                            // (wave-uniform; s_tok[p] holds the token it keeps)
-    float l[2], e[2];
+    // (classes k >= K -- the zero-padded output channels of conv6 and the lanes beyond them -- are masked exactly as
+    //  psample_kernel masks them: -inf logits, zero terms)
+    float l[NJ], e[NJ];
     float mx = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { l[j] = s_logit[p][lane + 64 * j] / a.temp; mx = fmaxf(mx, l[j]); }
+    for (int j = 0; j < NJ; ++j) {
+      const int k = lane + 64 * j;
+      l[j] = k < K ? s_logit[p][k] / a.temp : -INFINITY;
+      mx = fmaxf(mx, l[j]);
+    }
     mx = wave_max(mx);
     float se = 0.f;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) se += expf(l[j] - mx);
+    for (int j = 0; j < NJ; ++j) se += (lane + 64 * j < K) ? expf(l[j] - mx) : 0.f;
     se = wave_sum(se);
     const float lse = mx + logf(se);
     float mx2 = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { l[j] = l[j] - lse; mx2 = fmaxf(mx2, l[j]); }
+    for (int j = 0; j < NJ; ++j) { l[j] = l[j] - lse; mx2 = fmaxf(mx2, l[j]); }
     mx2 = wave_max(mx2);
     float se2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { e[j] = expf(l[j] - mx2); se2 += e[j]; }
+    for (int j = 0; j < NJ; ++j) { e[j] = (lane + 64 * j < K) ? expf(l[j] - mx2) : 0.f; se2 += e[j]; }
     se2 = wave_sum(se2);
     float best = -INFINITY;
     int besti = 0x7fffffff;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int k = lane + 64 * j;
-      float q;
-      if (a.q_in) q = a.q_in[pi * TK + k];
-      else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)(pi * TK + k), 1u, r); q = -logf(u01_open_left(r[0])); }
-      const float ratio = (e[j] / se2) / q;
-      if (ratio > best) { best = ratio; besti = k; }
+      if (k < K) {
+        float q;
+        if (a.q_in) q = a.q_in[pi * K + k];
+        else { uint32_t r[4]; philox4x32(seed, offset + (unsigned long long)(pi * K + k), 1u, r); q = -logf(u01_open_left(r[0])); }
+        const float ratio = (e[j] / se2) / q;
+        if (ratio > best) { best = ratio; besti = k; }
+      }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -298,7 +328,7 @@ extern "C" int spk_den_step_tail(const uint8_t* cnt5, int nch5, const uint8_t* c
     return SPK_ERR_ARG;
   if ((x1_s32_out_or_null == nullptr) != (cnt1_out_or_null == nullptr)) return SPK_ERR_ARG;
   if (x1_s32_out_or_null && (!conv1_w_packed_or_null || !bn1_a || !bn1_b)) return SPK_ERR_ARG;
-  if (nch5 != 8 || nch1 != 2 || K != TK || T > 127 || !((H == 7 && W == 7) || (H == 8 && W == 8))) return SPK_ERR_UNSUPPORTED;
+  if (nch5 != 8 || nch1 != 2 || K < 1 || K > TK_MAX || T > 127 || !((H == 7 && W == 7) || (H == 8 && W == 8))) return SPK_ERR_UNSUPPORTED;
   // the fused first layer writes sixteen 16-byte step records per position and scans with the module-default LIF constants
   // (spk_lif_const_input_bits16): any other step count would write outside x1_s32_out (T < 16) or give wrong spikes (T > 16)
   if (x1_s32_out_or_null && T != 16) return SPK_ERR_UNSUPPORTED;
@@ -309,8 +339,18 @@ extern "C" int spk_den_step_tail(const uint8_t* cnt5, int nch5, const uint8_t* c
   a.w1 = conv1_w_packed_or_null; a.b1 = conv1_bias_or_null; a.bn1_a = bn1_a; a.bn1_b = bn1_b;
   a.x1_out = x1_s32_out_or_null; a.cnt1_out = cnt1_out_or_null; a.t_next = (float)(t - 1);
   a.B = B; a.T = T;
-  if (H == 7) hipLaunchKernelGGL((step_tail_kernel<7, 7>), dim3(B), dim3(512), 0, stream, a);
-  else hipLaunchKernelGGL((step_tail_kernel<8, 8>), dim3(B), dim3(512), 0, stream, a);
+  a.K = K; a.ng = (K + 15) / 16;                    // wq / scale / bias_d hold ng * 16 channels (zero weights beyond K)
+  const int kg = (a.ng + 7) / 8;
+#define SPK_TAIL_LAUNCH(H_, W_, KG_)                                                                                          \
+  hipLaunchKernelGGL((step_tail_kernel<H_, W_, KG_>), dim3(B), dim3(512), (size_t)64 * (128 * KG_ + 4) * sizeof(float), stream, a)
+  if (H == 7) {
+    if (kg == 1) SPK_TAIL_LAUNCH(7, 7, 1); else if (kg == 2) SPK_TAIL_LAUNCH(7, 7, 2);
+    else if (kg == 3) SPK_TAIL_LAUNCH(7, 7, 3); else SPK_TAIL_LAUNCH(7, 7, 4);
+  } else {
+    if (kg == 1) SPK_TAIL_LAUNCH(8, 8, 1); else if (kg == 2) SPK_TAIL_LAUNCH(8, 8, 2);
+    else if (kg == 3) SPK_TAIL_LAUNCH(8, 8, 3); else SPK_TAIL_LAUNCH(8, 8, 4);
+  }
+#undef SPK_TAIL_LAUNCH
   SPK_LAUNCH_CHECK();
   return SPK_OK;
 }

@@ -430,16 +430,19 @@ class DummyModel(nn.Module):
     _latent_hw = (7, 7)        # latent size of the last call (7x7 MNIST-shaped, 8x8 CIFAR-shaped)
 
     def _impl_base(self, h, w):
-        """Kernel family used for conv2..conv6 on an h x w latent.  The matrix-core families carry conv2..conv5's
-        spikes in layouts only their own conv6 kernel reads, and that kernel packs 16 output channels per tile: any
-        ``num_embeddings`` that is not a multiple of 16 (the reference accepts every --codebook_size, R/main.py:58)
-        runs the whole call on the fp64 direct kernels."""
+        """Kernel family used for conv2..conv6 on an h x w latent.  conv2..conv5 never see ``num_embeddings``; the fp6 families'
+        logits layer runs on the spike counts with its output channels zero-padded to a multiple of 16 inside the packed weights
+        (round 6), so EVERY --codebook_size the reference accepts (R/main.py:58) stays on the matrix cores.  Only the int8 family's
+        per-step logits kernel (``collapse_conv6 = False`` or request 'i8') still needs a multiple of 16 and otherwise leaves the
+        call to the fp64 direct kernels."""
         req = self.conv_impl_request
-        if req == 'direct' or self.conv6[0].out_channels % 16 != 0:
+        if req == 'direct':
             return 'direct-f64'
         if (req in ('auto', 'fp6') and self.collapse_conv6 and
                 ops.den_fp6_supported(128, 64, 3, 1, 1, self.n_steps, h, w)):
             return 'mfma-fp6x6'
+        if self.conv6[0].out_channels % 16 != 0:
+            return 'direct-f64'
         return 'mfma-i8x4' if ops.den_mfma_supported(128, 64, 3, 1, 1, self.n_steps, h, w) else 'direct-f64'
 
     # the sampler's calls (fresh LIF state, nothing written back) take the second-generation fp6 kernel where it applies
@@ -502,7 +505,7 @@ class DummyModel(nn.Module):
         if not hasattr(conv, '_spk_params'):
             from spkdiff.fused import ConvParams
             object.__setattr__(conv, '_spk_params', ConvParams())
-        return conv, conv._spk_params.get_i8(conv)
+        return conv, conv._spk_params.get_i8(conv, pad_cout=True)
 
     def _run(self, inp_b2hw, stateful, record=None):
         T = self.n_steps
@@ -521,9 +524,9 @@ class DummyModel(nn.Module):
 
     def tail_fusable(self, h, w):
         """Can ``sample_step`` take the fused tail launch on an h x w latent?  (the reference's architecture on the certified
-        fp6 kernel family: 128 classes, 256 + 64 channels into conv6, T = 16, 7x7 or 8x8)"""
+        fp6 kernel family: up to 512 classes (any --codebook_size, R/main.py:58), 256 + 64 channels into conv6, T = 16, 7x7 or 8x8)"""
         return (self.use_step_tail and self._fused_ok() and not self.training and not has_hooks(self) and self.collapse_conv6
-                and self.n_steps == 16 and (h, w) in ((7, 7), (8, 8)) and self.conv6[0].out_channels == 128
+                and self.n_steps == 16 and (h, w) in ((7, 7), (8, 8)) and 1 <= self.conv6[0].out_channels <= ops.STEP_TAIL_MAX_K
                 and self.conv6[0].in_channels == 320 and self.conv5[0].out_channels == 256 and self.conv1[0].out_channels == 64
                 and self.conv1[0].in_channels == 2 and self.impl_for(h, w, stateful=False) == 'mfma-fp6v2')
 

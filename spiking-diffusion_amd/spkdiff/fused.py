@@ -45,10 +45,11 @@ class ConvParams:
             self.key = key
         return self.w_packed
 
-    def get_i8(self, conv):
-        key = (_ver(conv.weight), _ver(conv.bias))
+    def get_i8(self, conv, pad_cout=False):
+        """int8 digit planes of the denoiser family; pad_cout: output channels zero-padded to a multiple of 16 (logits layer)."""
+        key = (_ver(conv.weight), _ver(conv.bias), bool(pad_cout))
         if key != self.key_i8:
-            self.i8 = ops.den_pack_weight_i8(conv.weight, conv.bias)
+            self.i8 = ops.den_pack_weight_i8(conv.weight, conv.bias, pad_cout=pad_cout)
             self.key_i8 = key
         return self.i8
 

@@ -732,6 +732,7 @@ IN_PTC, IN_TINV, IN_SEQ = 0, 1, 2
 # "C4" spike tensors (fp4 e2m1 nibbles, 64 channels per 32-byte record: [B, C/64, H, W, 16, 32]) carry dtype int8 so that
 # they cannot be mistaken for the u8 CPTC layout of the same shape
 CHUNK_C4 = -64
+STEP_TAIL_MAX_K = 512        # csrc/step_tail.hip TK_MAX: classes the fused reverse-step tail takes (four 16-channel groups per wave)
 VQ_TRAIN_MAX_D = 64          # csrc/vq_train.hip VT_MAX_D: the fused VQ training operators keep one code vector per thread
 CHUNK_S32 = -32          # "S32": the same nibbles in 32-channel records [B, C/32, H, W, 16, 16] (fp6v2 kernel)
 C4_DTYPE = torch.int8
@@ -821,10 +822,18 @@ def den_mfma_supported(Cout, Cin, k, stride, pad, T, H, W):
             and nt <= 8 and lds <= 160 * 1024)
 
 
-def den_pack_weight_i8(w, bias):
-    """[Cout,Cin,3,3] fp32 -> (int8 digit planes, fp64 scale [Cout], fp64 bias [Cout])."""
+def den_pack_weight_i8(w, bias, pad_cout=False):
+    """[Cout,Cin,3,3] fp32 -> (int8 digit planes, fp64 scale [Cout], fp64 bias [Cout]).  pad_cout: output channels are
+    zero-padded to the next multiple of 16 first (the logits layer for any --codebook_size, R/main.py:58: the kernels that read
+    these planes take 16-channel column groups; scale / bias then have ceil16(Cout) entries, the extra ones are never read back)."""
     w = _dev(w.detach(), "weight", torch.float32)
     Cout, Cin = w.shape[0], w.shape[1]
+    if pad_cout and Cout % 16:
+        kp = (Cout + 15) // 16 * 16
+        w = torch.cat([w, w.new_zeros((kp - Cout,) + tuple(w.shape[1:]))], 0).contiguous()
+        if bias is not None:
+            bias = torch.cat([bias.detach(), bias.detach().new_zeros(kp - Cout)], 0)
+        Cout = kp
     nbytes = lib.spk_den_packed_weight_bytes(Cout, Cin)
     if nbytes < 0:
         raise NotImplementedError("spkdiff: MFMA conv needs Cout % 16 == 0 and Cin % 32 == 0")
@@ -866,7 +875,9 @@ def den_conv3x3_mfma(in0, packed, Cout, *, mode, in1=None, bn_a=None, bn_b=None,
 
 
 def den_conv3x3_counts(cnt0, packed, Cout, T, cnt1=None):
-    """Time-collapsed conv6: cnt0/cnt1 u8 spike counts [B, C/32, H, W, 32] -> logits fp32 [B, Cout, H, W]."""
+    """Time-collapsed conv6: cnt0/cnt1 u8 spike counts [B, C/32, H, W, 32] -> logits fp32 [B, Cout, H, W].  ``packed`` may hold
+    more (zero-padded) output channels than Cout (den_pack_weight_i8(pad_cout=True)): the kernel computes all of them and the
+    first Cout are returned."""
     cnt0 = _dev(cnt0, "cnt0", torch.uint8)
     B, nch0, H, W, ck = cnt0.shape
     if ck != 32:
@@ -876,10 +887,13 @@ def den_conv3x3_counts(cnt0, packed, Cout, T, cnt1=None):
         cnt1 = _dev(cnt1, "cnt1", torch.uint8)
         nch1 = cnt1.shape[1]
     wq, scale, bias_d = packed
-    out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=cnt0.device)
+    kp = int(scale.numel())
+    if kp < Cout or kp - Cout >= 16:
+        raise ValueError("packed logits weights do not belong to a layer of Cout output channels")
+    out = torch.empty((B, kp, H, W), dtype=torch.float32, device=cnt0.device)
     check(lib.spk_den_conv3x3_counts_mfma(_p(cnt0), nch0, _p(cnt1), nch1, _p(wq), _p(scale), _p(bias_d), _p(out), T, B,
-                                          H, W, Cout, _n_dyn(), _stream(cnt0)), "spk_den_conv3x3_counts_mfma")
-    return out
+                                          H, W, kp, _n_dyn(), _stream(cnt0)), "spk_den_conv3x3_counts_mfma")
+    return out if kp == Cout else out[:, :Cout].contiguous()
 
 
 # ------------------------------------------------------------------------------- fp6/fp4 block-scaled MFMA denoiser convs

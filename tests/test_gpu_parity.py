@@ -985,6 +985,7 @@ def test_flag_overflow_path_vae_fp6_small_capacity(dev, ops, layer, B, hw):
     kind = {"dec2": ops.VAE_OUT_COLLAPSED, "dec1": ops.VAE_OUT_S32, "enc2": ops.VAE_OUT_PTC}[layer]
     geo = dict(k=3, stride=2, pad=1, transposed=transposed, out_pad=1 if transposed else 0)
     Ho = 2 * hw if transposed else hw // 2
+    small = 8 if B >= 9 else 1                     # id-list entries of the list-AND-bitmap case (a B = 3 launch flags 2 .. 30 neurons)
     total = mism = 0
     flagged = {}
     try:
@@ -1007,7 +1008,7 @@ def test_flag_overflow_path_vae_fp6_small_capacity(dev, ops, layer, B, hw):
                 if layer == "dec1":
                     want = ops.ptc_to_spikes(want)
             words = int(_lib.lib.spk_vae_fp6_flag_words(B, Cout, Ho, Ho))
-            for cap in (-1, 8, 0):
+            for cap in (-1, small, 0):
                 ops.FLAG_CAP = cap
                 for rep in range(2):
                     got = ops.vae_fp6_fwd(s32, pk, Cout, bn_a=a, bn_b=b, transposed=transposed, out_kind=kind,
@@ -1021,10 +1022,10 @@ def test_flag_overflow_path_vae_fp6_small_capacity(dev, ops, layer, B, hw):
                 bad = int((want != got).sum())
                 total += want.numel(); mism += bad
                 assert bad == 0, (layer, trial, cap, bad)
-            assert flagged[(trial, -1)] == flagged[(trial, 8)] == flagged[(trial, 0)] > 0, flagged
+            assert flagged[(trial, -1)] == flagged[(trial, small)] == flagged[(trial, 0)] > 0, flagged
     finally:
         ops.FLAG_CAP = -1
-    assert max(flagged.values()) > 8, ("the id list of 8 must overflow for this test to mean anything", flagged)
+    assert max(flagged.values()) > small, ("the short id list must overflow for this test to mean anything", flagged)
     parity(f"flag_overflow_vae_fp6_{layer}_B{B}_{hw}x{hw}", values=total, mismatches=mism,
            flagged_per_trial={str(k[0]): v for k, v in flagged.items() if k[1] == -1})
 
@@ -2277,11 +2278,14 @@ def test_f13_sample_100_steps_and_decode_vs_reference_fixture(golden_dir, dev, t
     assert int((u82.cpu().numpy().astype(int) - ou8.astype(int)).__abs__().max()) <= 1
 
 
-@pytest.mark.parametrize("K", [100, 512])
+@pytest.mark.parametrize("K", [100, 200, 256, 512])
 def test_other_codebook_sizes_sample_and_train(dev, K):
-    """The reference accepts any --codebook_size (R/main.py:58).  K = 100 (not a multiple of 16: the whole denoiser call
-    runs on the fp64 direct kernels) and K = 512 (matrix-core path; p_sample with 8 classes per lane; the cross-entropy
-    tile no longer fits 64 KB of LDS) must sample, decode indices in range, agree with the oracle, and train."""
+    """The reference accepts any --codebook_size (R/main.py:58).  Round 6: every K stays on the matrix-core path -- conv2..conv5
+    never see K; the logits layer's output channels are zero-padded to a multiple of 16 inside its packed weights and the fused
+    reverse-step tail takes 1 <= K <= 512 (classes >= K masked as spk_psample_step masks them).  K = 100 / 200 (not multiples of
+    16), 256, 512 (p_sample with 8 classes per lane; the cross-entropy tile no longer fits 64 KB of LDS) must run 'mfma-fp6v2',
+    agree with the fp64 direct kernels and with the oracle (logits, tokens of host-noise trajectories through the fused tail,
+    through the three-launch form and through the direct kernels), sample in range under Philox + graph replay, and train."""
     from snn_model.vq_diffusion import DummyModel, AbsorbingDiffusion, functional
     import dataclasses
     cfg = dataclasses.replace(synth.MNIST, num_embeddings=K)
@@ -2290,7 +2294,7 @@ def test_other_codebook_sizes_sample_and_train(dev, K):
     functional.set_step_mode(net=den, step_mode='m')
     den.load_state_dict(sd)
     den.eval()
-    assert den.impl_for(7, 7) == ('direct-f64' if K % 16 else 'mfma-fp6v2')
+    assert den.impl_for(7, 7) == den.impl_for(8, 8) == 'mfma-fp6v2' and den.tail_fusable(7, 7)
     g = torch.Generator().manual_seed(K)
     x_t = torch.randint(0, K + 1, (3, 1, 7, 7), generator=g)
     t = torch.tensor([5, 50, 99])
@@ -2306,11 +2310,33 @@ def test_other_codebook_sizes_sample_and_train(dev, K):
     torch.manual_seed(K)
     otok = ref.absorbing_sample(sd, 3, K, 1.0, 6, 7, 16)
     n_bad = int((tok != otok).sum())
+    # the same trajectory without the fused tail (conv6 on counts -> logits -> spk_psample_step) and on the fp64 direct kernels
+    forms = {}
+    for name, (tailf, req) in {"three_launches": (False, 'auto'), "direct_f64": (True, 'direct')}.items():
+        den.use_step_tail, den.conv_impl_request = tailf, req
+        assert den.impl_for(7, 7) == ('direct-f64' if req == 'direct' else 'mfma-fp6v2') and not den.tail_fusable(7, 7)
+        torch.manual_seed(K)
+        forms[name] = int((ab.sample(temp=1.0, sample_steps=6).cpu() != otok).sum())
+        with torch.inference_mode():
+            lg2 = den(x_t.float().to(dev), t=t.to(dev))
+            functional.reset_net(den)
+        forms[name + "_logits"] = float((lg2 - logits).abs().max())
+    den.use_step_tail, den.conv_impl_request = True, 'auto'
+    # Philox noise: graph replay of the fused-tail loop == the eager three-launch loop on the same key
     ab.noise_source = 'philox'
+    torch.manual_seed(K + 1)
     tokp = ab.sample(temp=1.0, sample_steps=6)
-    parity(f"codebook_size_{K}", logits_max_abs_err=lerr, token_mismatches_6_steps=n_bad, impl=den.impl_for(7, 7))
+    den.use_step_tail, ab.use_graph = False, False
+    torch.manual_seed(K + 1)
+    tokp3 = ab.sample(temp=1.0, sample_steps=6)
+    den.use_step_tail, ab.use_graph = True, True
+    parity(f"codebook_size_{K}", logits_max_abs_err=lerr, token_mismatches_6_steps=n_bad, impl=den.impl_for(7, 7),
+           other_forms=forms, philox_tail_graph_vs_eager_three_launches=int((tokp != tokp3).sum()))
     assert logits.shape == (3, K, 7, 7) and lerr <= 1e-5
     assert n_bad == 0 and int(tokp.max()) < K and int(tokp.min()) >= 0
+    assert forms["three_launches"] == 0 and forms["direct_f64"] == 0, forms
+    assert forms["three_launches_logits"] == 0.0 and forms["direct_f64_logits"] <= 1e-5, forms
+    assert torch.equal(tokp, tokp3)
     # one training step on the same (t, u) as the oracle (masked cross-entropy with a [K][49] tile; K = 512 takes the
     # no-LDS-tile kernel); library forward convolutions may flip a few spikes: the F9 tolerances
     den.train()
@@ -2491,13 +2517,14 @@ def test_spike_generator_table_follows_invalidate_derived_and_is_not_shared(dev)
     assert not torch.equal(table(model), table(other))
     # (c) a capture of `other`'s decode, replays between eager calls
     f_ref, u_ref = other.decode_tokens(tokens, 16)
+    store = {}                                                    # (the captured launches' flag workspaces: theirs alone)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
+    with torch.cuda.stream(side), O.flag_scope(store):
         other.decode_tokens(tokens, 16)
     torch.cuda.current_stream().wait_stream(side)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g), O.flag_scope(store):
         f_g, u_g = other.decode_tokens(tokens, 16)
     u_eager_after_capture = other.decode_tokens(tokens, 16)[1]
     g.replay()
