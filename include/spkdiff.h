@@ -32,7 +32,7 @@ typedef struct ihipStream_t* spk_stream_t; /* == hipStream_t */
 
 #define SPK_VERSION 104 /* 0.1.4 -- bumped whenever an exported signature changes or entry points are added (round 4 inserted `int K`
                            * before the stream of spk_select_active / spk_select_needed: 101; round 5 added the VectorQuantizer's
-                           * training branch and the training convolutions: 102, the token-table spike generator: 103; round 6: `int flag_cap` in front of the
+                           * training branch and the training convolutions: 102, the token-table spike generator: 103; round 6: `int flag_cap` (and `int form` for spk_den_conv3x3_mfma_fp6v2) in front of the
                            * stream of the four certified-kernel entry points, spk_set_option / spk_get_option left the shipped library: 104); spkdiff/_lib.py refuses a library whose
                            * spk_version() differs from the signatures it declares */
 
@@ -272,6 +272,9 @@ int spk_den_conv3x3_mfma_fp6(const uint8_t* in_c4, int nch, const uint8_t* wq, c
  * flag_cap: how many flagged neurons the id list takes before the rest go to the overflow bitmap, which the tail launch scans and
  * clears (< 0 or > 2^20: the whole list of 2^20 entries -- what every product call passes).  The workspace layout does not depend on
  * it; the parity suite passes 64 and 0 so that the overflow path runs (tests/test_gpu_parity.py::test_flag_overflow_*).
+ * form: 0 = automatic (7x7 latents with fewer items -- B x Cout / 32 -- than half the CUs run two half-image items per image on
+ * four-wave workgroups: R/main.py's own n_samples = 16 leaves half the chip idle otherwise), 1 = whole-image items always (the
+ * reference form for the bit-equality test of the split).  Same spikes bit for bit either way.
  * SPK_ERR_UNSUPPORTED unless T == 16, H == W == 7 or 8, Cout % 32 == 0 (Cin = 32 * nch). */
 long long spk_den_packed_weight_fp6v2_bytes(int Cout, int Cin);
 int spk_den_pack_weight_fp6v2(const float* w, const float* bias, uint8_t* wq, double* scale, double* bias_d, float* wl1,
@@ -280,7 +283,7 @@ long long spk_den_fp6v2_flag_words(int B, int Cout, int H, int W);
 int spk_den_conv3x3_mfma_fp6v2(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale, const double* bias_d,
                                const float* wl1, const int* qtab, const float* bn_a, const float* bn_b, uint8_t* out_s32,
                                uint8_t* out_counts, unsigned* flag_words, int T, int B, int H, int W, int Cout,
-                               const int* n_dyn_or_null, int flag_cap, spk_stream_t stream);
+                               const int* n_dyn_or_null, int flag_cap, int form, spk_stream_t stream);
 /* Measurement aid: re-run ONE tail part of the last spk_den_conv3x3_mfma_fp6v2 call on the same arguments and workspace --
  * part 2: the exact recomputation of the neurons that call flagged (flag_words[1] holds their number, the id list is intact;
  * recomputing them again writes the same spikes), part 4: the last position of every image (7x7).  bench.py times these to

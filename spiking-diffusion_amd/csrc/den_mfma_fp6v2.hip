@@ -177,6 +177,14 @@ struct V2Args {
                                 // +1.8 % on the dense reverse process (86.8 -> 88.4 ms, same box, profiles/r4_ab_kernel_variants.txt)
                                 // -- the launch is bound by the depth of its chains of dependent reads, not by L2 bandwidth
 #endif
+#ifndef SPK_V2_HALF_FILL
+#define SPK_V2_HALF_FILL 2      // the small-batch split is taken while B x Cout / 32 x this <= workgroups (2: the halves still fit one per CU)
+#endif
+#ifndef SPK_V2_LPS_MIN_B
+#define SPK_V2_LPS_MIN_B 64     // full batches below this take the merged tail launch of the active-set calls (last position per image
+                                // pair from L2 + repairs): the LDS-shared form puts eight images on a workgroup, i.e. B / 8 x Cout / 32
+                                // workgroups -- at R/main.py's own B = 16 that is 2 x G serial chains (12.3 us per launch against 7.4)
+#endif
 #ifndef SPK_V2_LP_SPLIT_MAX
 #define SPK_V2_LP_SPLIT_MAX 512    // last-position part: up to this many units the four waves of a workgroup split a unit's K chunks
                                    // (1024 until round 4; same box, dense / elimination / lists, ms per 100-step sample at B = 256:
@@ -293,10 +301,21 @@ __device__ __forceinline__ void store_tile_masks(uint8_t* out, const unsigned lo
 // sampler will read at this reverse step, dilated by the layers in between) instead of all 48 -- tile k = list entries 2k,
 // 2k + 1, round-robin over the waves, NTP = ceil(entries / 8) tiles per wave; `slots` are the image slots with that tile
 // count.  Positions outside the list keep whatever the output buffer held: nothing downstream of a listed position reads them.
-template <int H, int W, int NWV, bool SPLIT, int NTP>
+// Small batches (round 6; R/main.py's own call is B = 16): an image x 32 output channels is ONE item, so a layer with B x Cout / 32
+// items below the CU count leaves CUs idle (B = 16: conv2 64, conv3 / conv5 128 items on 256 CUs).  HALF = the listed-positions
+// form (NTP = 3 tiles per wave of four) on two FIXED lists per image -- positions 0..23 and 24..47 -- i.e. two items per image, one
+// wave per SIMD.  Same arithmetic per position as every other form (bit-equal: test_fp6v2_small_batch_split_...).
+__device__ const uint8_t V2_HALF_REC[2][64] = {
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23,
+     23, 23, 23, 23, 23, 23, 23, 23, 23, 23, 23, 23, 23, 23, 23, 23, 23, 23, 23, 23, 23, 23, 23, 23, 24},
+    {24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47,
+     47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 24}};
+
+template <int H, int W, int NWV, bool SPLIT, int NTP, bool HALF = false>
 __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const int il, const int lanes, const int n_images,
                                            const int* __restrict__ slots) {
   constexpr bool PRUNE = NTP > 0;
+  static_assert(!HALF || (PRUNE && !SPLIT && H == 7 && W == 7 && NWV == 4 && NTP == 3), "half-image items: 7x7, four waves x three tiles");
   // how the four-digit form counts the active inputs of a row: REC: once per input record and chunk for the whole workgroup
   // (full items: the per-fragment popcounts were 29 % of the launch's vector issue), else per A fragment in the K loop
   // (listed positions: an item has few fragments, and the per-item passes of REC cost more than they save there: -2.5 %)
@@ -392,10 +411,10 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
   const uint8_t* const wbase = a.wq + (long long)g * nch * W_SLAB;
   // item index -> (image, band); the slab of a band starts (H/2 - 1) rows into the image for the bottom band
   auto aslab_of = [&](int itm, int c) -> const uint8_t* {
-    const int b = PRUNE ? slots[itm] : (SPLIT ? itm >> 1 : itm), band = SPLIT ? itm & 1 : 0;
+    const int b = HALF ? itm >> 1 : (PRUNE ? slots[itm] : (SPLIT ? itm >> 1 : itm)), band = SPLIT ? itm & 1 : 0;
     return a.in0 + ((long long)b * nch + c) * HW * POSB + band * (Hb - 1) * W * POSB;
   };
-  const int nitems = SPLIT ? 2 * n_images : n_images;
+  const int nitems = (SPLIT || HALF) ? 2 * n_images : n_images;
 
   // per-channel constants (the group is fixed: loaded once)
   const int co = g * 32 + (lane & 31);
@@ -438,11 +457,11 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
     }
   }
   for (int itm = il; itm < nitems; itm += lanes) {
-    const int b = PRUNE ? slots[itm] : (SPLIT ? itm >> 1 : itm), band = SPLIT ? itm & 1 : 0;
+    const int b = HALF ? itm >> 1 : (PRUNE ? slots[itm] : (SPLIT ? itm >> 1 : itm)), band = SPLIT ? itm & 1 : 0;
     const int band_off = band * PW * POSB;                // bottom band: fragment addresses one LDS row further down
     int n_list = 2 * NT * NWV;
     if constexpr (PRUNE) {
-      const uint8_t* rec = a.need + (long long)b * 64;
+      const uint8_t* rec = HALF ? &V2_HALF_REC[itm & 1][0] : a.need + (long long)b * 64;
       n_list = __builtin_amdgcn_readfirstlane((int)rec[48]);
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
@@ -898,6 +917,16 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_fp6v2_kernel(V2Args a) {
   int g, il, lanes;
   fp6v2_wg_map(a, g, il, lanes);
   fp6v2_body<H, W, NWV, SPLIT, 0>(a, g, il, lanes, Bn, nullptr);
+  fp6v2_handover(a);
+}
+
+// Small batches: two half-image items per image (fp6v2_body HALF), four waves
+template <int H, int W>
+__global__ __launch_bounds__(256, 1) void conv3x3_fp6v2_half_kernel(V2Args a) {
+  const int Bn = a.n_dyn ? (*a.n_dyn < a.B ? *a.n_dyn : a.B) : a.B;
+  int g, il, lanes;
+  fp6v2_wg_map(a, g, il, lanes);
+  fp6v2_body<H, W, 4, false, 3, true>(a, g, il, lanes, Bn, nullptr);
   fp6v2_handover(a);
 }
 
@@ -1528,8 +1557,9 @@ extern "C" long long spk_den_fp6v2_flag_words(int B, int Cout, int H, int W) {
 static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale, const double* bias_d,
                         const float* wl1, const int* qtab, const float* bn_a, const float* bn_b, uint8_t* out_s32,
                         uint8_t* out_counts, unsigned* flag_words, int T, int B, int H, int W, int Cout,
-                        const int* n_dyn_or_null, const uint8_t* need, int need_R, int need_r, int flag_cap, hipStream_t stream,
-                        int parts = 7) {
+                        const int* n_dyn_or_null, const uint8_t* need, int need_R, int need_r, int flag_cap, int form,
+                        hipStream_t stream, int parts = 7) {
+  const bool split_small = form == 0;                        // (form 1: whole-image items at any batch size)
   if (!in_s32 || nch <= 0 || !wq || !scale || !bias_d || !wl1 || !qtab || !bn_a || !bn_b || !out_s32 || !flag_words ||
       B <= 0 || H <= 0 || W <= 0 || Cout <= 0)
     return SPK_ERR_ARG;
@@ -1657,11 +1687,15 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   if (need) {
     if (grid / G < 6) return SPK_ERR_UNSUPPORTED;           // one image lane per tile-count class at least
     hipLaunchKernelGGL((conv3x3_fp6v2_listed_kernel<7, 7, 8>), dim3(grid), dim3(512), lds, stream, a);
+  } else if (split_small && (long long)B * G * SPK_V2_HALF_FILL <= grid) {
+    // fewer items than workgroups: two half-image items per image on four-wave workgroups (B = 16: conv2 / conv3 / conv5)
+    hipLaunchKernelGGL((conv3x3_fp6v2_half_kernel<7, 7>), dim3(grid), dim3(256), lds, stream, a);
   } else hipLaunchKernelGGL((conv3x3_fp6v2_kernel<7, 7, 8>), dim3(grid), dim3(512), lds8, stream, a);
 #endif
   SPK_LAUNCH_CHECK();
   const int n_lp = ((B + 2 * SPK_V2_LP_PAIRS - 1) / (2 * SPK_V2_LP_PAIRS)) * G;
-  if (!n_dyn_or_null && SPK_V2_MERGE_FULL && spk_opt(SPK_OPT_V2_LPS) != 0 && nch >= 2 && (long long)LPS_LDS + 4096 <= spk_lds_limit()) {
+  if (!n_dyn_or_null && SPK_V2_MERGE_FULL && spk_opt(SPK_OPT_V2_LPS) != 0 && nch >= 2 && B >= SPK_V2_LPS_MIN_B &&
+      (long long)LPS_LDS + 4096 <= spk_lds_limit()) {
     // round 5, full batches: last positions with LDS-shared weight tiles (eight images per workgroup), repairs beside them (four
     // workgroups per CU).  Same box, B = 256: den.conv4 / conv5 launches 386 / 373 -> 380 / 369 us, dense reverse process 91.6 -> 90.9 ms
     // (profiles/r5_ab_kernel_variants.txt (3)).  The sampler's active-set calls keep the form below: with few images the shared
@@ -1687,9 +1721,10 @@ extern "C" int spk_den_conv3x3_mfma_fp6v2(const uint8_t* in_s32, int nch, const 
                                           const double* bias_d, const float* wl1, const int* qtab, const float* bn_a,
                                           const float* bn_b, uint8_t* out_s32, uint8_t* out_counts, unsigned* flag_words,
                                           int T, int B, int H, int W, int Cout, const int* n_dyn_or_null, int flag_cap,
-                                          hipStream_t stream) {
+                                          int form, hipStream_t stream) {
+  if (form != 0 && form != 1) return SPK_ERR_ARG;
   return fp6v2_launch(in_s32, nch, wq, scale, bias_d, wl1, qtab, bn_a, bn_b, out_s32, out_counts, flag_words, T, B, H, W, Cout,
-                      n_dyn_or_null, nullptr, 0, 0, flag_cap, stream);
+                      n_dyn_or_null, nullptr, 0, 0, flag_cap, form, stream);
 }
 
 extern "C" int spk_den_conv3x3_mfma_fp6v2_part(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale,
@@ -1699,7 +1734,7 @@ extern "C" int spk_den_conv3x3_mfma_fp6v2_part(const uint8_t* in_s32, int nch, c
                                                int flag_cap, hipStream_t stream) {
   if (part != 2 && part != 4) return SPK_ERR_ARG;
   return fp6v2_launch(in_s32, nch, wq, scale, bias_d, wl1, qtab, bn_a, bn_b, out_s32, out_counts, flag_words, T, B, H, W, Cout,
-                      n_dyn_or_null, nullptr, 0, 0, flag_cap, stream, part);
+                      n_dyn_or_null, nullptr, 0, 0, flag_cap, 1, stream, part);
 }
 
 extern "C" int spk_den_conv3x3_mfma_fp6v2_listed(const uint8_t* in_s32, int nch, const uint8_t* wq, const double* scale,
@@ -1710,7 +1745,7 @@ extern "C" int spk_den_conv3x3_mfma_fp6v2_listed(const uint8_t* in_s32, int nch,
                                                  int flag_cap, hipStream_t stream) {
   if (!need || !n_dyn || need_radii <= 0 || need_radii > 8 || radius < 1 || radius > need_radii) return SPK_ERR_ARG;
   return fp6v2_launch(in_s32, nch, wq, scale, bias_d, wl1, qtab, bn_a, bn_b, out_s32, out_counts, flag_words, T, B, H, W, Cout,
-                      n_dyn, need, need_radii, radius - 1, flag_cap, stream);
+                      n_dyn, need, need_radii, radius - 1, flag_cap, 1, stream);
 }
 
 extern "C" int spk_spikes_to_s32(const float* spikes, uint8_t* out_s32, int T, int B, int C, int HW, hipStream_t stream) {

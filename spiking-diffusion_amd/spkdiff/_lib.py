@@ -87,7 +87,7 @@ _SIGS = {
     "spk_den_packed_weight_fp6v2_bytes": (c_longlong, [c_int, c_int]),
     "spk_den_pack_weight_fp6v2": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P]),
     "spk_den_fp6v2_flag_words": (c_longlong, [c_int, c_int, c_int, c_int]),
-    "spk_den_conv3x3_mfma_fp6v2": (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
+    "spk_den_conv3x3_mfma_fp6v2": (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, P]),
     "spk_den_conv3x3_mfma_fp6v2_part": (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_int,
                                                 c_int, P]),
     "spk_spikes_to_s32": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

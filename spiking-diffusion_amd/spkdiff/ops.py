@@ -1335,6 +1335,9 @@ def _flag_bitmap(device, words):
 # argument of spk_den_conv3x3_mfma_fp6v2* / spk_vae_fp6_fwd).  -1 = the whole list (2^20 entries): every product call.  The parity
 # suite sets 64 and 0 so that whole samplers / decoders run on the overflow path (tests: test_flag_overflow_*).
 FLAG_CAP = -1
+# `form` argument of spk_den_conv3x3_mfma_fp6v2: 0 = automatic (small batches: two half-image items per image), 1 = whole-image items
+# always (tests: the split form against it)
+FP6V2_FORM = 0
 
 
 def den_conv3x3_mfma_fp6v2(in0, packed, Cout, *, bn_a, bn_b, want_counts=False, need_radius=None):
@@ -1362,7 +1365,8 @@ def den_conv3x3_mfma_fp6v2(in0, packed, Cout, *, bn_a, bn_b, want_counts=False, 
         # SPK_ERR_UNSUPPORTED: this device / partition has too few CUs for the per-class division of the listed launch (e.g.
         # a 32-CU partition with Cout = 512).  The unlisted launch computes a superset of the listed positions: same tokens.
     check(lib.spk_den_conv3x3_mfma_fp6v2(_p(in0), nch, _p(wq), _p(scale), _p(bias_d), _p(wl1), _p(qtab), _p(bn_a), _p(bn_b),
-                                         _p(out), _p(cnt), _p(flags), T, B, H, W, Cout, _n_dyn(), int(FLAG_CAP), _stream(in0)),
+                                         _p(out), _p(cnt), _p(flags), T, B, H, W, Cout, _n_dyn(), int(FLAG_CAP), int(FP6V2_FORM),
+                                         _stream(in0)),
           "spk_den_conv3x3_mfma_fp6v2")
     if FP6V2_STATS is not None:
         _fp6v2_stats(in0, packed, Cout, bn_a, bn_b, out, cnt, flags)
@@ -1764,8 +1768,8 @@ def spikegen_tokens_s32(tokens, codebook, w_packed, bias, bn_a, bn_b, T=16, tabl
     table_slot: a dict OWNED BY THE CALLER's module (one per spike generator: no table is shared between models) that keeps the table
     buffer per (device, K, Cout) with the key and the stream of its last eager build.  table_key: anything that changes whenever
     codebook, weights or BN terms do (parameter versions + the owner's invalidation epoch); the slot's table is reused while the key
-    AND the stream are equal.  A call under stream capture always builds (the replay then rebuilds from the live parameters) and leaves
-    the slot marked unknown, as does any call without a key or slot."""
+    AND the stream are equal.  A call under stream capture always builds, into a buffer of its own (the graph's pool), and never touches
+    the slot: a replay bakes the derived inputs of capture time and must not leave its table behind an eager call's key."""
     tokens = _dev(tokens, "tokens", torch.int64)
     codebook = _dev(codebook.detach(), "codebook", torch.float32)
     K, D = codebook.shape
@@ -1778,8 +1782,8 @@ def spikegen_tokens_s32(tokens, codebook, w_packed, bias, bn_a, bn_b, T=16, tabl
     stream = _stream(tokens)
     capturing = torch.cuda.is_current_stream_capturing()
     ent = None
-    if table_slot is not None:
-        skey = (tokens.device, K, Cout)
+    if table_slot is not None and not capturing:    # (a captured call builds into a buffer of its own, from the graph's pool: replays
+        skey = (tokens.device, K, Cout)             #  -- which bake the derived inputs of capture time -- never write the eager slot)
         ent = table_slot.get(skey)
         if ent is None:
             ent = table_slot[skey] = [torch.empty(nbytes // 2, dtype=torch.int16, device=tokens.device), None, None]
@@ -1787,9 +1791,8 @@ def spikegen_tokens_s32(tokens, codebook, w_packed, bias, bn_a, bn_b, T=16, tabl
         ws, build = torch.empty(nbytes // 2, dtype=torch.int16, device=tokens.device), True
     else:
         ws = ent[0]
-        build = capturing or table_key is None or ent[1] != table_key or ent[2] != stream
-        # what the buffer holds is only known after an EAGER build on this stream; a captured launch has not run yet
-        ent[1], ent[2] = (None, None) if (capturing or table_key is None) else (table_key, stream)
+        build = table_key is None or ent[1] != table_key or ent[2] != stream
+        ent[1], ent[2] = (None, None) if table_key is None else (table_key, stream)
     B, h, w = tokens.shape
     out = torch.empty((B, 1, h, w, T, 16), dtype=C4_DTYPE, device=tokens.device)
     check(lib.spk_spikegen_tokens_s32(_p(tokens), _p(codebook), _p(w_packed), _p(bias), _p(bn_a), _p(bn_b), _p(ws), int(build), _p(out),

@@ -871,6 +871,54 @@ def test_vae_fp6_kernel_equals_the_int8_gather_kernel(dev, ops, layer, B, hw, Co
     parity(f"vae_fp6_{layer}_vs_int8_B{B}_{hw}x{hw}_c{Cout}", values=total, mismatches=mism)
 
 
+# ------------------------------------------------------------------------------------------------- round 6: small batches
+@pytest.mark.parametrize("B", [1, 5, 16, 31])
+def test_fp6v2_small_batch_split_bit_equal_to_whole_image_items(dev, ops, B):
+    """R/main.py's own call shape is n_samples = 16 (R/snn_model/vq_diffusion.py:51): B x Cout / 32 whole-image items leave half the
+    CUs idle in conv2 / conv3 / conv5.  The automatic form (spk_den_conv3x3_mfma_fp6v2 form 0) then runs two half-image items per
+    image on four-wave workgroups; spikes AND spike counts must equal the whole-image form (form 1) and the six-plane exact kernel
+    bit for bit -- full batches and the sampler's active-set calls (device-side image count), repeated launches on one workspace."""
+    g = torch.Generator().manual_seed(7100 + B)
+    total = mism = 0
+    for Cout, Cin in ((128, 64), (256, 128), (512, 256), (256, 512)):
+        w = ((torch.rand(Cout, Cin, 3, 3, generator=g) - 0.5) * 0.05)
+        w[:, :, 1, 1] *= 3.0
+        bias = (torch.rand(Cout, generator=g) - 0.5) * 0.2
+        a = ((torch.rand(Cout, generator=g) - 0.3) * 12.0).to(dev)
+        b = ((torch.rand(Cout, generator=g) - 0.4) * 1.5).to(dev)
+        sd = (torch.rand(16, B, Cin, 7, 7, generator=g) < 0.08).float().to(dev)
+        pk, xs = ops.den_pack_weight_fp6v2(w.to(dev), bias.to(dev)), ops.spikes_to_s32(sd)
+        outs = {}
+        try:
+            for form in (1, 0):
+                ops.FP6V2_FORM = form
+                for rep in range(2):
+                    o, c = ops.den_conv3x3_mfma_fp6v2(xs, pk, Cout, bn_a=a, bn_b=b, want_counts=True)
+                outs[form] = (o.clone(), c.clone())
+                if B >= 5:
+                    n = B // 2 + 1
+                    active = torch.arange(B, dtype=torch.int32, device=dev)
+                    n_act = torch.tensor([n, 0], dtype=torch.int32, device=dev)
+                    with ops.active_set(active, n_act):
+                        o, c = ops.den_conv3x3_mfma_fp6v2(xs, pk, Cout, bn_a=a, bn_b=b, want_counts=True)
+                    outs[(form, "active")] = (o[:n].clone(), c[:n].clone())
+        finally:
+            ops.FP6V2_FORM = 0
+        bad = int((outs[0][0] != outs[1][0]).sum()) + int((outs[0][1] != outs[1][1]).sum())
+        if B >= 5:
+            bad += int((outs[(0, "active")][0] != outs[(1, "active")][0]).sum()) + int((outs[(0, "active")][1] != outs[(1, "active")][1]).sum())
+            assert torch.equal(outs[(0, "active")][0], outs[0][0][:B // 2 + 1]), "the first n images of the full batch"
+        o1, c1 = ops.den_conv3x3_mfma_fp6(ops.spikes_to_c4(sd), ops.den_pack_weight_fp6(w.to(dev), bias.to(dev)), Cout, bn_a=a, bn_b=b,
+                                          want_counts=True)
+        bad += int((ops.c4_to_spikes(o1) != ops.s32_to_spikes(outs[0][0])).sum()) + int((c1 != outs[0][1]).sum())
+        total += outs[0][0].numel() * 2; mism += bad
+        assert bad == 0, (Cout, Cin, bad)
+        assert 0.001 < float(ops.s32_to_spikes(outs[0][0]).mean()) < 0.9
+    torch.cuda.synchronize()
+    assert all(flag_ws_clean(v) for k, v in ops._FLAG_DEFAULT.items() if k[0] == "den")
+    parity(f"fp6v2_small_batch_split_B{B}", neuron_steps=total, spike_mismatches=mism)
+
+
 # ------------------------------------------------------------------------------------------------- round 6: the overflow path of the flag list
 def _den_flagged(ops, B, Cout, H, W):
     """flag_words[1] of the workspace the last eager fp6v2 call of this shape used = neurons that call flagged."""
@@ -2517,6 +2565,8 @@ def test_spike_generator_table_follows_invalidate_derived_and_is_not_shared(dev)
     assert not torch.equal(table(model), table(other))
     # (c) a capture of `other`'s decode, replays between eager calls
     f_ref, u_ref = other.decode_tokens(tokens, 16)
+    from spkdiff.fused import derived_refs
+    refs = derived_refs(other)                                    # (what a graph owner keeps alive: the addresses its launches bake)
     store = {}                                                    # (the captured launches' flag workspaces: theirs alone)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -2532,8 +2582,9 @@ def test_spike_generator_table_follows_invalidate_derived_and_is_not_shared(dev)
     other.vq_layer.embeddings.weight.data.mul_(-1.0)            # new parameter state, same versions
     invalidate_derived(other)
     u_new = other.decode_tokens(tokens, 16)[1]
-    g.replay()                                                    # rebuilds the table in-graph from the live parameters
+    g.replay()                                # a STALE graph (its owner should have re-captured): it must not reach the eager table
     torch.cuda.synchronize()
+    del refs
     stale += int(not torch.equal(table(other), layerwise(other))) + int(not torch.equal(table(model), layerwise(model)))
     assert not torch.equal(u_new, u_ref)
     parity("spikegen_table_invalidation", stale_tables=stale)
