@@ -177,6 +177,13 @@ struct V2Args {
                                 // +1.8 % on the dense reverse process (86.8 -> 88.4 ms, same box, profiles/r4_ab_kernel_variants.txt)
                                 // -- the launch is bound by the depth of its chains of dependent reads, not by L2 bandwidth
 #endif
+#ifndef SPK_V2_GX_KB
+#define SPK_V2_GX_KB 2560       // XCD-aware walk: packed weights of the channel groups one XCD keeps (its L2 is 4 MB).  Round 6, same box
+                                // (profiles/r6_ab_kernel_variants.txt (2)): 1536 (rounds 2-5: four sets of 2 / 4 groups for conv5 / conv4, every
+                                // image slab fetched by four XCDs) -> 2560 (two sets of 4 / 8 groups, 2.4 MB of weights per L2): L2-miss traffic
+                                // of the conv5 / conv4 launches 320 / 194 -> 214 / 150 MB at the SAME time (88.2 ms per batch either way);
+                                // 6144 (one set, 4.9 MB of weights per L2): 312 / 346 MB -- the weights no longer stay resident
+#endif
 #ifndef SPK_V2_HALF_FILL
 #define SPK_V2_HALF_FILL 2      // the small-batch split is taken while B x Cout / 32 x this <= workgroups (2: the halves still fit one per CU)
 #endif
@@ -1593,7 +1600,7 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
     if ((wgs & 7) != 0) return 0;
     const int S = wgs / 8;
     int gx = 1;
-    while (gx * 2 <= G && gx * 2 <= S && (long long)gx * 2 * nch * W_SLAB <= 1536 * 1024) gx *= 2;
+    while (gx * 2 <= G && gx * 2 <= S && (long long)gx * 2 * nch * W_SLAB <= SPK_V2_GX_KB * 1024) gx *= 2;
     while (G / gx > 8 && gx * 2 <= G && gx * 2 <= S) gx *= 2;
     const int nsets = G / gx;
     if (G % gx == 0 && nsets <= 8 && 8 % nsets == 0 && S % gx == 0) { v.gx = gx; v.nsets = nsets; return wgs; }

@@ -40,9 +40,12 @@ __global__ __launch_bounds__(SPK_LIF_BLOCK) void lif_fwd_kernel(const float* __r
        g += (long long)gridDim.x * blockDim.x) {
     const long long n0 = g * VEC;
     float v[VEC];
-    if constexpr (VEC == 4) {
-      float4 t4 = *reinterpret_cast<const float4*>(v_io + n0);
-      v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+    if constexpr (VEC >= 4) {
+#pragma unroll
+      for (int q = 0; q < VEC / 4; ++q) {
+        float4 t4 = *reinterpret_cast<const float4*>(v_io + n0 + 4 * q);
+        v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
+      }
     } else {
       v[0] = v_io[n0];
     }
@@ -52,10 +55,13 @@ __global__ __launch_bounds__(SPK_LIF_BLOCK) void lif_fwd_kernel(const float* __r
       for (int i = 0; i < TU; ++i) {
         if (t0 + i < T) {
           const float* p = x + (long long)(t0 + i) * N + n0;
-          if constexpr (VEC == 4) {
-            f32x4 t4 = (SPK_LIF_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p))
-                                        : *reinterpret_cast<const f32x4*>(p);
-            xv[i][0] = t4.x; xv[i][1] = t4.y; xv[i][2] = t4.z; xv[i][3] = t4.w;
+          if constexpr (VEC >= 4) {
+#pragma unroll
+            for (int q = 0; q < VEC / 4; ++q) {
+              f32x4 t4 = (SPK_LIF_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + q)
+                                          : reinterpret_cast<const f32x4*>(p)[q];
+              xv[i][4 * q] = t4.x; xv[i][4 * q + 1] = t4.y; xv[i][4 * q + 2] = t4.z; xv[i][4 * q + 3] = t4.w;
+            }
           } else {
             xv[i][0] = __builtin_nontemporal_load(p);
           }
@@ -70,18 +76,24 @@ __global__ __launch_bounds__(SPK_LIF_BLOCK) void lif_fwd_kernel(const float* __r
           const long long o = (long long)(t0 + i) * N + n0;
           if constexpr (OUT == SPK_SPIKE_F32) {
             float* po = reinterpret_cast<float*>(out) + o;
-            if constexpr (VEC == 4) {
-              f32x4 r = {s[0] ? 1.f : 0.f, s[1] ? 1.f : 0.f, s[2] ? 1.f : 0.f, s[3] ? 1.f : 0.f};
-              if (SPK_LIF_NT & 2) __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(po));
-              else *reinterpret_cast<f32x4*>(po) = r;
+            if constexpr (VEC >= 4) {
+#pragma unroll
+              for (int q = 0; q < VEC / 4; ++q) {
+                f32x4 r = {s[4 * q] ? 1.f : 0.f, s[4 * q + 1] ? 1.f : 0.f, s[4 * q + 2] ? 1.f : 0.f, s[4 * q + 3] ? 1.f : 0.f};
+                if (SPK_LIF_NT & 2) __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(po) + q);
+                else reinterpret_cast<f32x4*>(po)[q] = r;
+              }
             } else {
               po[0] = s[0] ? 1.f : 0.f;
             }
           } else {
             uint8_t* po = reinterpret_cast<uint8_t*>(out) + o;
-            if constexpr (VEC == 4) {
-              uint32_t r = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
-              *reinterpret_cast<uint32_t*>(po) = r;
+            if constexpr (VEC >= 4) {
+#pragma unroll
+              for (int q = 0; q < VEC / 4; ++q) {
+                uint32_t r = (uint32_t)s[4 * q] | ((uint32_t)s[4 * q + 1] << 8) | ((uint32_t)s[4 * q + 2] << 16) | ((uint32_t)s[4 * q + 3] << 24);
+                reinterpret_cast<uint32_t*>(po)[q] = r;
+              }
             } else {
               po[0] = (uint8_t)s[0];
             }
@@ -89,8 +101,10 @@ __global__ __launch_bounds__(SPK_LIF_BLOCK) void lif_fwd_kernel(const float* __r
         }
       }
     }
-    if constexpr (VEC == 4) {
-      *reinterpret_cast<float4*>(v_io + n0) = make_float4(v[0], v[1], v[2], v[3]);
+    if constexpr (VEC >= 4) {
+#pragma unroll
+      for (int q = 0; q < VEC / 4; ++q)
+        *reinterpret_cast<float4*>(v_io + n0 + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     } else {
       v_io[n0] = v[0];
     }
@@ -292,9 +306,20 @@ extern "C" int spk_lif_fwd(const float* x_seq, float* v_inout, void* spike_out, 
   const bool f32 = spike_dtype == SPK_SPIKE_F32;
   const uintptr_t al = (uintptr_t)x_seq | (uintptr_t)v_inout | (uintptr_t)spike_out;
   const bool vec = (N % 4 == 0) && (al % 16 == 0);
+#ifndef SPK_LIF_VEC8
+#define SPK_LIF_VEC8 0          // 1: eight neurons per thread (two 16-byte requests per lane and step) where N % 8 == 0.  Round 6, same box:
+                                // 3.7-3.8 TB/s against 6.4 (a wave's request then covers every other 16 bytes of 2 KB): not instantiated
+#endif
+  [[maybe_unused]] const bool vec8 = SPK_LIF_VEC8 && vec && (N % 8 == 0) && (al % 32 == 0);
 #define SPK_LIF_LAUNCH(VEC, OUT, DIV)                                                                              \
   hipLaunchKernelGGL((lif_fwd_kernel<VEC, OUT, DIV>), dim3(lif_grid((N + VEC - 1) / VEC)), dim3(SPK_LIF_BLOCK), 0, stream, \
                      x_seq, v_inout, spike_out, T, N, tau, inv_tau, v_threshold, v_reset)
+#if SPK_LIF_VEC8
+  if (vec8) {
+    if (f32) { if (pow2) SPK_LIF_LAUNCH(8, SPK_SPIKE_F32, false); else SPK_LIF_LAUNCH(8, SPK_SPIKE_F32, true); }
+    else     { if (pow2) SPK_LIF_LAUNCH(8, SPK_SPIKE_U8, false);  else SPK_LIF_LAUNCH(8, SPK_SPIKE_U8, true); }
+  } else
+#endif
   if (vec) {
     if (f32) { if (pow2) SPK_LIF_LAUNCH(4, SPK_SPIKE_F32, false); else SPK_LIF_LAUNCH(4, SPK_SPIKE_F32, true); }
     else     { if (pow2) SPK_LIF_LAUNCH(4, SPK_SPIKE_U8, false);  else SPK_LIF_LAUNCH(4, SPK_SPIKE_U8, true); }

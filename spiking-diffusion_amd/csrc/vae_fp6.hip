@@ -180,6 +180,19 @@ __device__ unsigned long long g_vt_stamp[SPK_VT_NWV][8];
 #define VT_ACC(slot, t0) do { } while (0)
 #endif
 
+#ifndef SPK_VT_INWAVE_FIX
+#define SPK_VT_INWAVE_FIX 0     // 1 (round 6 experiment, measured SLOWER): a wave recomputes the neurons IT flags, exactly, right behind the tile's
+                                // stores (an out-of-line call on a path 0.6 % of the tiles take) -- no id list, no repair launch.  Bit-equal (28
+                                // vae_fp6 tests), and the three repair launches (8 + 8 + 6 us) go away, but the main launches grow by more:
+                                // convT2 198.8 -> 209.8, convT1 105.9 -> 110.5, conv2 65.3 -> 79.7 us; encode -> decode 0.555 -> 0.575 ms, same
+                                // box (profiles/r6_ab_kernel_variants.txt (3)).  0: id list + overflow bitmap + vae_fp6_fixup_kernel
+#endif
+// (the out-of-line form of vae_fix_neuron: the hot kernel then pays for the call only on the rare path)
+template <int GEO, int H, int W, int NCH, int OUT>
+__device__ __attribute__((noinline)) void vae_fix_neuron_call(const uint8_t* in, const int* qtab, const double* scale, const double* bias,
+                                                              const float* bn_a, const float* bn_b, const float* coef, void* out,
+                                                              int Cin, int Cout, long long nid, int lane);
+
 template <int GEO, int H, int W, int NCH, int OUT, int SPLIT, bool DB>
 __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
 #if SPK_VT_STAMP
@@ -584,11 +597,13 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
         const int ry = pc / CW, rx = pc - ry * CW;
         const int oy = GEO == 0 ? 2 * (part * RQ + ry) + PY : ry, ox = GEO == 0 ? 2 * rx + PX : rx;
         const long long pos = ((long long)b * Ho + oy) * Wo + ox;
+        const long long nid_f = pos * a.Cout + co;
         if (flg && ok) {
-          const long long nid = pos * a.Cout + co;
-          const unsigned idx = atomicAdd(a.flags, 1u);
-          if (idx < a.flag_cap) a.flags[2 + idx] = (unsigned)nid;
-          else atomicOr(a.flags + 2 + FLAG_CAP + (nid >> 5), 1u << (nid & 31));
+          const unsigned idx = atomicAdd(a.flags, 1u);            // (the count of flagged neurons: statistics, tests)
+          if constexpr (!SPK_VT_INWAVE_FIX) {
+            if (idx < a.flag_cap) a.flags[2 + idx] = (unsigned)nid_f;
+            else atomicOr(a.flags + 2 + FLAG_CAP + (nid_f >> 5), 1u << (nid_f & 31));
+          }
         }
         if (OUT == OUT_COLLAPSED) {
           if (ok) reinterpret_cast<float*>(a.out)[pos * a.Cout + co] = m;
@@ -610,6 +625,20 @@ __global__ __launch_bounds__(SPK_VT_NWV * 64, 1) void vae_fp6_kernel(TArgs a) {
             o.z = (((bitsv >> 8) & 0xfu) * 0x00204081u) & 0x01010101u;
             o.w = (((bitsv >> 12) & 0xfu) * 0x00204081u) & 0x01010101u;
             *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(a.out) + (pos * T16 + t) * a.Cout + g * 32 + 16 * hi) = o;
+          }
+        }
+        if constexpr (SPK_VT_INWAVE_FIX) {
+          unsigned long long fm = __builtin_amdgcn_ballot_w64(flg && ok);
+          if (fm) {                                             // (wave-uniform; 0.6 % of the tiles)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the tile's own stores first: the exact values overwrite them
+            while (fm) {
+              const int l = __builtin_ctzll(fm);
+              fm &= fm - 1;
+              const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(nid_f & 0xffffffffll), l);
+              const unsigned hi32 = (unsigned)__builtin_amdgcn_readlane((int)(nid_f >> 32), l);
+              vae_fix_neuron_call<GEO, H, W, NCH, OUT>(a.in, a.qtab, a.scale, a.bias, a.bn_a, a.bn_b, a.coef, a.out, a.Cin, a.Cout,
+                                                       (long long)(((unsigned long long)hi32 << 32) | lo), lane);
+            }
           }
         }
       }
@@ -771,6 +800,17 @@ __device__ __forceinline__ void vae_fix_neuron(const TArgs& a, long long nid, in
 }
 
 template <int GEO, int H, int W, int NCH, int OUT>
+__device__ __attribute__((noinline)) void vae_fix_neuron_call(const uint8_t* in, const int* qtab, const double* scale, const double* bias,
+                                                              const float* bn_a, const float* bn_b, const float* coef, void* out,
+                                                              int Cin, int Cout, long long nid, int lane) {
+  TArgs a;
+  a.in = in; a.qtab = qtab; a.scale = scale; a.bias = bias; a.bn_a = bn_a; a.bn_b = bn_b; a.coef = coef; a.out = out;
+  a.Cin = Cin; a.Cout = Cout;
+  a.wq = nullptr; a.flags = nullptr; a.flag_cap = 0; a.ticket_idx = 0; a.B = 0;
+  vae_fix_neuron<GEO, H, W, NCH, OUT>(a, nid, lane);
+}
+
+template <int GEO, int H, int W, int NCH, int OUT>
 __global__ __launch_bounds__(256) void vae_fp6_fixup_kernel(TArgs a, long long n_words) {
   const int lane = threadIdx.x & 63;
   const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwv = (long long)gridDim.x * 4;
@@ -908,8 +948,10 @@ int launch_vae(const TArgs& a, long long n_words, hipStream_t stream) {
   const int grid = cus >= G ? (cus / G) * G : G;
   hipLaunchKernelGGL((vae_fp6_kernel<GEO, H, W, NCH, OUT, SPLIT, DB>), dim3(grid), dim3(SPK_VT_NWV * 64), lds, stream, a);
   SPK_LAUNCH_CHECK();
-  hipLaunchKernelGGL((vae_fp6_fixup_kernel<GEO, H, W, NCH, OUT>), dim3(4 * cus), dim3(256), 0, stream, a, n_words);
-  SPK_LAUNCH_CHECK();
+  if constexpr (!SPK_VT_INWAVE_FIX) {
+    hipLaunchKernelGGL((vae_fp6_fixup_kernel<GEO, H, W, NCH, OUT>), dim3(4 * cus), dim3(256), 0, stream, a, n_words);
+    SPK_LAUNCH_CHECK();
+  }
   return SPK_OK;
 }
 

@@ -109,6 +109,10 @@ class AbsorbingDiffusion(Sampler):
         # layer r levels down is needed within distance r of a change.  True = the MFMA layers of the denoiser compute the
         # positions spk_select_needed lists for the step (7x7 latents; again the same tokens, draw for draw).
         self.list_positions = True
+        # ... from this batch size on: below it every launch of a reverse step is latency bound and the list bookkeeping (one more
+        # launch per step, per-class item division) costs more than the skipped positions save -- R/main.py's own n_samples = 16:
+        # 7.04 ms per 49-step sample without lists, 7.75 with; B = 32: 8.9 / 8.25 (tools/small_batch_time.py, profiles/r6_small_batch.txt)
+        self.list_min_batch = 24
         self.list_radii = 3                 # layers below the logits that take lists (1: conv5 only ... 4: conv2..conv5;
                                             # conv2 needs nearly every position anyway: 3 measured fastest)
         # Derived weight forms (digit planes, folded BN terms, captured graphs) are keyed on (data_ptr, _version), which
@@ -208,7 +212,7 @@ class AbsorbingDiffusion(Sampler):
         unmasked = torch.zeros((b, 1, h, w), dtype=torch.bool, device=dev)
         skip = self._skip_ok(h, w) and record is None
         act = None
-        need = ops.NeedLists(b, int(self.list_radii), dev) if skip and self._list_ok(h, w) else None
+        need = ops.NeedLists(b, int(self.list_radii), dev) if skip and self._list_ok(h, w, b) else None
         tail = (not skip) and dn.tail_fusable(h, w)                      # dense loop: the fused step tail (same tokens)
         pre1 = None
         for t in reversed(range(1, sample_steps + 1)):
@@ -242,8 +246,14 @@ class AbsorbingDiffusion(Sampler):
     def _skip_ok(self, h, w):
         return bool(self.skip_untouched)            # every kernel family takes the device-side image count
 
-    def _list_ok(self, h, w):
-        return bool(self.list_positions) and (h, w) == (7, 7)
+    def _list_ok(self, h, w, b=None):
+        return bool(self.list_positions) and (h, w) == (7, 7) and (b is None or b >= int(self.list_min_batch))
+
+    def form_for(self, b, h, w, sample_steps=None):
+        """Name of the launch form ``sample()`` takes for a batch of ``b`` on an h x w latent (same tokens in every form)."""
+        if not self._skip_ok(h, w):
+            return 'dense_step_tail' if self._denoise_fn.tail_fusable(h, w) else 'dense'
+        return 'elimination_lists' if self._list_ok(h, w, b) else 'elimination'
 
     STEP_STRIDE = 1 << 40        # 'global' layout: counters of one reverse step (images * h*w * K of them must fit)
 
@@ -321,7 +331,7 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
     same (seed, counter base)."""
     dn = self._denoise_fn
     skip = self._skip_ok(h, w)
-    lists = skip and self._list_ok(h, w)
+    lists = skip and self._list_ok(h, w, b)
     key = (str(dev), b, h, w, K, temp, sample_steps, int(self.mask_id), skip, lists, int(self.list_radii),
            bool(dn.use_step_tail), self.noise_layout, int(self.global_first), _weights_key(dn))
     entry = self._graphs.get(key)
