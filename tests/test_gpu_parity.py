@@ -2314,13 +2314,14 @@ def test_f13_sample_100_steps_and_decode_vs_reference_fixture(golden_dir, dev, t
     assert n_bad == 0, "100-step trajectory differs from the reference"
     assert err <= 1e-4 and u8_bad == 0
     assert torch.equal(out[True], tok), "untouched-image elimination changes no token over the full trajectory"
-    # and live against the oracle under another seed (the oracle is pinned to the reference by F6 and F13)
+    # and live against the oracle under another seed and temperature (the oracle is pinned to the reference by F6 and F13; 30 steps:
+    # the full length is the fixture's part above -- the host oracle is what this suite's wall time is made of)
     ab = AbsorbingDiffusion(den, mask_id=128)
     ab.n_samples, ab.noise_source = 4, 'host'
     torch.manual_seed(4242)
-    tok2 = ab.sample(temp=0.8, sample_steps=steps).cpu()
+    tok2 = ab.sample(temp=0.8, sample_steps=30).cpu()
     torch.manual_seed(4242)
-    ou8, otok = ref.sample_images(sdv, sdd, 4, 128, 0.8, steps, 7, 16)
+    ou8, otok = ref.sample_images(sdv, sdd, 4, 128, 0.8, 30, 7, 16)
     _, u82 = model.decode_tokens(tok2.reshape(4, 7, 7).to(dev))
     assert torch.equal(tok2, otok)
     assert int((u82.cpu().numpy().astype(int) - ou8.astype(int)).__abs__().max()) <= 1
@@ -2637,7 +2638,7 @@ def _philox_oracle_tokens(ops, dev, sd, key, B, steps, latent, temp=1.0, K=128, 
     return ref.absorbing_sample(sd, B, K, temp, steps, latent, 16, noise=noise)
 
 
-@pytest.mark.parametrize("B,steps", [(8, 100), (256, 10)])
+@pytest.mark.parametrize("B,steps", [(8, 100), (256, 6)])
 def test_timed_configuration_philox_graph_vs_oracle_on_dumped_noise(dev, ops, B, steps):
     """The configuration bench.py times -- noise_source='philox', the whole reverse process replayed from ONE hipGraph -- pinned
     to the oracle bit for bit: the noise the device drew is dumped (spk_philox_noise) and fed to the CPU oracle, whose tokens
@@ -2716,7 +2717,7 @@ def test_f15_bench_job_tokens_vs_fixture(golden_dir, dev):
 def test_bench_line_job_full_size_vs_oracle(dev, ops):
     """The bench line's OWN job -- B = 256 x 100 reverse steps, Philox noise, one hipGraph replay, dense and elimination + lists --
     against the CPU oracle on the dumped noise: all 12 544 tokens (the other timed-form tests stop at
-    B = 8 x 100 and B = 256 x 10).  Minutes of host work: SPKDIFF_RUN_SLOW=1, once per round through gpurun
+    B = 8 x 100 and B = 256 x 6).  Minutes of host work: SPKDIFF_RUN_SLOW=1, once per round through gpurun
     (tools/full_size_oracle.sh; log under profiles/).
 
     At this size -- 2.4e10 neuron-steps -- the oracle's own arithmetic shows: it convolves with oneDNN in fp32 (an accumulation
@@ -2855,13 +2856,13 @@ def test_sampler_trajectory_8x8_vs_live_oracle(dev, steps):
     from snn_model.vq_diffusion import AbsorbingDiffusion
     den, sd = build_den(synth.CIFAR, dev)
     bad = {}
+    torch.manual_seed(99 + steps)
+    want = ref.absorbing_sample(sd, 4, 128, 1.0, steps, 8, 16)           # (one oracle run: both forms draw the same host noise)
     for name, skip in (("dense", False), ("elim", True)):
         ab = AbsorbingDiffusion(den, mask_id=128, latent_shape=(8, 8))
         ab.n_samples, ab.noise_source, ab.skip_untouched = 4, 'host', skip
         torch.manual_seed(99 + steps)
         tok = ab.sample(temp=1.0, sample_steps=steps).cpu()
-        torch.manual_seed(99 + steps)
-        want = ref.absorbing_sample(sd, 4, 128, 1.0, steps, 8, 16)
         bad[name] = int((tok != want).sum())
     print(f"8x8 trajectory, {steps} steps, B=4: token mismatches {bad} of {want.numel()}")
     parity(f"trajectory_8x8_{steps}_steps_vs_live_oracle", token_mismatches=bad, tokens=int(want.numel()))
@@ -2895,7 +2896,7 @@ def test_sample_does_not_depend_on_how_the_batch_is_split(dev, ops):
     from snn_model.vq_diffusion import AbsorbingDiffusion
     den, sd = build_den(synth.MNIST, dev)
     model, _ = build_vae(synth.MNIST, dev)
-    B, steps, seed = 32, 30, 2024
+    B, steps, seed = 32, 20, 2024
 
     def run(parts, skip, layout='global'):
         toks = []
