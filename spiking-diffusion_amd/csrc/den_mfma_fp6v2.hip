@@ -109,7 +109,7 @@ struct V2Args {
 #ifndef SPK_V2_DBG
 #define SPK_V2_DBG 0            // experiments only: 1 = no steady-state DMA, 4 = no epilogue (results are wrong), 32 = zero
                                 // certification margin (nothing flagged: shows what the exact recomputation repairs),
-                                // 64 = the tail launch leaves the flag bitmap alone (flagged neurons can be counted),
+                                // 64 = the tail launch leaves the flag bitmap alone (flagged neurons can be counted), 512 = no chunk barrier in the K loop,
                                 // 128 = every workgroup stamps {s_memtime, s_memrealtime} around its item loop into the id
                                 // list (shader clock under this kernel's own load = d memtime / d memrealtime * 100 MHz)
 #endif
@@ -586,6 +586,8 @@ __device__ __forceinline__ void fp6v2_body(const V2Args& a, const int g, const i
             if constexpr (NBUF == 3 && !FIRST) {
               static_assert(NPA + NPW <= 15, "vmcnt immediate");
               asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NPA + NPW) : "memory");     // (this chunk's pieces may still fly)
+            } else if constexpr (SPK_V2_DBG & 512) {            // (timing only, results wrong: no chunk barrier -- what does it cost?)
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
               asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             }
