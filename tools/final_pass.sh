@@ -3,7 +3,7 @@
 # (--steps 20 --warmup 5: the job tests/golden/f15_bench_job_tokens.npz holds), the training line
 R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
 cd $R
-TAG=${1:-r5}
+TAG=${1:-r6}
 O=gpurun_out/${TAG}_final; rm -rf $O; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q -x > $O/gputest.log 2>&1
 grep -v PARITY_REPORT $O/gputest.log | tail -4 | cut -c1-300

@@ -5,7 +5,7 @@
 # step tail.  Each --pmc pass is its own run, never combined with a trace flag.  Outputs under gpurun_out/<tag>prof/;
 # tools/refresh_profiles.py <tag> copies them into profiles/ and derives the JSON summaries.
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r5}
+TAG=${1:-r6}
 O=$R/gpurun_out/${TAG}prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -36,3 +36,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/tail_sq -- python $R/tools/tail_time.py --child > $O/tail_sq.log 2>&1
 ls -R $O | grep -c csv
+# round 6: R/main.py's own call shape (B = 16, 49 steps + module-API decode)
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_mainpy -- python $R/bench.py --workload-main-py-shape --steps 20 --no-cpu-baseline > $O/bench_mainpy_under_prof.json 2> $O/bench_mainpy_under_prof.err

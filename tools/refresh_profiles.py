@@ -5,7 +5,7 @@ FETCH_SIZE doubled, WRITE_SIZE as is; KB = 1024 B; each entry carries the sha256
 the commit) and <tag>_conv4_fp6v2_sq_summary.json (matrix-pipe / LDS utilisation)."""
 import collections, csv, glob, hashlib, json, os, shutil, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r5"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r6"
 P = os.path.join(R, "gpurun_out", TAG + "prof")
 O = os.path.join(R, "profiles")
 
@@ -32,13 +32,15 @@ shutil.copy(newest("trace/runc/*_domain_stats.csv"), os.path.join(O, TAG + "_ben
 shutil.copy(os.path.join(P, "bench_under_prof.json"), os.path.join(O, TAG + "_bench_under_rocprof.json"))
 for src, dst in (("trace_headline/runc/*_kernel_stats.csv", TAG + "_bench_headline_kernel_stats.csv"),
                  ("trace_encdec/runc/*_kernel_stats.csv", TAG + "_encdec_kernel_stats.csv"),
-                 ("trace_lists/runc/*_kernel_stats.csv", TAG + "_lists_kernel_stats.csv")):
+                 ("trace_lists/runc/*_kernel_stats.csv", TAG + "_lists_kernel_stats.csv"),
+                 ("trace_mainpy/runc/*_kernel_stats.csv", TAG + "_main_py_shape_kernel_stats.csv")):
     try:
         shutil.copy(newest(src), os.path.join(O, dst))
     except IndexError:
         pass
 for src, dst in (("bench_headline_under_prof.json", TAG + "_bench_headline_under_rocprof.json"),
-                 ("bench_encdec_under_prof.json", TAG + "_encdec_under_rocprof.json"), ("listed_time.log", TAG + "_lists_listed_time.log")):
+                 ("bench_encdec_under_prof.json", TAG + "_encdec_under_rocprof.json"), ("listed_time.log", TAG + "_lists_listed_time.log"),
+                 ("bench_mainpy_under_prof.json", TAG + "_main_py_shape_under_rocprof.json")):
     if os.path.exists(os.path.join(P, src)):
         shutil.copy(os.path.join(P, src), os.path.join(O, dst))
 names = {"v2_FETCH_SIZE": TAG + "_conv4_fp6v2_pmc_fetch_size.csv", "v2_WRITE_SIZE": TAG + "_conv4_fp6v2_pmc_write_size.csv",
