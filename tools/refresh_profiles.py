@@ -95,10 +95,10 @@ for k in t:
         ns = 1024 * 784 * 32 * 16
         t[k]["valu_insts_per_neuron_step"] = vq.get("SQ_INSTS_VALU", (0.0, 0))[0] * 64.0 / ns
 entry("step_tail_kernel<7, 7> (conv6 on counts + token update + next conv1, B=256)", TAG + "_step_tail_pmc_fetch_size.csv",
-      TAG + "_step_tail_pmc_write_size.csv", ["step_tail_kernel<7, 7>"], "step_tail.hip",
+      TAG + "_step_tail_pmc_write_size.csv", ["step_tail_kernel<7, 7"], "step_tail.hip",
       {"algorithmic_bytes_per_launch": 256 * 49 * 32 * 10 + 8 * 10 * 18432 + 256 * 49 * (16 * 16 * 2 + 64) + 256 * 49 * 9,
        "note": "algorithmic = count records in + packed conv6 weights once + next conv1 spikes and counts out + token state",
-       "sq_counters_median": {c: v[0] for c, v in med(os.path.join(O, TAG + "_step_tail_pmc_sq.csv"), "step_tail_kernel<7, 7>").items()}})
+       "sq_counters_median": {c: v[0] for c, v in med(os.path.join(O, TAG + "_step_tail_pmc_sq.csv"), "step_tail_kernel<7, 7").items()}})
 json.dump(t, open(os.path.join(O, TAG + "_traffic.json"), "w"), indent=1)
 
 MAIN = "conv3x3_fp6v2_kernel"
