@@ -150,12 +150,17 @@ __global__ __launch_bounds__(512, 1) void step_tail_kernel(TailArgs a) {
     if (g >= ng) break;
     const int co_e = g * 16 + (col_e & 15);
     const double sc_e = a.scale[co_e], bT_e = a.bias[co_e] * (double)a.T;
+    // (KG > 1: everything the 90 unrolled steps derive from these is invariant over the groups -- hoisted out of this loop it was 120
+    //  spilled registers; opaque copies keep the per-step address arithmetic where it is used)
+    int rot_g = rot, ab_g[2] = {a_base[0], a_base[1]}, y_g[2] = {y_[0], y_[1]}, x_g[2] = {x_[0], x_[1]};
+    if constexpr (KG > 1) asm volatile("" : "+s"(rot_g), "+v"(ab_g[0]), "+v"(ab_g[1]), "+v"(y_g[0]), "+v"(y_g[1]), "+v"(x_g[0]), "+v"(x_g[1]));
+    auto chunk_g = [&](int i) -> int { const int c = i / 9 + rot_g; return c >= TNCH ? c - TNCH : c; };
     if (gi > 0) {                                   // (the first group's stream was started ahead of the count records)
       wg = a.wq + (long long)g * TNCH * TW_CHUNK + boff;
 #pragma unroll
       for (int i = 0; i < D; ++i) {
-        bq[i][0] = *reinterpret_cast<const v4i*>(wg + chunk_of(i) * TW_CHUNK + ((i % 9) * 2 + 0) * 32 * TCK);
-        bq[i][1] = *reinterpret_cast<const v4i*>(wg + chunk_of(i) * TW_CHUNK + ((i % 9) * 2 + 1) * 32 * TCK);
+        bq[i][0] = *reinterpret_cast<const v4i*>(wg + chunk_g(i) * TW_CHUNK + ((i % 9) * 2 + 0) * 32 * TCK);
+        bq[i][1] = *reinterpret_cast<const v4i*>(wg + chunk_g(i) * TW_CHUNK + ((i % 9) * 2 + 1) * 32 * TCK);
       }
     }
     v16i acc[2][2];
@@ -167,19 +172,19 @@ __global__ __launch_bounds__(512, 1) void step_tail_kernel(TailArgs a) {
         for (int r = 0; r < 16; ++r) acc[rt][j][r] = 0;
 #pragma unroll
     for (int i = 0; i < ((SPK_TAIL_DBG & 1) ? D : NIT); ++i) {
-      const int c = chunk_of(i), tap = i % 9;
+      const int c = chunk_g(i), tap = i % 9;
       const int dy = tap / 3 - 1, dx = tap % 3 - 1;
       const v4i b0 = bq[i % D][0], b1 = bq[i % D][1];
       if (i + D < NIT) {
-        const int c2 = chunk_of(i + D), tap2 = (i + D) % 9;
+        const int c2 = chunk_g(i + D), tap2 = (i + D) % 9;
         bq[i % D][0] = *reinterpret_cast<const v4i*>(wg + c2 * TW_CHUNK + (tap2 * 2 + 0) * 32 * TCK);
         bq[i % D][1] = *reinterpret_cast<const v4i*>(wg + c2 * TW_CHUNK + (tap2 * 2 + 1) * 32 * TCK);
       }
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        const int yy = y_[rt] + dy, xx = x_[rt] + dx;
+        const int yy = y_g[rt] + dy, xx = x_g[rt] + dx;
         const bool ok = rv[rt] && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const v4i av = s_a[c * AV + (ok ? a_base[rt] + (dy * W + dx) * 2 : HW * 2)];
+        const v4i av = s_a[c * AV + (ok ? ab_g[rt] + (dy * W + dx) * 2 : HW * 2)];
         acc[rt][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b0, acc[rt][0], 0, 0, 0);
         acc[rt][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b1, acc[rt][1], 0, 0, 0);
       }
