@@ -575,6 +575,72 @@ inline int grid_for(long long work_items) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+// RAW output of a spike-input layer with few output channels, one thread per (output position, STEP): the module-API form of the
+// decoder's read-out layer (R/main.py:397: `pred = model.decoder(quantized)` returns the per-step convolution [T,B,C,28,28], memout and
+// tanh are main.py's own calls).  conv_fused_kernel keeps all T accumulators of an output in one thread: B x 784 x C threads -- 49
+// workgroups at R/main.py's B = 16, 228 us.  Here T x as many threads each walk the taps once; a tap is one 16-byte read per 16 input
+// channels of the (position, step) record, spikes select weights into an fp64 sum in the same (ky, kx, ci) order (adding the 0.0 of a
+// silent channel changes no fp64 sum: the same values bit for bit).  Plain PTC input [B][H][W][T][Cin], Cin % 16 == 0, Cout <= 4.
+template <bool TRANSPOSED, int CO>
+__global__ __launch_bounds__(256) void conv_raw_steps_kernel(FusedArgs a) {
+  const int Cin = a.C0, T = a.T;
+  const long long total = (long long)a.B * a.Ho * a.Wo * T;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    long long r = i / T;
+    const int ox = (int)(r % a.Wo); r /= a.Wo;
+    const int oy = (int)(r % a.Ho);
+    const int b = (int)(r / a.Ho);
+    double acc[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) acc[co] = a.bias ? (double)a.bias[co] : 0.0;
+    for (int ky = 0; ky < a.k; ++ky) {
+      int iy;
+      if (TRANSPOSED) {
+        const int ty = oy + a.pad - ky;
+        if (ty < 0 || ty % a.stride) continue;
+        iy = ty / a.stride;
+      } else {
+        iy = oy * a.stride - a.pad + ky;
+      }
+      if (iy < 0 || iy >= a.H) continue;
+      for (int kx = 0; kx < a.k; ++kx) {
+        int ix;
+        if (TRANSPOSED) {
+          const int tx = ox + a.pad - kx;
+          if (tx < 0 || tx % a.stride) continue;
+          ix = tx / a.stride;
+        } else {
+          ix = ox * a.stride - a.pad + kx;
+        }
+        if (ix < 0 || ix >= a.W) continue;
+        const float* wp = a.wt + (long long)(ky * a.k + kx) * Cin * CO;
+        const uint8_t* sp = reinterpret_cast<const uint8_t*>(a.in0) + ((((long long)b * a.H + iy) * a.W + ix) * T + t) * Cin;
+        for (int c16 = 0; c16 < Cin; c16 += 16) {
+          const uint4 s16 = *reinterpret_cast<const uint4*>(sp + c16);
+          const unsigned w4[4] = {s16.x, s16.y, s16.z, s16.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (w4[q] == 0u) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if ((w4[q] >> (8 * e)) & 0xffu) {
+                const int ci = c16 + 4 * q + e;
+#pragma unroll
+                for (int co = 0; co < CO; ++co) acc[co] += (double)wp[(long long)ci * CO + co];
+              }
+            }
+          }
+        }
+      }
+    }
+    const long long plane = (long long)a.Ho * a.Wo;
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+      a.out_f32[(((long long)t * a.B + b) * CO + co) * plane + (long long)oy * a.Wo + ox] = (float)acc[co];
+  }
+}
+
 template <int INKIND, bool TR>
 int launch_mode(const FusedArgs& a, int mode, hipStream_t stream) {
   const long long total = (long long)a.B * a.Ho * a.Wo * a.Cout;
@@ -696,6 +762,17 @@ extern "C" int spk_conv_fused_fwd(const void* in0, const uint8_t* in1, int C0, i
     else if (k == 3 && C0 == 3) hipLaunchKernelGGL((tinv_lif_kernel<3, 3>), tg, tb, 0, stream, t);       // ... on RGB
     else if (k == 3 && C0 == 2) hipLaunchKernelGGL((tinv_lif_kernel<3, 2>), tg, tb, 0, stream, t);       // denoiser conv1
     else hipLaunchKernelGGL((tinv_lif_kernel<0, 0>), tg, tb, 0, stream, t);                               // (spike generator: 1x1, 16 channels -- measured faster with the weights left in L1)
+    SPK_LAUNCH_CHECK();
+    return SPK_OK;
+  }
+  if (in_kind == SPK_IN_PTC && mode == SPK_MODE_RAW && Cout <= 4 && Cout != 2 && C1 == 0 && chunk0 == C0 && (C0 % 16) == 0 && !n_dyn_or_null) {
+    // few output channels, per-step output (the decoder's read-out layer through the module API): one thread per (position, step)
+    const long long total = (long long)B * a.Ho * a.Wo * T;
+    const dim3 g(grid_for(total)), blk(256);
+#define SPK_RAW_STEPS(TR_, CO_) hipLaunchKernelGGL((conv_raw_steps_kernel<TR_, CO_>), g, blk, 0, stream, a)
+    if (transposed) { if (Cout == 1) SPK_RAW_STEPS(true, 1); else if (Cout == 3) SPK_RAW_STEPS(true, 3); else SPK_RAW_STEPS(true, 4); }
+    else            { if (Cout == 1) SPK_RAW_STEPS(false, 1); else if (Cout == 3) SPK_RAW_STEPS(false, 3); else SPK_RAW_STEPS(false, 4); }
+#undef SPK_RAW_STEPS
     SPK_LAUNCH_CHECK();
     return SPK_OK;
   }

@@ -871,6 +871,34 @@ def test_vae_fp6_kernel_equals_the_int8_gather_kernel(dev, ops, layer, B, hw, Co
     parity(f"vae_fp6_{layer}_vs_int8_B{B}_{hw}x{hw}_c{Cout}", values=total, mismatches=mism)
 
 
+# ------------------------------------------------------------------------------------------------- round 6: the module-API read-out layer
+@pytest.mark.parametrize("B,H,Cin,Cout,transposed,T", [(16, 28, 32, 1, True, 16), (3, 32, 32, 3, True, 16), (5, 9, 16, 4, False, 16),
+                                                       (2, 11, 48, 1, False, 4)])
+def test_raw_output_of_few_channel_spike_layers_step_parallel_kernel(dev, ops, B, H, Cin, Cout, transposed, T):
+    """`pred = model.decoder(quantized)` (R/main.py:397) returns the read-out layer's per-step convolution [T,B,C,28,28]; memout and tanh
+    are main.py's own calls.  For few output channels that layer runs conv_raw_steps_kernel (one thread per position AND step) instead of the
+    generic one-thread-per-output kernel: its values must equal the generic kernel's on the same spikes given as fp32 [T,B,C,H,W] (same fp64
+    sums in the same order) bit for bit, and the fp64 convolution to fp32 round-off."""
+    import torch.nn.functional as F
+    from spkdiff.ops import IN_PTC, IN_SEQ, MODE_RAW
+    g = torch.Generator().manual_seed(90 + B + Cout)
+    spikes = (torch.rand(T, B, Cin, H, H, generator=g) < 0.15).float()
+    w = (torch.rand((Cin, Cout, 3, 3) if transposed else (Cout, Cin, 3, 3), generator=g) - 0.5) * 0.4
+    bias = torch.rand(Cout, generator=g) - 0.5
+    wp = ops.pack_conv_weight(w.to(dev), transposed)
+    geo = dict(k=3, stride=1, pad=1, transposed=transposed)
+    sd = spikes.to(dev)
+    fast = ops.conv_fused(ops.spikes_to_ptc(sd), wp, bias.to(dev), in_kind=IN_PTC, T=T, mode=MODE_RAW, want_f32=True, **geo)["f32"]
+    gen = ops.conv_fused(sd, wp, bias.to(dev), in_kind=IN_SEQ, T=T, mode=MODE_RAW, want_f32=True, **geo)["f32"]
+    conv = (lambda x: F.conv_transpose2d(x, w.double(), bias.double(), stride=1, padding=1)) if transposed else \
+           (lambda x: F.conv2d(x, w.double(), bias.double(), stride=1, padding=1))
+    want = torch.stack([conv(spikes[t].double()) for t in range(T)])
+    err = float((fast.cpu().double() - want).abs().max())
+    parity(f"raw_steps_kernel_B{B}_{H}x{H}_c{Cout}", values=int(fast.numel()), mismatches_vs_generic=int((fast != gen).sum()), max_abs_err_vs_fp64=err)
+    assert fast.shape == (T, B, Cout, H, H) and torch.equal(fast, gen)
+    assert err <= 2e-6 * (1 + float(want.abs().max()))
+
+
 # ------------------------------------------------------------------------------------------------- round 6: small batches
 @pytest.mark.parametrize("B", [1, 5, 16, 31])
 def test_fp6v2_small_batch_split_bit_equal_to_whole_image_items(dev, ops, B):
