@@ -12,3 +12,6 @@ python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_defaul
 cut -c1-400 $O/bench_default.json
 python bench.py --workload train --steps 200 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_train.json
 cut -c1-250 $O/bench_train.json
+python bench.py --workload train_vqvae --steps 200 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_train_vqvae.json
+cut -c1-250 $O/bench_train_vqvae.json
+python tools/small_batch_time.py > $O/small_batch.txt 2>&1; cat $O/small_batch.txt
