@@ -11,6 +11,7 @@ run python tools/modes_stress.py 30 256
 run python tools/r6_stress.py 120
 # the measured-and-dropped launch forms: only in the `make variants` library (tools/variants_check.sh builds it)
 V=$R/spiking-diffusion_amd/spkdiff/variants/libspkdiff_variants.so
+make -C $R/spiking-diffusion_amd/csrc -j8 variants >/dev/null 2>&1
 if [ -f "$V" ]; then
   SPKDIFF_LIB=$V SPKDIFF_V2_LAG=1 run python tools/fp6v2_stress.py 40 32
   SPKDIFF_LIB=$V SPKDIFF_V2_WAVES=12 run python tools/fp6v2_stress.py 40 32
