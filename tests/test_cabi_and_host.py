@@ -261,12 +261,31 @@ def test_header_is_plain_c(tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("no gcc")
     src = tmp_path / "inc.c"
-    src.write_text('#include "spkdiff.h"\nint main(void) { return spk_conv_out_size(7, 3, 1, 1, 0, 0) == 7 ? 0 : 1; }\n')
+    # (spkdiff_variants.h: the two option entry points of the separate `make variants` library -- plain C as well)
+    src.write_text('#include "spkdiff.h"\n#include "spkdiff_variants.h"\n'
+                   'int main(void) { return spk_conv_out_size(7, 3, 1, 1, 0, 0) == 7 ? 0 : 1; }\n')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
 
+
+
+def test_shipped_library_has_no_settable_state_and_variant_sources_stay_out_of_it():
+    """the measured-and-dropped launch forms and the process-wide options are NOT in libspkdiff.so.  The forms' source is
+    an include file only a -DSPK_V2_VARIANTS=1 build pulls in; the default Makefile target compiles csrc/*.hip and nothing under
+    csrc/variants/; the variants header declares exactly the two option entry points."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "spiking-diffusion_amd", "csrc")
+    assert os.path.exists(os.path.join(csrc, "variants", "fp6v2_forms.inc"))
+    assert not [f for f in os.listdir(os.path.join(csrc, "variants")) if f.endswith(".hip")]
+    main = open(os.path.join(csrc, "den_mfma_fp6v2.hip")).read()
+    assert '#if SPK_V2_VARIANTS\n#include "variants/fp6v2_forms.inc"' in main
+    assert "duo_kernel" not in main.split('#include "variants/fp6v2_forms.inc"')[0]
+    assert len(main.splitlines()) < 2000
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "spkdiff_variants.h")).read(), flags=re.S)
+    assert sorted(set(re.findall(r"\b(spk_[a-z0-9_]+)\s*\(", txt))) == ["spk_get_option", "spk_set_option"]
+    assert "spk_set_option" not in re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "spkdiff.h")).read(), flags=re.S)
 
 
 def test_synth_cache_takes_over_a_stale_lock(tmp_path, monkeypatch):
