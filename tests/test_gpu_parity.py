@@ -3162,6 +3162,78 @@ def test_step_tail_equals_the_three_launches_it_replaces(dev, ops, cfg, L, B):
             assert pre is None
 
 
+@pytest.mark.parametrize("K,L", [(1, 7), (17, 7), (129, 8), (385, 7), (512, 8)])
+def test_step_tail_for_other_codebook_sizes_equals_the_three_launches(dev, ops, K, L):
+    """Round 6: spk_den_step_tail takes 1 <= K <= 512 classes (one to four 16-channel groups per wave; conv6's output channels zero-padded
+    to a multiple of 16 in the packed weights; classes >= K masked as spk_psample_step masks them; R/main.py:58 --codebook_size).  Edge sizes
+    -- one class, one class past a group, one past 128 / 384 (the next channel-group count per wave), the maximum -- against counts-conv6 +
+    spk_psample_step + the first layer's launch: logits, tokens, unmasked, the next step's conv1 spikes and counts; Philox and injected noise."""
+    from snn_model.vq_diffusion import DummyModel, functional
+    torch.manual_seed(K)
+    den = DummyModel(1, K).to(dev)
+    functional.set_step_mode(net=den, step_mode='m')
+    with torch.no_grad():
+        den.conv6[0].weight.mul_(20.0)                      # (random init: widen the logits so that the classes compete)
+    den.eval()
+    assert den.tail_fusable(L, L) and den.impl_for(L, L) == 'mfma-fp6v2'
+    g = torch.Generator().manual_seed(100 + K)
+    B, HW = 5, L * L
+    bad = 0
+    for trial, t in enumerate((41, 2, 1)):
+        x0 = torch.randint(0, K, (B, 1, L, L), generator=g)
+        un0 = torch.rand(B, 1, L, L, generator=g) < 0.5
+        x0[~un0] = K
+        x0, un0 = x0.to(dev), un0.to(dev)
+        x5, cnt5, x1, cnt1, which, impl, collapse = den._trunk(ops.den_build_input(x0, t), False)
+        conv6, packed6 = den._conv6_params()
+        logits = ops.den_conv3x3_counts(cnt5, packed6, K, 16, cnt1=cnt1)
+        assert logits.shape == (B, K, L, L)
+        u = q = None
+        if trial == 1:
+            u = torch.rand(B * HW, generator=g).to(dev)
+            q = torch.empty(B * HW, K).exponential_(1, generator=g).to(dev)
+        xa, una = x0.clone(), un0.clone()
+        nxt = torch.empty((B, 2, L, L), dtype=torch.float32, device=dev)
+        ops.psample_step(logits, xa, una, t, 0.9, u, q, seed=99, offset=777 * t, next_input=nxt if t > 1 else None)
+        xb, unb = x0.clone(), un0.clone()
+        conv1, bn1 = den.conv1[0], den.conv1[1]
+        a1, b1 = bn1.affine_terms()
+        c1 = (conv1._spk_params.get(conv1), conv1.bias.detach(), a1, b1) if t > 1 else None
+        pre, lg = ops.den_step_tail(cnt5, cnt1, packed6, xb, unb, t, 0.9, T=16, K=K, u=u, q=q, seed=99, offset=777 * t, conv1=c1,
+                                    want_logits=True)
+        bad += int(not torch.equal(lg, logits)) + int(not torch.equal(xa, xb)) + int(not torch.equal(una, unb))
+        assert int(xb.max()) <= K and int(xb[unb].max()) < K
+        if t > 1:
+            r1 = den.conv1.run(nxt, ops.IN_TINV, final='ptc', T=16, stateful=False, chunk_out=ops.CHUNK_S32, want_counts=True)
+            bad += int(not torch.equal(pre[0], r1['ptc'])) + int(not torch.equal(pre[1], r1['cnt']))
+        else:
+            assert pre is None and bool(unb.all())
+    parity(f"step_tail_K{K}_{L}x{L}", differing_outputs=bad)
+    assert bad == 0
+
+
+@pytest.mark.parametrize("B", [1, 6])
+def test_fp6v2_small_batch_split_with_no_active_image(dev, ops, B):
+    """The small-batch split under a device-side image count of ZERO (a reverse step in which no image of a small batch changes): nothing
+    is computed, the launch terminates, the workspace comes back clean, and the next call on it is right."""
+    g = torch.Generator().manual_seed(8200 + B)
+    Cout, Cin = 256, 128
+    w = ((torch.rand(Cout, Cin, 3, 3, generator=g) - 0.5) * 0.05).to(dev)
+    bias = ((torch.rand(Cout, generator=g) - 0.5) * 0.2).to(dev)
+    a = ((torch.rand(Cout, generator=g) - 0.3) * 8.0).to(dev)
+    b = ((torch.rand(Cout, generator=g) - 0.4) * 1.5).to(dev)
+    sd = (torch.rand(16, B, Cin, 7, 7, generator=g) < 0.08).float().to(dev)
+    pk, xs = ops.den_pack_weight_fp6v2(w, bias), ops.spikes_to_s32(sd)
+    want, cw = ops.den_conv3x3_mfma_fp6v2(xs, pk, Cout, bn_a=a, bn_b=b, want_counts=True)
+    active = torch.arange(B, dtype=torch.int32, device=dev)
+    with ops.active_set(active, torch.zeros(2, dtype=torch.int32, device=dev)):
+        ops.den_conv3x3_mfma_fp6v2(xs, pk, Cout, bn_a=a, bn_b=b, want_counts=True)
+    torch.cuda.synchronize()
+    assert all(flag_ws_clean(v) for k, v in ops._FLAG_DEFAULT.items() if k[0] == "den")
+    got, cg = ops.den_conv3x3_mfma_fp6v2(xs, pk, Cout, bn_a=a, bn_b=b, want_counts=True)
+    assert torch.equal(got, want) and torch.equal(cg, cw)
+
+
 @pytest.mark.parametrize("cfgname,L", [("mnist", 7), ("cifar", 8)])
 def test_sampler_with_and_without_the_fused_step_tail(dev, cfgname, L):
     """Dense sampling with the fused tail launch == with the three separate launches: graph replay, eager launches, host noise."""
