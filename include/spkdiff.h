@@ -30,10 +30,11 @@ extern "C" {
 
 typedef struct ihipStream_t* spk_stream_t; /* == hipStream_t */
 
-#define SPK_VERSION 104 /* 0.1.4 -- bumped whenever an exported signature changes or entry points are added (round 4 inserted `int K`
+#define SPK_VERSION 105 /* 0.1.5 -- bumped whenever an exported signature changes or entry points are added (round 4 inserted `int K`
                            * before the stream of spk_select_active / spk_select_needed: 101; round 5 added the VectorQuantizer's
                            * training branch and the training convolutions: 102, the token-table spike generator: 103; round 6: `int flag_cap` (and `int form` for spk_den_conv3x3_mfma_fp6v2) in front of the
-                           * stream of the four certified-kernel entry points, spk_set_option / spk_get_option left the shipped library: 104); spkdiff/_lib.py refuses a library whose
+                           * stream of the four certified-kernel entry points, spk_set_option / spk_get_option left the shipped library: 104;
+                           * `active` / `n_active` of spk_den_step_tail: 105); spkdiff/_lib.py refuses a library whose
                            * spk_version() differs from the signatures it declares */
 
 /* fused-kernel epilogue modes (spk_conv_fused_fwd) */
@@ -559,14 +560,18 @@ int spk_psample_step(const float* logits_bkhw, long long* x_t_inout, uint8_t* un
  * else: SPK_ERR_UNSUPPORTED (use the three launches).
  * The fused first layer is the time-invariant-input form with the module defaults baked in: T = 16 steps and
  * LIFNode(tau = 2, v_threshold = 1, v_reset = 0) (R/snn_model/vq_diffusion.py:161-165); with x1_s32_out set any other T is
- * SPK_ERR_UNSUPPORTED (conv6 alone takes T <= 127). */
+ * SPK_ERR_UNSUPPORTED (conv6 alone takes T <= 127).
+ * active / n_active (round 6, both or neither): the active-set form of the untouched-image elimination (spk_select_active) -- workgroup s
+ * serves slot s of the list: cnt5 / cnt1 / logits_out are indexed by slot (what the active-set denoiser launches produced), x_t / unmasked /
+ * the noise by image active[s], so the draws are those of the dense form; x1_s32_out must be NULL there (the next step's first layer is
+ * the next step's active set's). */
 int spk_den_step_tail(const uint8_t* cnt5, int nch5, const uint8_t* cnt1, int nch1, const int8_t* wq, const double* scale,
                       const double* bias_d, float* logits_out_or_null, long long* x_t_inout, uint8_t* unmasked_inout, int t,
                       float temp, const float* u_or_null, const float* q_or_null, unsigned long long philox_seed,
                       unsigned long long philox_offset, const unsigned long long* philox_state_or_null,
                       const float* conv1_w_packed_or_null, const float* conv1_bias_or_null, const float* bn1_a,
                       const float* bn1_b, uint8_t* x1_s32_out_or_null, uint8_t* cnt1_out_or_null, int T, int B, int H, int W,
-                      int K, spk_stream_t stream);
+                      int K, const int* active_or_null, const int* n_active_or_null, spk_stream_t stream);
 /* q_sample of the diffusion training step, R/snn_model/vq_diffusion.py:61-75: mask = u < t[b] / num_timesteps (fp32, as there);
  * x_t = mask ? mask_id : x_0;  x_0_ignore = mask ? x_0 : -1 (the loss's ignore index).  x0 / u / outputs fp32 [B*HW], t int64 [B],
  * mask_out optional u8.  u is the caller's draw (torch.rand_like in the reference's order). */

@@ -50,6 +50,9 @@ struct TailArgs {
   float t_next;
   int B, T;
   int K, ng;                                      // classes; 16-channel groups of the padded logits (ceil(K / 16))
+  // active-set form (the untouched-image elimination, spk_select_active): workgroup = SLOT s of the list; counts / logits are indexed by
+  // slot (what the active-set denoiser launches produced), tokens / unmasked / noise by IMAGE active[s]: the draws of the dense form
+  const int* active; const int* n_active;
 };
 
 // KG = channel groups per wave (1: K <= 128, the reference's default; 2 .. 4: K <= 256 / 384 / 512)
@@ -68,7 +71,13 @@ __global__ __launch_bounds__(512, 1) void step_tail_kernel(TailArgs a) {
   __shared__ float s_th[16];
   __shared__ unsigned s_pat[18];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x;
+  const int b = blockIdx.x;                       // slot: index of the count records and of the logits
+  int bi = b;                                     // image: index of tokens, unmasked and noise
+  if (a.active) {
+    const int n = *a.n_active < a.B ? *a.n_active : a.B;
+    if (b >= n) return;                           // (uniform over the workgroup)
+    bi = a.active[b];
+  }
   const int K = a.K, ng = a.ng;
   const int row = lane & 31, half = lane >> 5;
 
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(512, 1) void step_tail_kernel(TailArgs a) {
   if (a.philox_state) { seed = a.philox_state[0]; offset += a.philox_state[1]; }
   const float inv_t = 1.0f / (float)a.t;
   if (tid < HW) {
-    const long long pi = (long long)b * HW + tid;
+    const long long pi = (long long)bi * HW + tid;
     const uint8_t um = a.unmasked[pi];
     const long long tk = a.x_t[pi];
     float u;
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(512, 1) void step_tail_kernel(TailArgs a) {
 
   // ---- p_sample: wave w takes positions w, w + 8, ...; only positions that change at this step consume a sample (:140)
   for (int p = wave; p < ((SPK_TAIL_DBG & 2) ? 0 : HW); p += 8) {
-    const long long pi = (long long)b * HW + p;
+    const long long pi = (long long)bi * HW + p;
     if (!s_chg[p]) continue;                                            // (wave-uniform; s_tok[p] holds the token it keeps)
     // (classes k >= K -- the zero-padded output channels of conv6 and the lanes beyond them -- are masked exactly as
     //  psample_kernel masks them: -inf logits, zero terms)
@@ -328,10 +337,13 @@ extern "C" int spk_den_step_tail(const uint8_t* cnt5, int nch5, const uint8_t* c
                                  const unsigned long long* philox_state_or_null, const float* conv1_w_packed_or_null,
                                  const float* conv1_bias_or_null, const float* bn1_a, const float* bn1_b,
                                  uint8_t* x1_s32_out_or_null, uint8_t* cnt1_out_or_null, int T, int B, int H, int W, int K,
-                                 hipStream_t stream) {
+                                 const int* active_or_null, const int* n_active_or_null, hipStream_t stream) {
   if (!cnt5 || !cnt1 || !wq || !scale || !bias_d || !x_t_inout || !unmasked_inout || t <= 0 || !(temp > 0.f) || B <= 0 || T <= 0)
     return SPK_ERR_ARG;
   if ((x1_s32_out_or_null == nullptr) != (cnt1_out_or_null == nullptr)) return SPK_ERR_ARG;
+  if ((active_or_null == nullptr) != (n_active_or_null == nullptr)) return SPK_ERR_ARG;
+  // (the next step's first layer belongs to the NEXT step's active set, which only spk_select_active after this update knows)
+  if (active_or_null && x1_s32_out_or_null) return SPK_ERR_UNSUPPORTED;
   if (x1_s32_out_or_null && (!conv1_w_packed_or_null || !bn1_a || !bn1_b)) return SPK_ERR_ARG;
   if (nch5 != 8 || nch1 != 2 || K < 1 || K > TK_MAX || T > 127 || !((H == 7 && W == 7) || (H == 8 && W == 8))) return SPK_ERR_UNSUPPORTED;
   // the fused first layer writes sixteen 16-byte step records per position and scans with the module-default LIF constants
@@ -344,6 +356,7 @@ extern "C" int spk_den_step_tail(const uint8_t* cnt5, int nch5, const uint8_t* c
   a.w1 = conv1_w_packed_or_null; a.b1 = conv1_bias_or_null; a.bn1_a = bn1_a; a.bn1_b = bn1_b;
   a.x1_out = x1_s32_out_or_null; a.cnt1_out = cnt1_out_or_null; a.t_next = (float)(t - 1);
   a.B = B; a.T = T;
+  a.active = active_or_null; a.n_active = n_active_or_null;
   a.K = K; a.ng = (K + 15) / 16;                    // wq / scale / bias_d hold ng * 16 channels (zero weights beyond K)
   const int kg = (a.ng + 7) / 8;
 #define SPK_TAIL_LAUNCH(H_, W_, KG_)                                                                                          \

@@ -113,6 +113,9 @@ class AbsorbingDiffusion(Sampler):
         # launch per step, per-class item division) costs more than the skipped positions save -- R/main.py's own n_samples = 16:
         # 7.04 ms per 49-step sample without lists, 7.75 with; B = 32: 8.9 / 8.25 (tools/small_batch_time.py, profiles/r6_small_batch.txt)
         self.list_min_batch = 24
+        # elimination forms: conv6 on the spike counts + the token update of the ACTIVE images as one launch per slot (spk_den_step_tail with
+        # the active list) instead of two (spk_den_conv3x3_counts_mfma, spk_psample_step).  Same tokens; False = the two launches.
+        self.step_tail_in_elimination = True
         self.list_radii = 3                 # layers below the logits that take lists (1: conv5 only ... 4: conv2..conv5;
                                             # conv2 needs nearly every position anyway: 3 measured fastest)
         # Derived weight forms (digit planes, folded BN terms, captured graphs) are keyed on (data_ptr, _version), which
@@ -214,6 +217,7 @@ class AbsorbingDiffusion(Sampler):
         act = None
         need = ops.NeedLists(b, int(self.list_radii), dev) if skip and self._list_ok(h, w, b) else None
         tail = (not skip) and dn.tail_fusable(h, w)                      # dense loop: the fused step tail (same tokens)
+        tail_act = skip and self.step_tail_in_elimination and dn.tail_fusable(h, w)
         pre1 = None
         for t in reversed(range(1, sample_steps + 1)):
             u = q = None
@@ -235,10 +239,18 @@ class AbsorbingDiffusion(Sampler):
                 if need is not None:
                     ops.select_needed(unmasked, t, act, need, u, seed, off, K=K)
             with ops.active_set(*(act if skip else (None, None)), need=need):
-                logits = dn.logits_from_tokens(x_t, t)                   # denoiser + reset_net (:128-129)
-                if noise is None and self.noise_source == 'host':
-                    q = torch.empty(b * h * w, K).exponential_(1).to(dev)    # multinomial's one-draw fast path (:138)
-                ops.psample_step(logits, x_t, unmasked, t, temp, u, q, seed, off)
+                if skip and tail_act:
+                    # elimination forms, round 6: conv6 on the counts + the token update as ONE launch per active slot (the step tail
+                    # without a next-step first layer: that belongs to the next step's active set)
+                    if noise is None and self.noise_source == 'host':
+                        q = torch.empty(b * h * w, K).exponential_(1).to(dev)
+                    _, logits = dn.sample_step(x_t, unmasked, t, temp, u, q, seed, off, want_next=False,
+                                               want_logits=record is not None)
+                else:
+                    logits = dn.logits_from_tokens(x_t, t)                   # denoiser + reset_net (:128-129)
+                    if noise is None and self.noise_source == 'host':
+                        q = torch.empty(b * h * w, K).exponential_(1).to(dev)    # multinomial's one-draw fast path (:138)
+                    ops.psample_step(logits, x_t, unmasked, t, temp, u, q, seed, off)
             if record is not None:
                 record.append((t, x_t.clone(), unmasked.clone(), logits.clone()))
         return x_t
@@ -333,7 +345,7 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
     skip = self._skip_ok(h, w)
     lists = skip and self._list_ok(h, w, b)
     key = (str(dev), b, h, w, K, temp, sample_steps, int(self.mask_id), skip, lists, int(self.list_radii),
-           bool(dn.use_step_tail), self.noise_layout, int(self.global_first), _weights_key(dn))
+           bool(dn.use_step_tail), bool(self.step_tail_in_elimination), self.noise_layout, int(self.global_first), _weights_key(dn))
     entry = self._graphs.get(key)
     if entry is None:
         if len(self._graphs) >= 2:                              # at most two live graphs per sampler (e.g. dense and
@@ -348,6 +360,7 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
         # dense form: the fused step tail where the architecture fits (conv6 + token update + the next step's first layer in
         # one launch), else every spk_psample_step also writes the next step's denoiser input (one launch less per step)
         tail = (not skip) and dn.tail_fusable(h, w)
+        tail_act = skip and self.step_tail_in_elimination and dn.tail_fusable(h, w)
         inp = None if (skip or tail) else torch.empty((b, 2, h, w), dtype=torch.float32, device=dev)
 
         def body():
@@ -367,9 +380,12 @@ def _sample_graphed(self, dev, b, h, w, K, temp, sample_steps, seed, base):
                 elif t == sample_steps:
                     ops.den_build_input(x_t, t, out=inp)
                 with ops.active_set(*(act if skip else (None, None)), need=need):
-                    logits = dn.logits_from_tokens(x_t, t, inp=inp)
-                    ops.psample_step(logits, x_t, unmasked, t, temp, None, None, 0, off, philox_state=state,
-                                     next_input=inp if t > 1 else None)
+                    if tail_act:
+                        dn.sample_step(x_t, unmasked, t, temp, None, None, 0, off, philox_state=state, want_next=False)
+                    else:
+                        logits = dn.logits_from_tokens(x_t, t, inp=inp)
+                        ops.psample_step(logits, x_t, unmasked, t, temp, None, None, 0, off, philox_state=state,
+                                         next_input=inp if t > 1 else None)
 
         # warm-up on a side stream (weight packing, BN terms, allocator pools, this graph's own flag workspaces), then capture
         flag_ws = {}

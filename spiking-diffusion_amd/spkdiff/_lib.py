@@ -130,7 +130,7 @@ _SIGS = {
     "spk_psample_step": (c_int, [P, P, P, c_int, c_float, P, P, c_ulonglong, c_ulonglong, P, P, c_int, c_int, c_int,
                                  P, P, P, P]),
     "spk_den_step_tail": (c_int, [P, c_int, P, c_int, P, P, P, P, P, P, c_int, c_float, P, P, c_ulonglong, c_ulonglong, P, P, P,
-                                  P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+                                  P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "spk_philox_noise": (c_int, [c_ulonglong, c_ulonglong, P, P, P, c_int, c_int, c_int, P]),
     "spk_checksum_multi": (c_int, [P, c_int, P, P]),
     "spk_clock_probe": (c_int, [P, c_int, c_int, P]),
@@ -181,7 +181,7 @@ def version() -> int:
 
 # The signatures declared above are those of include/spkdiff.h at this version.  A stale libspkdiff.so or an SPKDIFF_LIB A/B
 # variant built from another header would take arguments at the wrong positions (silently wrong results): refuse it here.
-EXPECTED_VERSION = 104
+EXPECTED_VERSION = 105
 if version() != EXPECTED_VERSION:
     raise ImportError(f"spkdiff: {LIB_PATH} reports C-ABI version {version()}, this binding declares version "
                       f"{EXPECTED_VERSION} (include/spkdiff.h SPK_VERSION). Rebuild the library: make -C "

@@ -1863,7 +1863,9 @@ def den_step_tail(cnt5, cnt1, packed6, x_t, unmasked, t, temp, *, T, K, u=None, 
     """The tail of one dense reverse step as one launch (spk_den_step_tail): conv6 on the spike counts + time mean, the token
     update of ``psample_step`` (x_t / unmasked in place, same noise arguments) and -- with ``conv1 = (w_packed [9,2,64], bias,
     bn_a, bn_b)`` -- the first denoiser layer of the next step.  Returns (x1 S32 [B,2,h,w,16,16], cnt1 u8 [B,2,h,w,32]) or None,
-    and the logits fp32 [B,K,h,w] when asked for."""
+    and the logits fp32 [B,K,h,w] when asked for.  Inside an ``active_set`` scope (the untouched-image elimination) cnt5 / cnt1 / logits
+    are per SLOT of the active list and x_t / unmasked / the noise per image; ``conv1`` must be None there (the next step's first layer
+    belongs to the next step's active set)."""
     cnt5 = _dev(cnt5, "cnt5", torch.uint8)
     cnt1 = _dev(cnt1, "cnt1", torch.uint8)
     B, nch5, H, W, _ = cnt5.shape
@@ -1879,6 +1881,9 @@ def den_step_tail(cnt5, cnt1, packed6, x_t, unmasked, t, temp, *, T, K, u=None, 
         if q.numel() != B * H * W * K:
             raise ValueError("q must have B*HW*K entries")
     logits = torch.empty((B, K, H, W), dtype=torch.float32, device=cnt5.device) if want_logits else None
+    act, nact = (None, None) if ACTIVE is None else ACTIVE
+    if act is not None and conv1 is not None:
+        raise ValueError("den_step_tail: the fused first layer is the dense form's (inside an active_set scope pass conv1=None)")
     x1 = c1o = w1 = b1 = a1 = bb1 = None
     if conv1 is not None and int(T) != 16:
         raise NotImplementedError("spk_den_step_tail: the fused first layer is the T = 16, LIFNode(tau=2, v_threshold=1, "
@@ -1890,7 +1895,7 @@ def den_step_tail(cnt5, cnt1, packed6, x_t, unmasked, t, temp, *, T, K, u=None, 
     check(lib.spk_den_step_tail(_p(cnt5), int(nch5), _p(cnt1), int(cnt1.shape[1]), _p(wq), _p(scale), _p(bias_d), _p(logits),
                                 _p(x_t), _p(unmasked), int(t), float(temp), _p(u), _p(q), int(seed), int(offset),
                                 _p(philox_state), _p(w1), _p(b1), _p(a1), _p(bb1), _p(x1), _p(c1o), int(T), B, H, W, int(K),
-                                _stream(cnt5)), "spk_den_step_tail")
+                                _p(act), _p(nact), _stream(cnt5)), "spk_den_step_tail")
     return (None if x1 is None else (x1, c1o)), logits
 
 

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, n), f"{n} declared in include/spkdiff.h but not exported by libspkdiff.so"
         assert n in _lib.EXPORTS, f"{n} has no ctypes signature in spkdiff/_lib.py"
     assert set(_lib.EXPORTS) == set(names)
-    assert _lib.version() == _lib.EXPECTED_VERSION == 104
+    assert _lib.version() == _lib.EXPECTED_VERSION == 105
     # the shipped library keeps no process-wide state: the option entry points exist only in a `make variants` build
     # (include/spkdiff_variants.h), and its launch-shape options read as their compiled-in defaults
     if not os.environ.get("SPKDIFF_LIB"):

@@ -3212,6 +3212,50 @@ def test_step_tail_for_other_codebook_sizes_equals_the_three_launches(dev, ops, 
     assert bad == 0
 
 
+@pytest.mark.parametrize("cfgname,L,B,t", [("mnist", 7, 37, 30), ("mnist", 7, 5, 3), ("cifar", 8, 19, 12)])
+def test_step_tail_on_the_active_list_equals_the_two_launches(dev, ops, cfgname, L, B, t):
+    """Round 6, elimination forms: spk_den_step_tail with the active list (workgroup = slot; counts and logits per slot, tokens / unmasked /
+    noise per image active[s]) == spk_den_conv3x3_counts_mfma + spk_psample_step on the same list: logits, tokens, unmasked; images that are
+    not on the list stay untouched; Philox and injected noise (R/snn_model/vq_diffusion.py:113-140 for the images that change at step t)."""
+    cfg = synth.MNIST if cfgname == "mnist" else synth.CIFAR
+    den, _ = build_den(cfg, dev)
+    g = torch.Generator().manual_seed(55 + B)
+    HW, K = L * L, 128
+    for trial in range(2):
+        x0 = torch.randint(0, K, (B, 1, L, L), generator=g)
+        un0 = torch.rand(B, 1, L, L, generator=g) < 0.6
+        un0[1 % B] = True                                   # (an image with nothing left to unmask: never on the list)
+        x0[~un0] = K
+        x0, un0 = x0.to(dev), un0.to(dev)
+        inject = trial == 1
+        u = torch.rand(B * HW, generator=g).to(dev) if inject else None
+        q = torch.empty(B * HW, K).exponential_(1, generator=g).to(dev) if inject else None
+        act = ops.select_active(un0, t, u.view(B, 1, L, L) if inject else None, 31, 500 * t, K=K)
+        n = int(act[1][0].item())
+        assert 0 < n < B
+        out = {}
+        for form in ("two_launches", "step_tail"):
+            xa, una = x0.clone(), un0.clone()
+            with ops.active_set(*act):
+                x5, cnt5, x1, cnt1, which, impl, collapse = den._trunk(ops.den_build_input(xa, t), False)
+                conv6, packed6 = den._conv6_params()
+                if form == "two_launches":
+                    lg = ops.den_conv3x3_counts(cnt5, packed6, K, 16, cnt1=cnt1)
+                    ops.psample_step(lg, xa, una, t, 0.9, u, q, seed=31, offset=500 * t)
+                else:
+                    pre, lg = ops.den_step_tail(cnt5, cnt1, packed6, xa, una, t, 0.9, T=16, K=K, u=u, q=q, seed=31, offset=500 * t,
+                                                conv1=None, want_logits=True)
+                    assert pre is None
+            out[form] = (lg[:n].clone(), xa, una)
+        assert torch.equal(out["step_tail"][0], out["two_launches"][0])
+        assert torch.equal(out["step_tail"][1], out["two_launches"][1]) and torch.equal(out["step_tail"][2], out["two_launches"][2])
+        listed = torch.zeros(B, dtype=torch.bool, device=dev)
+        listed[act[0][:n].long()] = True
+        assert torch.equal(out["step_tail"][1][~listed], x0[~listed]) and torch.equal(out["step_tail"][2][~listed], un0[~listed])
+        assert int(out["step_tail"][2].sum()) > int(un0.sum())
+    parity(f"step_tail_active_list_{cfgname}_B{B}", images_on_the_list=n, differing=0)
+
+
 @pytest.mark.parametrize("B", [1, 6])
 def test_fp6v2_small_batch_split_with_no_active_image(dev, ops, B):
     """The small-batch split under a device-side image count of ZERO (a reverse step in which no image of a small batch changes): nothing
