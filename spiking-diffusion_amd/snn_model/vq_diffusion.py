@@ -114,8 +114,11 @@ class AbsorbingDiffusion(Sampler):
         # 7.04 ms per 49-step sample without lists, 7.75 with; B = 32: 8.9 / 8.25 (tools/small_batch_time.py, profiles/r6_small_batch.txt)
         self.list_min_batch = 24
         # elimination forms: conv6 on the spike counts + the token update of the ACTIVE images as one launch per slot (spk_den_step_tail with
-        # the active list) instead of two (spk_den_conv3x3_counts_mfma, spk_psample_step).  Same tokens; False = the two launches.
-        self.step_tail_in_elimination = True
+        # the active list) instead of two (spk_den_conv3x3_counts_mfma, spk_psample_step).  Same tokens -- and measured SLOWER (round 6, one
+        # box: B = 256 x 100 steps 35.30 against 34.88 ms, B = 64 18.70 / 17.58, B = 16 x 49 steps 7.93 / 7.13: a workgroup of the step tail
+        # is one image's 90-iteration weight stream, ~30 us whatever the number of slots, where the counts kernel spreads the active images'
+        # rows over the chip).  Off; kept as an opt-in with its test (profiles/r6_ab_kernel_variants.txt (6)).
+        self.step_tail_in_elimination = False
         self.list_radii = 3                 # layers below the logits that take lists (1: conv5 only ... 4: conv2..conv5;
                                             # conv2 needs nearly every position anyway: 3 measured fastest)
         # Derived weight forms (digit planes, folded BN terms, captured graphs) are keyed on (data_ptr, _version), which
