@@ -2666,7 +2666,7 @@ def _philox_oracle_tokens(ops, dev, sd, key, B, steps, latent, temp=1.0, K=128, 
     return ref.absorbing_sample(sd, B, K, temp, steps, latent, 16, noise=noise)
 
 
-@pytest.mark.parametrize("B,steps", [(8, 100), (256, 6)])
+@pytest.mark.parametrize("B,steps", [(4, 100), (256, 6)])
 def test_timed_configuration_philox_graph_vs_oracle_on_dumped_noise(dev, ops, B, steps):
     """The configuration bench.py times -- noise_source='philox', the whole reverse process replayed from ONE hipGraph -- pinned
     to the oracle bit for bit: the noise the device drew is dumped (spk_philox_noise) and fed to the CPU oracle, whose tokens
@@ -2745,7 +2745,7 @@ def test_f15_bench_job_tokens_vs_fixture(golden_dir, dev):
 def test_bench_line_job_full_size_vs_oracle(dev, ops):
     """The bench line's OWN job -- B = 256 x 100 reverse steps, Philox noise, one hipGraph replay, dense and elimination + lists --
     against the CPU oracle on the dumped noise: all 12 544 tokens (the other timed-form tests stop at
-    B = 8 x 100 and B = 256 x 6).  Minutes of host work: SPKDIFF_RUN_SLOW=1, once per round through gpurun
+    B = 4 x 100 and B = 256 x 6).  Minutes of host work: SPKDIFF_RUN_SLOW=1, once per round through gpurun
     (tools/full_size_oracle.sh; log under profiles/).
 
     At this size -- 2.4e10 neuron-steps -- the oracle's own arithmetic shows: it convolves with oneDNN in fp32 (an accumulation
@@ -2901,7 +2901,7 @@ def test_timed_configuration_8x8_philox_graph_vs_oracle_on_dumped_noise(dev, ops
     """The CIFAR-shaped sampler in the form bench.py times (Philox noise, hipGraph) against the oracle on the dumped noise."""
     from snn_model.vq_diffusion import AbsorbingDiffusion
     den, sd = build_den(synth.CIFAR, dev)
-    B, steps = 8, 40
+    B, steps = 4, 40
     got = {}
     for name, skip in (("dense", False), ("elim", True)):
         ab = AbsorbingDiffusion(den, mask_id=128, latent_shape=(8, 8))
