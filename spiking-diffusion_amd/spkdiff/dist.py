@@ -51,8 +51,16 @@ def gather_images(local_u8: torch.Tensor, total: int | None = None) -> torch.Ten
     if send.shape[0] != bmax:
         pad = torch.zeros((bmax - send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
         send = torch.cat((send, pad), 0)
-    out = torch.empty((world * bmax,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
-    dist.all_gather_into_tensor(out, send)
+    if send.is_cuda and dist.get_backend() == 'gloo':
+        # gloo (CPU tests; several ranks sharing ONE device as a testing aid: RCCL refuses that) stages device tensors itself, and with work
+        # still pending on the stream that staging took SECONDS per call when two processes shared a device (measured: 6.1 s per bench step
+        # against 0.2 s): hand it host tensors -- the images are 784 bytes each
+        host = torch.empty((world * bmax,) + tuple(send.shape[1:]), dtype=send.dtype)
+        dist.all_gather_into_tensor(host, send.cpu())
+        out = host.to(send.device)
+    else:
+        out = torch.empty((world * bmax,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        dist.all_gather_into_tensor(out, send)
     if all(hi - lo == bmax for lo, hi in sizes):
         return out
     parts = [out[r * bmax: r * bmax + (hi - lo)] for r, (lo, hi) in enumerate(sizes)]
