@@ -1597,12 +1597,16 @@ static int fp6v2_launch(const uint8_t* in_s32, int nch, const uint8_t* wq, const
   int grid = 0;
   a.gx = 0; a.nsets = 1;
   // (wgs: workgroups of the launch -- one per CU, or two for the duo form; returns the grid, 0 if the XCD-aware walk does not fit)
+  // (the sampler's active-set and listed calls keep the rounds 2-5 bound: with few image lanes per channel group two sets measured 1.2 %
+  //  slower there -- elimination + lists 34.37 against 33.96 ms, three alternating passes -- while full batches are indifferent in time and
+  //  fetch a third less: profiles/r6_ab_kernel_variants.txt (2))
+  const long long gx_kb = (n_dyn_or_null || need) ? 1536 : SPK_V2_GX_KB;
   auto xcd_walk = [&](V2Args& v, int wgs) -> int {
     v.gx = 0; v.nsets = 1;
     if ((wgs & 7) != 0) return 0;
     const int S = wgs / 8;
     int gx = 1;
-    while (gx * 2 <= G && gx * 2 <= S && (long long)gx * 2 * nch * W_SLAB <= SPK_V2_GX_KB * 1024) gx *= 2;
+    while (gx * 2 <= G && gx * 2 <= S && (long long)gx * 2 * nch * W_SLAB <= gx_kb * 1024) gx *= 2;
     while (G / gx > 8 && gx * 2 <= G && gx * 2 <= S) gx *= 2;
     const int nsets = G / gx;
     if (G % gx == 0 && nsets <= 8 && 8 % nsets == 0 && S % gx == 0) { v.gx = gx; v.nsets = nsets; return wgs; }
